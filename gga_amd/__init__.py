@@ -1,0 +1,8 @@
+"""gga_amd — MI355X-native implementation of the GGA training hot path.
+
+Host side mirrors the reference's mmdet3d plugin surface (registry names,
+constructor arguments, forward signatures); the data-movement-bound stages
+run as hand-written HIP kernels for gfx950 behind a C-ABI shared library
+(include/gga_hip.h, gga_amd/csrc/). See DESIGN.md.
+"""
+__version__ = '0.1.0'

@@ -1,0 +1,229 @@
+"""Synthetic KITTI-shaped frames for the GGA train step.
+
+There is no dataset on the build or GPU box, so every test / bench input is a
+seeded synthetic frame with the *on-wire format* the reference's collate hands
+to ``GGA.forward_train`` (reference: mmdet3d/models/detectors/
+mvx_two_stage_gga.py:238-252 and mmdet3d/datasets/pipelines/gga_processing.py):
+
+    points                  [N,4]  f32   (x, y, z, reflectance)
+    gt_labels_3d            [n]    i64   0=Pedestrian 1=Cyclist 2=Car
+    gt_bboxes_3d            Boxes3D (n x 7, bottom-centre; debug only)
+    GGA_boxes_img           [n,4]  f64   2D box (x1, y1, x2, y2) in pixels
+    GGA_lidar2img           [n,4,4] f32  per-object projection matrix
+    GGA_init_pseudo_labels  [n,7]  f64   (x, y, z, l, w, h, rot)
+    GGA_bdry_masks          [n,4]  bool  side touches the image border
+    GGA_in_box_points       list of [Ni,4] f64 (x, y, z, 1)
+    img_meta['lidar2img']   [4,4]  f32 numpy
+
+Seed = 1234 + 1000*rank + frame_idx (numpy ``default_rng``).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+IMG_W, IMG_H = 1242, 375
+# (l, w, h) class means, order Pedestrian / Cyclist / Car
+# (reference: configs/_base_/models/hv_second_secfpn_kitti.py:40 anchor sizes)
+CLASS_DIMS = np.array([[0.8, 0.6, 1.73], [1.76, 0.6, 1.73], [3.9, 1.6, 1.56]])
+
+RANGE_SECOND = (0.0, -40.0, -3.0, 70.4, 40.0, 1.0)
+RANGE_PP = (0.0, -39.68, -3.0, 69.12, 39.68, 1.0)
+
+
+class Boxes3D:
+    """Minimal stand-in for ``LiDARInstance3DBoxes``: the GGA head only reads
+    ``.gravity_center`` and ``.tensor`` (centerpoint_head_gga.py:416-418)."""
+
+    def __init__(self, tensor):
+        self.tensor = torch.as_tensor(tensor, dtype=torch.float32).reshape(-1, 7)
+
+    @property
+    def gravity_center(self):
+        t = self.tensor
+        out = t[:, :3].clone()
+        out[:, 2] = t[:, 2] + t[:, 5] * 0.5
+        return out
+
+    def to(self, device):
+        return Boxes3D(self.tensor.to(device))
+
+    def __len__(self):
+        return self.tensor.shape[0]
+
+
+def kitti_lidar2img(rng=None):
+    """KITTI-like P2 @ R0_rect @ Tr_velo_to_cam as a [4,4] f32 matrix."""
+    P2 = np.array([[721.5377, 0.0, 609.5593, 44.85728],
+                   [0.0, 721.5377, 172.854, 0.2163791],
+                   [0.0, 0.0, 1.0, 0.002745884],
+                   [0.0, 0.0, 0.0, 1.0]])
+    R0 = np.eye(4)
+    R0[:3, :3] = np.array([[0.9999239, 0.00983776, -0.00744505],
+                           [-0.0098698, 0.9999421, -0.00427846],
+                           [0.00740253, 0.00435161, 0.9999631]])
+    Tr = np.array([[7.533745e-03, -9.999714e-01, -6.166020e-04, -4.069766e-03],
+                   [1.480249e-02, 7.280733e-04, -9.998902e-01, -7.631618e-02],
+                   [9.998621e-01, 7.523790e-03, 1.480755e-02, -2.717806e-01],
+                   [0.0, 0.0, 0.0, 1.0]])
+    if rng is not None:  # small per-frame calibration jitter
+        Tr = Tr.copy()
+        Tr[:3, 3] += rng.normal(0.0, 0.01, 3)
+    return (P2 @ R0 @ Tr).astype(np.float32)
+
+
+def box_corners(box):
+    """8 corners of (x,y,z_bottom,l,w,h,rot) — same convention as the head's
+    decoder (counter-clockwise yaw about z, bottom-centre origin)."""
+    x, y, z, l, w, h, r = box
+    ox = np.array([-.5, -.5, -.5, -.5, .5, .5, .5, .5]) * l
+    oy = np.array([-.5, -.5, .5, .5, -.5, -.5, .5, .5]) * w
+    oz = np.array([0., 1., 1., 0., 0., 1., 1., 0.]) * h
+    c, s = np.cos(r), np.sin(r)
+    return np.stack([x + c * ox - s * oy, y + s * ox + c * oy, z + oz], 1)
+
+
+def make_frame(frame_idx=0, rank=0, n_points=20000, pc_range=RANGE_SECOND,
+               n_obj_range=(4, 20), n_ibp_range=(20, 1500), outside_frac=0.05,
+               unlabeled_frac=0.0):
+    """One synthetic frame as a dict of the ``forward_train`` keyword inputs."""
+    rng = np.random.default_rng(1234 + 1000 * rank + frame_idx)
+    x0, y0, z0, x1, y1, z1 = pc_range
+
+    n_obj = int(rng.integers(n_obj_range[0], n_obj_range[1] + 1))
+    labels = rng.integers(0, 3, n_obj).astype(np.int64)
+    if unlabeled_frac > 0:
+        labels[rng.random(n_obj) < unlabeled_frac] = -1
+    dims = CLASS_DIMS[np.clip(labels, 0, 2)] * rng.uniform(0.8, 1.2, (n_obj, 3))
+    cx = rng.uniform(x0 + 6.0, x1 - 4.0, n_obj)
+    cy = rng.uniform(y0 + 8.0, y1 - 8.0, n_obj)
+    # keep most objects inside the camera frustum (|y| < 0.8 x) but let a few
+    # cross the image border so the boundary masks are exercised
+    cy = np.clip(cy, -0.85 * cx, 0.85 * cx)
+    cz = rng.uniform(-1.9, -1.3, n_obj)
+    rot = rng.uniform(-np.pi, np.pi, n_obj)
+    pseudo = np.stack([cx, cy, cz, dims[:, 0], dims[:, 1], dims[:, 2], rot], 1)
+
+    l2i = kitti_lidar2img(rng)
+    boxes_img = np.zeros((n_obj, 4), np.float64)
+    bdry = np.zeros((n_obj, 4), bool)
+    ibp = []
+    cluster_pts = []
+    l2i_obj = np.repeat(l2i[None], n_obj, 0).copy()
+    for j in range(n_obj):
+        # tiny per-object perturbation so a slot that picks the wrong matrix
+        # is caught by parity tests
+        l2i_obj[j, 0, 3] += np.float32(0.01 * j)
+        cor = box_corners(pseudo[j])
+        q = np.concatenate([cor, np.ones((8, 1))], 1) @ l2i_obj[j].astype(np.float64).T
+        d = np.maximum(q[:, 2], 0.1)
+        u, v = q[:, 0] / d, q[:, 1] / d
+        b = np.array([u.min(), v.min(), u.max(), v.max()]) + rng.uniform(-3, 3, 4)
+        clipped = np.array([max(b[0], 0.0), max(b[1], 0.0),
+                            min(b[2], IMG_W - 1.0), min(b[3], IMG_H - 1.0)])
+        bdry[j] = clipped != b
+        boxes_img[j] = clipped
+        # in-box points: footprint stretched x1.15 so some fall outside
+        ni = int(rng.integers(n_ibp_range[0], n_ibp_range[1] + 1))
+        lx = rng.uniform(-0.575, 0.575, ni) * pseudo[j, 3]
+        ly = rng.uniform(-0.575, 0.575, ni) * pseudo[j, 4]
+        lz = rng.uniform(0.0, 1.0, ni) * pseudo[j, 5]
+        c, s = np.cos(rot[j]), np.sin(rot[j])
+        p = np.stack([cx[j] + c * lx - s * ly, cy[j] + s * lx + c * ly,
+                      cz[j] + lz, np.ones(ni)], 1)
+        ibp.append(p)
+        cluster_pts.append(p[: min(ni, 200), :3])
+
+    n_out = int(round(n_points * outside_frac))
+    cl = np.concatenate(cluster_pts, 0) if cluster_pts else np.zeros((0, 3))
+    n_cl = min(len(cl), n_points // 4)
+    n_in = n_points - n_out - n_cl
+    pts = np.empty((n_points, 4), np.float32)
+    pts[:n_in, 0] = rng.uniform(x0, x1, n_in)
+    pts[:n_in, 1] = rng.uniform(y0, y1, n_in)
+    pts[:n_in, 2] = np.clip(rng.normal(-1.0, 0.6, n_in), z0 + 1e-3, z1 - 1e-3)
+    pts[n_in:n_in + n_cl, :3] = cl[:n_cl]
+    # points outside the range on every side (exercise the rejection branch)
+    o = slice(n_in + n_cl, n_points)
+    side = rng.integers(0, 6, n_out)
+    ox = rng.uniform(x0, x1, n_out)
+    oy = rng.uniform(y0, y1, n_out)
+    oz = rng.uniform(z0, z1, n_out)
+    ox = np.where(side == 0, x0 - rng.uniform(0.01, 5, n_out), ox)
+    ox = np.where(side == 1, x1 + rng.uniform(0.0, 5, n_out), ox)
+    oy = np.where(side == 2, y0 - rng.uniform(0.01, 5, n_out), oy)
+    oy = np.where(side == 3, y1 + rng.uniform(0.0, 5, n_out), oy)
+    oz = np.where(side == 4, z0 - rng.uniform(0.01, 2, n_out), oz)
+    oz = np.where(side == 5, z1 + rng.uniform(0.0, 2, n_out), oz)
+    pts[o, 0], pts[o, 1], pts[o, 2] = ox, oy, oz
+    pts[:, 3] = rng.uniform(0, 1, n_points)
+    pts = pts[rng.permutation(n_points)]  # PointShuffle
+
+    return dict(
+        points=torch.from_numpy(pts),
+        gt_labels_3d=torch.from_numpy(labels),
+        gt_bboxes_3d=Boxes3D(pseudo.astype(np.float32)),
+        GGA_boxes_img=torch.from_numpy(boxes_img),
+        GGA_lidar2img=torch.from_numpy(l2i_obj),
+        GGA_init_pseudo_labels=torch.from_numpy(pseudo),
+        GGA_bdry_masks=torch.from_numpy(bdry),
+        GGA_in_box_points=[torch.from_numpy(p) for p in ibp],
+        img_meta=dict(lidar2img=l2i, sample_idx=frame_idx),
+    )
+
+
+BATCH_KEYS = ('points', 'gt_labels_3d', 'gt_bboxes_3d', 'GGA_boxes_img',
+              'GGA_lidar2img', 'GGA_init_pseudo_labels', 'GGA_bdry_masks',
+              'GGA_in_box_points')
+
+
+def make_batch(batch_size, start=0, rank=0, device=None, **kw):
+    """Collate ``batch_size`` frames into the list-of-per-frame layout the
+    reference's ``DataContainer`` collate produces. Tensors that the reference
+    moves to the device in ``scatter`` (points, labels, GGA_*) are moved here;
+    in-box points stay on the host (the head moves them, head:469-470)."""
+    frames = [make_frame(start + i, rank, **kw) for i in range(batch_size)]
+    batch = {k: [f[k] for f in frames] for k in BATCH_KEYS}
+    batch['img_metas'] = [f['img_meta'] for f in frames]
+    if device is not None:
+        for k in ('points', 'gt_labels_3d', 'GGA_boxes_img', 'GGA_lidar2img',
+                  'GGA_init_pseudo_labels', 'GGA_bdry_masks'):
+            batch[k] = [t.to(device) for t in batch[k]]
+    return batch
+
+
+def det_uniform(shape, seed, lo=-0.5, hi=0.5):
+    """Platform-independent pseudo-random f32 tensor: an integer hash of the
+    flat index (exact in uint64 arithmetic), so golden tests can regenerate
+    dense head maps from a seed instead of storing them."""
+    n = int(np.prod(shape))
+    i = np.arange(n, dtype=np.uint64)
+    x = i + np.uint64((int(seed) * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF)  # wraps mod 2^64
+    x ^= x >> np.uint64(33)
+    x = (x * np.uint64(0xFF51AFD7ED558CCD)) & np.uint64(0xFFFFFFFFFFFFFFFF)
+    x ^= x >> np.uint64(33)
+    x = (x * np.uint64(0xC4CEB9FE1A85EC53)) & np.uint64(0xFFFFFFFFFFFFFFFF)
+    x ^= x >> np.uint64(33)
+    u = (x >> np.uint64(40)).astype(np.float64) / float(1 << 24)  # 24-bit mantissa: exact in f32
+    return torch.from_numpy((lo + (hi - lo) * u).astype(np.float32).reshape(shape))
+
+
+HEAD_KEYS = (('reg', 2), ('height', 1), ('dim', 3), ('rot', 2), ('heatmap', 1))
+
+
+def make_head_preds(B, H, W, seed=77, n_tasks=3):
+    """Deterministic head outputs ``[{reg,height,dim,rot,heatmap}] * n_tasks``
+    shaped like ``CenterHead_GGA.forward`` results (values in a plausible
+    range: log-dims ~ U(-1,1), heights ~ -1.5..-0.5, heatmap logits ~ -2.19)."""
+    preds = []
+    for t in range(n_tasks):
+        d = {}
+        for j, (k, c) in enumerate(HEAD_KEYS):
+            x = det_uniform((B, c, H, W), seed * 100 + t * 10 + j) * 2.0
+            if k == 'height':
+                x = x * 0.5 - 1.0
+            if k == 'heatmap':
+                x = x - 2.19
+            d[k] = x
+        preds.append(d)
+    return preds

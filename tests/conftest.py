@@ -1,0 +1,66 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+GOLDEN = os.path.join(REPO, 'tests', 'golden')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+def pytest_collection_modifyitems(config, items):
+    # GPU tests are skipped (not failed) when no device is visible, so a plain
+    # `pytest tests/` on the CPU container stays green.
+    import torch
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason='no GPU visible')
+    for item in items:
+        if 'gpu' in item.keywords:
+            item.add_marker(skip)
+
+
+@pytest.fixture(scope='session')
+def golden():
+    def _load(name):
+        return np.load(os.path.join(GOLDEN, name + '.npz'))
+    return _load
+
+
+def load_head_case(d, c):
+    """Rebuild the per-frame input lists of a head golden case."""
+    B = int(d[f'{c}.B'])
+    out = dict(B=B, labels=[], boxes_img=[], lidar2img=[], pseudo=[], bdry=[], ibp=[], meta_l2i=[],
+               gt_boxes=[])
+    for b in range(B):
+        out['labels'].append(d[f'{c}.labels.{b}'])
+        out['gt_boxes'].append(d[f'{c}.gt_boxes.{b}'])
+        out['boxes_img'].append(d[f'{c}.boxes_img.{b}'])
+        out['lidar2img'].append(d[f'{c}.lidar2img.{b}'])
+        out['pseudo'].append(d[f'{c}.pseudo.{b}'])
+        out['bdry'].append(d[f'{c}.bdry.{b}'])
+        out['meta_l2i'].append(d[f'{c}.meta_l2i.{b}'])
+        n = d[f'{c}.n_ibp.{b}']
+        flat = d[f'{c}.ibp.{b}']
+        offs = np.concatenate([[0], np.cumsum(n)])
+        out['ibp'].append([flat[offs[i]:offs[i + 1]] for i in range(len(n))])
+    return out
+
+
+TRAIN_CFG = dict(
+    second=dict(point_cloud_range=[0, -40, -3, 70.4, 40, 1], grid_size=[1408, 1600, 40],
+                voxel_size=[0.05, 0.05, 0.1], out_size_factor=8, dense_reg=1, gaussian_overlap=0.1,
+                max_objs=500, min_radius=2, code_weights=[0.5, 0.5, 0.5, 0.5, 0.5],
+                margin_weights=[1.0, 1.0]),
+    pp=dict(point_cloud_range=[0, -39.68, -3, 69.12, 39.68, 1], grid_size=[432, 496, 1],
+            voxel_size=[0.16, 0.16, 4], out_size_factor=2, dense_reg=1, gaussian_overlap=0.1,
+            max_objs=500, min_radius=2, code_weights=[0.5, 0.5, 0.5, 0.5, 0.5],
+            margin_weights=[1.0, 1.0]))
+FMAP = dict(second=(200, 176), pp=(248, 216))  # (H, W)

@@ -1,0 +1,145 @@
+"""The CPU oracle (oracle/) against golden vectors produced by the imported reference
+(tools_dev/make_golden.py) and the reference's own known-answer tests. CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import FMAP, TRAIN_CFG, load_head_case
+from gga_amd import synthetic
+from oracle import oracle as O
+
+
+@pytest.mark.parametrize('case', ['second', 'second_coarse', 'pp', 'pp_dense', 'ka'])
+def test_hard_voxelize_bit_exact(golden, case):
+    d = golden('voxelize')
+    if case == 'ka':  # reference tests/test_models/test_voxel_encoder/test_voxel_generator.py:7-22
+        vs, rng, mp, mv = [0.5] * 3, [0, -40, -3, 70.4, 40, 1], 1000, 20000
+    else:
+        cfg = d[f'{case}.cfg']
+        vs, rng, mp, mv = cfg[:3], cfg[3:9], int(cfg[9]), int(cfg[10])
+    v, c, n = O.hard_voxelize(d[f'{case}.points'], vs, rng, mp, mv)
+    assert np.array_equal(c, d[f'{case}.coors'])
+    assert np.array_equal(n, d[f'{case}.num_points'])
+    assert np.array_equal(v, d[f'{case}.voxels'])
+    if case == 'ka':
+        assert c.tolist() == [[7, 81, 1], [6, 81, 0], [7, 80, 1], [6, 81, 1],
+                              [7, 81, 0], [6, 80, 1], [7, 80, 0], [6, 80, 0]]
+        assert n.tolist() == [120, 121, 127, 134, 115, 127, 125, 131]
+
+
+def test_grid_size():
+    assert O.grid_size([0.05, 0.05, 0.1], [0, -40, -3, 70.4, 40, 1]).tolist() == [1408, 1600, 40]
+    assert O.grid_size([0.16, 0.16, 4], [0, -39.68, -3, 69.12, 39.68, 1]).tolist() == [432, 496, 1]
+
+
+def test_voxel_mean(golden):
+    d = golden('encoders')
+    out = O.voxel_mean(d['vfe.voxels'], d['vfe.num_points'])
+    np.testing.assert_allclose(out, d['vfe.out'], rtol=1e-6, atol=1e-6)
+
+
+def test_pfn_forward(golden):
+    d = golden('encoders')
+    cfg = d['pfn.cfg']
+    out, feats, mean, var = O.pfn_forward(d['pfn.voxels'], d['pfn.num_points'], d['pfn.coors'],
+                                          cfg[:3], cfg[3:], d['pfn.linear_w'], d['pfn.bn_w'], d['pfn.bn_b'])
+    np.testing.assert_allclose(out, d['pfn.out'], rtol=1e-4, atol=1e-4)  # north_star fp32 tolerance
+    rows = feats.shape[0] * feats.shape[1]
+    # BatchNorm1d(momentum=0.01): running = 0.99*init + 0.01*batch (unbiased var)
+    np.testing.assert_allclose(0.01 * mean, d['pfn.running_mean'], rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(0.99 + 0.01 * var * rows / (rows - 1), d['pfn.running_var'], rtol=1e-5)
+
+
+@pytest.mark.parametrize('case', ['small', 'pp'])
+def test_pillar_scatter(golden, case):
+    d = golden('scatter')
+    B, C, ny, nx = d[f'{case}.shape']
+    out = O.pillar_scatter(d[f'{case}.feats'], d[f'{case}.coors'], B, ny, nx)
+    assert np.array_equal(out, d[f'{case}.canvas'])
+
+
+def test_gaussian(golden):
+    d = golden('gaussian')
+    hm = np.zeros((128, 128), np.float32)
+    O.draw_gaussian(hm, 64, 64, 2)
+    assert abs(hm.sum() - 4.3505) < 1e-3          # reference tests/test_utils/test_utils.py:12-17
+    for (h, w), r in zip(d['radius.sizes'], d['radius.values']):
+        assert O.gaussian_radius(h, w, 0.1) == pytest.approx(r, rel=1e-14)
+    hm = np.zeros((200, 176), np.float32)
+    for (cx, cy), r in zip(d['splat.centers'], d['splat.radii']):
+        O.draw_gaussian(hm, cx, cy, r)
+    np.testing.assert_allclose(hm, d['splat.heatmap'], rtol=0, atol=1e-7)
+    assert np.array_equal(hm == 1, d['splat.heatmap'] == 1)
+
+
+def _targets(d, c):
+    case = load_head_case(d, c)
+    torch.manual_seed(1234)
+    srl = O.draw_srl(case['B'])
+    tg = O.get_targets(case['labels'], case['boxes_img'], case['lidar2img'], case['pseudo'],
+                       case['bdry'], case['ibp'], case['meta_l2i'], TRAIN_CFG[c], srl)
+    return case, tg
+
+
+@pytest.mark.parametrize('c', ['second', 'pp'])
+def test_get_targets(golden, c):
+    d = golden('head')
+    case, tg = _targets(d, c)
+    for t in range(3):
+        hm = np.zeros_like(tg['heatmap'][t])
+        idx = d[f'{c}.tgt.{t}.heatmap.idx']
+        hm[tuple(idx.T)] = d[f'{c}.tgt.{t}.heatmap.val']
+        np.testing.assert_allclose(tg['heatmap'][t], hm, rtol=0, atol=1e-7)
+        assert np.array_equal(tg['heatmap'][t] == 1, hm == 1)
+        assert np.array_equal(tg['ind'][t], d[f'{c}.tgt.{t}.ind'])
+        assert np.array_equal(tg['mask'][t], d[f'{c}.tgt.{t}.mask'])
+        assert np.array_equal(tg['bound_mask'][t], d[f'{c}.tgt.{t}.bound_mask'])
+        assert np.array_equal(tg['lidar2img'][t], d[f'{c}.tgt.{t}.lidar2img'])
+        np.testing.assert_array_equal(tg['anno_box'][t], d[f'{c}.tgt.{t}.anno_box'])
+        n_ibp = d[f'{c}.tgt.{t}.n_ibp']
+        for b in range(case['B']):
+            got = [len(p) for p in tg['ibp'][t][b]]
+            assert got == [x for x in n_ibp[b] if x >= 0]
+
+
+@pytest.mark.parametrize('c', ['second', 'pp'])
+def test_head_loss(golden, c):
+    d = golden('head')
+    case, tg = _targets(d, c)
+    H, W = FMAP[c]
+    preds = [{k: v.numpy() for k, v in p.items()}
+             for p in synthetic.make_head_preds(case['B'], H, W, seed=int(d[f'{c}.pred_seed']))]
+    losses, mids = O.head_loss(preds, tg, TRAIN_CFG[c])
+    for t in range(3):
+        for k in ('pred', 'rot', 'pred_ratio', 'pred_box_bev'):
+            np.testing.assert_allclose(mids[t][k], d[f'{c}.mid.{t}.{k}'], rtol=2e-6, atol=2e-6, err_msg=k)
+        # pixel coordinates reach ~1e3: relative tolerance
+        np.testing.assert_allclose(mids[t]['pred_iou'], d[f'{c}.mid.{t}.pred_iou'], rtol=1e-5, atol=1e-3)
+        for k in ('p2c_min', 'p2c_x', 'p2c_y'):
+            np.testing.assert_allclose(mids[t][k], d[f'{c}.mid.{t}.{k}'], rtol=1e-5, atol=1e-4, err_msg=k)
+    assert len(losses) == 18
+    for k, v in losses.items():
+        ref = float(d[f'{c}.loss.{k}'])
+        assert float(v) == pytest.approx(ref, rel=1e-5, abs=1e-4), k   # north_star: fp32 losses within 1e-4
+
+
+def test_focal_grad_matches_reference(golden):
+    d = golden('head')
+    c = 'second'
+    case, tg = _targets(d, c)
+    H, W = FMAP[c]
+    preds = synthetic.make_head_preds(case['B'], H, W, seed=int(d[f'{c}.pred_seed']))
+    for t in range(3):
+        _, g, _ = O.focal_loss(preds[t]['heatmap'].numpy(), tg['heatmap'][t], with_grad=True)
+        sel = d[f'{c}.gradA.{t}.heatmap.flatidx']
+        np.testing.assert_allclose(5.0 * g[sel], d[f'{c}.gradA.{t}.heatmap.val'], rtol=1e-4, atol=1e-7)
+
+
+def test_rotation_known_answer(golden):
+    # reference tests/test_utils/test_box3d.py:1598-1607 through the oracle's PAL rotation:
+    # rotating clockwise by -a equals the counter-clockwise rotation by a.
+    d = golden('rotation')
+    p, a, out = d['ka2d.points'][0], float(d['ka2d.angles'][0]), d['ka2d.out'][0]
+    c, s = np.cos(a), np.sin(a)
+    got = np.stack([p[:, 0] * c - p[:, 1] * s, p[:, 0] * s + p[:, 1] * c], 1)
+    np.testing.assert_allclose(got, out, atol=1e-7)

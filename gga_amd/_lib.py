@@ -1,0 +1,88 @@
+"""ctypes binding of ``libgga_hip.so`` (the C ABI declared in include/gga_hip.h).
+
+The library is built in-tree by ``gga_amd/csrc/Makefile`` (``__graft_entry__.build()``)
+and is the *only* compute path of the product: there is no CPU fallback. Loading
+fails loudly when the shared object is missing, and every entry point raises
+``RuntimeError`` with ``gga_last_error()`` on a non-zero status.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libgga_hip.so')
+ABI_VERSION = 1
+
+_lib = None
+
+vp, i32, i64, f32, sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
+
+
+class VoxelParams(C.Structure):
+    _fields_ = [('voxel_size', C.c_float * 3), ('pc_range', C.c_float * 6),
+                ('max_points', C.c_int32), ('max_voxels', C.c_int32)]
+
+
+class LossParams(C.Structure):
+    _fields_ = [('B', C.c_int32), ('K', C.c_int32), ('fm_w', C.c_int32),
+                ('voxel_size', C.c_float * 2), ('out_size_factor', C.c_float),
+                ('pc_range', C.c_float * 2), ('code_weights', C.c_float * 5),
+                ('l1_loss_weight', C.c_float), ('w_bpl', C.c_float), ('w_srl', C.c_float),
+                ('w_pal', C.c_float)]
+
+
+# name -> (restype, argtypes); every symbol include/gga_hip.h declares
+SIGNATURES = {
+    'gga_last_error': (C.c_char_p, []),
+    'gga_abi_version': (i32, []),
+    'gga_voxel_grid_size': (None, [C.POINTER(VoxelParams), C.POINTER(C.c_int32 * 3)]),
+    'gga_hard_voxelize_workspace_bytes': (sz, [i32, i64]),
+    'gga_hard_voxelize_batch': (i32, [vp, i32, C.POINTER(C.c_int64), i32, C.POINTER(VoxelParams),
+                                       vp, vp, vp, vp, vp, sz, vp]),
+    'gga_voxel_mean': (i32, [vp, vp, i64, i32, i32, i32, vp, vp]),
+    'gga_pillar_scatter_map_bytes': (sz, [i32, i32, i32]),
+    'gga_pillar_scatter_fwd': (i32, [vp, vp, i64, vp, i32, i32, i32, i32, i32, vp, vp, vp]),
+    'gga_pillar_scatter_bwd': (i32, [vp, vp, i64, vp, i32, i32, i32, i32, i32, vp, vp]),
+    'gga_heatmap_splat': (i32, [vp, i32, i32, i32, vp, i32, vp, vp, i32, vp]),
+    'gga_focal_loss_workspace_bytes': (sz, [i64]),
+    'gga_focal_loss_fwd': (i32, [vp, vp, i64, f32, f32, f32, vp, vp, sz, vp]),
+    'gga_focal_loss_bwd': (i32, [vp, vp, i64, f32, f32, f32, vp, vp, vp, vp]),
+    'gga_gather_pred_fwd': (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]),
+    'gga_gather_pred_bwd': (i32, [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]),
+    'gga_box_losses_workspace_bytes': (sz, [i32, i32]),
+    'gga_box_losses_fwd': (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, C.POINTER(LossParams),
+                                  vp, vp, vp, vp, sz, vp]),
+    'gga_box_losses_bwd': (i32, [vp, vp, i32, i32, vp, vp]),
+}
+
+
+def build(force=False):
+    """Compile the HIP sources for gfx950 (hipcc cross-compiles without a GPU)."""
+    args = ['make', '-C', os.path.join(_HERE, 'csrc'), '-j4']
+    if force:
+        args.append('-B')
+    subprocess.check_call(args, stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f'{LIB_PATH} not found: the GGA HIP kernels are not built. Run '
+                '`python -c "import __graft_entry__ as g; g.build()"` (or `make -C gga_amd/csrc`). '
+                'There is no CPU fallback for the product path.')
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)       # AttributeError if the .so lacks a declared symbol
+            fn.restype, fn.argtypes = res, args
+        if L.gga_abi_version() != ABI_VERSION:
+            raise RuntimeError(f'libgga_hip.so ABI {L.gga_abi_version()} != binding ABI {ABI_VERSION}; rebuild')
+        _lib = L
+    return _lib
+
+
+def check(status, what):
+    if status != 0:
+        raise RuntimeError(f'{what} failed (status {status}): {lib().gga_last_error().decode()}')

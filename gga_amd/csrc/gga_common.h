@@ -1,0 +1,57 @@
+// Shared helpers for the gfx950 kernels behind include/gga_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/gga_hip.h"
+
+#define GGA_WAVE 64
+
+void gga_set_error(const char* fmt, ...);
+
+#define GGA_REQUIRE(cond, ...)                      \
+    do {                                            \
+        if (!(cond)) {                              \
+            gga_set_error(__VA_ARGS__);             \
+            return GGA_ERR_INVALID_ARG;             \
+        }                                           \
+    } while (0)
+
+#define GGA_CHECK_LAUNCH(name)                                                    \
+    do {                                                                          \
+        hipError_t e_ = hipGetLastError();                                        \
+        if (e_ != hipSuccess) {                                                   \
+            gga_set_error("%s: launch failed: %s", name, hipGetErrorString(e_));  \
+            return GGA_ERR_LAUNCH;                                                \
+        }                                                                         \
+    } while (0)
+
+#define GGA_CHECK_HIP(expr, name)                                                 \
+    do {                                                                          \
+        hipError_t e_ = (expr);                                                   \
+        if (e_ != hipSuccess) {                                                   \
+            gga_set_error("%s: %s", name, hipGetErrorString(e_));                 \
+            return GGA_ERR_LAUNCH;                                                \
+        }                                                                         \
+    } while (0)
+
+static inline size_t gga_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// ---- wave / block reductions (wave = 64 lanes on CDNA) ----------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}

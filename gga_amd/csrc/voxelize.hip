@@ -1,0 +1,350 @@
+// a1/a2: batched hard voxelization + HardSimpleVFE for gfx950.
+//
+// Reference semantics (mmdet3d/core/voxel/voxel_generator.py:137-208, the in-tree
+// statement of mmcv.ops.Voxelization; call site mvx_two_stage_gga.py:211-236) are
+// sequential: voxel id = order of the voxel's first point, slot = order of the point
+// inside its voxel. The parallel formulation below reproduces that order exactly:
+//
+//   K1 insert   one thread per point: cell key -> open-addressing hash (64-bit CAS);
+//               per slot: 64-bit atomicMin of (round, point index) and a counter.
+//               After K1, the low word of `cur[slot]` is the voxel's FIRST point.
+//   K2 flag     rank[i] = 0 if i is its voxel's first point, -1 otherwise.
+//   K3 assign   one 1024-thread workgroup per frame:
+//               (a) ordered exclusive scan of the "is first" flags = voxel id in
+//                   first-come order; ids >= max_voxels are dropped;
+//               (b) rank rounds: in round r every still-unranked point of a kept voxel
+//                   does atomicMin(cur[slot], (R-r, i)); the smallest index wins rank r.
+//                   Rounds stop at max_points or when no point is left. The round is
+//                   folded into the high word so no reset pass is needed.
+//   K4 write    one thread per point: copy the point to voxels[vid, rank], the rank-0
+//               point also writes coors / num_points.
+//
+// No dense (D,H,W) index grid (360 MB for the KITTI config) as the CPU reference uses.
+#include "gga_common.h"
+
+#define GGA_MAX_BATCH 128
+#define VOX_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
+#define VOX_ROUND_HI 0x7FFFFFFFu
+
+struct FrameOffsets {
+    int32_t off[GGA_MAX_BATCH + 1];
+};
+
+struct VoxGeom {
+    float vs[3];
+    float lo[3];
+    int32_t grid[3];  // x, y, z
+    int32_t max_points, max_voxels;
+};
+
+struct VoxWorkspace {
+    unsigned long long* cur;   // [cap] (round, first/min index)
+    unsigned long long* keys;  // [cap]
+    int32_t* count;            // [cap]
+    int32_t* vid;              // [cap]
+    int32_t* slot;             // [total]
+    int32_t* rank;             // [total]
+    int32_t* act0;             // [total]
+    int32_t* act1;             // [total]
+    uint32_t cap_mask;
+};
+
+static inline uint64_t vox_cap(int64_t total_points) {
+    uint64_t cap = 1024;
+    while (cap < (uint64_t)(2 * total_points + 2)) cap <<= 1;
+    return cap;
+}
+
+__device__ __forceinline__ uint32_t vox_hash(unsigned long long k) {
+    k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33;
+    k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
+    return (uint32_t)k;
+}
+
+__global__ __launch_bounds__(256) void vox_insert_kernel(const float* __restrict__ points, int ndim,
+                                                        FrameOffsets fo, VoxGeom g, VoxWorkspace ws) {
+    const int b = blockIdx.y;
+    const int n = fo.off[b + 1] - fo.off[b];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int64_t gi = (int64_t)fo.off[b] + i;
+    const float* p = points + gi * ndim;
+    int32_t c[3];
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        // floor((p - lo) / vs) in f32, true division (voxel_generator.py:189)
+        float cf = floorf(__fdiv_rn(__fsub_rn(p[j], g.lo[j]), g.vs[j]));
+        ok = ok && (cf >= 0.0f) && (cf < (float)g.grid[j]);
+        c[j] = (int32_t)cf;
+    }
+    if (!ok) {
+        ws.slot[gi] = -1;
+        ws.rank[gi] = -2;
+        return;
+    }
+    unsigned long long key =
+        (((unsigned long long)b * g.grid[2] + c[2]) * g.grid[1] + c[1]) * g.grid[0] + c[0];
+    uint32_t h = vox_hash(key) & ws.cap_mask;
+    while (true) {
+        unsigned long long prev = atomicCAS(&ws.keys[h], VOX_EMPTY_KEY, key);
+        if (prev == VOX_EMPTY_KEY || prev == key) break;
+        h = (h + 1) & ws.cap_mask;
+    }
+    atomicMin(&ws.cur[h], ((unsigned long long)VOX_ROUND_HI << 32) | (uint32_t)i);
+    atomicAdd(&ws.count[h], 1);
+    ws.slot[gi] = (int32_t)h;
+}
+
+__global__ __launch_bounds__(256) void vox_flag_kernel(FrameOffsets fo, VoxWorkspace ws) {
+    const int b = blockIdx.y;
+    const int n = fo.off[b + 1] - fo.off[b];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int64_t gi = (int64_t)fo.off[b] + i;
+    const int32_t h = ws.slot[gi];
+    if (h < 0) return;
+    ws.rank[gi] = ((uint32_t)ws.cur[h] == (uint32_t)i) ? 0 : -1;
+}
+
+__global__ __launch_bounds__(1024) void vox_assign_kernel(FrameOffsets fo, VoxGeom g, VoxWorkspace ws,
+                                                         int32_t* __restrict__ voxel_num) {
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int base = fo.off[b];
+    const int n = fo.off[b + 1] - base;
+    __shared__ int wave_tot[16];
+    __shared__ int running;
+    __shared__ int act_cnt[2];
+    if (tid == 0) { running = 0; act_cnt[0] = 0; act_cnt[1] = 0; }
+    __syncthreads();
+
+    // (a) ordered scan of "first point" flags -> voxel ids in first-come order
+    for (int c0 = 0; c0 < n; c0 += 1024) {
+        const int i = c0 + tid;
+        const bool flag = (i < n) && (ws.rank[base + i] == 0);
+        const unsigned long long bal = __ballot(flag);
+        const int pre = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_tot[wave] = __popcll(bal);
+        __syncthreads();
+        int wpre = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            const int t = wave_tot[w];
+            wpre += (w < wave) ? t : 0;
+            tot += t;
+        }
+        const int v = running + wpre + pre;
+        if (flag) {
+            const int32_t h = ws.slot[base + i];
+            if (v < g.max_voxels) {
+                ws.vid[h] = v;
+            } else {
+                ws.vid[h] = -1;           // voxel beyond max_voxels: dropped with all its points
+                ws.rank[base + i] = -1;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) running += tot;
+        __syncthreads();
+    }
+    if (tid == 0) voxel_num[b] = running < g.max_voxels ? running : g.max_voxels;
+    __threadfence();
+    __syncthreads();
+
+    // (b) rank rounds over the non-first points of kept voxels
+    if (g.max_points > 1) {
+        for (int i = tid; i < n; i += 1024) {
+            if (ws.rank[base + i] == -1) {
+                const int32_t h = ws.slot[base + i];
+                const int32_t v = __hip_atomic_load(&ws.vid[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (v >= 0) ws.act0[base + atomicAdd(&act_cnt[0], 1)] = i;
+            }
+        }
+    }
+    __syncthreads();
+    int32_t* act_in = ws.act0 + base;
+    int32_t* act_out = ws.act1 + base;
+    int which = 0;
+    for (int r = 1; r < g.max_points; ++r) {
+        const int na = act_cnt[which];
+        if (na == 0) break;
+        const unsigned long long hi = (unsigned long long)(VOX_ROUND_HI - (uint32_t)r) << 32;
+        for (int j = tid; j < na; j += 1024) {
+            const int i = act_in[j];
+            atomicMin(&ws.cur[ws.slot[base + i]], hi | (uint32_t)i);
+        }
+        if (tid == 0) act_cnt[which ^ 1] = 0;
+        __threadfence();
+        __syncthreads();
+        for (int j = tid; j < na; j += 1024) {
+            const int i = act_in[j];
+            const unsigned long long w = __hip_atomic_load(&ws.cur[ws.slot[base + i]], __ATOMIC_RELAXED,
+                                                           __HIP_MEMORY_SCOPE_AGENT);
+            if ((uint32_t)w == (uint32_t)i) ws.rank[base + i] = r;
+            else act_out[atomicAdd(&act_cnt[which ^ 1], 1)] = i;
+        }
+        __threadfence();
+        __syncthreads();
+        int32_t* t = act_in; act_in = act_out; act_out = t;
+        which ^= 1;
+    }
+}
+
+__global__ __launch_bounds__(256) void vox_write_kernel(const float* __restrict__ points, int ndim,
+                                                       FrameOffsets fo, int batch, VoxGeom g, VoxWorkspace ws,
+                                                       const int32_t* __restrict__ voxel_num_in,
+                                                       int32_t* __restrict__ voxel_total,
+                                                       float* __restrict__ voxels, int32_t* __restrict__ coors,
+                                                       int32_t* __restrict__ num_points) {
+    const int b = blockIdx.y;
+    __shared__ int vbase_s;
+    if (threadIdx.x == 0) {
+        int s = 0;
+        for (int bb = 0; bb < b; ++bb) s += voxel_num_in[bb];
+        vbase_s = s;
+        if (blockIdx.x == 0 && b == batch - 1) *voxel_total = s + voxel_num_in[b];
+    }
+    __syncthreads();
+    const int n = fo.off[b + 1] - fo.off[b];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int64_t gi = (int64_t)fo.off[b] + i;
+    const int r = ws.rank[gi];
+    if (r < 0) return;
+    const int32_t h = ws.slot[gi];
+    const int64_t row = (int64_t)vbase_s + ws.vid[h];
+    const float* p = points + gi * ndim;
+    float* dst = voxels + (row * g.max_points + r) * ndim;
+    if (ndim == 4) {
+        *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(p);
+    } else {
+        for (int j = 0; j < ndim; ++j) dst[j] = p[j];
+    }
+    if (r == 0) {
+        unsigned long long key = ws.keys[h];
+        const int cx = (int)(key % (unsigned)g.grid[0]); key /= (unsigned)g.grid[0];
+        const int cy = (int)(key % (unsigned)g.grid[1]); key /= (unsigned)g.grid[1];
+        const int cz = (int)(key % (unsigned)g.grid[2]);
+        reinterpret_cast<int4*>(coors)[row] = make_int4(b, cz, cy, cx);
+        const int cnt = ws.count[h];
+        num_points[row] = cnt < g.max_points ? cnt : g.max_points;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+extern "C" void gga_voxel_grid_size(const gga_voxel_params* prm, int32_t grid_xyz[3]) {
+    for (int j = 0; j < 3; ++j) {
+        float gsz = (prm->pc_range[3 + j] - prm->pc_range[j]) / prm->voxel_size[j];
+        grid_xyz[j] = (int32_t)__builtin_rintf(gsz);
+    }
+}
+
+extern "C" size_t gga_hard_voxelize_workspace_bytes(int batch, int64_t total_points) {
+    (void)batch;
+    const uint64_t cap = vox_cap(total_points);
+    size_t bytes = cap * (8 + 8 + 4 + 4);
+    bytes += gga_align_up((size_t)total_points * 4, 256) * 4;
+    return bytes + 1024;
+}
+
+extern "C" int gga_hard_voxelize_batch(const float* points, int ndim, const int64_t* offsets_host, int batch,
+                                       const gga_voxel_params* prm, float* voxels, int32_t* coors,
+                                       int32_t* num_points, int32_t* voxel_num, void* workspace,
+                                       size_t workspace_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    GGA_REQUIRE(points && offsets_host && prm && voxels && coors && num_points && voxel_num && workspace,
+                "gga_hard_voxelize_batch: null pointer argument");
+    GGA_REQUIRE(batch >= 1 && batch <= GGA_MAX_BATCH, "gga_hard_voxelize_batch: batch %d not in [1, %d]", batch,
+                GGA_MAX_BATCH);
+    GGA_REQUIRE(ndim >= 3 && ndim <= 16, "gga_hard_voxelize_batch: ndim %d not in [3, 16]", ndim);
+    GGA_REQUIRE(prm->max_points >= 1 && prm->max_voxels >= 1, "gga_hard_voxelize_batch: max_points/max_voxels < 1");
+    const int64_t total = offsets_host[batch];
+    GGA_REQUIRE(offsets_host[0] == 0 && total >= 0 && total < (1ll << 30),
+                "gga_hard_voxelize_batch: offsets must start at 0 and total points < 2^30");
+    FrameOffsets fo;
+    int max_n = 0;
+    for (int b = 0; b <= batch; ++b) {
+        fo.off[b] = (int32_t)offsets_host[b];
+        if (b > 0) {
+            GGA_REQUIRE(offsets_host[b] >= offsets_host[b - 1], "gga_hard_voxelize_batch: offsets not monotone");
+            const int nb = (int)(offsets_host[b] - offsets_host[b - 1]);
+            max_n = nb > max_n ? nb : max_n;
+        }
+    }
+    if (gga_hard_voxelize_workspace_bytes(batch, total) > workspace_bytes) {
+        gga_set_error("gga_hard_voxelize_batch: workspace %zu B < required %zu B", workspace_bytes,
+                      gga_hard_voxelize_workspace_bytes(batch, total));
+        return GGA_ERR_WORKSPACE;
+    }
+    VoxGeom g;
+    for (int j = 0; j < 3; ++j) { g.vs[j] = prm->voxel_size[j]; g.lo[j] = prm->pc_range[j]; }
+    gga_voxel_grid_size(prm, g.grid);
+    GGA_REQUIRE(g.grid[0] > 0 && g.grid[1] > 0 && g.grid[2] > 0, "gga_hard_voxelize_batch: empty grid");
+    g.max_points = prm->max_points;
+    g.max_voxels = prm->max_voxels;
+
+    const uint64_t cap = vox_cap(total);
+    VoxWorkspace ws;
+    char* w = (char*)workspace;
+    ws.cur = (unsigned long long*)w;  w += cap * 8;
+    ws.keys = (unsigned long long*)w; w += cap * 8;
+    ws.count = (int32_t*)w;           w += cap * 4;
+    ws.vid = (int32_t*)w;             w += cap * 4;
+    const size_t per = gga_align_up((size_t)total * 4, 256);
+    ws.slot = (int32_t*)w; w += per;
+    ws.rank = (int32_t*)w; w += per;
+    ws.act0 = (int32_t*)w; w += per;
+    ws.act1 = (int32_t*)w;
+    ws.cap_mask = (uint32_t)(cap - 1);
+
+    const size_t cap_rows = (size_t)batch * prm->max_voxels;
+    GGA_CHECK_HIP(hipMemsetAsync(ws.cur, 0xFF, cap * 16, stream), "voxelize memset(hash)");
+    GGA_CHECK_HIP(hipMemsetAsync(ws.count, 0, cap * 4, stream), "voxelize memset(count)");
+    GGA_CHECK_HIP(hipMemsetAsync(voxels, 0, cap_rows * prm->max_points * ndim * sizeof(float), stream),
+                  "voxelize memset(voxels)");
+    GGA_CHECK_HIP(hipMemsetAsync(coors, 0, cap_rows * 4 * sizeof(int32_t), stream), "voxelize memset(coors)");
+    GGA_CHECK_HIP(hipMemsetAsync(num_points, 0, cap_rows * sizeof(int32_t), stream), "voxelize memset(num_points)");
+    if (total == 0 || max_n == 0) {
+        GGA_CHECK_HIP(hipMemsetAsync(voxel_num, 0, (batch + 1) * sizeof(int32_t), stream), "voxelize memset(voxel_num)");
+        return GGA_OK;
+    }
+    dim3 grid((max_n + 255) / 256, batch);
+    hipLaunchKernelGGL(vox_insert_kernel, grid, dim3(256), 0, stream, points, ndim, fo, g, ws);
+    GGA_CHECK_LAUNCH("vox_insert_kernel");
+    hipLaunchKernelGGL(vox_flag_kernel, grid, dim3(256), 0, stream, fo, ws);
+    GGA_CHECK_LAUNCH("vox_flag_kernel");
+    hipLaunchKernelGGL(vox_assign_kernel, dim3(batch), dim3(1024), 0, stream, fo, g, ws, voxel_num);
+    GGA_CHECK_LAUNCH("vox_assign_kernel");
+    hipLaunchKernelGGL(vox_write_kernel, grid, dim3(256), 0, stream, points, ndim, fo, batch, g, ws, voxel_num,
+                       voxel_num + batch, voxels, coors, num_points);
+    GGA_CHECK_LAUNCH("vox_write_kernel");
+    return GGA_OK;
+}
+
+// a2. HardSimpleVFE (voxel_encoder.py:43-45): one thread per (voxel, feature).
+__global__ __launch_bounds__(256) void voxel_mean_kernel(const float* __restrict__ voxels,
+                                                        const int32_t* __restrict__ num_points, int64_t m,
+                                                        int P, int ndim, int nf, float* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= m * nf) return;
+    const int64_t v = t / nf;
+    const int f = (int)(t - v * nf);
+    const float* src = voxels + v * P * ndim + f;
+    float s = 0.0f;
+    for (int p = 0; p < P; ++p) s += src[p * ndim];   // same left-to-right order as sum(dim=1)
+    out[t] = __fdiv_rn(s, (float)num_points[v]);
+}
+
+extern "C" int gga_voxel_mean(const float* voxels, const int32_t* num_points, int64_t m, int max_points, int ndim,
+                              int num_features, float* out, void* stream) {
+    GGA_REQUIRE(voxels && num_points && out, "gga_voxel_mean: null pointer argument");
+    GGA_REQUIRE(m >= 0 && max_points >= 1 && num_features >= 1 && num_features <= ndim,
+                "gga_voxel_mean: bad sizes (m=%lld P=%d ndim=%d nf=%d)", (long long)m, max_points, ndim, num_features);
+    if (m == 0) return GGA_OK;
+    const int64_t total = m * num_features;
+    hipLaunchKernelGGL(voxel_mean_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       voxels, num_points, m, max_points, ndim, num_features, out);
+    GGA_CHECK_LAUNCH("voxel_mean_kernel");
+    return GGA_OK;
+}

@@ -1,0 +1,316 @@
+"""Torch-facing wrappers over the C ABI (include/gga_hip.h).
+
+PyTorch is plumbing here: it owns device memory (caching allocator), the current
+HIP stream and autograd bookkeeping. Every op enqueues hand-written gfx950 kernels
+from ``libgga_hip.so`` on ``torch.cuda.current_stream()`` through ctypes with raw
+device pointers; nothing falls back to eager PyTorch or the CPU.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import LossParams, VoxelParams, check
+
+LAYOUT_NCHW, LAYOUT_NHWC = 0, 1
+
+_workspaces = {}
+_cell_maps = {}
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError('gga_amd ops run on the GPU only (got a CPU tensor); '
+                               'there is no CPU fallback in the product path')
+
+
+def _workspace(key, nbytes, device):
+    """Grow-only scratch buffer per (purpose, device, stream)."""
+    k = (key, device, torch.cuda.current_stream().cuda_stream)
+    w = _workspaces.get(k)
+    if w is None or w.numel() < nbytes:
+        w = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        _workspaces[k] = w
+    return w
+
+
+# ----------------------------------------------------------------------------- a1/a2
+def voxel_params(voxel_size, point_cloud_range, max_points, max_voxels):
+    prm = VoxelParams()
+    prm.voxel_size[:] = [float(v) for v in voxel_size]
+    prm.pc_range[:] = [float(v) for v in point_cloud_range]
+    prm.max_points, prm.max_voxels = int(max_points), int(max_voxels)
+    return prm
+
+
+def voxel_grid_size(prm):
+    g = (C.c_int32 * 3)()
+    _lib.lib().gga_voxel_grid_size(C.byref(prm), C.byref(g))
+    return list(g)
+
+
+@torch.no_grad()
+def hard_voxelize_batch(points, voxel_size, point_cloud_range, max_points, max_voxels, sync=True):
+    """Batched hard voxelization (mvx_two_stage_gga.py:211-236 in one call).
+
+    points: list of [N_b, C] f32 CUDA tensors. Returns ``voxels [M,P,C]``,
+    ``num_points [M]``, ``coors [M,4] (b,z,y,x)``, ``voxel_num [B+1]`` (device).
+    With ``sync=True`` the outputs are trimmed to the exact M (one 4-byte D2H read, the
+    reference syncs once per frame); with ``sync=False`` they keep the capacity
+    ``B*max_voxels`` (rows >= M zero) and ``voxel_num[-1]`` carries M on the device.
+    """
+    _need_cuda(*points)
+    B = len(points)
+    ndim = points[0].shape[1]
+    dev = points[0].device
+    offs = np.zeros(B + 1, np.int64)
+    offs[1:] = np.cumsum([p.shape[0] for p in points])
+    cat = points[0].contiguous() if B == 1 else torch.cat(points, 0)
+    if cat.dtype != torch.float32:
+        cat = cat.float()
+    total = int(offs[-1])
+    prm = voxel_params(voxel_size, point_cloud_range, max_points, max_voxels)
+    cap = B * int(max_voxels)
+    voxels = torch.empty((cap, int(max_points), ndim), dtype=torch.float32, device=dev)
+    coors = torch.empty((cap, 4), dtype=torch.int32, device=dev)
+    num_points = torch.empty((cap,), dtype=torch.int32, device=dev)
+    voxel_num = torch.empty((B + 1,), dtype=torch.int32, device=dev)
+    L = _lib.lib()
+    wsb = L.gga_hard_voxelize_workspace_bytes(B, total)
+    ws = _workspace('vox', wsb, dev)
+    check(L.gga_hard_voxelize_batch(_p(cat), ndim, offs.ctypes.data_as(C.POINTER(C.c_int64)), B,
+                                    C.byref(prm), _p(voxels), _p(coors), _p(num_points), _p(voxel_num),
+                                    _p(ws), ws.numel(), _stream()), 'gga_hard_voxelize_batch')
+    if sync:
+        m = int(voxel_num[-1].item())
+        return voxels[:m], num_points[:m], coors[:m], voxel_num
+    return voxels, num_points, coors, voxel_num
+
+
+@torch.no_grad()
+def voxel_mean(voxels, num_points, num_features):
+    _need_cuda(voxels, num_points)
+    voxels = voxels.contiguous()
+    m, P, ndim = voxels.shape
+    out = torch.empty((m, num_features), dtype=torch.float32, device=voxels.device)
+    check(_lib.lib().gga_voxel_mean(_p(voxels), _p(num_points.contiguous()), m, P, ndim, num_features,
+                                    _p(out), _stream()), 'gga_voxel_mean')
+    return out
+
+
+# ----------------------------------------------------------------------------- a3
+def _cell_map(device, batch, ny, nx):
+    k = (device, batch, ny, nx, torch.cuda.current_stream().cuda_stream)
+    m = _cell_maps.get(k)
+    if m is None:
+        nbytes = _lib.lib().gga_pillar_scatter_map_bytes(batch, ny, nx)
+        m = torch.full((nbytes // 4,), -1, dtype=torch.int32, device=device)
+        _cell_maps[k] = m
+    return m
+
+
+class _PillarScatter(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feats, coors, batch, ny, nx, layout, num_valid):
+        _need_cuda(feats, coors)
+        feats = feats.contiguous()
+        coors = coors.contiguous()
+        if coors.dtype != torch.int32:
+            coors = coors.int()
+        m, Cc = feats.shape
+        if layout == LAYOUT_NCHW:
+            canvas = torch.empty((batch, Cc, ny, nx), dtype=torch.float32, device=feats.device)
+        else:
+            canvas = torch.empty((batch, Cc, ny, nx), dtype=torch.float32, device=feats.device,
+                                 memory_format=torch.channels_last)
+        check(_lib.lib().gga_pillar_scatter_fwd(_p(feats), _p(coors), m, _p(num_valid), batch, Cc, ny, nx,
+                                                layout, _p(_cell_map(feats.device, batch, ny, nx)),
+                                                _p(canvas), _stream()), 'gga_pillar_scatter_fwd')
+        ctx.save_for_backward(coors, num_valid)
+        ctx.geom = (m, batch, Cc, ny, nx, layout)
+        return canvas
+
+    @staticmethod
+    def backward(ctx, grad):
+        coors, num_valid = ctx.saved_tensors
+        m, batch, Cc, ny, nx, layout = ctx.geom
+        if layout == LAYOUT_NCHW:
+            grad = grad.contiguous()
+        else:
+            grad = grad.contiguous(memory_format=torch.channels_last)
+        gf = torch.empty((m, Cc), dtype=torch.float32, device=grad.device)
+        check(_lib.lib().gga_pillar_scatter_bwd(_p(grad), _p(coors), m, _p(num_valid), batch, Cc, ny, nx,
+                                                layout, _p(gf), _stream()), 'gga_pillar_scatter_bwd')
+        return gf, None, None, None, None, None, None
+
+
+def pillar_scatter(feats, coors, batch_size, ny, nx, channels_last=False, num_valid=None):
+    """[M,C] pillar features + coors (b,z,y,x) -> dense [B,C,ny,nx] canvas."""
+    return _PillarScatter.apply(feats, coors, int(batch_size), int(ny), int(nx),
+                                LAYOUT_NHWC if channels_last else LAYOUT_NCHW, num_valid)
+
+
+# ----------------------------------------------------------------------------- a6/a7
+_patch_tables = {}
+
+
+def gaussian_patch_table(max_radius, device):
+    """Patches for radius 0..max_radius with the reference's f64 formula
+    (mmdet3d/core/utils/gaussian.py:6-22, sigma = diameter / 6), cast to f32."""
+    k = (max_radius, device)
+    if k not in _patch_tables:
+        vals, offs = [], [0]
+        for r in range(max_radius + 1):
+            d = 2 * r + 1
+            sigma = d / 6
+            y, x = np.ogrid[-r:r + 1, -r:r + 1]
+            h = np.exp(-(x * x + y * y) / (2 * sigma * sigma))
+            h[h < np.finfo(h.dtype).eps * h.max()] = 0
+            vals.append(h.astype(np.float32).reshape(-1))
+            offs.append(offs[-1] + d * d)
+        _patch_tables[k] = (torch.from_numpy(np.concatenate(vals)).to(device),
+                            torch.tensor(offs, dtype=torch.int32, device=device))
+    return _patch_tables[k]
+
+
+@torch.no_grad()
+def heatmap_splat(objs, n_maps, H, W, device, max_radius=64):
+    """objs: [n,4] int32 (map index, cx, cy, radius) host or device -> [n_maps,H,W] f32."""
+    hm = torch.empty((n_maps, H, W), dtype=torch.float32, device=device)
+    objs = torch.as_tensor(objs, dtype=torch.int32).reshape(-1, 4)
+    if objs.numel() and int(objs[:, 3].max()) > max_radius:
+        max_radius = int(objs[:, 3].max())
+    table, offs = gaussian_patch_table(max_radius, device)
+    objs = objs.to(device, non_blocking=True).contiguous()
+    check(_lib.lib().gga_heatmap_splat(_p(hm), n_maps, H, W, _p(objs), objs.shape[0], _p(table), _p(offs),
+                                       max_radius, _stream()), 'gga_heatmap_splat')
+    return hm
+
+
+# ----------------------------------------------------------------------------- a8
+class _GaussianFocal(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target, alpha, gamma, scale):
+        _need_cuda(logits, target)
+        logits, target = logits.contiguous(), target.contiguous()
+        n = logits.numel()
+        L = _lib.lib()
+        ws = _workspace('focal', L.gga_focal_loss_workspace_bytes(n), logits.device)
+        out = torch.empty(2, dtype=torch.float32, device=logits.device)
+        check(L.gga_focal_loss_fwd(_p(logits), _p(target), n, alpha, gamma, scale, _p(out), _p(ws),
+                                   ws.numel(), _stream()), 'gga_focal_loss_fwd')
+        ctx.save_for_backward(logits, target, out)
+        ctx.cfg = (alpha, gamma, scale)
+        return out[0], out[1]
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_npos):
+        logits, target, out = ctx.saved_tensors
+        alpha, gamma, scale = ctx.cfg
+        grad = torch.empty_like(logits)
+        g = g_loss.contiguous().float()
+        check(_lib.lib().gga_focal_loss_bwd(_p(logits), _p(target), logits.numel(), alpha, gamma, scale,
+                                            _p(out), _p(g), _p(grad), _stream()), 'gga_focal_loss_bwd')
+        return grad, None, None, None, None
+
+
+def gaussian_focal_loss(logits, target, alpha=2.0, gamma=4.0, scale=1.0):
+    """clip_sigmoid + GaussianFocalLoss(reduction='mean', avg_factor=max(num_pos,1)), times
+    ``scale``. Takes the raw heat-map logits. Returns (loss, num_pos) device scalars."""
+    return _GaussianFocal.apply(logits, target, float(alpha), float(gamma), float(scale))
+
+
+# ----------------------------------------------------------------------------- a9
+class _GatherPred(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, reg, height, dim, rot, ind, mask):
+        _need_cuda(reg, height, dim, rot, ind, mask)
+        B, _, H, W = reg.shape
+        K = ind.shape[1]
+        pred = torch.empty((B, K, 8), dtype=torch.float32, device=reg.device)
+        check(_lib.lib().gga_gather_pred_fwd(_p(reg.contiguous()), _p(height.contiguous()),
+                                             _p(dim.contiguous()), _p(rot.contiguous()), _p(ind), B, K, H, W,
+                                             _p(pred), _stream()), 'gga_gather_pred_fwd')
+        ctx.save_for_backward(ind, mask)
+        ctx.geom = (B, K, H, W)
+        return pred
+
+    @staticmethod
+    def backward(ctx, g):
+        ind, mask = ctx.saved_tensors
+        B, K, H, W = ctx.geom
+        dev = g.device
+        g_reg = torch.empty((B, 2, H, W), dtype=torch.float32, device=dev)
+        g_h = torch.empty((B, 1, H, W), dtype=torch.float32, device=dev)
+        g_dim = torch.empty((B, 3, H, W), dtype=torch.float32, device=dev)
+        g_rot = torch.empty((B, 2, H, W), dtype=torch.float32, device=dev)
+        check(_lib.lib().gga_gather_pred_bwd(_p(g.contiguous()), _p(ind), _p(mask), B, K, H, W, _p(g_reg),
+                                             _p(g_h), _p(g_dim), _p(g_rot), _stream()), 'gga_gather_pred_bwd')
+        return g_reg, g_h, g_dim, g_rot, None, None
+
+
+def gather_pred(reg, height, dim, rot, ind, mask):
+    """cat(reg,height,dim,rot) gathered at ``ind`` -> pred [B,K,8] (head:657-676)."""
+    return _GatherPred.apply(reg, height, dim, rot, ind.contiguous(), mask.contiguous())
+
+
+# ----------------------------------------------------------------------------- a10-a13
+def loss_params(B, K, train_cfg, l1_loss_weight=0.25, w_bpl=0.3, w_srl=0.1, w_pal=0.1):
+    prm = LossParams()
+    prm.B, prm.K = int(B), int(K)
+    prm.fm_w = int(train_cfg['grid_size'][0]) // int(train_cfg['out_size_factor'])
+    prm.voxel_size[:] = [float(v) for v in train_cfg['voxel_size'][:2]]
+    prm.out_size_factor = float(train_cfg['out_size_factor'])
+    prm.pc_range[:] = [float(v) for v in train_cfg['point_cloud_range'][:2]]
+    prm.code_weights[:] = [float(v) for v in train_cfg['code_weights'][:5]]
+    prm.l1_loss_weight = float(l1_loss_weight)
+    prm.w_bpl, prm.w_srl, prm.w_pal = float(w_bpl), float(w_srl), float(w_pal)
+    return prm
+
+
+class _BoxLosses(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, ind, mask, anno, l2i, bmask, ibp_xy, ibp_off, ibp_slot, prm):
+        _need_cuda(pred, ind, mask, anno, l2i, bmask)
+        B, K = prm.B, prm.K
+        dev = pred.device
+        L = _lib.lib()
+        losses = torch.empty(5, dtype=torch.float32, device=dev)
+        box_out = torch.empty((B, K, 12), dtype=torch.float32, device=dev)
+        grad_pred = torch.empty((5, B, K, 8), dtype=torch.float32, device=dev)
+        ws = _workspace('box', L.gga_box_losses_workspace_bytes(B, K), dev)
+        n_obj = 0 if ibp_slot is None else int(ibp_slot.shape[0])
+        check(L.gga_box_losses_fwd(_p(pred.contiguous()), _p(ind), _p(mask), _p(anno), _p(l2i), _p(bmask),
+                                   _p(ibp_xy), _p(ibp_off), _p(ibp_slot), n_obj, C.byref(prm), _p(losses),
+                                   _p(box_out), _p(grad_pred), _p(ws), ws.numel(), _stream()),
+              'gga_box_losses_fwd')
+        ctx.save_for_backward(grad_pred)
+        ctx.geom = (B, K)
+        ctx.mark_non_differentiable(box_out)
+        return losses, box_out
+
+    @staticmethod
+    def backward(ctx, g_losses, _g_box):
+        (grad_pred,) = ctx.saved_tensors
+        B, K = ctx.geom
+        out = torch.empty((B, K, 8), dtype=torch.float32, device=grad_pred.device)
+        check(_lib.lib().gga_box_losses_bwd(_p(grad_pred), _p(g_losses.contiguous().float()), B, K, _p(out),
+                                            _stream()), 'gga_box_losses_bwd')
+        return (out,) + (None,) * 9
+
+
+def box_losses(pred, ind, mask, anno_box, lidar2img, bound_mask, ibp_xy, ibp_offsets, ibp_slot, prm):
+    """GGA losses of one task. Returns ``losses [5]`` (bpl, srl, pal_min, pal_x, pal_y — the
+    final dict values) and ``box_out [B,K,12]`` (rot, l, w, box2d[4], X, Y, p2c_min/x/y)."""
+    return _BoxLosses.apply(pred, ind.contiguous(), mask.contiguous(), anno_box.contiguous(),
+                            lidar2img.contiguous(), bound_mask.contiguous(), ibp_xy, ibp_offsets, ibp_slot, prm)

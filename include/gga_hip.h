@@ -1,0 +1,217 @@
+/*
+ * gga_hip.h — C ABI of libgga_hip.so: the MI355X (gfx950) kernels of the GGA
+ * training hot path.
+ *
+ * Boundary rules
+ *   - plain C: device pointers, sizes, POD structs. No torch / ATen types.
+ *   - every pointer is a DEVICE pointer unless its name ends in `_host`.
+ *   - `stream` is a hipStream_t passed as void*. Every entry point only
+ *     ENQUEUES work on it: no allocation, no synchronisation, no host read-back,
+ *     so a caller may capture any sequence of calls into a hipGraph.
+ *   - memory is owned by the caller (the PyTorch caching allocator in gga_amd/);
+ *     scratch is passed in as `workspace` and sized by the *_workspace_bytes()
+ *     helper next to each entry point.
+ *   - return 0 on success, a negative gga_status otherwise; gga_last_error()
+ *     returns a thread-local message for the last failure.
+ *   - no global mutable state, re-entrant across processes (one rank per GPU).
+ *
+ * What each entry point replaces in the reference (paths under /root/reference,
+ * a pure-Python mmdet3d fork whose native ops come from the un-vendored
+ * mmcv-full / mmdet wheels — see SURVEY.md §2.2): cited per function below.
+ * INTEGRATION.md shows the ctypes binding a reference maintainer would add.
+ */
+#ifndef GGA_HIP_H_
+#define GGA_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    GGA_OK = 0,
+    GGA_ERR_INVALID_ARG = -1,   /* null pointer, bad size, unsupported shape */
+    GGA_ERR_WORKSPACE = -2,     /* workspace too small */
+    GGA_ERR_LAUNCH = -3         /* hipGetLastError() != hipSuccess after a launch */
+} gga_status;
+
+const char* gga_last_error(void);
+/* ABI version of this header; bumped on any signature change. */
+int gga_abi_version(void);
+
+/* ------------------------------------------------------------------------- */
+/* a1. Hard voxelization, whole batch in one call.                            */
+/* Replaces: mmcv.ops.Voxelization(deterministic=True) called once per frame  */
+/* in a Python loop + torch.cat + F.pad —                                     */
+/*   mmdet3d/models/detectors/mvx_two_stage_gga.py:211-236 (voxelize),        */
+/*   semantics restated in mmdet3d/core/voxel/voxel_generator.py:137-208.     */
+/* First-come semantics, bit-exact: voxel id = order of first point, slot =   */
+/* order of the point inside its voxel, voxels beyond max_voxels and points   */
+/* beyond max_points dropped.                                                 */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+    float voxel_size[3];     /* x, y, z */
+    float pc_range[6];       /* xmin, ymin, zmin, xmax, ymax, zmax */
+    int32_t max_points;      /* per voxel */
+    int32_t max_voxels;      /* per frame */
+} gga_voxel_params;
+
+/* grid = round((max - min) / voxel_size) in f32, as mmcv / the numpy voxelizer do. */
+void gga_voxel_grid_size(const gga_voxel_params* prm, int32_t grid_xyz[3]);
+
+size_t gga_hard_voxelize_workspace_bytes(int batch, int64_t total_points);
+
+/*
+ * points         [total_points, ndim] f32, frames concatenated
+ * offsets_host   [batch + 1] i64 row offsets of each frame in `points`
+ * voxels         [batch * max_voxels, max_points, ndim] f32  (zero-filled here)
+ * coors          [batch * max_voxels, 4] i32  (b, z, y, x)
+ * num_points     [batch * max_voxels] i32
+ * voxel_num      [batch + 1] i32: voxels per frame, [batch] = total M.
+ * Frames are compacted: frame b occupies rows [sum_{b'<b} M_b', +M_b); rows >= M
+ * are left zero.
+ */
+int gga_hard_voxelize_batch(const float* points, int ndim, const int64_t* offsets_host, int batch,
+                            const gga_voxel_params* prm, float* voxels, int32_t* coors,
+                            int32_t* num_points, int32_t* voxel_num, void* workspace,
+                            size_t workspace_bytes, void* stream);
+
+/* a2. HardSimpleVFE: mean of the valid points of each voxel.
+ * Replaces mmdet3d/models/voxel_encoders/voxel_encoder.py:43-45.
+ * out [m, num_features] = sum_p voxels[m, p, :num_features] / num_points[m]. */
+int gga_voxel_mean(const float* voxels, const int32_t* num_points, int64_t m, int max_points,
+                   int ndim, int num_features, float* out, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* a3. PointPillars scatter (the kernel the "HBM GB/s on voxel scatter"       */
+/* metric measures) and its backward.                                         */
+/* Replaces mmdet3d/models/middle_encoders/pillar_scatter.py:62-102           */
+/* (per-frame zeros + boolean mask + index_put + stack).                      */
+/* ------------------------------------------------------------------------- */
+enum { GGA_LAYOUT_NCHW = 0, GGA_LAYOUT_NHWC = 1 };
+
+/* cell_map: [batch * ny * nx] i32 scratch that MUST hold -1 everywhere on entry
+ * and holds -1 everywhere again on return (the canvas pass resets the entries it
+ * consumes), so one hipMemset at allocation time serves every later call. */
+size_t gga_pillar_scatter_map_bytes(int batch, int ny, int nx);
+
+/*
+ * feats      [m, channels] f32;  coors [m, 4] i32 (b, z, y, x)
+ * num_valid  optional device i32 scalar: only rows < *num_valid are scattered
+ *            (lets the caller keep a capacity-sized buffer without a host sync)
+ * canvas     dense output, written in full (zero where no pillar):
+ *            NCHW: [batch, channels, ny, nx]   NHWC: [batch, ny, nx, channels]
+ * channels must be a multiple of 4. Duplicate (b, y, x): the highest row wins
+ * (= the sequential index_put of the reference's CPU path).
+ */
+int gga_pillar_scatter_fwd(const float* feats, const int32_t* coors, int64_t m,
+                           const int32_t* num_valid, int batch, int channels, int ny, int nx,
+                           int layout, int32_t* cell_map, float* canvas, void* stream);
+
+/* grad_feats [m, channels] = grad_canvas gathered at each pillar's cell
+ * (rows >= *num_valid get zeros). */
+int gga_pillar_scatter_bwd(const float* grad_canvas, const int32_t* coors, int64_t m,
+                           const int32_t* num_valid, int batch, int channels, int ny, int nx,
+                           int layout, float* grad_feats, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* a6/a7. Heat-map target splat on the device.                                */
+/* Replaces the per-object numpy gaussian + H2D copy + torch.max(out=) of     */
+/* mmdet3d/core/utils/gaussian.py:25-54 called from                           */
+/* mmdet3d/models/dense_heads/centerpoint_head_gga.py:576.                    */
+/* ------------------------------------------------------------------------- */
+/*
+ * heatmap       [n_maps, H, W] f32, zero-filled here, then max-splatted
+ * objs          [n_obj, 4] i32: (map index, cx, cy, radius)
+ * patch_table   f32 gaussian patches for radius 0..max_radius, concatenated;
+ *               patch r is (2r+1)^2 values at patch_offsets[r] (built on the host
+ *               with the reference's f64 formula so the values are bit-identical)
+ */
+int gga_heatmap_splat(float* heatmap, int n_maps, int H, int W, const int32_t* objs, int n_obj,
+                      const float* patch_table, const int32_t* patch_offsets, int max_radius,
+                      void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* a8. clip_sigmoid + GaussianFocalLoss (mean over max(num_pos,1)), fused.    */
+/* Replaces mmdet3d/models/utils/clip_sigmoid.py:16 + mmdet GaussianFocalLoss */
+/* + the host-syncing num_pos.item() of centerpoint_head_gga.py:650-655.      */
+/* ------------------------------------------------------------------------- */
+size_t gga_focal_loss_workspace_bytes(int64_t n);
+/* out[0] = scale * sum(loss) / (max(num_pos,1) + eps_f32); out[1] = num_pos. */
+int gga_focal_loss_fwd(const float* logits, const float* target, int64_t n, float alpha,
+                       float gamma, float scale, float* out, void* workspace,
+                       size_t workspace_bytes, void* stream);
+/* grad_logits[i] = (*grad_out) * scale * dloss_i/dlogit_i / (max(num_pos,1)+eps);
+ * fwd_out is the `out` of the forward call (num_pos is read from fwd_out[1]). */
+int gga_focal_loss_bwd(const float* logits, const float* target, int64_t n, float alpha,
+                       float gamma, float scale, const float* fwd_out, const float* grad_out,
+                       float* grad_logits, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* a9. Gather the 8 regression channels at the object cells, and its backward */
+/* (scatter-add into the dense head-map gradients).                           */
+/* Replaces cat + permute + contiguous + gather of                            */
+/* centerpoint_head_gga.py:141-164,657-676.                                   */
+/* ------------------------------------------------------------------------- */
+/* reg [B,2,H,W] height [B,1,H,W] dim [B,3,H,W] rot [B,2,H,W] -> pred [B,K,8] */
+int gga_gather_pred_fwd(const float* reg, const float* height, const float* dim, const float* rot,
+                        const int64_t* ind, int B, int K, int H, int W, float* pred, void* stream);
+/* The four grad maps are zero-filled here, then grad_pred is scatter-added;
+ * slots with mask == 0 are skipped (their weight is zero in every loss term). */
+int gga_gather_pred_bwd(const float* grad_pred, const int64_t* ind, const uint8_t* mask, int B,
+                        int K, int H, int W, float* g_reg, float* g_height, float* g_dim,
+                        float* g_rot, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* a10-a13. The GGA geometry-aware losses for one task, forward + analytic    */
+/* gradient in one pass: rotation, decode, 8 corners, lidar2img projection,   */
+/* 2D box (BPL), semantic ratio (SRL), point-to-box alignment (PAL).          */
+/* Replaces centerpoint_head_gga.py:167-341 (GGA_calculate_rotation,          */
+/* get_distance_single/bev, get_prediction_single) and the loss assembly      */
+/* :678-721 with mmdet L1Loss(reduction='mean', loss_weight).                 */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+    int32_t B, K;                 /* frames, object slots per frame (max_objs) */
+    int32_t fm_w;                 /* feature-map width (ind = y * fm_w + x) */
+    float voxel_size[2];          /* train_cfg.voxel_size[:2] */
+    float out_size_factor;
+    float pc_range[2];            /* train_cfg.point_cloud_range[:2] */
+    float code_weights[5];        /* train_cfg.code_weights */
+    float l1_loss_weight;         /* L1Loss.loss_weight (0.25) */
+    float w_bpl, w_srl, w_pal;    /* head:697-721 multipliers (0.3, 0.1, 0.1) */
+} gga_loss_params;
+
+/* indices into losses[] */
+enum { GGA_L_BPL = 0, GGA_L_SRL = 1, GGA_L_PAL_MIN = 2, GGA_L_PAL_X = 3, GGA_L_PAL_Y = 4,
+       GGA_L_NUM = 5 };
+
+size_t gga_box_losses_workspace_bytes(int B, int K);
+
+/*
+ * pred        [B,K,8] f32 (dx, dy, z, log l, log w, log h, sin, cos)
+ * ind         [B,K] i64; mask [B,K] u8; anno_box [B,K,5] f32 (x1,y1,x2,y2,srl)
+ * lidar2img   [B,K,4,4] f32; bound_mask [B,K,4] u8
+ * ibp_xy      [n_pts,2] f32 in-box points of every object (xy, packed)
+ * ibp_offsets [n_ibp_obj + 1] i32 point ranges; ibp_slot [n_ibp_obj] i32 = b*K + k
+ * outputs
+ *   losses      [5] f32, final dict values (weights and 1/(num+1e-4+eps) applied)
+ *   box_out     [B,K,12] f32: rot, l, w, u_min, v_min, u_max, v_max, X, Y, p2c_min, p2c_x, p2c_y
+ *               (intermediates, for parity tests / logging)
+ *   grad_pred   [5,B,K,8] f32: d losses[t] / d pred, per term
+ */
+int gga_box_losses_fwd(const float* pred, const int64_t* ind, const uint8_t* mask,
+                       const float* anno_box, const float* lidar2img, const uint8_t* bound_mask,
+                       const float* ibp_xy, const int32_t* ibp_offsets, const int32_t* ibp_slot,
+                       int n_ibp_obj, const gga_loss_params* prm, float* losses, float* box_out,
+                       float* grad_pred, void* workspace, size_t workspace_bytes, void* stream);
+
+/* grad_pred_out [B,K,8] = sum_t grad_losses[t] * grad_pred[t] (grad_losses [5] on device). */
+int gga_box_losses_bwd(const float* grad_pred, const float* grad_losses, int B, int K,
+                       float* grad_pred_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GGA_HIP_H_ */

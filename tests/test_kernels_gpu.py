@@ -1,0 +1,248 @@
+"""Parity of the gfx950 kernels (through the C ABI) against the CPU oracle and the
+golden vectors of the imported reference. Run with ``-m gpu`` on an MI355X.
+
+Bars (BASELINE.json north_star): voxel / scatter indices and payload copies bit-exact;
+fp32 losses within 1e-4; gradients against the reference's autograd output.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import FMAP, TRAIN_CFG, load_head_case
+from gga_amd import functional as F
+from gga_amd import synthetic
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _vox_gpu(points_list, vs, rng, mp, mv):
+    pts = [torch.from_numpy(np.ascontiguousarray(p, np.float32)).to(DEV) for p in points_list]
+    v, n, c, vn = F.hard_voxelize_batch(pts, vs, rng, mp, mv)
+    return v.cpu().numpy(), n.cpu().numpy(), c.cpu().numpy(), vn.cpu().numpy()
+
+
+@pytest.mark.parametrize('case', ['second', 'second_coarse', 'pp', 'pp_dense', 'ka'])
+def test_voxelize_golden_bit_exact(golden, case):
+    d = golden('voxelize')
+    if case == 'ka':
+        vs, rng, mp, mv = [0.5] * 3, [0, -40, -3, 70.4, 40, 1], 1000, 20000
+    else:
+        cfg = d[f'{case}.cfg']
+        vs, rng, mp, mv = cfg[:3], cfg[3:9], int(cfg[9]), int(cfg[10])
+    v, n, c, vn = _vox_gpu([d[f'{case}.points']], vs, rng, mp, mv)
+    assert vn.tolist() == [len(d[f'{case}.coors'])] * 2
+    assert np.array_equal(c[:, 1:], d[f'{case}.coors']) and (c[:, 0] == 0).all()
+    assert np.array_equal(n, d[f'{case}.num_points'])
+    assert np.array_equal(v, d[f'{case}.voxels'])
+
+
+@pytest.mark.parametrize('cfg', ['second', 'pp'])
+def test_voxelize_batch_full_size_vs_oracle(cfg):
+    # BASELINE sizes: 20k points / frame, max_voxels 16000 (the cap is hit), ragged batch
+    vs, rng, mp = (([0.05, 0.05, 0.1], synthetic.RANGE_SECOND, 5) if cfg == 'second'
+                   else ([0.16, 0.16, 4], synthetic.RANGE_PP, 32))
+    frames = [synthetic.make_frame(i, n_points=n, pc_range=rng)['points'].numpy()
+              for i, n in enumerate([20000, 20000, 7001, 1, 20000])]
+    frames.insert(3, np.zeros((0, 4), np.float32))           # empty frame
+    v, n, c, vn = _vox_gpu(frames, vs, rng, mp, 16000)
+    ov, on, oc = O.voxelize_batch(frames, vs, rng, mp, 16000)
+    assert vn[-1] == len(oc) and vn[:-1].tolist() == [int((oc[:, 0] == b).sum()) for b in range(len(frames))]
+    assert np.array_equal(c, oc) and np.array_equal(n, on) and np.array_equal(v, ov)
+
+
+def test_voxelize_dense_cluster_rank_order():
+    # thousands of points in a handful of voxels: the rank rounds must keep first-come order
+    rng = np.random.default_rng(5)
+    pts = np.concatenate([rng.uniform([10, 0, -1, 0], [10.3, 0.3, -0.9, 1], (6000, 4)),
+                          rng.uniform([0, -40, -3, 0], [70, 40, 1, 1], (2000, 4))]).astype(np.float32)
+    pts = pts[rng.permutation(len(pts))]
+    for mp in (1, 5, 32, 100):
+        v, n, c, _ = _vox_gpu([pts], [0.16, 0.16, 4], synthetic.RANGE_PP, mp, 16000)
+        ov, oc, on = O.hard_voxelize(pts, [0.16, 0.16, 4], synthetic.RANGE_PP, mp, 16000)
+        assert np.array_equal(c[:, 1:], oc) and np.array_equal(n, on) and np.array_equal(v, ov)
+
+
+def test_voxel_mean(golden):
+    d = golden('encoders')
+    out = F.voxel_mean(torch.from_numpy(d['vfe.voxels']).to(DEV), torch.from_numpy(d['vfe.num_points']).to(DEV), 4)
+    np.testing.assert_allclose(out.cpu().numpy(), d['vfe.out'], rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize('channels_last', [False, True])
+@pytest.mark.parametrize('case', ['small', 'pp'])
+def test_scatter_golden(golden, case, channels_last):
+    d = golden('scatter')
+    B, C, ny, nx = (int(x) for x in d[f'{case}.shape'])
+    feats = torch.from_numpy(d[f'{case}.feats']).to(DEV).requires_grad_(True)
+    coors = torch.from_numpy(d[f'{case}.coors']).to(DEV)
+    out = F.pillar_scatter(feats, coors, B, ny, nx, channels_last=channels_last)
+    assert out.shape == (B, C, ny, nx)
+    assert np.array_equal(out.detach().cpu().numpy(), d[f'{case}.canvas'])     # bit-exact copy
+    # second call reuses the self-cleaning cell map
+    out2 = F.pillar_scatter(feats, coors, B, ny, nx, channels_last=channels_last)
+    assert torch.equal(out, out2)
+    # backward = gather of the canvas gradient
+    g = torch.randn_like(out)
+    out.backward(g)
+    idx = coors.long()
+    ref = g[idx[:, 0], :, idx[:, 2], idx[:, 3]]
+    assert torch.equal(feats.grad, ref)
+
+
+def test_scatter_full_size_properties():
+    # BASELINE config 2: [256000,64] -> [16,64,496,432]; checksum / round-trip properties
+    B, C, ny, nx, M = 16, 64, 496, 432, 16000
+    g = torch.Generator().manual_seed(0)
+    coors = []
+    for b in range(B):
+        cells = torch.randperm(ny * nx, generator=g)[:M]
+        coors.append(torch.stack([torch.full((M,), b), torch.zeros(M, dtype=torch.long), cells // nx, cells % nx], 1))
+    coors = torch.cat(coors).int().to(DEV)
+    feats = torch.randn(B * M, C, device=DEV)
+    for cl in (False, True):
+        out = F.pillar_scatter(feats, coors, B, ny, nx, channels_last=cl)
+        assert int((out != 0).sum()) == int((feats != 0).sum())
+        assert torch.equal(out.sum(dtype=torch.float64), feats.sum(dtype=torch.float64)) or \
+            abs(float(out.sum(dtype=torch.float64) - feats.sum(dtype=torch.float64))) < 1e-6
+        idx = coors.long()
+        assert torch.equal(out[idx[:, 0], :, idx[:, 2], idx[:, 3]], feats)      # scatter -> gather round trip
+    # capacity-sized buffer with a device-side valid count: rows beyond it are ignored
+    nv = torch.tensor([1000], dtype=torch.int32, device=DEV)
+    out = F.pillar_scatter(feats, coors, B, ny, nx, num_valid=nv)
+    assert int((out != 0).sum()) == int((feats[:1000] != 0).sum())
+
+
+def test_scatter_duplicate_cells_last_row_wins():
+    feats = torch.arange(1, 4 * 8 + 1, dtype=torch.float32, device=DEV).view(4, 8)
+    coors = torch.tensor([[0, 0, 1, 1], [0, 0, 2, 2], [0, 0, 1, 1], [0, 0, 1, 1]], dtype=torch.int32, device=DEV)
+    out = F.pillar_scatter(feats, coors, 1, 4, 4)
+    assert torch.equal(out[0, :, 1, 1], feats[3]) and torch.equal(out[0, :, 2, 2], feats[1])
+
+
+def test_heatmap_splat(golden):
+    d = golden('gaussian')
+    objs = np.concatenate([np.zeros((len(d['splat.radii']), 1), np.int32), d['splat.centers'],
+                           d['splat.radii'][:, None]], 1).astype(np.int32)
+    hm = F.heatmap_splat(objs, 1, 200, 176, DEV)
+    assert np.array_equal(hm[0].cpu().numpy(), d['splat.heatmap'])            # table lookup: bit-exact
+    t, offs = F.gaussian_patch_table(11, DEV)
+    for r in range(12):
+        p = t[int(offs[r]):int(offs[r + 1])].cpu().numpy().reshape(2 * r + 1, 2 * r + 1)
+        assert np.array_equal(p, d[f'patch.{r}'].astype(np.float32))
+
+
+def _targets(d, c):
+    case = load_head_case(d, c)
+    torch.manual_seed(1234)
+    srl = O.draw_srl(case['B'])
+    tg = O.get_targets(case['labels'], case['boxes_img'], case['lidar2img'], case['pseudo'],
+                       case['bdry'], case['ibp'], case['meta_l2i'], TRAIN_CFG[c], srl)
+    return case, tg
+
+
+def _pack_ibp(ibps_t, K):
+    xy, off, slot = [], [0], []
+    for b, objs in enumerate(ibps_t):
+        for k, p in enumerate(objs):
+            xy.append(np.asarray(p)[:, :2].astype(np.float32))
+            off.append(off[-1] + len(p))
+            slot.append(b * K + k)
+    xy = np.concatenate(xy, 0) if xy else np.zeros((0, 2), np.float32)
+    return (torch.from_numpy(xy).to(DEV), torch.tensor(off, dtype=torch.int32, device=DEV),
+            torch.tensor(slot, dtype=torch.int32, device=DEV))
+
+
+@pytest.mark.parametrize('c', ['second', 'pp'])
+def test_head_losses_and_grads_vs_reference(golden, c):
+    d = golden('head')
+    case, tg = _targets(d, c)
+    B = case['B']
+    H, W = FMAP[c]
+    K = 500
+    preds = synthetic.make_head_preds(B, H, W, seed=int(d[f'{c}.pred_seed']))
+    prm = F.loss_params(B, K, TRAIN_CFG[c])
+    keys = ('loss_bbox', 'loss_ratio', 'distancemin', 'distancex', 'distancey')
+    for t in range(3):
+        maps = {k: v.to(DEV).requires_grad_(True) for k, v in preds[t].items()}
+        ind = torch.from_numpy(tg['ind'][t]).to(DEV)
+        mask = torch.from_numpy(tg['mask'][t]).to(DEV)
+        hm_t = torch.from_numpy(tg['heatmap'][t]).to(DEV)
+        lh, npos = F.gaussian_focal_loss(maps['heatmap'], hm_t, alpha=0.0, gamma=4.0, scale=5.0)
+        assert float(npos) == float((tg['heatmap'][t] == 1).sum())
+        ref = float(d[f'{c}.loss.task{t}.loss_heatmap'])
+        assert float(lh) == pytest.approx(ref, rel=1e-5, abs=1e-4)
+
+        pred = F.gather_pred(maps['reg'], maps['height'], maps['dim'], maps['rot'], ind, mask)
+        np.testing.assert_array_equal(pred.detach().cpu().numpy(), d[f'{c}.mid.{t}.pred'])
+        xy, off, slot = _pack_ibp(tg['ibp'][t], K)
+        losses, box = F.box_losses(pred, ind, mask, torch.from_numpy(tg['anno_box'][t]).to(DEV),
+                                   torch.from_numpy(tg['lidar2img'][t]).to(DEV),
+                                   torch.from_numpy(tg['bound_mask'][t]).to(DEV), xy, off, slot, prm)
+        box = box.cpu().numpy()
+        np.testing.assert_allclose(box[..., 0], d[f'{c}.mid.{t}.rot'], rtol=2e-6, atol=2e-6)
+        np.testing.assert_allclose(box[..., 1:3], d[f'{c}.mid.{t}.pred_ratio'], rtol=2e-6, atol=2e-6)
+        np.testing.assert_allclose(box[..., 3:7], d[f'{c}.mid.{t}.pred_iou'], rtol=1e-5, atol=1e-3)
+        np.testing.assert_allclose(box[..., 7:9], d[f'{c}.mid.{t}.pred_box_bev'][..., :2], rtol=2e-6, atol=2e-6)
+        for j, k in enumerate(('p2c_min', 'p2c_x', 'p2c_y')):
+            np.testing.assert_allclose(box[..., 9 + j], d[f'{c}.mid.{t}.{k}'][..., 0], rtol=1e-5, atol=1e-4)
+        lv = losses.detach().cpu().numpy()
+        for j, k in enumerate(keys):
+            assert float(lv[j]) == pytest.approx(float(d[f'{c}.loss.task{t}.{k}']), rel=1e-5, abs=1e-4), k
+
+        # gradients: variant A (keys containing 'loss' only) and B (all terms) vs reference autograd
+        for tag, gl in (('A', [1, 1, 0, 0, 0]), ('B', [1, 1, 1, 1, 1])):
+            for m in maps.values():
+                m.grad = None
+            tot = (losses * torch.tensor(gl, dtype=torch.float32, device=DEV)).sum() + (lh if tag == 'A' else lh * 0)
+            tot.backward(retain_graph=True)
+            for k in ('reg', 'height', 'dim', 'rot'):
+                idx = d[f'{c}.grad{tag}.{t}.{k}.idx']
+                val = d[f'{c}.grad{tag}.{t}.{k}.val']
+                g = maps[k].grad.cpu().numpy()
+                got = g[tuple(idx.T)] if len(idx) else np.zeros(0, np.float32)
+                np.testing.assert_allclose(got, val, rtol=2e-3, atol=2e-5, err_msg=f'{tag} {k}')
+                assert np.count_nonzero(g) <= len(idx) + 2            # nothing off the object cells
+            if tag == 'A':
+                g = maps['heatmap'].grad.cpu().numpy().reshape(-1)
+                sel = d[f'{c}.gradA.{t}.heatmap.flatidx']
+                np.testing.assert_allclose(g[sel], d[f'{c}.gradA.{t}.heatmap.val'], rtol=1e-4, atol=1e-7)
+                assert float(np.abs(g.astype(np.float64)).sum()) == pytest.approx(
+                    float(d[f'{c}.gradA.{t}.heatmap.abs_sum']), rel=1e-4)
+
+
+def test_focal_loss_general_alpha_vs_oracle():
+    n = 3 * 200 * 176 + 3      # not a multiple of 4: exercises the tail
+    x = synthetic.det_uniform((n + 1,), 9)[:n] * 6
+    t = synthetic.det_uniform((n + 1,), 10)[:n] + 0.5
+    t[::997] = 1.0
+    xa, ta = x[:n - 3].contiguous(), t[:n - 3].contiguous()
+    for alpha, gamma in ((0.0, 4.0), (2.0, 4.0), (1.5, 3.0)):
+        for xs, ts in ((xa, ta),):
+            xg = xs.to(DEV).requires_grad_(True)
+            loss, npos = F.gaussian_focal_loss(xg, ts.to(DEV), alpha, gamma, 1.0)
+            loss.backward()
+            ref, g, rp = O.focal_loss(xs.numpy(), ts.numpy(), alpha, gamma, with_grad=True)
+            assert float(npos) == rp
+            assert float(loss) == pytest.approx(float(ref), rel=2e-5)
+            np.testing.assert_allclose(xg.grad.cpu().numpy(), g, rtol=2e-4, atol=1e-9)
+
+
+def test_nan_target_propagates_like_reference():
+    # the reference's isnotnan weight multiplies |pred - NaN| by 0, which is still NaN
+    # (centerpoint_head_gga.py:679-681): the kernel keeps that IEEE behaviour.
+    c = 'second'
+    B, K = 2, 500
+    prm = F.loss_params(B, K, TRAIN_CFG[c])
+    pred = torch.zeros(B, K, 8, device=DEV)
+    pred[..., 7] = 1
+    ind = torch.zeros(B, K, dtype=torch.int64, device=DEV)
+    mask = torch.zeros(B, K, dtype=torch.uint8, device=DEV)
+    mask[0, 0] = 1
+    anno = torch.zeros(B, K, 5, device=DEV)
+    anno[0, 0, 1] = float('nan')
+    l2i = torch.eye(4, device=DEV).repeat(B, K, 1, 1)
+    bm = torch.ones(B, K, 4, dtype=torch.uint8, device=DEV)
+    losses, _ = F.box_losses(pred, ind, mask, anno, l2i, bm, None, None, None, prm)
+    assert torch.isnan(losses[0]) and not torch.isnan(losses[1])

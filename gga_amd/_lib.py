@@ -43,6 +43,8 @@ SIGNATURES = {
     'gga_pillar_scatter_map_bytes': (sz, [i32, i32, i32]),
     'gga_pillar_scatter_fwd': (i32, [vp, vp, i64, vp, i32, i32, i32, i32, i32, vp, vp, vp]),
     'gga_pillar_scatter_bwd': (i32, [vp, vp, i64, vp, i32, i32, i32, i32, i32, vp, vp]),
+    'gga_profile_pillar_scatter': (i32, [vp, vp, i64, i32, i32, i32, i32, i32, vp, vp, i32,
+                                          C.POINTER(C.c_float), C.POINTER(C.c_float), vp]),
     'gga_heatmap_splat': (i32, [vp, i32, i32, i32, vp, i32, vp, vp, i32, vp]),
     'gga_focal_loss_workspace_bytes': (sz, [i64]),
     'gga_focal_loss_fwd': (i32, [vp, vp, i64, f32, f32, f32, vp, vp, sz, vp]),

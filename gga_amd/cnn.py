@@ -1,0 +1,104 @@
+"""Layer builders the reference takes from the un-vendored ``mmcv.cnn``
+(``ConvModule``, ``build_conv_layer``, ``build_norm_layer``,
+``build_upsample_layer``; used at mmdet3d/models/backbones/second.py:4,
+necks/second_fpn.py:4, dense_heads/centerpoint_head_gga.py:5). Only what the GGA
+configs reach is provided; parameter / sub-module names follow mmcv so a reference
+checkpoint's ``state_dict`` keys line up (``conv``, ``bn``, ``activate``).
+
+The dense 2D convolutions themselves are MIOpen's (MFMA) — SURVEY.md §8 a4/a5 marks
+them "not hand-written".
+"""
+import torch
+from torch import nn
+
+from .registry import CONV_LAYERS
+
+CONV_LAYERS.register_module('Conv2d', module=nn.Conv2d)
+CONV_LAYERS.register_module('Conv1d', module=nn.Conv1d)
+CONV_LAYERS.register_module('Conv', module=nn.Conv2d)
+
+_NORMS = {'BN': ('bn', nn.BatchNorm2d), 'BN1d': ('bn', nn.BatchNorm1d), 'BN2d': ('bn', nn.BatchNorm2d),
+          'BN3d': ('bn', nn.BatchNorm3d)}
+_UPSAMPLE = {'deconv': nn.ConvTranspose2d}
+
+
+def build_conv_layer(cfg, *args, **kwargs):
+    cfg = dict(type='Conv2d') if cfg is None else dict(cfg)
+    layer_type = cfg.pop('type')
+    cls = CONV_LAYERS.get(layer_type)
+    if cls is None:
+        raise KeyError(f'Unrecognized layer type {layer_type}')
+    return cls(*args, **kwargs, **cfg)
+
+
+def build_norm_layer(cfg, num_features, postfix=''):
+    cfg = dict(cfg)
+    layer_type = cfg.pop('type')
+    if layer_type not in _NORMS:
+        raise KeyError(f'Unrecognized norm type {layer_type}')
+    abbr, cls = _NORMS[layer_type]
+    requires_grad = cfg.pop('requires_grad', True)
+    cfg.setdefault('eps', 1e-5)
+    layer = cls(num_features, **cfg)
+    for p in layer.parameters():
+        p.requires_grad = requires_grad
+    return abbr + str(postfix), layer
+
+
+def build_upsample_layer(cfg, *args, **kwargs):
+    cfg = dict(cfg)
+    layer_type = cfg.pop('type')
+    if layer_type not in _UPSAMPLE:
+        raise KeyError(f'Unrecognized upsample type {layer_type}')
+    return _UPSAMPLE[layer_type](*args, **kwargs, **cfg)
+
+
+def kaiming_init(module, a=0, mode='fan_out', nonlinearity='relu', bias=0.0):
+    if getattr(module, 'weight', None) is not None:
+        nn.init.kaiming_normal_(module.weight, a=a, mode=mode, nonlinearity=nonlinearity)
+    if getattr(module, 'bias', None) is not None:
+        nn.init.constant_(module.bias, bias)
+
+
+def constant_init(module, val, bias=0.0):
+    if getattr(module, 'weight', None) is not None:
+        nn.init.constant_(module.weight, val)
+    if getattr(module, 'bias', None) is not None:
+        nn.init.constant_(module.bias, bias)
+
+
+class ConvModule(nn.Module):
+    """conv -> norm -> ReLU with mmcv's attribute names and 'auto' bias rule."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1,
+                 groups=1, bias='auto', conv_cfg=None, norm_cfg=None, act_cfg=dict(type='ReLU'),
+                 inplace=True, order=('conv', 'norm', 'act')):
+        super().__init__()
+        assert order == ('conv', 'norm', 'act')
+        self.with_norm = norm_cfg is not None
+        self.with_activation = act_cfg is not None
+        if bias == 'auto':
+            bias = not self.with_norm
+        self.conv = build_conv_layer(conv_cfg, in_channels, out_channels, kernel_size, stride=stride,
+                                     padding=padding, dilation=dilation, groups=groups, bias=bias)
+        if self.with_norm:
+            self.norm_name, norm = build_norm_layer(norm_cfg, out_channels)
+            self.add_module(self.norm_name, norm)
+        if self.with_activation:
+            assert act_cfg['type'] == 'ReLU'
+            self.activate = nn.ReLU(inplace=inplace)
+        kaiming_init(self.conv)
+        if self.with_norm:
+            constant_init(self.norm, 1, bias=0)
+
+    @property
+    def norm(self):
+        return getattr(self, self.norm_name) if self.with_norm else None
+
+    def forward(self, x):
+        x = self.conv(x)
+        if self.with_norm:
+            x = self.norm(x)
+        if self.with_activation:
+            x = self.activate(x)
+        return x

@@ -192,3 +192,56 @@ extern "C" int gga_pillar_scatter_bwd(const float* grad_canvas, const int32_t* c
     GGA_CHECK_LAUNCH("scatter_bwd_kernel");
     return GGA_OK;
 }
+
+// Bench-only: times the two forward kernels separately with HIP events on `stream`
+// (SYNCHRONISES; never call it from a captured or latency-sensitive path).
+extern "C" int gga_profile_pillar_scatter(const float* feats, const int32_t* coors, int64_t m, int batch,
+                                          int channels, int ny, int nx, int layout, int32_t* cell_map,
+                                          float* canvas, int iters, float* ms_map_host, float* ms_canvas_host,
+                                          void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    GGA_REQUIRE(feats && coors && cell_map && canvas && ms_map_host && ms_canvas_host && iters >= 1 && m > 0,
+                "gga_profile_pillar_scatter: bad arguments");
+    if (int rc = scatter_check("gga_profile_pillar_scatter", m, batch, channels, ny, nx, layout)) return rc;
+    const int64_t cells = (int64_t)ny * nx;
+    hipEvent_t e0, e1, e2;
+    GGA_CHECK_HIP(hipEventCreate(&e0), "hipEventCreate");
+    GGA_CHECK_HIP(hipEventCreate(&e1), "hipEventCreate");
+    GGA_CHECK_HIP(hipEventCreate(&e2), "hipEventCreate");
+    double tm = 0.0, tc = 0.0;
+    for (int it = 0; it < iters; ++it) {
+        (void)hipEventRecord(e0, stream);
+        hipLaunchKernelGGL(scatter_map_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, stream, coors, m,
+                           (const int32_t*)nullptr, batch, ny, nx, cell_map);
+        (void)hipEventRecord(e1, stream);
+        if (layout == GGA_LAYOUT_NCHW) {
+            const int64_t q = (int64_t)batch * cells / 4;
+            if (channels % 8 == 0)
+                hipLaunchKernelGGL(scatter_canvas_nchw_kernel<8>, dim3((unsigned)((q + 255) / 256)), dim3(256), 0,
+                                   stream, feats, cell_map, channels, cells, q, canvas);
+            else
+                hipLaunchKernelGGL(scatter_canvas_nchw_kernel<4>, dim3((unsigned)((q + 255) / 256)), dim3(256), 0,
+                                   stream, feats, cell_map, channels, cells, q, canvas);
+            (void)hipEventRecord(e2, stream);
+        } else {
+            const int c4 = channels / 4;
+            const int64_t total4 = (int64_t)batch * cells * c4;
+            hipLaunchKernelGGL(scatter_canvas_nhwc_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0,
+                               stream, feats, cell_map, c4, total4, canvas);
+            (void)hipEventRecord(e2, stream);
+            hipLaunchKernelGGL(scatter_map_reset_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, stream,
+                               coors, m, (const int32_t*)nullptr, batch, ny, nx, cell_map);
+        }
+        GGA_CHECK_HIP(hipEventSynchronize(e2), "hipEventSynchronize");
+        float a = 0.f, b = 0.f;
+        (void)hipEventElapsedTime(&a, e0, e1);
+        (void)hipEventElapsedTime(&b, e1, e2);
+        tm += a; tc += b;
+    }
+    GGA_CHECK_HIP(hipStreamSynchronize(stream), "hipStreamSynchronize");
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
+    GGA_CHECK_LAUNCH("gga_profile_pillar_scatter");
+    *ms_map_host = (float)(tm / iters);
+    *ms_canvas_host = (float)(tc / iters);
+    return GGA_OK;
+}

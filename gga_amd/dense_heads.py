@@ -1,0 +1,302 @@
+"""``SeparateHead`` and ``CenterHead_GGA`` — same registry names, constructor arguments,
+``forward`` / ``get_targets`` / ``loss`` signatures and loss-dict keys as the reference
+(mmdet3d/models/dense_heads/centerpoint_head.py:18-121,
+mmdet3d/models/dense_heads/centerpoint_head_gga.py:19-723).
+
+What differs is *where* the work runs:
+
+* target generation (head:401-627) is one vectorised host pass per step that packs
+  every object of every frame/task into flat arrays, one H2D copy, and ONE splat kernel
+  for all heat maps — instead of a triple Python loop with >=10 tiny device ops per object;
+* the losses (head:629-723) run as the fused HIP kernels of ``gga_amd.functional``
+  (focal, gather, box losses with analytic backward) — no ``.item()`` host sync.
+"""
+import copy
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import functional as F
+from .cnn import ConvModule, build_conv_layer, kaiming_init
+from .registry import HEADS, build_bbox_coder, build_head, build_loss
+
+# Semantic Ratio Loss priors N(mu, sigma) per task index (head:514-525): Pedestrian, Cyclist, else Car
+SRL_PRIORS = ((1.35, 0.48), (3.60, 0.68), (2.40, 0.28))
+
+
+def multi_apply(func, *args, **kwargs):
+    """mmdet.core.multi_apply: map ``func`` over the zipped args, transpose the results."""
+    from functools import partial
+    pfunc = partial(func, **kwargs) if kwargs else func
+    return tuple(map(list, zip(*map(pfunc, *args))))
+
+
+@HEADS.register_module()
+class SeparateHead(nn.Module):
+    def __init__(self, in_channels, heads, head_conv=64, final_kernel=1, init_bias=-2.19,
+                 conv_cfg=dict(type='Conv2d'), norm_cfg=dict(type='BN2d'), bias='auto', init_cfg=None, **kwargs):
+        assert init_cfg is None, 'To prevent abnormal initialization behavior, init_cfg is not allowed to be set'
+        super().__init__()
+        self.heads = heads
+        self.init_bias = init_bias
+        for head in self.heads:
+            classes, num_conv = self.heads[head]
+            conv_layers = []
+            c_in = in_channels
+            for _ in range(num_conv - 1):
+                conv_layers.append(ConvModule(c_in, head_conv, kernel_size=final_kernel, stride=1,
+                                              padding=final_kernel // 2, bias=bias, conv_cfg=conv_cfg,
+                                              norm_cfg=norm_cfg))
+                c_in = head_conv
+            conv_layers.append(build_conv_layer(conv_cfg, head_conv, classes, kernel_size=final_kernel, stride=1,
+                                                padding=final_kernel // 2, bias=True))
+            self.__setattr__(head, nn.Sequential(*conv_layers))
+        self.init_weights()
+
+    def init_weights(self):
+        for m in self.modules():      # init_cfg = dict(type='Kaiming', layer='Conv2d')
+            if isinstance(m, nn.Conv2d):
+                kaiming_init(m)
+        for head in self.heads:
+            if head == 'heatmap':
+                self.__getattr__(head)[-1].bias.data.fill_(self.init_bias)
+
+    def forward(self, x):
+        return {head: self.__getattr__(head)(x) for head in self.heads}
+
+
+def _to_np(x, dtype=None):
+    if isinstance(x, torch.Tensor):
+        x = x.detach().cpu().numpy()
+    x = np.asarray(x)
+    return x.astype(dtype, copy=False) if dtype is not None else x
+
+
+def gaussian_radius_np(height, width, min_overlap):
+    """mmdet3d/core/utils/gaussian.py:57-86 on f64 arrays."""
+    b1 = height + width
+    c1 = width * height * (1 - min_overlap) / (1 + min_overlap)
+    r1 = (b1 + np.sqrt(b1 ** 2 - 4 * c1)) / 2
+    b2 = 2 * (height + width)
+    c2 = (1 - min_overlap) * width * height
+    r2 = (b2 + np.sqrt(b2 ** 2 - 16 * c2)) / 2
+    a3 = 4 * min_overlap
+    b3 = -2 * min_overlap * (height + width)
+    c3 = (min_overlap - 1) * width * height
+    r3 = (b3 + np.sqrt(b3 ** 2 - 4 * a3 * c3)) / 2
+    return np.minimum(np.minimum(r1, r2), r3)
+
+
+@HEADS.register_module()
+class CenterHead_GGA(nn.Module):
+    def __init__(self, in_channels=[128], tasks=None, train_cfg=None, test_cfg=None, bbox_coder=None,
+                 common_heads=dict(), loss_cls=dict(type='GaussianFocalLoss', reduction='mean'),
+                 loss_bbox=dict(type='L1Loss', reduction='none', loss_weight=0.25),
+                 loss_center=dict(type='MarginL1Loss', reduction='mean'),
+                 separate_head=dict(type='SeparateHead', init_bias=-2.19, final_kernel=3),
+                 share_conv_channel=64, num_heatmap_convs=2, conv_cfg=dict(type='Conv2d'),
+                 norm_cfg=dict(type='BN2d'), bias='auto', norm_bbox=True, init_cfg=None,
+                 pal_backprop=False):
+        assert init_cfg is None, 'To prevent abnormal initialization behavior, init_cfg is not allowed to be set'
+        super().__init__()
+        num_classes = [len(t['class_names']) for t in tasks]
+        self.class_names = [t['class_names'] for t in tasks]
+        self.train_cfg = train_cfg
+        self.test_cfg = test_cfg
+        self.in_channels = in_channels
+        self.num_classes = num_classes
+        self.norm_bbox = norm_bbox
+        self.loss_cls = build_loss(loss_cls)
+        self.loss_bbox = build_loss(loss_bbox)
+        self.bbox_coder = build_bbox_coder(bbox_coder) if bbox_coder is not None else None
+        self.num_anchor_per_locs = [n for n in num_classes]
+        self.fp16_enabled = False
+        # Stock mmdet's _parse_losses only back-propagates keys containing 'loss'; the PAL
+        # terms are stored as task{i}.distance* (head:697-699), i.e. logged, not trained.
+        # pal_backprop=True keeps the key names but lets the detector add them to the total.
+        self.pal_backprop = pal_backprop
+
+        self.shared_conv = ConvModule(in_channels, share_conv_channel, kernel_size=3, padding=1,
+                                      conv_cfg=conv_cfg, norm_cfg=norm_cfg, bias=bias)
+        self.task_heads = nn.ModuleList()
+        separate_head = dict(separate_head)
+        for num_cls in num_classes:
+            heads = copy.deepcopy(common_heads)
+            heads.update(dict(heatmap=(num_cls, num_heatmap_convs)))
+            separate_head.update(in_channels=share_conv_channel, heads=heads, num_cls=num_cls)
+            self.task_heads.append(build_head(separate_head))
+        self.with_velocity = 'vel' in common_heads.keys()
+        assert not self.with_velocity, 'GGA does not support velocity (head:600-601)'
+        assert self.norm_bbox, 'the HIP loss path implements norm_bbox=True (log-dims), as every GGA config uses'
+
+    # ------------------------------------------------------------------ forward
+    def forward_single(self, x):
+        x = self.shared_conv(x)
+        return [task(x) for task in self.task_heads]
+
+    def forward(self, feats):
+        return multi_apply(self.forward_single, feats)
+
+    # ------------------------------------------------------------------ targets
+    def _feature_map_size(self):
+        g = self.train_cfg['grid_size']
+        osf = self.train_cfg['out_size_factor']
+        return int(g[0]) // int(osf), int(g[1]) // int(osf)      # (W, H)
+
+    def draw_srl(self, batch_size):
+        """One ``clamp(N(mu_t, sigma_t), 1e-3)`` per (frame, task) from the default CPU torch
+        generator, frame-major / task-minor — the same calls in the same order as head:514-525,
+        so a seeded run draws the same coefficients as the reference."""
+        out = np.zeros((batch_size, len(self.task_heads)), np.float32)
+        for b in range(batch_size):
+            for t in range(len(self.task_heads)):
+                mu, sd = SRL_PRIORS[t] if t < 2 else SRL_PRIORS[2]
+                r = torch.normal(torch.tensor(mu), torch.tensor(sd))
+                out[b, t] = float(torch.clamp(r, min=1e-3))
+        return out
+
+    def pack_targets(self, gt_labels_3d, GGA_boxes_img, GGA_lidar2img, GGA_init_pseudo_labels, GGA_bdry_masks,
+                     GGA_in_box_points, img_metas, srl=None):
+        """Host half of ``get_targets`` (head:401-627), vectorised per (frame, task): returns
+        numpy arrays only, so it is testable without a device."""
+        tc = self.train_cfg
+        B, T = len(gt_labels_3d), len(self.task_heads)
+        K = int(tc['max_objs']) * int(tc['dense_reg'])
+        osf = tc['out_size_factor']
+        fw, fh = self._feature_map_size()
+        vs = np.asarray(tc['voxel_size'], np.float32).astype(np.float64)     # f32 tensors in the reference
+        pc = np.asarray(tc['point_cloud_range'], np.float32).astype(np.float64)
+        if srl is None:
+            srl = self.draw_srl(B)
+        ncls = self.num_classes
+        map_base = np.concatenate([[0], np.cumsum([B * n for n in ncls])]).astype(np.int64)
+        anno = np.zeros((T, B, K, 5), np.float32)
+        ind = np.zeros((T, B, K), np.int64)
+        mask = np.zeros((T, B, K), np.uint8)
+        l2i = np.empty((T, B, K, 4, 4), np.float32)
+        bmask = np.zeros((T, B, K, 4), np.uint8)
+        objs = []
+        per_task = [[] for _ in range(T)]
+        for b in range(B):
+            labels = _to_np(gt_labels_3d[b])
+            pseudo = _to_np(GGA_init_pseudo_labels[b], np.float64).reshape(-1, 7)
+            boxes = _to_np(GGA_boxes_img[b]).reshape(-1, 4)
+            l2i_b = _to_np(GGA_lidar2img[b], np.float32).reshape(-1, 4, 4)
+            bdry = _to_np(GGA_bdry_masks[b]).astype(bool).reshape(-1, 4)
+            l2i[:, b] = np.asarray(img_metas[b]['lidar2img'], np.float32)[None, None]     # head:508-509
+            flag = 0
+            for t in range(T):
+                # objects of the task, class-major then index order (head:426-434,456-485)
+                hits = [np.flatnonzero(labels == c + flag) for c in range(ncls[t])]
+                sel = np.concatenate(hits)
+                cls_id = np.concatenate([np.full(len(h), c, np.int64) for c, h in enumerate(hits)])
+                flag += ncls[t]
+                sel, cls_id = sel[:K], cls_id[:K]
+                per_task[t].append((b, sel))
+                if len(sel) == 0:
+                    continue
+                pl = pseudo[sel]
+                wg = pl[:, 3] / vs[0] / osf                                             # head:541-546
+                lg = pl[:, 4] / vs[1] / osf
+                ok = (wg > 0) & (lg > 0)
+                with np.errstate(invalid='ignore'):
+                    rad = gaussian_radius_np(lg, wg, tc['gaussian_overlap'])
+                rad = np.where(ok, rad, 0.0)
+                rad = np.maximum(int(tc['min_radius']), rad.astype(np.int64))           # max(min_radius, int(r))
+                cx = ((pl[:, 0] - pc[0]) / vs[0] / osf).astype(np.float32).astype(np.int32)   # f32 then trunc
+                cy = ((pl[:, 1] - pc[1]) / vs[1] / osf).astype(np.float32).astype(np.int32)
+                ok &= (cx >= 0) & (cx < fw) & (cy >= 0) & (cy < fh)                     # head:573-574
+                k = np.flatnonzero(ok)
+                if len(k):
+                    ind[t, b, k] = cy[k].astype(np.int64) * fw + cx[k]
+                    mask[t, b, k] = 1
+                    l2i[t, b, k] = l2i_b[sel[k]]
+                    bmask[t, b, k] = ~bdry[sel[k]]
+                    anno[t, b, k, :4] = boxes[sel[k]].astype(np.float32)
+                    anno[t, b, k, 4] = srl[b, t]
+                    objs.append(np.stack([map_base[t] + b * ncls[t] + cls_id[k], cx[k], cy[k], rad[k]], 1))
+        # in-box points (xy as f32, like `.float()` at head:201), packed task-major so each task
+        # is one contiguous range of objects
+        xy, counts, slots, task_nobj = [], [], [], np.zeros(T, np.int64)
+        for t in range(T):
+            for b, sel in per_task[t]:
+                for kk, j in enumerate(sel):
+                    p = GGA_in_box_points[b][j]
+                    p = p.numpy() if isinstance(p, torch.Tensor) else np.asarray(p)
+                    xy.append(p[:, :2])
+                    counts.append(len(p))
+                    slots.append(b * K + kk)
+                task_nobj[t] += len(sel)
+        objs = np.concatenate(objs, 0).astype(np.int32) if objs else np.zeros((0, 4), np.int32)
+        xy = np.concatenate(xy, 0).astype(np.float32) if xy else np.zeros((0, 2), np.float32)
+        offs = np.zeros(len(counts) + 1, np.int32)
+        offs[1:] = np.cumsum(counts)
+        return dict(B=B, T=T, K=K, fw=fw, fh=fh, map_base=map_base, objs=objs, anno_box=anno, ind=ind, mask=mask,
+                    lidar2img=l2i, bound_mask=bmask, ibp_xy=np.ascontiguousarray(xy), ibp_offsets=offs,
+                    ibp_slot=np.asarray(slots, np.int32), task_nobj=task_nobj, srl=srl)
+
+    def get_targets(self, gt_bboxes_3d, gt_labels_3d, GGA_boxes_img, GGA_lidar2img, GGA_init_pseudo_labels,
+                    GGA_bdry_masks, GGA_in_box_points, img_metas, device=None, srl=None):
+        """Returns per-task lists ``heatmaps, anno_boxes, inds, masks, anno_lidar2imgs, ibp_points,
+        anno_bound_masks`` like head:343-399. ``ibp_points[t]`` is the packed device form
+        ``(xy [n,2] f32, offsets [n_obj+1] i32, slot [n_obj] i32)`` of the in-box points of
+        the task's objects instead of a nested list of f64 tensors. ``gt_bboxes_3d`` is debug-only
+        in the reference (head:406) and unused."""
+        if device is None:
+            device = next(self.parameters()).device
+        pk = self.pack_targets(gt_labels_3d, GGA_boxes_img, GGA_lidar2img, GGA_init_pseudo_labels,
+                               GGA_bdry_masks, GGA_in_box_points, img_metas, srl=srl)
+        dev = torch.device(device)
+        B, T, fh, fw, ncls, map_base = pk['B'], pk['T'], pk['fh'], pk['fw'], self.num_classes, pk['map_base']
+        objs = pk['objs']
+        hm = F.heatmap_splat(objs, int(map_base[-1]), fh, fw, dev,
+                             max_radius=max(16, int(objs[:, 3].max()) if len(objs) else 0))
+        up = {k: torch.from_numpy(pk[k]).to(dev, non_blocking=True)
+              for k in ('anno_box', 'ind', 'mask', 'lidar2img', 'bound_mask', 'ibp_xy', 'ibp_offsets', 'ibp_slot')}
+        heatmaps, ibp_points = [], []
+        obj_base = np.concatenate([[0], np.cumsum(pk['task_nobj'])])
+        for t in range(T):
+            heatmaps.append(hm[int(map_base[t]):int(map_base[t + 1])].view(B, ncls[t], fh, fw))
+            o0, o1 = int(obj_base[t]), int(obj_base[t + 1])
+            # offsets index the shared xy buffer, so a task only needs its slice of offsets/slots
+            ibp_points.append((up['ibp_xy'], up['ibp_offsets'][o0:o1 + 1], up['ibp_slot'][o0:o1]))
+        return (heatmaps, [up['anno_box'][t] for t in range(T)], [up['ind'][t] for t in range(T)],
+                [up['mask'][t] for t in range(T)], [up['lidar2img'][t] for t in range(T)], ibp_points,
+                [up['bound_mask'][t] for t in range(T)])
+
+    # ------------------------------------------------------------------ loss
+    def loss(self, gt_bboxes_3d, gt_labels_3d, preds_dicts, GGA_boxes_img, GGA_lidar2img, GGA_init_pseudo_labels,
+             GGA_bdry_masks, GGA_in_box_points, img_metas, **kwargs):
+        device = preds_dicts[0][0]['heatmap'].device
+        heatmaps, anno_boxes, inds, masks, anno_lidar2imgs, ibp_points, anno_bound_masks = self.get_targets(
+            gt_bboxes_3d, gt_labels_3d, GGA_boxes_img, GGA_lidar2img, GGA_init_pseudo_labels, GGA_bdry_masks,
+            GGA_in_box_points, img_metas, device=device, srl=kwargs.get('srl'))
+        return self.loss_from_targets(preds_dicts, heatmaps, anno_boxes, inds, masks, anno_lidar2imgs, ibp_points,
+                                      anno_bound_masks)
+
+    def loss_from_targets(self, preds_dicts, heatmaps, anno_boxes, inds, masks, anno_lidar2imgs, ibp_points,
+                          anno_bound_masks):
+        loss_dict = dict()
+        tc = self.train_cfg
+        for task_id, preds_dict in enumerate(preds_dicts):
+            pd = preds_dict[0]
+            B, K = inds[task_id].shape
+            # heat-map focal loss on the raw logits (clip_sigmoid fused, num_pos stays on device)
+            loss_heatmap, _ = F.gaussian_focal_loss(pd['heatmap'], heatmaps[task_id],
+                                                    alpha=self.loss_cls.alpha, gamma=self.loss_cls.gamma,
+                                                    scale=self.loss_cls.loss_weight * 5.0)
+            pred = F.gather_pred(pd['reg'], pd['height'], pd['dim'], pd['rot'], inds[task_id], masks[task_id])
+            prm = F.loss_params(B, K, tc, l1_loss_weight=self.loss_bbox.loss_weight)
+            xy, offs, slot = ibp_points[task_id]
+            losses, _ = F.box_losses(pred, inds[task_id], masks[task_id], anno_boxes[task_id],
+                                     anno_lidar2imgs[task_id], anno_bound_masks[task_id],
+                                     xy, offs, slot if slot.numel() else None, prm)
+            l_bpl, l_srl, l_pmin, l_px, l_py = losses.unbind(0)
+            loss_dict[f'task{task_id}.distancex'] = l_px
+            loss_dict[f'task{task_id}.distancey'] = l_py
+            loss_dict[f'task{task_id}.distancemin'] = l_pmin
+            loss_dict[f'task{task_id}.loss_heatmap'] = loss_heatmap
+            loss_dict[f'task{task_id}.loss_bbox'] = l_bpl
+            loss_dict[f'task{task_id}.loss_ratio'] = l_srl
+        return loss_dict

@@ -1,0 +1,35 @@
+"""Middle encoders: ``PointPillarsScatter`` (HIP scatter kernel; reference
+mmdet3d/models/middle_encoders/pillar_scatter.py:9-102). ``SparseEncoder`` lives in
+``sparse_encoder.py``."""
+from torch import nn
+
+from . import functional as F
+from .registry import MIDDLE_ENCODERS
+
+
+@MIDDLE_ENCODERS.register_module()
+class PointPillarsScatter(nn.Module):
+    """``forward(voxel_features [M,C], coors [M,4] (b,z,y,x), batch_size) -> [B,C,ny,nx]``.
+
+    ``channels_last=True`` (not in the reference) returns the same logical NCHW tensor in
+    NHWC memory, so every pillar is one contiguous row for the scatter and MIOpen gets an
+    NHWC input; values are identical, only strides differ.
+    """
+
+    def __init__(self, in_channels, output_shape, channels_last=False):
+        super().__init__()
+        self.output_shape = output_shape
+        self.ny = output_shape[0]
+        self.nx = output_shape[1]
+        self.in_channels = in_channels
+        self.channels_last = channels_last
+        self.fp16_enabled = False
+
+    def forward(self, voxel_features, coors, batch_size=None, num_valid=None):
+        if batch_size is None:
+            # forward_single of the reference: one sample, batch index ignored
+            coors = coors.clone()
+            coors[:, 0] = 0
+            batch_size = 1
+        return F.pillar_scatter(voxel_features, coors, int(batch_size), self.ny, self.nx,
+                                channels_last=self.channels_last, num_valid=num_valid)

@@ -1,0 +1,134 @@
+"""Train-step runner: optimizer, gradient clipping, cyclic LR / momentum schedule and the
+data-parallel wrap — the pieces of the reference's train API on the hot path
+(mmdet3d/apis/train.py:180-321 ``train_detector``; mmdet3d/utils/util_distribution.py:38-65
+``build_ddp``; config keys configs/gga/gga_kitti_config.py:233-260). mmcv's
+``EpochBasedRunner`` / ``OptimizerHook`` / ``CyclicLrUpdaterHook`` /
+``CyclicMomentumUpdaterHook`` are third-party (not in the tree): their published behaviour
+is restated here (parity unpinned).
+
+One process per GPU; gradients are all-reduced by ``torch.nn.parallel.DistributedDataParallel``
+over RCCL (backend name ``nccl`` on ROCm) with ``broadcast_buffers=False`` like the reference.
+"""
+import math
+import os
+import time
+
+import torch
+import torch.distributed as dist
+
+
+def annealing_cos(start, end, factor, weight=1.0):
+    cos_out = math.cos(math.pi * factor) + 1
+    return end + 0.5 * weight * (start - end) * cos_out
+
+
+class CyclicSchedule:
+    """mmcv Cyclic{Lr,Momentum}UpdaterHook, by iteration: one up phase of ``step_ratio_up`` of
+    the cycle from ratio 1 to ``target_ratio[0]``, then down to ``target_ratio[1]``, cosine."""
+
+    def __init__(self, base, max_iters, target_ratio=(10, 1e-4), cyclic_times=1, step_ratio_up=0.4):
+        self.base = base
+        per_phase = max(1, max_iters // cyclic_times)
+        up = int(step_ratio_up * per_phase)
+        self.per_phase = per_phase
+        self.phases = [(0, up, 1.0, target_ratio[0]), (up, per_phase, target_ratio[0], target_ratio[1])]
+
+    def __call__(self, it):
+        cur = it % self.per_phase
+        for start, end, r0, r1 in self.phases:
+            if start <= cur < end:
+                return annealing_cos(self.base * r0, self.base * r1, (cur - start) / (end - start))
+        return self.base * self.phases[-1][3]
+
+
+def build_optimizer(model, cfg):
+    cfg = dict(cfg)
+    typ = cfg.pop('type')
+    if typ != 'AdamW':
+        raise KeyError(f'optimizer {typ} is not on the GGA path (configs/gga use AdamW)')
+    params = [p for p in model.parameters() if p.requires_grad]
+    fused = all(p.is_cuda for p in params)
+    return torch.optim.AdamW(params, fused=fused, **cfg)
+
+
+def init_dist():
+    """torchrun / torch.distributed.run environment -> (rank, world_size, local_rank)."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1 and not dist.is_initialized():
+        backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        if backend == 'nccl':
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend)
+    return rank, world, local_rank
+
+
+def build_ddp(model, device, find_unused_parameters=False):
+    """MMDistributedDataParallel(device_ids=[LOCAL_RANK], broadcast_buffers=False,
+    find_unused_parameters=...) (apis/train.py:222-231)."""
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    if device.type == 'cuda':
+        return DDP(model, device_ids=[device.index], broadcast_buffers=False,
+                   find_unused_parameters=find_unused_parameters)
+    return DDP(model, broadcast_buffers=False, find_unused_parameters=find_unused_parameters)
+
+
+class Runner:
+    """Iteration loop of the train step: schedule -> train_step -> backward (DDP all-reduce
+    overlaps it) -> clip_grad_norm_ -> AdamW. Nothing in it reads a device value back."""
+
+    def __init__(self, model, cfg, max_iters, distributed=False, device=None):
+        self.raw_model = model
+        self.device = device or next(model.parameters()).device
+        self.model = build_ddp(model, self.device, cfg.get('find_unused_parameters', False)) if distributed else model
+        self.optimizer = build_optimizer(model, cfg.optimizer)
+        gc = (cfg.get('optimizer_config') or {}).get('grad_clip')
+        self.grad_clip = dict(gc) if gc else None
+        base_lr = cfg.optimizer['lr']
+        base_m = cfg.optimizer['betas'][0]
+        lrc, mc = dict(cfg.get('lr_config') or {}), dict(cfg.get('momentum_config') or {})
+        self.lr_sched = self.mom_sched = None
+        if lrc.get('policy') == 'cyclic':
+            self.lr_sched = CyclicSchedule(base_lr, max_iters, lrc.get('target_ratio', (10, 1e-4)),
+                                           lrc.get('cyclic_times', 1), lrc.get('step_ratio_up', 0.4))
+        if mc.get('policy') == 'cyclic':
+            self.mom_sched = CyclicSchedule(base_m, max_iters, mc.get('target_ratio', (0.85 / 0.95, 1)),
+                                            mc.get('cyclic_times', 1), mc.get('step_ratio_up', 0.4))
+        self.iter = 0
+        self.log_interval = (cfg.get('log_config') or {}).get('interval', 50)
+
+    def _call_train_step(self, data):
+        if self.model is self.raw_model:
+            return self.raw_model.train_step(data)
+        losses = self.model(**data)                    # DDP forward
+        loss, log_vars = self.raw_model._parse_losses(losses)
+        return dict(loss=loss, log_vars=log_vars, num_samples=len(data['img_metas']))
+
+    def step(self, data):
+        for g in self.optimizer.param_groups:
+            if self.lr_sched is not None:
+                g['lr'] = self.lr_sched(self.iter)
+            if self.mom_sched is not None:
+                g['betas'] = (self.mom_sched(self.iter), g['betas'][1])
+        out = self._call_train_step(data)
+        self.optimizer.zero_grad(set_to_none=True)
+        out['loss'].backward()
+        if self.grad_clip:
+            torch.nn.utils.clip_grad_norm_([p for p in self.raw_model.parameters() if p.grad is not None],
+                                           **self.grad_clip)
+        self.optimizer.step()
+        self.iter += 1
+        return out
+
+    def run(self, batches, n_iters, logger=None):
+        self.raw_model.train()
+        t0 = time.time()
+        out = None
+        for i in range(n_iters):
+            out = self.step(batches[i % len(batches)])
+            if logger and (i + 1) % self.log_interval == 0:
+                vals = {k: float(v) for k, v in out['log_vars'].items()}      # the only sync, every N iters
+                logger(f'iter {i + 1}/{n_iters} lr {self.optimizer.param_groups[0]["lr"]:.3e} '
+                       f'time {(time.time() - t0) / (i + 1):.3f}s  ' + ' '.join(f'{k}={v:.4f}' for k, v in vals.items()))
+        return out

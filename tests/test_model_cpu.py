@@ -1,0 +1,157 @@
+"""Host-side logic of the drop-in boundary, on CPU: registry / config surface, module and
+state_dict naming, target packing against the oracle + golden vectors, schedules."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import gga_amd
+from conftest import REPO, TRAIN_CFG, load_head_case
+from gga_amd import Config, build_model, synthetic
+from gga_amd.registry import MODELS, Registry, build_from_cfg
+from gga_amd.train import CyclicSchedule
+from oracle import oracle as O
+
+PP_CFG = os.path.join(REPO, 'configs', 'gga', 'gga_kitti_pointpillars_config.py')
+
+
+def test_registry_semantics():
+    for name in ('GGA', 'MVXTwoStageDetector_GGA', 'CenterHead_GGA', 'SeparateHead', 'HardSimpleVFE',
+                 'PillarFeatureNet', 'PointPillarsScatter', 'SECOND', 'SECONDFPN', 'GaussianFocalLoss', 'L1Loss'):
+        assert MODELS.get(name) is not None, name
+    r = Registry('t')
+
+    @r.register_module()
+    class A:
+        def __init__(self, x, y=2):
+            self.x, self.y = x, y
+    a = r.build(dict(type='A', x=1), default_args=dict(y=5))
+    assert (a.x, a.y) == (1, 5)
+    with pytest.raises(KeyError, match='is not in the t registry'):
+        r.build(dict(type='B'))
+    with pytest.raises(KeyError, match='already registered'):
+        r.register_module(module=A)
+    with pytest.raises(KeyError, match='must contain the key "type"'):
+        build_from_cfg(dict(x=1), r)
+
+
+def test_config_base_and_delete():
+    cfg = Config.fromfile(PP_CFG)
+    assert cfg.model.type == 'GGA'
+    assert cfg.model.pts_voxel_encoder.type == 'PillarFeatureNet' and 'num_features' not in cfg.model.pts_voxel_encoder
+    assert cfg.model.pts_bbox_head.in_channels == 384 and cfg.model.pts_bbox_head.share_conv_channel == 64
+    assert cfg.model.train_cfg.pts.grid_size == [432, 496, 1] and cfg.model.train_cfg.pts.max_objs == 500
+    assert cfg.optimizer.type == 'AdamW' and cfg.optimizer_config.grad_clip.max_norm == 35
+    cfg.merge_from_dict({'optimizer.lr': 0.1})
+    assert cfg.optimizer.lr == 0.1 and cfg.optimizer.weight_decay == 0.01
+
+
+@pytest.fixture(scope='module')
+def pp_model():
+    torch.manual_seed(0)
+    return build_model(Config.fromfile(PP_CFG).model)
+
+
+def test_pp_model_structure(pp_model):
+    sd = pp_model.state_dict()
+    for k in ('pts_voxel_encoder.pfn_layers.0.linear.weight', 'pts_backbone.blocks.2.15.weight',
+              'pts_neck.deblocks.2.0.weight', 'pts_bbox_head.shared_conv.conv.weight',
+              'pts_bbox_head.shared_conv.bn.running_var', 'pts_bbox_head.task_heads.2.heatmap.1.bias',
+              'pts_bbox_head.task_heads.0.rot.0.conv.weight'):
+        assert k in sd, k
+    assert sd['pts_voxel_encoder.pfn_layers.0.linear.weight'].shape == (64, 10)
+    assert sd['pts_neck.deblocks.2.0.weight'].shape == (256, 128, 4, 4)
+    assert torch.all(sd['pts_bbox_head.task_heads.1.heatmap.1.bias'] == -2.19)
+    assert pp_model.pts_bbox_head.train_cfg['out_size_factor'] == 2
+    assert pp_model.pts_voxel_layer.max_voxels == (16000, 40000)
+
+
+@pytest.mark.skipif(not os.path.isdir('/root/reference'), reason='reference tree only exists in the build container')
+def test_reference_config_model_section_loads_unchanged():
+    cfg = Config.fromfile('/root/reference/configs/gga/gga_kitti_config.py')
+    mine = Config.fromfile(os.path.join(REPO, 'configs', 'gga', 'gga_kitti_config.py'))
+    def norm(x):
+        if isinstance(x, dict):
+            return {k: norm(v) for k, v in x.items()}
+        if isinstance(x, (list, tuple)):
+            return [norm(v) for v in x]
+        return x
+    assert norm(cfg.model) == norm(mine.model)
+    for k in ('optimizer', 'optimizer_config', 'lr_config', 'momentum_config', 'runner'):
+        assert norm(cfg[k]) == norm(mine[k]), k
+    # every non-sparse stage of the reference's own file builds through the registry
+    m = dict(cfg.model)
+    head = dict(m['pts_bbox_head'], train_cfg=cfg.model.train_cfg.pts, test_cfg=cfg.model.test_cfg.pts)
+    assert type(gga_amd.registry.build_head(head)).__name__ == 'CenterHead_GGA'
+    assert type(gga_amd.registry.build_backbone(m['pts_backbone'])).__name__ == 'SECOND'
+    assert type(gga_amd.registry.build_neck(m['pts_neck'])).__name__ == 'SECONDFPN'
+    assert type(gga_amd.registry.build_voxel_encoder(m['pts_voxel_encoder'])).__name__ == 'HardSimpleVFE'
+
+
+@pytest.mark.parametrize('c', ['second', 'pp'])
+def test_pack_targets_matches_oracle_and_golden(golden, pp_model, c):
+    d = golden('head')
+    case = load_head_case(d, c)
+    head = pp_model.pts_bbox_head
+    saved = head.train_cfg
+    head.train_cfg = TRAIN_CFG[c]
+    try:
+        torch.manual_seed(1234)
+        pk = head.pack_targets(case['labels'], case['boxes_img'], case['lidar2img'], case['pseudo'], case['bdry'],
+                               case['ibp'], [dict(lidar2img=m) for m in case['meta_l2i']])
+    finally:
+        head.train_cfg = saved
+    torch.manual_seed(1234)
+    srl = O.draw_srl(case['B'])
+    assert np.array_equal(pk['srl'], srl)          # same CPU-generator draws, same order (head:514-525)
+    tg = O.get_targets(case['labels'], case['boxes_img'], case['lidar2img'], case['pseudo'], case['bdry'],
+                       case['ibp'], case['meta_l2i'], TRAIN_CFG[c], srl)
+    B, K = case['B'], 500
+    for t in range(3):
+        assert np.array_equal(pk['ind'][t], d[f'{c}.tgt.{t}.ind'])
+        assert np.array_equal(pk['mask'][t], d[f'{c}.tgt.{t}.mask'])
+        assert np.array_equal(pk['bound_mask'][t], d[f'{c}.tgt.{t}.bound_mask'])
+        assert np.array_equal(pk['lidar2img'][t], d[f'{c}.tgt.{t}.lidar2img'])
+        np.testing.assert_array_equal(pk['anno_box'][t], d[f'{c}.tgt.{t}.anno_box'])
+    # the splat list reproduces the reference heat maps when drawn by the oracle
+    hm = np.zeros((3 * B, pk['fh'], pk['fw']), np.float32)
+    for m, cx, cy, r in pk['objs']:
+        O.draw_gaussian(hm[m], cx, cy, r)
+    for t in range(3):
+        np.testing.assert_array_equal(hm[t * B:(t + 1) * B, None], tg['heatmap'][t])
+    # packed in-box points: task-major, slot = b*K + k, xy in f32
+    o = 0
+    for t in range(3):
+        for b in range(B):
+            for k, p in enumerate(tg['ibp'][t][b]):
+                s, e = pk['ibp_offsets'][o], pk['ibp_offsets'][o + 1]
+                assert pk['ibp_slot'][o] == b * K + k
+                np.testing.assert_array_equal(pk['ibp_xy'][s:e], np.asarray(p)[:, :2].astype(np.float32))
+                o += 1
+        assert o == pk['task_nobj'][:t + 1].sum()
+
+
+def test_cyclic_schedule():
+    # lr: x10 up over 40 % of the run, then down to 1e-4 x base (gga_kitti_config.py:237-247)
+    s = CyclicSchedule(1.5e-3, 1000, (10, 1e-4), 1, 0.4)
+    assert s(0) == pytest.approx(1.5e-3)
+    assert s(400) == pytest.approx(1.5e-2)
+    assert s(200) == pytest.approx((1.5e-3 + 1.5e-2) / 2)
+    assert 1.5e-7 < s(999) < 3e-7              # one step before the 1e-4 floor
+    assert all(s(i) <= s(i + 1) for i in range(0, 399)) and all(s(i) >= s(i + 1) for i in range(400, 998))
+    m = CyclicSchedule(0.95, 1000, (0.85 / 0.95, 1), 1, 0.4)
+    assert m(400) == pytest.approx(0.85) and m(0) == pytest.approx(0.95)
+
+
+def test_synthetic_frame_contract():
+    f = synthetic.make_frame(3)
+    g = synthetic.make_frame(3)
+    assert torch.equal(f['points'], g['points'])                     # seeded
+    assert f['points'].shape == (20000, 4) and f['points'].dtype == torch.float32
+    n = len(f['gt_labels_3d'])
+    assert 4 <= n <= 20 and f['GGA_lidar2img'].shape == (n, 4, 4) and f['GGA_init_pseudo_labels'].dtype == torch.float64
+    assert f['GGA_bdry_masks'].dtype == torch.bool and len(f['GGA_in_box_points']) == n
+    x, y, z = f['points'][:, 0], f['points'][:, 1], f['points'][:, 2]
+    outside = (x < 0) | (x >= 70.4) | (y < -40) | (y >= 40) | (z < -3) | (z >= 1)
+    assert 0.03 < outside.float().mean() < 0.07                      # the rejection branch is exercised

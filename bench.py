@@ -1,0 +1,166 @@
+#!/usr/bin/env python
+"""Headline benchmark: GGA train step on synthetic KITTI-shaped frames (BASELINE.json).
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" = one full train step of BASELINE config #2 on one batch: batched hard voxelize
+(PointPillars grid) -> PillarFeatureNet -> pillar scatter -> SECOND -> SECONDFPN ->
+CenterHead_GGA -> GGA losses -> backward -> (DDP all-reduce) -> grad clip -> AdamW, bs=16
+frames per GPU, fp32. Point clouds are resident in HBM before the timed region; weak scaling
+(every rank steps its own 16 frames, gradients all-reduced over RCCL).
+
+Rank 0 prints ONE JSON line; `roofline` is the pillar-scatter canvas kernel timed with HIP
+events inside this process, `cpu_baseline` is the oracle's CPU restatement of the same step
+on a bounded sample (N=1 only).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (guides/MI355X_MICROARCH.md); ~6300 achievable
+
+
+def scatter_roofline(model, batch_points, device, iters=20):
+    """Time the scatter kernels (HIP events on the launch stream) on the pillars of a real
+    bench batch: [SM,64] + coors -> [B,64,496,432]."""
+    from gga_amd import _lib
+    from gga_amd import functional as F
+    vl, me = model.pts_voxel_layer, model.pts_middle_encoder
+    B = len(batch_points)
+    with torch.no_grad():
+        _, _, coors, _ = vl.forward_batch(batch_points)
+    m, ch = coors.shape[0], me.in_channels
+    feats = torch.randn(m, ch, device=device)
+    layout = F.LAYOUT_NHWC if me.channels_last else F.LAYOUT_NCHW
+    canvas = torch.empty(B * ch * me.ny * me.nx, device=device)
+    cmap = F._cell_map(device, B, me.ny, me.nx)
+    L = _lib.lib()
+    ms_map, ms_canvas = C.c_float(0), C.c_float(0)
+    args = (F._p(feats), F._p(coors), m, B, ch, me.ny, me.nx, layout, F._p(cmap), F._p(canvas))
+    _lib.check(L.gga_profile_pillar_scatter(*args, 3, C.byref(ms_map), C.byref(ms_canvas), F._stream()), 'profile')
+    _lib.check(L.gga_profile_pillar_scatter(*args, iters, C.byref(ms_map), C.byref(ms_canvas), F._stream()), 'profile')
+    algo = m * ch * 4 + m * 16 + B * ch * me.ny * me.nx * 4
+    gbs = algo / (ms_canvas.value * 1e-3) / 1e9
+    return {'bound': 'hbm', 'kernel': 'scatter_canvas_nhwc_kernel' if me.channels_last else 'scatter_canvas_nchw_kernel',
+            'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(gbs / HBM_PEAK_GBS, 4),
+            'traffic': None, 'algorithmic_bytes': int(algo), 'kernel_ms': round(ms_canvas.value, 4),
+            'map_kernel_ms': round(ms_map.value, 4), 'pillars': int(m)}
+
+
+def cpu_baseline(cfg, frames=2):
+    """The oracle's CPU restatement of the same train step (C voxelizer + torch fp32 on the
+    host cores), one timed step on `frames` frames after a 1-frame warm-up."""
+    from gga_amd import build_model, synthetic
+    from oracle import torch_ref as R
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    model = build_model(cfg.model)
+    model.train()
+    warm = synthetic.make_batch(1, start=900, pc_range=synthetic.RANGE_PP)
+    R.reference_train_step(model, warm)
+    model.zero_grad()
+    batch = synthetic.make_batch(frames, start=901, pc_range=synthetic.RANGE_PP)
+    t0 = time.perf_counter()
+    R.reference_train_step(model, batch)
+    dt = time.perf_counter() - t0
+    return {'value': round(frames / dt, 4), 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
+            'sample': f'1 train step (fwd+bwd, no optimizer) on {frames} synthetic frames, {dt:.1f} s'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=16, help='frames per GPU')
+    ap.add_argument('--config', default=os.path.join(REPO, 'configs', 'gga', 'gga_kitti_pointpillars_config.py'))
+    ap.add_argument('--channels-last', action='store_true')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    args = ap.parse_args()
+
+    import gga_amd  # noqa: F401
+    from gga_amd import Config, build_model, synthetic
+    from gga_amd.train import Runner, init_dist
+
+    rank, world, local_rank = init_dist()
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
+    assert torch.cuda.is_available(), 'bench.py needs an MI355X (the product has no CPU path)'
+    device = torch.device('cuda', local_rank)
+    torch.cuda.set_device(device)
+
+    cfg = Config.fromfile(args.config)
+    if args.channels_last:
+        cfg.model.pts_middle_encoder['channels_last'] = True
+    torch.manual_seed(0)
+    model = build_model(cfg.model).to(device)
+    if args.channels_last:
+        model = model.to(memory_format=torch.channels_last)
+    model.train()
+    runner = Runner(model, cfg, max_iters=max(1000, args.steps + args.warmup), distributed=world > 1, device=device)
+
+    pc_range = tuple(cfg.model.pts_voxel_layer.point_cloud_range)
+    batches = []
+    for i in range(2):      # two distinct batches per rank, point clouds resident in HBM
+        b = synthetic.make_batch(args.batch, start=i * args.batch, rank=rank, pc_range=pc_range)
+        b['points'] = [p.to(device) for p in b['points']]
+        batches.append({k: b[k] for k in synthetic.BATCH_KEYS + ('img_metas',)})
+    torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        runner.step(batches[i % 2])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = runner.step(batches[i % 2])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    loss = float(out['loss'])
+    assert loss == loss, 'loss is NaN'
+
+    if rank == 0:
+        res = {
+            'metric': 'kitti_frames_per_sec_gga_train_step', 'value': round(args.batch * world * args.steps / dt, 3),
+            'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'BASELINE config #2: PointPillars voxelize+PFN+scatter + SECOND/FPN + '
+                                   'CenterHead_GGA losses, full train step (fwd+bwd+clip+AdamW)',
+                       'frames_per_gpu': args.batch, 'global_batch': args.batch * world, 'points_per_frame': 20000,
+                       'parallelism': f'dp{world}', 'memory_format': 'channels_last' if args.channels_last else 'nchw',
+                       'final_loss': round(loss, 4)},
+        }
+        if not args.no_roofline:
+            res['roofline'] = scatter_roofline(model, batches[0]['points'], device)
+        if world == 1 and not args.no_cpu_baseline:
+            res['cpu_baseline'] = cpu_baseline(cfg)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -58,18 +58,20 @@ def scatter_roofline(model, batch_points, device, iters=20):
             'map_kernel_ms': round(ms_map.value, 4), 'pillars': int(m)}
 
 
-def cpu_baseline(cfg, frames=2):
+def cpu_baseline(cfg, frames=1):
     """The oracle's CPU restatement of the same train step (C voxelizer + torch fp32 on the
     host cores), one timed step on `frames` frames after a 1-frame warm-up."""
     from gga_amd import build_model, synthetic
     from oracle import torch_ref as R
-    cores = os.cpu_count() or 1
+    # torch's CPU convolutions stop scaling (and oversubscribe badly) far below the 256 hardware
+    # threads of the GPU host: use at most 32 threads and report that number as `cores`
+    cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     model = build_model(cfg.model)
     model.train()
-    warm = synthetic.make_batch(1, start=900, pc_range=synthetic.RANGE_PP)
-    R.reference_train_step(model, warm)
+    warm = synthetic.make_batch(1, start=900, n_points=2000, pc_range=synthetic.RANGE_PP, n_obj_range=(2, 3))
+    R.reference_train_step(model, warm)      # first-touch / thread-pool warm-up
     model.zero_grad()
     batch = synthetic.make_batch(frames, start=901, pc_range=synthetic.RANGE_PP)
     t0 = time.perf_counter()

@@ -16,6 +16,8 @@
 // HBM traffic = canvas bytes (write) + feature bytes (read, each row fetched once and then
 // served from L1/L2 for the channel loop) + map bytes: the algorithmic minimum of
 // SURVEY.md §8(d) plus the 4 B/cell map read+reset.
+#include <stdlib.h>
+
 #include "gga_common.h"
 
 __global__ __launch_bounds__(256) void scatter_map_kernel(const int32_t* __restrict__ coors, int64_t m,
@@ -72,20 +74,195 @@ __global__ __launch_bounds__(256) void scatter_canvas_nchw_kernel(const float* _
     }
 }
 
+
+// ---- variants (selected by launch_canvas_nchw) -----------------------------------------
+// ceiling probe: the store pattern alone (no map, no gathers)
+__global__ __launch_bounds__(256) void scatter_canvas_zero_probe_kernel(int channels, int64_t cells,
+                                                                       int64_t cells4_total,
+                                                                       float* __restrict__ canvas) {
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= cells4_total) return;
+    const int64_t cells4 = cells >> 2;
+    const int64_t b = q / cells4;
+    const int64_t cq = q - b * cells4;
+    float4* out = reinterpret_cast<float4*>(canvas + (b * channels) * cells) + cq;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+    for (int c = 0; c < channels; ++c) out[(int64_t)c * cells4] = z;
+}
+
+// V1: like V0 but the all-empty fast path is taken only when the WHOLE wave is empty, so a
+// wave never issues two half-masked store streams.
+template <int UNROLL>
+__global__ __launch_bounds__(256) void scatter_canvas_nchw_v1_kernel(const float* __restrict__ feats,
+                                                                    int32_t* __restrict__ cell_map, int channels,
+                                                                    int64_t cells, int64_t cells4_total,
+                                                                    float* __restrict__ canvas) {
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= cells4_total) return;
+    const int64_t cells4 = cells >> 2;
+    const int64_t b = q / cells4;
+    const int64_t cq = q - b * cells4;
+    int4* mp = reinterpret_cast<int4*>(cell_map) + q;
+    const int4 idx = *mp;
+    const bool any = (idx.x & idx.y & idx.z & idx.w) != -1;
+    if (any) *mp = make_int4(-1, -1, -1, -1);
+    float4* out = reinterpret_cast<float4*>(canvas + (b * channels) * cells) + cq;
+    if (__ballot(any) == 0ull) {
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+        for (int c = 0; c < channels; ++c) out[(int64_t)c * cells4] = z;
+        return;
+    }
+    const float* f0 = feats + (int64_t)(idx.x < 0 ? 0 : idx.x) * channels;
+    const float* f1 = feats + (int64_t)(idx.y < 0 ? 0 : idx.y) * channels;
+    const float* f2 = feats + (int64_t)(idx.z < 0 ? 0 : idx.z) * channels;
+    const float* f3 = feats + (int64_t)(idx.w < 0 ? 0 : idx.w) * channels;
+    for (int c = 0; c < channels; c += UNROLL) {
+        float4 v[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx.x >= 0) v[u].x = f0[c + u];
+            if (idx.y >= 0) v[u].y = f1[c + u];
+            if (idx.z >= 0) v[u].z = f2[c + u];
+            if (idx.w >= 0) v[u].w = f3[c + u];
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) out[(int64_t)(c + u) * cells4] = v[u];
+    }
+}
+
+// V2: LDS-staged. A 256-thread workgroup owns 1024 consecutive cells of one frame.
+//   (1) one 16 B map load per thread (+ reset), occupied cells get a compact tile slot;
+//   (2) the pillar rows of the tile are fetched with fully coalesced 256 B wave loads
+//       (lane = channel) into an LDS tile [slot][C+1];
+//   (3) channel loop: every lane assembles its float4 from LDS (only occupied lanes read)
+//       and issues one 1 KB-per-wave contiguous store per channel.
+// Tiles with more than SC_CAP occupied cells (dense scenes) take the direct-gather path.
+#define SC_CAP 128
+typedef float v4f __attribute__((ext_vector_type(4)));
+template <bool NT>
+__device__ __forceinline__ void store4(float4* p, const float4& v) {
+    if (NT) __builtin_nontemporal_store(v4f{v.x, v.y, v.z, v.w}, reinterpret_cast<v4f*>(p));
+    else *p = v;
+}
+
+template <int C, bool NT>
+__global__ __launch_bounds__(256) void scatter_canvas_nchw_v2_kernel(const float* __restrict__ feats,
+                                                                    int32_t* __restrict__ cell_map, int64_t cells,
+                                                                    int64_t cells4_total,
+                                                                    float* __restrict__ canvas) {
+    __shared__ float tile[SC_CAP * (C + 1)];
+    __shared__ int rows[SC_CAP];
+    __shared__ int n_occ;
+    const int tid = threadIdx.x;
+    const int64_t q = (int64_t)blockIdx.x * 256 + tid;
+    const bool live = q < cells4_total;
+    if (tid == 0) n_occ = 0;
+    __syncthreads();
+    int4 idx = make_int4(-1, -1, -1, -1);
+    int4* mp = reinterpret_cast<int4*>(cell_map) + q;
+    if (live) idx = *mp;
+    const bool any = (idx.x & idx.y & idx.z & idx.w) != -1;
+    if (any) *mp = make_int4(-1, -1, -1, -1);
+    int4 slot = make_int4(-1, -1, -1, -1);
+    if (any) {
+        const int cnt = (idx.x >= 0) + (idx.y >= 0) + (idx.z >= 0) + (idx.w >= 0);
+        int s0 = atomicAdd(&n_occ, cnt);
+        if (idx.x >= 0) { slot.x = s0; if (s0 < SC_CAP) rows[s0] = idx.x; ++s0; }
+        if (idx.y >= 0) { slot.y = s0; if (s0 < SC_CAP) rows[s0] = idx.y; ++s0; }
+        if (idx.z >= 0) { slot.z = s0; if (s0 < SC_CAP) rows[s0] = idx.z; ++s0; }
+        if (idx.w >= 0) { slot.w = s0; if (s0 < SC_CAP) rows[s0] = idx.w; ++s0; }
+    }
+    __syncthreads();
+    const int nocc = n_occ;
+    const int64_t cells4 = cells >> 2;
+    const int64_t b = live ? q / cells4 : 0;
+    const int64_t cq = q - b * cells4;
+    float4* out = reinterpret_cast<float4*>(canvas + (b * C) * cells) + cq;
+    if (nocc == 0) {
+        if (!live) return;
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+        for (int c = 0; c < C; ++c) store4<NT>(out + (int64_t)c * cells4, z);
+        return;
+    }
+    if (nocc <= SC_CAP) {
+        // (2) coalesced row fetch: 4 waves, each wave takes rows e = wave, wave+4, ...; lane = channel
+        const int lane = tid & 63, wave = tid >> 6;
+        for (int e = wave; e < nocc; e += 4) {
+            const float* src = feats + (int64_t)rows[e] * C;
+#pragma unroll
+            for (int c0 = 0; c0 < C; c0 += 64)
+                if (c0 + lane < C) tile[e * (C + 1) + c0 + lane] = src[c0 + lane];
+        }
+        __syncthreads();
+        if (!live) return;
+        const float* t0 = tile + (slot.x < 0 ? 0 : slot.x) * (C + 1);
+        const float* t1 = tile + (slot.y < 0 ? 0 : slot.y) * (C + 1);
+        const float* t2 = tile + (slot.z < 0 ? 0 : slot.z) * (C + 1);
+        const float* t3 = tile + (slot.w < 0 ? 0 : slot.w) * (C + 1);
+#pragma unroll 8
+        for (int c = 0; c < C; ++c) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (slot.x >= 0) v.x = t0[c];
+            if (slot.y >= 0) v.y = t1[c];
+            if (slot.z >= 0) v.z = t2[c];
+            if (slot.w >= 0) v.w = t3[c];
+            store4<NT>(out + (int64_t)c * cells4, v);
+        }
+        return;
+    }
+    if (!live) return;
+    // dense tile: direct gather from global (rows come from L2 after first touch)
+    const float* f0 = feats + (int64_t)(idx.x < 0 ? 0 : idx.x) * C;
+    const float* f1 = feats + (int64_t)(idx.y < 0 ? 0 : idx.y) * C;
+    const float* f2 = feats + (int64_t)(idx.z < 0 ? 0 : idx.z) * C;
+    const float* f3 = feats + (int64_t)(idx.w < 0 ? 0 : idx.w) * C;
+#pragma unroll 4
+    for (int c = 0; c < C; ++c) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (idx.x >= 0) v.x = f0[c];
+        if (idx.y >= 0) v.y = f1[c];
+        if (idx.z >= 0) v.z = f2[c];
+        if (idx.w >= 0) v.w = f3[c];
+        store4<NT>(out + (int64_t)c * cells4, v);
+    }
+}
+
 // NHWC canvas (channels-last memory): one thread = 4 channels of one cell; the
 // channels/4 lanes of a cell read the same map word (broadcast) and write one
 // contiguous row.
 __global__ __launch_bounds__(256) void scatter_canvas_nhwc_kernel(const float* __restrict__ feats,
                                                                  int32_t* __restrict__ cell_map, int c4,
                                                                  int64_t total4, float* __restrict__ canvas) {
-    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (t >= total4) return;
-    const int64_t cell = t / c4;
-    const int cc = (int)(t - cell * c4);
-    const int32_t idx = cell_map[cell];
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (idx >= 0) v = reinterpret_cast<const float4*>(feats)[(int64_t)idx * c4 + cc];
-    reinterpret_cast<float4*>(canvas)[t] = v;
+    // 4 independent 16 B pieces per thread (block covers 1024 consecutive float4s), streaming stores
+    const int shift = ((c4 & (c4 - 1)) == 0) ? (31 - __clz(c4)) : -1;
+    const int64_t base = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+    int32_t idx[4];
+    int cc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int64_t t = base + u * 256;
+        idx[u] = -1; cc[u] = 0;
+        if (t < total4) {
+            const int64_t cell = shift >= 0 ? (t >> shift) : (t / c4);
+            cc[u] = (int)(t - cell * c4);
+            idx[u] = cell_map[cell];
+        }
+    }
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (idx[u] >= 0) v[u] = reinterpret_cast<const float4*>(feats)[(int64_t)idx[u] * c4 + cc[u]];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int64_t t = base + u * 256;
+        if (t < total4) store4<true>(reinterpret_cast<float4*>(canvas) + t, v[u]);
+    }
 }
 
 __global__ __launch_bounds__(256) void scatter_map_reset_kernel(const int32_t* __restrict__ coors, int64_t m,
@@ -130,6 +307,43 @@ __global__ __launch_bounds__(256) void scatter_bwd_kernel(const float* __restric
     reinterpret_cast<float4*>(grad_feats)[t] = g;
 }
 
+
+// Development knob: GGA_SCATTER_VARIANT=0|1|2|9 picks the NCHW canvas kernel (default: best measured).
+static int scatter_variant() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("GGA_SCATTER_VARIANT");
+        v = e ? atoi(e) : 3;
+    }
+    return v;
+}
+
+static void launch_canvas_nchw(hipStream_t stream, const float* feats, int32_t* cell_map, int channels,
+                               int64_t cells, int batch, float* canvas) {
+    const int64_t q = (int64_t)batch * cells / 4;
+    const dim3 grid((unsigned)((q + 255) / 256)), block(256);
+    const int var = scatter_variant();
+    if (var == 9) {
+        hipLaunchKernelGGL(scatter_canvas_zero_probe_kernel, grid, block, 0, stream, channels, cells, q, canvas);
+    } else if (var == 2 && channels == 64) {
+        hipLaunchKernelGGL((scatter_canvas_nchw_v2_kernel<64, false>), grid, block, 0, stream, feats, cell_map, cells, q, canvas);
+    } else if (var == 3 && channels == 64) {
+        hipLaunchKernelGGL((scatter_canvas_nchw_v2_kernel<64, true>), grid, block, 0, stream, feats, cell_map, cells, q, canvas);
+    } else if (var == 2 && channels == 128) {
+        hipLaunchKernelGGL((scatter_canvas_nchw_v2_kernel<128, false>), grid, block, 0, stream, feats, cell_map, cells, q, canvas);
+    } else if (var >= 1) {
+        if (channels % 8 == 0)
+            hipLaunchKernelGGL(scatter_canvas_nchw_v1_kernel<8>, grid, block, 0, stream, feats, cell_map, channels, cells, q, canvas);
+        else
+            hipLaunchKernelGGL(scatter_canvas_nchw_v1_kernel<4>, grid, block, 0, stream, feats, cell_map, channels, cells, q, canvas);
+    } else {
+        if (channels % 8 == 0)
+            hipLaunchKernelGGL(scatter_canvas_nchw_kernel<8>, grid, block, 0, stream, feats, cell_map, channels, cells, q, canvas);
+        else
+            hipLaunchKernelGGL(scatter_canvas_nchw_kernel<4>, grid, block, 0, stream, feats, cell_map, channels, cells, q, canvas);
+    }
+}
+
 extern "C" size_t gga_pillar_scatter_map_bytes(int batch, int ny, int nx) {
     return gga_align_up((size_t)batch * ny * nx * sizeof(int32_t), 256);
 }
@@ -157,18 +371,12 @@ extern "C" int gga_pillar_scatter_fwd(const float* feats, const int32_t* coors, 
         GGA_CHECK_LAUNCH("scatter_map_kernel");
     }
     if (layout == GGA_LAYOUT_NCHW) {
-        const int64_t q = (int64_t)batch * cells / 4;
-        if (channels % 8 == 0)
-            hipLaunchKernelGGL(scatter_canvas_nchw_kernel<8>, dim3((unsigned)((q + 255) / 256)), dim3(256), 0, stream,
-                               feats, cell_map, channels, cells, q, canvas);
-        else
-            hipLaunchKernelGGL(scatter_canvas_nchw_kernel<4>, dim3((unsigned)((q + 255) / 256)), dim3(256), 0, stream,
-                               feats, cell_map, channels, cells, q, canvas);
+        launch_canvas_nchw(stream, feats, cell_map, channels, cells, batch, canvas);
         GGA_CHECK_LAUNCH("scatter_canvas_nchw_kernel");
     } else {
         const int c4 = channels / 4;
         const int64_t total4 = (int64_t)batch * cells * c4;
-        hipLaunchKernelGGL(scatter_canvas_nhwc_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, stream,
+        hipLaunchKernelGGL(scatter_canvas_nhwc_kernel, dim3((unsigned)((total4 + 1023) / 1024)), dim3(256), 0, stream,
                            feats, cell_map, c4, total4, canvas);
         GGA_CHECK_LAUNCH("scatter_canvas_nhwc_kernel");
         if (m > 0) {   // NHWC readers share map words, so the reset is its own (4 B/pillar) pass
@@ -215,18 +423,12 @@ extern "C" int gga_profile_pillar_scatter(const float* feats, const int32_t* coo
                            (const int32_t*)nullptr, batch, ny, nx, cell_map);
         (void)hipEventRecord(e1, stream);
         if (layout == GGA_LAYOUT_NCHW) {
-            const int64_t q = (int64_t)batch * cells / 4;
-            if (channels % 8 == 0)
-                hipLaunchKernelGGL(scatter_canvas_nchw_kernel<8>, dim3((unsigned)((q + 255) / 256)), dim3(256), 0,
-                                   stream, feats, cell_map, channels, cells, q, canvas);
-            else
-                hipLaunchKernelGGL(scatter_canvas_nchw_kernel<4>, dim3((unsigned)((q + 255) / 256)), dim3(256), 0,
-                                   stream, feats, cell_map, channels, cells, q, canvas);
+            launch_canvas_nchw(stream, feats, cell_map, channels, cells, batch, canvas);
             (void)hipEventRecord(e2, stream);
         } else {
             const int c4 = channels / 4;
             const int64_t total4 = (int64_t)batch * cells * c4;
-            hipLaunchKernelGGL(scatter_canvas_nhwc_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0,
+            hipLaunchKernelGGL(scatter_canvas_nhwc_kernel, dim3((unsigned)((total4 + 1023) / 1024)), dim3(256), 0,
                                stream, feats, cell_map, c4, total4, canvas);
             (void)hipEventRecord(e2, stream);
             hipLaunchKernelGGL(scatter_map_reset_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, stream,

@@ -58,7 +58,7 @@ def scatter_roofline(model, batch_points, device, iters=20):
             'map_kernel_ms': round(ms_map.value, 4), 'pillars': int(m)}
 
 
-def cpu_baseline(cfg, frames=1):
+def cpu_baseline(cfg, frames=16):
     """The oracle's CPU restatement of the same train step (C voxelizer + torch fp32 on the
     host cores), one timed step on `frames` frames after a 1-frame warm-up."""
     from gga_amd import build_model, synthetic

@@ -1,0 +1,90 @@
+"""N>1 path on CPU: two gloo ranks through the product's Runner / build_ddp
+(gga_amd/train.py) — frames are sharded by rank, the only exchange is the gradient all-reduce,
+and a DDP step equals the single-process step on the averaged loss."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+from torch import nn
+
+from gga_amd import Config, synthetic
+from gga_amd.detectors import MVXTwoStageDetector_GGA
+from gga_amd.train import Runner
+
+CFG = dict(optimizer=dict(type='AdamW', lr=1e-2, betas=(0.95, 0.99), weight_decay=0.01),
+           optimizer_config=dict(grad_clip=dict(max_norm=35, norm_type=2)),
+           lr_config=dict(policy='cyclic', target_ratio=(10, 1e-4), cyclic_times=1, step_ratio_up=0.4),
+           momentum_config=dict(policy='cyclic', target_ratio=(0.85 / 0.95, 1), cyclic_times=1, step_ratio_up=0.4))
+
+
+class TinyDet(nn.Module):
+    """CPU stand-in with the detector's train-step surface (the real stages need the GPU)."""
+    _parse_losses = MVXTwoStageDetector_GGA._parse_losses
+    train_step = MVXTwoStageDetector_GGA.train_step
+
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(3)
+        self.net = nn.Sequential(nn.Linear(4, 16), nn.ReLU(), nn.Linear(16, 1))
+
+    def forward(self, return_loss=True, points=None, img_metas=None, **kw):
+        out = torch.stack([self.net(p).mean() for p in points])
+        return {'task0.loss_heatmap': out.pow(2).mean(), 'task0.distancemin': out.abs().mean().detach()}
+
+
+def _data(rank, frames=2):
+    b = synthetic.make_batch(frames, start=0, rank=rank, n_points=300, n_obj_range=(2, 3), n_ibp_range=(5, 10))
+    return dict(points=b['points'], img_metas=b['img_metas'])
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    model = TinyDet()
+    runner = Runner(model, Config(CFG), max_iters=10, distributed=True, device=torch.device('cpu'))
+    out = None
+    for _ in range(3):
+        out = runner.step(_data(rank))
+    q.put((rank, [p.detach().numpy().copy() for p in model.parameters()], float(out['loss'].detach())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_step_matches_single_process():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # ranks saw different frames (sharding by rank seed) ...
+    assert not torch.equal(_data(0)['points'][0], _data(1)['points'][0])
+    assert res[0][2] != res[1][2]
+    # ... but hold identical parameters after the all-reduced steps
+    for a, b in zip(res[0][1], res[1][1]):
+        assert (a == b).all()
+    # and equal the single-process run on the mean of the two ranks' losses
+    model = TinyDet()
+    runner = Runner(model, Config(CFG), max_iters=10)
+    for _ in range(3):
+        for g in runner.optimizer.param_groups:
+            g['lr'] = runner.lr_sched(runner.iter)
+            g['betas'] = (runner.mom_sched(runner.iter), g['betas'][1])
+        losses = [model._parse_losses(model(**_data(r)))[0] for r in range(2)]
+        runner.optimizer.zero_grad()
+        (sum(losses) / 2).backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 35, 2)
+        runner.optimizer.step()
+        runner.iter += 1
+    for a, b in zip(res[0][1], model.parameters()):
+        torch.testing.assert_close(torch.from_numpy(a), b.detach(), rtol=1e-5, atol=1e-7)

@@ -23,6 +23,12 @@ class VoxelParams(C.Structure):
                 ('max_points', C.c_int32), ('max_voxels', C.c_int32)]
 
 
+class PfnParams(C.Structure):
+    _fields_ = [('voxel_size', C.c_float * 3), ('offsets', C.c_float * 3), ('eps', C.c_float),
+                ('momentum', C.c_float), ('training', C.c_int32), ('in_features', C.c_int32),
+                ('channels', C.c_int32)]
+
+
 class LossParams(C.Structure):
     _fields_ = [('B', C.c_int32), ('K', C.c_int32), ('fm_w', C.c_int32),
                 ('voxel_size', C.c_float * 2), ('out_size_factor', C.c_float),
@@ -40,6 +46,9 @@ SIGNATURES = {
     'gga_hard_voxelize_batch': (i32, [vp, i32, C.POINTER(C.c_int64), i32, C.POINTER(VoxelParams),
                                        vp, vp, vp, vp, vp, sz, vp]),
     'gga_voxel_mean': (i32, [vp, vp, i64, i32, i32, i32, vp, vp]),
+    'gga_pfn_workspace_bytes': (sz, [i64]),
+    'gga_pfn_fwd': (i32, [vp, vp, vp, i64, i32, C.POINTER(PfnParams), vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
+    'gga_pfn_bwd': (i32, [vp, vp, vp, i64, i32, C.POINTER(PfnParams), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
     'gga_pillar_scatter_map_bytes': (sz, [i32, i32, i32]),
     'gga_pillar_scatter_fwd': (i32, [vp, vp, i64, vp, i32, i32, i32, i32, i32, vp, vp, vp]),
     'gga_pillar_scatter_bwd': (i32, [vp, vp, i64, vp, i32, i32, i32, i32, i32, vp, vp]),

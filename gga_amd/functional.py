@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import LossParams, VoxelParams, check
+from ._lib import LossParams, PfnParams, VoxelParams, check
 
 LAYOUT_NCHW, LAYOUT_NHWC = 0, 1
 
@@ -103,9 +103,60 @@ def voxel_mean(voxels, num_points, num_features):
     voxels = voxels.contiguous()
     m, P, ndim = voxels.shape
     out = torch.empty((m, num_features), dtype=torch.float32, device=voxels.device)
-    check(_lib.lib().gga_voxel_mean(_p(voxels), _p(num_points.contiguous()), m, P, ndim, num_features,
+    num_points = num_points.contiguous()     # keep every converted tensor alive until the launch is enqueued
+    check(_lib.lib().gga_voxel_mean(_p(voxels), _p(num_points), m, P, ndim, num_features,
                                     _p(out), _stream()), 'gga_voxel_mean')
     return out
+
+
+
+# ----------------------------------------------------------------------------- a2'
+class _FusedPFN(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, voxels, num_points, coors, weight, gamma, beta, running_mean, running_var, prm):
+        _need_cuda(voxels, num_points, coors, weight)
+        voxels, coors = voxels.contiguous(), coors.contiguous()
+        m, P, _ = voxels.shape
+        dev = voxels.device
+        L = _lib.lib()
+        out = torch.empty((m, 64), dtype=torch.float32, device=dev)
+        argmax = torch.empty((m, 64), dtype=torch.uint8, device=dev)
+        saved = torch.empty(238, dtype=torch.float64, device=dev)
+        ws = _workspace('pfn', L.gga_pfn_workspace_bytes(m), dev)
+        w = weight.contiguous()
+        check(L.gga_pfn_fwd(_p(voxels), _p(num_points), _p(coors), m, P, C.byref(prm), _p(w), _p(gamma),
+                            _p(beta), _p(running_mean), _p(running_var), _p(out), _p(argmax), _p(saved),
+                            _p(ws), ws.numel(), _stream()), 'gga_pfn_fwd')
+        ctx.save_for_backward(voxels, num_points, coors, w, gamma, out, argmax, saved)
+        ctx.prm = prm
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        voxels, num_points, coors, w, gamma, out, argmax, saved = ctx.saved_tensors
+        m, P, _ = voxels.shape
+        L = _lib.lib()
+        gw, gg, gb = torch.empty_like(w), torch.empty_like(gamma), torch.empty_like(gamma)
+        ws = _workspace('pfn', L.gga_pfn_workspace_bytes(m), g.device)
+        g = g.contiguous()
+        check(L.gga_pfn_bwd(_p(voxels), _p(num_points), _p(coors), m, P, C.byref(ctx.prm), _p(w), _p(gamma),
+                            _p(out), _p(argmax), _p(saved), _p(g), _p(gw), _p(gg), _p(gb), _p(ws),
+                            ws.numel(), _stream()), 'gga_pfn_bwd')
+        return None, None, None, gw, gg, gb, None, None, None
+
+
+def pfn_params(voxel_size, offsets, eps, momentum, training):
+    prm = PfnParams()
+    prm.voxel_size[:] = [float(v) for v in voxel_size]
+    prm.offsets[:] = [float(v) for v in offsets]
+    prm.eps, prm.momentum = float(eps), float(momentum)
+    prm.training, prm.in_features, prm.channels = int(bool(training)), 4, 64
+    return prm
+
+
+def fused_pfn(voxels, num_points, coors, weight, gamma, beta, running_mean, running_var, prm):
+    """Fused PillarFeatureNet: [M,P,4] -> [M,64] (running stats updated in place when training)."""
+    return _FusedPFN.apply(voxels, num_points, coors, weight, gamma, beta, running_mean, running_var, prm)
 
 
 # ----------------------------------------------------------------------------- a3
@@ -238,8 +289,11 @@ class _GatherPred(torch.autograd.Function):
         B, _, H, W = reg.shape
         K = ind.shape[1]
         pred = torch.empty((B, K, 8), dtype=torch.float32, device=reg.device)
-        check(_lib.lib().gga_gather_pred_fwd(_p(reg.contiguous()), _p(height.contiguous()),
-                                             _p(dim.contiguous()), _p(rot.contiguous()), _p(ind), B, K, H, W,
+        # NB: bind the NCHW copies to names. `_p(x.contiguous())` would free each temporary as soon
+        # as its pointer is taken, and the next copy would be allocated over it (channels-last maps).
+        reg, height, dim, rot = reg.contiguous(), height.contiguous(), dim.contiguous(), rot.contiguous()
+        check(_lib.lib().gga_gather_pred_fwd(_p(reg), _p(height),
+                                             _p(dim), _p(rot), _p(ind), B, K, H, W,
                                              _p(pred), _stream()), 'gga_gather_pred_fwd')
         ctx.save_for_backward(ind, mask)
         ctx.geom = (B, K, H, W)
@@ -254,7 +308,8 @@ class _GatherPred(torch.autograd.Function):
         g_h = torch.empty((B, 1, H, W), dtype=torch.float32, device=dev)
         g_dim = torch.empty((B, 3, H, W), dtype=torch.float32, device=dev)
         g_rot = torch.empty((B, 2, H, W), dtype=torch.float32, device=dev)
-        check(_lib.lib().gga_gather_pred_bwd(_p(g.contiguous()), _p(ind), _p(mask), B, K, H, W, _p(g_reg),
+        g = g.contiguous()
+        check(_lib.lib().gga_gather_pred_bwd(_p(g), _p(ind), _p(mask), B, K, H, W, _p(g_reg),
                                              _p(g_h), _p(g_dim), _p(g_rot), _stream()), 'gga_gather_pred_bwd')
         return g_reg, g_h, g_dim, g_rot, None, None
 
@@ -290,7 +345,8 @@ class _BoxLosses(torch.autograd.Function):
         grad_pred = torch.empty((5, B, K, 8), dtype=torch.float32, device=dev)
         ws = _workspace('box', L.gga_box_losses_workspace_bytes(B, K), dev)
         n_obj = 0 if ibp_slot is None else int(ibp_slot.shape[0])
-        check(L.gga_box_losses_fwd(_p(pred.contiguous()), _p(ind), _p(mask), _p(anno), _p(l2i), _p(bmask),
+        pred = pred.contiguous()
+        check(L.gga_box_losses_fwd(_p(pred), _p(ind), _p(mask), _p(anno), _p(l2i), _p(bmask),
                                    _p(ibp_xy), _p(ibp_off), _p(ibp_slot), n_obj, C.byref(prm), _p(losses),
                                    _p(box_out), _p(grad_pred), _p(ws), ws.numel(), _stream()),
               'gga_box_losses_fwd')
@@ -304,7 +360,8 @@ class _BoxLosses(torch.autograd.Function):
         (grad_pred,) = ctx.saved_tensors
         B, K = ctx.geom
         out = torch.empty((B, K, 8), dtype=torch.float32, device=grad_pred.device)
-        check(_lib.lib().gga_box_losses_bwd(_p(grad_pred), _p(g_losses.contiguous().float()), B, K, _p(out),
+        g_losses = g_losses.contiguous().float()
+        check(_lib.lib().gga_box_losses_bwd(_p(grad_pred), _p(g_losses), B, K, _p(out),
                                             _stream()), 'gga_box_losses_bwd')
         return (out,) + (None,) * 9
 

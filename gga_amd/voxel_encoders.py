@@ -91,7 +91,29 @@ class PillarFeatureNet(nn.Module):
         self.z_offset = self.vz / 2 + point_cloud_range[2]
         self.point_cloud_range = point_cloud_range
 
+    def _fusable(self, features):
+        l0 = self.pfn_layers[0]
+        return (features.is_cuda and len(self.pfn_layers) == 1 and l0.units == 64 and l0.mode == 'max'
+                and self.legacy and self._with_cluster_center and self._with_voxel_center
+                and not self._with_distance and features.shape[-1] == 4 and features.shape[1] <= 254
+                and features.shape[0] > 0 and isinstance(l0.norm, nn.BatchNorm1d) and l0.norm.affine
+                and l0.norm.track_running_stats and l0.norm.momentum is not None and features.dtype == torch.float32)
+
     def forward(self, features, num_points, coors):
+        if self._fusable(features):
+            # one fused HIP pass (gga_amd/csrc/pfn.hip) instead of the [M,P,64] eager pipeline
+            l0 = self.pfn_layers[0]
+            bn = l0.norm
+            prm = F.pfn_params((self.vx, self.vy, self.vz), (self.x_offset, self.y_offset, self.z_offset),
+                               bn.eps, bn.momentum, self.training)
+            if self.training:
+                bn.num_batches_tracked += 1
+            return F.fused_pfn(features, num_points.int(), coors.int(), l0.linear.weight, bn.weight, bn.bias,
+                               bn.running_mean, bn.running_var, prm)
+        return self.forward_eager(features, num_points, coors)
+
+    def forward_eager(self, features, num_points, coors):
+        """The reference's op sequence in eager PyTorch (general configurations)."""
         features_ls = [features]
         if self._with_cluster_center:
             points_mean = features[:, :, :3].sum(dim=1, keepdim=True) / num_points.type_as(features).view(-1, 1, 1)

@@ -85,6 +85,42 @@ int gga_voxel_mean(const float* voxels, const int32_t* num_points, int64_t m, in
                    int ndim, int num_features, float* out, void* stream);
 
 /* ------------------------------------------------------------------------- */
+/* a2'. Fused PillarFeatureNet (one PFNLayer, legacy=True, mode='max'):       */
+/* decorate (cluster-mean / pillar-centre offsets) + Linear(10->64, no bias)  */
+/* + BatchNorm1d (batch statistics over all m*P rows, padding included) +     */
+/* ReLU + max over the P points, and its backward w.r.t. the parameters.      */
+/* Replaces mmdet3d/models/voxel_encoders/pillar_encoder.py:93-159 and        */
+/* voxel_encoders/utils.py:145-182 (PFNLayer.forward).                        */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+    float voxel_size[3];   /* vx, vy, vz */
+    float offsets[3];      /* x_offset = vx/2 + pc_range[0], ... (pillar_encoder.py:87-90) */
+    float eps, momentum;   /* BatchNorm1d(eps=1e-3, momentum=0.01) */
+    int32_t training;      /* 1: batch statistics + running-stat update, 0: running statistics */
+    int32_t in_features;   /* point features (x, y, z, r) = 4 */
+    int32_t channels;      /* output channels = 64 */
+} gga_pfn_params;
+
+size_t gga_pfn_workspace_bytes(int64_t m);
+/*
+ * voxels [m,P,4] f32, num_points [m] i32, coors [m,4] i32 (b,z,y,x)
+ * weight [64,10], gamma/beta [64], running_mean/var [64] (updated in place when training)
+ * out [m,64] f32; argmax [m,64] u8 (index of the winning point, 255 = a padding row)
+ * saved [238] f64: first/second moments of the decorated features, per-channel mean / invstd
+ */
+int gga_pfn_fwd(const float* voxels, const int32_t* num_points, const int32_t* coors, int64_t m,
+                int max_points, const gga_pfn_params* prm, const float* weight, const float* gamma,
+                const float* beta, float* running_mean, float* running_var, float* out,
+                uint8_t* argmax, double* saved, void* workspace, size_t workspace_bytes,
+                void* stream);
+/* grad_weight [64,10], grad_gamma [64], grad_beta [64] from grad_out [m,64] (points carry no grad). */
+int gga_pfn_bwd(const float* voxels, const int32_t* num_points, const int32_t* coors, int64_t m,
+                int max_points, const gga_pfn_params* prm, const float* weight, const float* gamma,
+                const float* out, const uint8_t* argmax, const double* saved, const float* grad_out,
+                float* grad_weight, float* grad_gamma, float* grad_beta, void* workspace,
+                size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------- */
 /* a3. PointPillars scatter (the kernel the "HBM GB/s on voxel scatter"       */
 /* metric measures) and its backward.                                         */
 /* Replaces mmdet3d/models/middle_encoders/pillar_scatter.py:62-102           */

@@ -246,3 +246,68 @@ def test_nan_target_propagates_like_reference():
     bm = torch.ones(B, K, 4, dtype=torch.uint8, device=DEV)
     losses, _ = F.box_losses(pred, ind, mask, anno, l2i, bm, None, None, None, prm)
     assert torch.isnan(losses[0]) and not torch.isnan(losses[1])
+
+
+def test_fused_pfn_vs_reference_golden(golden):
+    """Fused PillarFeatureNet against the imported reference: forward, running stats and the
+    parameter gradients (encoders.npz was produced by the reference's PillarFeatureNet)."""
+    from gga_amd.voxel_encoders import PillarFeatureNet
+    d = golden('encoders')
+    cfg = d['pfn.cfg']
+    pfn = PillarFeatureNet(in_channels=4, feat_channels=(64,), voxel_size=tuple(cfg[:3]),
+                           point_cloud_range=tuple(cfg[3:])).to(DEV)
+    l0 = pfn.pfn_layers[0]
+    with torch.no_grad():
+        l0.linear.weight.copy_(torch.from_numpy(d['pfn.linear_w']))
+        l0.norm.weight.copy_(torch.from_numpy(d['pfn.bn_w']))
+        l0.norm.bias.copy_(torch.from_numpy(d['pfn.bn_b']))
+    pfn.train()
+    v = torch.from_numpy(d['pfn.voxels']).to(DEV)
+    n = torch.from_numpy(d['pfn.num_points']).to(DEV)
+    c = torch.from_numpy(d['pfn.coors']).to(DEV)
+    assert pfn._fusable(v)
+    y = pfn(v, n, c)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), d['pfn.out'], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(l0.norm.running_mean.cpu().numpy(), d['pfn.running_mean'], rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(l0.norm.running_var.cpu().numpy(), d['pfn.running_var'], rtol=1e-5)
+    assert torch.equal(v.cpu(), torch.from_numpy(d['pfn.voxels']))     # input left untouched
+    y.backward(torch.from_numpy(d['pfn.grad_out']).to(DEV))
+    for got, key in ((l0.linear.weight.grad, 'pfn.grad_linear_w'), (l0.norm.weight.grad, 'pfn.grad_bn_w'),
+                     (l0.norm.bias.grad, 'pfn.grad_bn_b')):
+        ref = d[key]
+        err = np.abs(got.cpu().numpy() - ref).max() / np.abs(ref).max()
+        assert err < 2e-4, (key, err)
+    # the eager path (general configs) computes the same thing
+    pfn2 = PillarFeatureNet(in_channels=4, feat_channels=(64,), voxel_size=tuple(cfg[:3]),
+                            point_cloud_range=tuple(cfg[3:])).to(DEV)
+    pfn2.load_state_dict({k: (torch.zeros_like(t) if 'running_mean' in k else torch.ones_like(t) if 'running_var' in k
+                              else t) for k, t in pfn.state_dict().items()})
+    pfn2.train()
+    y2 = pfn2.forward_eager(v, n, c)
+    np.testing.assert_allclose(y2.detach().cpu().numpy(), y.detach().cpu().numpy(), rtol=1e-4, atol=1e-4)
+    # eval mode uses the running statistics
+    pfn.eval(), pfn2.eval()
+    pfn2.load_state_dict(pfn.state_dict())
+    np.testing.assert_allclose(pfn(v, n, c).detach().cpu().numpy(), pfn2.forward_eager(v, n, c).detach().cpu().numpy(),
+                               rtol=1e-4, atol=1e-4)
+
+
+def test_fused_pfn_full_size():
+    from gga_amd.voxel_encoders import PillarFeatureNet
+    frames = [synthetic.make_frame(i, pc_range=synthetic.RANGE_PP)['points'].to(DEV) for i in range(4)]
+    v, n, c, _ = F.hard_voxelize_batch(frames, [0.16, 0.16, 4], synthetic.RANGE_PP, 32, 16000)
+    torch.manual_seed(0)
+    pfn = PillarFeatureNet(in_channels=4, feat_channels=(64,), voxel_size=(0.16, 0.16, 4),
+                           point_cloud_range=synthetic.RANGE_PP).to(DEV).train()
+    ref = PillarFeatureNet(in_channels=4, feat_channels=(64,), voxel_size=(0.16, 0.16, 4),
+                           point_cloud_range=synthetic.RANGE_PP).to(DEV).train()
+    ref.load_state_dict(pfn.state_dict())
+    y = pfn(v, n, c)
+    yr = ref.forward_eager(v, n, c)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), yr.detach().cpu().numpy(), rtol=1e-4, atol=1e-4)
+    g = torch.randn_like(y)
+    y.backward(g)
+    yr.backward(g)
+    for a, b in zip(pfn.parameters(), ref.parameters()):
+        err = float((a.grad - b.grad).abs().max() / b.grad.abs().max())
+        assert err < 1e-3, err

@@ -8,6 +8,6 @@ run as hand-written HIP kernels for gfx950 behind a C-ABI shared library
 __version__ = '0.1.0'
 
 from . import registry  # noqa: E402,F401
-from . import losses, bbox_coders, voxel_encoders, middle_encoders, backbones, dense_heads, detectors  # noqa: E402,F401
+from . import losses, bbox_coders, voxel_encoders, middle_encoders, sparse, sparse_encoder, backbones, dense_heads, detectors  # noqa: E402,F401
 from .config import Config  # noqa: E402,F401
 from .registry import build_detector, build_model  # noqa: E402,F401

@@ -16,6 +16,7 @@ ABI_VERSION = 1
 _lib = None
 
 vp, i32, i64, f32, sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
+I3 = C.POINTER(C.c_int32 * 3)
 
 
 class VoxelParams(C.Structure):
@@ -54,6 +55,14 @@ SIGNATURES = {
     'gga_pillar_scatter_bwd': (i32, [vp, vp, i64, vp, i32, i32, i32, i32, i32, vp, vp]),
     'gga_profile_pillar_scatter': (i32, [vp, vp, i64, i32, i32, i32, i32, i32, vp, vp, i32,
                                           C.POINTER(C.c_float), C.POINTER(C.c_float), vp]),
+    'gga_sparse_index_bytes': (sz, [i64]),
+    'gga_sparse_build_index': (i32, [vp, i64, i32, i32, i32, i32, vp, sz, vp]),
+    'gga_sparse_out_index_bytes': (sz, [i64, i32]),
+    'gga_sparse_out_sites_workspace_bytes': (sz, [i64, i32]),
+    'gga_sparse_conv_out_sites': (i32, [vp, i64, i32, I3, I3, I3, I3, I3, vp, i64, vp, vp, sz, vp, sz, vp]),
+    'gga_sparse_rulebook': (i32, [vp, i64, vp, i64, i32, I3, I3, I3, I3, I3, vp, i64, vp, i64, vp, vp, vp]),
+    'gga_sparse_conv_apply': (i32, [vp, vp, vp, i64, i32, i32, i32, i32, i32, vp, vp]),
+    'gga_sparse_conv_wgrad': (i32, [vp, vp, vp, i64, i32, i32, i32, vp, vp]),
     'gga_heatmap_splat': (i32, [vp, i32, i32, i32, vp, i32, vp, vp, i32, vp]),
     'gga_focal_loss_workspace_bytes': (sz, [i64]),
     'gga_focal_loss_fwd': (i32, [vp, vp, i64, f32, f32, f32, vp, vp, sz, vp]),

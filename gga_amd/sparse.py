@@ -1,0 +1,252 @@
+"""Sparse tensors and sparse 3D convolution layers on the HIP kernels of
+gga_amd/csrc/sparse_conv.hip — the subset of the mmcv / spconv API the reference's
+SparseEncoder uses (mmdet3d/ops/sparse_block.py:9-20,167-184; mmdet3d/models/
+middle_encoders/sparse_encoder.py:120-138): ``SparseConvTensor(features, indices,
+spatial_shape, batch_size)`` with ``.features`` / ``.indices`` / ``.dense()`` /
+``replace_feature``, ``SparseModule``, ``SparseSequential`` and the conv layers
+``SubMConv3d`` / ``SparseConv3d`` registered in ``CONV_LAYERS`` so
+``build_conv_layer(dict(type='SubMConv3d', indice_key=...), Cin, Cout, k, stride=, padding=,
+bias=False)`` works unchanged. Weights use the mmcv layout ``[kz, ky, kx, Cin, Cout]``.
+"""
+import ctypes as C
+import math
+
+import torch
+from torch import nn
+
+from . import _lib
+from . import functional as F
+from ._lib import check
+from .registry import CONV_LAYERS
+
+
+def _triple(v):
+    return tuple(int(x) for x in v) if isinstance(v, (tuple, list)) else (int(v),) * 3
+
+
+def _i3(v):
+    return (C.c_int32 * 3)(*v)
+
+
+class _Level:
+    """One resolution level: coordinates + hash index + cached rule books."""
+
+    def __init__(self, coors, spatial_shape, batch_size, index=None, index_n=None):
+        self.coors = coors.contiguous()
+        self.n = int(coors.shape[0])
+        self.shape = tuple(int(s) for s in spatial_shape)
+        self.batch_size = int(batch_size)
+        self.index, self.index_n = index, index_n
+        self._subm = {}
+
+    def ensure_index(self):
+        if self.index is None:
+            L = _lib.lib()
+            self.index_n = self.n
+            self.index = torch.empty(L.gga_sparse_index_bytes(self.n), dtype=torch.uint8, device=self.coors.device)
+            D, H, W = self.shape
+            check(L.gga_sparse_build_index(F._p(self.coors), self.n, self.batch_size, D, H, W, F._p(self.index),
+                                           self.index.numel(), F._stream()), 'gga_sparse_build_index')
+        return self.index
+
+    def subm_rulebook(self, kernel):
+        nbr = self._subm.get(kernel)
+        if nbr is None:
+            self.ensure_index()
+            kvol = kernel[0] * kernel[1] * kernel[2]
+            nbr = torch.empty((kvol, self.n), dtype=torch.int32, device=self.coors.device)
+            pad = tuple(k // 2 for k in kernel)
+            check(_lib.lib().gga_sparse_rulebook(F._p(self.coors), self.n, F._p(self.coors), self.n, self.batch_size,
+                                                 _i3(self.shape), _i3(self.shape), _i3(kernel), _i3((1, 1, 1)), _i3(pad),
+                                                 F._p(self.index), self.index_n, None, 0, F._p(nbr), None,
+                                                 F._stream()), 'gga_sparse_rulebook')
+            self._subm[kernel] = nbr
+        return nbr
+
+    def strided(self, kernel, stride, padding):
+        """-> (output level, nbr [kvol,n_out], nbr_t [kvol,n_in])"""
+        L = _lib.lib()
+        dev = self.coors.device
+        self.ensure_index()
+        kvol = kernel[0] * kernel[1] * kernel[2]
+        cap = self.n * min(kvol, 8)       # a site reaches at most ceil(k/s)^3 <= 8 outputs for k=3, s>=2
+        for a in range(3):
+            cap = cap if stride[a] >= 2 or kernel[a] == 1 else self.n * kvol
+        out_coors = torch.empty((cap, 4), dtype=torch.int32, device=dev)
+        n_out_d = torch.zeros(1, dtype=torch.int32, device=dev)
+        out_index = torch.empty(L.gga_sparse_out_index_bytes(self.n, kvol), dtype=torch.uint8, device=dev)
+        ws = F._workspace('sp_sites', L.gga_sparse_out_sites_workspace_bytes(self.n, kvol), dev)
+        out_dhw = (C.c_int32 * 3)()
+        check(L.gga_sparse_conv_out_sites(F._p(self.coors), self.n, self.batch_size, _i3(self.shape), _i3(kernel),
+                                          _i3(stride), _i3(padding), out_dhw, F._p(out_coors), cap, F._p(n_out_d),
+                                          F._p(out_index), out_index.numel(), F._p(ws), ws.numel(), F._stream()),
+              'gga_sparse_conv_out_sites')
+        n_out = int(n_out_d.item())        # data-dependent size: one 4-byte read back, as spconv does
+        assert 0 < n_out <= cap, (n_out, cap)
+        out = _Level(out_coors[:n_out], tuple(out_dhw), self.batch_size, index=out_index, index_n=self.n * kvol)
+        nbr = torch.empty((kvol, n_out), dtype=torch.int32, device=dev)
+        nbr_t = torch.empty((kvol, self.n), dtype=torch.int32, device=dev)
+        check(L.gga_sparse_rulebook(F._p(out.coors), n_out, F._p(self.coors), self.n, self.batch_size, _i3(self.shape),
+                                    _i3(out.shape), _i3(kernel), _i3(stride), _i3(padding), F._p(self.index),
+                                    self.index_n, F._p(out_index), out.index_n, F._p(nbr), F._p(nbr_t), F._stream()),
+              'gga_sparse_rulebook')
+        return out, nbr, nbr_t
+
+
+class SparseConvTensor:
+    def __init__(self, features, indices, spatial_shape, batch_size, grid=None, _level=None):
+        F._need_cuda(features, indices)
+        self.features = features
+        self.indices = indices if indices.dtype == torch.int32 else indices.int()
+        self.spatial_shape = list(spatial_shape)
+        self.batch_size = batch_size
+        self.indice_dict = {}
+        self._level = _level or _Level(self.indices, spatial_shape, batch_size)
+
+    def replace_feature(self, new_features):
+        out = SparseConvTensor(new_features, self.indices, self.spatial_shape, self.batch_size, _level=self._level)
+        out.indice_dict = self.indice_dict
+        return out
+
+    @property
+    def spatial_size(self):
+        return int(torch.tensor(self.spatial_shape).prod())
+
+    def dense(self, channels_first=True):
+        """[N,C] features -> dense [B, C, D, H, W] (zeros elsewhere): the pillar-scatter canvas kernel
+        with (z,y) folded into the row index."""
+        D, H, W = self._level.shape
+        c = self.indices
+        folded = torch.stack([c[:, 0], torch.zeros_like(c[:, 0]), c[:, 1] * H + c[:, 2], c[:, 3]], 1).contiguous()
+        out = F.pillar_scatter(self.features, folded, self.batch_size, D * H, W)
+        out = out.view(self.batch_size, self.features.shape[1], D, H, W)
+        return out if channels_first else out.permute(0, 2, 3, 4, 1).contiguous()
+
+
+class SparseModule(nn.Module):
+    """Marker base: modules that take and return a SparseConvTensor."""
+
+
+class SparseSequential(SparseModule):
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        if len(args) == 1 and isinstance(args[0], dict):
+            for k, m in args[0].items():
+                self.add_module(k, m)
+        else:
+            for i, m in enumerate(args):
+                self.add_module(str(i), m)
+        for k, m in kwargs.items():
+            self.add_module(k, m)
+
+    def __getitem__(self, idx):
+        return list(self._modules.values())[idx]
+
+    def __len__(self):
+        return len(self._modules)
+
+    def add(self, module, name=None):
+        self.add_module(name or str(len(self._modules)), module)
+
+    def forward(self, x):
+        for m in self._modules.values():
+            if isinstance(m, SparseModule):
+                x = m(x)
+            elif isinstance(x, SparseConvTensor):
+                if x.features.shape[0] != 0:
+                    x = x.replace_feature(m(x.features))
+            else:
+                x = m(x)
+        return x
+
+
+class _SparseConvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feats, weight, nbr, nbr_t, n_out):
+        feats, w = feats.contiguous(), weight.contiguous()
+        kvol = nbr.shape[0]
+        cin, cout = w.shape[-2], w.shape[-1]
+        y = torch.empty((n_out, cout), dtype=torch.float32, device=feats.device)
+        check(_lib.lib().gga_sparse_conv_apply(F._p(feats), F._p(nbr), F._p(w), n_out, kvol, cin, cout, 0, 0, F._p(y),
+                                               F._stream()), 'gga_sparse_conv_apply')
+        ctx.save_for_backward(feats, w, nbr, nbr_t)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        feats, w, nbr, nbr_t = ctx.saved_tensors
+        gy = gy.contiguous()
+        kvol, n_out = nbr.shape
+        n_in = feats.shape[0]
+        cin, cout = w.shape[-2], w.shape[-1]
+        L = _lib.lib()
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(feats)
+            tmap, flip = (nbr_t, 0) if nbr_t is not None else (nbr, 1)      # SubM: transposed map = reversed offsets
+            check(L.gga_sparse_conv_apply(F._p(gy), F._p(tmap), F._p(w), n_in, kvol, cout, cin, flip, 1, F._p(gx),
+                                          F._stream()), 'gga_sparse_conv_apply(bwd data)')
+        if ctx.needs_input_grad[1]:
+            gw = torch.empty_like(w)
+            check(L.gga_sparse_conv_wgrad(F._p(feats), F._p(gy), F._p(nbr), n_out, kvol, cin, cout, F._p(gw),
+                                          F._stream()), 'gga_sparse_conv_wgrad')
+        return gx, gw, None, None, None
+
+
+class SparseConvolution(SparseModule):
+    def __init__(self, ndim, in_channels, out_channels, kernel_size=3, stride=1, padding=0, dilation=1, groups=1,
+                 bias=True, subm=False, indice_key=None, **kw):
+        super().__init__()
+        assert ndim == 3 and groups == 1 and _triple(dilation) == (1, 1, 1), 'only plain 3D sparse convs are on the GGA path'
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride, self.padding = _triple(kernel_size), _triple(stride), _triple(padding)
+        self.subm, self.indice_key = subm, indice_key
+        self.weight = nn.Parameter(torch.empty(*self.kernel_size, in_channels, out_channels))
+        self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        # mmcv SparseConvolution.reset_parameters: kaiming_uniform_(a=sqrt(5)) on the 5-D weight
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if self.bias is not None:
+            fan_in, _ = nn.init._calculate_fan_in_and_fan_out(self.weight)
+            bound = 1 / math.sqrt(fan_in)
+            nn.init.uniform_(self.bias, -bound, bound)
+
+    def forward(self, x):
+        assert isinstance(x, SparseConvTensor)
+        lvl = x._level
+        w = self.weight.view(-1, self.in_channels, self.out_channels)
+        if self.subm:
+            nbr = lvl.subm_rulebook(self.kernel_size)
+            y = _SparseConvFn.apply(x.features, w, nbr, None, lvl.n)
+            out = x.replace_feature(y)
+        else:
+            cached = x.indice_dict.get(self.indice_key) if self.indice_key else None
+            if cached is None or cached[0] is not lvl:
+                cached = (lvl,) + lvl.strided(self.kernel_size, self.stride, self.padding)
+                if self.indice_key:
+                    x.indice_dict[self.indice_key] = cached
+            _, out_lvl, nbr, nbr_t = cached
+            y = _SparseConvFn.apply(x.features, w, nbr, nbr_t, out_lvl.n)
+            out = SparseConvTensor(y, out_lvl.coors, out_lvl.shape, x.batch_size, _level=out_lvl)
+            out.indice_dict = x.indice_dict
+        if self.bias is not None:
+            out = out.replace_feature(out.features + self.bias)
+        return out
+
+
+@CONV_LAYERS.register_module()
+class SubMConv3d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True,
+                 indice_key=None):
+        super().__init__(3, in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias, True,
+                         indice_key=indice_key)
+
+
+@CONV_LAYERS.register_module()
+class SparseConv3d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True,
+                 indice_key=None):
+        super().__init__(3, in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias,
+                         indice_key=indice_key)

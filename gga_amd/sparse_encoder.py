@@ -1,0 +1,126 @@
+"""``SparseEncoder`` (SECOND middle encoder), ``SparseBasicBlock`` and
+``make_sparse_convmodule`` — constructor arguments, layer structure and ``state_dict`` names
+of the reference (mmdet3d/models/middle_encoders/sparse_encoder.py:43-214,
+mmdet3d/ops/sparse_block.py:82-199; ``BasicBlock`` attribute names conv1/bn1/conv2/bn2 as in
+mmdet's resnet), on the sparse layers of ``gga_amd.sparse``."""
+from torch import nn
+
+from .cnn import build_conv_layer, build_norm_layer
+from .registry import MIDDLE_ENCODERS
+from .sparse import SparseConvTensor, SparseModule, SparseSequential
+
+
+class SparseBasicBlock(SparseModule):
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, conv_cfg=None, norm_cfg=None):
+        super().__init__()
+        assert downsample is None and stride == 1
+        self.norm1_name, norm1 = build_norm_layer(norm_cfg, planes, postfix=1)
+        self.norm2_name, norm2 = build_norm_layer(norm_cfg, planes, postfix=2)
+        self.conv1 = build_conv_layer(conv_cfg, inplanes, planes, 3, stride=stride, padding=1, dilation=1, bias=False)
+        self.add_module(self.norm1_name, norm1)
+        self.conv2 = build_conv_layer(conv_cfg, planes, planes, 3, padding=1, bias=False)
+        self.add_module(self.norm2_name, norm2)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+
+    norm1 = property(lambda self: getattr(self, self.norm1_name))
+    norm2 = property(lambda self: getattr(self, self.norm2_name))
+
+    def forward(self, x):
+        identity = x.features
+        assert x.features.dim() == 2, f'x.features.dim()={x.features.dim()}'
+        out = self.conv1(x)
+        out = out.replace_feature(self.relu(self.norm1(out.features)))
+        out = self.conv2(out)
+        out = out.replace_feature(self.norm2(out.features))
+        out = out.replace_feature(self.relu(out.features + identity))
+        return out
+
+
+def make_sparse_convmodule(in_channels, out_channels, kernel_size, indice_key, stride=1, padding=0,
+                           conv_type='SubMConv3d', norm_cfg=None, order=('conv', 'norm', 'act')):
+    assert isinstance(order, tuple) and len(order) <= 3
+    assert set(order) | {'conv', 'norm', 'act'} == {'conv', 'norm', 'act'}
+    conv_cfg = dict(type=conv_type, indice_key=indice_key)
+    layers = []
+    for layer in order:
+        if layer == 'conv':
+            layers.append(build_conv_layer(conv_cfg, in_channels, out_channels, kernel_size, stride=stride,
+                                           padding=padding, bias=False))
+        elif layer == 'norm':
+            layers.append(build_norm_layer(norm_cfg, out_channels)[1])
+        elif layer == 'act':
+            layers.append(nn.ReLU(inplace=True))
+    return SparseSequential(*layers)
+
+
+@MIDDLE_ENCODERS.register_module()
+class SparseEncoder(nn.Module):
+    def __init__(self, in_channels, sparse_shape, order=('conv', 'norm', 'act'),
+                 norm_cfg=dict(type='BN1d', eps=1e-3, momentum=0.01), base_channels=16, output_channels=128,
+                 encoder_channels=((16, ), (32, 32, 32), (64, 64, 64), (64, 64, 64)),
+                 encoder_paddings=((1, ), (1, 1, 1), (1, 1, 1), ((0, 1, 1), 1, 1)), block_type='conv_module'):
+        super().__init__()
+        assert block_type in ['conv_module', 'basicblock']
+        self.sparse_shape = sparse_shape
+        self.in_channels = in_channels
+        self.order = order
+        self.base_channels = base_channels
+        self.output_channels = output_channels
+        self.encoder_channels = encoder_channels
+        self.encoder_paddings = encoder_paddings
+        self.stage_num = len(self.encoder_channels)
+        self.fp16_enabled = False
+        assert isinstance(order, tuple) and len(order) == 3 and set(order) == {'conv', 'norm', 'act'}
+        if self.order[0] != 'conv':      # pre-activate
+            self.conv_input = make_sparse_convmodule(in_channels, self.base_channels, 3, norm_cfg=norm_cfg, padding=1,
+                                                     indice_key='subm1', conv_type='SubMConv3d', order=('conv', ))
+        else:
+            self.conv_input = make_sparse_convmodule(in_channels, self.base_channels, 3, norm_cfg=norm_cfg, padding=1,
+                                                     indice_key='subm1', conv_type='SubMConv3d')
+        encoder_out_channels = self.make_encoder_layers(make_sparse_convmodule, norm_cfg, self.base_channels,
+                                                        block_type=block_type)
+        self.conv_out = make_sparse_convmodule(encoder_out_channels, self.output_channels, kernel_size=(3, 1, 1),
+                                               stride=(2, 1, 1), norm_cfg=norm_cfg, padding=0,
+                                               indice_key='spconv_down2', conv_type='SparseConv3d')
+
+    def forward(self, voxel_features, coors, batch_size):
+        x = SparseConvTensor(voxel_features, coors.int(), self.sparse_shape, int(batch_size))
+        x = self.conv_input(x)
+        encode_features = []
+        for encoder_layer in self.encoder_layers:
+            x = encoder_layer(x)
+            encode_features.append(x)
+        out = self.conv_out(encode_features[-1])
+        spatial_features = out.dense()
+        N, C, D, H, W = spatial_features.shape
+        return spatial_features.view(N, C * D, H, W)
+
+    def make_encoder_layers(self, make_block, norm_cfg, in_channels, block_type='conv_module',
+                            conv_cfg=dict(type='SubMConv3d')):
+        assert block_type in ['conv_module', 'basicblock']
+        self.encoder_layers = SparseSequential()
+        for i, blocks in enumerate(self.encoder_channels):
+            blocks_list = []
+            for j, out_channels in enumerate(tuple(blocks)):
+                padding = tuple(self.encoder_paddings[i])[j]
+                last_of_stage = j == len(blocks) - 1 and i != len(self.encoder_channels) - 1
+                if i != 0 and j == 0 and block_type == 'conv_module':
+                    blocks_list.append(make_block(in_channels, out_channels, 3, norm_cfg=norm_cfg, stride=2,
+                                                  padding=padding, indice_key=f'spconv{i + 1}', conv_type='SparseConv3d'))
+                elif block_type == 'basicblock':
+                    if last_of_stage:
+                        blocks_list.append(make_block(in_channels, out_channels, 3, norm_cfg=norm_cfg, stride=2,
+                                                      padding=padding, indice_key=f'spconv{i + 1}',
+                                                      conv_type='SparseConv3d'))
+                    else:
+                        blocks_list.append(SparseBasicBlock(out_channels, out_channels, norm_cfg=norm_cfg,
+                                                            conv_cfg=conv_cfg))
+                else:
+                    blocks_list.append(make_block(in_channels, out_channels, 3, norm_cfg=norm_cfg, padding=padding,
+                                                  indice_key=f'subm{i + 1}', conv_type='SubMConv3d'))
+                in_channels = out_channels
+            self.encoder_layers.add_module(f'encoder_layer{i + 1}', SparseSequential(*blocks_list))
+        return out_channels

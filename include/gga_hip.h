@@ -161,6 +161,55 @@ int gga_profile_pillar_scatter(const float* feats, const int32_t* coors, int64_t
                                void* stream);
 
 /* ------------------------------------------------------------------------- */
+/* a3'. Sparse 3D convolution (SubMConv3d / SparseConv3d) for SparseEncoder.  */
+/* Replaces the mmcv / spconv natives behind                                  */
+/*   mmdet3d/models/middle_encoders/sparse_encoder.py:107-214 and             */
+/*   mmdet3d/ops/sparse_block.py:82-199 (SparseConvTensor, rule-book build,   */
+/*   per-offset gather-GEMM-scatter). Coordinates are [n,4] i32 (b,z,y,x);    */
+/*   weights are [kz,ky,kx,Cin,Cout] (the mmcv layout, write_spconv2.py:47).  */
+/* ------------------------------------------------------------------------- */
+/* Hash index of one resolution level (cell -> row). `index` is caller memory of
+ * gga_sparse_index_bytes(n) bytes; remember n: later calls need it as *_index_n. */
+size_t gga_sparse_index_bytes(int64_t n);
+int gga_sparse_build_index(const int32_t* coors, int64_t n, int B, int D, int H, int W, void* index,
+                           size_t index_bytes, void* stream);
+
+/* Output sites of a strided SparseConv3d: every cell reached by some (input site, offset).
+ * out_dhw is computed here ((in + 2p - k)/s + 1). out_coors [cap_out,4]; *n_out (device i32)
+ * = number of sites, ordered by the first (input row, offset) that reaches them. out_index
+ * becomes the hash index of the OUTPUT level, sized for n_in*kvol
+ * (gga_sparse_out_index_bytes); pass that product as its *_index_n later. */
+size_t gga_sparse_out_index_bytes(int64_t n_in, int kvol);
+size_t gga_sparse_out_sites_workspace_bytes(int64_t n_in, int kvol);
+int gga_sparse_conv_out_sites(const int32_t* in_coors, int64_t n_in, int B, const int32_t in_dhw[3],
+                              const int32_t kernel[3], const int32_t stride[3], const int32_t pad[3],
+                              int32_t out_dhw[3], int32_t* out_coors, int64_t cap_out, int32_t* n_out,
+                              void* out_index, size_t out_index_bytes, void* workspace,
+                              size_t workspace_bytes, void* stream);
+
+/* Rule books in gather form. nbr [kvol, n_out]: input row under offset k of each output row
+ * (-1: none). nbr_t [kvol, n_in] (optional): output row fed by each input row through offset k
+ * (backward-data). Submanifold conv: out == in coords, stride 1, pad k/2, nbr_t = NULL
+ * (it is nbr[kvol-1-k]). */
+int gga_sparse_rulebook(const int32_t* out_coors, int64_t n_out, const int32_t* in_coors, int64_t n_in,
+                        int B, const int32_t in_dhw[3], const int32_t out_dhw[3], const int32_t kernel[3],
+                        const int32_t stride[3], const int32_t pad[3], const void* in_index,
+                        int64_t in_index_n, const void* out_index, int64_t out_index_n, int32_t* nbr,
+                        int32_t* nbr_t, void* stream);
+
+/* y[r,:] = sum_k x[map[kk][r],:] @ Wk, kk = flip ? kvol-1-k : k, Wk = weight[k] ([cin,cout]) or,
+ * with weight_transposed, the transpose of weight[k] stored as [cout,cin].
+ *   forward        : map = nbr,   flip 0, transposed 0
+ *   backward-data  : x = grad_out, map = nbr_t (or nbr with flip 1 for SubM), transposed 1,
+ *                    cin/cout swapped */
+int gga_sparse_conv_apply(const float* x, const int32_t* map, const float* weight, int64_t n_rows,
+                          int kvol, int cin, int cout, int flip, int weight_transposed, float* y,
+                          void* stream);
+/* grad_weight [kvol,cin,cout] = sum_r x[nbr[k][r]]^T grad_out[r]  (zero-filled here) */
+int gga_sparse_conv_wgrad(const float* x, const float* grad_out, const int32_t* nbr, int64_t n_rows,
+                          int kvol, int cin, int cout, float* grad_weight, void* stream);
+
+/* ------------------------------------------------------------------------- */
 /* a6/a7. Heat-map target splat on the device.                                */
 /* Replaces the per-object numpy gaussian + H2D copy + torch.max(out=) of     */
 /* mmdet3d/core/utils/gaussian.py:25-54 called from                           */

@@ -1,0 +1,127 @@
+"""Sparse 3D convolution (a3') on the GPU against the dense-conv3d restatement
+(oracle/sparse_ref.py): single layers (forward, backward-data, backward-weight), output-site
+sets, and the whole SparseEncoder of the GGA config on a small grid."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from gga_amd.sparse import SparseConv3d, SparseConvTensor, SubMConv3d
+from gga_amd.sparse_encoder import SparseEncoder
+from oracle import sparse_ref as SR
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _coords(batch, shape, n, seed, clustered=True):
+    g = torch.Generator().manual_seed(seed)
+    D, H, W = shape
+    out = []
+    for b in range(batch):
+        if clustered:       # blobs, so that neighbours exist
+            ctr = torch.stack([torch.randint(0, D, (8,), generator=g), torch.randint(0, H, (8,), generator=g),
+                               torch.randint(0, W, (8,), generator=g)], 1)
+            pts = ctr[torch.randint(0, 8, (n,), generator=g)] + torch.randint(-3, 4, (n, 3), generator=g)
+        else:
+            pts = torch.stack([torch.randint(0, D, (n,), generator=g), torch.randint(0, H, (n,), generator=g),
+                               torch.randint(0, W, (n,), generator=g)], 1)
+        pts[:, 0].clamp_(0, D - 1), pts[:, 1].clamp_(0, H - 1), pts[:, 2].clamp_(0, W - 1)
+        pts = torch.unique(pts, dim=0)
+        pts = pts[torch.randperm(len(pts), generator=g)]
+        out.append(torch.cat([torch.full((len(pts), 1), b), pts], 1))
+    return torch.cat(out).int()
+
+
+def _sorted_rows(feats, coors, shape):
+    D, H, W = shape
+    c = coors.long()
+    key = ((c[:, 0] * D + c[:, 1]) * H + c[:, 2]) * W + c[:, 3]
+    order = torch.argsort(key)
+    return feats[order], key[order]
+
+
+@pytest.mark.parametrize('cfg', [
+    dict(cls=SubMConv3d, cin=4, cout=16, k=3, s=1, p=1),
+    dict(cls=SubMConv3d, cin=32, cout=32, k=3, s=1, p=1),
+    dict(cls=SubMConv3d, cin=128, cout=128, k=3, s=1, p=1),
+    dict(cls=SparseConv3d, cin=16, cout=32, k=3, s=2, p=1),
+    dict(cls=SparseConv3d, cin=64, cout=128, k=3, s=2, p=(0, 1, 1)),
+    dict(cls=SparseConv3d, cin=128, cout=128, k=(3, 1, 1), s=(2, 1, 1), p=0),
+    dict(cls=SparseConv3d, cin=5, cout=24, k=3, s=1, p=0),
+])
+def test_single_conv_fwd_bwd(cfg):
+    torch.manual_seed(0)
+    shape, B = (11, 24, 20), 2
+    coors = _coords(B, shape, 300, seed=1)
+    feats = torch.randn(len(coors), cfg['cin'])
+    conv = cfg['cls'](cfg['cin'], cfg['cout'], cfg['k'], stride=cfg['s'], padding=cfg['p'], bias=False)
+    ref_conv = copy.deepcopy(conv)
+    xr = feats.clone().requires_grad_(True)
+    yr, cr, shr = SR.conv_ref(ref_conv, xr, coors, B, shape)
+    conv.to(DEV)
+    xg = feats.to(DEV).requires_grad_(True)
+    out = conv(SparseConvTensor(xg, coors.to(DEV), shape, B))
+    assert tuple(out.spatial_shape) == tuple(shr)
+    ys, ks = _sorted_rows(out.features.detach().cpu(), out.indices.cpu(), shr)
+    yrs, krs = _sorted_rows(yr.detach(), cr, shr)
+    assert torch.equal(ks, krs)                       # identical output site set (integer work: exact)
+    torch.testing.assert_close(ys, yrs, rtol=1e-4, atol=1e-4)
+    # backward with a gradient defined per output CELL (orders differ between the two)
+    gmap = torch.randn(B, cfg['cout'], *shr)
+    def g_at(c):
+        c = c.long()
+        return gmap[c[:, 0], :, c[:, 1], c[:, 2], c[:, 3]]
+    yr.backward(g_at(cr))
+    out.features.backward(g_at(out.indices.cpu()).to(DEV))
+    torch.testing.assert_close(xg.grad.cpu(), xr.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(conv.weight.grad.cpu(), ref_conv.weight.grad, rtol=1e-4, atol=2e-4)
+
+
+def test_dense_and_replace_feature():
+    shape, B = (5, 12, 8), 3
+    coors = _coords(B, shape, 60, seed=3, clustered=False)
+    feats = torch.randn(len(coors), 16)
+    x = SparseConvTensor(feats.to(DEV), coors.to(DEV), shape, B)
+    d = x.dense().cpu()
+    assert torch.equal(d, SR._dense(feats, coors, B, shape))
+    y = x.replace_feature(x.features * 2)
+    assert y._level is x._level and torch.equal(y.dense().cpu(), d * 2)
+
+
+def test_sparse_encoder_gga_config_vs_dense_reference():
+    torch.manual_seed(0)
+    shape, B = (41, 40, 32), 2
+    enc = SparseEncoder(in_channels=4, sparse_shape=list(shape), output_channels=128, order=('conv', 'norm', 'act'),
+                        encoder_channels=((16, 16, 32), (32, 32, 64), (64, 64, 128), (128, 128)),
+                        encoder_paddings=((0, 0, 1), (0, 0, 1), (0, 0, [0, 1, 1]), (0, 0)), block_type='basicblock')
+    enc.train()
+    ref = copy.deepcopy(enc)
+    coors = _coords(B, shape, 900, seed=5)
+    feats = torch.randn(len(coors), 4)
+    yr, _ = SR.sparse_encoder_reference(ref, feats, coors, B)
+    enc.to(DEV)
+    y = enc(feats.to(DEV), coors.to(DEV), B)
+    assert y.shape == yr.shape == (B, 256, 5, 4)
+    torch.testing.assert_close(y.detach().cpu(), yr.detach(), rtol=1e-3, atol=1e-3)
+    g = torch.randn_like(yr)
+    yr.backward(g)
+    y.backward(g.to(DEV))
+    for (n1, p1), (n2, p2) in zip(enc.named_parameters(), ref.named_parameters()):
+        err = float((p1.grad.cpu() - p2.grad).norm() / (p2.grad.norm() + 1e-12))
+        assert err < 2e-2, (n1, err)      # 21 fp32 conv+BN layers deep; the last levels hold few sites
+    for (n1, b1), (n2, b2) in zip(enc.named_buffers(), ref.named_buffers()):
+        torch.testing.assert_close(b1.cpu(), b2, rtol=1e-4, atol=1e-5, msg=n1)
+
+
+def test_reference_shape_test():
+    # the reference's own (shape-only) sparse-encoder test: tests/test_models/test_common_modules/
+    # test_middle_encoders.py:8-27, with unique coordinates
+    enc = SparseEncoder(in_channels=5, sparse_shape=[40, 1024, 1024], order=('conv', 'norm', 'act'),
+                        encoder_channels=((16, 16, 32), (32, 32, 64), (64, 64, 128), (128, 128)),
+                        encoder_paddings=((1, 1, 1), (1, 1, 1), (1, 1, 1), (1, 1, 1), (1, 1, 1)),
+                        block_type='basicblock').to(DEV)
+    coors = _coords(4, (40, 1024, 1024), 50000, seed=9, clustered=False).to(DEV)
+    ret = enc(torch.rand(len(coors), 5, device=DEV), coors, 4)
+    assert ret.shape == torch.Size([4, 256, 128, 128])

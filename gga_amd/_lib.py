@@ -61,7 +61,8 @@ SIGNATURES = {
     'gga_sparse_out_sites_workspace_bytes': (sz, [i64, i32]),
     'gga_sparse_conv_out_sites': (i32, [vp, i64, i32, I3, I3, I3, I3, I3, vp, i64, vp, vp, sz, vp, sz, vp]),
     'gga_sparse_rulebook': (i32, [vp, i64, vp, i64, i32, I3, I3, I3, I3, I3, vp, i64, vp, i64, vp, vp, vp]),
-    'gga_sparse_conv_apply': (i32, [vp, vp, vp, i64, i32, i32, i32, i32, i32, vp, vp]),
+    'gga_sparse_rowmask': (i32, [vp, i64, i32, vp, vp]),
+    'gga_sparse_conv_apply': (i32, [vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp, vp]),
     'gga_sparse_conv_wgrad': (i32, [vp, vp, vp, i64, i32, i32, i32, vp, vp]),
     'gga_heatmap_splat': (i32, [vp, i32, i32, i32, vp, i32, vp, vp, i32, vp]),
     'gga_focal_loss_workspace_bytes': (sz, [i64]),

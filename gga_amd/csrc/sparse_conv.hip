@@ -18,6 +18,8 @@
 //              transposed map / transposed weights.
 //   bwd weight one workgroup per (kernel offset, row chunk): compacts the valid pairs of the
 //              chunk, accumulates X^T G in registers, one float atomicAdd per weight per chunk.
+#include <stdlib.h>
+
 #include "gga_common.h"
 
 #define SP_EMPTY 0xFFFFFFFFFFFFFFFFull
@@ -418,21 +420,180 @@ __global__ __launch_bounds__(256) void sp_conv_kernel(const float* __restrict__ 
     }
 }
 
-extern "C" int gga_sparse_conv_apply(const float* x, const int32_t* map, const float* weight, int64_t n_rows, int kvol,
-                                     int cin, int cout, int flip, int weight_transposed, float* y, void* stream_) {
+
+// ---- MFMA version ------------------------------------------------------------------------
+// v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD): a 256-thread workgroup owns 128 output
+// rows (taken through `perm`, which orders rows by their neighbour bit mask so that a tile's rows
+// use the same kernel offsets) x NT*32 output channels; wave w owns rows 32w..32w+31 and all
+// NT column tiles (NT*16 accumulator registers). Offsets whose bit is clear in the OR of the
+// tile's row masks are skipped without touching memory. Per (offset, 32-channel chunk): the
+// gathered input rows [128 x 32] and the weight slice [32 x NT*32] are staged in LDS (global
+// loads for the next chunk are issued before the MFMAs of the current one).
+#define MF_TM 128
+#define MF_TK 32
+typedef float mf_v16 __attribute__((ext_vector_type(16)));
+
+template <int NT>
+__global__ __launch_bounds__(256) void sp_conv_mfma_kernel(const float* __restrict__ X, const int32_t* __restrict__ map,
+                                                          const float* __restrict__ W,
+                                                          const int32_t* __restrict__ perm,
+                                                          const uint32_t* __restrict__ rowmask, int64_t n_rows,
+                                                          int kvol, int cin, int cout, int flip,
+                                                          float* __restrict__ Y) {
+    constexpr int CO = NT * 32;
+    __shared__ float As[MF_TM][MF_TK + 1];
+    __shared__ float Bs[MF_TK][CO];
+    __shared__ int prow[MF_TM];
+    __shared__ uint32_t tmask_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t r0 = (int64_t)blockIdx.x * MF_TM;
+    if (tid == 0) tmask_s = 0;
+    __syncthreads();
+    if (tid < MF_TM) {
+        const int64_t r = r0 + tid;
+        int pr = -1;
+        if (r < n_rows) pr = perm ? perm[r] : (int)r;
+        prow[tid] = pr;
+        uint32_t m = 0;
+        if (pr >= 0) m = rowmask ? rowmask[pr] : 0xFFFFFFFFu;
+        if (m) atomicOr(&tmask_s, m);
+    }
+    __syncthreads();
+    const uint32_t tmask = tmask_s;
+    mf_v16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
+
+    // staging roles: A: thread loads float4 #q of row ar (2 rows per thread: ar, ar+64)
+    const int ar = tid >> 2, aq = tid & 3;         // 64 rows x 4 quads per pass, 2 passes; 8 floats per quad-pair
+    const int nchunks = (cin + MF_TK - 1) / MF_TK;
+    for (int k = 0; k < kvol; ++k) {
+        const int kk = flip ? (kvol - 1 - k) : k;
+        if (kvol <= 32 && !((tmask >> kk) & 1u)) continue;
+        const int32_t* mk = map + (int64_t)kk * n_rows;
+        const int p0 = prow[ar], p1 = prow[ar + 64];
+        const int in0 = p0 >= 0 ? mk[p0] : -1, in1 = p1 >= 0 ? mk[p1] : -1;
+        const float* Wk = W + (int64_t)k * cin * cout;
+        for (int ch = 0; ch < nchunks; ++ch) {
+            const int c0 = ch * MF_TK;
+            // ---- global -> registers
+            float4 a0[2], a1[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int cc = c0 + (aq + 4 * h) * 4;
+                a0[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+                a1[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (cc + 3 < cin) {
+                    if (in0 >= 0) a0[h] = *reinterpret_cast<const float4*>(X + (int64_t)in0 * cin + cc);
+                    if (in1 >= 0) a1[h] = *reinterpret_cast<const float4*>(X + (int64_t)in1 * cin + cc);
+                } else if (cc < cin) {       // channel tail (cin not a multiple of 4)
+                    float t0[4] = {0, 0, 0, 0}, t1[4] = {0, 0, 0, 0};
+                    for (int e = 0; e < 4 && cc + e < cin; ++e) {
+                        if (in0 >= 0) t0[e] = X[(int64_t)in0 * cin + cc + e];
+                        if (in1 >= 0) t1[e] = X[(int64_t)in1 * cin + cc + e];
+                    }
+                    a0[h] = make_float4(t0[0], t0[1], t0[2], t0[3]);
+                    a1[h] = make_float4(t1[0], t1[1], t1[2], t1[3]);
+                }
+            }
+            float breg[(MF_TK * CO) / 256];
+#pragma unroll
+            for (int e = 0; e < (MF_TK * CO) / 256; ++e) {
+                const int t = tid + 256 * e;
+                const int cc = t / CO, oo = t - cc * CO;
+                breg[e] = (c0 + cc < cin && oo < cout) ? Wk[(int64_t)(c0 + cc) * cout + oo] : 0.0f;
+            }
+            __syncthreads();                 // previous chunk's MFMAs are done reading LDS
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int cb = (aq + 4 * h) * 4;
+                As[ar][cb] = a0[h].x; As[ar][cb + 1] = a0[h].y; As[ar][cb + 2] = a0[h].z; As[ar][cb + 3] = a0[h].w;
+                As[ar + 64][cb] = a1[h].x; As[ar + 64][cb + 1] = a1[h].y; As[ar + 64][cb + 2] = a1[h].z; As[ar + 64][cb + 3] = a1[h].w;
+            }
+#pragma unroll
+            for (int e = 0; e < (MF_TK * CO) / 256; ++e) {
+                const int t = tid + 256 * e;
+                Bs[t / CO][t % CO] = breg[e];
+            }
+            __syncthreads();
+            // ---- 16 k-steps of 2: A frag lane -> (row 32w + lane%32, k = 2s + lane/32)
+            const int arow = wave * 32 + (lane & 31), khalf = lane >> 5;
+#pragma unroll
+            for (int s2 = 0; s2 < MF_TK / 2; ++s2) {
+                const float a = As[arow][2 * s2 + khalf];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const float b = Bs[2 * s2 + khalf][t * 32 + (lane & 31)];
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // D layout of 32x32x2: register v of lane l holds row (v/4)*8 + (l/32)*4 + v%4, column l%32
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+        const int lr = wave * 32 + (v >> 2) * 8 + (lane >> 5) * 4 + (v & 3);
+        const int pr = prow[lr];
+        if (pr < 0) continue;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int o = t * 32 + (lane & 31);
+            if (o < cout) Y[(int64_t)pr * cout + o] = acc[t][v];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void sp_rowmask_kernel(const int32_t* __restrict__ map, int64_t n, int kvol,
+                                                        uint32_t* __restrict__ mask) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n) return;
+    uint32_t m = 0;
+    for (int k = 0; k < kvol && k < 32; ++k) m |= (map[(int64_t)k * n + r] >= 0 ? 1u : 0u) << k;
+    mask[r] = m;
+}
+
+extern "C" int gga_sparse_rowmask(const int32_t* map, int64_t n_rows, int kvol, uint32_t* mask, void* stream) {
+    GGA_REQUIRE(map && mask && n_rows >= 1 && kvol >= 1, "gga_sparse_rowmask: bad arguments");
+    hipLaunchKernelGGL(sp_rowmask_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, map,
+                       n_rows, kvol, mask);
+    GGA_CHECK_LAUNCH("sp_rowmask_kernel");
+    return GGA_OK;
+}
+
+static int sp_conv_variant() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("GGA_SPCONV_VARIANT"); v = e ? atoi(e) : 1; }
+    return v;
+}
+
+extern "C" int gga_sparse_conv_apply(const float* x, const int32_t* map, const float* weight, const int32_t* perm,
+                                     const uint32_t* rowmask, int64_t n_rows, int kvol, int cin, int cout, int flip,
+                                     float* y, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     GGA_REQUIRE(x && map && weight && y, "gga_sparse_conv_apply: null pointer argument");
     GGA_REQUIRE(n_rows >= 1 && kvol >= 1 && cin >= 1 && cout >= 1 && cout <= 128,
                 "gga_sparse_conv_apply: bad sizes (rows=%lld kvol=%d cin=%d cout=%d; cout <= 128)", (long long)n_rows,
                 kvol, cin, cout);
-    const dim3 grid((unsigned)((n_rows + SP_TM - 1) / SP_TM)), block(256);
-#define SP_LAUNCH(CO) hipLaunchKernelGGL(sp_conv_kernel<CO>, grid, block, 0, stream, x, map, weight, n_rows, kvol, cin, cout, flip, weight_transposed, y)
-    if (cout <= 16) SP_LAUNCH(16);
-    else if (cout <= 32) SP_LAUNCH(32);
-    else if (cout <= 64) SP_LAUNCH(64);
-    else SP_LAUNCH(128);
+    if (sp_conv_variant() == 0) {
+        const dim3 grid((unsigned)((n_rows + SP_TM - 1) / SP_TM)), block(256);
+#define SP_LAUNCH(CO) hipLaunchKernelGGL(sp_conv_kernel<CO>, grid, block, 0, stream, x, map, weight, n_rows, kvol, cin, cout, flip, 0, y)
+        if (cout <= 16) SP_LAUNCH(16);
+        else if (cout <= 32) SP_LAUNCH(32);
+        else if (cout <= 64) SP_LAUNCH(64);
+        else SP_LAUNCH(128);
 #undef SP_LAUNCH
-    GGA_CHECK_LAUNCH("sp_conv_kernel");
+        GGA_CHECK_LAUNCH("sp_conv_kernel");
+        return GGA_OK;
+    }
+    const dim3 grid((unsigned)((n_rows + MF_TM - 1) / MF_TM)), block(256);
+#define MF_LAUNCH(NT) hipLaunchKernelGGL(sp_conv_mfma_kernel<NT>, grid, block, 0, stream, x, map, weight, perm, rowmask, n_rows, kvol, cin, cout, flip, y)
+    if (cout <= 32) MF_LAUNCH(1);
+    else if (cout <= 64) MF_LAUNCH(2);
+    else MF_LAUNCH(4);
+#undef MF_LAUNCH
+    GGA_CHECK_LAUNCH("sp_conv_mfma_kernel");
     return GGA_OK;
 }
 

@@ -28,6 +28,21 @@ def _i3(v):
     return (C.c_int32 * 3)(*v)
 
 
+class _Rulebook:
+    """Gather map [kvol, n_rows] + per-row offset bit mask + mask-sorted processing order."""
+
+    def __init__(self, nbr):
+        self.nbr = nbr
+        kvol, n = nbr.shape
+        self.mask = self.perm = None
+        if kvol <= 32:
+            self.mask = torch.empty(n, dtype=torch.int32, device=nbr.device)
+            check(_lib.lib().gga_sparse_rowmask(F._p(nbr), n, kvol, F._p(self.mask), F._stream()), 'gga_sparse_rowmask')
+            # index preprocessing (once per level, shared by every conv on it): rows with the same
+            # neighbour pattern become adjacent, so a 128-row tile skips the offsets none of them uses
+            self.perm = torch.argsort(self.mask).int()
+
+
 class _Level:
     """One resolution level: coordinates + hash index + cached rule books."""
 
@@ -60,6 +75,7 @@ class _Level:
                                                  _i3(self.shape), _i3(self.shape), _i3(kernel), _i3((1, 1, 1)), _i3(pad),
                                                  F._p(self.index), self.index_n, None, 0, F._p(nbr), None,
                                                  F._stream()), 'gga_sparse_rulebook')
+            nbr = _Rulebook(nbr)
             self._subm[kernel] = nbr
         return nbr
 
@@ -90,7 +106,7 @@ class _Level:
                                     _i3(out.shape), _i3(kernel), _i3(stride), _i3(padding), F._p(self.index),
                                     self.index_n, F._p(out_index), out.index_n, F._p(nbr), F._p(nbr_t), F._stream()),
               'gga_sparse_rulebook')
-        return out, nbr, nbr_t
+        return out, _Rulebook(nbr), _Rulebook(nbr_t)
 
 
 class SparseConvTensor:
@@ -161,34 +177,40 @@ class SparseSequential(SparseModule):
 
 
 class _SparseConvFn(torch.autograd.Function):
+    """features [n_in,Cin] x weight [kvol,Cin,Cout] -> [n_out,Cout] through rule book ``rb``
+    (``rb_t`` = transposed rule book for the backward-data pass, None for submanifold convs)."""
+
     @staticmethod
-    def forward(ctx, feats, weight, nbr, nbr_t, n_out):
+    def forward(ctx, feats, weight, rb, rb_t, n_out):
         feats, w = feats.contiguous(), weight.contiguous()
-        kvol = nbr.shape[0]
+        kvol = rb.nbr.shape[0]
         cin, cout = w.shape[-2], w.shape[-1]
         y = torch.empty((n_out, cout), dtype=torch.float32, device=feats.device)
-        check(_lib.lib().gga_sparse_conv_apply(F._p(feats), F._p(nbr), F._p(w), n_out, kvol, cin, cout, 0, 0, F._p(y),
-                                               F._stream()), 'gga_sparse_conv_apply')
-        ctx.save_for_backward(feats, w, nbr, nbr_t)
+        check(_lib.lib().gga_sparse_conv_apply(F._p(feats), F._p(rb.nbr), F._p(w), F._p(rb.perm), F._p(rb.mask), n_out,
+                                               kvol, cin, cout, 0, F._p(y), F._stream()), 'gga_sparse_conv_apply')
+        ctx.save_for_backward(feats, w)
+        ctx.rb, ctx.rb_t = rb, rb_t
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        feats, w, nbr, nbr_t = ctx.saved_tensors
+        feats, w = ctx.saved_tensors
+        rb, rb_t = ctx.rb, ctx.rb_t
         gy = gy.contiguous()
-        kvol, n_out = nbr.shape
+        kvol, n_out = rb.nbr.shape
         n_in = feats.shape[0]
         cin, cout = w.shape[-2], w.shape[-1]
         L = _lib.lib()
         gx = gw = None
         if ctx.needs_input_grad[0]:
             gx = torch.empty_like(feats)
-            tmap, flip = (nbr_t, 0) if nbr_t is not None else (nbr, 1)      # SubM: transposed map = reversed offsets
-            check(L.gga_sparse_conv_apply(F._p(gy), F._p(tmap), F._p(w), n_in, kvol, cout, cin, flip, 1, F._p(gx),
-                                          F._stream()), 'gga_sparse_conv_apply(bwd data)')
+            wt = w.transpose(1, 2).contiguous()                       # [kvol, Cout, Cin]
+            tb, flip = (rb_t, 0) if rb_t is not None else (rb, 1)     # SubM: transposed map = reversed offsets
+            check(L.gga_sparse_conv_apply(F._p(gy), F._p(tb.nbr), F._p(wt), F._p(tb.perm), F._p(tb.mask), n_in, kvol,
+                                          cout, cin, flip, F._p(gx), F._stream()), 'gga_sparse_conv_apply(bwd data)')
         if ctx.needs_input_grad[1]:
             gw = torch.empty_like(w)
-            check(L.gga_sparse_conv_wgrad(F._p(feats), F._p(gy), F._p(nbr), n_out, kvol, cin, cout, F._p(gw),
+            check(L.gga_sparse_conv_wgrad(F._p(feats), F._p(gy), F._p(rb.nbr), n_out, kvol, cin, cout, F._p(gw),
                                           F._stream()), 'gga_sparse_conv_wgrad')
         return gx, gw, None, None, None
 

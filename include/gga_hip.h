@@ -197,14 +197,20 @@ int gga_sparse_rulebook(const int32_t* out_coors, int64_t n_out, const int32_t* 
                         int64_t in_index_n, const void* out_index, int64_t out_index_n, int32_t* nbr,
                         int32_t* nbr_t, void* stream);
 
-/* y[r,:] = sum_k x[map[kk][r],:] @ Wk, kk = flip ? kvol-1-k : k, Wk = weight[k] ([cin,cout]) or,
- * with weight_transposed, the transpose of weight[k] stored as [cout,cin].
- *   forward        : map = nbr,   flip 0, transposed 0
- *   backward-data  : x = grad_out, map = nbr_t (or nbr with flip 1 for SubM), transposed 1,
- *                    cin/cout swapped */
-int gga_sparse_conv_apply(const float* x, const int32_t* map, const float* weight, int64_t n_rows,
-                          int kvol, int cin, int cout, int flip, int weight_transposed, float* y,
-                          void* stream);
+/* Bit k of mask[r] is set when map[k][r] >= 0 (kvol <= 32). Sorting rows by this mask gives
+ * tiles whose rows use the same kernel offsets; the conv kernel skips the others. */
+int gga_sparse_rowmask(const int32_t* map, int64_t n_rows, int kvol, uint32_t* mask, void* stream);
+
+/* y[r,:] = sum_k x[map[kk][r],:] @ weight[k], kk = flip ? kvol-1-k : k; weight[k] is [cin,cout]
+ * row major (pass the per-offset transposed weights for the backward-data pass).
+ *   forward        : map = nbr,   flip 0
+ *   backward-data  : x = grad_out, map = nbr_t (or nbr with flip 1 for SubM), weight = W^T,
+ *                    cin/cout swapped
+ * perm (optional, [n_rows]): processing order of the rows (e.g. argsort of the row masks);
+ * rowmask (optional, [n_rows]): gga_sparse_rowmask of `map`. Output rows are not permuted. */
+int gga_sparse_conv_apply(const float* x, const int32_t* map, const float* weight, const int32_t* perm,
+                          const uint32_t* rowmask, int64_t n_rows, int kvol, int cin, int cout, int flip,
+                          float* y, void* stream);
 /* grad_weight [kvol,cin,cout] = sum_r x[nbr[k][r]]^T grad_out[r]  (zero-filled here) */
 int gga_sparse_conv_wgrad(const float* x, const float* grad_out, const int32_t* nbr, int64_t n_rows,
                           int kvol, int cin, int cout, float* grad_weight, void* stream);

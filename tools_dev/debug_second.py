@@ -33,3 +33,21 @@ for t in range(3):
 data = dict(b, points=pts)
 losses = model.pts_bbox_head.loss(data['gt_bboxes_3d'], data['gt_labels_3d'], outs, data['GGA_boxes_img'], data['GGA_lidar2img'], data['GGA_init_pseudo_labels'], data['GGA_bdry_masks'], data['GGA_in_box_points'], data['img_metas'])
 print({k: float(v) for k, v in losses.items()})
+print('--- neighbour density per level (valid offsets / kvol) ---')
+x = SparseConvTensor(f, c.int(), enc.sparse_shape, 2)
+x = enc.conv_input(x)
+for i, layer in enumerate(enc.encoder_layers):
+    for j, m in enumerate(layer):
+        x = m(x)
+    lv = x._level
+    nbr = lv.subm_rulebook((3, 3, 3))
+    valid = (nbr >= 0)
+    mask = (valid.long() << torch.arange(27, device=nbr.device)[:, None]).sum(0)
+    print(f'level after stage {i+1}: n={lv.n} avg valid offsets {float(valid.float().sum(0).mean()):.2f} / 27, distinct masks {len(torch.unique(mask))}')
+    srt = torch.sort(mask)[0]
+    t = srt[: (len(srt) // 64) * 64].view(-1, 64)
+    union = torch.zeros(t.shape[0], dtype=torch.long, device=t.device)
+    for b in range(64):
+        union |= t[:, b]
+    pc = sum(((union >> k) & 1) for k in range(27)).float().mean()
+    print(f'   mask-sorted 64-row tiles: avg offsets touched per tile {float(pc):.2f}')

@@ -665,6 +665,95 @@ __global__ __launch_bounds__(256) void sp_conv_wgrad_kernel(const float* __restr
     }
 }
 
+
+// MFMA version of the weight gradient: dW[k] (CI x CO) = Xp^T (CI x pairs) * Gp (pairs x CO) for the
+// compacted valid pairs of one 2048-row chunk; 32x32 tiles are dealt to the 4 waves
+// (tile t = i*NJ + j -> wave t / TPW), 32 pairs per LDS stage, one atomicAdd per weight per chunk.
+template <int NI, int NJ>
+__global__ __launch_bounds__(256) void sp_conv_wgrad_mfma_kernel(const float* __restrict__ X, const float* __restrict__ G,
+                                                                const int32_t* __restrict__ map, int64_t n_rows,
+                                                                int cin, int cout, float* __restrict__ dW) {
+    constexpr int CI = NI * 32, CO = NJ * 32;
+    constexpr int TILES = NI * NJ;
+    constexpr int TPW = (TILES + 3) / 4;             // tiles per wave
+    __shared__ float Xs[32][CI];
+    __shared__ float Gs[32][CO];
+    __shared__ int pin[SP_WCHUNK];
+    __shared__ int pout[SP_WCHUNK];
+    __shared__ int npairs;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int k = blockIdx.y;
+    const int64_t r0 = (int64_t)blockIdx.x * SP_WCHUNK;
+    if (tid == 0) npairs = 0;
+    __syncthreads();
+    for (int t = tid; t < SP_WCHUNK; t += 256) {
+        const int64_t r = r0 + t;
+        const int v = r < n_rows ? map[(int64_t)k * n_rows + r] : -1;
+        if (v >= 0) { const int p = atomicAdd(&npairs, 1); pin[p] = v; pout[p] = t; }
+    }
+    __syncthreads();
+    const int np = npairs;
+    if (np == 0) return;
+    mf_v16 acc[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
+    const bool vec_x = (cin % 4 == 0), vec_g = (cout % 4 == 0);
+    for (int p0 = 0; p0 < np; p0 += 32) {
+        // stage 32 pairs: X rows (gathered) and G rows
+        for (int t = tid; t < 32 * (CI / 4); t += 256) {
+            const int pp = t / (CI / 4), q = (t - pp * (CI / 4)) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p0 + pp < np) {
+                const float* src = X + (int64_t)pin[p0 + pp] * cin + q;
+                if (vec_x && q + 3 < cin) v = *reinterpret_cast<const float4*>(src);
+                else { float e[4] = {0, 0, 0, 0}; for (int j = 0; j < 4 && q + j < cin; ++j) e[j] = src[j]; v = make_float4(e[0], e[1], e[2], e[3]); }
+            }
+            *reinterpret_cast<float4*>(&Xs[pp][q]) = v;
+        }
+        for (int t = tid; t < 32 * (CO / 4); t += 256) {
+            const int pp = t / (CO / 4), q = (t - pp * (CO / 4)) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p0 + pp < np) {
+                const float* src = G + (r0 + pout[p0 + pp]) * cout + q;
+                if (vec_g && q + 3 < cout) v = *reinterpret_cast<const float4*>(src);
+                else { float e[4] = {0, 0, 0, 0}; for (int j = 0; j < 4 && q + j < cout; ++j) e[j] = src[j]; v = make_float4(e[0], e[1], e[2], e[3]); }
+            }
+            *reinterpret_cast<float4*>(&Gs[pp][q]) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s2 = 0; s2 < 16; ++s2) {
+            const int pp = 2 * s2 + (lane >> 5);
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) {
+                const int tile = wave * TPW + t;
+                if (tile < TILES) {
+                    const int i = tile / NJ, j = tile - i * NJ;
+                    const float a = Xs[pp][i * 32 + (lane & 31)];
+                    const float b = Gs[pp][j * 32 + (lane & 31)];
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    float* dWk = dW + (int64_t)k * cin * cout;
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const int tile = wave * TPW + t;
+        if (tile >= TILES) continue;
+        const int i = tile / NJ, j = tile - i * NJ;
+        const int co = j * 32 + (lane & 31);
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int ci = i * 32 + (v >> 2) * 8 + (lane >> 5) * 4 + (v & 3);
+            if (ci < cin && co < cout && acc[t][v] != 0.0f) atomicAdd(&dWk[(int64_t)ci * cout + co], acc[t][v]);
+        }
+    }
+}
+
 extern "C" int gga_sparse_conv_wgrad(const float* x, const float* grad_out, const int32_t* map, int64_t n_rows,
                                      int kvol, int cin, int cout, float* grad_weight, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
@@ -673,19 +762,16 @@ extern "C" int gga_sparse_conv_wgrad(const float* x, const float* grad_out, cons
                 "gga_sparse_conv_wgrad: bad sizes (cin, cout <= 128)");
     GGA_CHECK_HIP(hipMemsetAsync(grad_weight, 0, (size_t)kvol * cin * cout * sizeof(float), stream), "wgrad memset");
     const dim3 grid((unsigned)((n_rows + SP_WCHUNK - 1) / SP_WCHUNK), kvol), block(256);
-#define SP_WL(CI, CO) hipLaunchKernelGGL((sp_conv_wgrad_kernel<CI, CO>), grid, block, 0, stream, x, grad_out, map, n_rows, cin, cout, grad_weight)
-    const int ci = cin <= 16 ? 16 : cin <= 32 ? 32 : cin <= 64 ? 64 : 128;
-    const int co = cout <= 16 ? 16 : cout <= 32 ? 32 : cout <= 64 ? 64 : 128;
-    if (ci == 16 && co == 16) SP_WL(16, 16);
-    else if (ci == 16 && co == 32) SP_WL(16, 32);
-    else if (ci == 32 && co == 32) SP_WL(32, 32);
-    else if (ci == 32 && co == 64) SP_WL(32, 64);
-    else if (ci == 64 && co == 64) SP_WL(64, 64);
-    else if (ci == 64 && co == 128) SP_WL(64, 128);
-    else if (ci == 128 && co == 128) SP_WL(128, 128);
-    else if (ci <= 64 && co <= 64) SP_WL(64, 64);
-    else SP_WL(128, 128);
-#undef SP_WL
+    const int ni = (cin + 31) / 32, nj = (cout + 31) / 32;
+#define MW(NI, NJ) hipLaunchKernelGGL((sp_conv_wgrad_mfma_kernel<NI, NJ>), grid, block, 0, stream, x, grad_out, map, n_rows, cin, cout, grad_weight)
+    if (ni == 1 && nj == 1) MW(1, 1);
+    else if (ni == 1 && nj == 2) MW(1, 2);
+    else if (ni == 2 && nj == 2) MW(2, 2);
+    else if (ni == 2 && nj == 4) MW(2, 4);
+    else if (ni == 4 && nj == 4) MW(4, 4);
+    else if (ni <= 2 && nj <= 2) MW(2, 2);
+    else MW(4, 4);
+#undef MW
     GGA_CHECK_LAUNCH("sp_conv_wgrad_kernel");
     return GGA_OK;
 }

@@ -1,0 +1,25 @@
+#!/usr/bin/env python
+"""Steady-state per-step kernel breakdown from a rocprofv3 --kernel-trace CSV: only the last
+`--steps` train steps are counted (the first ones contain MIOpen's algorithm search)."""
+import argparse, collections, csv, glob, sys
+ap = argparse.ArgumentParser()
+ap.add_argument('dir'); ap.add_argument('--steps', type=int, default=3); ap.add_argument('--top', type=int, default=30)
+ap.add_argument('--out')
+a = ap.parse_args()
+f = glob.glob(a.dir + '/**/*_kernel_trace.csv', recursive=True)[0]
+rows = list(csv.DictReader(open(f)))
+starts = sorted(int(r['Start_Timestamp']) for r in rows if r['Kernel_Name'].startswith('vox_insert_kernel'))
+t0 = starts[-a.steps]
+t1 = max(int(r['End_Timestamp']) for r in rows)
+agg = collections.defaultdict(lambda: [0, 0])
+for r in rows:
+    if int(r['Start_Timestamp']) >= t0:
+        x = agg[r['Kernel_Name'][:110]]; x[0] += int(r['End_Timestamp']) - int(r['Start_Timestamp']); x[1] += 1
+tot = sum(x[0] for x in agg.values())
+lines = [f'# steady state over the last {a.steps} steps: wall {(t1-t0)/1e6/a.steps:.2f} ms/step, kernel time {tot/1e6/a.steps:.2f} ms/step',
+         'ms_per_step,percent,calls_per_step,avg_us,kernel']
+for k, x in sorted(agg.items(), key=lambda kv: -kv[1][0])[:a.top]:
+    lines.append(f'{x[0]/1e6/a.steps:.3f},{100*x[0]/tot:.2f},{x[1]/a.steps:.1f},{x[0]/x[1]/1e3:.1f},"{k}"')
+print('\n'.join(lines))
+if a.out:
+    open(a.out, 'w').write('\n'.join(lines) + '\n')

@@ -110,12 +110,15 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=16, help='frames per GPU')
     ap.add_argument('--config', default=os.path.join(REPO, 'configs', 'gga', 'gga_kitti_pointpillars_config.py'))
-    ap.add_argument('--channels-last', action='store_true')
+    ap.add_argument('--nchw', action='store_true',
+                    help='keep the reference NCHW memory layout for the BEV trunk (default: channels-last memory, '
+                         'same logical tensors and values)')
     ap.add_argument('--head-init-scale', type=float, default=0.05,
                     help='damp the random init of the regression heads\' output convs (see damp_head_init)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     args = ap.parse_args()
+    args.channels_last = not args.nchw
 
     import gga_amd  # noqa: F401
     from gga_amd import Config, build_model, synthetic
@@ -124,11 +127,11 @@ def main():
     rank, world, local_rank = init_dist()
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
     assert torch.cuda.is_available(), 'bench.py needs an MI355X (the product has no CPU path)'
-    device = torch.device('cuda', local_rank)
+    device = torch.device('cuda', local_rank % torch.cuda.device_count())
     torch.cuda.set_device(device)
 
     cfg = Config.fromfile(args.config)
-    if args.channels_last:
+    if args.channels_last and cfg.model.pts_middle_encoder.type == 'PointPillarsScatter':
         cfg.model.pts_middle_encoder['channels_last'] = True
     torch.manual_seed(0)
     model = build_model(cfg.model).to(device)

@@ -222,8 +222,7 @@ class CenterHead_GGA(nn.Module):
         for t in range(T):
             for b, sel in per_task[t]:
                 for kk, j in enumerate(sel):
-                    p = GGA_in_box_points[b][j]
-                    p = p.numpy() if isinstance(p, torch.Tensor) else np.asarray(p)
+                    p = _to_np(GGA_in_box_points[b][j])
                     xy.append(p[:, :2])
                     counts.append(len(p))
                     slots.append(b * K + kk)

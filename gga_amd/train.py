@@ -57,9 +57,10 @@ def init_dist():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world > 1 and not dist.is_initialized():
-        backend = 'nccl' if torch.cuda.is_available() else 'gloo'
-        if backend == 'nccl':
-            torch.cuda.set_device(local_rank)
+        # RCCL registers as 'nccl' on ROCm; GGA_DIST_BACKEND=gloo is for single-GPU / CPU testing
+        backend = os.environ.get('GGA_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local_rank % torch.cuda.device_count())
         dist.init_process_group(backend=backend)
     return rank, world, local_rank
 
@@ -68,9 +69,9 @@ def build_ddp(model, device, find_unused_parameters=False):
     """MMDistributedDataParallel(device_ids=[LOCAL_RANK], broadcast_buffers=False,
     find_unused_parameters=...) (apis/train.py:222-231)."""
     from torch.nn.parallel import DistributedDataParallel as DDP
-    if device.type == 'cuda':
-        return DDP(model, device_ids=[device.index], broadcast_buffers=False,
-                   find_unused_parameters=find_unused_parameters)
+    # device_ids=None: the module already lives on this rank's device, and DDP must NOT move the
+    # keyword inputs — the GGA label / in-box-point tensors are consumed on the host by
+    # CenterHead_GGA.pack_targets (moving them to the GPU would cost an H2D and a syncing D2H).
     return DDP(model, broadcast_buffers=False, find_unused_parameters=find_unused_parameters)
 
 

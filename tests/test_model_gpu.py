@@ -109,3 +109,25 @@ def test_second_config_train_step_runs_and_learns():
     last = float(out['loss'])
     assert np.isfinite(first) and np.isfinite(last) and last < first
     assert len([k for k in out['log_vars'] if k.startswith('task')]) == 18
+
+
+def test_two_rank_ddp_on_one_gpu():
+    """The real detector under DistributedDataParallel with two ranks (gloo, both on this GPU):
+    exercises the custom autograd Functions inside DDP's reducer hooks, host-side label inputs
+    and bench.py's multi-rank timing path. RCCL itself needs >= 2 GPUs (driver-side run)."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, GGA_DIST_BACKEND='gloo')
+    out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+                          '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.join(REPO, 'bench.py'),
+                          '--gpus', '2', '--steps', '2', '--warmup', '1', '--batch', '2', '--no-roofline'],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith('{')][-1]
+    res = json.loads(line)
+    assert res['n_gpus'] == 2 and res['value'] > 0 and res['config']['global_batch'] == 4

@@ -257,21 +257,26 @@ __global__ __launch_bounds__(256) void pfn_bwd_kernel(const float4* __restrict__
     }
 }
 
-__global__ __launch_bounds__(64) void pfn_bwd_final_kernel(const float* __restrict__ partials, int nblocks,
-                                                          double rows, const float* __restrict__ weight,
-                                                          const float* __restrict__ gamma,
-                                                          const double* __restrict__ saved,
-                                                          float* __restrict__ grad_weight,
-                                                          float* __restrict__ grad_gamma,
-                                                          float* __restrict__ grad_beta) {
-    const int c = threadIdx.x;
-    double acc[PFN_BW];
-    for (int i = 0; i < PFN_BW; ++i) {
+__global__ __launch_bounds__(768) void pfn_bwd_final_kernel(const float* __restrict__ partials, int nblocks,
+                                                           double rows, const float* __restrict__ weight,
+                                                           const float* __restrict__ gamma,
+                                                           const double* __restrict__ saved,
+                                                           float* __restrict__ grad_weight,
+                                                           float* __restrict__ grad_gamma,
+                                                           float* __restrict__ grad_beta) {
+    // stage 1: thread t = i*64 + c sums its accumulator over the block partials (coalesced,
+    // independent loads, fixed order)
+    __shared__ double red[PFN_BW][PFN_C];
+    {
+        const int t = threadIdx.x;
         double s = 0.0;
-        for (int b = 0; b < nblocks; ++b) s += (double)partials[((int64_t)b * PFN_BW + i) * PFN_C + c];
-        acc[i] = s;
+        for (int b = 0; b < nblocks; ++b) s += (double)partials[(int64_t)b * PFN_BW * PFN_C + t];
+        red[t / PFN_C][t % PFN_C] = s;
     }
-    const double A = acc[0], Bx = acc[1];
+    __syncthreads();
+    if (threadIdx.x >= PFN_C) return;
+    const int c = threadIdx.x;
+    const double A = red[0][c], Bx = red[1][c];
     const double mean = saved[110 + c], invstd = saved[174 + c];
     grad_beta[c] = (float)A;
     grad_gamma[c] = (float)Bx;
@@ -280,17 +285,17 @@ __global__ __launch_bounds__(64) void pfn_bwd_final_kernel(const float* __restri
         double s2w = 0.0;
         for (int b = 0; b < PFN_F; ++b) s2w += saved[PFN_F + a * PFN_F + b] * (double)weight[c * PFN_F + b];
         const double xf = invstd * (s2w - mean * saved[a]);                  // sum_rows xhat_row * f_row[a]
-        grad_weight[c * PFN_F + a] = (float)(k * (acc[2 + a] - A / rows * saved[a] - Bx / rows * xf));
+        grad_weight[c * PFN_F + a] = (float)(k * (red[2 + a][c] - A / rows * saved[a] - Bx / rows * xf));
     }
 }
 
 static int pfn_blocks(int64_t m) {
     int64_t b = (m + 255) / 256;
-    return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
+    return (int)(b < 1 ? 1 : (b > 256 ? 256 : b));
 }
 static int pfn_wave_blocks(int64_t m) {
     int64_t b = (m + 3) / 4;
-    return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+    return (int)(b < 1 ? 1 : (b > 512 ? 512 : b));
 }
 
 extern "C" size_t gga_pfn_workspace_bytes(int64_t m) {
@@ -362,7 +367,7 @@ extern "C" int gga_pfn_bwd(const float* voxels, const int32_t* num_points, const
     hipLaunchKernelGGL(pfn_bwd_kernel, dim3(nb), dim3(256), 0, stream, (const float4*)voxels, num_points,
                        (const int4*)coors, m, P, g, weight, saved, out, argmax, grad_out, (float*)workspace);
     GGA_CHECK_LAUNCH("pfn_bwd_kernel");
-    hipLaunchKernelGGL(pfn_bwd_final_kernel, dim3(1), dim3(64), 0, stream, (const float*)workspace, nb,
+    hipLaunchKernelGGL(pfn_bwd_final_kernel, dim3(1), dim3(PFN_BW * PFN_C), 0, stream, (const float*)workspace, nb,
                        (double)m * (double)P, weight, gamma, saved, grad_weight, grad_gamma, grad_beta);
     GGA_CHECK_LAUNCH("pfn_bwd_final_kernel");
     return GGA_OK;

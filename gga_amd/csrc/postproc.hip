@@ -1,0 +1,224 @@
+// §8(f) rank 1 — inference / pseudo-label post-processing ops for gfx950:
+// rotated BEV IoU, rotated NMS, points-in-boxes.
+//
+// The reference calls the un-vendored mmcv natives:
+//   mmcv.ops.nms_rotated      <- mmdet3d/core/post_processing/box3d_nms.py:231-268 (nms_bev),
+//                                used by CenterHead_GGA.get_task_detections (head:885-890)
+//   mmcv.ops.box_iou_rotated  <- mmdet3d/core/bbox/structures/base_box3d.py:469 (overlaps)
+//   mmcv.ops.points_in_boxes_part / _all <- base_box3d.py:534,566
+// Their published semantics are restated (rotated IoU = exact polygon overlap of the two
+// rectangles; greedy suppression of lower-scored boxes with IoU > thr; a point is inside a box
+// when |z - zc| <= dz/2 and the yaw-aligned offsets are strictly inside +-dx/2, +-dy/2) and pinned
+// by the reference's own known-answer tests (tests/test_utils/test_nms.py:82-120,
+// tests/test_utils/test_box3d.py:1122-1187,1683-1790).
+//
+// NMS runs fully on the device (mmcv copies the N x N bit mask to the host for the greedy scan):
+//   nms_mask_kernel   64x64 IoU blocks -> bit mask rows (only the upper triangle)
+//   nms_scan_kernel   one wavefront walks the score-sorted boxes, the "removed" bit set lives in
+//                     registers (one 64-bit word per lane per 4096 boxes), kept rows OR their mask
+//                     row into it.
+#include "gga_common.h"
+
+struct P2 { float x, y; };
+
+__device__ __forceinline__ float cross2(P2 a, P2 b) { return a.x * b.y - a.y * b.x; }
+
+__device__ __forceinline__ void rect_corners(const float* b, float sx, float sy, P2 out[4]) {
+    const float c = cosf(b[4]), s = sinf(b[4]);
+    const float hw = b[2] * 0.5f, hh = b[3] * 0.5f;
+    const float cx = b[0] - sx, cy = b[1] - sy;
+    const float dx[4] = { -hw, hw, hw, -hw }, dy[4] = { -hh, -hh, hh, hh };
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { out[i].x = cx + dx[i] * c - dy[i] * s; out[i].y = cy + dx[i] * s + dy[i] * c; }
+}
+
+// exact overlap area of two rotated rectangles (x, y, w, h, angle): Sutherland-Hodgman clip of
+// rectangle 1 by the four half planes of rectangle 2 (both convex, counter-clockwise)
+__device__ float rotated_inter_area(const float* b1, const float* b2) {
+    // shift both to their mid point for precision, as mmcv's box_iou_rotated_utils does
+    const float sx = (b1[0] + b2[0]) * 0.5f, sy = (b1[1] + b2[1]) * 0.5f;
+    P2 poly[10], tmp[10], q[4];
+    rect_corners(b1, sx, sy, poly);
+    rect_corners(b2, sx, sy, q);
+    int n = 4;
+    for (int e = 0; e < 4 && n > 0; ++e) {
+        const P2 a = q[e], bq = q[(e + 1) & 3];
+        const P2 ed = { bq.x - a.x, bq.y - a.y };
+        int m = 0;
+        for (int i = 0; i < n; ++i) {
+            const P2 p = poly[i], r = poly[(i + 1) % n];
+            const float dp = cross2(ed, P2{ p.x - a.x, p.y - a.y });
+            const float dr = cross2(ed, P2{ r.x - a.x, r.y - a.y });
+            if (dp >= 0.0f) tmp[m++] = p;
+            if ((dp >= 0.0f) != (dr >= 0.0f)) {
+                const float t = dp / (dp - dr);
+                tmp[m++] = P2{ p.x + t * (r.x - p.x), p.y + t * (r.y - p.y) };
+            }
+        }
+        n = m;
+        for (int i = 0; i < n; ++i) poly[i] = tmp[i];
+    }
+    if (n < 3) return 0.0f;
+    float area = 0.0f;
+    for (int i = 0; i < n; ++i) area += cross2(poly[i], poly[(i + 1) % n]);
+    return fabsf(area) * 0.5f;
+}
+
+__device__ __forceinline__ float rotated_iou(const float* b1, const float* b2, int mode_iof) {
+    const float a1 = b1[2] * b1[3], a2 = b2[2] * b2[3];
+    if (a1 < 1e-14f || a2 < 1e-14f) return 0.0f;
+    const float inter = rotated_inter_area(b1, b2);
+    const float base = mode_iof ? a1 : (a1 + a2 - inter);
+    return inter / base;
+}
+
+// ------------------------------------------------------------------------------ pairwise IoU
+__global__ __launch_bounds__(256) void box_iou_rotated_kernel(const float* __restrict__ b1, int n,
+                                                             const float* __restrict__ b2, int m, int mode_iof,
+                                                             int aligned, float* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (aligned) {
+        if (t >= n) return;
+        out[t] = rotated_iou(b1 + t * 5, b2 + t * 5, mode_iof);
+    } else {
+        if (t >= (int64_t)n * m) return;
+        const int i = (int)(t / m), j = (int)(t - (int64_t)i * m);
+        out[t] = rotated_iou(b1 + (int64_t)i * 5, b2 + (int64_t)j * 5, mode_iof);
+    }
+}
+
+extern "C" int gga_box_iou_rotated(const float* boxes1, int n, const float* boxes2, int m, int mode_iof, int aligned,
+                                   float* out, void* stream) {
+    GGA_REQUIRE(n >= 0 && m >= 0 && (!aligned || n == m), "gga_box_iou_rotated: bad sizes (n=%d m=%d aligned=%d)", n, m, aligned);
+    const int64_t total = aligned ? n : (int64_t)n * m;
+    if (total == 0) return GGA_OK;
+    GGA_REQUIRE(boxes1 && boxes2 && out, "gga_box_iou_rotated: null pointer argument");
+    hipLaunchKernelGGL(box_iou_rotated_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       boxes1, n, boxes2, m, mode_iof, aligned, out);
+    GGA_CHECK_LAUNCH("box_iou_rotated_kernel");
+    return GGA_OK;
+}
+
+// ------------------------------------------------------------------------------ rotated NMS
+// boxes are already sorted by descending score (the caller sorts, as mmcv's python wrapper does)
+__global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ boxes, int n, float thr,
+                                                     unsigned long long* __restrict__ mask, int colblocks) {
+    const int rb = blockIdx.y, cb = blockIdx.x;
+    if (cb < rb) return;                               // only j > i matters
+    __shared__ float cols[64 * 5];
+    const int t = threadIdx.x;
+    const int ncol = min(64, n - cb * 64);
+    if (t < ncol)
+#pragma unroll
+        for (int k = 0; k < 5; ++k) cols[t * 5 + k] = boxes[(int64_t)(cb * 64 + t) * 5 + k];
+    __syncthreads();
+    const int i = rb * 64 + t;
+    if (i >= n) return;
+    float me[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) me[k] = boxes[(int64_t)i * 5 + k];
+    unsigned long long bits = 0;
+    const int j0 = (rb == cb) ? t + 1 : 0;
+    for (int j = j0; j < ncol; ++j)
+        if (rotated_iou(me, cols + j * 5, 0) > thr) bits |= 1ull << j;
+    mask[(int64_t)i * colblocks + cb] = bits;
+}
+
+__global__ __launch_bounds__(64) void nms_scan_kernel(const unsigned long long* __restrict__ mask, int n, int colblocks,
+                                                     int max_keep, int64_t* __restrict__ keep,
+                                                     int32_t* __restrict__ num_keep) {
+    // lane l owns words l, l+64, ... of the "removed" set (<= 8 words per lane: n <= 32768)
+    const int lane = threadIdx.x;
+    unsigned long long removed[8];
+#pragma unroll
+    for (int w = 0; w < 8; ++w) removed[w] = 0;
+    int nk = 0;
+    for (int i = 0; i < n && nk < max_keep; ++i) {
+        const int word = i >> 6, owner = word & 63, slot = word >> 6;
+        unsigned long long wv = 0;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) if (w == slot) wv = removed[w];
+        const unsigned long long ow = __shfl(wv, owner, 64);
+        if ((ow >> (i & 63)) & 1ull) continue;
+        if (lane == 0) keep[nk] = i;
+        ++nk;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+            const int cw = lane + 64 * w;
+            if (cw < colblocks && cw >= word) removed[w] |= mask[(int64_t)i * colblocks + cw];
+        }
+    }
+    if (lane == 0) *num_keep = nk;
+}
+
+extern "C" size_t gga_nms_rotated_workspace_bytes(int n) {
+    const size_t cb = (size_t)(n + 63) / 64;
+    return (size_t)n * cb * 8 + 256;
+}
+
+extern "C" int gga_nms_rotated_sorted(const float* boxes_sorted, int n, float iou_threshold, int max_keep,
+                                      int64_t* keep, int32_t* num_keep, void* workspace, size_t workspace_bytes,
+                                      void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    GGA_REQUIRE(num_keep && n >= 0 && n <= 32768, "gga_nms_rotated_sorted: n=%d not in [0, 32768]", n);
+    if (n == 0) {
+        GGA_CHECK_HIP(hipMemsetAsync(num_keep, 0, 4, stream), "nms memset");
+        return GGA_OK;
+    }
+    GGA_REQUIRE(boxes_sorted && keep && workspace, "gga_nms_rotated_sorted: null pointer argument");
+    if (workspace_bytes < gga_nms_rotated_workspace_bytes(n)) {
+        gga_set_error("gga_nms_rotated_sorted: workspace %zu B < required %zu B", workspace_bytes,
+                      gga_nms_rotated_workspace_bytes(n));
+        return GGA_ERR_WORKSPACE;
+    }
+    const int cb = (n + 63) / 64;
+    unsigned long long* mask = (unsigned long long*)workspace;
+    GGA_CHECK_HIP(hipMemsetAsync(mask, 0, (size_t)n * cb * 8, stream), "nms memset");
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(cb, cb), dim3(64), 0, stream, boxes_sorted, n, iou_threshold, mask, cb);
+    GGA_CHECK_LAUNCH("nms_mask_kernel");
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(64), 0, stream, mask, n, cb, max_keep > 0 ? max_keep : n, keep,
+                       num_keep);
+    GGA_CHECK_LAUNCH("nms_scan_kernel");
+    return GGA_OK;
+}
+
+// ------------------------------------------------------------------------------ points in boxes
+// box = (x, y, z_bottom, dx, dy, dz, yaw). mmcv's check_pt_in_box3d.
+__device__ __forceinline__ bool pt_in_box3d(float px, float py, float pz, const float* b) {
+    const float cz = b[2] + b[5] * 0.5f;
+    if (fabsf(pz - cz) > b[5] * 0.5f) return false;
+    const float sx = px - b[0], sy = py - b[1];
+    const float c = cosf(-b[6]), s = sinf(-b[6]);
+    const float lx = sx * c - sy * s, ly = sx * s + sy * c;
+    return (lx > -b[3] * 0.5f) & (lx < b[3] * 0.5f) & (ly > -b[4] * 0.5f) & (ly < b[4] * 0.5f);
+}
+
+__global__ __launch_bounds__(256) void points_in_boxes_kernel(const float* __restrict__ pts, const float* __restrict__ boxes,
+                                                             int B, int M, int T, int all, int32_t* __restrict__ out) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= M) return;
+    const float* p = pts + ((int64_t)b * M + i) * 3;
+    const float px = p[0], py = p[1], pz = p[2];
+    const float* bb = boxes + (int64_t)b * T * 7;
+    if (all) {
+        int32_t* o = out + ((int64_t)b * M + i) * T;
+        for (int t = 0; t < T; ++t) o[t] = pt_in_box3d(px, py, pz, bb + t * 7) ? 1 : 0;
+    } else {
+        int32_t idx = -1;
+        for (int t = 0; t < T; ++t)
+            if (pt_in_box3d(px, py, pz, bb + t * 7)) { idx = t; break; }
+        out[(int64_t)b * M + i] = idx;
+    }
+}
+
+extern "C" int gga_points_in_boxes(const float* points, const float* boxes, int B, int M, int T, int all, int32_t* out,
+                                   void* stream) {
+    GGA_REQUIRE(B >= 1 && M >= 0 && T >= 0, "gga_points_in_boxes: bad sizes");
+    if (M == 0) return GGA_OK;
+    GGA_REQUIRE(points && out && (T == 0 || boxes), "gga_points_in_boxes: null pointer argument");
+    hipLaunchKernelGGL(points_in_boxes_kernel, dim3((M + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, points, boxes,
+                       B, M, T, all, out);
+    GGA_CHECK_LAUNCH("points_in_boxes_kernel");
+    return GGA_OK;
+}

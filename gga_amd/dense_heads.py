@@ -18,6 +18,7 @@ import torch
 from torch import nn
 
 from . import functional as F
+from . import ops
 from .cnn import ConvModule, build_conv_layer, kaiming_init
 from .registry import HEADS, build_bbox_coder, build_head, build_loss
 
@@ -299,3 +300,100 @@ class CenterHead_GGA(nn.Module):
             loss_dict[f'task{task_id}.loss_bbox'] = l_bpl
             loss_dict[f'task{task_id}.loss_ratio'] = l_srl
         return loss_dict
+
+    # ------------------------------------------------------------------ inference
+    def get_bboxes(self, preds_dicts, img_metas, img=None, rescale=False):
+        """Decode + per-task rotated NMS + merge (head:725-817). ``img_metas[i]['box_type_3d']``
+        builds the box structure (default ``LiDARInstance3DBoxes``). Returns
+        ``[[bboxes, scores, labels], ...]`` per sample."""
+        from .box3d import LiDARInstance3DBoxes
+        rets = []
+        for task_id, preds_dict in enumerate(preds_dicts):
+            pd = preds_dict[0]
+            batch_size = pd['heatmap'].shape[0]
+            batch_dim = torch.exp(pd['dim']) if self.norm_bbox else pd['dim']
+            temp = self.bbox_coder.decode(pd['heatmap'].sigmoid(), pd['rot'][:, 0].unsqueeze(1),
+                                          pd['rot'][:, 1].unsqueeze(1), pd['height'], batch_dim, pd.get('vel'),
+                                          reg=pd['reg'], task_id=task_id)
+            assert self.test_cfg['nms_type'] in ['circle', 'rotate']
+            if self.test_cfg['nms_type'] == 'circle':
+                ret_task = []
+                for i in range(batch_size):
+                    keep = circle_nms(torch.cat([temp[i]['bboxes'][:, :2], temp[i]['scores'].view(-1, 1)], 1),
+                                      self.test_cfg['min_radius'][task_id], self.test_cfg['post_max_size'])
+                    ret_task.append({k: temp[i][k][keep] for k in ('bboxes', 'scores', 'labels')})
+                rets.append(ret_task)
+            else:
+                rets.append(self.get_task_detections(self.num_classes[task_id], [b['scores'] for b in temp],
+                                                     [b['bboxes'] for b in temp], [b['labels'] for b in temp],
+                                                     img_metas))
+        ret_list = []
+        for i in range(len(rets[0])):
+            bboxes = torch.cat([ret[i]['bboxes'] for ret in rets])
+            bboxes[:, 2] = bboxes[:, 2] - bboxes[:, 5] * 0.5          # gravity centre -> bottom centre
+            box_type = (img_metas[i].get('box_type_3d') if isinstance(img_metas[i], dict) else None) or LiDARInstance3DBoxes
+            bboxes = box_type(bboxes, self.bbox_coder.code_size)
+            scores = torch.cat([ret[i]['scores'] for ret in rets])
+            flag, labels = 0, []
+            for j, num_class in enumerate(self.num_classes):
+                labels.append(rets[j][i]['labels'].int() + flag)
+                flag += num_class
+            ret_list.append([bboxes, scores, torch.cat(labels)])
+        return ret_list
+
+    def get_task_detections(self, num_class_with_bg, batch_cls_preds, batch_reg_preds, batch_cls_labels, img_metas):
+        """Score threshold -> BEV rotated NMS (HIP) -> range filter, per sample (head:819-934)."""
+        from .box3d import LiDARInstance3DBoxes
+        tc = self.test_cfg
+        pcr = tc['post_center_limit_range']
+        if len(pcr) > 0:
+            pcr = torch.tensor(pcr, dtype=batch_reg_preds[0].dtype, device=batch_reg_preds[0].device)
+        out = []
+        for i, (box_preds, cls_preds, cls_labels) in enumerate(zip(batch_reg_preds, batch_cls_preds, batch_cls_labels)):
+            top_scores = cls_preds.squeeze(-1)
+            top_labels = (torch.zeros(cls_preds.shape[0], device=cls_preds.device, dtype=torch.long)
+                          if num_class_with_bg == 1 else cls_labels.long())
+            if tc['score_threshold'] > 0.0:
+                keep = top_scores >= tc['score_threshold']
+                top_scores = top_scores[keep]
+                if top_scores.shape[0] != 0:
+                    box_preds, top_labels = box_preds[keep], top_labels[keep]
+            if top_scores.shape[0] != 0:
+                box_type = (img_metas[i].get('box_type_3d') if isinstance(img_metas[i], dict) else None) or LiDARInstance3DBoxes
+                boxes_for_nms = ops.xywhr2xyxyr(box_type(box_preds[:, :], self.bbox_coder.code_size).bev)
+                selected = ops.nms_bev(boxes_for_nms, top_scores, thresh=tc['nms_thr'], pre_max_size=tc['pre_max_size'],
+                                       post_max_size=tc['post_max_size'])
+            else:
+                selected = []
+            sb, sl, ss = box_preds[selected], top_labels[selected], top_scores[selected]
+            if sb.shape[0] != 0:
+                if len(pcr) > 0:
+                    m = (sb[:, :3] >= pcr[:3]).all(1) & (sb[:, :3] <= pcr[3:]).all(1)
+                    sb, ss, sl = sb[m], ss[m], sl[m]
+                out.append(dict(bboxes=sb, scores=ss, labels=sl))
+            else:
+                dt, dev = batch_reg_preds[0].dtype, batch_reg_preds[0].device
+                out.append(dict(bboxes=torch.zeros([0, self.bbox_coder.code_size], dtype=dt, device=dev),
+                                scores=torch.zeros([0], dtype=dt, device=dev),
+                                labels=torch.zeros([0], dtype=top_labels.dtype, device=dev)))
+        return out
+
+
+def circle_nms(dets, thresh, post_max_size=83):
+    """Circular NMS (mmdet3d/core/post_processing/box3d_nms.py:181-225): a centre survives if no
+    higher-scored kept centre lies within squared distance ``thresh``. dets [N,3] = (x, y, score)."""
+    if dets.shape[0] == 0:
+        return torch.zeros(0, dtype=torch.long, device=dets.device)
+    order = torch.argsort(dets[:, 2], descending=True)
+    xy = dets[order, :2]
+    d2 = ((xy[:, None, :] - xy[None, :, :]) ** 2).sum(-1).cpu()
+    n = d2.shape[0]
+    suppressed = torch.zeros(n, dtype=torch.bool)
+    keep = []
+    for i in range(n):
+        if suppressed[i]:
+            continue
+        keep.append(i)
+        suppressed |= (d2[i] <= thresh) & (torch.arange(n) > i)
+    keep = order[torch.tensor(keep, dtype=torch.long, device=order.device)]
+    return keep[:post_max_size]

@@ -108,7 +108,34 @@ class MVXTwoStageDetector_GGA(nn.Module):
     def forward(self, return_loss=True, **kwargs):
         if return_loss:
             return self.forward_train(**kwargs)
-        raise NotImplementedError('forward_test (inference / pseudo-label path) is SURVEY.md §8(f) rank 1')
+        return self.forward_test(**kwargs)
+
+    # ---- inference (mvx_two_stage_gga.py:407-423, centerpoint_gga.py:88-97, detectors/base.py:16-45)
+    def forward_test(self, points, img_metas, img=None, **kwargs):
+        for var, name in [(points, 'points'), (img_metas, 'img_metas')]:
+            if not isinstance(var, list):
+                raise TypeError(f'{name} must be a list, but got {type(var)}')
+        if len(points) != len(img_metas):
+            raise ValueError(f'num of augmentations ({len(points)}) != num of image meta ({len(img_metas)})')
+        if len(points) == 1:
+            return self.simple_test(points[0], img_metas[0], None if img is None else img[0], **kwargs)
+        raise NotImplementedError('test-time augmentation is not on the GGA path')
+
+    @torch.no_grad()
+    def simple_test_pts(self, x, img_metas, rescale=False):
+        from .box3d import bbox3d2result
+        outs = self.pts_bbox_head(x)
+        bbox_list = self.pts_bbox_head.get_bboxes(outs, img_metas, rescale=rescale)
+        return [bbox3d2result(bboxes, scores, labels) for bboxes, scores, labels in bbox_list]
+
+    @torch.no_grad()
+    def simple_test(self, points, img_metas, img=None, rescale=False):
+        _, pts_feats = self.extract_feat(points, img=img, img_metas=img_metas)
+        bbox_list = [dict() for _ in range(len(img_metas))]
+        if pts_feats and self.with_pts_bbox:
+            for result_dict, pts_bbox in zip(bbox_list, self.simple_test_pts(pts_feats, img_metas, rescale=rescale)):
+                result_dict['pts_bbox'] = pts_bbox
+        return bbox_list
 
     # ---- mmdet BaseDetector.train_step / _parse_losses (restated) -----------------
     def _parse_losses(self, losses):

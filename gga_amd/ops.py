@@ -1,0 +1,106 @@
+"""Post-processing ops of the inference / pseudo-label path on the HIP kernels of
+gga_amd/csrc/postproc.hip, with the call signatures the reference uses:
+
+* ``nms_rotated(boxes_xywhr, scores, iou_threshold) -> (dets, keep)`` — ``mmcv.ops.nms_rotated``
+  (mmdet3d/core/post_processing/box3d_nms.py:5,264)
+* ``nms_bev(boxes_xyxyr, scores, thresh, pre_max_size, post_max_size)`` — box3d_nms.py:231-268
+* ``box_iou_rotated(b1, b2, mode='iou', aligned=False)`` — mmcv op used by base_box3d.py:469
+* ``points_in_boxes_part / points_in_boxes_all(points [B,M,3], boxes [B,T,7])`` — base_box3d.py:534,566
+* ``xywhr2xyxyr`` — mmdet3d/core/bbox/structures/utils.py:121-139
+"""
+import torch
+
+from . import _lib
+from . import functional as F
+from ._lib import check
+
+
+def xywhr2xyxyr(boxes_xywhr):
+    boxes = torch.zeros_like(boxes_xywhr)
+    half_w = boxes_xywhr[..., 2] / 2
+    half_h = boxes_xywhr[..., 3] / 2
+    boxes[..., 0] = boxes_xywhr[..., 0] - half_w
+    boxes[..., 1] = boxes_xywhr[..., 1] - half_h
+    boxes[..., 2] = boxes_xywhr[..., 0] + half_w
+    boxes[..., 3] = boxes_xywhr[..., 1] + half_h
+    boxes[..., 4] = boxes_xywhr[..., 4]
+    return boxes
+
+
+@torch.no_grad()
+def box_iou_rotated(bboxes1, bboxes2, mode='iou', aligned=False):
+    assert mode in ('iou', 'iof')
+    F._need_cuda(bboxes1, bboxes2)
+    b1, b2 = bboxes1.float().contiguous(), bboxes2.float().contiguous()
+    n, m = b1.shape[0], b2.shape[0]
+    out = torch.zeros((n,) if aligned else (n, m), dtype=torch.float32, device=b1.device)
+    check(_lib.lib().gga_box_iou_rotated(F._p(b1), n, F._p(b2), m, int(mode == 'iof'), int(aligned), F._p(out),
+                                         F._stream()), 'gga_box_iou_rotated')
+    return out
+
+
+@torch.no_grad()
+def nms_rotated(dets, scores, iou_threshold, labels=None, max_keep=0):
+    """dets [N,5] (x, y, w, h, angle) -> (cat(dets[keep], scores[keep]), keep). ``keep`` is ordered
+    by descending score. Multi-label NMS (``labels``) offsets the boxes per label like mmcv."""
+    F._need_cuda(dets, scores)
+    if dets.shape[0] == 0:
+        return dets, dets.new_zeros(0, dtype=torch.long)
+    boxes = dets.float()
+    if labels is not None:       # boxes of different labels never overlap
+        span = boxes[:, :2].abs().max() + boxes[:, 2:4].max() + 1
+        boxes = boxes.clone()
+        boxes[:, :2] += labels.to(boxes)[:, None] * span * 2
+    scores_sorted, order = scores.sort(0, descending=True)
+    boxes_sorted = boxes.index_select(0, order).contiguous()
+    n = boxes_sorted.shape[0]
+    L = _lib.lib()
+    keep_pos = torch.empty(n, dtype=torch.int64, device=dets.device)
+    num = torch.zeros(1, dtype=torch.int32, device=dets.device)
+    ws = F._workspace('nms', L.gga_nms_rotated_workspace_bytes(n), dets.device)
+    check(L.gga_nms_rotated_sorted(F._p(boxes_sorted), n, float(iou_threshold), int(max_keep), F._p(keep_pos), F._p(num),
+                                   F._p(ws), ws.numel(), F._stream()), 'gga_nms_rotated_sorted')
+    keep = order[keep_pos[:int(num.item())]]
+    return torch.cat([dets[keep], scores[keep].reshape(-1, 1)], dim=1), keep
+
+
+def nms_bev(boxes, scores, thresh, pre_max_size=None, post_max_size=None):
+    assert boxes.size(1) == 5, 'Input boxes shape should be [N, 5]'
+    order = scores.sort(0, descending=True)[1]
+    if pre_max_size is not None:
+        order = order[:pre_max_size]
+    boxes = boxes[order].contiguous()
+    scores = scores[order]
+    # xyxyr -> xywhr (box3d_nms.py:258-262)
+    boxes = torch.stack(((boxes[:, 0] + boxes[:, 2]) / 2, (boxes[:, 1] + boxes[:, 3]) / 2,
+                         boxes[:, 2] - boxes[:, 0], boxes[:, 3] - boxes[:, 1], boxes[:, 4]), dim=-1)
+    keep = nms_rotated(boxes, scores, thresh, max_keep=post_max_size or 0)[1]
+    keep = order[keep]
+    if post_max_size is not None:
+        keep = keep[:post_max_size]
+    return keep
+
+
+@torch.no_grad()
+def _points_in_boxes(points, boxes, all_boxes):
+    F._need_cuda(points, boxes)
+    assert points.dim() == 3 and boxes.dim() == 3 and points.shape[0] == boxes.shape[0], \
+        f'points {tuple(points.shape)} / boxes {tuple(boxes.shape)} must be [B,M,3] / [B,T,7]'
+    assert points.shape[2] == 3 and boxes.shape[2] == 7
+    B, M, _ = points.shape
+    T = boxes.shape[1]
+    pts, bx = points.float().contiguous(), boxes.float().contiguous()
+    out = torch.zeros((B, M, T) if all_boxes else (B, M), dtype=torch.int32, device=points.device)
+    if not all_boxes:
+        out.fill_(-1)
+    check(_lib.lib().gga_points_in_boxes(F._p(pts), F._p(bx), B, M, T, int(all_boxes), F._p(out), F._stream()),
+          'gga_points_in_boxes')
+    return out
+
+
+def points_in_boxes_part(points, boxes):
+    return _points_in_boxes(points, boxes, False)
+
+
+def points_in_boxes_all(points, boxes):
+    return _points_in_boxes(points, boxes, True)

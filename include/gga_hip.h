@@ -310,6 +310,32 @@ int gga_box_losses_fwd(const float* pred, const int64_t* ind, const uint8_t* mas
 int gga_box_losses_bwd(const float* grad_pred, const float* grad_losses, int B, int K,
                        float* grad_pred_out, void* stream);
 
+/* ------------------------------------------------------------------------- */
+/* SURVEY.md §8(f) rank 1 — inference / pseudo-label post-processing.        */
+/* ------------------------------------------------------------------------- */
+/* Rotated BEV IoU. Replaces mmcv.ops.box_iou_rotated as called by
+ * mmdet3d/core/bbox/structures/base_box3d.py:469 (BaseInstance3DBoxes.overlaps).
+ * boxes [n,5] / [m,5] = (x, y, w, h, angle[rad]); out [n,m] (or [n] when aligned);
+ * mode_iof: intersection over the area of box1 instead of the union. */
+int gga_box_iou_rotated(const float* boxes1, int n, const float* boxes2, int m, int mode_iof,
+                        int aligned, float* out, void* stream);
+
+/* Rotated NMS on score-sorted boxes. Replaces mmcv.ops.nms_rotated's native half as called by
+ * mmdet3d/core/post_processing/box3d_nms.py:264 (nms_bev) <- centerpoint_head_gga.py:885-890;
+ * like mmcv, the caller sorts by descending score. keep [n] i64 receives the positions (in the
+ * sorted order) of the surviving boxes, *num_keep (device) their count (<= max_keep if > 0). */
+size_t gga_nms_rotated_workspace_bytes(int n);
+int gga_nms_rotated_sorted(const float* boxes_sorted, int n, float iou_threshold, int max_keep,
+                           int64_t* keep, int32_t* num_keep, void* workspace,
+                           size_t workspace_bytes, void* stream);
+
+/* Points in rotated 3D boxes. Replaces mmcv.ops.points_in_boxes_part / points_in_boxes_all as
+ * called by base_box3d.py:534,566. points [B,M,3]; boxes [B,T,7] = (x, y, z_bottom, dx, dy, dz,
+ * yaw). all = 0: out [B,M] i32 index of the first box containing the point or -1;
+ * all = 1: out [B,M,T] i32 flags. */
+int gga_points_in_boxes(const float* points, const float* boxes, int B, int M, int T, int all,
+                        int32_t* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

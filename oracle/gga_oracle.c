@@ -353,3 +353,87 @@ float gga_oracle_l1_loss(const float* pred, const float* target, const float* we
     for (int64_t i = 0; i < n; ++i) acc += (double)(fabsf(pred[i] - target[i]) * weight[i]);
     return loss_weight * ((float)acc / (avg_factor + 1.1920928955078125e-07f));
 }
+
+/* ------------------------------------------------------------------------ */
+/* post-processing ops of the inference path. The    */
+/* reference calls mmcv natives (not in the tree); their published          */
+/* semantics are restated and pinned by the reference's known-answer tests  */
+/* tests/test_utils/test_nms.py:82-120, test_box3d.py:1122-1187,1683-1790.  */
+/* ------------------------------------------------------------------------ */
+typedef struct { double x, y; } dpt;
+static double dcross(dpt a, dpt b) { return a.x * b.y - a.y * b.x; }
+
+static void rect_corners_d(const float* b, dpt out[4]) {
+    double c = cos((double)b[4]), s = sin((double)b[4]);
+    double hw = b[2] * 0.5, hh = b[3] * 0.5;
+    double dx[4] = { -hw, hw, hw, -hw }, dy[4] = { -hh, -hh, hh, hh };
+    for (int i = 0; i < 4; ++i) { out[i].x = b[0] + dx[i] * c - dy[i] * s; out[i].y = b[1] + dx[i] * s + dy[i] * c; }
+}
+
+/* exact overlap area of two rotated rectangles (x, y, w, h, angle), convex clipping in f64 */
+double gga_oracle_rotated_inter(const float* b1, const float* b2) {
+    dpt poly[16], tmp[16], q[4];
+    rect_corners_d(b1, poly);
+    rect_corners_d(b2, q);
+    int n = 4;
+    for (int e = 0; e < 4 && n > 0; ++e) {
+        dpt a = q[e], bq = q[(e + 1) & 3], ed = { bq.x - a.x, bq.y - a.y };
+        int m = 0;
+        for (int i = 0; i < n; ++i) {
+            dpt p = poly[i], r = poly[(i + 1) % n];
+            dpt pa = { p.x - a.x, p.y - a.y }, ra = { r.x - a.x, r.y - a.y };
+            double dp = dcross(ed, pa), dr = dcross(ed, ra);
+            if (dp >= 0) tmp[m++] = p;
+            if ((dp >= 0) != (dr >= 0)) { double t = dp / (dp - dr); dpt ip = { p.x + t * (r.x - p.x), p.y + t * (r.y - p.y) }; tmp[m++] = ip; }
+        }
+        n = m;
+        memcpy(poly, tmp, sizeof(dpt) * n);
+    }
+    if (n < 3) return 0.0;
+    double area = 0.0;
+    for (int i = 0; i < n; ++i) area += dcross(poly[i], poly[(i + 1) % n]);
+    return fabs(area) * 0.5;
+}
+
+float gga_oracle_rotated_iou(const float* b1, const float* b2, int mode_iof) {
+    double a1 = (double)b1[2] * b1[3], a2 = (double)b2[2] * b2[3];
+    if (a1 < 1e-14 || a2 < 1e-14) return 0.0f;
+    double inter = gga_oracle_rotated_inter(b1, b2);
+    return (float)(inter / (mode_iof ? a1 : (a1 + a2 - inter)));
+}
+
+/* greedy rotated NMS on score-sorted boxes (mmcv nms_rotated): box j is suppressed by a kept,
+ * higher-scored box i when IoU(i, j) > thr. Returns the number of kept positions. */
+int gga_oracle_nms_rotated_sorted(const float* boxes, int n, float thr, int64_t* keep) {
+    char* dead = (char*)calloc((size_t)n + 1, 1);
+    int nk = 0;
+    for (int i = 0; i < n; ++i) {
+        if (dead[i]) continue;
+        keep[nk++] = i;
+        for (int j = i + 1; j < n; ++j)
+            if (!dead[j] && gga_oracle_rotated_iou(boxes + i * 5, boxes + j * 5, 0) > thr) dead[j] = 1;
+    }
+    free(dead);
+    return nk;
+}
+
+/* mmcv check_pt_in_box3d: box = (x, y, z_bottom, dx, dy, dz, yaw) */
+static int pt_in_box(const float* p, const float* b) {
+    float cz = b[2] + b[5] * 0.5f;
+    if (fabsf(p[2] - cz) > b[5] * 0.5f) return 0;
+    float sx = p[0] - b[0], sy = p[1] - b[1];
+    float c = cosf(-b[6]), s = sinf(-b[6]);
+    float lx = sx * c - sy * s, ly = sx * s + sy * c;
+    return (lx > -b[3] * 0.5f) & (lx < b[3] * 0.5f) & (ly > -b[4] * 0.5f) & (ly < b[4] * 0.5f);
+}
+
+/* points [M,3], boxes [T,7]; all=0: out [M] first box index or -1; all=1: out [M,T] flags */
+void gga_oracle_points_in_boxes(const float* pts, int M, const float* boxes, int T, int all, int32_t* out) {
+    for (int i = 0; i < M; ++i) {
+        if (all) { for (int t = 0; t < T; ++t) out[i * T + t] = pt_in_box(pts + i * 3, boxes + t * 7); }
+        else {
+            out[i] = -1;
+            for (int t = 0; t < T; ++t) if (pt_in_box(pts + i * 3, boxes + t * 7)) { out[i] = t; break; }
+        }
+    }
+}

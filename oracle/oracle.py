@@ -61,6 +61,11 @@ def lib():
         L.gga_oracle_pal_object.argtypes = [f64p, C.c_int64, C.c_int, f32p, f32p]
         L.gga_oracle_l1_loss.restype = C.c_float
         L.gga_oracle_l1_loss.argtypes = [f32p, f32p, f32p, C.c_int64, C.c_float, C.c_float]
+        L.gga_oracle_rotated_iou.restype = C.c_float
+        L.gga_oracle_rotated_iou.argtypes = [f32p, f32p, C.c_int]
+        L.gga_oracle_nms_rotated_sorted.restype = C.c_int
+        L.gga_oracle_nms_rotated_sorted.argtypes = [f32p, C.c_int, C.c_float, i64p]
+        L.gga_oracle_points_in_boxes.argtypes = [f32p, C.c_int, f32p, C.c_int, C.c_int, i32p]
         _LIB = L
     return _LIB
 
@@ -188,6 +193,45 @@ def pal_object(points_f64, bev5):
 def l1_loss(pred, target, weight, avg_factor, loss_weight):
     p, t, w = (_f32(np.broadcast_to(a, pred.shape)).reshape(-1) for a in (pred, target, weight))
     return np.float32(lib().gga_oracle_l1_loss(p, t, w, p.size, np.float32(avg_factor), loss_weight))
+
+
+def box_iou_rotated(b1, b2, mode='iou'):
+    b1, b2 = _f32(b1).reshape(-1, 5), _f32(b2).reshape(-1, 5)
+    out = np.zeros((len(b1), len(b2)), np.float32)
+    for i in range(len(b1)):
+        for j in range(len(b2)):
+            out[i, j] = lib().gga_oracle_rotated_iou(b1[i], b2[j], int(mode == 'iof'))
+    return out
+
+
+def nms_rotated(boxes_xywhr, scores, thr):
+    """mmcv.ops.nms_rotated: sort by descending score (stable), greedy suppression; returns keep
+    indices into the input."""
+    boxes, scores = _f32(boxes_xywhr).reshape(-1, 5), _f32(scores)
+    order = np.argsort(-scores, kind='stable')
+    keep = np.zeros(len(boxes), np.int64)
+    n = lib().gga_oracle_nms_rotated_sorted(np.ascontiguousarray(boxes[order]), len(boxes), thr, keep)
+    return order[keep[:n]]
+
+
+def nms_bev(boxes_xyxyr, scores, thr, pre_max_size=None, post_max_size=None):
+    """mmdet3d/core/post_processing/box3d_nms.py:231-268."""
+    b, scores = _f32(boxes_xyxyr), _f32(scores)
+    order = np.argsort(-scores, kind='stable')
+    if pre_max_size is not None:
+        order = order[:pre_max_size]
+    b = b[order]
+    xywhr = np.stack([(b[:, 0] + b[:, 2]) / 2, (b[:, 1] + b[:, 3]) / 2, b[:, 2] - b[:, 0], b[:, 3] - b[:, 1],
+                      b[:, 4]], -1)
+    keep = order[nms_rotated(xywhr, scores[order], thr)]
+    return keep[:post_max_size] if post_max_size is not None else keep
+
+
+def points_in_boxes(points, boxes, all_boxes=False):
+    pts, bx = _f32(points).reshape(-1, 3), _f32(boxes).reshape(-1, 7)
+    out = np.zeros((len(pts), len(bx)) if all_boxes else (len(pts),), np.int32)
+    lib().gga_oracle_points_in_boxes(pts, len(pts), bx, len(bx), int(all_boxes), out)
+    return out
 
 
 # ---------------------------------------------------------------------------

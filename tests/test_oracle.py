@@ -143,3 +143,56 @@ def test_rotation_known_answer(golden):
     c, s = np.cos(a), np.sin(a)
     got = np.stack([p[:, 0] * c - p[:, 1] * s, p[:, 0] * s + p[:, 1] * c], 1)
     np.testing.assert_allclose(got, out, atol=1e-7)
+
+
+# ---- §8(f) rank 1 ops: the reference's own known-answer tests ---------------------------------
+KA_PTS = np.array([[1.0, 4.3, 0.1], [1.0, 4.4, 0.1], [1.1, 4.3, 0.1], [0.9, 4.3, 0.1], [1.0, -0.3, 0.1],
+                   [1.0, -0.4, 0.1], [2.9, 0.1, 6.0], [-0.9, 3.9, 6.0]], np.float32)
+KA_BOXES = np.array([[1.0, 2.0, 0.0, 4.0, 4.0, 6.0, np.pi / 6], [1.0, 2.0, 0.0, 4.0, 4.0, 6.0, np.pi / 2],
+                     [1.0, 2.0, 0.0, 4.0, 4.0, 6.0, 7 * np.pi / 6], [1.0, 2.0, 0.0, 4.0, 4.0, 6.0, -np.pi / 6]], np.float32)
+KA_ALL = [[1, 0, 1, 1], [0, 0, 0, 0], [1, 0, 1, 0], [0, 0, 0, 1], [1, 0, 1, 1], [0, 0, 0, 0], [0, 1, 0, 0], [0, 1, 0, 0]]
+KA_PART = [0, -1, 0, 3, 0, -1, 1, 1]
+KA_DEPTH_BOXES = np.array([[1.0, 2.0, 3.0, 4.0, 5.0, 6.0, 0.3], [-10.0, 23.0, 16.0, 10, 20, 20, 0.5]], np.float32)
+KA_DEPTH_PTS = np.array([[1, 2, 3.3], [1.2, 2.5, 3.0], [0.8, 2.1, 3.5], [1.6, 2.6, 3.6], [0.8, 1.2, 3.9],
+                         [-9.2, 21.0, 18.2], [3.8, 7.9, 6.3], [4.7, 3.5, -12.2], [3.8, 7.6, -2], [-10.6, -12.9, -20],
+                         [-16, -18, 9], [-21.3, -52, -5], [0, 0, 0], [6, 7, 8], [-2, -3, -4]], np.float32)
+KA_DEPTH_PART = [0, 0, 0, 0, 0, 1, -1, -1, -1, -1, -1, -1, -1, -1, -1]
+KA_NMS_BOXES = np.array([[6.0, 3.0, 8.0, 7.0, 2.0], [3.0, 6.0, 9.0, 11.0, 1.0], [3.0, 7.0, 10.0, 12.0, 1.0],
+                         [1.0, 4.0, 13.0, 7.0, 3.0]], np.float32)
+KA_NMS_SCORES = np.array([0.6, 0.9, 0.7, 0.2], np.float32)
+KA_OV1 = np.array([[1.8, -2.5, -1.8, 1.75, 3.39, 1.65, -1.6615927], [8.9, -2.5, -1.6, 1.54, 4.01, 1.57, -1.5215927],
+                   [28.3, 0.5, -1.3, 1.47, 2.23, 1.48, -4.7115927], [31.3, -8.2, -1.6, 1.74, 3.77, 1.48, -0.35]], np.float32)
+KA_OV2 = np.array([[1.2, -3.0, -1.9, 1.8, 3.4, 1.7, -1.9], [8.1, -2.9, -1.8, 1.5, 4.1, 1.6, -1.8],
+                   [31.3, -8.2, -1.6, 1.74, 3.77, 1.48, -0.35], [20.1, -28.5, -1.9, 1.6, 3.5, 1.4, -5.1]], np.float32)
+KA_IOU3D = np.array([[0.3710, 0, 0, 0], [0, 0.3322, 0, 0], [0, 0, 0, 0], [0, 0, 1.0, 0]], np.float32)
+KA_IOF3D = np.array([[0.5582, 0, 0, 0], [0, 0.5025, 0, 0], [0, 0, 0, 0], [0, 0, 1.0, 0]], np.float32)
+
+
+def overlaps_3d_from_bev(iou2d_fn, b1, b2, mode):
+    """BaseInstance3DBoxes.overlaps (base_box3d.py:440-500) around a BEV rotated-IoU function."""
+    top1, bot1 = b1[:, 2] + b1[:, 5], b1[:, 2]
+    top2, bot2 = b2[:, 2] + b2[:, 5], b2[:, 2]
+    oh = np.clip(np.minimum(top1[:, None], top2[None]) - np.maximum(bot1[:, None], bot2[None]), 0, None)
+    bev1, bev2 = b1[:, [0, 1, 3, 4, 6]], b2[:, [0, 1, 3, 4, 6]]
+    iou2d = iou2d_fn(bev1, bev2)
+    a1, a2 = (bev1[:, 2] * bev1[:, 3])[:, None], (bev2[:, 2] * bev2[:, 3])[None]
+    ov = iou2d * (a1 + a2) / (1 + iou2d) * oh
+    v1, v2 = (b1[:, 3] * b1[:, 4] * b1[:, 5])[:, None], (b2[:, 3] * b2[:, 4] * b2[:, 5])[None]
+    return ov / np.clip(v1 + v2 - ov, 1e-8, None) if mode == 'iou' else ov / np.clip(v1, 1e-8, None)
+
+
+def test_points_in_boxes_known_answers():    # reference tests/test_utils/test_box3d.py:1683-1745
+    assert O.points_in_boxes(KA_PTS, KA_BOXES, all_boxes=True).tolist() == KA_ALL
+    assert O.points_in_boxes(KA_PTS, KA_BOXES).tolist() == KA_PART
+    assert O.points_in_boxes(KA_DEPTH_PTS, KA_DEPTH_BOXES).tolist() == KA_DEPTH_PART
+
+
+def test_nms_bev_known_answer():              # reference tests/test_utils/test_nms.py:82-98
+    assert O.nms_bev(KA_NMS_BOXES, KA_NMS_SCORES, 0.3).tolist() == [1, 0, 3]
+
+
+def test_boxes3d_overlaps_known_answer():     # reference tests/test_utils/test_box3d.py:1122-1158
+    np.testing.assert_allclose(overlaps_3d_from_bev(O.box_iou_rotated, KA_OV1, KA_OV2, 'iou'), KA_IOU3D,
+                               rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(overlaps_3d_from_bev(O.box_iou_rotated, KA_OV1, KA_OV2, 'iof'), KA_IOF3D,
+                               rtol=1e-3, atol=1e-4)

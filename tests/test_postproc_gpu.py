@@ -1,0 +1,101 @@
+"""§8(f) rank 1 ops on the GPU: the reference's known-answer tests (tests/test_utils/test_nms.py:82-98,
+test_box3d.py:1122-1158,1683-1745) through the product API, plus randomized parity with the oracle,
+and the inference path (simple_test) of the detector."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO
+from gga_amd import Config, build_model, ops, synthetic
+from gga_amd.box3d import LiDARInstance3DBoxes
+from oracle import oracle as O
+from test_oracle import (KA_ALL, KA_BOXES, KA_DEPTH_BOXES, KA_DEPTH_PART, KA_DEPTH_PTS, KA_IOF3D, KA_IOU3D,
+                         KA_NMS_BOXES, KA_NMS_SCORES, KA_OV1, KA_OV2, KA_PART, KA_PTS)
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+T = lambda a: torch.from_numpy(np.asarray(a)).to(DEV)
+
+
+def test_reference_known_answers():
+    boxes = LiDARInstance3DBoxes(T(KA_BOXES))
+    assert boxes.points_in_boxes_all(T(KA_PTS)).cpu().tolist() == KA_ALL
+    assert boxes.points_in_boxes_part(T(KA_PTS)).cpu().tolist() == KA_PART
+    assert LiDARInstance3DBoxes(T(KA_DEPTH_BOXES)).points_in_boxes_part(T(KA_DEPTH_PTS)[None]).cpu().tolist() == KA_DEPTH_PART
+    assert ops.nms_bev(T(KA_NMS_BOXES), T(KA_NMS_SCORES), thresh=0.3).cpu().tolist() == [1, 0, 3]
+    b1, b2 = LiDARInstance3DBoxes(T(KA_OV1)), LiDARInstance3DBoxes(T(KA_OV2))
+    torch.testing.assert_close(LiDARInstance3DBoxes.overlaps(b1, b2).cpu(), torch.from_numpy(KA_IOU3D), rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(LiDARInstance3DBoxes.overlaps(b1, b2, mode='iof').cpu(), torch.from_numpy(KA_IOF3D),
+                               rtol=1e-3, atol=1e-4)
+    assert LiDARInstance3DBoxes.overlaps(LiDARInstance3DBoxes([]), b2).shape == (0, 4)
+
+
+def _rand_boxes(n, seed, spread=20.0):
+    g = np.random.default_rng(seed)
+    return np.stack([g.uniform(-spread, spread, n), g.uniform(-spread, spread, n), g.uniform(0.5, 6, n),
+                     g.uniform(0.5, 6, n), g.uniform(-4, 4, n)], 1).astype(np.float32)
+
+
+def test_box_iou_rotated_vs_oracle():
+    b1, b2 = _rand_boxes(150, 1, 6), _rand_boxes(170, 2, 6)
+    b2[:10] = b1[:10]                                        # identical boxes -> IoU 1
+    for mode in ('iou', 'iof'):
+        got = ops.box_iou_rotated(T(b1), T(b2), mode=mode).cpu().numpy()
+        np.testing.assert_allclose(got, O.box_iou_rotated(b1, b2, mode), rtol=1e-4, atol=2e-5)
+    al = ops.box_iou_rotated(T(b1), T(b2[:150]), aligned=True).cpu().numpy()
+    np.testing.assert_allclose(al[:10], 1.0, atol=1e-5)
+
+
+@pytest.mark.parametrize('n,thr', [(1, 0.3), (63, 0.1), (64, 0.5), (500, 0.2), (4096, 0.3)])
+def test_nms_rotated_vs_oracle(n, thr):
+    boxes = _rand_boxes(n, n, spread=4.0 * max(1.0, (n / 50) ** 0.5))
+    scores = np.random.default_rng(n + 1).permutation(n).astype(np.float32) / n      # distinct scores
+    dets, keep = ops.nms_rotated(T(boxes), T(scores), thr)
+    ref = O.nms_rotated(boxes, scores, thr)
+    got = keep.cpu().numpy()
+    if not np.array_equal(got, ref):
+        # a decision may flip only where an IoU sits within fp32 noise of the threshold
+        iou = O.box_iou_rotated(boxes, boxes)
+        assert (np.abs(iou - thr) < 1e-5).any(), (len(got), len(ref))
+    assert dets.shape == (len(got), 6) and torch.equal(dets[:, 5].cpu(), torch.from_numpy(scores[got]))
+    assert ops.nms_rotated(T(boxes), T(scores), thr, max_keep=3)[1].numel() == min(3, len(ref))
+
+
+def test_points_in_boxes_batch_vs_oracle():
+    g = np.random.default_rng(3)
+    B, M, Tn = 3, 5000, 40
+    pts = g.uniform(-12, 12, (B, M, 3)).astype(np.float32)
+    boxes = np.concatenate([g.uniform(-10, 10, (B, Tn, 2)), g.uniform(-3, 1, (B, Tn, 1)), g.uniform(0.5, 6, (B, Tn, 3)),
+                            g.uniform(-4, 4, (B, Tn, 1))], 2).astype(np.float32)
+    part = ops.points_in_boxes_part(T(pts), T(boxes)).cpu().numpy()
+    allb = ops.points_in_boxes_all(T(pts), T(boxes)).cpu().numpy()
+    for b in range(B):
+        assert np.array_equal(part[b], O.points_in_boxes(pts[b], boxes[b]))
+        assert np.array_equal(allb[b], O.points_in_boxes(pts[b], boxes[b], all_boxes=True))
+    assert (part >= 0).sum() > 100
+
+
+def test_simple_test_inference_path():
+    cfg = Config.fromfile(os.path.join(REPO, 'configs', 'gga', 'gga_kitti_pointpillars_config.py'))
+    torch.manual_seed(0)
+    model = build_model(cfg.model).to(DEV).eval()
+    b = synthetic.make_batch(2, n_points=8000, pc_range=synthetic.RANGE_PP)
+    res = model(return_loss=False, points=[[p.to(DEV) for p in b['points']]], img_metas=[b['img_metas']])
+    assert len(res) == 2
+    tc = cfg.model.test_cfg.pts
+    for r in res:
+        d = r['pts_bbox']
+        n = len(d['boxes_3d'])
+        assert d['boxes_3d'].tensor.shape == (n, 7) and d['scores_3d'].shape == (n,) and d['labels_3d'].shape == (n,)
+        assert n <= 3 * tc.post_max_size and set(d['labels_3d'].tolist()) <= {0, 1, 2}
+        if n:
+            assert float(d['scores_3d'].min()) >= tc.score_threshold
+            # survivors of one class do not overlap beyond the NMS threshold
+            for c in range(3):
+                bx = d['boxes_3d'].tensor[d['labels_3d'] == c].to(DEV)
+                if len(bx) > 1:
+                    iou = ops.box_iou_rotated(bx[:, [0, 1, 3, 4, 6]], bx[:, [0, 1, 3, 4, 6]]).cpu()
+                    iou.fill_diagonal_(0)
+                    assert float(iou.max()) <= tc.nms_thr + 1e-4

@@ -115,6 +115,7 @@ def main():
                          'same logical tensors and values)')
     ap.add_argument('--head-init-scale', type=float, default=0.05,
                     help='damp the random init of the regression heads\' output convs (see damp_head_init)')
+    ap.add_argument('--miopen-find', action='store_true', help='torch.backends.cudnn.benchmark=True (MIOpen find mode)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     args = ap.parse_args()
@@ -130,6 +131,7 @@ def main():
     device = torch.device('cuda', local_rank % torch.cuda.device_count())
     torch.cuda.set_device(device)
 
+    torch.backends.cudnn.benchmark = bool(args.miopen_find)
     cfg = Config.fromfile(args.config)
     if args.channels_last and cfg.model.pts_middle_encoder.type == 'PointPillarsScatter':
         cfg.model.pts_middle_encoder['channels_last'] = True
@@ -137,7 +139,8 @@ def main():
     model = build_model(cfg.model).to(device)
     damp_head_init(model, args.head_init_scale)
     if args.channels_last:
-        model = model.to(memory_format=torch.channels_last)
+        from gga_amd.cnn import to_channels_last
+        model = to_channels_last(model)
     model.train()
     runner = Runner(model, cfg, max_iters=max(1000, args.steps + args.warmup), distributed=world > 1, device=device)
 

@@ -102,3 +102,13 @@ class ConvModule(nn.Module):
         if self.with_activation:
             x = self.activate(x)
         return x
+
+
+def to_channels_last(model):
+    """Put the dense 2D trunk (Conv2d / ConvTranspose2d weights) in channels-last memory so MIOpen
+    runs its NHWC kernels; values, shapes and ``state_dict`` are unchanged. Sparse-conv weights
+    (5-D) and everything else are left alone."""
+    for m in model.modules():
+        if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+            m.weight.data = m.weight.data.contiguous(memory_format=torch.channels_last)
+    return model

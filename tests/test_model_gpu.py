@@ -43,7 +43,8 @@ def test_pp_train_step_matches_cpu_reference(channels_last):
     ref_losses, _ = R.reference_train_step(ref, batch, srl=srl)
     model.to(DEV)
     if channels_last:
-        model.to(memory_format=torch.channels_last)
+        from gga_amd.cnn import to_channels_last
+        to_channels_last(model)
     data = dict(batch, points=[p.to(DEV) for p in batch['points']])
     feats = model.extract_feat(data['points'], None, data['img_metas'])[1]
     outs = model.pts_bbox_head(feats)

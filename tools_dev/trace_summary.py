@@ -8,9 +8,14 @@ ap.add_argument('--out')
 a = ap.parse_args()
 f = glob.glob(a.dir + '/**/*_kernel_trace.csv', recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
+# one train step = one vox_insert_kernel ... until the optimizer's last kernel; bench.py's roofline
+# probe (which also voxelizes once) runs after the timed steps and is cut off at its first scatter_map
 starts = sorted(int(r['Start_Timestamp']) for r in rows if r['Kernel_Name'].startswith('vox_insert_kernel'))
+opt = sorted(int(r['End_Timestamp']) for r in rows if 'FusedOptimizerTensorListMetadata' in r['Kernel_Name'] or 'multi_tensor_apply' in r['Kernel_Name'])
+t1 = opt[-1]
+starts = [t for t in starts if t < t1]
 t0 = starts[-a.steps]
-t1 = max(int(r['End_Timestamp']) for r in rows)
+rows = [r for r in rows if int(r['End_Timestamp']) <= t1]
 agg = collections.defaultdict(lambda: [0, 0])
 for r in rows:
     if int(r['Start_Timestamp']) >= t0:

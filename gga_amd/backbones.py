@@ -4,7 +4,7 @@ import numpy as np
 import torch
 from torch import nn
 
-from .cnn import build_conv_layer, build_norm_layer, build_upsample_layer, kaiming_init
+from .cnn import build_conv_layer, build_norm_layer, build_upsample_layer, kaiming_init, run_conv_bn_relu
 from .registry import BACKBONES, NECKS
 
 
@@ -35,7 +35,7 @@ class SECOND(nn.Module):
     def forward(self, x):
         outs = []
         for blk in self.blocks:
-            x = blk(x)
+            x = run_conv_bn_relu(blk, x)
             outs.append(x)
         return tuple(outs)
 
@@ -68,5 +68,5 @@ class SECONDFPN(nn.Module):
 
     def forward(self, x):
         assert len(x) == len(self.in_channels)
-        ups = [deblock(x[i]) for i, deblock in enumerate(self.deblocks)]
+        ups = [run_conv_bn_relu(deblock, x[i]) for i, deblock in enumerate(self.deblocks)]
         return [torch.cat(ups, dim=1) if len(ups) > 1 else ups[0]]

@@ -98,10 +98,28 @@ class ConvModule(nn.Module):
     def forward(self, x):
         x = self.conv(x)
         if self.with_norm:
-            x = self.norm(x)
+            from . import functional as F        # fused BN(+ReLU) HIP pass for channels-last activations
+            return F.bn_act(x, self.norm, relu=self.with_activation)
         if self.with_activation:
             x = self.activate(x)
         return x
+
+
+def run_conv_bn_relu(seq, x):
+    """Run an ``nn.Sequential`` made of (conv, BatchNorm, ReLU) triples — the block structure of
+    SECOND / SECONDFPN — with the BatchNorm+ReLU pairs fused (``functional.bn_act``)."""
+    from . import functional as F
+    mods = list(seq)
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        if (isinstance(m, nn.modules.batchnorm._BatchNorm) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)):
+            x = F.bn_act(x, m, relu=True)
+            i += 2
+        else:
+            x = m(x)
+            i += 1
+    return x
 
 
 def to_channels_last(model):

@@ -1,0 +1,337 @@
+// Fused BatchNorm (+ residual add) (+ ReLU) over a [rows, C] row-major tensor, forward and backward
+// (gfx950). [rows, C] is both the sparse feature matrix of SparseEncoder ([N, C]) and the memory of
+// a channels-last [B, C, H, W] activation of the BEV trunk ([B*H*W, C]).
+//
+// Reference: the BN + ReLU pairs of mmdet3d/models/backbones/second.py:46-63, necks/
+// second_fpn.py:66-69, dense_heads/centerpoint_head.py (ConvModule), ops/sparse_block.py:117-134
+// (norm1+relu, norm2 + identity + relu) and sparse_block.py:186-196 run as separate cuDNN / ATen
+// kernels: stats, normalise, ReLU, (add), and in backward ReLU-grad, reduce, elementwise — 13
+// passes over the activation per layer. Here:
+//   fwd  pass 1  per-channel sum / sum of squares (f32 per thread over a short run, f64 across)
+//        pass 2  y = relu(x*scale + shift (+ residual)); the ReLU sign is kept as 1 bit/element
+//   bwd  pass 1  sum g, sum g*xhat with g = dy * sign bit           (reads dy, x, bits)
+//        pass 2  dx = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)), d_residual = g
+// 8 passes, all 16 B/lane coalesced, fixed-order (deterministic) reductions.
+// A thread always owns the same 4 channels: its float4 index advances by a multiple of C/4.
+#include "gga_common.h"
+
+#define BN_MAX_BLOCKS 2048
+#define BN_U 4            // independent 16 B loads in flight per thread
+
+struct BnGeom {
+    int64_t n4;      // rows * C / 4
+    int c4;          // C / 4
+};
+
+static int bn_grid(int64_t n4) {
+    int64_t b = (n4 + 256 * BN_U - 1) / (256 * BN_U);
+    if (b < 1) b = 1;
+    return (int)(b > BN_MAX_BLOCKS ? BN_MAX_BLOCKS : b);
+}
+
+// partials layout: [block][stat][C]  (stat 0/1)
+template <bool BWD>
+__global__ __launch_bounds__(256) void bn_reduce_kernel(const float4* __restrict__ a, const float4* __restrict__ b,
+                                                       const unsigned long long* __restrict__ bits,
+                                                       const float* __restrict__ saved, BnGeom g, int relu,
+                                                       double* __restrict__ partials) {
+    // forward : a = x                -> sums of x and x^2
+    // backward: a = dy, b = x, bits  -> sums of g and g*xhat
+    const int tid = threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    const int64_t e0 = (int64_t)blockIdx.x * 256 + tid;
+    const int cg = (int)(e0 % g.c4);                  // fixed channel group of this thread
+    float mean[4] = {0, 0, 0, 0}, inv[4] = {1, 1, 1, 1};
+    if (BWD) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { mean[j] = saved[cg * 4 + j]; inv[j] = saved[g.c4 * 4 + cg * 4 + j]; }
+    }
+    double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+    float f0[4] = {0, 0, 0, 0}, f1[4] = {0, 0, 0, 0};
+    int run = 0;
+    for (int64_t eb = e0; eb < g.n4; eb += stride * BN_U) {
+        float4 av[BN_U], bv[BN_U];
+        unsigned long long wv[BN_U][4];
+#pragma unroll
+        for (int u = 0; u < BN_U; ++u) {                 // issue every load of the batch first
+            const int64_t e = eb + u * stride;
+            av[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            bv[u] = av[u];
+            if (e < g.n4) {
+                av[u] = a[e];
+                if (BWD) {
+                    bv[u] = b[e];
+                    if (relu) {
+                        const unsigned long long* w = bits + (e >> 6) * 4;   // [e / 64][component]
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) wv[u][j] = w[j];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < BN_U; ++u) {
+            const int64_t e = eb + u * stride;
+            if (e >= g.n4) continue;
+            float va[4] = { av[u].x, av[u].y, av[u].z, av[u].w };
+            if (BWD) {
+                const float xa[4] = { bv[u].x, bv[u].y, bv[u].z, bv[u].w };
+                if (relu) {
+                    const int l = (int)(e & 63);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (!((wv[u][j] >> l) & 1ull)) va[j] = 0.0f;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { f0[j] += va[j]; f1[j] += va[j] * ((xa[j] - mean[j]) * inv[j]); }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { f0[j] += va[j]; f1[j] += va[j] * va[j]; }
+            }
+        }
+        if (++run == 8) {                               // flush the short f32 run (32 rows) into f64
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { s0[j] += f0[j]; s1[j] += f1[j]; f0[j] = 0; f1[j] = 0; }
+            run = 0;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { s0[j] += f0[j]; s1[j] += f1[j]; }
+    __shared__ double sh[256][8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { sh[tid][j] = s0[j]; sh[tid][4 + j] = s1[j]; }
+    __syncthreads();
+    // threads with the same channel group are tid = cg0 + k*c4 (256 % c4 == 0 when c4 <= 256)
+    const int cg0 = (int)(((int64_t)blockIdx.x * 256) % g.c4);
+    const int per = g.c4 <= 256 ? g.c4 : 256;
+    if (tid < per) {
+        double r[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int t = tid; t < 256; t += per)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) r[q] += sh[t][q];
+        const int grp = (cg0 + tid) % g.c4;
+        double* out = partials + (int64_t)blockIdx.x * 2 * g.c4 * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { out[grp * 4 + j] = r[j]; out[g.c4 * 4 + grp * 4 + j] = r[4 + j]; }
+    }
+}
+
+// one thread per channel
+__global__ __launch_bounds__(64) void bn_fwd_final_kernel(const double* __restrict__ partials, int nblocks, int C,
+                                                          double rows, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float eps, float momentum,
+                                                          int training, float* __restrict__ running_mean,
+                                                          float* __restrict__ running_var, float* __restrict__ saved,
+                                                          float* __restrict__ scale_shift) {
+    // one wavefront per channel: lanes stride over the block partials, fixed-order butterfly sum
+    const int c = blockIdx.x, lane = threadIdx.x;
+    float mean, invstd;
+    if (training) {
+        double s = 0.0, ss = 0.0;
+        for (int b = lane; b < nblocks; b += 64) { s += partials[(int64_t)b * 2 * C + c]; ss += partials[(int64_t)b * 2 * C + C + c]; }
+        s = wave_sum(s); ss = wave_sum(ss);
+        const double mu = s / rows;
+        double var = ss / rows - mu * mu;
+        var = var > 0.0 ? var : 0.0;
+        mean = (float)mu;
+        invstd = (float)(1.0 / sqrt(var + (double)eps));
+        const double unb = rows > 1.0 ? var * rows / (rows - 1.0) : var;
+        if (lane == 0) {
+            running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * mean;
+            running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)unb;
+        }
+    } else {
+        mean = running_mean[c];
+        invstd = 1.0f / sqrtf(running_var[c] + eps);
+    }
+    if (lane != 0) return;
+    saved[c] = mean;
+    saved[C + c] = invstd;
+    const float sc = (gamma ? gamma[c] : 1.0f) * invstd;
+    scale_shift[c] = sc;
+    scale_shift[C + c] = (beta ? beta[c] : 0.0f) - mean * sc;
+}
+
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float4* __restrict__ x, const float4* __restrict__ res,
+                                                      const float* __restrict__ scale_shift, BnGeom g, int relu,
+                                                      float4* __restrict__ y, unsigned long long* __restrict__ bits) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    const int64_t e0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int cg = (int)(e0 % g.c4);
+    const int C = g.c4 * 4;
+    const float4 sc = *reinterpret_cast<const float4*>(scale_shift + cg * 4);
+    const float4 sh = *reinterpret_cast<const float4*>(scale_shift + C + cg * 4);
+    const int64_t n4_round = (g.n4 + 63) & ~63ll;       // whole waves iterate together (ballot)
+    for (int64_t eb = e0; eb < n4_round; eb += stride * BN_U) {
+        float4 xv[BN_U], rv[BN_U];
+#pragma unroll
+        for (int u = 0; u < BN_U; ++u) {
+            const int64_t e = eb + u * stride;
+            xv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            rv[u] = xv[u];
+            if (e < g.n4) { xv[u] = x[e]; if (res) rv[u] = res[e]; }
+        }
+#pragma unroll
+        for (int u = 0; u < BN_U; ++u) {
+            const int64_t e = eb + u * stride;
+            if (e >= n4_round) continue;                 // wave-uniform: e and n4_round are multiples of 64 apart
+            const bool live = e < g.n4;
+            float4 v;
+            v.x = xv[u].x * sc.x + sh.x + rv[u].x; v.y = xv[u].y * sc.y + sh.y + rv[u].y;
+            v.z = xv[u].z * sc.z + sh.z + rv[u].z; v.w = xv[u].w * sc.w + sh.w + rv[u].w;
+            if (relu) {
+                const unsigned long long b0 = __ballot(live && v.x > 0.0f), b1 = __ballot(live && v.y > 0.0f);
+                const unsigned long long b2 = __ballot(live && v.z > 0.0f), b3 = __ballot(live && v.w > 0.0f);
+                if ((threadIdx.x & 63) == 0) {
+                    unsigned long long* w = bits + (e >> 6) * 4;
+                    w[0] = b0; w[1] = b1; w[2] = b2; w[3] = b3;
+                }
+                v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f);
+            }
+            if (live) y[e] = v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void bn_bwd_final_kernel(const double* __restrict__ partials, int nblocks, int C,
+                                                          double rows, const float* __restrict__ gamma,
+                                                          const float* __restrict__ saved, float* __restrict__ dgamma,
+                                                          float* __restrict__ dbeta, float* __restrict__ coef) {
+    const int c = blockIdx.x, lane = threadIdx.x;
+    double s = 0.0, sx = 0.0;
+    for (int b = lane; b < nblocks; b += 64) { s += partials[(int64_t)b * 2 * C + c]; sx += partials[(int64_t)b * 2 * C + C + c]; }
+    s = wave_sum(s); sx = wave_sum(sx);
+    if (lane != 0) return;
+    if (dbeta) dbeta[c] = (float)s;
+    if (dgamma) dgamma[c] = (float)sx;
+    const float k = (gamma ? gamma[c] : 1.0f) * saved[C + c];
+    coef[c] = k;                              // gamma * invstd
+    coef[C + c] = (float)(s / rows);          // mean(g)
+    coef[2 * C + c] = (float)(sx / rows);     // mean(g * xhat)
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float4* __restrict__ dy, const float4* __restrict__ x,
+                                                          const unsigned long long* __restrict__ bits,
+                                                          const float* __restrict__ saved, const float* __restrict__ coef,
+                                                          BnGeom g, int relu, float4* __restrict__ dx,
+                                                          float4* __restrict__ dres) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    const int64_t e0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int cg = (int)(e0 % g.c4);
+    const int C = g.c4 * 4;
+    float mean[4], inv[4], k[4], mg[4], mgx[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        mean[j] = saved[cg * 4 + j]; inv[j] = saved[C + cg * 4 + j];
+        k[j] = coef[cg * 4 + j]; mg[j] = coef[C + cg * 4 + j]; mgx[j] = coef[2 * C + cg * 4 + j];
+    }
+    for (int64_t eb = e0; eb < g.n4; eb += stride * BN_U) {
+        float4 gv[BN_U], xv[BN_U];
+        unsigned long long wv[BN_U][4];
+#pragma unroll
+        for (int u = 0; u < BN_U; ++u) {
+            const int64_t e = eb + u * stride;
+            if (e < g.n4) {
+                gv[u] = dy[e]; xv[u] = x[e];
+                if (relu) {
+                    const unsigned long long* w = bits + (e >> 6) * 4;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) wv[u][j] = w[j];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < BN_U; ++u) {
+            const int64_t e = eb + u * stride;
+            if (e >= g.n4) continue;
+            float ga[4] = { gv[u].x, gv[u].y, gv[u].z, gv[u].w };
+            const float xa[4] = { xv[u].x, xv[u].y, xv[u].z, xv[u].w };
+            if (relu) {
+                const int l = (int)(e & 63);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (!((wv[u][j] >> l) & 1ull)) ga[j] = 0.0f;
+            }
+            float o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = k[j] * (ga[j] - mg[j] - ((xa[j] - mean[j]) * inv[j]) * mgx[j]);
+            dx[e] = make_float4(o[0], o[1], o[2], o[3]);
+            if (dres) dres[e] = make_float4(ga[0], ga[1], ga[2], ga[3]);
+        }
+    }
+}
+
+extern "C" size_t gga_bn_relu_workspace_bytes(int64_t rows, int channels) {
+    (void)rows;
+    return (size_t)BN_MAX_BLOCKS * 2 * channels * sizeof(double) + 3 * (size_t)channels * sizeof(float) + 256;
+}
+extern "C" size_t gga_bn_relu_mask_bytes(int64_t rows, int channels) {
+    const int64_t n4 = rows * channels / 4;
+    return (size_t)((n4 + 63) / 64) * 4 * sizeof(unsigned long long);
+}
+
+static int bn_check(const char* fn, int64_t rows, int C) {
+    GGA_REQUIRE(rows >= 1 && C >= 4 && C % 4 == 0, "%s: need rows >= 1 and channels %% 4 == 0 (rows=%lld C=%d)", fn,
+                (long long)rows, C);
+    const int c4 = C / 4;
+    GGA_REQUIRE(c4 <= 256 && 256 % c4 == 0, "%s: channels/4 (%d) must divide 256", fn, c4);
+    return GGA_OK;
+}
+
+extern "C" int gga_bn_relu_fwd(const float* x, const float* residual, const float* gamma, const float* beta,
+                               float* running_mean, float* running_var, int64_t rows, int channels, float eps,
+                               float momentum, int training, int relu, float* y, void* mask_bits, float* saved,
+                               void* workspace, size_t workspace_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (int rc = bn_check("gga_bn_relu_fwd", rows, channels)) return rc;
+    GGA_REQUIRE(x && y && saved && workspace && running_mean && running_var && (!relu || mask_bits),
+                "gga_bn_relu_fwd: null pointer argument");
+    if (workspace_bytes < gga_bn_relu_workspace_bytes(rows, channels)) {
+        gga_set_error("gga_bn_relu_fwd: workspace too small");
+        return GGA_ERR_WORKSPACE;
+    }
+    const BnGeom g = { rows * channels / 4, channels / 4 };
+    const int nb = bn_grid(g.n4);
+    double* partials = (double*)workspace;
+    float* scale_shift = (float*)((char*)workspace + (size_t)BN_MAX_BLOCKS * 2 * channels * sizeof(double));
+    if (training) {
+        hipLaunchKernelGGL(bn_reduce_kernel<false>, dim3(nb), dim3(256), 0, stream, (const float4*)x, (const float4*)nullptr,
+                           (const unsigned long long*)nullptr, (const float*)nullptr, g, 0, partials);
+        GGA_CHECK_LAUNCH("bn_reduce_kernel<fwd>");
+    }
+    hipLaunchKernelGGL(bn_fwd_final_kernel, dim3(channels), dim3(64), 0, stream, partials, nb, channels,
+                       (double)rows, gamma, beta, eps, momentum, training, running_mean, running_var, saved,
+                       scale_shift);
+    GGA_CHECK_LAUNCH("bn_fwd_final_kernel");
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(nb), dim3(256), 0, stream, (const float4*)x, (const float4*)residual,
+                       scale_shift, g, relu, (float4*)y, (unsigned long long*)mask_bits);
+    GGA_CHECK_LAUNCH("bn_apply_kernel");
+    return GGA_OK;
+}
+
+extern "C" int gga_bn_relu_bwd(const float* grad_y, const float* x, const void* mask_bits, const float* gamma,
+                               const float* saved, int64_t rows, int channels, int relu, float* grad_x,
+                               float* grad_residual, float* grad_gamma, float* grad_beta, void* workspace,
+                               size_t workspace_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (int rc = bn_check("gga_bn_relu_bwd", rows, channels)) return rc;
+    GGA_REQUIRE(grad_y && x && saved && grad_x && workspace && (!relu || mask_bits),
+                "gga_bn_relu_bwd: null pointer argument");
+    if (workspace_bytes < gga_bn_relu_workspace_bytes(rows, channels)) {
+        gga_set_error("gga_bn_relu_bwd: workspace too small");
+        return GGA_ERR_WORKSPACE;
+    }
+    const BnGeom g = { rows * channels / 4, channels / 4 };
+    const int nb = bn_grid(g.n4);
+    double* partials = (double*)workspace;
+    float* coef = (float*)((char*)workspace + (size_t)BN_MAX_BLOCKS * 2 * channels * sizeof(double));
+    hipLaunchKernelGGL(bn_reduce_kernel<true>, dim3(nb), dim3(256), 0, stream, (const float4*)grad_y, (const float4*)x,
+                       (const unsigned long long*)mask_bits, saved, g, relu, partials);
+    GGA_CHECK_LAUNCH("bn_reduce_kernel<bwd>");
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(channels), dim3(64), 0, stream, partials, nb, channels,
+                       (double)rows, gamma, saved, grad_gamma, grad_beta, coef);
+    GGA_CHECK_LAUNCH("bn_bwd_final_kernel");
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nb), dim3(256), 0, stream, (const float4*)grad_y, (const float4*)x,
+                       (const unsigned long long*)mask_bits, saved, coef, g, relu, (float4*)grad_x,
+                       (float4*)grad_residual);
+    GGA_CHECK_LAUNCH("bn_bwd_apply_kernel");
+    return GGA_OK;
+}

@@ -371,3 +371,65 @@ def box_losses(pred, ind, mask, anno_box, lidar2img, bound_mask, ibp_xy, ibp_off
     final dict values) and ``box_out [B,K,12]`` (rot, l, w, box2d[4], X, Y, p2c_min/x/y)."""
     return _BoxLosses.apply(pred, ind.contiguous(), mask.contiguous(), anno_box.contiguous(),
                             lidar2img.contiguous(), bound_mask.contiguous(), ibp_xy, ibp_offsets, ibp_slot, prm)
+
+
+# ----------------------------------------------------------------------------- fused BN (+res) (+ReLU)
+class _BNAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, residual, gamma, beta, running_mean, running_var, eps, momentum, training, relu, rows, C):
+        L = _lib.lib()
+        dev = x.device
+        y = torch.empty_like(x)                       # same strides (channels-last stays channels-last)
+        saved = torch.empty(2 * C, dtype=torch.float32, device=dev)
+        bits = torch.empty(L.gga_bn_relu_mask_bytes(rows, C), dtype=torch.uint8, device=dev) if relu else None
+        ws = _workspace('bn', L.gga_bn_relu_workspace_bytes(rows, C), dev)
+        check(L.gga_bn_relu_fwd(_p(x), _p(residual), _p(gamma), _p(beta), _p(running_mean), _p(running_var), rows, C,
+                                eps, momentum, int(training), int(relu), _p(y), _p(bits), _p(saved), _p(ws),
+                                ws.numel(), _stream()), 'gga_bn_relu_fwd')
+        ctx.save_for_backward(x, gamma, saved, bits)
+        ctx.cfg = (rows, C, relu, residual is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, gamma, saved, bits = ctx.saved_tensors
+        rows, C, relu, has_res = ctx.cfg
+        L = _lib.lib()
+        # the incoming gradient must have the memory layout of x ([rows, C] row major)
+        gy = gy.contiguous(memory_format=torch.channels_last) if x.dim() == 4 else gy.contiguous()
+        gx = torch.empty_like(x)
+        gres = torch.empty_like(x) if has_res else None
+        gg, gb = torch.empty(C, dtype=torch.float32, device=x.device), torch.empty(C, dtype=torch.float32, device=x.device)
+        ws = _workspace('bn', L.gga_bn_relu_workspace_bytes(rows, C), x.device)
+        check(L.gga_bn_relu_bwd(_p(gy), _p(x), _p(bits), _p(gamma), _p(saved), rows, C, int(relu), _p(gx), _p(gres),
+                                _p(gg), _p(gb), _p(ws), ws.numel(), _stream()), 'gga_bn_relu_bwd')
+        return gx, gres, gg, gb, None, None, None, None, None, None, None, None
+
+
+def _rows_channels(x):
+    """[rows, C] view of a 2-D contiguous or 4-D channels-last tensor, else None."""
+    if x.dim() == 2 and x.is_contiguous():
+        return x.shape[0], x.shape[1]
+    if x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last) and not (x.shape[1] == 1):
+        return x.shape[0] * x.shape[2] * x.shape[3], x.shape[1]
+    return None
+
+
+def bn_act(x, bn, relu=True, residual=None):
+    """``relu(bn(x) + residual)`` (each part optional) — one fused HIP pass pair when ``x`` is a CUDA
+    f32 [rows, C] / channels-last tensor in training mode, the eager ops otherwise."""
+    rc = _rows_channels(x) if (x.is_cuda and x.dtype == torch.float32) else None
+    C = x.shape[1]
+    ok = (rc is not None and rc[0] >= 1 and C % 4 == 0 and C // 4 <= 256 and 256 % (C // 4) == 0 and bn.affine
+          and bn.track_running_stats and bn.momentum is not None
+          and (bn.training or not torch.is_grad_enabled())
+          and (residual is None or (residual.shape == x.shape and residual.stride() == x.stride())))
+    if not ok:
+        y = bn(x)
+        if residual is not None:
+            y = y + residual
+        return torch.relu(y) if relu else y
+    if bn.training:
+        bn.num_batches_tracked += 1
+    return _BNAct.apply(x, residual, bn.weight, bn.bias, bn.running_mean, bn.running_var, float(bn.eps),
+                        float(bn.momentum), bool(bn.training), bool(relu), int(rc[0]), int(C))

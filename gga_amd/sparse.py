@@ -165,11 +165,20 @@ class SparseSequential(SparseModule):
         self.add_module(name or str(len(self._modules)), module)
 
     def forward(self, x):
-        for m in self._modules.values():
+        mods = list(self._modules.values())
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            i += 1
             if isinstance(m, SparseModule):
                 x = m(x)
             elif isinstance(x, SparseConvTensor):
-                if x.features.shape[0] != 0:
+                if x.features.shape[0] == 0:
+                    continue
+                if isinstance(m, nn.modules.batchnorm._BatchNorm) and i < len(mods) and isinstance(mods[i], nn.ReLU):
+                    x = x.replace_feature(F.bn_act(x.features, m, relu=True))     # fused BN + ReLU on [N, C]
+                    i += 1
+                else:
                     x = x.replace_feature(m(x.features))
             else:
                 x = m(x)

@@ -5,6 +5,7 @@ mmdet3d/ops/sparse_block.py:82-199; ``BasicBlock`` attribute names conv1/bn1/con
 mmdet's resnet), on the sparse layers of ``gga_amd.sparse``."""
 from torch import nn
 
+from . import functional as F
 from .cnn import build_conv_layer, build_norm_layer
 from .registry import MIDDLE_ENCODERS
 from .sparse import SparseConvTensor, SparseModule, SparseSequential
@@ -32,10 +33,10 @@ class SparseBasicBlock(SparseModule):
         identity = x.features
         assert x.features.dim() == 2, f'x.features.dim()={x.features.dim()}'
         out = self.conv1(x)
-        out = out.replace_feature(self.relu(self.norm1(out.features)))
+        out = out.replace_feature(F.bn_act(out.features, self.norm1, relu=True))
         out = self.conv2(out)
-        out = out.replace_feature(self.norm2(out.features))
-        out = out.replace_feature(self.relu(out.features + identity))
+        # relu(norm2(.) + identity) in one fused pass
+        out = out.replace_feature(F.bn_act(out.features, self.norm2, relu=True, residual=identity))
         return out
 
 

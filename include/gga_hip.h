@@ -216,6 +216,28 @@ int gga_sparse_conv_wgrad(const float* x, const float* grad_out, const int32_t* 
                           int kvol, int cin, int cout, float* grad_weight, void* stream);
 
 /* ------------------------------------------------------------------------- */
+/* a4/a5 (elementwise part). Fused training-mode BatchNorm (+ residual add)   */
+/* (+ ReLU) over a [rows, channels] row-major tensor = the sparse [N,C]        */
+/* features and the memory of a channels-last [B,C,H,W] activation.           */
+/* Replaces the separate BN / ReLU / add kernels of                            */
+/*   mmdet3d/models/backbones/second.py:46-63, necks/second_fpn.py:66-69,      */
+/*   dense_heads/centerpoint_head.py (ConvModule), ops/sparse_block.py:117-134 */
+/* y = relu(bn(x) + residual); channels % 4 == 0 and channels/4 must divide 256. */
+/* ------------------------------------------------------------------------- */
+size_t gga_bn_relu_workspace_bytes(int64_t rows, int channels);
+size_t gga_bn_relu_mask_bytes(int64_t rows, int channels);   /* 1 bit / element ReLU sign */
+/* saved [2*channels] f32 receives mean / invstd; running stats are updated when training. */
+int gga_bn_relu_fwd(const float* x, const float* residual, const float* gamma, const float* beta,
+                    float* running_mean, float* running_var, int64_t rows, int channels, float eps,
+                    float momentum, int training, int relu, float* y, void* mask_bits, float* saved,
+                    void* workspace, size_t workspace_bytes, void* stream);
+/* batch-statistics backward: grad_x, optional grad_residual (= masked grad_y), grad_gamma/beta. */
+int gga_bn_relu_bwd(const float* grad_y, const float* x, const void* mask_bits, const float* gamma,
+                    const float* saved, int64_t rows, int channels, int relu, float* grad_x,
+                    float* grad_residual, float* grad_gamma, float* grad_beta, void* workspace,
+                    size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------- */
 /* a6/a7. Heat-map target splat on the device.                                */
 /* Replaces the per-object numpy gaussian + H2D copy + torch.max(out=) of     */
 /* mmdet3d/core/utils/gaussian.py:25-54 called from                           */

@@ -311,3 +311,58 @@ def test_fused_pfn_full_size():
     for a, b in zip(pfn.parameters(), ref.parameters()):
         err = float((a.grad - b.grad).abs().max() / b.grad.abs().max())
         assert err < 1e-3, err
+
+
+@pytest.mark.parametrize('shape,cl', [((70001, 16), False), ((3000, 128), False), ((4, 64, 62, 54), True),
+                                       ((2, 256, 31, 27), True), ((3, 8, 5, 7), True)])
+@pytest.mark.parametrize('relu,res', [(True, False), (False, False), (True, True)])
+def test_fused_bn_act_vs_torch(shape, cl, relu, res):
+    """Fused BatchNorm(+residual)(+ReLU) against eager torch: values, running stats, all gradients."""
+    torch.manual_seed(0)
+    C = shape[1]
+    bn = (torch.nn.BatchNorm2d if len(shape) == 4 else torch.nn.BatchNorm1d)(C, eps=1e-3, momentum=0.01).to(DEV)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5), bn.bias.uniform_(-0.5, 0.5)
+    ref = copy_bn = __import__('copy').deepcopy(bn)
+    x = torch.randn(*shape, device=DEV) * 3 + 1.5
+    r = torch.randn(*shape, device=DEV) if res else None
+    if cl:
+        x = x.contiguous(memory_format=torch.channels_last)
+        r = r.contiguous(memory_format=torch.channels_last) if res else None
+    x1, x2 = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    r1 = r.clone().requires_grad_(True) if res else None
+    r2 = r.clone().requires_grad_(True) if res else None
+    assert F._rows_channels(x1) is not None
+    y = F.bn_act(x1, bn, relu=relu, residual=r1)
+    yr = ref(x2)
+    if res:
+        yr = yr + r2
+    if relu:
+        yr = torch.relu(yr)
+    torch.testing.assert_close(y, yr, rtol=1e-4, atol=1e-4)
+    assert y.stride() == x.stride()
+    torch.testing.assert_close(bn.running_mean, ref.running_mean, rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(bn.running_var, ref.running_var, rtol=1e-4, atol=1e-6)
+    assert int(bn.num_batches_tracked) == 1
+    g = torch.randn_like(yr)
+    y.backward(g)
+    yr.backward(g)
+    # an element whose pre-activation rounds to either side of 0 may take the other ReLU branch
+    near0 = (yr.detach().abs() < 1e-5) & (y.detach().abs() < 1e-5) if relu else torch.zeros_like(yr, dtype=torch.bool)
+    assert int(near0.sum()) <= max(3, yr.numel() // 10000) or not relu or float((yr.detach() == 0).float().mean()) > 0.2
+    gx1, gx2 = x1.grad.clone(), x2.grad.clone()
+    flip = (gx1 - gx2).abs() > 1e-4 + 1e-3 * gx2.abs()
+    assert int(flip.sum()) <= 3 and bool((near0 | ~flip).all() or int(flip.sum()) <= 3)
+    gx1[flip] = gx2[flip]
+    torch.testing.assert_close(gx1, gx2, rtol=1e-3, atol=1e-4)
+    # (a flipped boundary element also moves its channel's d_gamma / d_beta by one g value)
+    torch.testing.assert_close(bn.weight.grad, ref.weight.grad, rtol=1e-2, atol=1e-2)
+    torch.testing.assert_close(bn.bias.grad, ref.bias.grad, rtol=1e-2, atol=1e-2)
+    if res:
+        assert int(((r1.grad - r2.grad).abs() > 1e-6).sum()) <= 3
+    # eval mode uses the running statistics
+    bn.eval(), ref.eval()
+    with torch.no_grad():
+        ye = F.bn_act(x, bn, relu=relu, residual=r)
+        yre = ref(x) + (r if res else 0)
+        torch.testing.assert_close(ye, torch.relu(yre) if relu else yre, rtol=1e-4, atol=1e-4)

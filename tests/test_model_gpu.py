@@ -73,6 +73,10 @@ def test_runner_steps_and_loss_decreases():
     cfg = Config.fromfile(PP_CFG)
     torch.manual_seed(0)
     model = build_model(cfg.model).to(DEV)
+    with torch.no_grad():       # keep exp(log-dims) finite on noise inputs (see bench.damp_head_init)
+        for th in model.pts_bbox_head.task_heads:
+            for name in ('reg', 'height', 'dim', 'rot'):
+                getattr(th, name)[-1].weight.mul_(0.05)
     runner = Runner(model, cfg, max_iters=100)
     b = synthetic.make_batch(2, n_points=4000, pc_range=synthetic.RANGE_PP)
     b['points'] = [p.to(DEV) for p in b['points']]

@@ -64,7 +64,14 @@ class SeparateHead(nn.Module):
                 self.__getattr__(head)[-1].bias.data.fill_(self.init_bias)
 
     def forward(self, x):
-        return {head: self.__getattr__(head)(x) for head in self.heads}
+        out = {}
+        for head in self.heads:
+            seq = self.__getattr__(head)
+            y = x
+            for m in list(seq)[:-1]:
+                y = m(y)
+            out[head] = F.head_conv3x3(y, seq[-1])     # 1-3 channel output conv: HBM-bound HIP kernel
+        return out
 
 
 def _to_np(x, dtype=None):

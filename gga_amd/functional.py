@@ -433,3 +433,50 @@ def bn_act(x, bn, relu=True, residual=None):
         bn.num_batches_tracked += 1
     return _BNAct.apply(x, residual, bn.weight, bn.bias, bn.running_mean, bn.running_var, float(bn.eps),
                         float(bn.momentum), bool(bn.training), bool(relu), int(rc[0]), int(C))
+
+
+# ----------------------------------------------------------------------------- head output convs
+class _HeadConv3x3(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        B, C, H, W = x.shape
+        cout = weight.shape[0]
+        w = weight.contiguous()                       # logical [cout, 64, 3, 3], NCHW-contiguous
+        y = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device)
+        check(_lib.lib().gga_head_conv3x3_fwd(_p(x), _p(w), _p(bias), B, H, W, C, cout, _p(y), _stream()),
+              'gga_head_conv3x3_fwd')
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gy = gy.contiguous()
+        B, C, H, W = x.shape
+        cout = w.shape[0]
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            # the input gradient writes the full [B,64,H,W] tensor: already bandwidth-bound in MIOpen
+            gx = torch.ops.aten.convolution_backward(gy, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                                     [True, False, False])[0]
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            gw = torch.empty_like(w)
+            gb = torch.empty(cout, dtype=torch.float32, device=x.device) if ctx.has_bias else None
+            L = _lib.lib()
+            ws = _workspace('headconv', L.gga_head_conv3x3_workspace_bytes(cout), x.device)
+            check(L.gga_head_conv3x3_wgrad(_p(x), _p(gy), B, H, W, C, cout, _p(gw), _p(gb), _p(ws), ws.numel(),
+                                           _stream()), 'gga_head_conv3x3_wgrad')
+        return gx, gw, gb
+
+
+def head_conv3x3(x, conv):
+    """``conv(x)`` for the output convs of the head branches (64 -> 1..4 channels, 3x3, pad 1): the
+    HBM-bound HIP kernels when ``x`` is a CUDA f32 channels-last activation, MIOpen otherwise."""
+    ok = (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == 64
+          and x.is_contiguous(memory_format=torch.channels_last) and conv.out_channels <= 4
+          and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1)
+          and conv.dilation == (1, 1) and conv.groups == 1 and conv.padding_mode == 'zeros')
+    if not ok:
+        return conv(x)
+    return _HeadConv3x3.apply(x, conv.weight, conv.bias)

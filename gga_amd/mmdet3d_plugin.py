@@ -1,0 +1,17 @@
+"""Register the MI355X classes into the REFERENCE's registry.
+
+Only meaningful inside a checkout of the reference (mmdet3d importable):
+``import gga_amd.mmdet3d_plugin`` before ``build_model`` replaces the CUDA-backed classes by the
+HIP-backed ones under the same names, so ``configs/gga/*.py`` run unchanged."""
+import gga_amd
+from gga_amd.registry import MODELS as _OURS
+
+try:
+    from mmdet3d.models.builder import MODELS as _THEIRS
+except ImportError as e:        # not inside the reference: nothing to plug into
+    raise ImportError('gga_amd.mmdet3d_plugin needs the reference (mmdet3d) to be importable') from e
+
+NAMES = ('GGA', 'MVXTwoStageDetector_GGA', 'CenterHead_GGA', 'SeparateHead', 'SECOND', 'SECONDFPN',
+         'PointPillarsScatter', 'SparseEncoder', 'HardSimpleVFE', 'PillarFeatureNet')
+for _name in NAMES:
+    _THEIRS.register_module(name=_name, force=True, module=_OURS.get(_name))

@@ -237,6 +237,19 @@ int gga_bn_relu_bwd(const float* grad_y, const float* x, const void* mask_bits, 
                     float* grad_residual, float* grad_gamma, float* grad_beta, void* workspace,
                     size_t workspace_bytes, void* stream);
 
+/* a5 (output convs of the head branches): 3x3 conv, 64 input channels -> 1..4 output channels,
+ * stride 1, pad 1, + bias. Replaces the last layer of each SeparateHead branch,
+ * mmdet3d/models/dense_heads/centerpoint_head.py:70-79 (HBM-bound, not GEMM-shaped).
+ * x: channels-last memory [B,H,W,64] of a [B,64,H,W] tensor; weight [cout,64,3,3]; y [B,cout,H,W]
+ * NCHW-contiguous. The input gradient stays with the framework's convolution backward. */
+int gga_head_conv3x3_fwd(const float* x, const float* weight, const float* bias, int B, int H, int W,
+                         int cin, int cout, float* y, void* stream);
+/* grad_weight [cout,64,3,3] and grad_bias [cout] (optional) from grad_y [B,cout,H,W] */
+size_t gga_head_conv3x3_workspace_bytes(int cout);
+int gga_head_conv3x3_wgrad(const float* x, const float* grad_y, int B, int H, int W, int cin, int cout,
+                           float* grad_weight, float* grad_bias, void* workspace, size_t workspace_bytes,
+                           void* stream);
+
 /* ------------------------------------------------------------------------- */
 /* a6/a7. Heat-map target splat on the device.                                */
 /* Replaces the per-object numpy gaussian + H2D copy + torch.max(out=) of     */

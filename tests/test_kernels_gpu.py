@@ -366,3 +366,33 @@ def test_fused_bn_act_vs_torch(shape, cl, relu, res):
         ye = F.bn_act(x, bn, relu=relu, residual=r)
         yre = ref(x) + (r if res else 0)
         torch.testing.assert_close(ye, torch.relu(yre) if relu else yre, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize('cout,bias', [(1, True), (2, True), (3, True), (4, False)])
+def test_head_output_conv_vs_torch(cout, bias):
+    """64 -> 1..4 channel 3x3 output conv of the head branches against torch's convolution."""
+    torch.manual_seed(cout)
+    B, H, W = 3, 37, 29
+    conv = torch.nn.Conv2d(64, cout, 3, padding=1, bias=bias).to(DEV)
+    x = torch.randn(B, 64, H, W, device=DEV).contiguous(memory_format=torch.channels_last)
+    x1, x2 = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    y = F.head_conv3x3(x1, conv)
+    assert y.is_contiguous() and y.grad_fn is not None and 'HeadConv' in type(y.grad_fn).__name__
+    ref = conv(x2)
+    torch.testing.assert_close(y, ref, rtol=1e-4, atol=1e-4)
+    g = torch.randn_like(ref)
+    gw_ref, gb_ref = None, None
+    ref.backward(g)
+    gw_ref = conv.weight.grad.clone()
+    gb_ref = conv.bias.grad.clone() if bias else None
+    conv.weight.grad = None
+    if bias:
+        conv.bias.grad = None
+    y.backward(g.contiguous())
+    torch.testing.assert_close(x1.grad, x2.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(conv.weight.grad, gw_ref, rtol=1e-3, atol=1e-3)
+    if bias:
+        torch.testing.assert_close(conv.bias.grad, gb_ref, rtol=1e-4, atol=1e-3)
+    # NCHW input falls back to the framework convolution
+    z = F.head_conv3x3(x.contiguous(), conv)
+    torch.testing.assert_close(z, ref.detach(), rtol=1e-4, atol=1e-4)

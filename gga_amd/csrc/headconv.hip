@@ -166,13 +166,16 @@ __global__ __launch_bounds__(256) void headconv_wgrad_kernel(const float* __rest
                                                (gds[2 * COUT + threadIdx.x] + gds[3 * COUT + threadIdx.x]);
 }
 
+// one wavefront per output value: lanes stride over the block partials (fixed order)
 __global__ __launch_bounds__(256) void headconv_wgrad_final_kernel(const float* __restrict__ partials, int nblocks,
                                                                   int n_w, int cout, float* __restrict__ dw,
                                                                   float* __restrict__ dbias) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (i >= n_w + cout) return;
     double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += (double)partials[(int64_t)b * (n_w + cout) + i];
+    for (int b = lane; b < nblocks; b += 64) s += (double)partials[(int64_t)b * (n_w + cout) + i];
+    s = wave_sum(s);
+    if (lane != 0) return;
     if (i < n_w) dw[i] = (float)s;
     else if (dbias) dbias[i - n_w] = (float)s;
 }
@@ -224,7 +227,7 @@ extern "C" int gga_head_conv3x3_wgrad(const float* x, const float* grad_y, int B
 #undef HC_W
     GGA_CHECK_LAUNCH("headconv_wgrad_kernel");
     const int n_w = cout * HC_CIN * 9;
-    hipLaunchKernelGGL(headconv_wgrad_final_kernel, dim3((n_w + cout + 255) / 256), dim3(256), 0, stream, partials, nb, n_w,
+    hipLaunchKernelGGL(headconv_wgrad_final_kernel, dim3((n_w + cout + 3) / 4), dim3(256), 0, stream, partials, nb, n_w,
                        cout, grad_weight, grad_bias);
     GGA_CHECK_LAUNCH("headconv_wgrad_final_kernel");
     return GGA_OK;

@@ -234,16 +234,17 @@ __global__ __launch_bounds__(256) void scatter_canvas_nchw_v2_kernel(const float
 // NHWC canvas (channels-last memory): one thread = 4 channels of one cell; the
 // channels/4 lanes of a cell read the same map word (broadcast) and write one
 // contiguous row.
+template <int U>
 __global__ __launch_bounds__(256) void scatter_canvas_nhwc_kernel(const float* __restrict__ feats,
                                                                  int32_t* __restrict__ cell_map, int c4,
                                                                  int64_t total4, float* __restrict__ canvas) {
-    // 4 independent 16 B pieces per thread (block covers 1024 consecutive float4s), streaming stores
+    // U independent 16 B pieces per thread (block covers U*256 consecutive float4s), streaming stores
     const int shift = ((c4 & (c4 - 1)) == 0) ? (31 - __clz(c4)) : -1;
-    const int64_t base = (int64_t)blockIdx.x * 1024 + threadIdx.x;
-    int32_t idx[4];
-    int cc[4];
+    const int64_t base = (int64_t)blockIdx.x * (U * 256) + threadIdx.x;
+    int32_t idx[U];
+    int cc[U];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < U; ++u) {
         const int64_t t = base + u * 256;
         idx[u] = -1; cc[u] = 0;
         if (t < total4) {
@@ -252,17 +253,26 @@ __global__ __launch_bounds__(256) void scatter_canvas_nhwc_kernel(const float* _
             idx[u] = cell_map[cell];
         }
     }
-    float4 v[4];
+    float4 v[U];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < U; ++u) {
         v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (idx[u] >= 0) v[u] = reinterpret_cast<const float4*>(feats)[(int64_t)idx[u] * c4 + cc[u]];
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < U; ++u) {
         const int64_t t = base + u * 256;
         if (t < total4) store4<true>(reinterpret_cast<float4*>(canvas) + t, v[u]);
     }
+}
+
+static void launch_canvas_nhwc(hipStream_t stream, const float* feats, int32_t* cell_map, int c4, int64_t total4,
+                               float* canvas) {
+    static int u = -1;
+    if (u < 0) { const char* e = getenv("GGA_SCATTER_NHWC_UNROLL"); u = e ? atoi(e) : 1; }   // measured: 1 piece/thread + NT stores = 7.6 TB/s, 4 = 5.8, 16 = 5.6
+#define NH(U) hipLaunchKernelGGL(scatter_canvas_nhwc_kernel<U>, dim3((unsigned)((total4 + U * 256 - 1) / (U * 256))), dim3(256), 0, stream, feats, cell_map, c4, total4, canvas)
+    if (u == 2) NH(2); else if (u == 4) NH(4); else if (u == 8) NH(8); else if (u == 16) NH(16); else NH(1);
+#undef NH
 }
 
 __global__ __launch_bounds__(256) void scatter_map_reset_kernel(const int32_t* __restrict__ coors, int64_t m,
@@ -376,8 +386,7 @@ extern "C" int gga_pillar_scatter_fwd(const float* feats, const int32_t* coors, 
     } else {
         const int c4 = channels / 4;
         const int64_t total4 = (int64_t)batch * cells * c4;
-        hipLaunchKernelGGL(scatter_canvas_nhwc_kernel, dim3((unsigned)((total4 + 1023) / 1024)), dim3(256), 0, stream,
-                           feats, cell_map, c4, total4, canvas);
+        launch_canvas_nhwc(stream, feats, cell_map, c4, total4, canvas);
         GGA_CHECK_LAUNCH("scatter_canvas_nhwc_kernel");
         if (m > 0) {   // NHWC readers share map words, so the reset is its own (4 B/pillar) pass
             hipLaunchKernelGGL(scatter_map_reset_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, stream,
@@ -428,8 +437,7 @@ extern "C" int gga_profile_pillar_scatter(const float* feats, const int32_t* coo
         } else {
             const int c4 = channels / 4;
             const int64_t total4 = (int64_t)batch * cells * c4;
-            hipLaunchKernelGGL(scatter_canvas_nhwc_kernel, dim3((unsigned)((total4 + 1023) / 1024)), dim3(256), 0,
-                               stream, feats, cell_map, c4, total4, canvas);
+            launch_canvas_nhwc(stream, feats, cell_map, c4, total4, canvas);
             (void)hipEventRecord(e2, stream);
             hipLaunchKernelGGL(scatter_map_reset_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, stream,
                                coors, m, (const int32_t*)nullptr, batch, ny, nx, cell_map);

@@ -60,4 +60,7 @@ if __name__ == '__main__':
         one()
     else:
         for v in sys.argv[1:] or ['0', '1', '2', '9']:
-            subprocess.call([sys.executable, __file__, 'one'], env=dict(os.environ, GGA_SCATTER_VARIANT=v))
+            if v.startswith('u'):
+                subprocess.call([sys.executable, __file__, 'one'], env=dict(os.environ, GGA_SCATTER_NHWC_UNROLL=v[1:]))
+            else:
+                subprocess.call([sys.executable, __file__, 'one'], env=dict(os.environ, GGA_SCATTER_VARIANT=v))

@@ -341,113 +341,87 @@ extern "C" int gga_sparse_rulebook(const int32_t* out_coors, int64_t n_out, cons
 }
 
 // ------------------------------------------------------------------------------ convolution
-// Y[r, :] = sum_k X[map[kk][r], :] @ Wk   (kk = K-1-k when `flip`),  Wk = W[k] ([Cin,Cout] row
-// major) or its transpose when `wt`. Tile: 64 rows x CO cols per 256-thread workgroup; thread
-// (ty = tid / 16, tx = tid % 16) owns rows 4*ty..4*ty+3 and cols tx + 16*j.
-#define SP_TM 64
-#define SP_TK 16
-
-template <int CO>   // CO = padded output channels handled by the workgroup: 16, 32, 64 or 128
-__global__ __launch_bounds__(256) void sp_conv_kernel(const float* __restrict__ X, const int32_t* __restrict__ map,
-                                                     const float* __restrict__ W, int64_t n_rows, int kvol, int cin,
-                                                     int cout, int flip, int wt, float* __restrict__ Y) {
-    constexpr int NJ = CO / 16;
-    __shared__ float As[SP_TM][SP_TK + 1];
-    __shared__ float Ws[SP_TK][CO];
-    __shared__ int rows[SP_TM];
-    __shared__ int any_s;
-    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
-    const int64_t r0 = (int64_t)blockIdx.x * SP_TM;
-    float acc[4][NJ];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) acc[i][j] = 0.0f;
-
-    for (int k = 0; k < kvol; ++k) {
-        const int kk = flip ? (kvol - 1 - k) : k;
-        if (tid == 0) any_s = 0;
-        __syncthreads();
-        if (tid < SP_TM) {
-            const int64_t r = r0 + tid;
-            const int v = r < n_rows ? map[(int64_t)kk * n_rows + r] : -1;
-            rows[tid] = v;
-            if (v >= 0) any_s = 1;
-        }
-        __syncthreads();
-        if (!any_s) continue;                           // no row of this tile uses offset k
-        const float* Wk = W + (int64_t)k * cin * cout;
-        for (int c0 = 0; c0 < cin; c0 += SP_TK) {
-            // stage A: 64 rows x 16 input channels (zeros for absent neighbours / channel tail)
-            for (int t = tid; t < SP_TM * SP_TK; t += 256) {
-                const int rr = t >> 4, cc = t & 15;
-                const int v = rows[rr];
-                As[rr][cc] = (v >= 0 && c0 + cc < cin) ? X[(int64_t)v * cin + c0 + cc] : 0.0f;
-            }
-            // stage W: 16 input channels x CO output channels
-            for (int t = tid; t < SP_TK * CO; t += 256) {
-                const int cc = t / CO, oo = t - cc * CO;
-                float w = 0.0f;
-                if (c0 + cc < cin && oo < cout)
-                    w = wt ? Wk[(int64_t)oo * cin + c0 + cc] : Wk[(int64_t)(c0 + cc) * cout + oo];
-                Ws[cc][oo] = w;
-            }
-            __syncthreads();
-#pragma unroll
-            for (int cc = 0; cc < SP_TK; ++cc) {
-                float a[4], b[NJ];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) a[i] = As[ty * 4 + i][cc];
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) b[j] = Ws[cc][tx + 16 * j];
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j) acc[i][j] += a[i] * b[j];
-            }
-            __syncthreads();
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int64_t r = r0 + ty * 4 + i;
-        if (r >= n_rows) continue;
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int o = tx + 16 * j;
-            if (o < cout) Y[r * cout + o] = acc[i][j];
-        }
-    }
-}
-
-
-// ---- MFMA version ------------------------------------------------------------------------
-// v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD): a 256-thread workgroup owns 128 output
-// rows (taken through `perm`, which orders rows by their neighbour bit mask so that a tile's rows
-// use the same kernel offsets) x NT*32 output channels; wave w owns rows 32w..32w+31 and all
-// NT column tiles (NT*16 accumulator registers). Offsets whose bit is clear in the OR of the
-// tile's row masks are skipped without touching memory. Per (offset, 32-channel chunk): the
-// gathered input rows [128 x 32] and the weight slice [32 x NT*32] are staged in LDS (global
-// loads for the next chunk are issued before the MFMAs of the current one).
+// Y[r, :] = sum_k X[map[kk][r], :] @ W[k]   (kk = K-1-k when `flip`) on v_mfma_f32_32x32x2_f32
+// (exact fp32, 64 FLOP/clk/SIMD).
+//
+// A 256-thread workgroup owns 128 output rows (taken through `perm`, which orders rows by their
+// neighbour bit mask so that a tile's rows use the same kernel offsets) x NT*32 output channels;
+// wave w owns rows 32w..32w+31 and all NT column tiles (NT*16 accumulator registers). Offsets
+// whose bit is clear in the OR of the tile's row masks are skipped without touching memory, and a
+// wave skips the MFMAs of offsets none of its own 32 rows uses.
+//
+// Work is a flat sequence of (offset, 32-input-channel chunk) stages. Per stage the gathered
+// input rows [128 x 32] and the weight slice [32 x NT*32] sit in LDS in *fragment order*: the
+// 32x32x2 A operand of lane (h = lane/32, m = lane%32) at k-step s is A[m][2s+h], so row m keeps
+// its even channels in floats 0..15 and its odd channels in 16..31 and a lane fetches four
+// k-steps with one ds_read_b128; the weights are packed the same way on the host side of the
+// ABI (gga_sparse_pack_weight), 16*NT contiguous floats per lane and stage, so staging them is a
+// straight 16-byte copy. Row strides of 36 / 16*NT+4 floats keep the b128 reads conflict-free.
+// The global loads of stage i+1 (and the rule-book entries of the offset after it) are issued
+// before the MFMAs of stage i and land in LDS after them.
 #define MF_TM 128
 #define MF_TK 32
+#define MF_ASTR 36
 typedef float mf_v16 __attribute__((ext_vector_type(16)));
 
-template <int NT>
+static inline int mf_nt(int cout) { return cout <= 32 ? 1 : (cout <= 64 ? 2 : 4); }
+
+// packed[k][chunk][lane = h*32+n][g][t][j] = W[k][chunk*32 + 2*(4g+j) + h][t*32 + n]
+__global__ __launch_bounds__(256) void sp_pack_weight_kernel(const float* __restrict__ W, int kvol, int cin, int cout,
+                                                            int nt, int transpose, int64_t total,
+                                                            float* __restrict__ P) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int per_lane = 16 * nt, per_stage = 64 * per_lane;
+    const int nchunks = (cin + MF_TK - 1) / MF_TK;
+    const int64_t stage = i / per_stage;
+    int r = (int)(i - stage * per_stage);
+    const int k = (int)(stage / nchunks), ch = (int)(stage - (int64_t)k * nchunks);
+    const int lane = r / per_lane; r -= lane * per_lane;
+    const int g = r / (4 * nt); r -= g * 4 * nt;
+    const int t = r >> 2, j = r & 3;
+    const int c = ch * MF_TK + 2 * (4 * g + j) + (lane >> 5), o = t * 32 + (lane & 31);
+    float v = 0.0f;
+    if (c < cin && o < cout)
+        v = transpose ? W[((int64_t)k * cout + o) * cin + c] : W[((int64_t)k * cin + c) * cout + o];
+    P[i] = v;
+}
+
+extern "C" size_t gga_sparse_packed_weight_bytes(int kvol, int cin, int cout) {
+    if (kvol < 1 || cin < 1 || cout < 1 || cout > 128) return 0;
+    return (size_t)kvol * ((cin + MF_TK - 1) / MF_TK) * 64 * 16 * mf_nt(cout) * sizeof(float);
+}
+
+extern "C" int gga_sparse_pack_weight(const float* weight, int kvol, int cin, int cout, int transpose, float* packed,
+                                      void* stream) {
+    GGA_REQUIRE(weight && packed, "gga_sparse_pack_weight: null pointer argument");
+    GGA_REQUIRE(kvol >= 1 && cin >= 1 && cout >= 1 && cout <= 128, "gga_sparse_pack_weight: bad sizes (kvol=%d cin=%d cout=%d; cout <= 128)",
+                kvol, cin, cout);
+    const int64_t total = (int64_t)(gga_sparse_packed_weight_bytes(kvol, cin, cout) / sizeof(float));
+    hipLaunchKernelGGL(sp_pack_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       weight, kvol, cin, cout, mf_nt(cout), transpose, total, packed);
+    GGA_CHECK_LAUNCH("sp_pack_weight_kernel");
+    return GGA_OK;
+}
+
+template <int NT, bool VEC>
 __global__ __launch_bounds__(256) void sp_conv_mfma_kernel(const float* __restrict__ X, const int32_t* __restrict__ map,
-                                                          const float* __restrict__ W,
+                                                          const float* __restrict__ Wp,
                                                           const int32_t* __restrict__ perm,
                                                           const uint32_t* __restrict__ rowmask, int64_t n_rows,
                                                           int kvol, int cin, int cout, int flip,
                                                           float* __restrict__ Y) {
-    constexpr int CO = NT * 32;
-    __shared__ float As[MF_TM][MF_TK + 1];
-    __shared__ float Bs[MF_TK][CO];
+    constexpr int BL = 16 * NT;            // packed weight floats per lane and stage
+    constexpr int BSTR = BL + 4;           // LDS stride of a lane's block
+    constexpr int ASZ = MF_TM * MF_ASTR, BSZ = 64 * BSTR;
+    __shared__ __attribute__((aligned(16))) float As[2 * ASZ];      // double buffered: one barrier per stage
+    __shared__ __attribute__((aligned(16))) float Bs[2 * BSZ];
     __shared__ int prow[MF_TM];
-    __shared__ uint32_t tmask_s;
+    __shared__ uint32_t wmask_s[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t r0 = (int64_t)blockIdx.x * MF_TM;
-    if (tid == 0) tmask_s = 0;
+    // mask-sorted order puts the rows with the most neighbours last: start those tiles first
+    const int64_t r0 = (int64_t)(gridDim.x - 1 - blockIdx.x) * MF_TM;
+    if (tid < 4) wmask_s[tid] = 0;
     __syncthreads();
     if (tid < MF_TM) {
         const int64_t r = r0 + tid;
@@ -455,80 +429,153 @@ __global__ __launch_bounds__(256) void sp_conv_mfma_kernel(const float* __restri
         if (r < n_rows) pr = perm ? perm[r] : (int)r;
         prow[tid] = pr;
         uint32_t m = 0;
-        if (pr >= 0) m = rowmask ? rowmask[pr] : 0xFFFFFFFFu;
-        if (m) atomicOr(&tmask_s, m);
+        if (pr >= 0) m = (rowmask && kvol <= 32) ? rowmask[pr] : 0xFFFFFFFFu;
+        if (m) atomicOr(&wmask_s[tid >> 5], m);
     }
     __syncthreads();
-    const uint32_t tmask = tmask_s;
+    // wave-uniform: keep them in scalar registers so the offset scan below is scalar code
+    const uint32_t wmask = __builtin_amdgcn_readfirstlane(wmask_s[wave]);
+    const uint32_t tmask = __builtin_amdgcn_readfirstlane(wmask_s[0] | wmask_s[1] | wmask_s[2] | wmask_s[3]);
     mf_v16 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
 
-    // staging roles: A: thread loads float4 #q of row ar (2 rows per thread: ar, ar+64)
-    const int ar = tid >> 2, aq = tid & 3;         // 64 rows x 4 quads per pass, 2 passes; 8 floats per quad-pair
     const int nchunks = (cin + MF_TK - 1) / MF_TK;
-    for (int k = 0; k < kvol; ++k) {
+    // staging roles. A: thread (ar = tid/4, aq = tid%4) loads float4 #aq and #aq+4 of the 32-channel
+    // chunk for rows ar and ar+64. B: NT float4 of the packed stage, consecutive across threads.
+    const int ar = tid >> 2, aq = tid & 3;
+    const int p0 = prow[ar], p1 = prow[ar + 64];
+    auto enabled = [&](int k) { const int kk = flip ? (kvol - 1 - k) : k; return kvol > 32 || ((tmask >> kk) & 1u); };
+    auto next_enabled = [&](int k) { while (k < kvol && !enabled(k)) ++k; return k; };
+    auto load_idx = [&](int k, int& i0, int& i1) {
         const int kk = flip ? (kvol - 1 - k) : k;
-        if (kvol <= 32 && !((tmask >> kk) & 1u)) continue;
         const int32_t* mk = map + (int64_t)kk * n_rows;
-        const int p0 = prow[ar], p1 = prow[ar + 64];
-        const int in0 = p0 >= 0 ? mk[p0] : -1, in1 = p1 >= 0 ? mk[p1] : -1;
-        const float* Wk = W + (int64_t)k * cin * cout;
-        for (int ch = 0; ch < nchunks; ++ch) {
-            const int c0 = ch * MF_TK;
-            // ---- global -> registers
-            float4 a0[2], a1[2];
+        i0 = mk[p0 >= 0 ? p0 : 0];        // rows past n_rows gather something valid; they are never written
+        i1 = mk[p1 >= 0 ? p1 : 0];
+    };
+    float4 a0[2], a1[2];
+    float4 bq0, bq1, bq2, bq3;             // named (not an array): keeps them in registers across the MFMA phase
+    bq0 = bq1 = bq2 = bq3 = make_float4(0.f, 0.f, 0.f, 0.f);
+    // loads are unconditional (absent neighbours / channels past cin read row 0 / channel 0 and
+    // are zeroed when they are written to LDS), so nothing waits on them before the MFMAs
+    auto load_stage = [&](int k, int ch, int i0, int i1) {
+        const int c0 = ch * MF_TK;
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int cc = c0 + (aq + 4 * h) * 4;
-                a0[h] = make_float4(0.f, 0.f, 0.f, 0.f);
-                a1[h] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (cc + 3 < cin) {
-                    if (in0 >= 0) a0[h] = *reinterpret_cast<const float4*>(X + (int64_t)in0 * cin + cc);
-                    if (in1 >= 0) a1[h] = *reinterpret_cast<const float4*>(X + (int64_t)in1 * cin + cc);
-                } else if (cc < cin) {       // channel tail (cin not a multiple of 4)
-                    float t0[4] = {0, 0, 0, 0}, t1[4] = {0, 0, 0, 0};
-                    for (int e = 0; e < 4 && cc + e < cin; ++e) {
-                        if (in0 >= 0) t0[e] = X[(int64_t)in0 * cin + cc + e];
-                        if (in1 >= 0) t1[e] = X[(int64_t)in1 * cin + cc + e];
-                    }
-                    a0[h] = make_float4(t0[0], t0[1], t0[2], t0[3]);
-                    a1[h] = make_float4(t1[0], t1[1], t1[2], t1[3]);
+        for (int h = 0; h < 2; ++h) {
+            const int cc = c0 + (aq + 4 * h) * 4;
+            if (VEC) {
+                const int co = cc < cin ? cc : 0;
+                a0[h] = *reinterpret_cast<const float4*>(X + (int64_t)(i0 >= 0 ? i0 : 0) * cin + co);
+                a1[h] = *reinterpret_cast<const float4*>(X + (int64_t)(i1 >= 0 ? i1 : 0) * cin + co);
+            } else {                       // channel count not a multiple of 4: scalar gathers
+                float t0[4], t1[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int co = cc + e < cin ? cc + e : 0;
+                    t0[e] = X[(int64_t)(i0 >= 0 ? i0 : 0) * cin + co];
+                    t1[e] = X[(int64_t)(i1 >= 0 ? i1 : 0) * cin + co];
                 }
+                a0[h] = make_float4(t0[0], t0[1], t0[2], t0[3]);
+                a1[h] = make_float4(t1[0], t1[1], t1[2], t1[3]);
             }
-            float breg[(MF_TK * CO) / 256];
+        }
+        const float4* src = reinterpret_cast<const float4*>(Wp + ((int64_t)k * nchunks + ch) * (64 * BL));
+        bq0 = src[tid];
+        if (NT > 1) bq1 = src[tid + 256];
+        if (NT > 2) { bq2 = src[tid + 512]; bq3 = src[tid + 768]; }
+    };
+    auto store_stage = [&](int buf, int ch, int i0, int i1) {
 #pragma unroll
-            for (int e = 0; e < (MF_TK * CO) / 256; ++e) {
-                const int t = tid + 256 * e;
-                const int cc = t / CO, oo = t - cc * CO;
-                breg[e] = (c0 + cc < cin && oo < cout) ? Wk[(int64_t)(c0 + cc) * cout + oo] : 0.0f;
+        for (int h = 0; h < 2; ++h) {
+            const int q = aq + 4 * h;      // channels 4q..4q+3 -> k-steps 2q, 2q+1 of halves 0 (x, z) and 1 (y, w)
+            const int cc = ch * MF_TK + 4 * q;
+            const bool v0 = i0 >= 0, v1 = i1 >= 0;
+            const bool cx = cc < cin, cy = cc + 1 < cin, cz = cc + 2 < cin, cw = cc + 3 < cin;
+            float* d0 = As + buf * ASZ + ar * MF_ASTR + 2 * q;
+            float* d1 = d0 + 64 * MF_ASTR;
+            *reinterpret_cast<float2*>(d0) = make_float2(v0 && cx ? a0[h].x : 0.f, v0 && cz ? a0[h].z : 0.f);
+            *reinterpret_cast<float2*>(d0 + 16) = make_float2(v0 && cy ? a0[h].y : 0.f, v0 && cw ? a0[h].w : 0.f);
+            *reinterpret_cast<float2*>(d1) = make_float2(v1 && cx ? a1[h].x : 0.f, v1 && cz ? a1[h].z : 0.f);
+            *reinterpret_cast<float2*>(d1 + 16) = make_float2(v1 && cy ? a1[h].y : 0.f, v1 && cw ? a1[h].w : 0.f);
+        }
+        // float4 #f of the stage belongs to lane block f / (4*NT), piece f % (4*NT)
+#define MF_BST(E, V) { const int f = tid + 256 * (E); *reinterpret_cast<float4*>(Bs + buf * BSZ + (f / (4 * NT)) * BSTR + (f % (4 * NT)) * 4) = V; }
+        MF_BST(0, bq0);
+        if (NT > 1) MF_BST(1, bq1);
+        if (NT > 2) { MF_BST(2, bq2); MF_BST(3, bq3); }
+#undef MF_BST
+    };
+
+    // Stage bookkeeping (all wave-uniform): (k, ch) is being multiplied out of LDS buffer `buf`,
+    // (k1, ch1) sits in the staging registers (loaded one iteration ago with rule-book entries
+    // ia0/ia1), (k2, ch2) is fetched during this iteration. Within an iteration the staging work
+    // is placed between the four MFMA groups so its VALU / LDS / VMEM instructions issue in the
+    // shadow of the matrix pipe instead of in a separate phase.
+    int k = next_enabled(0), ch = 0;
+    if (k < kvol) {
+        int ia0, ia1, in0n, in1n;
+        load_idx(k, ia0, ia1);
+        int knext = next_enabled(k + 1);                 // first enabled offset after the one being loaded
+        load_idx(knext < kvol ? knext : k, in0n, in1n);
+        load_stage(k, 0, ia0, ia1);
+        store_stage(0, 0, ia0, ia1);
+        int k1 = k, ch1 = 1;
+        if (ch1 == nchunks) { ch1 = 0; k1 = knext; }
+        auto fetch_next = [&](int kq, int chq) {         // issue the loads of stage (kq, chq); entering a new offset rotates the rule-book registers
+            const bool valid = kq < kvol;
+            const bool adv = valid && chq == 0;
+            ia0 = adv ? in0n : ia0;
+            ia1 = adv ? in1n : ia1;
+            if (adv) knext = next_enabled(kq + 1);
+            load_idx(knext < kvol ? knext : k, in0n, in1n);
+            load_stage(valid ? kq : k, valid ? chq : ch, ia0, ia1);
+        };
+        fetch_next(k1, ch1);
+        __syncthreads();
+        int buf = 0;
+        while (true) {
+            const float* Ap = As + buf * ASZ + (wave * 32 + (lane & 31)) * MF_ASTR + (lane >> 5) * 16;
+            const float* Bp = Bs + buf * BSZ + lane * BSTR;
+            int k2 = k1, ch2 = ch1 + 1;
+            if (ch2 == nchunks) { ch2 = 0; k2 = knext; }
+            const int kk = flip ? (kvol - 1 - k) : k;
+            const bool mm = kvol > 32 || ((wmask >> kk) & 1u);
+#define MF_READ(G, S)                                                                                                \
+            fa[S] = *reinterpret_cast<const float4*>(Ap + 4 * (G));                                                   \
+            _Pragma("unroll") for (int t = 0; t < NT; ++t) fb[S][t] = *reinterpret_cast<const float4*>(Bp + ((G) * NT + t) * 4);
+#define MF_MMA(S)                                                                                                    \
+            _Pragma("unroll") for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[S].x, fb[S][t].x, acc[t], 0, 0, 0); \
+            _Pragma("unroll") for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[S].y, fb[S][t].y, acc[t], 0, 0, 0); \
+            _Pragma("unroll") for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[S].z, fb[S][t].z, acc[t], 0, 0, 0); \
+            _Pragma("unroll") for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[S].w, fb[S][t].w, acc[t], 0, 0, 0);
+            if (mm) {
+                float4 fa[2], fb[2][NT];
+                MF_READ(0, 0);
+                MF_READ(1, 1);
+                MF_MMA(0);
+                __builtin_amdgcn_sched_barrier(0);
+                store_stage(buf ^ 1, ch1, ia0, ia1);     // buf^1 was last read before the previous barrier
+                MF_READ(2, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                MF_MMA(1);
+                __builtin_amdgcn_sched_barrier(0);
+                fetch_next(k2, ch2);
+                MF_READ(3, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                MF_MMA(0);
+                MF_MMA(1);
+            } else {                                     // none of this wave's rows uses the offset
+                store_stage(buf ^ 1, ch1, ia0, ia1);
+                fetch_next(k2, ch2);
             }
-            __syncthreads();                 // previous chunk's MFMAs are done reading LDS
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int cb = (aq + 4 * h) * 4;
-                As[ar][cb] = a0[h].x; As[ar][cb + 1] = a0[h].y; As[ar][cb + 2] = a0[h].z; As[ar][cb + 3] = a0[h].w;
-                As[ar + 64][cb] = a1[h].x; As[ar + 64][cb + 1] = a1[h].y; As[ar + 64][cb + 2] = a1[h].z; As[ar + 64][cb + 3] = a1[h].w;
-            }
-#pragma unroll
-            for (int e = 0; e < (MF_TK * CO) / 256; ++e) {
-                const int t = tid + 256 * e;
-                Bs[t / CO][t % CO] = breg[e];
-            }
+#undef MF_READ
+#undef MF_MMA
+            if (k1 >= kvol) break;
             __syncthreads();
-            // ---- 16 k-steps of 2: A frag lane -> (row 32w + lane%32, k = 2s + lane/32)
-            const int arow = wave * 32 + (lane & 31), khalf = lane >> 5;
-#pragma unroll
-            for (int s2 = 0; s2 < MF_TK / 2; ++s2) {
-                const float a = As[arow][2 * s2 + khalf];
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const float b = Bs[2 * s2 + khalf][t * 32 + (lane & 31)];
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
-                }
-            }
+            buf ^= 1;
+            k = k1; ch = ch1; k1 = k2; ch1 = ch2;
         }
     }
     // D layout of 32x32x2: register v of lane l holds row (v/4)*8 + (l/32)*4 + v%4, column l%32
@@ -562,124 +609,56 @@ extern "C" int gga_sparse_rowmask(const int32_t* map, int64_t n_rows, int kvol, 
     return GGA_OK;
 }
 
-static int sp_conv_variant() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("GGA_SPCONV_VARIANT"); v = e ? atoi(e) : 1; }
-    return v;
-}
-
-extern "C" int gga_sparse_conv_apply(const float* x, const int32_t* map, const float* weight, const int32_t* perm,
+extern "C" int gga_sparse_conv_apply(const float* x, const int32_t* map, const float* packed_weight, const int32_t* perm,
                                      const uint32_t* rowmask, int64_t n_rows, int kvol, int cin, int cout, int flip,
                                      float* y, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    GGA_REQUIRE(x && map && weight && y, "gga_sparse_conv_apply: null pointer argument");
+    GGA_REQUIRE(x && map && packed_weight && y, "gga_sparse_conv_apply: null pointer argument");
     GGA_REQUIRE(n_rows >= 1 && kvol >= 1 && cin >= 1 && cout >= 1 && cout <= 128,
                 "gga_sparse_conv_apply: bad sizes (rows=%lld kvol=%d cin=%d cout=%d; cout <= 128)", (long long)n_rows,
                 kvol, cin, cout);
-    if (sp_conv_variant() == 0) {
-        const dim3 grid((unsigned)((n_rows + SP_TM - 1) / SP_TM)), block(256);
-#define SP_LAUNCH(CO) hipLaunchKernelGGL(sp_conv_kernel<CO>, grid, block, 0, stream, x, map, weight, n_rows, kvol, cin, cout, flip, 0, y)
-        if (cout <= 16) SP_LAUNCH(16);
-        else if (cout <= 32) SP_LAUNCH(32);
-        else if (cout <= 64) SP_LAUNCH(64);
-        else SP_LAUNCH(128);
-#undef SP_LAUNCH
-        GGA_CHECK_LAUNCH("sp_conv_kernel");
-        return GGA_OK;
-    }
     const dim3 grid((unsigned)((n_rows + MF_TM - 1) / MF_TM)), block(256);
-#define MF_LAUNCH(NT) hipLaunchKernelGGL(sp_conv_mfma_kernel<NT>, grid, block, 0, stream, x, map, weight, perm, rowmask, n_rows, kvol, cin, cout, flip, y)
-    if (cout <= 32) MF_LAUNCH(1);
-    else if (cout <= 64) MF_LAUNCH(2);
-    else MF_LAUNCH(4);
+#define MF_LAUNCH(NT, VEC) hipLaunchKernelGGL((sp_conv_mfma_kernel<NT, VEC>), grid, block, 0, stream, x, map, packed_weight, perm, rowmask, n_rows, kvol, cin, cout, flip, y)
+    if ((cin & 3) == 0) {
+        switch (mf_nt(cout)) {
+            case 1: MF_LAUNCH(1, true); break;
+            case 2: MF_LAUNCH(2, true); break;
+            default: MF_LAUNCH(4, true); break;
+        }
+    } else {
+        switch (mf_nt(cout)) {
+            case 1: MF_LAUNCH(1, false); break;
+            case 2: MF_LAUNCH(2, false); break;
+            default: MF_LAUNCH(4, false); break;
+        }
+    }
 #undef MF_LAUNCH
     GGA_CHECK_LAUNCH("sp_conv_mfma_kernel");
     return GGA_OK;
 }
 
-// dW[k][ci][co] += sum_r X[map[k][r]][ci] * G[r][co] over the rows of the chunk.
-// grid = (row chunks, kvol); thread (ty, tx) owns ci = ty + 16*i, co = tx + 16*j.
+
+// ------------------------------------------------------------------------------ weight gradient
+// dW[k] (CI x CO) = Xp^T (CI x pairs) * Gp (pairs x CO) over the valid (input row, output row)
+// pairs of offset k, on v_mfma_f32_32x32x2_f32. grid = (2048-row chunks, kvol): a workgroup
+// compacts the chunk's valid pairs of its offset into LDS, then walks them 32 at a time: the
+// gathered X rows and the G rows of the next 32 pairs are fetched into registers before the
+// MFMAs of the current ones and written to the other LDS buffer after them (one barrier per
+// stage). The NI x NJ 32x32 tiles of dW[k] are dealt to the 4 waves (tile = wave*TPW + t), so
+// the waves of a row of tiles share the X fragment; one atomicAdd per weight and chunk.
 #define SP_WCHUNK 2048
-template <int CI, int CO>
-__global__ __launch_bounds__(256) void sp_conv_wgrad_kernel(const float* __restrict__ X, const float* __restrict__ G,
-                                                           const int32_t* __restrict__ map, int64_t n_rows, int cin,
-                                                           int cout, float* __restrict__ dW) {
-    constexpr int NI = CI / 16, NJ = CO / 16;
-    __shared__ float Xs[32][CI + 1];
-    __shared__ float Gs[32][CO + 1];
-    __shared__ int pin[SP_WCHUNK];       // compacted valid pairs of the chunk: input row
-    __shared__ int pout[SP_WCHUNK];      //                                      output row (chunk-local)
-    __shared__ int npairs;
-    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
-    const int k = blockIdx.y;
-    const int64_t r0 = (int64_t)blockIdx.x * SP_WCHUNK;
-    if (tid == 0) npairs = 0;
-    __syncthreads();
-    for (int t = tid; t < SP_WCHUNK; t += 256) {
-        const int64_t r = r0 + t;
-        const int v = r < n_rows ? map[(int64_t)k * n_rows + r] : -1;
-        if (v >= 0) { const int p = atomicAdd(&npairs, 1); pin[p] = v; pout[p] = t; }
-    }
-    __syncthreads();
-    const int np = npairs;
-    if (np == 0) return;
-    float acc[NI][NJ];
-#pragma unroll
-    for (int i = 0; i < NI; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) acc[i][j] = 0.0f;
-    for (int p0 = 0; p0 < np; p0 += 32) {
-        for (int t = tid; t < 32 * CI; t += 256) {
-            const int pp = t / CI, cc = t - pp * CI;
-            Xs[pp][cc] = (p0 + pp < np && cc < cin) ? X[(int64_t)pin[p0 + pp] * cin + cc] : 0.0f;
-        }
-        for (int t = tid; t < 32 * CO; t += 256) {
-            const int pp = t / CO, oo = t - pp * CO;
-            Gs[pp][oo] = (p0 + pp < np && oo < cout) ? G[(r0 + pout[p0 + pp]) * cout + oo] : 0.0f;
-        }
-        __syncthreads();
-#pragma unroll 8
-        for (int pp = 0; pp < 32; ++pp) {
-            float a[NI], b[NJ];
-#pragma unroll
-            for (int i = 0; i < NI; ++i) a[i] = Xs[pp][ty + 16 * i];
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) b[j] = Gs[pp][tx + 16 * j];
-#pragma unroll
-            for (int i = 0; i < NI; ++i)
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) acc[i][j] += a[i] * b[j];
-        }
-        __syncthreads();
-    }
-    float* dWk = dW + (int64_t)k * cin * cout;
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-        const int ci = ty + 16 * i;
-        if (ci >= cin) continue;
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int co = tx + 16 * j;
-            if (co < cout && acc[i][j] != 0.0f) atomicAdd(&dWk[(int64_t)ci * cout + co], acc[i][j]);
-        }
-    }
-}
-
-
-// MFMA version of the weight gradient: dW[k] (CI x CO) = Xp^T (CI x pairs) * Gp (pairs x CO) for the
-// compacted valid pairs of one 2048-row chunk; 32x32 tiles are dealt to the 4 waves
-// (tile t = i*NJ + j -> wave t / TPW), 32 pairs per LDS stage, one atomicAdd per weight per chunk.
-template <int NI, int NJ>
+template <int NI, int NJ, bool VEC>
 __global__ __launch_bounds__(256) void sp_conv_wgrad_mfma_kernel(const float* __restrict__ X, const float* __restrict__ G,
                                                                 const int32_t* __restrict__ map, int64_t n_rows,
                                                                 int cin, int cout, float* __restrict__ dW) {
     constexpr int CI = NI * 32, CO = NJ * 32;
     constexpr int TILES = NI * NJ;
     constexpr int TPW = (TILES + 3) / 4;             // tiles per wave
-    __shared__ float Xs[32][CI];
-    __shared__ float Gs[32][CO];
-    __shared__ int pin[SP_WCHUNK];
-    __shared__ int pout[SP_WCHUNK];
+    constexpr int XSZ = 32 * CI, GSZ = 32 * CO;
+    __shared__ __attribute__((aligned(16))) float Xs[2 * XSZ];
+    __shared__ __attribute__((aligned(16))) float Gs[2 * GSZ];
+    __shared__ int pin[SP_WCHUNK];       // compacted valid pairs of the chunk: input row
+    __shared__ uint16_t pout[SP_WCHUNK]; //                                      output row (chunk-local)
     __shared__ int npairs;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int k = blockIdx.y;
@@ -689,7 +668,7 @@ __global__ __launch_bounds__(256) void sp_conv_wgrad_mfma_kernel(const float* __
     for (int t = tid; t < SP_WCHUNK; t += 256) {
         const int64_t r = r0 + t;
         const int v = r < n_rows ? map[(int64_t)k * n_rows + r] : -1;
-        if (v >= 0) { const int p = atomicAdd(&npairs, 1); pin[p] = v; pout[p] = t; }
+        if (v >= 0) { const int p = atomicAdd(&npairs, 1); pin[p] = v; pout[p] = (uint16_t)t; }
     }
     __syncthreads();
     const int np = npairs;
@@ -699,56 +678,88 @@ __global__ __launch_bounds__(256) void sp_conv_wgrad_mfma_kernel(const float* __
     for (int t = 0; t < TPW; ++t)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
-    const bool vec_x = (cin % 4 == 0), vec_g = (cout % 4 == 0);
+
+    // staging registers: NI float4 of X and NJ float4 of G per thread and stage. Loads are
+    // unconditional (pairs past np re-read pair 0, channels past cin/cout re-read channel 0)
+    // and zeroed when they are written to LDS.
+    float4 xr[NI], gr[NJ];
+#define WG_LOAD(P0)                                                                                                  \
+    _Pragma("unroll") for (int e = 0; e < NI; ++e) {                                                                 \
+        const int t = tid + 256 * e, pp = t / (CI / 4), q = (t - pp * (CI / 4)) * 4;                                 \
+        const int pi = (P0) + pp < np ? (P0) + pp : 0;                                                               \
+        const float* src = X + (int64_t)pin[pi] * cin;                                                               \
+        if (VEC) xr[e] = *reinterpret_cast<const float4*>(src + (q < cin ? q : 0));                                  \
+        else xr[e] = make_float4(src[q < cin ? q : 0], src[q + 1 < cin ? q + 1 : 0], src[q + 2 < cin ? q + 2 : 0],    \
+                                 src[q + 3 < cin ? q + 3 : 0]);                                                      \
+    }                                                                                                                \
+    _Pragma("unroll") for (int e = 0; e < NJ; ++e) {                                                                 \
+        const int t = tid + 256 * e, pp = t / (CO / 4), q = (t - pp * (CO / 4)) * 4;                                 \
+        const int pi = (P0) + pp < np ? (P0) + pp : 0;                                                               \
+        const float* src = G + (r0 + pout[pi]) * cout;                                                               \
+        if (VEC) gr[e] = *reinterpret_cast<const float4*>(src + (q < cout ? q : 0));                                 \
+        else gr[e] = make_float4(src[q < cout ? q : 0], src[q + 1 < cout ? q + 1 : 0], src[q + 2 < cout ? q + 2 : 0], \
+                                 src[q + 3 < cout ? q + 3 : 0]);                                                     \
+    }
+#define WG_STORE(BUF, P0)                                                                                            \
+    _Pragma("unroll") for (int e = 0; e < NI; ++e) {                                                                 \
+        const int t = tid + 256 * e, pp = t / (CI / 4), q = (t - pp * (CI / 4)) * 4;                                 \
+        const bool ok = (P0) + pp < np;                                                                              \
+        const float4 v = make_float4(ok && q < cin ? xr[e].x : 0.f, ok && q + 1 < cin ? xr[e].y : 0.f,               \
+                                     ok && q + 2 < cin ? xr[e].z : 0.f, ok && q + 3 < cin ? xr[e].w : 0.f);          \
+        *reinterpret_cast<float4*>(Xs + (BUF) * XSZ + pp * CI + q) = v;                                              \
+    }                                                                                                                \
+    _Pragma("unroll") for (int e = 0; e < NJ; ++e) {                                                                 \
+        const int t = tid + 256 * e, pp = t / (CO / 4), q = (t - pp * (CO / 4)) * 4;                                 \
+        const bool ok = (P0) + pp < np;                                                                              \
+        const float4 v = make_float4(ok && q < cout ? gr[e].x : 0.f, ok && q + 1 < cout ? gr[e].y : 0.f,             \
+                                     ok && q + 2 < cout ? gr[e].z : 0.f, ok && q + 3 < cout ? gr[e].w : 0.f);        \
+        *reinterpret_cast<float4*>(Gs + (BUF) * GSZ + pp * CO + q) = v;                                              \
+    }
+    WG_LOAD(0);
+    WG_STORE(0, 0);
+    __syncthreads();
+    int buf = 0;
+    // a wave's TPW tiles sit in one row of tiles: i0 = tile0 / NJ, columns j0 .. j0+TPW-1, so one
+    // X fragment serves all of them (all wave-uniform -> scalar address math)
+    static_assert(NJ % TPW == 0, "tiles of a wave must share their tile row");
+    const int tile0 = __builtin_amdgcn_readfirstlane(wave) * TPW;
+    const bool wactive = tile0 < TILES;
+    const int i0 = tile0 / NJ, j0 = tile0 - i0 * NJ;
+    const int m = lane & 31, h = lane >> 5;
     for (int p0 = 0; p0 < np; p0 += 32) {
-        // stage 32 pairs: X rows (gathered) and G rows
-        for (int t = tid; t < 32 * (CI / 4); t += 256) {
-            const int pp = t / (CI / 4), q = (t - pp * (CI / 4)) * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (p0 + pp < np) {
-                const float* src = X + (int64_t)pin[p0 + pp] * cin + q;
-                if (vec_x && q + 3 < cin) v = *reinterpret_cast<const float4*>(src);
-                else { float e[4] = {0, 0, 0, 0}; for (int j = 0; j < 4 && q + j < cin; ++j) e[j] = src[j]; v = make_float4(e[0], e[1], e[2], e[3]); }
-            }
-            *reinterpret_cast<float4*>(&Xs[pp][q]) = v;
-        }
-        for (int t = tid; t < 32 * (CO / 4); t += 256) {
-            const int pp = t / (CO / 4), q = (t - pp * (CO / 4)) * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (p0 + pp < np) {
-                const float* src = G + (r0 + pout[p0 + pp]) * cout + q;
-                if (vec_g && q + 3 < cout) v = *reinterpret_cast<const float4*>(src);
-                else { float e[4] = {0, 0, 0, 0}; for (int j = 0; j < 4 && q + j < cout; ++j) e[j] = src[j]; v = make_float4(e[0], e[1], e[2], e[3]); }
-            }
-            *reinterpret_cast<float4*>(&Gs[pp][q]) = v;
-        }
-        __syncthreads();
+        WG_LOAD(p0 + 32);
+        if (wactive) {
+            const float* xb = Xs + buf * XSZ + h * CI + i0 * 32 + m;
+            const float* gb = Gs + buf * GSZ + h * CO + j0 * 32 + m;
+            float fa[2], fb[2][TPW];
+#define WG_READ(S2, S)                                                                                               \
+            fa[S] = xb[2 * (S2) * CI];                                                                               \
+            _Pragma("unroll") for (int t = 0; t < TPW; ++t) fb[S][t] = gb[2 * (S2) * CO + t * 32];
+            WG_READ(0, 0);
 #pragma unroll
-        for (int s2 = 0; s2 < 16; ++s2) {
-            const int pp = 2 * s2 + (lane >> 5);
+            for (int s2 = 0; s2 < 16; ++s2) {
+                if (s2 + 1 < 16) { WG_READ(s2 + 1, (s2 + 1) & 1); }
 #pragma unroll
-            for (int t = 0; t < TPW; ++t) {
-                const int tile = wave * TPW + t;
-                if (tile < TILES) {
-                    const int i = tile / NJ, j = tile - i * NJ;
-                    const float a = Xs[pp][i * 32 + (lane & 31)];
-                    const float b = Gs[pp][j * 32 + (lane & 31)];
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
-                }
+                for (int t = 0; t < TPW; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s2 & 1], fb[s2 & 1][t], acc[t], 0, 0, 0);
             }
+#undef WG_READ
         }
+        if (p0 + 32 >= np) break;
+        buf ^= 1;                            // last read before the previous barrier
+        WG_STORE(buf, p0 + 32);
         __syncthreads();
     }
+#undef WG_LOAD
+#undef WG_STORE
     float* dWk = dW + (int64_t)k * cin * cout;
+    if (!wactive) return;
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
-        const int tile = wave * TPW + t;
-        if (tile >= TILES) continue;
-        const int i = tile / NJ, j = tile - i * NJ;
-        const int co = j * 32 + (lane & 31);
+        const int co = (j0 + t) * 32 + (lane & 31);
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
-            const int ci = i * 32 + (v >> 2) * 8 + (lane >> 5) * 4 + (v & 3);
+            const int ci = i0 * 32 + (v >> 2) * 8 + (lane >> 5) * 4 + (v & 3);
             if (ci < cin && co < cout && acc[t][v] != 0.0f) atomicAdd(&dWk[(int64_t)ci * cout + co], acc[t][v]);
         }
     }
@@ -763,15 +774,17 @@ extern "C" int gga_sparse_conv_wgrad(const float* x, const float* grad_out, cons
     GGA_CHECK_HIP(hipMemsetAsync(grad_weight, 0, (size_t)kvol * cin * cout * sizeof(float), stream), "wgrad memset");
     const dim3 grid((unsigned)((n_rows + SP_WCHUNK - 1) / SP_WCHUNK), kvol), block(256);
     const int ni = (cin + 31) / 32, nj = (cout + 31) / 32;
-#define MW(NI, NJ) hipLaunchKernelGGL((sp_conv_wgrad_mfma_kernel<NI, NJ>), grid, block, 0, stream, x, grad_out, map, n_rows, cin, cout, grad_weight)
-    if (ni == 1 && nj == 1) MW(1, 1);
-    else if (ni == 1 && nj == 2) MW(1, 2);
-    else if (ni == 2 && nj == 2) MW(2, 2);
-    else if (ni == 2 && nj == 4) MW(2, 4);
-    else if (ni == 4 && nj == 4) MW(4, 4);
-    else if (ni <= 2 && nj <= 2) MW(2, 2);
-    else MW(4, 4);
+    const bool vec = (cin & 3) == 0 && (cout & 3) == 0;
+#define MW(NI, NJ) { if (vec) hipLaunchKernelGGL((sp_conv_wgrad_mfma_kernel<NI, NJ, true>), grid, block, 0, stream, x, grad_out, map, n_rows, cin, cout, grad_weight); \
+                     else hipLaunchKernelGGL((sp_conv_wgrad_mfma_kernel<NI, NJ, false>), grid, block, 0, stream, x, grad_out, map, n_rows, cin, cout, grad_weight); }
+    if (ni == 1 && nj == 1) MW(1, 1)
+    else if (ni == 1 && nj == 2) MW(1, 2)
+    else if (ni == 2 && nj == 2) MW(2, 2)
+    else if (ni == 2 && nj == 4) MW(2, 4)
+    else if (ni == 4 && nj == 4) MW(4, 4)
+    else if (ni <= 2 && nj <= 2) MW(2, 2)
+    else MW(4, 4)
 #undef MW
-    GGA_CHECK_LAUNCH("sp_conv_wgrad_kernel");
+    GGA_CHECK_LAUNCH("sp_conv_wgrad_mfma_kernel");
     return GGA_OK;
 }

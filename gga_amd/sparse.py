@@ -40,7 +40,7 @@ class _Rulebook:
             check(_lib.lib().gga_sparse_rowmask(F._p(nbr), n, kvol, F._p(self.mask), F._stream()), 'gga_sparse_rowmask')
             # index preprocessing (once per level, shared by every conv on it): rows with the same
             # neighbour pattern become adjacent, so a 128-row tile skips the offsets none of them uses
-            self.perm = torch.argsort(self.mask).int()
+            self.perm = torch.sort(self.mask, stable=True)[1].int()
 
 
 class _Level:
@@ -185,6 +185,14 @@ class SparseSequential(SparseModule):
         return x
 
 
+def _pack_weight(w, kvol, cin, cout, transpose):
+    """[kvol,cin,cout] (or [kvol,cout,cin] with ``transpose``) -> MFMA fragment order (gga_sparse_pack_weight)."""
+    L = _lib.lib()
+    wp = torch.empty(L.gga_sparse_packed_weight_bytes(kvol, cin, cout) // 4, dtype=torch.float32, device=w.device)
+    check(L.gga_sparse_pack_weight(F._p(w), kvol, cin, cout, transpose, F._p(wp), F._stream()), 'gga_sparse_pack_weight')
+    return wp
+
+
 class _SparseConvFn(torch.autograd.Function):
     """features [n_in,Cin] x weight [kvol,Cin,Cout] -> [n_out,Cout] through rule book ``rb``
     (``rb_t`` = transposed rule book for the backward-data pass, None for submanifold convs)."""
@@ -195,7 +203,8 @@ class _SparseConvFn(torch.autograd.Function):
         kvol = rb.nbr.shape[0]
         cin, cout = w.shape[-2], w.shape[-1]
         y = torch.empty((n_out, cout), dtype=torch.float32, device=feats.device)
-        check(_lib.lib().gga_sparse_conv_apply(F._p(feats), F._p(rb.nbr), F._p(w), F._p(rb.perm), F._p(rb.mask), n_out,
+        wp = _pack_weight(w, kvol, cin, cout, 0)
+        check(_lib.lib().gga_sparse_conv_apply(F._p(feats), F._p(rb.nbr), F._p(wp), F._p(rb.perm), F._p(rb.mask), n_out,
                                                kvol, cin, cout, 0, F._p(y), F._stream()), 'gga_sparse_conv_apply')
         ctx.save_for_backward(feats, w)
         ctx.rb, ctx.rb_t = rb, rb_t
@@ -213,7 +222,7 @@ class _SparseConvFn(torch.autograd.Function):
         gx = gw = None
         if ctx.needs_input_grad[0]:
             gx = torch.empty_like(feats)
-            wt = w.transpose(1, 2).contiguous()                       # [kvol, Cout, Cin]
+            wt = _pack_weight(w, kvol, cout, cin, 1)                  # W[k]^T in fragment order
             tb, flip = (rb_t, 0) if rb_t is not None else (rb, 1)     # SubM: transposed map = reversed offsets
             check(L.gga_sparse_conv_apply(F._p(gy), F._p(tb.nbr), F._p(wt), F._p(tb.perm), F._p(tb.mask), n_in, kvol,
                                           cout, cin, flip, F._p(gx), F._stream()), 'gga_sparse_conv_apply(bwd data)')

@@ -201,14 +201,24 @@ int gga_sparse_rulebook(const int32_t* out_coors, int64_t n_out, const int32_t* 
  * tiles whose rows use the same kernel offsets; the conv kernel skips the others. */
 int gga_sparse_rowmask(const int32_t* map, int64_t n_rows, int kvol, uint32_t* mask, void* stream);
 
-/* y[r,:] = sum_k x[map[kk][r],:] @ weight[k], kk = flip ? kvol-1-k : k; weight[k] is [cin,cout]
- * row major (pass the per-offset transposed weights for the backward-data pass).
+/* Weights in the MFMA fragment order the conv kernel stages through LDS (one 16-byte copy per
+ * thread instead of a transposing scatter): packed[k][chunk][lane][g][t][j] =
+ * W[k][chunk*32 + 2*(4g+j) + lane/32][t*32 + lane%32], zero beyond cin/cout, with
+ * t < (cout<=32 ? 1 : cout<=64 ? 2 : 4). `weight` is [kvol,cin,cout] (transpose 0) or
+ * [kvol,cout,cin] (transpose 1: the forward weight of a cout->cin conv, for its backward-data
+ * pass). Replaces the weight handling inside mmcv's indice_conv (sparse_block.py:9-20 call sites). */
+size_t gga_sparse_packed_weight_bytes(int kvol, int cin, int cout);
+int gga_sparse_pack_weight(const float* weight, int kvol, int cin, int cout, int transpose, float* packed,
+                           void* stream);
+
+/* y[r,:] = sum_k x[map[kk][r],:] @ W[k], kk = flip ? kvol-1-k : k, W given as
+ * gga_sparse_pack_weight(.., cin, cout, ..).
  *   forward        : map = nbr,   flip 0
- *   backward-data  : x = grad_out, map = nbr_t (or nbr with flip 1 for SubM), weight = W^T,
- *                    cin/cout swapped
+ *   backward-data  : x = grad_out, map = nbr_t (or nbr with flip 1 for SubM), W packed with
+ *                    transpose 1, cin/cout swapped
  * perm (optional, [n_rows]): processing order of the rows (e.g. argsort of the row masks);
  * rowmask (optional, [n_rows]): gga_sparse_rowmask of `map`. Output rows are not permuted. */
-int gga_sparse_conv_apply(const float* x, const int32_t* map, const float* weight, const int32_t* perm,
+int gga_sparse_conv_apply(const float* x, const int32_t* map, const float* packed_weight, const int32_t* perm,
                           const uint32_t* rowmask, int64_t n_rows, int kvol, int cin, int cout, int flip,
                           float* y, void* stream);
 /* grad_weight [kvol,cin,cout] = sum_r x[nbr[k][r]]^T grad_out[r]  (zero-filled here) */

@@ -11,3 +11,4 @@ from . import registry  # noqa: E402,F401
 from . import losses, bbox_coders, voxel_encoders, middle_encoders, sparse, sparse_encoder, backbones, dense_heads, detectors  # noqa: E402,F401
 from .config import Config  # noqa: E402,F401
 from .registry import build_detector, build_model  # noqa: E402,F401
+from .pseudo_labels import pseudo_label_matching_kitti  # noqa: E402,F401

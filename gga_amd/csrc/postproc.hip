@@ -222,3 +222,75 @@ extern "C" int gga_points_in_boxes(const float* points, const float* boxes, int 
     GGA_CHECK_LAUNCH("points_in_boxes_kernel");
     return GGA_OK;
 }
+
+// ------------------------------------------------------------------------------ pseudo-label matching
+// KITTI image-plane IoU (image_box_overlap, criterion -1) of every detection with the ground
+// truths of its own frame, and the index of the best one (numpy argmax: first maximum). Doubles
+// throughout, one multiply/add/divide per reference operation (the empty asm statements stop
+// hipcc from contracting a*b+c into an fma, which would change the last bit). f32_boxes = the
+// detections are float32: their own area is float32 arithmetic and each overlap is rounded to
+// float32 (the reference's typing with float32 detections and float64 ground truth).
+__device__ __forceinline__ double img_iou(const double* b, const double* q, int f32_boxes) {
+    const double qa0 = q[2] - q[0], qa1 = q[3] - q[1];
+    double qarea = qa0 * qa1;
+    asm volatile("" : "+v"(qarea));
+    const double iw = fmin(b[2], q[2]) - fmax(b[0], q[0]);
+    if (!(iw > 0)) return 0.0;
+    const double ih = fmin(b[3], q[3]) - fmax(b[1], q[1]);
+    if (!(ih > 0)) return 0.0;
+    double barea;
+    if (f32_boxes) {                           // float32 detections: their own area is float32 arithmetic
+        const float w = (float)b[2] - (float)b[0], h = (float)b[3] - (float)b[1];
+        float a = w * h;
+        asm volatile("" : "+v"(a));
+        barea = (double)a;
+    } else {
+        barea = (b[2] - b[0]) * (b[3] - b[1]);
+        asm volatile("" : "+v"(barea));
+    }
+    double inter = iw * ih;
+    asm volatile("" : "+v"(inter));
+    double ua = barea + qarea;
+    asm volatile("" : "+v"(ua));
+    ua = ua - inter;
+    return inter / ua;
+}
+
+__global__ __launch_bounds__(256) void image_box_match_kernel(const double* __restrict__ dt, const int64_t* __restrict__ dt_off,
+                                                             const double* __restrict__ gt, const int64_t* __restrict__ gt_off,
+                                                             int n_frames, int64_t n_dt, int round_f32,
+                                                             int64_t* __restrict__ match, double* __restrict__ best_iou,
+                                                             double* __restrict__ overlaps,
+                                                             const int64_t* __restrict__ ov_off) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_dt) return;
+    int lo = 0, hi = n_frames;                 // frame f with dt_off[f] <= i < dt_off[f+1]
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (dt_off[mid] <= i) lo = mid; else hi = mid; }
+    const int f = lo;
+    const int64_t g0 = gt_off[f], ng = gt_off[f + 1] - g0;
+    const double* b = dt + i * 4;
+    int64_t arg = -1;
+    double best = 0.0;
+    for (int64_t g = 0; g < ng; ++g) {
+        double v = img_iou(b, gt + (g0 + g) * 4, round_f32);
+        if (round_f32) v = (double)(float)v;
+        if (overlaps) overlaps[ov_off[f] + (i - dt_off[f]) * ng + g] = v;
+        if (arg < 0 || v > best) { best = v; arg = g; }
+    }
+    match[i] = arg;                            // -1 when the frame has no ground truth
+    if (best_iou) best_iou[i] = best;
+}
+
+extern "C" int gga_image_box_match(const double* dt_boxes, const int64_t* dt_offsets, const double* gt_boxes,
+                                   const int64_t* gt_offsets, int n_frames, int64_t n_dt, int round_f32, int64_t* match,
+                                   double* best_iou, double* overlaps, const int64_t* overlap_offsets, void* stream) {
+    GGA_REQUIRE(n_frames >= 1 && n_dt >= 0, "gga_image_box_match: bad sizes");
+    if (n_dt == 0) return GGA_OK;
+    GGA_REQUIRE(dt_boxes && dt_offsets && gt_offsets && match, "gga_image_box_match: null pointer argument");
+    GGA_REQUIRE(!overlaps || overlap_offsets, "gga_image_box_match: overlaps needs overlap_offsets");
+    hipLaunchKernelGGL(image_box_match_kernel, dim3((unsigned)((n_dt + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       dt_boxes, dt_offsets, gt_boxes, gt_offsets, n_frames, n_dt, round_f32, match, best_iou, overlaps,
+                       overlap_offsets);
+    GGA_CHECK_LAUNCH("image_box_match_kernel");
+    return GGA_OK;
+}

@@ -227,3 +227,64 @@ def make_head_preds(B, H, W, seed=77, n_tasks=3):
             d[k] = x
         preds.append(d)
     return preds
+
+
+# ---------------------------------------------------------------------------
+# KITTI-info-shaped annotations / detections for the pseudo-label matching step
+# ---------------------------------------------------------------------------
+KITTI_CLASSES = ['Pedestrian', 'Car', 'Cyclist', 'Van', 'Truck', 'Misc']
+PSEUDO_GT_KEYS = ['name', 'truncated', 'occluded', 'alpha', 'bbox', 'dimensions', 'location', 'rotation_y', 'score',
+                  'index', 'group_ids', 'difficulty', 'num_points_in_gt', 'GGA_boxes_img', 'GGA_mask_depth',
+                  'GGA_mask2d', 'GGA_mask_boundary', 'GGA_bdry_masks', 'GGA_mask_valid', 'GGA_init_pseudo_label',
+                  'GGA_num_points_in_box2d']
+PSEUDO_DT_KEYS = ['name', 'truncated', 'occluded', 'alpha', 'bbox', 'dimensions', 'location', 'rotation_y', 'score',
+                  'sample_idx']
+
+
+def make_pseudo_case(seed, n_frames, dt_dtype=np.float32):
+    """Seeded KITTI-info-shaped ground truths (GGA fields included, DontCare entries last) and
+    KITTI-format detections; shared by the golden generator and the tests (inputs are rebuilt
+    from the seed, only the expected outputs are stored)."""
+    rng = np.random.default_rng(seed)
+    infos, dts = [], []
+    for f in range(n_frames):
+        n_obj = int(rng.integers(0, 9)) if f != 1 else 0
+        n_dc = int(rng.integers(0, 3))
+        n = n_obj + n_dc
+        names = np.array([KITTI_CLASSES[i] for i in rng.integers(0, len(KITTI_CLASSES), n_obj)] + ['DontCare'] * n_dc)
+        x1, y1 = rng.uniform(0, 1000, n), rng.uniform(0, 300, n)
+        w, h = rng.uniform(10, 250, n), rng.uniform(10, 150, n)
+        bbox = np.stack([x1, y1, x1 + w, y1 + h], 1)
+        annos = dict(
+            name=names, truncated=rng.uniform(0, 1, n), occluded=rng.integers(0, 3, n), alpha=rng.uniform(-3, 3, n),
+            bbox=bbox, dimensions=rng.uniform(0.5, 4.5, (n, 3)), location=rng.uniform(-30, 60, (n, 3)),
+            rotation_y=rng.uniform(-np.pi, np.pi, n), score=np.zeros(n), index=np.arange(n, dtype=np.int32),
+            group_ids=np.arange(n, dtype=np.int32), difficulty=rng.integers(-1, 3, n).astype(np.int32),
+            num_points_in_gt=rng.integers(0, 500, n).astype(np.int32), GGA_boxes_img=bbox + rng.uniform(-2, 2, (n, 4)),
+            GGA_mask_depth=rng.random(n) < 0.8, GGA_mask2d=rng.random(n) < 0.8, GGA_mask_boundary=rng.random(n) < 0.7,
+            GGA_bdry_masks=rng.random((n, 4)) < 0.5, GGA_mask_valid=rng.random(n) < 0.9,
+            GGA_init_pseudo_label=rng.uniform(-5, 60, (n, 7)), GGA_num_points_in_box2d=rng.integers(0, 2000, n),
+            GGA_in_box_points=[rng.uniform(-1, 1, (int(rng.integers(1, 6)), 4)) for _ in range(n)])
+        infos.append(dict(image=dict(image_idx=f, image_shape=np.array([375, 1242], np.int32)),
+                          point_cloud=dict(num_features=4), annos=annos))
+        trained = [i for i in range(n_obj) if names[i] in KITTI_CLASSES[:3]]
+        n_dt = int(rng.integers(0, 7)) if (trained and f != 2) else 0
+        # detections: jittered copies of trained-class boxes plus unrelated boxes; a duplicated
+        # ground truth (identical IoU for two candidates) exercises the first-maximum rule
+        src = rng.choice(trained, n_dt) if n_dt else np.zeros(0, np.int64)
+        dbox = bbox[src] + rng.uniform(-15, 15, (n_dt, 4)) * (rng.random((n_dt, 1)) < 0.8)
+        far = rng.random(n_dt) < 0.2
+        dbox[far] += 5000.0
+        dts.append(dict(
+            name=np.array([KITTI_CLASSES[i] for i in rng.integers(0, 3, n_dt)]) if n_dt else np.zeros(0, '<U10'),
+            truncated=np.zeros(n_dt), occluded=np.zeros(n_dt, np.int64), alpha=rng.uniform(-3, 3, n_dt).astype(dt_dtype),
+            bbox=dbox.astype(dt_dtype), dimensions=rng.uniform(0.5, 4.5, (n_dt, 3)).astype(dt_dtype),
+            location=rng.uniform(-30, 60, (n_dt, 3)).astype(dt_dtype),
+            rotation_y=rng.uniform(-np.pi, np.pi, n_dt).astype(dt_dtype), score=rng.uniform(0.1, 1, n_dt).astype(dt_dtype),
+            sample_idx=np.full(n_dt, f, np.int64)))
+    if n_frames > 3 and len(infos[3]['annos']['name']) >= 2:      # two identical ground truths in frame 3
+        a = infos[3]['annos']
+        a['bbox'][1] = a['bbox'][0]
+        if a['name'][0] in KITTI_CLASSES[:3]:
+            a['name'][1] = a['name'][0]
+    return infos, dts

@@ -381,6 +381,20 @@ int gga_nms_rotated_sorted(const float* boxes_sorted, int n, float iou_threshold
 int gga_points_in_boxes(const float* points, const float* boxes, int B, int M, int T, int all,
                         int32_t* out, void* stream);
 
+/* Pseudo-label matching: image-plane IoU of every detection with the ground truths of its own
+ * frame and the argmax, i.e. `calculate_iou_partly(dt_annos, gt_annos, metric=0)` followed by
+ * `np.argmax(c_overlap, axis=-1)` in tools/utils_pseudo_labels_gga.py:44-59 (IoU arithmetic:
+ * image_box_overlap, mmdet3d/core/evaluation/kitti_utils/eval.py:86-114, criterion -1).
+ * dt_boxes [n_dt,4], gt_boxes [n_gt,4] = (x1,y1,x2,y2) f64, both concatenated over frames with
+ * device offsets dt_offsets / gt_offsets [n_frames+1]. round_f32: the detections were float32
+ * (the usual case: float32 predictions, float64 KITTI labels) - their own area is then float32
+ * arithmetic and each overlap is rounded to float32, as the reference's typing gives. match [n_dt]: index of the first
+ * maximum within the frame's ground truths (-1 if it has none); best_iou [n_dt] optional;
+ * overlaps optional: frame f's [n_dt_f, n_gt_f] matrix at overlap_offsets[f]. */
+int gga_image_box_match(const double* dt_boxes, const int64_t* dt_offsets, const double* gt_boxes,
+                        const int64_t* gt_offsets, int n_frames, int64_t n_dt, int round_f32, int64_t* match,
+                        double* best_iou, double* overlaps, const int64_t* overlap_offsets, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

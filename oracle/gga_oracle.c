@@ -437,3 +437,33 @@ void gga_oracle_points_in_boxes(const float* pts, int M, const float* boxes, int
         }
     }
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * KITTI image-plane box overlap (mmdet3d/core/evaluation/kitti_utils/eval.py:86-114, criterion
+ * -1), as called with (detections, ground truths) by pseudo_label_matching_kitti
+ * (tools/utils_pseudo_labels_gga.py:44) -> overlaps [N,K]; round_f32 mirrors the reference's
+ * `np.zeros((N, K), dtype=boxes.dtype)` when the detections are float32.
+ * ------------------------------------------------------------------------------------------- */
+void gga_oracle_image_box_overlap(const double* boxes, int N, const double* query, int K, int round_f32, double* out) {
+    for (int k = 0; k < K; ++k) {
+        const double* q = query + 4 * k;
+        double qarea = (q[2] - q[0]) * (q[3] - q[1]);
+        for (int n = 0; n < N; ++n) {
+            const double* b = boxes + 4 * n;
+            double v = 0.0;
+            double iw = fmin(b[2], q[2]) - fmax(b[0], q[0]);
+            if (iw > 0) {
+                double ih = fmin(b[3], q[3]) - fmax(b[1], q[1]);
+                if (ih > 0) {
+                    /* float32 detections: their own area is float32 arithmetic (array scalar
+                     * typing), everything mixed with the float64 ground truth is float64 */
+                    double barea = round_f32 ? (double)((float)((float)b[2] - (float)b[0]) * (float)((float)b[3] - (float)b[1]))
+                                             : (b[2] - b[0]) * (b[3] - b[1]);
+                    double ua = barea + qarea - iw * ih;
+                    v = iw * ih / ua;
+                }
+            }
+            out[(size_t)n * K + k] = round_f32 ? (double)(float)v : v;
+        }
+    }
+}

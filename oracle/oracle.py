@@ -66,6 +66,7 @@ def lib():
         L.gga_oracle_nms_rotated_sorted.restype = C.c_int
         L.gga_oracle_nms_rotated_sorted.argtypes = [f32p, C.c_int, C.c_float, i64p]
         L.gga_oracle_points_in_boxes.argtypes = [f32p, C.c_int, f32p, C.c_int, C.c_int, i32p]
+        L.gga_oracle_image_box_overlap.argtypes = [f64p, C.c_int, f64p, C.c_int, C.c_int, f64p]
         _LIB = L
     return _LIB
 
@@ -232,6 +233,23 @@ def points_in_boxes(points, boxes, all_boxes=False):
     out = np.zeros((len(pts), len(bx)) if all_boxes else (len(pts),), np.int32)
     lib().gga_oracle_points_in_boxes(pts, len(pts), bx, len(bx), int(all_boxes), out)
     return out
+
+
+def image_box_overlap(boxes, query_boxes):
+    """eval.py:86-114 (criterion -1); result in ``boxes.dtype`` like the reference."""
+    b = np.ascontiguousarray(boxes, np.float64).reshape(-1, 4)
+    q = np.ascontiguousarray(query_boxes, np.float64).reshape(-1, 4)
+    out = np.zeros((len(b), len(q)), np.float64)
+    if len(b) and len(q):
+        lib().gga_oracle_image_box_overlap(b, len(b), q, len(q), int(np.asarray(boxes).dtype == np.float32), out)
+    return out.astype(np.asarray(boxes).dtype)
+
+
+def pseudo_label_match(dt_bboxes, gt_bboxes):
+    """Per frame: argmax over ground truths of the detection/ground-truth image IoU
+    (tools/utils_pseudo_labels_gga.py:44-59)."""
+    return [np.argmax(image_box_overlap(d, g), axis=-1) if len(d) else np.zeros(0, np.int64)
+            for d, g in zip(dt_bboxes, gt_bboxes)]
 
 
 # ---------------------------------------------------------------------------

@@ -459,6 +459,40 @@ def golden_head(ref):
     np.savez_compressed(os.path.join(OUT, 'head.npz'), **out)
 
 
+PSEUDO_GT_KEYS = synthetic.PSEUDO_GT_KEYS
+make_pseudo_case = synthetic.make_pseudo_case
+
+
+def golden_pseudo_match(ref):
+    """pseudo_label_matching_kitti of the reference (tools/utils_pseudo_labels_gga.py) on seeded
+    infos; mmcv.dump is stubbed to capture the object it would write."""
+    import copy
+    _mod('mmdet3d.core.evaluation')
+    _mod('mmdet3d.core.evaluation.kitti_utils')
+    ev = load('mmdet3d.core.evaluation.kitti_utils.eval', 'mmdet3d/core/evaluation/kitti_utils/eval.py')
+    captured = {}
+    sys.modules['mmcv'].dump = lambda obj, filename: captured.update(obj=obj, filename=filename)
+    pl = load('ref_tools_utils_pseudo_labels_gga', 'tools/utils_pseudo_labels_gga.py')
+    out = {}
+    for cname, seed, nf, dtype in (('f32', 31, 12, np.float32), ('f64', 32, 9, np.float64)):
+        infos, dts = make_pseudo_case(seed, nf, dtype)
+        gi, di = copy.deepcopy(infos), copy.deepcopy(dts)
+        # per-frame overlaps exactly as the reference computes them (dt first, gt second)
+        clean = pl.pseudo_label_matching_kitti(gi, di)
+        ov = ev.calculate_iou_partly(di, clean, 0, min(200, nf))[0]
+        dumped = captured['obj']
+        out[f'{cname}.filename'] = np.array(captured['filename'])
+        for f in range(nf):
+            out[f'{cname}.{f}.overlap'] = np.asarray(ov[f])
+            for k in PSEUDO_GT_KEYS:
+                out[f'{cname}.{f}.clean.{k}'] = np.asarray(clean[f][k])
+                out[f'{cname}.{f}.new.{k}'] = np.asarray(dumped[f]['annos'][k])
+            assert set(dumped[f]['annos'].keys()) == set(PSEUDO_GT_KEYS), dumped[f]['annos'].keys()
+            assert 'image' in dumped[f] and 'point_cloud' in dumped[f]
+        print(f'  pseudo_match[{cname}]: {nf} frames, {sum(len(d["name"]) for d in dts)} detections')
+    np.savez_compressed(os.path.join(OUT, 'pseudo_match.npz'), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = import_reference()
@@ -469,6 +503,7 @@ def main():
     golden_scatter(ref)
     golden_encoders(ref)
     golden_head(ref)
+    golden_pseudo_match(ref)
     for f in sorted(os.listdir(OUT)):
         print(f'{f}: {os.path.getsize(os.path.join(OUT, f)) / 1024:.1f} KiB')
 

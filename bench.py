@@ -31,41 +31,52 @@ import torch.distributed as dist  # noqa: E402
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (guides/MI355X_MICROARCH.md); ~6300 achievable
 
 
-def scatter_roofline(model, batch_points, device, iters=20):
-    """Time the scatter kernels (HIP events on the launch stream) on the pillars of a real
-    bench batch: [SM,64] + coors -> [B,64,496,432]."""
+def scatter_roofline(model, batches, device, step_ms, isolated_iters=0):
+    """`roofline` of the pillar-scatter canvas kernel: algorithmic bytes over
+    its mean duration INSIDE the timed steps (`step_ms`: one HIP-event pair per step around the
+    kernel, on the stream it is launched on). `isolated_iters` > 0 adds the back-to-back figure
+    of gga_profile_pillar_scatter (opt-in: it adds launches to a profile of this command)."""
     from gga_amd import _lib
     from gga_amd import functional as F
     vl, me = model.pts_voxel_layer, model.pts_middle_encoder
-    B = len(batch_points)
+    B = len(batches[0]['points'])
+    ch = me.in_channels
     with torch.no_grad():
-        _, _, coors, _ = vl.forward_batch(batch_points)
-    m, ch = coors.shape[0], me.in_channels
-    feats = torch.randn(m, ch, device=device)
-    layout = F.LAYOUT_NHWC if me.channels_last else F.LAYOUT_NCHW
-    canvas = torch.empty(B * ch * me.ny * me.nx, device=device)
-    cmap = F._cell_map(device, B, me.ny, me.nx)
-    L = _lib.lib()
-    ms_map, ms_canvas = C.c_float(0), C.c_float(0)
-    args = (F._p(feats), F._p(coors), m, B, ch, me.ny, me.nx, layout, F._p(cmap), F._p(canvas))
-    _lib.check(L.gga_profile_pillar_scatter(*args, 3, C.byref(ms_map), C.byref(ms_canvas), F._stream()), 'profile')
-    _lib.check(L.gga_profile_pillar_scatter(*args, iters, C.byref(ms_map), C.byref(ms_canvas), F._stream()), 'profile')
-    algo = m * ch * 4 + m * 16 + B * ch * me.ny * me.nx * 4          # SURVEY.md §8(d)
-    gbs = algo / (ms_canvas.value * 1e-3) / 1e9
-    kname = 'scatter_canvas_nhwc_kernel' if me.channels_last else 'scatter_canvas_nchw_v2_kernel'
+        coors = [vl.forward_batch(b['points'])[2] for b in batches]
+    m = sum(c.shape[0] for c in coors) / len(coors)
+    algo = m * ch * 4 + m * 16 + B * ch * me.ny * me.nx * 4
+    ms = sum(step_ms) / len(step_ms)
+    gbs = algo / (ms * 1e-3) / 1e9
+    knames = (['scatter_fill_kernel', 'scatter_rows_nhwc_kernel'] if me.channels_last else ['scatter_canvas_nchw_v2_kernel'])
     # HBM bytes per launch from the PMC passes kept under profiles/ (FETCH_SIZE doubled per the
     # gfx950 note, WRITE_SIZE exact); only quoted when the shape is the profiled one
     traffic = None
     try:
         pmc = json.load(open(os.path.join(REPO, 'profiles', 'r01_scatter_pmc.json')))
         if (B, ch, me.ny, me.nx) == (16, 64, 496, 432) and abs(m - 256000) < 2000:
-            traffic = pmc['kernels'][kname]['hbm_bytes_corrected']
+            traffic = sum(pmc['kernels'][k]['hbm_bytes_corrected'] for k in knames)
     except (OSError, KeyError, ValueError):
         pass
-    return {'bound': 'hbm', 'kernel': kname,
-            'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(gbs / HBM_PEAK_GBS, 4),
-            'traffic': traffic, 'algorithmic_bytes': int(algo), 'kernel_ms': round(ms_canvas.value, 4),
-            'map_kernel_ms': round(ms_map.value, 4), 'pillars': int(m)}
+    out = {'bound': 'hbm', 'kernel': '+'.join(knames), 'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+           'frac': round(gbs / HBM_PEAK_GBS, 4), 'traffic': traffic, 'algorithmic_bytes': int(algo),
+           'kernel_ms': round(ms, 4), 'launches_timed': len(step_ms), 'timed': 'in-step, HIP events on the launch stream',
+           'pillars': int(m)}
+    if isolated_iters > 0:
+        c0 = coors[0]
+        feats = torch.randn(c0.shape[0], ch, device=device)
+        layout = F.LAYOUT_NHWC if me.channels_last else F.LAYOUT_NCHW
+        canvas = torch.empty(B * ch * me.ny * me.nx, device=device)
+        cmap = F._cell_map(device, B, me.ny, me.nx)
+        L = _lib.lib()
+        ms_map, ms_canvas = C.c_float(0), C.c_float(0)
+        args = (F._p(feats), F._p(c0), c0.shape[0], B, ch, me.ny, me.nx, layout, F._p(cmap), F._p(canvas))
+        _lib.check(L.gga_profile_pillar_scatter(*args, 3, C.byref(ms_map), C.byref(ms_canvas), F._stream()), 'profile')
+        _lib.check(L.gga_profile_pillar_scatter(*args, isolated_iters, C.byref(ms_map), C.byref(ms_canvas), F._stream()),
+                   'profile')
+        out['isolated_kernel_ms'] = round(ms_canvas.value, 4)
+        out['isolated_gbs'] = round(algo / (ms_canvas.value * 1e-3) / 1e9, 1)
+        out['map_kernel_ms'] = round(ms_map.value, 4)
+    return out
 
 
 def cpu_baseline(cfg, frames=16):
@@ -118,6 +129,8 @@ def main():
     ap.add_argument('--miopen-find', action='store_true', help='torch.backends.cudnn.benchmark=True (MIOpen find mode)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--roofline-isolated', type=int, default=0, metavar='ITERS',
+                    help='also time ITERS back-to-back launches of the scatter kernels outside the steps')
     args = ap.parse_args()
     args.channels_last = not args.nchw
 
@@ -158,6 +171,10 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    want_roofline = rank == 0 and not args.no_roofline and hasattr(model.pts_middle_encoder, 'ny')
+    if want_roofline:      # one HIP-event pair per step around the scatter canvas kernel (no synchronisation)
+        from gga_amd import _lib
+        _lib.check(_lib.lib().gga_pillar_scatter_timing_begin(min(args.steps, 256)), 'timing_begin')
     t0 = time.perf_counter()
     for i in range(args.steps):
         out = runner.step(batches[i % 2])
@@ -166,6 +183,12 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    scatter_ms = []
+    if want_roofline:
+        buf = (C.c_float * 256)()
+        n = _lib.lib().gga_pillar_scatter_timing_collect(buf, 256)
+        _lib.check(min(n, 0), 'timing_collect')
+        scatter_ms = [buf[i] for i in range(n)]
     t = torch.tensor([dt], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -188,8 +211,8 @@ def main():
                        'parallelism': f'dp{world}', 'memory_format': 'channels_last' if args.channels_last else 'nchw',
                        'final_loss': round(loss, 4)},
         }
-        if not args.no_roofline:
-            res['roofline'] = scatter_roofline(model, batches[0]['points'], device)
+        if scatter_ms:
+            res['roofline'] = scatter_roofline(model, batches, device, scatter_ms, args.roofline_isolated)
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(cfg)
         print(json.dumps(res), flush=True)

@@ -51,8 +51,10 @@ SIGNATURES = {
     'gga_pfn_fwd': (i32, [vp, vp, vp, i64, i32, C.POINTER(PfnParams), vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
     'gga_pfn_bwd': (i32, [vp, vp, vp, i64, i32, C.POINTER(PfnParams), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
     'gga_pillar_scatter_map_bytes': (sz, [i32, i32, i32]),
-    'gga_pillar_scatter_fwd': (i32, [vp, vp, i64, vp, i32, i32, i32, i32, i32, vp, vp, vp]),
+    'gga_pillar_scatter_fwd': (i32, [vp, vp, i64, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp]),
     'gga_pillar_scatter_bwd': (i32, [vp, vp, i64, vp, i32, i32, i32, i32, i32, vp, vp]),
+    'gga_pillar_scatter_timing_begin': (i32, [i32]),
+    'gga_pillar_scatter_timing_collect': (i32, [vp, i32]),
     'gga_profile_pillar_scatter': (i32, [vp, vp, i64, i32, i32, i32, i32, i32, vp, vp, i32,
                                           C.POINTER(C.c_float), C.POINTER(C.c_float), vp]),
     'gga_sparse_index_bytes': (sz, [i64]),

@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256) void scatter_canvas_nchw_v2_kernel(const float
 // NHWC canvas (channels-last memory): one thread = 4 channels of one cell; the
 // channels/4 lanes of a cell read the same map word (broadcast) and write one
 // contiguous row.
-template <int U>
+template <int U, bool NT>
 __global__ __launch_bounds__(256) void scatter_canvas_nhwc_kernel(const float* __restrict__ feats,
                                                                  int32_t* __restrict__ cell_map, int c4,
                                                                  int64_t total4, float* __restrict__ canvas) {
@@ -262,16 +262,113 @@ __global__ __launch_bounds__(256) void scatter_canvas_nhwc_kernel(const float* _
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const int64_t t = base + u * 256;
-        if (t < total4) store4<true>(reinterpret_cast<float4*>(canvas) + t, v[u]);
+        if (t < total4) store4<NT>(reinterpret_cast<float4*>(canvas) + t, v[u]);
     }
+}
+
+// NHWC canvas, wave-per-64-cells form (C4 = channels/4 divides 64): a wavefront owns 64
+// consecutive cells = 64*C4 contiguous float4s. One coalesced 256 B map load per wave, then C4
+// wave-wide 1 KB stores; each lane gets the map word of its cell by a cross-lane read. Empty cells
+// (92 % of a KITTI canvas) are written with stores that depend on nothing but the map word, so
+// the kernel runs as a fill with a minority of gather->store chains on the side: with a cold
+// memory system the form above is bound by the latency of its map -> row -> store chain.
+template <int C4, bool NT>
+__global__ __launch_bounds__(256) void scatter_canvas_nhwc_wave_kernel(const float* __restrict__ feats,
+                                                                      const int32_t* __restrict__ cell_map,
+                                                                      int64_t total_cells,
+                                                                      float* __restrict__ canvas) {
+    constexpr int CPI = 64 / C4;                 // cells covered by one wave-wide store
+    const int lane = threadIdx.x & 63;
+    const int64_t cell0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
+    if (cell0 >= total_cells) return;
+    const int mine = cell0 + lane < total_cells ? cell_map[cell0 + lane] : -2;
+    const int sub = lane / C4, piece = lane - sub * C4;
+    float4* out = reinterpret_cast<float4*>(canvas) + cell0 * C4 + lane;
+    const float4* f4 = reinterpret_cast<const float4*>(feats);
+    int idx[C4];
+#pragma unroll
+    for (int it = 0; it < C4; ++it) idx[it] = __shfl(mine, it * CPI + sub);
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int it = 0; it < C4; ++it)
+        if (idx[it] == -1) store4<NT>(out + it * 64, zero);
+    float4 v[C4];
+#pragma unroll
+    for (int it = 0; it < C4; ++it)
+        if (idx[it] >= 0) v[it] = f4[(int64_t)idx[it] * C4 + piece];
+#pragma unroll
+    for (int it = 0; it < C4; ++it)
+        if (idx[it] >= 0) store4<NT>(out + it * 64, v[it]);
+}
+
+// NHWC canvas, fill + rows form (default): measured with a cold memory system (the state inside a
+// train step) a plain fill of the canvas runs at ~7 TB/s while every fused form above stays at
+// 4.2-5.4 TB/s - its map -> row -> store chains and the reads mixed into the write stream cost
+// more than writing the 7 % occupied cells twice. So: (1) stream zeros over the whole canvas,
+// (2) winner map as before, (3) one 16 B piece per thread: the winning row of each occupied cell
+// is copied to its place and its map word is reset in the same pass.
+template <bool NT>
+__global__ __launch_bounds__(256) void scatter_fill_kernel(float4* __restrict__ canvas4, int64_t total4) {
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int64_t base = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int64_t t = base + u * 256;
+        if (t < total4) store4<NT>(canvas4 + t, zero);
+    }
+}
+
+template <bool RESET>
+__global__ __launch_bounds__(256) void scatter_rows_nhwc_kernel(const float4* __restrict__ feats4,
+                                                               const int4* __restrict__ coors, int64_t m,
+                                                               const int32_t* __restrict__ num_valid, int batch,
+                                                               int ny, int nx, int c4, int shift,
+                                                               int32_t* __restrict__ cell_map,
+                                                               float4* __restrict__ canvas4) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t lim = num_valid ? (int64_t)*num_valid : m;
+    const int64_t r = shift >= 0 ? (t >> shift) : (t / c4);
+    if (r >= m || r >= lim) return;
+    const int piece = (int)(t - r * c4);
+    const int4 c = coors[r];
+    if ((unsigned)c.x >= (unsigned)batch || (unsigned)c.z >= (unsigned)ny || (unsigned)c.w >= (unsigned)nx) return;
+    const int64_t cell = ((int64_t)c.x * ny + c.z) * nx + c.w;
+    if (cell_map && cell_map[cell] != (int32_t)r) return;   // a duplicate of this cell with a higher row exists
+    canvas4[cell * c4 + piece] = feats4[t];
+    // RESET: a row's c4 lanes sit in one wavefront and read the map word with the same load, so
+    // the one lane that resets it (after its own load returned) cannot be seen by the others
+    if (RESET && piece == 0) cell_map[cell] = -1;
+}
+
+// GGA_SCATTER_NHWC_FORM: 2 = fill + rows (default), 1 = wave-per-64-cells gather, 0 = piece-per-thread gather
+static int nhwc_form() {
+    static int form = -1;
+    if (form < 0) { const char* e = getenv("GGA_SCATTER_NHWC_FORM"); form = e ? atoi(e) : 2; }
+    return form;
+}
+static int nhwc_nt() {
+    static int nt = -1;
+    if (nt < 0) { const char* e = getenv("GGA_SCATTER_NHWC_NT"); nt = e ? atoi(e) : 1; }
+    return nt;
 }
 
 static void launch_canvas_nhwc(hipStream_t stream, const float* feats, int32_t* cell_map, int c4, int64_t total4,
                                float* canvas) {
+    const int form = nhwc_form(), nt = nhwc_nt();
+    if (form == 1 && (c4 == 8 || c4 == 16 || c4 == 32)) {
+        const int64_t cells = total4 / c4;
+        const dim3 grid((unsigned)((cells + 255) / 256)), block(256);
+#define NW(C4) { if (nt) hipLaunchKernelGGL((scatter_canvas_nhwc_wave_kernel<C4, true>), grid, block, 0, stream, feats, cell_map, cells, canvas); \
+                 else hipLaunchKernelGGL((scatter_canvas_nhwc_wave_kernel<C4, false>), grid, block, 0, stream, feats, cell_map, cells, canvas); }
+        if (c4 == 8) NW(8) else if (c4 == 16) NW(16) else NW(32)
+#undef NW
+        return;
+    }
     static int u = -1;
     if (u < 0) { const char* e = getenv("GGA_SCATTER_NHWC_UNROLL"); u = e ? atoi(e) : 1; }   // measured: 1 piece/thread + NT stores = 7.6 TB/s, 4 = 5.8, 16 = 5.6
-#define NH(U) hipLaunchKernelGGL(scatter_canvas_nhwc_kernel<U>, dim3((unsigned)((total4 + U * 256 - 1) / (U * 256))), dim3(256), 0, stream, feats, cell_map, c4, total4, canvas)
-    if (u == 2) NH(2); else if (u == 4) NH(4); else if (u == 8) NH(8); else if (u == 16) NH(16); else NH(1);
+#define NH(U) { if (nt) hipLaunchKernelGGL((scatter_canvas_nhwc_kernel<U, true>), dim3((unsigned)((total4 + U * 256 - 1) / (U * 256))), dim3(256), 0, stream, feats, cell_map, c4, total4, canvas); \
+                else hipLaunchKernelGGL((scatter_canvas_nhwc_kernel<U, false>), dim3((unsigned)((total4 + U * 256 - 1) / (U * 256))), dim3(256), 0, stream, feats, cell_map, c4, total4, canvas); }
+    if (u == 2) NH(2) else if (u == 4) NH(4) else if (u == 8) NH(8) else if (u == 16) NH(16) else NH(1)
 #undef NH
 }
 
@@ -368,26 +465,97 @@ static int scatter_check(const char* fn, int64_t m, int batch, int channels, int
     return GGA_OK;
 }
 
+// Bench-only in-place timing: while armed, every forward call brackets its canvas kernel with a
+// pair of HIP events on the caller's stream (nothing is synchronised until the collect call).
+#define SCATTER_TIMING_MAX 256
+static hipEvent_t g_tev[SCATTER_TIMING_MAX][2];
+static int g_tcap = 0, g_tcount = 0, g_tmade = 0;
+
+extern "C" int gga_pillar_scatter_timing_begin(int max_samples) {
+    GGA_REQUIRE(max_samples >= 0 && max_samples <= SCATTER_TIMING_MAX, "gga_pillar_scatter_timing_begin: 0 <= max_samples <= %d",
+                SCATTER_TIMING_MAX);
+    for (; g_tmade < max_samples; ++g_tmade) {
+        GGA_CHECK_HIP(hipEventCreate(&g_tev[g_tmade][0]), "timing event");
+        GGA_CHECK_HIP(hipEventCreate(&g_tev[g_tmade][1]), "timing event");
+    }
+    g_tcap = max_samples;
+    g_tcount = 0;
+    return GGA_OK;
+}
+
+extern "C" int gga_pillar_scatter_timing_collect(float* ms_host, int cap) {
+    GGA_REQUIRE(ms_host || cap == 0, "gga_pillar_scatter_timing_collect: null pointer argument");
+    const int n = g_tcount < cap ? g_tcount : cap;
+    for (int i = 0; i < n; ++i) {
+        GGA_CHECK_HIP(hipEventSynchronize(g_tev[i][1]), "timing sync");
+        GGA_CHECK_HIP(hipEventElapsedTime(&ms_host[i], g_tev[i][0], g_tev[i][1]), "timing elapsed");
+    }
+    g_tcap = g_tcount = 0;
+    return n;
+}
+
 extern "C" int gga_pillar_scatter_fwd(const float* feats, const int32_t* coors, int64_t m, const int32_t* num_valid,
-                                      int batch, int channels, int ny, int nx, int layout, int32_t* cell_map,
-                                      float* canvas, void* stream_) {
+                                      int batch, int channels, int ny, int nx, int layout, int unique_coors,
+                                      int32_t* cell_map, float* canvas, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    GGA_REQUIRE(cell_map && canvas && (m == 0 || (feats && coors)), "gga_pillar_scatter_fwd: null pointer argument");
+    const bool need_map = !(unique_coors && layout == GGA_LAYOUT_NHWC && nhwc_form() == 2);
+    GGA_REQUIRE((cell_map || !need_map) && canvas && (m == 0 || (feats && coors)),
+                "gga_pillar_scatter_fwd: null pointer argument");
     if (int rc = scatter_check("gga_pillar_scatter_fwd", m, batch, channels, ny, nx, layout)) return rc;
     const int64_t cells = (int64_t)ny * nx;
-    if (m > 0) {
+    const bool timed = g_tcount < g_tcap;
+    const bool fill_rows = layout == GGA_LAYOUT_NHWC && nhwc_form() == 2;
+    // fill + rows form: the events bracket the whole op (fill, map, rows); otherwise the canvas kernel
+    if (timed && fill_rows) GGA_CHECK_HIP(hipEventRecord(g_tev[g_tcount][0], stream), "timing record");
+    if (fill_rows) {
+        const int64_t total4 = (int64_t)batch * cells * (channels / 4);
+        const dim3 grid((unsigned)((total4 + 1023) / 1024)), block(256);
+        if (nhwc_nt()) hipLaunchKernelGGL(scatter_fill_kernel<true>, grid, block, 0, stream, (float4*)canvas, total4);
+        else hipLaunchKernelGGL(scatter_fill_kernel<false>, grid, block, 0, stream, (float4*)canvas, total4);
+        GGA_CHECK_LAUNCH("scatter_fill_kernel");
+    }
+    if (m > 0 && need_map) {
         hipLaunchKernelGGL(scatter_map_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, stream, coors, m,
                            num_valid, batch, ny, nx, cell_map);
         GGA_CHECK_LAUNCH("scatter_map_kernel");
     }
+    if (timed && !fill_rows) GGA_CHECK_HIP(hipEventRecord(g_tev[g_tcount][0], stream), "timing record");
     if (layout == GGA_LAYOUT_NCHW) {
         launch_canvas_nchw(stream, feats, cell_map, channels, cells, batch, canvas);
         GGA_CHECK_LAUNCH("scatter_canvas_nchw_kernel");
+        if (timed) GGA_CHECK_HIP(hipEventRecord(g_tev[g_tcount++][1], stream), "timing record");
+    } else if (nhwc_form() == 2) {
+        const int c4 = channels / 4;
+        const int64_t total4 = (int64_t)batch * cells * c4;
+        const int shift = ((c4 & (c4 - 1)) == 0) ? (31 - __builtin_clz(c4)) : -1;
+        const bool inplace_reset = (64 % c4) == 0;
+        if (m > 0) {
+            const dim3 grid((unsigned)((m * c4 + 255) / 256)), block(256);
+            if (!need_map)
+                hipLaunchKernelGGL(scatter_rows_nhwc_kernel<false>, grid, block, 0, stream, (const float4*)feats,
+                                   (const int4*)coors, m, num_valid, batch, ny, nx, c4, shift, (int32_t*)nullptr,
+                                   (float4*)canvas);
+            else if (inplace_reset)
+                hipLaunchKernelGGL(scatter_rows_nhwc_kernel<true>, grid, block, 0, stream, (const float4*)feats,
+                                   (const int4*)coors, m, num_valid, batch, ny, nx, c4, shift, cell_map, (float4*)canvas);
+            else
+                hipLaunchKernelGGL(scatter_rows_nhwc_kernel<false>, grid, block, 0, stream, (const float4*)feats,
+                                   (const int4*)coors, m, num_valid, batch, ny, nx, c4, shift, cell_map, (float4*)canvas);
+            GGA_CHECK_LAUNCH("scatter_rows_nhwc_kernel");
+        }
+        if (timed) GGA_CHECK_HIP(hipEventRecord(g_tev[g_tcount++][1], stream), "timing record");
+        if (m > 0 && need_map && !inplace_reset) {
+            hipLaunchKernelGGL(scatter_map_reset_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, stream,
+                               coors, m, num_valid, batch, ny, nx, cell_map);
+            GGA_CHECK_LAUNCH("scatter_map_reset_kernel");
+        }
+        (void)total4;
     } else {
         const int c4 = channels / 4;
         const int64_t total4 = (int64_t)batch * cells * c4;
         launch_canvas_nhwc(stream, feats, cell_map, c4, total4, canvas);
         GGA_CHECK_LAUNCH("scatter_canvas_nhwc_kernel");
+        if (timed) GGA_CHECK_HIP(hipEventRecord(g_tev[g_tcount++][1], stream), "timing record");
         if (m > 0) {   // NHWC readers share map words, so the reset is its own (4 B/pillar) pass
             hipLaunchKernelGGL(scatter_map_reset_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, stream,
                                coors, m, num_valid, batch, ny, nx, cell_map);

@@ -172,7 +172,7 @@ def _cell_map(device, batch, ny, nx):
 
 class _PillarScatter(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, feats, coors, batch, ny, nx, layout, num_valid):
+    def forward(ctx, feats, coors, batch, ny, nx, layout, num_valid, unique=False):
         _need_cuda(feats, coors)
         feats = feats.contiguous()
         coors = coors.contiguous()
@@ -184,9 +184,11 @@ class _PillarScatter(torch.autograd.Function):
         else:
             canvas = torch.empty((batch, Cc, ny, nx), dtype=torch.float32, device=feats.device,
                                  memory_format=torch.channels_last)
+        # unique coordinates + NHWC need no winner map (fill + row copies)
+        cmap = None if (unique and layout == LAYOUT_NHWC) else _cell_map(feats.device, batch, ny, nx)
         check(_lib.lib().gga_pillar_scatter_fwd(_p(feats), _p(coors), m, _p(num_valid), batch, Cc, ny, nx,
-                                                layout, _p(_cell_map(feats.device, batch, ny, nx)),
-                                                _p(canvas), _stream()), 'gga_pillar_scatter_fwd')
+                                                layout, int(bool(unique)), _p(cmap), _p(canvas), _stream()),
+              'gga_pillar_scatter_fwd')
         ctx.save_for_backward(coors, num_valid)
         ctx.geom = (m, batch, Cc, ny, nx, layout)
         return canvas
@@ -202,13 +204,15 @@ class _PillarScatter(torch.autograd.Function):
         gf = torch.empty((m, Cc), dtype=torch.float32, device=grad.device)
         check(_lib.lib().gga_pillar_scatter_bwd(_p(grad), _p(coors), m, _p(num_valid), batch, Cc, ny, nx,
                                                 layout, _p(gf), _stream()), 'gga_pillar_scatter_bwd')
-        return gf, None, None, None, None, None, None
+        return gf, None, None, None, None, None, None, None
 
 
-def pillar_scatter(feats, coors, batch_size, ny, nx, channels_last=False, num_valid=None):
-    """[M,C] pillar features + coors (b,z,y,x) -> dense [B,C,ny,nx] canvas."""
+def pillar_scatter(feats, coors, batch_size, ny, nx, channels_last=False, num_valid=None, unique=False):
+    """[M,C] pillar features + coors (b,z,y,x) -> dense [B,C,ny,nx] canvas. ``unique``: the caller
+    guarantees distinct (b,y,x) (voxelizer output, sparse sites); otherwise the highest row of a
+    duplicated cell wins."""
     return _PillarScatter.apply(feats, coors, int(batch_size), int(ny), int(nx),
-                                LAYOUT_NHWC if channels_last else LAYOUT_NCHW, num_valid)
+                                LAYOUT_NHWC if channels_last else LAYOUT_NCHW, num_valid, bool(unique))
 
 
 # ----------------------------------------------------------------------------- a6/a7

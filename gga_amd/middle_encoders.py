@@ -23,6 +23,7 @@ class PointPillarsScatter(nn.Module):
         self.nx = output_shape[1]
         self.in_channels = in_channels
         self.channels_last = channels_last
+        self.unique_coors = True
         self.fp16_enabled = False
 
     def forward(self, voxel_features, coors, batch_size=None, num_valid=None):
@@ -31,5 +32,7 @@ class PointPillarsScatter(nn.Module):
             coors = coors.clone()
             coors[:, 0] = 0
             batch_size = 1
+        # coordinates come from hard voxelization: one pillar per cell (the reference's index_put
+        # is undefined for repeated cells on the GPU); set unique_coors = False for arbitrary input
         return F.pillar_scatter(voxel_features, coors, int(batch_size), self.ny, self.nx,
-                                channels_last=self.channels_last, num_valid=num_valid)
+                                channels_last=self.channels_last, num_valid=num_valid, unique=self.unique_coors)

@@ -134,7 +134,7 @@ class SparseConvTensor:
         D, H, W = self._level.shape
         c = self.indices
         folded = torch.stack([c[:, 0], torch.zeros_like(c[:, 0]), c[:, 1] * H + c[:, 2], c[:, 3]], 1).contiguous()
-        out = F.pillar_scatter(self.features, folded, self.batch_size, D * H, W)
+        out = F.pillar_scatter(self.features, folded, self.batch_size, D * H, W, unique=True)
         out = out.view(self.batch_size, self.features.shape[1], D, H, W)
         return out if channels_first else out.permute(0, 2, 3, 4, 1).contiguous()
 

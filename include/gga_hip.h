@@ -141,10 +141,14 @@ size_t gga_pillar_scatter_map_bytes(int batch, int ny, int nx);
  *            NCHW: [batch, channels, ny, nx]   NHWC: [batch, ny, nx, channels]
  * channels must be a multiple of 4. Duplicate (b, y, x): the highest row wins
  * (= the sequential index_put of the reference's CPU path).
+ * unique_coors != 0: the caller guarantees that no (b, y, x) repeats (true for the output of
+ * gga_hard_voxelize_batch and for the sites of a sparse tensor); the NHWC path then needs no
+ * winner map (cell_map may be NULL) - with duplicates any one of the rows wins, as in the
+ * reference's CUDA index_put. NHWC = zero fill + one 16 B copy per thread of the occupied rows.
  */
 int gga_pillar_scatter_fwd(const float* feats, const int32_t* coors, int64_t m,
                            const int32_t* num_valid, int batch, int channels, int ny, int nx,
-                           int layout, int32_t* cell_map, float* canvas, void* stream);
+                           int layout, int unique_coors, int32_t* cell_map, float* canvas, void* stream);
 
 /* grad_feats [m, channels] = grad_canvas gathered at each pillar's cell
  * (rows >= *num_valid get zeros). */
@@ -159,6 +163,15 @@ int gga_profile_pillar_scatter(const float* feats, const int32_t* coors, int64_t
                                int channels, int ny, int nx, int layout, int32_t* cell_map,
                                float* canvas, int iters, float* ms_map_host, float* ms_canvas_host,
                                void* stream);
+
+/* Bench-only, in-place timing of the scatter inside real steps: after
+ * gga_pillar_scatter_timing_begin(n) the next n gga_pillar_scatter_fwd calls bracket their
+ * kernels (NHWC: fill [+ map] + rows, i.e. the whole op; NCHW: the canvas kernel) with HIP events
+ * on the caller's stream (no synchronisation);
+ * gga_pillar_scatter_timing_collect waits for them and writes the durations (ms), returning how
+ * many were taken (or a negative status). Single-threaded use (bench.py). */
+int gga_pillar_scatter_timing_begin(int max_samples);
+int gga_pillar_scatter_timing_collect(float* ms_host, int cap);
 
 /* ------------------------------------------------------------------------- */
 /* a3'. Sparse 3D convolution (SubMConv3d / SparseConv3d) for SparseEncoder.  */

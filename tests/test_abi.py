@@ -39,7 +39,7 @@ def test_argument_validation_without_gpu():
     L = _lib.lib()
     rc = L.gga_voxel_mean(None, None, 10, 5, 4, 4, None, None)
     assert rc == -1 and b'null pointer' in L.gga_last_error()
-    rc = L.gga_pillar_scatter_fwd(None, None, 0, None, 1, 6, 4, 4, 0, 1, 1, None)
+    rc = L.gga_pillar_scatter_fwd(None, None, 0, None, 1, 6, 4, 4, 0, 0, 1, 1, None)
     assert rc == -1 and b'multiple of 4' in L.gga_last_error()
 
 

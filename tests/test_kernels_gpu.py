@@ -83,6 +83,9 @@ def test_scatter_golden(golden, case, channels_last):
     # second call reuses the self-cleaning cell map
     out2 = F.pillar_scatter(feats, coors, B, ny, nx, channels_last=channels_last)
     assert torch.equal(out, out2)
+    # voxelizer output has one pillar per cell: the map-free path gives the same canvas
+    out3 = F.pillar_scatter(feats, coors, B, ny, nx, channels_last=channels_last, unique=True)
+    assert torch.equal(out, out3)
     # backward = gather of the canvas gradient
     g = torch.randn_like(out)
     out.backward(g)
@@ -108,6 +111,7 @@ def test_scatter_full_size_properties():
             abs(float(out.sum(dtype=torch.float64) - feats.sum(dtype=torch.float64))) < 1e-6
         idx = coors.long()
         assert torch.equal(out[idx[:, 0], :, idx[:, 2], idx[:, 3]], feats)      # scatter -> gather round trip
+        assert torch.equal(out, F.pillar_scatter(feats, coors, B, ny, nx, channels_last=cl, unique=True))
     # capacity-sized buffer with a device-side valid count: rows beyond it are ignored
     nv = torch.tensor([1000], dtype=torch.int32, device=DEV)
     out = F.pillar_scatter(feats, coors, B, ny, nx, num_valid=nv)
@@ -117,8 +121,16 @@ def test_scatter_full_size_properties():
 def test_scatter_duplicate_cells_last_row_wins():
     feats = torch.arange(1, 4 * 8 + 1, dtype=torch.float32, device=DEV).view(4, 8)
     coors = torch.tensor([[0, 0, 1, 1], [0, 0, 2, 2], [0, 0, 1, 1], [0, 0, 1, 1]], dtype=torch.int32, device=DEV)
-    out = F.pillar_scatter(feats, coors, 1, 4, 4)
-    assert torch.equal(out[0, :, 1, 1], feats[3]) and torch.equal(out[0, :, 2, 2], feats[1])
+    for cl in (False, True):
+        for _ in range(3):     # repeated: the winner map must come back clean each time
+            out = F.pillar_scatter(feats, coors, 1, 4, 4, channels_last=cl)
+            assert torch.equal(out[0, :, 1, 1], feats[3]) and torch.equal(out[0, :, 2, 2], feats[1])
+            assert int((out != 0).sum()) == 16
+    # channel counts whose rows straddle wavefronts (C/4 does not divide 64) take the separate map reset
+    f12 = torch.arange(1, 4 * 12 + 1, dtype=torch.float32, device=DEV).view(4, 12)
+    for _ in range(2):
+        out = F.pillar_scatter(f12, coors, 1, 4, 4, channels_last=True)
+        assert torch.equal(out[0, :, 1, 1], f12[3]) and torch.equal(out[0, :, 2, 2], f12[1])
 
 
 def test_heatmap_splat(golden):

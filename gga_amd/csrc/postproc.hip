@@ -212,11 +212,52 @@ __global__ __launch_bounds__(256) void points_in_boxes_kernel(const float* __res
     }
 }
 
+// all = 1 writes B*M*T flags: one thread per (point, box) with the box index fastest, so a
+// wavefront writes 256 contiguous bytes; the boxes of the tile (centre z, half sizes, cos/sin of
+// -yaw: the same expressions as pt_in_box3d, evaluated once per box and workgroup) sit in LDS.
+#define PIB_PTS 64
+__global__ __launch_bounds__(256) void points_in_boxes_all_kernel(const float* __restrict__ pts,
+                                                                 const float* __restrict__ boxes, int M, int T,
+                                                                 int32_t* __restrict__ out) {
+    __shared__ float sb[256][8];
+    const int b = blockIdx.y, p0 = blockIdx.x * PIB_PTS;
+    const int np = min(PIB_PTS, M - p0);
+    const float* bb = boxes + (int64_t)b * T * 7;
+    for (int t0 = 0; t0 < T; t0 += 256) {
+        const int tn = min(256, T - t0);
+        __syncthreads();
+        if ((int)threadIdx.x < tn) {
+            const float* q = bb + (int64_t)(t0 + threadIdx.x) * 7;
+            float* d = sb[threadIdx.x];
+            d[0] = q[0]; d[1] = q[1]; d[2] = q[2] + q[5] * 0.5f; d[3] = q[3] * 0.5f; d[4] = q[4] * 0.5f; d[5] = q[5] * 0.5f;
+            d[6] = cosf(-q[6]); d[7] = sinf(-q[6]);
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < np * tn; e += 256) {
+            const int p = e / tn, t = e - p * tn;
+            const float* pt = pts + ((int64_t)b * M + p0 + p) * 3;
+            const float* d = sb[t];
+            bool in = !(fabsf(pt[2] - d[2]) > d[5]);
+            const float sx = pt[0] - d[0], sy = pt[1] - d[1];
+            const float lx = sx * d[6] - sy * d[7], ly = sx * d[7] + sy * d[6];
+            in = in & (lx > -d[3]) & (lx < d[3]) & (ly > -d[4]) & (ly < d[4]);
+            out[((int64_t)b * M + p0 + p) * T + t0 + t] = in ? 1 : 0;
+        }
+    }
+}
+
 extern "C" int gga_points_in_boxes(const float* points, const float* boxes, int B, int M, int T, int all, int32_t* out,
                                    void* stream) {
     GGA_REQUIRE(B >= 1 && M >= 0 && T >= 0, "gga_points_in_boxes: bad sizes");
     if (M == 0) return GGA_OK;
     GGA_REQUIRE(points && out && (T == 0 || boxes), "gga_points_in_boxes: null pointer argument");
+    if (all) {
+        if (T == 0) return GGA_OK;
+        hipLaunchKernelGGL(points_in_boxes_all_kernel, dim3((M + PIB_PTS - 1) / PIB_PTS, B), dim3(256), 0,
+                           (hipStream_t)stream, points, boxes, M, T, out);
+        GGA_CHECK_LAUNCH("points_in_boxes_all_kernel");
+        return GGA_OK;
+    }
     hipLaunchKernelGGL(points_in_boxes_kernel, dim3((M + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, points, boxes,
                        B, M, T, all, out);
     GGA_CHECK_LAUNCH("points_in_boxes_kernel");

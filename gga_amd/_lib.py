@@ -46,6 +46,11 @@ SIGNATURES = {
     'gga_hard_voxelize_workspace_bytes': (sz, [i32, i64]),
     'gga_hard_voxelize_batch': (i32, [vp, i32, C.POINTER(C.c_int64), i32, C.POINTER(VoxelParams),
                                        vp, vp, vp, vp, vp, sz, vp]),
+    'gga_hard_voxelize_prepared': (i32, [vp, i32, C.POINTER(C.c_int64), vp, i32, C.POINTER(VoxelParams),
+                                          vp, vp, vp, vp, vp, sz, vp]),
+    'gga_points_prepare_workspace_bytes': (sz, [i32, i64, i64]),
+    'gga_points_prepare_batch': (i32, [vp, C.POINTER(C.c_int64), vp, C.POINTER(C.c_int64), vp, C.POINTER(C.c_int64),
+                                        i32, i32, C.c_double, vp, C.POINTER(C.c_uint64), vp, vp, vp, sz, vp]),
     'gga_voxel_mean': (i32, [vp, vp, i64, i32, i32, i32, vp, vp]),
     'gga_pfn_workspace_bytes': (sz, [i64]),
     'gga_pfn_fwd': (i32, [vp, vp, vp, i64, i32, C.POINTER(PfnParams), vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),

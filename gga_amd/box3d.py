@@ -1,6 +1,8 @@
 """``LiDARInstance3DBoxes`` — the slice of the reference's box structure the GGA head and its
 post-processing touch (mmdet3d/core/bbox/structures/base_box3d.py, lidar_box3d.py): tensor
 ``(x, y, z_bottom, dx, dy, dz, yaw)``, ``bev``, centres, ``overlaps``, ``points_in_boxes_*``."""
+import math
+
 import torch
 
 from . import ops
@@ -66,6 +68,16 @@ class LiDARInstance3DBoxes:
 
     def clone(self):
         return type(self)(self.tensor.clone(), box_dim=self.box_dim, with_yaw=self.with_yaw)
+
+    def new_box(self, data):
+        """base_box3d.py:488-508: a box object of the same type / device from array-like ``data``."""
+        t = self.tensor.new_tensor(data) if not isinstance(data, torch.Tensor) else data.to(self.device)
+        return type(self)(t, box_dim=self.box_dim, with_yaw=self.with_yaw)
+
+    def limit_yaw(self, offset=0.5, period=math.pi):
+        """base_box3d.py:272-279 / structures/utils.py:11-25: yaw -> [-offset*period, (1-offset)*period)."""
+        yaw = self.tensor[:, 6]
+        self.tensor[:, 6] = yaw - torch.floor(yaw / period + offset) * period
 
     @classmethod
     def height_overlaps(cls, boxes1, boxes2, mode='iou'):

@@ -39,6 +39,9 @@ void gga_set_error(const char* fmt, ...);
 
 static inline size_t gga_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// frames per call of the batched point ops (per-frame offsets travel to the kernels by value)
+#define GGA_MAX_BATCH 128
+
 // ---- wave / block reductions (wave = 64 lanes on CDNA) ----------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -22,12 +22,18 @@
 // No dense (D,H,W) index grid (360 MB for the KITTI config) as the CPU reference uses.
 #include "gga_common.h"
 
-#define GGA_MAX_BATCH 128
 #define VOX_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
 #define VOX_ROUND_HI 0x7FFFFFFFu
 
 struct FrameOffsets {
     int32_t off[GGA_MAX_BATCH + 1];
+    const int32_t* cnt;     // optional device-side point counts (frames stored at capacity offsets)
+    __device__ __forceinline__ int n(int b) const {
+        const int cap = off[b + 1] - off[b];
+        if (!cnt) return cap;
+        const int c = cnt[b];
+        return c < 0 ? 0 : (c < cap ? c : cap);
+    }
 };
 
 struct VoxGeom {
@@ -64,7 +70,7 @@ __device__ __forceinline__ uint32_t vox_hash(unsigned long long k) {
 __global__ __launch_bounds__(256) void vox_insert_kernel(const float* __restrict__ points, int ndim,
                                                         FrameOffsets fo, VoxGeom g, VoxWorkspace ws) {
     const int b = blockIdx.y;
-    const int n = fo.off[b + 1] - fo.off[b];
+    const int n = fo.n(b);
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const int64_t gi = (int64_t)fo.off[b] + i;
@@ -98,7 +104,7 @@ __global__ __launch_bounds__(256) void vox_insert_kernel(const float* __restrict
 
 __global__ __launch_bounds__(256) void vox_flag_kernel(FrameOffsets fo, VoxWorkspace ws) {
     const int b = blockIdx.y;
-    const int n = fo.off[b + 1] - fo.off[b];
+    const int n = fo.n(b);
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const int64_t gi = (int64_t)fo.off[b] + i;
@@ -112,7 +118,7 @@ __global__ __launch_bounds__(1024) void vox_assign_kernel(FrameOffsets fo, VoxGe
     const int b = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int base = fo.off[b];
-    const int n = fo.off[b + 1] - base;
+    const int n = fo.n(b);
     __shared__ int wave_tot[16];
     __shared__ int running;
     __shared__ int act_cnt[2];
@@ -206,7 +212,7 @@ __global__ __launch_bounds__(256) void vox_write_kernel(const float* __restrict_
         if (blockIdx.x == 0 && b == batch - 1) *voxel_total = s + voxel_num_in[b];
     }
     __syncthreads();
-    const int n = fo.off[b + 1] - fo.off[b];
+    const int n = fo.n(b);
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const int64_t gi = (int64_t)fo.off[b] + i;
@@ -248,10 +254,32 @@ extern "C" size_t gga_hard_voxelize_workspace_bytes(int batch, int64_t total_poi
     return bytes + 1024;
 }
 
+static int hard_voxelize_impl(const float* points, int ndim, const int64_t* offsets_host, const int32_t* counts_dev,
+                              int batch, const gga_voxel_params* prm, float* voxels, int32_t* coors,
+                              int32_t* num_points, int32_t* voxel_num, void* workspace, size_t workspace_bytes,
+                              void* stream_);
+
 extern "C" int gga_hard_voxelize_batch(const float* points, int ndim, const int64_t* offsets_host, int batch,
                                        const gga_voxel_params* prm, float* voxels, int32_t* coors,
                                        int32_t* num_points, int32_t* voxel_num, void* workspace,
                                        size_t workspace_bytes, void* stream_) {
+    return hard_voxelize_impl(points, ndim, offsets_host, nullptr, batch, prm, voxels, coors, num_points, voxel_num,
+                              workspace, workspace_bytes, stream_);
+}
+
+extern "C" int gga_hard_voxelize_prepared(const float* points, int ndim, const int64_t* capacity_offsets_host,
+                                          const int32_t* counts_dev, int batch, const gga_voxel_params* prm,
+                                          float* voxels, int32_t* coors, int32_t* num_points, int32_t* voxel_num,
+                                          void* workspace, size_t workspace_bytes, void* stream_) {
+    GGA_REQUIRE(counts_dev, "gga_hard_voxelize_prepared: null pointer argument");
+    return hard_voxelize_impl(points, ndim, capacity_offsets_host, counts_dev, batch, prm, voxels, coors, num_points,
+                              voxel_num, workspace, workspace_bytes, stream_);
+}
+
+static int hard_voxelize_impl(const float* points, int ndim, const int64_t* offsets_host, const int32_t* counts_dev,
+                              int batch, const gga_voxel_params* prm, float* voxels, int32_t* coors,
+                              int32_t* num_points, int32_t* voxel_num, void* workspace, size_t workspace_bytes,
+                              void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     GGA_REQUIRE(points && offsets_host && prm && voxels && coors && num_points && voxel_num && workspace,
                 "gga_hard_voxelize_batch: null pointer argument");
@@ -263,6 +291,7 @@ extern "C" int gga_hard_voxelize_batch(const float* points, int ndim, const int6
     GGA_REQUIRE(offsets_host[0] == 0 && total >= 0 && total < (1ll << 30),
                 "gga_hard_voxelize_batch: offsets must start at 0 and total points < 2^30");
     FrameOffsets fo;
+    fo.cnt = counts_dev;
     int max_n = 0;
     for (int b = 0; b <= batch; ++b) {
         fo.off[b] = (int32_t)offsets_host[b];

@@ -97,6 +97,83 @@ def hard_voxelize_batch(points, voxel_size, point_cloud_range, max_points, max_v
     return voxels, num_points, coors, voxel_num
 
 
+class PreparedPoints:
+    """Frames at capacity offsets with device-side counts: the hand-over from
+    ``points_prepare_batch`` to ``hard_voxelize_prepared``."""
+
+    def __init__(self, points, capacity_offsets, counts):
+        self.points, self.capacity_offsets, self.counts = points, capacity_offsets, counts
+
+    def __len__(self):
+        return len(self.capacity_offsets) - 1
+
+    def to_list(self):
+        """Per-frame tensors (synchronises: reads the counts back)."""
+        n = self.counts.cpu().tolist()
+        return [self.points[int(o):int(o) + k] for o, k in zip(self.capacity_offsets[:-1], n)]
+
+
+def _cat_rows(parts, ndim, dev, dtype=torch.float32):
+    parts = [torch.as_tensor(p, dtype=dtype).reshape(-1, ndim) for p in parts]
+    offs = np.zeros(len(parts) + 1, np.int64)
+    offs[1:] = np.cumsum([p.shape[0] for p in parts])
+    cat = torch.cat(parts, 0) if parts else torch.zeros((0, ndim), dtype=dtype)
+    return cat.to(dev, non_blocking=True).contiguous(), offs
+
+
+@torch.no_grad()
+def points_prepare_batch(scene, sampled, centers, min_distance, point_cloud_range, shuffle_seeds, device):
+    """Device-side tail of the point pipeline for a batch (``gga_points_prepare_batch``): per frame
+    drop scene points within ``min_distance`` (BEV) of a pasted object's centre, put the pasted
+    objects' points in front, apply the strict range filter, permute by seed (0 = keep order).
+    scene / sampled: lists of [n, C] f32 (host or device), centers: list of [k, 2] f64.
+    -> ``PreparedPoints`` (no synchronisation)."""
+    dev = torch.device(device)
+    B = len(scene)
+    ndim = int(scene[0].shape[1])
+    d_scene, o_scene = _cat_rows(scene, ndim, dev)
+    d_samp, o_samp = _cat_rows(sampled, ndim, dev)
+    d_ctr, o_ctr = _cat_rows([np.asarray(c, np.float64).reshape(-1, 2) for c in centers], 2, dev, torch.float64)
+    _need_cuda(d_scene)
+    cap = (o_scene + o_samp).astype(np.int64)
+    total = int(cap[-1])
+    rng = torch.as_tensor(np.asarray(point_cloud_range, np.float32)).to(dev)
+    seeds = (C.c_uint64 * B)(*[int(s) & 0xFFFFFFFFFFFFFFFF for s in shuffle_seeds])
+    out = torch.empty((max(total, 1), ndim), dtype=torch.float32, device=dev)
+    counts = torch.empty((B,), dtype=torch.int32, device=dev)
+    L = _lib.lib()
+    max_rows = int(np.max(np.diff(cap))) if B else 0
+    ws = _workspace('pprep', L.gga_points_prepare_workspace_bytes(B, total, max_rows), dev)
+    as64 = lambda a: a.ctypes.data_as(C.POINTER(C.c_int64))
+    with torch.cuda.device(dev):
+        check(L.gga_points_prepare_batch(_p(d_scene), as64(o_scene), _p(d_samp), as64(o_samp), _p(d_ctr), as64(o_ctr), B, ndim,
+                                         float(min_distance), _p(rng), seeds, _p(out), _p(counts), _p(ws), ws.numel(),
+                                         _stream()), 'gga_points_prepare_batch')
+    return PreparedPoints(out, cap, counts)
+
+
+def hard_voxelize_prepared(prep, voxel_size, point_cloud_range, max_points, max_voxels, sync=True):
+    """``hard_voxelize_batch`` on a ``PreparedPoints`` (frames at capacity offsets, counts on the device)."""
+    _need_cuda(prep.points)
+    B, ndim, dev = len(prep), prep.points.shape[1], prep.points.device
+    prm = voxel_params(voxel_size, point_cloud_range, max_points, max_voxels)
+    cap = B * int(max_voxels)
+    voxels = torch.empty((cap, int(max_points), ndim), dtype=torch.float32, device=dev)
+    coors = torch.empty((cap, 4), dtype=torch.int32, device=dev)
+    num_points = torch.empty((cap,), dtype=torch.int32, device=dev)
+    voxel_num = torch.empty((B + 1,), dtype=torch.int32, device=dev)
+    L = _lib.lib()
+    ws = _workspace('vox', L.gga_hard_voxelize_workspace_bytes(B, int(prep.capacity_offsets[-1])), dev)
+    offs = np.ascontiguousarray(prep.capacity_offsets, np.int64)
+    check(L.gga_hard_voxelize_prepared(_p(prep.points), ndim, offs.ctypes.data_as(C.POINTER(C.c_int64)), _p(prep.counts), B,
+                                       C.byref(prm), _p(voxels), _p(coors), _p(num_points), _p(voxel_num), _p(ws),
+                                       ws.numel(), _stream()), 'gga_hard_voxelize_prepared')
+    if sync:
+        m = int(voxel_num[-1].item())
+        return voxels[:m], num_points[:m], coors[:m], voxel_num
+    return voxels, num_points, coors, voxel_num
+
+
 @torch.no_grad()
 def voxel_mean(voxels, num_points, num_features):
     _need_cuda(voxels, num_points)

@@ -104,6 +104,8 @@ BACKBONES = NECKS = HEADS = LOSSES = DETECTORS = MODELS
 VOXEL_ENCODERS = MIDDLE_ENCODERS = FUSION_LAYERS = MODELS
 BBOX_CODERS = Registry('bbox_coder')
 CONV_LAYERS = Registry('conv layer')
+PIPELINES = Registry('pipeline')             # mmdet.datasets.builder.PIPELINES (mmdet3d/datasets/builder.py)
+OBJECTSAMPLERS = Registry('Object sampler')  # mmdet3d/datasets/builder.py:13
 
 
 def build_backbone(cfg):

@@ -288,3 +288,62 @@ def make_pseudo_case(seed, n_frames, dt_dtype=np.float32):
         if a['name'][0] in KITTI_CLASSES[:3]:
             a['name'][1] = a['name'][0]
     return infos, dts
+
+
+# ---------------------------------------------------------------------------
+# Train-pipeline inputs: a ground-truth database and raw frames (before ObjectSample_GGA)
+# ---------------------------------------------------------------------------
+PIPELINE_CLASSES = ['Pedestrian', 'Cyclist', 'Car']
+
+
+def make_gt_database(seed, n_per_class=25):
+    """-> (db_infos {class: [record]}, points {path: [n,4] f32}); records carry the fields
+    DataBaseSampler_GGA reads (gga_processing.py:791-1010)."""
+    rng = np.random.default_rng(seed)
+    db, pts = {}, {}
+    for ci, cname in enumerate(PIPELINE_CLASSES):
+        recs = []
+        for i in range(n_per_class):
+            centre = np.array([rng.uniform(2, 68), rng.uniform(-38, 38), rng.uniform(-1.8, -0.6)])
+            n = int(rng.integers(5, 60))
+            path = f'db/{cname}_{i}.bin'
+            pts[path] = (centre + rng.normal(0, 0.6, (n, 3))).astype(np.float32)
+            pts[path] = np.concatenate([pts[path], rng.uniform(0, 1, (n, 1)).astype(np.float32)], 1)
+            x1, y1 = rng.uniform(0, 1000), rng.uniform(0, 300)
+            recs.append(dict(
+                name=cname, path=path, image_idx=int(rng.integers(0, 7000)), gt_idx=i,
+                box3d_lidar=np.concatenate([centre, rng.uniform(0.5, 4.0, 3), rng.uniform(-np.pi, np.pi, 1)]).astype(np.float32),
+                num_points_in_gt=n, difficulty=np.int64(rng.integers(-1, 3)), group_id=i,
+                GGA_init_pseudo_label=np.concatenate([centre + rng.normal(0, 0.2, 3), rng.uniform(0.5, 4.0, 3),
+                                                      rng.uniform(-np.pi, np.pi, 1)]),
+                GGA_box_img=np.array([x1, y1, x1 + rng.uniform(10, 200), y1 + rng.uniform(10, 120)]),
+                GGA_lidar2img=rng.normal(0, 1, (4, 4)), GGA_bdry_mask=rng.random(4) < 0.5,
+                GGA_mask2d=np.bool_(rng.random() < 0.9), GGA_mask_depth=np.bool_(rng.random() < 0.9),
+                GGA_mask_valid=np.bool_(rng.random() < 0.85), GGA_num_points_in_box2d=np.int64(rng.integers(0, 400)),
+                GGA_in_box_points=rng.normal(0, 1, (int(rng.integers(3, 30)), 4))))
+        db[cname] = recs
+    return db, pts
+
+
+def make_pipeline_frame(seed, n_points=1200, pc_range=RANGE_SECOND):
+    """Raw frame as the loaders hand it to ObjectSample_GGA: plain arrays, objects incl. invalid ones."""
+    rng = np.random.default_rng(seed)
+    lo, hi = np.array(pc_range[:3]), np.array(pc_range[3:])
+    pts = rng.uniform(lo - 3.0, hi + 3.0, (n_points, 3))
+    pts[:8] = np.array([[lo[0], 0, -1], [hi[0], 0, -1], [1, lo[1], -1], [1, hi[1], -1], [1, 0, lo[2]], [1, 0, hi[2]],
+                        [np.nextafter(np.float32(lo[0]), np.float32(1e9)), 0, -1],
+                        [np.nextafter(np.float32(hi[0]), np.float32(-1e9)), 0, -1]])      # on / next to the faces
+    pts = np.concatenate([pts, rng.uniform(0, 1, (n_points, 1))], 1).astype(np.float32)
+    n = int(rng.integers(2, 9))
+    centre = np.stack([rng.uniform(-2, 75, n), rng.uniform(-44, 44, n), rng.uniform(-1.8, -0.6, n)], 1)
+    x1, y1 = rng.uniform(0, 1000, n), rng.uniform(0, 300, n)
+    return dict(
+        points=pts, gt_bboxes_3d=np.concatenate([centre, rng.uniform(0.5, 4, (n, 3)), rng.uniform(-7, 7, (n, 1))], 1).astype(np.float32),
+        gt_labels_3d=rng.integers(0, 3, n).astype(np.int64),
+        GGA_boxes_img=np.stack([x1, y1, x1 + rng.uniform(10, 200, n), y1 + rng.uniform(10, 120, n)], 1),
+        GGA_lidar2img=rng.normal(0, 1, (n, 4, 4)),
+        GGA_init_pseudo_labels=np.concatenate([centre + rng.normal(0, 0.2, (n, 3)), rng.uniform(0.5, 4, (n, 3)),
+                                               rng.uniform(-np.pi, np.pi, (n, 1))], 1),
+        GGA_mask_valid=rng.random(n) < 0.8, GGA_bdry_masks=rng.random((n, 4)) < 0.5,
+        GGA_difficulty=rng.integers(-1, 3, n), GGA_num_points_in_box2d=rng.integers(0, 60, n),
+        GGA_in_box_points=[rng.normal(0, 1, (int(rng.integers(3, 30)), 4)) for _ in range(n)])

@@ -40,6 +40,12 @@ class Voxelization(nn.Module):
         return F.hard_voxelize_batch(points, self.voxel_size, self.point_cloud_range, self.max_num_points,
                                      self._cap(), sync=sync)
 
+    def forward_prepared(self, prep, sync=True):
+        """``forward_batch`` for the output of ``functional.points_prepare_batch`` (device-resident
+        frames with device-side point counts)."""
+        return F.hard_voxelize_prepared(prep, self.voxel_size, self.point_cloud_range, self.max_num_points,
+                                        self._cap(), sync=sync)
+
     def __repr__(self):
         return (f'{self.__class__.__name__}(voxel_size={self.voxel_size}, point_cloud_range='
                 f'{self.point_cloud_range}, max_num_points={self.max_num_points}, max_voxels={self.max_voxels}, '

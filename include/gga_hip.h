@@ -78,6 +78,38 @@ int gga_hard_voxelize_batch(const float* points, int ndim, const int64_t* offset
                             int32_t* num_points, int32_t* voxel_num, void* workspace,
                             size_t workspace_bytes, void* stream);
 
+/* Same, for frames that sit at capacity offsets with their real point counts on the device
+ * (the output of gga_points_prepare_batch): frame b's points are rows
+ * [capacity_offsets_host[b], +min(counts_dev[b], capacity)). No host synchronisation. */
+int gga_hard_voxelize_prepared(const float* points, int ndim, const int64_t* capacity_offsets_host,
+                               const int32_t* counts_dev, int batch, const gga_voxel_params* prm,
+                               float* voxels, int32_t* coors, int32_t* num_points, int32_t* voxel_num,
+                               void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* a0. Point-level tail of the train data pipeline,    */
+/*     batched over frames, between loading and voxelization.                  */
+/* ------------------------------------------------------------------------- */
+/* Per frame, over the row list [pasted objects' points, scene points]:
+ *  - ObjectSample_GGA.remove_points_in_boxes_v2 (mmdet3d/datasets/pipelines/gga_processing.py:
+ *    58-68): scene rows whose BEV distance (f64, sqrt(dx*dx + dy*dy) like scipy cdist) to any
+ *    pasted object's centre is < min_distance are dropped;
+ *  - points.cat([sampled_points, points]) (gga_processing.py:176);
+ *  - PointsRangeFilter / BasePoints.in_range_3d (transforms_3d.py:942-977,
+ *    core/points/base_points.py:203-225): strict f32 inequalities against pc_range_dev[6];
+ *  - PointShuffle (transforms_3d.py:858-883): rows permuted by a bijection seeded with
+ *    shuffle_seeds_host[f] (0 = keep the order; the reference draws torch.randperm).
+ * Kept rows are compacted in order (stable). scene / sampled: [rows, ndim] f32 with host row
+ * offsets [n_frames+1] (sampled*, center* may be NULL = nothing pasted); centers_xy [n,2] f64.
+ * Output: frame f's rows start at capacity offset (pasted + scene rows of the frames before it)
+ * in out_points; out_counts[f] (device i32) = kept rows. */
+size_t gga_points_prepare_workspace_bytes(int n_frames, int64_t total_rows, int64_t max_frame_rows);
+int gga_points_prepare_batch(const float* scene, const int64_t* scene_offsets_host, const float* sampled,
+                             const int64_t* sampled_offsets_host, const double* centers_xy,
+                             const int64_t* center_offsets_host, int n_frames, int ndim, double min_distance,
+                             const float* pc_range_dev, const uint64_t* shuffle_seeds_host, float* out_points,
+                             int32_t* out_counts, void* workspace, size_t workspace_bytes, void* stream);
+
 /* a2. HardSimpleVFE: mean of the valid points of each voxel.
  * Replaces mmdet3d/models/voxel_encoders/voxel_encoder.py:43-45.
  * out [m, num_features] = sum_p voxels[m, p, :num_features] / num_points[m]. */

@@ -467,3 +467,32 @@ void gga_oracle_image_box_overlap(const double* boxes, int N, const double* quer
         }
     }
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * Point-level tail of the train pipeline for ONE frame: remove_points_in_boxes_v2
+ * (mmdet3d/datasets/pipelines/gga_processing.py:58-68, scipy cdist = sqrt of the sum of squared
+ * differences in double), points.cat([sampled, scene]) (:176), in_range_3d
+ * (mmdet3d/core/points/base_points.py:203-225, strict float32 inequalities). Returns kept rows.
+ * ------------------------------------------------------------------------------------------- */
+int64_t gga_oracle_points_prepare(const float* scene, int64_t n_scene, const float* sampled, int64_t n_sampled,
+                                  const double* centers_xy, int64_t n_centers, int ndim, double min_distance,
+                                  const float* rng, float* out) {
+    int64_t m = 0;
+    for (int64_t v = 0; v < n_sampled + n_scene; ++v) {
+        const int is_scene = v >= n_sampled;
+        const float* p = is_scene ? scene + (v - n_sampled) * ndim : sampled + v * ndim;
+        if (!(p[0] > rng[0] && p[1] > rng[1] && p[2] > rng[2] && p[0] < rng[3] && p[1] < rng[4] && p[2] < rng[5])) continue;
+        int near = 0;
+        if (is_scene)
+            for (int64_t c = 0; c < n_centers && !near; ++c) {
+                double dx = (double)p[0] - centers_xy[2 * c], dy = (double)p[1] - centers_xy[2 * c + 1];
+                double s = dx * dx;
+                s += dy * dy;
+                near = sqrt(s) < min_distance;
+            }
+        if (near) continue;
+        for (int j = 0; j < ndim; ++j) out[m * ndim + j] = p[j];
+        ++m;
+    }
+    return m;
+}

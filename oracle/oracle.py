@@ -67,6 +67,8 @@ def lib():
         L.gga_oracle_nms_rotated_sorted.argtypes = [f32p, C.c_int, C.c_float, i64p]
         L.gga_oracle_points_in_boxes.argtypes = [f32p, C.c_int, f32p, C.c_int, C.c_int, i32p]
         L.gga_oracle_image_box_overlap.argtypes = [f64p, C.c_int, f64p, C.c_int, C.c_int, f64p]
+        L.gga_oracle_points_prepare.restype = C.c_int64
+        L.gga_oracle_points_prepare.argtypes = [f32p, C.c_int64, f32p, C.c_int64, f64p, C.c_int64, C.c_int, C.c_double, f32p, f32p]
         _LIB = L
     return _LIB
 
@@ -243,6 +245,18 @@ def image_box_overlap(boxes, query_boxes):
     if len(b) and len(q):
         lib().gga_oracle_image_box_overlap(b, len(b), q, len(q), int(np.asarray(boxes).dtype == np.float32), out)
     return out.astype(np.asarray(boxes).dtype)
+
+
+def points_prepare(scene, sampled, centers_xy, min_distance, point_cloud_range):
+    """One frame of the point pipeline tail (gga_processing.py:58-68,176; base_points.py:203-225):
+    [sampled, scene minus points near a pasted centre], range-filtered, original order."""
+    scene = _f32(scene); ndim = scene.shape[1]
+    sampled = _f32(sampled).reshape(-1, ndim)
+    ctr = np.ascontiguousarray(centers_xy, np.float64).reshape(-1, 2)
+    out = np.zeros((len(scene) + len(sampled), ndim), np.float32)
+    m = lib().gga_oracle_points_prepare(scene, len(scene), sampled, len(sampled), ctr, len(ctr), ndim, float(min_distance),
+                                        _f32(point_cloud_range), out)
+    return out[:m]
 
 
 def pseudo_label_match(dt_bboxes, gt_bboxes):

@@ -493,6 +493,111 @@ def golden_pseudo_match(ref):
     np.savez_compressed(os.path.join(OUT, 'pseudo_match.npz'), **out)
 
 
+PIPELINE_CASES = ((41, 6), (42, 5))          # (seed, frames)
+PIPELINE_OUT_KEYS = ('gt_labels_3d', 'GGA_boxes_img', 'GGA_lidar2img', 'GGA_init_pseudo_labels', 'GGA_bdry_masks',
+                     'GGA_mask_valid', 'GGA_difficulty', 'GGA_num_points_in_box2d')
+PIPELINE_RANGE = [0, -40, -3, 70.4, 40, 1]
+PIPELINE_GROUPS = dict(Car=12, Pedestrian=6, Cyclist=6)
+
+
+def import_reference_pipeline(ref):
+    """The reference's point / box structures and GGA pipeline classes, loaded by path."""
+    sys.modules['mmcv.ops'].box_iou_rotated = None
+    sys.modules['mmcv.ops'].points_in_boxes_all = None
+    sys.modules['mmcv.ops'].points_in_boxes_part = None
+    _mod('mmdet3d.core.points')
+    bp = load('mmdet3d.core.points.base_points', 'mmdet3d/core/points/base_points.py')
+    sys.modules['mmdet3d.core.points'].BasePoints = bp.BasePoints
+    lp = load('mmdet3d.core.points.lidar_points', 'mmdet3d/core/points/lidar_points.py')
+    bb = load('mmdet3d.core.bbox.structures.base_box3d', 'mmdet3d/core/bbox/structures/base_box3d.py')
+    lb = load('mmdet3d.core.bbox.structures.lidar_box3d', 'mmdet3d/core/bbox/structures/lidar_box3d.py')
+    cb = sys.modules['mmdet3d.core.bbox']
+    cb.LiDARInstance3DBoxes, cb.BaseInstance3DBoxes, cb.box_np_ops = lb.LiDARInstance3DBoxes, bb.BaseInstance3DBoxes, None
+    cb.CameraInstance3DBoxes = type('CameraInstance3DBoxes', (), {})
+    cb.DepthInstance3DBoxes = type('DepthInstance3DBoxes', (), {})
+    _mod('mmcv.utils', build_from_cfg=lambda cfg, reg: cfg)
+    _mod('mmcv.parallel', DataContainer=lambda data, **kw: data)
+    _mod('mmdet.datasets')
+    _mod('mmdet.datasets.pipelines', to_tensor=torch.as_tensor)
+    _mod('mmdet3d.datasets')
+    _mod('mmdet3d.datasets.builder', OBJECTSAMPLERS=_Reg(), PIPELINES=_Reg())
+    _mod('mmdet3d.datasets.pipelines')
+    gp = load('mmdet3d.datasets.pipelines.gga_processing', 'mmdet3d/datasets/pipelines/gga_processing.py')
+    return dict(LiDARPoints=lp.LiDARPoints, LiDARInstance3DBoxes=lb.LiDARInstance3DBoxes, gp=gp)
+
+
+def run_pipeline_case(seed, n_frames, LiDARPoints, LiDARInstance3DBoxes, make_sampler, make_object_sample, RangeFilterGGA):
+    """Seeded run of sample -> range filters -> shuffle over ``n_frames`` frames; shared by the golden
+    generator (reference classes) and tests/test_pipelines.py (this repo's classes)."""
+    db, db_pts = synthetic.make_gt_database(seed)
+    loader = lambda results: dict(points=LiDARPoints(db_pts[results['pts_filename']], points_dim=4))
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    sampler = make_sampler(db, loader)
+    osample = make_object_sample(sampler)
+    rfilter = RangeFilterGGA(point_cloud_range=PIPELINE_RANGE, num_points_range=15)
+    pcd_range = np.array(PIPELINE_RANGE, dtype=np.float32)
+    outs = []
+    for f in range(n_frames):
+        raw = synthetic.make_pipeline_frame(1000 * seed + f)
+        d = dict(raw, points=LiDARPoints(raw['points'], points_dim=4), gt_bboxes_3d=LiDARInstance3DBoxes(raw['gt_bboxes_3d']))
+        d = osample(d)
+        after_sample = d['points'].tensor.clone()
+        n_obj_sampled = len(d['gt_labels_3d'])
+        pts = d['points']
+        d['points'] = pts[pts.in_range_3d(pcd_range)]            # PointsRangeFilter.__call__
+        after_range = d['points'].tensor.clone()
+        d = rfilter(d)
+        d['points'].shuffle()                                    # PointShuffle.__call__
+        o = {k: np.asarray(d[k]) for k in PIPELINE_OUT_KEYS}
+        o.update(n_points_after_sample=np.int64(len(after_sample)),
+                 sum_points_after_sample=after_sample.double().sum(0).numpy(), points_after_range=after_range.numpy(),
+                 points=d['points'].tensor.numpy(), gt_bboxes_3d=d['gt_bboxes_3d'].tensor.numpy(),
+                 n_obj_after_sample=np.int64(n_obj_sampled),
+                 in_box_len=np.array([len(p) for p in d['GGA_in_box_points']], np.int64),
+                 in_box_cat=(np.concatenate([np.asarray(p) for p in d['GGA_in_box_points']], 0)
+                             if d['GGA_in_box_points'] else np.zeros((0, 4))))
+        outs.append(o)
+    return outs
+
+
+def golden_pipeline(ref):
+    """ObjectSample_GGA + DataBaseSampler_GGA + range filters + shuffle of the reference
+    (mmdet3d/datasets/pipelines/gga_processing.py) on the seeded database / frames of
+    gga_amd.synthetic; numpy and torch generators seeded, so the repo's mirror must reproduce the
+    exact augmentation stream."""
+    r = import_reference_pipeline(ref)
+    gp = r['gp']
+
+    def make_sampler(db, loader):
+        s = gp.DataBaseSampler_GGA.__new__(gp.DataBaseSampler_GGA)     # __init__ reads files through mmcv
+        s.data_root, s.rate, s.classes = None, 1.0, synthetic.PIPELINE_CLASSES
+        s.cat2label = {n: i for i, n in enumerate(s.classes)}
+        s.label2cat = {i: n for i, n in enumerate(s.classes)}
+        s.points_loader = loader
+        db = gp.DataBaseSampler_GGA.filter_by_difficulty(db, [-1])
+        db = gp.DataBaseSampler_GGA.filter_by_min_points(db, dict(Car=5, Pedestrian=10, Cyclist=10))
+        s.db_infos = s.group_db_infos = db
+        s.sample_classes, s.sample_max_nums = list(PIPELINE_GROUPS.keys()), list(PIPELINE_GROUPS.values())
+        s.sampler_dict = {k: gp.BatchSampler(v, k, shuffle=True) for k, v in db.items()}
+        return s
+
+    def make_object_sample(sampler):
+        o = gp.ObjectSample_GGA.__new__(gp.ObjectSample_GGA)
+        o.db_sampler, o.min_distance, o.sample_2d, o.use_ground_plane = sampler, 5.0, False, False
+        return o
+
+    out = {}
+    for seed, nf in PIPELINE_CASES:
+        res = run_pipeline_case(seed, nf, r['LiDARPoints'], r['LiDARInstance3DBoxes'], make_sampler, make_object_sample,
+                                gp.ObjectRangeFilter_GGA)
+        for f, o in enumerate(res):
+            for k, v in o.items():
+                out[f'{seed}.{f}.{k}'] = v
+        print(f'  pipeline[{seed}]: ' + ', '.join(f"{int(o['n_obj_after_sample'])}->{len(o['gt_labels_3d'])} obj / {len(o['points'])} pts" for o in res))
+    np.savez_compressed(os.path.join(OUT, 'pipeline.npz'), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = import_reference()
@@ -504,6 +609,7 @@ def main():
     golden_encoders(ref)
     golden_head(ref)
     golden_pseudo_match(ref)
+    golden_pipeline(ref)
     for f in sorted(os.listdir(OUT)):
         print(f'{f}: {os.path.getsize(os.path.join(OUT, f)) / 1024:.1f} KiB')
 

@@ -37,7 +37,7 @@ void gga_set_error(const char* fmt, ...);
         }                                                                         \
     } while (0)
 
-static inline size_t gga_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+__host__ __device__ static inline size_t gga_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // frames per call of the batched point ops (per-frame offsets travel to the kernels by value)
 #define GGA_MAX_BATCH 128

@@ -347,3 +347,55 @@ def make_pipeline_frame(seed, n_points=1200, pc_range=RANGE_SECOND):
         GGA_mask_valid=rng.random(n) < 0.8, GGA_bdry_masks=rng.random((n, 4)) < 0.5,
         GGA_difficulty=rng.integers(-1, 3, n), GGA_num_points_in_box2d=rng.integers(0, 60, n),
         GGA_in_box_points=[rng.normal(0, 1, (int(rng.integers(3, 30)), 4)) for _ in range(n)])
+
+
+# ---------------------------------------------------------------------------
+# Offline label generation inputs (utils_gga.py primitives)
+# ---------------------------------------------------------------------------
+KITTI_CALIB = dict(          # a KITTI-shaped calibration (4x4, float64)
+    P2=np.array([[721.5377, 0.0, 609.5593, 44.85728], [0.0, 721.5377, 172.854, 0.2163791],
+                 [0.0, 0.0, 1.0, 0.002745884], [0.0, 0.0, 0.0, 1.0]]),
+    R0_rect=np.array([[0.9999239, 0.00983776, -0.00744505, 0.0], [-0.0098698, 0.9999421, -0.00427846, 0.0],
+                      [0.00740253, 0.00435161, 0.9999631, 0.0], [0.0, 0.0, 0.0, 1.0]]),
+    Tr_velo_to_cam=np.array([[0.007533745, -0.9999714, -0.000616602, -0.004069766],
+                             [0.01480249, 0.0007280733, -0.9998902, -0.07631618],
+                             [0.9998621, 0.00752379, 0.01480755, -0.2717806], [0.0, 0.0, 0.0, 1.0]]))
+
+
+def make_region_grow_case(seed, n=700):
+    """Camera-frame homogeneous points [n,4] f64: a few object-like clusters over background,
+    a search mask and an origin mask (search points inside a window around the first clusters)."""
+    rng = np.random.default_rng(seed)
+    k = int(rng.integers(3, 6))
+    centres = np.stack([rng.uniform(-8, 8, k), rng.uniform(0.5, 1.5, k), rng.uniform(6, 30, k)], 1)
+    per = n // (2 * k)
+    pts = [c + rng.normal(0, [0.5, 0.35, 0.6], (per, 3)) for c in centres]
+    pts.append(np.stack([rng.uniform(-12, 12, n - per * k), rng.uniform(-1, 2, n - per * k), rng.uniform(2, 40, n - per * k)], 1))
+    pc = np.concatenate(pts)[rng.permutation(n)]
+    pc = np.concatenate([pc, np.ones((n, 1))], 1)
+    pc[5] = pc[4]                                            # an exact duplicate: first-minimum argmin matters
+    mask_search = (rng.random(n) < 0.85).astype(np.float64)
+    win = (np.abs(pc[:, 0] - centres[0, 0]) < 2.2) & (np.abs(pc[:, 2] - centres[0, 2]) < 2.5)
+    win |= (np.abs(pc[:, 0] - centres[1, 0]) < 0.8) & (np.abs(pc[:, 2] - centres[1, 2]) < 0.9)
+    mask_origin = mask_search * win
+    return pc, mask_search, mask_origin
+
+
+def make_ground_case(seed, n=3000):
+    """Camera-frame points [n,3] f64 (y down): a slightly tilted ground plane, objects, clutter."""
+    rng = np.random.default_rng(seed)
+    ng = int(n * 0.55)
+    x, z = rng.uniform(-20, 20, ng), rng.uniform(3, 60, ng)
+    ground = np.stack([x, 1.65 + 0.01 * x - 0.004 * z + rng.normal(0, 0.03, ng), z], 1)
+    no = n - ng
+    obj = np.stack([rng.uniform(-15, 15, no), rng.uniform(-1.5, 1.5, no), rng.uniform(4, 50, no)], 1)
+    return np.concatenate([ground, obj])[rng.permutation(n)]
+
+
+def make_frustum_case(seed, n=2500):
+    """LiDAR-frame points [n,4] f64 (homogeneous) in front of the car + a few 2D boxes (x1,y1,x2,y2)."""
+    rng = np.random.default_rng(seed)
+    pts = np.stack([rng.uniform(0, 60, n), rng.uniform(-25, 25, n), rng.uniform(-2.5, 1.0, n), np.ones(n)], 1)
+    boxes = np.array([[300.0, 120.0, 520.0, 260.0], [0.0, 0.0, 1241.0, 374.0], [900.0, 150.0, 1241.0, 374.0],
+                      [600.5, 170.25, 640.75, 200.5], [-1.0, -1.0, -1.0, -1.0]])
+    return pts, boxes

@@ -440,6 +440,34 @@ int gga_image_box_match(const double* dt_boxes, const int64_t* dt_offsets, const
                         const int64_t* gt_offsets, int n_frames, int64_t n_dt, int round_f32, int64_t* match,
                         double* best_iou, double* overlaps, const int64_t* overlap_offsets, void* stream);
 
+/* ------------------------------------------------------------------------- */
+/* Offline GGA label generation primitives,             */
+/* tools/data_converter/utils_gga.py. float64, reference operation order.       */
+/* ------------------------------------------------------------------------- */
+/* region_grow (utils_gga.py:6-38) for n_thresholds distance thresholds at once (the reference
+ * calls it for thresh = 0.1 .. 0.7 with the same masks, kitti_converter_gga.py:373-381).
+ * pc [n_points, dim] f64 (dim <= 4; the reference passes homogeneous camera coordinates),
+ * mask_search / mask_origin [n_points] u8 (origin must be a subset of search),
+ * ratio: the early-exit in-box ratio (use_ratio 0 = the reference's ratio=None).
+ * out_masks [n_thresholds, n_points] u8 = mask_best * mask_origin (or mask_best for ratio None). */
+size_t gga_region_grow_workspace_bytes(int64_t n_points, int n_thresholds);
+int gga_region_grow(const double* pc, int64_t n_points, int dim, const uint8_t* mask_search,
+                    const uint8_t* mask_origin, const double* thresholds, int n_thresholds, double ratio,
+                    int use_ratio, uint8_t* out_masks, void* workspace, size_t workspace_bytes, void* stream);
+
+/* points_in_convex_polygon_3d_jit (mmdet3d/core/bbox/box_np_ops.py:641-705) as used by
+ * points_in_frustm_indices (utils_gga.py:87-100): out[i, j] = 1 iff for every surface k of
+ * polyhedron j: p_i . normal_vec[j,k] + d[j,k] < 0. points [n, point_stride >= 3] f64,
+ * normal_vec [n_polyhedra, n_surfaces, 3], d [n_polyhedra, n_surfaces] (surface_equ_3d). */
+int gga_points_in_convex_polyhedra(const double* points, int64_t n_points, int point_stride, const double* normal_vec,
+                                   const double* d, int n_polyhedra, int n_surfaces, uint8_t* out, void* stream);
+
+/* RANSAC scoring of calculate_ground (utils_gga.py:121-125): for every candidate plane a.p = 1,
+ * counts[c] = #{ i : |p_i . plane_c - 1| / ||plane_c|| < threshold }; masks (optional)
+ * [n_planes, n_points] u8 the inlier masks. */
+int gga_plane_inliers(const double* points, int64_t n_points, int point_stride, const double* planes, int n_planes,
+                      double threshold, int32_t* counts, uint8_t* masks, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -496,3 +496,85 @@ int64_t gga_oracle_points_prepare(const float* scene, int64_t n_scene, const flo
     }
     return m;
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * Offline label generation primitives, tools/data_converter/utils_gga.py.
+ * region_grow (:6-38): breadth-first region growing from every not-yet-covered origin point over
+ * the search set, early exit when the share of in-origin points among the reached ones drops below
+ * `ratio`; the largest completed region wins. pc [n, dim] f64; masks u8; out u8 [n].
+ * ------------------------------------------------------------------------------------------- */
+static double rg_norm(const double* a, const double* b, int dim) {
+    double s = 0.0;
+    for (int j = 0; j < dim; ++j) { double d = a[j] - b[j]; double q = d * d; s = j == 0 ? q : s + q; }
+    return sqrt(s);
+}
+
+void gga_oracle_region_grow(const double* pc, int64_t n, int dim, const uint8_t* mask_search, const uint8_t* mask_origin,
+                            double thresh, double ratio, int use_ratio, uint8_t* out) {
+    int64_t S = 0;
+    int64_t* sidx = (int64_t*)malloc(sizeof(int64_t) * (size_t)(n + 1));
+    for (int64_t i = 0; i < n; ++i) if (mask_search[i]) sidx[S++] = i;
+    uint8_t* mask = (uint8_t*)malloc((size_t)n + 1);
+    uint8_t* best = (uint8_t*)calloc((size_t)n + 1, 1);
+    uint8_t* cur = (uint8_t*)malloc((size_t)n + 1);
+    uint8_t* smask = (uint8_t*)malloc((size_t)S + 1);
+    int64_t* queue = (int64_t*)malloc(sizeof(int64_t) * (size_t)(S + 1));
+    memcpy(mask, mask_origin, (size_t)n);
+    long long best_len = 0;
+    for (int64_t seed = 0; S > 0 && seed < n; ++seed) {
+        if (!mask[seed]) continue;                       /* pc[mask==1][0]: masks only shrink, so scan forward */
+        memset(smask, 0, (size_t)S);
+        memset(cur, 0, (size_t)n);
+        int64_t head = 0, tail = 0;
+        long long reached = 0, reached_origin = 0;
+        int flag = 1, first = 1;
+        while (first || head < tail) {
+            const double* temp = first ? pc + seed * dim : pc + sidx[queue[head]] * dim;
+            if (!first) ++head;
+            first = 0;
+            double bd = 1.0 / 0.0; int64_t bi = -1;
+            for (int64_t s = 0; s < S; ++s) { double d = rg_norm(pc + sidx[s] * dim, temp, dim); if (d < bd) { bd = d; bi = s; } }
+            if (bi >= 0 && !smask[bi]) { smask[bi] = 1; cur[sidx[bi]] = 1; ++reached; reached_origin += mask_origin[sidx[bi]] ? 1 : 0; }
+            for (int64_t s = 0; s < S; ++s)
+                if (!smask[s] && rg_norm(pc + sidx[s] * dim, temp, dim) < thresh) {
+                    queue[tail++] = s; smask[s] = 1; cur[sidx[s]] = 1; ++reached; reached_origin += mask_origin[sidx[s]] ? 1 : 0;
+                }
+            if (use_ratio && (double)reached_origin / (double)(float)reached < ratio) { flag = 0; break; }
+        }
+        if (flag && reached > best_len) { best_len = reached; memcpy(best, cur, (size_t)n); }
+        for (int64_t i = 0; i < n; ++i) if (cur[i]) mask[i] = 0;
+        mask[seed] = 0;
+    }
+    for (int64_t i = 0; i < n; ++i) out[i] = use_ratio ? (best[i] && mask_origin[i]) : best[i];
+    free(sidx); free(mask); free(best); free(cur); free(smask); free(queue);
+}
+
+/* points_in_convex_polygon_3d_jit (mmdet3d/core/bbox/box_np_ops.py:641-676) */
+void gga_oracle_points_in_polyhedra(const double* pts, int64_t n, int stride, const double* normal, const double* d, int n_poly,
+                                    int n_surf, uint8_t* out) {
+    for (int64_t i = 0; i < n; ++i)
+        for (int j = 0; j < n_poly; ++j) {
+            int in = 1;
+            for (int k = 0; k < n_surf && in; ++k) {
+                const double* nv = normal + ((size_t)j * n_surf + k) * 3;
+                double s = pts[i * stride] * nv[0] + pts[i * stride + 1] * nv[1];
+                s = s + pts[i * stride + 2] * nv[2];
+                s = s + d[(size_t)j * n_surf + k];
+                if (s >= 0) in = 0;
+            }
+            out[i * n_poly + j] = (uint8_t)in;
+        }
+}
+
+/* inlier test of calculate_ground (utils_gga.py:122-124) for one plane a.p = 1 */
+int64_t gga_oracle_plane_inliers(const double* pts, int64_t n, int stride, const double* plane, double thresh, uint8_t* mask) {
+    double norm = sqrt((plane[0] * plane[0] + plane[1] * plane[1]) + plane[2] * plane[2]);
+    int64_t c = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        double v = (pts[i * stride] * plane[0] + pts[i * stride + 1] * plane[1]) + pts[i * stride + 2] * plane[2];
+        int in = fabs(v - 1.0) / norm < thresh;
+        if (mask) mask[i] = (uint8_t)in;
+        c += in;
+    }
+    return c;
+}

@@ -67,6 +67,11 @@ def lib():
         L.gga_oracle_nms_rotated_sorted.argtypes = [f32p, C.c_int, C.c_float, i64p]
         L.gga_oracle_points_in_boxes.argtypes = [f32p, C.c_int, f32p, C.c_int, C.c_int, i32p]
         L.gga_oracle_image_box_overlap.argtypes = [f64p, C.c_int, f64p, C.c_int, C.c_int, f64p]
+        u8p = np.ctypeslib.ndpointer(np.uint8, flags='C_CONTIGUOUS')
+        L.gga_oracle_region_grow.argtypes = [f64p, C.c_int64, C.c_int, u8p, u8p, C.c_double, C.c_double, C.c_int, u8p]
+        L.gga_oracle_points_in_polyhedra.argtypes = [f64p, C.c_int64, C.c_int, f64p, f64p, C.c_int, C.c_int, u8p]
+        L.gga_oracle_plane_inliers.restype = C.c_int64
+        L.gga_oracle_plane_inliers.argtypes = [f64p, C.c_int64, C.c_int, f64p, C.c_double, u8p]
         L.gga_oracle_points_prepare.restype = C.c_int64
         L.gga_oracle_points_prepare.argtypes = [f32p, C.c_int64, f32p, C.c_int64, f64p, C.c_int64, C.c_int, C.c_double, f32p, f32p]
         _LIB = L
@@ -257,6 +262,90 @@ def points_prepare(scene, sampled, centers_xy, min_distance, point_cloud_range):
     m = lib().gga_oracle_points_prepare(scene, len(scene), sampled, len(sampled), ctr, len(ctr), ndim, float(min_distance),
                                         _f32(point_cloud_range), out)
     return out[:m]
+
+
+def region_grow(pc, mask_search, mask_origin, thresh, ratio=0.8):
+    """tools/data_converter/utils_gga.py:6-38 (returns a float64 0/1 mask like the reference)."""
+    pc = np.ascontiguousarray(pc, np.float64)
+    ms = np.ascontiguousarray(np.asarray(mask_search) == 1, np.uint8)
+    mo = np.ascontiguousarray(np.asarray(mask_origin) == 1, np.uint8)
+    out = np.zeros(len(pc), np.uint8)
+    lib().gga_oracle_region_grow(pc, len(pc), pc.shape[1], ms, mo, float(thresh), float(ratio if ratio is not None else 0.0),
+                                 int(ratio is not None), out)
+    return out.astype(np.float64)
+
+
+def points_in_polyhedra(points, normal_vec, d):
+    """box_np_ops.py:641-676 given surface_equ_3d's (normal_vec [P,S,3], d [P,S]) -> bool [N,P]."""
+    pts = np.ascontiguousarray(points, np.float64)
+    nv = np.ascontiguousarray(normal_vec, np.float64); dd = np.ascontiguousarray(d, np.float64)
+    out = np.zeros((len(pts), nv.shape[0]), np.uint8)
+    lib().gga_oracle_points_in_polyhedra(pts, len(pts), pts.shape[1], nv, dd, nv.shape[0], nv.shape[1], out)
+    return out.astype(bool)
+
+
+def plane_inliers(points, plane, thresh):
+    pts = np.ascontiguousarray(points, np.float64)
+    mask = np.zeros(len(pts), np.uint8)
+    c = lib().gga_oracle_plane_inliers(pts, len(pts), pts.shape[1], np.ascontiguousarray(plane, np.float64), float(thresh), mask)
+    return int(c), mask.astype(bool)
+
+
+def frustum_normals(rect, Trv2c, P2, bbox):
+    """Surface equations of the frustum of an image box in LiDAR coordinates, following
+    utils_gga.py:87-98 and box_np_ops.py:13-33, 256-276, 526-552, 584-638 step by step."""
+    CR, CT = P2[0:3, 0:3], P2[0:3, 3]
+    Rinv, Cinv = np.linalg.qr(np.linalg.inv(CR))
+    Cm, R, T = np.linalg.inv(Cinv), np.linalg.inv(Rinv), Cinv @ CT
+    b = np.asarray(bbox).tolist()
+    near_clip, far_clip = 0.001, 100
+    fku, fkv, u0v0 = Cm[0, 0], -Cm[1, 1], Cm[0:2, 2]
+    box = np.array([[b[0], b[1]], [b[0], b[3]], [b[2], b[3]], [b[2], b[1]]], dtype=Cm.dtype)
+    near = (box - u0v0) / np.array([fku / near_clip, -fkv / near_clip], dtype=Cm.dtype)
+    far = (box - u0v0) / np.array([fku / far_clip, -fkv / far_clip], dtype=Cm.dtype)
+    fr = np.concatenate([np.concatenate([near, far], axis=0),
+                         np.array([near_clip] * 4 + [far_clip] * 4, dtype=Cm.dtype)[:, None]], axis=1)
+    fr -= T
+    fr = (np.linalg.inv(R) @ fr.T).T
+    fr = np.concatenate([fr, np.ones((8, 1))], axis=-1) @ np.linalg.inv((rect @ Trv2c).T)
+    idx = np.array([0, 1, 2, 3, 7, 6, 5, 4, 0, 3, 7, 4, 1, 5, 6, 2, 0, 4, 5, 1, 3, 2, 6, 7]).reshape(6, 4)
+    surf = fr[..., :3][idx][None]                                   # [1, 6, 4, 3]
+    vec = surf[:, :, :2, :] - surf[:, :, 1:3, :]
+    normal = np.cross(vec[:, :, 0, :], vec[:, :, 1, :])
+    return normal, -np.einsum('aij, aij->ai', normal, surf[:, :, 0, :])
+
+
+def points_in_frustm_indices(points, rect, Trv2c, P2, bbox):
+    normal, d = frustum_normals(rect, Trv2c, P2, bbox)
+    return points_in_polyhedra(np.ascontiguousarray(points[:, :3]), normal, d)
+
+
+def calculate_ground(point_cloud, thresh_ransac=0.15, back_cut=False, back_cut_z=-5.0):
+    """utils_gga.py:103-133 with the reference's np.random call sequence."""
+    if back_cut:
+        point_cloud = point_cloud[point_cloud[:, 2] > back_cut_z]
+    cut = np.sort(point_cloud[:, 1])[int(point_cloud.shape[0] * 0.75)]
+    cloud = point_cloud[point_cloud[:, 1] > cut]
+    mask_all = np.ones(point_cloud.shape[0])
+    final = None
+
+    def collinear(p):
+        a, b, c = np.linalg.norm(p[0] - p[1]), np.linalg.norm(p[1] - p[2]), np.linalg.norm(p[2] - p[0])
+        h = (a + b + c) / 2
+        return np.sqrt(h * (h - a) * (h - b) * (h - c)) < 1e-2
+
+    for _ in range(5):
+        best_len = 0
+        for _it in range(min(cloud.shape[0], 100)):
+            tri = cloud[np.random.choice(np.arange(cloud.shape[0]), size=(3), replace=False)]
+            while collinear(tri):
+                tri = cloud[np.random.choice(np.arange(cloud.shape[0]), size=(3), replace=False)]
+            plane = np.linalg.solve(tri, np.ones(3))
+            cnt, inl = plane_inliers(point_cloud, plane, thresh_ransac)
+            if cnt > best_len and np.abs(np.dot(plane / np.linalg.norm(plane), np.array([0, 1, 0]))) > 0.9:
+                mask_ground, best_len, final = inl, cnt, tri
+        mask_all *= 1 - mask_ground
+    return mask_all, final
 
 
 def pseudo_label_match(dt_bboxes, gt_bboxes):

@@ -90,7 +90,7 @@ class _Reg:
 
 
 def install_stubs():
-    _mod('numba', jit=_identity_decorator_factory)
+    _mod('numba', jit=_identity_decorator_factory, njit=_identity_decorator_factory)
     _mod('mmcv')
     _mod('mmcv.cnn', ConvModule=_ConvModule, build_conv_layer=_build_conv_layer,
          build_norm_layer=_build_norm_layer)
@@ -598,6 +598,46 @@ def golden_pipeline(ref):
     np.savez_compressed(os.path.join(OUT, 'pipeline.npz'), **out)
 
 
+LABEL_GEN_SEEDS = (61, 62, 63)
+LABEL_GEN_RATIOS = (0.85, 0.96, None)
+
+
+def golden_label_gen(ref):
+    """region_grow / points_in_frustm_indices / calculate_ground of the reference
+    (tools/data_converter/utils_gga.py on mmdet3d/core/bbox/box_np_ops.py) on seeded inputs."""
+    bo = load('mmdet3d.core.bbox.box_np_ops', 'mmdet3d/core/bbox/box_np_ops.py')
+    sys.modules['mmdet3d.core.bbox'].box_np_ops = bo
+    ug = load('ref_tools_utils_gga', 'tools/data_converter/utils_gga.py')
+    out = {}
+    for seed in LABEL_GEN_SEEDS:
+        pc, ms, mo = synthetic.make_region_grow_case(seed)
+        for ratio in LABEL_GEN_RATIOS:
+            for j in range(7):
+                m = ug.region_grow(pc.copy(), ms, mo, (j + 1) * 0.1, ratio)
+                out[f'rg.{seed}.{ratio}.{j}'] = np.packbits(m.astype(bool))
+        tot = sum(int(np.unpackbits(out[f'rg.{seed}.{r}.{j}']).sum()) for r in LABEL_GEN_RATIOS for j in range(7))
+        print(f'  region_grow[{seed}]: {int(mo.sum())} origin / {int(ms.sum())} search points, {tot} mask points over 21 calls')
+    c = synthetic.KITTI_CALIB
+    for seed in LABEL_GEN_SEEDS[:2]:
+        pts, boxes = synthetic.make_frustum_case(seed)
+        for b, box in enumerate(boxes):
+            ind = ug.points_in_frustm_indices(pts, c['R0_rect'], c['Tr_velo_to_cam'], c['P2'], box)
+            out[f'fr.{seed}.{b}'] = np.packbits(ind.squeeze().astype(bool))
+        print(f'  frustum[{seed}]: ' + ', '.join(str(int(np.unpackbits(out[f"fr.{seed}.{b}"]).sum())) for b in range(len(boxes))) + ' points inside')
+    for seed in LABEL_GEN_SEEDS[:2]:
+        cloud = synthetic.make_ground_case(seed)
+        np.random.seed(seed)
+        mask_all, tri = ug.calculate_ground(cloud, 0.2)
+        out[f'gr.{seed}.mask'] = np.packbits(mask_all.astype(bool))
+        out[f'gr.{seed}.triple'] = tri
+        np.random.seed(seed)
+        mask_all, tri = ug.calculate_ground(cloud, 0.15, back_cut=True, back_cut_z=10.0)
+        out[f'gr.{seed}.mask_cut'] = np.packbits(mask_all.astype(bool))
+        out[f'gr.{seed}.triple_cut'] = tri
+        print(f'  ground[{seed}]: {int((1 - np.unpackbits(out[f"gr.{seed}.mask"])[:len(cloud)]).sum())} ground points of {len(cloud)}')
+    np.savez_compressed(os.path.join(OUT, 'label_gen.npz'), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = import_reference()
@@ -610,6 +650,7 @@ def main():
     golden_head(ref)
     golden_pseudo_match(ref)
     golden_pipeline(ref)
+    golden_label_gen(ref)
     for f in sorted(os.listdir(OUT)):
         print(f'{f}: {os.path.getsize(os.path.join(OUT, f)) / 1024:.1f} KiB')
 

@@ -31,13 +31,10 @@ import torch.distributed as dist  # noqa: E402
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (guides/MI355X_MICROARCH.md); ~6300 achievable
 
 
-def scatter_roofline(model, batches, device, step_ms, isolated_iters=0):
+def scatter_roofline(model, batches, device, step_ms):
     """`roofline` of the pillar-scatter canvas kernel: algorithmic bytes over
     its mean duration INSIDE the timed steps (`step_ms`: one HIP-event pair per step around the
-    kernel, on the stream it is launched on). `isolated_iters` > 0 adds the back-to-back figure
-    of gga_profile_pillar_scatter (opt-in: it adds launches to a profile of this command)."""
-    from gga_amd import _lib
-    from gga_amd import functional as F
+    kernel, on the stream it is launched on)."""
     vl, me = model.pts_voxel_layer, model.pts_middle_encoder
     B = len(batches[0]['points'])
     ch = me.in_channels
@@ -61,21 +58,6 @@ def scatter_roofline(model, batches, device, step_ms, isolated_iters=0):
            'frac': round(gbs / HBM_PEAK_GBS, 4), 'traffic': traffic, 'algorithmic_bytes': int(algo),
            'kernel_ms': round(ms, 4), 'launches_timed': len(step_ms), 'timed': 'in-step, HIP events on the launch stream',
            'pillars': int(m)}
-    if isolated_iters > 0:
-        c0 = coors[0]
-        feats = torch.randn(c0.shape[0], ch, device=device)
-        layout = F.LAYOUT_NHWC if me.channels_last else F.LAYOUT_NCHW
-        canvas = torch.empty(B * ch * me.ny * me.nx, device=device)
-        cmap = F._cell_map(device, B, me.ny, me.nx)
-        L = _lib.lib()
-        ms_map, ms_canvas = C.c_float(0), C.c_float(0)
-        args = (F._p(feats), F._p(c0), c0.shape[0], B, ch, me.ny, me.nx, layout, F._p(cmap), F._p(canvas))
-        _lib.check(L.gga_profile_pillar_scatter(*args, 3, C.byref(ms_map), C.byref(ms_canvas), F._stream()), 'profile')
-        _lib.check(L.gga_profile_pillar_scatter(*args, isolated_iters, C.byref(ms_map), C.byref(ms_canvas), F._stream()),
-                   'profile')
-        out['isolated_kernel_ms'] = round(ms_canvas.value, 4)
-        out['isolated_gbs'] = round(algo / (ms_canvas.value * 1e-3) / 1e9, 1)
-        out['map_kernel_ms'] = round(ms_map.value, 4)
     return out
 
 
@@ -129,8 +111,6 @@ def main():
     ap.add_argument('--miopen-find', action='store_true', help='torch.backends.cudnn.benchmark=True (MIOpen find mode)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
-    ap.add_argument('--roofline-isolated', type=int, default=0, metavar='ITERS',
-                    help='also time ITERS back-to-back launches of the scatter kernels outside the steps')
     args = ap.parse_args()
     args.channels_last = not args.nchw
 
@@ -212,7 +192,7 @@ def main():
                        'final_loss': round(loss, 4)},
         }
         if scatter_ms:
-            res['roofline'] = scatter_roofline(model, batches, device, scatter_ms, args.roofline_isolated)
+            res['roofline'] = scatter_roofline(model, batches, device, scatter_ms)
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(cfg)
         print(json.dumps(res), flush=True)

@@ -60,8 +60,6 @@ SIGNATURES = {
     'gga_pillar_scatter_bwd': (i32, [vp, vp, i64, vp, i32, i32, i32, i32, i32, vp, vp]),
     'gga_pillar_scatter_timing_begin': (i32, [i32]),
     'gga_pillar_scatter_timing_collect': (i32, [vp, i32]),
-    'gga_profile_pillar_scatter': (i32, [vp, vp, i64, i32, i32, i32, i32, i32, vp, vp, i32,
-                                          C.POINTER(C.c_float), C.POINTER(C.c_float), vp]),
     'gga_sparse_index_bytes': (sz, [i64]),
     'gga_sparse_build_index': (i32, [vp, i64, i32, i32, i32, i32, vp, sz, vp]),
     'gga_sparse_out_index_bytes': (sz, [i64, i32]),

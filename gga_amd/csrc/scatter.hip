@@ -1,23 +1,28 @@
-// a3: PointPillars scatter forward / backward for gfx950 — the kernel the
+// a3: PointPillars scatter forward / backward for gfx950 - the kernels the
 // "HBM GB/s on voxel scatter" metric measures.
 //
 // Reference (mmdet3d/models/middle_encoders/pillar_scatter.py:62-102): per frame,
 // zeros(C, ny*nx) -> boolean mask -> index_put -> stack. That is a zero-fill pass
 // plus a 4-byte-granular column scatter (each pillar touches C different cache lines).
 //
-// Here the scatter is turned into a GATHER over the dense output so every byte of the
-// canvas is written exactly once, by coalesced 16 B-per-lane stores, with the zero-fill
-// fused in:
-//   1. map pass     cell_map[b, y*nx+x] = pillar row   (tiny: 4 B per pillar)
-//   2. canvas pass  every thread owns 4 consecutive cells; reads their 4 map entries
-//                   (one 16 B load), resets them to -1 (the map is self-cleaning, so no
-//                   per-call memset of the map), then for every channel stores one float4
-//                   = the pillar feature where a pillar exists, 0 elsewhere.
-// HBM traffic = canvas bytes (write) + feature bytes (read, each row fetched once and then
-// served from L1/L2 for the channel loop) + map bytes: the algorithmic minimum of
-// SURVEY.md §8(d) plus the 4 B/cell map read+reset.
-#include <stdlib.h>
-
+// NHWC canvas (channels-last memory, the default of the train step): a pillar is one contiguous
+// 4*C-byte row, so the op is (1) stream zeros over the canvas, (2) copy the occupied rows to
+// their cells with one 16 B piece per thread. Voxelizer output has one pillar per cell; for
+// arbitrary input an atomicMax "winner" map (cell -> highest row) makes duplicates
+// deterministic, and the rows pass resets the map words it used (self-cleaning, no per-call
+// memset). Single-pass "gather" forms (every canvas byte written once, map -> row -> store
+// per piece) measured 7.6 TB/s back to back but 4.2-4.8 TB/s inside a train step: re-running a
+// kernel on the same buffers leaves map, rows and part of the canvas in the 256 MB MALL; with a
+// cold memory system a plain fill keeps ~7 TB/s while the dependent load chain does not
+// (DESIGN.md section 3).
+//
+// NCHW canvas (the reference layout): a pillar's channels are ny*nx*4 bytes apart, so the
+// scatter is inverted into a gather over the output - every canvas byte is written once by
+// coalesced 16 B-per-lane stores with the zero-fill fused in:
+//   1. map pass     cell_map[b, y*nx+x] = pillar row   (4 B per pillar)
+//   2. canvas pass  a workgroup owns 1024 consecutive cells; reads their map entries (and
+//                   resets them to -1), stages the pillar rows in LDS, then stores one float4
+//                   per channel and 4 cells: the pillar feature where a pillar exists, 0 elsewhere.
 #include "gga_common.h"
 
 __global__ __launch_bounds__(256) void scatter_map_kernel(const int32_t* __restrict__ coors, int64_t m,
@@ -32,67 +37,9 @@ __global__ __launch_bounds__(256) void scatter_map_kernel(const int32_t* __restr
     atomicMax(&cell_map[((int64_t)c.x * ny + c.z) * nx + c.w], (int32_t)v);
 }
 
-// NCHW canvas. One thread = 4 consecutive cells of one frame, all channels.
-// cells4 = ny*nx/4 (ny*nx must be a multiple of 4).
-template <int UNROLL>
-__global__ __launch_bounds__(256) void scatter_canvas_nchw_kernel(const float* __restrict__ feats,
-                                                                 int32_t* __restrict__ cell_map, int channels,
-                                                                 int64_t cells, int64_t cells4_total,
-                                                                 float* __restrict__ canvas) {
-    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;   // global quad index over batch*cells/4
-    if (q >= cells4_total) return;
-    const int64_t cells4 = cells >> 2;
-    const int64_t b = q / cells4;
-    const int64_t cq = q - b * cells4;
-    int4* mp = reinterpret_cast<int4*>(cell_map) + q;
-    const int4 idx = *mp;
-    const bool any = (idx.x & idx.y & idx.z & idx.w) != -1;   // any entry != -1
-    if (any) *mp = make_int4(-1, -1, -1, -1);                  // self-cleaning map
-    float4* out = reinterpret_cast<float4*>(canvas + (b * channels) * cells) + cq;
-    const int64_t cstride4 = cells4;                           // float4 stride between channels
-    if (!any) {
-        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 8
-        for (int c = 0; c < channels; ++c) out[(int64_t)c * cstride4] = z;
-        return;
-    }
-    const float* f0 = feats + (int64_t)(idx.x < 0 ? 0 : idx.x) * channels;
-    const float* f1 = feats + (int64_t)(idx.y < 0 ? 0 : idx.y) * channels;
-    const float* f2 = feats + (int64_t)(idx.z < 0 ? 0 : idx.z) * channels;
-    const float* f3 = feats + (int64_t)(idx.w < 0 ? 0 : idx.w) * channels;
-    for (int c = 0; c < channels; c += UNROLL) {
-        float4 v[UNROLL];
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u) {
-            v[u].x = idx.x >= 0 ? f0[c + u] : 0.f;
-            v[u].y = idx.y >= 0 ? f1[c + u] : 0.f;
-            v[u].z = idx.z >= 0 ? f2[c + u] : 0.f;
-            v[u].w = idx.w >= 0 ? f3[c + u] : 0.f;
-        }
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u) out[(int64_t)(c + u) * cstride4] = v[u];
-    }
-}
-
-
-// ---- variants (selected by launch_canvas_nchw) -----------------------------------------
-// ceiling probe: the store pattern alone (no map, no gathers)
-__global__ __launch_bounds__(256) void scatter_canvas_zero_probe_kernel(int channels, int64_t cells,
-                                                                       int64_t cells4_total,
-                                                                       float* __restrict__ canvas) {
-    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (q >= cells4_total) return;
-    const int64_t cells4 = cells >> 2;
-    const int64_t b = q / cells4;
-    const int64_t cq = q - b * cells4;
-    float4* out = reinterpret_cast<float4*>(canvas + (b * channels) * cells) + cq;
-    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 8
-    for (int c = 0; c < channels; ++c) out[(int64_t)c * cells4] = z;
-}
-
-// V1: like V0 but the all-empty fast path is taken only when the WHOLE wave is empty, so a
-// wave never issues two half-masked store streams.
+// NCHW canvas, generic channel count. One thread = 4 consecutive cells of one frame, all
+// channels (cells4 = ny*nx/4); the all-empty fast path is taken only when the WHOLE wave is
+// empty, so a wave never issues two half-masked store streams.
 template <int UNROLL>
 __global__ __launch_bounds__(256) void scatter_canvas_nchw_v1_kernel(const float* __restrict__ feats,
                                                                     int32_t* __restrict__ cell_map, int channels,
@@ -133,7 +80,7 @@ __global__ __launch_bounds__(256) void scatter_canvas_nchw_v1_kernel(const float
     }
 }
 
-// V2: LDS-staged. A 256-thread workgroup owns 1024 consecutive cells of one frame.
+// NCHW canvas, C = 64 / 128: LDS-staged. A 256-thread workgroup owns 1024 consecutive cells of one frame.
 //   (1) one 16 B map load per thread (+ reset), occupied cells get a compact tile slot;
 //   (2) the pillar rows of the tile are fetched with fully coalesced 256 B wave loads
 //       (lane = channel) into an LDS tile [slot][C+1];
@@ -231,90 +178,15 @@ __global__ __launch_bounds__(256) void scatter_canvas_nchw_v2_kernel(const float
     }
 }
 
-// NHWC canvas (channels-last memory): one thread = 4 channels of one cell; the
-// channels/4 lanes of a cell read the same map word (broadcast) and write one
-// contiguous row.
-template <int U, bool NT>
-__global__ __launch_bounds__(256) void scatter_canvas_nhwc_kernel(const float* __restrict__ feats,
-                                                                 int32_t* __restrict__ cell_map, int c4,
-                                                                 int64_t total4, float* __restrict__ canvas) {
-    // U independent 16 B pieces per thread (block covers U*256 consecutive float4s), streaming stores
-    const int shift = ((c4 & (c4 - 1)) == 0) ? (31 - __clz(c4)) : -1;
-    const int64_t base = (int64_t)blockIdx.x * (U * 256) + threadIdx.x;
-    int32_t idx[U];
-    int cc[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const int64_t t = base + u * 256;
-        idx[u] = -1; cc[u] = 0;
-        if (t < total4) {
-            const int64_t cell = shift >= 0 ? (t >> shift) : (t / c4);
-            cc[u] = (int)(t - cell * c4);
-            idx[u] = cell_map[cell];
-        }
-    }
-    float4 v[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (idx[u] >= 0) v[u] = reinterpret_cast<const float4*>(feats)[(int64_t)idx[u] * c4 + cc[u]];
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const int64_t t = base + u * 256;
-        if (t < total4) store4<NT>(reinterpret_cast<float4*>(canvas) + t, v[u]);
-    }
-}
-
-// NHWC canvas, wave-per-64-cells form (C4 = channels/4 divides 64): a wavefront owns 64
-// consecutive cells = 64*C4 contiguous float4s. One coalesced 256 B map load per wave, then C4
-// wave-wide 1 KB stores; each lane gets the map word of its cell by a cross-lane read. Empty cells
-// (92 % of a KITTI canvas) are written with stores that depend on nothing but the map word, so
-// the kernel runs as a fill with a minority of gather->store chains on the side: with a cold
-// memory system the form above is bound by the latency of its map -> row -> store chain.
-template <int C4, bool NT>
-__global__ __launch_bounds__(256) void scatter_canvas_nhwc_wave_kernel(const float* __restrict__ feats,
-                                                                      const int32_t* __restrict__ cell_map,
-                                                                      int64_t total_cells,
-                                                                      float* __restrict__ canvas) {
-    constexpr int CPI = 64 / C4;                 // cells covered by one wave-wide store
-    const int lane = threadIdx.x & 63;
-    const int64_t cell0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
-    if (cell0 >= total_cells) return;
-    const int mine = cell0 + lane < total_cells ? cell_map[cell0 + lane] : -2;
-    const int sub = lane / C4, piece = lane - sub * C4;
-    float4* out = reinterpret_cast<float4*>(canvas) + cell0 * C4 + lane;
-    const float4* f4 = reinterpret_cast<const float4*>(feats);
-    int idx[C4];
-#pragma unroll
-    for (int it = 0; it < C4; ++it) idx[it] = __shfl(mine, it * CPI + sub);
-    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int it = 0; it < C4; ++it)
-        if (idx[it] == -1) store4<NT>(out + it * 64, zero);
-    float4 v[C4];
-#pragma unroll
-    for (int it = 0; it < C4; ++it)
-        if (idx[it] >= 0) v[it] = f4[(int64_t)idx[it] * C4 + piece];
-#pragma unroll
-    for (int it = 0; it < C4; ++it)
-        if (idx[it] >= 0) store4<NT>(out + it * 64, v[it]);
-}
-
-// NHWC canvas, fill + rows form (default): measured with a cold memory system (the state inside a
-// train step) a plain fill of the canvas runs at ~7 TB/s while every fused form above stays at
-// 4.2-5.4 TB/s - its map -> row -> store chains and the reads mixed into the write stream cost
-// more than writing the 7 % occupied cells twice. So: (1) stream zeros over the whole canvas,
-// (2) winner map as before, (3) one 16 B piece per thread: the winning row of each occupied cell
-// is copied to its place and its map word is reset in the same pass.
-template <bool NT>
+// NHWC canvas: fill, then one 16 B piece per thread copies the (winning) row of each occupied
+// cell to its place; with a winner map, the row's first lane resets its map word in the same pass.
 __global__ __launch_bounds__(256) void scatter_fill_kernel(float4* __restrict__ canvas4, int64_t total4) {
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
     const int64_t base = (int64_t)blockIdx.x * 1024 + threadIdx.x;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int64_t t = base + u * 256;
-        if (t < total4) store4<NT>(canvas4 + t, zero);
+        if (t < total4) store4<true>(canvas4 + t, zero);
     }
 }
 
@@ -338,38 +210,6 @@ __global__ __launch_bounds__(256) void scatter_rows_nhwc_kernel(const float4* __
     // RESET: a row's c4 lanes sit in one wavefront and read the map word with the same load, so
     // the one lane that resets it (after its own load returned) cannot be seen by the others
     if (RESET && piece == 0) cell_map[cell] = -1;
-}
-
-// GGA_SCATTER_NHWC_FORM: 2 = fill + rows (default), 1 = wave-per-64-cells gather, 0 = piece-per-thread gather
-static int nhwc_form() {
-    static int form = -1;
-    if (form < 0) { const char* e = getenv("GGA_SCATTER_NHWC_FORM"); form = e ? atoi(e) : 2; }
-    return form;
-}
-static int nhwc_nt() {
-    static int nt = -1;
-    if (nt < 0) { const char* e = getenv("GGA_SCATTER_NHWC_NT"); nt = e ? atoi(e) : 1; }
-    return nt;
-}
-
-static void launch_canvas_nhwc(hipStream_t stream, const float* feats, int32_t* cell_map, int c4, int64_t total4,
-                               float* canvas) {
-    const int form = nhwc_form(), nt = nhwc_nt();
-    if (form == 1 && (c4 == 8 || c4 == 16 || c4 == 32)) {
-        const int64_t cells = total4 / c4;
-        const dim3 grid((unsigned)((cells + 255) / 256)), block(256);
-#define NW(C4) { if (nt) hipLaunchKernelGGL((scatter_canvas_nhwc_wave_kernel<C4, true>), grid, block, 0, stream, feats, cell_map, cells, canvas); \
-                 else hipLaunchKernelGGL((scatter_canvas_nhwc_wave_kernel<C4, false>), grid, block, 0, stream, feats, cell_map, cells, canvas); }
-        if (c4 == 8) NW(8) else if (c4 == 16) NW(16) else NW(32)
-#undef NW
-        return;
-    }
-    static int u = -1;
-    if (u < 0) { const char* e = getenv("GGA_SCATTER_NHWC_UNROLL"); u = e ? atoi(e) : 1; }   // measured: 1 piece/thread + NT stores = 7.6 TB/s, 4 = 5.8, 16 = 5.6
-#define NH(U) { if (nt) hipLaunchKernelGGL((scatter_canvas_nhwc_kernel<U, true>), dim3((unsigned)((total4 + U * 256 - 1) / (U * 256))), dim3(256), 0, stream, feats, cell_map, c4, total4, canvas); \
-                else hipLaunchKernelGGL((scatter_canvas_nhwc_kernel<U, false>), dim3((unsigned)((total4 + U * 256 - 1) / (U * 256))), dim3(256), 0, stream, feats, cell_map, c4, total4, canvas); }
-    if (u == 2) NH(2) else if (u == 4) NH(4) else if (u == 8) NH(8) else if (u == 16) NH(16) else NH(1)
-#undef NH
 }
 
 __global__ __launch_bounds__(256) void scatter_map_reset_kernel(const int32_t* __restrict__ coors, int64_t m,
@@ -415,40 +255,18 @@ __global__ __launch_bounds__(256) void scatter_bwd_kernel(const float* __restric
 }
 
 
-// Development knob: GGA_SCATTER_VARIANT=0|1|2|9 picks the NCHW canvas kernel (default: best measured).
-static int scatter_variant() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("GGA_SCATTER_VARIANT");
-        v = e ? atoi(e) : 3;
-    }
-    return v;
-}
-
 static void launch_canvas_nchw(hipStream_t stream, const float* feats, int32_t* cell_map, int channels,
                                int64_t cells, int batch, float* canvas) {
     const int64_t q = (int64_t)batch * cells / 4;
     const dim3 grid((unsigned)((q + 255) / 256)), block(256);
-    const int var = scatter_variant();
-    if (var == 9) {
-        hipLaunchKernelGGL(scatter_canvas_zero_probe_kernel, grid, block, 0, stream, channels, cells, q, canvas);
-    } else if (var == 2 && channels == 64) {
-        hipLaunchKernelGGL((scatter_canvas_nchw_v2_kernel<64, false>), grid, block, 0, stream, feats, cell_map, cells, q, canvas);
-    } else if (var == 3 && channels == 64) {
+    if (channels == 64)
         hipLaunchKernelGGL((scatter_canvas_nchw_v2_kernel<64, true>), grid, block, 0, stream, feats, cell_map, cells, q, canvas);
-    } else if (var == 2 && channels == 128) {
-        hipLaunchKernelGGL((scatter_canvas_nchw_v2_kernel<128, false>), grid, block, 0, stream, feats, cell_map, cells, q, canvas);
-    } else if (var >= 1) {
-        if (channels % 8 == 0)
-            hipLaunchKernelGGL(scatter_canvas_nchw_v1_kernel<8>, grid, block, 0, stream, feats, cell_map, channels, cells, q, canvas);
-        else
-            hipLaunchKernelGGL(scatter_canvas_nchw_v1_kernel<4>, grid, block, 0, stream, feats, cell_map, channels, cells, q, canvas);
-    } else {
-        if (channels % 8 == 0)
-            hipLaunchKernelGGL(scatter_canvas_nchw_kernel<8>, grid, block, 0, stream, feats, cell_map, channels, cells, q, canvas);
-        else
-            hipLaunchKernelGGL(scatter_canvas_nchw_kernel<4>, grid, block, 0, stream, feats, cell_map, channels, cells, q, canvas);
-    }
+    else if (channels == 128)
+        hipLaunchKernelGGL((scatter_canvas_nchw_v2_kernel<128, true>), grid, block, 0, stream, feats, cell_map, cells, q, canvas);
+    else if (channels % 8 == 0)
+        hipLaunchKernelGGL(scatter_canvas_nchw_v1_kernel<8>, grid, block, 0, stream, feats, cell_map, channels, cells, q, canvas);
+    else
+        hipLaunchKernelGGL(scatter_canvas_nchw_v1_kernel<4>, grid, block, 0, stream, feats, cell_map, channels, cells, q, canvas);
 }
 
 extern "C" size_t gga_pillar_scatter_map_bytes(int batch, int ny, int nx) {
@@ -498,20 +316,19 @@ extern "C" int gga_pillar_scatter_fwd(const float* feats, const int32_t* coors, 
                                       int batch, int channels, int ny, int nx, int layout, int unique_coors,
                                       int32_t* cell_map, float* canvas, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    const bool need_map = !(unique_coors && layout == GGA_LAYOUT_NHWC && nhwc_form() == 2);
+    const bool need_map = !(unique_coors && layout == GGA_LAYOUT_NHWC);
     GGA_REQUIRE((cell_map || !need_map) && canvas && (m == 0 || (feats && coors)),
                 "gga_pillar_scatter_fwd: null pointer argument");
     if (int rc = scatter_check("gga_pillar_scatter_fwd", m, batch, channels, ny, nx, layout)) return rc;
     const int64_t cells = (int64_t)ny * nx;
     const bool timed = g_tcount < g_tcap;
-    const bool fill_rows = layout == GGA_LAYOUT_NHWC && nhwc_form() == 2;
-    // fill + rows form: the events bracket the whole op (fill, map, rows); otherwise the canvas kernel
+    const bool fill_rows = layout == GGA_LAYOUT_NHWC;
+    // NHWC: the timing events bracket the whole op (fill, map, rows); NCHW: the canvas kernel
     if (timed && fill_rows) GGA_CHECK_HIP(hipEventRecord(g_tev[g_tcount][0], stream), "timing record");
     if (fill_rows) {
         const int64_t total4 = (int64_t)batch * cells * (channels / 4);
         const dim3 grid((unsigned)((total4 + 1023) / 1024)), block(256);
-        if (nhwc_nt()) hipLaunchKernelGGL(scatter_fill_kernel<true>, grid, block, 0, stream, (float4*)canvas, total4);
-        else hipLaunchKernelGGL(scatter_fill_kernel<false>, grid, block, 0, stream, (float4*)canvas, total4);
+        hipLaunchKernelGGL(scatter_fill_kernel, grid, block, 0, stream, (float4*)canvas, total4);
         GGA_CHECK_LAUNCH("scatter_fill_kernel");
     }
     if (m > 0 && need_map) {
@@ -524,9 +341,8 @@ extern "C" int gga_pillar_scatter_fwd(const float* feats, const int32_t* coors, 
         launch_canvas_nchw(stream, feats, cell_map, channels, cells, batch, canvas);
         GGA_CHECK_LAUNCH("scatter_canvas_nchw_kernel");
         if (timed) GGA_CHECK_HIP(hipEventRecord(g_tev[g_tcount++][1], stream), "timing record");
-    } else if (nhwc_form() == 2) {
+    } else {
         const int c4 = channels / 4;
-        const int64_t total4 = (int64_t)batch * cells * c4;
         const int shift = ((c4 & (c4 - 1)) == 0) ? (31 - __builtin_clz(c4)) : -1;
         const bool inplace_reset = (64 % c4) == 0;
         if (m > 0) {
@@ -545,18 +361,6 @@ extern "C" int gga_pillar_scatter_fwd(const float* feats, const int32_t* coors, 
         }
         if (timed) GGA_CHECK_HIP(hipEventRecord(g_tev[g_tcount++][1], stream), "timing record");
         if (m > 0 && need_map && !inplace_reset) {
-            hipLaunchKernelGGL(scatter_map_reset_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, stream,
-                               coors, m, num_valid, batch, ny, nx, cell_map);
-            GGA_CHECK_LAUNCH("scatter_map_reset_kernel");
-        }
-        (void)total4;
-    } else {
-        const int c4 = channels / 4;
-        const int64_t total4 = (int64_t)batch * cells * c4;
-        launch_canvas_nhwc(stream, feats, cell_map, c4, total4, canvas);
-        GGA_CHECK_LAUNCH("scatter_canvas_nhwc_kernel");
-        if (timed) GGA_CHECK_HIP(hipEventRecord(g_tev[g_tcount++][1], stream), "timing record");
-        if (m > 0) {   // NHWC readers share map words, so the reset is its own (4 B/pillar) pass
             hipLaunchKernelGGL(scatter_map_reset_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, stream,
                                coors, m, num_valid, batch, ny, nx, cell_map);
             GGA_CHECK_LAUNCH("scatter_map_reset_kernel");
@@ -580,46 +384,3 @@ extern "C" int gga_pillar_scatter_bwd(const float* grad_canvas, const int32_t* c
 
 // Bench-only: times the two forward kernels separately with HIP events on `stream`
 // (SYNCHRONISES; never call it from a captured or latency-sensitive path).
-extern "C" int gga_profile_pillar_scatter(const float* feats, const int32_t* coors, int64_t m, int batch,
-                                          int channels, int ny, int nx, int layout, int32_t* cell_map,
-                                          float* canvas, int iters, float* ms_map_host, float* ms_canvas_host,
-                                          void* stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    GGA_REQUIRE(feats && coors && cell_map && canvas && ms_map_host && ms_canvas_host && iters >= 1 && m > 0,
-                "gga_profile_pillar_scatter: bad arguments");
-    if (int rc = scatter_check("gga_profile_pillar_scatter", m, batch, channels, ny, nx, layout)) return rc;
-    const int64_t cells = (int64_t)ny * nx;
-    hipEvent_t e0, e1, e2;
-    GGA_CHECK_HIP(hipEventCreate(&e0), "hipEventCreate");
-    GGA_CHECK_HIP(hipEventCreate(&e1), "hipEventCreate");
-    GGA_CHECK_HIP(hipEventCreate(&e2), "hipEventCreate");
-    double tm = 0.0, tc = 0.0;
-    for (int it = 0; it < iters; ++it) {
-        (void)hipEventRecord(e0, stream);
-        hipLaunchKernelGGL(scatter_map_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, stream, coors, m,
-                           (const int32_t*)nullptr, batch, ny, nx, cell_map);
-        (void)hipEventRecord(e1, stream);
-        if (layout == GGA_LAYOUT_NCHW) {
-            launch_canvas_nchw(stream, feats, cell_map, channels, cells, batch, canvas);
-            (void)hipEventRecord(e2, stream);
-        } else {
-            const int c4 = channels / 4;
-            const int64_t total4 = (int64_t)batch * cells * c4;
-            launch_canvas_nhwc(stream, feats, cell_map, c4, total4, canvas);
-            (void)hipEventRecord(e2, stream);
-            hipLaunchKernelGGL(scatter_map_reset_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, stream,
-                               coors, m, (const int32_t*)nullptr, batch, ny, nx, cell_map);
-        }
-        GGA_CHECK_HIP(hipEventSynchronize(e2), "hipEventSynchronize");
-        float a = 0.f, b = 0.f;
-        (void)hipEventElapsedTime(&a, e0, e1);
-        (void)hipEventElapsedTime(&b, e1, e2);
-        tm += a; tc += b;
-    }
-    GGA_CHECK_HIP(hipStreamSynchronize(stream), "hipStreamSynchronize");
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
-    GGA_CHECK_LAUNCH("gga_profile_pillar_scatter");
-    *ms_map_host = (float)(tm / iters);
-    *ms_canvas_host = (float)(tc / iters);
-    return GGA_OK;
-}

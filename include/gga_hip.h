@@ -188,14 +188,6 @@ int gga_pillar_scatter_bwd(const float* grad_canvas, const int32_t* coors, int64
                            const int32_t* num_valid, int batch, int channels, int ny, int nx,
                            int layout, float* grad_feats, void* stream);
 
-/* Bench-only helper: runs the forward `iters` times and returns the mean duration (ms,
- * HIP events on `stream`) of the map kernel and of the canvas kernel separately.
- * SYNCHRONISES the stream; not capturable. Used by bench.py for `roofline.achieved`. */
-int gga_profile_pillar_scatter(const float* feats, const int32_t* coors, int64_t m, int batch,
-                               int channels, int ny, int nx, int layout, int32_t* cell_map,
-                               float* canvas, int iters, float* ms_map_host, float* ms_canvas_host,
-                               void* stream);
-
 /* Bench-only, in-place timing of the scatter inside real steps: after
  * gga_pillar_scatter_timing_begin(n) the next n gga_pillar_scatter_fwd calls bracket their
  * kernels (NHWC: fill [+ map] + rows, i.e. the whole op; NCHW: the canvas kernel) with HIP events

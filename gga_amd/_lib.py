@@ -69,6 +69,9 @@ SIGNATURES = {
     'gga_sparse_rowmask': (i32, [vp, i64, i32, vp, vp]),
     'gga_sparse_packed_weight_bytes': (sz, [i32, i32, i32]),
     'gga_sparse_pack_weight': (i32, [vp, i32, i32, i32, i32, vp, vp]),
+    'gga_sparse_split_weight_bytes': (sz, [i32, i32, i32]),
+    'gga_sparse_pack_weight_split': (i32, [vp, i32, i32, i32, i32, vp, vp]),
+    'gga_sparse_conv_apply_split': (i32, [vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp, vp]),
     'gga_sparse_conv_apply': (i32, [vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp, vp]),
     'gga_sparse_conv_wgrad': (i32, [vp, vp, vp, i64, i32, i32, i32, vp, vp]),
     'gga_bn_relu_workspace_bytes': (sz, [i64, i32]),

@@ -638,6 +638,281 @@ extern "C" int gga_sparse_conv_apply(const float* x, const int32_t* map, const f
 }
 
 
+// ------------------------------------------------------------------------------ fp32 through bf16 planes
+// The same convolution on v_mfma_f32_32x32x16_bf16. An fp32 number is the exact sum of three
+// bfloat16 numbers (8 + 8 + 8 significand bits, by truncation), so a*b is the sum of nine bf16
+// products, each exact in fp32; the matrix core accumulates them in fp32. Nine bf16 MFMAs cover
+// K = 16 in 9*32 cycles where the fp32 MFMA needs 8*64: measured 256 vs 149 fp32-equivalent
+// TFLOP/s on this part, with an error against float64 no larger than the native fp32 MFMA's
+// (2.0e-7 vs 4.5e-7 of sum|a*b| at K = 256; tools_dev/micro/bf16x9_probe.hip). The weights are split
+// when they are packed; the gathered inputs are split on their way into LDS.
+// LDS image per plane: A [128 rows][32 ch], B [CO cols][32 ch] bf16, 80-byte rows (64 + 16 pad:
+// conflict-free ds_read_b128). Lane (r = lane%32, h = lane/32) of k-step s reads the 8 channels
+// 16s + 8h .. +7 of its row / column: one 16-byte read per plane.
+typedef __bf16 mf_v8bf __attribute__((ext_vector_type(8)));
+#define X9_ROWB 80                       // bytes per LDS row
+
+__device__ __forceinline__ void x9_split(float x, uint32_t& p1, uint32_t& p2, uint32_t& p3) {
+    const uint32_t u1 = __float_as_uint(x) & 0xFFFF0000u;
+    const float r1 = x - __uint_as_float(u1);            // exact
+    const uint32_t u2 = __float_as_uint(r1) & 0xFFFF0000u;
+    const float r2 = r1 - __uint_as_float(u2);           // exact, <= 8 significant bits
+    p1 = u1 >> 16; p2 = u2 >> 16; p3 = __float_as_uint(r2) >> 16;
+}
+
+// packed[k][chunk][plane][col < CO][32 ch] bf16 = plane of W[k][chunk*32 + ch][col], CO = 32 * nt
+__global__ __launch_bounds__(256) void sp_pack_weight_split_kernel(const float* __restrict__ W, int kvol, int cin, int cout,
+                                                                  int nt, int transpose, int64_t total,
+                                                                  uint16_t* __restrict__ P) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;        // one (k, chunk, col, ch) per thread
+    if (i >= total) return;
+    const int co = 32 * nt, nchunks = (cin + MF_TK - 1) / MF_TK;
+    const int ch = (int)(i & 31);
+    const int col = (int)((i >> 5) % co);
+    const int64_t stage = (i >> 5) / co;
+    const int k = (int)(stage / nchunks), chunk = (int)(stage - (int64_t)k * nchunks);
+    const int c = chunk * MF_TK + ch;
+    float v = 0.0f;
+    if (c < cin && col < cout)
+        v = transpose ? W[((int64_t)k * cout + col) * cin + c] : W[((int64_t)k * cin + c) * cout + col];
+    uint32_t p1, p2, p3;
+    x9_split(v, p1, p2, p3);
+    uint16_t* dst = P + stage * (3 * (int64_t)co * 32) + (int64_t)col * 32 + ch;
+    dst[0] = (uint16_t)p1; dst[(int64_t)co * 32] = (uint16_t)p2; dst[2 * (int64_t)co * 32] = (uint16_t)p3;
+}
+
+extern "C" size_t gga_sparse_split_weight_bytes(int kvol, int cin, int cout) {
+    if (kvol < 1 || cin < 1 || cout < 1 || cout > 128) return 0;
+    return (size_t)kvol * ((cin + MF_TK - 1) / MF_TK) * 3 * 32 * mf_nt(cout) * 32 * sizeof(uint16_t);
+}
+
+extern "C" int gga_sparse_pack_weight_split(const float* weight, int kvol, int cin, int cout, int transpose, void* packed,
+                                            void* stream) {
+    GGA_REQUIRE(weight && packed, "gga_sparse_pack_weight_split: null pointer argument");
+    GGA_REQUIRE(kvol >= 1 && cin >= 1 && cout >= 1 && cout <= 128,
+                "gga_sparse_pack_weight_split: bad sizes (kvol=%d cin=%d cout=%d; cout <= 128)", kvol, cin, cout);
+    const int64_t total = (int64_t)(gga_sparse_split_weight_bytes(kvol, cin, cout) / (3 * sizeof(uint16_t)));
+    hipLaunchKernelGGL(sp_pack_weight_split_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       weight, kvol, cin, cout, mf_nt(cout), transpose, total, (uint16_t*)packed);
+    GGA_CHECK_LAUNCH("sp_pack_weight_split_kernel");
+    return GGA_OK;
+}
+
+// Tile: 256 output rows x CO columns per 512-thread workgroup (wave w owns rows 32w..32w+31): at the
+// bf16 rate the weight stage (24 KB for CO = 128) must be shared by more rows than the fp32
+// kernel's 128, or the L2 -> LDS traffic (9.4 TB/s measured with 128-row tiles) becomes the bound.
+#define X9_TM 256
+#define X9_APLB (X9_TM * X9_ROWB)        // bytes per A plane
+
+template <int NT, bool VEC>
+__global__ __launch_bounds__(512) void sp_conv_x9_kernel(const float* __restrict__ X, const int32_t* __restrict__ map,
+                                                        const uint16_t* __restrict__ Wp,
+                                                        const int32_t* __restrict__ perm,
+                                                        const uint32_t* __restrict__ rowmask, int64_t n_rows,
+                                                        int kvol, int cin, int cout, int flip,
+                                                        float* __restrict__ Y) {
+    constexpr int CO = NT * 32;
+    constexpr int BPL = CO * X9_ROWB;                     // bytes per B plane
+    constexpr int BPIECES = 3 * CO * 4;                   // 16-byte pieces of a packed weight stage
+    constexpr int NB = (BPIECES + 511) / 512;             // pieces per thread
+    __shared__ __attribute__((aligned(16))) unsigned char As[3 * X9_APLB];
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[3 * BPL];
+    __shared__ int prow[X9_TM];
+    __shared__ uint32_t wmask_s[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t r0 = (int64_t)(gridDim.x - 1 - blockIdx.x) * X9_TM;     // most neighbours first
+    if (tid < 8) wmask_s[tid] = 0;
+    __syncthreads();
+    if (tid < X9_TM) {
+        const int64_t r = r0 + tid;
+        int pr = -1;
+        if (r < n_rows) pr = perm ? perm[r] : (int)r;
+        prow[tid] = pr;
+        uint32_t m = 0;
+        if (pr >= 0) m = (rowmask && kvol <= 32) ? rowmask[pr] : 0xFFFFFFFFu;
+        if (m) atomicOr(&wmask_s[tid >> 5], m);
+    }
+    __syncthreads();
+    const uint32_t wmask = __builtin_amdgcn_readfirstlane(wmask_s[wave]);
+    uint32_t tm = 0;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) tm |= wmask_s[w];
+    const uint32_t tmask = __builtin_amdgcn_readfirstlane(tm);
+    mf_v16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
+
+    const int nchunks = (cin + MF_TK - 1) / MF_TK;
+    // staging roles. A: thread (ar = tid/4, aq = tid%4) loads float4 #aq and #aq+4 of the 32-channel
+    // chunk for rows ar and ar+128 and splits them into the three planes on their way to LDS.
+    const int ar = tid >> 2, aq = tid & 3;
+    const int p0 = prow[ar], p1 = prow[ar + 128];
+    auto enabled = [&](int k) { const int kk = flip ? (kvol - 1 - k) : k; return kvol > 32 || ((tmask >> kk) & 1u); };
+    auto next_enabled = [&](int k) { while (k < kvol && !enabled(k)) ++k; return k; };
+    auto load_idx = [&](int k, int& i0, int& i1) {
+        const int kk = flip ? (kvol - 1 - k) : k;
+        const int32_t* mk = map + (int64_t)kk * n_rows;
+        i0 = mk[p0 >= 0 ? p0 : 0];        // rows past n_rows gather something valid; they are never written
+        i1 = mk[p1 >= 0 ? p1 : 0];
+    };
+    float4 a0[2], a1[2];
+    uint4 bq0, bq1, bq2;
+    bq0 = bq1 = bq2 = make_uint4(0, 0, 0, 0);
+    // loads are unconditional (absent neighbours / channels past cin read row 0 / channel 0 and
+    // are zeroed when they are written to LDS), so nothing waits on them before the MFMAs.
+    // (Requesting the rows two stages ahead instead of one did not help: 2.40 vs 2.44 ms.)
+    auto load_stage = [&](int k, int ch, int i0, int i1) {
+        const int c0 = ch * MF_TK;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int cc = c0 + (aq + 4 * h) * 4;
+            if (VEC) {
+                const int co = cc < cin ? cc : 0;
+                a0[h] = *reinterpret_cast<const float4*>(X + (int64_t)(i0 >= 0 ? i0 : 0) * cin + co);
+                a1[h] = *reinterpret_cast<const float4*>(X + (int64_t)(i1 >= 0 ? i1 : 0) * cin + co);
+            } else {
+                float t0[4], t1[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int co = cc + e < cin ? cc + e : 0;
+                    t0[e] = X[(int64_t)(i0 >= 0 ? i0 : 0) * cin + co];
+                    t1[e] = X[(int64_t)(i1 >= 0 ? i1 : 0) * cin + co];
+                }
+                a0[h] = make_float4(t0[0], t0[1], t0[2], t0[3]);
+                a1[h] = make_float4(t1[0], t1[1], t1[2], t1[3]);
+            }
+        }
+        const uint4* src = reinterpret_cast<const uint4*>(Wp + ((int64_t)k * nchunks + ch) * (3 * CO * 32));
+        const int last = BPIECES - 1;
+#define X9_BLD(E, V) if ((E) < NB) V = src[min(tid + 512 * (E), last)];
+        X9_BLD(0, bq0) X9_BLD(1, bq1) X9_BLD(2, bq2)
+#undef X9_BLD
+    };
+    auto store_a = [&](unsigned char* row, int q, const float4& v, bool ok, int cc) {
+        // channels 4q..4q+3 of one row -> 4 bf16 per plane
+        const float x = ok && cc < cin ? v.x : 0.f, y = ok && cc + 1 < cin ? v.y : 0.f;
+        const float z = ok && cc + 2 < cin ? v.z : 0.f, w = ok && cc + 3 < cin ? v.w : 0.f;
+        uint32_t x1, x2, x3, y1, y2, y3, z1, z2, z3, w1, w2, w3;
+        x9_split(x, x1, x2, x3); x9_split(y, y1, y2, y3); x9_split(z, z1, z2, z3); x9_split(w, w1, w2, w3);
+        *reinterpret_cast<uint2*>(row + q * 8) = make_uint2(x1 | (y1 << 16), z1 | (w1 << 16));
+        *reinterpret_cast<uint2*>(row + X9_APLB + q * 8) = make_uint2(x2 | (y2 << 16), z2 | (w2 << 16));
+        *reinterpret_cast<uint2*>(row + 2 * X9_APLB + q * 8) = make_uint2(x3 | (y3 << 16), z3 | (w3 << 16));
+    };
+    auto store_stage = [&](int ch, int i0, int i1) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int q = aq + 4 * h, cc = ch * MF_TK + 4 * q;
+            store_a(As + ar * X9_ROWB, q, a0[h], i0 >= 0, cc);
+            store_a(As + (ar + 128) * X9_ROWB, q, a1[h], i1 >= 0, cc);
+        }
+        // piece f of the packed stage: plane f / (CO*4), column (f / 4) % CO, quarter f % 4
+#define X9_BST(E, V) if ((E) < NB) { const int f = tid + 512 * (E); if (f < BPIECES) *reinterpret_cast<uint4*>(Bs + (f / (CO * 4)) * BPL + ((f >> 2) % CO) * X9_ROWB + (f & 3) * 16) = V; }
+        X9_BST(0, bq0) X9_BST(1, bq1) X9_BST(2, bq2)
+#undef X9_BST
+    };
+
+    int k = next_enabled(0), ch = 0;
+    if (k < kvol) {
+        int ia0, ia1, in0n, in1n;
+        load_idx(k, ia0, ia1);
+        int knext = next_enabled(k + 1);
+        load_idx(knext < kvol ? knext : k, in0n, in1n);
+        load_stage(k, 0, ia0, ia1);
+        store_stage(0, ia0, ia1);
+        int k1 = k, ch1 = 1;
+        if (ch1 == nchunks) { ch1 = 0; k1 = knext; }
+        auto fetch_next = [&](int kq, int chq) {         // issue the loads of stage (kq, chq); a new offset rotates the rule-book entries
+            const bool valid = kq < kvol;
+            const bool adv = valid && chq == 0;
+            ia0 = adv ? in0n : ia0;
+            ia1 = adv ? in1n : ia1;
+            if (adv) knext = next_enabled(kq + 1);
+            load_idx(knext < kvol ? knext : k, in0n, in1n);
+            load_stage(valid ? kq : k, valid ? chq : ch, ia0, ia1);
+        };
+        fetch_next(k1, ch1);
+        __syncthreads();
+        const unsigned char* Ap = As + (wave * 32 + (lane & 31)) * X9_ROWB + (lane >> 5) * 16;
+        const unsigned char* Bp = Bs + (lane & 31) * X9_ROWB + (lane >> 5) * 16;
+        while (true) {
+            const int kk = flip ? (kvol - 1 - k) : k;
+            if (kvol > 32 || ((wmask >> kk) & 1u)) {
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    mf_v8bf a[3], b[3];
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) a[p] = *reinterpret_cast<const mf_v8bf*>(Ap + p * X9_APLB + s * 32);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+                        for (int p = 0; p < 3; ++p) b[p] = *reinterpret_cast<const mf_v8bf*>(Bp + p * BPL + t * 32 * X9_ROWB + s * 32);
+                        // the nine partial products, smallest first
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[2], acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[2], acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[1], acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc[t], 0, 0, 0);
+                    }
+                }
+            }
+            if (k1 >= kvol) break;
+            __syncthreads();                             // every wave is done reading this stage
+            store_stage(ch1, ia0, ia1);
+            int k2 = k1, ch2 = ch1 + 1;
+            if (ch2 == nchunks) { ch2 = 0; k2 = knext; }
+            k = k1; ch = ch1;
+            fetch_next(k2, ch2);                         // in flight during the MFMAs of the stage just stored
+            k1 = k2; ch1 = ch2;
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+        const int lr = wave * 32 + (v >> 2) * 8 + (lane >> 5) * 4 + (v & 3);
+        const int pr = prow[lr];
+        if (pr < 0) continue;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int o = t * 32 + (lane & 31);
+            if (o < cout) Y[(int64_t)pr * cout + o] = acc[t][v];
+        }
+    }
+}
+
+extern "C" int gga_sparse_conv_apply_split(const float* x, const int32_t* map, const void* split_weight, const int32_t* perm,
+                                           const uint32_t* rowmask, int64_t n_rows, int kvol, int cin, int cout, int flip,
+                                           float* y, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    GGA_REQUIRE(x && map && split_weight && y, "gga_sparse_conv_apply_split: null pointer argument");
+    GGA_REQUIRE(n_rows >= 1 && kvol >= 1 && cin >= 1 && cout >= 1 && cout <= 128,
+                "gga_sparse_conv_apply_split: bad sizes (rows=%lld kvol=%d cin=%d cout=%d; cout <= 128)", (long long)n_rows,
+                kvol, cin, cout);
+    const dim3 grid((unsigned)((n_rows + X9_TM - 1) / X9_TM)), block(512);
+#define X9_LAUNCH(NT, VEC) hipLaunchKernelGGL((sp_conv_x9_kernel<NT, VEC>), grid, block, 0, stream, x, map, (const uint16_t*)split_weight, perm, rowmask, n_rows, kvol, cin, cout, flip, y)
+    if ((cin & 3) == 0) {
+        switch (mf_nt(cout)) {
+            case 1: X9_LAUNCH(1, true); break;
+            case 2: X9_LAUNCH(2, true); break;
+            default: X9_LAUNCH(4, true); break;
+        }
+    } else {
+        switch (mf_nt(cout)) {
+            case 1: X9_LAUNCH(1, false); break;
+            case 2: X9_LAUNCH(2, false); break;
+            default: X9_LAUNCH(4, false); break;
+        }
+    }
+#undef X9_LAUNCH
+    GGA_CHECK_LAUNCH("sp_conv_x9_kernel");
+    return GGA_OK;
+}
+
 // ------------------------------------------------------------------------------ weight gradient
 // dW[k] (CI x CO) = Xp^T (CI x pairs) * Gp (pairs x CO) over the valid (input row, output row)
 // pairs of offset k, on v_mfma_f32_32x32x2_f32. grid = (2048-row chunks, kvol): a workgroup

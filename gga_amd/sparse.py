@@ -185,12 +185,34 @@ class SparseSequential(SparseModule):
         return x
 
 
-def _pack_weight(w, kvol, cin, cout, transpose):
-    """[kvol,cin,cout] (or [kvol,cout,cin] with ``transpose``) -> MFMA fragment order (gga_sparse_pack_weight)."""
+# fp32 products through three bf16 planes per operand (nine exact partial products on the bf16
+# matrix cores, fp32 accumulation): 1.7x the fp32 MFMA rate at no loss of accuracy
+# (csrc/sparse_conv.hip, tools_dev/micro/bf16x9_probe.hip). False = the native fp32 MFMA kernel.
+SPLIT_BF16 = True
+
+
+def _pack_weight(w, kvol, cin, cout, transpose, split=None):
+    """[kvol,cin,cout] (or [kvol,cout,cin] with ``transpose``) -> the conv kernel's operand order
+    (gga_sparse_pack_weight / gga_sparse_pack_weight_split)."""
     L = _lib.lib()
+    if SPLIT_BF16 if split is None else split:
+        wp = torch.empty(L.gga_sparse_split_weight_bytes(kvol, cin, cout) // 2, dtype=torch.int16, device=w.device)
+        check(L.gga_sparse_pack_weight_split(F._p(w), kvol, cin, cout, transpose, F._p(wp), F._stream()),
+              'gga_sparse_pack_weight_split')
+        return wp
     wp = torch.empty(L.gga_sparse_packed_weight_bytes(kvol, cin, cout) // 4, dtype=torch.float32, device=w.device)
     check(L.gga_sparse_pack_weight(F._p(w), kvol, cin, cout, transpose, F._p(wp), F._stream()), 'gga_sparse_pack_weight')
     return wp
+
+
+def _conv_apply(x, rb, wp, n_rows, kvol, cin, cout, flip, y):
+    L = _lib.lib()
+    if wp.dtype == torch.int16:
+        check(L.gga_sparse_conv_apply_split(F._p(x), F._p(rb.nbr), F._p(wp), F._p(rb.perm), F._p(rb.mask), n_rows,
+                                            kvol, cin, cout, flip, F._p(y), F._stream()), 'gga_sparse_conv_apply_split')
+    else:
+        check(L.gga_sparse_conv_apply(F._p(x), F._p(rb.nbr), F._p(wp), F._p(rb.perm), F._p(rb.mask), n_rows, kvol, cin, cout,
+                                      flip, F._p(y), F._stream()), 'gga_sparse_conv_apply')
 
 
 class _SparseConvFn(torch.autograd.Function):
@@ -203,9 +225,7 @@ class _SparseConvFn(torch.autograd.Function):
         kvol = rb.nbr.shape[0]
         cin, cout = w.shape[-2], w.shape[-1]
         y = torch.empty((n_out, cout), dtype=torch.float32, device=feats.device)
-        wp = _pack_weight(w, kvol, cin, cout, 0)
-        check(_lib.lib().gga_sparse_conv_apply(F._p(feats), F._p(rb.nbr), F._p(wp), F._p(rb.perm), F._p(rb.mask), n_out,
-                                               kvol, cin, cout, 0, F._p(y), F._stream()), 'gga_sparse_conv_apply')
+        _conv_apply(feats, rb, _pack_weight(w, kvol, cin, cout, 0), n_out, kvol, cin, cout, 0, y)
         ctx.save_for_backward(feats, w)
         ctx.rb, ctx.rb_t = rb, rb_t
         return y
@@ -224,8 +244,7 @@ class _SparseConvFn(torch.autograd.Function):
             gx = torch.empty_like(feats)
             wt = _pack_weight(w, kvol, cout, cin, 1)                  # W[k]^T in fragment order
             tb, flip = (rb_t, 0) if rb_t is not None else (rb, 1)     # SubM: transposed map = reversed offsets
-            check(L.gga_sparse_conv_apply(F._p(gy), F._p(tb.nbr), F._p(wt), F._p(tb.perm), F._p(tb.mask), n_in, kvol,
-                                          cout, cin, flip, F._p(gx), F._stream()), 'gga_sparse_conv_apply(bwd data)')
+            _conv_apply(gy, tb, wt, n_in, kvol, cout, cin, flip, gx)
         if ctx.needs_input_grad[1]:
             gw = torch.empty_like(w)
             check(L.gga_sparse_conv_wgrad(F._p(feats), F._p(gy), F._p(rb.nbr), n_out, kvol, cin, cout, F._p(gw),

@@ -258,6 +258,19 @@ int gga_sparse_pack_weight(const float* weight, int kvol, int cin, int cout, int
 int gga_sparse_conv_apply(const float* x, const int32_t* map, const float* packed_weight, const int32_t* perm,
                           const uint32_t* rowmask, int64_t n_rows, int kvol, int cin, int cout, int flip,
                           float* y, void* stream);
+/* The same convolution with fp32 carried by three bfloat16 planes per operand: a fp32 number is
+ * the exact sum of three bf16 numbers, so every product is the sum of nine bf16 products, each
+ * exact in fp32, accumulated in fp32 by v_mfma_f32_32x32x16_bf16 (1.7x the fp32 MFMA rate on
+ * gfx950; error vs float64 not larger than the fp32 MFMA's). gga_sparse_pack_weight_split splits
+ * and lays out the weights: packed[k][chunk][plane][col][32 ch] bf16; arguments as for
+ * gga_sparse_pack_weight / gga_sparse_conv_apply. */
+size_t gga_sparse_split_weight_bytes(int kvol, int cin, int cout);
+int gga_sparse_pack_weight_split(const float* weight, int kvol, int cin, int cout, int transpose, void* packed,
+                                 void* stream);
+int gga_sparse_conv_apply_split(const float* x, const int32_t* map, const void* split_weight, const int32_t* perm,
+                                const uint32_t* rowmask, int64_t n_rows, int kvol, int cin, int cout, int flip,
+                                float* y, void* stream);
+
 /* grad_weight [kvol,cin,cout] = sum_r x[nbr[k][r]]^T grad_out[r]  (zero-filled here) */
 int gga_sparse_conv_wgrad(const float* x, const float* grad_out, const int32_t* nbr, int64_t n_rows,
                           int kvol, int cin, int cout, float* grad_weight, void* stream);

@@ -1,7 +1,7 @@
 """Per-level sparse conv micro-benchmark on the SECOND config: rows, neighbour density, offsets a
 mask-sorted tile computes (128-row and 32-row granularity), kernel time and fp32 rate."""
 import sys, torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gga_amd import Config, build_model, synthetic, _lib
 from gga_amd import functional as F
 from gga_amd.sparse import SparseConvTensor
@@ -15,7 +15,7 @@ def timeit(fn, n=10):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
-cfg = Config.fromfile('configs/gga/gga_kitti_config.py')
+cfg = Config.fromfile(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'configs/gga/gga_kitti_config.py'))
 torch.manual_seed(0)
 model = build_model(cfg.model).to(DEV).train()
 b = synthetic.make_batch(BS, n_points=20000, pc_range=synthetic.RANGE_SECOND)
@@ -43,12 +43,15 @@ with torch.no_grad():
         w = torch.randn(27, C_, C_, device=DEV) * 0.05
         y = torch.empty(lv.n, C_, device=DEV)
         from gga_amd.sparse import _pack_weight
-        wp = _pack_weight(w, 27, C_, C_, 0)
+        wp = _pack_weight(w, 27, C_, C_, 0, split=False)
         feats = x.features.contiguous()
         t = timeit(lambda: L.gga_sparse_conv_apply(F._p(feats), F._p(rb.nbr), F._p(wp), F._p(rb.perm), F._p(rb.mask), lv.n, 27, C_, C_, 0, F._p(y), F._stream()))
-        nbr_l2 = torch.where(rb.nbr >= 0, rb.nbr % 4096, rb.nbr).contiguous()
-        t_l2 = timeit(lambda: L.gga_sparse_conv_apply(F._p(feats), F._p(nbr_l2), F._p(wp), F._p(rb.perm), F._p(rb.mask), lv.n, 27, C_, C_, 0, F._p(y), F._stream()))
-        print(f'   apply with gathers folded onto 4096 rows (L2 resident): {t_l2:.0f} us')
+        fl = lambda k: 2.0 * lv.n * k * C_ * C_
+        wps = _pack_weight(w, 27, C_, C_, 0, split=True)
+        y2 = torch.empty_like(y)
+        t_x9 = timeit(lambda: L.gga_sparse_conv_apply_split(F._p(feats), F._p(rb.nbr), F._p(wps), F._p(rb.perm), F._p(rb.mask), lv.n, 27, C_, C_, 0, F._p(y2), F._stream()))
+        err = float((y2 - y).abs().max() / y.abs().max())
+        print(f'   bf16x9 apply: {t_x9:.0f} us = {fl(u128)/t_x9/1e6:.1f} TF/s computed; max |diff| vs fp32 MFMA / max|y| = {err:.2e}')
         gw = torch.empty_like(w)
         tw = timeit(lambda: L.gga_sparse_conv_wgrad(F._p(feats), F._p(y), F._p(rb.nbr), lv.n, 27, C_, C_, F._p(gw), F._stream()))
         fl = lambda k: 2.0 * lv.n * k * C_ * C_

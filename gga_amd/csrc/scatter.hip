@@ -80,7 +80,8 @@ __global__ __launch_bounds__(256) void scatter_canvas_nchw_v1_kernel(const float
     }
 }
 
-// NCHW canvas, C = 64 / 128: LDS-staged. A 256-thread workgroup owns 1024 consecutive cells of one frame.
+// NCHW canvas, C = 64 (the PointPillars canvas; at C = 128 - SparseEncoder.dense() - the generic kernel
+// above measured 3x faster, 0.32 vs 0.94 ms): LDS-staged. A 256-thread workgroup owns 1024 consecutive cells of one frame.
 //   (1) one 16 B map load per thread (+ reset), occupied cells get a compact tile slot;
 //   (2) the pillar rows of the tile are fetched with fully coalesced 256 B wave loads
 //       (lane = channel) into an LDS tile [slot][C+1];
@@ -261,8 +262,6 @@ static void launch_canvas_nchw(hipStream_t stream, const float* feats, int32_t* 
     const dim3 grid((unsigned)((q + 255) / 256)), block(256);
     if (channels == 64)
         hipLaunchKernelGGL((scatter_canvas_nchw_v2_kernel<64, true>), grid, block, 0, stream, feats, cell_map, cells, q, canvas);
-    else if (channels == 128)
-        hipLaunchKernelGGL((scatter_canvas_nchw_v2_kernel<128, true>), grid, block, 0, stream, feats, cell_map, cells, q, canvas);
     else if (channels % 8 == 0)
         hipLaunchKernelGGL(scatter_canvas_nchw_v1_kernel<8>, grid, block, 0, stream, feats, cell_map, channels, cells, q, canvas);
     else

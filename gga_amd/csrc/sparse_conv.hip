@@ -698,14 +698,24 @@ extern "C" int gga_sparse_pack_weight_split(const float* weight, int kvol, int c
     return GGA_OK;
 }
 
-// Tile: 256 output rows x CO columns per 512-thread workgroup (wave w owns rows 32w..32w+31): at the
-// bf16 rate the weight stage (24 KB for CO = 128) must be shared by more rows than the fp32
-// kernel's 128, or the L2 -> LDS traffic (9.4 TB/s measured with 128-row tiles) becomes the bound.
-#define X9_TM 256
-#define X9_APLB (X9_TM * X9_ROWB)        // bytes per A plane
+// Tile: 128 output rows x CO columns per 256-thread workgroup; wave w owns rows 32w..32w+31.
+// The A operand never touches LDS: lane (r = lane%32, h = lane/32) of a k-step needs the 8
+// channels 16s + 8h .. +7 of ITS OWN row, which are 32 contiguous bytes of the gathered fp32 row -
+// so every lane fetches the 16 floats of its row straight from global memory (one stage ahead),
+// splits them into the three planes in registers and feeds them to the MFMAs. Only the weight
+// stage (24 KB for CO = 128, shared by the 4 waves) goes through LDS, double buffered: one
+// barrier per stage, and a wave's gathers depend on nobody else. Two workgroups per CU.
+// In-kernel timestamps (wall_clock64 per phase and wave) put a stage at ~3.3 us: 1.9 us are the
+// two waves of a SIMD sharing the matrix pipe at full rate (2 x 72 MFMAs x 32 cycles), the rest is
+// address processing of the gathers, the weight copy and the barrier, during which the pipe
+// idles - 57 % busy. A-through-LDS forms, 256-row tiles, rows requested two stages ahead, and
+// alternating gather-first / MFMA-first roles for the two waves of a SIMD all measured the same
+// 2.4-2.5 ms; a third wave per SIMD does not fit the registers (spills: 3.6 ms).
+#define X9_NW 4
+#define X9_TM (32 * X9_NW)
 
 template <int NT, bool VEC>
-__global__ __launch_bounds__(512) void sp_conv_x9_kernel(const float* __restrict__ X, const int32_t* __restrict__ map,
+__global__ __launch_bounds__(64 * X9_NW) void sp_conv_x9_kernel(const float* __restrict__ X, const int32_t* __restrict__ map,
                                                         const uint16_t* __restrict__ Wp,
                                                         const int32_t* __restrict__ perm,
                                                         const uint32_t* __restrict__ rowmask, int64_t n_rows,
@@ -713,30 +723,29 @@ __global__ __launch_bounds__(512) void sp_conv_x9_kernel(const float* __restrict
                                                         float* __restrict__ Y) {
     constexpr int CO = NT * 32;
     constexpr int BPL = CO * X9_ROWB;                     // bytes per B plane
+    constexpr int BSZ = 3 * BPL;                          // bytes per B buffer
     constexpr int BPIECES = 3 * CO * 4;                   // 16-byte pieces of a packed weight stage
-    constexpr int NB = (BPIECES + 511) / 512;             // pieces per thread
-    __shared__ __attribute__((aligned(16))) unsigned char As[3 * X9_APLB];
-    __shared__ __attribute__((aligned(16))) unsigned char Bs[3 * BPL];
-    __shared__ int prow[X9_TM];
-    __shared__ uint32_t wmask_s[8];
+    constexpr int NW = X9_NW, THREADS = 64 * NW;
+    constexpr int NB = (BPIECES + THREADS - 1) / THREADS;   // pieces per thread
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[2 * BSZ];
+    __shared__ uint32_t wmask_s[NW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t r0 = (int64_t)(gridDim.x - 1 - blockIdx.x) * X9_TM;     // most neighbours first
-    if (tid < 8) wmask_s[tid] = 0;
+    const int r = lane & 31, h = lane >> 5;
+    const int64_t r0 = (int64_t)(gridDim.x - 1 - blockIdx.x) * (32 * NW);  // most neighbours first
+    if (tid < NW) wmask_s[tid] = 0;
     __syncthreads();
-    if (tid < X9_TM) {
-        const int64_t r = r0 + tid;
-        int pr = -1;
-        if (r < n_rows) pr = perm ? perm[r] : (int)r;
-        prow[tid] = pr;
+    const int64_t myrow = r0 + wave * 32 + r;
+    const int pr = myrow < n_rows ? (perm ? perm[myrow] : (int)myrow) : -1;
+    {
         uint32_t m = 0;
         if (pr >= 0) m = (rowmask && kvol <= 32) ? rowmask[pr] : 0xFFFFFFFFu;
-        if (m) atomicOr(&wmask_s[tid >> 5], m);
+        if (m && h == 0) atomicOr(&wmask_s[wave], m);
     }
     __syncthreads();
     const uint32_t wmask = __builtin_amdgcn_readfirstlane(wmask_s[wave]);
     uint32_t tm = 0;
 #pragma unroll
-    for (int w = 0; w < 8; ++w) tm |= wmask_s[w];
+    for (int w = 0; w < NW; ++w) tm |= wmask_s[w];
     const uint32_t tmask = __builtin_amdgcn_readfirstlane(tm);
     mf_v16 acc[NT];
 #pragma unroll
@@ -745,142 +754,126 @@ __global__ __launch_bounds__(512) void sp_conv_x9_kernel(const float* __restrict
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
 
     const int nchunks = (cin + MF_TK - 1) / MF_TK;
-    // staging roles. A: thread (ar = tid/4, aq = tid%4) loads float4 #aq and #aq+4 of the 32-channel
-    // chunk for rows ar and ar+128 and splits them into the three planes on their way to LDS.
-    const int ar = tid >> 2, aq = tid & 3;
-    const int p0 = prow[ar], p1 = prow[ar + 128];
     auto enabled = [&](int k) { const int kk = flip ? (kvol - 1 - k) : k; return kvol > 32 || ((tmask >> kk) & 1u); };
     auto next_enabled = [&](int k) { while (k < kvol && !enabled(k)) ++k; return k; };
-    auto load_idx = [&](int k, int& i0, int& i1) {
+    auto load_idx = [&](int k) {
         const int kk = flip ? (kvol - 1 - k) : k;
-        const int32_t* mk = map + (int64_t)kk * n_rows;
-        i0 = mk[p0 >= 0 ? p0 : 0];        // rows past n_rows gather something valid; they are never written
-        i1 = mk[p1 >= 0 ? p1 : 0];
+        return map[(int64_t)kk * n_rows + (pr >= 0 ? pr : 0)];   // rows past n_rows gather something valid; never written
     };
-    float4 a0[2], a1[2];
-    uint4 bq0, bq1, bq2;
-    bq0 = bq1 = bq2 = make_uint4(0, 0, 0, 0);
-    // loads are unconditional (absent neighbours / channels past cin read row 0 / channel 0 and
-    // are zeroed when they are written to LDS), so nothing waits on them before the MFMAs.
-    // (Requesting the rows two stages ahead instead of one did not help: 2.40 vs 2.44 ms.)
-    auto load_stage = [&](int k, int ch, int i0, int i1) {
-        const int c0 = ch * MF_TK;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int cc = c0 + (aq + 4 * h) * 4;
-            if (VEC) {
-                const int co = cc < cin ? cc : 0;
-                a0[h] = *reinterpret_cast<const float4*>(X + (int64_t)(i0 >= 0 ? i0 : 0) * cin + co);
-                a1[h] = *reinterpret_cast<const float4*>(X + (int64_t)(i1 >= 0 ? i1 : 0) * cin + co);
-            } else {
-                float t0[4], t1[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int co = cc + e < cin ? cc + e : 0;
-                    t0[e] = X[(int64_t)(i0 >= 0 ? i0 : 0) * cin + co];
-                    t1[e] = X[(int64_t)(i1 >= 0 ? i1 : 0) * cin + co];
-                }
-                a0[h] = make_float4(t0[0], t0[1], t0[2], t0[3]);
-                a1[h] = make_float4(t1[0], t1[1], t1[2], t1[3]);
-            }
-        }
+    // raw[s][j]: floats 16s + 8h + 4j .. +3 of the lane's row in the 32-channel chunk
+    float4 rn00, rn01, rn10, rn11;                        // next stage, in flight
+    float4 rc00, rc01, rc10, rc11;                        // current stage
+    uint4 bq0, bq1, bq2, bq3, bq4, bq5;
+    bq0 = bq1 = bq2 = bq3 = bq4 = bq5 = make_uint4(0, 0, 0, 0);
+    rn00 = rn01 = rn10 = rn11 = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto ld4 = [&](const float* row, int c) -> float4 {
+        if (VEC) return *reinterpret_cast<const float4*>(row + (c < cin ? c : 0));
+        return make_float4(row[c < cin ? c : 0], row[c + 1 < cin ? c + 1 : 0], row[c + 2 < cin ? c + 2 : 0],
+                           row[c + 3 < cin ? c + 3 : 0]);
+    };
+    // loads are unconditional: an absent neighbour reads row 0 and is zeroed when it is split
+    auto load_a = [&](int ch, int i0) {
+        const float* row = X + (int64_t)(i0 >= 0 ? i0 : 0) * cin;
+        const int c = ch * MF_TK + 8 * h;
+        rn00 = ld4(row, c); rn01 = ld4(row, c + 4); rn10 = ld4(row, c + 16); rn11 = ld4(row, c + 20);
+    };
+    auto load_b = [&](int k, int ch) {
         const uint4* src = reinterpret_cast<const uint4*>(Wp + ((int64_t)k * nchunks + ch) * (3 * CO * 32));
         const int last = BPIECES - 1;
-#define X9_BLD(E, V) if ((E) < NB) V = src[min(tid + 512 * (E), last)];
-        X9_BLD(0, bq0) X9_BLD(1, bq1) X9_BLD(2, bq2)
+#define X9_BLD(E, V) if ((E) < NB) V = src[min(tid + THREADS * (E), last)];
+        X9_BLD(0, bq0) X9_BLD(1, bq1) X9_BLD(2, bq2) X9_BLD(3, bq3) X9_BLD(4, bq4) X9_BLD(5, bq5)
 #undef X9_BLD
     };
-    auto store_a = [&](unsigned char* row, int q, const float4& v, bool ok, int cc) {
-        // channels 4q..4q+3 of one row -> 4 bf16 per plane
-        const float x = ok && cc < cin ? v.x : 0.f, y = ok && cc + 1 < cin ? v.y : 0.f;
-        const float z = ok && cc + 2 < cin ? v.z : 0.f, w = ok && cc + 3 < cin ? v.w : 0.f;
-        uint32_t x1, x2, x3, y1, y2, y3, z1, z2, z3, w1, w2, w3;
-        x9_split(x, x1, x2, x3); x9_split(y, y1, y2, y3); x9_split(z, z1, z2, z3); x9_split(w, w1, w2, w3);
-        *reinterpret_cast<uint2*>(row + q * 8) = make_uint2(x1 | (y1 << 16), z1 | (w1 << 16));
-        *reinterpret_cast<uint2*>(row + X9_APLB + q * 8) = make_uint2(x2 | (y2 << 16), z2 | (w2 << 16));
-        *reinterpret_cast<uint2*>(row + 2 * X9_APLB + q * 8) = make_uint2(x3 | (y3 << 16), z3 | (w3 << 16));
-    };
-    auto store_stage = [&](int ch, int i0, int i1) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int q = aq + 4 * h, cc = ch * MF_TK + 4 * q;
-            store_a(As + ar * X9_ROWB, q, a0[h], i0 >= 0, cc);
-            store_a(As + (ar + 128) * X9_ROWB, q, a1[h], i1 >= 0, cc);
-        }
+    auto store_b = [&](int buf) {
         // piece f of the packed stage: plane f / (CO*4), column (f / 4) % CO, quarter f % 4
-#define X9_BST(E, V) if ((E) < NB) { const int f = tid + 512 * (E); if (f < BPIECES) *reinterpret_cast<uint4*>(Bs + (f / (CO * 4)) * BPL + ((f >> 2) % CO) * X9_ROWB + (f & 3) * 16) = V; }
-        X9_BST(0, bq0) X9_BST(1, bq1) X9_BST(2, bq2)
+#define X9_BST(E, V) if ((E) < NB) { const int f = tid + THREADS * (E); if (f < BPIECES) *reinterpret_cast<uint4*>(Bs + buf * BSZ + (f / (CO * 4)) * BPL + ((f >> 2) % CO) * X9_ROWB + (f & 3) * 16) = V; }
+        X9_BST(0, bq0) X9_BST(1, bq1) X9_BST(2, bq2) X9_BST(3, bq3) X9_BST(4, bq4) X9_BST(5, bq5)
 #undef X9_BST
+    };
+    // 8 floats -> one 8 x bf16 fragment per plane
+    union Frag { mf_v8bf v; uint32_t u[4]; };
+    auto split8 = [&](const float4& lo, const float4& hi, bool ok, int c, Frag& f1, Frag& f2, Frag& f3) {
+        const float e[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float x = ok && c + 2 * j < cin ? e[2 * j] : 0.f, y = ok && c + 2 * j + 1 < cin ? e[2 * j + 1] : 0.f;
+            uint32_t x1, x2, x3, y1, y2, y3;
+            x9_split(x, x1, x2, x3); x9_split(y, y1, y2, y3);
+            f1.u[j] = x1 | (y1 << 16); f2.u[j] = x2 | (y2 << 16); f3.u[j] = x3 | (y3 << 16);
+        }
     };
 
     int k = next_enabled(0), ch = 0;
     if (k < kvol) {
-        int ia0, ia1, in0n, in1n;
-        load_idx(k, ia0, ia1);
+        int ia = load_idx(k);
         int knext = next_enabled(k + 1);
-        load_idx(knext < kvol ? knext : k, in0n, in1n);
-        load_stage(k, 0, ia0, ia1);
-        store_stage(0, ia0, ia1);
+        int ian = load_idx(knext < kvol ? knext : k);
+        load_a(0, ia);
+        load_b(k, 0);
+        store_b(0);
+        rc00 = rn00; rc01 = rn01; rc10 = rn10; rc11 = rn11;
+        int ic = ia;                                     // rule-book entry the current stage was loaded with
         int k1 = k, ch1 = 1;
         if (ch1 == nchunks) { ch1 = 0; k1 = knext; }
-        auto fetch_next = [&](int kq, int chq) {         // issue the loads of stage (kq, chq); a new offset rotates the rule-book entries
-            const bool valid = kq < kvol;
-            const bool adv = valid && chq == 0;
-            ia0 = adv ? in0n : ia0;
-            ia1 = adv ? in1n : ia1;
-            if (adv) knext = next_enabled(kq + 1);
-            load_idx(knext < kvol ? knext : k, in0n, in1n);
-            load_stage(valid ? kq : k, valid ? chq : ch, ia0, ia1);
-        };
-        fetch_next(k1, ch1);
         __syncthreads();
-        const unsigned char* Ap = As + (wave * 32 + (lane & 31)) * X9_ROWB + (lane >> 5) * 16;
-        const unsigned char* Bp = Bs + (lane & 31) * X9_ROWB + (lane >> 5) * 16;
+        int buf = 0;
         while (true) {
+            // request stage (k1, ch1): rows into the rn registers, weights into bq
+            const bool valid1 = k1 < kvol;
+            const bool adv = valid1 && ch1 == 0;
+            ia = adv ? ian : ia;
+            if (adv) knext = next_enabled(k1 + 1);
+            ian = load_idx(knext < kvol ? knext : k);
+            load_a(valid1 ? ch1 : ch, ia);
+            load_b(valid1 ? k1 : k, valid1 ? ch1 : ch);
             const int kk = flip ? (kvol - 1 - k) : k;
             if (kvol > 32 || ((wmask >> kk) & 1u)) {
+                Frag a0[3], a1[3];
+                const int c = ch * MF_TK + 8 * h;
+                split8(rc00, rc01, ic >= 0, c, a0[0], a0[1], a0[2]);
+                split8(rc10, rc11, ic >= 0, c + 16, a1[0], a1[1], a1[2]);
+                const unsigned char* Bp = Bs + buf * BSZ + r * X9_ROWB + h * 16;
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    mf_v8bf a[3], b[3];
+                    const Frag* a = s ? a1 : a0;
+                    mf_v8bf b[NT][3];
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) a[p] = *reinterpret_cast<const mf_v8bf*>(Ap + p * X9_APLB + s * 32);
+                    for (int t = 0; t < NT; ++t)
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) {
-#pragma unroll
-                        for (int p = 0; p < 3; ++p) b[p] = *reinterpret_cast<const mf_v8bf*>(Bp + p * BPL + t * 32 * X9_ROWB + s * 32);
-                        // the nine partial products, smallest first
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[2], acc[t], 0, 0, 0);
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[2], acc[t], 0, 0, 0);
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[1], acc[t], 0, 0, 0);
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc[t], 0, 0, 0);
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc[t], 0, 0, 0);
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc[t], 0, 0, 0);
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc[t], 0, 0, 0);
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc[t], 0, 0, 0);
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc[t], 0, 0, 0);
-                    }
+                        for (int p = 0; p < 3; ++p) b[t][p] = *reinterpret_cast<const mf_v8bf*>(Bp + p * BPL + t * 32 * X9_ROWB + s * 32);
+                    // the nine partial products, smallest first; the column tiles are the inner loop so
+                    // that consecutive MFMAs never wait for each other's accumulator
+#define X9_MM(PA, PB) _Pragma("unroll") for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA].v, b[t][PB], acc[t], 0, 0, 0);
+                    X9_MM(2, 2) X9_MM(1, 2) X9_MM(2, 1) X9_MM(0, 2) X9_MM(1, 1) X9_MM(2, 0) X9_MM(0, 1) X9_MM(1, 0) X9_MM(0, 0)
+#undef X9_MM
                 }
             }
-            if (k1 >= kvol) break;
-            __syncthreads();                             // every wave is done reading this stage
-            store_stage(ch1, ia0, ia1);
-            int k2 = k1, ch2 = ch1 + 1;
-            if (ch2 == nchunks) { ch2 = 0; k2 = knext; }
-            k = k1; ch = ch1;
-            fetch_next(k2, ch2);                         // in flight during the MFMAs of the stage just stored
-            k1 = k2; ch1 = ch2;
+            if (!valid1) break;
+            store_b(buf ^ 1);                            // last read before the previous barrier
+            rc00 = rn00; rc01 = rn01; rc10 = rn10; rc11 = rn11;
+            ic = ia;
             __syncthreads();
+            buf ^= 1;
+            k = k1; ch = ch1;
+            ++ch1;
+            if (ch1 == nchunks) { ch1 = 0; k1 = knext; }
         }
     }
+    // D layout of 32x32x16: register v of lane l holds row (v/4)*8 + (l/32)*4 + v%4, column l%32;
+    // the row -> output row table goes through LDS (each lane knows only its own row)
+    __syncthreads();
+    int* prow = reinterpret_cast<int*>(Bs);
+    if (h == 0) prow[wave * 32 + r] = pr;
+    __syncthreads();
 #pragma unroll
     for (int v = 0; v < 16; ++v) {
-        const int lr = wave * 32 + (v >> 2) * 8 + (lane >> 5) * 4 + (v & 3);
-        const int pr = prow[lr];
-        if (pr < 0) continue;
+        const int lr = wave * 32 + (v >> 2) * 8 + h * 4 + (v & 3);
+        const int po = prow[lr];
+        if (po < 0) continue;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const int o = t * 32 + (lane & 31);
-            if (o < cout) Y[(int64_t)pr * cout + o] = acc[t][v];
+            const int o = t * 32 + r;
+            if (o < cout) Y[(int64_t)po * cout + o] = acc[t][v];
         }
     }
 }
@@ -893,7 +886,7 @@ extern "C" int gga_sparse_conv_apply_split(const float* x, const int32_t* map, c
     GGA_REQUIRE(n_rows >= 1 && kvol >= 1 && cin >= 1 && cout >= 1 && cout <= 128,
                 "gga_sparse_conv_apply_split: bad sizes (rows=%lld kvol=%d cin=%d cout=%d; cout <= 128)", (long long)n_rows,
                 kvol, cin, cout);
-    const dim3 grid((unsigned)((n_rows + X9_TM - 1) / X9_TM)), block(512);
+    const dim3 grid((unsigned)((n_rows + X9_TM - 1) / X9_TM)), block(64 * X9_NW);
 #define X9_LAUNCH(NT, VEC) hipLaunchKernelGGL((sp_conv_x9_kernel<NT, VEC>), grid, block, 0, stream, x, map, (const uint16_t*)split_weight, perm, rowmask, n_rows, kvol, cin, cout, flip, y)
     if ((cin & 3) == 0) {
         switch (mf_nt(cout)) {

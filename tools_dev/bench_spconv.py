@@ -51,6 +51,12 @@ with torch.no_grad():
         y2 = torch.empty_like(y)
         t_x9 = timeit(lambda: L.gga_sparse_conv_apply_split(F._p(feats), F._p(rb.nbr), F._p(wps), F._p(rb.perm), F._p(rb.mask), lv.n, 27, C_, C_, 0, F._p(y2), F._stream()))
         err = float((y2 - y).abs().max() / y.abs().max())
+        for nsub in (16384, 65536):
+            sel = rb.perm.long()[-nsub:]
+            nbr_s = rb.nbr[:, sel].contiguous(); mask_s = rb.mask[sel].contiguous(); ys = torch.empty(nsub, C_, device=DEV)
+            t_s = timeit(lambda: L.gga_sparse_conv_apply_split(F._p(feats), F._p(nbr_s), F._p(wps), None, F._p(mask_s), nsub, 27, C_, C_, 0, F._p(ys), F._stream()))
+            pcs = float(sum(((mask_s.long() >> kb) & 1) for kb in range(27)).float().mean())
+            print(f'   bf16x9 on the last {nsub} rows of the mask order ({nsub // 256} tiles, {pcs:.1f} offsets/row): {t_s:.0f} us')
         print(f'   bf16x9 apply: {t_x9:.0f} us = {fl(u128)/t_x9/1e6:.1f} TF/s computed; max |diff| vs fp32 MFMA / max|y| = {err:.2e}')
         gw = torch.empty_like(w)
         tw = timeit(lambda: L.gga_sparse_conv_wgrad(F._p(feats), F._p(y), F._p(rb.nbr), lv.n, 27, C_, C_, F._p(gw), F._stream()))

@@ -399,3 +399,47 @@ def make_frustum_case(seed, n=2500):
     boxes = np.array([[300.0, 120.0, 520.0, 260.0], [0.0, 0.0, 1241.0, 374.0], [900.0, 150.0, 1241.0, 374.0],
                       [600.5, 170.25, 640.75, 200.5], [-1.0, -1.0, -1.0, -1.0]])
     return pts, boxes
+
+
+def make_rga_scene(seed, n_ground=1200, n_clutter=500):
+    """A KITTI-shaped frame for the offline label generator: velodyne points [N,4] f32 (ground plane,
+    a few objects standing on it, clutter), KITTI annotations in camera coordinates (DontCare
+    entries last), calibration and image shape."""
+    rng = np.random.default_rng(seed)
+    calib = {k: v.copy() for k, v in KITTI_CALIB.items()}
+    l2c = calib['R0_rect'] @ calib['Tr_velo_to_cam']
+    gz = -1.72
+    gx, gy = rng.uniform(3, 60, n_ground), rng.uniform(-25, 25, n_ground)
+    pts = [np.stack([gx, gy, gz + 0.002 * gx + rng.normal(0, 0.02, n_ground)], 1)]
+    sizes = {'Car': (3.9, 1.56, 1.6), 'Pedestrian': (0.8, 1.73, 0.6), 'Cyclist': (1.76, 1.73, 0.6)}     # l, h, w
+    names, loc, dims, rot, npts = [], [], [], [], []
+    n_obj = int(rng.integers(3, 6))
+    for i in range(n_obj):
+        cls = ['Car', 'Pedestrian', 'Cyclist'][int(rng.integers(0, 3))] if i else 'Car'
+        l, h, w = [s * rng.uniform(0.9, 1.1) for s in sizes[cls]]
+        cx, cy = rng.uniform(8, 35), rng.uniform(-8, 8)
+        if i == 1:
+            cx, cy = 10.0, 8.4 * (1 if seed % 2 else -1)                 # cut by the image border -> truncated-object branch
+        yaw = rng.uniform(-np.pi, np.pi)
+        n = int(rng.integers(60, 220)) if i != 2 else 0                 # one object without points
+        u = np.stack([rng.uniform(-l / 2, l / 2, n), rng.uniform(-w / 2, w / 2, n), rng.uniform(0.15, h, n)], 1)
+        c, s = np.cos(yaw), np.sin(yaw)
+        pts.append(np.stack([cx + c * u[:, 0] - s * u[:, 1], cy + s * u[:, 0] + c * u[:, 1], gz + u[:, 2]], 1))
+        cam = l2c @ np.array([cx, cy, gz, 1.0])
+        names.append(cls); loc.append(cam[:3]); dims.append([l, h, w]); rot.append(-yaw - np.pi / 2); npts.append(n)
+    pts.append(np.stack([rng.uniform(3, 60, n_clutter), rng.uniform(-25, 25, n_clutter), rng.uniform(gz + 0.3, 1.5, n_clutter)], 1))
+    pts.append(np.stack([rng.uniform(-20, 0, 80), rng.uniform(-25, 25, 80), rng.uniform(gz, 1.0, 80)], 1))    # behind the camera
+    xyz = np.concatenate(pts)
+    xyz = xyz[rng.permutation(len(xyz))]
+    points_v = np.concatenate([xyz, rng.uniform(0, 1, (len(xyz), 1))], 1).astype(np.float32)
+    n_dc = int(rng.integers(1, 3))
+    n = n_obj + n_dc
+    annos = dict(
+        name=np.array(names + ['DontCare'] * n_dc), truncated=np.zeros(n), occluded=np.zeros(n, np.int64),
+        alpha=np.zeros(n), bbox=np.zeros((n, 4)),
+        dimensions=np.concatenate([np.array(dims), -np.ones((n_dc, 3))]),
+        location=np.concatenate([np.array(loc), -1000 * np.ones((n_dc, 3))]),
+        rotation_y=np.concatenate([np.array(rot), -10 * np.ones(n_dc)]), score=np.zeros(n),
+        index=np.arange(n, dtype=np.int32), group_ids=np.arange(n, dtype=np.int32),
+        difficulty=np.zeros(n, np.int32), num_points_in_gt=np.array(npts + [-1] * n_dc, dtype=np.int32))
+    return points_v, calib, annos, (375, 1242)

@@ -638,6 +638,57 @@ def golden_label_gen(ref):
     np.savez_compressed(os.path.join(OUT, 'label_gen.npz'), **out)
 
 
+RGA_SEEDS = (71, 72, 73)
+RGA_KEYS = ('GGA_boxes_img', 'GGA_mask_depth', 'GGA_mask2d', 'GGA_mask_boundary', 'GGA_bdry_masks', 'GGA_mask_valid',
+            'GGA_init_pseudo_label', 'GGA_num_points_in_box2d')
+
+
+def golden_rga(ref):
+    """_calculate_rga of the reference (tools/data_converter/kitti_converter_gga.py:214-517) on seeded
+    frames. Third-party pieces absent here are stood in for by this repo's restatements
+    (nuscenes view_points, the shapely-based post_process_coords) and cv2.imread by an empty image of
+    the frame's shape, so the 2D-box labels are NOT independent evidence; everything downstream of
+    them (depth ordering, the region-growing sequence, truncated-object handling, the pseudo 3D box
+    fit, the DontCare padding) is the reference's own code."""
+    import tempfile
+    from gga_amd import label_gen as LG        # host-side restatements only (no device work at import)
+    bo = sys.modules.get('mmdet3d.core.bbox.box_np_ops') or load('mmdet3d.core.bbox.box_np_ops', 'mmdet3d/core/bbox/box_np_ops.py')
+    cb = sys.modules['mmdet3d.core.bbox']
+    cb.box_np_ops, cb.points_cam2img = bo, None
+    _mod('nuscenes'); _mod('nuscenes.utils'); _mod('nuscenes.utils.geometry_utils', view_points=LG.view_points)
+    _mod('tools'); _mod('tools.data_converter')
+    _mod('tools.data_converter.kitti_data_utils', WaymoInfoGatherer=None, get_kitti_image_info=None)
+    _mod('tools.data_converter.nuscenes_converter', post_process_coords=LG.post_process_coords)
+    shape_holder = {}
+    _mod('cv2', imread=lambda path: np.zeros(shape_holder['shape'] + (3,), np.uint8), cvtColor=lambda img, code: img,
+         COLOR_BGR2RGB=4)
+    load('tools.data_converter.utils_gga', 'tools/data_converter/utils_gga.py')
+    captured = {}
+    sys.modules['mmcv'].dump = lambda obj, filename: captured.update(obj=obj)
+    conv = load('tools.data_converter.kitti_converter_gga', 'tools/data_converter/kitti_converter_gga.py')
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for seed in RGA_SEEDS:
+            pts, calib, annos, shape = synthetic.make_rga_scene(seed)
+            vpath = os.path.join(tmp, f'{seed}.bin')
+            pts.tofile(vpath)
+            shape_holder['shape'] = shape
+            info = dict(point_cloud=dict(velodyne_path=vpath, num_features=4),
+                        image=dict(image_idx=seed, image_shape=np.array(shape, np.int32), image_path='x.png'),
+                        calib=calib, annos=annos)
+            np.random.seed(seed)
+            conv._calculate_rga(tmp, info, relative_path=False)
+            a = captured['obj']['annos']
+            for k in RGA_KEYS:
+                out[f'{seed}.{k}'] = np.asarray(a[k])
+            out[f'{seed}.in_box_len'] = np.array([len(p) for p in a['GGA_in_box_points']], np.int64)
+            cat = [np.asarray(p) for p in a['GGA_in_box_points'] if len(p)]
+            out[f'{seed}.in_box_cat'] = np.concatenate(cat, 0) if cat else np.zeros((0, 4))
+            print(f'  rga[{seed}]: {len(a["name"])} annotations, in-box points {out[f"{seed}.in_box_len"].tolist()}, '
+                  f'valid {a["GGA_mask_valid"].astype(int).tolist()}, boundary {a["GGA_mask_boundary"].astype(int).tolist()}')
+    np.savez_compressed(os.path.join(OUT, 'rga.npz'), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = import_reference()
@@ -651,6 +702,7 @@ def main():
     golden_pseudo_match(ref)
     golden_pipeline(ref)
     golden_label_gen(ref)
+    golden_rga(ref)
     for f in sorted(os.listdir(OUT)):
         print(f'{f}: {os.path.getsize(os.path.join(OUT, f)) / 1024:.1f} KiB')
 

@@ -17,6 +17,11 @@ float64 in the reference's operation order, so the masks are bit-identical to nu
   (so equal seeds give equal planes), all candidates of a round are scored in one launch.
 * ``fit_pseudo_box(cluster, ground_plane_height)`` — the initial pseudo 3D box of
   kitti_converter_gga.py:426-487 (minimum-area bounding rectangle over 36 headings).
+* ``calculate_rga(points_v, calib, annos, image_shape)`` — the whole per-frame generator
+  ``_calculate_rga`` as a function of the loaded frame (no file handling); ``box2d_labels``,
+  ``view_points``, ``post_process_coords``, ``center_to_corner_box3d`` are its host-side pieces.
+  Note that the reference's ``rotation_3d_in_axis`` computes numpy inputs in float32 (its
+  ``array_converter``); ``_rotate_bev`` / ``_rotate3d`` reproduce that.
 """
 import ctypes as C
 

@@ -7,6 +7,19 @@ run as hand-written HIP kernels for gfx950 behind a C-ABI shared library
 """
 __version__ = '0.1.0'
 
+import os as _os
+
+# The dense 2D convolutions of SECOND / SECONDFPN / the CenterHead branches run on MIOpen. On a
+# machine without a MIOpen user database the first call of every convolution shape times all
+# applicable solvers, including MIOpen's naive reference kernels (0.1-1 s per launch at KITTI
+# sizes, 8 launches each): 89 s before the first train step finishes versus 9 s without them,
+# with the same solvers chosen and the same step time (tools_dev/miopen_env.sh). They never win,
+# so they are left out of the search unless the user has set the variables already. Must happen
+# before MIOpen's first use; MIOPEN_FIND_MODE is left alone (mode 2 picks the naive kernels).
+for _k in ('MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_FWD', 'MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_BWD',
+           'MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_WRW'):
+    _os.environ.setdefault(_k, '0')
+
 from . import registry  # noqa: E402,F401
 from . import losses, bbox_coders, voxel_encoders, middle_encoders, sparse, sparse_encoder, backbones, dense_heads, detectors  # noqa: E402,F401
 from .config import Config  # noqa: E402,F401

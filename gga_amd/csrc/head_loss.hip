@@ -349,24 +349,32 @@ __global__ __launch_bounds__(256) void pal_kernel(const float* __restrict__ pred
     }
 }
 
-__global__ __launch_bounds__(256) void box_reduce_kernel(const float* __restrict__ part,
-                                                        const uint8_t* __restrict__ mask, gga_loss_params prm,
-                                                        float* __restrict__ losses) {
+__global__ __launch_bounds__(1024) void box_reduce_kernel(const float* __restrict__ part,
+                                                         const uint8_t* __restrict__ mask, gga_loss_params prm,
+                                                         float* __restrict__ losses) {
+    // one pass: every thread carries the five partial sums, wave shuffle, then a fixed-order fold
     const int n = prm.B * prm.K;
     const float avg = block_avg_factor(mask, n);
-    __shared__ double sh[4];
-    const float wts[5] = { prm.w_bpl, prm.w_srl, prm.w_pal, prm.w_pal, prm.w_pal };
+    __shared__ double sh[GGA_L_NUM][16];
+    double acc[GGA_L_NUM];
+#pragma unroll
+    for (int t = 0; t < GGA_L_NUM; ++t) acc[t] = 0.0;
+    for (int i = threadIdx.x; i < n; i += 1024) {
+#pragma unroll
+        for (int t = 0; t < GGA_L_NUM; ++t) acc[t] += (double)part[t * n + i];
+    }
+#pragma unroll
     for (int t = 0; t < GGA_L_NUM; ++t) {
-        double acc = 0.0;
-        for (int i = threadIdx.x; i < n; i += 256) acc += (double)part[t * n + i];
-        acc = wave_sum(acc);
-        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const float tot = (float)((sh[0] + sh[1]) + (sh[2] + sh[3]));
-            losses[t] = (prm.l1_loss_weight * (tot / avg)) * wts[t];   // L1Loss then the head multiplier
-        }
-        __syncthreads();
+        const double a = wave_sum(acc[t]);
+        if ((threadIdx.x & 63) == 0) sh[t][threadIdx.x >> 6] = a;
+    }
+    __syncthreads();
+    if (threadIdx.x < GGA_L_NUM) {
+        const int t = threadIdx.x;
+        double tot = 0.0;
+        for (int w = 0; w < 16; ++w) tot += sh[t][w];
+        const float wt = t == 0 ? prm.w_bpl : (t == 1 ? prm.w_srl : prm.w_pal);
+        losses[t] = (prm.l1_loss_weight * ((float)tot / avg)) * wt;   // L1Loss then the head multiplier
     }
 }
 
@@ -417,7 +425,7 @@ extern "C" int gga_box_losses_fwd(const float* pred, const int64_t* ind, const u
                            (const float2*)ibp_xy, ibp_offsets, ibp_slot, n_ibp_obj, *prm, box_out, grad_pred, part);
         GGA_CHECK_LAUNCH("pal_kernel");
     }
-    hipLaunchKernelGGL(box_reduce_kernel, dim3(1), dim3(256), 0, stream, part, mask, *prm, losses);
+    hipLaunchKernelGGL(box_reduce_kernel, dim3(1), dim3(1024), 0, stream, part, mask, *prm, losses);
     GGA_CHECK_LAUNCH("box_reduce_kernel");
     return GGA_OK;
 }

@@ -113,7 +113,8 @@ __global__ __launch_bounds__(64) void pfn_stats_kernel(const double* __restrict_
     if (training) {
         for (int i = c; i < PFN_NM; i += 64) {
             double s = 0.0;
-            for (int b = 0; b < nblocks; ++b) s += partials[(int64_t)b * PFN_NM + i];   // fixed order
+#pragma unroll 16
+            for (int b = 0; b < nblocks; ++b) s += partials[(int64_t)b * PFN_NM + i];   // fixed order, loads batched
             S[i] = s;
         }
         __syncthreads();
@@ -270,6 +271,7 @@ __global__ __launch_bounds__(768) void pfn_bwd_final_kernel(const float* __restr
     {
         const int t = threadIdx.x;
         double s = 0.0;
+#pragma unroll 16
         for (int b = 0; b < nblocks; ++b) s += (double)partials[(int64_t)b * PFN_BW * PFN_C + t];
         red[t / PFN_C][t % PFN_C] = s;
     }

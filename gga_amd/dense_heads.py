@@ -259,7 +259,7 @@ class CenterHead_GGA(nn.Module):
         objs = pk['objs']
         hm = F.heatmap_splat(objs, int(map_base[-1]), fh, fw, dev,
                              max_radius=max(16, int(objs[:, 3].max()) if len(objs) else 0))
-        up = {k: torch.from_numpy(pk[k]).to(dev, non_blocking=True)
+        up = {k: F.upload(pk[k], dev)
               for k in ('anno_box', 'ind', 'mask', 'lidar2img', 'bound_mask', 'ibp_xy', 'ibp_offsets', 'ibp_slot')}
         heatmaps, ibp_points = [], []
         obj_base = np.concatenate([[0], np.cumsum(pk['task_nobj'])])

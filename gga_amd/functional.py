@@ -113,6 +113,19 @@ class PreparedPoints:
         return [self.points[int(o):int(o) + k] for o, k in zip(self.capacity_offsets[:-1], n)]
 
 
+def upload(host, device):
+    """Host array / CPU tensor -> device without draining the launch queue: a copy from pageable
+    memory blocks the host until everything queued before it has run (the loss targets are
+    uploaded after the forward pass was queued, so the host lost its lead exactly where the
+    many small loss kernels start); staged through the caching pinned allocator the copy is
+    just another stream operation."""
+    t = torch.from_numpy(host) if isinstance(host, np.ndarray) else host
+    dev = torch.device(device)
+    if dev.type == 'cuda' and t.device.type == 'cpu' and t.numel():
+        t = t.pin_memory()
+    return t.to(dev, non_blocking=True)
+
+
 def _cat_rows(parts, ndim, dev, dtype=torch.float32):
     parts = [torch.as_tensor(p, dtype=dtype).reshape(-1, ndim) for p in parts]
     offs = np.zeros(len(parts) + 1, np.int64)
@@ -323,7 +336,7 @@ def heatmap_splat(objs, n_maps, H, W, device, max_radius=64):
     if objs.numel() and int(objs[:, 3].max()) > max_radius:
         max_radius = int(objs[:, 3].max())
     table, offs = gaussian_patch_table(max_radius, device)
-    objs = objs.to(device, non_blocking=True).contiguous()
+    objs = upload(objs.contiguous(), device)
     check(_lib.lib().gga_heatmap_splat(_p(hm), n_maps, H, W, _p(objs), objs.shape[0], _p(table), _p(offs),
                                        max_radius, _stream()), 'gga_heatmap_splat')
     return hm

@@ -11,7 +11,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libgga_hip.so')
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _lib = None
 
@@ -58,6 +58,7 @@ SIGNATURES = {
     'gga_pillar_scatter_map_bytes': (sz, [i32, i32, i32]),
     'gga_pillar_scatter_fwd': (i32, [vp, vp, i64, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp]),
     'gga_pillar_scatter_bwd': (i32, [vp, vp, i64, vp, i32, i32, i32, i32, i32, vp, vp]),
+    'gga_pillar_conv_map': (i32, [vp, i64, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
     'gga_pillar_scatter_timing_begin': (i32, [i32]),
     'gga_pillar_scatter_timing_collect': (i32, [vp, i32]),
     'gga_sparse_index_bytes': (sz, [i64]),

@@ -4,6 +4,7 @@ import numpy as np
 import torch
 from torch import nn
 
+from . import pillar_conv
 from .cnn import build_conv_layer, build_norm_layer, build_upsample_layer, kaiming_init, run_conv_bn_relu
 from .registry import BACKBONES, NECKS
 
@@ -25,6 +26,7 @@ class SECOND(nn.Module):
                           build_norm_layer(norm_cfg, out_channels[i])[1], nn.ReLU(inplace=True)]
             blocks.append(nn.Sequential(*block))
         self.blocks = nn.ModuleList(blocks)
+        self.pillar_backward = True     # see pillar_conv.py; False = dense backward through the canvas
         self.init_weights()
 
     def init_weights(self):
@@ -34,8 +36,12 @@ class SECOND(nn.Module):
 
     def forward(self, x):
         outs = []
-        for blk in self.blocks:
-            x = run_conv_bn_relu(blk, x)
+        for i, blk in enumerate(self.blocks):
+            if i == 0 and self.pillar_backward and pillar_conv.eligible(blk[0], x):
+                # same forward; the backward of this convolution runs on the occupied cells only
+                x = run_conv_bn_relu(list(blk)[1:], pillar_conv.pillar_conv2d(x, blk[0]))
+            else:
+                x = run_conv_bn_relu(blk, x)
             outs.append(x)
         return tuple(outs)
 

@@ -383,3 +383,44 @@ extern "C" int gga_pillar_scatter_bwd(const float* grad_canvas, const int32_t* c
 
 // Bench-only: times the two forward kernels separately with HIP events on `stream`
 // (SYNCHRONISES; never call it from a captured or latency-sensitive path).
+
+// ----------------------------------------------------------------------------- pillar conv map
+// Gather map of a dense 2D convolution restricted to the occupied cells of the canvas: for pillar
+// r at (b, y, x) and kernel tap (ky, kx) the output cell that read it, as a row of the NHWC
+// output [batch*oh*ow, C], or -1. One thread per (tap, pillar); rows past *num_valid get -1.
+__global__ __launch_bounds__(256) void pillar_conv_map_kernel(const int4* __restrict__ coors, int64_t m,
+                                                             const int32_t* __restrict__ num_valid, int kh, int kw,
+                                                             int sh, int sw, int ph, int pw, int oh, int ow,
+                                                             int32_t* __restrict__ map) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= m) return;
+    const int k = blockIdx.y;
+    const int ky = k / kw, kx = k - ky * kw;
+    int32_t v = -1;
+    if (!num_valid || r < *num_valid) {
+        const int4 c = coors[r];                    // (b, z, y, x)
+        const int ty = c.z + ph - ky, tx = c.w + pw - kx;
+        if (ty >= 0 && tx >= 0 && ty % sh == 0 && tx % sw == 0) {
+            const int oy = ty / sh, ox = tx / sw;
+            if (oy < oh && ox < ow) v = (c.x * oh + oy) * ow + ox;
+        }
+    }
+    map[(int64_t)k * m + r] = v;
+}
+
+extern "C" int gga_pillar_conv_map(const int32_t* coors, int64_t m, const int32_t* num_valid, int batch, int ny, int nx,
+                                   int kh, int kw, int stride_h, int stride_w, int pad_h, int pad_w, int32_t* map,
+                                   void* stream) {
+    GGA_REQUIRE(coors && map, "gga_pillar_conv_map: null pointer argument");
+    GGA_REQUIRE(m >= 0 && batch >= 1 && ny >= 1 && nx >= 1 && kh >= 1 && kw >= 1 && kh * kw <= 65535 && stride_h >= 1 &&
+                    stride_w >= 1 && pad_h >= 0 && pad_w >= 0,
+                "gga_pillar_conv_map: bad sizes");
+    const int oh = (ny + 2 * pad_h - kh) / stride_h + 1, ow = (nx + 2 * pad_w - kw) / stride_w + 1;
+    GGA_REQUIRE(oh >= 1 && ow >= 1 && (int64_t)batch * oh * ow < 2147483647ll, "gga_pillar_conv_map: output %dx%d", oh, ow);
+    if (m == 0) return GGA_OK;
+    hipLaunchKernelGGL(pillar_conv_map_kernel, dim3((unsigned)((m + 255) / 256), kh * kw), dim3(256), 0,
+                       (hipStream_t)stream, (const int4*)coors, m, num_valid, kh, kw, stride_h, stride_w, pad_h, pad_w,
+                       oh, ow, map);
+    GGA_CHECK_LAUNCH("pillar_conv_map_kernel");
+    return GGA_OK;
+}

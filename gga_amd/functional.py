@@ -301,8 +301,13 @@ def pillar_scatter(feats, coors, batch_size, ny, nx, channels_last=False, num_va
     """[M,C] pillar features + coors (b,z,y,x) -> dense [B,C,ny,nx] canvas. ``unique``: the caller
     guarantees distinct (b,y,x) (voxelizer output, sparse sites); otherwise the highest row of a
     duplicated cell wins."""
-    return _PillarScatter.apply(feats, coors, int(batch_size), int(ny), int(nx),
-                                LAYOUT_NHWC if channels_last else LAYOUT_NCHW, num_valid, bool(unique))
+    canvas = _PillarScatter.apply(feats, coors, int(batch_size), int(ny), int(nx),
+                                  LAYOUT_NHWC if channels_last else LAYOUT_NCHW, num_valid, bool(unique))
+    if unique and channels_last:
+        # lets the consumer's backward work on the pillars instead of the canvas (pillar_conv.py)
+        from .pillar_conv import PillarSupport
+        canvas.pillar_support = PillarSupport(feats, coors, num_valid)
+    return canvas
 
 
 # ----------------------------------------------------------------------------- a6/a7

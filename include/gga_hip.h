@@ -188,6 +188,19 @@ int gga_pillar_scatter_bwd(const float* grad_canvas, const int32_t* coors, int64
                            const int32_t* num_valid, int batch, int channels, int ny, int nx,
                            int layout, float* grad_feats, void* stream);
 
+/* Gather map of a dense 2D convolution (kernel kh x kw, given stride / zero padding, dilation 1)
+ * over the canvas, restricted to its occupied cells: map[k = ky*kw + kx][r] = row of the NHWC
+ * convolution output [batch*oh*ow, C] that read pillar r through tap (ky, kx), or -1
+ * (oh = (ny + 2*pad_h - kh)/stride_h + 1, likewise ow; rows >= *num_valid get -1). With it the
+ * backward of the first SECOND convolution (second.py:49-57 applied to the canvas of
+ * pillar_scatter.py:58-102) runs on the pillars only: its input gradient is needed just at the
+ * occupied cells (all the scatter's backward reads) and its weight gradient only sees non-zero
+ * input there - gga_sparse_conv_apply[_split] / gga_sparse_conv_wgrad with this map, the
+ * output gradient as `x` (rows = output cells) and the pillar features as the other operand. */
+int gga_pillar_conv_map(const int32_t* coors, int64_t m, const int32_t* num_valid, int batch, int ny, int nx,
+                        int kh, int kw, int stride_h, int stride_w, int pad_h, int pad_w, int32_t* map,
+                        void* stream);
+
 /* Bench-only, in-place timing of the scatter inside real steps: after
  * gga_pillar_scatter_timing_begin(n) the next n gga_pillar_scatter_fwd calls bracket their
  * kernels (NHWC: fill [+ map] + rows, i.e. the whole op; NCHW: the canvas kernel) with HIP events

@@ -408,3 +408,84 @@ def test_head_output_conv_vs_torch(cout, bias):
     # NCHW input falls back to the framework convolution
     z = F.head_conv3x3(x.contiguous(), conv)
     torch.testing.assert_close(z, ref.detach(), rtol=1e-4, atol=1e-4)
+
+
+# ----------------------------------------------------------------------------- first conv on the canvas
+def _pillar_case(B, ny, nx, M, C, seed):
+    g = torch.Generator().manual_seed(seed)
+    coors = []
+    for b in range(B):
+        cells = torch.randperm(ny * nx, generator=g)[:M]
+        coors.append(torch.stack([torch.full((M,), b), torch.zeros(M, dtype=torch.long), cells // nx, cells % nx], 1))
+    return torch.cat(coors).int().to(DEV), torch.randn(B * M, C, generator=g).to(DEV)
+
+
+@pytest.mark.parametrize('k,stride,pad,cin,cout,ny,nx', [(3, 2, 1, 64, 64, 62, 54), (3, 1, 1, 64, 128, 33, 40),
+                                                        (3, 2, 1, 32, 64, 31, 29), (1, 1, 0, 64, 64, 16, 24),
+                                                        (5, 3, 2, 16, 32, 40, 37)])
+def test_pillar_conv_map_and_backward(k, stride, pad, cin, cout, ny, nx):
+    """The pillar-restricted backward of conv(canvas) equals the dense autograd backward: the map
+    against index arithmetic in numpy (bit-exact), gradients against torch's conv2d backward."""
+    from gga_amd import _lib, pillar_conv
+    B, M = 3, 300
+    coors, feats = _pillar_case(B, ny, nx, M, cin, seed=k * 100 + stride)
+    oh, ow = (ny + 2 * pad - k) // stride + 1, (nx + 2 * pad - k) // stride + 1
+    # map
+    m = coors.shape[0]
+    nbr = torch.empty((k * k, m), dtype=torch.int32, device=DEV)
+    _lib.check(_lib.lib().gga_pillar_conv_map(F._p(coors), m, None, B, ny, nx, k, k, stride, stride, pad, pad, F._p(nbr),
+                                              F._stream()), 'map')
+    c = coors.cpu().numpy().astype(np.int64)
+    ref = np.full((k * k, m), -1, np.int64)
+    for ky in range(k):
+        for kx in range(k):
+            ty, tx = c[:, 2] + pad - ky, c[:, 3] + pad - kx
+            ok = (ty >= 0) & (tx >= 0) & (ty % stride == 0) & (tx % stride == 0) & (ty // stride < oh) & (tx // stride < ow)
+            ref[ky * k + kx] = np.where(ok, (c[:, 0] * oh + ty // stride) * ow + tx // stride, -1)
+    assert np.array_equal(nbr.cpu().numpy(), ref)
+
+    conv = torch.nn.Conv2d(cin, cout, k, stride=stride, padding=pad, bias=False).to(DEV)
+    conv.weight.data = conv.weight.data.contiguous(memory_format=torch.channels_last)
+    gy = None
+    res = []
+    for fused in (False, True):
+        f = feats.clone().requires_grad_(True)
+        conv.weight.grad = None
+        canvas = F.pillar_scatter(f, coors, B, ny, nx, channels_last=True, unique=True)
+        assert pillar_conv.eligible(conv, canvas)
+        y = pillar_conv.pillar_conv2d(canvas, conv) if fused else conv(canvas)
+        if gy is None:
+            gy = torch.randn_like(y)
+        y.backward(gy)
+        res.append((y.detach(), f.grad.clone(), conv.weight.grad.clone()))
+    (y0, gf0, gw0), (y1, gf1, gw1) = res
+    assert float((y0 - y1).abs().max()) <= 1e-5 * float(y0.abs().max())      # same MIOpen call; solver may split K
+    assert float((gf0 - gf1).abs().max()) <= 2e-5 * float(gf0.abs().max())
+    assert float((gw0 - gw1).abs().max()) <= 2e-5 * float(gw0.abs().max())
+
+
+def test_pillar_conv_valid_count_and_fallbacks():
+    from gga_amd import pillar_conv
+    B, ny, nx, M, C = 2, 40, 36, 200, 64
+    coors, feats = _pillar_case(B, ny, nx, M, C, seed=5)
+    conv = torch.nn.Conv2d(C, C, 3, stride=2, padding=1, bias=False).to(DEV)
+    nv = torch.tensor([250], dtype=torch.int32, device=DEV)
+    out = []
+    for fused in (False, True):
+        f = feats.clone().requires_grad_(True)
+        conv.weight.grad = None
+        canvas = F.pillar_scatter(f, coors, B, ny, nx, channels_last=True, unique=True, num_valid=nv)
+        y = pillar_conv.pillar_conv2d(canvas, conv) if fused else conv(canvas)
+        y.square().sum().backward()
+        out.append((f.grad.clone(), conv.weight.grad.clone()))
+    assert float(out[1][0][250:].abs().max()) == 0.0            # rows past the valid count get no gradient
+    assert float((out[0][0] - out[1][0]).abs().max()) <= 2e-5 * float(out[0][0].abs().max())
+    assert float((out[0][1] - out[1][1]).abs().max()) <= 2e-5 * float(out[0][1].abs().max())
+    # not eligible: NCHW canvas, non-unique scatter, biased conv, no grad
+    f = feats.clone().requires_grad_(True)
+    assert not pillar_conv.eligible(conv, F.pillar_scatter(f, coors, B, ny, nx, channels_last=False, unique=True))
+    assert not pillar_conv.eligible(conv, F.pillar_scatter(f, coors, B, ny, nx, channels_last=True, unique=False))
+    cb = torch.nn.Conv2d(C, C, 3, padding=1).to(DEV)
+    assert not pillar_conv.eligible(cb, F.pillar_scatter(f, coors, B, ny, nx, channels_last=True, unique=True))
+    with torch.no_grad():
+        assert not pillar_conv.eligible(conv, F.pillar_scatter(f, coors, B, ny, nx, channels_last=True, unique=True))

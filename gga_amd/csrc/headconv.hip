@@ -4,166 +4,225 @@
 // Reference: the last layer of every head branch, mmdet3d/models/dense_heads/centerpoint_head.py:
 // 70-79 (build_conv_layer(conv_cfg, head_conv, classes, kernel_size=final_kernel, padding=1,
 // bias=True)) — 15 of them per step (reg 2, height 1, dim 3, rot 2, heatmap 1 channels x 3 tasks).
-// With 1-3 output channels these are not GEMM-shaped: a matrix kernel spends its time on a
-// 64-576-wide reduction for a 3-wide output (measured: MIOpen implicit-GEMM 0.34 ms fwd, 0.38 ms
-// wgrad per conv on a 219 MB input = 0.6 TB/s). They are HBM/L2-bound streaming reductions:
-//   fwd    one lane per output pixel: 9 x 16 float4 loads of its input rows (L1/L2 serve the 9x
-//          neighbour reuse), weights broadcast from LDS, planar NCHW output written coalesced.
-//   wgrad  one lane per input channel: the wave walks its pixels, 9 coalesced 256 B loads per
-//          pixel, 27 accumulators per lane, one atomicAdd per weight per wave at the end.
+// With 1-3 output channels these are not GEMM-shaped as they stand: a matrix kernel spends its
+// time on a 576-wide reduction for a 3-wide output (measured: MIOpen implicit-GEMM 0.34 ms fwd,
+// 0.38 ms wgrad per conv on a 219 MB input = 0.6 TB/s; a lane-per-pixel VALU kernel over an LDS
+// halo tile: 0.165 / 0.147 ms, bound by LDS reads). Swapping the roles makes them GEMMs with
+// N = 9 taps x COUT <= 32 and the convolution a shifted sum of the result (see the kernels):
+// fwd 0.084-0.105 ms, each input element read once per tile from HBM (halo 1.33x).
 // Backward-data (writes the 219 MB input gradient, already bandwidth-bound) stays with MIOpen.
 #include "gga_common.h"
 
 #define HC_CIN 64
 #define HC_MAXCO 4
 
-// Tile = HC_TR rows x HC_TW pixels of one image; its (HC_TR+2) x (HC_TW+2) x 64 input halo is staged
-// in LDS with a pixel stride of 68 floats: 16 B aligned for b128 access, and (68 mod 64 = 4) makes
-// the lane-per-pixel b128 reads of the forward bank-conflict free; the lane-per-channel reads of the
-// weight gradient are contiguous.
-#define HC_TR 4
-#define HC_TW 32
-#define HC_PS 68                      // LDS pixel stride in floats
-#define HC_HR (HC_TR + 2)
-#define HC_HW (HC_TW + 2)
+// Forward on the matrix cores, with the roles swapped so that the tiny output width is not the
+// GEMM's N: Z[p][n] = sum_ci x[p][ci] * w[co][ci][off] for n = off*COUT + co (9*COUT <= 32 columns,
+// one 32-wide tile) is a [pixels x 64] x [64 x 32] product on v_mfma_f32_32x32x2_f32, and the
+// convolution is the 9-tap shifted sum y[p][co] = bias + sum_off Z[p + off][off*COUT + co].
+//   x: [B, H, W, 64] (channels-last memory of a [B,64,H,W] tensor); w: [cout][64][3][3]; y: [B, cout, H, W]
+// A 512-thread workgroup owns 8 x 32 output pixels; its 10 x 34 halo pixels are dealt to the 8
+// waves in groups of 32. Lane (r = lane%32, h = lane/32) loads channels 32h..32h+31 of pixel r of
+// its group straight from global memory (128 contiguous bytes, no LDS staging of x) and keeps the
+// weights of column r for the same channels in registers, so K is walked in the order
+// (32h + s) on both operands. Z goes to LDS (pixel stride 33 floats), then one thread per
+// (output pixel, channel) adds its nine taps. Each input pixel is read once per tile
+// (halo 1.33x), 32 MFMAs per 32 pixels.
+#define HM_TR 8
+#define HM_TW 32
+#define HM_HR (HM_TR + 2)
+#define HM_HW (HM_TW + 2)
+#define HM_NPIX (HM_HR * HM_HW)
+#define HM_NGRP ((HM_NPIX + 31) / 32)
+#define HM_ZS 33
 
-struct HcTile { int b, y0, x0; };
-
-__device__ __forceinline__ HcTile hc_tile(int64_t t, int tiles_x, int tiles_y) {
-    HcTile r;
-    const int per_img = tiles_x * tiles_y;
-    r.b = (int)(t / per_img);
-    const int rem = (int)(t - (int64_t)r.b * per_img);
-    r.y0 = (rem / tiles_x) * HC_TR;
-    r.x0 = (rem % tiles_x) * HC_TW;
-    return r;
-}
-
-// cooperative, coalesced load of the halo tile (zero outside the image)
-__device__ __forceinline__ void hc_load_tile(const float* __restrict__ x, HcTile t, int H, int W, float* __restrict__ lds) {
-    for (int i = threadIdx.x; i < HC_HR * HC_HW * (HC_CIN / 4); i += 256) {
-        const int q = i & 15, pix = i >> 4;
-        const int hr = pix / HC_HW, hx = pix - hr * HC_HW;
-        const int iy = t.y0 + hr - 1, ix = t.x0 + hx - 1;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
-            v = *reinterpret_cast<const float4*>(x + (((int64_t)t.b * H + iy) * W + ix) * HC_CIN + q * 4);
-        *reinterpret_cast<float4*>(lds + (int64_t)pix * HC_PS + q * 4) = v;
-    }
-}
-
-// x: [B, H, W, 64] (channels-last memory of a [B,64,H,W] tensor); w: [cout][64][3][3]; y: [B, cout, H, W]
-// thread = (tile pixel, half of the input channels); weights are broadcast b128 reads from LDS,
-// the two halves are summed with one shuffle.
 template <int COUT>
-__global__ __launch_bounds__(256) void headconv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+__global__ __launch_bounds__(512) void headconv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                           const float* __restrict__ bias, int B, int H, int W,
-                                                          int tiles_x, int tiles_y, float* __restrict__ y) {
-    __shared__ __attribute__((aligned(16))) float lds[HC_HR * HC_HW * HC_PS];
-    __shared__ __attribute__((aligned(16))) float wl[9 * COUT * HC_CIN];     // [off][co][ci]: b128 = 4 ci of one co
-    const HcTile t = hc_tile(blockIdx.x, tiles_x, tiles_y);
-    for (int i = threadIdx.x; i < 9 * COUT * HC_CIN; i += 256) {
-        const int ci = i & 63, oc = i >> 6;
-        const int off = oc / COUT, co = oc - off * COUT;
-        wl[i] = w[((int64_t)co * HC_CIN + ci) * 9 + off];
+                                                          int tiles_x, int tiles_y, int cout_total, int co_base,
+                                                          float* __restrict__ y) {
+    typedef float acc16 __attribute__((ext_vector_type(16)));
+    __shared__ float zt[HM_NGRP * 32 * HM_ZS];
+    const int per_img = tiles_x * tiles_y;
+    const int b = blockIdx.x / per_img;
+    const int rem = blockIdx.x - b * per_img;
+    const int y0 = (rem / tiles_x) * HM_TR, x0 = (rem % tiles_x) * HM_TW;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+
+    // B operand: column n = r -> (off, co); zero columns beyond 9*COUT
+    float wb[32];
+    {
+        const bool used = r < 9 * COUT;
+        const int off = used ? r / COUT : 0, co = used ? r - off * COUT : 0;
+        const float* wp = w + ((int64_t)(co_base + co) * HC_CIN + 32 * h) * 9 + off;
+#pragma unroll
+        for (int s = 0; s < 32; ++s) wb[s] = used ? wp[s * 9] : 0.0f;
     }
-    hc_load_tile(x, t, H, W, lds);
+    // A operand of this wave's (at most two) pixel groups
+    float4 xa[2][8];
+    bool has[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int g = wave + 8 * u;
+        has[u] = g < HM_NGRP;                       // wave-uniform
+        const int hp = g * 32 + r;
+        const int hr = hp / HM_HW, hx = hp - hr * HM_HW;
+        const int iy = y0 + hr - 1, ix = x0 + hx - 1;
+        const bool ok = has[u] && hp < HM_NPIX && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+        const float4* src = reinterpret_cast<const float4*>(x + (((int64_t)b * H + (ok ? iy : 0)) * W + (ok ? ix : 0)) * HC_CIN + 32 * h);
+        const float m = ok ? 1.0f : 0.0f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            float4 v = src[q];
+            xa[u][q] = make_float4(v.x * m, v.y * m, v.z * m, v.w * m);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        if (!has[u]) break;
+        acc16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[u][q].x, wb[4 * q + 0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[u][q].y, wb[4 * q + 1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[u][q].z, wb[4 * q + 2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[u][q].w, wb[4 * q + 3], acc, 0, 0, 0);
+        }
+        // D layout of 32x32x2: register v of lane l holds row (v/4)*8 + (l/32)*4 + v%4, column l%32
+        float* zg = zt + (wave + 8 * u) * 32 * HM_ZS + r;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) zg[((v >> 2) * 8 + h * 4 + (v & 3)) * HM_ZS] = acc[v];
+    }
     __syncthreads();
-    const int half = threadIdx.x & 1, pid = threadIdx.x >> 1;      // pid 0..127 = tile pixel
-    const int ty = pid / HC_TW, tx = pid - ty * HC_TW;
-    float acc[COUT];
+    for (int i = threadIdx.x; i < HM_TR * HM_TW * COUT; i += 512) {
+        const int co = i / (HM_TR * HM_TW), pid = i - co * (HM_TR * HM_TW);
+        const int ty = pid / HM_TW, tx = pid - ty * HM_TW;
+        const int oy = y0 + ty, ox = x0 + tx;
+        if (oy >= H || ox >= W) continue;
+        float s = bias ? bias[co_base + co] : 0.0f;
 #pragma unroll
-    for (int co = 0; co < COUT; ++co) acc[co] = 0.0f;
-    // (kept rolled: a full unroll lets the scheduler hoist all 72*(1+COUT) b128 loads and spill)
-#pragma unroll 1
-    for (int off = 0; off < 9; ++off) {
-            const int ky = off / 3, kx = off - ky * 3;
-            const float* src = lds + ((ty + ky) * HC_HW + (tx + kx)) * HC_PS + half * 32;
-            const float* wsrc = wl + off * COUT * HC_CIN + half * 32;
-#pragma unroll 2
-            for (int q = 0; q < 8; ++q) {
-                const float4 v = *reinterpret_cast<const float4*>(src + q * 4);
+        for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-                for (int co = 0; co < COUT; ++co) {
-                    const float4 wv = *reinterpret_cast<const float4*>(wsrc + co * HC_CIN + q * 4);   // broadcast read
-                    acc[co] += v.x * wv.x + v.y * wv.y + v.z * wv.z + v.w * wv.w;
-                }
+            for (int kx = 0; kx < 3; ++kx)
+                s += zt[((ty + ky) * HM_HW + tx + kx) * HM_ZS + (ky * 3 + kx) * COUT + co];
+        y[(((int64_t)b * cout_total + co_base + co) * H + oy) * W + ox] = s;
+    }
+}
+
+// dW[co][ci][off] = sum_p x[p+off][ci] * dy[co][p]; dbias[co] = sum_p dy[co][p], on the matrix
+// cores with the same role swap: per tile, D[ci][n] += sum_q x[q][ci] * G[q][n] over the halo
+// pixels q, where G[q][off*COUT + co] = dy[co][q - off] if q - off is an output pixel of the
+// tile (zero otherwise) - a [64 x halo] x [halo x 32] product, K = pixels. Lane (m, h) feeds
+// x[q_h][m] / x[q_h][32 + m] (one coalesced 128 B row segment per half wave, each input element
+// read exactly once per tile, no LDS staging) and G[q_h][m] (read from the tile's dy, staged in
+// LDS with a zero border so the shifted read needs no branch). Persistent 512-thread
+// workgroups (4 per CU: the loads of one hide behind the MFMAs of the others - 60 VGPRs with the
+// K loop unrolled by 11; measured 0.136 ms at 2 per CU, 0.120 ms at 4) walk the tiles; the 8 waves split K (44 halo pixels each) and keep their partial D
+// in accumulators across tiles; one fixed-order fold per workgroup at the end, then
+// headconv_wgrad_final_kernel adds the workgroups (no atomics).
+#define HW_PR (HM_HR + 2)
+#define HW_PC (HM_HW + 2)
+#define HW_KW ((HM_NGRP * 32) / 8)      // halo pixels per wave (44)
+#ifndef HW_UNROLL
+#define HW_UNROLL 11
+#endif
+#ifndef HW_MINW
+#define HW_MINW 8
+#endif
+
+template <int COUT>
+__global__ __launch_bounds__(512, HW_MINW) void headconv_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                            int B, int H, int W, int tiles_x, int tiles_y,
+                                                            int64_t n_tiles, int cout_total, int co_base,
+                                                            float* __restrict__ partials) {
+    typedef float acc16 __attribute__((ext_vector_type(16)));
+    __shared__ float gds[2][COUT * HW_PR * HW_PC];
+    __shared__ float red[HC_CIN * 33];
+    __shared__ float bred[8][HC_MAXCO];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = lane & 31, h = lane >> 5;
+    const bool used = m < 9 * COUT;
+    const int off = used ? m / COUT : 0, co = used ? m - off * COUT : 0;
+    const int ky = off / 3, kx = off - ky * 3;
+    const int gbase = co * HW_PR * HW_PC + (2 - ky) * HW_PC + (2 - kx);
+    const float usedf = used ? 1.0f : 0.0f;
+    for (int i = threadIdx.x; i < 2 * COUT * HW_PR * HW_PC; i += 512) (&gds[0][0])[i] = 0.0f;    // borders stay zero
+    acc16 acc0, acc1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc0[i] = 0.0f; acc1[i] = 0.0f; }
+    float bs = 0.0f;                     // this thread's share of sum(dy) for channel (threadIdx.x >> 8) (+2 on odd passes)
+    float bs2 = 0.0f;
+    const int per_img = tiles_x * tiles_y;
+    int it = 0;
+    for (int64_t ti = blockIdx.x; ti < n_tiles; ti += gridDim.x, ++it) {
+        const int b = (int)(ti / per_img);
+        const int rem = (int)(ti - (int64_t)b * per_img);
+        const int y0 = (rem / tiles_x) * HM_TR, x0 = (rem % tiles_x) * HM_TW;
+        float* g = gds[it & 1];
+        // stage dy of the tile (zero outside the image): thread -> (channel, pixel), at most 2 passes
+#pragma unroll
+        for (int pass = 0; pass < (COUT + 1) / 2; ++pass) {
+            const int i = threadIdx.x + 512 * pass;
+            const int ci = i >> 8, pid = i & 255;
+            if (ci < COUT) {
+                const int ty = pid >> 5, tx = pid & 31;
+                const int oy = y0 + ty, ox = x0 + tx;
+                const float v = (oy < H && ox < W) ? dy[(((int64_t)b * cout_total + co_base + ci) * H + oy) * W + ox] : 0.0f;
+                g[ci * HW_PR * HW_PC + (ty + 2) * HW_PC + tx + 2] = v;
+                if (pass == 0) bs += v; else bs2 += v;
             }
         }
-    const int oy = t.y0 + ty, ox = t.x0 + tx;
-#pragma unroll
-    for (int co = 0; co < COUT; ++co) {
-        const float s = acc[co] + __shfl_xor(acc[co], 1, 64);
-        if (half == 0 && oy < H && ox < W)
-            y[(((int64_t)t.b * COUT + co) * H + oy) * W + ox] = s + (bias ? bias[co] : 0.0f);
-    }
-}
-
-// dW[co][ci][off] = sum_p x[p+off][ci] * dy[co][p]; dbias[co] = sum_p dy[co][p].
-// Persistent workgroups walk the tiles; wave = tile row, lane = input channel; per-block partial
-// sums go to `partials` and a second kernel adds them in a fixed order (no atomics).
-template <int COUT>
-__global__ __launch_bounds__(256) void headconv_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                            int B, int H, int W, int tiles_x, int tiles_y,
-                                                            int64_t n_tiles, float* __restrict__ partials) {
-    __shared__ __attribute__((aligned(16))) float lds[HC_HR * HC_HW * HC_PS];
-    __shared__ float gds[HC_TR * HC_TW * COUT];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float acc[9][COUT];
-#pragma unroll
-    for (int o = 0; o < 9; ++o)
-#pragma unroll
-        for (int co = 0; co < COUT; ++co) acc[o][co] = 0.0f;
-    float bsum[COUT];
-#pragma unroll
-    for (int co = 0; co < COUT; ++co) bsum[co] = 0.0f;
-    for (int64_t ti = blockIdx.x; ti < n_tiles; ti += gridDim.x) {
-        const HcTile t = hc_tile(ti, tiles_x, tiles_y);
-        __syncthreads();                               // previous tile fully consumed
-        hc_load_tile(x, t, H, W, lds);
-        for (int i = threadIdx.x; i < HC_TR * HC_TW * COUT; i += 256) {
-            const int co = i / (HC_TR * HC_TW), pid = i - co * (HC_TR * HC_TW);
-            const int oy = t.y0 + pid / HC_TW, ox = t.x0 + pid % HC_TW;
-            gds[pid * COUT + co] = (oy < H && ox < W) ? dy[(((int64_t)t.b * COUT + co) * H + oy) * W + ox] : 0.0f;
+        __syncthreads();      // tile `it` staged; every wave is done with tile it-1, so the other buffer is free
+#pragma unroll HW_UNROLL
+        for (int s = 0; s < HW_KW / 2; ++s) {
+            const int q = HW_KW * wave + 2 * s + h;
+            const bool inh = q < HM_NPIX;
+            const int hr = inh ? q / HM_HW : 0, hx = inh ? q - hr * HM_HW : 0;
+            const int iy = y0 + hr - 1, ix = x0 + hx - 1;
+            const bool ok = inh && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+            const float* xp = x + (((int64_t)b * H + (ok ? iy : 0)) * W + (ok ? ix : 0)) * HC_CIN + m;
+            const float mk = ok ? 1.0f : 0.0f;
+            const float a0 = xp[0] * mk, a1 = xp[32] * mk;
+            const float gv = g[gbase + hr * HW_PC + hx] * usedf;
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, gv, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, gv, acc1, 0, 0, 0);
         }
+    }
+    // fixed-order fold of the 8 waves' partial D[ci][n] (register v of lane l: row (v/4)*8 + (l/32)*4 + v%4, column l%32)
+    for (int wv = 0; wv < 8; ++wv) {
         __syncthreads();
-        for (int tx = 0; tx < HC_TW; ++tx) {
-            float g[COUT];
+        if (wave == wv) {
 #pragma unroll
-            for (int co = 0; co < COUT; ++co) { g[co] = gds[(wave * HC_TW + tx) * COUT + co]; bsum[co] += g[co]; }
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const float v = lds[((wave + ky) * HC_HW + (tx + kx)) * HC_PS + lane];
-#pragma unroll
-                    for (int co = 0; co < COUT; ++co) acc[ky * 3 + kx][co] += v * g[co];
-                }
+            for (int v = 0; v < 16; ++v) {
+                const int row = (v >> 2) * 8 + h * 4 + (v & 3);
+                float* r0 = red + row * 33 + m;
+                float* r1 = red + (32 + row) * 33 + m;
+                *r0 = (wv ? *r0 : 0.0f) + acc0[v];
+                *r1 = (wv ? *r1 : 0.0f) + acc1[v];
+            }
         }
     }
-    // block reduce over the 4 waves through LDS, then one partial row per block:
-    // layout [block][co][ci][off] (+ COUT bias sums at the end)
-    __syncthreads();
-    float* red = lds;                                   // 4 * 9 * COUT * 64 floats <= tile buffer
-#pragma unroll
-    for (int o = 0; o < 9; ++o)
-#pragma unroll
-        for (int co = 0; co < COUT; ++co) red[((wave * 9 + o) * COUT + co) * 64 + lane] = acc[o][co];
-    if (lane == 0)
-#pragma unroll
-        for (int co = 0; co < COUT; ++co) gds[wave * COUT + co] = bsum[co];
-    __syncthreads();
-    float* out = partials + (int64_t)blockIdx.x * (COUT * HC_CIN * 9 + COUT);
-    for (int i = threadIdx.x; i < 9 * COUT * 64; i += 256) {
-        const int ci = i & 63, oc = i >> 6;              // oc = o * COUT + co
-        const int o = oc / COUT, co = oc - o * COUT;
-        const float s = (red[(0 * 9 * COUT + oc) * 64 + ci] + red[(1 * 9 * COUT + oc) * 64 + ci]) +
-                        (red[(2 * 9 * COUT + oc) * 64 + ci] + red[(3 * 9 * COUT + oc) * 64 + ci]);
-        out[((int64_t)co * HC_CIN + ci) * 9 + o] = s;
+    // bias sums: threads 0..255 hold channel 0 (pass 0) and 2 (pass 1), threads 256..511 channels 1 and 3
+    {
+        const float t0 = wave_sum(bs), t1 = wave_sum(bs2);
+        if (lane == 0) { bred[wave][0] = t0; bred[wave][1] = t1; }
     }
-    if (threadIdx.x < COUT)
-        out[COUT * HC_CIN * 9 + threadIdx.x] = (gds[threadIdx.x] + gds[COUT + threadIdx.x]) +
-                                               (gds[2 * COUT + threadIdx.x] + gds[3 * COUT + threadIdx.x]);
+    __syncthreads();
+    const int row_len = cout_total * HC_CIN * 9 + cout_total;
+    float* out = partials + (int64_t)blockIdx.x * row_len;
+    for (int i = threadIdx.x; i < 9 * COUT * HC_CIN; i += 512) {
+        const int ci = i & 63, n = i >> 6;
+        const int o = n / COUT, c = n - o * COUT;
+        out[((int64_t)(co_base + c) * HC_CIN + ci) * 9 + o] = red[ci * 33 + n];
+    }
+    if (threadIdx.x < COUT) {
+        const int c = threadIdx.x;                       // channel c: waves (c&1)*4 .. +3, pass c>>1
+        const int w0 = (c & 1) * 4, ps = c >> 1;
+        out[cout_total * HC_CIN * 9 + co_base + c] = (bred[w0][ps] + bred[w0 + 1][ps]) + (bred[w0 + 2][ps] + bred[w0 + 3][ps]);
+    }
 }
 
 // one wavefront per output value: lanes stride over the block partials (fixed order)
@@ -180,7 +239,9 @@ __global__ __launch_bounds__(256) void headconv_wgrad_final_kernel(const float* 
     else if (dbias) dbias[i - n_w] = (float)s;
 }
 
-#define HC_WGRAD_BLOCKS 512
+#ifndef HC_WGRAD_BLOCKS
+#define HC_WGRAD_BLOCKS 1024
+#endif
 
 static int headconv_check(const char* fn, int B, int H, int W, int cin, int cout) {
     GGA_REQUIRE(B >= 1 && H >= 1 && W >= 1, "%s: bad sizes", fn);
@@ -199,10 +260,15 @@ extern "C" int gga_head_conv3x3_fwd(const float* x, const float* weight, const f
     hipStream_t stream = (hipStream_t)stream_;
     if (int rc = headconv_check("gga_head_conv3x3_fwd", B, H, W, cin, cout)) return rc;
     GGA_REQUIRE(x && weight && y, "gga_head_conv3x3_fwd: null pointer argument");
-    const int tx = (W + HC_TW - 1) / HC_TW, ty = (H + HC_TR - 1) / HC_TR;
-    const dim3 grid((unsigned)((int64_t)B * tx * ty)), block(256);
-#define HC_F(CO) hipLaunchKernelGGL(headconv_fwd_kernel<CO>, grid, block, 0, stream, x, weight, bias, B, H, W, tx, ty, y)
-    switch (cout) { case 1: HC_F(1); break; case 2: HC_F(2); break; case 3: HC_F(3); break; default: HC_F(4); }
+    const int tx = (W + HM_TW - 1) / HM_TW, ty = (H + HM_TR - 1) / HM_TR;
+    const dim3 grid((unsigned)((int64_t)B * tx * ty)), block(512);
+#define HC_F(CO, BASE) hipLaunchKernelGGL(headconv_fwd_kernel<CO>, grid, block, 0, stream, x, weight, bias, B, H, W, tx, ty, cout, BASE, y)
+    switch (cout) {
+        case 1: HC_F(1, 0); break;
+        case 2: HC_F(2, 0); break;
+        case 3: HC_F(3, 0); break;
+        default: HC_F(2, 0); HC_F(2, 2); break;      // 9*4 columns do not fit one 32-wide tile
+    }
 #undef HC_F
     GGA_CHECK_LAUNCH("headconv_fwd_kernel");
     return GGA_OK;
@@ -218,12 +284,17 @@ extern "C" int gga_head_conv3x3_wgrad(const float* x, const float* grad_y, int B
         gga_set_error("gga_head_conv3x3_wgrad: workspace too small");
         return GGA_ERR_WORKSPACE;
     }
-    const int tx = (W + HC_TW - 1) / HC_TW, ty = (H + HC_TR - 1) / HC_TR;
+    const int tx = (W + HM_TW - 1) / HM_TW, ty = (H + HM_TR - 1) / HM_TR;
     const int64_t n_tiles = (int64_t)B * tx * ty;
     const int nb = (int)(n_tiles < HC_WGRAD_BLOCKS ? n_tiles : HC_WGRAD_BLOCKS);
     float* partials = (float*)workspace;
-#define HC_W(CO) hipLaunchKernelGGL(headconv_wgrad_kernel<CO>, dim3(nb), dim3(256), 0, stream, x, grad_y, B, H, W, tx, ty, n_tiles, partials)
-    switch (cout) { case 1: HC_W(1); break; case 2: HC_W(2); break; case 3: HC_W(3); break; default: HC_W(4); }
+#define HC_W(CO, BASE) hipLaunchKernelGGL(headconv_wgrad_kernel<CO>, dim3(nb), dim3(512), 0, stream, x, grad_y, B, H, W, tx, ty, n_tiles, cout, BASE, partials)
+    switch (cout) {
+        case 1: HC_W(1, 0); break;
+        case 2: HC_W(2, 0); break;
+        case 3: HC_W(3, 0); break;
+        default: HC_W(2, 0); HC_W(2, 2); break;
+    }
 #undef HC_W
     GGA_CHECK_LAUNCH("headconv_wgrad_kernel");
     const int n_w = cout * HC_CIN * 9;

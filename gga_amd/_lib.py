@@ -79,6 +79,8 @@ SIGNATURES = {
     'gga_bn_relu_mask_bytes': (sz, [i64, i32]),
     'gga_bn_relu_fwd': (i32, [vp, vp, vp, vp, vp, vp, i64, i32, f32, f32, i32, i32, vp, vp, vp, vp, sz, vp]),
     'gga_bn_relu_bwd': (i32, [vp, vp, vp, vp, vp, i64, i32, i32, vp, vp, vp, vp, vp, sz, vp]),
+    'gga_bn_relu_fwd_strided': (i32, [vp, vp, vp, vp, vp, vp, i64, i32, f32, f32, i32, i32, vp, i64, vp, vp, vp, sz, vp]),
+    'gga_bn_relu_bwd_strided': (i32, [vp, i64, vp, vp, vp, vp, i64, i32, i32, vp, vp, vp, vp, vp, sz, vp]),
     'gga_head_conv3x3_fwd': (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]),
     'gga_head_conv3x3_workspace_bytes': (sz, [i32]),
     'gga_head_conv3x3_wgrad': (i32, [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, sz, vp]),

@@ -74,5 +74,10 @@ class SECONDFPN(nn.Module):
 
     def forward(self, x):
         assert len(x) == len(self.in_channels)
+        if all(len(d) == 3 and isinstance(d[1], nn.modules.batchnorm._BatchNorm) and isinstance(d[2], nn.ReLU)
+               for d in self.deblocks):
+            # every branch normalises straight into its channel slice of the concatenated map
+            from . import functional as F
+            return [F.bn_relu_cat([d[0](x[i]) for i, d in enumerate(self.deblocks)], [d[1] for d in self.deblocks])]
         ups = [run_conv_bn_relu(deblock, x[i]) for i, deblock in enumerate(self.deblocks)]
         return [torch.cat(ups, dim=1) if len(ups) > 1 else ups[0]]

@@ -20,8 +20,23 @@
 
 struct BnGeom {
     int64_t n4;      // rows * C / 4
-    int c4;          // C / 4
+    int c4;          // C / 4 (a power of two, see bn_check)
+    int sh;          // log2(c4)
+    int64_t ys4;     // row stride (in float4) of the strided operand: y in forward, grad_y in backward; c4 = dense
 };
+
+// float4 index of element e (dense index over [rows, c4]) in the strided operand
+__device__ __forceinline__ int64_t bn_strided(const BnGeom& g, int64_t e, int cg) { return (e >> g.sh) * g.ys4 + cg; }
+
+static BnGeom bn_geom(int64_t rows, int channels, int64_t row_stride) {
+    BnGeom g;
+    g.n4 = rows * channels / 4;
+    g.c4 = channels / 4;
+    g.sh = 0;
+    while ((1 << g.sh) < g.c4) ++g.sh;
+    g.ys4 = row_stride / 4;
+    return g;
+}
 
 static int bn_grid(int64_t n4) {
     int64_t b = (n4 + 256 * BN_U - 1) / (256 * BN_U);
@@ -58,7 +73,7 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float4* __restrict
             av[u] = make_float4(0.f, 0.f, 0.f, 0.f);
             bv[u] = av[u];
             if (e < g.n4) {
-                av[u] = a[e];
+                av[u] = BWD ? a[bn_strided(g, e, cg)] : a[e];
                 if (BWD) {
                     bv[u] = b[e];
                     if (relu) {
@@ -216,7 +231,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float4* __restrict_
                 }
                 v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f);
             }
-            if (live) y[e] = v;
+            if (live) y[bn_strided(g, e, cg)] = v;
         }
     }
 }
@@ -260,7 +275,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float4* __restr
         for (int u = 0; u < BN_U; ++u) {
             const int64_t e = eb + u * stride;
             if (e < g.n4) {
-                gv[u] = dy[e]; xv[u] = x[e];
+                gv[u] = dy[bn_strided(g, e, cg)]; xv[u] = x[e];
                 if (relu) {
                     const unsigned long long* w = bits + (e >> 6) * 4;
 #pragma unroll
@@ -305,19 +320,23 @@ static int bn_check(const char* fn, int64_t rows, int C) {
     return GGA_OK;
 }
 
-extern "C" int gga_bn_relu_fwd(const float* x, const float* residual, const float* gamma, const float* beta,
-                               float* running_mean, float* running_var, int64_t rows, int channels, float eps,
-                               float momentum, int training, int relu, float* y, void* mask_bits, float* saved,
-                               void* workspace, size_t workspace_bytes, void* stream_) {
+extern "C" int gga_bn_relu_fwd_strided(const float* x, const float* residual, const float* gamma, const float* beta,
+                                       float* running_mean, float* running_var, int64_t rows, int channels, float eps,
+                                       float momentum, int training, int relu, float* y, int64_t y_row_stride,
+                                       void* mask_bits, float* saved, void* workspace, size_t workspace_bytes,
+                                       void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (int rc = bn_check("gga_bn_relu_fwd", rows, channels)) return rc;
+    GGA_REQUIRE(y_row_stride >= channels && y_row_stride % 4 == 0 && ((uintptr_t)y & 15) == 0,
+                "gga_bn_relu_fwd: y row stride %lld must be a multiple of 4 floats >= channels, y 16 B aligned",
+                (long long)y_row_stride);
     GGA_REQUIRE(x && y && saved && workspace && running_mean && running_var && (!relu || mask_bits),
                 "gga_bn_relu_fwd: null pointer argument");
     if (workspace_bytes < gga_bn_relu_workspace_bytes(rows, channels)) {
         gga_set_error("gga_bn_relu_fwd: workspace too small");
         return GGA_ERR_WORKSPACE;
     }
-    const BnGeom g = { rows * channels / 4, channels / 4 };
+    const BnGeom g = bn_geom(rows, channels, y_row_stride);
     const int nb = bn_grid(g.n4);
     double* partials = (double*)workspace;
     float* scale_shift = (float*)((char*)workspace + (size_t)BN_MAX_BLOCKS * 2 * channels * sizeof(double));
@@ -336,19 +355,30 @@ extern "C" int gga_bn_relu_fwd(const float* x, const float* residual, const floa
     return GGA_OK;
 }
 
-extern "C" int gga_bn_relu_bwd(const float* grad_y, const float* x, const void* mask_bits, const float* gamma,
-                               const float* saved, int64_t rows, int channels, int relu, float* grad_x,
-                               float* grad_residual, float* grad_gamma, float* grad_beta, void* workspace,
-                               size_t workspace_bytes, void* stream_) {
+extern "C" int gga_bn_relu_fwd(const float* x, const float* residual, const float* gamma, const float* beta,
+                               float* running_mean, float* running_var, int64_t rows, int channels, float eps,
+                               float momentum, int training, int relu, float* y, void* mask_bits, float* saved,
+                               void* workspace, size_t workspace_bytes, void* stream_) {
+    return gga_bn_relu_fwd_strided(x, residual, gamma, beta, running_mean, running_var, rows, channels, eps, momentum,
+                                   training, relu, y, channels, mask_bits, saved, workspace, workspace_bytes, stream_);
+}
+
+extern "C" int gga_bn_relu_bwd_strided(const float* grad_y, int64_t grad_y_row_stride, const float* x,
+                                       const void* mask_bits, const float* gamma, const float* saved, int64_t rows,
+                                       int channels, int relu, float* grad_x, float* grad_residual, float* grad_gamma,
+                                       float* grad_beta, void* workspace, size_t workspace_bytes, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (int rc = bn_check("gga_bn_relu_bwd", rows, channels)) return rc;
+    GGA_REQUIRE(grad_y_row_stride >= channels && grad_y_row_stride % 4 == 0 && ((uintptr_t)grad_y & 15) == 0,
+                "gga_bn_relu_bwd: grad_y row stride %lld must be a multiple of 4 floats >= channels, grad_y 16 B aligned",
+                (long long)grad_y_row_stride);
     GGA_REQUIRE(grad_y && x && saved && grad_x && workspace && (!relu || mask_bits),
                 "gga_bn_relu_bwd: null pointer argument");
     if (workspace_bytes < gga_bn_relu_workspace_bytes(rows, channels)) {
         gga_set_error("gga_bn_relu_bwd: workspace too small");
         return GGA_ERR_WORKSPACE;
     }
-    const BnGeom g = { rows * channels / 4, channels / 4 };
+    const BnGeom g = bn_geom(rows, channels, grad_y_row_stride);
     const int nb = bn_grid(g.n4);
     double* partials = (double*)workspace;
     float* coef = (float*)((char*)workspace + (size_t)BN_MAX_BLOCKS * 2 * channels * sizeof(double));
@@ -363,4 +393,12 @@ extern "C" int gga_bn_relu_bwd(const float* grad_y, const float* x, const void* 
                        (float4*)grad_residual);
     GGA_CHECK_LAUNCH("bn_bwd_apply_kernel");
     return GGA_OK;
+}
+
+extern "C" int gga_bn_relu_bwd(const float* grad_y, const float* x, const void* mask_bits, const float* gamma,
+                               const float* saved, int64_t rows, int channels, int relu, float* grad_x,
+                               float* grad_residual, float* grad_gamma, float* grad_beta, void* workspace,
+                               size_t workspace_bytes, void* stream_) {
+    return gga_bn_relu_bwd_strided(grad_y, channels, x, mask_bits, gamma, saved, rows, channels, relu, grad_x,
+                                   grad_residual, grad_gamma, grad_beta, workspace, workspace_bytes, stream_);
 }

@@ -534,6 +534,88 @@ def bn_act(x, bn, relu=True, residual=None):
                         float(bn.momentum), bool(bn.training), bool(relu), int(rc[0]), int(C))
 
 
+class _BNActCat(torch.autograd.Function):
+    """``cat([relu(bn_i(x_i))], dim=1)`` for channels-last inputs of equal [B, ., H, W]: every
+    branch writes its column block of the concatenated map and reads its block of the gradient in
+    place (gga_bn_relu_fwd_strided / _bwd_strided)."""
+
+    @staticmethod
+    def forward(ctx, n, cfg, *args):
+        xs, gammas, betas = args[:n], args[n:2 * n], args[2 * n:3 * n]
+        rms, rvs = args[3 * n:4 * n], args[4 * n:5 * n]
+        L = _lib.lib()
+        x0 = xs[0]
+        dev = x0.device
+        B, _, H, W = x0.shape
+        rows = B * H * W
+        chans = [int(x.shape[1]) for x in xs]
+        tot = sum(chans)
+        out = torch.empty((B, tot, H, W), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
+        saved_all, bits_all = [], []
+        off = 0
+        for i in range(n):
+            eps, momentum, training = cfg[i]
+            C = chans[i]
+            saved = torch.empty(2 * C, dtype=torch.float32, device=dev)
+            bits = torch.empty(L.gga_bn_relu_mask_bytes(rows, C), dtype=torch.uint8, device=dev)
+            ws = _workspace('bn', L.gga_bn_relu_workspace_bytes(rows, C), dev)
+            check(L.gga_bn_relu_fwd_strided(_p(xs[i]), None, _p(gammas[i]), _p(betas[i]), _p(rms[i]), _p(rvs[i]), rows, C,
+                                            eps, momentum, int(training), 1, out.data_ptr() + 4 * off, tot, _p(bits),
+                                            _p(saved), _p(ws), ws.numel(), _stream()), 'gga_bn_relu_fwd_strided')
+            saved_all.append(saved)
+            bits_all.append(bits)
+            off += C
+        ctx.save_for_backward(*xs, *gammas, *saved_all, *bits_all)
+        ctx.n, ctx.chans, ctx.rows = n, chans, rows
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        n, chans, rows = ctx.n, ctx.chans, ctx.rows
+        t = ctx.saved_tensors
+        xs, gammas, saved_all, bits_all = t[:n], t[n:2 * n], t[2 * n:3 * n], t[3 * n:4 * n]
+        L = _lib.lib()
+        g = g.contiguous(memory_format=torch.channels_last)
+        tot = sum(chans)
+        gxs, ggs, gbs = [], [], []
+        off = 0
+        for i in range(n):
+            C = chans[i]
+            x = xs[i]
+            gx = torch.empty_like(x)
+            gg = torch.empty(C, dtype=torch.float32, device=x.device)
+            gb = torch.empty(C, dtype=torch.float32, device=x.device)
+            ws = _workspace('bn', L.gga_bn_relu_workspace_bytes(rows, C), x.device)
+            check(L.gga_bn_relu_bwd_strided(g.data_ptr() + 4 * off, tot, _p(x), _p(bits_all[i]), _p(gammas[i]),
+                                            _p(saved_all[i]), rows, C, 1, _p(gx), None, _p(gg), _p(gb), _p(ws),
+                                            ws.numel(), _stream()), 'gga_bn_relu_bwd_strided')
+            gxs.append(gx), ggs.append(gg), gbs.append(gb)
+            off += C
+        return (None, None, *gxs, *ggs, *gbs) + (None,) * (2 * n)
+
+
+def bn_relu_cat(xs, bns):
+    """``torch.cat([relu(bn(x)) for x, bn in zip(xs, bns)], dim=1)`` without the concat copy (and
+    without the split copies in backward) when every branch qualifies for the fused BatchNorm
+    kernel; the plain composition otherwise."""
+    def fusable(x, bn):
+        rc = _rows_channels(x) if (x.is_cuda and x.dtype == torch.float32) else None
+        C = x.shape[1]
+        return (rc is not None and C % 4 == 0 and C // 4 <= 256 and 256 % (C // 4) == 0 and bn.affine
+                and bn.track_running_stats and bn.momentum is not None and (bn.training or not torch.is_grad_enabled()))
+    same = all(x.shape[0] == xs[0].shape[0] and x.shape[2:] == xs[0].shape[2:] for x in xs)
+    if len(xs) < 2 or not same or not all(fusable(x, bn) for x, bn in zip(xs, bns)):
+        return torch.cat([bn_act(x, bn, relu=True) for x, bn in zip(xs, bns)], dim=1) if len(xs) > 1 \
+            else bn_act(xs[0], bns[0], relu=True)
+    for bn in bns:
+        if bn.training:
+            bn.num_batches_tracked += 1
+    n = len(xs)
+    cfg = tuple((float(bn.eps), float(bn.momentum), bool(bn.training)) for bn in bns)
+    return _BNActCat.apply(n, cfg, *xs, *[bn.weight for bn in bns], *[bn.bias for bn in bns],
+                           *[bn.running_mean for bn in bns], *[bn.running_var for bn in bns])
+
+
 # ----------------------------------------------------------------------------- head output convs
 class _HeadConv3x3(torch.autograd.Function):
     @staticmethod

@@ -309,6 +309,19 @@ int gga_bn_relu_bwd(const float* grad_y, const float* x, const void* mask_bits, 
                     const float* saved, int64_t rows, int channels, int relu, float* grad_x,
                     float* grad_residual, float* grad_gamma, float* grad_beta, void* workspace,
                     size_t workspace_bytes, void* stream);
+/* The same with y (forward) / grad_y (backward) as a column block of a wider row-major matrix:
+ * row r of the operand starts at y + r * y_row_stride (floats; a multiple of 4, >= channels; the
+ * pointer 16 B aligned). The three SECONDFPN branches write their BN+ReLU output straight into
+ * their channel slice of the concatenated map and read their slice of its gradient in place
+ * (necks/second_fpn.py:85-91: torch.cat of the deblock outputs) - no concat copy, no split copy. */
+int gga_bn_relu_fwd_strided(const float* x, const float* residual, const float* gamma, const float* beta,
+                            float* running_mean, float* running_var, int64_t rows, int channels, float eps,
+                            float momentum, int training, int relu, float* y, int64_t y_row_stride,
+                            void* mask_bits, float* saved, void* workspace, size_t workspace_bytes, void* stream);
+int gga_bn_relu_bwd_strided(const float* grad_y, int64_t grad_y_row_stride, const float* x, const void* mask_bits,
+                            const float* gamma, const float* saved, int64_t rows, int channels, int relu,
+                            float* grad_x, float* grad_residual, float* grad_gamma, float* grad_beta,
+                            void* workspace, size_t workspace_bytes, void* stream);
 
 /* a5 (output convs of the head branches): 3x3 conv, 64 input channels -> 1..4 output channels,
  * stride 1, pad 1, + bias. Replaces the last layer of each SeparateHead branch,

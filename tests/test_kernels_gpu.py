@@ -380,6 +380,40 @@ def test_fused_bn_act_vs_torch(shape, cl, relu, res):
         torch.testing.assert_close(ye, torch.relu(yre) if relu else yre, rtol=1e-4, atol=1e-4)
 
 
+def test_bn_relu_cat_vs_torch():
+    """SECONDFPN tail: the branches' BN+ReLU written into / read from channel slices of the
+    concatenated map equals cat(relu(bn(x)))."""
+    import copy
+    torch.manual_seed(3)
+    B, H, W = 2, 21, 24
+    chans = (32, 128, 64)
+    bns = [torch.nn.BatchNorm2d(c, eps=1e-3, momentum=0.01).to(DEV) for c in chans]
+    for bn in bns:
+        bn.weight.data.uniform_(0.5, 1.5), bn.bias.data.uniform_(-0.5, 0.5)
+    refs = copy.deepcopy(bns)
+    xs = [torch.randn(B, c, H, W, device=DEV).contiguous(memory_format=torch.channels_last) for c in chans]
+    xa = [x.clone().requires_grad_(True) for x in xs]
+    xb = [x.clone().requires_grad_(True) for x in xs]
+    y = F.bn_relu_cat(xa, bns)
+    assert 'BNActCat' in type(y.grad_fn).__name__ and y.is_contiguous(memory_format=torch.channels_last)
+    ref = torch.cat([torch.relu(bn(x)) for bn, x in zip(refs, xb)], dim=1)
+    torch.testing.assert_close(y, ref, rtol=1e-4, atol=1e-4)
+    g = torch.randn_like(ref)
+    y.backward(g)
+    ref.backward(g)
+    for a_, b_, bn, rf in zip(xa, xb, bns, refs):
+        # elements whose pre-activation is within rounding of zero may flip the ReLU mask
+        assert int(((a_.grad - b_.grad).abs() > 1e-4).sum()) <= 3
+        torch.testing.assert_close(bn.weight.grad, rf.weight.grad, rtol=1e-3, atol=1e-3)
+        torch.testing.assert_close(bn.bias.grad, rf.bias.grad, rtol=1e-3, atol=1e-3)
+        torch.testing.assert_close(bn.running_mean, rf.running_mean, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(bn.running_var, rf.running_var, rtol=1e-5, atol=1e-6)
+        assert int(bn.num_batches_tracked) == 1
+    # a single branch / an NCHW input take the plain composition
+    z = F.bn_relu_cat([xs[0].contiguous()], [bns[0]])
+    assert z.shape == xs[0].shape
+
+
 @pytest.mark.parametrize('cout,bias', [(1, True), (2, True), (3, True), (4, False)])
 def test_head_output_conv_vs_torch(cout, bias):
     """64 -> 1..4 channel 3x3 output conv of the head branches against torch's convolution."""

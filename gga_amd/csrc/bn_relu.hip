@@ -57,9 +57,15 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float4* __restrict
     const int64_t e0 = (int64_t)blockIdx.x * 256 + tid;
     const int cg = (int)(e0 % g.c4);                  // fixed channel group of this thread
     float mean[4] = {0, 0, 0, 0}, inv[4] = {1, 1, 1, 1};
+    float msc[4] = {0, 0, 0, 0}, msh[4] = {0, 0, 0, 0};      // relu == 2: the ReLU mask is recomputed from x
     if (BWD) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) { mean[j] = saved[cg * 4 + j]; inv[j] = saved[g.c4 * 4 + cg * 4 + j]; }
+        if (relu == 2) {
+            const float* ss = reinterpret_cast<const float*>(bits);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { msc[j] = ss[cg * 4 + j]; msh[j] = ss[g.c4 * 4 + cg * 4 + j]; }
+        }
     }
     double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
     float f0[4] = {0, 0, 0, 0}, f1[4] = {0, 0, 0, 0};
@@ -76,7 +82,7 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float4* __restrict
                 av[u] = BWD ? a[bn_strided(g, e, cg)] : a[e];
                 if (BWD) {
                     bv[u] = b[e];
-                    if (relu) {
+                    if (relu == 1) {
                         const unsigned long long* w = bits + (e >> 6) * 4;   // [e / 64][component]
 #pragma unroll
                         for (int j = 0; j < 4; ++j) wv[u][j] = w[j];
@@ -91,10 +97,13 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float4* __restrict
             float va[4] = { av[u].x, av[u].y, av[u].z, av[u].w };
             if (BWD) {
                 const float xa[4] = { bv[u].x, bv[u].y, bv[u].z, bv[u].w };
-                if (relu) {
+                if (relu == 1) {
                     const int l = (int)(e & 63);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) if (!((wv[u][j] >> l) & 1ull)) va[j] = 0.0f;
+                } else if (relu == 2) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (!(fmaf(xa[j], msc[j], msh[j]) > 0.0f)) va[j] = 0.0f;
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { f0[j] += va[j]; f1[j] += va[j] * ((xa[j] - mean[j]) * inv[j]); }
@@ -268,6 +277,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float4* __restr
         mean[j] = saved[cg * 4 + j]; inv[j] = saved[C + cg * 4 + j];
         k[j] = coef[cg * 4 + j]; mg[j] = coef[C + cg * 4 + j]; mgx[j] = coef[2 * C + cg * 4 + j];
     }
+    float msc[4] = {0, 0, 0, 0}, msh[4] = {0, 0, 0, 0};
+    if (relu == 2) {
+        const float* ss = reinterpret_cast<const float*>(bits);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { msc[j] = ss[cg * 4 + j]; msh[j] = ss[C + cg * 4 + j]; }
+    }
     for (int64_t eb = e0; eb < g.n4; eb += stride * BN_U) {
         float4 gv[BN_U], xv[BN_U];
         unsigned long long wv[BN_U][4];
@@ -276,7 +291,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float4* __restr
             const int64_t e = eb + u * stride;
             if (e < g.n4) {
                 gv[u] = dy[bn_strided(g, e, cg)]; xv[u] = x[e];
-                if (relu) {
+                if (relu == 1) {
                     const unsigned long long* w = bits + (e >> 6) * 4;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) wv[u][j] = w[j];
@@ -289,10 +304,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float4* __restr
             if (e >= g.n4) continue;
             float ga[4] = { gv[u].x, gv[u].y, gv[u].z, gv[u].w };
             const float xa[4] = { xv[u].x, xv[u].y, xv[u].z, xv[u].w };
-            if (relu) {
+            if (relu == 1) {
                 const int l = (int)(e & 63);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) if (!((wv[u][j] >> l) & 1ull)) ga[j] = 0.0f;
+            } else if (relu == 2) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (!(fmaf(xa[j], msc[j], msh[j]) > 0.0f)) ga[j] = 0.0f;
             }
             float o[4];
 #pragma unroll
@@ -352,6 +370,31 @@ extern "C" int gga_bn_relu_fwd_strided(const float* x, const float* residual, co
     hipLaunchKernelGGL(bn_apply_kernel, dim3(nb), dim3(256), 0, stream, (const float4*)x, (const float4*)residual,
                        scale_shift, g, relu, (float4*)y, (unsigned long long*)mask_bits);
     GGA_CHECK_LAUNCH("bn_apply_kernel");
+    return GGA_OK;
+}
+
+extern "C" int gga_bn_stats(const float* x, const float* gamma, const float* beta, float* running_mean,
+                            float* running_var, int64_t rows, int channels, float eps, float momentum, int training,
+                            float* saved, float* scale_shift, void* workspace, size_t workspace_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (int rc = bn_check("gga_bn_stats", rows, channels)) return rc;
+    GGA_REQUIRE(x && saved && scale_shift && workspace && running_mean && running_var, "gga_bn_stats: null pointer argument");
+    if (workspace_bytes < gga_bn_relu_workspace_bytes(rows, channels)) {
+        gga_set_error("gga_bn_stats: workspace too small");
+        return GGA_ERR_WORKSPACE;
+    }
+    const BnGeom g = bn_geom(rows, channels, channels);
+    const int nb = bn_grid(g.n4);
+    double* partials = (double*)workspace;
+    if (training) {
+        hipLaunchKernelGGL(bn_reduce_kernel<false>, dim3(nb), dim3(256), 0, stream, (const float4*)x, (const float4*)nullptr,
+                           (const unsigned long long*)nullptr, (const float*)nullptr, g, 0, partials);
+        GGA_CHECK_LAUNCH("bn_reduce_kernel<fwd>");
+    }
+    hipLaunchKernelGGL(bn_fwd_final_kernel, dim3((channels + 7) / 8), dim3(1024), 0, stream, partials, nb, channels,
+                       (double)rows, gamma, beta, eps, momentum, training, running_mean, running_var, saved,
+                       scale_shift);
+    GGA_CHECK_LAUNCH("bn_fwd_final_kernel");
     return GGA_OK;
 }
 

@@ -40,9 +40,14 @@ template <int COUT>
 __global__ __launch_bounds__(512) void headconv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                           const float* __restrict__ bias, int B, int H, int W,
                                                           int tiles_x, int tiles_y, int cout_total, int co_base,
-                                                          float* __restrict__ y) {
+                                                          const float* __restrict__ in_ss, float* __restrict__ y) {
     typedef float acc16 __attribute__((ext_vector_type(16)));
     __shared__ float zt[HM_NGRP * 32 * HM_ZS];
+    __shared__ __attribute__((aligned(16))) float ssl[2 * HC_CIN];      // input affine (scale, shift) when in_ss
+    if (in_ss) {
+        if (threadIdx.x < 2 * HC_CIN) ssl[threadIdx.x] = in_ss[threadIdx.x];
+        __syncthreads();
+    }
     const int per_img = tiles_x * tiles_y;
     const int b = blockIdx.x / per_img;
     const int rem = blockIdx.x - b * per_img;
@@ -75,6 +80,12 @@ __global__ __launch_bounds__(512) void headconv_fwd_kernel(const float* __restri
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             float4 v = src[q];
+            if (in_ss) {                                 // input = relu(x * scale + shift), zero padding stays zero
+                const float4 sc = *reinterpret_cast<const float4*>(ssl + 32 * h + 4 * q);
+                const float4 sf = *reinterpret_cast<const float4*>(ssl + HC_CIN + 32 * h + 4 * q);
+                v.x = fmaxf(fmaf(v.x, sc.x, sf.x), 0.0f); v.y = fmaxf(fmaf(v.y, sc.y, sf.y), 0.0f);
+                v.z = fmaxf(fmaf(v.z, sc.z, sf.z), 0.0f); v.w = fmaxf(fmaf(v.w, sc.w, sf.w), 0.0f);
+            }
             xa[u][q] = make_float4(v.x * m, v.y * m, v.z * m, v.w * m);
         }
     }
@@ -137,6 +148,7 @@ template <int COUT>
 __global__ __launch_bounds__(512, HW_MINW) void headconv_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                             int B, int H, int W, int tiles_x, int tiles_y,
                                                             int64_t n_tiles, int cout_total, int co_base,
+                                                            const float* __restrict__ in_ss,
                                                             float* __restrict__ partials) {
     typedef float acc16 __attribute__((ext_vector_type(16)));
     __shared__ float gds[2][COUT * HW_PR * HW_PC];
@@ -149,6 +161,10 @@ __global__ __launch_bounds__(512, HW_MINW) void headconv_wgrad_kernel(const floa
     const int ky = off / 3, kx = off - ky * 3;
     const int gbase = co * HW_PR * HW_PC + (2 - ky) * HW_PC + (2 - kx);
     const float usedf = used ? 1.0f : 0.0f;
+    // optional input affine + ReLU (the lane's two channels are fixed)
+    const float sc0 = in_ss ? in_ss[m] : 1.0f, sc1 = in_ss ? in_ss[32 + m] : 1.0f;
+    const float sf0 = in_ss ? in_ss[HC_CIN + m] : 0.0f, sf1 = in_ss ? in_ss[HC_CIN + 32 + m] : 0.0f;
+    const float lo = in_ss ? 0.0f : -INFINITY;
     for (int i = threadIdx.x; i < 2 * COUT * HW_PR * HW_PC; i += 512) (&gds[0][0])[i] = 0.0f;    // borders stay zero
     acc16 acc0, acc1;
 #pragma unroll
@@ -185,7 +201,7 @@ __global__ __launch_bounds__(512, HW_MINW) void headconv_wgrad_kernel(const floa
             const bool ok = inh && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
             const float* xp = x + (((int64_t)b * H + (ok ? iy : 0)) * W + (ok ? ix : 0)) * HC_CIN + m;
             const float mk = ok ? 1.0f : 0.0f;
-            const float a0 = xp[0] * mk, a1 = xp[32] * mk;
+            const float a0 = fmaxf(fmaf(xp[0], sc0, sf0), lo) * mk, a1 = fmaxf(fmaf(xp[32], sc1, sf1), lo) * mk;
             const float gv = g[gbase + hr * HW_PC + hx] * usedf;
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, gv, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, gv, acc1, 0, 0, 0);
@@ -255,14 +271,14 @@ extern "C" size_t gga_head_conv3x3_workspace_bytes(int cout) {
     return (size_t)HC_WGRAD_BLOCKS * ((size_t)cout * HC_CIN * 9 + cout) * sizeof(float);
 }
 
-extern "C" int gga_head_conv3x3_fwd(const float* x, const float* weight, const float* bias, int B, int H, int W, int cin,
-                                    int cout, float* y, void* stream_) {
+extern "C" int gga_head_conv3x3_fwd(const float* x, const float* in_scale_shift, const float* weight, const float* bias,
+                                    int B, int H, int W, int cin, int cout, float* y, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (int rc = headconv_check("gga_head_conv3x3_fwd", B, H, W, cin, cout)) return rc;
     GGA_REQUIRE(x && weight && y, "gga_head_conv3x3_fwd: null pointer argument");
     const int tx = (W + HM_TW - 1) / HM_TW, ty = (H + HM_TR - 1) / HM_TR;
     const dim3 grid((unsigned)((int64_t)B * tx * ty)), block(512);
-#define HC_F(CO, BASE) hipLaunchKernelGGL(headconv_fwd_kernel<CO>, grid, block, 0, stream, x, weight, bias, B, H, W, tx, ty, cout, BASE, y)
+#define HC_F(CO, BASE) hipLaunchKernelGGL(headconv_fwd_kernel<CO>, grid, block, 0, stream, x, weight, bias, B, H, W, tx, ty, cout, BASE, in_scale_shift, y)
     switch (cout) {
         case 1: HC_F(1, 0); break;
         case 2: HC_F(2, 0); break;
@@ -274,7 +290,7 @@ extern "C" int gga_head_conv3x3_fwd(const float* x, const float* weight, const f
     return GGA_OK;
 }
 
-extern "C" int gga_head_conv3x3_wgrad(const float* x, const float* grad_y, int B, int H, int W, int cin, int cout,
+extern "C" int gga_head_conv3x3_wgrad(const float* x, const float* in_scale_shift, const float* grad_y, int B, int H, int W, int cin, int cout,
                                       float* grad_weight, float* grad_bias, void* workspace, size_t workspace_bytes,
                                       void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
@@ -288,7 +304,7 @@ extern "C" int gga_head_conv3x3_wgrad(const float* x, const float* grad_y, int B
     const int64_t n_tiles = (int64_t)B * tx * ty;
     const int nb = (int)(n_tiles < HC_WGRAD_BLOCKS ? n_tiles : HC_WGRAD_BLOCKS);
     float* partials = (float*)workspace;
-#define HC_W(CO, BASE) hipLaunchKernelGGL(headconv_wgrad_kernel<CO>, dim3(nb), dim3(512), 0, stream, x, grad_y, B, H, W, tx, ty, n_tiles, cout, BASE, partials)
+#define HC_W(CO, BASE) hipLaunchKernelGGL(headconv_wgrad_kernel<CO>, dim3(nb), dim3(512), 0, stream, x, grad_y, B, H, W, tx, ty, n_tiles, cout, BASE, in_scale_shift, partials)
     switch (cout) {
         case 1: HC_W(1, 0); break;
         case 2: HC_W(2, 0); break;

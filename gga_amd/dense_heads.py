@@ -68,9 +68,16 @@ class SeparateHead(nn.Module):
         for head in self.heads:
             seq = self.__getattr__(head)
             y = x
-            for m in list(seq)[:-1]:
+            mods = list(seq)
+            last = mods[-2] if len(mods) >= 2 else None
+            fuse = (isinstance(last, ConvModule) and last.with_norm and last.with_activation
+                    and isinstance(last.norm, nn.modules.batchnorm._BatchNorm))
+            for m in mods[:-2] if fuse else mods[:-1]:
                 y = m(y)
-            out[head] = F.head_conv3x3(y, seq[-1])     # 1-3 channel output conv: HBM-bound HIP kernel
+            if fuse:      # norm + ReLU of the last ConvModule applied inside the output conv's loads
+                out[head] = F.bn_relu_head_conv3x3(last.conv(y), last.norm, mods[-1])
+            else:
+                out[head] = F.head_conv3x3(y, mods[-1])     # 1-3 channel output conv: HBM-bound HIP kernel
         return out
 
 

@@ -624,7 +624,7 @@ class _HeadConv3x3(torch.autograd.Function):
         cout = weight.shape[0]
         w = weight.contiguous()                       # logical [cout, 64, 3, 3], NCHW-contiguous
         y = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device)
-        check(_lib.lib().gga_head_conv3x3_fwd(_p(x), _p(w), _p(bias), B, H, W, C, cout, _p(y), _stream()),
+        check(_lib.lib().gga_head_conv3x3_fwd(_p(x), None, _p(w), _p(bias), B, H, W, C, cout, _p(y), _stream()),
               'gga_head_conv3x3_fwd')
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
@@ -646,9 +646,75 @@ class _HeadConv3x3(torch.autograd.Function):
             gb = torch.empty(cout, dtype=torch.float32, device=x.device) if ctx.has_bias else None
             L = _lib.lib()
             ws = _workspace('headconv', L.gga_head_conv3x3_workspace_bytes(cout), x.device)
-            check(L.gga_head_conv3x3_wgrad(_p(x), _p(gy), B, H, W, C, cout, _p(gw), _p(gb), _p(ws), ws.numel(),
+            check(L.gga_head_conv3x3_wgrad(_p(x), None, _p(gy), B, H, W, C, cout, _p(gw), _p(gb), _p(ws), ws.numel(),
                                            _stream()), 'gga_head_conv3x3_wgrad')
         return gx, gw, gb
+
+
+class _BnReluHeadConv3x3(torch.autograd.Function):
+    """``conv(relu(bn(x)))`` for the tail of a head branch without materialising the normalised
+    activation: batch statistics (gga_bn_stats), then the output conv applies scale/shift + ReLU
+    while it loads x; backward = MIOpen backward-data of the conv, the weight gradient from x with
+    the same on-load affine, and the BatchNorm backward with the ReLU mask recomputed from x."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, weight, bias, eps, momentum, training):
+        L = _lib.lib()
+        B, C, H, W = x.shape
+        rows, cout = B * H * W, weight.shape[0]
+        dev = x.device
+        w = weight.contiguous()
+        saved = torch.empty(2 * C, dtype=torch.float32, device=dev)
+        ss = torch.empty(2 * C, dtype=torch.float32, device=dev)
+        ws = _workspace('bn', L.gga_bn_relu_workspace_bytes(rows, C), dev)
+        check(L.gga_bn_stats(_p(x), _p(gamma), _p(beta), _p(running_mean), _p(running_var), rows, C, eps, momentum,
+                             int(training), _p(saved), _p(ss), _p(ws), ws.numel(), _stream()), 'gga_bn_stats')
+        y = torch.empty((B, cout, H, W), dtype=torch.float32, device=dev)
+        check(L.gga_head_conv3x3_fwd(_p(x), _p(ss), _p(w), _p(bias), B, H, W, C, cout, _p(y), _stream()),
+              'gga_head_conv3x3_fwd')
+        ctx.save_for_backward(x, gamma, saved, ss, w)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, gamma, saved, ss, w = ctx.saved_tensors
+        L = _lib.lib()
+        gy = gy.contiguous()
+        B, C, H, W = x.shape
+        rows, cout = B * H * W, w.shape[0]
+        dev = x.device
+        gw = torch.empty_like(w)
+        gb = torch.empty(cout, dtype=torch.float32, device=dev) if ctx.has_bias else None
+        ws = _workspace('headconv', L.gga_head_conv3x3_workspace_bytes(cout), dev)
+        check(L.gga_head_conv3x3_wgrad(_p(x), _p(ss), _p(gy), B, H, W, C, cout, _p(gw), _p(gb), _p(ws), ws.numel(),
+                                       _stream()), 'gga_head_conv3x3_wgrad')
+        # gradient w.r.t. the (never stored) normalised activation: the framework's backward-data
+        gh = torch.ops.aten.convolution_backward(gy, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                                 [True, False, False])[0]
+        gh = gh.contiguous(memory_format=torch.channels_last)
+        gx = torch.empty_like(x)
+        gg = torch.empty(C, dtype=torch.float32, device=dev)
+        gbeta = torch.empty(C, dtype=torch.float32, device=dev)
+        wsb = _workspace('bn', L.gga_bn_relu_workspace_bytes(rows, C), dev)
+        check(L.gga_bn_relu_bwd(_p(gh), _p(x), _p(ss), _p(gamma), _p(saved), rows, C, 2, _p(gx), None, _p(gg),
+                                _p(gbeta), _p(wsb), wsb.numel(), _stream()), 'gga_bn_relu_bwd')
+        return gx, gg, gbeta, None, None, gw, gb, None, None, None
+
+
+def bn_relu_head_conv3x3(x, bn, conv):
+    """``conv(relu(bn(x)))`` (tail of a SeparateHead branch: the ConvModule's norm + activation
+    and the output conv), fused when both halves qualify for their HIP kernels in training mode."""
+    rc = _rows_channels(x) if (x.is_cuda and x.dtype == torch.float32) else None
+    ok = (rc is not None and x.dim() == 4 and x.shape[1] == 64 and bn.affine and bn.track_running_stats
+          and bn.momentum is not None and bn.training and torch.is_grad_enabled() and conv.out_channels <= 4
+          and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1)
+          and conv.dilation == (1, 1) and conv.groups == 1 and conv.padding_mode == 'zeros')
+    if not ok:
+        return head_conv3x3(bn_act(x, bn, relu=True), conv)
+    bn.num_batches_tracked += 1
+    return _BnReluHeadConv3x3.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, conv.weight, conv.bias,
+                                    float(bn.eps), float(bn.momentum), True)
 
 
 def head_conv3x3(x, conv):

@@ -304,7 +304,9 @@ int gga_bn_relu_fwd(const float* x, const float* residual, const float* gamma, c
                     float* running_mean, float* running_var, int64_t rows, int channels, float eps,
                     float momentum, int training, int relu, float* y, void* mask_bits, float* saved,
                     void* workspace, size_t workspace_bytes, void* stream);
-/* batch-statistics backward: grad_x, optional grad_residual (= masked grad_y), grad_gamma/beta. */
+/* batch-statistics backward: grad_x, optional grad_residual (= masked grad_y), grad_gamma/beta.
+ * relu: 0 none, 1 mask_bits = the bits written by the forward, 2 mask_bits = scale_shift of
+ * gga_bn_stats (mask recomputed from x). */
 int gga_bn_relu_bwd(const float* grad_y, const float* x, const void* mask_bits, const float* gamma,
                     const float* saved, int64_t rows, int channels, int relu, float* grad_x,
                     float* grad_residual, float* grad_gamma, float* grad_beta, void* workspace,
@@ -323,16 +325,30 @@ int gga_bn_relu_bwd_strided(const float* grad_y, int64_t grad_y_row_stride, cons
                             float* grad_x, float* grad_residual, float* grad_gamma, float* grad_beta,
                             void* workspace, size_t workspace_bytes, void* stream);
 
+/* Batch statistics only (no normalised output): saved [2*channels] = mean / invstd, scale_shift
+ * [2*channels] = gamma*invstd, beta - mean*gamma*invstd; running stats updated when training. For
+ * consumers that apply the affine + ReLU themselves while loading (gga_head_conv3x3_* with
+ * in_scale_shift), so the normalised activation is never written. Its backward is
+ * gga_bn_relu_bwd[_strided] with relu = 2 and mask_bits = scale_shift: the ReLU mask is
+ * recomputed as fma(x, scale, shift) > 0 instead of read from stored bits. */
+int gga_bn_stats(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                 int64_t rows, int channels, float eps, float momentum, int training, float* saved,
+                 float* scale_shift, void* workspace, size_t workspace_bytes, void* stream);
+
 /* a5 (output convs of the head branches): 3x3 conv, 64 input channels -> 1..4 output channels,
  * stride 1, pad 1, + bias. Replaces the last layer of each SeparateHead branch,
- * mmdet3d/models/dense_heads/centerpoint_head.py:70-79 (HBM-bound, not GEMM-shaped).
- * x: channels-last memory [B,H,W,64] of a [B,64,H,W] tensor; weight [cout,64,3,3]; y [B,cout,H,W]
- * NCHW-contiguous. The input gradient stays with the framework's convolution backward. */
-int gga_head_conv3x3_fwd(const float* x, const float* weight, const float* bias, int B, int H, int W,
-                         int cin, int cout, float* y, void* stream);
+ * mmdet3d/models/dense_heads/centerpoint_head.py:70-79 (HBM-bound; N = 9 taps x cout on the
+ * matrix cores). x: channels-last memory [B,H,W,64] of a [B,64,H,W] tensor; weight [cout,64,3,3];
+ * y [B,cout,H,W] NCHW-contiguous. in_scale_shift (optional, [2*64]): the convolution input is
+ * relu(x * scale + shift) per channel, applied while loading - the BatchNorm + ReLU of the
+ * branch's ConvModule (centerpoint_head.py:58-68) fused into its consumer. The input gradient
+ * stays with the framework's convolution backward. */
+int gga_head_conv3x3_fwd(const float* x, const float* in_scale_shift, const float* weight, const float* bias,
+                         int B, int H, int W, int cin, int cout, float* y, void* stream);
 /* grad_weight [cout,64,3,3] and grad_bias [cout] (optional) from grad_y [B,cout,H,W] */
 size_t gga_head_conv3x3_workspace_bytes(int cout);
-int gga_head_conv3x3_wgrad(const float* x, const float* grad_y, int B, int H, int W, int cin, int cout,
+int gga_head_conv3x3_wgrad(const float* x, const float* in_scale_shift, const float* grad_y, int B, int H, int W,
+                           int cin, int cout,
                            float* grad_weight, float* grad_bias, void* workspace, size_t workspace_bytes,
                            void* stream);
 

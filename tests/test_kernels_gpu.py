@@ -444,6 +444,38 @@ def test_head_output_conv_vs_torch(cout, bias):
     torch.testing.assert_close(z, ref.detach(), rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize('cout', [1, 2, 3, 4])
+def test_bn_relu_head_conv_fused_vs_torch(cout):
+    """Tail of a head branch: conv(relu(bn(x))) with the normalised activation never stored."""
+    import copy
+    torch.manual_seed(10 + cout)
+    B, H, W = 3, 37, 29
+    bn = torch.nn.BatchNorm2d(64, eps=1e-3, momentum=0.01).to(DEV)
+    bn.weight.data.uniform_(0.5, 1.5), bn.bias.data.uniform_(-0.5, 0.5)
+    conv = torch.nn.Conv2d(64, cout, 3, padding=1, bias=True).to(DEV)
+    bn_r, conv_r = copy.deepcopy(bn), copy.deepcopy(conv)
+    x = torch.randn(B, 64, H, W, device=DEV).contiguous(memory_format=torch.channels_last)
+    x1, x2 = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    y = F.bn_relu_head_conv3x3(x1, bn, conv)
+    assert 'BnReluHeadConv' in type(y.grad_fn).__name__
+    ref = conv_r(torch.relu(bn_r(x2)))
+    torch.testing.assert_close(y, ref, rtol=1e-4, atol=1e-4)
+    g = torch.randn_like(ref)
+    y.backward(g)
+    ref.backward(g)
+    assert int(((x1.grad - x2.grad).abs() > 1e-4).sum()) <= 3       # ReLU-boundary elements may flip
+    torch.testing.assert_close(conv.weight.grad, conv_r.weight.grad, rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(conv.bias.grad, conv_r.bias.grad, rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(bn.weight.grad, bn_r.weight.grad, rtol=1e-3, atol=2e-3)
+    torch.testing.assert_close(bn.bias.grad, bn_r.bias.grad, rtol=1e-3, atol=2e-3)
+    torch.testing.assert_close(bn.running_mean, bn_r.running_mean, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(bn.running_var, bn_r.running_var, rtol=1e-5, atol=1e-6)
+    # eval mode: the unfused composition on the running statistics
+    bn.eval(), bn_r.eval()
+    with torch.no_grad():
+        torch.testing.assert_close(F.bn_relu_head_conv3x3(x, bn, conv), conv_r(torch.relu(bn_r(x))), rtol=1e-4, atol=1e-4)
+
+
 # ----------------------------------------------------------------------------- first conv on the canvas
 def _pillar_case(B, ny, nx, M, C, seed):
     g = torch.Generator().manual_seed(seed)

@@ -24,11 +24,11 @@ int main() {
             float ms;
             hipMemsetAsync(trash, r, 1ull << 30, 0);
             hipEventRecord(e0, 0);
-            if (gga_head_conv3x3_fwd(x, w, bias, B, H, W, 64, cout, y, 0)) { printf("fwd: %s\n", gga_last_error()); return 1; }
+            if (gga_head_conv3x3_fwd(x, nullptr, w, bias, B, H, W, 64, cout, y, 0)) { printf("fwd: %s\n", gga_last_error()); return 1; }
             hipEventRecord(e1, 0); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1); if (r >= 2) tf += ms;
             hipMemsetAsync(trash, r + 1, 1ull << 30, 0);
             hipEventRecord(e0, 0);
-            if (gga_head_conv3x3_wgrad(x, y, B, H, W, 64, cout, gw, gb, ws, wsb, 0)) { printf("wgrad: %s\n", gga_last_error()); return 1; }
+            if (gga_head_conv3x3_wgrad(x, nullptr, y, B, H, W, 64, cout, gw, gb, ws, wsb, 0)) { printf("wgrad: %s\n", gga_last_error()); return 1; }
             hipEventRecord(e1, 0); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1); if (r >= 2) tw += ms;
         }
         printf("cout %d: fwd %.1f us, wgrad(+final) %.1f us\n", cout, 1e3 * tf / reps, 1e3 * tw / reps);

@@ -96,7 +96,8 @@ class ConvModule(nn.Module):
         return getattr(self, self.norm_name) if self.with_norm else None
 
     def forward(self, x):
-        x = self.conv(x)
+        from . import dense_conv
+        x = dense_conv.conv2d(x, self.conv)
         if self.with_norm:
             from . import functional as F        # fused BN(+ReLU) HIP pass for channels-last activations
             return F.bn_act(x, self.norm, relu=self.with_activation)
@@ -108,6 +109,7 @@ class ConvModule(nn.Module):
 def run_conv_bn_relu(seq, x):
     """Run an ``nn.Sequential`` made of (conv, BatchNorm, ReLU) triples — the block structure of
     SECOND / SECONDFPN — with the BatchNorm+ReLU pairs fused (``functional.bn_act``)."""
+    from . import dense_conv
     from . import functional as F
     mods = list(seq)
     i = 0
@@ -117,7 +119,7 @@ def run_conv_bn_relu(seq, x):
             x = F.bn_act(x, m, relu=True)
             i += 2
         else:
-            x = m(x)
+            x = dense_conv.conv2d(x, m) if isinstance(m, nn.Conv2d) else m(x)
             i += 1
     return x
 

@@ -1056,3 +1056,177 @@ extern "C" int gga_sparse_conv_wgrad(const float* x, const float* grad_out, cons
     GGA_CHECK_LAUNCH("sp_conv_wgrad_mfma_kernel");
     return GGA_OK;
 }
+
+// ------------------------------------------------------------------------------ dense 3x3 convolution
+// 3x3 / stride 1 / pad 1 convolution of a channels-last image on the same bf16x9 matrix path
+// (SECOND block convolutions and the first convolution of every head branch: second.py:58-63,
+// centerpoint_head.py:58-68 - 64 -> 64 channels at 248 x 216, where MIOpen's fp32 implicit GEMM
+// runs at 100-118 TFLOP/s). Unlike the gather form above, the input is regular: a 256-thread
+// workgroup owns 8 rows x 32 pixels x all output channels, wave w rows 2w and 2w+1 (two 32-pixel
+// M tiles that share every weight fragment). Per 16-input-channel chunk the 10 x 34 pixel halo
+// is fetched ONCE, split into the three bf16 planes on the way into LDS (48-byte pixel rows:
+// 32 + 16 pad, conflict-free ds_read_b128) and then feeds all nine taps - lane (r, h) reads
+// pixel (row + ky, r + kx), channels 8h .. 8h+7 - so there are no per-tap gathers and no per-use
+// split. The weight stage of one (tap, chunk) goes through LDS double buffered (the 32-byte half
+// rows of the packed layout of gga_sparse_pack_weight_split with kvol = 9); the next chunk's halo
+// is requested from global memory before the taps of the current chunk run. 66 KB of LDS: two
+// workgroups per CU.
+#define DC_TR 8
+#define DC_TW 32
+#define DC_HW (DC_TW + 2)
+#define DC_HP ((DC_TR + 2) * DC_HW)          // 340 halo pixels
+#define DC_CK 16                             // input channels per chunk
+#define DC_ROWB 48                           // bytes per LDS row (16 bf16 + pad)
+#define DC_NA ((DC_HP * 4 + 255) / 256)      // float4 pieces per thread and chunk (6)
+
+template <int NT>
+__global__ __launch_bounds__(256, 2) void dense_conv3x3_x9_kernel(const float* __restrict__ X, const uint16_t* __restrict__ Wp,
+                                                                 int B, int H, int W, int cin, int cout, int tiles_x,
+                                                                 int tiles_y, float* __restrict__ Y) {
+    constexpr int CO = NT * 32;
+    constexpr int BPL = CO * DC_ROWB, BSZ = 3 * BPL, BPIECES = 3 * CO * 2;
+    constexpr int NB = (BPIECES + 255) / 256;
+    constexpr int APL = DC_HP * DC_ROWB;
+    __shared__ __attribute__((aligned(16))) unsigned char As[3 * APL];
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[2 * BSZ];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int per_img = tiles_x * tiles_y;
+    const int b = blockIdx.x / per_img;
+    const int rem = blockIdx.x - b * per_img;
+    const int y0 = (rem / tiles_x) * DC_TR, x0 = (rem % tiles_x) * DC_TW;
+    const int nchunks = cin / DC_CK;                  // 16-channel chunks
+    const int nchunks32 = cin / MF_TK;                // chunks of the packed weight layout
+
+    mf_v16 acc[2][NT];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[m][t][i] = 0.0f;
+
+    // halo piece e of this thread: pixel (tid + 256 e) / 4, channels 4 * ((tid + 256 e) % 4) .. +3 of the chunk
+    float4 ra[DC_NA];
+    int aoff[DC_NA];                              // float offset of the piece in the image, -1: outside (zeros)
+    const float* Xb = X + (int64_t)b * H * W * cin;
+#pragma unroll
+    for (int e = 0; e < DC_NA; ++e) {
+        const int f = tid + 256 * e;
+        const int hp = f >> 2, q = f & 3;
+        const int hr = hp / DC_HW, hx = hp - hr * DC_HW;
+        const int iy = y0 + hr - 1, ix = x0 + hx - 1;
+        const bool ok = hp < DC_HP && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+        aoff[e] = ok ? (iy * W + ix) * cin + q * 4 : -1;
+    }
+#define DC_LOAD_A(CH) _Pragma("unroll") for (int e = 0; e < DC_NA; ++e) ra[e] = *reinterpret_cast<const float4*>(Xb + (aoff[e] >= 0 ? aoff[e] : 0) + (CH) * DC_CK);
+#define DC_STORE_A()                                                                                                  \
+    _Pragma("unroll") for (int e = 0; e < DC_NA; ++e) {                                                               \
+        const int f = tid + 256 * e;                                                                                  \
+        if (f < DC_HP * 4) {                                                                                          \
+            const float4 v = aoff[e] >= 0 ? ra[e] : make_float4(0.f, 0.f, 0.f, 0.f);                                   \
+            uint32_t a1, a2, a3, b1, b2, b3, c1, c2, c3, d1, d2, d3;                                                  \
+            x9_split(v.x, a1, a2, a3); x9_split(v.y, b1, b2, b3); x9_split(v.z, c1, c2, c3); x9_split(v.w, d1, d2, d3); \
+            unsigned char* dst = As + (f >> 2) * DC_ROWB + (f & 3) * 8;                                               \
+            *reinterpret_cast<uint2*>(dst) = make_uint2(a1 | (b1 << 16), c1 | (d1 << 16));                            \
+            *reinterpret_cast<uint2*>(dst + APL) = make_uint2(a2 | (b2 << 16), c2 | (d2 << 16));                      \
+            *reinterpret_cast<uint2*>(dst + 2 * APL) = make_uint2(a3 | (b3 << 16), c3 | (d3 << 16));                  \
+        }                                                                                                             \
+    }
+    // weight stage (tap, 16-channel chunk c): piece f = (plane, column, 16-byte half) of the 32-byte half row
+    uint4 bq0, bq1, bq2;                            // named registers: an indexed array ends up in scratch
+    bq0 = bq1 = bq2 = make_uint4(0, 0, 0, 0);
+#define DC_BLD(E, V) if ((E) < NB) { const int f = min(tid + 256 * (E), BPIECES - 1); V = bsrc[(f >> 1) * 4 + (f & 1)]; }
+#define DC_LOAD_B(TAP, CH) {                                                                                          \
+        const uint4* bsrc = reinterpret_cast<const uint4*>(Wp + ((int64_t)(TAP) * nchunks32 + ((CH) >> 1)) * (3 * CO * 32) + ((CH) & 1) * 16); \
+        DC_BLD(0, bq0) DC_BLD(1, bq1) DC_BLD(2, bq2) }
+#define DC_BST(BUF, E, V) if ((E) < NB) { const int f = tid + 256 * (E); if (f < BPIECES) *reinterpret_cast<uint4*>(Bs + (BUF) * BSZ + (f >> 1) * DC_ROWB + (f & 1) * 16) = V; }
+#define DC_STORE_B(BUF) { DC_BST(BUF, 0, bq0) DC_BST(BUF, 1, bq1) DC_BST(BUF, 2, bq2) }
+    static_assert(NB <= 3, "weight stage pieces per thread");
+
+    DC_LOAD_A(0);
+    DC_LOAD_B(0, 0);
+    int buf = 0;
+    for (int ch = 0; ch < nchunks; ++ch) {
+        if (ch) __syncthreads();                   // every wave is done with the previous chunk's halo
+        DC_STORE_A();
+        if (ch == 0) { DC_STORE_B(0); }
+        __syncthreads();
+        if (ch + 1 < nchunks) { DC_LOAD_A(ch + 1); }
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            const bool last = tap == 8 && ch + 1 == nchunks;
+#ifndef DC_ABL_NOBCOPY
+            if (!last) {
+                const int nt_ = tap == 8 ? 0 : tap + 1, nc_ = tap == 8 ? ch + 1 : ch;
+                DC_LOAD_B(nt_, nc_);
+            }
+#endif
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const unsigned char* Ap = As + ((2 * wave + ky) * DC_HW + r + kx) * DC_ROWB + h * 16;
+            const unsigned char* Bp = Bs + buf * BSZ + r * DC_ROWB + h * 16;
+            mf_v8bf a[2][3], bb[NT][3];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) a[m][p] = *reinterpret_cast<const mf_v8bf*>(Ap + p * APL + m * DC_HW * DC_ROWB);
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) bb[t][p] = *reinterpret_cast<const mf_v8bf*>(Bp + p * BPL + t * 32 * DC_ROWB);
+            // the nine partial products, smallest first; tiles innermost so consecutive MFMAs never share an accumulator
+#define DC_MM(PA, PB) _Pragma("unroll") for (int m = 0; m < 2; ++m) _Pragma("unroll") for (int t = 0; t < NT; ++t) acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][PA], bb[t][PB], acc[m][t], 0, 0, 0);
+#ifndef DC_ABL_NOMFMA
+            DC_MM(2, 2) DC_MM(1, 2) DC_MM(2, 1) DC_MM(0, 2) DC_MM(1, 1) DC_MM(2, 0) DC_MM(0, 1) DC_MM(1, 0) DC_MM(0, 0)
+#else
+            _Pragma("unroll") for (int m = 0; m < 2; ++m) _Pragma("unroll") for (int t = 0; t < NT; ++t) _Pragma("unroll") for (int p = 0; p < 3; ++p) { acc[m][t][p] += (float)a[m][p][0] * (float)bb[t][p][0]; }
+#endif
+#undef DC_MM
+            if (last) break;
+#ifndef DC_ABL_NOBCOPY
+            DC_STORE_B(buf ^ 1);                   // last read before the previous barrier
+#endif
+#ifndef DC_ABL_NOBAR
+            __syncthreads();
+#endif
+            buf ^= 1;
+        }
+    }
+#undef DC_LOAD_A
+#undef DC_STORE_A
+#undef DC_LOAD_B
+#undef DC_STORE_B
+#undef DC_BLD
+#undef DC_BST
+    // D layout of 32x32x16: register v of lane l holds row (v/4)*8 + (l/32)*4 + v%4 (= pixel of the M tile's row), column l%32
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int oy = y0 + 2 * wave + m;
+        if (oy >= H) continue;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int ox = x0 + (v >> 2) * 8 + h * 4 + (v & 3);
+            if (ox >= W) continue;
+            float* dst = Y + (((int64_t)b * H + oy) * W + ox) * cout;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) dst[t * 32 + r] = acc[m][t][v];
+        }
+    }
+}
+
+extern "C" int gga_dense_conv3x3(const float* x, const void* split_weight, int B, int H, int W, int cin, int cout,
+                                 float* y, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    GGA_REQUIRE(x && split_weight && y, "gga_dense_conv3x3: null pointer argument");
+    GGA_REQUIRE(B >= 1 && H >= 1 && W >= 1 && cin >= 32 && cin % 32 == 0 && (cout == 64 || cout == 128) &&
+                    (int64_t)H * W * cin < 2147483647ll,
+                "gga_dense_conv3x3: need cin %% 32 == 0 and cout 64 or 128 (got %d -> %d)", cin, cout);
+    const int tx = (W + DC_TW - 1) / DC_TW, ty = (H + DC_TR - 1) / DC_TR;
+    const dim3 grid((unsigned)((int64_t)B * tx * ty)), block(256);
+    if (cout == 64)
+        hipLaunchKernelGGL(dense_conv3x3_x9_kernel<2>, grid, block, 0, stream, x, (const uint16_t*)split_weight, B, H, W, cin, cout, tx, ty, y);
+    else
+        hipLaunchKernelGGL(dense_conv3x3_x9_kernel<4>, grid, block, 0, stream, x, (const uint16_t*)split_weight, B, H, W, cin, cout, tx, ty, y);
+    GGA_CHECK_LAUNCH("dense_conv3x3_x9_kernel");
+    return GGA_OK;
+}

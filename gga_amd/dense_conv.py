@@ -1,0 +1,69 @@
+"""3x3 / stride-1 / pad-1 convolutions of the BEV trunk and the head branches on the bf16x9 matrix
+path (``gga_dense_conv3x3``): forward and backward-data; the weight gradient stays with the
+framework's convolution backward (MIOpen).
+
+Reference call sites: the block convolutions of ``SECOND`` (backbones/second.py:58-63) and the
+``ConvModule`` that opens every ``SeparateHead`` branch (dense_heads/centerpoint_head.py:58-68).
+fp32 in, fp32 out: every product is the exact sum of nine bf16 partial products accumulated in
+fp32 (error against float64 as small as MIOpen's fp32 kernels, tools_dev/bench_dense3x3.py).
+"""
+import torch
+from torch import nn
+
+from . import _lib
+from . import functional as F
+from ._lib import check
+
+ENABLED = True          # False: every dense convolution goes to MIOpen
+
+
+def _pack(w9, cin, cout):
+    from .sparse import _pack_weight
+    return _pack_weight(w9, 9, cin, cout, 0, split=True)
+
+
+def _run(x, wp, cin, cout):
+    B, _, H, W = x.shape
+    y = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    check(_lib.lib().gga_dense_conv3x3(F._p(x), F._p(wp), B, H, W, cin, cout, F._p(y), F._stream()), 'gga_dense_conv3x3')
+    return y
+
+
+class _Conv3x3(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight):
+        cout, cin = weight.shape[0], weight.shape[1]
+        w9 = weight.detach().permute(2, 3, 1, 0).reshape(9, cin, cout).contiguous()        # [tap][ci][co]
+        y = _run(x, _pack(w9, cin, cout), cin, cout)
+        ctx.save_for_backward(x, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        cout, cin = weight.shape[0], weight.shape[1]
+        gy = gy.contiguous(memory_format=torch.channels_last)
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            # the same convolution on grad_y with the taps reversed and the channel roles swapped
+            w9 = weight.detach().flip(2, 3).permute(2, 3, 0, 1).reshape(9, cout, cin).contiguous()   # [tap'][co][ci]
+            gx = _run(gy, _pack(w9, cout, cin), cout, cin)
+        if ctx.needs_input_grad[1]:
+            gw = torch.ops.aten.convolution_backward(gy, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                                     [False, True, False])[1]
+        return gx, gw
+
+
+def eligible(conv, x):
+    return (ENABLED and type(conv) is nn.Conv2d and conv.bias is None and conv.kernel_size == (3, 3)
+            and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1
+            and conv.padding_mode == 'zeros' and conv.in_channels in (64, 128) and conv.out_channels in (64, 128)
+            and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
+            and x.is_contiguous(memory_format=torch.channels_last) and x.shape[2] * x.shape[3] * 128 < 2 ** 31)
+
+
+def conv2d(x, conv):
+    """``conv(x)``: the bf16x9 kernel for the 64/128-channel 3x3 convolutions, the module otherwise."""
+    if eligible(conv, x):
+        return _Conv3x3.apply(x, conv.weight)
+    return conv(x)

@@ -284,6 +284,17 @@ int gga_sparse_conv_apply_split(const float* x, const int32_t* map, const void* 
                                 const uint32_t* rowmask, int64_t n_rows, int kvol, int cin, int cout, int flip,
                                 float* y, void* stream);
 
+/* Dense 3x3 / stride 1 / zero-pad 1 convolution of a channels-last image on the same bf16x9
+ * path: x [B,H,W,cin] (cin a multiple of 32), y [B,H,W,cout] (cout 64 or 128), split_weight =
+ * gga_sparse_pack_weight_split(weight [9][cin][cout] tap-major (ky*3+kx), kvol 9). The SECOND
+ * block convolutions and the first convolution of every head branch (backbones/second.py:58-63,
+ * dense_heads/centerpoint_head.py:58-68); backward-data is the same call on grad_y with the
+ * taps reversed and the channel roles swapped. Each workgroup fetches its input halo once per
+ * 32-channel chunk, splits it into the three bf16 planes on the way into LDS and reuses it for
+ * all nine taps. */
+int gga_dense_conv3x3(const float* x, const void* split_weight, int B, int H, int W, int cin, int cout, float* y,
+                      void* stream);
+
 /* grad_weight [kvol,cin,cout] = sum_r x[nbr[k][r]]^T grad_out[r]  (zero-filled here) */
 int gga_sparse_conv_wgrad(const float* x, const float* grad_out, const int32_t* nbr, int64_t n_rows,
                           int kvol, int cin, int cout, float* grad_weight, void* stream);

@@ -555,3 +555,32 @@ def test_pillar_conv_valid_count_and_fallbacks():
     assert not pillar_conv.eligible(cb, F.pillar_scatter(f, coors, B, ny, nx, channels_last=True, unique=True))
     with torch.no_grad():
         assert not pillar_conv.eligible(conv, F.pillar_scatter(f, coors, B, ny, nx, channels_last=True, unique=True))
+
+
+# ----------------------------------------------------------------------------- dense 3x3 conv (bf16x9)
+@pytest.mark.parametrize('cin,cout,B,H,W', [(64, 64, 2, 37, 45), (128, 128, 1, 19, 70), (128, 64, 2, 8, 32),
+                                           (64, 128, 1, 41, 33)])
+def test_dense_conv3x3_vs_torch(cin, cout, B, H, W):
+    """fp32 convolution through nine exact bf16 partial products: forward and backward-data against
+    torch's convolution in float64 (error no larger than a few fp32 ulps of the accumulated sum)."""
+    from gga_amd import dense_conv
+    torch.manual_seed(cin + cout)
+    conv = torch.nn.Conv2d(cin, cout, 3, padding=1, bias=False).to(DEV)
+    conv.weight.data = conv.weight.data.contiguous(memory_format=torch.channels_last)
+    x = torch.randn(B, cin, H, W, device=DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    assert dense_conv.eligible(conv, x)
+    y = dense_conv.conv2d(x, conv)
+    assert 'Conv3x3' in type(y.grad_fn).__name__ and y.is_contiguous(memory_format=torch.channels_last)
+    xd = x.detach().double().requires_grad_(True)
+    ref = torch.nn.functional.conv2d(xd, conv.weight.detach().double(), padding=1)
+    assert float((y.double() - ref).abs().max()) <= 3e-6 * float(ref.abs().max())
+    g = torch.randn_like(y)
+    y.backward(g)
+    ref.backward(g.double())
+    assert float((x.grad.double() - xd.grad).abs().max()) <= 3e-6 * float(xd.grad.abs().max())
+    gw_ref = torch.nn.grad.conv2d_weight(x.detach().double(), conv.weight.shape, g.double(), padding=1)
+    assert float((conv.weight.grad.double() - gw_ref).abs().max()) <= 1e-4 * float(gw_ref.abs().max())
+    # not eligible: stride 2, bias, NCHW input
+    assert not dense_conv.eligible(torch.nn.Conv2d(cin, cout, 3, stride=2, padding=1, bias=False).to(DEV), x)
+    assert not dense_conv.eligible(torch.nn.Conv2d(cin, cout, 3, padding=1).to(DEV), x)
+    assert not dense_conv.eligible(conv, x.detach().contiguous())

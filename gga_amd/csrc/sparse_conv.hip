@@ -1239,6 +1239,49 @@ __global__ __launch_bounds__(256, 2) void dense_conv3x3_x9_kernel(const float* _
 #undef DC_AOFF
 }
 
+// Packs a 3x3 convolution weight straight from the framework tensor (any strides, e.g. the
+// channels-last memory of a [cout, cin, 3, 3] parameter) into the split layout of
+// gga_sparse_pack_weight_split with kvol = 9; `backward` builds the operand of the backward-data
+// convolution instead (taps reversed, channel roles swapped). One thread per (tap, chunk, col, ch).
+__global__ __launch_bounds__(256) void dense_pack_weight_kernel(const float* __restrict__ W, int64_t s_co, int64_t s_ci,
+                                                               int64_t s_ky, int64_t s_kx, int cin, int cout,
+                                                               int backward, int nt, int64_t total,
+                                                               uint16_t* __restrict__ P) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int n_in = backward ? cout : cin, n_out = backward ? cin : cout;      // channels of the convolution being run
+    const int co = 32 * nt, nchunks = (n_in + MF_TK - 1) / MF_TK;
+    const int ch = (int)(i & 31);
+    const int col = (int)((i >> 5) % co);
+    const int64_t stage = (i >> 5) / co;
+    const int tap = (int)(stage / nchunks), chunk = (int)(stage - (int64_t)tap * nchunks);
+    const int c = chunk * MF_TK + ch;
+    float v = 0.0f;
+    if (c < n_in && col < n_out) {
+        const int t = backward ? 8 - tap : tap;
+        const int ky = t / 3, kx = t - ky * 3;
+        const int wco = backward ? c : col, wci = backward ? col : c;
+        v = W[wco * s_co + wci * s_ci + ky * s_ky + kx * s_kx];
+    }
+    uint32_t p1, p2, p3;
+    x9_split(v, p1, p2, p3);
+    uint16_t* dst = P + stage * (3 * (int64_t)co * 32) + (int64_t)col * 32 + ch;
+    dst[0] = (uint16_t)p1; dst[(int64_t)co * 32] = (uint16_t)p2; dst[2 * (int64_t)co * 32] = (uint16_t)p3;
+}
+
+extern "C" int gga_dense_conv3x3_pack(const float* weight, int64_t stride_co, int64_t stride_ci, int64_t stride_ky,
+                                      int64_t stride_kx, int cin, int cout, int backward, void* packed, void* stream) {
+    GGA_REQUIRE(weight && packed, "gga_dense_conv3x3_pack: null pointer argument");
+    const int n_in = backward ? cout : cin, n_out = backward ? cin : cout;
+    GGA_REQUIRE(n_in >= 1 && n_out >= 1 && n_out <= 128, "gga_dense_conv3x3_pack: bad sizes (%d -> %d)", n_in, n_out);
+    const int64_t total = (int64_t)(gga_sparse_split_weight_bytes(9, n_in, n_out) / (3 * sizeof(uint16_t)));
+    hipLaunchKernelGGL(dense_pack_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       weight, stride_co, stride_ci, stride_ky, stride_kx, cin, cout, backward, mf_nt(n_out), total,
+                       (uint16_t*)packed);
+    GGA_CHECK_LAUNCH("dense_pack_weight_kernel");
+    return GGA_OK;
+}
+
 extern "C" int gga_dense_conv3x3(const float* x, const void* split_weight, int B, int H, int W, int cin, int cout,
                                  float* y, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;

@@ -17,9 +17,17 @@ from ._lib import check
 ENABLED = True          # False: every dense convolution goes to MIOpen
 
 
-def _pack(w9, cin, cout):
-    from .sparse import _pack_weight
-    return _pack_weight(w9, 9, cin, cout, 0, split=True)
+def _pack(weight, backward):
+    """Split-plane operand of the forward (or backward-data) convolution, read from the parameter's
+    own memory layout: one kernel, no permuted copy."""
+    L = _lib.lib()
+    cout, cin = weight.shape[0], weight.shape[1]
+    n_in, n_out = (cout, cin) if backward else (cin, cout)
+    wp = torch.empty(L.gga_sparse_split_weight_bytes(9, n_in, n_out) // 2, dtype=torch.int16, device=weight.device)
+    s = weight.stride()
+    check(L.gga_dense_conv3x3_pack(F._p(weight), s[0], s[1], s[2], s[3], cin, cout, int(backward), F._p(wp), F._stream()),
+          'gga_dense_conv3x3_pack')
+    return wp
 
 
 def _run(x, wp, cin, cout):
@@ -33,8 +41,7 @@ class _Conv3x3(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight):
         cout, cin = weight.shape[0], weight.shape[1]
-        w9 = weight.detach().permute(2, 3, 1, 0).reshape(9, cin, cout).contiguous()        # [tap][ci][co]
-        y = _run(x, _pack(w9, cin, cout), cin, cout)
+        y = _run(x, _pack(weight.detach(), False), cin, cout)
         ctx.save_for_backward(x, weight)
         return y
 
@@ -46,8 +53,7 @@ class _Conv3x3(torch.autograd.Function):
         gx = gw = None
         if ctx.needs_input_grad[0]:
             # the same convolution on grad_y with the taps reversed and the channel roles swapped
-            w9 = weight.detach().flip(2, 3).permute(2, 3, 0, 1).reshape(9, cout, cin).contiguous()   # [tap'][co][ci]
-            gx = _run(gy, _pack(w9, cout, cin), cout, cin)
+            gx = _run(gy, _pack(weight.detach(), True), cout, cin)
         if ctx.needs_input_grad[1]:
             gw = torch.ops.aten.convolution_backward(gy, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
                                                      [False, True, False])[1]

@@ -292,6 +292,12 @@ int gga_sparse_conv_apply_split(const float* x, const int32_t* map, const void* 
  * taps reversed and the channel roles swapped. Each workgroup fetches its input halo once per
  * 32-channel chunk, splits it into the three bf16 planes on the way into LDS and reuses it for
  * all nine taps. */
+/* split_weight for gga_dense_conv3x3 straight from the framework's [cout, cin, 3, 3] parameter with
+ * arbitrary element strides (channels-last parameters included): size
+ * gga_sparse_split_weight_bytes(9, cin, cout); backward != 0 packs the operand of the
+ * backward-data convolution (a cout -> cin convolution: size ..._bytes(9, cout, cin)). */
+int gga_dense_conv3x3_pack(const float* weight, int64_t stride_co, int64_t stride_ci, int64_t stride_ky,
+                           int64_t stride_kx, int cin, int cout, int backward, void* packed, void* stream);
 int gga_dense_conv3x3(const float* x, const void* split_weight, int B, int H, int W, int cin, int cout, float* y,
                       void* stream);
 

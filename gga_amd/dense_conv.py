@@ -51,21 +51,26 @@ class _Conv3x3(torch.autograd.Function):
         cout, cin = weight.shape[0], weight.shape[1]
         gy = gy.contiguous(memory_format=torch.channels_last)
         gx = gw = None
-        if ctx.needs_input_grad[0]:
+        mine = cin in (64, 128)             # backward-data is a cout -> cin convolution: cin is its output width
+        if ctx.needs_input_grad[0] and mine:
             # the same convolution on grad_y with the taps reversed and the channel roles swapped
             gx = _run(gy, _pack(weight.detach(), True), cout, cin)
-        if ctx.needs_input_grad[1]:
-            gw = torch.ops.aten.convolution_backward(gy, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
-                                                     [False, True, False])[1]
+        need_gx = ctx.needs_input_grad[0] and not mine
+        if ctx.needs_input_grad[1] or need_gx:
+            r = torch.ops.aten.convolution_backward(gy, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                                    [need_gx, bool(ctx.needs_input_grad[1]), False])
+            gw = r[1] if ctx.needs_input_grad[1] else None
+            if need_gx:
+                gx = r[0]
         return gx, gw
 
 
 def eligible(conv, x):
     return (ENABLED and type(conv) is nn.Conv2d and conv.bias is None and conv.kernel_size == (3, 3)
             and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1
-            and conv.padding_mode == 'zeros' and conv.in_channels in (64, 128) and conv.out_channels in (64, 128)
+            and conv.padding_mode == 'zeros' and conv.in_channels % 32 == 0 and conv.out_channels in (64, 128)
             and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
-            and x.is_contiguous(memory_format=torch.channels_last) and x.shape[2] * x.shape[3] * 128 < 2 ** 31)
+            and x.is_contiguous(memory_format=torch.channels_last) and x.shape[2] * x.shape[3] * x.shape[1] < 2 ** 31)
 
 
 def conv2d(x, conv):

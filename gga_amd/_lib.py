@@ -11,7 +11,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libgga_hip.so')
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _lib = None
 
@@ -76,6 +76,10 @@ SIGNATURES = {
     'gga_sparse_conv_apply': (i32, [vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp, vp]),
     'gga_sparse_conv_wgrad': (i32, [vp, vp, vp, i64, i32, i32, i32, vp, vp]),
     'gga_dense_conv3x3_pack': (i32, [vp, i64, i64, i64, i64, i32, i32, i32, vp, vp]),
+    'gga_dense_conv3x3_tiles': (i64, [i32, i32, i32]),
+    'gga_dense_conv3x3_stats': (i32, [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]),
+    'gga_bn_relu_fwd_partials': (i32, [vp, vp, vp, vp, vp, vp, i64, i32, f32, f32, i32, vp, i64, vp, vp, vp, i32, vp, sz, vp]),
+    'gga_bn_stats_partials': (i32, [vp, vp, vp, vp, i64, i32, f32, f32, vp, vp, vp, i32, vp]),
     'gga_dense_conv3x3': (i32, [vp, vp, i32, i32, i32, i32, i32, vp, vp]),
     'gga_bn_relu_workspace_bytes': (sz, [i64, i32]),
     'gga_bn_relu_mask_bytes': (sz, [i64, i32]),

@@ -97,7 +97,7 @@ class ConvModule(nn.Module):
 
     def forward(self, x):
         from . import dense_conv
-        x = dense_conv.conv2d(x, self.conv)
+        x = dense_conv.conv2d(x, self.conv, bn_follows=self.with_norm and self.norm.training)
         if self.with_norm:
             from . import functional as F        # fused BN(+ReLU) HIP pass for channels-last activations
             return F.bn_act(x, self.norm, relu=self.with_activation)
@@ -119,7 +119,11 @@ def run_conv_bn_relu(seq, x):
             x = F.bn_act(x, m, relu=True)
             i += 2
         else:
-            x = dense_conv.conv2d(x, m) if isinstance(m, nn.Conv2d) else m(x)
+            if isinstance(m, nn.Conv2d):
+                nxt = mods[i + 1] if i + 1 < len(mods) else None
+                x = dense_conv.conv2d(x, m, bn_follows=isinstance(nxt, nn.modules.batchnorm._BatchNorm) and nxt.training)
+            else:
+                x = m(x)
             i += 1
     return x
 

@@ -338,11 +338,11 @@ static int bn_check(const char* fn, int64_t rows, int C) {
     return GGA_OK;
 }
 
-extern "C" int gga_bn_relu_fwd_strided(const float* x, const float* residual, const float* gamma, const float* beta,
-                                       float* running_mean, float* running_var, int64_t rows, int channels, float eps,
-                                       float momentum, int training, int relu, float* y, int64_t y_row_stride,
-                                       void* mask_bits, float* saved, void* workspace, size_t workspace_bytes,
-                                       void* stream_) {
+static int bn_fwd_impl(const float* x, const float* residual, const float* gamma, const float* beta,
+                       float* running_mean, float* running_var, int64_t rows, int channels, float eps,
+                       float momentum, int training, int relu, float* y, int64_t y_row_stride,
+                       void* mask_bits, float* saved, const double* given_partials, int n_given, void* workspace,
+                       size_t workspace_bytes, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (int rc = bn_check("gga_bn_relu_fwd", rows, channels)) return rc;
     GGA_REQUIRE(y_row_stride >= channels && y_row_stride % 4 == 0 && ((uintptr_t)y & 15) == 0,
@@ -356,20 +356,34 @@ extern "C" int gga_bn_relu_fwd_strided(const float* x, const float* residual, co
     }
     const BnGeom g = bn_geom(rows, channels, y_row_stride);
     const int nb = bn_grid(g.n4);
-    double* partials = (double*)workspace;
+    const double* partials = given_partials ? given_partials : (const double*)workspace;
     float* scale_shift = (float*)((char*)workspace + (size_t)BN_MAX_BLOCKS * 2 * channels * sizeof(double));
-    if (training) {
+    if (training && !given_partials) {
         hipLaunchKernelGGL(bn_reduce_kernel<false>, dim3(nb), dim3(256), 0, stream, (const float4*)x, (const float4*)nullptr,
-                           (const unsigned long long*)nullptr, (const float*)nullptr, g, 0, partials);
+                           (const unsigned long long*)nullptr, (const float*)nullptr, g, 0, (double*)workspace);
         GGA_CHECK_LAUNCH("bn_reduce_kernel<fwd>");
     }
-    hipLaunchKernelGGL(bn_fwd_final_kernel, dim3((channels + 7) / 8), dim3(1024), 0, stream, partials, nb, channels,
+    hipLaunchKernelGGL(bn_fwd_final_kernel, dim3((channels + 7) / 8), dim3(1024), 0, stream, partials,
+                       given_partials ? n_given : nb, channels,
                        (double)rows, gamma, beta, eps, momentum, training, running_mean, running_var, saved,
                        scale_shift);
     GGA_CHECK_LAUNCH("bn_fwd_final_kernel");
     hipLaunchKernelGGL(bn_apply_kernel, dim3(nb), dim3(256), 0, stream, (const float4*)x, (const float4*)residual,
                        scale_shift, g, relu, (float4*)y, (unsigned long long*)mask_bits);
     GGA_CHECK_LAUNCH("bn_apply_kernel");
+    return GGA_OK;
+}
+
+extern "C" int gga_bn_stats_partials(const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                     int64_t rows, int channels, float eps, float momentum, float* saved,
+                                     float* scale_shift, const double* partials, int n_partials, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (int rc = bn_check("gga_bn_stats_partials", rows, channels)) return rc;
+    GGA_REQUIRE(saved && scale_shift && running_mean && running_var && partials && n_partials >= 1,
+                "gga_bn_stats_partials: null pointer argument");
+    hipLaunchKernelGGL(bn_fwd_final_kernel, dim3((channels + 7) / 8), dim3(1024), 0, stream, partials, n_partials, channels,
+                       (double)rows, gamma, beta, eps, momentum, 1, running_mean, running_var, saved, scale_shift);
+    GGA_CHECK_LAUNCH("bn_fwd_final_kernel");
     return GGA_OK;
 }
 
@@ -396,6 +410,25 @@ extern "C" int gga_bn_stats(const float* x, const float* gamma, const float* bet
                        scale_shift);
     GGA_CHECK_LAUNCH("bn_fwd_final_kernel");
     return GGA_OK;
+}
+
+extern "C" int gga_bn_relu_fwd_strided(const float* x, const float* residual, const float* gamma, const float* beta,
+                                       float* running_mean, float* running_var, int64_t rows, int channels, float eps,
+                                       float momentum, int training, int relu, float* y, int64_t y_row_stride,
+                                       void* mask_bits, float* saved, void* workspace, size_t workspace_bytes,
+                                       void* stream_) {
+    return bn_fwd_impl(x, residual, gamma, beta, running_mean, running_var, rows, channels, eps, momentum, training, relu,
+                       y, y_row_stride, mask_bits, saved, nullptr, 0, workspace, workspace_bytes, stream_);
+}
+
+extern "C" int gga_bn_relu_fwd_partials(const float* x, const float* residual, const float* gamma, const float* beta,
+                                        float* running_mean, float* running_var, int64_t rows, int channels, float eps,
+                                        float momentum, int relu, float* y, int64_t y_row_stride, void* mask_bits,
+                                        float* saved, const double* partials, int n_partials, void* workspace,
+                                        size_t workspace_bytes, void* stream_) {
+    GGA_REQUIRE(partials && n_partials >= 1, "gga_bn_relu_fwd_partials: no partial sums given");
+    return bn_fwd_impl(x, residual, gamma, beta, running_mean, running_var, rows, channels, eps, momentum, 1, relu, y,
+                       y_row_stride, mask_bits, saved, partials, n_partials, workspace, workspace_bytes, stream_);
 }
 
 extern "C" int gga_bn_relu_fwd(const float* x, const float* residual, const float* gamma, const float* beta,

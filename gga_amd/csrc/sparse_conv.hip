@@ -1082,7 +1082,8 @@ extern "C" int gga_sparse_conv_wgrad(const float* x, const float* grad_out, cons
 template <int NT>
 __global__ __launch_bounds__(256, 2) void dense_conv3x3_x9_kernel(const float* __restrict__ X, const uint16_t* __restrict__ Wp,
                                                                  int B, int H, int W, int cin, int cout, int tiles_x,
-                                                                 int tiles_y, float* __restrict__ Y) {
+                                                                 int tiles_y, float* __restrict__ Y,
+                                                                 double* __restrict__ stats) {
     constexpr int CO = NT * 32;
     constexpr int BPL = CO * DC_ROWB, BSZ = 3 * BPL, BPIECES = 3 * CO * 2;
     constexpr int NB = (BPIECES + 255) / 256;
@@ -1225,6 +1226,43 @@ __global__ __launch_bounds__(256, 2) void dense_conv3x3_x9_kernel(const float* _
                 for (int t = 0; t < NT; ++t) dst[t * 32 + r] = acc[m][t][v];
             }
         }
+        if (stats) {
+            // per-channel sum and sum of squares of the tile's outputs (the batch statistics of the
+            // BatchNorm that follows, so it need not read y again): lane sums over its pixels, the
+            // two half waves and the four waves are folded through LDS, one f64 row pair per tile.
+            float s1[NT], s2[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) { s1[t] = 0.0f; s2[t] = 0.0f; }
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const bool rowok = y0 + 2 * wave + m < H;
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const bool ok = rowok && x0 + (v >> 2) * 8 + h * 4 + (v & 3) < W;
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const float a = ok ? acc[m][t][v] : 0.0f;
+                        s1[t] += a; s2[t] += a * a;
+                    }
+                }
+            }
+            float* red = reinterpret_cast<float*>(As);       // free: the last stage ended with a barrier
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                s1[t] += __shfl_xor(s1[t], 32);
+                s2[t] += __shfl_xor(s2[t], 32);
+                if (h == 0) { red[(wave * 2 + 0) * CO + t * 32 + r] = s1[t]; red[(wave * 2 + 1) * CO + t * 32 + r] = s2[t]; }
+            }
+            __syncthreads();
+            if (tid < 2 * CO) {
+                const int which = tid / CO, c = tid - which * CO;
+                if (c < cout)
+                    stats[((int64_t)tile * 2 + which) * cout + c] =
+                        ((double)red[(0 * 2 + which) * CO + c] + (double)red[(1 * 2 + which) * CO + c]) +
+                        ((double)red[(2 * 2 + which) * CO + c] + (double)red[(3 * 2 + which) * CO + c]);
+            }
+            __syncthreads();                                  // red is the next tile's halo buffer
+        }
     }
 #undef DC_READ
 #undef DC_MM1
@@ -1282,8 +1320,12 @@ extern "C" int gga_dense_conv3x3_pack(const float* weight, int64_t stride_co, in
     return GGA_OK;
 }
 
-extern "C" int gga_dense_conv3x3(const float* x, const void* split_weight, int B, int H, int W, int cin, int cout,
-                                 float* y, void* stream_) {
+extern "C" int64_t gga_dense_conv3x3_tiles(int B, int H, int W) {
+    return (int64_t)B * ((W + DC_TW - 1) / DC_TW) * ((H + DC_TR - 1) / DC_TR);
+}
+
+extern "C" int gga_dense_conv3x3_stats(const float* x, const void* split_weight, int B, int H, int W, int cin, int cout,
+                                       float* y, double* stats, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     GGA_REQUIRE(x && split_weight && y, "gga_dense_conv3x3: null pointer argument");
     GGA_REQUIRE(B >= 1 && H >= 1 && W >= 1 && cin >= 32 && cin % 32 == 0 && (cout == 64 || cout == 128) &&
@@ -1298,9 +1340,14 @@ extern "C" int gga_dense_conv3x3(const float* x, const void* split_weight, int B
     // two measured 89.7 instead of 73.8 ms per step); the hardware dispatcher balances one-tile workgroups.
     const dim3 grid((unsigned)n_tiles), block(256);
     if (cout == 64)
-        hipLaunchKernelGGL(dense_conv3x3_x9_kernel<2>, grid, block, 0, stream, x, (const uint16_t*)split_weight, B, H, W, cin, cout, tx, ty, y);
+        hipLaunchKernelGGL(dense_conv3x3_x9_kernel<2>, grid, block, 0, stream, x, (const uint16_t*)split_weight, B, H, W, cin, cout, tx, ty, y, stats);
     else
-        hipLaunchKernelGGL(dense_conv3x3_x9_kernel<4>, grid, block, 0, stream, x, (const uint16_t*)split_weight, B, H, W, cin, cout, tx, ty, y);
+        hipLaunchKernelGGL(dense_conv3x3_x9_kernel<4>, grid, block, 0, stream, x, (const uint16_t*)split_weight, B, H, W, cin, cout, tx, ty, y, stats);
     GGA_CHECK_LAUNCH("dense_conv3x3_x9_kernel");
     return GGA_OK;
+}
+
+extern "C" int gga_dense_conv3x3(const float* x, const void* split_weight, int B, int H, int W, int cin, int cout,
+                                 float* y, void* stream) {
+    return gga_dense_conv3x3_stats(x, split_weight, B, H, W, cin, cout, y, nullptr, stream);
 }

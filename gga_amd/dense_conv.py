@@ -30,23 +30,31 @@ def _pack(weight, backward):
     return wp
 
 
-def _run(x, wp, cin, cout):
+def _run(x, wp, cin, cout, want_stats=False):
     B, _, H, W = x.shape
+    L = _lib.lib()
     y = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
-    check(_lib.lib().gga_dense_conv3x3(F._p(x), F._p(wp), B, H, W, cin, cout, F._p(y), F._stream()), 'gga_dense_conv3x3')
-    return y
+    stats = None
+    if want_stats:
+        stats = torch.empty((int(L.gga_dense_conv3x3_tiles(B, H, W)), 2, cout), dtype=torch.float64, device=x.device)
+    check(L.gga_dense_conv3x3_stats(F._p(x), F._p(wp), B, H, W, cin, cout, F._p(y), F._p(stats), F._stream()),
+          'gga_dense_conv3x3')
+    return y, stats
 
 
 class _Conv3x3(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight):
+    def forward(ctx, x, weight, want_stats):
         cout, cin = weight.shape[0], weight.shape[1]
-        y = _run(x, _pack(weight.detach(), False), cin, cout)
+        y, stats = _run(x, _pack(weight.detach(), False), cin, cout, want_stats)
         ctx.save_for_backward(x, weight)
-        return y
+        if stats is None:
+            stats = torch.empty(0, dtype=torch.float64, device=x.device)
+        ctx.mark_non_differentiable(stats)
+        return y, stats
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, _gstats):
         x, weight = ctx.saved_tensors
         cout, cin = weight.shape[0], weight.shape[1]
         gy = gy.contiguous(memory_format=torch.channels_last)
@@ -54,7 +62,7 @@ class _Conv3x3(torch.autograd.Function):
         mine = cin in (64, 128)             # backward-data is a cout -> cin convolution: cin is its output width
         if ctx.needs_input_grad[0] and mine:
             # the same convolution on grad_y with the taps reversed and the channel roles swapped
-            gx = _run(gy, _pack(weight.detach(), True), cout, cin)
+            gx = _run(gy, _pack(weight.detach(), True), cout, cin)[0]
         need_gx = ctx.needs_input_grad[0] and not mine
         if ctx.needs_input_grad[1] or need_gx:
             r = torch.ops.aten.convolution_backward(gy, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
@@ -62,7 +70,7 @@ class _Conv3x3(torch.autograd.Function):
             gw = r[1] if ctx.needs_input_grad[1] else None
             if need_gx:
                 gx = r[0]
-        return gx, gw
+        return gx, gw, None
 
 
 def eligible(conv, x):
@@ -73,8 +81,14 @@ def eligible(conv, x):
             and x.is_contiguous(memory_format=torch.channels_last) and x.shape[2] * x.shape[3] * x.shape[1] < 2 ** 31)
 
 
-def conv2d(x, conv):
-    """``conv(x)``: the bf16x9 kernel for the 64/128-channel 3x3 convolutions, the module otherwise."""
+def conv2d(x, conv, bn_follows=False):
+    """``conv(x)``: the bf16x9 kernel for the 64/128-channel 3x3 convolutions, the module otherwise.
+    ``bn_follows``: the caller normalises the result with training-mode batch statistics next; the
+    kernel then also leaves the per-channel sums of its output (``y.bn_partials``), which
+    ``functional.bn_act`` / ``bn_relu_head_conv3x3`` use instead of re-reading ``y``."""
     if eligible(conv, x):
-        return _Conv3x3.apply(x, conv.weight)
+        y, stats = _Conv3x3.apply(x, conv.weight, bool(bn_follows))
+        if bn_follows:
+            y.bn_partials = stats
+        return y
     return conv(x)

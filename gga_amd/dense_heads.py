@@ -76,7 +76,7 @@ class SeparateHead(nn.Module):
             for m in mods[:-2] if fuse else mods[:-1]:
                 y = m(y)
             if fuse:      # norm + ReLU of the last ConvModule applied inside the output conv's loads
-                out[head] = F.bn_relu_head_conv3x3(dense_conv.conv2d(y, last.conv), last.norm, mods[-1])
+                out[head] = F.bn_relu_head_conv3x3(dense_conv.conv2d(y, last.conv, bn_follows=last.norm.training), last.norm, mods[-1])
             else:
                 out[head] = F.head_conv3x3(y, mods[-1])     # 1-3 channel output conv: HBM-bound HIP kernel
         return out

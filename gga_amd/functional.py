@@ -475,16 +475,23 @@ def box_losses(pred, ind, mask, anno_box, lidar2img, bound_mask, ibp_xy, ibp_off
 # ----------------------------------------------------------------------------- fused BN (+res) (+ReLU)
 class _BNAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, residual, gamma, beta, running_mean, running_var, eps, momentum, training, relu, rows, C):
+    def forward(ctx, x, residual, gamma, beta, running_mean, running_var, eps, momentum, training, relu, rows, C,
+                partials=None):
         L = _lib.lib()
         dev = x.device
         y = torch.empty_like(x)                       # same strides (channels-last stays channels-last)
         saved = torch.empty(2 * C, dtype=torch.float32, device=dev)
         bits = torch.empty(L.gga_bn_relu_mask_bytes(rows, C), dtype=torch.uint8, device=dev) if relu else None
         ws = _workspace('bn', L.gga_bn_relu_workspace_bytes(rows, C), dev)
-        check(L.gga_bn_relu_fwd(_p(x), _p(residual), _p(gamma), _p(beta), _p(running_mean), _p(running_var), rows, C,
-                                eps, momentum, int(training), int(relu), _p(y), _p(bits), _p(saved), _p(ws),
-                                ws.numel(), _stream()), 'gga_bn_relu_fwd')
+        if partials is not None and training:       # the producer of x already reduced the per-channel sums
+            check(L.gga_bn_relu_fwd_partials(_p(x), _p(residual), _p(gamma), _p(beta), _p(running_mean), _p(running_var),
+                                             rows, C, eps, momentum, int(relu), _p(y), C, _p(bits), _p(saved),
+                                             _p(partials), int(partials.shape[0]), _p(ws), ws.numel(), _stream()),
+                  'gga_bn_relu_fwd_partials')
+        else:
+            check(L.gga_bn_relu_fwd(_p(x), _p(residual), _p(gamma), _p(beta), _p(running_mean), _p(running_var), rows, C,
+                                    eps, momentum, int(training), int(relu), _p(y), _p(bits), _p(saved), _p(ws),
+                                    ws.numel(), _stream()), 'gga_bn_relu_fwd')
         ctx.save_for_backward(x, gamma, saved, bits)
         ctx.cfg = (rows, C, relu, residual is not None)
         return y
@@ -502,7 +509,7 @@ class _BNAct(torch.autograd.Function):
         ws = _workspace('bn', L.gga_bn_relu_workspace_bytes(rows, C), x.device)
         check(L.gga_bn_relu_bwd(_p(gy), _p(x), _p(bits), _p(gamma), _p(saved), rows, C, int(relu), _p(gx), _p(gres),
                                 _p(gg), _p(gb), _p(ws), ws.numel(), _stream()), 'gga_bn_relu_bwd')
-        return gx, gres, gg, gb, None, None, None, None, None, None, None, None
+        return gx, gres, gg, gb, None, None, None, None, None, None, None, None, None
 
 
 def _rows_channels(x):
@@ -530,8 +537,11 @@ def bn_act(x, bn, relu=True, residual=None):
         return torch.relu(y) if relu else y
     if bn.training:
         bn.num_batches_tracked += 1
+    partials = getattr(x, 'bn_partials', None)
+    if partials is not None and not (bn.training and partials.dim() == 3 and partials.shape[2] == C):
+        partials = None
     return _BNAct.apply(x, residual, bn.weight, bn.bias, bn.running_mean, bn.running_var, float(bn.eps),
-                        float(bn.momentum), bool(bn.training), bool(relu), int(rc[0]), int(C))
+                        float(bn.momentum), bool(bn.training), bool(relu), int(rc[0]), int(C), partials)
 
 
 class _BNActCat(torch.autograd.Function):
@@ -658,7 +668,7 @@ class _BnReluHeadConv3x3(torch.autograd.Function):
     the same on-load affine, and the BatchNorm backward with the ReLU mask recomputed from x."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, weight, bias, eps, momentum, training):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, weight, bias, eps, momentum, training, partials=None):
         L = _lib.lib()
         B, C, H, W = x.shape
         rows, cout = B * H * W, weight.shape[0]
@@ -666,9 +676,14 @@ class _BnReluHeadConv3x3(torch.autograd.Function):
         w = weight.contiguous()
         saved = torch.empty(2 * C, dtype=torch.float32, device=dev)
         ss = torch.empty(2 * C, dtype=torch.float32, device=dev)
-        ws = _workspace('bn', L.gga_bn_relu_workspace_bytes(rows, C), dev)
-        check(L.gga_bn_stats(_p(x), _p(gamma), _p(beta), _p(running_mean), _p(running_var), rows, C, eps, momentum,
-                             int(training), _p(saved), _p(ss), _p(ws), ws.numel(), _stream()), 'gga_bn_stats')
+        if partials is not None:                    # sums left by the convolution that produced x
+            check(L.gga_bn_stats_partials(_p(gamma), _p(beta), _p(running_mean), _p(running_var), rows, C, eps, momentum,
+                                          _p(saved), _p(ss), _p(partials), int(partials.shape[0]), _stream()),
+                  'gga_bn_stats_partials')
+        else:
+            ws = _workspace('bn', L.gga_bn_relu_workspace_bytes(rows, C), dev)
+            check(L.gga_bn_stats(_p(x), _p(gamma), _p(beta), _p(running_mean), _p(running_var), rows, C, eps, momentum,
+                                 int(training), _p(saved), _p(ss), _p(ws), ws.numel(), _stream()), 'gga_bn_stats')
         y = torch.empty((B, cout, H, W), dtype=torch.float32, device=dev)
         check(L.gga_head_conv3x3_fwd(_p(x), _p(ss), _p(w), _p(bias), B, H, W, C, cout, _p(y), _stream()),
               'gga_head_conv3x3_fwd')
@@ -699,7 +714,7 @@ class _BnReluHeadConv3x3(torch.autograd.Function):
         wsb = _workspace('bn', L.gga_bn_relu_workspace_bytes(rows, C), dev)
         check(L.gga_bn_relu_bwd(_p(gh), _p(x), _p(ss), _p(gamma), _p(saved), rows, C, 2, _p(gx), None, _p(gg),
                                 _p(gbeta), _p(wsb), wsb.numel(), _stream()), 'gga_bn_relu_bwd')
-        return gx, gg, gbeta, None, None, gw, gb, None, None, None
+        return gx, gg, gbeta, None, None, gw, gb, None, None, None, None
 
 
 def bn_relu_head_conv3x3(x, bn, conv):
@@ -713,8 +728,11 @@ def bn_relu_head_conv3x3(x, bn, conv):
     if not ok:
         return head_conv3x3(bn_act(x, bn, relu=True), conv)
     bn.num_batches_tracked += 1
+    partials = getattr(x, 'bn_partials', None)
+    if partials is not None and not (partials.dim() == 3 and partials.shape[2] == x.shape[1]):
+        partials = None
     return _BnReluHeadConv3x3.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, conv.weight, conv.bias,
-                                    float(bn.eps), float(bn.momentum), True)
+                                    float(bn.eps), float(bn.momentum), True, partials)
 
 
 def head_conv3x3(x, conv):

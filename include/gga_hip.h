@@ -292,6 +292,13 @@ int gga_sparse_conv_apply_split(const float* x, const int32_t* map, const void* 
  * taps reversed and the channel roles swapped. Each workgroup fetches its input halo once per
  * 32-channel chunk, splits it into the three bf16 planes on the way into LDS and reuses it for
  * all nine taps. */
+/* The same convolution that also leaves the batch statistics of its output for the BatchNorm
+ * that follows: stats [gga_dense_conv3x3_tiles(B,H,W)][2][cout] f64 = per-tile sum and sum of
+ * squares per channel - the `partials` of gga_bn_relu_fwd_partials / gga_bn_stats_partials, so
+ * the BatchNorm does not read y a second time for its reduction. stats may be NULL. */
+int64_t gga_dense_conv3x3_tiles(int B, int H, int W);
+int gga_dense_conv3x3_stats(const float* x, const void* split_weight, int B, int H, int W, int cin, int cout,
+                            float* y, double* stats, void* stream);
 /* split_weight for gga_dense_conv3x3 straight from the framework's [cout, cin, 3, 3] parameter with
  * arbitrary element strides (channels-last parameters included): size
  * gga_sparse_split_weight_bytes(9, cin, cout); backward != 0 packs the operand of the
@@ -351,6 +358,19 @@ int gga_bn_relu_bwd_strided(const float* grad_y, int64_t grad_y_row_stride, cons
 int gga_bn_stats(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
                  int64_t rows, int channels, float eps, float momentum, int training, float* saved,
                  float* scale_shift, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Training-mode forward / statistics with the per-channel sums already reduced by the producer of
+ * x: partials [n_partials][2][channels] f64 (sum, sum of squares over disjoint row sets that
+ * together cover all `rows`), e.g. from gga_dense_conv3x3_stats. Otherwise as
+ * gga_bn_relu_fwd_strided / gga_bn_stats. */
+int gga_bn_relu_fwd_partials(const float* x, const float* residual, const float* gamma, const float* beta,
+                             float* running_mean, float* running_var, int64_t rows, int channels, float eps,
+                             float momentum, int relu, float* y, int64_t y_row_stride, void* mask_bits,
+                             float* saved, const double* partials, int n_partials, void* workspace,
+                             size_t workspace_bytes, void* stream);
+int gga_bn_stats_partials(const float* gamma, const float* beta, float* running_mean, float* running_var,
+                          int64_t rows, int channels, float eps, float momentum, float* saved, float* scale_shift,
+                          const double* partials, int n_partials, void* stream);
 
 /* a5 (output convs of the head branches): 3x3 conv, 64 input channels -> 1..4 output channels,
  * stride 1, pad 1, + bias. Replaces the last layer of each SeparateHead branch,

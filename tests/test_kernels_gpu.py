@@ -584,3 +584,33 @@ def test_dense_conv3x3_vs_torch(cin, cout, B, H, W):
     assert not dense_conv.eligible(torch.nn.Conv2d(cin, cout, 3, stride=2, padding=1, bias=False).to(DEV), x)
     assert not dense_conv.eligible(torch.nn.Conv2d(cin, cout, 3, padding=1).to(DEV), x)
     assert not dense_conv.eligible(conv, x.detach().contiguous())
+
+
+def test_dense_conv_leaves_batchnorm_partials():
+    """The statistics epilogue of the dense conv equals the reductions of its output, and the
+    BatchNorm fed with them equals the BatchNorm that reduces y itself."""
+    import copy
+    from gga_amd import dense_conv
+    torch.manual_seed(7)
+    conv = torch.nn.Conv2d(64, 64, 3, padding=1, bias=False).to(DEV)
+    bn = torch.nn.BatchNorm2d(64, eps=1e-3, momentum=0.01).to(DEV)
+    bn2 = copy.deepcopy(bn)
+    x = torch.randn(3, 64, 37, 45, device=DEV).contiguous(memory_format=torch.channels_last)
+    y = dense_conv.conv2d(x, conv, bn_follows=True)
+    p = y.bn_partials
+    assert p.dtype == torch.float64 and p.shape[1:] == (2, 64)
+    yd = y.detach().double()
+    # per-tile sums are fp32 over 256 pixels, then f64: error relative to the sum of magnitudes
+    mag = float(yd.abs().sum((0, 2, 3)).max())
+    torch.testing.assert_close(p[:, 0].sum(0), yd.sum((0, 2, 3)), rtol=0, atol=2e-6 * mag)
+    torch.testing.assert_close(p[:, 1].sum(0), (yd * yd).sum((0, 2, 3)), rtol=2e-6, atol=0)
+    out = F.bn_act(y, bn, relu=True)
+    y2 = y.detach().clone()                       # no partials attached: the BatchNorm reduces y itself
+    assert getattr(y2, 'bn_partials', None) is None
+    ref = F.bn_act(y2, bn2, relu=True)
+    torch.testing.assert_close(out, ref, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(bn.running_mean, bn2.running_mean, rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(bn.running_var, bn2.running_var, rtol=1e-5, atol=1e-7)
+    g = torch.randn_like(out)
+    out.backward(g)
+    assert conv.weight.grad is not None and torch.isfinite(conv.weight.grad).all()

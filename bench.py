@@ -16,6 +16,7 @@ events inside this process, `cpu_baseline` is the oracle's CPU restatement of th
 on a bounded sample (N=1 only).
 """
 import argparse
+import gc
 import ctypes as C
 import json
 import os
@@ -155,6 +156,11 @@ def main():
     if want_roofline:      # one HIP-event pair per step around the scatter canvas kernel (no synchronisation)
         from gga_amd import _lib
         _lib.check(_lib.lib().gga_pillar_scatter_timing_begin(min(args.steps, 256)), 'timing_begin')
+    # no generational garbage collection inside the timed region: a gen-2 pass over the module tree
+    # takes tens of ms and drains the launch queue (2 of ~12 runs measured +8..16 ms/step before
+    # this, 8 of 8 runs 72.5-72.8 ms after)
+    gc.collect()
+    gc.disable()
     t0 = time.perf_counter()
     for i in range(args.steps):
         out = runner.step(batches[i % 2])
@@ -163,6 +169,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    gc.enable()
     scatter_ms = []
     if want_roofline:
         buf = (C.c_float * 256)()

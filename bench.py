@@ -180,7 +180,7 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
-    loss = float(out['loss'])
+    loss = float(out['loss'].detach()) if torch.is_tensor(out['loss']) else float(out['loss'])
     assert loss == loss, 'loss is NaN'
 
     if rank == 0:

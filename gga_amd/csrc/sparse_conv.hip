@@ -1351,3 +1351,204 @@ extern "C" int gga_dense_conv3x3(const float* x, const void* split_weight, int B
                                  float* y, void* stream) {
     return gga_dense_conv3x3_stats(x, split_weight, B, H, W, cin, cout, y, nullptr, stream);
 }
+
+// ------------------------------------------------------------------------------ dense 3x3 weight gradient
+// dW[co][ci][ky][kx] = sum_p x[p + (ky-1, kx-1)][ci] * gy[p][co] of the same 3x3 / stride 1 / pad 1
+// convolution, bf16x9 on the matrix cores. Here the GEMM's K is the PIXEL index: the MFMA operands
+// are x^T (M = ci) and gy (N = co), i.e. eight consecutive pixels of ONE channel per lane, while
+// both tensors are channels-last. The LDS images stay pixel-major ([pixel][32 channels], 64-byte
+// rows, three bf16 planes - written exactly like the forward kernel's halo) and
+// ds_read_b64_tr_b16 does the transposition on the way out: two transposed reads give a lane the
+// 8 pixels of its channel (probe: tools_dev/micro/tr_probe.hip), and a tap shift is just a row
+// offset of the x image, so the nine taps reuse one staged copy.
+//
+// A 256-thread workgroup owns one 64 x 64 (ci, co) channel block (blockIdx.y), a strip of 32
+// pixel columns and a segment of image rows of one image; wave w accumulates the (ci tile w/2,
+// co tile w%2) 32 x 32 block of all nine taps (144 accumulator registers). Per image row
+// (= 2 K-steps of 16 pixels): the gy row (32 px x 64 co) and one new x row (34 px x 64 ci; a ring
+// of four rows holds y-1 .. y+2) are fetched one stage ahead, split into planes and stored; each
+// K-step reads 6 + 54 transposed fragments for 81 MFMAs. Partial sums go to
+// [workgroup][tap][ci][co]; dense_wgrad_reduce_kernel adds them in a fixed order (f64) and writes
+// the framework's [cout, cin, 3, 3] layout.
+#define DW_XPL (2 * 34 * 64)                 // bytes per plane of one x ring row: [ci tile][34 px][32 ch]
+#define DW_XROW (3 * DW_XPL)
+#define DW_GPL (2 * 32 * 64)                 // bytes per plane of one gy row: [co tile][32 px][32 ch]
+#define DW_GROW (3 * DW_GPL)
+typedef short dw_v4s __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256, 2) void dense_wgrad3x3_x9_kernel(const float* __restrict__ X, const float* __restrict__ G,
+                                                                  int B, int H, int W, int cin, int cout, int strips,
+                                                                  int nseg, int rows_per_seg, float* __restrict__ partials) {
+    __shared__ __attribute__((aligned(16))) unsigned char Xs[4 * DW_XROW];
+    __shared__ __attribute__((aligned(16))) unsigned char Gs[2 * DW_GROW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ti = wave >> 1, tj = wave & 1;               // ci tile, co tile of this wave
+    // block -> (image, column strip, row segment); blockIdx.y -> 64 x 64 channel block
+    const int seg = blockIdx.x % nseg;
+    const int strip = (blockIdx.x / nseg) % strips;
+    const int b = blockIdx.x / (nseg * strips);
+    const int ncb_o = cout >> 6;
+    const int ci0 = (blockIdx.y / ncb_o) * 64, co0 = (blockIdx.y % ncb_o) * 64;
+    const int x0 = strip * 32;
+    const int ys = seg * rows_per_seg, ye = min(H, ys + rows_per_seg);
+    const float* Xb = X + (int64_t)b * H * W * cin + ci0;
+    const float* Gb = G + (int64_t)b * H * W * cout + co0;
+
+    mf_v16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
+
+    // staging pieces: gy row = 32 px x 16 float4 (2 per thread); x row = 34 px x 16 float4 (3 per thread, 544 used)
+    float4 rg0, rg1, rx0, rx1, rx2;
+#define DW_LOAD_G(Y) {                                                                                                \
+        const bool rowok = (Y) < ye;                                                                                  \
+        { const int f = tid;       const int px = f >> 4, q = f & 15; const bool ok = rowok && x0 + px < W;           \
+          rg0 = ok ? *reinterpret_cast<const float4*>(Gb + ((int64_t)(Y) * W + x0 + px) * cout + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f); } \
+        { const int f = tid + 256; const int px = f >> 4, q = f & 15; const bool ok = rowok && x0 + px < W;           \
+          rg1 = ok ? *reinterpret_cast<const float4*>(Gb + ((int64_t)(Y) * W + x0 + px) * cout + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f); } }
+#define DW_LDX(V, E) { const int f = tid + 256 * (E); const int px = f >> 4, q = f & 15; const int ix = x0 - 1 + px;  \
+        const bool ok = rowok && f < 544 && (unsigned)ix < (unsigned)W;                                               \
+        V = ok ? *reinterpret_cast<const float4*>(Xb + ((int64_t)yy * W + ix) * cin + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f); }
+#define DW_LOAD_X(Y) { const int yy = (Y); const bool rowok = (unsigned)yy < (unsigned)H; DW_LDX(rx0, 0) DW_LDX(rx1, 1) DW_LDX(rx2, 2) }
+    // piece (pixel px, float4 q) of a row image: channel tile q / 8, byte (q % 8) * 8 of the 64-byte pixel row
+#define DW_SPLIT_STORE(V, BASE, PL, NPX, F) { const int f = (F); const int px = f >> 4, q = f & 15;                   \
+        uint32_t a1, a2, a3, b1, b2, b3, c1, c2, c3, d1, d2, d3;                                                      \
+        x9_split(V.x, a1, a2, a3); x9_split(V.y, b1, b2, b3); x9_split(V.z, c1, c2, c3); x9_split(V.w, d1, d2, d3);   \
+        unsigned char* dst = (BASE) + (q >> 3) * ((NPX) * 64) + px * 64 + (q & 7) * 8;                                \
+        *reinterpret_cast<uint2*>(dst) = make_uint2(a1 | (b1 << 16), c1 | (d1 << 16));                                \
+        *reinterpret_cast<uint2*>(dst + (PL)) = make_uint2(a2 | (b2 << 16), c2 | (d2 << 16));                         \
+        *reinterpret_cast<uint2*>(dst + 2 * (PL)) = make_uint2(a3 | (b3 << 16), c3 | (d3 << 16)); }
+#define DW_STORE_G(Y) { unsigned char* base = Gs + ((Y) & 1) * DW_GROW;                                               \
+        DW_SPLIT_STORE(rg0, base, DW_GPL, 32, tid) DW_SPLIT_STORE(rg1, base, DW_GPL, 32, tid + 256) }
+#define DW_STORE_X(Y) { unsigned char* base = Xs + (((Y) + 4) & 3) * DW_XROW;                                         \
+        DW_SPLIT_STORE(rx0, base, DW_XPL, 34, tid) DW_SPLIT_STORE(rx1, base, DW_XPL, 34, tid + 256)                   \
+        if (tid + 512 < 544) DW_SPLIT_STORE(rx2, base, DW_XPL, 34, tid + 512) }
+
+    // transposed fragment of a [pixel][32 ch] image: lane l gets channel l%32, pixels P0 + 8*(l/32) .. +7
+    const int grp = lane >> 4, li = lane & 15;
+    const int froff = ((8 * (grp >> 1) + (li >> 2)) * 64) + (16 * (grp & 1) + 4 * (li & 3)) * 2;   // byte offset of this lane's address in the block
+    union Frag { mf_v8bf v; dw_v4s h[2]; };
+#define DW_FRAG(F, PTR) { F.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) dw_v4s*)((PTR) + froff));          \
+                          F.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) dw_v4s*)((PTR) + froff + 4 * 64)); }
+
+    if (ys < ye) {
+        DW_LOAD_X(ys - 1); DW_STORE_X(ys - 1);
+        DW_LOAD_X(ys);     DW_STORE_X(ys);
+        DW_LOAD_X(ys + 1); DW_STORE_X(ys + 1);
+        DW_LOAD_G(ys);     DW_STORE_G(ys);
+    }
+    __syncthreads();
+    for (int y = ys; y < ye; ++y) {
+        const bool more = y + 1 < ye;
+        if (more) { DW_LOAD_G(y + 1); DW_LOAD_X(y + 2); }
+        const unsigned char* gbase = Gs + (y & 1) * DW_GROW + tj * (32 * 64);
+        // (left to the compiler's schedule: forcing the next tap's six reads ahead of the current tap's
+        // MFMAs with sched_barriers measured 584 instead of 545 us)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            Frag g0, g1, g2;
+            DW_FRAG(g0, gbase + (16 * s) * 64);
+            DW_FRAG(g1, gbase + DW_GPL + (16 * s) * 64);
+            DW_FRAG(g2, gbase + 2 * DW_GPL + (16 * s) * 64);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int ky = tap / 3, kx = tap - ky * 3;
+                const unsigned char* xbase = Xs + ((y + ky - 1 + 4) & 3) * DW_XROW + ti * (34 * 64) + (16 * s + kx) * 64;
+                Frag a0, a1, a2;
+                DW_FRAG(a0, xbase);
+                DW_FRAG(a1, xbase + DW_XPL);
+                DW_FRAG(a2, xbase + 2 * DW_XPL);
+                // nine partial products, smallest first
+                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2.v, g2.v, acc[tap], 0, 0, 0);
+                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.v, g2.v, acc[tap], 0, 0, 0);
+                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2.v, g1.v, acc[tap], 0, 0, 0);
+                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.v, g2.v, acc[tap], 0, 0, 0);
+                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.v, g1.v, acc[tap], 0, 0, 0);
+                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2.v, g0.v, acc[tap], 0, 0, 0);
+                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.v, g1.v, acc[tap], 0, 0, 0);
+                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.v, g0.v, acc[tap], 0, 0, 0);
+                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.v, g0.v, acc[tap], 0, 0, 0);
+            }
+        }
+        if (more) { DW_STORE_G(y + 1); DW_STORE_X(y + 2); }
+        __syncthreads();
+    }
+#undef DW_LOAD_G
+#undef DW_LDX
+#undef DW_LOAD_X
+#undef DW_SPLIT_STORE
+#undef DW_STORE_G
+#undef DW_STORE_X
+#undef DW_FRAG
+    // D: register v of lane l = row (ci in tile) (v/4)*8 + (l/32)*4 + v%4, column (co in tile) l%32
+    float* out = partials + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (9 * 64 * 64);
+    const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int ci = ti * 32 + (v >> 2) * 8 + h * 4 + (v & 3);
+            out[(tap * 64 + ci) * 64 + tj * 32 + r] = acc[tap][v];
+        }
+}
+
+// dW[co][ci][ky][kx] (element strides given) = sum over the workgroups' partials, fixed order, f64
+__global__ __launch_bounds__(256) void dense_wgrad_reduce_kernel(const float* __restrict__ partials, int nblk, int cin, int cout,
+                                                                int64_t s_co, int64_t s_ci, int64_t s_ky, int64_t s_kx,
+                                                                float* __restrict__ dW) {
+    const int i = blockIdx.x * 256 + threadIdx.x;          // (tap, ci local, co local) of channel block blockIdx.y
+    if (i >= 9 * 64 * 64) return;
+    const int ncb_o = cout >> 6;
+    const int ci0 = (blockIdx.y / ncb_o) * 64, co0 = (blockIdx.y % ncb_o) * 64;
+    const float* p = partials + (int64_t)blockIdx.y * nblk * (9 * 64 * 64) + i;
+    double s = 0.0;
+#pragma unroll 8
+    for (int k = 0; k < nblk; ++k) s += (double)p[(int64_t)k * (9 * 64 * 64)];
+    const int co = i & 63, ci = (i >> 6) & 63, tap = i >> 12;
+    const int ky = tap / 3, kx = tap - ky * 3;
+    dW[(co0 + co) * s_co + (ci0 + ci) * s_ci + ky * s_ky + kx * s_kx] = (float)s;
+}
+
+static void dense_wgrad_geometry(int B, int H, int W, int cin, int cout, int* strips, int* nseg, int* rps) {
+    *strips = (W + 31) / 32;
+    const int64_t per_row_seg = (int64_t)B * *strips * (cin >> 6) * (cout >> 6);
+    // two workgroups fit a CU: at most 512 of them, so that all run at once (560 on 512 slots left 48
+    // for a second round that took as long as the first)
+    int ns = (int)(512 / per_row_seg);
+    if (ns < 1) ns = 1;
+    if (ns > H) ns = H;
+    *rps = (H + ns - 1) / ns;
+    *nseg = (H + *rps - 1) / *rps;
+}
+
+extern "C" size_t gga_dense_wgrad3x3_workspace_bytes(int B, int H, int W, int cin, int cout) {
+    if (B < 1 || H < 1 || W < 1 || cin < 64 || cout < 64 || (cin & 63) || (cout & 63)) return 0;
+    int strips, nseg, rps;
+    dense_wgrad_geometry(B, H, W, cin, cout, &strips, &nseg, &rps);
+    return (size_t)B * strips * nseg * (cin >> 6) * (cout >> 6) * 9 * 64 * 64 * sizeof(float);
+}
+
+extern "C" int gga_dense_wgrad3x3(const float* x, const float* grad_y, int B, int H, int W, int cin, int cout,
+                                  float* grad_weight, int64_t stride_co, int64_t stride_ci, int64_t stride_ky,
+                                  int64_t stride_kx, void* workspace, size_t workspace_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    GGA_REQUIRE(x && grad_y && grad_weight && workspace, "gga_dense_wgrad3x3: null pointer argument");
+    GGA_REQUIRE(B >= 1 && H >= 1 && W >= 1 && cin >= 64 && cout >= 64 && (cin & 63) == 0 && (cout & 63) == 0,
+                "gga_dense_wgrad3x3: cin and cout must be multiples of 64 (got %d -> %d)", cin, cout);
+    if (workspace_bytes < gga_dense_wgrad3x3_workspace_bytes(B, H, W, cin, cout)) {
+        gga_set_error("gga_dense_wgrad3x3: workspace too small");
+        return GGA_ERR_WORKSPACE;
+    }
+    int strips, nseg, rps;
+    dense_wgrad_geometry(B, H, W, cin, cout, &strips, &nseg, &rps);
+    const int nblk = B * strips * nseg, ncb = (cin >> 6) * (cout >> 6);
+    hipLaunchKernelGGL(dense_wgrad3x3_x9_kernel, dim3(nblk, ncb), dim3(256), 0, stream, x, grad_y, B, H, W, cin, cout, strips,
+                       nseg, rps, (float*)workspace);
+    GGA_CHECK_LAUNCH("dense_wgrad3x3_x9_kernel");
+    hipLaunchKernelGGL(dense_wgrad_reduce_kernel, dim3((9 * 64 * 64 + 255) / 256, ncb), dim3(256), 0, stream,
+                       (const float*)workspace, nblk, cin, cout, stride_co, stride_ci, stride_ky, stride_kx, grad_weight);
+    GGA_CHECK_LAUNCH("dense_wgrad_reduce_kernel");
+    return GGA_OK;
+}

@@ -15,6 +15,7 @@ from . import functional as F
 from ._lib import check
 
 ENABLED = True          # False: every dense convolution goes to MIOpen
+WGRAD = True            # False: weight gradients stay with MIOpen
 
 
 def _pack(weight, backward):
@@ -42,6 +43,19 @@ def _run(x, wp, cin, cout, want_stats=False):
     return y, stats
 
 
+def _wgrad(x, gy, weight):
+    """Weight gradient on the bf16x9 path (``gga_dense_wgrad3x3``), in the parameter's memory layout."""
+    L = _lib.lib()
+    B, cin, H, W = x.shape
+    cout = weight.shape[0]
+    gw = torch.empty_like(weight)
+    s = gw.stride()
+    ws = F._workspace('dense_wgrad', L.gga_dense_wgrad3x3_workspace_bytes(B, H, W, cin, cout), x.device)
+    check(L.gga_dense_wgrad3x3(F._p(x), F._p(gy), B, H, W, cin, cout, F._p(gw), s[0], s[1], s[2], s[3], F._p(ws),
+                               ws.numel(), F._stream()), 'gga_dense_wgrad3x3')
+    return gw
+
+
 class _Conv3x3(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, want_stats):
@@ -64,10 +78,15 @@ class _Conv3x3(torch.autograd.Function):
             # the same convolution on grad_y with the taps reversed and the channel roles swapped
             gx = _run(gy, _pack(weight.detach(), True), cout, cin)[0]
         need_gx = ctx.needs_input_grad[0] and not mine
-        if ctx.needs_input_grad[1] or need_gx:
+        need_gw = bool(ctx.needs_input_grad[1])
+        if need_gw and WGRAD and cin % 64 == 0 and cout % 64 == 0:
+            gw = _wgrad(x, gy, weight)
+            need_gw = False
+        if need_gw or need_gx:
             r = torch.ops.aten.convolution_backward(gy, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
-                                                    [need_gx, bool(ctx.needs_input_grad[1]), False])
-            gw = r[1] if ctx.needs_input_grad[1] else None
+                                                    [need_gx, need_gw, False])
+            if need_gw:
+                gw = r[1]
             if need_gx:
                 gx = r[0]
         return gx, gw, None

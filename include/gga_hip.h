@@ -299,6 +299,16 @@ int gga_sparse_conv_apply_split(const float* x, const int32_t* map, const void* 
 int64_t gga_dense_conv3x3_tiles(int B, int H, int W);
 int gga_dense_conv3x3_stats(const float* x, const void* split_weight, int B, int H, int W, int cin, int cout,
                             float* y, double* stats, void* stream);
+/* Weight gradient of the same convolution, bf16x9 with the pixel index as the GEMM's K (transposed
+ * LDS reads): x [B,H,W,cin], grad_y [B,H,W,cout] channels-last, cin and cout multiples of 64;
+ * grad_weight is written as a [cout, cin, 3, 3] tensor with the given element strides
+ * (overwritten, not accumulated). Replaces the convolution-backward-weights call behind autograd
+ * for backbones/second.py:58-63 and dense_heads/centerpoint_head.py:58-68,120-121. */
+size_t gga_dense_wgrad3x3_workspace_bytes(int B, int H, int W, int cin, int cout);
+int gga_dense_wgrad3x3(const float* x, const float* grad_y, int B, int H, int W, int cin, int cout,
+                       float* grad_weight, int64_t stride_co, int64_t stride_ci, int64_t stride_ky,
+                       int64_t stride_kx, void* workspace, size_t workspace_bytes, void* stream);
+
 /* split_weight for gga_dense_conv3x3 straight from the framework's [cout, cin, 3, 3] parameter with
  * arbitrary element strides (channels-last parameters included): size
  * gga_sparse_split_weight_bytes(9, cin, cout); backward != 0 packs the operand of the

@@ -579,7 +579,7 @@ def test_dense_conv3x3_vs_torch(cin, cout, B, H, W):
     ref.backward(g.double())
     assert float((x.grad.double() - xd.grad).abs().max()) <= 3e-6 * float(xd.grad.abs().max())
     gw_ref = torch.nn.grad.conv2d_weight(x.detach().double(), conv.weight.shape, g.double(), padding=1)
-    assert float((conv.weight.grad.double() - gw_ref).abs().max()) <= 1e-4 * float(gw_ref.abs().max())
+    assert float((conv.weight.grad.double() - gw_ref).abs().max()) <= 1e-5 * float(gw_ref.abs().max())   # bf16x9 weight gradient
     # not eligible: stride 2, bias, NCHW input
     assert not dense_conv.eligible(torch.nn.Conv2d(cin, cout, 3, stride=2, padding=1, bias=False).to(DEV), x)
     assert not dense_conv.eligible(torch.nn.Conv2d(cin, cout, 3, padding=1).to(DEV), x)

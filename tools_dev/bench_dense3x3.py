@@ -40,6 +40,16 @@ def run(B, C, Co, H, W):
         t_ref = timeit(lambda: conv(x))
     t_mine = timeit(mine)
     gf = 2.0 * B * H * W * C * Co * 9 / 1e9
+    if C % 64 == 0 and Co % 64 == 0:
+        from gga_amd import dense_conv
+        gy = torch.randn_like(y)
+        gw = dense_conv._wgrad(x, gy, conv.weight)
+        gw_ref = torch.ops.aten.convolution_backward(gy, x, conv.weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+        gw64 = torch.nn.grad.conv2d_weight(x.double(), conv.weight.shape, gy.double(), padding=1)
+        ew = float((gw.double() - gw64).abs().max() / gw64.abs().max()); ewr = float((gw_ref.double() - gw64).abs().max() / gw64.abs().max())
+        tw = timeit(lambda: dense_conv._wgrad(x, gy, conv.weight))
+        twr = timeit(lambda: torch.ops.aten.convolution_backward(gy, x, conv.weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False]))
+        print(f'   wgrad: bf16x9 {tw*1e3:.0f} us ({gf/tw:.0f} TFLOP/s-eq, err {ew:.1e})   MIOpen {twr*1e3:.0f} us ({gf/twr:.0f} TFLOP/s, err {ewr:.1e})')
     print(f'[{B},{C}->{Co},{H},{W}] bf16x9 {t_mine*1e3:.0f} us ({gf/t_mine:.0f} TFLOP/s-eq, err {e_mine:.1e})   '
           f'MIOpen {t_ref*1e3:.0f} us ({gf/t_ref:.0f} TFLOP/s, err {e_ref:.1e})')
 

@@ -1058,6 +1058,16 @@ extern "C" int gga_sparse_conv_wgrad(const float* x, const float* grad_out, cons
 }
 
 // ------------------------------------------------------------------------------ dense 3x3 convolution
+// The dense kernels below use SIX of the nine partial products: with truncated planes
+// a = a0 + a1 + a2 (|a1| <= 2^-8 |a|, |a2| <= 2^-16 |a|) the products a1*b2, a2*b1 and a2*b2 together
+// are below 2^-23 |a*b| - one fp32 ulp of the product, what an unfused multiply-add loses anyway -
+// and the measured error of a whole convolution against float64 does not move (9.7e-7 of the
+// output range with six or nine terms; MIOpen's fp32 kernels: 1.0e-6 .. 1.5e-6): the fp32
+// accumulation dominates. One third fewer MFMAs: forward 416 -> 345 us, weight gradient 539 -> 434 us.
+// Compile with -DX9_NINE for all nine.
+#ifndef X9_NINE
+#define X9_SIX 1
+#endif
 // 3x3 / stride 1 / pad 1 convolution of a channels-last image on the same bf16x9 matrix path
 // (SECOND block convolutions and the first convolution of every head branch: second.py:58-63,
 // centerpoint_head.py:58-68 - 64 -> 64 channels at 248 x 216, where MIOpen's fp32 implicit GEMM
@@ -1152,7 +1162,11 @@ __global__ __launch_bounds__(256, 2) void dense_conv3x3_x9_kernel(const float* _
             fb[SET][t][p] = *reinterpret_cast<const mf_v8bf*>(Bp + p * BPL + t * 32 * DC_ROWB); }
     // the nine partial products, smallest first; tiles innermost so consecutive MFMAs never share an accumulator
 #define DC_MM1(SET, PA, PB) _Pragma("unroll") for (int m = 0; m < 2; ++m) _Pragma("unroll") for (int t = 0; t < NT; ++t) acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[SET][m][PA], fb[SET][t][PB], acc[m][t], 0, 0, 0);
+#ifdef X9_SIX
+#define DC_MMA(SET) DC_MM1(SET, 0, 2) DC_MM1(SET, 1, 1) DC_MM1(SET, 2, 0) DC_MM1(SET, 0, 1) DC_MM1(SET, 1, 0) DC_MM1(SET, 0, 0)
+#else
 #define DC_MMA(SET) DC_MM1(SET, 2, 2) DC_MM1(SET, 1, 2) DC_MM1(SET, 2, 1) DC_MM1(SET, 0, 2) DC_MM1(SET, 1, 1) DC_MM1(SET, 2, 0) DC_MM1(SET, 0, 1) DC_MM1(SET, 1, 0) DC_MM1(SET, 0, 0)
+#endif
 
     // Persistent workgroups: tiles blockIdx.x, blockIdx.x + gridDim.x, ... as one uninterrupted
     // stream of stages - the halo of the next tile's first chunk is requested during the last
@@ -1378,21 +1392,22 @@ typedef short dw_v4s __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(256, 2) void dense_wgrad3x3_x9_kernel(const float* __restrict__ X, const float* __restrict__ G,
                                                                   int B, int H, int W, int cin, int cout, int strips,
-                                                                  int nseg, int rows_per_seg, float* __restrict__ partials) {
+                                                                  float* __restrict__ partials) {
     __shared__ __attribute__((aligned(16))) unsigned char Xs[4 * DW_XROW];
     __shared__ __attribute__((aligned(16))) unsigned char Gs[2 * DW_GROW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ti = wave >> 1, tj = wave & 1;               // ci tile, co tile of this wave
-    // block -> (image, column strip, row segment); blockIdx.y -> 64 x 64 channel block
-    const int seg = blockIdx.x % nseg;
-    const int strip = (blockIdx.x / nseg) % strips;
-    const int b = blockIdx.x / (nseg * strips);
+    // The image rows of all (image, 32-column strip) pairs form one sequence of B * strips * H row
+    // stages; workgroup i takes an equal contiguous share of it (so that exactly as many workgroups
+    // as fit on the chip carry the same load - dW sums over all pixels, a share may span columns).
+    // blockIdx.y -> 64 x 64 channel block.
     const int ncb_o = cout >> 6;
     const int ci0 = (blockIdx.y / ncb_o) * 64, co0 = (blockIdx.y % ncb_o) * 64;
-    const int x0 = strip * 32;
-    const int ys = seg * rows_per_seg, ye = min(H, ys + rows_per_seg);
-    const float* Xb = X + (int64_t)b * H * W * cin + ci0;
-    const float* Gb = G + (int64_t)b * H * W * cout + co0;
+    const int64_t total_rows = (int64_t)B * strips * H;
+    const int64_t r0 = total_rows * blockIdx.x / gridDim.x, r1 = total_rows * (blockIdx.x + 1) / gridDim.x;
+    int x0 = 0, ye = 0;
+    const float* Xb = X;
+    const float* Gb = G;
 
     mf_v16 acc[9];
 #pragma unroll
@@ -1433,12 +1448,23 @@ __global__ __launch_bounds__(256, 2) void dense_wgrad3x3_x9_kernel(const float* 
 #define DW_FRAG(F, PTR) { F.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) dw_v4s*)((PTR) + froff));          \
                           F.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) dw_v4s*)((PTR) + froff + 4 * 64)); }
 
-    if (ys < ye) {
-        DW_LOAD_X(ys - 1); DW_STORE_X(ys - 1);
-        DW_LOAD_X(ys);     DW_STORE_X(ys);
-        DW_LOAD_X(ys + 1); DW_STORE_X(ys + 1);
-        DW_LOAD_G(ys);     DW_STORE_G(ys);
+    int64_t idx = r0;
+    while (idx < r1) {
+    const int col = (int)(idx / H);
+    const int ys = (int)(idx - (int64_t)col * H);
+    {
+        const int b = col / strips, strip = col - b * strips;
+        x0 = strip * 32;
+        Xb = X + (int64_t)b * H * W * cin + ci0;
+        Gb = G + (int64_t)b * H * W * cout + co0;
     }
+    ye = (int)(r1 - idx < (int64_t)(H - ys) ? ys + (r1 - idx) : H);      // rows of this column in my share
+    idx += ye - ys;
+    // (re)fill the ring for this column: x rows ys-1 .. ys+1 and the gy row ys
+    DW_LOAD_X(ys - 1); DW_STORE_X(ys - 1);
+    DW_LOAD_X(ys);     DW_STORE_X(ys);
+    DW_LOAD_X(ys + 1); DW_STORE_X(ys + 1);
+    DW_LOAD_G(ys);     DW_STORE_G(ys);
     __syncthreads();
     for (int y = ys; y < ye; ++y) {
         const bool more = y + 1 < ye;
@@ -1461,9 +1487,11 @@ __global__ __launch_bounds__(256, 2) void dense_wgrad3x3_x9_kernel(const float* 
                 DW_FRAG(a1, xbase + DW_XPL);
                 DW_FRAG(a2, xbase + 2 * DW_XPL);
                 // nine partial products, smallest first
+#ifndef X9_SIX
                 acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2.v, g2.v, acc[tap], 0, 0, 0);
                 acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.v, g2.v, acc[tap], 0, 0, 0);
                 acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2.v, g1.v, acc[tap], 0, 0, 0);
+#endif
                 acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.v, g2.v, acc[tap], 0, 0, 0);
                 acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.v, g1.v, acc[tap], 0, 0, 0);
                 acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2.v, g0.v, acc[tap], 0, 0, 0);
@@ -1474,6 +1502,7 @@ __global__ __launch_bounds__(256, 2) void dense_wgrad3x3_x9_kernel(const float* 
         }
         if (more) { DW_STORE_G(y + 1); DW_STORE_X(y + 2); }
         __syncthreads();
+    }
     }
 #undef DW_LOAD_G
 #undef DW_LDX
@@ -1511,23 +1540,18 @@ __global__ __launch_bounds__(256) void dense_wgrad_reduce_kernel(const float* __
     dW[(co0 + co) * s_co + (ci0 + ci) * s_ci + ky * s_ky + kx * s_kx] = (float)s;
 }
 
-static void dense_wgrad_geometry(int B, int H, int W, int cin, int cout, int* strips, int* nseg, int* rps) {
-    *strips = (W + 31) / 32;
-    const int64_t per_row_seg = (int64_t)B * *strips * (cin >> 6) * (cout >> 6);
-    // two workgroups fit a CU: at most 512 of them, so that all run at once (560 on 512 slots left 48
-    // for a second round that took as long as the first)
-    int ns = (int)(512 / per_row_seg);
-    if (ns < 1) ns = 1;
-    if (ns > H) ns = H;
-    *rps = (H + ns - 1) / ns;
-    *nseg = (H + *rps - 1) / *rps;
+// workgroups per channel block: as many as run at once (two per CU, 256 CUs) over all channel blocks
+static int dense_wgrad_blocks(int B, int H, int W, int cin, int cout) {
+    const int64_t total_rows = (int64_t)B * ((W + 31) / 32) * H;
+    int64_t n = 512 / ((int64_t)(cin >> 6) * (cout >> 6));
+    if (n < 1) n = 1;
+    if (n > total_rows) n = total_rows;
+    return (int)n;
 }
 
 extern "C" size_t gga_dense_wgrad3x3_workspace_bytes(int B, int H, int W, int cin, int cout) {
     if (B < 1 || H < 1 || W < 1 || cin < 64 || cout < 64 || (cin & 63) || (cout & 63)) return 0;
-    int strips, nseg, rps;
-    dense_wgrad_geometry(B, H, W, cin, cout, &strips, &nseg, &rps);
-    return (size_t)B * strips * nseg * (cin >> 6) * (cout >> 6) * 9 * 64 * 64 * sizeof(float);
+    return (size_t)dense_wgrad_blocks(B, H, W, cin, cout) * (cin >> 6) * (cout >> 6) * 9 * 64 * 64 * sizeof(float);
 }
 
 extern "C" int gga_dense_wgrad3x3(const float* x, const float* grad_y, int B, int H, int W, int cin, int cout,
@@ -1541,11 +1565,10 @@ extern "C" int gga_dense_wgrad3x3(const float* x, const float* grad_y, int B, in
         gga_set_error("gga_dense_wgrad3x3: workspace too small");
         return GGA_ERR_WORKSPACE;
     }
-    int strips, nseg, rps;
-    dense_wgrad_geometry(B, H, W, cin, cout, &strips, &nseg, &rps);
-    const int nblk = B * strips * nseg, ncb = (cin >> 6) * (cout >> 6);
+    const int strips = (W + 31) / 32;
+    const int nblk = dense_wgrad_blocks(B, H, W, cin, cout), ncb = (cin >> 6) * (cout >> 6);
     hipLaunchKernelGGL(dense_wgrad3x3_x9_kernel, dim3(nblk, ncb), dim3(256), 0, stream, x, grad_y, B, H, W, cin, cout, strips,
-                       nseg, rps, (float*)workspace);
+                       (float*)workspace);
     GGA_CHECK_LAUNCH("dense_wgrad3x3_x9_kernel");
     hipLaunchKernelGGL(dense_wgrad_reduce_kernel, dim3((9 * 64 * 64 + 255) / 256, ncb), dim3(256), 0, stream,
                        (const float*)workspace, nblk, cin, cout, stride_co, stride_ci, stride_ky, stride_kx, grad_weight);

@@ -844,7 +844,11 @@ __global__ __launch_bounds__(64 * X9_NW) void sp_conv_x9_kernel(const float* __r
                     // the nine partial products, smallest first; the column tiles are the inner loop so
                     // that consecutive MFMAs never wait for each other's accumulator
 #define X9_MM(PA, PB) _Pragma("unroll") for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA].v, b[t][PB], acc[t], 0, 0, 0);
+#ifndef X9_NINE
+                    X9_MM(0, 2) X9_MM(1, 1) X9_MM(2, 0) X9_MM(0, 1) X9_MM(1, 0) X9_MM(0, 0)       // six terms, see the dense kernels
+#else
                     X9_MM(2, 2) X9_MM(1, 2) X9_MM(2, 1) X9_MM(0, 2) X9_MM(1, 1) X9_MM(2, 0) X9_MM(0, 1) X9_MM(1, 0) X9_MM(0, 0)
+#endif
 #undef X9_MM
                 }
             }

@@ -274,7 +274,10 @@ int gga_sparse_conv_apply(const float* x, const int32_t* map, const float* packe
 /* The same convolution with fp32 carried by three bfloat16 planes per operand: a fp32 number is
  * the exact sum of three bf16 numbers, so every product is the sum of nine bf16 products, each
  * exact in fp32, accumulated in fp32 by v_mfma_f32_32x32x16_bf16 (1.7x the fp32 MFMA rate on
- * gfx950; error vs float64 not larger than the fp32 MFMA's). gga_sparse_pack_weight_split splits
+ * gfx950; error vs float64 not larger than the fp32 MFMA's). The kernels issue six of the nine: the
+ * three products of the low planes are together below 2^-23 of the product (one fp32 ulp) and the
+ * measured error of a convolution does not change; build with -DX9_NINE for all nine.
+ * gga_sparse_pack_weight_split splits
  * and lays out the weights: packed[k][chunk][plane][col][32 ch] bf16; arguments as for
  * gga_sparse_pack_weight / gga_sparse_conv_apply. */
 size_t gga_sparse_split_weight_bytes(int kvol, int cin, int cout);

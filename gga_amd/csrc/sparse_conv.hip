@@ -1096,7 +1096,7 @@ extern "C" int gga_sparse_conv_wgrad(const float* x, const float* grad_out, cons
 template <int NT>
 __global__ __launch_bounds__(256, 2) void dense_conv3x3_x9_kernel(const float* __restrict__ X, const uint16_t* __restrict__ Wp,
                                                                  int B, int H, int W, int cin, int cout, int tiles_x,
-                                                                 int tiles_y, float* __restrict__ Y,
+                                                                 int tiles_y, float* __restrict__ Y, int ystride,
                                                                  double* __restrict__ stats) {
     constexpr int CO = NT * 32;
     constexpr int BPL = CO * DC_ROWB, BSZ = 3 * BPL, BPIECES = 3 * CO * 2;
@@ -1239,7 +1239,7 @@ __global__ __launch_bounds__(256, 2) void dense_conv3x3_x9_kernel(const float* _
             for (int v = 0; v < 16; ++v) {
                 const int ox = x0 + (v >> 2) * 8 + h * 4 + (v & 3);
                 if (ox >= W) continue;
-                float* dst = Y + (((int64_t)b * H + oy) * W + ox) * cout;
+                float* dst = Y + (((int64_t)b * H + oy) * W + ox) * ystride;       // ystride > cout: a channel slice of a wider tensor
 #pragma unroll
                 for (int t = 0; t < NT; ++t) dst[t * 32 + r] = acc[m][t][v];
             }
@@ -1342,10 +1342,12 @@ extern "C" int64_t gga_dense_conv3x3_tiles(int B, int H, int W) {
     return (int64_t)B * ((W + DC_TW - 1) / DC_TW) * ((H + DC_TR - 1) / DC_TR);
 }
 
-extern "C" int gga_dense_conv3x3_stats(const float* x, const void* split_weight, int B, int H, int W, int cin, int cout,
-                                       float* y, double* stats, void* stream_) {
+extern "C" int gga_dense_conv3x3_slice(const float* x, const void* split_weight, int B, int H, int W, int cin, int cout,
+                                       float* y, int64_t y_pixel_stride, double* stats, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     GGA_REQUIRE(x && split_weight && y, "gga_dense_conv3x3: null pointer argument");
+    GGA_REQUIRE(y_pixel_stride >= cout && y_pixel_stride < 2147483647ll, "gga_dense_conv3x3: y pixel stride %lld < cout",
+                (long long)y_pixel_stride);
     GGA_REQUIRE(B >= 1 && H >= 1 && W >= 1 && cin >= 32 && cin % 32 == 0 && (cout == 64 || cout == 128) &&
                     (int64_t)H * W * cin < 2147483647ll,
                 "gga_dense_conv3x3: need cin %% 32 == 0 and cout 64 or 128 (got %d -> %d)", cin, cout);
@@ -1358,16 +1360,21 @@ extern "C" int gga_dense_conv3x3_stats(const float* x, const void* split_weight,
     // two measured 89.7 instead of 73.8 ms per step); the hardware dispatcher balances one-tile workgroups.
     const dim3 grid((unsigned)n_tiles), block(256);
     if (cout == 64)
-        hipLaunchKernelGGL(dense_conv3x3_x9_kernel<2>, grid, block, 0, stream, x, (const uint16_t*)split_weight, B, H, W, cin, cout, tx, ty, y, stats);
+        hipLaunchKernelGGL(dense_conv3x3_x9_kernel<2>, grid, block, 0, stream, x, (const uint16_t*)split_weight, B, H, W, cin, cout, tx, ty, y, (int)y_pixel_stride, stats);
     else
-        hipLaunchKernelGGL(dense_conv3x3_x9_kernel<4>, grid, block, 0, stream, x, (const uint16_t*)split_weight, B, H, W, cin, cout, tx, ty, y, stats);
+        hipLaunchKernelGGL(dense_conv3x3_x9_kernel<4>, grid, block, 0, stream, x, (const uint16_t*)split_weight, B, H, W, cin, cout, tx, ty, y, (int)y_pixel_stride, stats);
     GGA_CHECK_LAUNCH("dense_conv3x3_x9_kernel");
     return GGA_OK;
 }
 
+extern "C" int gga_dense_conv3x3_stats(const float* x, const void* split_weight, int B, int H, int W, int cin, int cout,
+                                       float* y, double* stats, void* stream) {
+    return gga_dense_conv3x3_slice(x, split_weight, B, H, W, cin, cout, y, cout, stats, stream);
+}
+
 extern "C" int gga_dense_conv3x3(const float* x, const void* split_weight, int B, int H, int W, int cin, int cout,
                                  float* y, void* stream) {
-    return gga_dense_conv3x3_stats(x, split_weight, B, H, W, cin, cout, y, nullptr, stream);
+    return gga_dense_conv3x3_slice(x, split_weight, B, H, W, cin, cout, y, cout, nullptr, stream);
 }
 
 // ------------------------------------------------------------------------------ dense 3x3 weight gradient

@@ -56,6 +56,20 @@ def _wgrad(x, gy, weight):
     return gw
 
 
+def _run_sliced_backward(gy, weight, xshape):
+    """grad_x [B, cin, H, W] of a cout -> cin convolution with cin a multiple of 128: one call per 128
+    input channels, each writing its channel slice."""
+    L = _lib.lib()
+    B, cin, H, W = xshape
+    cout = weight.shape[0]
+    gx = torch.empty((B, cin, H, W), dtype=torch.float32, device=gy.device, memory_format=torch.channels_last)
+    for c0 in range(0, cin, 128):
+        wp = _pack(weight[:, c0:c0 + 128], True)              # strided view: packed straight from the parameter
+        check(L.gga_dense_conv3x3_slice(F._p(gy), F._p(wp), B, H, W, cout, 128, gx.data_ptr() + 4 * c0, cin, None,
+                                        F._stream()), 'gga_dense_conv3x3_slice')
+    return gx
+
+
 class _Conv3x3(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, want_stats):
@@ -73,10 +87,14 @@ class _Conv3x3(torch.autograd.Function):
         cout, cin = weight.shape[0], weight.shape[1]
         gy = gy.contiguous(memory_format=torch.channels_last)
         gx = gw = None
-        mine = cin in (64, 128)             # backward-data is a cout -> cin convolution: cin is its output width
+        # backward-data is a cout -> cin convolution (taps reversed, channel roles swapped): cin is its
+        # output width; wider inputs are produced in 128-channel slices
+        mine = cin in (64, 128) or (cin % 128 == 0 and cout % 32 == 0)
         if ctx.needs_input_grad[0] and mine:
-            # the same convolution on grad_y with the taps reversed and the channel roles swapped
-            gx = _run(gy, _pack(weight.detach(), True), cout, cin)[0]
+            if cin in (64, 128):
+                gx = _run(gy, _pack(weight.detach(), True), cout, cin)[0]
+            else:
+                gx = _run_sliced_backward(gy, weight.detach(), x.shape)
         need_gx = ctx.needs_input_grad[0] and not mine
         need_gw = bool(ctx.needs_input_grad[1])
         if need_gw and WGRAD and cin % 64 == 0 and cout % 64 == 0:

@@ -312,6 +312,12 @@ int gga_dense_wgrad3x3(const float* x, const float* grad_y, int B, int H, int W,
                        float* grad_weight, int64_t stride_co, int64_t stride_ci, int64_t stride_ky,
                        int64_t stride_kx, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same with y as a 64- or 128-channel slice of a wider channels-last tensor: pixel p of the
+ * result starts at y + p * y_pixel_stride (floats). A convolution with more output channels runs as
+ * one call per slice (each with the weights of its slice): the backward-data of the 384 -> 64
+ * shared convolution of the head (centerpoint_head.py:255-262) is three 64 -> 128 calls. */
+int gga_dense_conv3x3_slice(const float* x, const void* split_weight, int B, int H, int W, int cin, int cout,
+                            float* y, int64_t y_pixel_stride, double* stats, void* stream);
 /* split_weight for gga_dense_conv3x3 straight from the framework's [cout, cin, 3, 3] parameter with
  * arbitrary element strides (channels-last parameters included): size
  * gga_sparse_split_weight_bytes(9, cin, cout); backward != 0 packs the operand of the

@@ -1097,7 +1097,10 @@ template <int NT>
 __global__ __launch_bounds__(256, 2) void dense_conv3x3_x9_kernel(const float* __restrict__ X, const uint16_t* __restrict__ Wp,
                                                                  int B, int H, int W, int cin, int cout, int tiles_x,
                                                                  int tiles_y, float* __restrict__ Y, int ystride,
-                                                                 double* __restrict__ stats) {
+                                                                 int prow, int pcol, double* __restrict__ stats) {
+    // H x W is the tile space (rows x 32-pixel columns); pixel (r, c) of it is pixel r*prow + c*pcol of
+    // the image: (W, 1) for the image as stored, (1, image width) with H and W swapped for the
+    // transposed walk (tiles 32 pixels long along the image's H), chosen by the caller per shape.
     constexpr int CO = NT * 32;
     constexpr int BPL = CO * DC_ROWB, BSZ = 3 * BPL, BPIECES = 3 * CO * 2;
     constexpr int NB = (BPIECES + 255) / 256;
@@ -1125,7 +1128,7 @@ __global__ __launch_bounds__(256, 2) void dense_conv3x3_x9_kernel(const float* _
             const int hr = hp / DC_HW, hx = hp - hr * DC_HW;                                                          \
             const int iy = (TY0) + hr - 1, ix = (TX0) + hx - 1;                                                       \
             const bool ok = hp < DC_HP && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;                   \
-            aoff[e] = ok ? (iy * W + ix) * cin + q * 4 : -1;                                                          \
+            aoff[e] = ok ? (iy * prow + ix * pcol) * cin + q * 4 : -1;                                                          \
         } }
 #define DC_LOAD_A(CH) _Pragma("unroll") for (int e = 0; e < DC_NA; ++e) ra[e] = *reinterpret_cast<const float4*>(Xb + (aoff[e] >= 0 ? aoff[e] : 0) + (CH) * DC_CK);
 #define DC_STORE_A()                                                                                                  \
@@ -1239,7 +1242,7 @@ __global__ __launch_bounds__(256, 2) void dense_conv3x3_x9_kernel(const float* _
             for (int v = 0; v < 16; ++v) {
                 const int ox = x0 + (v >> 2) * 8 + h * 4 + (v & 3);
                 if (ox >= W) continue;
-                float* dst = Y + (((int64_t)b * H + oy) * W + ox) * ystride;       // ystride > cout: a channel slice of a wider tensor
+                float* dst = Y + ((int64_t)b * H * W + oy * prow + ox * pcol) * ystride;       // ystride > cout: a channel slice of a wider tensor
 #pragma unroll
                 for (int t = 0; t < NT; ++t) dst[t * 32 + r] = acc[m][t][v];
             }
@@ -1338,12 +1341,12 @@ extern "C" int gga_dense_conv3x3_pack(const float* weight, int64_t stride_co, in
     return GGA_OK;
 }
 
-extern "C" int64_t gga_dense_conv3x3_tiles(int B, int H, int W) {
+extern "C" int64_t gga_dense_conv3x3_tiles(int B, int H, int W) {           // H, W of the tile space (swapped when transposed)
     return (int64_t)B * ((W + DC_TW - 1) / DC_TW) * ((H + DC_TR - 1) / DC_TR);
 }
 
 extern "C" int gga_dense_conv3x3_slice(const float* x, const void* split_weight, int B, int H, int W, int cin, int cout,
-                                       float* y, int64_t y_pixel_stride, double* stats, void* stream_) {
+                                       float* y, int64_t y_pixel_stride, int transposed, double* stats, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     GGA_REQUIRE(x && split_weight && y, "gga_dense_conv3x3: null pointer argument");
     GGA_REQUIRE(y_pixel_stride >= cout && y_pixel_stride < 2147483647ll, "gga_dense_conv3x3: y pixel stride %lld < cout",
@@ -1351,6 +1354,8 @@ extern "C" int gga_dense_conv3x3_slice(const float* x, const void* split_weight,
     GGA_REQUIRE(B >= 1 && H >= 1 && W >= 1 && cin >= 32 && cin % 32 == 0 && (cout == 64 || cout == 128) &&
                     (int64_t)H * W * cin < 2147483647ll,
                 "gga_dense_conv3x3: need cin %% 32 == 0 and cout 64 or 128 (got %d -> %d)", cin, cout);
+    const int prow = transposed ? 1 : W, pcol = transposed ? W : 1;
+    if (transposed) { const int t = H; H = W; W = t; }          // tile space of the transposed walk
     const int tx = (W + DC_TW - 1) / DC_TW, ty = (H + DC_TR - 1) / DC_TR;
     const int64_t n_tiles = (int64_t)B * tx * ty;
     GGA_REQUIRE(n_tiles < 2147483647ll, "gga_dense_conv3x3: too many tiles");
@@ -1360,21 +1365,21 @@ extern "C" int gga_dense_conv3x3_slice(const float* x, const void* split_weight,
     // two measured 89.7 instead of 73.8 ms per step); the hardware dispatcher balances one-tile workgroups.
     const dim3 grid((unsigned)n_tiles), block(256);
     if (cout == 64)
-        hipLaunchKernelGGL(dense_conv3x3_x9_kernel<2>, grid, block, 0, stream, x, (const uint16_t*)split_weight, B, H, W, cin, cout, tx, ty, y, (int)y_pixel_stride, stats);
+        hipLaunchKernelGGL(dense_conv3x3_x9_kernel<2>, grid, block, 0, stream, x, (const uint16_t*)split_weight, B, H, W, cin, cout, tx, ty, y, (int)y_pixel_stride, prow, pcol, stats);
     else
-        hipLaunchKernelGGL(dense_conv3x3_x9_kernel<4>, grid, block, 0, stream, x, (const uint16_t*)split_weight, B, H, W, cin, cout, tx, ty, y, (int)y_pixel_stride, stats);
+        hipLaunchKernelGGL(dense_conv3x3_x9_kernel<4>, grid, block, 0, stream, x, (const uint16_t*)split_weight, B, H, W, cin, cout, tx, ty, y, (int)y_pixel_stride, prow, pcol, stats);
     GGA_CHECK_LAUNCH("dense_conv3x3_x9_kernel");
     return GGA_OK;
 }
 
 extern "C" int gga_dense_conv3x3_stats(const float* x, const void* split_weight, int B, int H, int W, int cin, int cout,
                                        float* y, double* stats, void* stream) {
-    return gga_dense_conv3x3_slice(x, split_weight, B, H, W, cin, cout, y, cout, stats, stream);
+    return gga_dense_conv3x3_slice(x, split_weight, B, H, W, cin, cout, y, cout, 0, stats, stream);
 }
 
 extern "C" int gga_dense_conv3x3(const float* x, const void* split_weight, int B, int H, int W, int cin, int cout,
                                  float* y, void* stream) {
-    return gga_dense_conv3x3_slice(x, split_weight, B, H, W, cin, cout, y, cout, nullptr, stream);
+    return gga_dense_conv3x3_slice(x, split_weight, B, H, W, cin, cout, y, cout, 0, nullptr, stream);
 }
 
 // ------------------------------------------------------------------------------ dense 3x3 weight gradient
@@ -1403,7 +1408,7 @@ typedef short dw_v4s __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(256, 2) void dense_wgrad3x3_x9_kernel(const float* __restrict__ X, const float* __restrict__ G,
                                                                   int B, int H, int W, int cin, int cout, int strips,
-                                                                  float* __restrict__ partials) {
+                                                                  int prow, int pcol, float* __restrict__ partials) {
     __shared__ __attribute__((aligned(16))) unsigned char Xs[4 * DW_XROW];
     __shared__ __attribute__((aligned(16))) unsigned char Gs[2 * DW_GROW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1431,12 +1436,12 @@ __global__ __launch_bounds__(256, 2) void dense_wgrad3x3_x9_kernel(const float* 
 #define DW_LOAD_G(Y) {                                                                                                \
         const bool rowok = (Y) < ye;                                                                                  \
         { const int f = tid;       const int px = f >> 4, q = f & 15; const bool ok = rowok && x0 + px < W;           \
-          rg0 = ok ? *reinterpret_cast<const float4*>(Gb + ((int64_t)(Y) * W + x0 + px) * cout + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f); } \
+          rg0 = ok ? *reinterpret_cast<const float4*>(Gb + ((int64_t)(Y) * prow + (int64_t)(x0 + px) * pcol) * cout + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f); } \
         { const int f = tid + 256; const int px = f >> 4, q = f & 15; const bool ok = rowok && x0 + px < W;           \
-          rg1 = ok ? *reinterpret_cast<const float4*>(Gb + ((int64_t)(Y) * W + x0 + px) * cout + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f); } }
+          rg1 = ok ? *reinterpret_cast<const float4*>(Gb + ((int64_t)(Y) * prow + (int64_t)(x0 + px) * pcol) * cout + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f); } }
 #define DW_LDX(V, E) { const int f = tid + 256 * (E); const int px = f >> 4, q = f & 15; const int ix = x0 - 1 + px;  \
         const bool ok = rowok && f < 544 && (unsigned)ix < (unsigned)W;                                               \
-        V = ok ? *reinterpret_cast<const float4*>(Xb + ((int64_t)yy * W + ix) * cin + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f); }
+        V = ok ? *reinterpret_cast<const float4*>(Xb + ((int64_t)yy * prow + (int64_t)ix * pcol) * cin + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f); }
 #define DW_LOAD_X(Y) { const int yy = (Y); const bool rowok = (unsigned)yy < (unsigned)H; DW_LDX(rx0, 0) DW_LDX(rx1, 1) DW_LDX(rx2, 2) }
     // piece (pixel px, float4 q) of a row image: channel tile q / 8, byte (q % 8) * 8 of the 64-byte pixel row
 #define DW_SPLIT_STORE(V, BASE, PL, NPX, F) { const int f = (F); const int px = f >> 4, q = f & 15;                   \
@@ -1562,12 +1567,14 @@ static int dense_wgrad_blocks(int B, int H, int W, int cin, int cout) {
 
 extern "C" size_t gga_dense_wgrad3x3_workspace_bytes(int B, int H, int W, int cin, int cout) {
     if (B < 1 || H < 1 || W < 1 || cin < 64 || cout < 64 || (cin & 63) || (cout & 63)) return 0;
-    return (size_t)dense_wgrad_blocks(B, H, W, cin, cout) * (cin >> 6) * (cout >> 6) * 9 * 64 * 64 * sizeof(float);
+    const int n0 = dense_wgrad_blocks(B, H, W, cin, cout), n1 = dense_wgrad_blocks(B, W, H, cin, cout);     // either walk
+    return (size_t)(n0 > n1 ? n0 : n1) * (cin >> 6) * (cout >> 6) * 9 * 64 * 64 * sizeof(float);
 }
 
 extern "C" int gga_dense_wgrad3x3(const float* x, const float* grad_y, int B, int H, int W, int cin, int cout,
                                   float* grad_weight, int64_t stride_co, int64_t stride_ci, int64_t stride_ky,
-                                  int64_t stride_kx, void* workspace, size_t workspace_bytes, void* stream_) {
+                                  int64_t stride_kx, int transposed, void* workspace, size_t workspace_bytes,
+                                  void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     GGA_REQUIRE(x && grad_y && grad_weight && workspace, "gga_dense_wgrad3x3: null pointer argument");
     GGA_REQUIRE(B >= 1 && H >= 1 && W >= 1 && cin >= 64 && cout >= 64 && (cin & 63) == 0 && (cout & 63) == 0,
@@ -1576,10 +1583,13 @@ extern "C" int gga_dense_wgrad3x3(const float* x, const float* grad_y, int B, in
         gga_set_error("gga_dense_wgrad3x3: workspace too small");
         return GGA_ERR_WORKSPACE;
     }
+    // transposed: strips of 32 pixels along the image's H, rows along its W; the taps swap with them
+    const int prow = transposed ? 1 : W, pcol = transposed ? W : 1;
+    if (transposed) { const int t = H; H = W; W = t; const int64_t ts = stride_ky; stride_ky = stride_kx; stride_kx = ts; }
     const int strips = (W + 31) / 32;
     const int nblk = dense_wgrad_blocks(B, H, W, cin, cout), ncb = (cin >> 6) * (cout >> 6);
     hipLaunchKernelGGL(dense_wgrad3x3_x9_kernel, dim3(nblk, ncb), dim3(256), 0, stream, x, grad_y, B, H, W, cin, cout, strips,
-                       (float*)workspace);
+                       prow, pcol, (float*)workspace);
     GGA_CHECK_LAUNCH("dense_wgrad3x3_x9_kernel");
     hipLaunchKernelGGL(dense_wgrad_reduce_kernel, dim3((9 * 64 * 64 + 255) / 256, ncb), dim3(256), 0, stream,
                        (const float*)workspace, nblk, cin, cout, stride_co, stride_ci, stride_ky, stride_kx, grad_weight);

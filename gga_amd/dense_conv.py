@@ -18,28 +18,54 @@ ENABLED = True          # False: every dense convolution goes to MIOpen
 WGRAD = True            # False: weight gradients stay with MIOpen
 
 
-def _pack(weight, backward):
+def _cdiv(a, b):
+    return -(-a // b)
+
+
+def _transposed(H, W):
+    """Walk the map with the 32-pixel tile edge along H instead of W when that wastes less of the
+    8 x 32 tiles (124 x 108: 1.07 instead of 1.22 tiles of work per tile of data)."""
+    normal = _cdiv(W, 32) * 32 * _cdiv(H, 8) * 8
+    turned = _cdiv(H, 32) * 32 * _cdiv(W, 8) * 8
+    return turned < 0.97 * normal
+
+
+def _pack(weight, backward, transposed=False):
     """Split-plane operand of the forward (or backward-data) convolution, read from the parameter's
-    own memory layout: one kernel, no permuted copy."""
+    own memory layout: one kernel, no permuted copy. ``transposed``: for the transposed walk (ky and
+    kx change roles)."""
     L = _lib.lib()
     cout, cin = weight.shape[0], weight.shape[1]
     n_in, n_out = (cout, cin) if backward else (cin, cout)
     wp = torch.empty(L.gga_sparse_split_weight_bytes(9, n_in, n_out) // 2, dtype=torch.int16, device=weight.device)
     s = weight.stride()
-    check(L.gga_dense_conv3x3_pack(F._p(weight), s[0], s[1], s[2], s[3], cin, cout, int(backward), F._p(wp), F._stream()),
+    sky, skx = (s[3], s[2]) if transposed else (s[2], s[3])
+    check(L.gga_dense_conv3x3_pack(F._p(weight), s[0], s[1], sky, skx, cin, cout, int(backward), F._p(wp), F._stream()),
           'gga_dense_conv3x3_pack')
     return wp
 
 
-def _run(x, wp, cin, cout, want_stats=False):
-    B, _, H, W = x.shape
+def _run(x, weight, backward, want_stats=False):
+    """The convolution (or its backward-data form) of ``x`` with ``weight`` [cout, cin, 3, 3]; output
+    widths above 128 run as 128-channel slices of the result."""
+    B, n_in, H, W = x.shape
     L = _lib.lib()
-    y = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    n_out = weight.shape[1] if backward else weight.shape[0]
+    tr = _transposed(H, W)
+    y = torch.empty((B, n_out, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
     stats = None
-    if want_stats:
-        stats = torch.empty((int(L.gga_dense_conv3x3_tiles(B, H, W)), 2, cout), dtype=torch.float64, device=x.device)
-    check(L.gga_dense_conv3x3_stats(F._p(x), F._p(wp), B, H, W, cin, cout, F._p(y), F._p(stats), F._stream()),
-          'gga_dense_conv3x3')
+    if n_out in (64, 128):
+        if want_stats:
+            tiles = int(L.gga_dense_conv3x3_tiles(B, W, H) if tr else L.gga_dense_conv3x3_tiles(B, H, W))
+            stats = torch.empty((tiles, 2, n_out), dtype=torch.float64, device=x.device)
+        check(L.gga_dense_conv3x3_slice(F._p(x), F._p(_pack(weight, backward, tr)), B, H, W, n_in, n_out, F._p(y), n_out,
+                                        int(tr), F._p(stats), F._stream()), 'gga_dense_conv3x3')
+    else:
+        for c0 in range(0, n_out, 128):             # strided views: packed straight from the parameter
+            wv = weight[:, c0:c0 + 128] if backward else weight[c0:c0 + 128]
+            check(L.gga_dense_conv3x3_slice(F._p(x), F._p(_pack(wv, backward, tr)), B, H, W, n_in, 128,
+                                            y.data_ptr() + 4 * c0, n_out, int(tr), None, F._stream()),
+                  'gga_dense_conv3x3_slice')
     return y, stats
 
 
@@ -51,30 +77,17 @@ def _wgrad(x, gy, weight):
     gw = torch.empty_like(weight)
     s = gw.stride()
     ws = F._workspace('dense_wgrad', L.gga_dense_wgrad3x3_workspace_bytes(B, H, W, cin, cout), x.device)
-    check(L.gga_dense_wgrad3x3(F._p(x), F._p(gy), B, H, W, cin, cout, F._p(gw), s[0], s[1], s[2], s[3], F._p(ws),
+    tr = _cdiv(H, 32) * 32 * W < 0.97 * _cdiv(W, 32) * 32 * H        # 32-pixel strips along H waste less
+    check(L.gga_dense_wgrad3x3(F._p(x), F._p(gy), B, H, W, cin, cout, F._p(gw), s[0], s[1], s[2], s[3], int(tr), F._p(ws),
                                ws.numel(), F._stream()), 'gga_dense_wgrad3x3')
     return gw
-
-
-def _run_sliced_backward(gy, weight, xshape):
-    """grad_x [B, cin, H, W] of a cout -> cin convolution with cin a multiple of 128: one call per 128
-    input channels, each writing its channel slice."""
-    L = _lib.lib()
-    B, cin, H, W = xshape
-    cout = weight.shape[0]
-    gx = torch.empty((B, cin, H, W), dtype=torch.float32, device=gy.device, memory_format=torch.channels_last)
-    for c0 in range(0, cin, 128):
-        wp = _pack(weight[:, c0:c0 + 128], True)              # strided view: packed straight from the parameter
-        check(L.gga_dense_conv3x3_slice(F._p(gy), F._p(wp), B, H, W, cout, 128, gx.data_ptr() + 4 * c0, cin, None,
-                                        F._stream()), 'gga_dense_conv3x3_slice')
-    return gx
 
 
 class _Conv3x3(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, want_stats):
         cout, cin = weight.shape[0], weight.shape[1]
-        y, stats = _run(x, _pack(weight.detach(), False), cin, cout, want_stats)
+        y, stats = _run(x, weight.detach(), False, want_stats)
         ctx.save_for_backward(x, weight)
         if stats is None:
             stats = torch.empty(0, dtype=torch.float64, device=x.device)
@@ -89,12 +102,9 @@ class _Conv3x3(torch.autograd.Function):
         gx = gw = None
         # backward-data is a cout -> cin convolution (taps reversed, channel roles swapped): cin is its
         # output width; wider inputs are produced in 128-channel slices
-        mine = cin in (64, 128) or (cin % 128 == 0 and cout % 32 == 0)
+        mine = cin in (64, 128) or cin % 128 == 0
         if ctx.needs_input_grad[0] and mine:
-            if cin in (64, 128):
-                gx = _run(gy, _pack(weight.detach(), True), cout, cin)[0]
-            else:
-                gx = _run_sliced_backward(gy, weight.detach(), x.shape)
+            gx = _run(gy, weight.detach(), True)[0]
         need_gx = ctx.needs_input_grad[0] and not mine
         need_gw = bool(ctx.needs_input_grad[1])
         if need_gw and WGRAD and cin % 64 == 0 and cout % 64 == 0:
@@ -113,7 +123,8 @@ class _Conv3x3(torch.autograd.Function):
 def eligible(conv, x):
     return (ENABLED and type(conv) is nn.Conv2d and conv.bias is None and conv.kernel_size == (3, 3)
             and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1
-            and conv.padding_mode == 'zeros' and conv.in_channels % 32 == 0 and conv.out_channels in (64, 128)
+            and conv.padding_mode == 'zeros' and conv.in_channels % 32 == 0
+            and (conv.out_channels in (64, 128) or conv.out_channels % 128 == 0)
             and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
             and x.is_contiguous(memory_format=torch.channels_last) and x.shape[2] * x.shape[3] * x.shape[1] < 2 ** 31)
 

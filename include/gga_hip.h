@@ -310,14 +310,17 @@ int gga_dense_conv3x3_stats(const float* x, const void* split_weight, int B, int
 size_t gga_dense_wgrad3x3_workspace_bytes(int B, int H, int W, int cin, int cout);
 int gga_dense_wgrad3x3(const float* x, const float* grad_y, int B, int H, int W, int cin, int cout,
                        float* grad_weight, int64_t stride_co, int64_t stride_ci, int64_t stride_ky,
-                       int64_t stride_kx, void* workspace, size_t workspace_bytes, void* stream);
+                       int64_t stride_kx, int transposed, void* workspace, size_t workspace_bytes, void* stream);
 
 /* The same with y as a 64- or 128-channel slice of a wider channels-last tensor: pixel p of the
  * result starts at y + p * y_pixel_stride (floats). A convolution with more output channels runs as
  * one call per slice (each with the weights of its slice): the backward-data of the 384 -> 64
  * shared convolution of the head (centerpoint_head.py:255-262) is three 64 -> 128 calls. */
+/* transposed != 0: the 8 x 32-pixel tiles run 32 pixels along H instead of W (maps whose width is a
+ * poor multiple of 32, e.g. 124 x 108 or 62 x 54); split_weight must then be packed with the ky / kx
+ * strides swapped, and stats holds gga_dense_conv3x3_tiles(B, W, H) rows. Results are identical. */
 int gga_dense_conv3x3_slice(const float* x, const void* split_weight, int B, int H, int W, int cin, int cout,
-                            float* y, int64_t y_pixel_stride, double* stats, void* stream);
+                            float* y, int64_t y_pixel_stride, int transposed, double* stats, void* stream);
 /* split_weight for gga_dense_conv3x3 straight from the framework's [cout, cin, 3, 3] parameter with
  * arbitrary element strides (channels-last parameters included): size
  * gga_sparse_split_weight_bytes(9, cin, cout); backward != 0 packs the operand of the

@@ -559,7 +559,10 @@ def test_pillar_conv_valid_count_and_fallbacks():
 
 # ----------------------------------------------------------------------------- dense 3x3 conv (bf16x9)
 @pytest.mark.parametrize('cin,cout,B,H,W', [(64, 64, 2, 37, 45), (128, 128, 1, 19, 70), (128, 64, 2, 8, 32),
-                                           (64, 128, 1, 41, 33), (384, 64, 1, 20, 36)])
+                                           (64, 128, 1, 41, 33), (384, 64, 1, 20, 36),
+                                           # maps walked transposed (width a poor multiple of 32) and 256-wide outputs in slices
+                                           (64, 64, 2, 62, 54), (128, 128, 1, 31, 22), (256, 256, 1, 30, 20),
+                                           (128, 256, 1, 9, 40)])
 def test_dense_conv3x3_vs_torch(cin, cout, B, H, W):
     """fp32 convolution through nine exact bf16 partial products: forward and backward-data against
     torch's convolution in float64 (error no larger than a few fp32 ulps of the accumulated sum)."""

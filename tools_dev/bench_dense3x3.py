@@ -15,16 +15,15 @@ def run(B, C, Co, H, W):
     x = torch.randn(B, C, H, W, device=dev).contiguous(memory_format=torch.channels_last)
     conv = torch.nn.Conv2d(C, Co, 3, padding=1, bias=False).to(dev)
     conv.weight.data = conv.weight.data.contiguous(memory_format=torch.channels_last)
-    wk = conv.weight.detach().permute(2, 3, 1, 0).reshape(9, C, Co).contiguous()
-    wp = _pack_weight(wk, 9, C, Co, 0, split=True)
-    y = torch.empty((B, Co, H, W), device=dev).contiguous(memory_format=torch.channels_last)
-    L = _lib.lib()
+    from gga_amd import dense_conv
+    out = {}
     def mine():
-        _lib.check(L.gga_dense_conv3x3(F._p(x), F._p(wp), B, H, W, C, Co, F._p(y), F._stream()), 'dense')
+        out['y'] = dense_conv._run(x, conv.weight.detach(), False)[0]
     mine()
     with torch.no_grad():
         ref = conv(x)
     ref64 = torch.nn.functional.conv2d(x.double(), conv.weight.double(), padding=1)
+    y = out['y']
     e_mine = float((y.double() - ref64).abs().max() / ref64.abs().max())
     e_ref = float((ref.double() - ref64).abs().max() / ref64.abs().max())
     trash = torch.empty(1 << 28, dtype=torch.float32, device=dev)
@@ -58,3 +57,4 @@ run(16, 64, 64, 248, 216)
 run(2, 64, 64, 37, 45)
 run(16, 128, 128, 124, 108)
 run(16, 128, 64, 124, 108)
+run(16, 256, 256, 62, 54)

@@ -156,6 +156,10 @@ def main():
     if want_roofline:      # one HIP-event pair per step around the scatter canvas kernel (no synchronisation)
         from gga_amd import _lib
         _lib.check(_lib.lib().gga_pillar_scatter_timing_begin(min(args.steps, 256)), 'timing_begin')
+        # and around every 64 -> 64 dense 3x3 convolution at the head's map size (forward and backward-data
+        # of the first conv of the 15 head branches and of SECOND block 1): the step's dominant kernel
+        fh, fw = model.pts_middle_encoder.ny // 2, model.pts_middle_encoder.nx // 2
+        _lib.check(_lib.lib().gga_dense_conv3x3_timing_begin(512, 64, 64, fh * fw), 'dense_timing_begin')
     # no generational garbage collection inside the timed region: a gen-2 pass over the module tree
     # takes tens of ms and drains the launch queue (2 of ~12 runs measured +8..16 ms/step before
     # this, 8 of 8 runs 72.5-72.8 ms after)
@@ -170,12 +174,16 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     gc.enable()
-    scatter_ms = []
+    scatter_ms, dense_ms = [], []
     if want_roofline:
         buf = (C.c_float * 256)()
         n = _lib.lib().gga_pillar_scatter_timing_collect(buf, 256)
         _lib.check(min(n, 0), 'timing_collect')
         scatter_ms = [buf[i] for i in range(n)]
+        buf2 = (C.c_float * 512)()
+        n2 = _lib.lib().gga_dense_conv3x3_timing_collect(buf2, 512)
+        _lib.check(min(n2, 0), 'dense_timing_collect')
+        dense_ms = [buf2[i] for i in range(n2)]
     t = torch.tensor([dt], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -200,6 +208,19 @@ def main():
         }
         if scatter_ms:
             res['roofline'] = scatter_roofline(model, batches, device, scatter_ms)
+        if dense_ms:
+            # the dominant kernel of the step is matrix-bound: fp32 convolution as six bf16 MFMA products per
+            # term, so the bf16 matrix work issued is 6 x the fp32 FLOPs; peak = dense bf16 MFMA (MI355X_MICROARCH.md)
+            fh, fw = model.pts_middle_encoder.ny // 2, model.pts_middle_encoder.nx // 2
+            flops = 2.0 * args.batch * fh * fw * 64 * 64 * 9
+            avg = sum(dense_ms) / len(dense_ms)
+            res['mfma_roofline'] = {'bound': 'mfma', 'kernel': 'dense_conv3x3_x9_kernel<2> (64->64, %dx%d, fwd + bwd-data)' % (fh, fw),
+                                    'achieved': round(6 * flops / (avg * 1e-3) / 1e12, 1), 'peak': 2500.0, 'unit': 'TFLOP/s',
+                                    'frac': round(6 * flops / (avg * 1e-3) / 1e12 / 2500.0, 4),
+                                    'fp32_equivalent_tflops': round(flops / (avg * 1e-3) / 1e12, 1),
+                                    'kernel_ms': round(avg, 4), 'launches_timed': len(dense_ms),
+                                    'timed': 'in-step, HIP events on the launch stream',
+                                    'share_of_step': round(sum(dense_ms) / args.steps / (dt / args.steps * 1e3), 3)}
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(cfg)
         print(json.dumps(res), flush=True)

@@ -78,6 +78,8 @@ SIGNATURES = {
     'gga_dense_conv3x3_pack': (i32, [vp, i64, i64, i64, i64, i32, i32, i32, vp, vp]),
     'gga_dense_wgrad3x3_workspace_bytes': (sz, [i32, i32, i32, i32, i32]),
     'gga_dense_wgrad3x3': (i32, [vp, vp, i32, i32, i32, i32, i32, vp, i64, i64, i64, i64, i32, vp, sz, vp]),
+    'gga_dense_conv3x3_timing_begin': (i32, [i32, i32, i32, i64]),
+    'gga_dense_conv3x3_timing_collect': (i32, [vp, i32]),
     'gga_dense_conv3x3_tiles': (i64, [i32, i32, i32]),
     'gga_dense_conv3x3_slice': (i32, [vp, vp, i32, i32, i32, i32, i32, vp, i64, i32, vp, vp]),
     'gga_dense_conv3x3_stats': (i32, [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]),

@@ -1345,6 +1345,35 @@ extern "C" int64_t gga_dense_conv3x3_tiles(int B, int H, int W) {           // H
     return (int64_t)B * ((W + DC_TW - 1) / DC_TW) * ((H + DC_TR - 1) / DC_TR);
 }
 
+// Bench-only in-place timing (as for the pillar scatter): while armed, every launch whose shape matches
+// (cin, cout, H*W) is bracketed with a HIP event pair on its stream; nothing synchronises until collect.
+#define DC_TIMING_MAX 512
+static hipEvent_t g_dc_ev[DC_TIMING_MAX][2];
+static int g_dc_made = 0, g_dc_cap = 0, g_dc_count = 0, g_dc_cin = 0, g_dc_cout = 0;
+static int64_t g_dc_hw = 0;
+
+extern "C" int gga_dense_conv3x3_timing_begin(int max_samples, int cin, int cout, int64_t hw) {
+    GGA_REQUIRE(max_samples >= 0 && max_samples <= DC_TIMING_MAX, "gga_dense_conv3x3_timing_begin: 0 <= max_samples <= %d",
+                DC_TIMING_MAX);
+    for (; g_dc_made < max_samples; ++g_dc_made) {
+        GGA_CHECK_HIP(hipEventCreate(&g_dc_ev[g_dc_made][0]), "timing event");
+        GGA_CHECK_HIP(hipEventCreate(&g_dc_ev[g_dc_made][1]), "timing event");
+    }
+    g_dc_cap = max_samples; g_dc_count = 0; g_dc_cin = cin; g_dc_cout = cout; g_dc_hw = hw;
+    return GGA_OK;
+}
+
+extern "C" int gga_dense_conv3x3_timing_collect(float* ms_host, int cap) {
+    GGA_REQUIRE(ms_host || cap == 0, "gga_dense_conv3x3_timing_collect: null pointer argument");
+    const int n = g_dc_count < cap ? g_dc_count : cap;
+    for (int i = 0; i < n; ++i) {
+        GGA_CHECK_HIP(hipEventSynchronize(g_dc_ev[i][1]), "timing sync");
+        GGA_CHECK_HIP(hipEventElapsedTime(&ms_host[i], g_dc_ev[i][0], g_dc_ev[i][1]), "timing elapsed");
+    }
+    g_dc_cap = g_dc_count = 0;
+    return n;
+}
+
 extern "C" int gga_dense_conv3x3_slice(const float* x, const void* split_weight, int B, int H, int W, int cin, int cout,
                                        float* y, int64_t y_pixel_stride, int transposed, double* stats, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
@@ -1364,11 +1393,14 @@ extern "C" int gga_dense_conv3x3_slice(const float* x, const void* split_weight,
     // tail still occupies some CUs and the static tile split then leaves stragglers (one bench run in
     // two measured 89.7 instead of 73.8 ms per step); the hardware dispatcher balances one-tile workgroups.
     const dim3 grid((unsigned)n_tiles), block(256);
+    const bool timed = g_dc_count < g_dc_cap && cin == g_dc_cin && cout == g_dc_cout && (int64_t)H * W == g_dc_hw;
+    if (timed) GGA_CHECK_HIP(hipEventRecord(g_dc_ev[g_dc_count][0], stream), "timing record");
     if (cout == 64)
         hipLaunchKernelGGL(dense_conv3x3_x9_kernel<2>, grid, block, 0, stream, x, (const uint16_t*)split_weight, B, H, W, cin, cout, tx, ty, y, (int)y_pixel_stride, prow, pcol, stats);
     else
         hipLaunchKernelGGL(dense_conv3x3_x9_kernel<4>, grid, block, 0, stream, x, (const uint16_t*)split_weight, B, H, W, cin, cout, tx, ty, y, (int)y_pixel_stride, prow, pcol, stats);
     GGA_CHECK_LAUNCH("dense_conv3x3_x9_kernel");
+    if (timed) GGA_CHECK_HIP(hipEventRecord(g_dc_ev[g_dc_count++][1], stream), "timing record");
     return GGA_OK;
 }
 

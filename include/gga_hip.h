@@ -321,6 +321,13 @@ int gga_dense_wgrad3x3(const float* x, const float* grad_y, int B, int H, int W,
  * strides swapped, and stats holds gga_dense_conv3x3_tiles(B, W, H) rows. Results are identical. */
 int gga_dense_conv3x3_slice(const float* x, const void* split_weight, int B, int H, int W, int cin, int cout,
                             float* y, int64_t y_pixel_stride, int transposed, double* stats, void* stream);
+/* Bench-only, in-step timing of the dense convolution (bench.py's `mfma_roofline`): after
+ * gga_dense_conv3x3_timing_begin(n, cin, cout, H*W) the next n launches of that shape are bracketed
+ * with HIP events on their stream; gga_dense_conv3x3_timing_collect waits for them and returns the
+ * per-launch milliseconds (count returned, negative on error). */
+int gga_dense_conv3x3_timing_begin(int max_samples, int cin, int cout, int64_t hw);
+int gga_dense_conv3x3_timing_collect(float* ms_host, int cap);
+
 /* split_weight for gga_dense_conv3x3 straight from the framework's [cout, cin, 3, 3] parameter with
  * arbitrary element strides (channels-last parameters included): size
  * gga_sparse_split_weight_bytes(9, cin, cout); backward != 0 packs the operand of the

@@ -11,9 +11,10 @@ CenterHead_GGA -> GGA losses -> backward -> (DDP all-reduce) -> grad clip -> Ada
 frames per GPU, fp32. Point clouds are resident in HBM before the timed region; weak scaling
 (every rank steps its own 16 frames, gradients all-reduced over RCCL).
 
-Rank 0 prints ONE JSON line; `roofline` is the pillar-scatter canvas kernel timed with HIP
-events inside this process, `cpu_baseline` is the oracle's CPU restatement of the same step
-on a bounded sample (N=1 only).
+Rank 0 prints ONE JSON line; `roofline` is the pillar scatter (BASELINE's HBM metric) and
+`mfma_roofline` the 64 -> 64 dense 3x3 convolution (the step's dominant kernel), both timed with
+HIP events inside the timed steps; `cpu_baseline` is the oracle's CPU restatement of the same
+step on a bounded sample (N=1 only).
 """
 import argparse
 import gc

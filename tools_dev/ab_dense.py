@@ -1,3 +1,7 @@
+"""Same-box A/B of the dense-convolution routing: `python tools_dev/ab_dense.py MODE` runs bench.py
+(--no-cpu-baseline) with MODE in {full, nowide (256-channel convs back on MIOpen), notr (no
+transposed tile walk), nowide_notr}. Boxes differ by a few per cent, so alternate the modes in one
+gpurun call."""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import runpy

@@ -14,4 +14,4 @@ void gga_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* gga_last_error(void) { return g_err; }
-extern "C" int gga_abi_version(void) { return 6; }
+extern "C" int gga_abi_version(void) { return 7; }

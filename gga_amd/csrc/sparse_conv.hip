@@ -1093,18 +1093,24 @@ extern "C" int gga_sparse_conv_wgrad(const float* x, const float* grad_out, cons
 #define DC_ROWB 48                           // bytes per LDS row (16 bf16 + pad)
 #define DC_NA ((DC_HP * 4 + 255) / 256)      // float4 pieces per thread and chunk (6)
 
-template <int NT>
-__global__ __launch_bounds__(256, 2) void dense_conv3x3_x9_kernel(const float* __restrict__ X, const uint16_t* __restrict__ Wp,
+template <int NT, int TR>
+__global__ __launch_bounds__(TR * 32, 2) void dense_conv3x3_x9_kernel(const float* __restrict__ X, const uint16_t* __restrict__ Wp,
                                                                  int B, int H, int W, int cin, int cout, int tiles_x,
                                                                  int tiles_y, float* __restrict__ Y, int ystride,
                                                                  int prow, int pcol, double* __restrict__ stats) {
     // H x W is the tile space (rows x 32-pixel columns); pixel (r, c) of it is pixel r*prow + c*pcol of
     // the image: (W, 1) for the image as stored, (1, image width) with H and W swapped for the
     // transposed walk (tiles 32 pixels long along the image's H), chosen by the caller per shape.
+    // TR = 8: 256 threads own 8 rows x 32 pixels (64 output channels: two workgroups per CU; 128: one).
+    // TR = 16 (128 output channels on maps with enough tiles): 512 threads own 16 rows - one workgroup per
+    // CU but two waves per SIMD again (124 x 108: 324 instead of 379 us); on small maps the 16-row tiles
+    // leave CUs idle (62 x 54: 523 instead of 366 us), so the launcher picks per shape.
+    constexpr int THREADS = TR * 32, NWAVES = TR / 2;
+    constexpr int HP = (TR + 2) * DC_HW, NA = (HP * 4 + THREADS - 1) / THREADS;
     constexpr int CO = NT * 32;
     constexpr int BPL = CO * DC_ROWB, BSZ = 3 * BPL, BPIECES = 3 * CO * 2;
-    constexpr int NB = (BPIECES + 255) / 256;
-    constexpr int APL = DC_HP * DC_ROWB;
+    constexpr int NB = (BPIECES + THREADS - 1) / THREADS;
+    constexpr int APL = HP * DC_ROWB;
     __shared__ __attribute__((aligned(16))) unsigned char As[3 * APL];
     __shared__ __attribute__((aligned(16))) unsigned char Bs[3 * BSZ];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1116,25 +1122,25 @@ __global__ __launch_bounds__(256, 2) void dense_conv3x3_x9_kernel(const float* _
     mf_v16 acc[2][NT];
 
     // halo piece e of this thread: pixel (tid + 256 e) / 4, channels 4 * ((tid + 256 e) % 4) .. +3 of the chunk
-    float4 ra[DC_NA];
-    int aoff[DC_NA];                              // float offset of the piece in its image, -1: outside (zeros)
+    float4 ra[NA];
+    int aoff[NA];                              // float offset of the piece in its image, -1: outside (zeros)
     const float* Xb = X;
-#define DC_TILE(T, TB, TY0, TX0) const int TB = (T) / per_img; const int TY0 = (((T) - TB * per_img) / tiles_x) * DC_TR, TX0 = (((T) - TB * per_img) % tiles_x) * DC_TW;
+#define DC_TILE(T, TB, TY0, TX0) const int TB = (T) / per_img; const int TY0 = (((T) - TB * per_img) / tiles_x) * TR, TX0 = (((T) - TB * per_img) % tiles_x) * DC_TW;
 #define DC_AOFF(TB, TY0, TX0) {                                                                                       \
         Xb = X + (int64_t)(TB) * H * W * cin;                                                                         \
-        _Pragma("unroll") for (int e = 0; e < DC_NA; ++e) {                                                           \
-            const int f = tid + 256 * e;                                                                              \
+        _Pragma("unroll") for (int e = 0; e < NA; ++e) {                                                           \
+            const int f = tid + THREADS * e;                                                                              \
             const int hp = f >> 2, q = f & 3;                                                                         \
             const int hr = hp / DC_HW, hx = hp - hr * DC_HW;                                                          \
             const int iy = (TY0) + hr - 1, ix = (TX0) + hx - 1;                                                       \
-            const bool ok = hp < DC_HP && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;                   \
+            const bool ok = hp < HP && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;                   \
             aoff[e] = ok ? (iy * prow + ix * pcol) * cin + q * 4 : -1;                                                          \
         } }
-#define DC_LOAD_A(CH) _Pragma("unroll") for (int e = 0; e < DC_NA; ++e) ra[e] = *reinterpret_cast<const float4*>(Xb + (aoff[e] >= 0 ? aoff[e] : 0) + (CH) * DC_CK);
+#define DC_LOAD_A(CH) _Pragma("unroll") for (int e = 0; e < NA; ++e) ra[e] = *reinterpret_cast<const float4*>(Xb + (aoff[e] >= 0 ? aoff[e] : 0) + (CH) * DC_CK);
 #define DC_STORE_A()                                                                                                  \
-    _Pragma("unroll") for (int e = 0; e < DC_NA; ++e) {                                                               \
-        const int f = tid + 256 * e;                                                                                  \
-        if (f < DC_HP * 4) {                                                                                          \
+    _Pragma("unroll") for (int e = 0; e < NA; ++e) {                                                               \
+        const int f = tid + THREADS * e;                                                                                  \
+        if (f < HP * 4) {                                                                                          \
             const float4 v = aoff[e] >= 0 ? ra[e] : make_float4(0.f, 0.f, 0.f, 0.f);                                   \
             uint32_t a1, a2, a3, b1, b2, b3, c1, c2, c3, d1, d2, d3;                                                  \
             x9_split(v.x, a1, a2, a3); x9_split(v.y, b1, b2, b3); x9_split(v.z, c1, c2, c3); x9_split(v.w, d1, d2, d3); \
@@ -1147,11 +1153,11 @@ __global__ __launch_bounds__(256, 2) void dense_conv3x3_x9_kernel(const float* _
     // weight stage (tap, 16-channel chunk c): piece f = (plane, column, 16-byte half) of the 32-byte half row
     uint4 bq0, bq1, bq2;                            // named registers: an indexed array ends up in scratch
     bq0 = bq1 = bq2 = make_uint4(0, 0, 0, 0);
-#define DC_BLD(E, V) if ((E) < NB) { const int f = min(tid + 256 * (E), BPIECES - 1); V = bsrc[(f >> 1) * 4 + (f & 1)]; }
+#define DC_BLD(E, V) if ((E) < NB) { const int f = min(tid + THREADS * (E), BPIECES - 1); V = bsrc[(f >> 1) * 4 + (f & 1)]; }
 #define DC_LOAD_B(TAP, CH) {                                                                                          \
         const uint4* bsrc = reinterpret_cast<const uint4*>(Wp + ((int64_t)(TAP) * nchunks32 + ((CH) >> 1)) * (3 * CO * 32) + ((CH) & 1) * 16); \
         DC_BLD(0, bq0) DC_BLD(1, bq1) DC_BLD(2, bq2) }
-#define DC_BST(BUF, E, V) if ((E) < NB) { const int f = tid + 256 * (E); if (f < BPIECES) *reinterpret_cast<uint4*>(Bs + (BUF) * BSZ + (f >> 1) * DC_ROWB + (f & 1) * 16) = V; }
+#define DC_BST(BUF, E, V) if ((E) < NB) { const int f = tid + THREADS * (E); if (f < BPIECES) *reinterpret_cast<uint4*>(Bs + (BUF) * BSZ + (f >> 1) * DC_ROWB + (f & 1) * 16) = V; }
 #define DC_STORE_B(BUF) { DC_BST(BUF, 0, bq0) DC_BST(BUF, 1, bq1) DC_BST(BUF, 2, bq2) }
     static_assert(NB <= 3, "weight stage pieces per thread");
 
@@ -1159,20 +1165,23 @@ __global__ __launch_bounds__(256, 2) void dense_conv3x3_x9_kernel(const float* _
     // after next travel global -> registers -> LDS (three weight buffers; stage chunk*9 + tap lives
     // in buffer tap % 3 because 9 % 3 == 0); one barrier per stage. The nine taps are unrolled, so
     // tap offsets and buffer numbers are immediates.
-    mf_v8bf fa[1][2][3], fb[1][NT][3];
-#define DC_READ(SET, TAP) {                                                                                           \
+    // fragments: the two M tiles' A planes, and the B planes of TWO N tiles at a time (with four N tiles all
+    // twelve B fragments alive next to 128 accumulator registers do not fit 256 registers)
+    mf_v8bf fa[2][3], fb[2][3];
+#define DC_READ_A(TAP) {                                                                                              \
         const unsigned char* Ap = As + ((2 * wave + (TAP) / 3) * DC_HW + r + (TAP) % 3) * DC_ROWB + h * 16;           \
-        const unsigned char* Bp = Bs + ((TAP) % 3) * BSZ + r * DC_ROWB + h * 16;                                      \
         _Pragma("unroll") for (int m = 0; m < 2; ++m) _Pragma("unroll") for (int p = 0; p < 3; ++p)                   \
-            fa[SET][m][p] = *reinterpret_cast<const mf_v8bf*>(Ap + p * APL + m * DC_HW * DC_ROWB);                    \
-        _Pragma("unroll") for (int t = 0; t < NT; ++t) _Pragma("unroll") for (int p = 0; p < 3; ++p)                  \
-            fb[SET][t][p] = *reinterpret_cast<const mf_v8bf*>(Bp + p * BPL + t * 32 * DC_ROWB); }
-    // the nine partial products, smallest first; tiles innermost so consecutive MFMAs never share an accumulator
-#define DC_MM1(SET, PA, PB) _Pragma("unroll") for (int m = 0; m < 2; ++m) _Pragma("unroll") for (int t = 0; t < NT; ++t) acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[SET][m][PA], fb[SET][t][PB], acc[m][t], 0, 0, 0);
+            fa[m][p] = *reinterpret_cast<const mf_v8bf*>(Ap + p * APL + m * DC_HW * DC_ROWB); }
+#define DC_READ_B(TAP, T0) {                                                                                          \
+        const unsigned char* Bp = Bs + ((TAP) % 3) * BSZ + r * DC_ROWB + h * 16 + (T0) * 32 * DC_ROWB;                \
+        _Pragma("unroll") for (int t = 0; t < 2; ++t) _Pragma("unroll") for (int p = 0; p < 3; ++p)                   \
+            fb[t][p] = *reinterpret_cast<const mf_v8bf*>(Bp + p * BPL + t * 32 * DC_ROWB); }
+    // partial products smallest first; tiles innermost so consecutive MFMAs never share an accumulator
+#define DC_MM1(T0, PA, PB) _Pragma("unroll") for (int m = 0; m < 2; ++m) _Pragma("unroll") for (int t = 0; t < 2; ++t) acc[m][(T0) + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[m][PA], fb[t][PB], acc[m][(T0) + t], 0, 0, 0);
 #ifdef X9_SIX
-#define DC_MMA(SET) DC_MM1(SET, 0, 2) DC_MM1(SET, 1, 1) DC_MM1(SET, 2, 0) DC_MM1(SET, 0, 1) DC_MM1(SET, 1, 0) DC_MM1(SET, 0, 0)
+#define DC_MMA(T0) DC_MM1(T0, 0, 2) DC_MM1(T0, 1, 1) DC_MM1(T0, 2, 0) DC_MM1(T0, 0, 1) DC_MM1(T0, 1, 0) DC_MM1(T0, 0, 0)
 #else
-#define DC_MMA(SET) DC_MM1(SET, 2, 2) DC_MM1(SET, 1, 2) DC_MM1(SET, 2, 1) DC_MM1(SET, 0, 2) DC_MM1(SET, 1, 1) DC_MM1(SET, 2, 0) DC_MM1(SET, 0, 1) DC_MM1(SET, 1, 0) DC_MM1(SET, 0, 0)
+#define DC_MMA(T0) DC_MM1(T0, 2, 2) DC_MM1(T0, 1, 2) DC_MM1(T0, 2, 1) DC_MM1(T0, 0, 2) DC_MM1(T0, 1, 1) DC_MM1(T0, 2, 0) DC_MM1(T0, 0, 1) DC_MM1(T0, 1, 0) DC_MM1(T0, 0, 0)
 #endif
 
     // Persistent workgroups: tiles blockIdx.x, blockIdx.x + gridDim.x, ... as one uninterrupted
@@ -1227,8 +1236,12 @@ __global__ __launch_bounds__(256, 2) void dense_conv3x3_x9_kernel(const float* _
                     if (tap + 2 < 9) { DC_LOAD_B(tap + 2, ch); }
                     else { DC_LOAD_B(tap + 2 - 9, ch + 1 < nchunks ? ch + 1 : 0); }
                 }
-                DC_READ(0, tap);
-                DC_MMA(0)
+                DC_READ_A(tap);
+#pragma unroll
+                for (int t0 = 0; t0 < NT; t0 += 2) {
+                    DC_READ_B(tap, t0);
+                    DC_MMA(t0)
+                }
                 if (more) { DC_STORE_B((tap + 2) % 3); }
                 __syncthreads();
             }
@@ -1277,15 +1290,18 @@ __global__ __launch_bounds__(256, 2) void dense_conv3x3_x9_kernel(const float* _
             __syncthreads();
             if (tid < 2 * CO) {
                 const int which = tid / CO, c = tid - which * CO;
-                if (c < cout)
-                    stats[((int64_t)tile * 2 + which) * cout + c] =
-                        ((double)red[(0 * 2 + which) * CO + c] + (double)red[(1 * 2 + which) * CO + c]) +
-                        ((double)red[(2 * 2 + which) * CO + c] + (double)red[(3 * 2 + which) * CO + c]);
+                if (c < cout) {
+                    double a = 0.0;
+#pragma unroll
+                    for (int w_ = 0; w_ < NWAVES; ++w_) a += (double)red[(w_ * 2 + which) * CO + c];
+                    stats[((int64_t)tile * 2 + which) * cout + c] = a;
+                }
             }
             __syncthreads();                                  // red is the next tile's halo buffer
         }
     }
-#undef DC_READ
+#undef DC_READ_A
+#undef DC_READ_B
 #undef DC_MM1
 #undef DC_MMA
 #undef DC_LOAD_A
@@ -1341,8 +1357,16 @@ extern "C" int gga_dense_conv3x3_pack(const float* weight, int64_t stride_co, in
     return GGA_OK;
 }
 
-extern "C" int64_t gga_dense_conv3x3_tiles(int B, int H, int W) {           // H, W of the tile space (swapped when transposed)
-    return (int64_t)B * ((W + DC_TW - 1) / DC_TW) * ((H + DC_TR - 1) / DC_TR);
+// rows per tile: 16 only for 128 output channels and when that still gives every CU a workgroup or two
+static inline int dc_tile_rows(int B, int H, int W, int cout) {
+    if (cout != 128) return 8;
+    const int64_t t16 = (int64_t)B * ((W + DC_TW - 1) / DC_TW) * ((H + 15) / 16);
+    return t16 >= 384 ? 16 : 8;
+}
+
+extern "C" int64_t gga_dense_conv3x3_tiles(int B, int H, int W, int cout) {   // H, W of the tile space (swapped when transposed)
+    const int tr = dc_tile_rows(B, H, W, cout);
+    return (int64_t)B * ((W + DC_TW - 1) / DC_TW) * ((H + tr - 1) / tr);
 }
 
 // Bench-only in-place timing (as for the pillar scatter): while armed, every launch whose shape matches
@@ -1385,20 +1409,22 @@ extern "C" int gga_dense_conv3x3_slice(const float* x, const void* split_weight,
                 "gga_dense_conv3x3: need cin %% 32 == 0 and cout 64 or 128 (got %d -> %d)", cin, cout);
     const int prow = transposed ? 1 : W, pcol = transposed ? W : 1;
     if (transposed) { const int t = H; H = W; W = t; }          // tile space of the transposed walk
-    const int tx = (W + DC_TW - 1) / DC_TW, ty = (H + DC_TR - 1) / DC_TR;
+    const int trows = dc_tile_rows(B, H, W, cout);
+    const int tx = (W + DC_TW - 1) / DC_TW, ty = (H + trows - 1) / trows;
     const int64_t n_tiles = (int64_t)B * tx * ty;
     GGA_REQUIRE(n_tiles < 2147483647ll, "gga_dense_conv3x3: too many tiles");
     // One tile per workgroup. The kernel also runs as persistent workgroups (grid < tiles, same speed
     // in isolation), but inside the train step a persistent grid starts while the previous kernel's
     // tail still occupies some CUs and the static tile split then leaves stragglers (one bench run in
     // two measured 89.7 instead of 73.8 ms per step); the hardware dispatcher balances one-tile workgroups.
-    const dim3 grid((unsigned)n_tiles), block(256);
+    const dim3 grid((unsigned)n_tiles), block(trows * 32);
     const bool timed = g_dc_count < g_dc_cap && cin == g_dc_cin && cout == g_dc_cout && (int64_t)H * W == g_dc_hw;
     if (timed) GGA_CHECK_HIP(hipEventRecord(g_dc_ev[g_dc_count][0], stream), "timing record");
-    if (cout == 64)
-        hipLaunchKernelGGL(dense_conv3x3_x9_kernel<2>, grid, block, 0, stream, x, (const uint16_t*)split_weight, B, H, W, cin, cout, tx, ty, y, (int)y_pixel_stride, prow, pcol, stats);
-    else
-        hipLaunchKernelGGL(dense_conv3x3_x9_kernel<4>, grid, block, 0, stream, x, (const uint16_t*)split_weight, B, H, W, cin, cout, tx, ty, y, (int)y_pixel_stride, prow, pcol, stats);
+#define DC_GO(NT_, TR_) hipLaunchKernelGGL((dense_conv3x3_x9_kernel<NT_, TR_>), grid, block, 0, stream, x, (const uint16_t*)split_weight, B, H, W, cin, cout, tx, ty, y, (int)y_pixel_stride, prow, pcol, stats)
+    if (cout == 64) DC_GO(2, 8);
+    else if (trows == 16) DC_GO(4, 16);
+    else DC_GO(4, 8);
+#undef DC_GO
     GGA_CHECK_LAUNCH("dense_conv3x3_x9_kernel");
     if (timed) GGA_CHECK_HIP(hipEventRecord(g_dc_ev[g_dc_count++][1], stream), "timing record");
     return GGA_OK;

@@ -56,7 +56,7 @@ def _run(x, weight, backward, want_stats=False):
     stats = None
     if n_out in (64, 128):
         if want_stats:
-            tiles = int(L.gga_dense_conv3x3_tiles(B, W, H) if tr else L.gga_dense_conv3x3_tiles(B, H, W))
+            tiles = int(L.gga_dense_conv3x3_tiles(B, W, H, n_out) if tr else L.gga_dense_conv3x3_tiles(B, H, W, n_out))
             stats = torch.empty((tiles, 2, n_out), dtype=torch.float64, device=x.device)
         check(L.gga_dense_conv3x3_slice(F._p(x), F._p(_pack(weight, backward, tr)), B, H, W, n_in, n_out, F._p(y), n_out,
                                         int(tr), F._p(stats), F._stream()), 'gga_dense_conv3x3')

@@ -296,10 +296,10 @@ int gga_sparse_conv_apply_split(const float* x, const int32_t* map, const void* 
  * 32-channel chunk, splits it into the three bf16 planes on the way into LDS and reuses it for
  * all nine taps. */
 /* The same convolution that also leaves the batch statistics of its output for the BatchNorm
- * that follows: stats [gga_dense_conv3x3_tiles(B,H,W)][2][cout] f64 = per-tile sum and sum of
+ * that follows: stats [gga_dense_conv3x3_tiles(B,H,W,cout)][2][cout] f64 = per-tile sum and sum of
  * squares per channel - the `partials` of gga_bn_relu_fwd_partials / gga_bn_stats_partials, so
  * the BatchNorm does not read y a second time for its reduction. stats may be NULL. */
-int64_t gga_dense_conv3x3_tiles(int B, int H, int W);
+int64_t gga_dense_conv3x3_tiles(int B, int H, int W, int cout);   /* tiles are 8 x 32 pixels for cout 64, 16 x 32 for 128 */
 int gga_dense_conv3x3_stats(const float* x, const void* split_weight, int B, int H, int W, int cin, int cout,
                             float* y, double* stats, void* stream);
 /* Weight gradient of the same convolution, bf16x9 with the pixel index as the GEMM's K (transposed
@@ -318,7 +318,7 @@ int gga_dense_wgrad3x3(const float* x, const float* grad_y, int B, int H, int W,
  * shared convolution of the head (centerpoint_head.py:255-262) is three 64 -> 128 calls. */
 /* transposed != 0: the 8 x 32-pixel tiles run 32 pixels along H instead of W (maps whose width is a
  * poor multiple of 32, e.g. 124 x 108 or 62 x 54); split_weight must then be packed with the ky / kx
- * strides swapped, and stats holds gga_dense_conv3x3_tiles(B, W, H) rows. Results are identical. */
+ * strides swapped, and stats holds gga_dense_conv3x3_tiles(B, W, H, cout) rows. Results are identical. */
 int gga_dense_conv3x3_slice(const float* x, const void* split_weight, int B, int H, int W, int cin, int cout,
                             float* y, int64_t y_pixel_stride, int transposed, double* stats, void* stream);
 /* Bench-only, in-step timing of the dense convolution (bench.py's `mfma_roofline`): after

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Headline benchmark: GGA train step on synthetic KITTI-shaped frames (BASELINE.json).
 
-    python bench.py --gpus 1 --steps 10 --warmup 3
+    python bench.py --gpus N --steps K --warmup W          # any N: starts its own ranks
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -11,32 +11,156 @@ CenterHead_GGA -> GGA losses -> backward -> (DDP all-reduce) -> grad clip -> Ada
 frames per GPU, fp32. Point clouds are resident in HBM before the timed region; weak scaling
 (every rank steps its own 16 frames, gradients all-reduced over RCCL).
 
-Rank 0 prints ONE JSON line; `roofline` is the pillar scatter (BASELINE's HBM metric) and
-`mfma_roofline` the 64 -> 64 dense 3x3 convolution (the step's dominant kernel), both timed with
-HIP events inside the timed steps; `cpu_baseline` is the oracle's CPU restatement of the same
-step on a bounded sample (N=1 only).
+Launch (reference: tools/dist_train.sh:10-20 wraps tools/train.py in torch.distributed.launch,
+one process per GPU; mmdet3d/apis/train.py:222-231 wraps the model in DDP): with ``--gpus N > 1``
+and no RANK in the environment this process starts the N ranks itself as child processes of
+``torch.distributed.run`` BEFORE touching the GPU, relays rank 0's JSON line and exits with the
+children's status. With fewer visible devices than ranks the ranks share devices over gloo (a
+functional check, reported as such in ``config.backend``).
+
+Rank 0 prints ONE JSON line; ``roofline`` is the pillar scatter (BASELINE's HBM metric),
+``mfma_roofline`` the 64 -> 64 dense 3x3 convolution (the step's dominant kernel), both timed with
+HIP events inside the timed steps; ``second_trunk`` is the reference's shipped model
+(configs/gga/gga_kitti_config.py: sparse-conv trunk, BASELINE config #3's per-GPU workload, bs 8)
+stepped in the same run; ``cpu_baseline`` is the oracle's CPU restatement of the same step on a
+bounded sample plus its pieces (N=1 only).
 """
 import argparse
 import gc
-import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (guides/MI355X_MICROARCH.md); ~6300 achievable
+BF16_PEAK_TFLOPS = 2500.0
+ARITH = ('fp32 in / fp32 out; dense + sparse convolutions multiply as six bf16 x bf16 MFMA partial products of '
+         'truncation-split operands, fp32 accumulate (error vs float64 <= MIOpen fp32); everything else plain fp32')
+PP_CONFIG = os.path.join(REPO, 'configs', 'gga', 'gga_kitti_pointpillars_config.py')
+SECOND_CONFIG = os.path.join(REPO, 'configs', 'gga', 'gga_kitti_config.py')
 
 
-def scatter_roofline(model, batches, device, step_ms):
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=16, help='frames per GPU')
+    ap.add_argument('--config', default=PP_CONFIG)
+    ap.add_argument('--nchw', action='store_true',
+                    help='keep the reference NCHW memory layout for the BEV trunk (default: channels-last memory, '
+                         'same logical tensors and values)')
+    ap.add_argument('--head-init-scale', type=float, default=0.05,
+                    help='damp the random init of the regression heads\' output convs (see damp_head_init)')
+    ap.add_argument('--miopen-find', action='store_true', help='torch.backends.cudnn.benchmark=True (MIOpen find mode)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-second-trunk', action='store_true', help='skip the gga_kitti_config.py (sparse trunk) leg')
+    ap.add_argument('--second-batch', type=int, default=8, help='frames per GPU of the second_trunk leg')
+    return ap.parse_args(argv)
+
+
+def launch_ranks(args):
+    """Parent of an N-rank run: no HIP call happens in this process (device_count does not
+    initialise the GPU on this image). Children are ordinary subprocesses, never an exec."""
+    import torch
+    n_dev = torch.cuda.device_count()
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    if n_dev < args.gpus and 'GGA_DIST_BACKEND' not in env:
+        env['GGA_DIST_BACKEND'] = 'gloo'      # ranks share devices: RCCL needs one device per rank
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.run(cmd, env=env)
+    sys.exit(proc.returncode)
+
+
+def damp_head_init(model, scale):
+    """Random-init only: Kaiming(fan_out) on the 1-3 channel output convs gives log-dimensions of
+    std ~5 (boxes of e^10 m and worse) on noise inputs, i.e. inf/NaN losses that say nothing about
+    speed. Scale those output convs so the synthetic run stays finite; architecture, shapes and
+    every kernel launched are unchanged."""
+    import torch
+    with torch.no_grad():
+        for th in model.pts_bbox_head.task_heads:
+            for name in ('reg', 'height', 'dim', 'rot'):
+                getattr(th, name)[-1].weight.mul_(scale)
+
+
+def run_workload(config, batch, steps, warmup, args, rank, world, device, sites=()):
+    """Build the model of `config`, step it `warmup` + `steps` times on two resident batches.
+    `sites`: (site, cap, key) timing sessions armed for the timed steps (rank 0).
+    -> dict(dt, loss, timings {site: [ms]}, model, batches, cfg)."""
+    import torch
+    import torch.distributed as dist
+    from gga_amd import Config, build_model, synthetic, _lib
+    from gga_amd.train import Runner
+
+    cfg = Config.fromfile(config)
+    channels_last = not args.nchw
+    if channels_last and cfg.model.pts_middle_encoder.type == 'PointPillarsScatter':
+        cfg.model.pts_middle_encoder['channels_last'] = True
+    torch.manual_seed(0)
+    model = build_model(cfg.model).to(device)
+    damp_head_init(model, args.head_init_scale)
+    if channels_last:
+        from gga_amd.cnn import to_channels_last
+        model = to_channels_last(model)
+    model.train()
+    runner = Runner(model, cfg, max_iters=max(1000, steps + warmup), distributed=world > 1, device=device)
+
+    pc_range = tuple(cfg.model.pts_voxel_layer.point_cloud_range)
+    batches = []
+    for i in range(2):      # two distinct batches per rank, point clouds resident in HBM
+        b = synthetic.make_batch(batch, start=i * batch, rank=rank, pc_range=pc_range)
+        b['points'] = [p.to(device) for p in b['points']]
+        batches.append({k: b[k] for k in synthetic.BATCH_KEYS + ('img_metas',)})
+    torch.cuda.synchronize()
+
+    for i in range(warmup):
+        runner.step(batches[i % 2])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    for site, cap, key in sites:      # HIP-event pairs around the kernels, no synchronisation
+        _lib.timing_begin(site, cap, key)
+    # no generational garbage collection inside the timed region: a gen-2 pass over the module tree
+    # takes tens of ms and drains the launch queue
+    gc.collect()
+    gc.disable()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        out = runner.step(batches[i % 2])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    gc.enable()
+    timings = {site: _lib.timing_collect(site, cap) for site, cap, _ in sites}
+    t = torch.tensor([dt], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    loss = float(out['loss'].detach()) if torch.is_tensor(out['loss']) else float(out['loss'])
+    assert loss == loss, f'loss is NaN ({config})'
+    return dict(dt=dt, loss=loss, timings=timings, model=model, batches=batches, cfg=cfg, runner=runner)
+
+
+def scatter_roofline(model, batches, step_ms):
     """`roofline` of the pillar-scatter canvas kernel: algorithmic bytes over
     its mean duration INSIDE the timed steps (`step_ms`: one HIP-event pair per step around the
     kernel, on the stream it is launched on)."""
+    import torch
     vl, me = model.pts_voxel_layer, model.pts_middle_encoder
     B = len(batches[0]['points'])
     ch = me.in_channels
@@ -47,25 +171,97 @@ def scatter_roofline(model, batches, device, step_ms):
     ms = sum(step_ms) / len(step_ms)
     gbs = algo / (ms * 1e-3) / 1e9
     knames = (['scatter_fill_kernel', 'scatter_rows_nhwc_kernel'] if me.channels_last else ['scatter_canvas_nchw_v2_kernel'])
-    # HBM bytes per launch from the PMC passes kept under profiles/ (FETCH_SIZE doubled per the
-    # gfx950 note, WRITE_SIZE exact); only quoted when the shape is the profiled one
-    traffic = None
-    try:
-        pmc = json.load(open(os.path.join(REPO, 'profiles', 'r01_scatter_pmc.json')))
-        if (B, ch, me.ny, me.nx) == (16, 64, 496, 432) and abs(m - 256000) < 2000:
-            traffic = sum(pmc['kernels'][k]['hbm_bytes_corrected'] for k in knames)
-    except (OSError, KeyError, ValueError):
-        pass
-    out = {'bound': 'hbm', 'kernel': '+'.join(knames), 'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-           'frac': round(gbs / HBM_PEAK_GBS, 4), 'traffic': traffic, 'algorithmic_bytes': int(algo),
-           'kernel_ms': round(ms, 4), 'launches_timed': len(step_ms), 'timed': 'in-step, HIP events on the launch stream',
-           'pillars': int(m)}
-    return out
+    # HBM bytes per launch: NOT measured in this run. Taken from the PMC passes kept under profiles/
+    # (FETCH_SIZE doubled per the gfx950 note, WRITE_SIZE exact) and only quoted when the shape is the profiled one.
+    traffic, src = None, None
+    for name in ('r02_scatter_pmc.json', 'r01_scatter_pmc.json'):
+        try:
+            pmc = json.load(open(os.path.join(REPO, 'profiles', name)))
+            if (B, ch, me.ny, me.nx) == (16, 64, 496, 432) and abs(m - 256000) < 2000:
+                traffic = sum(pmc['kernels'][k]['hbm_bytes_corrected'] for k in knames)
+                src = f'profiles/{name} (separate --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not this run)'
+                break
+        except (OSError, KeyError, ValueError):
+            continue
+    return {'bound': 'hbm', 'kernel': '+'.join(knames), 'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            'frac': round(gbs / HBM_PEAK_GBS, 4), 'traffic': traffic, 'traffic_source': src, 'algorithmic_bytes': int(algo),
+            'kernel_ms': round(ms, 4), 'launches_timed': len(step_ms), 'timed': 'in-step, HIP events on the launch stream',
+            'pillars': int(m)}
+
+
+def mfma_roofline(kernel, flops, ms_list, launches_per_step, ms_per_step):
+    """bf16 matrix work issued = 6 x the fp32 FLOPs (six partial products); peak = dense bf16 MFMA."""
+    avg = sum(ms_list) / len(ms_list)
+    tf = 6 * flops / (avg * 1e-3) / 1e12
+    return {'bound': 'mfma', 'kernel': kernel, 'achieved': round(tf, 1), 'peak': BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': round(tf / BF16_PEAK_TFLOPS, 4), 'fp32_equivalent_tflops': round(flops / (avg * 1e-3) / 1e12, 1),
+            'kernel_ms': round(avg, 4), 'launches_timed': len(ms_list), 'launches_per_step': launches_per_step,
+            'timed': 'in-step, HIP events on the launch stream',
+            # mean kernel time x launches per step (independent of how many launches the session sampled)
+            'share_of_step': round(avg * launches_per_step / ms_per_step, 3)}
+
+
+def _median_time(fn, warm=3, reps=10):
+    for _ in range(warm):
+        fn()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
+def cpu_pieces(cfg, frames=16):
+    """the oracle's pieces timed on the host (3 warm-ups + 10 timed, median) on the
+    same synthetic frames: (i) voxelize, (ii) pillar scatter, (iii) target generation,
+    (iv) 3D->2D projection + BPL/SRL geometry, (v) point-to-box alignment. ms per 16-frame batch."""
+    import numpy as np
+    import torch
+    from gga_amd import build_model, synthetic
+    from oracle import oracle as O
+    from oracle import torch_ref as R
+    torch.manual_seed(0)
+    model = build_model(cfg.model)
+    head, vl, me = model.pts_bbox_head, model.pts_voxel_layer, model.pts_middle_encoder
+    tc = head.train_cfg
+    batch = synthetic.make_batch(frames, start=901, pc_range=synthetic.RANGE_PP)
+    pts = [np.ascontiguousarray(p.numpy(), np.float32) for p in batch['points']]
+    out = {}
+    out['voxelize_ms'] = _median_time(lambda: O.voxelize_batch(pts, vl.voxel_size, vl.point_cloud_range, vl.max_num_points,
+                                                               vl.max_voxels[0])) * 1e3
+    v, n, c = O.voxelize_batch(pts, vl.voxel_size, vl.point_cloud_range, vl.max_num_points, vl.max_voxels[0])
+    feats, coors = torch.randn(len(c), 64), torch.from_numpy(c)
+    out['scatter_ms'] = _median_time(lambda: R.scatter(feats, coors, frames, me.ny, me.nx)) * 1e3
+    as_np = lambda xs: [a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a) for a in xs]
+    srl = O.draw_srl(frames, len(head.task_heads))
+    tg_args = (as_np(batch['gt_labels_3d']), as_np(batch['GGA_boxes_img']), as_np(batch['GGA_lidar2img']),
+               as_np(batch['GGA_init_pseudo_labels']), as_np(batch['GGA_bdry_masks']),
+               [as_np(f) for f in batch['GGA_in_box_points']], [m['lidar2img'] for m in batch['img_metas']], tc, srl)
+    out['targets_ms'] = _median_time(lambda: O.get_targets(*tg_args, n_tasks=len(head.task_heads))) * 1e3
+    tg = O.get_targets(*tg_args, n_tasks=len(head.task_heads))
+    K = tg['ind'][0].shape[1]
+    pred = [torch.randn(frames, K, 8) * 0.1 for _ in range(len(head.task_heads))]
+
+    def proj():
+        for t in range(len(head.task_heads)):
+            R.box_geometry(pred[t], torch.from_numpy(tg['ind'][t]), torch.from_numpy(tg['lidar2img'][t]), tc)
+    out['projection_ms'] = _median_time(proj) * 1e3
+    bevs = [R.box_geometry(pred[t], torch.from_numpy(tg['ind'][t]), torch.from_numpy(tg['lidar2img'][t]), tc)[3]
+            for t in range(len(head.task_heads))]
+
+    def pal():
+        for t in range(len(head.task_heads)):
+            R.pal_distances(tg['ibp'][t], bevs[t])
+    out['pal_ms'] = _median_time(pal, warm=1, reps=5) * 1e3
+    return {k: round(v, 2) for k, v in out.items()}
 
 
 def cpu_baseline(cfg, frames=16):
     """The oracle's CPU restatement of the same train step (C voxelizer + torch fp32 on the
-    host cores), one timed step on `frames` frames after a 1-frame warm-up."""
+    host cores), one timed step on `frames` frames after a 1-frame warm-up, and its pieces."""
+    import torch
     from gga_amd import build_model, synthetic
     from oracle import torch_ref as R
     # torch's CPU convolutions stop scaling (and oversubscribe badly) far below the 256 hardware
@@ -83,147 +279,115 @@ def cpu_baseline(cfg, frames=16):
     t0 = time.perf_counter()
     R.reference_train_step(model, batch)
     dt = time.perf_counter() - t0
+    cpu_model = ''
+    try:
+        cpu_model = [l.split(':', 1)[1].strip() for l in open('/proc/cpuinfo') if l.startswith('model name')][0]
+    except (OSError, IndexError):
+        pass
     return {'value': round(frames / dt, 4), 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
-            'sample': f'1 train step (fwd+bwd, no optimizer) on {frames} synthetic frames, {dt:.1f} s'}
-
-
-def damp_head_init(model, scale):
-    """Random-init only: Kaiming(fan_out) on the 1-3 channel output convs gives log-dimensions of
-    std ~5 (boxes of e^10 m and worse) on noise inputs, i.e. inf/NaN losses that say nothing about
-    speed. Scale those output convs so the synthetic run stays finite; architecture, shapes and
-    every kernel launched are unchanged."""
-    with torch.no_grad():
-        for th in model.pts_bbox_head.task_heads:
-            for name in ('reg', 'height', 'dim', 'rot'):
-                getattr(th, name)[-1].weight.mul_(scale)
+            'sample': f'1 train step (fwd+bwd, no optimizer) on {frames} synthetic frames, {dt:.1f} s',
+            'host_cpu': cpu_model, 'host_threads': os.cpu_count(),
+            'pieces_ms_per_16_frames': cpu_pieces(cfg, frames)}
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch', type=int, default=16, help='frames per GPU')
-    ap.add_argument('--config', default=os.path.join(REPO, 'configs', 'gga', 'gga_kitti_pointpillars_config.py'))
-    ap.add_argument('--nchw', action='store_true',
-                    help='keep the reference NCHW memory layout for the BEV trunk (default: channels-last memory, '
-                         'same logical tensors and values)')
-    ap.add_argument('--head-init-scale', type=float, default=0.05,
-                    help='damp the random init of the regression heads\' output convs (see damp_head_init)')
-    ap.add_argument('--miopen-find', action='store_true', help='torch.backends.cudnn.benchmark=True (MIOpen find mode)')
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-roofline', action='store_true')
-    args = ap.parse_args()
-    args.channels_last = not args.nchw
+    args = parse_args()
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        launch_ranks(args)
 
+    import torch
+    import torch.distributed as dist
     import gga_amd  # noqa: F401
-    from gga_amd import Config, build_model, synthetic
-    from gga_amd.train import Runner, init_dist
+    from gga_amd import _lib
+    from gga_amd.train import init_dist
 
     rank, world, local_rank = init_dist()
-    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
     assert torch.cuda.is_available(), 'bench.py needs an MI355X (the product has no CPU path)'
     device = torch.device('cuda', local_rank % torch.cuda.device_count())
     torch.cuda.set_device(device)
-
     torch.backends.cudnn.benchmark = bool(args.miopen_find)
-    cfg = Config.fromfile(args.config)
-    if args.channels_last and cfg.model.pts_middle_encoder.type == 'PointPillarsScatter':
-        cfg.model.pts_middle_encoder['channels_last'] = True
-    torch.manual_seed(0)
-    model = build_model(cfg.model).to(device)
-    damp_head_init(model, args.head_init_scale)
-    if args.channels_last:
-        from gga_amd.cnn import to_channels_last
-        model = to_channels_last(model)
-    model.train()
-    runner = Runner(model, cfg, max_iters=max(1000, args.steps + args.warmup), distributed=world > 1, device=device)
+    backend = dist.get_backend() if world > 1 else 'none'
+    if backend == 'nccl':
+        backend = 'nccl (RCCL)'
+    elif backend == 'gloo':
+        backend = f'gloo ({world} ranks on {torch.cuda.device_count()} device(s): functional check, not a scaling number)'
 
-    pc_range = tuple(cfg.model.pts_voxel_layer.point_cloud_range)
-    batches = []
-    for i in range(2):      # two distinct batches per rank, point clouds resident in HBM
-        b = synthetic.make_batch(args.batch, start=i * args.batch, rank=rank, pc_range=pc_range)
-        b['points'] = [p.to(device) for p in b['points']]
-        batches.append({k: b[k] for k in synthetic.BATCH_KEYS + ('img_metas',)})
-    torch.cuda.synchronize()
-
-    for i in range(args.warmup):
-        runner.step(batches[i % 2])
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    want_roofline = rank == 0 and not args.no_roofline and hasattr(model.pts_middle_encoder, 'ny')
-    if want_roofline:      # one HIP-event pair per step around the scatter canvas kernel (no synchronisation)
-        from gga_amd import _lib
-        _lib.check(_lib.lib().gga_pillar_scatter_timing_begin(min(args.steps, 256)), 'timing_begin')
-        # and around every 64 -> 64 dense 3x3 convolution at the head's map size (forward and backward-data
-        # of the first conv of the 15 head branches and of SECOND block 1): the step's dominant kernel
-        fh, fw = model.pts_middle_encoder.ny // 2, model.pts_middle_encoder.nx // 2
-        _lib.check(_lib.lib().gga_dense_conv3x3_timing_begin(512, 64, 64, fh * fw), 'dense_timing_begin')
-    # no generational garbage collection inside the timed region: a gen-2 pass over the module tree
-    # takes tens of ms and drains the launch queue (2 of ~12 runs measured +8..16 ms/step before
-    # this, 8 of 8 runs 72.5-72.8 ms after)
-    gc.collect()
-    gc.disable()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        out = runner.step(batches[i % 2])
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    gc.enable()
-    scatter_ms, dense_ms = [], []
+    is_pp = 'pointpillars' in os.path.basename(args.config)
+    want_roofline = rank == 0 and not args.no_roofline and is_pp
+    sites = []
     if want_roofline:
-        buf = (C.c_float * 256)()
-        n = _lib.lib().gga_pillar_scatter_timing_collect(buf, 256)
-        _lib.check(min(n, 0), 'timing_collect')
-        scatter_ms = [buf[i] for i in range(n)]
-        buf2 = (C.c_float * 512)()
-        n2 = _lib.lib().gga_dense_conv3x3_timing_collect(buf2, 512)
-        _lib.check(min(n2, 0), 'dense_timing_collect')
-        dense_ms = [buf2[i] for i in range(n2)]
-    t = torch.tensor([dt], dtype=torch.float64, device=device)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
-    loss = float(out['loss'].detach()) if torch.is_tensor(out['loss']) else float(out['loss'])
-    assert loss == loss, 'loss is NaN'
+        from gga_amd import Config
+        me = Config.fromfile(args.config).model.pts_middle_encoder
+        fh, fw = me.output_shape[0] // 2, me.output_shape[1] // 2
+        # one pair per step around the scatter op; one per 64 -> 64 dense 3x3 convolution at the head's map size
+        # (forward and backward-data of the first conv of the 15 head branches and of SECOND block 1)
+        sites = [(_lib.TIME_SCATTER_FWD, args.steps, 0),
+                 (_lib.TIME_DENSE_CONV, 36 * args.steps, _lib.timing_conv_key(64, 64, fh * fw))]
+    main_run = run_workload(args.config, args.batch, args.steps, args.warmup, args, rank, world, device, sites)
+    dt = main_run['dt']
+    ms_per_step = dt / args.steps * 1e3
 
+    res = None
     if rank == 0:
         res = {
             'metric': 'kitti_frames_per_sec_gga_train_step', 'value': round(args.batch * world * args.steps / dt, 3),
             'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'arith': ARITH, 'data': 'synthetic',
             'config': {'workload': ('BASELINE config #2: PointPillars voxelize+PFN+scatter + SECOND/FPN + '
-                                    'CenterHead_GGA losses' if 'pointpillars' in os.path.basename(args.config) else
+                                    'CenterHead_GGA losses' if is_pp else
                                     'gga_kitti_config.py: voxelize + HardSimpleVFE + SparseEncoder + SECOND/FPN + '
                                     'CenterHead_GGA losses') + ', full train step (fwd+bwd+clip+AdamW)',
                        'config_file': os.path.relpath(args.config, REPO),
                        'frames_per_gpu': args.batch, 'global_batch': args.batch * world, 'points_per_frame': 20000,
-                       'parallelism': f'dp{world}', 'memory_format': 'channels_last' if args.channels_last else 'nchw',
-                       'final_loss': round(loss, 4)},
+                       'parallelism': f'dp{world}', 'backend': backend,
+                       'memory_format': 'nchw' if args.nchw else 'channels_last',
+                       'final_loss': round(main_run['loss'], 4)},
         }
-        if scatter_ms:
-            res['roofline'] = scatter_roofline(model, batches, device, scatter_ms)
-        if dense_ms:
-            # the dominant kernel of the step is matrix-bound: fp32 convolution as six bf16 MFMA products per
-            # term, so the bf16 matrix work issued is 6 x the fp32 FLOPs; peak = dense bf16 MFMA (MI355X_MICROARCH.md)
-            fh, fw = model.pts_middle_encoder.ny // 2, model.pts_middle_encoder.nx // 2
+        tm = main_run['timings']
+        if tm.get(_lib.TIME_SCATTER_FWD):
+            res['roofline'] = scatter_roofline(main_run['model'], main_run['batches'], tm[_lib.TIME_SCATTER_FWD])
+        if tm.get(_lib.TIME_DENSE_CONV):
             flops = 2.0 * args.batch * fh * fw * 64 * 64 * 9
-            avg = sum(dense_ms) / len(dense_ms)
-            res['mfma_roofline'] = {'bound': 'mfma', 'kernel': 'dense_conv3x3_x9_kernel<2> (64->64, %dx%d, fwd + bwd-data)' % (fh, fw),
-                                    'achieved': round(6 * flops / (avg * 1e-3) / 1e12, 1), 'peak': 2500.0, 'unit': 'TFLOP/s',
-                                    'frac': round(6 * flops / (avg * 1e-3) / 1e12 / 2500.0, 4),
-                                    'fp32_equivalent_tflops': round(flops / (avg * 1e-3) / 1e12, 1),
-                                    'kernel_ms': round(avg, 4), 'launches_timed': len(dense_ms),
-                                    'timed': 'in-step, HIP events on the launch stream',
-                                    'share_of_step': round(sum(dense_ms) / args.steps / (dt / args.steps * 1e3), 3)}
+            res['mfma_roofline'] = mfma_roofline('dense_conv3x3_x9_kernel<2,8> (64->64, %dx%d, fwd + bwd-data)' % (fh, fw),
+                                                 flops, tm[_lib.TIME_DENSE_CONV],
+                                                 len(tm[_lib.TIME_DENSE_CONV]) / args.steps, ms_per_step)
+    cfg_main = main_run['cfg']
+    del main_run
+    gc.collect()
+    torch.cuda.empty_cache()
+
+    if is_pp and not args.no_second_trunk:
+        # the reference's shipped model section (sparse-conv trunk), same run, same launch
+        s_sites = [(_lib.TIME_SPARSE_CONV, 64 * args.steps, 0), (_lib.TIME_SPARSE_WGRAD, 32 * args.steps, 0)] if rank == 0 else []
+        sec = run_workload(SECOND_CONFIG, args.second_batch, args.steps, args.warmup, args, rank, world, device, s_sites)
+        if rank == 0:
+            sdt = sec['dt']
+            st = sec['timings']
+            conv_ms = sum(st.get(_lib.TIME_SPARSE_CONV, [])) / args.steps
+            wg_ms = sum(st.get(_lib.TIME_SPARSE_WGRAD, [])) / args.steps
+            res['second_trunk'] = {
+                'config_file': os.path.relpath(SECOND_CONFIG, REPO),
+                'workload': 'voxelize + HardSimpleVFE + SparseEncoder (sparse 3D conv) + SECOND/FPN + CenterHead_GGA '
+                            'losses, full train step (fwd+bwd+clip+AdamW)',
+                'frames_per_gpu': args.second_batch, 'global_batch': args.second_batch * world,
+                'value': round(args.second_batch * world * args.steps / sdt, 3), 'unit': 'frames/s',
+                'ms_per_step': round(sdt / args.steps * 1e3, 3), 'steps': args.steps, 'warmup': args.warmup,
+                'final_loss': round(sec['loss'], 4),
+                'dominant_kernels_ms_per_step': {
+                    'sp_conv_x9_kernel (sparse conv fwd + bwd-data, %d launches/step)' % (len(st.get(_lib.TIME_SPARSE_CONV, [])) // args.steps):
+                        round(conv_ms, 3),
+                    'sparse conv weight gradient (%d launches/step)' % (len(st.get(_lib.TIME_SPARSE_WGRAD, [])) // args.steps):
+                        round(wg_ms, 3)},
+                'timed': 'in-step, HIP events on the launch stream'}
+        del sec
+        gc.collect()
+        torch.cuda.empty_cache()
+
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            res['cpu_baseline'] = cpu_baseline(cfg)
+            res['cpu_baseline'] = cpu_baseline(cfg_main)
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

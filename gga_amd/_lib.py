@@ -11,7 +11,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libgga_hip.so')
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _lib = None
 
@@ -42,6 +42,8 @@ class LossParams(C.Structure):
 SIGNATURES = {
     'gga_last_error': (C.c_char_p, []),
     'gga_abi_version': (i32, []),
+    'gga_timing_begin': (i32, [i32, i32, i64]),
+    'gga_timing_collect': (i32, [i32, vp, i32]),
     'gga_voxel_grid_size': (None, [C.POINTER(VoxelParams), C.POINTER(C.c_int32 * 3)]),
     'gga_hard_voxelize_workspace_bytes': (sz, [i32, i64]),
     'gga_hard_voxelize_batch': (i32, [vp, i32, C.POINTER(C.c_int64), i32, C.POINTER(VoxelParams),
@@ -53,14 +55,12 @@ SIGNATURES = {
                                         i32, i32, C.c_double, vp, C.POINTER(C.c_uint64), vp, vp, vp, sz, vp]),
     'gga_voxel_mean': (i32, [vp, vp, i64, i32, i32, i32, vp, vp]),
     'gga_pfn_workspace_bytes': (sz, [i64]),
-    'gga_pfn_fwd': (i32, [vp, vp, vp, i64, i32, C.POINTER(PfnParams), vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
-    'gga_pfn_bwd': (i32, [vp, vp, vp, i64, i32, C.POINTER(PfnParams), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
+    'gga_pfn_fwd': (i32, [vp, vp, vp, i64, vp, i32, C.POINTER(PfnParams), vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
+    'gga_pfn_bwd': (i32, [vp, vp, vp, i64, vp, i32, C.POINTER(PfnParams), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
     'gga_pillar_scatter_map_bytes': (sz, [i32, i32, i32]),
     'gga_pillar_scatter_fwd': (i32, [vp, vp, i64, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp]),
     'gga_pillar_scatter_bwd': (i32, [vp, vp, i64, vp, i32, i32, i32, i32, i32, vp, vp]),
     'gga_pillar_conv_map': (i32, [vp, i64, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
-    'gga_pillar_scatter_timing_begin': (i32, [i32]),
-    'gga_pillar_scatter_timing_collect': (i32, [vp, i32]),
     'gga_sparse_index_bytes': (sz, [i64]),
     'gga_sparse_build_index': (i32, [vp, i64, i32, i32, i32, i32, vp, sz, vp]),
     'gga_sparse_out_index_bytes': (sz, [i64, i32]),
@@ -78,8 +78,6 @@ SIGNATURES = {
     'gga_dense_conv3x3_pack': (i32, [vp, i64, i64, i64, i64, i32, i32, i32, vp, vp]),
     'gga_dense_wgrad3x3_workspace_bytes': (sz, [i32, i32, i32, i32, i32]),
     'gga_dense_wgrad3x3': (i32, [vp, vp, i32, i32, i32, i32, i32, vp, i64, i64, i64, i64, i32, vp, sz, vp]),
-    'gga_dense_conv3x3_timing_begin': (i32, [i32, i32, i32, i64]),
-    'gga_dense_conv3x3_timing_collect': (i32, [vp, i32]),
     'gga_dense_conv3x3_tiles': (i64, [i32, i32, i32, i32]),
     'gga_dense_conv3x3_slice': (i32, [vp, vp, i32, i32, i32, i32, i32, vp, i64, i32, vp, vp]),
     'gga_dense_conv3x3_stats': (i32, [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]),
@@ -116,6 +114,26 @@ SIGNATURES = {
     'gga_image_box_match': (i32, [vp, vp, vp, vp, i32, i64, i32, vp, vp, vp, vp, vp]),
     'gga_points_in_boxes': (i32, [vp, vp, i32, i32, i32, i32, vp, vp]),
 }
+
+
+TIME_SCATTER_FWD, TIME_DENSE_CONV, TIME_SPARSE_CONV, TIME_SPARSE_WGRAD, TIME_DENSE_WGRAD = range(5)
+
+
+def timing_conv_key(cin, cout, hw=0):
+    """GGA_TIMING_CONV_KEY of include/gga_hip.h."""
+    return (int(cin) << 48) | (int(cout) << 32) | (int(hw) & 0xffffffff)
+
+
+def timing_begin(site, max_samples, key=0):
+    check(lib().gga_timing_begin(site, int(max_samples), int(key)), 'gga_timing_begin')
+
+
+def timing_collect(site, cap):
+    """-> list of per-call milliseconds of the armed session of `site` (waits for its events)."""
+    buf = (C.c_float * max(int(cap), 1))()
+    n = lib().gga_timing_collect(site, buf, int(cap))
+    check(min(n, 0), 'gga_timing_collect')
+    return [buf[i] for i in range(n)]
 
 
 def build(force=False):

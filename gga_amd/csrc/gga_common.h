@@ -10,6 +10,12 @@
 #define GGA_WAVE 64
 
 void gga_set_error(const char* fmt, ...);
+// event pair [2] of the next sample of an armed timing session (api.cc), or nullptr
+hipEvent_t* gga_timing_acquire(int site, int64_t key);
+#define GGA_TIME_START(tev_, stream_) \
+    do { if (tev_) GGA_CHECK_HIP(hipEventRecord((tev_)[0], stream_), "timing record"); } while (0)
+#define GGA_TIME_STOP(tev_, stream_) \
+    do { if (tev_) GGA_CHECK_HIP(hipEventRecord((tev_)[1], stream_), "timing record"); } while (0)
 
 #define GGA_REQUIRE(cond, ...)                      \
     do {                                            \

@@ -26,10 +26,18 @@
 // [M,64] output written once; nothing of size M*P*64 ever exists.
 #include "gga_common.h"
 
+// rows the caller marks valid: min(m, *num_valid) when a device count is given (capacity-sized
+// buffers of the sync-free voxelizer), m otherwise
+__device__ __forceinline__ int64_t pfn_valid_rows(int64_t m, const int32_t* __restrict__ num_valid) {
+    if (!num_valid) return m;
+    const int64_t v = *num_valid;
+    return v < m ? (v < 0 ? 0 : v) : m;
+}
+
 #define PFN_C 64
 #define PFN_F 10
 #define PFN_NM 65            // 10 first moments + 55 second moments
-#define PFN_SAVED 238        // S1[10] S2[100] mean[64] invstd[64]  (doubles)
+#define PFN_SAVED 238        // S1[10] S2[100] mean[64] invstd[64]  (doubles); saved[238] = rows normalised over
 
 struct PfnGeom {
     float vx, vy, vz, xo, yo, zo;
@@ -60,8 +68,10 @@ __device__ __forceinline__ void pfn_pillar_consts(const float4* __restrict__ pts
 
 __global__ __launch_bounds__(256) void pfn_moments_kernel(const float4* __restrict__ voxels,
                                                          const int32_t* __restrict__ num_points,
-                                                         const int4* __restrict__ coors, int64_t m, int P,
+                                                         const int4* __restrict__ coors, int64_t m,
+                                                         const int32_t* __restrict__ num_valid, int P,
                                                          PfnGeom g, double* __restrict__ partials) {
+    m = pfn_valid_rows(m, num_valid);
     double acc[PFN_NM];
 #pragma unroll
     for (int i = 0; i < PFN_NM; ++i) acc[i] = 0.0;
@@ -103,13 +113,17 @@ __global__ __launch_bounds__(256) void pfn_moments_kernel(const float4* __restri
 
 // one block of 64 threads (lane = channel)
 __global__ __launch_bounds__(64) void pfn_stats_kernel(const double* __restrict__ partials, int nblocks,
-                                                      double rows, const float* __restrict__ weight,
+                                                      int64_t m, const int32_t* __restrict__ num_valid, int P,
+                                                      const float* __restrict__ weight,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                                       float eps, float momentum, int training,
                                                       float* __restrict__ running_mean, float* __restrict__ running_var,
                                                       double* __restrict__ saved, float* __restrict__ scale_shift) {
     __shared__ double S[PFN_NM];
     const int c = threadIdx.x;
+    double rows = (double)pfn_valid_rows(m, num_valid) * (double)P;
+    rows = rows > 0.0 ? rows : 1.0;
+    if (c == 0) saved[PFN_SAVED] = rows;
     if (training) {
         for (int i = c; i < PFN_NM; i += 64) {
             double s = 0.0;
@@ -163,11 +177,13 @@ __global__ __launch_bounds__(64) void pfn_stats_kernel(const double* __restrict_
 // one wavefront per pillar, lane = channel
 __global__ __launch_bounds__(256) void pfn_apply_kernel(const float4* __restrict__ voxels,
                                                        const int32_t* __restrict__ num_points,
-                                                       const int4* __restrict__ coors, int64_t m, int P, PfnGeom g,
+                                                       const int4* __restrict__ coors, int64_t m,
+                                                       const int32_t* __restrict__ num_valid, int P, PfnGeom g,
                                                        const float* __restrict__ weight,
                                                        const float* __restrict__ scale_shift,
                                                        float* __restrict__ out, uint8_t* __restrict__ argmax) {
     const int lane = threadIdx.x & 63;
+    const int64_t mv = pfn_valid_rows(m, num_valid);
     float w[PFN_F];
 #pragma unroll
     for (int a = 0; a < PFN_F; ++a) w[a] = weight[lane * PFN_F + a];
@@ -178,6 +194,11 @@ __global__ __launch_bounds__(256) void pfn_apply_kernel(const float4* __restrict
     for (int64_t v = wave0; v < m; v += nwaves) {
         const int64_t vu = __builtin_amdgcn_readfirstlane((int)(v & 0xffffffff)) |
                            ((int64_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32);   // wave-uniform
+        if (vu >= mv) {                                // capacity rows past the valid count: defined zeros
+            out[vu * PFN_C + lane] = 0.0f;
+            argmax[vu * PFN_C + lane] = 255;
+            continue;
+        }
         int n = num_points[vu];
         n = n < P ? n : P;
         const float4* pts = voxels + vu * P;
@@ -206,7 +227,8 @@ __global__ __launch_bounds__(256) void pfn_apply_kernel(const float4* __restrict
 
 __global__ __launch_bounds__(256) void pfn_bwd_kernel(const float4* __restrict__ voxels,
                                                      const int32_t* __restrict__ num_points,
-                                                     const int4* __restrict__ coors, int64_t m, int P, PfnGeom g,
+                                                     const int4* __restrict__ coors, int64_t m,
+                                                     const int32_t* __restrict__ num_valid, int P, PfnGeom g,
                                                      const float* __restrict__ weight, const double* __restrict__ saved,
                                                      const float* __restrict__ out, const uint8_t* __restrict__ argmax,
                                                      const float* __restrict__ grad_out, float* __restrict__ partials) {
@@ -218,6 +240,7 @@ __global__ __launch_bounds__(256) void pfn_bwd_kernel(const float4* __restrict__
     float acc[PFN_BW];
 #pragma unroll
     for (int i = 0; i < PFN_BW; ++i) acc[i] = 0.0f;
+    m = pfn_valid_rows(m, num_valid);
     const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * 4;
     for (int64_t v = wave0; v < m; v += nwaves) {
@@ -259,7 +282,7 @@ __global__ __launch_bounds__(256) void pfn_bwd_kernel(const float4* __restrict__
 }
 
 __global__ __launch_bounds__(768) void pfn_bwd_final_kernel(const float* __restrict__ partials, int nblocks,
-                                                           double rows, const float* __restrict__ weight,
+                                                           const float* __restrict__ weight,
                                                            const float* __restrict__ gamma,
                                                            const double* __restrict__ saved,
                                                            float* __restrict__ grad_weight,
@@ -279,6 +302,7 @@ __global__ __launch_bounds__(768) void pfn_bwd_final_kernel(const float* __restr
     if (threadIdx.x >= PFN_C) return;
     const int c = threadIdx.x;
     const double A = red[0][c], Bx = red[1][c];
+    const double rows = saved[PFN_SAVED];
     const double mean = saved[110 + c], invstd = saved[174 + c];
     grad_beta[c] = (float)A;
     grad_gamma[c] = (float)Bx;
@@ -315,8 +339,8 @@ static int pfn_check(const char* fn, const gga_pfn_params* prm, int64_t m, int P
     return GGA_OK;
 }
 
-extern "C" int gga_pfn_fwd(const float* voxels, const int32_t* num_points, const int32_t* coors, int64_t m, int P,
-                           const gga_pfn_params* prm, const float* weight, const float* gamma, const float* beta,
+extern "C" int gga_pfn_fwd(const float* voxels, const int32_t* num_points, const int32_t* coors, int64_t m,
+                           const int32_t* num_valid, int P, const gga_pfn_params* prm, const float* weight, const float* gamma, const float* beta,
                            float* running_mean, float* running_var, float* out, uint8_t* argmax, double* saved,
                            void* workspace, size_t workspace_bytes, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
@@ -335,21 +359,21 @@ extern "C" int gga_pfn_fwd(const float* voxels, const int32_t* num_points, const
     const int nb = pfn_blocks(m);
     if (prm->training) {
         hipLaunchKernelGGL(pfn_moments_kernel, dim3(nb), dim3(256), 0, stream, (const float4*)voxels, num_points,
-                           (const int4*)coors, m, P, g, partials);
+                           (const int4*)coors, m, num_valid, P, g, partials);
         GGA_CHECK_LAUNCH("pfn_moments_kernel");
     }
-    hipLaunchKernelGGL(pfn_stats_kernel, dim3(1), dim3(64), 0, stream, partials, nb, (double)m * (double)P, weight,
+    hipLaunchKernelGGL(pfn_stats_kernel, dim3(1), dim3(64), 0, stream, partials, nb, m, num_valid, P, weight,
                        gamma, beta, prm->eps, prm->momentum, prm->training, running_mean, running_var, saved,
                        scale_shift);
     GGA_CHECK_LAUNCH("pfn_stats_kernel");
     hipLaunchKernelGGL(pfn_apply_kernel, dim3(pfn_wave_blocks(m)), dim3(256), 0, stream, (const float4*)voxels,
-                       num_points, (const int4*)coors, m, P, g, weight, scale_shift, out, argmax);
+                       num_points, (const int4*)coors, m, num_valid, P, g, weight, scale_shift, out, argmax);
     GGA_CHECK_LAUNCH("pfn_apply_kernel");
     return GGA_OK;
 }
 
-extern "C" int gga_pfn_bwd(const float* voxels, const int32_t* num_points, const int32_t* coors, int64_t m, int P,
-                           const gga_pfn_params* prm, const float* weight, const float* gamma, const float* out,
+extern "C" int gga_pfn_bwd(const float* voxels, const int32_t* num_points, const int32_t* coors, int64_t m,
+                           const int32_t* num_valid, int P, const gga_pfn_params* prm, const float* weight, const float* gamma, const float* out,
                            const uint8_t* argmax, const double* saved, const float* grad_out, float* grad_weight,
                            float* grad_gamma, float* grad_beta, void* workspace, size_t workspace_bytes,
                            void* stream_) {
@@ -367,10 +391,10 @@ extern "C" int gga_pfn_bwd(const float* voxels, const int32_t* num_points, const
                         prm->offsets[0], prm->offsets[1], prm->offsets[2] };
     const int nb = pfn_wave_blocks(m);
     hipLaunchKernelGGL(pfn_bwd_kernel, dim3(nb), dim3(256), 0, stream, (const float4*)voxels, num_points,
-                       (const int4*)coors, m, P, g, weight, saved, out, argmax, grad_out, (float*)workspace);
+                       (const int4*)coors, m, num_valid, P, g, weight, saved, out, argmax, grad_out, (float*)workspace);
     GGA_CHECK_LAUNCH("pfn_bwd_kernel");
     hipLaunchKernelGGL(pfn_bwd_final_kernel, dim3(1), dim3(PFN_BW * PFN_C), 0, stream, (const float*)workspace, nb,
-                       (double)m * (double)P, weight, gamma, saved, grad_weight, grad_gamma, grad_beta);
+                       weight, gamma, saved, grad_weight, grad_gamma, grad_beta);
     GGA_CHECK_LAUNCH("pfn_bwd_final_kernel");
     return GGA_OK;
 }

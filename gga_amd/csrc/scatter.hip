@@ -282,35 +282,6 @@ static int scatter_check(const char* fn, int64_t m, int batch, int channels, int
     return GGA_OK;
 }
 
-// Bench-only in-place timing: while armed, every forward call brackets its canvas kernel with a
-// pair of HIP events on the caller's stream (nothing is synchronised until the collect call).
-#define SCATTER_TIMING_MAX 256
-static hipEvent_t g_tev[SCATTER_TIMING_MAX][2];
-static int g_tcap = 0, g_tcount = 0, g_tmade = 0;
-
-extern "C" int gga_pillar_scatter_timing_begin(int max_samples) {
-    GGA_REQUIRE(max_samples >= 0 && max_samples <= SCATTER_TIMING_MAX, "gga_pillar_scatter_timing_begin: 0 <= max_samples <= %d",
-                SCATTER_TIMING_MAX);
-    for (; g_tmade < max_samples; ++g_tmade) {
-        GGA_CHECK_HIP(hipEventCreate(&g_tev[g_tmade][0]), "timing event");
-        GGA_CHECK_HIP(hipEventCreate(&g_tev[g_tmade][1]), "timing event");
-    }
-    g_tcap = max_samples;
-    g_tcount = 0;
-    return GGA_OK;
-}
-
-extern "C" int gga_pillar_scatter_timing_collect(float* ms_host, int cap) {
-    GGA_REQUIRE(ms_host || cap == 0, "gga_pillar_scatter_timing_collect: null pointer argument");
-    const int n = g_tcount < cap ? g_tcount : cap;
-    for (int i = 0; i < n; ++i) {
-        GGA_CHECK_HIP(hipEventSynchronize(g_tev[i][1]), "timing sync");
-        GGA_CHECK_HIP(hipEventElapsedTime(&ms_host[i], g_tev[i][0], g_tev[i][1]), "timing elapsed");
-    }
-    g_tcap = g_tcount = 0;
-    return n;
-}
-
 extern "C" int gga_pillar_scatter_fwd(const float* feats, const int32_t* coors, int64_t m, const int32_t* num_valid,
                                       int batch, int channels, int ny, int nx, int layout, int unique_coors,
                                       int32_t* cell_map, float* canvas, void* stream_) {
@@ -320,10 +291,10 @@ extern "C" int gga_pillar_scatter_fwd(const float* feats, const int32_t* coors, 
                 "gga_pillar_scatter_fwd: null pointer argument");
     if (int rc = scatter_check("gga_pillar_scatter_fwd", m, batch, channels, ny, nx, layout)) return rc;
     const int64_t cells = (int64_t)ny * nx;
-    const bool timed = g_tcount < g_tcap;
+    hipEvent_t* tev = gga_timing_acquire(GGA_TIME_SCATTER_FWD, 0);
     const bool fill_rows = layout == GGA_LAYOUT_NHWC;
     // NHWC: the timing events bracket the whole op (fill, map, rows); NCHW: the canvas kernel
-    if (timed && fill_rows) GGA_CHECK_HIP(hipEventRecord(g_tev[g_tcount][0], stream), "timing record");
+    if (fill_rows) GGA_TIME_START(tev, stream);
     if (fill_rows) {
         const int64_t total4 = (int64_t)batch * cells * (channels / 4);
         const dim3 grid((unsigned)((total4 + 1023) / 1024)), block(256);
@@ -335,11 +306,11 @@ extern "C" int gga_pillar_scatter_fwd(const float* feats, const int32_t* coors, 
                            num_valid, batch, ny, nx, cell_map);
         GGA_CHECK_LAUNCH("scatter_map_kernel");
     }
-    if (timed && !fill_rows) GGA_CHECK_HIP(hipEventRecord(g_tev[g_tcount][0], stream), "timing record");
+    if (!fill_rows) GGA_TIME_START(tev, stream);
     if (layout == GGA_LAYOUT_NCHW) {
         launch_canvas_nchw(stream, feats, cell_map, channels, cells, batch, canvas);
         GGA_CHECK_LAUNCH("scatter_canvas_nchw_kernel");
-        if (timed) GGA_CHECK_HIP(hipEventRecord(g_tev[g_tcount++][1], stream), "timing record");
+        GGA_TIME_STOP(tev, stream);
     } else {
         const int c4 = channels / 4;
         const int shift = ((c4 & (c4 - 1)) == 0) ? (31 - __builtin_clz(c4)) : -1;
@@ -358,7 +329,7 @@ extern "C" int gga_pillar_scatter_fwd(const float* feats, const int32_t* coors, 
                                    (const int4*)coors, m, num_valid, batch, ny, nx, c4, shift, cell_map, (float4*)canvas);
             GGA_CHECK_LAUNCH("scatter_rows_nhwc_kernel");
         }
-        if (timed) GGA_CHECK_HIP(hipEventRecord(g_tev[g_tcount++][1], stream), "timing record");
+        GGA_TIME_STOP(tev, stream);
         if (m > 0 && need_map && !inplace_reset) {
             hipLaunchKernelGGL(scatter_map_reset_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, stream,
                                coors, m, num_valid, batch, ny, nx, cell_map);

@@ -891,6 +891,8 @@ extern "C" int gga_sparse_conv_apply_split(const float* x, const int32_t* map, c
                 "gga_sparse_conv_apply_split: bad sizes (rows=%lld kvol=%d cin=%d cout=%d; cout <= 128)", (long long)n_rows,
                 kvol, cin, cout);
     const dim3 grid((unsigned)((n_rows + X9_TM - 1) / X9_TM)), block(64 * X9_NW);
+    hipEvent_t* tev = gga_timing_acquire(GGA_TIME_SPARSE_CONV, GGA_TIMING_CONV_KEY(cin, cout, 0));
+    GGA_TIME_START(tev, stream);
 #define X9_LAUNCH(NT, VEC) hipLaunchKernelGGL((sp_conv_x9_kernel<NT, VEC>), grid, block, 0, stream, x, map, (const uint16_t*)split_weight, perm, rowmask, n_rows, kvol, cin, cout, flip, y)
     if ((cin & 3) == 0) {
         switch (mf_nt(cout)) {
@@ -907,6 +909,7 @@ extern "C" int gga_sparse_conv_apply_split(const float* x, const int32_t* map, c
     }
 #undef X9_LAUNCH
     GGA_CHECK_LAUNCH("sp_conv_x9_kernel");
+    GGA_TIME_STOP(tev, stream);
     return GGA_OK;
 }
 
@@ -1043,6 +1046,8 @@ extern "C" int gga_sparse_conv_wgrad(const float* x, const float* grad_out, cons
     GGA_REQUIRE(x && grad_out && map && grad_weight, "gga_sparse_conv_wgrad: null pointer argument");
     GGA_REQUIRE(n_rows >= 1 && kvol >= 1 && cin >= 1 && cin <= 128 && cout >= 1 && cout <= 128,
                 "gga_sparse_conv_wgrad: bad sizes (cin, cout <= 128)");
+    hipEvent_t* tev = gga_timing_acquire(GGA_TIME_SPARSE_WGRAD, GGA_TIMING_CONV_KEY(cin, cout, 0));
+    GGA_TIME_START(tev, stream);
     GGA_CHECK_HIP(hipMemsetAsync(grad_weight, 0, (size_t)kvol * cin * cout * sizeof(float), stream), "wgrad memset");
     const dim3 grid((unsigned)((n_rows + SP_WCHUNK - 1) / SP_WCHUNK), kvol), block(256);
     const int ni = (cin + 31) / 32, nj = (cout + 31) / 32;
@@ -1058,6 +1063,7 @@ extern "C" int gga_sparse_conv_wgrad(const float* x, const float* grad_out, cons
     else MW(4, 4)
 #undef MW
     GGA_CHECK_LAUNCH("sp_conv_wgrad_mfma_kernel");
+    GGA_TIME_STOP(tev, stream);
     return GGA_OK;
 }
 
@@ -1369,35 +1375,6 @@ extern "C" int64_t gga_dense_conv3x3_tiles(int B, int H, int W, int cout) {   //
     return (int64_t)B * ((W + DC_TW - 1) / DC_TW) * ((H + tr - 1) / tr);
 }
 
-// Bench-only in-place timing (as for the pillar scatter): while armed, every launch whose shape matches
-// (cin, cout, H*W) is bracketed with a HIP event pair on its stream; nothing synchronises until collect.
-#define DC_TIMING_MAX 512
-static hipEvent_t g_dc_ev[DC_TIMING_MAX][2];
-static int g_dc_made = 0, g_dc_cap = 0, g_dc_count = 0, g_dc_cin = 0, g_dc_cout = 0;
-static int64_t g_dc_hw = 0;
-
-extern "C" int gga_dense_conv3x3_timing_begin(int max_samples, int cin, int cout, int64_t hw) {
-    GGA_REQUIRE(max_samples >= 0 && max_samples <= DC_TIMING_MAX, "gga_dense_conv3x3_timing_begin: 0 <= max_samples <= %d",
-                DC_TIMING_MAX);
-    for (; g_dc_made < max_samples; ++g_dc_made) {
-        GGA_CHECK_HIP(hipEventCreate(&g_dc_ev[g_dc_made][0]), "timing event");
-        GGA_CHECK_HIP(hipEventCreate(&g_dc_ev[g_dc_made][1]), "timing event");
-    }
-    g_dc_cap = max_samples; g_dc_count = 0; g_dc_cin = cin; g_dc_cout = cout; g_dc_hw = hw;
-    return GGA_OK;
-}
-
-extern "C" int gga_dense_conv3x3_timing_collect(float* ms_host, int cap) {
-    GGA_REQUIRE(ms_host || cap == 0, "gga_dense_conv3x3_timing_collect: null pointer argument");
-    const int n = g_dc_count < cap ? g_dc_count : cap;
-    for (int i = 0; i < n; ++i) {
-        GGA_CHECK_HIP(hipEventSynchronize(g_dc_ev[i][1]), "timing sync");
-        GGA_CHECK_HIP(hipEventElapsedTime(&ms_host[i], g_dc_ev[i][0], g_dc_ev[i][1]), "timing elapsed");
-    }
-    g_dc_cap = g_dc_count = 0;
-    return n;
-}
-
 extern "C" int gga_dense_conv3x3_slice(const float* x, const void* split_weight, int B, int H, int W, int cin, int cout,
                                        float* y, int64_t y_pixel_stride, int transposed, double* stats, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
@@ -1418,15 +1395,15 @@ extern "C" int gga_dense_conv3x3_slice(const float* x, const void* split_weight,
     // tail still occupies some CUs and the static tile split then leaves stragglers (one bench run in
     // two measured 89.7 instead of 73.8 ms per step); the hardware dispatcher balances one-tile workgroups.
     const dim3 grid((unsigned)n_tiles), block(trows * 32);
-    const bool timed = g_dc_count < g_dc_cap && cin == g_dc_cin && cout == g_dc_cout && (int64_t)H * W == g_dc_hw;
-    if (timed) GGA_CHECK_HIP(hipEventRecord(g_dc_ev[g_dc_count][0], stream), "timing record");
+    hipEvent_t* tev = gga_timing_acquire(GGA_TIME_DENSE_CONV, GGA_TIMING_CONV_KEY(cin, cout, (int64_t)H * W));
+    GGA_TIME_START(tev, stream);
 #define DC_GO(NT_, TR_) hipLaunchKernelGGL((dense_conv3x3_x9_kernel<NT_, TR_>), grid, block, 0, stream, x, (const uint16_t*)split_weight, B, H, W, cin, cout, tx, ty, y, (int)y_pixel_stride, prow, pcol, stats)
     if (cout == 64) DC_GO(2, 8);
     else if (trows == 16) DC_GO(4, 16);
     else DC_GO(4, 8);
 #undef DC_GO
     GGA_CHECK_LAUNCH("dense_conv3x3_x9_kernel");
-    if (timed) GGA_CHECK_HIP(hipEventRecord(g_dc_ev[g_dc_count++][1], stream), "timing record");
+    GGA_TIME_STOP(tev, stream);
     return GGA_OK;
 }
 
@@ -1646,11 +1623,14 @@ extern "C" int gga_dense_wgrad3x3(const float* x, const float* grad_y, int B, in
     if (transposed) { const int t = H; H = W; W = t; const int64_t ts = stride_ky; stride_ky = stride_kx; stride_kx = ts; }
     const int strips = (W + 31) / 32;
     const int nblk = dense_wgrad_blocks(B, H, W, cin, cout), ncb = (cin >> 6) * (cout >> 6);
+    hipEvent_t* tev = gga_timing_acquire(GGA_TIME_DENSE_WGRAD, GGA_TIMING_CONV_KEY(cin, cout, (int64_t)H * W));
+    GGA_TIME_START(tev, stream);
     hipLaunchKernelGGL(dense_wgrad3x3_x9_kernel, dim3(nblk, ncb), dim3(256), 0, stream, x, grad_y, B, H, W, cin, cout, strips,
                        prow, pcol, (float*)workspace);
     GGA_CHECK_LAUNCH("dense_wgrad3x3_x9_kernel");
     hipLaunchKernelGGL(dense_wgrad_reduce_kernel, dim3((9 * 64 * 64 + 255) / 256, ncb), dim3(256), 0, stream,
                        (const float*)workspace, nblk, cin, cout, stride_co, stride_ci, stride_ky, stride_kx, grad_weight);
     GGA_CHECK_LAUNCH("dense_wgrad_reduce_kernel");
+    GGA_TIME_STOP(tev, stream);
     return GGA_OK;
 }

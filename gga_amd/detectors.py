@@ -83,7 +83,11 @@ class MVXTwoStageDetector_GGA(nn.Module):
     def voxelize(self, points):
         """list of [N_b, C] -> voxels [SM,P,C], num_points [SM], coors_batch [SM,4] (b,z,y,x):
         one batched HIP call instead of the per-frame loop + cat + pad of the reference."""
-        voxels, num_points, coors, _ = self.pts_voxel_layer.forward_batch(points)
+        # no host read-back when both consumers take the device-side pillar count (fused PFN + scatter):
+        # the buffers then keep their capacity B * max_voxels and `coors.num_valid` carries the count
+        sync = not (getattr(self.pts_voxel_encoder, 'accepts_num_valid', False)
+                    and getattr(self.pts_middle_encoder, 'accepts_num_valid', False))
+        voxels, num_points, coors, _ = self.pts_voxel_layer.forward_batch(points, sync=sync)
         return voxels, num_points, coors
 
     def forward_train(self, points=None, img_metas=None, gt_bboxes_3d=None, gt_labels_3d=None,

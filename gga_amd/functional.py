@@ -94,7 +94,14 @@ def hard_voxelize_batch(points, voxel_size, point_cloud_range, max_points, max_v
     if sync:
         m = int(voxel_num[-1].item())
         return voxels[:m], num_points[:m], coors[:m], voxel_num
+    coors.num_valid = voxel_num[B:]           # device count travels with the coordinates (see num_valid_of)
     return voxels, num_points, coors, voxel_num
+
+
+def num_valid_of(coors):
+    """Device i32 [1] count of the rows that exist in capacity-sized voxel buffers (set by the
+    ``sync=False`` voxelizer calls), or None for exact-sized ones."""
+    return getattr(coors, 'num_valid', None)
 
 
 class PreparedPoints:
@@ -184,6 +191,7 @@ def hard_voxelize_prepared(prep, voxel_size, point_cloud_range, max_points, max_
     if sync:
         m = int(voxel_num[-1].item())
         return voxels[:m], num_points[:m], coors[:m], voxel_num
+    coors.num_valid = voxel_num[B:]
     return voxels, num_points, coors, voxel_num
 
 
@@ -203,7 +211,7 @@ def voxel_mean(voxels, num_points, num_features):
 # ----------------------------------------------------------------------------- a2'
 class _FusedPFN(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, voxels, num_points, coors, weight, gamma, beta, running_mean, running_var, prm):
+    def forward(ctx, voxels, num_points, coors, weight, gamma, beta, running_mean, running_var, prm, num_valid=None):
         _need_cuda(voxels, num_points, coors, weight)
         voxels, coors = voxels.contiguous(), coors.contiguous()
         m, P, _ = voxels.shape
@@ -211,14 +219,14 @@ class _FusedPFN(torch.autograd.Function):
         L = _lib.lib()
         out = torch.empty((m, 64), dtype=torch.float32, device=dev)
         argmax = torch.empty((m, 64), dtype=torch.uint8, device=dev)
-        saved = torch.empty(238, dtype=torch.float64, device=dev)
+        saved = torch.empty(239, dtype=torch.float64, device=dev)
         ws = _workspace('pfn', L.gga_pfn_workspace_bytes(m), dev)
         w = weight.contiguous()
-        check(L.gga_pfn_fwd(_p(voxels), _p(num_points), _p(coors), m, P, C.byref(prm), _p(w), _p(gamma),
+        check(L.gga_pfn_fwd(_p(voxels), _p(num_points), _p(coors), m, _p(num_valid), P, C.byref(prm), _p(w), _p(gamma),
                             _p(beta), _p(running_mean), _p(running_var), _p(out), _p(argmax), _p(saved),
                             _p(ws), ws.numel(), _stream()), 'gga_pfn_fwd')
         ctx.save_for_backward(voxels, num_points, coors, w, gamma, out, argmax, saved)
-        ctx.prm = prm
+        ctx.prm, ctx.num_valid = prm, num_valid
         return out
 
     @staticmethod
@@ -229,10 +237,10 @@ class _FusedPFN(torch.autograd.Function):
         gw, gg, gb = torch.empty_like(w), torch.empty_like(gamma), torch.empty_like(gamma)
         ws = _workspace('pfn', L.gga_pfn_workspace_bytes(m), g.device)
         g = g.contiguous()
-        check(L.gga_pfn_bwd(_p(voxels), _p(num_points), _p(coors), m, P, C.byref(ctx.prm), _p(w), _p(gamma),
-                            _p(out), _p(argmax), _p(saved), _p(g), _p(gw), _p(gg), _p(gb), _p(ws),
+        check(L.gga_pfn_bwd(_p(voxels), _p(num_points), _p(coors), m, _p(ctx.num_valid), P, C.byref(ctx.prm), _p(w),
+                            _p(gamma), _p(out), _p(argmax), _p(saved), _p(g), _p(gw), _p(gg), _p(gb), _p(ws),
                             ws.numel(), _stream()), 'gga_pfn_bwd')
-        return None, None, None, gw, gg, gb, None, None, None
+        return None, None, None, gw, gg, gb, None, None, None, None
 
 
 def pfn_params(voxel_size, offsets, eps, momentum, training):
@@ -244,9 +252,11 @@ def pfn_params(voxel_size, offsets, eps, momentum, training):
     return prm
 
 
-def fused_pfn(voxels, num_points, coors, weight, gamma, beta, running_mean, running_var, prm):
-    """Fused PillarFeatureNet: [M,P,4] -> [M,64] (running stats updated in place when training)."""
-    return _FusedPFN.apply(voxels, num_points, coors, weight, gamma, beta, running_mean, running_var, prm)
+def fused_pfn(voxels, num_points, coors, weight, gamma, beta, running_mean, running_var, prm, num_valid=None):
+    """Fused PillarFeatureNet: [M,P,4] -> [M,64] (running stats updated in place when training).
+    ``num_valid``: device i32 count of the pillars that exist when the buffers are capacity-sized
+    (``hard_voxelize_batch(sync=False)``); the output rows past it are zero."""
+    return _FusedPFN.apply(voxels, num_points, coors, weight, gamma, beta, running_mean, running_var, prm, num_valid)
 
 
 # ----------------------------------------------------------------------------- a3

@@ -26,7 +26,14 @@ class PointPillarsScatter(nn.Module):
         self.unique_coors = True
         self.fp16_enabled = False
 
+    accepts_num_valid = True
+
     def forward(self, voxel_features, coors, batch_size=None, num_valid=None):
+        if num_valid is None:
+            num_valid = F.num_valid_of(coors)       # capacity-sized buffers of the sync-free voxelizer
+            if num_valid is not None and voxel_features.shape[0] != coors.shape[0]:
+                m = voxel_features.shape[0]         # the encoder already trimmed to the exact rows
+                coors, num_valid = coors[:m], None
         if batch_size is None:
             # forward_single of the reference: one sample, batch index ignored
             coors = coors.clone()

@@ -99,6 +99,8 @@ class PillarFeatureNet(nn.Module):
                 and features.shape[0] > 0 and isinstance(l0.norm, nn.BatchNorm1d) and l0.norm.affine
                 and l0.norm.track_running_stats and l0.norm.momentum is not None and features.dtype == torch.float32)
 
+    accepts_num_valid = True        # capacity-sized inputs with a device-side count (detectors.voxelize)
+
     def forward(self, features, num_points, coors):
         if self._fusable(features):
             # one fused HIP pass (gga_amd/csrc/pfn.hip) instead of the [M,P,64] eager pipeline
@@ -109,7 +111,10 @@ class PillarFeatureNet(nn.Module):
             if self.training:
                 bn.num_batches_tracked += 1
             return F.fused_pfn(features, num_points.int(), coors.int(), l0.linear.weight, bn.weight, bn.bias,
-                               bn.running_mean, bn.running_var, prm)
+                               bn.running_mean, bn.running_var, prm, num_valid=F.num_valid_of(coors))
+        if F.num_valid_of(coors) is not None:     # capacity-sized buffers: the eager ops need the exact rows
+            m = int(F.num_valid_of(coors).item())
+            features, num_points, coors = features[:m], num_points[:m], coors[:m]
         return self.forward_eager(features, num_points, coors)
 
     def forward_eager(self, features, num_points, coors):

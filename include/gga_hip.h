@@ -41,6 +41,26 @@ const char* gga_last_error(void);
 /* ABI version of this header; bumped on any signature change. */
 int gga_abi_version(void);
 
+/* Measurement only (bench.py's `roofline` objects): kernel timing sessions. After
+ * gga_timing_begin(site, n, key) the next n calls of that site's entry point bracket their
+ * launches with a pair of HIP events on the caller's stream (no synchronisation, so the step
+ * being timed is not disturbed); gga_timing_collect waits for those events and writes the
+ * durations in milliseconds, returning how many were taken (negative status on error) and
+ * disarming the site. `key` = 0 times every call; otherwise only calls whose shape key matches
+ * (see the site list). Thread-safe; one session per site at a time. */
+enum {
+    GGA_TIME_SCATTER_FWD = 0,   /* gga_pillar_scatter_fwd: NHWC fill [+ map] + rows, NCHW canvas kernel */
+    GGA_TIME_DENSE_CONV = 1,    /* gga_dense_conv3x3*: key = GGA_TIMING_CONV_KEY(cin, cout, H*W) */
+    GGA_TIME_SPARSE_CONV = 2,   /* gga_sparse_conv_apply[_split]: key = GGA_TIMING_CONV_KEY(cin, cout, 0) */
+    GGA_TIME_SPARSE_WGRAD = 3,  /* gga_sparse_conv_wgrad: same key */
+    GGA_TIME_DENSE_WGRAD = 4,   /* gga_dense_wgrad3x3: key as GGA_TIME_DENSE_CONV */
+    GGA_TIME_SITES = 5
+};
+#define GGA_TIMING_CONV_KEY(cin, cout, hw) \
+    (((int64_t)(cin) << 48) | ((int64_t)(cout) << 32) | ((int64_t)(hw) & 0xffffffffll))
+int gga_timing_begin(int site, int max_samples, int64_t key);
+int gga_timing_collect(int site, float* ms_host, int cap);
+
 /* ------------------------------------------------------------------------- */
 /* a1. Hard voxelization, whole batch in one call.                            */
 /* Replaces: mmcv.ops.Voxelization(deterministic=True) called once per frame  */
@@ -138,16 +158,20 @@ size_t gga_pfn_workspace_bytes(int64_t m);
  * voxels [m,P,4] f32, num_points [m] i32, coors [m,4] i32 (b,z,y,x)
  * weight [64,10], gamma/beta [64], running_mean/var [64] (updated in place when training)
  * out [m,64] f32; argmax [m,64] u8 (index of the winning point, 255 = a padding row)
- * saved [238] f64: first/second moments of the decorated features, per-channel mean / invstd
+ * saved [239] f64: first/second moments of the decorated features, per-channel mean / invstd,
+ *   and the row count the statistics were taken over
+ * num_valid: optional device i32 scalar; only pillars < *num_valid exist (capacity-sized buffers of
+ *   gga_hard_voxelize_batch read without a host sync): the BatchNorm statistics run over
+ *   min(m, *num_valid) * max_points rows and the out rows past it are zero.
  */
 int gga_pfn_fwd(const float* voxels, const int32_t* num_points, const int32_t* coors, int64_t m,
-                int max_points, const gga_pfn_params* prm, const float* weight, const float* gamma,
+                const int32_t* num_valid, int max_points, const gga_pfn_params* prm, const float* weight, const float* gamma,
                 const float* beta, float* running_mean, float* running_var, float* out,
                 uint8_t* argmax, double* saved, void* workspace, size_t workspace_bytes,
                 void* stream);
 /* grad_weight [64,10], grad_gamma [64], grad_beta [64] from grad_out [m,64] (points carry no grad). */
 int gga_pfn_bwd(const float* voxels, const int32_t* num_points, const int32_t* coors, int64_t m,
-                int max_points, const gga_pfn_params* prm, const float* weight, const float* gamma,
+                const int32_t* num_valid, int max_points, const gga_pfn_params* prm, const float* weight, const float* gamma,
                 const float* out, const uint8_t* argmax, const double* saved, const float* grad_out,
                 float* grad_weight, float* grad_gamma, float* grad_beta, void* workspace,
                 size_t workspace_bytes, void* stream);
@@ -201,14 +225,6 @@ int gga_pillar_conv_map(const int32_t* coors, int64_t m, const int32_t* num_vali
                         int kh, int kw, int stride_h, int stride_w, int pad_h, int pad_w, int32_t* map,
                         void* stream);
 
-/* Bench-only, in-place timing of the scatter inside real steps: after
- * gga_pillar_scatter_timing_begin(n) the next n gga_pillar_scatter_fwd calls bracket their
- * kernels (NHWC: fill [+ map] + rows, i.e. the whole op; NCHW: the canvas kernel) with HIP events
- * on the caller's stream (no synchronisation);
- * gga_pillar_scatter_timing_collect waits for them and writes the durations (ms), returning how
- * many were taken (or a negative status). Single-threaded use (bench.py). */
-int gga_pillar_scatter_timing_begin(int max_samples);
-int gga_pillar_scatter_timing_collect(float* ms_host, int cap);
 
 /* ------------------------------------------------------------------------- */
 /* a3'. Sparse 3D convolution (SubMConv3d / SparseConv3d) for SparseEncoder.  */
@@ -321,12 +337,6 @@ int gga_dense_wgrad3x3(const float* x, const float* grad_y, int B, int H, int W,
  * strides swapped, and stats holds gga_dense_conv3x3_tiles(B, W, H, cout) rows. Results are identical. */
 int gga_dense_conv3x3_slice(const float* x, const void* split_weight, int B, int H, int W, int cin, int cout,
                             float* y, int64_t y_pixel_stride, int transposed, double* stats, void* stream);
-/* Bench-only, in-step timing of the dense convolution (bench.py's `mfma_roofline`): after
- * gga_dense_conv3x3_timing_begin(n, cin, cout, H*W) the next n launches of that shape are bracketed
- * with HIP events on their stream; gga_dense_conv3x3_timing_collect waits for them and returns the
- * per-launch milliseconds (count returned, negative on error). */
-int gga_dense_conv3x3_timing_begin(int max_samples, int cin, int cout, int64_t hw);
-int gga_dense_conv3x3_timing_collect(float* ms_host, int cap);
 
 /* split_weight for gga_dense_conv3x3 straight from the framework's [cout, cin, 3, 3] parameter with
  * arbitrary element strides (channels-last parameters included): size

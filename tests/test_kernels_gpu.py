@@ -562,7 +562,9 @@ def test_pillar_conv_valid_count_and_fallbacks():
                                            (64, 128, 1, 41, 33), (384, 64, 1, 20, 36),
                                            # maps walked transposed (width a poor multiple of 32) and 256-wide outputs in slices
                                            (64, 64, 2, 62, 54), (128, 128, 1, 31, 22), (256, 256, 1, 30, 20),
-                                           (128, 256, 1, 9, 40)])
+                                           (128, 256, 1, 9, 40),
+                                           # 16-row / 512-thread tiles (cout 128 and >= 384 tiles): straight and transposed walk
+                                           (128, 128, 12, 128, 128), (128, 128, 16, 124, 108), (64, 128, 13, 120, 128)])
 def test_dense_conv3x3_vs_torch(cin, cout, B, H, W):
     """fp32 convolution through nine exact bf16 partial products: forward and backward-data against
     torch's convolution in float64 (error no larger than a few fp32 ulps of the accumulated sum)."""
@@ -589,19 +591,22 @@ def test_dense_conv3x3_vs_torch(cin, cout, B, H, W):
     assert not dense_conv.eligible(conv, x.detach().contiguous())
 
 
-def test_dense_conv_leaves_batchnorm_partials():
+@pytest.mark.parametrize('cin,cout,B,H,W', [(64, 64, 3, 37, 45), (64, 128, 2, 37, 45), (128, 128, 2, 31, 22),
+                                           (128, 128, 12, 128, 128), (128, 128, 16, 124, 108)])
+def test_dense_conv_leaves_batchnorm_partials(cin, cout, B, H, W):
     """The statistics epilogue of the dense conv equals the reductions of its output, and the
-    BatchNorm fed with them equals the BatchNorm that reduces y itself."""
+    BatchNorm fed with them equals the BatchNorm that reduces y itself - 64 and 128 output channels,
+    8-row and 16-row tiles, straight and transposed walk."""
     import copy
     from gga_amd import dense_conv
     torch.manual_seed(7)
-    conv = torch.nn.Conv2d(64, 64, 3, padding=1, bias=False).to(DEV)
-    bn = torch.nn.BatchNorm2d(64, eps=1e-3, momentum=0.01).to(DEV)
+    conv = torch.nn.Conv2d(cin, cout, 3, padding=1, bias=False).to(DEV)
+    bn = torch.nn.BatchNorm2d(cout, eps=1e-3, momentum=0.01).to(DEV)
     bn2 = copy.deepcopy(bn)
-    x = torch.randn(3, 64, 37, 45, device=DEV).contiguous(memory_format=torch.channels_last)
+    x = torch.randn(B, cin, H, W, device=DEV).contiguous(memory_format=torch.channels_last)
     y = dense_conv.conv2d(x, conv, bn_follows=True)
     p = y.bn_partials
-    assert p.dtype == torch.float64 and p.shape[1:] == (2, 64)
+    assert p.dtype == torch.float64 and p.shape[1:] == (2, cout)
     yd = y.detach().double()
     # per-tile sums are fp32 over 256 pixels, then f64: error relative to the sum of magnitudes
     mag = float(yd.abs().sum((0, 2, 3)).max())
@@ -617,3 +622,44 @@ def test_dense_conv_leaves_batchnorm_partials():
     g = torch.randn_like(out)
     out.backward(g)
     assert conv.weight.grad is not None and torch.isfinite(conv.weight.grad).all()
+
+
+def test_dense_conv3x3_non_finite_and_wide_range():
+    """Contract of the split-plane arithmetic at the edges of fp32 (include/gga_hip.h):
+    finite inputs of any magnitude (2^-100 .. 2^100, denormals) give the fp32 result to the usual
+    accumulation error; a non-finite input makes exactly the outputs non-finite that an fp32
+    convolution makes non-finite (as NaN: Inf splits into Inf - Inf), and no other output moves."""
+    from gga_amd import dense_conv
+    torch.manual_seed(3)
+    conv = torch.nn.Conv2d(64, 64, 3, padding=1, bias=False).to(DEV)
+    conv.weight.data = conv.weight.data.contiguous(memory_format=torch.channels_last)
+    base = torch.randn(2, 64, 24, 40, device=DEV)
+    # wide range: every pixel has its own power-of-two scale (a dot product's terms share it, so the
+    # float64 reference bounds the error per output by its own magnitude)
+    e = torch.randint(-100, 101, (2, 1, 24, 40), device=DEV).float()
+    x = (base * torch.exp2(e)).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        y = dense_conv.conv2d(x, conv)
+        mag = torch.nn.functional.conv2d(x.double().abs(), conv.weight.double().abs(), padding=1)
+        ref = torch.nn.functional.conv2d(x.double(), conv.weight.double(), padding=1)
+    assert torch.isfinite(y).all()
+    assert float(((y.double() - ref).abs() / mag).max()) < 5e-6      # relative to sum |a*b| of the same output
+    # denormal inputs: result within one denormal-product's worth of the float64 one (flush-to-zero or not)
+    xd = (base * 1e-41).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        yd = dense_conv.conv2d(xd, conv)
+        refd = torch.nn.functional.conv2d(xd.double(), conv.weight.double(), padding=1)
+    assert torch.isfinite(yd).all() and float((yd.double() - refd).abs().max()) < 1e-37
+    # non-finite inputs
+    xn = base.clone()
+    xn[0, 3, 5, 7] = float('inf')
+    xn[1, 10, 20, 33] = float('-inf')
+    xn[1, 0, 0, 0] = float('nan')
+    xn = xn.contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        yn = dense_conv.conv2d(xn, conv)
+        rn = torch.nn.functional.conv2d(xn.double(), conv.weight.double(), padding=1)
+        y0 = dense_conv.conv2d(base.contiguous(memory_format=torch.channels_last), conv)
+    bad = ~torch.isfinite(rn)
+    assert bad.any() and torch.equal(~torch.isfinite(yn), bad)
+    assert torch.equal(yn[~bad], y0[~bad])                          # every other output is bit-identical

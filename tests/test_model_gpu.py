@@ -14,6 +14,7 @@ from oracle import torch_ref as R
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
 PP_CFG = os.path.join(REPO, 'configs', 'gga', 'gga_kitti_pointpillars_config.py')
+GRAD_TOL = 1e-3      # per-parameter relative L2 error of the gradients against the CPU restatement
 
 
 def test_graft_smoke():
@@ -53,9 +54,10 @@ def test_pp_train_step_matches_cpu_reference(channels_last):
                                       data['GGA_in_box_points'], data['img_metas'], srl=srl)
     assert set(losses) == set(ref_losses) and len(losses) == 18
     for k, v in ref_losses.items():
-        assert float(losses[k]) == pytest.approx(float(v), rel=2e-4, abs=1e-4), k     # north_star: within 1e-4
+        assert float(losses[k]) == pytest.approx(float(v), rel=1e-4, abs=1e-4), k     # north_star: within 1e-4
     total, log_vars = model._parse_losses(losses)
     total.backward()
+    worst = {}
     for (n1, p1), (n2, p2) in zip(model.named_parameters(), ref.named_parameters()):
         assert n1 == n2
         if p2.grad is None:
@@ -64,8 +66,11 @@ def test_pp_train_step_matches_cpu_reference(channels_last):
         g1, g2 = p1.grad.cpu(), p2.grad
         denom = float(g2.norm())
         if denom > 1e-6:
-            # MIOpen picks fp32 Winograd kernels for the 3x3 trunk convs: ~5e-3 drift on the earliest layers
-            assert float((g1 - g2).norm()) / denom < 2e-2, (n1, float((g1 - g2).norm()) / denom)
+            # every layer's gradient within 1e-3 of the CPU restatement's (relative L2), see GRAD_TOL
+            err = float((g1 - g2).norm()) / denom
+            worst[n1] = err
+            assert err < GRAD_TOL, (n1, err)
+    print('worst gradient errors:', sorted(worst.items(), key=lambda kv: -kv[1])[:5])
 
 
 def test_runner_steps_and_loss_decreases():
@@ -122,20 +127,30 @@ def test_multi_step_trajectory_matches_cpu_restatement():
         torch.nn.utils.clip_grad_norm_([p for p in ref.parameters() if p.grad is not None], max_norm=35, norm_type=2)
         opt.step()
         ref_losses.append(float(total.detach()))
-    # GPU path
+    # GPU path; before every step the CPU restatement is also evaluated from a copy of the GPU
+    # model's CURRENT weights (same batch, same SRL draws): the loss curve along the real
+    # trajectory, step by step, within the north-star tolerance
     torch.manual_seed(123)
     model.to(DEV)
     runner = Runner(model, cfg, max_iters=100)
-    losses = []
+    losses, resync = [], []
     for it in range(n_steps):
         b = batches[it % 2]
         data = {k: b[k] for k in synthetic.BATCH_KEYS + ('img_metas',)}
         data['points'] = [p.to(DEV) for p in b['points']]
+        here = copy.deepcopy(model).cpu()
+        rng = torch.get_rng_state()
+        _, total_here = R.reference_train_step(here, b, backward=False)
+        torch.set_rng_state(rng)              # the GPU step draws the same SRL factors
+        resync.append(float(total_here.detach()))
         losses.append(float(runner.step(data)['loss'].detach()))
-    # step 0 starts from identical weights: within the north-star tolerance. AdamW divides by
-    # sqrt(v): where a gradient is ~0, fp32-rounding-level differences (MIOpen vs CPU convs) become
-    # lr-sized weight differences, so the trajectories separate by about 10x per step
-    for it, tol in enumerate((2e-4, 1e-3, 1e-2)):
+    for it in range(n_steps):
+        assert losses[it] == pytest.approx(resync[it], rel=1e-4), (it, losses, resync)
+    # free-running trajectories (each side keeps its own weights): step 0 starts from identical
+    # weights. AdamW divides by sqrt(v): where a gradient is ~0, fp32-rounding-level differences
+    # between the two convolution implementations become lr-sized weight differences, so the
+    # trajectories separate by about 10x per step
+    for it, tol in enumerate((1e-4, 1e-3, 1e-2)):
         assert losses[it] == pytest.approx(ref_losses[it], rel=tol), (it, losses, ref_losses)
     num = sum(float((p.detach().cpu() - q.detach()).pow(2).sum()) for p, q in zip(model.parameters(), ref.parameters()))
     den = sum(float(q.detach().pow(2).sum()) for q in ref.parameters())
@@ -167,26 +182,54 @@ def test_second_config_train_step_runs_and_learns():
     assert len([k for k in out['log_vars'] if k.startswith('task')]) == 18
 
 
-def test_two_rank_ddp_on_one_gpu():
-    """The real detector under DistributedDataParallel with two ranks (gloo, both on this GPU):
-    exercises the custom autograd Functions inside DDP's reducer hooks, host-side label inputs
-    and bench.py's multi-rank timing path. RCCL itself needs >= 2 GPUs (driver-side run)."""
+def _run_bench(extra, env=None, timeout=900):
     import json
-    import socket
     import subprocess
     import sys
-    with socket.socket() as s:
-        s.bind(('127.0.0.1', 0))
-        port = s.getsockname()[1]
-    env = dict(os.environ, GGA_DIST_BACKEND='gloo')
-    out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
-                          '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.join(REPO, 'bench.py'),
-                          '--gpus', '2', '--steps', '2', '--warmup', '1', '--batch', '2', '--no-roofline'],
-                         env=env, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stderr[-2000:]
-    line = [l for l in out.stdout.splitlines() if l.startswith('{')][-1]
-    res = json.loads(line)
+    out = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py')] + extra, env=env, capture_output=True, text=True,
+                         timeout=timeout)
+    assert out.returncode == 0, out.stderr[-3000:]
+    return json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
+
+
+def test_bench_gpus2_plain_command_starts_its_own_ranks():
+    """`python bench.py --gpus 2` as a plain command (no torchrun wrapper): the parent starts two
+    ranks before touching the GPU (tools/dist_train.sh:10-20 in the reference). On a one-GPU box the
+    ranks share the device over gloo; the real detector runs under DistributedDataParallel with the
+    custom autograd Functions inside DDP's reducer hooks and host-side label inputs. Both configs:
+    the PointPillars trunk as the main line, the shipped sparse trunk as `second_trunk`."""
+    res = _run_bench(['--gpus', '2', '--steps', '2', '--warmup', '1', '--batch', '2', '--second-batch', '2',
+                      '--no-roofline'])
     assert res['n_gpus'] == 2 and res['value'] > 0 and res['config']['global_batch'] == 4
+    assert res['config']['parallelism'] == 'dp2'
+    n_dev = torch.cuda.device_count()
+    assert res['config']['backend'].startswith('nccl' if n_dev >= 2 else 'gloo')
+    st = res['second_trunk']
+    assert st['global_batch'] == 4 and st['value'] > 0 and st['config_file'].endswith('gga_kitti_config.py')
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='RCCL needs one device per rank (>= 2 GPUs)')
+def test_two_rank_rccl_both_configs():
+    """Two ranks on two GPUs, backend nccl (= RCCL): gradient all-reduce over xGMI for the
+    PointPillars config and for configs/gga/gga_kitti_config.py (BASELINE config #3's workload)."""
+    env = dict(os.environ, GGA_DIST_BACKEND='nccl')
+    res = _run_bench(['--gpus', '2', '--steps', '3', '--warmup', '2', '--batch', '4', '--second-batch', '4',
+                      '--no-roofline'], env=env)
+    assert res['n_gpus'] == 2 and res['config']['backend'].startswith('nccl')
+    assert res['config']['global_batch'] == 8 and res['second_trunk']['global_batch'] == 8
+    assert res['value'] > 0 and res['second_trunk']['value'] > 0
+
+
+def test_bench_line_contract_single_gpu():
+    """The default single-GPU line carries every field the driver and the judge read."""
+    res = _run_bench(['--steps', '2', '--warmup', '1', '--batch', '2', '--second-batch', '2', '--no-cpu-baseline'])
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+              'vs_baseline', 'dtype', 'arith', 'data', 'config', 'roofline', 'mfma_roofline', 'second_trunk'):
+        assert k in res, k
+    assert res['roofline']['bound'] == 'hbm' and res['roofline']['launches_timed'] == 2
+    assert res['mfma_roofline']['launches_timed'] == 2 * res['mfma_roofline']['launches_per_step']
+    assert 0 < res['mfma_roofline']['share_of_step'] < 1
+    assert 'six bf16' in res['arith'] and res['dtype'] == 'f32'
 
 
 def test_edge_cases_empty_inputs():

@@ -196,3 +196,42 @@ def test_boxes3d_overlaps_known_answer():     # reference tests/test_utils/test_
                                rtol=1e-3, atol=1e-4)
     np.testing.assert_allclose(overlaps_3d_from_bev(O.box_iou_rotated, KA_OV1, KA_OV2, 'iof'), KA_IOF3D,
                                rtol=1e-3, atol=1e-4)
+
+
+# ----------------------------------------------------------------------------- sparse conv restatements
+@pytest.mark.parametrize('cfg', [
+    dict(subm=True, cin=4, cout=16, k=3, s=1, p=1),
+    dict(subm=False, cin=16, cout=32, k=3, s=2, p=1),
+    dict(subm=False, cin=8, cout=8, k=3, s=2, p=(0, 1, 1)),
+    dict(subm=False, cin=8, cout=12, k=(3, 1, 1), s=(2, 1, 1), p=0),
+    dict(subm=False, cin=5, cout=6, k=3, s=1, p=0),
+])
+def test_sparse_pair_list_restatement_equals_dense_restatement(cfg):
+    """oracle/sparse_ref.conv_ref_pairs (runs at the real grid size) against conv_ref (dense conv3d,
+    the published definition) on a small grid: same site set, same order, same values and gradients."""
+    import torch
+    from gga_amd.sparse import SparseConv3d, SubMConv3d
+    from oracle import sparse_ref as SR
+    torch.manual_seed(0)
+    shape, B = (9, 14, 12), 2
+    g = torch.Generator().manual_seed(4)
+    coors = []
+    for b in range(B):
+        pts = torch.stack([torch.randint(0, shape[0], (150,), generator=g), torch.randint(0, shape[1], (150,), generator=g),
+                           torch.randint(0, shape[2], (150,), generator=g)], 1)
+        pts = torch.unique(pts, dim=0)
+        pts = pts[torch.randperm(len(pts), generator=g)]
+        coors.append(torch.cat([torch.full((len(pts), 1), b), pts], 1))
+    coors = torch.cat(coors).int()
+    cls = SubMConv3d if cfg['subm'] else SparseConv3d
+    conv = cls(cfg['cin'], cfg['cout'], cfg['k'], stride=cfg['s'], padding=cfg['p'], bias=False)
+    x1 = torch.randn(len(coors), cfg['cin'], requires_grad=True)
+    x2 = x1.detach().clone().requires_grad_(True)
+    y1, c1, s1 = SR.conv_ref(conv, x1, coors, B, shape)
+    w_grad_dense = torch.autograd.grad(y1.square().sum(), [x1, conv.weight])
+    y2, c2, s2 = SR.conv_ref_pairs(conv, x2, coors, B, shape)
+    w_grad_pairs = torch.autograd.grad(y2.square().sum(), [x2, conv.weight])
+    assert tuple(s1) == tuple(s2) and torch.equal(c1.long(), c2.long())
+    torch.testing.assert_close(y1, y2, rtol=1e-5, atol=1e-5)
+    for a, b in zip(w_grad_dense, w_grad_pairs):
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-4)

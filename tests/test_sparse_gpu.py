@@ -110,7 +110,7 @@ def test_sparse_encoder_gga_config_vs_dense_reference():
     y.backward(g.to(DEV))
     for (n1, p1), (n2, p2) in zip(enc.named_parameters(), ref.named_parameters()):
         err = float((p1.grad.cpu() - p2.grad).norm() / (p2.grad.norm() + 1e-12))
-        assert err < 2e-2, (n1, err)      # 21 fp32 conv+BN layers deep; the last levels hold few sites
+        assert err < 2e-3, (n1, err)      # 21 fp32 conv+BN layers deep; the last levels hold few sites
     for (n1, b1), (n2, b2) in zip(enc.named_buffers(), ref.named_buffers()):
         torch.testing.assert_close(b1.cpu(), b2, rtol=1e-4, atol=1e-5, msg=n1)
 
@@ -125,3 +125,55 @@ def test_reference_shape_test():
     coors = _coords(4, (40, 1024, 1024), 50000, seed=9, clustered=False).to(DEV)
     ret = enc(torch.rand(len(coors), 5, device=DEV), coors, 4)
     assert ret.shape == torch.Size([4, 256, 128, 128])
+
+
+def test_sparse_encoder_full_grid_vs_pair_list_reference():
+    """The SparseEncoder of configs/gga/gga_kitti_config.py at its real grid (41 x 1600 x 1408) on four
+    voxelized synthetic KITTI frames (> 50 k input sites): after EVERY convolution the site set
+    equals the pair-list restatement's exactly and the features agree; then the gradients of every
+    parameter. (The dense conv3d restatement cannot hold this grid; oracle/sparse_ref.conv_ref_pairs
+    is pinned to it on small grids by tests/test_oracle.py.)"""
+    import os
+    from conftest import REPO
+    from gga_amd import Config, synthetic
+    from gga_amd import functional as F
+    from gga_amd.registry import build_middle_encoder
+    from gga_amd.sparse import SparseConvolution
+    cfg = Config.fromfile(os.path.join(REPO, 'configs', 'gga', 'gga_kitti_config.py'))
+    torch.manual_seed(0)
+    enc = build_middle_encoder(cfg.model.pts_middle_encoder)
+    enc.train()
+    ref = copy.deepcopy(enc)
+    B = 4
+    batch = synthetic.make_batch(B, n_points=20000, pc_range=synthetic.RANGE_SECOND)
+    vl = cfg.model.pts_voxel_layer
+    v, n, c, _ = F.hard_voxelize_batch([p.to(DEV) for p in batch['points']], vl.voxel_size, vl.point_cloud_range,
+                                       vl.max_num_points, vl.max_voxels[0])
+    feats = F.voxel_mean(v, n, 4)
+    assert len(c) > 50000
+    trace = []
+    yr, _ = SR.sparse_encoder_reference(ref, feats.cpu(), c.cpu(), B, pairs=True, trace=trace)
+    enc.to(DEV)
+    got = []
+    hooks = [m.register_forward_hook(lambda mod, inp, out: got.append((out.features.detach().cpu(), out.indices.cpu(),
+                                                                       tuple(out.spatial_shape))))
+             for m in enc.modules() if isinstance(m, SparseConvolution)]
+    y = enc(feats, c, B)
+    for h in hooks:
+        h.remove()
+    assert len(got) == len(trace) == 21
+    for i, ((f1, c1, s1), (f2, c2, s2)) in enumerate(zip(got, trace)):
+        assert tuple(s1) == tuple(s2), i
+        a, ka = _sorted_rows(f1, c1, s1)
+        b, kb = _sorted_rows(f2.detach(), c2, s2)
+        assert torch.equal(ka, kb), f'conv {i}: site sets differ ({len(ka)} vs {len(kb)})'
+        err = float((a - b).norm() / b.norm())
+        assert err < 2e-4, (i, len(ka), err)
+    assert y.shape == yr.shape == (B, 256, 200, 176)
+    torch.testing.assert_close(y.detach().cpu(), yr.detach(), rtol=1e-3, atol=1e-3)
+    g = torch.randn_like(yr)
+    yr.backward(g)
+    y.backward(g.to(DEV))
+    for (n1, p1), (n2, p2) in zip(enc.named_parameters(), ref.named_parameters()):
+        err = float((p1.grad.cpu() - p2.grad).norm() / (p2.grad.norm() + 1e-12))
+        assert err < 1e-3, (n1, err)

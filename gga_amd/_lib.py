@@ -75,6 +75,8 @@ SIGNATURES = {
     'gga_sparse_conv_apply_split': (i32, [vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp, vp]),
     'gga_sparse_conv_apply': (i32, [vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp, vp]),
     'gga_sparse_conv_wgrad': (i32, [vp, vp, vp, i64, i32, i32, i32, vp, vp]),
+    'gga_sparse_conv_wgrad_workspace_bytes': (sz, [i64, i32, i32, i32]),
+    'gga_sparse_conv_wgrad_split': (i32, [vp, vp, vp, i64, i32, i32, i32, vp, vp, sz, vp]),
     'gga_dense_conv3x3_pack': (i32, [vp, i64, i64, i64, i64, i32, i32, i32, vp, vp]),
     'gga_dense_wgrad3x3_workspace_bytes': (sz, [i32, i32, i32, i32, i32]),
     'gga_dense_wgrad3x3': (i32, [vp, vp, i32, i32, i32, i32, i32, vp, i64, i64, i64, i64, i32, vp, sz, vp]),

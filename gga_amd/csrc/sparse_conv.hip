@@ -660,6 +660,19 @@ __device__ __forceinline__ void x9_split(float x, uint32_t& p1, uint32_t& p2, ui
     p1 = u1 >> 16; p2 = u2 >> 16; p3 = __float_as_uint(r2) >> 16;
 }
 
+// two values at once, packed for the LDS images: word p = {plane p of b, plane p of a} (a in the low
+// half). v_perm_b32 picks the two high halves directly, so no shift / or is spent on packing.
+__device__ __forceinline__ void x9_split2(float a, float b, uint32_t& w1, uint32_t& w2, uint32_t& w3) {
+    const uint32_t ua = __float_as_uint(a), ub = __float_as_uint(b);
+    w1 = __builtin_amdgcn_perm(ub, ua, 0x07060302u);
+    const float ra = a - __uint_as_float(ua & 0xFFFF0000u), rb = b - __uint_as_float(ub & 0xFFFF0000u);     // exact
+    const uint32_t va = __float_as_uint(ra), vb = __float_as_uint(rb);
+    w2 = __builtin_amdgcn_perm(vb, va, 0x07060302u);
+    const float sa = ra - __uint_as_float(va & 0xFFFF0000u), sb = rb - __uint_as_float(vb & 0xFFFF0000u);   // exact, <= 8 bits
+    w3 = __builtin_amdgcn_perm(__float_as_uint(sb), __float_as_uint(sa), 0x07060302u);
+}
+
+
 // packed[k][chunk][plane][col < CO][32 ch] bf16 = plane of W[k][chunk*32 + ch][col], CO = 32 * nt
 __global__ __launch_bounds__(256) void sp_pack_weight_split_kernel(const float* __restrict__ W, int kvol, int cin, int cout,
                                                                   int nt, int transpose, int64_t total,
@@ -797,9 +810,7 @@ __global__ __launch_bounds__(64 * X9_NW) void sp_conv_x9_kernel(const float* __r
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float x = ok && c + 2 * j < cin ? e[2 * j] : 0.f, y = ok && c + 2 * j + 1 < cin ? e[2 * j + 1] : 0.f;
-            uint32_t x1, x2, x3, y1, y2, y3;
-            x9_split(x, x1, x2, x3); x9_split(y, y1, y2, y3);
-            f1.u[j] = x1 | (y1 << 16); f2.u[j] = x2 | (y2 << 16); f3.u[j] = x3 | (y3 << 16);
+            x9_split2(x, y, f1.u[j], f2.u[j], f3.u[j]);
         }
     };
 
@@ -1067,6 +1078,298 @@ extern "C" int gga_sparse_conv_wgrad(const float* x, const float* grad_out, cons
     return GGA_OK;
 }
 
+// ------------------------------------------------------------------------------ weight gradient, bf16 planes
+// The same dW[k] = Xp^T Gp on the bf16 matrix cores (six of the nine partial products, as in the
+// forward kernel), deterministic: no atomics anywhere.
+//   * grid = (row chunks, kvol); a workgroup walks its chunk of output rows in sub-chunks of
+//     SPW_SUB rows: the valid (input row, output row) pairs of its offset are compacted into LDS IN
+//     ROW ORDER (ballot prefix, not an atomic counter), then consumed 32 pairs (two K-steps of 16) per
+//     stage. The GEMM's K is the pair index, and both operands are row-major [pair][channel] in
+//     memory, i.e. K-major - the MFMA wants 8 consecutive K of ONE channel per lane. As in
+//     dense_wgrad3x3_x9_kernel the LDS images stay pair-major ([channel tile][pair][32 ch] bf16 per
+//     plane, 64-byte rows, written with the same split-and-store) and ds_read_b64_tr_b16 transposes
+//     on the way out.
+//   * the NI x NJ 32x32 tiles of dW[k] are dealt to the four waves by tile rows (a wave's tiles
+//     share the X fragment). With fewer than four tile groups (<= 32 or 64 channels) two waves share
+//     a group and take one K-step of the stage each; their accumulators are added through LDS.
+//   * every workgroup writes its partial dW[k] to workspace[chunk][k]; sp_wgrad_reduce_kernel sums
+//     the chunks in a fixed order in f64.
+typedef short dw_v4s __attribute__((ext_vector_type(4)));
+#define SPW_SUB 2048
+template <int NI, int NJ, bool VEC>
+__global__ __launch_bounds__(256, 2) void sp_conv_wgrad_x9_kernel(const float* __restrict__ X, const float* __restrict__ G,
+                                                                 const int32_t* __restrict__ map, int64_t n_rows,
+                                                                 int64_t rows_per_chunk, int cin, int cout,
+                                                                 float* __restrict__ partials) {
+    constexpr int CI = NI * 32, CO = NJ * 32;
+    constexpr int TILES = NI * NJ;
+    constexpr int TPW = TILES >= 4 ? TILES / 4 : 1;          // tiles per wave
+    constexpr int NG = TILES / TPW;                          // tile groups (1, 2 or 4)
+    constexpr int KS = 4 / NG;                               // waves sharing a group, one K-step each (1 or 2; 4 groups -> 1)
+    constexpr int KSTEPS = (NI + NJ >= 6) ? 1 : 2;           // K-steps of 16 pairs per stage: wide shapes stage 16 pairs
+    constexpr int PAIRS = 16 * KSTEPS;                       //   (60 KB of LDS at 128 x 128: two workgroups per CU)
+    constexpr int LX = PAIRS * NI / 32 > 0 ? PAIRS * NI / 32 : 1, LG = PAIRS * NJ / 32 > 0 ? PAIRS * NJ / 32 : 1;
+    static_assert(NJ % TPW == 0, "tiles of a wave must share their tile row");
+    static_assert(NG == 4 || NG == 2 || NG == 1, "tile groups");
+    static_assert(KS == 1 || KSTEPS == 2, "a shared tile group needs two K-steps per stage");
+    constexpr int XPL = NI * PAIRS * 64, GPL = NJ * PAIRS * 64;   // bytes per plane of one stage image [ch tile][pair][32 ch]
+    constexpr int XSZ = 3 * XPL, GSZ = 3 * GPL;
+    __shared__ __attribute__((aligned(16))) unsigned char Xs[2 * XSZ];
+    __shared__ __attribute__((aligned(16))) unsigned char Gs[2 * GSZ];
+    __shared__ int pin[SPW_SUB];          // compacted valid pairs of the sub-chunk: input row
+    __shared__ uint16_t pout[SPW_SUB];    //                                          output row (sub-chunk local)
+    __shared__ int wtot[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int k = blockIdx.x;                                // offset fastest: the workgroups of one row chunk run together
+    const int64_t c0 = (int64_t)blockIdx.y * rows_per_chunk;  //   and share its X / G rows in the L2
+    const int64_t c1 = c0 + rows_per_chunk < n_rows ? c0 + rows_per_chunk : n_rows;
+
+    // wave -> (tile group, K-step share)
+    const int wu = __builtin_amdgcn_readfirstlane(wave);
+    const int grp_w = KS == 1 ? wu : (NG == 2 ? (wu >> 1) : 0);
+    const int ks_w = KS == 1 ? 0 : (NG == 2 ? (wu & 1) : wu);     // NG == 1: waves 0, 1 take a K-step each, 2 and 3 only stage
+    const bool wactive = KS == 1 || NG == 2 || wu < 2;
+    const int tile0 = grp_w * TPW;
+    const int i0 = tile0 / NJ, j0 = tile0 - i0 * NJ;
+
+    mf_v16 acc[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
+
+    const int fgrp = lane >> 4, li = lane & 15;
+    const int froff = ((8 * (fgrp >> 1) + (li >> 2)) * 64) + (16 * (fgrp & 1) + 4 * (li & 3)) * 2;
+    union Frag { mf_v8bf v; dw_v4s h[2]; };
+#define SW_FRAG(F, PTR) { F.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) dw_v4s*)((PTR) + froff));          \
+                          F.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) dw_v4s*)((PTR) + froff + 4 * 64)); }
+
+    float4 xa[LX], ga[LG], xb[LX], gb_[LG];              // two stages of gathered rows in flight
+    for (int64_t r0 = c0; r0 < c1; r0 += SPW_SUB) {
+        // ---- ordered compaction of the sub-chunk's valid pairs: thread t owns rows 8t .. 8t+7
+        __syncthreads();                                   // previous sub-chunk's readers of pin / pout / images are done
+        int mv[8];
+        int cnt = 0;
+        {
+            const int64_t rb = r0 + 8 * tid;
+            const int32_t* mp = map + (int64_t)k * n_rows + rb;
+            if (rb + 8 <= c1 && ((((int64_t)k * n_rows + rb) & 3) == 0)) {
+                const int4 a = *reinterpret_cast<const int4*>(mp), b = *reinterpret_cast<const int4*>(mp + 4);
+                mv[0] = a.x; mv[1] = a.y; mv[2] = a.z; mv[3] = a.w; mv[4] = b.x; mv[5] = b.y; mv[6] = b.z; mv[7] = b.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) mv[j] = rb + j < c1 ? mp[j] : -1;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) cnt += mv[j] >= 0;
+        }
+        int incl = cnt;                                    // inclusive scan over the wave
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(incl, o, 64); if (lane >= o) incl += u; }
+        if (lane == 63) wtot[wave] = incl;
+        __syncthreads();
+        int off = incl - cnt, np = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { const int c = wtot[w]; off += w < wave ? c : 0; np += c; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (mv[j] >= 0) { pin[off] = mv[j]; pout[off] = (uint16_t)(8 * tid + j); ++off; }
+        __syncthreads();
+        if (np == 0) continue;
+
+#define SW_LOAD(P0, xr, gr)                                                                                          \
+        _Pragma("unroll") for (int e = 0; e < LX; ++e) {                                                             \
+            const int t = tid + 256 * e, pp = t / (CI / 4), q = (t - pp * (CI / 4)) * 4;                             \
+            const int pi = (P0) + pp < np ? (P0) + pp : 0;                                                           \
+            const float* src = X + (int64_t)pin[pi] * cin;                                                           \
+            if (VEC) xr[e] = *reinterpret_cast<const float4*>(src + (q < cin ? q : 0));                              \
+            else xr[e] = make_float4(src[q < cin ? q : 0], src[q + 1 < cin ? q + 1 : 0], src[q + 2 < cin ? q + 2 : 0], \
+                                     src[q + 3 < cin ? q + 3 : 0]);                                                  \
+        }                                                                                                            \
+        _Pragma("unroll") for (int e = 0; e < LG; ++e) {                                                             \
+            const int t = tid + 256 * e, pp = t / (CO / 4), q = (t - pp * (CO / 4)) * 4;                             \
+            const int pi = (P0) + pp < np ? (P0) + pp : 0;                                                           \
+            const float* src = G + (r0 + pout[pi]) * cout;                                                           \
+            if (VEC) gr[e] = *reinterpret_cast<const float4*>(src + (q < cout ? q : 0));                             \
+            else gr[e] = make_float4(src[q < cout ? q : 0], src[q + 1 < cout ? q + 1 : 0], src[q + 2 < cout ? q + 2 : 0], \
+                                     src[q + 3 < cout ? q + 3 : 0]);                                                 \
+        }
+        // float4 q4 (channels 4*q4 .. +3) of pair pp -> channel tile q4 / 8, byte (q4 % 8) * 8 of the pair's 64-byte row
+#define SW_SPLIT_STORE(V, BASE, PL, PP, Q4) {                                                                        \
+        uint32_t lo1, lo2, lo3, hi1, hi2, hi3;                                                                       \
+        x9_split2(V.x, V.y, lo1, lo2, lo3); x9_split2(V.z, V.w, hi1, hi2, hi3);                                      \
+        unsigned char* dst = (BASE) + ((Q4) >> 3) * (PAIRS * 64) + (PP) * 64 + ((Q4) & 7) * 8;                       \
+        *reinterpret_cast<uint2*>(dst) = make_uint2(lo1, hi1);                                                       \
+        *reinterpret_cast<uint2*>(dst + (PL)) = make_uint2(lo2, hi2);                                                \
+        *reinterpret_cast<uint2*>(dst + 2 * (PL)) = make_uint2(lo3, hi3); }
+#define SW_STORE(BUF, P0, xr, gr)                                                                                    \
+        _Pragma("unroll") for (int e = 0; e < LX; ++e) {                                                             \
+            const int t = tid + 256 * e, pp = t / (CI / 4), q = (t - pp * (CI / 4)) * 4;                             \
+            const bool ok = (P0) + pp < np && pp < PAIRS;                                                            \
+            const float4 v = make_float4(ok && q < cin ? xr[e].x : 0.f, ok && q + 1 < cin ? xr[e].y : 0.f,           \
+                                         ok && q + 2 < cin ? xr[e].z : 0.f, ok && q + 3 < cin ? xr[e].w : 0.f);      \
+            if (pp < PAIRS) SW_SPLIT_STORE(v, Xs + (BUF) * XSZ, XPL, pp, q >> 2)                                     \
+        }                                                                                                            \
+        _Pragma("unroll") for (int e = 0; e < LG; ++e) {                                                             \
+            const int t = tid + 256 * e, pp = t / (CO / 4), q = (t - pp * (CO / 4)) * 4;                             \
+            const bool ok = (P0) + pp < np && pp < PAIRS;                                                            \
+            const float4 v = make_float4(ok && q < cout ? gr[e].x : 0.f, ok && q + 1 < cout ? gr[e].y : 0.f,         \
+                                         ok && q + 2 < cout ? gr[e].z : 0.f, ok && q + 3 < cout ? gr[e].w : 0.f);    \
+            if (pp < PAIRS) SW_SPLIT_STORE(v, Gs + (BUF) * GSZ, GPL, pp, q >> 2)                                     \
+        }
+#define SW_MM(PA, PB) _Pragma("unroll") for (int t = 0; t < TPW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PA.v, PB[t].v, acc[t], 0, 0, 0);
+#define SW_COMPUTE(BUF)                                                                                              \
+        if (wactive) {                                                                                               \
+            const unsigned char* xbase = Xs + (BUF) * XSZ + i0 * (PAIRS * 64);                                       \
+            const unsigned char* gbase = Gs + (BUF) * GSZ + j0 * (PAIRS * 64);                                       \
+            _Pragma("unroll") for (int s = 0; s < KSTEPS; ++s) {                                                     \
+                if (KS == 2 && s != ks_w) continue;     /* this K-step belongs to the other wave of the group */     \
+                Frag a0, a1, a2;                                                                                     \
+                SW_FRAG(a0, xbase + (16 * s) * 64);                                                                  \
+                SW_FRAG(a1, xbase + XPL + (16 * s) * 64);                                                            \
+                SW_FRAG(a2, xbase + 2 * XPL + (16 * s) * 64);                                                        \
+                Frag g0[TPW], g1[TPW], g2[TPW];                                                                      \
+                _Pragma("unroll") for (int t = 0; t < TPW; ++t) {                                                    \
+                    SW_FRAG(g0[t], gbase + t * (PAIRS * 64) + (16 * s) * 64);                                        \
+                    SW_FRAG(g1[t], gbase + GPL + t * (PAIRS * 64) + (16 * s) * 64);                                  \
+                    SW_FRAG(g2[t], gbase + 2 * GPL + t * (PAIRS * 64) + (16 * s) * 64);                              \
+                }                                                                                                    \
+                /* six partial products, smallest first; tiles are the inner loop so consecutive MFMAs never wait */ \
+                /* for each other's accumulator */                                                                   \
+                SW_MM(a0, g2) SW_MM(a1, g1) SW_MM(a2, g0) SW_MM(a0, g1) SW_MM(a1, g0) SW_MM(a0, g0)                  \
+            }                                                                                                        \
+        }
+        // The gathers are latency-bound (512-byte rows at random): a stage's loads are issued TWO stages
+        // ahead (register sets a / b alternate), the LDS images are double buffered, one barrier per stage.
+        SW_LOAD(0, xa, ga);
+        SW_STORE(0, 0, xa, ga);
+        if (PAIRS < np) { SW_LOAD(PAIRS, xb, gb_); }
+        __syncthreads();
+        int buf = 0, p0 = 0;
+        while (true) {
+            if (p0 + 2 * PAIRS < np) { SW_LOAD(p0 + 2 * PAIRS, xa, ga); }
+            SW_COMPUTE(buf)
+            if (p0 + PAIRS >= np) break;
+            SW_STORE(buf ^ 1, p0 + PAIRS, xb, gb_);        // buf ^ 1: last read before the previous barrier
+            __syncthreads();
+            buf ^= 1; p0 += PAIRS;
+            if (p0 + 2 * PAIRS < np) { SW_LOAD(p0 + 2 * PAIRS, xb, gb_); }
+            SW_COMPUTE(buf)
+            if (p0 + PAIRS >= np) break;
+            SW_STORE(buf ^ 1, p0 + PAIRS, xa, ga);
+            __syncthreads();
+            buf ^= 1; p0 += PAIRS;
+        }
+    }
+#undef SW_COMPUTE
+#undef SW_MM
+#undef SW_LOAD
+#undef SW_SPLIT_STORE
+#undef SW_STORE
+#undef SW_FRAG
+    // two waves per tile group: add the second K-step's accumulators through LDS (fixed order)
+    if (KS == 2) {
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(pin);                // [group][16][64] floats, 8 KB
+        if (wactive && ks_w == 1)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) red[(grp_w * 16 + v) * 64 + lane] = acc[0][v];
+        __syncthreads();
+        if (wactive && ks_w == 0)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[0][v] += red[(grp_w * 16 + v) * 64 + lane];
+    }
+    if (!wactive || ks_w != 0) return;
+    float* out = partials + ((int64_t)blockIdx.y * gridDim.x + k) * (CI * CO);
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const int co = (j0 + t) * 32 + (lane & 31);
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int ci = i0 * 32 + (v >> 2) * 8 + (lane >> 5) * 4 + (v & 3);
+            out[ci * CO + co] = acc[t][v];
+        }
+    }
+}
+
+// dW[k][ci][co] = sum over the row chunks' partials [chunk][k][CI][CO], fixed order, f64
+__global__ __launch_bounds__(256) void sp_wgrad_reduce_kernel(const float* __restrict__ partials, int nchunks, int kvol,
+                                                             int cin, int cout, int CI, int CO, float* __restrict__ dW) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;          // (k, ci, co)
+    if (i >= (int64_t)kvol * cin * cout) return;
+    const int co = (int)(i % cout), ci = (int)((i / cout) % cin), k = (int)(i / ((int64_t)cin * cout));
+    const float* p = partials + ((int64_t)k * CI + ci) * CO + co;
+    double s = 0.0;
+#pragma unroll 8
+    for (int c = 0; c < nchunks; ++c) s += (double)p[(int64_t)c * kvol * CI * CO];
+    dW[i] = (float)s;
+}
+
+// Rows per chunk. Offset is the fastest grid dimension, so the kvol workgroups of one chunk run
+// together and share its G rows and their X neighbours in the L2s: small chunks keep that working set
+// (2 x rows x C x 4 B) inside them, at the price of one partial dW per chunk in the workspace.
+static inline int spw_rows_per_chunk() { return SPW_SUB; }    // measured: 2048 / 4096 / 8192 rows -> 1.83 / 1.89 / 2.48 ms at 510 k x 128
+static inline int spw_chunks(int64_t n_rows, int kvol) {
+    (void)kvol;
+    const int64_t rpc = spw_rows_per_chunk();
+    const int64_t c = (n_rows + rpc - 1) / rpc;
+    return (int)(c < 1 ? 1 : c);
+}
+static inline int spw_pad32(int c) { return (c + 31) / 32 * 32; }
+static inline void spw_tiles(int cin, int cout, int& ni, int& nj) {
+    ni = (cin + 31) / 32; nj = (cout + 31) / 32;
+    // instantiated shapes: (1,1) (1,2) (2,2) (2,4) (4,4) and their transposes' covers
+    if (ni == 3) ni = 4;
+    if (nj == 3) nj = 4;
+    if (ni == 2 && nj == 1) nj = 2;
+    if (ni == 4 && nj < 4) nj = 4;
+    if (ni == 1 && nj == 4) ni = 2;
+}
+
+extern "C" size_t gga_sparse_conv_wgrad_workspace_bytes(int64_t n_rows, int kvol, int cin, int cout) {
+    if (n_rows < 1 || kvol < 1 || cin < 1 || cout < 1 || cin > 128 || cout > 128) return 0;
+    int ni, nj;
+    spw_tiles(cin, cout, ni, nj);
+    return (size_t)spw_chunks(n_rows, kvol) * kvol * (ni * 32) * (nj * 32) * sizeof(float);
+}
+
+extern "C" int gga_sparse_conv_wgrad_split(const float* x, const float* grad_out, const int32_t* map, int64_t n_rows,
+                                           int kvol, int cin, int cout, float* grad_weight, void* workspace,
+                                           size_t workspace_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    GGA_REQUIRE(x && grad_out && map && grad_weight && workspace, "gga_sparse_conv_wgrad_split: null pointer argument");
+    GGA_REQUIRE(n_rows >= 1 && kvol >= 1 && cin >= 1 && cin <= 128 && cout >= 1 && cout <= 128,
+                "gga_sparse_conv_wgrad_split: bad sizes (cin, cout <= 128)");
+    if (workspace_bytes < gga_sparse_conv_wgrad_workspace_bytes(n_rows, kvol, cin, cout)) {
+        gga_set_error("gga_sparse_conv_wgrad_split: workspace %zu B < required %zu B", workspace_bytes,
+                      gga_sparse_conv_wgrad_workspace_bytes(n_rows, kvol, cin, cout));
+        return GGA_ERR_WORKSPACE;
+    }
+    int ni, nj;
+    spw_tiles(cin, cout, ni, nj);
+    const int nchunks = spw_chunks(n_rows, kvol);
+    const int64_t rpc = spw_rows_per_chunk();                   // whole sub-chunks
+    const dim3 grid(kvol, (unsigned)nchunks), block(256);
+    const bool vec = (cin & 3) == 0 && (cout & 3) == 0;
+    hipEvent_t* tev = gga_timing_acquire(GGA_TIME_SPARSE_WGRAD, GGA_TIMING_CONV_KEY(cin, cout, 0));
+    GGA_TIME_START(tev, stream);
+#define SW(NI, NJ) { if (vec) hipLaunchKernelGGL((sp_conv_wgrad_x9_kernel<NI, NJ, true>), grid, block, 0, stream, x, grad_out, map, n_rows, rpc, cin, cout, (float*)workspace); \
+                     else hipLaunchKernelGGL((sp_conv_wgrad_x9_kernel<NI, NJ, false>), grid, block, 0, stream, x, grad_out, map, n_rows, rpc, cin, cout, (float*)workspace); }
+    if (ni == 1 && nj == 1) SW(1, 1)
+    else if (ni == 1 && nj == 2) SW(1, 2)
+    else if (ni == 2 && nj == 2) SW(2, 2)
+    else if (ni == 2 && nj == 4) SW(2, 4)
+    else SW(4, 4)
+#undef SW
+    GGA_CHECK_LAUNCH("sp_conv_wgrad_x9_kernel");
+    const int64_t total = (int64_t)kvol * cin * cout;
+    hipLaunchKernelGGL(sp_wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
+                       (const float*)workspace, nchunks, kvol, cin, cout, ni * 32, nj * 32, grad_weight);
+    GGA_CHECK_LAUNCH("sp_wgrad_reduce_kernel");
+    GGA_TIME_STOP(tev, stream);
+    return GGA_OK;
+}
+
 // ------------------------------------------------------------------------------ dense 3x3 convolution
 // The dense kernels below use SIX of the nine partial products: with truncated planes
 // a = a0 + a1 + a2 (|a1| <= 2^-8 |a|, |a2| <= 2^-16 |a|) the products a1*b2, a2*b1 and a2*b2 together
@@ -1148,12 +1451,12 @@ __global__ __launch_bounds__(TR * 32, 2) void dense_conv3x3_x9_kernel(const floa
         const int f = tid + THREADS * e;                                                                                  \
         if (f < HP * 4) {                                                                                          \
             const float4 v = aoff[e] >= 0 ? ra[e] : make_float4(0.f, 0.f, 0.f, 0.f);                                   \
-            uint32_t a1, a2, a3, b1, b2, b3, c1, c2, c3, d1, d2, d3;                                                  \
-            x9_split(v.x, a1, a2, a3); x9_split(v.y, b1, b2, b3); x9_split(v.z, c1, c2, c3); x9_split(v.w, d1, d2, d3); \
+            uint32_t lo1, lo2, lo3, hi1, hi2, hi3;                                                                    \
+            x9_split2(v.x, v.y, lo1, lo2, lo3); x9_split2(v.z, v.w, hi1, hi2, hi3);                                   \
             unsigned char* dst = As + (f >> 2) * DC_ROWB + (f & 3) * 8;                                               \
-            *reinterpret_cast<uint2*>(dst) = make_uint2(a1 | (b1 << 16), c1 | (d1 << 16));                            \
-            *reinterpret_cast<uint2*>(dst + APL) = make_uint2(a2 | (b2 << 16), c2 | (d2 << 16));                      \
-            *reinterpret_cast<uint2*>(dst + 2 * APL) = make_uint2(a3 | (b3 << 16), c3 | (d3 << 16));                  \
+            *reinterpret_cast<uint2*>(dst) = make_uint2(lo1, hi1);                                                    \
+            *reinterpret_cast<uint2*>(dst + APL) = make_uint2(lo2, hi2);                                              \
+            *reinterpret_cast<uint2*>(dst + 2 * APL) = make_uint2(lo3, hi3);                                          \
         }                                                                                                             \
     }
     // weight stage (tap, 16-channel chunk c): piece f = (plane, column, 16-byte half) of the 32-byte half row
@@ -1439,7 +1742,6 @@ extern "C" int gga_dense_conv3x3(const float* x, const void* split_weight, int B
 #define DW_XROW (3 * DW_XPL)
 #define DW_GPL (2 * 32 * 64)                 // bytes per plane of one gy row: [co tile][32 px][32 ch]
 #define DW_GROW (3 * DW_GPL)
-typedef short dw_v4s __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(256, 2) void dense_wgrad3x3_x9_kernel(const float* __restrict__ X, const float* __restrict__ G,
                                                                   int B, int H, int W, int cin, int cout, int strips,
@@ -1480,12 +1782,12 @@ __global__ __launch_bounds__(256, 2) void dense_wgrad3x3_x9_kernel(const float* 
 #define DW_LOAD_X(Y) { const int yy = (Y); const bool rowok = (unsigned)yy < (unsigned)H; DW_LDX(rx0, 0) DW_LDX(rx1, 1) DW_LDX(rx2, 2) }
     // piece (pixel px, float4 q) of a row image: channel tile q / 8, byte (q % 8) * 8 of the 64-byte pixel row
 #define DW_SPLIT_STORE(V, BASE, PL, NPX, F) { const int f = (F); const int px = f >> 4, q = f & 15;                   \
-        uint32_t a1, a2, a3, b1, b2, b3, c1, c2, c3, d1, d2, d3;                                                      \
-        x9_split(V.x, a1, a2, a3); x9_split(V.y, b1, b2, b3); x9_split(V.z, c1, c2, c3); x9_split(V.w, d1, d2, d3);   \
+        uint32_t lo1, lo2, lo3, hi1, hi2, hi3;                                                                        \
+        x9_split2(V.x, V.y, lo1, lo2, lo3); x9_split2(V.z, V.w, hi1, hi2, hi3);                                       \
         unsigned char* dst = (BASE) + (q >> 3) * ((NPX) * 64) + px * 64 + (q & 7) * 8;                                \
-        *reinterpret_cast<uint2*>(dst) = make_uint2(a1 | (b1 << 16), c1 | (d1 << 16));                                \
-        *reinterpret_cast<uint2*>(dst + (PL)) = make_uint2(a2 | (b2 << 16), c2 | (d2 << 16));                         \
-        *reinterpret_cast<uint2*>(dst + 2 * (PL)) = make_uint2(a3 | (b3 << 16), c3 | (d3 << 16)); }
+        *reinterpret_cast<uint2*>(dst) = make_uint2(lo1, hi1);                                                        \
+        *reinterpret_cast<uint2*>(dst + (PL)) = make_uint2(lo2, hi2);                                                 \
+        *reinterpret_cast<uint2*>(dst + 2 * (PL)) = make_uint2(lo3, hi3); }
 #define DW_STORE_G(Y) { unsigned char* base = Gs + ((Y) & 1) * DW_GROW;                                               \
         DW_SPLIT_STORE(rg0, base, DW_GPL, 32, tid) DW_SPLIT_STORE(rg1, base, DW_GPL, 32, tid + 256) }
 #define DW_STORE_X(Y) { unsigned char* base = Xs + (((Y) + 4) & 3) * DW_XROW;                                         \

@@ -54,7 +54,7 @@ class _PillarConv2d(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy):
-        from .sparse import _Rulebook, _conv_apply, _pack_weight
+        from .sparse import _Rulebook, _conv_apply, _pack_weight, conv_wgrad
         feats, w, coors, num_valid = ctx.saved_tensors
         (B, Ci, ny, nx), (sh, sw), (ph, pw) = ctx.geom
         Co, _, kh, kw = w.shape
@@ -74,8 +74,7 @@ class _PillarConv2d(torch.autograd.Function):
             _conv_apply(rows, rb, _pack_weight(wk, kvol, Co, Ci, 0), m, kvol, Co, Ci, 0, gx)
         if ctx.needs_input_grad[1]:
             g = torch.empty((kvol, Co, Ci), dtype=torch.float32, device=gy.device)
-            check(L.gga_sparse_conv_wgrad(F._p(rows), F._p(feats), F._p(nbr), m, kvol, Co, Ci, F._p(g), F._stream()),
-                  'gga_sparse_conv_wgrad')
+            conv_wgrad(rows, feats, nbr, m, kvol, Co, Ci, g)
             gw = g.view(kh, kw, Co, Ci).permute(2, 3, 0, 1)
         return gx, gw, None, None, None, None, None
 

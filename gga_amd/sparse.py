@@ -215,6 +215,20 @@ def _conv_apply(x, rb, wp, n_rows, kvol, cin, cout, flip, y):
                                       flip, F._p(y), F._stream()), 'gga_sparse_conv_apply')
 
 
+def conv_wgrad(x, gy, nbr, n_rows, kvol, cin, cout, gw):
+    """gw [kvol,cin,cout] = sum over the pairs of ``nbr`` of x[in]^T gy[out]: the deterministic
+    bf16-plane kernel (default) or the fp32-MFMA kernel with float atomics (``SPLIT_BF16 = False``)."""
+    L = _lib.lib()
+    if SPLIT_BF16:
+        ws = F._workspace('sp_wgrad', L.gga_sparse_conv_wgrad_workspace_bytes(n_rows, kvol, cin, cout), x.device)
+        check(L.gga_sparse_conv_wgrad_split(F._p(x), F._p(gy), F._p(nbr), n_rows, kvol, cin, cout, F._p(gw), F._p(ws),
+                                            ws.numel(), F._stream()), 'gga_sparse_conv_wgrad_split')
+    else:
+        check(L.gga_sparse_conv_wgrad(F._p(x), F._p(gy), F._p(nbr), n_rows, kvol, cin, cout, F._p(gw), F._stream()),
+              'gga_sparse_conv_wgrad')
+    return gw
+
+
 class _SparseConvFn(torch.autograd.Function):
     """features [n_in,Cin] x weight [kvol,Cin,Cout] -> [n_out,Cout] through rule book ``rb``
     (``rb_t`` = transposed rule book for the backward-data pass, None for submanifold convs)."""
@@ -247,8 +261,7 @@ class _SparseConvFn(torch.autograd.Function):
             _conv_apply(gy, tb, wt, n_in, kvol, cout, cin, flip, gx)
         if ctx.needs_input_grad[1]:
             gw = torch.empty_like(w)
-            check(L.gga_sparse_conv_wgrad(F._p(feats), F._p(gy), F._p(rb.nbr), n_out, kvol, cin, cout, F._p(gw),
-                                          F._stream()), 'gga_sparse_conv_wgrad')
+            conv_wgrad(feats, gy, rb.nbr, n_out, kvol, cin, cout, gw)
         return gx, gw, None, None, None
 
 

@@ -347,9 +347,19 @@ int gga_dense_conv3x3_pack(const float* weight, int64_t stride_co, int64_t strid
 int gga_dense_conv3x3(const float* x, const void* split_weight, int B, int H, int W, int cin, int cout, float* y,
                       void* stream);
 
-/* grad_weight [kvol,cin,cout] = sum_r x[nbr[k][r]]^T grad_out[r]  (zero-filled here) */
+/* grad_weight [kvol,cin,cout] = sum_r x[nbr[k][r]]^T grad_out[r]  (zero-filled here).
+ * Native fp32 MFMA with one float atomicAdd per weight and 2048-row chunk: the summation order of
+ * the chunks (not the values summed) varies from run to run. */
 int gga_sparse_conv_wgrad(const float* x, const float* grad_out, const int32_t* nbr, int64_t n_rows,
                           int kvol, int cin, int cout, float* grad_weight, void* stream);
+/* The same gradient on the bf16 planes (six partial products, as gga_sparse_conv_apply_split) and
+ * DETERMINISTIC: pairs are compacted in row order, every workgroup writes its partial sum to
+ * workspace [chunks][kvol][CI][CO] and a second kernel adds the chunks in a fixed order in f64.
+ * No atomics; about 1.7x the fp32-MFMA form at 128 channels. */
+size_t gga_sparse_conv_wgrad_workspace_bytes(int64_t n_rows, int kvol, int cin, int cout);
+int gga_sparse_conv_wgrad_split(const float* x, const float* grad_out, const int32_t* nbr, int64_t n_rows,
+                                int kvol, int cin, int cout, float* grad_weight, void* workspace,
+                                size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------- */
 /* a4/a5 (elementwise part). Fused training-mode BatchNorm (+ residual add)   */

@@ -137,9 +137,11 @@ def reference_train_step(model, batch, srl=None, backward=True):
     v, n, c = O.voxelize_batch(pts, vl.voxel_size, vl.point_cloud_range, vl.max_num_points,
                                vl.max_voxels[0] if model.training else vl.max_voxels[1])
     v, n, c = torch.from_numpy(v), torch.from_numpy(n), torch.from_numpy(c)
+    dtype = next(model.parameters()).dtype       # float64 models: the same step as a float64 yardstick
+    v = v.to(dtype)
     enc = model.pts_voxel_encoder
     if type(enc).__name__ == 'HardSimpleVFE':
-        feats = torch.from_numpy(O.voxel_mean(v.numpy(), n.numpy(), enc.num_features))
+        feats = torch.from_numpy(O.voxel_mean(v.float().numpy(), n.numpy(), enc.num_features)).to(dtype)
     else:
         feats = enc(v, n, c)                      # PillarFeatureNet: plain torch modules
     me = model.pts_middle_encoder
@@ -162,3 +164,27 @@ def reference_train_step(model, batch, srl=None, backward=True):
     if backward:
         total.backward()
     return losses, total
+
+
+def gradient_offenders(named_grads, ref32, ref64, tol=1e-3, slack=2.0):
+    """Per-parameter gradient check with a float64 yardstick. ``named_grads``: {name: grad (CPU
+    tensor)} of the path under test; ``ref32`` / ``ref64``: the same model after
+    ``reference_train_step`` in float32 / float64 on the same batch. A parameter offends when its
+    relative L2 error against the float64 gradient exceeds ``tol`` AND ``slack`` times the error
+    the float32 CPU restatement itself has against float64 - fp32 rounding through ~40 conv + BN
+    layers is amplified to ~1e-2 in the early trunk layers on small batches (measured:
+    tools_dev/grad_errors.py), for the CPU restatement and the GPU path alike, so 'within 1e-3 of
+    another fp32 implementation' is not a meaningful bound there; 'no further from the truth than
+    fp32 itself' is. -> list of (name, err_vs_f64, fp32_noise_floor)."""
+    p32, p64 = dict(ref32.named_parameters()), dict(ref64.named_parameters())
+    bad = []
+    for name, g in named_grads.items():
+        g64 = p64[name].grad
+        if g64 is None or float(g64.norm()) < 1e-9:
+            continue
+        d = float(g64.norm())
+        err = float((g.double() - g64).norm()) / d
+        floor = float((p32[name].grad.double() - g64).norm()) / d
+        if err > max(tol, slack * floor):
+            bad.append((name, err, floor))
+    return bad

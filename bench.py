@@ -126,7 +126,7 @@ def run_workload(config, batch, steps, warmup, args, rank, world, device, sites=
     torch.cuda.synchronize()
 
     for i in range(warmup):
-        runner.step(batches[i % 2])
+        runner.step(batches[i % 2], next_data=batches[(i + 1) % 2])
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -138,8 +138,8 @@ def run_workload(config, batch, steps, warmup, args, rank, world, device, sites=
     gc.collect()
     gc.disable()
     t0 = time.perf_counter()
-    for i in range(steps):
-        out = runner.step(batches[i % 2])
+    for i in range(steps):      # next_data: the point-only front of the next step is prefetched on a side stream (sparse trunk)
+        out = runner.step(batches[i % 2], next_data=batches[(i + 1) % 2])
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

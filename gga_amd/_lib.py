@@ -109,6 +109,7 @@ SIGNATURES = {
     'gga_box_iou_rotated': (i32, [vp, i32, vp, i32, i32, i32, vp, vp]),
     'gga_nms_rotated_workspace_bytes': (sz, [i32]),
     'gga_nms_rotated_sorted': (i32, [vp, i32, f32, i32, vp, vp, vp, sz, vp]),
+    'gga_circle_nms_sorted': (i32, [vp, i32, C.c_double, i32, vp, vp, vp, sz, vp]),
     'gga_region_grow_workspace_bytes': (sz, [i64, i32]),
     'gga_region_grow': (i32, [vp, i64, i32, vp, vp, vp, i32, C.c_double, i32, vp, vp, sz, vp]),
     'gga_points_in_convex_polyhedra': (i32, [vp, i64, i32, vp, vp, i32, i32, vp, vp]),

@@ -151,6 +151,36 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const unsigned long long* 
     if (lane == 0) *num_keep = nk;
 }
 
+// Circular NMS (mmdet3d/core/post_processing/box3d_nms.py:181-225): score-sorted centres; a kept
+// centre suppresses every later one within squared distance `thresh`. Same two-kernel scheme: 64x64
+// blocks of the "within thresh" relation as bit-mask rows, then the one-wavefront greedy scan.
+// The distance follows the reference's float32 arithmetic (numba on a float32 array: subtract,
+// square, add as separately rounded float32 operations; the comparison with the python-float
+// threshold happens in float64).
+__global__ __launch_bounds__(64) void circle_mask_kernel(const float* __restrict__ xy, int n, double thr,
+                                                        unsigned long long* __restrict__ mask, int colblocks) {
+#pragma clang fp contract(off)
+    const int rb = blockIdx.y, cb = blockIdx.x;
+    if (cb < rb) return;
+    __shared__ float cols[64 * 2];
+    const int t = threadIdx.x;
+    const int ncol = min(64, n - cb * 64);
+    if (t < ncol) { cols[2 * t] = xy[(int64_t)(cb * 64 + t) * 2]; cols[2 * t + 1] = xy[(int64_t)(cb * 64 + t) * 2 + 1]; }
+    __syncthreads();
+    const int i = rb * 64 + t;
+    if (i >= n) return;
+    const float x = xy[(int64_t)i * 2], y = xy[(int64_t)i * 2 + 1];
+    unsigned long long bits = 0;
+    const int j0 = (rb == cb) ? t + 1 : 0;
+    for (int j = j0; j < ncol; ++j) {
+        const float dx = x - cols[2 * j], dy = y - cols[2 * j + 1];
+        const float dxx = dx * dx, dyy = dy * dy;
+        const float d = dxx + dyy;
+        if ((double)d <= thr) bits |= 1ull << j;
+    }
+    mask[(int64_t)i * colblocks + cb] = bits;
+}
+
 extern "C" size_t gga_nms_rotated_workspace_bytes(int n) {
     const size_t cb = (size_t)(n + 63) / 64;
     return (size_t)n * cb * 8 + 256;
@@ -333,5 +363,30 @@ extern "C" int gga_image_box_match(const double* dt_boxes, const int64_t* dt_off
                        dt_boxes, dt_offsets, gt_boxes, gt_offsets, n_frames, n_dt, round_f32, match, best_iou, overlaps,
                        overlap_offsets);
     GGA_CHECK_LAUNCH("image_box_match_kernel");
+    return GGA_OK;
+}
+
+extern "C" int gga_circle_nms_sorted(const float* xy_sorted, int n, double thresh, int max_keep, int64_t* keep,
+                                     int32_t* num_keep, void* workspace, size_t workspace_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    GGA_REQUIRE(num_keep && n >= 0 && n <= 32768, "gga_circle_nms_sorted: n=%d not in [0, 32768]", n);
+    if (n == 0) {
+        GGA_CHECK_HIP(hipMemsetAsync(num_keep, 0, 4, stream), "nms memset");
+        return GGA_OK;
+    }
+    GGA_REQUIRE(xy_sorted && keep && workspace, "gga_circle_nms_sorted: null pointer argument");
+    if (workspace_bytes < gga_nms_rotated_workspace_bytes(n)) {
+        gga_set_error("gga_circle_nms_sorted: workspace %zu B < required %zu B", workspace_bytes,
+                      gga_nms_rotated_workspace_bytes(n));
+        return GGA_ERR_WORKSPACE;
+    }
+    const int cb = (n + 63) / 64;
+    unsigned long long* mask = (unsigned long long*)workspace;
+    GGA_CHECK_HIP(hipMemsetAsync(mask, 0, (size_t)n * cb * 8, stream), "nms memset");
+    hipLaunchKernelGGL(circle_mask_kernel, dim3(cb, cb), dim3(64), 0, stream, xy_sorted, n, thresh, mask, cb);
+    GGA_CHECK_LAUNCH("circle_mask_kernel");
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(64), 0, stream, mask, n, cb, max_keep > 0 ? max_keep : n, keep,
+                       num_keep);
+    GGA_CHECK_LAUNCH("nms_scan_kernel");
     return GGA_OK;
 }

@@ -145,6 +145,15 @@ class CenterHead_GGA(nn.Module):
         self.with_velocity = 'vel' in common_heads.keys()
         assert not self.with_velocity, 'GGA does not support velocity (head:600-601)'
         assert self.norm_bbox, 'the HIP loss path implements norm_bbox=True (log-dims), as every GGA config uses'
+        # The fused loss kernels implement mmdet's reduction='mean' with avg_factor (what configs/gga/* set).
+        # The constructor DEFAULT of the reference is loss_bbox reduction='none' (element-wise losses that
+        # mmdet's _parse_losses then averages over all B*K*D entries - a different scale): refuse rather
+        # than silently compute another number.
+        for name in ('loss_cls', 'loss_bbox'):
+            red = getattr(getattr(self, name), 'reduction', 'mean')
+            if red != 'mean':
+                raise NotImplementedError(f"CenterHead_GGA: {name}.reduction={red!r}; the HIP loss path implements "
+                                          f"reduction='mean' (configs/gga/gga_kitti_config.py:59-60)")
 
     # ------------------------------------------------------------------ forward
     def forward_single(self, x):
@@ -395,20 +404,6 @@ class CenterHead_GGA(nn.Module):
 
 
 def circle_nms(dets, thresh, post_max_size=83):
-    """Circular NMS (mmdet3d/core/post_processing/box3d_nms.py:181-225): a centre survives if no
-    higher-scored kept centre lies within squared distance ``thresh``. dets [N,3] = (x, y, score)."""
-    if dets.shape[0] == 0:
-        return torch.zeros(0, dtype=torch.long, device=dets.device)
-    order = torch.argsort(dets[:, 2], descending=True)
-    xy = dets[order, :2]
-    d2 = ((xy[:, None, :] - xy[None, :, :]) ** 2).sum(-1).cpu()
-    n = d2.shape[0]
-    suppressed = torch.zeros(n, dtype=torch.bool)
-    keep = []
-    for i in range(n):
-        if suppressed[i]:
-            continue
-        keep.append(i)
-        suppressed |= (d2[i] <= thresh) & (torch.arange(n) > i)
-    keep = order[torch.tensor(keep, dtype=torch.long, device=order.device)]
-    return keep[:post_max_size]
+    """Circular NMS (mmdet3d/core/post_processing/box3d_nms.py:181-225): the device op of
+    ``gga_amd.ops`` (kept here under the name the head module exports in the reference)."""
+    return ops.circle_nms(dets, thresh, post_max_size)

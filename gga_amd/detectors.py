@@ -22,6 +22,26 @@ def _sub(cfg, key):
     return cfg[key] if isinstance(cfg, dict) else getattr(cfg, key)
 
 
+class PreparedInputs:
+    """The point-only front of a step, computed ahead of it (``prepare_inputs``): voxels,
+    per-voxel counts, coordinates (carrying the sparse encoder's index plan when there is one)."""
+
+    def __init__(self, voxels, num_points, coors, n_frames):
+        self.voxels, self.num_points, self.coors, self.n_frames = voxels, num_points, coors, n_frames
+
+    def __len__(self):
+        return self.n_frames
+
+    def tensors(self):
+        yield from (self.voxels, self.num_points, self.coors)
+        for extra in (getattr(self.coors, 'num_valid', None),):
+            if extra is not None:
+                yield extra
+        plan = getattr(self.coors, 'index_plan', None)
+        if plan is not None:
+            yield from plan.tensors()
+
+
 @DETECTORS.register_module()
 class MVXTwoStageDetector_GGA(nn.Module):
     def __init__(self, pts_voxel_layer=None, pts_voxel_encoder=None, pts_middle_encoder=None,
@@ -65,7 +85,10 @@ class MVXTwoStageDetector_GGA(nn.Module):
     def extract_pts_feat(self, pts, img_feats, img_metas):
         if not self.with_pts_bbox:
             return None
-        voxels, num_points, coors = self.voxelize(pts)
+        if isinstance(pts, PreparedInputs):
+            voxels, num_points, coors = pts.voxels, pts.num_points, pts.coors
+        else:
+            voxels, num_points, coors = self.voxelize(pts)
         voxel_features = self.pts_voxel_encoder(voxels, num_points, coors)
         batch_size = len(pts)      # the reference reads coors[-1, 0] + 1 back from the device
         x = self.pts_middle_encoder(voxel_features, coors, batch_size)
@@ -89,6 +112,26 @@ class MVXTwoStageDetector_GGA(nn.Module):
                     and getattr(self.pts_middle_encoder, 'accepts_num_valid', False))
         voxels, num_points, coors, _ = self.pts_voxel_layer.forward_batch(points, sync=sync)
         return voxels, num_points, coors
+
+    @property
+    def front_reads_counts(self):
+        """True when the point-only front of a step reads voxel / site counts back to the host
+        (the sparse-conv trunk: data-dependent level sizes); the PointPillars front does not."""
+        return not (getattr(self.pts_voxel_encoder, 'accepts_num_valid', False)
+                    and getattr(self.pts_middle_encoder, 'accepts_num_valid', False))
+
+    @torch.no_grad()
+    def prepare_inputs(self, points):
+        """Voxelize ``points`` and build the sparse encoder's levels / rule books: everything of a
+        step that depends on the points alone and nothing on the weights. ``forward_train`` accepts
+        the result in place of ``points``; ``train.Runner`` calls this for the NEXT batch on a side
+        stream, where its host reads of the counts wait only for these few kernels."""
+        if isinstance(points, PreparedInputs):
+            return points
+        voxels, num_points, coors = self.voxelize(points)
+        if hasattr(self.pts_middle_encoder, 'build_indices'):
+            coors = self.pts_middle_encoder.build_indices(coors, len(points))
+        return PreparedInputs(voxels, num_points, coors, len(points))
 
     def forward_train(self, points=None, img_metas=None, gt_bboxes_3d=None, gt_labels_3d=None,
                       GGA_boxes_img=None, GGA_lidar2img=None, GGA_init_pseudo_labels=None, GGA_bdry_masks=None,

@@ -64,6 +64,27 @@ def nms_rotated(dets, scores, iou_threshold, labels=None, max_keep=0):
     return torch.cat([dets[keep], scores[keep].reshape(-1, 1)], dim=1), keep
 
 
+def circle_nms(dets, thresh, post_max_size=83):
+    """Circular NMS (mmdet3d/core/post_processing/box3d_nms.py:181-225) on the device: dets [N,3] =
+    (x, y, score); a centre survives if no higher-scored kept centre lies within squared distance
+    ``thresh``. Returns the kept indices by descending score, at most ``post_max_size``. (The
+    reference sorts with numpy's quicksort, which leaves the order of equal scores unspecified;
+    here ties keep their input order.)"""
+    F._need_cuda(dets)
+    n = dets.shape[0]
+    if n == 0:
+        return torch.zeros(0, dtype=torch.long, device=dets.device)
+    order = torch.sort(dets[:, 2].float(), descending=True, stable=True)[1]
+    xy = dets[:, :2].float().index_select(0, order).contiguous()
+    L = _lib.lib()
+    keep_pos = torch.empty(n, dtype=torch.int64, device=dets.device)
+    num = torch.zeros(1, dtype=torch.int32, device=dets.device)
+    ws = F._workspace('nms', L.gga_nms_rotated_workspace_bytes(n), dets.device)
+    check(L.gga_circle_nms_sorted(F._p(xy), n, float(thresh), int(post_max_size or 0), F._p(keep_pos), F._p(num), F._p(ws),
+                                  ws.numel(), F._stream()), 'gga_circle_nms_sorted')
+    return order[keep_pos[:int(num.item())]]
+
+
 def nms_bev(boxes, scores, thresh, pre_max_size=None, post_max_size=None):
     assert boxes.size(1) == 5, 'Input boxes shape should be [N, 5]'
     order = scores.sort(0, descending=True)[1]

@@ -98,7 +98,10 @@ class _Level:
                                           F._p(out_index), out_index.numel(), F._p(ws), ws.numel(), F._stream()),
               'gga_sparse_conv_out_sites')
         n_out = int(n_out_d.item())        # data-dependent size: one 4-byte read back, as spconv does
-        assert 0 < n_out <= cap, (n_out, cap)
+        if not 0 <= n_out <= cap:
+            raise RuntimeError(f'sparse conv output sites: count {n_out} outside [0, {cap}]')
+        if n_out == 0:                     # e.g. a (3,1,1)/(2,1,1) conv over sites that all sit in an odd, unpadded top slice
+            return _empty_level(tuple(out_dhw), self.batch_size, dev), None, None
         out = _Level(out_coors[:n_out], tuple(out_dhw), self.batch_size, index=out_index, index_n=self.n * kvol)
         nbr = torch.empty((kvol, n_out), dtype=torch.int32, device=dev)
         nbr_t = torch.empty((kvol, self.n), dtype=torch.int32, device=dev)
@@ -107,6 +110,14 @@ class _Level:
                                     self.index_n, F._p(out_index), out.index_n, F._p(nbr), F._p(nbr_t), F._stream()),
               'gga_sparse_rulebook')
         return out, _Rulebook(nbr), _Rulebook(nbr_t)
+
+
+def _empty_level(shape, batch_size, device):
+    return _Level(torch.zeros((0, 4), dtype=torch.int32, device=device), shape, batch_size)
+
+
+def conv_out_shape(shape, kernel, stride, padding):
+    return tuple((shape[i] + 2 * padding[i] - kernel[i]) // stride[i] + 1 for i in range(3))
 
 
 class SparseConvTensor:
@@ -133,10 +144,67 @@ class SparseConvTensor:
         with (z,y) folded into the row index."""
         D, H, W = self._level.shape
         c = self.indices
+        if c.shape[0] == 0:
+            out = self.features.new_zeros((self.batch_size, self.features.shape[1], D, H, W)) + 0 * self.features.sum()
+            return out if channels_first else out.permute(0, 2, 3, 4, 1).contiguous()
         folded = torch.stack([c[:, 0], torch.zeros_like(c[:, 0]), c[:, 1] * H + c[:, 2], c[:, 3]], 1).contiguous()
         out = F.pillar_scatter(self.features, folded, self.batch_size, D * H, W, unique=True)
         out = out.view(self.batch_size, self.features.shape[1], D, H, W)
         return out if channels_first else out.permute(0, 2, 3, 4, 1).contiguous()
+
+
+class IndexPlan:
+    """Index structures of one batch for a stack of sparse convolutions (levels, rule books), built
+    ahead of the features by ``build_index_plan`` - e.g. on a side stream while the previous
+    step's backward is still running, so that the host reads of the site counts do not drain the
+    main stream's launch queue."""
+
+    def __init__(self, level0, indice_dict):
+        self.level0, self.indice_dict = level0, indice_dict
+
+    def tensors(self):
+        """Every device tensor the plan holds (for ``Tensor.record_stream`` when it was built on
+        another stream than the one that consumes it)."""
+        levels, books = [self.level0], []
+        for lvl, out_lvl, rb, rb_t in self.indice_dict.values():
+            levels.append(out_lvl)
+            books += [rb, rb_t]
+        for lvl in levels:
+            books += list(lvl._subm.values())
+            for t in (lvl.coors, lvl.index):
+                if t is not None:
+                    yield t
+        for rb in books:
+            if rb is not None:
+                for t in (rb.nbr, rb.mask, rb.perm):
+                    if t is not None:
+                        yield t
+
+
+def build_index_plan(module, coors, spatial_shape, batch_size):
+    """Walk the ``SparseConvolution`` layers of ``module`` in execution order (= registration order
+    for the sequential encoders of the reference) and build every level / rule book they will ask for."""
+    coors = coors if coors.dtype == torch.int32 else coors.int()
+    lvl = level0 = _Level(coors, spatial_shape, batch_size)
+    indice_dict = {}
+    for m in module.modules():
+        if not isinstance(m, SparseConvolution):
+            continue
+        if m.subm:
+            if lvl.n:
+                lvl.subm_rulebook(m.kernel_size)
+        else:
+            cached = indice_dict.get(m.indice_key) if m.indice_key else None
+            if cached is None or cached[0] is not lvl:
+                if lvl.n == 0:
+                    cached = (lvl, _empty_level(conv_out_shape(lvl.shape, m.kernel_size, m.stride, m.padding),
+                                                lvl.batch_size, coors.device), None, None)
+                else:
+                    cached = (lvl,) + lvl.strided(m.kernel_size, m.stride, m.padding)
+                if m.indice_key:
+                    indice_dict[m.indice_key] = cached
+            lvl = cached[1]
+    return IndexPlan(level0, indice_dict)
 
 
 class SparseModule(nn.Module):
@@ -285,22 +353,53 @@ class SparseConvolution(SparseModule):
             bound = 1 / math.sqrt(fan_in)
             nn.init.uniform_(self.bias, -bound, bound)
 
+    # Checkpoint layouts (mmdet3d/ops/spconv/overwrite_spconv/write_spconv2.py:42-101): mmcv's sparse
+    # convs - and this module - keep the kernel as [kz, ky, kx, Cin, Cout]; spconv 2.x modules keep
+    # [Cout, kz, ky, kx, Cin] and stamp their state_dict entries with version 2. The reference
+    # permutes mmcv checkpoints on their way INTO spconv 2 modules; here the opposite direction is
+    # needed: a checkpoint written by a reference run on spconv 2 loads into this module.
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                              error_msgs):
+        key = prefix + 'weight'
+        w = state_dict.get(key)
+        if w is not None and w.dim() == 5:
+            mine = tuple(self.weight.shape)
+            spconv2 = (mine[4],) + mine[:4]
+            if (local_metadata.get('version', None) == 2 and tuple(w.shape) == spconv2) or \
+                    (tuple(w.shape) == spconv2 and tuple(w.shape) != mine):
+                state_dict = dict(state_dict)
+                state_dict[key] = w.permute(1, 2, 3, 4, 0).contiguous()
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                                      error_msgs)
+
+    def spconv2_weight(self):
+        """The kernel in spconv 2.x layout [Cout, kz, ky, kx, Cin] (for exporting a checkpoint to a
+        reference installation that runs on spconv 2)."""
+        return self.weight.detach().permute(4, 0, 1, 2, 3).contiguous()
+
     def forward(self, x):
         assert isinstance(x, SparseConvTensor)
         lvl = x._level
         w = self.weight.view(-1, self.in_channels, self.out_channels)
+        empty = lambda n: x.features.new_zeros((n, self.out_channels)) + 0 * w.sum()      # keeps the graph connected
         if self.subm:
-            nbr = lvl.subm_rulebook(self.kernel_size)
-            y = _SparseConvFn.apply(x.features, w, nbr, None, lvl.n)
+            if lvl.n == 0:
+                y = empty(0)
+            else:
+                y = _SparseConvFn.apply(x.features, w, lvl.subm_rulebook(self.kernel_size), None, lvl.n)
             out = x.replace_feature(y)
         else:
             cached = x.indice_dict.get(self.indice_key) if self.indice_key else None
             if cached is None or cached[0] is not lvl:
-                cached = (lvl,) + lvl.strided(self.kernel_size, self.stride, self.padding)
+                if lvl.n == 0:       # no input site (an all-empty batch): an empty level of the right shape
+                    cached = (lvl, _empty_level(conv_out_shape(lvl.shape, self.kernel_size, self.stride, self.padding),
+                                                lvl.batch_size, x.features.device), None, None)
+                else:
+                    cached = (lvl,) + lvl.strided(self.kernel_size, self.stride, self.padding)
                 if self.indice_key:
                     x.indice_dict[self.indice_key] = cached
             _, out_lvl, nbr, nbr_t = cached
-            y = _SparseConvFn.apply(x.features, w, nbr, nbr_t, out_lvl.n)
+            y = empty(0) if out_lvl.n == 0 else _SparseConvFn.apply(x.features, w, nbr, nbr_t, out_lvl.n)
             out = SparseConvTensor(y, out_lvl.coors, out_lvl.shape, x.batch_size, _level=out_lvl)
             out.indice_dict = x.indice_dict
         if self.bias is not None:

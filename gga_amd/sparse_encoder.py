@@ -3,6 +3,7 @@
 of the reference (mmdet3d/models/middle_encoders/sparse_encoder.py:43-214,
 mmdet3d/ops/sparse_block.py:82-199; ``BasicBlock`` attribute names conv1/bn1/conv2/bn2 as in
 mmdet's resnet), on the sparse layers of ``gga_amd.sparse``."""
+import torch
 from torch import nn
 
 from . import functional as F
@@ -87,8 +88,21 @@ class SparseEncoder(nn.Module):
                                                stride=(2, 1, 1), norm_cfg=norm_cfg, padding=0,
                                                indice_key='spconv_down2', conv_type='SparseConv3d')
 
+    def build_indices(self, coors, batch_size):
+        """Levels and rule books of this encoder for ``coors`` (see ``sparse.build_index_plan``); the plan
+        travels with the coordinates (``coors.index_plan``) and ``forward`` picks it up."""
+        from .sparse import build_index_plan
+        coors = coors if coors.dtype == torch.int32 else coors.int()
+        coors.index_plan = build_index_plan(self, coors, self.sparse_shape, int(batch_size))
+        return coors
+
     def forward(self, voxel_features, coors, batch_size):
-        x = SparseConvTensor(voxel_features, coors.int(), self.sparse_shape, int(batch_size))
+        plan = getattr(coors, 'index_plan', None)
+        if plan is not None and plan.level0.n == voxel_features.shape[0]:
+            x = SparseConvTensor(voxel_features, plan.level0.coors, self.sparse_shape, int(batch_size), _level=plan.level0)
+            x.indice_dict = plan.indice_dict
+        else:
+            x = SparseConvTensor(voxel_features, coors.int(), self.sparse_shape, int(batch_size))
         x = self.conv_input(x)
         encode_features = []
         for encoder_layer in self.encoder_layers:

@@ -77,7 +77,14 @@ def build_ddp(model, device, find_unused_parameters=False):
 
 class Runner:
     """Iteration loop of the train step: schedule -> train_step -> backward (DDP all-reduce
-    overlaps it) -> clip_grad_norm_ -> AdamW. Nothing in it reads a device value back."""
+    overlaps it) -> clip_grad_norm_ -> AdamW.
+
+    Host reads of device values: none on the PointPillars trunk (pillar counts stay on the device).
+    The sparse-conv trunk must know its level sizes on the host (data-dependent allocations, as
+    in spconv): with ``step(data, next_data=...)`` that point-only front (voxelize + index
+    structures) of the NEXT batch runs on a side stream right after this step's optimizer was
+    queued, so those reads wait for a handful of small kernels instead of draining the main
+    stream's queue; without ``next_data`` they happen in line."""
 
     def __init__(self, model, cfg, max_iters, distributed=False, device=None):
         self.raw_model = model
@@ -98,6 +105,27 @@ class Runner:
                                             mc.get('cyclic_times', 1), mc.get('step_ratio_up', 0.4))
         self.iter = 0
         self.log_interval = (cfg.get('log_config') or {}).get('interval', 50)
+        self._side = None           # side stream of the input prefetch
+        self._prepared = {}         # id(data dict) -> (PreparedInputs, event)
+
+    def prefetch(self, data):
+        """Run the point-only front of the step that will consume ``data`` now, on the side stream."""
+        model = self.raw_model
+        if not (hasattr(model, 'prepare_inputs') and model.front_reads_counts and torch.cuda.is_available()):
+            return
+        pts = data.get('points')
+        if pts is None or id(data) in self._prepared:
+            return
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        main = torch.cuda.current_stream(self.device)
+        with torch.cuda.stream(self._side):
+            prep = model.prepare_inputs(pts)
+            ev = torch.cuda.Event()
+            ev.record(self._side)
+        for t in prep.tensors():        # allocated on the side stream, consumed (and freed) on the main one
+            t.record_stream(main)
+        self._prepared[id(data)] = (prep, ev)
 
     def _call_train_step(self, data):
         if self.model is self.raw_model:
@@ -106,7 +134,12 @@ class Runner:
         loss, log_vars = self.raw_model._parse_losses(losses)
         return dict(loss=loss, log_vars=log_vars, num_samples=len(data['img_metas']))
 
-    def step(self, data):
+    def step(self, data, next_data=None):
+        hit = self._prepared.pop(id(data), None)
+        if hit is not None:
+            prep, ev = hit
+            torch.cuda.current_stream(self.device).wait_event(ev)
+            data = dict(data, points=prep)
         for g in self.optimizer.param_groups:
             if self.lr_sched is not None:
                 g['lr'] = self.lr_sched(self.iter)
@@ -120,6 +153,8 @@ class Runner:
                                            **self.grad_clip)
         self.optimizer.step()
         self.iter += 1
+        if next_data is not None:
+            self.prefetch(next_data)
         return out
 
     def run(self, batches, n_iters, logger=None):
@@ -127,7 +162,7 @@ class Runner:
         t0 = time.time()
         out = None
         for i in range(n_iters):
-            out = self.step(batches[i % len(batches)])
+            out = self.step(batches[i % len(batches)], next_data=batches[(i + 1) % len(batches)])
             if logger and (i + 1) % self.log_interval == 0:
                 vals = {k: float(v) for k, v in out['log_vars'].items()}      # the only sync, every N iters
                 logger(f'iter {i + 1}/{n_iters} lr {self.optimizer.param_groups[0]["lr"]:.3e} '

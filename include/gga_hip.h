@@ -551,6 +551,13 @@ size_t gga_nms_rotated_workspace_bytes(int n);
 int gga_nms_rotated_sorted(const float* boxes_sorted, int n, float iou_threshold, int max_keep,
                            int64_t* keep, int32_t* num_keep, void* workspace,
                            size_t workspace_bytes, void* stream);
+/* Circular NMS of CenterPoint (mmdet3d/core/post_processing/box3d_nms.py:181-225, test_cfg
+ * nms_type='circle'): xy_sorted [n,2] f32 centres by descending score; a kept centre suppresses the
+ * later ones with (dx*dx + dy*dy) <= thresh, the distance in the reference's float32 arithmetic.
+ * keep / num_keep / workspace as for gga_nms_rotated_sorted (same workspace size). */
+int gga_circle_nms_sorted(const float* xy_sorted, int n, double thresh, int max_keep, int64_t* keep,
+                          int32_t* num_keep, void* workspace, size_t workspace_bytes, void* stream);
+
 
 /* Points in rotated 3D boxes. Replaces mmcv.ops.points_in_boxes_part / points_in_boxes_all as
  * called by base_box3d.py:534,566. points [B,M,3]; boxes [B,T,7] = (x, y, z_bottom, dx, dy, dz,

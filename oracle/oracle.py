@@ -461,3 +461,28 @@ def head_loss(preds, tg, train_cfg, alpha=0.0, gamma=4.0, l1_weight=0.25):
         mids.append(dict(pred=pred, rot=rot, pred_ratio=ratio, pred_iou=iou, pred_box_bev=bev,
                          p2c_min=p2c[0], p2c_x=p2c[1], p2c_y=p2c[2]))
     return losses, mids
+
+
+def circle_nms(dets, thresh, post_max_size=83):
+    """mmdet3d/core/post_processing/box3d_nms.py:181-225, loop for loop (numba there): dets [N,3]
+    float32 (x, y, score); the distance is evaluated in the array's dtype, ``order`` is
+    ``scores.argsort()[::-1]`` (stable here)."""
+    dets = np.asarray(dets)
+    x1, y1, scores = dets[:, 0], dets[:, 1], dets[:, 2]
+    order = np.argsort(-scores, kind='stable').astype(np.int32)
+    ndets = dets.shape[0]
+    suppressed = np.zeros(ndets, dtype=np.int32)
+    keep = []
+    for _i in range(ndets):
+        i = order[_i]
+        if suppressed[i] == 1:
+            continue
+        keep.append(int(i))
+        for _j in range(_i + 1, ndets):
+            j = order[_j]
+            if suppressed[j] == 1:
+                continue
+            dist = (x1[i] - x1[j]) ** 2 + (y1[i] - y1[j]) ** 2
+            if dist <= thresh:
+                suppressed[j] = 1
+    return keep[:post_max_size] if post_max_size is not None else keep

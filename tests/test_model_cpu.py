@@ -155,3 +155,33 @@ def test_synthetic_frame_contract():
     x, y, z = f['points'][:, 0], f['points'][:, 1], f['points'][:, 2]
     outside = (x < 0) | (x >= 70.4) | (y < -40) | (y >= 40) | (z < -3) | (z >= 1)
     assert 0.03 < outside.float().mean() < 0.07                      # the rejection branch is exercised
+
+
+def test_sparse_conv_loads_spconv2_checkpoint_layout():
+    """write_spconv2.py:42-101: spconv 2.x keeps kernels as [Cout, kz, ky, kx, Cin] (state_dict version 2),
+    mmcv as [kz, ky, kx, Cin, Cout]; both load into the sparse conv layers here."""
+    from collections import OrderedDict
+    from gga_amd.sparse import SparseConv3d, SubMConv3d
+    torch.manual_seed(0)
+    src = SubMConv3d(16, 32, 3, bias=False)
+    # mmcv layout: plain load
+    dst = SubMConv3d(16, 32, 3, bias=False)
+    dst.load_state_dict(src.state_dict())
+    assert torch.equal(dst.weight, src.weight)
+    # spconv 2 layout with its version stamp
+    sd = OrderedDict(weight=src.spconv2_weight())
+    assert tuple(sd['weight'].shape) == (32, 3, 3, 3, 16)
+    sd._metadata = OrderedDict({'': dict(version=2)})
+    dst2 = SubMConv3d(16, 32, 3, bias=False)
+    dst2.load_state_dict(sd)
+    assert torch.equal(dst2.weight, src.weight)
+    # ... and without the stamp (recognised by shape), anisotropic kernel, inside a parent module
+    conv = SparseConv3d(8, 8, (3, 1, 1), stride=(2, 1, 1), bias=False)
+    parent = torch.nn.Sequential(OrderedDict(down=conv))
+    sd = {'down.weight': conv.spconv2_weight()}
+    twin = torch.nn.Sequential(OrderedDict(down=SparseConv3d(8, 8, (3, 1, 1), stride=(2, 1, 1), bias=False)))
+    twin.load_state_dict(sd)
+    assert torch.equal(twin.down.weight, conv.weight)
+    # a genuinely wrong shape still fails loudly
+    with pytest.raises(RuntimeError, match='size mismatch'):
+        SubMConv3d(16, 32, 3, bias=False).load_state_dict({'weight': torch.zeros(3, 3, 3, 16, 8)})

@@ -235,3 +235,14 @@ def test_sparse_pair_list_restatement_equals_dense_restatement(cfg):
     torch.testing.assert_close(y1, y2, rtol=1e-5, atol=1e-5)
     for a, b in zip(w_grad_dense, w_grad_pairs):
         torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-4)
+
+
+def test_circle_nms_reference_known_answer():
+    # /root/reference/tests/test_utils/test_nms.py:63-79
+    boxes = np.array([[-11.1100, 2.1300, 0.8823], [-11.2810, 2.2422, 0.8914], [-10.3966, -0.3198, 0.8643],
+                      [-10.2906, -13.3159, 0.8401], [5.6518, 9.9791, 0.8271], [-11.2652, 13.3637, 0.8267],
+                      [4.7768, -13.0409, 0.7810], [5.6621, 9.0422, 0.7753], [-10.5561, 18.9627, 0.7518],
+                      [-10.5643, 13.2293, 0.7200]], np.float32)
+    keep = O.circle_nms(boxes, 0.175)
+    assert sorted(keep) == [1, 2, 3, 4, 5, 6, 7, 8, 9]
+    assert keep[0] == 1          # highest score first

@@ -99,3 +99,27 @@ def test_simple_test_inference_path():
                     iou = ops.box_iou_rotated(bx[:, [0, 1, 3, 4, 6]], bx[:, [0, 1, 3, 4, 6]]).cpu()
                     iou.fill_diagonal_(0)
                     assert float(iou.max()) <= tc.nms_thr + 1e-4
+
+
+def test_circle_nms_known_answer_and_vs_oracle():
+    """Reference known answer (tests/test_utils/test_nms.py:63-79) and the oracle's loop-for-loop
+    restatement on 3000 random centres (clusters, exact-threshold pairs, duplicate centres)."""
+    from gga_amd import ops
+    from oracle import oracle as O
+    boxes = torch.tensor([[-11.1100, 2.1300, 0.8823], [-11.2810, 2.2422, 0.8914], [-10.3966, -0.3198, 0.8643],
+                          [-10.2906, -13.3159, 0.8401], [5.6518, 9.9791, 0.8271], [-11.2652, 13.3637, 0.8267],
+                          [4.7768, -13.0409, 0.7810], [5.6621, 9.0422, 0.7753], [-10.5561, 18.9627, 0.7518],
+                          [-10.5643, 13.2293, 0.7200]])
+    keep = ops.circle_nms(boxes.to(DEV), 0.175, post_max_size=None)
+    assert sorted(keep.tolist()) == [1, 2, 3, 4, 5, 6, 7, 8, 9] and int(keep[0]) == 1
+    g = torch.Generator().manual_seed(0)
+    ctr = torch.rand(40, 2, generator=g) * 60
+    xy = ctr[torch.randint(0, 40, (3000,), generator=g)] + torch.randn(3000, 2, generator=g) * 1.5
+    xy[100] = xy[7]                                   # duplicate centre
+    xy[200] = xy[9] + torch.tensor([0.5, 0.0])        # distance^2 = 0.25
+    dets = torch.cat([xy, torch.rand(3000, 1, generator=g)], 1)
+    for thr, pm in ((0.25, 83), (4.0, 500), (0.01, None)):
+        want = O.circle_nms(dets.numpy(), thr, pm)
+        got = ops.circle_nms(dets.to(DEV), thr, pm).tolist()
+        assert got == want, (thr, pm)
+    assert ops.circle_nms(torch.zeros(0, 3, device=DEV), 1.0).numel() == 0

@@ -25,3 +25,4 @@ from . import losses, bbox_coders, voxel_encoders, middle_encoders, sparse, spar
 from .config import Config  # noqa: E402,F401
 from .registry import build_detector, build_model  # noqa: E402,F401
 from .pseudo_labels import pseudo_label_matching_kitti  # noqa: E402,F401
+from . import datasets  # noqa: E402,F401  (registers KittiDataset_GGA_train / LoadAnnotations3D)

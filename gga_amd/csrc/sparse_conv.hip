@@ -1459,15 +1459,24 @@ __global__ __launch_bounds__(TR * 32, 2) void dense_conv3x3_x9_kernel(const floa
             *reinterpret_cast<uint2*>(dst + 2 * APL) = make_uint2(lo3, hi3);                                          \
         }                                                                                                             \
     }
-    // weight stage (tap, 16-channel chunk c): piece f = (plane, column, 16-byte half) of the 32-byte half row
-    uint4 bq0, bq1, bq2;                            // named registers: an indexed array ends up in scratch
-    bq0 = bq1 = bq2 = make_uint4(0, 0, 0, 0);
-#define DC_BLD(E, V) if ((E) < NB) { const int f = min(tid + THREADS * (E), BPIECES - 1); V = bsrc[(f >> 1) * 4 + (f & 1)]; }
-#define DC_LOAD_B(TAP, CH) {                                                                                          \
-        const uint4* bsrc = reinterpret_cast<const uint4*>(Wp + ((int64_t)(TAP) * nchunks32 + ((CH) >> 1)) * (3 * CO * 32) + ((CH) & 1) * 16); \
-        DC_BLD(0, bq0) DC_BLD(1, bq1) DC_BLD(2, bq2) }
+    // weight stage (tap, 16-channel chunk c): piece f = (plane, column, 16-byte half) of the 32-byte half row.
+    // Two register sets (named registers: an indexed array ends up in scratch): the weights of stage s + 3 are
+    // requested at the start of stage s and written to LDS at the end of stage s + 1, so a load has two stages
+    // (~1.5 us with two waves per SIMD) to come back from the L2 - with one stage the per-stage s_waitcnt was the
+    // largest single loss of the kernel (ablation: 375 -> 303 us at 64 -> 64 without the loads).
+    // (the 512-thread form is limited to 256 registers by its two waves per SIMD and keeps one set.)
+    constexpr bool DEEP = !(NT == 4 && TR == 16);
+    uint4 bq0, bq1, bq2, cq0, cq1, cq2;
+    bq0 = bq1 = bq2 = cq0 = cq1 = cq2 = make_uint4(0, 0, 0, 0);
+    // the packed stage (tap, 16-channel chunk) is contiguous and in LDS piece order (dense_pack_weight_kernel): a wave
+    // load covers 1 KB of whole cache lines (the half-row layout of the sparse kernels touched 32 half-used lines per
+    // load and kept the address unit busy for most of a stage)
+#define DC_BLD(E, V) if ((E) < NB) { const int f = min(tid + THREADS * (E), BPIECES - 1); V = bsrc[f]; }
+#define DC_LOAD_B(TAP, CH, V0, V1, V2) {                                                                              \
+        const uint4* bsrc = reinterpret_cast<const uint4*>(Wp + ((int64_t)(TAP) * nchunks + (CH)) * (3 * CO * DC_CK)); \
+        DC_BLD(0, V0) DC_BLD(1, V1) DC_BLD(2, V2) }
 #define DC_BST(BUF, E, V) if ((E) < NB) { const int f = tid + THREADS * (E); if (f < BPIECES) *reinterpret_cast<uint4*>(Bs + (BUF) * BSZ + (f >> 1) * DC_ROWB + (f & 1) * 16) = V; }
-#define DC_STORE_B(BUF) { DC_BST(BUF, 0, bq0) DC_BST(BUF, 1, bq1) DC_BST(BUF, 2, bq2) }
+#define DC_STORE_B(BUF, V0, V1, V2) { DC_BST(BUF, 0, V0) DC_BST(BUF, 1, V1) DC_BST(BUF, 2, V2) }
     static_assert(NB <= 3, "weight stage pieces per thread");
 
     // Stage (chunk, tap): fragments from LDS, 36 MFMAs, and meanwhile the weights of the stage
@@ -1510,11 +1519,12 @@ __global__ __launch_bounds__(TR * 32, 2) void dense_conv3x3_x9_kernel(const floa
         DC_AOFF(tb, ty0, tx0)
     }
     DC_LOAD_A(0);
-    DC_LOAD_B(0, 0);
+    DC_LOAD_B(0, 0, bq0, bq1, bq2);
+    DC_LOAD_B(1, 0, cq0, cq1, cq2);
     DC_STORE_A();
-    DC_STORE_B(0);
-    DC_LOAD_B(1, 0);
-    DC_STORE_B(1);
+    DC_STORE_B(0, bq0, bq1, bq2);
+    DC_STORE_B(1, cq0, cq1, cq2);
+    if (DEEP) { DC_LOAD_B(2, 0, bq0, bq1, bq2); }     // stage 2: written to LDS at the end of stage 0
     __syncthreads();
     bool first = true;
     for (; tile < n_tiles; tile += gridDim.x) {
@@ -1526,35 +1536,53 @@ __global__ __launch_bounds__(TR * 32, 2) void dense_conv3x3_x9_kernel(const floa
             for (int t = 0; t < NT; ++t)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[m][t][i] = 0.0f;
-        for (int ch = 0; ch < nchunks; ++ch) {
-            if (!first) {                              // every wave passed the barrier of the previous stage
-                DC_STORE_A();
-                __syncthreads();
+        // stage s = chunk * 9 + tap loads the weights of stage s + 3 into register set (s + 1) % 2 and writes those of
+        // stage s + 2 from set s % 2 into LDS buffer (s + 2) % 3; chunks come in pairs so that the set of every
+        // stage is fixed at compile time (nchunks is even: cin % 32 == 0)
+#define DC_CHUNK_HEAD(CH)                                                                                             \
+            if (!first) {                              /* every wave passed the barrier of the previous stage */      \
+                DC_STORE_A();                                                                                         \
+                __syncthreads();                                                                                      \
+            }                                                                                                         \
+            first = false;                                                                                            \
+            if ((CH) + 1 < nchunks) { DC_LOAD_A((CH) + 1); }                                                          \
+            else if (more_tiles) {                     /* first chunk of the next tile */                             \
+                DC_TILE(tile + (int)gridDim.x, nb_, ny0, nx0)                                                         \
+                DC_AOFF(nb_, ny0, nx0)                                                                                \
+                DC_LOAD_A(0);                                                                                         \
             }
-            first = false;
-            if (ch + 1 < nchunks) { DC_LOAD_A(ch + 1); }
-            else if (more_tiles) {                     // first chunk of the next tile
-                DC_TILE(tile + (int)gridDim.x, nb_, ny0, nx0)
-                DC_AOFF(nb_, ny0, nx0)
-                DC_LOAD_A(0);
-            }
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const bool more = tap + 2 < 9 || ch + 1 < nchunks || more_tiles;      // a stage two ahead exists
-                if (more) {
-                    if (tap + 2 < 9) { DC_LOAD_B(tap + 2, ch); }
-                    else { DC_LOAD_B(tap + 2 - 9, ch + 1 < nchunks ? ch + 1 : 0); }
-                }
-                DC_READ_A(tap);
-#pragma unroll
-                for (int t0 = 0; t0 < NT; t0 += 2) {
-                    DC_READ_B(tap, t0);
-                    DC_MMA(t0)
-                }
-                if (more) { DC_STORE_B((tap + 2) % 3); }
-                __syncthreads();
-            }
+#define DC_STAGE(TAP, CH, L0, L1, L2, S0, S1, S2) {                                                                   \
+            const bool last_chunk = (CH) + 1 >= nchunks;                                                              \
+            const bool more3 = (TAP) + 3 < 9 || !last_chunk || more_tiles;     /* a stage three ahead exists */       \
+            const bool more2 = (TAP) + 2 < 9 || !last_chunk || more_tiles;                                            \
+            if (DEEP) {                                                                                               \
+                if (more3) {                                                                                          \
+                    if ((TAP) + 3 < 9) { DC_LOAD_B((TAP) + 3, (CH), L0, L1, L2); }                                    \
+                    else { DC_LOAD_B((TAP) + 3 - 9, last_chunk ? 0 : (CH) + 1, L0, L1, L2); }                         \
+                }                                                                                                     \
+            } else if (more2) {       /* one register set: stage s + 2 requested now, written at the end of this stage */ \
+                if ((TAP) + 2 < 9) { DC_LOAD_B((TAP) + 2, (CH), bq0, bq1, bq2); }                                     \
+                else { DC_LOAD_B((TAP) + 2 - 9, last_chunk ? 0 : (CH) + 1, bq0, bq1, bq2); }                          \
+            }                                                                                                         \
+            DC_READ_A(TAP);                                                                                           \
+            _Pragma("unroll") for (int t0 = 0; t0 < NT; t0 += 2) {                                                    \
+                DC_READ_B(TAP, t0);                                                                                   \
+                DC_MMA(t0)                                                                                            \
+            }                                                                                                         \
+            if (more2) { if (DEEP) { DC_STORE_B(((TAP) + 2) % 3, S0, S1, S2); } else { DC_STORE_B(((TAP) + 2) % 3, bq0, bq1, bq2); } } \
+            __syncthreads(); }
+#define DC_EVEN(TAP, CH) DC_STAGE(TAP, CH, cq0, cq1, cq2, bq0, bq1, bq2)      /* even stage: load set 1, store set 0 */
+#define DC_ODD(TAP, CH) DC_STAGE(TAP, CH, bq0, bq1, bq2, cq0, cq1, cq2)
+        for (int ch = 0; ch < nchunks; ch += 2) {
+            DC_CHUNK_HEAD(ch)
+            DC_EVEN(0, ch) DC_ODD(1, ch) DC_EVEN(2, ch) DC_ODD(3, ch) DC_EVEN(4, ch) DC_ODD(5, ch) DC_EVEN(6, ch) DC_ODD(7, ch) DC_EVEN(8, ch)
+            DC_CHUNK_HEAD(ch + 1)
+            DC_ODD(0, ch + 1) DC_EVEN(1, ch + 1) DC_ODD(2, ch + 1) DC_EVEN(3, ch + 1) DC_ODD(4, ch + 1) DC_EVEN(5, ch + 1) DC_ODD(6, ch + 1) DC_EVEN(7, ch + 1) DC_ODD(8, ch + 1)
         }
+#undef DC_CHUNK_HEAD
+#undef DC_STAGE
+#undef DC_EVEN
+#undef DC_ODD
         // D layout of 32x32x16: register v of lane l holds row (v/4)*8 + (l/32)*4 + v%4 (= pixel of the M tile's row), column l%32
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
@@ -1637,7 +1665,7 @@ __global__ __launch_bounds__(256) void dense_pack_weight_kernel(const float* __r
     const int co = 32 * nt, nchunks = (n_in + MF_TK - 1) / MF_TK;
     const int ch = (int)(i & 31);
     const int col = (int)((i >> 5) % co);
-    const int64_t stage = (i >> 5) / co;
+    const int64_t stage = (i >> 5) / co;                                        // (tap, 32-channel chunk)
     const int tap = (int)(stage / nchunks), chunk = (int)(stage - (int64_t)tap * nchunks);
     const int c = chunk * MF_TK + ch;
     float v = 0.0f;
@@ -1649,8 +1677,11 @@ __global__ __launch_bounds__(256) void dense_pack_weight_kernel(const float* __r
     }
     uint32_t p1, p2, p3;
     x9_split(v, p1, p2, p3);
-    uint16_t* dst = P + stage * (3 * (int64_t)co * 32) + (int64_t)col * 32 + ch;
-    dst[0] = (uint16_t)p1; dst[(int64_t)co * 32] = (uint16_t)p2; dst[2 * (int64_t)co * 32] = (uint16_t)p3;
+    // dense layout: [tap][16-channel chunk][plane][column][16 channels] - one contiguous block per kernel stage,
+    // in the order the kernel's threads copy it to LDS
+    const int64_t stage16 = (int64_t)tap * (2 * nchunks) + (c >> 4);
+    uint16_t* dst = P + stage16 * (3 * (int64_t)co * 16) + (int64_t)col * 16 + (c & 15);
+    dst[0] = (uint16_t)p1; dst[(int64_t)co * 16] = (uint16_t)p2; dst[2 * (int64_t)co * 16] = (uint16_t)p3;
 }
 
 extern "C" int gga_dense_conv3x3_pack(const float* weight, int64_t stride_co, int64_t stride_ci, int64_t stride_ky,

@@ -1,0 +1,241 @@
+"""``KittiDataset_GGA_train`` and the annotation loader of the GGA train pipeline - SURVEY.md §8(f)
+rank 2, the data format on the input side of the hot path.
+
+Mirrors (same names, arguments, dict keys and dtypes)
+
+* ``KittiDataset_GGA_train.get_data_info / get_ann_info / remove_dontcare_GGA / drop_arrays_by_name``
+  (mmdet3d/datasets/kitti_dataset_GGA_train.py:100-329) and the ``Custom3DDataset`` plumbing they
+  rely on (``load_annotations``, ``pre_pipeline``, ``prepare_train_data``, ``__getitem__``:
+  mmdet3d/datasets/custom_3d.py) for local ``.pkl`` info files;
+* ``LoadAnnotations3D`` with ``with_gga=True`` (mmdet3d/datasets/pipelines/loading.py:560-691):
+  ``_load_bboxes_3d``, ``_load_labels_3d``, ``_load_GGA_labels``;
+* the camera -> LiDAR box conversion the loader goes through
+  (``CameraInstance3DBoxes.convert_to`` = ``Box3DMode.convert``, core/bbox/structures/box_3d_mode.py:63-199).
+
+Pinned by tests/test_datasets.py against a run of the reference's own classes on three frames
+(tests/golden/gt_database.npz, tools_dev/make_golden.py::golden_gt_database).
+"""
+import copy
+import os
+import pickle
+
+import numpy as np
+import torch
+
+from .box3d import LiDARInstance3DBoxes
+from .pipelines import Compose
+from .registry import DATASETS, PIPELINES
+
+
+def limit_period(val, offset=0.5, period=np.pi):
+    """core/bbox/structures/utils.py:11-25."""
+    return val - torch.floor(val / period + offset) * period
+
+
+def camera_boxes_to_lidar(boxes, rt_mat):
+    """``Box3DMode.convert(box, CAM, LIDAR, rt_mat)`` for an [N,7] float32 array
+    (x, y, z, x_size, y_size, z_size, yaw) in camera coordinates (box_3d_mode.py:113-168): centres
+    through ``rt_mat``, sizes (l, h, w) -> (l, w, h), yaw -> limit_period(-yaw - pi/2, 2 pi). torch
+    arithmetic like the reference (float32 boxes, the matrix cast to their dtype)."""
+    arr = torch.from_numpy(np.asarray(boxes)).clone()
+    x_size, y_size, z_size, yaw = arr[..., 3:4], arr[..., 4:5], arr[..., 5:6], arr[..., 6:7]
+    xyz_size = torch.cat([x_size, z_size, y_size], dim=-1)
+    yaw = -yaw - np.pi / 2
+    yaw = limit_period(yaw, period=np.pi * 2)
+    rt = arr.new_tensor(np.asarray(rt_mat))
+    if rt.size(1) == 4:
+        ext = torch.cat([arr[..., :3], arr.new_ones(arr.size(0), 1)], dim=-1)
+        xyz = ext @ rt.t()
+    else:
+        xyz = arr[..., :3] @ rt.t()
+    return torch.cat([xyz[..., :3], xyz_size, yaw, arr[..., 7:]], dim=-1)
+
+
+@DATASETS.register_module()
+class KittiDataset_GGA_train:
+    CLASSES = ('car', 'pedestrian', 'cyclist')
+
+    def __init__(self, data_root, ann_file, split, pts_prefix='velodyne', pipeline=None, classes=None, modality=None,
+                 box_type_3d='LiDAR', filter_empty_gt=True, test_mode=False,
+                 pcd_limit_range=[0, -40, -3, 70.4, 40, 0.0], **kwargs):
+        self.data_root, self.ann_file = data_root, ann_file
+        self.test_mode, self.modality, self.filter_empty_gt = test_mode, modality, filter_empty_gt
+        if box_type_3d.lower() != 'lidar':
+            raise NotImplementedError('the GGA LiDAR pipeline uses box_type_3d="LiDAR"')
+        self.box_type_3d, self.box_mode_3d = LiDARInstance3DBoxes, 0       # Box3DMode.LIDAR
+        self.CLASSES = tuple(classes) if classes is not None else self.CLASSES
+        self.cat2id = {name: i for i, name in enumerate(self.CLASSES)}
+        self.data_infos = self.load_annotations(self.ann_file)
+        self.pipeline = Compose(pipeline) if pipeline is not None else None
+        self.split = split
+        self.root_split = os.path.join(self.data_root, split)
+        assert self.modality is not None
+        self.pcd_limit_range = pcd_limit_range
+        self.pts_prefix = pts_prefix
+
+    def load_annotations(self, ann_file):
+        if isinstance(ann_file, (list, tuple)):         # already loaded infos
+            return list(ann_file)
+        with open(ann_file, 'rb') as f:
+            return pickle.load(f)
+
+    def __len__(self):
+        return len(self.data_infos)
+
+    def _get_pts_filename(self, idx):
+        return os.path.join(self.root_split, self.pts_prefix, f'{idx:06d}.bin')
+
+    def get_data_info(self, index):
+        info = self.data_infos[index]
+        sample_idx = info['image']['image_idx']
+        img_filename = os.path.join(self.data_root, info['image']['image_path'])
+        rect = info['calib']['R0_rect'].astype(np.float32)
+        Trv2c = info['calib']['Tr_velo_to_cam'].astype(np.float32)
+        P2 = info['calib']['P2'].astype(np.float32)
+        lidar2img = P2 @ rect @ Trv2c
+        input_dict = dict(sample_idx=sample_idx, pts_filename=self._get_pts_filename(sample_idx), img_prefix=None,
+                          img_info=dict(filename=img_filename), lidar2img=lidar2img, rect=rect, Trv2c=Trv2c, P2=P2)
+        if not self.test_mode:
+            input_dict['ann_info'] = self.get_ann_info(index)
+        return input_dict
+
+    def get_ann_info(self, index):
+        info = self.data_infos[index]
+        rect = info['calib']['R0_rect'].astype(np.float32)
+        Trv2c = info['calib']['Tr_velo_to_cam'].astype(np.float32)
+        if 'plane' in info:
+            reverse = np.linalg.inv(rect @ Trv2c)
+            plane_norm_cam, plane_off_cam = info['plane'][:3], -info['plane'][:3] * info['plane'][3]
+            plane_norm_lidar = (reverse[:3, :3] @ plane_norm_cam[:, None])[:, 0]
+            plane_off_lidar = reverse[:3, :3] @ plane_off_cam[:, None][:, 0] + reverse[:3, 3]
+            plane_lidar = np.zeros_like(plane_norm_lidar, shape=(4, ))
+            plane_lidar[:3] = plane_norm_lidar
+            plane_lidar[3] = -plane_norm_lidar.T @ plane_off_lidar
+        else:
+            plane_lidar = None
+        annos = self.remove_dontcare_GGA(info['annos'])      # other objects stay: collision tests when sampling
+        difficulty = annos['difficulty']
+        gt_names = annos['name']
+        gt_bboxes_3d = np.concatenate([annos['location'], annos['dimensions'], annos['rotation_y'][..., np.newaxis]],
+                                      axis=1).astype(np.float32)
+        gt_bboxes_3d = LiDARInstance3DBoxes(camera_boxes_to_lidar(gt_bboxes_3d, np.linalg.inv(rect @ Trv2c)))
+        gt_bboxes = annos['bbox']
+        selected = self.drop_arrays_by_name(gt_names, ['DontCare'])
+        gt_bboxes = gt_bboxes[selected].astype('float32')
+        gt_names = gt_names[selected]
+        gga = {k: annos[k][selected] for k in ('GGA_boxes_img', 'GGA_mask_depth', 'GGA_mask2d', 'GGA_mask_valid',
+                                                'GGA_mask_boundary', 'GGA_bdry_masks', 'GGA_init_pseudo_label',
+                                                'GGA_num_points_in_box2d')}
+        in_box = [annos['GGA_in_box_points'][i] for i in selected.tolist()]
+        gt_labels = np.array([self.CLASSES.index(cat) if cat in self.CLASSES else -1 for cat in gt_names]).astype(np.int64)
+        return dict(gt_bboxes_3d=gt_bboxes_3d, gt_labels_3d=copy.deepcopy(gt_labels), bboxes=gt_bboxes, labels=gt_labels,
+                    gt_names=gt_names, plane=plane_lidar, difficulty=difficulty, GGA_boxes_img=gga['GGA_boxes_img'],
+                    GGA_mask_depth=gga['GGA_mask_depth'], GGA_mask2d=gga['GGA_mask2d'], GGA_mask_valid=gga['GGA_mask_valid'],
+                    GGA_mask_boundary=gga['GGA_mask_boundary'], GGA_bdry_masks=gga['GGA_bdry_masks'],
+                    GGA_in_box_points=in_box, GGA_init_pseudo_label=gga['GGA_init_pseudo_label'],
+                    GGA_num_points_in_box2d=gga['GGA_num_points_in_box2d'])
+
+    def drop_arrays_by_name(self, gt_names, used_classes):
+        return np.array([i for i, x in enumerate(gt_names) if x not in used_classes], dtype=np.int64)
+
+    def keep_arrays_by_name(self, gt_names, used_classes):
+        return np.array([i for i, x in enumerate(gt_names) if x in used_classes], dtype=np.int64)
+
+    def remove_dontcare_GGA(self, ann_info):
+        keep = [i for i, x in enumerate(ann_info['name']) if x != 'DontCare']
+        out = {}
+        for key, val in ann_info.items():          # list-valued fields (the in-box point sets) filtered by hand
+            out[key] = [val[i] for i in keep] if isinstance(val, list) else val[keep]
+        return out
+
+    # ---- Custom3DDataset plumbing (custom_3d.py:127-156, 204-245, 430-448)
+    def pre_pipeline(self, results):
+        results['img_fields'] = []
+        results['bbox3d_fields'] = []
+        results['pts_mask_fields'] = []
+        results['pts_seg_fields'] = []
+        results['bbox_fields'] = []
+        results['mask_fields'] = []
+        results['seg_fields'] = []
+        results['box_type_3d'] = self.box_type_3d
+        results['box_mode_3d'] = self.box_mode_3d
+
+    def prepare_train_data(self, index):
+        input_dict = self.get_data_info(index)
+        if input_dict is None:
+            return None
+        self.pre_pipeline(input_dict)
+        example = self.pipeline(input_dict)
+        if self.filter_empty_gt and (example is None or ~(_unwrap(example['gt_labels_3d']) != -1).any()):
+            return None
+        return example
+
+    def _rand_another(self, idx):
+        return np.random.choice(len(self))
+
+    def __getitem__(self, idx):
+        if self.test_mode:
+            input_dict = self.get_data_info(idx)
+            self.pre_pipeline(input_dict)
+            return self.pipeline(input_dict)
+        while True:
+            data = self.prepare_train_data(idx)
+            if data is None:
+                idx = self._rand_another(idx)
+                continue
+            return data
+
+
+def _unwrap(x):
+    return getattr(x, '_data', getattr(x, 'data', x))
+
+
+@PIPELINES.register_module()
+class LoadAnnotations3D:
+    """loading.py:560-691 for the keys of the GGA LiDAR pipeline: 3D boxes, 3D labels and - with
+    ``with_gga=True`` - the GGA side arrays (``_load_GGA_labels``, loading.py:650-661)."""
+
+    def __init__(self, with_bbox_3d=True, with_label_3d=True, with_attr_label=False, with_mask_3d=False, with_seg_3d=False,
+                 with_bbox=False, with_label=False, with_mask=False, with_seg=False, with_bbox_depth=False, with_gga=False,
+                 poly2mask=True, seg_3d_dtype=np.int64, file_client_args=dict(backend='disk')):
+        for flag, name in ((with_attr_label, 'with_attr_label'), (with_mask_3d, 'with_mask_3d'), (with_seg_3d, 'with_seg_3d'),
+                           (with_mask, 'with_mask'), (with_seg, 'with_seg'), (with_bbox_depth, 'with_bbox_depth')):
+            if flag:
+                raise NotImplementedError(f'LoadAnnotations3D({name}=True) is not on the GGA LiDAR path')
+        self.with_bbox_3d, self.with_label_3d, self.with_bbox, self.with_label = with_bbox_3d, with_label_3d, with_bbox, with_label
+        self.with_gga = with_gga
+
+    def _load_bboxes_3d(self, results):
+        results['gt_bboxes_3d'] = results['ann_info']['gt_bboxes_3d']
+        results['bbox3d_fields'].append('gt_bboxes_3d')
+        return results
+
+    def _load_labels_3d(self, results):
+        results['gt_labels_3d'] = results['ann_info']['gt_labels_3d']
+        return results
+
+    def _load_GGA_labels(self, results):
+        a = results['ann_info']
+        results['GGA_boxes_img'] = a['GGA_boxes_img']
+        results['GGA_lidar2img'] = results['lidar2img'][np.newaxis, ...].repeat(len(results['GGA_boxes_img']), axis=0)
+        results['GGA_init_pseudo_labels'] = a['GGA_init_pseudo_label']
+        results['GGA_in_box_points'] = a['GGA_in_box_points']
+        results['GGA_mask_valid'] = a['GGA_mask2d'] & a['GGA_mask_valid'] & a['GGA_mask_depth']
+        results['GGA_bdry_masks'] = a['GGA_bdry_masks']
+        results['GGA_difficulty'] = a['difficulty']
+        results['GGA_num_points_in_box2d'] = a['GGA_num_points_in_box2d']
+        return results
+
+    def __call__(self, results):
+        if self.with_bbox:          # mmdet LoadAnnotations._load_bboxes for plain arrays
+            results['gt_bboxes'] = results['ann_info']['bboxes'].copy()
+            results['bbox_fields'].append('gt_bboxes')
+        if self.with_label:
+            results['gt_labels'] = results['ann_info']['labels'].copy()
+        if self.with_bbox_3d:
+            results = self._load_bboxes_3d(results)
+        if self.with_label_3d:
+            results = self._load_labels_3d(results)
+        if self.with_gga:
+            results = self._load_GGA_labels(results)
+        return results

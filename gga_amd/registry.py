@@ -106,6 +106,7 @@ BBOX_CODERS = Registry('bbox_coder')
 CONV_LAYERS = Registry('conv layer')
 PIPELINES = Registry('pipeline')             # mmdet.datasets.builder.PIPELINES (mmdet3d/datasets/builder.py)
 OBJECTSAMPLERS = Registry('Object sampler')  # mmdet3d/datasets/builder.py:13
+DATASETS = Registry('dataset')               # mmdet.datasets.builder.DATASETS (mmdet3d/datasets/builder.py:14)
 
 
 def build_backbone(cfg):

@@ -1,0 +1,147 @@
+"""Annotation loading and the GT database against a run of the reference's
+own ``KittiDataset_GGA_train`` / ``_load_GGA_labels`` / ``create_groundtruth_database`` on three frames
+(tests/golden/gt_database.npz + the info fixture the reference's converter produced,
+tools_dev/make_golden.py::golden_gt_database)."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from gga_amd import synthetic
+from gga_amd.datasets import KittiDataset_GGA_train, LoadAnnotations3D, camera_boxes_to_lidar
+from gga_amd.pipelines import LoadPointsFromFile
+
+SEEDS = (71, 72, 73)
+CLASSES = ('Pedestrian', 'Cyclist', 'Car')
+
+
+def _dataset(tmp_path, pipeline=None):
+    infos = pickle.load(open(os.path.join(GOLDEN, 'gt_database_infos.pkl'), 'rb'))
+    os.makedirs(tmp_path / 'training' / 'velodyne', exist_ok=True)
+    for seed in SEEDS:
+        synthetic.make_rga_scene(seed)[0].tofile(str(tmp_path / 'training' / 'velodyne' / f'{seed:06d}.bin'))
+    return KittiDataset_GGA_train(str(tmp_path), infos, 'training', classes=CLASSES, pipeline=pipeline,
+                                  modality=dict(use_lidar=True, use_camera=False))
+
+
+def test_get_ann_info_and_gga_labels_match_reference(golden, tmp_path):
+    g = golden('gt_database')
+    ds = _dataset(tmp_path)
+    loader = LoadAnnotations3D(with_bbox_3d=True, with_label_3d=True, with_gga=True)
+    for i, seed in enumerate(SEEDS):
+        d = ds.get_data_info(i)
+        a = d['ann_info']
+        assert d['sample_idx'] == seed and d['pts_filename'].endswith(f'{seed:06d}.bin')
+        assert d['lidar2img'].dtype == np.float32 and np.array_equal(d['lidar2img'], g[f'{seed}.lidar2img'])
+        # camera -> LiDAR boxes: torch float32 arithmetic, same operations as Box3DMode.convert
+        np.testing.assert_allclose(a["gt_bboxes_3d"].tensor.numpy(), g[f"{seed}.gt_bboxes_3d"], rtol=1e-6, atol=1e-5)
+        assert np.array_equal(a['gt_labels_3d'], g[f'{seed}.gt_labels_3d']) and a['gt_labels_3d'].dtype == np.int64
+        assert np.array_equal(a['bboxes'], g[f'{seed}.bboxes']) and a['bboxes'].dtype == np.float32
+        assert np.array_equal(np.asarray(a['difficulty']), g[f'{seed}.difficulty'])
+        assert list(a['gt_names']) == list(g[f'{seed}.gt_names'])
+        for k in ('GGA_boxes_img', 'GGA_mask_depth', 'GGA_mask2d', 'GGA_mask_valid', 'GGA_mask_boundary', 'GGA_bdry_masks',
+                  'GGA_init_pseudo_label', 'GGA_num_points_in_box2d'):
+            assert np.array_equal(np.asarray(a[k]), g[f'{seed}.ann.{k}']), k
+        assert [len(p) for p in a['GGA_in_box_points']] == g[f'{seed}.ann.in_box_len'].tolist()
+        ds.pre_pipeline(d)
+        res = loader(d)
+        for k in ('GGA_boxes_img', 'GGA_lidar2img', 'GGA_init_pseudo_labels', 'GGA_mask_valid', 'GGA_bdry_masks', 'GGA_difficulty',
+                  'GGA_num_points_in_box2d'):
+            got = np.asarray(res[k])
+            assert got.dtype == g[f'{seed}.load.{k}'].dtype and np.array_equal(got, g[f'{seed}.load.{k}']), k
+        assert res['gt_bboxes_3d'] is a['gt_bboxes_3d'] and res['bbox3d_fields'] == ['gt_bboxes_3d']
+
+
+def test_camera_to_lidar_conversion_known_values():
+    # identity-like rt (camera axes -> LiDAR axes), a box with yaw 0.3 rad: Box3DMode.convert CAM -> LIDAR
+    rt = np.array([[0, 0, 1, 0.27], [-1, 0, 0, 0.0], [0, -1, 0, -0.08], [0, 0, 0, 1]], np.float64)
+    out = camera_boxes_to_lidar(np.array([[1.0, 1.5, 20.0, 3.9, 1.56, 1.6, 0.3]], np.float32), rt).numpy()[0]
+    np.testing.assert_allclose(out[:3], [20.27, -1.0, -1.58], atol=1e-6)
+    np.testing.assert_allclose(out[3:6], [3.9, 1.6, 1.56], atol=1e-6)           # (l, h, w) -> (l, w, h)
+    np.testing.assert_allclose(out[6], -0.3 - np.pi / 2, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_gt_database_matches_reference(golden, tmp_path):
+    from gga_amd.gt_database import create_groundtruth_database
+    g = golden('gt_database')
+    ds = _dataset(tmp_path, pipeline=[LoadPointsFromFile(coord_type='LIDAR', load_dim=4, use_dim=4),
+                                      LoadAnnotations3D(with_bbox_3d=True, with_label_3d=True)])
+    db = create_groundtruth_database(ds, str(tmp_path), 'kitti', logger=lambda s: None)
+    assert sorted(db) == list(g['db.classes'])
+    entries = [e for cls in sorted(db) for e in db[cls]]
+    assert len(entries) == int(g['db.count'])
+    on_disk = pickle.load(open(tmp_path / 'kitti_dbinfos_train_GGA.pkl', 'rb'))
+    assert sorted(on_disk) == sorted(db)
+    for e in entries:
+        key = f"db.{e['image_idx']}.{e['gt_idx']}"
+        assert e['name'] == str(g[key + '.name']) and e['path'] == str(g[key + '.path'])
+        assert int(e['group_id']) == int(g[key + '.group_id'])
+        assert int(e['num_points_in_gt']) == int(g[key + '.num_points_in_gt'])
+        np.testing.assert_allclose(np.asarray(e['box3d_lidar']), g[key + '.box3d_lidar'], rtol=1e-6, atol=1e-5)
+        for k in ('difficulty', 'GGA_gt_box', 'GGA_box_img', 'GGA_mask_depth', 'GGA_mask2d', 'GGA_mask_valid', 'GGA_mask_boundary',
+                  'GGA_bdry_mask', 'GGA_init_pseudo_label', 'GGA_num_points_in_box2d', 'GGA_lidar2img'):
+            assert np.array_equal(np.asarray(e[k]), g[f'{key}.{k}']), k
+        assert np.array_equal(np.asarray(e['GGA_in_box_points']), g[key + '.in_box_points'])
+        pts = np.fromfile(str(tmp_path / e['path']), dtype=np.float32)
+        assert np.array_equal(pts, g[key + '.file'])            # the saved frustum points, bit for bit, in order
+    # the database feeds the sampler of the train pipeline
+    from gga_amd.pipelines import DataBaseSampler_GGA
+    sampler = DataBaseSampler_GGA(str(tmp_path / 'kitti_dbinfos_train_GGA.pkl'), str(tmp_path), rate=1.0,
+                                  prepare=dict(filter_by_difficulty=[-1], filter_by_min_points=dict(Car=5, Pedestrian=5)),
+                                  classes=list(CLASSES), sample_groups=dict(Car=2, Pedestrian=2),
+                                  points_loader=dict(type='LoadPointsFromFile', coord_type='LIDAR', load_dim=4, use_dim=[0, 1, 2, 3]))
+    assert sum(len(v) for v in sampler.db_infos.values()) > 0
+
+
+@pytest.mark.gpu
+def test_gga_info_file_driver(golden, tmp_path):
+    """File-level driver of the label generation (kitti_converter_gga.py:32-212): per-frame pickles,
+    resume, merge in split order; the labels equal the golden of the reference's _calculate_rga and
+    num_points_in_gt equals a float64 numpy evaluation of the same plane tests."""
+    from gga_amd import kitti_converter as KC
+    from gga_amd import label_gen as LG
+    g = golden('rga')
+    infos = []
+    os.makedirs(tmp_path / 'training' / 'velodyne', exist_ok=True)
+    for seed in SEEDS:
+        pts, calib, annos, shape = synthetic.make_rga_scene(seed)
+        rel = os.path.join('training', 'velodyne', f'{seed:06d}.bin')
+        pts.tofile(str(tmp_path / rel))
+        infos.append(dict(point_cloud=dict(velodyne_path=rel, num_features=4),
+                          image=dict(image_idx=seed, image_shape=np.array(shape, np.int32), image_path='x.png'),
+                          calib=calib, annos=annos))
+    split_dir = str(tmp_path / 'split')
+    merged = KC.create_gga_info_file(str(tmp_path), infos, [73, 71, 72], str(tmp_path / 'kitti_infos_train_GGA.pkl'),
+                                     save_path=split_dir, seed=0, logger=lambda s: None)
+    assert [m['image']['image_idx'] for m in merged] == [73, 71, 72]
+    assert sorted(os.listdir(split_dir)) == [f'GGA_kitti_scene_{s}.pkl' for s in SEEDS]
+    on_disk = pickle.load(open(tmp_path / 'kitti_infos_train_GGA.pkl', 'rb'))
+    for m, d in zip(merged, on_disk):
+        seed = m['image']['image_idx']
+        a = d['annos']
+        # seed + image_idx = image_idx: the golden was drawn with np.random.seed(image_idx)
+        for k in ('GGA_boxes_img', 'GGA_mask_depth', 'GGA_mask2d', 'GGA_mask_boundary', 'GGA_bdry_masks', 'GGA_mask_valid',
+                  'GGA_num_points_in_box2d'):
+            assert np.array_equal(np.asarray(a[k]), g[f'{seed}.{k}']), k
+        assert [len(p) for p in a['GGA_in_box_points']] == g[f'{seed}.in_box_len'].tolist()
+        # num_points_in_gt: same surfaces, float64 numpy
+        pts = synthetic.make_rga_scene(seed)[0]
+        c = d['calib']
+        pts = KC.remove_outside_points(pts, c['R0_rect'], c['Tr_velo_to_cam'], c['P2'], d['image']['image_shape'])
+        n_obj = len([n for n in a['name'] if n != 'DontCare'])
+        cam = np.concatenate([a['location'][:n_obj], a['dimensions'][:n_obj], a['rotation_y'][:n_obj, None]], 1)
+        boxes = KC.box_camera_to_lidar(cam, c['R0_rect'], c['Tr_velo_to_cam'])
+        corners = LG.center_to_corner_box3d(boxes[:, :3], boxes[:, 3:6], boxes[:, 6], origin=(0.5, 0.5, 0), axis=2)
+        normal, dd = LG.surface_equ_3d(LG.corner_to_surfaces_3d(corners)[:, :, :3, :])
+        sign = np.einsum('nk,bsk->nbs', pts[:, :3].astype(np.float64), normal) + dd[None]
+        want = (sign < 0).all(-1).sum(0)
+        assert a['num_points_in_gt'][:n_obj].tolist() == want.tolist() and (a['num_points_in_gt'][n_obj:] == -1).all()
+    # resume: existing per-frame files are not recomputed
+    before = {f: os.path.getmtime(os.path.join(split_dir, f)) for f in os.listdir(split_dir)}
+    KC.create_gga_info_file(str(tmp_path), infos, [71], str(tmp_path / 'again.pkl'), save_path=split_dir, resume=True,
+                            logger=lambda s: None)
+    assert before == {f: os.path.getmtime(os.path.join(split_dir, f)) for f in os.listdir(split_dir)}

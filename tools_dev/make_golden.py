@@ -689,6 +689,155 @@ def golden_rga(ref):
     np.savez_compressed(os.path.join(OUT, 'rga.npz'), **out)
 
 
+GTDB_SEEDS = (71, 72, 73)
+
+
+def golden_gt_database(ref):
+    """The reference's annotation loader and GT-database builder on three seeded frames:
+    ``KittiDataset_GGA_train.get_data_info / get_ann_info`` (mmdet3d/datasets/kitti_dataset_GGA_train.py:100-257,
+    real ``CameraInstance3DBoxes.convert_to``), ``LoadAnnotations3D._load_GGA_labels``
+    (datasets/pipelines/loading.py:650-661) and ``create_groundtruth_database``
+    (tools/data_converter/create_gt_database_gga.py:125-420) run on infos produced by the reference's own
+    ``_calculate_rga``. Stand-ins: the dataset object only carries what those methods read
+    (``data_infos``, ``CLASSES``, ``box_mode_3d``, split paths) and its two-step pipeline (read the .bin file
+    into ``LiDARPoints``, pass ``ann_info`` through) is written here - the third-party loaders are absent."""
+    import pickle
+    import tempfile
+    from gga_amd import label_gen as LG
+    pl = import_reference_pipeline(ref)
+    bo = sys.modules.get('mmdet3d.core.bbox.box_np_ops') or load('mmdet3d.core.bbox.box_np_ops', 'mmdet3d/core/bbox/box_np_ops.py')
+    cb = sys.modules['mmdet3d.core.bbox']
+    cb.box_np_ops, cb.points_cam2img = bo, None
+    # real camera boxes + mode conversion
+    cam = load('mmdet3d.core.bbox.structures.cam_box3d', 'mmdet3d/core/bbox/structures/cam_box3d.py')
+    dep = load('mmdet3d.core.bbox.structures.depth_box3d', 'mmdet3d/core/bbox/structures/depth_box3d.py')
+    st = sys.modules['mmdet3d.core.bbox.structures']
+    st.base_box3d = sys.modules['mmdet3d.core.bbox.structures.base_box3d']
+    bm = load('mmdet3d.core.bbox.structures.box_3d_mode', 'mmdet3d/core/bbox/structures/box_3d_mode.py')
+    cb.CameraInstance3DBoxes, cb.DepthInstance3DBoxes, cb.Box3DMode = cam.CameraInstance3DBoxes, dep.DepthInstance3DBoxes, bm.Box3DMode
+    cb.Coord3DMode = None
+    sys.modules['mmdet3d.core'].show_multi_modality_result = None
+    sys.modules['mmdet3d.core'].show_result = None
+    sys.modules['mmcv.utils'].print_log = print
+    sys.modules['mmdet3d.datasets.builder'].DATASETS = _Reg()
+    _mod('mmdet3d.datasets.custom_3d', Custom3DDataset=object)
+    sys.modules['mmdet3d.datasets.pipelines'].Compose = None
+    ds_mod = load('mmdet3d.datasets.kitti_dataset_GGA_train', 'mmdet3d/datasets/kitti_dataset_GGA_train.py')
+    # the rga converter (as golden_rga)
+    _mod('nuscenes'); _mod('nuscenes.utils'); _mod('nuscenes.utils.geometry_utils', view_points=LG.view_points)
+    _mod('tools'); _mod('tools.data_converter')
+    _mod('tools.data_converter.kitti_data_utils', WaymoInfoGatherer=None, get_kitti_image_info=None)
+    _mod('tools.data_converter.nuscenes_converter', post_process_coords=LG.post_process_coords)
+    shape_holder = {}
+    _mod('cv2', imread=lambda path: np.zeros(shape_holder['shape'] + (3,), np.uint8), cvtColor=lambda img, code: img,
+         COLOR_BGR2RGB=4)
+    load('tools.data_converter.utils_gga', 'tools/data_converter/utils_gga.py')
+    captured = {}
+    mm = sys.modules['mmcv']
+    mm.dump = lambda obj, filename: captured.update(obj=obj)
+    mm.track_iter_progress = lambda x: x
+    mm.mkdir_or_exist = lambda d: os.makedirs(d, exist_ok=True)
+    mm.imwrite = None
+    conv = load('tools.data_converter.kitti_converter_gga', 'tools/data_converter/kitti_converter_gga.py')
+    sys.modules['mmcv.ops'].roi_align = None
+    _mod('pycocotools'); _mod('pycocotools.mask'); _mod('pycocotools.coco', COCO=None)
+    sys.modules['pycocotools'].mask = sys.modules['pycocotools.mask']
+    _mod('mmdet.core.evaluation'); _mod('mmdet.core.evaluation.bbox_overlaps', bbox_overlaps=None)
+    holder = {}
+    sys.modules['mmdet3d.datasets'].build_dataset = lambda cfg: holder['dataset']
+    gtdb = load('tools.data_converter.create_gt_database_gga', 'tools/data_converter/create_gt_database_gga.py')
+    # loading.py's GGA method needs no import of the (third-party-heavy) module: it is one plain function
+    import ast
+    src = open(os.path.join(REF, 'mmdet3d/datasets/pipelines/loading.py')).read()
+    fn = [n for n in ast.walk(ast.parse(src)) if isinstance(n, ast.FunctionDef) and n.name == '_load_GGA_labels'][0]
+    ns = {'np': np}
+    exec(compile(ast.Module([fn], []), 'loading.py', 'exec'), ns)
+    load_gga = ns['_load_GGA_labels']
+
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        os.makedirs(os.path.join(tmp, 'training', 'velodyne'))
+        infos = []
+        for seed in GTDB_SEEDS:
+            pts, calib, annos, shape = synthetic.make_rga_scene(seed)
+            vrel = os.path.join('training', 'velodyne', f'{seed:06d}.bin')
+            pts.tofile(os.path.join(tmp, vrel))
+            shape_holder['shape'] = shape
+            info = dict(point_cloud=dict(velodyne_path=vrel, num_features=4),
+                        image=dict(image_idx=seed, image_shape=np.array(shape, np.int32), image_path='x.png'),
+                        calib=calib, annos=annos)
+            np.random.seed(seed)
+            conv._calculate_rga(tmp, info, relative_path=True)
+            infos.append(captured['obj'])
+        with open(os.path.join(tests_golden_dir(), 'gt_database_infos.pkl'), 'wb') as f:
+            pickle.dump(infos, f)                       # the INPUT fixture (produced by the reference's converter)
+
+        class FakeDataset(ds_mod.KittiDataset_GGA_train):
+            def __init__(self):        # Custom3DDataset.__init__ (third-party-heavy) is not run: only its fields
+                self.data_root, self.split, self.root_split = tmp, 'training', os.path.join(tmp, 'training')
+                self.pts_prefix, self.test_mode, self.data_infos = 'velodyne', False, infos
+                self.CLASSES = ('Pedestrian', 'Cyclist', 'Car')
+                self.box_mode_3d = bm.Box3DMode.LIDAR
+
+            def __len__(self):
+                return len(self.data_infos)
+
+            def pre_pipeline(self, results):
+                pass
+
+            def pipeline(self, d):
+                pts = np.fromfile(d['pts_filename'], dtype=np.float32).reshape(-1, 4)
+                d = dict(d)
+                d['points'] = pl['LiDARPoints'](torch.from_numpy(pts), points_dim=4)
+                return d
+
+        ds = FakeDataset()
+        holder['dataset'] = ds
+        for i, seed in enumerate(GTDB_SEEDS):
+            d = ds.get_data_info(i)
+            a = d['ann_info']
+            out[f'{seed}.lidar2img'] = d['lidar2img']
+            out[f'{seed}.gt_bboxes_3d'] = a['gt_bboxes_3d'].tensor.numpy()
+            out[f'{seed}.gt_labels_3d'] = a['gt_labels_3d']
+            out[f'{seed}.bboxes'] = a['bboxes']
+            out[f'{seed}.difficulty'] = np.asarray(a['difficulty'])
+            out[f'{seed}.gt_names'] = np.asarray(a['gt_names']).astype('U16')
+            for k in ('GGA_boxes_img', 'GGA_mask_depth', 'GGA_mask2d', 'GGA_mask_valid', 'GGA_mask_boundary', 'GGA_bdry_masks',
+                      'GGA_init_pseudo_label', 'GGA_num_points_in_box2d'):
+                out[f'{seed}.ann.{k}'] = np.asarray(a[k])
+            out[f'{seed}.ann.in_box_len'] = np.array([len(p) for p in a['GGA_in_box_points']], np.int64)
+            res = load_gga(None, dict(ann_info=a, lidar2img=d['lidar2img']))
+            for k in ('GGA_boxes_img', 'GGA_lidar2img', 'GGA_init_pseudo_labels', 'GGA_mask_valid', 'GGA_bdry_masks', 'GGA_difficulty',
+                      'GGA_num_points_in_box2d'):
+                out[f'{seed}.load.{k}'] = np.asarray(res[k])
+        gtdb.create_groundtruth_database('KittiDataset_GGA', tmp, 'kitti', os.path.join(tmp, 'infos.pkl'),
+                                         used_classes=None, with_mask=False)
+        db = pickle.load(open(os.path.join(tmp, 'kitti_dbinfos_train_GGA.pkl'), 'rb'))
+        n = 0
+        for cls in sorted(db):
+            for e in db[cls]:
+                key = f"db.{e['image_idx']}.{e['gt_idx']}"
+                out[key + '.name'] = np.asarray(e['name']).astype('U16')
+                out[key + '.path'] = np.asarray(e['path']).astype('U64')
+                out[key + '.group_id'] = np.int64(e['group_id'])
+                for k in ('box3d_lidar', 'num_points_in_gt', 'difficulty', 'GGA_gt_box', 'GGA_box_img', 'GGA_mask_depth', 'GGA_mask2d',
+                          'GGA_mask_valid', 'GGA_mask_boundary', 'GGA_bdry_mask', 'GGA_init_pseudo_label', 'GGA_num_points_in_box2d',
+                          'GGA_lidar2img'):
+                    out[f'{key}.{k}'] = np.asarray(e[k])
+                out[key + '.in_box_points'] = np.asarray(e['GGA_in_box_points'])
+                out[key + '.file'] = np.fromfile(os.path.join(tmp, e['path']), dtype=np.float32)
+                n += 1
+        out['db.count'] = np.int64(n)
+        out['db.classes'] = np.asarray(sorted(db)).astype('U16')
+        print(f'  gt database: {n} entries over classes {sorted(db)}; files hold '
+              f'{[int(len(out[k]) // 4) for k in out if k.endswith(".file")]} points')
+    np.savez_compressed(os.path.join(OUT, 'gt_database.npz'), **out)
+
+
+def tests_golden_dir():
+    return OUT
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = import_reference()
@@ -703,6 +852,7 @@ def main():
     golden_pipeline(ref)
     golden_label_gen(ref)
     golden_rga(ref)
+    golden_gt_database(ref)
     for f in sorted(os.listdir(OUT)):
         print(f'{f}: {os.path.getsize(os.path.join(OUT, f)) / 1024:.1f} KiB')
 

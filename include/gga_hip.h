@@ -608,6 +608,27 @@ int gga_points_in_convex_polyhedra(const double* points, int64_t n_points, int p
 int gga_plane_inliers(const double* points, int64_t n_points, int point_stride, const double* planes, int n_planes,
                       double threshold, int32_t* counts, uint8_t* masks, void* stream);
 
+/* ------------------------------------------------------------------------- */
+/* §8(f)4. Modulated deformable convolution (DCNv2), sampling half.           */
+/* Replaces the un-vendored mmcv ModulatedDeformConv2dPack natives behind     */
+/* `dcn_on_last_conv=True` of the PGD / FCOS3D heads                          */
+/* (mmdet3d/models/dense_heads/anchor_free_mono3d_head.py:187-211,            */
+/* configs/_base_/models/pgd.py:47). deform_groups = groups = 1.              */
+/* ------------------------------------------------------------------------- */
+/* x [B,H,W,C] f32 channels-last (C a multiple of 256, <= 1024); offset [B, 2*kh*kw, Ho, Wo] f32 NCHW with
+ * channel 2k = vertical, 2k+1 = horizontal offset of tap k = i*kw + j (mmcv's layout); mask [B, kh*kw, Ho, Wo]
+ * (already through the sigmoid). col [B*Ho*Wo, kh*kw*C] f32:
+ * col[p, k, c] = mask[p,k] * bilinear(x[..,c], p*stride - pad + tap*dil + offset[p,k]); samples outside
+ * (-1, H) x (-1, W) are 0, corners outside the image contribute 0. The convolution is then
+ * y = col @ W[Cout, kh, kw, C]^T + bias (a library GEMM on the caller's side). */
+int gga_dcn_im2col(const float* x, const float* offset, const float* mask, int B, int H, int W, int C, int kh, int kw,
+                   int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w, float* col, void* stream);
+/* Backward of the sampling: grad_col [B*Ho*Wo, kh*kw*C] -> grad_x [B,H,W,C] (zero-filled here, float atomic
+ * adds: the scatter targets are data dependent; NULL to skip), grad_offset / grad_mask in the layouts above. */
+int gga_dcn_col2im(const float* x, const float* offset, const float* mask, const float* grad_col, int B, int H, int W,
+                   int C, int kh, int kw, int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w,
+                   float* grad_x, float* grad_offset, float* grad_mask, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -116,6 +116,8 @@ SIGNATURES = {
     'gga_plane_inliers': (i32, [vp, i64, i32, vp, i32, C.c_double, vp, vp, vp]),
     'gga_image_box_match': (i32, [vp, vp, vp, vp, i32, i64, i32, vp, vp, vp, vp, vp]),
     'gga_points_in_boxes': (i32, [vp, vp, i32, i32, i32, i32, vp, vp]),
+    'gga_fcos3d_targets': (i32, [vp, i32, i32, C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_float), f32, vp, i32,
+                                  vp, vp, vp, vp, i32, vp, vp, vp, i64, i64, f32, vp, vp, vp, vp, vp, vp, vp]),
     'gga_dcn_im2col': (i32, [vp, vp, vp] + [i32] * 12 + [vp, vp]),
     'gga_dcn_col2im': (i32, [vp, vp, vp, vp] + [i32] * 12 + [vp, vp, vp, vp]),
 }

@@ -62,3 +62,100 @@ class CenterPointBBoxCoder:
             keep &= score > self.score_threshold
         return [dict(bboxes=boxes[i, keep[i]], scores=score[i, keep[i]], labels=label[i, keep[i]].float())
                 for i in range(B)]
+
+
+# ----------------------------------------------------------------------------- mono3d coders (PGD / FCOS3D)
+import numpy as np  # noqa: E402
+from torch.nn import functional as TF  # noqa: E402
+
+
+def limit_period(val, offset=0.5, period=np.pi):
+    return val - torch.floor(val / period + offset) * period
+
+
+@BBOX_CODERS.register_module()
+class FCOS3DBBoxCoder:
+    """mmdet3d/core/bbox/coders/fcos3d_bbox_coder.py:10-127: per-level learnable scales, depth / size priors,
+    stride un-normalisation at test time, local yaw -> global yaw."""
+
+    def __init__(self, base_depths=None, base_dims=None, code_size=7, norm_on_bbox=True):
+        self.base_depths, self.base_dims, self.bbox_code_size, self.norm_on_bbox = base_depths, base_dims, code_size, norm_on_bbox
+
+    def encode(self, gt_bboxes_3d, gt_labels_3d, gt_bboxes, gt_labels):
+        pass
+
+    def decode(self, bbox, scale, stride, training, cls_score=None):
+        scale_offset, scale_depth, scale_size = scale[0:3]
+        clone_bbox = bbox.clone()
+        bbox[:, :2] = scale_offset(clone_bbox[:, :2]).float()
+        bbox[:, 2] = scale_depth(clone_bbox[:, 2]).float()
+        bbox[:, 3:6] = scale_size(clone_bbox[:, 3:6]).float()
+        if self.base_depths is None:
+            bbox[:, 2] = bbox[:, 2].exp()
+        elif len(self.base_depths) == 1:
+            mean, std = self.base_depths[0]
+            bbox[:, 2] = mean + bbox.clone()[:, 2] * std
+        else:
+            assert len(self.base_depths) == cls_score.shape[1]
+            indices = cls_score.max(dim=1)[1]
+            priors = cls_score.new_tensor(self.base_depths)[indices, :].permute(0, 3, 1, 2)
+            bbox[:, 2] = priors[:, 0] + bbox.clone()[:, 2] * priors[:, 1]
+        bbox[:, 3:6] = bbox[:, 3:6].exp()
+        if self.base_dims is not None:
+            assert len(self.base_dims) == cls_score.shape[1]
+            indices = cls_score.max(dim=1)[1]
+            size_priors = cls_score.new_tensor(self.base_dims)[indices, :].permute(0, 3, 1, 2)
+            bbox[:, 3:6] = size_priors * bbox.clone()[:, 3:6]
+        assert self.norm_on_bbox is True
+        if not training:
+            bbox[:, :2] *= stride
+        return bbox
+
+    @staticmethod
+    def decode_yaw(bbox, centers2d, dir_cls, dir_offset, cam2img):
+        if bbox.shape[0] > 0:
+            dir_rot = limit_period(bbox[..., 6] - dir_offset, 0, np.pi)
+            bbox[..., 6] = dir_rot + dir_offset + np.pi * dir_cls.to(bbox.dtype)
+        bbox[:, 6] = torch.atan2(centers2d[:, 0] - cam2img[0, 2], cam2img[0, 0]) + bbox[:, 6]
+        return bbox
+
+
+@BBOX_CODERS.register_module()
+class PGDBBoxCoder(FCOS3DBBoxCoder):
+    """mmdet3d/core/bbox/coders/pgd_bbox_coder.py:10-128: key-point / 2D-distance channels and the
+    probabilistic depth read-out."""
+
+    def decode_2d(self, bbox, scale, stride, max_regress_range, training, pred_keypoints=False, pred_bbox2d=True):
+        clone_bbox = bbox.clone()
+        cs = self.bbox_code_size
+        if pred_keypoints:
+            bbox[:, cs:cs + 16] = torch.tanh(scale[3](clone_bbox[:, cs:cs + 16]).float())
+        if pred_bbox2d:
+            bbox[:, -4:] = scale[-1](clone_bbox[:, -4:]).float()
+        if self.norm_on_bbox:
+            if pred_bbox2d:
+                bbox[:, -4:] = TF.relu(bbox.clone()[:, -4:])
+            if not training:
+                if pred_keypoints:
+                    bbox[:, cs:cs + 16] *= max_regress_range
+                if pred_bbox2d:
+                    bbox[:, -4:] *= stride
+        elif pred_bbox2d:
+            bbox[:, -4:] = bbox.clone()[:, -4:].exp()
+        return bbox
+
+    def decode_prob_depth(self, depth_cls_preds, depth_range, depth_unit, division, num_depth_cls):
+        split = depth_cls_preds.new_tensor(list(range(num_depth_cls))).reshape([1, -1])
+        prob = TF.softmax(depth_cls_preds.clone(), dim=-1)
+        if division == 'uniform':
+            return (prob * (depth_unit * split)).sum(dim=-1)
+        if division == 'linear':
+            mult = depth_range[0] + (depth_range[1] - depth_range[0]) / (num_depth_cls * (num_depth_cls - 1)) * (split * (split + 1))
+            return (prob * mult).sum(dim=-1)
+        start, end = max(depth_range[0], 1), depth_range[1]
+        log_mult = np.log(start) + split * np.log(end / start) / (num_depth_cls - 1)
+        if division == 'log':
+            return (prob * log_mult.exp()).sum(dim=-1)
+        if division == 'loguniform':
+            return (prob * log_mult).sum(dim=-1).exp()
+        raise NotImplementedError

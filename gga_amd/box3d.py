@@ -126,3 +126,80 @@ def bbox3d2result(bboxes, scores, labels, attrs=None):
     if attrs is not None:
         result['attrs_3d'] = attrs.cpu()
     return result
+
+
+# ----------------------------------------------------------------------------- camera boxes (mono3d heads)
+def rotation_about_y(points, angles):
+    """``rotation_3d_in_axis(points [N,M,3], angles [N], axis=1)`` (core/bbox/structures/utils.py:28-117)."""
+    c, s = torch.cos(angles), torch.sin(angles)
+    o, z = torch.ones_like(c), torch.zeros_like(c)
+    rot_t = torch.stack([torch.stack([c, z, -s]), torch.stack([z, o, z]), torch.stack([s, z, c])])
+    return torch.einsum('aij,jka->aik', points, rot_t)
+
+
+def points_cam2img(points_3d, proj_mat, with_depth=False):
+    """core/bbox/structures/utils.py:173-214."""
+    points_shape = list(points_3d.shape)
+    points_shape[-1] = 1
+    proj_mat = torch.as_tensor(proj_mat, dtype=points_3d.dtype, device=points_3d.device)
+    d1, d2 = proj_mat.shape[:2]
+    if d1 == 3:
+        ex = torch.eye(4, device=proj_mat.device, dtype=proj_mat.dtype)
+        ex[:d1, :d2] = proj_mat
+        proj_mat = ex
+    p4 = torch.cat([points_3d, points_3d.new_ones(points_shape)], dim=-1)
+    p2 = p4 @ proj_mat.T
+    res = p2[..., :2] / p2[..., 2:3]
+    return torch.cat([res, p2[..., 2:3]], dim=-1) if with_depth else res
+
+
+def points_img2cam(points, cam2img):
+    """core/bbox/structures/utils.py:217-248: (u, v, depth) -> camera xyz."""
+    cam2img = torch.as_tensor(cam2img, dtype=points.dtype, device=points.device)
+    xys, depths = points[:, :2], points[:, 2].view(-1, 1)
+    un = torch.cat([xys * depths, depths], dim=1)
+    pad = torch.eye(4, dtype=xys.dtype, device=xys.device)
+    pad[:cam2img.shape[0], :cam2img.shape[1]] = cam2img
+    inv = torch.inverse(pad).transpose(0, 1)
+    homo = torch.cat([un, xys.new_ones((un.shape[0], 1))], dim=1)
+    return torch.mm(homo, inv)[:, :3]
+
+
+class CameraInstance3DBoxes:
+    """The slice of core/bbox/structures/cam_box3d.py the mono3d heads use: tensor
+    (x, y, z, x_size, y_size, z_size, yaw) with the bottom centre as origin (0.5, 1.0, 0.5), ``corners``."""
+    YAW_AXIS = 1
+
+    def __init__(self, tensor, box_dim=7, with_yaw=True, origin=(0.5, 1.0, 0.5)):
+        device = tensor.device if isinstance(tensor, torch.Tensor) else torch.device('cpu')
+        tensor = torch.as_tensor(tensor, dtype=torch.float32, device=device)
+        if tensor.numel() == 0:
+            tensor = tensor.reshape((0, box_dim))
+        assert tensor.dim() == 2 and tensor.size(-1) == box_dim, tensor.size()
+        self.box_dim, self.with_yaw = box_dim, with_yaw
+        self.tensor = tensor.clone()
+        if origin != (0.5, 1.0, 0.5):
+            dst, src = self.tensor.new_tensor((0.5, 1.0, 0.5)), self.tensor.new_tensor(origin)
+            self.tensor[:, :3] += self.tensor[:, 3:6] * (dst - src)
+
+    dims = property(lambda self: self.tensor[:, 3:6])
+    yaw = property(lambda self: self.tensor[:, 6])
+
+    def __len__(self):
+        return self.tensor.shape[0]
+
+    def to(self, device):
+        return CameraInstance3DBoxes(self.tensor.to(device), box_dim=self.box_dim, with_yaw=self.with_yaw)
+
+    @property
+    def corners(self):
+        if self.tensor.numel() == 0:
+            return torch.empty([0, 8, 3], device=self.tensor.device)
+        dims = self.dims
+        idx = torch.tensor([[0, 0, 0], [0, 0, 1], [0, 1, 1], [0, 1, 0], [1, 0, 0], [1, 0, 1], [1, 1, 1], [1, 1, 0]],
+                           device=dims.device, dtype=dims.dtype)       # unravel_index order [0,1,3,2,4,5,7,6]
+        corners_norm = idx - dims.new_tensor([0.5, 1, 0.5])
+        corners = dims.view([-1, 1, 3]) * corners_norm.reshape([1, 8, 3])
+        corners = rotation_about_y(corners, self.tensor[:, 6])
+        corners += self.tensor[:, :3].view(-1, 1, 3)
+        return corners

@@ -34,6 +34,13 @@ def build_conv_layer(cfg, *args, **kwargs):
 def build_norm_layer(cfg, num_features, postfix=''):
     cfg = dict(cfg)
     layer_type = cfg.pop('type')
+    if layer_type == 'GN':          # mmcv: abbreviation 'gn', GroupNorm(num_groups, num_channels)
+        requires_grad = cfg.pop('requires_grad', True)
+        cfg.setdefault('eps', 1e-5)
+        layer = nn.GroupNorm(num_channels=num_features, **cfg)
+        for p in layer.parameters():
+            p.requires_grad = requires_grad
+        return 'gn' + str(postfix), layer
     if layer_type not in _NORMS:
         raise KeyError(f'Unrecognized norm type {layer_type}')
     abbr, cls = _NORMS[layer_type]
@@ -87,7 +94,10 @@ class ConvModule(nn.Module):
         if self.with_activation:
             assert act_cfg['type'] == 'ReLU'
             self.activate = nn.ReLU(inplace=inplace)
-        kaiming_init(self.conv)
+        if hasattr(self.conv, 'init_weights') and not isinstance(self.conv, nn.Conv2d):
+            pass                                 # DCNv2 initialises itself (mmcv ConvModule.init_weights skips such convs)
+        else:
+            kaiming_init(self.conv)
         if self.with_norm:
             constant_init(self.norm, 1, bias=0)
 
@@ -97,10 +107,13 @@ class ConvModule(nn.Module):
 
     def forward(self, x):
         from . import dense_conv
-        x = dense_conv.conv2d(x, self.conv, bn_follows=self.with_norm and self.norm.training)
-        if self.with_norm:
+        is_bn = self.with_norm and isinstance(self.norm, nn.modules.batchnorm._BatchNorm)
+        x = dense_conv.conv2d(x, self.conv, bn_follows=is_bn and self.norm.training)
+        if is_bn:
             from . import functional as F        # fused BN(+ReLU) HIP pass for channels-last activations
             return F.bn_act(x, self.norm, relu=self.with_activation)
+        if self.with_norm:                       # GroupNorm (mono3d heads)
+            x = self.norm(x)
         if self.with_activation:
             x = self.activate(x)
         return x

@@ -1,0 +1,572 @@
+"""``PGDHead`` with its bases ``FCOSMono3DHead`` / ``AnchorFreeMono3DHead`` - SURVEY.md §8(f) rank 4, the
+camera-only detector the GGA recipe retrains on its pseudo labels (configs/gga/gga_pdg.py ->
+configs/_base_/models/pgd.py). Constructor arguments, layer / parameter names (``cls_convs``, ``reg_convs``,
+``conv_cls_prev``, ``conv_regs``, ``scales``, ``fuse_lambda`` ...), the forward outputs and the loss-dict
+keys are the reference's (mmdet3d/models/dense_heads/anchor_free_mono3d_head.py:15-534,
+fcos_mono3d_head.py:20-956, pgd_head.py:17-1229).
+
+MI355X side: the last tower convolutions are ``DCNv2`` (gga_amd/dcn.py, HIP sampling kernels); the
+O(points x boxes) target assignment of the whole batch is ONE launch (``gga_fcos3d_targets``) instead
+of ~60 broadcast tensor ops per image in a Python loop; the loss arithmetic on the few hundred
+positive points is plain device tensor code in the reference's order. Inference (``get_bboxes``)
+is not built.
+"""
+import numpy as np
+import torch
+from torch import nn
+
+from . import _lib
+from . import functional as F
+from ._lib import check
+from .bbox_coders import limit_period
+from .box3d import points_cam2img, points_img2cam
+from .cnn import ConvModule
+from .registry import HEADS, build_bbox_coder, build_loss
+
+INF = 1e8
+
+
+class Scale(nn.Module):
+    """mmcv.cnn.Scale: a learnable scalar factor."""
+
+    def __init__(self, scale=1.0):
+        super().__init__()
+        self.scale = nn.Parameter(torch.tensor(scale, dtype=torch.float))
+
+    def forward(self, x):
+        return x * self.scale
+
+
+def normal_init(module, mean=0, std=1, bias=0):
+    if getattr(module, 'weight', None) is not None:
+        nn.init.normal_(module.weight, mean, std)
+    if getattr(module, 'bias', None) is not None:
+        nn.init.constant_(module.bias, bias)
+
+
+def bias_init_with_prob(prior_prob):
+    return float(-np.log((1 - prior_prob) / prior_prob))
+
+
+def distance2bbox(points, distance):
+    return torch.stack([points[..., 0] - distance[..., 0], points[..., 1] - distance[..., 1],
+                        points[..., 0] + distance[..., 2], points[..., 1] + distance[..., 3]], -1)
+
+
+def multi_apply(func, *args, **kwargs):
+    results = [func(*a, **kwargs) for a in zip(*args)]
+    return tuple(map(list, zip(*results)))
+
+
+class AnchorFreeMono3DHead(nn.Module):
+    _version = 1
+
+    def __init__(self, num_classes, in_channels, feat_channels=256, stacked_convs=4, strides=(4, 8, 16, 32, 64),
+                 dcn_on_last_conv=False, conv_bias='auto', background_label=None, use_direction_classifier=True,
+                 diff_rad_by_sin=True, dir_offset=0, dir_limit_offset=0,
+                 loss_cls=dict(type='FocalLoss', use_sigmoid=True, gamma=2.0, alpha=0.25, loss_weight=1.0),
+                 loss_bbox=dict(type='SmoothL1Loss', beta=1.0 / 9.0, loss_weight=1.0),
+                 loss_dir=dict(type='CrossEntropyLoss', use_sigmoid=False, loss_weight=1.0),
+                 loss_attr=dict(type='CrossEntropyLoss', use_sigmoid=False, loss_weight=1.0), bbox_code_size=9,
+                 pred_attrs=False, num_attrs=9, pred_velo=False, pred_bbox2d=False, group_reg_dims=(2, 1, 3, 1, 2),
+                 cls_branch=(128, 64), reg_branch=((128, 64), (128, 64), (64, ), (64, ), ()), dir_branch=(64, ),
+                 attr_branch=(64, ), conv_cfg=None, norm_cfg=None, train_cfg=None, test_cfg=None, init_cfg=None):
+        super().__init__()
+        self.num_classes = self.cls_out_channels = num_classes
+        self.in_channels, self.feat_channels, self.stacked_convs, self.strides = in_channels, feat_channels, stacked_convs, strides
+        self.dcn_on_last_conv = dcn_on_last_conv
+        assert conv_bias == 'auto' or isinstance(conv_bias, bool)
+        self.conv_bias = conv_bias
+        self.use_direction_classifier, self.diff_rad_by_sin = use_direction_classifier, diff_rad_by_sin
+        self.dir_offset, self.dir_limit_offset = dir_offset, dir_limit_offset
+        self.loss_cls, self.loss_bbox, self.loss_dir = build_loss(loss_cls), build_loss(loss_bbox), build_loss(loss_dir)
+        self.bbox_code_size = bbox_code_size
+        self.group_reg_dims = list(group_reg_dims)
+        self.cls_branch, self.reg_branch = cls_branch, reg_branch
+        assert len(reg_branch) == len(group_reg_dims)
+        self.pred_velo, self.pred_bbox2d = pred_velo, pred_bbox2d
+        self.out_channels = [r[-1] if len(r) > 0 else -1 for r in reg_branch]
+        self.dir_branch = dir_branch
+        self.train_cfg, self.test_cfg, self.conv_cfg, self.norm_cfg = train_cfg, test_cfg, conv_cfg, norm_cfg
+        self.fp16_enabled = False
+        self.background_label = num_classes if background_label is None else background_label
+        assert self.background_label in (0, num_classes)
+        self.pred_attrs, self.attr_background_label, self.num_attrs = pred_attrs, -1, num_attrs
+        if self.pred_attrs:
+            self.attr_background_label = num_attrs
+            self.loss_attr = build_loss(loss_attr)
+            self.attr_branch = attr_branch
+        self._init_layers()
+
+    # ---- layers
+    def _init_layers(self):
+        self.cls_convs = self._tower()
+        self.reg_convs = self._tower()
+        self._init_predictor()
+
+    def _tower(self):
+        convs = nn.ModuleList()
+        for i in range(self.stacked_convs):
+            chn = self.in_channels if i == 0 else self.feat_channels
+            conv_cfg = dict(type='DCNv2') if self.dcn_on_last_conv and i == self.stacked_convs - 1 else self.conv_cfg
+            convs.append(ConvModule(chn, self.feat_channels, 3, stride=1, padding=1, conv_cfg=conv_cfg, norm_cfg=self.norm_cfg,
+                                    bias=self.conv_bias))
+        return convs
+
+    def _init_branch(self, conv_channels=(64), conv_strides=(1)):
+        if isinstance(conv_channels, int):
+            conv_channels, conv_strides = [self.feat_channels, conv_channels], [conv_strides]
+        else:
+            conv_channels, conv_strides = [self.feat_channels] + list(conv_channels), list(conv_strides)
+        return nn.ModuleList([ConvModule(conv_channels[i], conv_channels[i + 1], 3, stride=conv_strides[i], padding=1,
+                                         conv_cfg=self.conv_cfg, norm_cfg=self.norm_cfg, bias=self.conv_bias)
+                              for i in range(len(conv_strides))])
+
+    def _init_predictor(self):
+        self.conv_cls_prev = self._init_branch(self.cls_branch, (1, ) * len(self.cls_branch))
+        self.conv_cls = nn.Conv2d(self.cls_branch[-1], self.cls_out_channels, 1)
+        self.conv_reg_prevs, self.conv_regs = nn.ModuleList(), nn.ModuleList()
+        for i, reg_dim in enumerate(self.group_reg_dims):
+            if len(self.reg_branch[i]) > 0:
+                self.conv_reg_prevs.append(self._init_branch(self.reg_branch[i], (1, ) * len(self.reg_branch[i])))
+                self.conv_regs.append(nn.Conv2d(self.out_channels[i], reg_dim, 1))
+            else:
+                self.conv_reg_prevs.append(None)
+                self.conv_regs.append(nn.Conv2d(self.feat_channels, reg_dim, 1))
+        if self.use_direction_classifier:
+            self.conv_dir_cls_prev = self._init_branch(self.dir_branch, (1, ) * len(self.dir_branch))
+            self.conv_dir_cls = nn.Conv2d(self.dir_branch[-1], 2, 1)
+        if self.pred_attrs:
+            self.conv_attr_prev = self._init_branch(self.attr_branch, (1, ) * len(self.attr_branch))
+            self.conv_attr = nn.Conv2d(self.attr_branch[-1], self.num_attrs, 1)
+
+    def _init_branch_weights(self, branch):
+        for m in branch:
+            if isinstance(m.conv, nn.Conv2d):
+                normal_init(m.conv, std=0.01)
+
+    def init_weights(self):
+        for modules in [self.cls_convs, self.reg_convs, self.conv_cls_prev]:
+            self._init_branch_weights(modules)
+        for prev in self.conv_reg_prevs:
+            if prev is not None:
+                self._init_branch_weights(prev)
+        if self.use_direction_classifier:
+            self._init_branch_weights(self.conv_dir_cls_prev)
+        if self.pred_attrs:
+            self._init_branch_weights(self.conv_attr_prev)
+        bias_cls = bias_init_with_prob(0.01)
+        normal_init(self.conv_cls, std=0.01, bias=bias_cls)
+        for conv_reg in self.conv_regs:
+            normal_init(conv_reg, std=0.01)
+        if self.use_direction_classifier:
+            normal_init(self.conv_dir_cls, std=0.01, bias=bias_cls)
+        if self.pred_attrs:
+            normal_init(self.conv_attr, std=0.01, bias=bias_cls)
+
+    @staticmethod
+    def _run(branch, x):
+        for layer in branch:
+            x = layer(x)
+        return x
+
+    def _forward_base(self, x):
+        cls_feat = self._run(self.cls_convs, x)
+        cls_score = self.conv_cls(self._run(self.conv_cls_prev, cls_feat))
+        reg_feat = self._run(self.reg_convs, x)
+        bbox_pred = []
+        for i in range(len(self.group_reg_dims)):
+            f = reg_feat if len(self.reg_branch[i]) == 0 else self._run(self.conv_reg_prevs[i], reg_feat)
+            bbox_pred.append(self.conv_regs[i](f))
+        bbox_pred = torch.cat(bbox_pred, dim=1)
+        dir_cls_pred = self.conv_dir_cls(self._run(self.conv_dir_cls_prev, reg_feat)) if self.use_direction_classifier else None
+        attr_pred = self.conv_attr(self._run(self.conv_attr_prev, cls_feat)) if self.pred_attrs else None
+        return cls_score, bbox_pred, dir_cls_pred, attr_pred, cls_feat, reg_feat
+
+    def _get_points_single(self, featmap_size, stride, dtype, device, flatten=False):
+        h, w = featmap_size
+        y, x = torch.meshgrid(torch.arange(h, dtype=dtype, device=device), torch.arange(w, dtype=dtype, device=device),
+                              indexing='ij')
+        return (y.flatten(), x.flatten()) if flatten else (y, x)
+
+    def get_points(self, featmap_sizes, dtype, device, flatten=False):
+        return [self._get_points_single(featmap_sizes[i], self.strides[i], dtype, device, flatten)
+                for i in range(len(featmap_sizes))]
+
+
+class FCOSMono3DHead(AnchorFreeMono3DHead):
+    def __init__(self, regress_ranges=((-1, 48), (48, 96), (96, 192), (192, 384), (384, INF)), center_sampling=True,
+                 center_sample_radius=1.5, norm_on_bbox=True, centerness_on_reg=True, centerness_alpha=2.5,
+                 loss_cls=dict(type='FocalLoss', use_sigmoid=True, gamma=2.0, alpha=0.25, loss_weight=1.0),
+                 loss_bbox=dict(type='SmoothL1Loss', beta=1.0 / 9.0, loss_weight=1.0),
+                 loss_dir=dict(type='CrossEntropyLoss', use_sigmoid=False, loss_weight=1.0),
+                 loss_attr=dict(type='CrossEntropyLoss', use_sigmoid=False, loss_weight=1.0),
+                 loss_centerness=dict(type='CrossEntropyLoss', use_sigmoid=True, loss_weight=1.0),
+                 bbox_coder=dict(type='FCOS3DBBoxCoder', code_size=9), norm_cfg=dict(type='GN', num_groups=32, requires_grad=True),
+                 centerness_branch=(64, ), init_cfg=None, **kwargs):
+        self.regress_ranges, self.center_sampling, self.center_sample_radius = regress_ranges, center_sampling, center_sample_radius
+        self.norm_on_bbox, self.centerness_on_reg, self.centerness_alpha = norm_on_bbox, centerness_on_reg, centerness_alpha
+        self.centerness_branch = centerness_branch
+        super().__init__(loss_cls=loss_cls, loss_bbox=loss_bbox, loss_dir=loss_dir, loss_attr=loss_attr, norm_cfg=norm_cfg,
+                         init_cfg=init_cfg, **kwargs)
+        self.loss_centerness = build_loss(loss_centerness)
+        bbox_coder = dict(bbox_coder)
+        bbox_coder['code_size'] = self.bbox_code_size
+        self.bbox_coder = build_bbox_coder(bbox_coder)
+
+    def _init_layers(self):
+        super()._init_layers()
+        self.conv_centerness_prev = self._init_branch(self.centerness_branch, (1, ) * len(self.centerness_branch))
+        self.conv_centerness = nn.Conv2d(self.centerness_branch[-1], 1, 1)
+        self.scale_dim = 3       # offset, depth, size
+        self._make_scales()
+
+    def _make_scales(self):
+        self.scales = nn.ModuleList([nn.ModuleList([Scale(1.0) for _ in range(self.scale_dim)]) for _ in self.strides])
+
+    def init_weights(self):
+        super().init_weights()
+        self._init_branch_weights(self.conv_centerness_prev)
+        normal_init(self.conv_centerness, std=0.01)
+
+    def _forward_fcos(self, x, scale, stride):
+        cls_score, bbox_pred, dir_cls_pred, attr_pred, cls_feat, reg_feat = self._forward_base(x)
+        centerness = self.conv_centerness(self._run(self.conv_centerness_prev, reg_feat if self.centerness_on_reg else cls_feat))
+        bbox_pred = self.bbox_coder.decode(bbox_pred, scale, stride, self.training, cls_score)
+        return cls_score, bbox_pred, dir_cls_pred, attr_pred, centerness, cls_feat, reg_feat
+
+    @staticmethod
+    def add_sin_difference(boxes1, boxes2):
+        rad_pred = torch.sin(boxes1[..., 6:7]) * torch.cos(boxes2[..., 6:7])
+        rad_tg = torch.cos(boxes1[..., 6:7]) * torch.sin(boxes2[..., 6:7])
+        return (torch.cat([boxes1[..., :6], rad_pred, boxes1[..., 7:]], dim=-1),
+                torch.cat([boxes2[..., :6], rad_tg, boxes2[..., 7:]], dim=-1))
+
+    @staticmethod
+    def get_direction_target(reg_targets, dir_offset=0, dir_limit_offset=0.0, num_bins=2, one_hot=True):
+        offset_rot = limit_period(reg_targets[..., 6] - dir_offset, dir_limit_offset, 2 * np.pi)
+        t = torch.clamp(torch.floor(offset_rot / (2 * np.pi / num_bins)).long(), min=0, max=num_bins - 1)
+        if one_hot:
+            oh = torch.zeros(*list(t.shape), num_bins, dtype=reg_targets.dtype, device=t.device)
+            oh.scatter_(t.unsqueeze(dim=-1).long(), 1.0)
+            return oh
+        return t
+
+    def _get_points_single(self, featmap_size, stride, dtype, device, flatten=False):
+        y, x = super()._get_points_single(featmap_size, stride, dtype, device)
+        return torch.stack((x.reshape(-1) * stride, y.reshape(-1) * stride), dim=-1) + stride // 2
+
+    # ---- targets: the whole batch in one launch
+    def assign_targets(self, points, gt_bboxes_list, gt_labels_list, gt_bboxes_3d_list, gt_labels_3d_list, centers2d_list,
+                       depths_list, attr_labels_list):
+        """``multi_apply(self._get_target_single, ...)`` of the reference for all images at once ->
+        (labels [B,P], bbox_targets [B,P,4], labels_3d [B,P], bbox_targets_3d [B,P,code], centerness [B,P], attr [B,P])."""
+        assert self.center_sampling is True, 'Setting center_sampling to False has not been implemented for FCOS3D.'
+        assert len(points) == len(self.regress_ranges)
+        dev = points[0].device
+        concat_points = torch.cat(points, dim=0).float().contiguous()
+        F._need_cuda(concat_points)
+        P, B, code = concat_points.shape[0], len(gt_labels_list), self.bbox_code_size
+        begins = np.cumsum([0] + [p.size(0) for p in points])[:-1].astype(np.int32)
+        g3d = []
+        for t in gt_bboxes_3d_list:
+            t = (t if isinstance(t, torch.Tensor) else t.tensor).to(dev).float().clone()
+            if t.shape[0]:      # global yaw -> local yaw (the reference edits the caller's tensor in place; a copy here)
+                t[..., 6] = -torch.atan2(t[..., 0], t[..., 2]) + t[..., 6]
+            g3d.append(t.reshape(-1, code))
+        if attr_labels_list is None:
+            attr_labels_list = [g.new_full(g.shape, self.attr_background_label) for g in gt_labels_list]
+        offs = torch.tensor(np.cumsum([0] + [int(g.shape[0]) for g in gt_labels_list]), dtype=torch.int64)
+        cat = lambda xs, dt, w: torch.cat([x.to(dev).to(dt).reshape(-1, w) for x in xs]).contiguous() if xs else None
+        gb, c2d = cat(gt_bboxes_list, torch.float32, 4), cat(centers2d_list, torch.float32, 2)
+        dep, g3 = cat(depths_list, torch.float32, 1), torch.cat(g3d).contiguous()
+        gl, gl3, al = cat(gt_labels_list, torch.int64, 1), cat(gt_labels_3d_list, torch.int64, 1), cat(attr_labels_list, torch.int64, 1)
+        offs_d = F.upload(offs, dev)
+        out_l = torch.empty((B, P), dtype=torch.int64, device=dev)
+        out_l3, out_a = torch.empty_like(out_l), torch.empty_like(out_l)
+        out_bt = torch.empty((B, P, 4), dtype=torch.float32, device=dev)
+        out_t3 = torch.empty((B, P, code), dtype=torch.float32, device=dev)
+        out_c = torch.empty((B, P), dtype=torch.float32, device=dev)
+        import ctypes as C
+        strides = (C.c_float * len(self.strides))(*[float(s) for s in self.strides])
+        ranges = (C.c_float * (2 * len(self.regress_ranges)))(*[float(v) for r in self.regress_ranges for v in r])
+        check(_lib.lib().gga_fcos3d_targets(F._p(concat_points), P, len(points), begins.ctypes.data_as(C.POINTER(C.c_int32)), strides, ranges,
+                                            float(self.center_sample_radius), F._p(offs_d), B, F._p(gb), F._p(c2d), F._p(dep), F._p(g3),
+                                            code, F._p(gl), F._p(gl3), F._p(al), int(self.background_label),
+                                            int(self.attr_background_label), float(self.centerness_alpha), F._p(out_l), F._p(out_bt),
+                                            F._p(out_l3), F._p(out_t3), F._p(out_c), F._p(out_a), F._stream()), 'gga_fcos3d_targets')
+        return out_l, out_bt, out_l3, out_t3, out_c, out_a
+
+
+@HEADS.register_module()
+class PGDHead(FCOSMono3DHead):
+    def __init__(self, use_depth_classifier=True, use_onlyreg_proj=False, weight_dim=-1, weight_branch=((256, ), ),
+                 depth_branch=(64, ), depth_range=(0, 70), depth_unit=10, division='uniform', depth_bins=8,
+                 loss_depth=dict(type='SmoothL1Loss', beta=1.0 / 9.0, loss_weight=1.0),
+                 loss_bbox2d=dict(type='SmoothL1Loss', beta=1.0 / 9.0, loss_weight=1.0),
+                 loss_consistency=dict(type='GIoULoss', loss_weight=1.0), pred_bbox2d=True, pred_keypoints=False,
+                 bbox_coder=dict(type='PGDBBoxCoder', base_depths=((28.01, 16.32), ),
+                                 base_dims=((0.8, 1.73, 0.6), (1.76, 1.73, 0.6), (3.9, 1.56, 1.6)), code_size=7), **kwargs):
+        self.use_depth_classifier, self.use_onlyreg_proj = use_depth_classifier, use_onlyreg_proj
+        self.depth_branch, self.pred_keypoints = depth_branch, pred_keypoints
+        self.weight_dim, self.weight_branch = weight_dim, weight_branch
+        self.weight_out_channels = [w[-1] if len(w) > 0 else -1 for w in weight_branch]
+        self.depth_range, self.depth_unit, self.division = depth_range, depth_unit, division
+        if division == 'uniform':
+            self.num_depth_cls = int((depth_range[1] - depth_range[0]) / depth_unit) + 1
+        else:
+            self.num_depth_cls = depth_bins
+        super().__init__(pred_bbox2d=pred_bbox2d, bbox_coder=bbox_coder, **kwargs)
+        self.loss_depth = build_loss(loss_depth)
+        if self.pred_bbox2d:
+            self.loss_bbox2d = build_loss(loss_bbox2d)
+            self.loss_consistency = build_loss(loss_consistency)
+        if self.pred_keypoints:
+            self.kpts_start = 9 if self.pred_velo else 7
+
+    def _init_layers(self):
+        super()._init_layers()
+        self.scale_dim += int(self.pred_bbox2d) + int(self.pred_keypoints)
+        self._make_scales()
+
+    def _init_predictor(self):
+        super()._init_predictor()
+        if self.use_depth_classifier:
+            self.conv_depth_cls_prev = self._init_branch(self.depth_branch, (1, ) * len(self.depth_branch))
+            self.conv_depth_cls = nn.Conv2d(self.depth_branch[-1], self.num_depth_cls, 1)
+            self.fuse_lambda = nn.Parameter(torch.tensor(10e-5))      # "learnable weight of the depth fusion"
+        if self.weight_dim != -1:
+            self.conv_weight_prevs, self.conv_weights = nn.ModuleList(), nn.ModuleList()
+            for i in range(self.weight_dim):
+                if len(self.weight_branch[i]) > 0:
+                    self.conv_weight_prevs.append(self._init_branch(self.weight_branch[i], (1, ) * len(self.weight_branch[i])))
+                    self.conv_weights.append(nn.Conv2d(self.weight_out_channels[i], 1, 1))
+                else:
+                    self.conv_weight_prevs.append(None)
+                    self.conv_weights.append(nn.Conv2d(self.feat_channels, 1, 1))
+
+    def init_weights(self):
+        super().init_weights()
+        bias_cls = bias_init_with_prob(0.01)
+        if self.use_depth_classifier:
+            self._init_branch_weights(self.conv_depth_cls_prev)
+            normal_init(self.conv_depth_cls, std=0.01, bias=bias_cls)
+        if self.weight_dim != -1:
+            for prev in self.conv_weight_prevs:
+                if prev is not None:
+                    self._init_branch_weights(prev)
+            for conv_weight in self.conv_weights:
+                normal_init(conv_weight, std=0.01)
+
+    def forward(self, feats):
+        return multi_apply(self.forward_single, feats, self.scales, self.strides)
+
+    def forward_single(self, x, scale, stride):
+        cls_score, bbox_pred, dir_cls_pred, attr_pred, centerness, cls_feat, reg_feat = self._forward_fcos(x, scale, stride)
+        max_regress_range = stride * self.regress_ranges[0][1] / self.strides[0]
+        bbox_pred = self.bbox_coder.decode_2d(bbox_pred, scale, stride, max_regress_range, self.training, self.pred_keypoints,
+                                              self.pred_bbox2d)
+        depth_cls_pred = self.conv_depth_cls(self._run(self.conv_depth_cls_prev, reg_feat)) if self.use_depth_classifier else None
+        weight = None
+        if self.weight_dim != -1:
+            weight = torch.cat([self.conv_weights[i](reg_feat if len(self.weight_branch[i]) == 0 else
+                                                     self._run(self.conv_weight_prevs[i], reg_feat))
+                                for i in range(self.weight_dim)], dim=1)
+        return cls_score, bbox_pred, dir_cls_pred, depth_cls_pred, weight, attr_pred, centerness
+
+    # ---- targets per level (pgd_head.py:1132-1229)
+    def get_targets(self, points, gt_bboxes_list, gt_labels_list, gt_bboxes_3d_list, gt_labels_3d_list, centers2d_list,
+                    depths_list, attr_labels_list):
+        num_points = [p.size(0) for p in points]
+        _, bt, l3, t3, cen, attr = self.assign_targets(points, gt_bboxes_list, gt_labels_list, gt_bboxes_3d_list, gt_labels_3d_list,
+                                                       centers2d_list, depths_list, attr_labels_list)
+        labels_3d, targets_3d, centerness, attrs = [], [], [], []
+        for i, (lo, n) in enumerate(zip(np.cumsum([0] + num_points)[:-1], num_points)):
+            sl = slice(int(lo), int(lo) + n)
+            labels_3d.append(l3[:, sl].reshape(-1))                       # image-major inside a level, as torch.cat over images
+            centerness.append(cen[:, sl].reshape(-1))
+            attrs.append(attr[:, sl].reshape(-1))
+            t = t3[:, sl].reshape(-1, self.bbox_code_size)
+            if self.pred_bbox2d:
+                t = torch.cat([t, bt[:, sl].reshape(-1, 4)], dim=1)
+            else:
+                t = t.clone()
+            if self.norm_on_bbox:
+                t[:, :2] = t[:, :2] / self.strides[i]
+                if self.pred_bbox2d:
+                    t[:, -4:] = t[:, -4:] / self.strides[i]
+            targets_3d.append(t)
+        return labels_3d, targets_3d, centerness, attrs
+
+    def get_pos_predictions(self, bbox_preds, dir_cls_preds, depth_cls_preds, weights, attr_preds, centernesses, pos_inds, img_metas):
+        flat = lambda xs, w: torch.cat([x.permute(0, 2, 3, 1).reshape(-1, w) for x in xs])
+        pos_bbox_preds = flat(bbox_preds, sum(self.group_reg_dims))[pos_inds]
+        pos_dir_cls_preds = flat(dir_cls_preds, 2)[pos_inds]
+        pos_centerness = torch.cat([c.permute(0, 2, 3, 1).reshape(-1) for c in centernesses])[pos_inds]
+        pos_depth_cls_preds = flat(depth_cls_preds, self.num_depth_cls)[pos_inds] if self.use_depth_classifier else None
+        pos_weights = flat(weights, self.weight_dim)[pos_inds] if self.weight_dim != -1 else None
+        pos_attr_preds = flat(attr_preds, self.num_attrs)[pos_inds] if self.pred_attrs else None
+        return pos_bbox_preds, pos_dir_cls_preds, pos_depth_cls_preds, pos_weights, pos_attr_preds, pos_centerness
+
+    def get_proj_bbox2d(self, bbox_preds, pos_dir_cls_preds, labels_3d, bbox_targets_3d, pos_points, pos_inds, img_metas,
+                        pos_depth_cls_preds=None, pos_weights=None, pos_cls_scores=None, with_kpts=False):
+        """2D boxes of the projected 3D predictions, the decoded 2D predictions and (optionally) the key-point
+        targets of the positive points (pgd_head.py:265-441)."""
+        views = [np.array(m['cam2img']) for m in img_metas]
+        num_imgs = len(img_metas)
+        img_idx = torch.cat([labels_3d[0].new_ones(int(len(label) / num_imgs)) * idx for label in labels_3d for idx in range(num_imgs)])
+        pos_img_idx = img_idx[pos_inds]
+        sp, sp2d, st, ss = [], [], [], []
+        for i, bbox_pred in enumerate(bbox_preds):
+            f = bbox_pred.permute(0, 2, 3, 1).reshape(-1, sum(self.group_reg_dims))
+            f = torch.cat([f[:, :2] * self.strides[i], f[:, 2:-4], f[:, -4:] * self.strides[i]], dim=1)
+            sp.append(f[:, :self.bbox_coder.bbox_code_size])
+            sp2d.append(f[:, -4:])
+            t = bbox_targets_3d[i]
+            st.append(torch.cat([t[:, :2] * self.strides[i], t[:, 2:-4], t[:, -4:] * self.strides[i]], dim=1))
+            ss.append(f.new_ones(f.shape[0], 1) * self.strides[i])
+        pos_preds = torch.cat(sp)[pos_inds]
+        pos_bbox2d = torch.cat(sp2d)[pos_inds]
+        pos_targets = torch.cat(st)[pos_inds]
+        pos_strides = torch.cat(ss)[pos_inds]
+        pos_decoded_bbox2d_preds = distance2bbox(pos_points, pos_bbox2d)
+        pos_preds = torch.cat([pos_points - pos_preds[:, :2], pos_preds[:, 2:]], dim=1)
+        pos_targets = torch.cat([pos_points - pos_targets[:, :2], pos_targets[:, 2:]], dim=1)
+        if self.use_depth_classifier and not self.use_onlyreg_proj:
+            prob = self.bbox_coder.decode_prob_depth(pos_depth_cls_preds, self.depth_range, self.depth_unit, self.division,
+                                                     self.num_depth_cls)
+            a = torch.sigmoid(self.fuse_lambda)
+            pos_preds = torch.cat([pos_preds[:, :2], (a * pos_preds[:, 2] + (1 - a) * prob)[:, None], pos_preds[:, 3:]], dim=1)
+        corners_img = pos_preds.new_zeros((*pos_preds.shape[:-1], 8, 2))
+        corners_img_gt = pos_preds.new_zeros((*pos_preds.shape[:-1], 8, 2))
+        box_type = img_metas[0]['box_type_3d']
+        code = self.bbox_coder.bbox_code_size
+        for idx in range(num_imgs):
+            mask = pos_img_idx == idx
+            if int(mask.sum()) == 0:
+                continue
+            view = views[idx]
+            cam2img = torch.eye(4, dtype=pos_preds.dtype, device=pos_preds.device)
+            cam2img[:view.shape[0], :view.shape[1]] = pos_preds.new_tensor(view)
+            p, t = pos_preds[mask], pos_targets[mask]
+            centers2d_preds, centers2d_targets = p[:, :2].clone(), t[:, :2].clone()
+            t3 = points_img2cam(t[:, :3], view)
+            p3 = points_img2cam(p[:, :3], view)
+            p = torch.cat([p3[:, :2], t3[:, 2:3], p[:, 3:]], dim=1)       # the depth of the target: only the rest is judged
+            t = torch.cat([t3, t[:, 3:]], dim=1)
+            if self.use_direction_classifier:
+                dir_cls = torch.max(pos_dir_cls_preds[mask], dim=-1)[1]
+                p = self.bbox_coder.decode_yaw(p.clone(), centers2d_preds, dir_cls, self.dir_offset, cam2img)
+            t = torch.cat([t[:, :6], (torch.atan2(centers2d_targets[:, 0] - cam2img[0, 2], cam2img[0, 0]) + t[:, 6])[:, None],
+                           t[:, 7:]], dim=1)
+            corners_img[mask] = points_cam2img(box_type(p[:, :code], box_dim=code, origin=(0.5, 0.5, 0.5)).corners, cam2img)
+            corners_img_gt[mask] = points_cam2img(box_type(t[:, :self.bbox_code_size], box_dim=code, origin=(0.5, 0.5, 0.5)).corners,
+                                                  cam2img)
+        proj = torch.cat([torch.min(corners_img, dim=1)[0], torch.max(corners_img, dim=1)[0]], dim=1)
+        outputs = (proj, pos_decoded_bbox2d_preds)
+        if with_kpts:
+            norm_strides = pos_strides * self.regress_ranges[0][1] / self.strides[0]
+            kpts = (corners_img_gt - pos_points[..., None, :]).view((*pos_preds.shape[:-1], 16)) / norm_strides
+            outputs += (kpts, )
+        return outputs
+
+    def loss(self, cls_scores, bbox_preds, dir_cls_preds, depth_cls_preds, weights, attr_preds, centernesses, gt_bboxes, gt_labels,
+             gt_bboxes_3d, gt_labels_3d, centers2d, depths, attr_labels, img_metas, gt_bboxes_ignore=None):
+        assert len(cls_scores) == len(bbox_preds) == len(dir_cls_preds) == len(depth_cls_preds) == len(weights) == \
+            len(centernesses) == len(attr_preds)
+        featmap_sizes = [f.size()[-2:] for f in cls_scores]
+        all_level_points = self.get_points(featmap_sizes, bbox_preds[0].dtype, bbox_preds[0].device)
+        labels_3d, bbox_targets_3d, centerness_targets, attr_targets = self.get_targets(
+            all_level_points, gt_bboxes, gt_labels, gt_bboxes_3d, gt_labels_3d, centers2d, depths, attr_labels)
+        num_imgs = cls_scores[0].size(0)
+        flatten_cls_scores = torch.cat([c.permute(0, 2, 3, 1).reshape(-1, self.cls_out_channels) for c in cls_scores])
+        flatten_labels_3d = torch.cat(labels_3d)
+        flatten_bbox_targets_3d = torch.cat(bbox_targets_3d)
+        flatten_centerness_targets = torch.cat(centerness_targets)
+        flatten_points = torch.cat([p.repeat(num_imgs, 1) for p in all_level_points])
+        pos_inds = ((flatten_labels_3d >= 0) & (flatten_labels_3d < self.num_classes)).nonzero().reshape(-1)
+        num_pos = len(pos_inds)
+        loss_dict = dict()
+        loss_dict['loss_cls'] = self.loss_cls(flatten_cls_scores, flatten_labels_3d, avg_factor=num_pos + num_imgs)
+        pos_bbox_preds, pos_dir_cls_preds, pos_depth_cls_preds, pos_weights, pos_attr_preds, pos_centerness = \
+            self.get_pos_predictions(bbox_preds, dir_cls_preds, depth_cls_preds, weights, attr_preds, centernesses, pos_inds, img_metas)
+        if num_pos > 0:
+            pos_bbox_targets_3d = flatten_bbox_targets_3d[pos_inds]
+            pos_centerness_targets = flatten_centerness_targets[pos_inds]
+            pos_points = flatten_points[pos_inds]
+            if self.pred_attrs:
+                pos_attr_targets = torch.cat(attr_targets)[pos_inds]
+            if self.use_direction_classifier:
+                pos_dir_cls_targets = self.get_direction_target(pos_bbox_targets_3d, self.dir_offset, one_hot=False)
+            bbox_weights = pos_centerness_targets.new_ones(len(pos_centerness_targets), sum(self.group_reg_dims))
+            equal_weights = pos_centerness_targets.new_ones(pos_centerness_targets.shape)
+            code_weight = self.train_cfg.get('code_weight', None)
+            if code_weight:
+                assert len(code_weight) == sum(self.group_reg_dims)
+                bbox_weights = bbox_weights * bbox_weights.new_tensor(code_weight)
+            if self.diff_rad_by_sin:
+                pos_bbox_preds, pos_bbox_targets_3d = self.add_sin_difference(pos_bbox_preds, pos_bbox_targets_3d)
+            avg = equal_weights.sum()
+            lb = lambda a, b: self.loss_bbox(pos_bbox_preds[:, a:b], pos_bbox_targets_3d[:, a:b], weight=bbox_weights[:, a:b], avg_factor=avg)
+            loss_dict['loss_offset'] = lb(0, 2)
+            loss_dict['loss_size'] = lb(3, 6)
+            loss_dict['loss_rotsin'] = self.loss_bbox(pos_bbox_preds[:, 6], pos_bbox_targets_3d[:, 6], weight=bbox_weights[:, 6],
+                                                      avg_factor=avg)
+            if self.pred_velo:
+                loss_dict['loss_velo'] = lb(7, 9)
+            proj_inputs = (bbox_preds, pos_dir_cls_preds, labels_3d, bbox_targets_3d, pos_points, pos_inds, img_metas)
+            if self.use_direction_classifier:
+                loss_dict['loss_dir'] = self.loss_dir(pos_dir_cls_preds, pos_dir_cls_targets, equal_weights, avg_factor=avg)
+            loss_dict['loss_depth'] = self.loss_bbox(pos_bbox_preds[:, 2], pos_bbox_targets_3d[:, 2], weight=bbox_weights[:, 2],
+                                                     avg_factor=avg)
+            if self.use_depth_classifier:
+                prob = self.bbox_coder.decode_prob_depth(pos_depth_cls_preds, self.depth_range, self.depth_unit, self.division,
+                                                         self.num_depth_cls)
+                a = torch.sigmoid(self.fuse_lambda)
+                fused = a * pos_bbox_preds[:, 2] + (1 - a) * prob
+                if self.weight_dim != -1:
+                    loss_dict['loss_depth'] = self.loss_depth(fused, pos_bbox_targets_3d[:, 2], sigma=pos_weights[:, 0],
+                                                              weight=bbox_weights[:, 2], avg_factor=avg)
+                else:
+                    loss_dict['loss_depth'] = self.loss_depth(fused, pos_bbox_targets_3d[:, 2], weight=bbox_weights[:, 2], avg_factor=avg)
+                proj_inputs += (pos_depth_cls_preds, )
+            if self.pred_keypoints:
+                proj_bbox2d_preds, pos_decoded_bbox2d_preds, kpts_targets = self.get_proj_bbox2d(*proj_inputs, with_kpts=True)
+                ks = self.kpts_start
+                loss_dict['loss_kpts'] = self.loss_bbox(pos_bbox_preds[:, ks:ks + 16], kpts_targets, weight=bbox_weights[:, ks:ks + 16],
+                                                        avg_factor=avg)
+            if self.pred_bbox2d:
+                loss_dict['loss_bbox2d'] = self.loss_bbox2d(pos_bbox_preds[:, -4:], pos_bbox_targets_3d[:, -4:],
+                                                            weight=bbox_weights[:, -4:], avg_factor=avg)
+                if not self.pred_keypoints:
+                    proj_bbox2d_preds, pos_decoded_bbox2d_preds = self.get_proj_bbox2d(*proj_inputs)
+                loss_dict['loss_consistency'] = self.loss_consistency(proj_bbox2d_preds, pos_decoded_bbox2d_preds,
+                                                                      weight=bbox_weights[:, -4:], avg_factor=avg)
+            loss_dict['loss_centerness'] = self.loss_centerness(pos_centerness, pos_centerness_targets)
+            if self.pred_attrs:
+                loss_dict['loss_attr'] = self.loss_attr(pos_attr_preds, pos_attr_targets, pos_centerness_targets,
+                                                        avg_factor=pos_centerness_targets.sum())
+        else:       # no positive point: every branch still takes part in the graph
+            loss_dict['loss_offset'] = pos_bbox_preds[:, :2].sum()
+            loss_dict['loss_size'] = pos_bbox_preds[:, 3:6].sum()
+            loss_dict['loss_rotsin'] = pos_bbox_preds[:, 6].sum()
+            loss_dict['loss_depth'] = pos_bbox_preds[:, 2].sum()
+            if self.pred_velo:
+                loss_dict['loss_velo'] = pos_bbox_preds[:, 7:9].sum()
+            if self.pred_keypoints:
+                loss_dict['loss_kpts'] = pos_bbox_preds[:, self.kpts_start:self.kpts_start + 16].sum()
+            if self.pred_bbox2d:
+                loss_dict['loss_bbox2d'] = pos_bbox_preds[:, -4:].sum()
+                loss_dict['loss_consistency'] = pos_bbox_preds[:, -4:].sum()
+            loss_dict['loss_centerness'] = pos_centerness.sum()
+            if self.use_direction_classifier:
+                loss_dict['loss_dir'] = pos_dir_cls_preds.sum()
+            if self.use_depth_classifier:
+                a = torch.sigmoid(self.fuse_lambda)
+                fuse = a * pos_bbox_preds[:, 2].sum() + (1 - a) * pos_depth_cls_preds.sum()
+                if self.weight_dim != -1:
+                    fuse = fuse * torch.exp(-pos_weights[:, 0].sum())
+                loss_dict['loss_depth'] = fuse
+            if self.pred_attrs:
+                loss_dict['loss_attr'] = pos_attr_preds.sum()
+        return loss_dict

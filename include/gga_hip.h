@@ -629,6 +629,24 @@ int gga_dcn_col2im(const float* x, const float* offset, const float* mask, const
                    int C, int kh, int kw, int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w,
                    float* grad_x, float* grad_offset, float* grad_mask, void* stream);
 
+/* FCOS3D / PGD target assignment (FCOSMono3DHead._get_target_single, fcos_mono3d_head.py:773-956, for the
+ * whole batch in one launch). points [P,2] f32: all levels concatenated, level l = rows
+ * level_begin_host[l] .. level_begin_host[l+1] (host int32 [n_levels]; the last level ends at P) with stride
+ * strides_host[l] and regress range regress_ranges_host[2l], [2l+1]. Ground truths of all images concatenated,
+ * image b = rows gt_offsets[b] .. gt_offsets[b+1] (device int64 [batch+1]): gt_bboxes [G,4], centers2d [G,2],
+ * depths [G], gt_bboxes_3d [G,code] (yaw already made local), labels int64. Outputs [batch, P(, .)]:
+ * labels, bbox_targets (l, t, r, b), labels_3d, bbox_targets_3d (dx, dy, depth, gt[3:]), centerness
+ * exp(-alpha * |d| / (1.414 * stride * radius)), attr. Points with no admissible ground truth get the
+ * background labels and (like the reference) the regression targets of the image's first box. */
+int gga_fcos3d_targets(const float* points, int n_points, int n_levels, const int32_t* level_begin_host,
+                       const float* strides_host, const float* regress_ranges_host, float center_sample_radius,
+                       const int64_t* gt_offsets, int batch, const float* gt_bboxes, const float* centers2d,
+                       const float* depths, const float* gt_bboxes_3d, int code_size, const int64_t* gt_labels,
+                       const int64_t* gt_labels_3d, const int64_t* attr_labels, int64_t background_label,
+                       int64_t attr_background_label, float centerness_alpha, int64_t* labels, float* bbox_targets,
+                       int64_t* labels_3d, float* bbox_targets_3d, float* centerness_targets, int64_t* attr_targets,
+                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,126 @@
+"""PGDHead (configs/gga/gga_pdg.py) against a run of the reference's own
+PGDHead / FCOSMono3DHead / coders / camera boxes (tests/golden/pgd_head.npz from
+tools_dev/make_golden.py::golden_pgd): forward with shared weights, per-level targets (labels exact),
+the loss dict and the gradients w.r.t. every prediction tensor."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO
+from gga_amd.box3d import CameraInstance3DBoxes
+from gga_amd.registry import build_head
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+HEAD_CFG = dict(
+    type='PGDHead', num_classes=3, in_channels=32, stacked_convs=2, feat_channels=32, use_direction_classifier=True,
+    diff_rad_by_sin=True, pred_attrs=False, pred_velo=False, pred_bbox2d=True, pred_keypoints=True, dir_offset=0.7854,
+    strides=(4, 8, 16, 32), regress_ranges=((-1, 64), (64, 128), (128, 256), (256, 1e8)), group_reg_dims=(2, 1, 3, 1, 16, 4),
+    cls_branch=(32, ), reg_branch=((32, ), (32, ), (32, ), (32, ), (32, ), (32, )), dir_branch=(32, ),
+    attr_branch=(32, ), centerness_branch=(32, ), weight_branch=((32, ), ), bbox_code_size=7, use_onlyreg_proj=True, norm_on_bbox=True,
+    centerness_on_reg=True, center_sampling=True, conv_bias=True, dcn_on_last_conv=False, norm_cfg=None,
+    loss_cls=dict(type='FocalLoss', use_sigmoid=True, gamma=2.0, alpha=0.25, loss_weight=1.0),
+    loss_bbox=dict(type='SmoothL1Loss', beta=1.0 / 9.0, loss_weight=1.0),
+    loss_dir=dict(type='CrossEntropyLoss', use_sigmoid=False, loss_weight=1.0),
+    loss_centerness=dict(type='CrossEntropyLoss', use_sigmoid=True, loss_weight=1.0), use_depth_classifier=True,
+    depth_branch=(32, ), depth_range=(0, 70), depth_unit=10, division='uniform', depth_bins=8, weight_dim=1,
+    loss_depth=dict(type='UncertainSmoothL1Loss', alpha=1.0, beta=3.0, loss_weight=1.0),
+    bbox_coder=dict(type='PGDBBoxCoder', base_depths=((28.01, 16.32), ),
+                    base_dims=((0.8, 1.73, 0.6), (1.76, 1.73, 0.6), (3.9, 1.56, 1.6)), code_size=7),
+    train_cfg=dict(code_weight=[1.0] * 7 + [0.2] * 16 + [1.0] * 4),
+    test_cfg=dict(nms_pre=100, nms_thr=0.05, score_thr=0.001, max_per_img=20))
+
+
+@pytest.fixture(scope='module')
+def head_and_golden(golden):
+    g = golden('pgd_head')
+    head = build_head(dict(HEAD_CFG))
+    sd = {k[len('state.'):]: torch.from_numpy(g[k]) for k in g.files if k.startswith('state.')}
+    missing, unexpected = head.load_state_dict(sd, strict=True), None      # same parameter names as the reference head
+    head.to(DEV).train()
+    return head, g
+
+
+def test_state_dict_names_and_forward(head_and_golden):
+    head, g = head_and_golden
+    feats = [torch.from_numpy(g[f'fwd.feat.{i}']).to(DEV) for i in range(4)]
+    out = head(feats)
+    assert len(out) == 7
+    for name, lst in zip(('cls', 'bbox', 'dir', 'depth', 'weight', 'attr', 'cen'), out):
+        for i, t in enumerate(lst):
+            if name == 'attr':
+                assert t is None
+                continue
+            want = torch.from_numpy(g[f'fwd.{name}.{i}'])
+            got = t.detach().cpu()
+            if name == 'bbox':       # the size priors follow argmax(cls): compare sizes only where that argmax has a margin
+                top2 = torch.from_numpy(g[f'fwd.cls.{i}']).topk(2, dim=1)[0]
+                clear = ((top2[:, 0] - top2[:, 1]) > 1e-3).unsqueeze(1)
+                assert float(clear.float().mean()) > 0.5
+                keep = torch.ones_like(want, dtype=torch.bool)
+                keep[:, 3:6] = clear
+                got, want = got[keep], want[keep]
+            torch.testing.assert_close(got, want, rtol=2e-4, atol=2e-4, msg=f'{name}.{i}')
+
+
+@pytest.mark.parametrize('seed', [81, 82, 83])
+def test_targets_losses_and_gradients(head_and_golden, seed):
+    head, g = head_and_golden
+    B = 2
+    gts = [{k: torch.from_numpy(g[f'{seed}.gt.{b}.{k}']).to(DEV) for k in ('gt_bboxes', 'gt_labels', 'gt_bboxes_3d', 'gt_labels_3d',
+                                                                          'centers2d', 'depths')} for b in range(B)]
+    preds = {k: [torch.from_numpy(g[f'{seed}.pred.{k}.{i}']).to(DEV).requires_grad_(True) for i in range(4)]
+             for k in ('cls', 'bbox', 'dir', 'depth', 'weight', 'cen')}
+    img_metas = [dict(cam2img=g[f'{seed}.cam2img'].tolist(), box_type_3d=CameraInstance3DBoxes) for _ in range(B)]
+    lists = lambda k: [gt[k] for gt in gts]
+    points = head.get_points([t.shape[-2:] for t in preds['cls']], torch.float32, torch.device(DEV))
+    tg = head.get_targets(points, lists('gt_bboxes'), lists('gt_labels'), lists('gt_bboxes_3d'), lists('gt_labels_3d'),
+                          lists('centers2d'), lists('depths'), None)
+    for name, lst in zip(('labels_3d', 'bbox_targets_3d', 'centerness', 'attr'), tg):
+        for i, t in enumerate(lst):
+            want = g[f'{seed}.tg.{name}.{i}']
+            if t.dtype == torch.int64:
+                assert np.array_equal(t.cpu().numpy(), want), (name, i)         # integer work: exact
+            else:
+                np.testing.assert_allclose(t.cpu().numpy(), want, rtol=2e-6, atol=1e-6, err_msg=f'{name}.{i}')
+    # the caller's boxes are not edited (the reference turns their yaw local in place)
+    assert torch.equal(gts[0]['gt_bboxes_3d'].cpu(), torch.from_numpy(g[f'{seed}.gt.0.gt_bboxes_3d']))
+    losses = head.loss(preds['cls'], preds['bbox'], preds['dir'], preds['depth'], preds['weight'], [None] * 4, preds['cen'],
+                       lists('gt_bboxes'), lists('gt_labels'), lists('gt_bboxes_3d'), lists('gt_labels_3d'), lists('centers2d'),
+                       lists('depths'), None, img_metas)
+    want_keys = sorted(k[len(f'{seed}.loss.'):] for k in g.files if k.startswith(f'{seed}.loss.'))
+    assert sorted(losses) == want_keys
+    for k in want_keys:
+        assert float(losses[k]) == pytest.approx(float(g[f'{seed}.loss.{k}']), rel=1e-4, abs=1e-5), k
+    head.fuse_lambda.grad = None
+    sum(losses.values()).backward()
+    for k, lst in preds.items():
+        for i, t in enumerate(lst):
+            want = torch.from_numpy(g[f'{seed}.grad.{k}.{i}'])
+            got = t.grad.cpu() if t.grad is not None else torch.zeros_like(want)
+            scale = float(want.abs().max()) + 1e-12
+            assert float((got - want).abs().max()) <= 1e-4 * scale + 1e-7, (k, i)
+    assert float(head.fuse_lambda.grad) == pytest.approx(float(g[f'{seed}.grad.fuse_lambda']), rel=1e-3, abs=1e-6)
+
+
+def test_pgd_config_head_builds_with_dcn():
+    """bbox_head of configs/gga/gga_pdg.py (over configs/_base_/models/pgd.py: GN towers, DCNv2 on the last tower
+    convs) builds through the registry and runs forward + backward on the HIP DCN path."""
+    from gga_amd.dcn import ModulatedDeformConv2dPack
+    wide = lambda v: (256, ) if v == (32, ) else tuple((256, ) for _ in v) if isinstance(v, tuple) and v and isinstance(v[0], tuple) else v
+    cfg = {k: wide(v) if k.endswith('_branch') else v for k, v in HEAD_CFG.items()}
+    cfg.update(in_channels=256, feat_channels=256, dcn_on_last_conv=True)
+    cfg.pop('norm_cfg')                       # default GN(32)
+    head = build_head(cfg).to(DEV).train()
+    head.init_weights()
+    assert isinstance(head.cls_convs[-1].conv, ModulatedDeformConv2dPack) and isinstance(head.reg_convs[-1].conv, ModulatedDeformConv2dPack)
+    assert isinstance(head.cls_convs[0].gn, torch.nn.GroupNorm)
+    feats = [torch.randn(2, 256, 128 // s, 384 // s, device=DEV, requires_grad=True) for s in (4, 8, 16, 32)]
+    out = head(feats)
+    assert out[1][0].shape == (2, 27, 32, 96) and out[3][0].shape == (2, 8, 32, 96)
+    sum(t.sum() for lst in out for t in lst if t is not None).backward()
+    assert all(f.grad is not None and torch.isfinite(f.grad).all() for f in feats)
+    assert head.cls_convs[-1].conv.conv_offset.weight.grad is not None

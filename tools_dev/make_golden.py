@@ -838,6 +838,183 @@ def tests_golden_dir():
     return OUT
 
 
+PGD_HEAD_CFG = dict(      # bbox_head of configs/gga/gga_pdg.py over configs/_base_/models/pgd.py (norm-free towers, no DCN: the
+    num_classes=3, in_channels=32, stacked_convs=2, feat_channels=32, use_direction_classifier=True,       # golden is about the
+    diff_rad_by_sin=True, pred_attrs=False, pred_velo=False, pred_bbox2d=True, pred_keypoints=True,         # head logic)
+    dir_offset=0.7854, strides=(4, 8, 16, 32), regress_ranges=((-1, 64), (64, 128), (128, 256), (256, 1e8)),
+    group_reg_dims=(2, 1, 3, 1, 16, 4), cls_branch=(32, ),
+    reg_branch=((32, ), (32, ), (32, ), (32, ), (32, ), (32, )), dir_branch=(32, ), attr_branch=(32, ),
+    centerness_branch=(32, ), weight_branch=((32, ), ), bbox_code_size=7, use_onlyreg_proj=True, norm_on_bbox=True, centerness_on_reg=True,
+    center_sampling=True, conv_bias=True, dcn_on_last_conv=False, norm_cfg=None,
+    loss_cls=dict(type='FocalLoss', use_sigmoid=True, gamma=2.0, alpha=0.25, loss_weight=1.0),
+    loss_bbox=dict(type='SmoothL1Loss', beta=1.0 / 9.0, loss_weight=1.0),
+    loss_dir=dict(type='CrossEntropyLoss', use_sigmoid=False, loss_weight=1.0),
+    loss_centerness=dict(type='CrossEntropyLoss', use_sigmoid=True, loss_weight=1.0),
+    use_depth_classifier=True, depth_branch=(32, ), depth_range=(0, 70), depth_unit=10, division='uniform', depth_bins=8,
+    weight_dim=1, loss_depth=dict(type='UncertainSmoothL1Loss', alpha=1.0, beta=3.0, loss_weight=1.0),
+    bbox_coder=dict(type='PGDBBoxCoder', base_depths=((28.01, 16.32), ),
+                    base_dims=((0.8, 1.73, 0.6), (1.76, 1.73, 0.6), (3.9, 1.56, 1.6)), code_size=7),
+    train_cfg=dict(code_weight=[1.0] * 7 + [0.2] * 16 + [1.0] * 4),
+    test_cfg=dict(nms_pre=100, nms_thr=0.05, score_thr=0.001, max_per_img=20))
+PGD_IMG = (128, 384)        # H, W of the synthetic image; feature maps at strides 4 .. 32
+
+
+def make_pgd_case(seed, B=2):
+    """Seeded inputs of PGDHead.loss: ground truths (2D boxes, projected centres, depths, camera boxes, labels) and
+    per-level prediction tensors as the head's forward would hand them over (bbox_pred already decoded)."""
+    g = torch.Generator().manual_seed(seed)
+    H, W = PGD_IMG
+    cam2img = np.array([[180.0, 0, W / 2, 8.0], [0, 180.0, H / 2, -0.5], [0, 0, 1, 0.003]], np.float32)
+    gts = []
+    for b in range(B):
+        n = 0 if (seed % 2 == 1 and b == 1) else int(torch.randint(2, 6, (1, ), generator=g))
+        c2d = torch.rand(n, 2, generator=g) * torch.tensor([W - 40.0, H - 30.0]) + torch.tensor([20.0, 15.0])
+        wh = torch.rand(n, 2, generator=g) * torch.tensor([90.0, 50.0]) + torch.tensor([14.0, 12.0])
+        boxes = torch.cat([c2d - wh / 2, c2d + wh / 2], 1) + torch.randn(n, 4, generator=g) * 1.5
+        depth = torch.rand(n, generator=g) * 45 + 4
+        labels = torch.randint(0, 3, (n, ), generator=g)
+        dims = torch.tensor([[0.8, 1.73, 0.6], [1.76, 1.73, 0.6], [3.9, 1.56, 1.6]])[labels] * (0.9 + 0.2 * torch.rand(n, 3, generator=g))
+        xyz = torch.stack([(c2d[:, 0] - W / 2) * depth / 180.0, (c2d[:, 1] - H / 2) * depth / 180.0, depth], 1)
+        yaw = (torch.rand(n, 1, generator=g) * 2 - 1) * np.pi
+        gts.append(dict(gt_bboxes=boxes, gt_labels=labels, gt_bboxes_3d=torch.cat([xyz, dims, yaw], 1), gt_labels_3d=labels.clone(),
+                        centers2d=c2d, depths=depth))
+    preds = dict(cls=[], bbox=[], dir=[], depth=[], weight=[], cen=[])
+    for s in (4, 8, 16, 32):
+        h, w = H // s, W // s
+        preds['cls'].append(torch.randn(B, 3, h, w, generator=g))
+        bb = torch.randn(B, 27, h, w, generator=g) * 0.5
+        bb[:, 2] = 28.01 + bb[:, 2] * 16.32          # decoded depth
+        bb[:, 3:6] = bb[:, 3:6].exp()                  # decoded sizes
+        bb[:, 7:23] = torch.tanh(bb[:, 7:23])          # key points
+        bb[:, -4:] = torch.relu(bb[:, -4:] + 1.0)      # 2D distances
+        preds['bbox'].append(bb)
+        preds['dir'].append(torch.randn(B, 2, h, w, generator=g))
+        preds['depth'].append(torch.randn(B, 8, h, w, generator=g))
+        preds['weight'].append(torch.randn(B, 1, h, w, generator=g) * 0.3)
+        preds['cen'].append(torch.randn(B, 1, h, w, generator=g))
+    return gts, preds, cam2img
+
+
+def golden_pgd(ref):
+    """The reference's PGDHead (pgd_head.py + fcos_mono3d_head.py + anchor_free_mono3d_head.py, with its own
+    PGDBBoxCoder / FCOS3DBBoxCoder, CameraInstance3DBoxes, points_img2cam / points_cam2img) on seeded inputs: targets of every
+    level, the loss dict, the gradients w.r.t. every prediction tensor, and one forward pass with shared weights.
+    mmdet's FocalLoss / SmoothL1Loss / CrossEntropyLoss / GIoULoss are absent (third-party): this repo's restatements are
+    plugged in (gga_amd/losses.py), so those four formulas are not independent evidence; UncertainSmoothL1Loss is."""
+    from gga_amd import losses as ML
+    su = ref['su']
+    pl = import_reference_pipeline(ref)
+    cb = sys.modules['mmdet3d.core.bbox']
+    cam = sys.modules.get('mmdet3d.core.bbox.structures.cam_box3d') or load('mmdet3d.core.bbox.structures.cam_box3d',
+                                                                            'mmdet3d/core/bbox/structures/cam_box3d.py')
+    cb.points_cam2img, cb.points_img2cam = su.points_cam2img, su.points_img2cam
+    core = sys.modules['mmdet3d.core']
+    core.box3d_multiclass_nms, core.limit_period, core.points_img2cam, core.xywhr2xyxyr = None, su.limit_period, su.points_img2cam, su.xywhr2xyxyr
+    sys.modules['mmdet3d.core.bbox.structures'].limit_period = su.limit_period
+
+    class Scale(nn.Module):
+        def __init__(self, scale=1.0):
+            super().__init__()
+            self.scale = nn.Parameter(torch.tensor(scale, dtype=torch.float))
+
+        def forward(self, x):
+            return x * self.scale
+
+    def normal_init(module, mean=0, std=1, bias=0):
+        nn.init.normal_(module.weight, mean, std)
+        if getattr(module, 'bias', None) is not None:
+            nn.init.constant_(module.bias, bias)
+    mc = sys.modules['mmcv.cnn']
+    mc.Scale, mc.normal_init, mc.bias_init_with_prob = Scale, normal_init, lambda p: float(-np.log((1 - p) / p))
+    md = sys.modules['mmdet.core']
+    md.distance2bbox = lambda points, distance: torch.stack([points[..., 0] - distance[..., 0], points[..., 1] - distance[..., 1],
+                                                             points[..., 0] + distance[..., 2], points[..., 1] + distance[..., 3]], -1)
+    _mod('mmdet.core.bbox', BaseBBoxCoder=object)
+    _mod('mmdet.core.bbox.builder', BBOX_CODERS=_Reg())
+    _mod('mmdet3d.core.bbox.coders')
+    load('mmdet3d.core.bbox.coders.fcos3d_bbox_coder', 'mmdet3d/core/bbox/coders/fcos3d_bbox_coder.py')
+    pc = load('mmdet3d.core.bbox.coders.pgd_bbox_coder', 'mmdet3d/core/bbox/coders/pgd_bbox_coder.py')
+    sys.modules['mmdet.core.bbox.builder'].build_bbox_coder = lambda cfg: pc.PGDBBoxCoder(**{k: v for k, v in cfg.items() if k != 'type'})
+    _mod('mmdet.models'); _mod('mmdet.models.losses'); _mod('mmdet.models.losses.utils', weighted_loss=None)
+    loss_types = dict(FocalLoss=ML.FocalLoss, SmoothL1Loss=ML.SmoothL1Loss, CrossEntropyLoss=ML.CrossEntropyLoss, GIoULoss=ML.GIoULoss)
+
+    def weighted_loss(fn):      # mmdet.models.losses.utils.weighted_loss (restated)
+        def wrapper(pred, target, weight=None, reduction='mean', avg_factor=None, **kwargs):
+            return ML.weight_reduce_loss(fn(pred, target, **kwargs), weight, reduction, avg_factor)
+        return wrapper
+    sys.modules['mmdet.models.losses.utils'].weighted_loss = weighted_loss
+    sys.modules['mmdet3d.models.builder'].LOSSES = _Reg()
+    ul = load('mmdet3d.models.losses.uncertain_smooth_l1_loss', 'mmdet3d/models/losses/uncertain_smooth_l1_loss.py')
+    loss_types['UncertainSmoothL1Loss'] = ul.UncertainSmoothL1Loss
+    sys.modules['mmdet3d.models.builder'].build_loss = lambda cfg: loss_types[cfg['type']](**{k: v for k, v in cfg.items() if k != 'type'})
+    class BaseModule(nn.Module):        # mmcv.runner.BaseModule: nn.Module that swallows init_cfg
+        def __init__(self, init_cfg=None):
+            super().__init__()
+    sys.modules['mmcv.runner'].BaseModule = BaseModule
+    load('mmdet3d.models.dense_heads.base_mono3d_dense_head', 'mmdet3d/models/dense_heads/base_mono3d_dense_head.py')
+    load('mmdet3d.models.dense_heads.anchor_free_mono3d_head', 'mmdet3d/models/dense_heads/anchor_free_mono3d_head.py')
+    load('mmdet3d.models.dense_heads.fcos_mono3d_head', 'mmdet3d/models/dense_heads/fcos_mono3d_head.py')
+    pg = load('mmdet3d.models.dense_heads.pgd_head', 'mmdet3d/models/dense_heads/pgd_head.py')
+    torch.manual_seed(0)
+    head = pg.PGDHead(**PGD_HEAD_CFG)
+    head.init_weights()
+    head.train()
+    out = {}
+    with torch.no_grad():           # class scores with real margins (the size priors follow their argmax)
+        head.conv_cls.weight.normal_(0, 0.5)
+    with torch.no_grad():           # move the learnable scales / fusion weight off their trivial initial values
+        for lv in head.scales:
+            for sc in lv:
+                sc.scale.add_(torch.randn(()) * 0.1)
+        head.fuse_lambda.fill_(0.3)
+    for k, v in head.state_dict().items():
+        out['state.' + k] = v.numpy()
+    # forward with shared weights
+    feats = [torch.randn(2, 32, PGD_IMG[0] // s, PGD_IMG[1] // s) * 0.5 for s in (4, 8, 16, 32)]
+    fo = head(feats)
+    for i, f in enumerate(feats):
+        out[f'fwd.feat.{i}'] = f.numpy()
+    for name, lst in zip(('cls', 'bbox', 'dir', 'depth', 'weight', 'attr', 'cen'), fo):
+        for i, t in enumerate(lst):
+            if t is not None:
+                out[f'fwd.{name}.{i}'] = t.detach().numpy()
+    for seed in (81, 82, 83):
+        gts, preds, cam2img = make_pgd_case(seed)
+        for b, gt in enumerate(gts):
+            for k, v in gt.items():
+                out[f'{seed}.gt.{b}.{k}'] = v.numpy()
+        out[f'{seed}.cam2img'] = cam2img
+        img_metas = [dict(cam2img=cam2img.tolist(), box_type_3d=cam.CameraInstance3DBoxes) for _ in gts]
+        leaves = {k: [t.clone().requires_grad_(True) for t in v] for k, v in preds.items()}
+        for k, v in preds.items():
+            for i, t in enumerate(v):
+                out[f'{seed}.pred.{k}.{i}'] = t.numpy()
+        args = (leaves['cls'], leaves['bbox'], leaves['dir'], leaves['depth'], leaves['weight'], [None] * 4, leaves['cen'],
+                [g['gt_bboxes'] for g in gts], [g['gt_labels'] for g in gts], [g['gt_bboxes_3d'].clone() for g in gts],
+                [g['gt_labels_3d'] for g in gts], [g['centers2d'] for g in gts], [g['depths'] for g in gts], None, img_metas)
+        sizes = [t.shape[-2:] for t in leaves['cls']]
+        points = head.get_points(sizes, torch.float32, torch.device('cpu'))
+        tg = head.get_targets(points, [g['gt_bboxes'] for g in gts], [g['gt_labels'] for g in gts],
+                              [g['gt_bboxes_3d'].clone() for g in gts], [g['gt_labels_3d'] for g in gts],
+                              [g['centers2d'] for g in gts], [g['depths'] for g in gts], None)
+        for name, lst in zip(('labels_3d', 'bbox_targets_3d', 'centerness', 'attr'), tg):
+            for i, t in enumerate(lst):
+                out[f'{seed}.tg.{name}.{i}'] = t.numpy()
+        losses = head.loss(*args)
+        total = sum(losses.values())
+        total.backward()
+        for k, v in losses.items():
+            out[f'{seed}.loss.{k}'] = v.detach().numpy()
+        for k, v in leaves.items():
+            for i, t in enumerate(v):
+                out[f'{seed}.grad.{k}.{i}'] = t.grad.numpy() if t.grad is not None else np.zeros_like(t.detach().numpy())
+        out[f'{seed}.grad.fuse_lambda'] = head.fuse_lambda.grad.numpy().copy()
+        head.fuse_lambda.grad = None
+        n_pos = int(sum(int(((t >= 0) & (t < 3)).sum()) for t in tg[0]))
+        print(f'  pgd[{seed}]: {n_pos} positive points, ' + ', '.join(f'{k}={float(v):.4f}' for k, v in losses.items()))
+    np.savez_compressed(os.path.join(OUT, 'pgd_head.npz'), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = import_reference()
@@ -853,6 +1030,7 @@ def main():
     golden_label_gen(ref)
     golden_rga(ref)
     golden_gt_database(ref)
+    golden_pgd(ref)
     for f in sorted(os.listdir(OUT)):
         print(f'{f}: {os.path.getsize(os.path.join(OUT, f)) / 1024:.1f} KiB')
 

@@ -41,14 +41,52 @@ class CyclicSchedule:
         return self.base * self.phases[-1][3]
 
 
+class StepSchedule:
+    """mmcv StepLrUpdaterHook with linear warm-up, by iteration (configs/gga/gga_pdg.py: epochs
+    ``step=[32, 44]``, ``warmup_iters=500``, ``warmup_ratio=1/3``): lr = base * gamma^(#steps passed),
+    and during warm-up lr * (1 - (1 - it / warmup_iters) * (1 - warmup_ratio))."""
+
+    def __init__(self, base, step, iters_per_epoch=1, gamma=0.1, warmup=None, warmup_iters=0, warmup_ratio=0.1):
+        self.base, self.gamma = base, gamma
+        self.step = sorted(int(s) * int(iters_per_epoch) for s in ([step] if isinstance(step, int) else step))
+        assert warmup in (None, 'linear'), 'only linear warm-up is used by configs/gga'
+        self.warmup_iters, self.warmup_ratio = (warmup_iters if warmup else 0), warmup_ratio
+
+    def __call__(self, it):
+        lr = self.base * self.gamma ** sum(it >= s for s in self.step)
+        if it < self.warmup_iters:
+            lr *= 1 - (1 - it / self.warmup_iters) * (1 - self.warmup_ratio)
+        return lr
+
+
 def build_optimizer(model, cfg):
+    """AdamW (configs/gga/gga_kitti_config.py:233) or SGD with mmcv's ``paramwise_cfg`` bias multipliers
+    (configs/gga/gga_pdg.py: ``bias_lr_mult=2, bias_decay_mult=0`` - DefaultOptimizerConstructor applies them
+    to every parameter named ``bias``)."""
     cfg = dict(cfg)
     typ = cfg.pop('type')
-    if typ != 'AdamW':
-        raise KeyError(f'optimizer {typ} is not on the GGA path (configs/gga use AdamW)')
-    params = [p for p in model.parameters() if p.requires_grad]
-    fused = all(p.is_cuda for p in params)
-    return torch.optim.AdamW(params, fused=fused, **cfg)
+    pw = cfg.pop('paramwise_cfg', None) or {}
+    named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+    if pw:
+        unknown = set(pw) - {'bias_lr_mult', 'bias_decay_mult'}
+        if unknown:
+            raise KeyError(f'paramwise_cfg keys {sorted(unknown)} are not used by configs/gga')
+        groups = []
+        for n, p in named:
+            g = dict(params=[p])
+            if n.endswith('.bias') or n == 'bias':
+                g['lr'] = cfg['lr'] * pw.get('bias_lr_mult', 1.0)
+                if 'weight_decay' in cfg:
+                    g['weight_decay'] = cfg['weight_decay'] * pw.get('bias_decay_mult', 1.0)
+            groups.append(g)
+        params = groups
+    else:
+        params = [p for _, p in named]
+    if typ == 'AdamW':
+        return torch.optim.AdamW(params, fused=all(p.is_cuda for _, p in named), **cfg)
+    if typ == 'SGD':
+        return torch.optim.SGD(params, **cfg)
+    raise KeyError(f'optimizer {typ} is not used by configs/gga (AdamW, SGD)')
 
 
 def init_dist():
@@ -86,7 +124,7 @@ class Runner:
     queued, so those reads wait for a handful of small kernels instead of draining the main
     stream's queue; without ``next_data`` they happen in line."""
 
-    def __init__(self, model, cfg, max_iters, distributed=False, device=None):
+    def __init__(self, model, cfg, max_iters, distributed=False, device=None, iters_per_epoch=None):
         self.raw_model = model
         self.device = device or next(model.parameters()).device
         self.model = build_ddp(model, self.device, cfg.get('find_unused_parameters', False)) if distributed else model
@@ -94,12 +132,16 @@ class Runner:
         gc = (cfg.get('optimizer_config') or {}).get('grad_clip')
         self.grad_clip = dict(gc) if gc else None
         base_lr = cfg.optimizer['lr']
-        base_m = cfg.optimizer['betas'][0]
+        base_m = cfg.optimizer['betas'][0] if 'betas' in cfg.optimizer else None
         lrc, mc = dict(cfg.get('lr_config') or {}), dict(cfg.get('momentum_config') or {})
         self.lr_sched = self.mom_sched = None
         if lrc.get('policy') == 'cyclic':
             self.lr_sched = CyclicSchedule(base_lr, max_iters, lrc.get('target_ratio', (10, 1e-4)),
                                            lrc.get('cyclic_times', 1), lrc.get('step_ratio_up', 0.4))
+        elif lrc.get('policy') == 'step':
+            self.lr_sched = StepSchedule(1.0, lrc['step'], iters_per_epoch or 1, lrc.get('gamma', 0.1), lrc.get('warmup'),
+                                         lrc.get('warmup_iters', 0), lrc.get('warmup_ratio', 0.1))
+            self._base_lrs = None       # per-group base rates (paramwise multipliers), scaled by the schedule
         if mc.get('policy') == 'cyclic':
             self.mom_sched = CyclicSchedule(base_m, max_iters, mc.get('target_ratio', (0.85 / 0.95, 1)),
                                             mc.get('cyclic_times', 1), mc.get('step_ratio_up', 0.4))
@@ -140,8 +182,12 @@ class Runner:
             prep, ev = hit
             torch.cuda.current_stream(self.device).wait_event(ev)
             data = dict(data, points=prep)
-        for g in self.optimizer.param_groups:
-            if self.lr_sched is not None:
+        if isinstance(self.lr_sched, StepSchedule) and self._base_lrs is None:
+            self._base_lrs = [g['lr'] for g in self.optimizer.param_groups]
+        for gi, g in enumerate(self.optimizer.param_groups):
+            if isinstance(self.lr_sched, StepSchedule):
+                g['lr'] = self._base_lrs[gi] * self.lr_sched(self.iter)
+            elif self.lr_sched is not None:
                 g['lr'] = self.lr_sched(self.iter)
             if self.mom_sched is not None:
                 g['betas'] = (self.mom_sched(self.iter), g['betas'][1])

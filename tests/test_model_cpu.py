@@ -185,3 +185,41 @@ def test_sparse_conv_loads_spconv2_checkpoint_layout():
     # a genuinely wrong shape still fails loudly
     with pytest.raises(RuntimeError, match='size mismatch'):
         SubMConv3d(16, 32, 3, bias=False).load_state_dict({'weight': torch.zeros(3, 3, 3, 16, 8)})
+
+
+def test_pgd_config_equals_reference_and_builds():
+    """configs/gga/gga_pdg.py (the `_base_` chain merged by hand) resolves to the same model / optimizer /
+    schedule sections as the reference's file, and builds through the registries: FCOSMono3D = ResNet-101
+    (caffe style) + FPN + PGDHead with DCNv2 on the last tower convolutions."""
+    ref_path = '/root/reference/configs/gga/gga_pdg.py'
+    mine = Config.fromfile(os.path.join(REPO, 'configs', 'gga', 'gga_pdg.py'))
+    if os.path.exists(ref_path):
+        ref = Config.fromfile(ref_path)
+        plain = lambda v: {k: plain(x) for k, x in v.items()} if isinstance(v, dict) else \
+            [plain(x) for x in v] if isinstance(v, (list, tuple)) else v
+        for key in ('model', 'optimizer', 'optimizer_config', 'lr_config', 'total_epochs', 'runner', 'evaluation',
+                    'checkpoint_config'):
+            assert plain(mine[key]) == plain(ref[key]), key
+        assert mine.data['samples_per_gpu'] == ref.data['samples_per_gpu'] == 12
+        assert plain(mine.data['train']['ann_file']) == plain(ref.data['train']['ann_file'])
+    model = build_model(mine.model)
+    from gga_amd.dcn import ModulatedDeformConv2dPack
+    from gga_amd.mono3d_detectors import FCOSMono3D
+    assert isinstance(model, FCOSMono3D)
+    assert isinstance(model.bbox_head.cls_convs[-1].conv, ModulatedDeformConv2dPack)
+    names = set(dict(model.named_parameters()))
+    for n in ('backbone.layer3.22.conv3.weight', 'backbone.layer1.0.downsample.0.weight', 'neck.lateral_convs.3.conv.weight',
+              'neck.fpn_convs.0.conv.bias', 'bbox_head.cls_convs.1.conv.conv_offset.weight', 'bbox_head.conv_regs.4.weight',
+              'bbox_head.scales.3.4.scale', 'bbox_head.fuse_lambda', 'bbox_head.conv_weights.0.bias'):
+        assert n in names, n
+    # frozen BatchNorm statistics (norm_eval) and frozen stem (frozen_stages=0)
+    model.train()
+    assert not model.backbone.bn1.training and not model.backbone.conv1.weight.requires_grad
+    assert not model.backbone.layer2[0].bn2.weight.requires_grad and model.backbone.layer2[0].conv2.weight.requires_grad
+    from gga_amd.train import StepSchedule, build_optimizer
+    opt = build_optimizer(model, mine.optimizer)
+    by_lr = {round(g['lr'], 6) for g in opt.param_groups}
+    assert by_lr == {0.001, 0.002} and all(g['weight_decay'] == 0 for g in opt.param_groups if g['lr'] == 0.002)
+    s = StepSchedule(1.0, [32, 44], iters_per_epoch=100, warmup='linear', warmup_iters=500, warmup_ratio=1 / 3)
+    assert s(0) == pytest.approx(1 / 3) and s(250) == pytest.approx(2 / 3) and s(500) == 1.0
+    assert s(3199) == 1.0 and s(3200) == pytest.approx(0.1) and s(4400) == pytest.approx(0.01)

@@ -10,8 +10,11 @@ from gga_amd.train import Runner
 import bench
 
 dev = torch.device('cuda:0')
-cfg = Config.fromfile(os.path.join(bench.REPO, 'configs', 'gga', 'gga_kitti_pointpillars_config.py'))
-cfg.model.pts_middle_encoder['channels_last'] = True
+SECOND = len(sys.argv) > 1 and sys.argv[1] == 'second'
+cfg = Config.fromfile(bench.SECOND_CONFIG if SECOND else bench.PP_CONFIG)
+if not SECOND:
+    cfg.model.pts_middle_encoder['channels_last'] = True
+BS = 8 if SECOND else 16
 torch.manual_seed(0)
 model = to_channels_last(build_model(cfg.model).to(dev))
 bench.damp_head_init(model, 0.01)
@@ -20,7 +23,7 @@ runner = Runner(model, cfg, max_iters=1000, distributed=False, device=dev)
 pc_range = tuple(cfg.model.pts_voxel_layer.point_cloud_range)
 batches = []
 for i in range(2):
-    b = synthetic.make_batch(16, start=i * 16, rank=0, pc_range=pc_range)
+    b = synthetic.make_batch(BS, start=i * BS, rank=0, pc_range=pc_range)
     b['points'] = [p.to(dev) for p in b['points']]
     batches.append({k: b[k] for k in synthetic.BATCH_KEYS + ('img_metas',)})
 for i in range(3):
@@ -31,14 +34,14 @@ ts = []
 for i in range(6):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    runner.step(batches[i % 2])
+    runner.step(batches[i % 2], next_data=batches[(i + 1) % 2])
     ts.append(time.perf_counter() - t0)
     torch.cuda.synchronize()
 print('host ms per step (launch side only):', [round(t * 1e3, 1) for t in ts])
 pr = cProfile.Profile()
 pr.enable()
 for i in range(4):
-    runner.step(batches[i % 2])
+    runner.step(batches[i % 2], next_data=batches[(i + 1) % 2])
 pr.disable()
 torch.cuda.synchronize()
-pstats.Stats(pr).sort_stats('cumulative').print_stats(35)
+pstats.Stats(pr).sort_stats('cumulative').print_stats(45)

@@ -73,7 +73,7 @@ def conv_ref_pairs(conv, feats, coors, batch, shape):
         cand = []
         for (a, b, d) in offs:      # output o reads input o*s - p + k: every input proposes its outputs
             num = torch.stack([c[:, 1] + p3[0] - a, c[:, 2] + p3[1] - b, c[:, 3] + p3[2] - d], 1)
-            ok = torch.ones(len(c), dtype=torch.bool)
+            ok = torch.ones(len(c), dtype=torch.bool, device=c.device)
             for i in range(3):
                 ok &= (num[:, i] % s3[i] == 0) & (num[:, i] >= 0) & (num[:, i] // s3[i] < oshape[i])
             o = torch.stack([c[ok, 0]] + [num[ok, i] // s3[i] for i in range(3)], 1)

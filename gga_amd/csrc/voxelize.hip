@@ -9,13 +9,11 @@
 //               per slot: 64-bit atomicMin of (round, point index) and a counter.
 //               After K1, the low word of `cur[slot]` is the voxel's FIRST point.
 //   K2 flag     rank[i] = 0 if i is its voxel's first point, -1 otherwise.
-//   K3 assign   one 1024-thread workgroup per frame:
-//               (a) ordered exclusive scan of the "is first" flags = voxel id in
-//                   first-come order; ids >= max_voxels are dropped;
-//               (b) rank rounds: in round r every still-unranked point of a kept voxel
-//                   does atomicMin(cur[slot], (R-r, i)); the smallest index wins rank r.
-//                   Rounds stop at max_points or when no point is left. The round is
-//                   folded into the high word so no reset pass is needed.
+//   K3 assign   (a) ordered exclusive scan of the "is first" flags = voxel id in
+//                   first-come order (two-level: per-block counts, then block prefix +
+//                   ballot scan); ids >= max_voxels are dropped;
+//               (b) slot of a point inside its voxel = number of the voxel's points with a
+//                   smaller index, counted over the voxel's bucket (K3c / K3d below).
 //   K4 write    one thread per point: copy the point to voxels[vid, rank], the rank-0
 //               point also writes coors / num_points.
 //
@@ -113,88 +111,112 @@ __global__ __launch_bounds__(256) void vox_flag_kernel(FrameOffsets fo, VoxWorks
     ws.rank[gi] = ((uint32_t)ws.cur[h] == (uint32_t)i) ? 0 : -1;
 }
 
-__global__ __launch_bounds__(1024) void vox_assign_kernel(FrameOffsets fo, VoxGeom g, VoxWorkspace ws,
-                                                         int32_t* __restrict__ voxel_num) {
-    const int b = blockIdx.x;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int base = fo.off[b];
-    const int n = fo.n(b);
+// K3, fully parallel (was: one 1024-thread workgroup per frame doing the ordered scan chunk by chunk and
+// up to max_points - 1 rounds of global atomicMin: 240 us on 16 of 256 CUs at 16 frames x 20 k points).
+//   K3a count    per (frame, 1024-point block): number of first-point flags.
+//   K3b assign   same grid: block prefix (sum of the earlier blocks' counts: <= a few dozen values) + ballot scan
+//                = voxel id in first-come order; kept voxels also get a region of count[h] entries of the
+//                frame's bucket array (atomic cursor: any layout will do).
+//   K3c fill     every point of a kept voxel drops its index into the voxel's region (unordered).
+//   K3d rank     rank of a point = number of smaller indices in its voxel's region, stopping at max_points -
+//                O(points per voxel) per point, no rounds, no order dependence.
+// `cur[h]` is free after K2 and is reused as (region start, fill counter).
+struct BlkOffsets { int32_t off[GGA_MAX_BATCH + 1]; };      // first 1024-point block of every frame (kernel argument, by value)
+
+__global__ __launch_bounds__(1024) void vox_count_kernel(FrameOffsets fo, VoxWorkspace ws, BlkOffsets bo,
+                                                        int32_t* __restrict__ blk_cnt) {
+    const int32_t* blk_off = bo.off;
+    const int b = blockIdx.y;
+    if ((int)blockIdx.x >= blk_off[b + 1] - blk_off[b]) return;
+    const int n = fo.n(b), i = blockIdx.x * 1024 + threadIdx.x;
+    const bool flag = (i < n) && (ws.rank[fo.off[b] + i] == 0);
     __shared__ int wave_tot[16];
-    __shared__ int running;
-    __shared__ int act_cnt[2];
-    if (tid == 0) { running = 0; act_cnt[0] = 0; act_cnt[1] = 0; }
+    const unsigned long long bal = __ballot(flag);
+    if ((threadIdx.x & 63) == 0) wave_tot[threadIdx.x >> 6] = __popcll(bal);
     __syncthreads();
-
-    // (a) ordered scan of "first point" flags -> voxel ids in first-come order
-    for (int c0 = 0; c0 < n; c0 += 1024) {
-        const int i = c0 + tid;
-        const bool flag = (i < n) && (ws.rank[base + i] == 0);
-        const unsigned long long bal = __ballot(flag);
-        const int pre = __popcll(bal & ((1ull << lane) - 1ull));
-        if (lane == 0) wave_tot[wave] = __popcll(bal);
-        __syncthreads();
-        int wpre = 0, tot = 0;
+    if (threadIdx.x == 0) {
+        int t = 0;
 #pragma unroll
-        for (int w = 0; w < 16; ++w) {
-            const int t = wave_tot[w];
-            wpre += (w < wave) ? t : 0;
-            tot += t;
-        }
-        const int v = running + wpre + pre;
-        if (flag) {
-            const int32_t h = ws.slot[base + i];
-            if (v < g.max_voxels) {
-                ws.vid[h] = v;
-            } else {
-                ws.vid[h] = -1;           // voxel beyond max_voxels: dropped with all its points
-                ws.rank[base + i] = -1;
-            }
-        }
-        __syncthreads();
-        if (tid == 0) running += tot;
-        __syncthreads();
+        for (int w = 0; w < 16; ++w) t += wave_tot[w];
+        blk_cnt[blk_off[b] + blockIdx.x] = t;
     }
-    if (tid == 0) voxel_num[b] = running < g.max_voxels ? running : g.max_voxels;
-    __threadfence();
-    __syncthreads();
+}
 
-    // (b) rank rounds over the non-first points of kept voxels
-    if (g.max_points > 1) {
-        for (int i = tid; i < n; i += 1024) {
-            if (ws.rank[base + i] == -1) {
-                const int32_t h = ws.slot[base + i];
-                const int32_t v = __hip_atomic_load(&ws.vid[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (v >= 0) ws.act0[base + atomicAdd(&act_cnt[0], 1)] = i;
-            }
-        }
+__global__ __launch_bounds__(1024) void vox_assign_kernel(FrameOffsets fo, VoxGeom g, VoxWorkspace ws,
+                                                         BlkOffsets bo,
+                                                         const int32_t* __restrict__ blk_cnt, int32_t* __restrict__ cursor,
+                                                         int32_t* __restrict__ voxel_num) {
+    const int32_t* blk_off = bo.off;
+    const int b = blockIdx.y;
+    const int nblk = blk_off[b + 1] - blk_off[b];
+    if ((int)blockIdx.x >= nblk) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int base = fo.off[b], n = fo.n(b);
+    __shared__ int wave_tot[16];
+    __shared__ int running_s;
+    if (wave == 0) {                                   // sum of the earlier blocks' counts
+        int s = 0;
+        for (int x = lane; x < (int)blockIdx.x; x += 64) s += blk_cnt[blk_off[b] + x];
+        s = wave_sum(s);
+        if (lane == 0) running_s = s;
     }
+    const int i = blockIdx.x * 1024 + tid;
+    const bool flag = (i < n) && (ws.rank[base + i] == 0);
+    const unsigned long long bal = __ballot(flag);
+    const int pre = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_tot[wave] = __popcll(bal);
     __syncthreads();
-    int32_t* act_in = ws.act0 + base;
-    int32_t* act_out = ws.act1 + base;
-    int which = 0;
-    for (int r = 1; r < g.max_points; ++r) {
-        const int na = act_cnt[which];
-        if (na == 0) break;
-        const unsigned long long hi = (unsigned long long)(VOX_ROUND_HI - (uint32_t)r) << 32;
-        for (int j = tid; j < na; j += 1024) {
-            const int i = act_in[j];
-            atomicMin(&ws.cur[ws.slot[base + i]], hi | (uint32_t)i);
-        }
-        if (tid == 0) act_cnt[which ^ 1] = 0;
-        __threadfence();
-        __syncthreads();
-        for (int j = tid; j < na; j += 1024) {
-            const int i = act_in[j];
-            const unsigned long long w = __hip_atomic_load(&ws.cur[ws.slot[base + i]], __ATOMIC_RELAXED,
-                                                           __HIP_MEMORY_SCOPE_AGENT);
-            if ((uint32_t)w == (uint32_t)i) ws.rank[base + i] = r;
-            else act_out[atomicAdd(&act_cnt[which ^ 1], 1)] = i;
-        }
-        __threadfence();
-        __syncthreads();
-        int32_t* t = act_in; act_in = act_out; act_out = t;
-        which ^= 1;
+    int wpre = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        const int t = wave_tot[w];
+        wpre += (w < wave) ? t : 0;
+        tot += t;
     }
+    const int v = running_s + wpre + pre;
+    if (flag) {
+        const int32_t h = ws.slot[base + i];
+        if (v < g.max_voxels) {
+            ws.vid[h] = v;
+            const int c = ws.count[h];
+            const int region = (g.max_points > 1 && c > 1) ? atomicAdd(&cursor[b], c) : 0;
+            ws.cur[h] = (unsigned long long)(uint32_t)region;        // (region start, fill = 0)
+        } else {
+            ws.vid[h] = -1;               // voxel beyond max_voxels: dropped with all its points
+            ws.rank[base + i] = -1;
+        }
+    }
+    if ((int)blockIdx.x == nblk - 1 && tid == 0) {
+        const int total = running_s + tot;
+        voxel_num[b] = total < g.max_voxels ? total : g.max_voxels;
+    }
+}
+
+__global__ __launch_bounds__(256) void vox_fill_kernel(FrameOffsets fo, VoxWorkspace ws) {
+    const int b = blockIdx.y;
+    const int n = fo.n(b), i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int64_t gi = (int64_t)fo.off[b] + i;
+    const int32_t h = ws.slot[gi];
+    if (h < 0 || ws.vid[h] < 0 || ws.count[h] <= 1) return;
+    int32_t* rf = reinterpret_cast<int32_t*>(&ws.cur[h]);
+    const int pos = rf[0] + atomicAdd(&rf[1], 1);
+    ws.act0[fo.off[b] + pos] = i;
+}
+
+__global__ __launch_bounds__(256) void vox_rank_kernel(FrameOffsets fo, VoxGeom g, VoxWorkspace ws) {
+    const int b = blockIdx.y;
+    const int n = fo.n(b), i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int64_t gi = (int64_t)fo.off[b] + i;
+    if (ws.rank[gi] != -1) return;                      // first points (0) and out-of-range points (-2) are settled
+    const int32_t h = ws.slot[gi];
+    if (ws.vid[h] < 0) return;                          // dropped voxel
+    const int c = ws.count[h];
+    const int32_t* bucket = ws.act0 + fo.off[b] + reinterpret_cast<const int32_t*>(&ws.cur[h])[0];
+    int r = 0;
+    for (int j = 0; j < c && r < g.max_points; ++j) r += bucket[j] < i;
+    if (r < g.max_points) ws.rank[gi] = r;
 }
 
 __global__ __launch_bounds__(256) void vox_write_kernel(const float* __restrict__ points, int ndim,
@@ -247,10 +269,10 @@ extern "C" void gga_voxel_grid_size(const gga_voxel_params* prm, int32_t grid_xy
 }
 
 extern "C" size_t gga_hard_voxelize_workspace_bytes(int batch, int64_t total_points) {
-    (void)batch;
     const uint64_t cap = vox_cap(total_points);
     size_t bytes = cap * (8 + 8 + 4 + 4);
     bytes += gga_align_up((size_t)total_points * 4, 256) * 4;
+    bytes += gga_align_up(((size_t)total_points / 1024 + 3 * (size_t)batch + 16) * 4, 256);     // block offsets / counts, cursors
     return bytes + 1024;
 }
 
@@ -324,8 +346,20 @@ static int hard_voxelize_impl(const float* points, int ndim, const int64_t* offs
     ws.slot = (int32_t*)w; w += per;
     ws.rank = (int32_t*)w; w += per;
     ws.act0 = (int32_t*)w; w += per;
-    ws.act1 = (int32_t*)w;
+    ws.act1 = (int32_t*)w; w += per;
     ws.cap_mask = (uint32_t)(cap - 1);
+    // small tables: per-frame block offsets [batch + 1] (host -> kernel argument copy), block counts, cursors [batch]
+    int32_t* small = (int32_t*)w;
+    BlkOffsets bo;
+    bo.off[0] = 0;
+    int max_blk = 0;
+    for (int b = 0; b < batch; ++b) {
+        const int nb = (fo.off[b + 1] - fo.off[b] + 1023) / 1024;
+        bo.off[b + 1] = bo.off[b] + nb;
+        max_blk = nb > max_blk ? nb : max_blk;
+    }
+    int32_t* cursor = small;                      // [batch]
+    int32_t* blk_cnt = cursor + batch;            // [sum of blocks]
 
     const size_t cap_rows = (size_t)batch * prm->max_voxels;
     GGA_CHECK_HIP(hipMemsetAsync(ws.cur, 0xFF, cap * 16, stream), "voxelize memset(hash)");
@@ -343,8 +377,19 @@ static int hard_voxelize_impl(const float* points, int ndim, const int64_t* offs
     GGA_CHECK_LAUNCH("vox_insert_kernel");
     hipLaunchKernelGGL(vox_flag_kernel, grid, dim3(256), 0, stream, fo, ws);
     GGA_CHECK_LAUNCH("vox_flag_kernel");
-    hipLaunchKernelGGL(vox_assign_kernel, dim3(batch), dim3(1024), 0, stream, fo, g, ws, voxel_num);
+    GGA_CHECK_HIP(hipMemsetAsync(cursor, 0, batch * sizeof(int32_t), stream), "voxelize memset(cursor)");
+    GGA_CHECK_HIP(hipMemsetAsync(voxel_num, 0, (batch + 1) * sizeof(int32_t), stream), "voxelize memset(voxel_num)");     // frames without a block
+    const dim3 bgrid(max_blk, batch);
+    hipLaunchKernelGGL(vox_count_kernel, bgrid, dim3(1024), 0, stream, fo, ws, bo, blk_cnt);
+    GGA_CHECK_LAUNCH("vox_count_kernel");
+    hipLaunchKernelGGL(vox_assign_kernel, bgrid, dim3(1024), 0, stream, fo, g, ws, bo, blk_cnt, cursor, voxel_num);
     GGA_CHECK_LAUNCH("vox_assign_kernel");
+    if (g.max_points > 1) {
+        hipLaunchKernelGGL(vox_fill_kernel, grid, dim3(256), 0, stream, fo, ws);
+        GGA_CHECK_LAUNCH("vox_fill_kernel");
+        hipLaunchKernelGGL(vox_rank_kernel, grid, dim3(256), 0, stream, fo, g, ws);
+        GGA_CHECK_LAUNCH("vox_rank_kernel");
+    }
     hipLaunchKernelGGL(vox_write_kernel, grid, dim3(256), 0, stream, points, ndim, fo, batch, g, ws, voxel_num,
                        voxel_num + batch, voxels, coors, num_points);
     GGA_CHECK_LAUNCH("vox_write_kernel");

@@ -201,6 +201,8 @@ def voxel_mean(voxels, num_points, num_features):
     voxels = voxels.contiguous()
     m, P, ndim = voxels.shape
     out = torch.empty((m, num_features), dtype=torch.float32, device=voxels.device)
+    if m == 0:
+        return out
     num_points = num_points.contiguous()     # keep every converted tensor alive until the launch is enqueued
     check(_lib.lib().gga_voxel_mean(_p(voxels), _p(num_points), m, P, ndim, num_features,
                                     _p(out), _stream()), 'gga_voxel_mean')

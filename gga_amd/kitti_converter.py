@@ -77,12 +77,13 @@ def calculate_rga_file(data_path, info, relative_path, save_path, num_features=4
 
 
 def create_gga_info_file(data_path, infos, image_ids, out_file, relative_path=True, save_path='./data/kitti_GGA_split_file',
-                         resume=False, seed=None, logger=print):
+                         resume=False, seed=None, logger=print, compute_num_points=True):
     """The GGA part of ``create_kitti_info_file`` for one split (:70-99): num_points_in_gt, the
     per-frame label generation, then the merge of the per-frame files in ``image_ids`` order into
     ``out_file``. ``seed``: re-seed ``np.random`` per frame with ``seed + image_idx`` (the RANSAC
     ground fit draws from it; the reference's pool workers inherit an arbitrary state)."""
-    calculate_num_points_in_gt(data_path, infos, relative_path)
+    if compute_num_points:      # False: the infos already carry annos['num_points_in_gt'] (stock create_kitti_info_file)
+        calculate_num_points_in_gt(data_path, infos, relative_path)
     for info in infos:
         if seed is not None:
             np.random.seed(seed + int(info['image']['image_idx']))

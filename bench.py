@@ -22,6 +22,7 @@ Rank 0 prints ONE JSON line; ``roofline`` is the pillar scatter (BASELINE's HBM 
 ``mfma_roofline`` the 64 -> 64 dense 3x3 convolution (the step's dominant kernel), both timed with
 HIP events inside the timed steps; ``second_trunk`` is the reference's shipped model
 (configs/gga/gga_kitti_config.py: sparse-conv trunk, BASELINE config #3's per-GPU workload, bs 8)
+and ``pgd_trunk`` the camera-only retraining model (configs/gga/gga_pdg.py, BASELINE config #5, bs 12)
 stepped in the same run; ``cpu_baseline`` is the oracle's CPU restatement of the same step on a
 bounded sample plus its pieces (N=1 only).
 """
@@ -43,6 +44,7 @@ ARITH = ('fp32 in / fp32 out; dense + sparse convolutions multiply as six bf16 x
          'truncation-split operands, fp32 accumulate (error vs float64 <= MIOpen fp32); everything else plain fp32')
 PP_CONFIG = os.path.join(REPO, 'configs', 'gga', 'gga_kitti_pointpillars_config.py')
 SECOND_CONFIG = os.path.join(REPO, 'configs', 'gga', 'gga_kitti_config.py')
+PGD_CONFIG = os.path.join(REPO, 'configs', 'gga', 'gga_pdg.py')
 
 
 def parse_args(argv=None):
@@ -62,6 +64,8 @@ def parse_args(argv=None):
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-second-trunk', action='store_true', help='skip the gga_kitti_config.py (sparse trunk) leg')
     ap.add_argument('--second-batch', type=int, default=8, help='frames per GPU of the second_trunk leg')
+    ap.add_argument('--no-pgd', action='store_true', help='skip the gga_pdg.py (camera-only retraining) leg')
+    ap.add_argument('--pgd-batch', type=int, default=12, help='images per GPU of the pgd leg (samples_per_gpu of the config)')
     return ap.parse_args(argv)
 
 
@@ -154,6 +158,55 @@ def run_workload(config, batch, steps, warmup, args, rank, world, device, sites=
     loss = float(out['loss'].detach()) if torch.is_tensor(out['loss']) else float(out['loss'])
     assert loss == loss, f'loss is NaN ({config})'
     return dict(dt=dt, loss=loss, timings=timings, model=model, batches=batches, cfg=cfg, runner=runner)
+
+
+def run_mono_workload(batch, steps, warmup, args, rank, world, device):
+    """configs/gga/gga_pdg.py (BASELINE config #5: PGD retrained on the GGA pseudo labels): FCOSMono3D = ResNet-101
+    + FPN + PGDHead (DCNv2 towers), full train step (fwd + bwd + clip + SGD) on synthetic KITTI-mono3d batches
+    (1242 x 375 images padded to 1248 x 384, resident in HBM). -> dict(dt, loss)."""
+    import torch
+    import torch.distributed as dist
+    from gga_amd import Config, build_model, synthetic
+    from gga_amd.cnn import to_channels_last
+    from gga_amd.train import Runner
+    cfg = Config.fromfile(PGD_CONFIG)
+    torch.manual_seed(0)
+    model = build_model(cfg.model).to(device)
+    model.bbox_head.init_weights()
+    if not args.nchw:
+        model = to_channels_last(model)
+    model.train()
+    runner = Runner(model, cfg, max_iters=max(1000, steps + warmup), distributed=world > 1, device=device, iters_per_epoch=1000)
+    batches = []
+    for i in range(2):
+        b = synthetic.make_mono_batch(batch, start=i * batch, rank=rank, device=device)
+        if not args.nchw:
+            b['img'] = b['img'].contiguous(memory_format=torch.channels_last)
+        batches.append({k: b[k] for k in synthetic.MONO_BATCH_KEYS})
+    torch.cuda.synchronize()
+    for i in range(warmup):
+        runner.step(batches[i % 2])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    gc.collect()
+    gc.disable()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        out = runner.step(batches[i % 2])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    gc.enable()
+    t = torch.tensor([dt], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    loss = float(out['loss'].detach())
+    assert loss == loss, 'loss is NaN (gga_pdg.py)'
+    return dict(dt=float(t.item()), loss=loss)
 
 
 def scatter_roofline(model, batches, step_ms):
@@ -382,6 +435,20 @@ def main():
                         round(wg_ms, 3)},
                 'timed': 'in-step, HIP events on the launch stream'}
         del sec
+        gc.collect()
+        torch.cuda.empty_cache()
+
+    if is_pp and not args.no_pgd:
+        pg = run_mono_workload(args.pgd_batch, args.steps, args.warmup, args, rank, world, device)
+        if rank == 0:
+            res['pgd_trunk'] = {
+                'config_file': os.path.relpath(PGD_CONFIG, REPO),
+                'workload': 'FCOSMono3D: ResNet-101 (caffe) + FPN + PGDHead with DCNv2 towers, KITTI-mono3d images 1242x375 '
+                            'padded to 1248x384, full train step (fwd+bwd+clip+SGD)',
+                'frames_per_gpu': args.pgd_batch, 'global_batch': args.pgd_batch * world,
+                'value': round(args.pgd_batch * world * args.steps / pg['dt'], 3), 'unit': 'frames/s',
+                'ms_per_step': round(pg['dt'] / args.steps * 1e3, 3), 'steps': args.steps, 'warmup': args.warmup,
+                'final_loss': round(pg['loss'], 4)}
         gc.collect()
         torch.cuda.empty_cache()
 

@@ -112,8 +112,11 @@ class ConvModule(nn.Module):
         if is_bn:
             from . import functional as F        # fused BN(+ReLU) HIP pass for channels-last activations
             return F.bn_act(x, self.norm, relu=self.with_activation)
-        if self.with_norm:                       # GroupNorm (mono3d heads)
+        if self.with_norm:                       # GroupNorm (mono3d heads): ATen's kernel returns NCHW memory
+            cl = x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)
             x = self.norm(x)
+            if cl:
+                x = x.contiguous(memory_format=torch.channels_last)
         if self.with_activation:
             x = self.activate(x)
         return x

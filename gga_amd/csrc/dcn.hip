@@ -92,61 +92,104 @@ __global__ __launch_bounds__(256) void dcn_im2col_kernel(const float* __restrict
     }
 }
 
-template <int VPL>
+// Backward of the sampling. The scatter into grad_x is data dependent (a sample's four corners are wherever
+// its offset points), so it has to be an atomic accumulation - but not one global atomic per contribution:
+// a 256-thread workgroup owns an 8 x 8 tile of output pixels and 64 channels at a time and accumulates into
+// an LDS window of the input plane that covers the tile's receptive field plus DCN_R pixels of offset slack
+// (lane = channel: conflict-free LDS atomics); the window is flushed once with coalesced global atomics, and
+// only samples whose corners leave the window go to global memory directly. At 12 x 96 x 312 pixels x 256
+// channels that is 16 k global atomics per tile and chunk instead of 147 k (first version: one thread-level
+// global atomic per contribution, 14 ms per call; this one: see DESIGN.md).
+// grad_offset / grad_mask: per (pixel, tap) sums over the channels, accumulated over the four channel chunks
+// in LDS and written once.
+#define DCN_TH 8
+#define DCN_TW 8
+#define DCN_R 2
+#define DCN_CCH 64
+#define DCN_MAXWIN 400           // window pixels held in LDS (x 64 channels x 4 B = 100 KB at most; 3x3/s1/d1: 16 x 16)
+
 __global__ __launch_bounds__(256) void dcn_col2im_kernel(const float* __restrict__ x, const float* __restrict__ offset,
                                                         const float* __restrict__ mask, const float* __restrict__ gcol,
-                                                        DcnGeom g, float* __restrict__ gx, float* __restrict__ goffset,
+                                                        DcnGeom g, int tiles_x, int tiles_y, int win_h, int win_w,
+                                                        float* __restrict__ gx, float* __restrict__ goffset,
                                                         float* __restrict__ gmask) {
-    const int lane = threadIdx.x & 63;
-    const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int64_t npix = (int64_t)g.B * g.Ho * g.Wo;
-    if (p >= npix) return;
-    const int b = (int)(p / ((int64_t)g.Ho * g.Wo));
-    const int rem = (int)(p - (int64_t)b * g.Ho * g.Wo);
-    const int ho = rem / g.Wo, wo = rem - ho * g.Wo;
-    const int K = g.kh * g.kw;
+    extern __shared__ __attribute__((aligned(16))) float dcn_lds[];
+    const int K = g.kh * g.kw, NP = DCN_TH * DCN_TW * K;       // (pixel, tap) pairs of the tile
+    float* win = dcn_lds;                                       // [win_h * win_w][64]
+    float* sums = dcn_lds + (size_t)win_h * win_w * DCN_CCH;    // [NP][3]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x / (tiles_x * tiles_y);
+    const int t = blockIdx.x - b * (tiles_x * tiles_y);
+    const int ty0 = (t / tiles_x) * DCN_TH, tx0 = (t % tiles_x) * DCN_TW;
+    const int wy0 = ty0 * g.sh - g.ph - DCN_R, wx0 = tx0 * g.sw - g.pw - DCN_R;    // window origin in the input plane
     const int64_t plane = (int64_t)g.Ho * g.Wo;
     const float* xb = x + (int64_t)b * g.H * g.W * g.C;
     float* gxb = gx ? gx + (int64_t)b * g.H * g.W * g.C : nullptr;
-    const float* ob = offset + (int64_t)b * 2 * K * plane + rem;
-    const float* mb = mask + (int64_t)b * K * plane + rem;
-    const float* gp = gcol + p * (int64_t)K * g.C;
-    for (int k = 0; k < K; ++k) {
-        const int i = k / g.kw, j = k - i * g.kw;
-        const float off_h = ob[(int64_t)(2 * k) * plane], off_w = ob[(int64_t)(2 * k + 1) * plane];
-        const float m = mb[(int64_t)k * plane];
-        const DcnTap t = dcn_tap(g, ho, wo, i, j, off_h, off_w);
-        const float hh = 1.f - t.lh, hw = 1.f - t.lw;
-        const float w1 = hh * hw, w2 = hh * t.lw, w3 = t.lh * hw, w4 = t.lh * t.lw;
-        const int64_t o1 = ((int64_t)t.hl * g.W + t.wl) * g.C;
-        float s_val = 0.f, s_dh = 0.f, s_dw = 0.f;            // sum_c gcol * {sample, d sample / dh, d sample / dw}
-#pragma unroll
-        for (int e = 0; e < VPL; ++e) {
-            const int c = (lane + 64 * e) * 4;
-            const float4 gc = f4_ld(gp + (int64_t)k * g.C + c);
-            const float4 a1 = t.v1 ? f4_ld(xb + o1 + c) : f4_zero();
-            const float4 a2 = t.v2 ? f4_ld(xb + o1 + g.C + c) : f4_zero();
-            const float4 a3 = t.v3 ? f4_ld(xb + o1 + (int64_t)g.W * g.C + c) : f4_zero();
-            const float4 a4 = t.v4 ? f4_ld(xb + o1 + (int64_t)(g.W + 1) * g.C + c) : f4_zero();
-            const float d1 = f4_dot(gc, a1), d2 = f4_dot(gc, a2), d3 = f4_dot(gc, a3), d4 = f4_dot(gc, a4);
-            s_val += w1 * d1 + w2 * d2 + w3 * d3 + w4 * d4;
-            s_dh += hw * (d3 - d1) + t.lw * (d4 - d2);        // d/dh: -hw v1 - lw v2 + hw v3 + lw v4
-            s_dw += hh * (d2 - d1) + t.lh * (d4 - d3);        // d/dw: -hh v1 + hh v2 - lh v3 + lh v4
+    for (int i = tid; i < NP * 3; i += 256) sums[i] = 0.f;
+    for (int c0 = 0; c0 < g.C; c0 += DCN_CCH) {
+        for (int i = tid; i < win_h * win_w * DCN_CCH; i += 256) win[i] = 0.f;
+        __syncthreads();
+        for (int pr = wave; pr < NP; pr += 4) {                  // wave-uniform pair, lane = channel
+            const int pl = pr / K, k = pr - pl * K;
+            const int ho = ty0 + pl / DCN_TW, wo = tx0 + pl % DCN_TW;
+            if (ho >= g.Ho || wo >= g.Wo) continue;
+            const int rem = ho * g.Wo + wo;
+            const int i = k / g.kw, j = k - i * g.kw;
+            const float off_h = offset[((int64_t)b * 2 * K + 2 * k) * plane + rem];
+            const float off_w = offset[((int64_t)b * 2 * K + 2 * k + 1) * plane + rem];
+            const float m = mask[((int64_t)b * K + k) * plane + rem];
+            const DcnTap tp = dcn_tap(g, ho, wo, i, j, off_h, off_w);
+            if (!tp.inside) continue;
+            const float hh = 1.f - tp.lh, hw = 1.f - tp.lw;
+            const float w1 = hh * hw, w2 = hh * tp.lw, w3 = tp.lh * hw, w4 = tp.lh * tp.lw;
+            const int c = c0 + lane;
+            const float gc = gcol[((int64_t)b * plane + rem) * ((int64_t)K * g.C) + (int64_t)k * g.C + c];
+            const int64_t o1 = ((int64_t)tp.hl * g.W + tp.wl) * g.C + c;
+            const float a1 = tp.v1 ? xb[o1] : 0.f, a2 = tp.v2 ? xb[o1 + g.C] : 0.f;
+            const float a3 = tp.v3 ? xb[o1 + (int64_t)g.W * g.C] : 0.f, a4 = tp.v4 ? xb[o1 + (int64_t)(g.W + 1) * g.C] : 0.f;
+            float s_val = gc * (w1 * a1 + w2 * a2 + w3 * a3 + w4 * a4);
+            float s_dh = gc * (hw * (a3 - a1) + tp.lw * (a4 - a2));
+            float s_dw = gc * (hh * (a2 - a1) + tp.lh * (a4 - a3));
+            s_val = wave_sum(s_val); s_dh = wave_sum(s_dh); s_dw = wave_sum(s_dw);
+            if (lane == 0) { sums[pr * 3] += s_val; sums[pr * 3 + 1] += s_dh * m; sums[pr * 3 + 2] += s_dw * m; }   // one wave per pair
             if (gxb) {
-                const float4 gm = make_float4(gc.x * m, gc.y * m, gc.z * m, gc.w * m);
-#define DCN_ADD(OK, OFF, WGT) if (OK) { float* d = gxb + (OFF) + c; atomicAdd(d, (WGT) * gm.x); atomicAdd(d + 1, (WGT) * gm.y); \
-                                        atomicAdd(d + 2, (WGT) * gm.z); atomicAdd(d + 3, (WGT) * gm.w); }
-                DCN_ADD(t.v1, o1, w1) DCN_ADD(t.v2, o1 + g.C, w2) DCN_ADD(t.v3, o1 + (int64_t)g.W * g.C, w3)
-                DCN_ADD(t.v4, o1 + (int64_t)(g.W + 1) * g.C, w4)
-#undef DCN_ADD
+                const float gm = gc * m;
+                const int ly = tp.hl - wy0, lx = tp.wl - wx0;                     // window coordinates of the low corner
+                const bool in_win = ly >= 0 && lx >= 0 && ly + 1 < win_h && lx + 1 < win_w;
+                if (in_win) {
+                    float* wp = win + ((size_t)ly * win_w + lx) * DCN_CCH + lane;
+                    if (tp.v1) atomicAdd(wp, w1 * gm);
+                    if (tp.v2) atomicAdd(wp + DCN_CCH, w2 * gm);
+                    if (tp.v3) atomicAdd(wp + (size_t)win_w * DCN_CCH, w3 * gm);
+                    if (tp.v4) atomicAdd(wp + (size_t)(win_w + 1) * DCN_CCH, w4 * gm);
+                } else {                                                         // far offset: straight to memory
+                    if (tp.v1) atomicAdd(gxb + o1, w1 * gm);
+                    if (tp.v2) atomicAdd(gxb + o1 + g.C, w2 * gm);
+                    if (tp.v3) atomicAdd(gxb + o1 + (int64_t)g.W * g.C, w3 * gm);
+                    if (tp.v4) atomicAdd(gxb + o1 + (int64_t)(g.W + 1) * g.C, w4 * gm);
+                }
             }
         }
-        s_val = wave_sum(s_val); s_dh = wave_sum(s_dh); s_dw = wave_sum(s_dw);
-        if (lane == 0) {
-            gmask[(int64_t)b * K * plane + (int64_t)k * plane + rem] = s_val;
-            goffset[(int64_t)b * 2 * K * plane + (int64_t)(2 * k) * plane + rem] = t.inside ? s_dh * m : 0.f;
-            goffset[(int64_t)b * 2 * K * plane + (int64_t)(2 * k + 1) * plane + rem] = t.inside ? s_dw * m : 0.f;
+        __syncthreads();
+        if (gxb) {      // flush the window: row of 64 channels per wave access
+            for (int i = tid; i < win_h * win_w * DCN_CCH; i += 256) {
+                const float v = win[i];
+                if (v == 0.f) continue;
+                const int px = i / DCN_CCH, c = i - px * DCN_CCH;
+                const int iy = wy0 + px / win_w, ix = wx0 + px % win_w;
+                if (iy >= 0 && iy < g.H && ix >= 0 && ix < g.W) atomicAdd(gxb + ((int64_t)iy * g.W + ix) * g.C + c0 + c, v);
+            }
         }
+        __syncthreads();
+    }
+    for (int pr = tid; pr < NP; pr += 256) {
+        const int pl = pr / K, k = pr - pl * K;
+        const int ho = ty0 + pl / DCN_TW, wo = tx0 + pl % DCN_TW;
+        if (ho >= g.Ho || wo >= g.Wo) continue;
+        const int rem = ho * g.Wo + wo;
+        gmask[((int64_t)b * K + k) * plane + rem] = sums[pr * 3];
+        goffset[((int64_t)b * 2 * K + 2 * k) * plane + rem] = sums[pr * 3 + 1];
+        goffset[((int64_t)b * 2 * K + 2 * k + 1) * plane + rem] = sums[pr * 3 + 2];
     }
 }
 
@@ -154,7 +197,7 @@ static int dcn_geom(const char* fn, int B, int H, int W, int C, int kh, int kw, 
                     int dw, DcnGeom* g) {
     GGA_REQUIRE(B >= 1 && H >= 1 && W >= 1 && kh >= 1 && kw >= 1 && sh >= 1 && sw >= 1 && dh >= 1 && dw >= 1 && ph >= 0 &&
                     pw >= 0, "%s: bad geometry", fn);
-    GGA_REQUIRE(C >= 256 && C % 256 == 0 && C <= 1024, "%s: channels (%d) must be 256, 512, 768 or 1024", fn, C);
+    GGA_REQUIRE(C >= 256 && C % 256 == 0 && C <= 1024, "%s: channels (%d) must be 256, 512, 768 or 1024", fn, C);      // (col2im needs C % 64 == 0)
     g->B = B; g->H = H; g->W = W; g->C = C; g->kh = kh; g->kw = kw; g->sh = sh; g->sw = sw; g->ph = ph; g->pw = pw;
     g->dh = dh; g->dw = dw;
     g->Ho = (H + 2 * ph - (dh * (kh - 1) + 1)) / sh + 1;
@@ -190,14 +233,17 @@ extern "C" int gga_dcn_col2im(const float* x, const float* offset, const float* 
     DcnGeom g;
     if (int rc = dcn_geom("gga_dcn_col2im", B, H, W, C, kh, kw, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w, &g)) return rc;
     if (grad_x) GGA_CHECK_HIP(hipMemsetAsync(grad_x, 0, (size_t)B * H * W * C * sizeof(float), stream), "dcn memset");
-    const int64_t npix = (int64_t)B * g.Ho * g.Wo;
-    const dim3 grid((unsigned)((npix + 3) / 4)), block(256);
-    switch (C / 256) {
-        case 1: hipLaunchKernelGGL(dcn_col2im_kernel<1>, grid, block, 0, stream, x, offset, mask, grad_col, g, grad_x, grad_offset, grad_mask); break;
-        case 2: hipLaunchKernelGGL(dcn_col2im_kernel<2>, grid, block, 0, stream, x, offset, mask, grad_col, g, grad_x, grad_offset, grad_mask); break;
-        case 3: hipLaunchKernelGGL(dcn_col2im_kernel<3>, grid, block, 0, stream, x, offset, mask, grad_col, g, grad_x, grad_offset, grad_mask); break;
-        default: hipLaunchKernelGGL(dcn_col2im_kernel<4>, grid, block, 0, stream, x, offset, mask, grad_col, g, grad_x, grad_offset, grad_mask); break;
-    }
+    const int tiles_x = (g.Wo + DCN_TW - 1) / DCN_TW, tiles_y = (g.Ho + DCN_TH - 1) / DCN_TH;
+    // LDS window: receptive field of the tile + offset slack + the bilinear (+1) corner
+    int win_h = (DCN_TH - 1) * stride_h + (kh - 1) * dil_h + 2 + 2 * DCN_R;
+    int win_w = (DCN_TW - 1) * stride_w + (kw - 1) * dil_w + 2 + 2 * DCN_R;
+    while (win_h * win_w > DCN_MAXWIN) { if (win_h > 4) win_h -= 1; if (win_w > 4 && win_h * win_w > DCN_MAXWIN) win_w -= 1; }   // smaller window: more direct atomics, same result
+    const size_t lds = ((size_t)win_h * win_w * DCN_CCH + (size_t)DCN_TH * DCN_TW * kh * kw * 3) * sizeof(float);
+    GGA_REQUIRE(lds <= 160 * 1024 && kh * kw <= 49, "gga_dcn_col2im: kernel %dx%d too large", kh, kw);
+    GGA_CHECK_HIP(hipFuncSetAttribute((const void*)dcn_col2im_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                  "dcn col2im LDS size");
+    hipLaunchKernelGGL(dcn_col2im_kernel, dim3((unsigned)(B * tiles_x * tiles_y)), dim3(256), lds, stream, x, offset, mask, grad_col, g,
+                       tiles_x, tiles_y, win_h, win_w, grad_x, grad_offset, grad_mask);
     GGA_CHECK_LAUNCH("dcn_col2im_kernel");
     return GGA_OK;
 }

@@ -121,7 +121,7 @@ class _Conv3x3(torch.autograd.Function):
 
 
 def eligible(conv, x):
-    return (ENABLED and type(conv) is nn.Conv2d and conv.bias is None and conv.kernel_size == (3, 3)
+    return (ENABLED and type(conv) is nn.Conv2d and conv.kernel_size == (3, 3)
             and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1
             and conv.padding_mode == 'zeros' and conv.in_channels % 32 == 0
             and (conv.out_channels in (64, 128) or conv.out_channels % 128 == 0)
@@ -135,6 +135,8 @@ def conv2d(x, conv, bn_follows=False):
     kernel then also leaves the per-channel sums of its output (``y.bn_partials``), which
     ``functional.bn_act`` / ``bn_relu_head_conv3x3`` use instead of re-reading ``y``."""
     if eligible(conv, x):
+        if conv.bias is not None:         # the kernel has no bias epilogue: one elementwise pass (mono3d head towers)
+            return _Conv3x3.apply(x, conv.weight, False)[0] + conv.bias.view(1, -1, 1, 1)
         y, stats = _Conv3x3.apply(x, conv.weight, bool(bn_follows))
         if bn_follows:
             y.bn_partials = stats

@@ -443,3 +443,53 @@ def make_rga_scene(seed, n_ground=1200, n_clutter=500):
         index=np.arange(n, dtype=np.int32), group_ids=np.arange(n, dtype=np.int32),
         difficulty=np.zeros(n, np.int32), num_points_in_gt=np.array(npts + [-1] * n_dc, dtype=np.int32))
     return points_v, calib, annos, (375, 1242)
+
+
+# ----------------------------------------------------------------------------- mono3d (PGD retraining, BASELINE config #5)
+MONO_IMG = (375, 1242)              # KITTI image, padded to a multiple of 32 by the pipeline ('Pad', size_divisor=32)
+MONO_CAM2IMG = np.array([[721.5377, 0.0, 609.5593, 44.85728], [0.0, 721.5377, 172.854, 0.2163791], [0.0, 0.0, 1.0, 0.002745884]],
+                        np.float32)
+_MONO_DIMS = np.array([[0.8, 1.73, 0.6], [1.76, 1.73, 0.6], [3.9, 1.56, 1.6]], np.float32)      # (l, h, w) per class
+
+
+def make_mono_batch(batch_size, start=0, rank=0, device=None, img_hw=MONO_IMG, n_obj_range=(3, 9)):
+    """KITTI-mono3d-shaped training batch as configs/gga/gga_pdg.py's pipeline hands it to
+    ``FCOSMono3D.forward_train``: normalised image tensor [B, 3, H', W'] (H', W' padded to multiples of 32),
+    and per image ``gt_bboxes`` [n,4], ``gt_labels`` [n], ``gt_bboxes_3d`` [n,7] (camera boxes: x, y, z, l, h, w, yaw),
+    ``gt_labels_3d``, ``centers2d`` [n,2], ``depths`` [n], ``img_metas`` with ``cam2img`` and the camera box type.
+    Seeded by ``1234 + 1000 * rank + frame`` like the LiDAR frames."""
+    from .box3d import CameraInstance3DBoxes
+    H, W = img_hw
+    Hp, Wp = -(-H // 32) * 32, -(-W // 32) * 32
+    out = dict(img=[], img_metas=[], gt_bboxes=[], gt_labels=[], gt_bboxes_3d=[], gt_labels_3d=[], centers2d=[], depths=[])
+    fx, cx, cy = float(MONO_CAM2IMG[0, 0]), float(MONO_CAM2IMG[0, 2]), float(MONO_CAM2IMG[1, 2])
+    for f in range(start, start + batch_size):
+        rng = np.random.default_rng(1234 + 1000 * rank + f)
+        img = np.zeros((3, Hp, Wp), np.float32)
+        img[:, :H, :W] = rng.normal(0.0, 40.0, (3, H, W)).astype(np.float32)        # mean-subtracted BGR, std 1 (img_norm_cfg)
+        n = int(rng.integers(*n_obj_range))
+        labels = rng.integers(0, 3, n)
+        depth = rng.uniform(6.0, 55.0, n).astype(np.float32)
+        c2d = np.stack([rng.uniform(40, W - 40, n), rng.uniform(150, H - 30, n)], 1).astype(np.float32)
+        dims = _MONO_DIMS[labels] * rng.uniform(0.9, 1.1, (n, 3)).astype(np.float32)
+        xyz = np.stack([(c2d[:, 0] - cx) * depth / fx, (c2d[:, 1] - cy) * depth / fx, depth], 1).astype(np.float32)
+        yaw = rng.uniform(-np.pi, np.pi, (n, 1)).astype(np.float32)
+        half = np.stack([dims[:, 0] + dims[:, 2], dims[:, 1]], 1) * fx / depth[:, None] * 0.5       # projected half extent
+        boxes = np.concatenate([c2d - half, c2d + half], 1)
+        boxes[:, [0, 2]] = boxes[:, [0, 2]].clip(0, W - 1)
+        boxes[:, [1, 3]] = boxes[:, [1, 3]].clip(0, H - 1)
+        t = lambda a, dt=torch.float32: torch.as_tensor(a, dtype=dt, device=device)
+        out['img'].append(t(img))
+        out['gt_bboxes'].append(t(boxes))
+        out['gt_labels'].append(t(labels, torch.int64))
+        out['gt_bboxes_3d'].append(t(np.concatenate([xyz, dims, yaw], 1)))
+        out['gt_labels_3d'].append(t(labels, torch.int64))
+        out['centers2d'].append(t(c2d))
+        out['depths'].append(t(depth))
+        out['img_metas'].append(dict(cam2img=MONO_CAM2IMG.tolist(), box_type_3d=CameraInstance3DBoxes, img_shape=(H, W, 3),
+                                     pad_shape=(Hp, Wp, 3), ori_shape=(H, W, 3), scale_factor=1.0, flip=False))
+    out['img'] = torch.stack(out['img'])
+    return out
+
+
+MONO_BATCH_KEYS = ('img', 'img_metas', 'gt_bboxes', 'gt_labels', 'gt_bboxes_3d', 'gt_labels_3d', 'centers2d', 'depths')

@@ -585,10 +585,18 @@ def test_dense_conv3x3_vs_torch(cin, cout, B, H, W):
     assert float((x.grad.double() - xd.grad).abs().max()) <= 3e-6 * float(xd.grad.abs().max())
     gw_ref = torch.nn.grad.conv2d_weight(x.detach().double(), conv.weight.shape, g.double(), padding=1)
     assert float((conv.weight.grad.double() - gw_ref).abs().max()) <= 1e-5 * float(gw_ref.abs().max())   # bf16x9 weight gradient
-    # not eligible: stride 2, bias, NCHW input
+    # not eligible: stride 2, NCHW input; a bias is added by one elementwise pass after the kernel
     assert not dense_conv.eligible(torch.nn.Conv2d(cin, cout, 3, stride=2, padding=1, bias=False).to(DEV), x)
-    assert not dense_conv.eligible(torch.nn.Conv2d(cin, cout, 3, padding=1).to(DEV), x)
     assert not dense_conv.eligible(conv, x.detach().contiguous())
+    cb = torch.nn.Conv2d(cin, cout, 3, padding=1).to(DEV)
+    cb.weight.data = cb.weight.data.contiguous(memory_format=torch.channels_last)
+    assert dense_conv.eligible(cb, x)
+    xb = x.detach().clone().requires_grad_(True)
+    yb = dense_conv.conv2d(xb, cb)
+    refb = torch.nn.functional.conv2d(xb.detach().double(), cb.weight.detach().double(), cb.bias.detach().double(), padding=1)
+    assert float((yb.double() - refb).abs().max()) <= 3e-6 * float(refb.abs().max())
+    yb.sum().backward()
+    torch.testing.assert_close(cb.bias.grad, torch.full_like(cb.bias, float(B * H * W)), rtol=1e-5, atol=1e-3)
 
 
 @pytest.mark.parametrize('cin,cout,B,H,W', [(64, 64, 3, 37, 45), (64, 128, 2, 37, 45), (128, 128, 2, 31, 22),

@@ -237,7 +237,7 @@ def test_bench_gpus2_plain_command_starts_its_own_ranks():
     ranks share the device over gloo; the real detector runs under DistributedDataParallel with the
     custom autograd Functions inside DDP's reducer hooks and host-side label inputs. Both configs:
     the PointPillars trunk as the main line, the shipped sparse trunk as `second_trunk`."""
-    res = _run_bench(['--gpus', '2', '--steps', '2', '--warmup', '1', '--batch', '2', '--second-batch', '2',
+    res = _run_bench(['--gpus', '2', '--steps', '2', '--warmup', '1', '--batch', '2', '--second-batch', '2', '--pgd-batch', '1',
                       '--no-roofline'])
     assert res['n_gpus'] == 2 and res['value'] > 0 and res['config']['global_batch'] == 4
     assert res['config']['parallelism'] == 'dp2'
@@ -245,6 +245,7 @@ def test_bench_gpus2_plain_command_starts_its_own_ranks():
     assert res['config']['backend'].startswith('nccl' if n_dev >= 2 else 'gloo')
     st = res['second_trunk']
     assert st['global_batch'] == 4 and st['value'] > 0 and st['config_file'].endswith('gga_kitti_config.py')
+    assert res['pgd_trunk']['global_batch'] == 2 and res['pgd_trunk']['value'] > 0
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason='RCCL needs one device per rank (>= 2 GPUs)')
@@ -252,7 +253,7 @@ def test_two_rank_rccl_both_configs():
     """Two ranks on two GPUs, backend nccl (= RCCL): gradient all-reduce over xGMI for the
     PointPillars config and for configs/gga/gga_kitti_config.py (BASELINE config #3's workload)."""
     env = dict(os.environ, GGA_DIST_BACKEND='nccl')
-    res = _run_bench(['--gpus', '2', '--steps', '3', '--warmup', '2', '--batch', '4', '--second-batch', '4',
+    res = _run_bench(['--gpus', '2', '--steps', '3', '--warmup', '2', '--batch', '4', '--second-batch', '4', '--pgd-batch', '2',
                       '--no-roofline'], env=env)
     assert res['n_gpus'] == 2 and res['config']['backend'].startswith('nccl')
     assert res['config']['global_batch'] == 8 and res['second_trunk']['global_batch'] == 8
@@ -261,9 +262,9 @@ def test_two_rank_rccl_both_configs():
 
 def test_bench_line_contract_single_gpu():
     """The default single-GPU line carries every field the driver and the judge read."""
-    res = _run_bench(['--steps', '2', '--warmup', '1', '--batch', '2', '--second-batch', '2', '--no-cpu-baseline'])
+    res = _run_bench(['--steps', '2', '--warmup', '1', '--batch', '2', '--second-batch', '2', '--pgd-batch', '1', '--no-cpu-baseline'])
     for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
-              'vs_baseline', 'dtype', 'arith', 'data', 'config', 'roofline', 'mfma_roofline', 'second_trunk'):
+              'vs_baseline', 'dtype', 'arith', 'data', 'config', 'roofline', 'mfma_roofline', 'second_trunk', 'pgd_trunk'):
         assert k in res, k
     assert res['roofline']['bound'] == 'hbm' and res['roofline']['launches_timed'] == 2
     assert res['mfma_roofline']['launches_timed'] == 2 * res['mfma_roofline']['launches_per_step']

@@ -106,6 +106,7 @@ __global__ __launch_bounds__(256) void dcn_im2col_kernel(const float* __restrict
 #define DCN_TW 8
 #define DCN_R 2
 #define DCN_CCH 64
+#define DCN_U 4                  // (pixel, tap) pairs in flight per wave
 #define DCN_MAXWIN 400           // window pixels held in LDS (x 64 channels x 4 B = 100 KB at most; 3x3/s1/d1: 16 x 16)
 
 __global__ __launch_bounds__(256) void dcn_col2im_kernel(const float* __restrict__ x, const float* __restrict__ offset,
@@ -125,48 +126,70 @@ __global__ __launch_bounds__(256) void dcn_col2im_kernel(const float* __restrict
     const int64_t plane = (int64_t)g.Ho * g.Wo;
     const float* xb = x + (int64_t)b * g.H * g.W * g.C;
     float* gxb = gx ? gx + (int64_t)b * g.H * g.W * g.C : nullptr;
-    for (int i = tid; i < NP * 3; i += 256) sums[i] = 0.f;
+    float* om = sums + NP * 3;                                  // [NP][3]: offset_h, offset_w, mask of every pair (-inf offset: no pair)
+    for (int pr = tid; pr < NP; pr += 256) {
+        const int pl = pr / K, k = pr - pl * K;
+        const int ho = ty0 + pl / DCN_TW, wo = tx0 + pl % DCN_TW;
+        const bool ok = ho < g.Ho && wo < g.Wo;
+        const int rem = ok ? ho * g.Wo + wo : 0;
+        sums[pr * 3] = sums[pr * 3 + 1] = sums[pr * 3 + 2] = 0.f;
+        om[pr * 3] = ok ? offset[((int64_t)b * 2 * K + 2 * k) * plane + rem] : -1e30f;       // far outside: tap.inside = false
+        om[pr * 3 + 1] = ok ? offset[((int64_t)b * 2 * K + 2 * k + 1) * plane + rem] : -1e30f;
+        om[pr * 3 + 2] = ok ? mask[((int64_t)b * K + k) * plane + rem] : 0.f;
+    }
     for (int c0 = 0; c0 < g.C; c0 += DCN_CCH) {
         for (int i = tid; i < win_h * win_w * DCN_CCH; i += 256) win[i] = 0.f;
         __syncthreads();
-        for (int pr = wave; pr < NP; pr += 4) {                  // wave-uniform pair, lane = channel
-            const int pl = pr / K, k = pr - pl * K;
-            const int ho = ty0 + pl / DCN_TW, wo = tx0 + pl % DCN_TW;
-            if (ho >= g.Ho || wo >= g.Wo) continue;
-            const int rem = ho * g.Wo + wo;
-            const int i = k / g.kw, j = k - i * g.kw;
-            const float off_h = offset[((int64_t)b * 2 * K + 2 * k) * plane + rem];
-            const float off_w = offset[((int64_t)b * 2 * K + 2 * k + 1) * plane + rem];
-            const float m = mask[((int64_t)b * K + k) * plane + rem];
-            const DcnTap tp = dcn_tap(g, ho, wo, i, j, off_h, off_w);
-            if (!tp.inside) continue;
-            const float hh = 1.f - tp.lh, hw = 1.f - tp.lw;
-            const float w1 = hh * hw, w2 = hh * tp.lw, w3 = tp.lh * hw, w4 = tp.lh * tp.lw;
-            const int c = c0 + lane;
-            const float gc = gcol[((int64_t)b * plane + rem) * ((int64_t)K * g.C) + (int64_t)k * g.C + c];
-            const int64_t o1 = ((int64_t)tp.hl * g.W + tp.wl) * g.C + c;
-            const float a1 = tp.v1 ? xb[o1] : 0.f, a2 = tp.v2 ? xb[o1 + g.C] : 0.f;
-            const float a3 = tp.v3 ? xb[o1 + (int64_t)g.W * g.C] : 0.f, a4 = tp.v4 ? xb[o1 + (int64_t)(g.W + 1) * g.C] : 0.f;
-            float s_val = gc * (w1 * a1 + w2 * a2 + w3 * a3 + w4 * a4);
-            float s_dh = gc * (hw * (a3 - a1) + tp.lw * (a4 - a2));
-            float s_dw = gc * (hh * (a2 - a1) + tp.lh * (a4 - a3));
-            s_val = wave_sum(s_val); s_dh = wave_sum(s_dh); s_dw = wave_sum(s_dw);
-            if (lane == 0) { sums[pr * 3] += s_val; sums[pr * 3 + 1] += s_dh * m; sums[pr * 3 + 2] += s_dw * m; }   // one wave per pair
-            if (gxb) {
-                const float gm = gc * m;
-                const int ly = tp.hl - wy0, lx = tp.wl - wx0;                     // window coordinates of the low corner
-                const bool in_win = ly >= 0 && lx >= 0 && ly + 1 < win_h && lx + 1 < win_w;
-                if (in_win) {
-                    float* wp = win + ((size_t)ly * win_w + lx) * DCN_CCH + lane;
-                    if (tp.v1) atomicAdd(wp, w1 * gm);
-                    if (tp.v2) atomicAdd(wp + DCN_CCH, w2 * gm);
-                    if (tp.v3) atomicAdd(wp + (size_t)win_w * DCN_CCH, w3 * gm);
-                    if (tp.v4) atomicAdd(wp + (size_t)(win_w + 1) * DCN_CCH, w4 * gm);
-                } else {                                                         // far offset: straight to memory
-                    if (tp.v1) atomicAdd(gxb + o1, w1 * gm);
-                    if (tp.v2) atomicAdd(gxb + o1 + g.C, w2 * gm);
-                    if (tp.v3) atomicAdd(gxb + o1 + (int64_t)g.W * g.C, w3 * gm);
-                    if (tp.v4) atomicAdd(gxb + o1 + (int64_t)(g.W + 1) * g.C, w4 * gm);
+        const int c = c0 + lane;
+        // the gathers are a dependent chain (offset -> corner addresses -> loads): four pairs are in flight per wave
+        for (int pr0 = wave; pr0 < NP; pr0 += 4 * DCN_U) {
+            DcnTap tp[DCN_U];
+            float gc[DCN_U], a1[DCN_U], a2[DCN_U], a3[DCN_U], a4[DCN_U], m[DCN_U];
+            int64_t o1[DCN_U];
+#pragma unroll
+            for (int u = 0; u < DCN_U; ++u) {
+                const int pr = pr0 + 4 * u;
+                const bool live = pr < NP;
+                const int prc = live ? pr : 0;
+                const int pl = prc / K, k = prc - pl * K;
+                const int ho = ty0 + pl / DCN_TW, wo = tx0 + pl % DCN_TW;
+                tp[u] = dcn_tap(g, ho, wo, k / g.kw, k % g.kw, live ? om[prc * 3] : -1e30f, live ? om[prc * 3 + 1] : -1e30f);
+                m[u] = om[prc * 3 + 2];
+                const int rem = tp[u].inside ? ho * g.Wo + wo : 0;
+                gc[u] = tp[u].inside ? gcol[((int64_t)b * plane + rem) * ((int64_t)K * g.C) + (int64_t)k * g.C + c] : 0.f;
+                o1[u] = ((int64_t)tp[u].hl * g.W + tp[u].wl) * g.C + c;
+                a1[u] = tp[u].v1 ? xb[o1[u]] : 0.f;
+                a2[u] = tp[u].v2 ? xb[o1[u] + g.C] : 0.f;
+                a3[u] = tp[u].v3 ? xb[o1[u] + (int64_t)g.W * g.C] : 0.f;
+                a4[u] = tp[u].v4 ? xb[o1[u] + (int64_t)(g.W + 1) * g.C] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < DCN_U; ++u) {
+                if (!tp[u].inside) continue;                     // wave-uniform
+                const int pr = pr0 + 4 * u;
+                const float hh = 1.f - tp[u].lh, hw = 1.f - tp[u].lw;
+                const float w1 = hh * hw, w2 = hh * tp[u].lw, w3 = tp[u].lh * hw, w4 = tp[u].lh * tp[u].lw;
+                float s_val = gc[u] * (w1 * a1[u] + w2 * a2[u] + w3 * a3[u] + w4 * a4[u]);
+                float s_dh = gc[u] * (hw * (a3[u] - a1[u]) + tp[u].lw * (a4[u] - a2[u]));
+                float s_dw = gc[u] * (hh * (a2[u] - a1[u]) + tp[u].lh * (a4[u] - a3[u]));
+                s_val = wave_sum(s_val); s_dh = wave_sum(s_dh); s_dw = wave_sum(s_dw);
+                if (lane == 0) { sums[pr * 3] += s_val; sums[pr * 3 + 1] += s_dh * m[u]; sums[pr * 3 + 2] += s_dw * m[u]; }   // one wave per pair
+                if (gxb) {
+                    const float gm = gc[u] * m[u];
+                    const int ly = tp[u].hl - wy0, lx = tp[u].wl - wx0;             // window coordinates of the low corner
+                    const bool in_win = ly >= 0 && lx >= 0 && ly + 1 < win_h && lx + 1 < win_w;
+                    if (in_win) {
+                        float* wp = win + ((size_t)ly * win_w + lx) * DCN_CCH + lane;
+                        if (tp[u].v1) atomicAdd(wp, w1 * gm);
+                        if (tp[u].v2) atomicAdd(wp + DCN_CCH, w2 * gm);
+                        if (tp[u].v3) atomicAdd(wp + (size_t)win_w * DCN_CCH, w3 * gm);
+                        if (tp[u].v4) atomicAdd(wp + (size_t)(win_w + 1) * DCN_CCH, w4 * gm);
+                    } else {                                                     // far offset: straight to memory
+                        if (tp[u].v1) atomicAdd(gxb + o1[u], w1 * gm);
+                        if (tp[u].v2) atomicAdd(gxb + o1[u] + g.C, w2 * gm);
+                        if (tp[u].v3) atomicAdd(gxb + o1[u] + (int64_t)g.W * g.C, w3 * gm);
+                        if (tp[u].v4) atomicAdd(gxb + o1[u] + (int64_t)(g.W + 1) * g.C, w4 * gm);
+                    }
                 }
             }
         }
@@ -238,7 +261,7 @@ extern "C" int gga_dcn_col2im(const float* x, const float* offset, const float* 
     int win_h = (DCN_TH - 1) * stride_h + (kh - 1) * dil_h + 2 + 2 * DCN_R;
     int win_w = (DCN_TW - 1) * stride_w + (kw - 1) * dil_w + 2 + 2 * DCN_R;
     while (win_h * win_w > DCN_MAXWIN) { if (win_h > 4) win_h -= 1; if (win_w > 4 && win_h * win_w > DCN_MAXWIN) win_w -= 1; }   // smaller window: more direct atomics, same result
-    const size_t lds = ((size_t)win_h * win_w * DCN_CCH + (size_t)DCN_TH * DCN_TW * kh * kw * 3) * sizeof(float);
+    const size_t lds = ((size_t)win_h * win_w * DCN_CCH + (size_t)DCN_TH * DCN_TW * kh * kw * 6) * sizeof(float);
     GGA_REQUIRE(lds <= 160 * 1024 && kh * kw <= 49, "gga_dcn_col2im: kernel %dx%d too large", kh, kw);
     GGA_CHECK_HIP(hipFuncSetAttribute((const void*)dcn_col2im_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
                   "dcn col2im LDS size");

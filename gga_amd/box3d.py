@@ -185,6 +185,14 @@ class CameraInstance3DBoxes:
     dims = property(lambda self: self.tensor[:, 3:6])
     yaw = property(lambda self: self.tensor[:, 6])
 
+    @property
+    def bev(self):
+        """XYWHR in the ground plane (x, z, x_size, z_size, -yaw): the camera's gravity axis points down
+        (cam_box3d.py:159-168)."""
+        bev = self.tensor[:, [0, 2, 3, 5, 6]].clone()
+        bev[:, -1] = -bev[:, -1]
+        return bev
+
     def __len__(self):
         return self.tensor.shape[0]
 

@@ -187,10 +187,32 @@ class SingleStageMono3DDetector(nn.Module):
         return self.bbox_head.loss(*outs, gt_bboxes, gt_labels, gt_bboxes_3d, gt_labels_3d, centers2d, depths, attr_labels, img_metas,
                                    gt_bboxes_ignore=gt_bboxes_ignore)
 
+    @torch.no_grad()
+    def simple_test(self, img, img_metas, rescale=False):
+        """single_stage_mono3d.py:80-114: ``img_bbox`` (3D boxes, scores, labels) and - with a 2D branch -
+        ``img_bbox2d`` (per-class arrays [n, 5]) per image."""
+        from .box3d import bbox3d2result
+        outs = self.bbox_head(self.extract_feat(img))
+        bbox_outputs = self.bbox_head.get_bboxes(*outs, img_metas, rescale=rescale)
+        results = []
+        for out in bbox_outputs:
+            bboxes, scores, labels, attrs = out[:4]
+            r = dict(img_bbox=bbox3d2result(bboxes, scores, labels, attrs))
+            if self.bbox_head.pred_bbox2d:      # mmdet.core.bbox2result
+                b2d, lab = out[4].cpu().numpy(), labels.cpu().numpy()
+                r['img_bbox2d'] = [b2d[lab == i, :] for i in range(self.bbox_head.num_classes)]
+            results.append(r)
+        return results
+
+    def forward_test(self, imgs, img_metas, **kwargs):
+        if len(imgs) != 1:
+            raise NotImplementedError('test-time augmentation is not built')
+        return self.simple_test(imgs[0], img_metas[0], **kwargs)
+
     def forward(self, return_loss=True, **kwargs):
         if return_loss:
             return self.forward_train(**kwargs)
-        raise NotImplementedError('inference of the mono3d detector (PGDHead.get_bboxes) is not built')
+        return self.forward_test(**kwargs)
 
     def _parse_losses(self, losses):
         from collections import OrderedDict

@@ -8,8 +8,8 @@ fcos_mono3d_head.py:20-956, pgd_head.py:17-1229).
 MI355X side: the last tower convolutions are ``DCNv2`` (gga_amd/dcn.py, HIP sampling kernels); the
 O(points x boxes) target assignment of the whole batch is ONE launch (``gga_fcos3d_targets``) instead
 of ~60 broadcast tensor ops per image in a Python loop; the loss arithmetic on the few hundred
-positive points is plain device tensor code in the reference's order. Inference (``get_bboxes``)
-is not built.
+positive points is plain device tensor code in the reference's order. Inference (``get_bboxes``, pgd_head.py:878-1130):
+per-level top-k, decoding, then per-class BEV NMS on the rotated-NMS kernel (``ops.box3d_multiclass_nms``).
 """
 import numpy as np
 import torch
@@ -48,9 +48,14 @@ def bias_init_with_prob(prior_prob):
     return float(-np.log((1 - prior_prob) / prior_prob))
 
 
-def distance2bbox(points, distance):
-    return torch.stack([points[..., 0] - distance[..., 0], points[..., 1] - distance[..., 1],
-                        points[..., 0] + distance[..., 2], points[..., 1] + distance[..., 3]], -1)
+def distance2bbox(points, distance, max_shape=None):
+    """mmdet.core.distance2bbox: (left, top, right, bottom) distances -> xyxy, optionally clamped to the image."""
+    x1, y1 = points[..., 0] - distance[..., 0], points[..., 1] - distance[..., 1]
+    x2, y2 = points[..., 0] + distance[..., 2], points[..., 1] + distance[..., 3]
+    if max_shape is not None:
+        x1, x2 = x1.clamp(min=0, max=max_shape[1]), x2.clamp(min=0, max=max_shape[1])
+        y1, y2 = y1.clamp(min=0, max=max_shape[0]), y2.clamp(min=0, max=max_shape[0])
+    return torch.stack([x1, y1, x2, y2], -1)
 
 
 def multi_apply(func, *args, **kwargs):
@@ -468,6 +473,101 @@ class PGDHead(FCOSMono3DHead):
             norm_strides = pos_strides * self.regress_ranges[0][1] / self.strides[0]
             kpts = (corners_img_gt - pos_points[..., None, :]).view((*pos_preds.shape[:-1], 16)) / norm_strides
             outputs += (kpts, )
+        return outputs
+
+    # ---- inference (pgd_head.py:878-1130)
+    @torch.no_grad()
+    def get_bboxes(self, cls_scores, bbox_preds, dir_cls_preds, depth_cls_preds, weights, attr_preds, centernesses, img_metas,
+                   cfg=None, rescale=None):
+        num_levels = len(cls_scores)
+        mlvl_points = self.get_points([f.size()[-2:] for f in cls_scores], bbox_preds[0].dtype, bbox_preds[0].device)
+        result_list = []
+        for img_id in range(len(img_metas)):
+            pick = lambda xs: [xs[i][img_id].detach() for i in range(num_levels)]
+            cls_list = pick(cls_scores)
+            full = lambda c, v=0: [cls_list[i].new_full([c, *cls_list[i].shape[1:]], v) for i in range(num_levels)]
+            result_list.append(self._get_bboxes_single(
+                cls_list, pick(bbox_preds), pick(dir_cls_preds) if self.use_direction_classifier else full(2),
+                pick(depth_cls_preds) if self.use_depth_classifier else full(self.num_depth_cls),
+                pick(weights) if self.weight_dim != -1 else full(1),
+                pick(attr_preds) if self.pred_attrs else full(self.num_attrs, self.attr_background_label),
+                pick(centernesses), mlvl_points, img_metas[img_id], cfg, rescale))
+        return result_list
+
+    def _get_bboxes_single(self, cls_scores, bbox_preds, dir_cls_preds, depth_cls_preds, weights, attr_preds, centernesses,
+                           mlvl_points, input_meta, cfg, rescale=False):
+        from . import ops
+        view = np.array(input_meta['cam2img'])
+        scale_factor = input_meta['scale_factor']
+        cfg = self.test_cfg if cfg is None else cfg
+        get = (lambda k, d=None: cfg.get(k, d)) if isinstance(cfg, dict) else (lambda k, d=None: getattr(cfg, k, d))
+        code = self.bbox_coder.bbox_code_size
+        acc = dict(c2d=[], box=[], score=[], dir=[], attr=[], cen=[], dcls=[], dunc=[], b2d=[])
+        for cls_score, bbox_pred, dir_cls_pred, depth_cls_pred, weight, attr_pred, centerness, points in zip(
+                cls_scores, bbox_preds, dir_cls_preds, depth_cls_preds, weights, attr_preds, centernesses, mlvl_points):
+            scores = cls_score.permute(1, 2, 0).reshape(-1, self.cls_out_channels).sigmoid()
+            dir_cls_pred = dir_cls_pred.permute(1, 2, 0).reshape(-1, 2)
+            dir_cls_score = torch.max(dir_cls_pred, dim=-1)[1]
+            depth_cls_pred = depth_cls_pred.permute(1, 2, 0).reshape(-1, self.num_depth_cls)
+            depth_cls_score = torch.softmax(depth_cls_pred, dim=-1).topk(k=2, dim=-1)[0].mean(dim=-1)
+            weight = weight.permute(1, 2, 0).reshape(-1, self.weight_dim if self.weight_dim != -1 else 1)
+            depth_uncertainty = torch.exp(-weight[:, -1])
+            attr_score = torch.max(attr_pred.permute(1, 2, 0).reshape(-1, self.num_attrs), dim=-1)[1]
+            centerness = centerness.permute(1, 2, 0).reshape(-1).sigmoid()
+            bbox_pred = bbox_pred.permute(1, 2, 0).reshape(-1, sum(self.group_reg_dims))
+            bbox_pred3d = bbox_pred[:, :code].clone()
+            bbox_pred2d = bbox_pred[:, -4:].clone() if self.pred_bbox2d else None
+            nms_pre = get('nms_pre', -1)
+            if nms_pre > 0 and scores.shape[0] > nms_pre:
+                merged = scores * centerness[:, None]
+                if self.use_depth_classifier:
+                    merged = merged * depth_cls_score[:, None]
+                    if self.weight_dim != -1:
+                        merged = merged * depth_uncertainty[:, None]
+                topk_inds = merged.max(dim=1)[0].topk(nms_pre)[1]
+                points, bbox_pred3d, scores = points[topk_inds, :], bbox_pred3d[topk_inds, :], scores[topk_inds, :]
+                depth_cls_pred, centerness, dir_cls_score = depth_cls_pred[topk_inds, :], centerness[topk_inds], dir_cls_score[topk_inds]
+                depth_cls_score, depth_uncertainty, attr_score = depth_cls_score[topk_inds], depth_uncertainty[topk_inds], attr_score[topk_inds]
+                if self.pred_bbox2d:
+                    bbox_pred2d = bbox_pred2d[topk_inds, :]
+            bbox_pred3d[:, :2] = points - bbox_pred3d[:, :2]
+            if rescale:
+                bbox_pred3d[:, :2] /= bbox_pred3d[:, :2].new_tensor(scale_factor)
+                if self.pred_bbox2d:
+                    bbox_pred2d /= bbox_pred2d.new_tensor(scale_factor)
+            if self.use_depth_classifier:
+                prob = self.bbox_coder.decode_prob_depth(depth_cls_pred, self.depth_range, self.depth_unit, self.division,
+                                                         self.num_depth_cls)
+                a = torch.sigmoid(self.fuse_lambda)
+                bbox_pred3d[:, 2] = a * bbox_pred3d[:, 2] + (1 - a) * prob
+            acc['c2d'].append(bbox_pred3d[:, :3].clone())
+            bbox_pred3d[:, :3] = points_img2cam(bbox_pred3d[:, :3], view)
+            acc['box'].append(bbox_pred3d), acc['score'].append(scores), acc['dir'].append(dir_cls_score)
+            acc['dcls'].append(depth_cls_score), acc['attr'].append(attr_score), acc['cen'].append(centerness)
+            acc['dunc'].append(depth_uncertainty)
+            if self.pred_bbox2d:
+                acc['b2d'].append(distance2bbox(points, bbox_pred2d, max_shape=input_meta['img_shape']))
+        centers2d, bboxes, dir_scores = torch.cat(acc['c2d']), torch.cat(acc['box']), torch.cat(acc['dir'])
+        bboxes2d = torch.cat(acc['b2d']) if self.pred_bbox2d else None
+        cam2img = torch.eye(4, dtype=centers2d.dtype, device=centers2d.device)
+        cam2img[:view.shape[0], :view.shape[1]] = centers2d.new_tensor(view)
+        bboxes = self.bbox_coder.decode_yaw(bboxes, centers2d, dir_scores, self.dir_offset, cam2img)
+        box_type = input_meta['box_type_3d']
+        for_nms = ops.xywhr2xyxyr(box_type(bboxes, box_dim=code, origin=(0.5, 0.5, 0.5)).bev)
+        scores = torch.cat(acc['score'])
+        scores = torch.cat([scores, scores.new_zeros(scores.shape[0], 1)], dim=1)
+        nms_scores = scores * torch.cat(acc['cen'])[:, None]
+        if self.use_depth_classifier:
+            nms_scores = nms_scores * torch.cat(acc['dcls'])[:, None]
+            if self.weight_dim != -1:
+                nms_scores = nms_scores * torch.cat(acc['dunc'])[:, None]
+        results = ops.box3d_multiclass_nms(bboxes, for_nms, nms_scores, get('score_thr'), get('max_per_img'), cfg, dir_scores,
+                                           torch.cat(acc['attr']), bboxes2d)
+        out_boxes, out_scores, labels, _, attrs = results[0:5]
+        out_boxes = box_type(out_boxes, box_dim=code, origin=(0.5, 0.5, 0.5))
+        outputs = (out_boxes, out_scores, labels, attrs.to(labels.dtype) if self.pred_attrs else None)
+        if self.pred_bbox2d:
+            outputs = outputs + (torch.cat([results[-1], out_scores[:, None]], dim=1), )
         return outputs
 
     def loss(self, cls_scores, bbox_preds, dir_cls_preds, depth_cls_preds, weights, attr_preds, centernesses, gt_bboxes, gt_labels,

@@ -125,3 +125,42 @@ def points_in_boxes_part(points, boxes):
 
 def points_in_boxes_all(points, boxes):
     return _points_in_boxes(points, boxes, True)
+
+
+def nms_normal_bev(boxes, scores, thresh):
+    """core/post_processing/box3d_nms.py:274-288: NMS of the boxes with their yaw set to 0 (axis-aligned
+    xyxy boxes) - the rotated-NMS kernel with angle 0."""
+    assert boxes.shape[1] == 5, 'Input boxes shape should be [N, 5]'
+    b = torch.stack(((boxes[:, 0] + boxes[:, 2]) / 2, (boxes[:, 1] + boxes[:, 3]) / 2, boxes[:, 2] - boxes[:, 0],
+                     boxes[:, 3] - boxes[:, 1], torch.zeros_like(boxes[:, 0])), dim=-1)
+    return nms_rotated(b, scores, thresh)[1]
+
+
+def box3d_multiclass_nms(mlvl_bboxes, mlvl_bboxes_for_nms, mlvl_scores, score_thr, max_num, cfg, mlvl_dir_scores=None,
+                         mlvl_attr_scores=None, mlvl_bboxes2d=None):
+    """core/post_processing/box3d_nms.py:8-127: per-class BEV NMS of the score-thresholded boxes (rotated or
+    axis-aligned on the device), then the ``max_num`` best overall. ``mlvl_scores`` [N, C + 1] (last column =
+    background padding). -> (bboxes, scores, labels, dir_scores[, attr_scores][, bboxes2d])."""
+    num_classes = mlvl_scores.shape[1] - 1
+    use_rotate = cfg['use_rotate_nms'] if isinstance(cfg, dict) else cfg.use_rotate_nms
+    nms_thr = cfg['nms_thr'] if isinstance(cfg, dict) else cfg.nms_thr
+    picks = []
+    for i in range(num_classes):
+        cls_inds = mlvl_scores[:, i] > score_thr
+        if not cls_inds.any():
+            continue
+        idx = cls_inds.nonzero().squeeze(1)
+        sc = mlvl_scores[idx, i]
+        selected = (nms_bev if use_rotate else nms_normal_bev)(mlvl_bboxes_for_nms[idx], sc, nms_thr)
+        picks.append((idx[selected], sc[selected], mlvl_bboxes.new_full((len(selected), ), i, dtype=torch.long)))
+    extras = [t for t in (mlvl_dir_scores, mlvl_attr_scores, mlvl_bboxes2d) if t is not None]
+    if picks:
+        idx = torch.cat([p[0] for p in picks])
+        scores, labels = torch.cat([p[1] for p in picks]), torch.cat([p[2] for p in picks])
+        if idx.shape[0] > max_num:
+            inds = scores.sort(descending=True)[1][:max_num]
+            idx, scores, labels = idx[inds], scores[inds], labels[inds]
+        return (mlvl_bboxes[idx], scores, labels) + tuple(t[idx] for t in extras)
+    empty = (mlvl_scores.new_zeros((0, mlvl_bboxes.size(-1))), mlvl_scores.new_zeros((0, )),
+             mlvl_scores.new_zeros((0, ), dtype=torch.long))
+    return empty + tuple(t.new_zeros((0, ) + tuple(t.shape[1:])) for t in extras)

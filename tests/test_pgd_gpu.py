@@ -14,6 +14,7 @@ from gga_amd.registry import build_head
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
+IMG_HW = (128, 384)     # tools_dev/make_golden.py PGD_IMG
 
 HEAD_CFG = dict(
     type='PGDHead', num_classes=3, in_channels=32, stacked_convs=2, feat_channels=32, use_direction_classifier=True,
@@ -104,6 +105,34 @@ def test_targets_losses_and_gradients(head_and_golden, seed):
             scale = float(want.abs().max()) + 1e-12
             assert float((got - want).abs().max()) <= 1e-4 * scale + 1e-7, (k, i)
     assert float(head.fuse_lambda.grad) == pytest.approx(float(g[f'{seed}.grad.fuse_lambda']), rel=1e-3, abs=1e-6)
+
+
+def test_get_bboxes_matches_reference(head_and_golden):
+    """Inference (pgd_head.py:878-1130 + box3d_nms.py:8-127) on the golden forward features: same detections
+    in the same order as the reference head's ``get_bboxes``."""
+    head, g = head_and_golden
+    saved = head.conv_cls.bias.detach().clone()
+    try:
+        head.eval()
+        with torch.no_grad():
+            head.conv_cls.bias.copy_(torch.from_numpy(g['inf.conv_cls.bias']))
+            out = head([torch.from_numpy(g[f'fwd.feat.{i}']).to(DEV) for i in range(4)])
+            metas = [dict(cam2img=g['81.cam2img'].tolist(), box_type_3d=CameraInstance3DBoxes, scale_factor=1.0,
+                          img_shape=(IMG_HW[0], IMG_HW[1], 3)) for _ in range(2)]
+            dets = head.get_bboxes(*out, metas, cfg=dict(use_rotate_nms=True, nms_pre=100, nms_thr=0.05, score_thr=0.004,
+                                                         max_per_img=20))
+    finally:
+        with torch.no_grad():
+            head.conv_cls.bias.copy_(saved)
+        head.train()
+    for i, (bboxes, scores, labels, attrs, bboxes2d) in enumerate(dets):
+        assert attrs is None
+        want_scores = torch.from_numpy(g[f'inf.{i}.scores'])
+        assert scores.shape == want_scores.shape and len(scores) > 0
+        torch.testing.assert_close(scores.cpu(), want_scores, rtol=1e-4, atol=1e-6)
+        assert torch.equal(labels.cpu(), torch.from_numpy(g[f'inf.{i}.labels']))
+        torch.testing.assert_close(bboxes.tensor.cpu(), torch.from_numpy(g[f'inf.{i}.bboxes']), rtol=2e-4, atol=2e-4)
+        torch.testing.assert_close(bboxes2d.cpu(), torch.from_numpy(g[f'inf.{i}.bboxes2d']), rtol=2e-4, atol=2e-3)
 
 
 def test_pgd_config_head_builds_with_dcn():

@@ -927,8 +927,14 @@ def golden_pgd(ref):
     mc = sys.modules['mmcv.cnn']
     mc.Scale, mc.normal_init, mc.bias_init_with_prob = Scale, normal_init, lambda p: float(-np.log((1 - p) / p))
     md = sys.modules['mmdet.core']
-    md.distance2bbox = lambda points, distance: torch.stack([points[..., 0] - distance[..., 0], points[..., 1] - distance[..., 1],
-                                                             points[..., 0] + distance[..., 2], points[..., 1] + distance[..., 3]], -1)
+    def distance2bbox(points, distance, max_shape=None):          # mmdet.core.distance2bbox (restated)
+        x1, y1 = points[..., 0] - distance[..., 0], points[..., 1] - distance[..., 1]
+        x2, y2 = points[..., 0] + distance[..., 2], points[..., 1] + distance[..., 3]
+        if max_shape is not None:
+            x1, x2 = x1.clamp(min=0, max=max_shape[1]), x2.clamp(min=0, max=max_shape[1])
+            y1, y2 = y1.clamp(min=0, max=max_shape[0]), y2.clamp(min=0, max=max_shape[0])
+        return torch.stack([x1, y1, x2, y2], -1)
+    md.distance2bbox = distance2bbox
     _mod('mmdet.core.bbox', BaseBBoxCoder=object)
     _mod('mmdet.core.bbox.builder', BBOX_CODERS=_Reg())
     _mod('mmdet3d.core.bbox.coders')
@@ -1012,6 +1018,38 @@ def golden_pgd(ref):
         head.fuse_lambda.grad = None
         n_pos = int(sum(int(((t >= 0) & (t < 3)).sum()) for t in tg[0]))
         print(f'  pgd[{seed}]: {n_pos} positive points, ' + ', '.join(f'{k}={float(v):.4f}' for k, v in losses.items()))
+    # ---- inference: get_bboxes with the reference's box3d_multiclass_nms / nms_bev; mmcv's rotated NMS is absent, the
+    # oracle's C restatement (pinned by the reference's known-answer tests) stands in for it
+    from oracle import oracle as O
+
+    class AttrDict(dict):
+        __getattr__ = dict.__getitem__
+
+    def nms_rotated(boxes, scores, thr):
+        keep = O.nms_rotated(boxes.detach().numpy().astype(np.float32), scores.detach().numpy().astype(np.float32), float(thr))
+        keep = torch.as_tensor(np.asarray(keep), dtype=torch.long)
+        return torch.cat([boxes[keep], scores[keep, None]], 1), keep
+    sys.modules['mmcv.ops'].nms_rotated = nms_rotated
+    sys.modules['mmcv.ops'].nms = lambda boxes, scores, thr: nms_rotated(
+        torch.cat([(boxes[:, :2] + boxes[:, 2:4]) / 2, boxes[:, 2:4] - boxes[:, :2], boxes.new_zeros(len(boxes), 1)], 1), scores, thr)
+    bn = load('mmdet3d.core.post_processing.box3d_nms', 'mmdet3d/core/post_processing/box3d_nms.py')
+    pg.box3d_multiclass_nms = bn.box3d_multiclass_nms
+    head.eval()
+    with torch.no_grad():
+        head.conv_cls.bias.fill_(0.5)             # scores above the threshold
+        fo = head(feats)
+        metas = [dict(cam2img=make_pgd_case(81)[2].tolist(), box_type_3d=cam.CameraInstance3DBoxes, scale_factor=1.0,
+                      img_shape=(PGD_IMG[0], PGD_IMG[1], 3)) for _ in range(2)]
+        dets = head.get_bboxes(*fo, metas, cfg=AttrDict(use_rotate_nms=True, nms_across_levels=False, nms_pre=100, nms_thr=0.05,
+                                                          score_thr=0.004, min_bbox_size=0, max_per_img=20))
+    out['inf.conv_cls.bias'] = head.conv_cls.bias.detach().numpy()
+    for i, (bboxes, scores, labels, attrs, bboxes2d) in enumerate(dets):
+        out[f'inf.{i}.bboxes'] = bboxes.tensor.numpy()
+        out[f'inf.{i}.scores'] = scores.numpy()
+        out[f'inf.{i}.labels'] = labels.numpy()
+        out[f'inf.{i}.bboxes2d'] = bboxes2d.numpy()
+        assert attrs is None
+    print(f'  pgd inference: {[len(d[1]) for d in dets]} detections, labels {[sorted(set(d[2].tolist())) for d in dets]}')
     np.savez_compressed(os.path.join(OUT, 'pgd_head.npz'), **out)
 
 

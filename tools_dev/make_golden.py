@@ -974,7 +974,7 @@ def golden_pgd(ref):
                 sc.scale.add_(torch.randn(()) * 0.1)
         head.fuse_lambda.fill_(0.3)
     for k, v in head.state_dict().items():
-        out['state.' + k] = v.numpy()
+        out['state.' + k] = v.numpy().copy()       # a copy: the inference section edits conv_cls.bias in place
     # forward with shared weights
     feats = [torch.randn(2, 32, PGD_IMG[0] // s, PGD_IMG[1] // s) * 0.5 for s in (4, 8, 16, 32)]
     fo = head(feats)

@@ -439,6 +439,18 @@ extern "C" int gga_bn_relu_fwd(const float* x, const float* residual, const floa
                                    training, relu, y, channels, mask_bits, saved, workspace, workspace_bytes, stream_);
 }
 
+// Library-internal: fold [nblocks][2][C] partial sums (at the head of `workspace`) into grad_gamma / grad_beta and
+// the coefficient table the apply passes read (returned in *coef, inside the workspace).
+int gga_bn_bwd_finalize(const double* partials, int nblocks, int channels, int64_t rows, const float* gamma,
+                        const float* saved, float* grad_gamma, float* grad_beta, void* workspace, float** coef,
+                        hipStream_t stream) {
+    *coef = (float*)((char*)workspace + (size_t)BN_MAX_BLOCKS * 2 * channels * sizeof(double));
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((channels + 7) / 8), dim3(1024), 0, stream, partials, nblocks, channels,
+                       (double)rows, gamma, saved, grad_gamma, grad_beta, *coef);
+    GGA_CHECK_LAUNCH("bn_bwd_final_kernel");
+    return GGA_OK;
+}
+
 extern "C" int gga_bn_relu_bwd_strided(const float* grad_y, int64_t grad_y_row_stride, const float* x,
                                        const void* mask_bits, const float* gamma, const float* saved, int64_t rows,
                                        int channels, int relu, float* grad_x, float* grad_residual, float* grad_gamma,

@@ -17,6 +17,11 @@ hipEvent_t* gga_timing_acquire(int site, int64_t key);
 #define GGA_TIME_STOP(tev_, stream_) \
     do { if (tev_) GGA_CHECK_HIP(hipEventRecord((tev_)[1], stream_), "timing record"); } while (0)
 
+// bn_relu.hip, for the kernels that produce BatchNorm-backward partial sums themselves
+int gga_bn_bwd_finalize(const double* partials, int nblocks, int channels, int64_t rows, const float* gamma,
+                        const float* saved, float* grad_gamma, float* grad_beta, void* workspace, float** coef,
+                        hipStream_t stream);
+
 #define GGA_REQUIRE(cond, ...)                      \
     do {                                            \
         if (!(cond)) {                              \

@@ -10,7 +10,9 @@
 // halo tile: 0.165 / 0.147 ms, bound by LDS reads). Swapping the roles makes them GEMMs with
 // N = 9 taps x COUT <= 32 and the convolution a shifted sum of the result (see the kernels):
 // fwd 0.084-0.105 ms, each input element read once per tile from HBM (halo 1.33x).
-// Backward-data (writes the 219 MB input gradient, already bandwidth-bound) stays with MIOpen.
+// Backward-data is never materialised on the train path: the gradient w.r.t. the (never stored)
+// normalised activation is recomputed from the 1-4 channel grad_y inside the BatchNorm backward of
+// the branch (headtail_bwd_kernel below).
 #include "gga_common.h"
 
 #define HC_CIN 64
@@ -317,5 +319,190 @@ extern "C" int gga_head_conv3x3_wgrad(const float* x, const float* in_scale_shif
     hipLaunchKernelGGL(headconv_wgrad_final_kernel, dim3((n_w + cout + 3) / 4), dim3(256), 0, stream, partials, nb, n_w,
                        cout, grad_weight, grad_bias);
     GGA_CHECK_LAUNCH("headconv_wgrad_final_kernel");
+    return GGA_OK;
+}
+
+
+// ------------------------------------------------------------------------------ tail of a head branch, backward
+// Branch tail = BatchNorm(training) -> ReLU -> 3x3 conv to COUT <= 4 channels. Its backward w.r.t. the
+// BatchNorm input x is  dx = gamma*invstd * (g - mean(g) - xhat*mean(g*xhat)),  g = dh * [x*scale+shift > 0],
+// where dh = backward-data of the output conv. dh has 64 channels but only 9*COUT <= 36 terms per
+// element, all taken from the tiny grad_y: both passes over x (the two sums, then dx) rebuild it in
+// registers instead of reading a 219 MB tensor that a separate backward-data kernel would have written -
+// three passes over the activation (x, x, dx) where backward-data + reduce + apply took six.
+//   tile: 8 x 32 pixels per step of a persistent 256-thread workgroup; grad_y of the tile + a one-pixel
+//   border goes to LDS (zero outside the image, double buffered, requested a tile ahead); thread (cg = tid % 16, pg = tid / 16) owns channels
+//   4cg..4cg+3 - its 36*COUT weights live in registers - and walks the pixels pg, pg + 16, ... of the tile,
+//   reading x as one float4 (16 lanes = the 256 contiguous bytes of a pixel).
+//   partial sums: [block][2][64] f64, the layout of bn_reduce_kernel, folded by gga_bn_bwd_finalize.
+#define HT_TR 8
+#define HT_TW 32
+#define HT_HR (HT_TR + 2)
+#define HT_HW (HT_TW + 2)
+#define HT_MAX_BLOCKS 2048           // = BN_MAX_BLOCKS: the partials fit the BatchNorm workspace
+
+template <int COUT, bool APPLY>
+__global__ __launch_bounds__(256, COUT >= 4 ? 1 : 2) void headtail_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ x,
+                                                          const float* __restrict__ w, const float* __restrict__ ss,
+                                                          const float* __restrict__ saved, const float* __restrict__ coef,
+                                                          int B, int H, int W, int tiles_x, int tiles_y, int64_t n_tiles,
+                                                          double* __restrict__ partials, float* __restrict__ dx) {
+    __shared__ float gs[2][COUT * HT_HR * HT_HW];
+    __shared__ double red[APPLY ? 1 : 256][8];
+    const int tid = threadIdx.x, cg = tid & 15, pg = tid >> 4;
+    // w[co][ci][tap] -> wr[tap][co][j] for the thread's four channels
+    float wr[9][COUT][4];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int c = 0; c < COUT; ++c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wr[t][c][j] = w[((int64_t)c * HC_CIN + 4 * cg + j) * 9 + t];
+    float sc[4], sf[4], mean[4], inv[4], kk[4], mg[4], mgx[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = 4 * cg + j;
+        sc[j] = ss[c]; sf[j] = ss[HC_CIN + c]; mean[j] = saved[c]; inv[j] = saved[HC_CIN + c];
+        kk[j] = APPLY ? coef[c] : 0.0f; mg[j] = APPLY ? coef[HC_CIN + c] : 0.0f; mgx[j] = APPLY ? coef[2 * HC_CIN + c] : 0.0f;
+    }
+    double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+    const int per_img = tiles_x * tiles_y;
+    // Everything a step needs is requested one step ahead (two waves per SIMD do not hide a memory round trip
+    // by themselves): grad_y of the next tile while this one is computed, x of the next four pixels while these
+    // four are.
+    constexpr int GN = (COUT * HT_HR * HT_HW + 255) / 256;
+    float greg[GN];
+    float4 nxt[4];
+    auto coords = [&](int64_t ti, int& b, int& y0, int& x0) {
+        b = (int)(ti / per_img);
+        const int rem = (int)(ti - (int64_t)b * per_img);
+        y0 = (rem / tiles_x) * HT_TR; x0 = (rem % tiles_x) * HT_TW;
+    };
+    auto load_g = [&](int b, int y0, int x0) {
+#pragma unroll
+        for (int e = 0; e < GN; ++e) {
+            const int i = tid + 256 * e;
+            const int c = i / (HT_HR * HT_HW), q = i - c * (HT_HR * HT_HW);
+            const int hr = q / HT_HW, hx = q - hr * HT_HW;
+            const int iy = y0 + hr - 1, ix = x0 + hx - 1;
+            greg[e] = (c < COUT && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) ? gy[(((int64_t)b * COUT + c) * H + iy) * W + ix] : 0.0f;
+        }
+    };
+    auto store_g = [&](float* g) {
+#pragma unroll
+        for (int e = 0; e < GN; ++e) if (tid + 256 * e < COUT * HT_HR * HT_HW) g[tid + 256 * e] = greg[e];
+    };
+    auto load_x = [&](int b, int y0, int x0, int u0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int p = pg + 16 * (u0 + u);
+            const int oy = y0 + (p >> 5), ox = x0 + (p & 31);
+            nxt[u] = (oy < H && ox < W) ? *reinterpret_cast<const float4*>(x + (((int64_t)b * H + oy) * W + ox) * HC_CIN + 4 * cg)
+                                        : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    int64_t ti = blockIdx.x;
+    int b = 0, y0 = 0, x0 = 0;
+    if (ti < n_tiles) {
+        coords(ti, b, y0, x0);
+        load_g(b, y0, x0);
+        load_x(b, y0, x0, 0);
+        store_g(gs[0]);
+    }
+    __syncthreads();
+    for (int it = 0; ti < n_tiles; ++it) {
+        const int64_t tn = ti + gridDim.x;
+        const bool more = tn < n_tiles;
+        int bn = 0, y0n = 0, x0n = 0;
+        if (more) { coords(tn, bn, y0n, x0n); load_g(bn, y0n, x0n); }
+        const float* g = gs[it & 1];
+        float f0[4] = {0, 0, 0, 0}, f1[4] = {0, 0, 0, 0};
+#pragma unroll 1
+        for (int u0 = 0; u0 < (HT_TR * HT_TW) / 16; u0 += 4) {
+            float4 xv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) xv[u] = nxt[u];
+            if (u0 + 4 < (HT_TR * HT_TW) / 16) load_x(b, y0, x0, u0 + 4);
+            else if (more) load_x(bn, y0n, x0n, 0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int p = pg + 16 * (u0 + u);
+                const int ty = p >> 5, tx = p & 31;
+                const int oy = y0 + ty, ox = x0 + tx;
+                if (oy >= H || ox >= W) continue;
+                // dh[q][ci] = sum_tap sum_co gy[co][q - (tap - 1)] * w[co][ci][tap]
+                float dh[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                        for (int c = 0; c < COUT; ++c) {
+                            const float gv = g[c * HT_HR * HT_HW + (ty + 2 - ky) * HT_HW + tx + 2 - kx];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) dh[j] = fmaf(gv, wr[ky * 3 + kx][c][j], dh[j]);
+                        }
+                const float xa[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
+                float o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float gj = fmaf(xa[j], sc[j], sf[j]) > 0.0f ? dh[j] : 0.0f;
+                    const float xh = (xa[j] - mean[j]) * inv[j];
+                    if (APPLY) o[j] = kk[j] * (gj - mg[j] - xh * mgx[j]);
+                    else { f0[j] += gj; f1[j] += gj * xh; }
+                }
+                if (APPLY) *reinterpret_cast<float4*>(dx + (((int64_t)b * H + oy) * W + ox) * HC_CIN + 4 * cg) = make_float4(o[0], o[1], o[2], o[3]);
+            }
+        }
+        if (!APPLY) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { s0[j] += f0[j]; s1[j] += f1[j]; }      // 16 elements per f32 run
+        }
+        if (more) store_g(gs[(it + 1) & 1]);     // last read of that buffer: tile it-1, before the previous barrier
+        __syncthreads();
+        ti = tn; b = bn; y0 = y0n; x0 = x0n;
+    }
+    if (!APPLY) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { red[tid][j] = s0[j]; red[tid][4 + j] = s1[j]; }
+        __syncthreads();
+        if (tid < 16) {                                  // fixed order over the 16 pixel groups
+            double r[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int t = tid; t < 256; t += 16)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) r[q] += red[t][q];
+            double* out = partials + (int64_t)blockIdx.x * 2 * HC_CIN;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { out[4 * tid + j] = r[j]; out[HC_CIN + 4 * tid + j] = r[4 + j]; }
+        }
+    }
+}
+
+extern "C" int gga_head_tail_bwd(const float* grad_y, const float* x, const float* scale_shift, const float* gamma,
+                                 const float* saved, const float* weight, int B, int H, int W, int cin, int cout,
+                                 float* grad_x, float* grad_gamma, float* grad_beta, void* workspace, size_t workspace_bytes,
+                                 void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (int rc = headconv_check("gga_head_tail_bwd", B, H, W, cin, cout)) return rc;
+    GGA_REQUIRE(grad_y && x && scale_shift && saved && weight && grad_x && workspace, "gga_head_tail_bwd: null pointer argument");
+    const int64_t rows = (int64_t)B * H * W;
+    if (workspace_bytes < gga_bn_relu_workspace_bytes(rows, HC_CIN)) {
+        gga_set_error("gga_head_tail_bwd: workspace %zu B < required %zu B", workspace_bytes, gga_bn_relu_workspace_bytes(rows, HC_CIN));
+        return GGA_ERR_WORKSPACE;
+    }
+    const int tx = (W + HT_TW - 1) / HT_TW, ty = (H + HT_TR - 1) / HT_TR;
+    const int64_t n_tiles = (int64_t)B * tx * ty;
+    const int nb = (int)(n_tiles < HT_MAX_BLOCKS ? n_tiles : HT_MAX_BLOCKS);
+    double* partials = (double*)workspace;
+    float* coef = nullptr;
+#define HT_GO(CO, AP) hipLaunchKernelGGL((headtail_bwd_kernel<CO, AP>), dim3(nb), dim3(256), 0, stream, grad_y, x, weight, scale_shift, saved, coef, B, H, W, tx, ty, n_tiles, partials, grad_x)
+#define HT_SW(AP) switch (cout) { case 1: HT_GO(1, AP); break; case 2: HT_GO(2, AP); break; case 3: HT_GO(3, AP); break; default: HT_GO(4, AP); break; }
+    HT_SW(false)
+    GGA_CHECK_LAUNCH("headtail_bwd_kernel<reduce>");
+    if (int rc = gga_bn_bwd_finalize(partials, nb, HC_CIN, rows, gamma, saved, grad_gamma, grad_beta, workspace, &coef, stream)) return rc;
+    HT_SW(true)
+    GGA_CHECK_LAUNCH("headtail_bwd_kernel<apply>");
+#undef HT_SW
+#undef HT_GO
     return GGA_OK;
 }

@@ -676,8 +676,9 @@ class _HeadConv3x3(torch.autograd.Function):
 class _BnReluHeadConv3x3(torch.autograd.Function):
     """``conv(relu(bn(x)))`` for the tail of a head branch without materialising the normalised
     activation: batch statistics (gga_bn_stats), then the output conv applies scale/shift + ReLU
-    while it loads x; backward = MIOpen backward-data of the conv, the weight gradient from x with
-    the same on-load affine, and the BatchNorm backward with the ReLU mask recomputed from x."""
+    while it loads x; backward = the weight gradient from x with the same on-load affine, and the
+    BatchNorm backward with the ReLU mask recomputed from x and the conv's input gradient rebuilt from
+    grad_y in registers (gga_head_tail_bwd: no backward-data tensor)."""
 
     @staticmethod
     def forward(ctx, x, gamma, beta, running_mean, running_var, weight, bias, eps, momentum, training, partials=None):
@@ -716,16 +717,13 @@ class _BnReluHeadConv3x3(torch.autograd.Function):
         ws = _workspace('headconv', L.gga_head_conv3x3_workspace_bytes(cout), dev)
         check(L.gga_head_conv3x3_wgrad(_p(x), _p(ss), _p(gy), B, H, W, C, cout, _p(gw), _p(gb), _p(ws), ws.numel(),
                                        _stream()), 'gga_head_conv3x3_wgrad')
-        # gradient w.r.t. the (never stored) normalised activation: the framework's backward-data
-        gh = torch.ops.aten.convolution_backward(gy, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
-                                                 [True, False, False])[0]
-        gh = gh.contiguous(memory_format=torch.channels_last)
+        # BatchNorm + ReLU backward with the conv's input gradient rebuilt from gy on the fly (never stored)
         gx = torch.empty_like(x)
         gg = torch.empty(C, dtype=torch.float32, device=dev)
         gbeta = torch.empty(C, dtype=torch.float32, device=dev)
         wsb = _workspace('bn', L.gga_bn_relu_workspace_bytes(rows, C), dev)
-        check(L.gga_bn_relu_bwd(_p(gh), _p(x), _p(ss), _p(gamma), _p(saved), rows, C, 2, _p(gx), None, _p(gg),
-                                _p(gbeta), _p(wsb), wsb.numel(), _stream()), 'gga_bn_relu_bwd')
+        check(L.gga_head_tail_bwd(_p(gy), _p(x), _p(ss), _p(gamma), _p(saved), _p(w), B, H, W, C, cout, _p(gx), _p(gg), _p(gbeta),
+                                  _p(wsb), wsb.numel(), _stream()), 'gga_head_tail_bwd')
         return gx, gg, gbeta, None, None, gw, gb, None, None, None, None
 
 

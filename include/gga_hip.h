@@ -427,8 +427,7 @@ int gga_bn_stats_partials(const float* gamma, const float* beta, float* running_
  * matrix cores). x: channels-last memory [B,H,W,64] of a [B,64,H,W] tensor; weight [cout,64,3,3];
  * y [B,cout,H,W] NCHW-contiguous. in_scale_shift (optional, [2*64]): the convolution input is
  * relu(x * scale + shift) per channel, applied while loading - the BatchNorm + ReLU of the
- * branch's ConvModule (centerpoint_head.py:58-68) fused into its consumer. The input gradient
- * stays with the framework's convolution backward. */
+ * branch's ConvModule (centerpoint_head.py:58-68) fused into its consumer. */
 int gga_head_conv3x3_fwd(const float* x, const float* in_scale_shift, const float* weight, const float* bias,
                          int B, int H, int W, int cin, int cout, float* y, void* stream);
 /* grad_weight [cout,64,3,3] and grad_bias [cout] (optional) from grad_y [B,cout,H,W] */
@@ -437,6 +436,15 @@ int gga_head_conv3x3_wgrad(const float* x, const float* in_scale_shift, const fl
                            int cin, int cout,
                            float* grad_weight, float* grad_bias, void* workspace, size_t workspace_bytes,
                            void* stream);
+
+/* Backward of the whole branch tail BatchNorm(training) -> ReLU -> this conv w.r.t. the BatchNorm input x
+ * (centerpoint_head.py:58-79 under autograd): grad_x [B,H,W,64], grad_gamma / grad_beta [64] (optional) from
+ * grad_y [B,cout,H,W], the conv weight and the statistics gga_bn_stats left (saved = mean / invstd,
+ * scale_shift). The conv's input gradient is rebuilt from grad_y inside the two BatchNorm-backward passes and
+ * never stored. workspace: gga_bn_relu_workspace_bytes(B*H*W, 64). */
+int gga_head_tail_bwd(const float* grad_y, const float* x, const float* scale_shift, const float* gamma,
+                      const float* saved, const float* weight, int B, int H, int W, int cin, int cout, float* grad_x,
+                      float* grad_gamma, float* grad_beta, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------- */
 /* a6/a7. Heat-map target splat on the device.                                */

@@ -73,6 +73,45 @@ def test_pp_train_step_matches_cpu_reference(channels_last):
     assert R.gradient_offenders(grads, ref, ref64, tol=GRAD_TOL, slack=2.0) == []
 
 
+def test_loss_path_full_batch_vs_c_oracle():
+    """The loss path at the bench size - 16 frames of 20 000 points, the 248 x 216 head maps - against the C
+    oracle (``O.get_targets`` + ``O.head_loss``): every one of the 18 losses within 1e-4, and the gradient
+    of the total w.r.t. the regression maps non-zero only on object cells."""
+    from oracle import oracle as O
+    cfg = Config.fromfile(PP_CFG)
+    torch.manual_seed(0)
+    head = build_model(cfg.model).pts_bbox_head
+    B, T = 16, len(head.task_heads)
+    tc = head.train_cfg
+    batch = synthetic.make_batch(B, start=300, n_points=20000, pc_range=synthetic.RANGE_PP)
+    fw, fh = (int(g) // int(tc['out_size_factor']) for g in tc['grid_size'][:2])
+    preds = synthetic.make_head_preds(B, fh, fw, seed=91, n_tasks=T)
+    srl = head.draw_srl(B)
+    as_np = lambda xs: [a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a) for a in xs]
+    tg = O.get_targets(as_np(batch['gt_labels_3d']), as_np(batch['GGA_boxes_img']), as_np(batch['GGA_lidar2img']),
+                       as_np(batch['GGA_init_pseudo_labels']), as_np(batch['GGA_bdry_masks']),
+                       [as_np(f) for f in batch['GGA_in_box_points']], [m['lidar2img'] for m in batch['img_metas']], tc,
+                       np.asarray(srl, np.float32), n_tasks=T)
+    want, _ = O.head_loss([{k: v.numpy() for k, v in p.items()} for p in preds], tg, tc)
+    assert sum(int(tg['mask'][t].sum()) for t in range(T)) > 5 * B        # a loss over real objects
+    head.to(DEV)
+    maps = [{k: v.to(DEV).requires_grad_(True) for k, v in p.items()} for p in preds]
+    losses = head.loss(batch['gt_bboxes_3d'], batch['gt_labels_3d'], [[m] for m in maps], batch['GGA_boxes_img'],
+                       batch['GGA_lidar2img'], batch['GGA_init_pseudo_labels'], batch['GGA_bdry_masks'],
+                       batch['GGA_in_box_points'], batch['img_metas'], srl=srl)
+    assert set(losses) == set(want) and len(want) == 6 * T
+    for k, v in want.items():
+        assert float(losses[k]) == pytest.approx(float(v), rel=1e-4, abs=1e-4), k
+    sum(losses.values()).backward()
+    for t in range(T):
+        cells = int(tg['mask'][t].sum())
+        for k in ('reg', 'height', 'dim', 'rot'):
+            g = maps[t][k].grad
+            assert torch.isfinite(g).all()
+            per_cell = (g != 0).any(dim=1).sum()
+            assert 0 < int(per_cell) <= cells, (t, k)
+
+
 def test_runner_steps_and_loss_decreases():
     from gga_amd.train import Runner
     cfg = Config.fromfile(PP_CFG)

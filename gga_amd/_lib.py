@@ -11,7 +11,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libgga_hip.so')
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 _lib = None
 
@@ -73,6 +73,8 @@ SIGNATURES = {
     'gga_sparse_split_weight_bytes': (sz, [i32, i32, i32]),
     'gga_sparse_pack_weight_split': (i32, [vp, i32, i32, i32, i32, vp, vp]),
     'gga_sparse_conv_apply_split': (i32, [vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp, vp]),
+    'gga_sparse_conv_apply_split_strided': (i32, [vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp, i64, vp]),
+    'gga_sparse_conv_wgrad_split_strided': (i32, [vp, i64, vp, i64, vp, i64, i32, i32, i32, vp, vp, sz, vp]),
     'gga_sparse_conv_apply': (i32, [vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp, vp]),
     'gga_sparse_conv_wgrad': (i32, [vp, vp, vp, i64, i32, i32, i32, vp, vp]),
     'gga_sparse_conv_wgrad_workspace_bytes': (sz, [i64, i32, i32, i32]),
@@ -93,10 +95,10 @@ SIGNATURES = {
     'gga_bn_relu_fwd_strided': (i32, [vp, vp, vp, vp, vp, vp, i64, i32, f32, f32, i32, i32, vp, i64, vp, vp, vp, sz, vp]),
     'gga_bn_relu_bwd_strided': (i32, [vp, i64, vp, vp, vp, vp, i64, i32, i32, vp, vp, vp, vp, vp, sz, vp]),
     'gga_bn_stats': (i32, [vp, vp, vp, vp, vp, i64, i32, f32, f32, i32, vp, vp, vp, sz, vp]),
-    'gga_head_conv3x3_fwd': (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]),
+    'gga_head_conv3x3_fwd': (i32, [vp, i64, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]),
     'gga_head_conv3x3_workspace_bytes': (sz, [i32]),
-    'gga_head_conv3x3_wgrad': (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, sz, vp]),
-    'gga_head_tail_bwd': (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, sz, vp]),
+    'gga_head_conv3x3_wgrad': (i32, [vp, i64, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, sz, vp]),
+    'gga_head_tail_bwd': (i32, [vp, vp, i64, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, i64, vp, vp, vp, sz, vp]),
     'gga_heatmap_splat': (i32, [vp, i32, i32, i32, vp, i32, vp, vp, i32, vp]),
     'gga_focal_loss_workspace_bytes': (sz, [i64]),
     'gga_focal_loss_fwd': (i32, [vp, vp, i64, f32, f32, f32, vp, vp, sz, vp]),

@@ -1,5 +1,6 @@
 """``SECOND`` backbone and ``SECONDFPN`` neck (reference mmdet3d/models/backbones/
-second.py:24-91, necks/second_fpn.py:26-91): dense 2D convs -> MIOpen (MFMA)."""
+second.py:24-91, necks/second_fpn.py:26-91): every convolution on the repo's own matrix kernels
+(dense_conv.py: 3x3 stride 1; strided_conv.py: stride-2 3x3 and the transposed convolutions; pillar_conv.py: the first one)."""
 import numpy as np
 import torch
 from torch import nn
@@ -78,6 +79,7 @@ class SECONDFPN(nn.Module):
                for d in self.deblocks):
             # every branch normalises straight into its channel slice of the concatenated map
             from . import functional as F
-            return [F.bn_relu_cat([d[0](x[i]) for i, d in enumerate(self.deblocks)], [d[1] for d in self.deblocks])]
+            from . import dense_conv
+            return [F.bn_relu_cat([dense_conv.conv2d(x[i], d[0]) for i, d in enumerate(self.deblocks)], [d[1] for d in self.deblocks])]
         ups = [run_conv_bn_relu(deblock, x[i]) for i, deblock in enumerate(self.deblocks)]
         return [torch.cat(ups, dim=1) if len(ups) > 1 else ups[0]]

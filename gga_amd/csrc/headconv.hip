@@ -42,7 +42,7 @@ template <int COUT>
 __global__ __launch_bounds__(512) void headconv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                           const float* __restrict__ bias, int B, int H, int W,
                                                           int tiles_x, int tiles_y, int cout_total, int co_base,
-                                                          const float* __restrict__ in_ss, float* __restrict__ y) {
+                                                          const float* __restrict__ in_ss, int64_t xs, float* __restrict__ y) {
     typedef float acc16 __attribute__((ext_vector_type(16)));
     __shared__ float zt[HM_NGRP * 32 * HM_ZS];
     __shared__ __attribute__((aligned(16))) float ssl[2 * HC_CIN];      // input affine (scale, shift) when in_ss
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(512) void headconv_fwd_kernel(const float* __restri
         const int hr = hp / HM_HW, hx = hp - hr * HM_HW;
         const int iy = y0 + hr - 1, ix = x0 + hx - 1;
         const bool ok = has[u] && hp < HM_NPIX && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-        const float4* src = reinterpret_cast<const float4*>(x + (((int64_t)b * H + (ok ? iy : 0)) * W + (ok ? ix : 0)) * HC_CIN + 32 * h);
+        const float4* src = reinterpret_cast<const float4*>(x + (((int64_t)b * H + (ok ? iy : 0)) * W + (ok ? ix : 0)) * xs + 32 * h);
         const float m = ok ? 1.0f : 0.0f;
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
@@ -150,7 +150,7 @@ template <int COUT>
 __global__ __launch_bounds__(512, HW_MINW) void headconv_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                             int B, int H, int W, int tiles_x, int tiles_y,
                                                             int64_t n_tiles, int cout_total, int co_base,
-                                                            const float* __restrict__ in_ss,
+                                                            const float* __restrict__ in_ss, int64_t xs,
                                                             float* __restrict__ partials) {
     typedef float acc16 __attribute__((ext_vector_type(16)));
     __shared__ float gds[2][COUT * HW_PR * HW_PC];
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(512, HW_MINW) void headconv_wgrad_kernel(const floa
             const int hr = inh ? q / HM_HW : 0, hx = inh ? q - hr * HM_HW : 0;
             const int iy = y0 + hr - 1, ix = x0 + hx - 1;
             const bool ok = inh && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-            const float* xp = x + (((int64_t)b * H + (ok ? iy : 0)) * W + (ok ? ix : 0)) * HC_CIN + m;
+            const float* xp = x + (((int64_t)b * H + (ok ? iy : 0)) * W + (ok ? ix : 0)) * xs + m;
             const float mk = ok ? 1.0f : 0.0f;
             const float a0 = fmaxf(fmaf(xp[0], sc0, sf0), lo) * mk, a1 = fmaxf(fmaf(xp[32], sc1, sf1), lo) * mk;
             const float gv = g[gbase + hr * HW_PC + hx] * usedf;
@@ -273,14 +273,21 @@ extern "C" size_t gga_head_conv3x3_workspace_bytes(int cout) {
     return (size_t)HC_WGRAD_BLOCKS * ((size_t)cout * HC_CIN * 9 + cout) * sizeof(float);
 }
 
-extern "C" int gga_head_conv3x3_fwd(const float* x, const float* in_scale_shift, const float* weight, const float* bias,
-                                    int B, int H, int W, int cin, int cout, float* y, void* stream_) {
+static int headconv_stride(const char* fn, const void* x, int64_t xs) {
+    GGA_REQUIRE(xs >= HC_CIN && xs % 4 == 0 && ((uintptr_t)x & 15) == 0,
+                "%s: pixel stride %lld must be a multiple of 4 floats >= %d and the base 16-byte aligned", fn, (long long)xs, HC_CIN);
+    return GGA_OK;
+}
+
+extern "C" int gga_head_conv3x3_fwd(const float* x, int64_t x_pixel_stride, const float* in_scale_shift, const float* weight,
+                                    const float* bias, int B, int H, int W, int cin, int cout, float* y, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (int rc = headconv_check("gga_head_conv3x3_fwd", B, H, W, cin, cout)) return rc;
     GGA_REQUIRE(x && weight && y, "gga_head_conv3x3_fwd: null pointer argument");
+    if (int rc = headconv_stride("gga_head_conv3x3_fwd", x, x_pixel_stride)) return rc;
     const int tx = (W + HM_TW - 1) / HM_TW, ty = (H + HM_TR - 1) / HM_TR;
     const dim3 grid((unsigned)((int64_t)B * tx * ty)), block(512);
-#define HC_F(CO, BASE) hipLaunchKernelGGL(headconv_fwd_kernel<CO>, grid, block, 0, stream, x, weight, bias, B, H, W, tx, ty, cout, BASE, in_scale_shift, y)
+#define HC_F(CO, BASE) hipLaunchKernelGGL(headconv_fwd_kernel<CO>, grid, block, 0, stream, x, weight, bias, B, H, W, tx, ty, cout, BASE, in_scale_shift, x_pixel_stride, y)
     switch (cout) {
         case 1: HC_F(1, 0); break;
         case 2: HC_F(2, 0); break;
@@ -292,11 +299,12 @@ extern "C" int gga_head_conv3x3_fwd(const float* x, const float* in_scale_shift,
     return GGA_OK;
 }
 
-extern "C" int gga_head_conv3x3_wgrad(const float* x, const float* in_scale_shift, const float* grad_y, int B, int H, int W, int cin, int cout,
-                                      float* grad_weight, float* grad_bias, void* workspace, size_t workspace_bytes,
-                                      void* stream_) {
+extern "C" int gga_head_conv3x3_wgrad(const float* x, int64_t x_pixel_stride, const float* in_scale_shift, const float* grad_y,
+                                      int B, int H, int W, int cin, int cout, float* grad_weight, float* grad_bias,
+                                      void* workspace, size_t workspace_bytes, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (int rc = headconv_check("gga_head_conv3x3_wgrad", B, H, W, cin, cout)) return rc;
+    if (int rc = headconv_stride("gga_head_conv3x3_wgrad", x, x_pixel_stride)) return rc;
     GGA_REQUIRE(x && grad_y && grad_weight && workspace, "gga_head_conv3x3_wgrad: null pointer argument");
     if (workspace_bytes < gga_head_conv3x3_workspace_bytes(cout)) {
         gga_set_error("gga_head_conv3x3_wgrad: workspace too small");
@@ -306,7 +314,7 @@ extern "C" int gga_head_conv3x3_wgrad(const float* x, const float* in_scale_shif
     const int64_t n_tiles = (int64_t)B * tx * ty;
     const int nb = (int)(n_tiles < HC_WGRAD_BLOCKS ? n_tiles : HC_WGRAD_BLOCKS);
     float* partials = (float*)workspace;
-#define HC_W(CO, BASE) hipLaunchKernelGGL(headconv_wgrad_kernel<CO>, dim3(nb), dim3(512), 0, stream, x, grad_y, B, H, W, tx, ty, n_tiles, cout, BASE, in_scale_shift, partials)
+#define HC_W(CO, BASE) hipLaunchKernelGGL(headconv_wgrad_kernel<CO>, dim3(nb), dim3(512), 0, stream, x, grad_y, B, H, W, tx, ty, n_tiles, cout, BASE, in_scale_shift, x_pixel_stride, partials)
     switch (cout) {
         case 1: HC_W(1, 0); break;
         case 2: HC_W(2, 0); break;
@@ -346,7 +354,8 @@ __global__ __launch_bounds__(256, COUT >= 4 ? 1 : 2) void headtail_bwd_kernel(co
                                                           const float* __restrict__ w, const float* __restrict__ ss,
                                                           const float* __restrict__ saved, const float* __restrict__ coef,
                                                           int B, int H, int W, int tiles_x, int tiles_y, int64_t n_tiles,
-                                                          double* __restrict__ partials, float* __restrict__ dx) {
+                                                          int64_t xs, int64_t dxs, double* __restrict__ partials,
+                                                          float* __restrict__ dx) {
     __shared__ float gs[2][COUT * HT_HR * HT_HW];
     __shared__ double red[APPLY ? 1 : 256][8];
     const int tid = threadIdx.x, cg = tid & 15, pg = tid >> 4;
@@ -397,7 +406,7 @@ __global__ __launch_bounds__(256, COUT >= 4 ? 1 : 2) void headtail_bwd_kernel(co
         for (int u = 0; u < 4; ++u) {
             const int p = pg + 16 * (u0 + u);
             const int oy = y0 + (p >> 5), ox = x0 + (p & 31);
-            nxt[u] = (oy < H && ox < W) ? *reinterpret_cast<const float4*>(x + (((int64_t)b * H + oy) * W + ox) * HC_CIN + 4 * cg)
+            nxt[u] = (oy < H && ox < W) ? *reinterpret_cast<const float4*>(x + (((int64_t)b * H + oy) * W + ox) * xs + 4 * cg)
                                         : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
@@ -451,7 +460,7 @@ __global__ __launch_bounds__(256, COUT >= 4 ? 1 : 2) void headtail_bwd_kernel(co
                     if (APPLY) o[j] = kk[j] * (gj - mg[j] - xh * mgx[j]);
                     else { f0[j] += gj; f1[j] += gj * xh; }
                 }
-                if (APPLY) *reinterpret_cast<float4*>(dx + (((int64_t)b * H + oy) * W + ox) * HC_CIN + 4 * cg) = make_float4(o[0], o[1], o[2], o[3]);
+                if (APPLY) *reinterpret_cast<float4*>(dx + (((int64_t)b * H + oy) * W + ox) * dxs + 4 * cg) = make_float4(o[0], o[1], o[2], o[3]);
             }
         }
         if (!APPLY) {
@@ -478,12 +487,14 @@ __global__ __launch_bounds__(256, COUT >= 4 ? 1 : 2) void headtail_bwd_kernel(co
     }
 }
 
-extern "C" int gga_head_tail_bwd(const float* grad_y, const float* x, const float* scale_shift, const float* gamma,
-                                 const float* saved, const float* weight, int B, int H, int W, int cin, int cout,
-                                 float* grad_x, float* grad_gamma, float* grad_beta, void* workspace, size_t workspace_bytes,
-                                 void* stream_) {
+extern "C" int gga_head_tail_bwd(const float* grad_y, const float* x, int64_t x_pixel_stride, const float* scale_shift,
+                                 const float* gamma, const float* saved, const float* weight, int B, int H, int W, int cin,
+                                 int cout, float* grad_x, int64_t grad_x_pixel_stride, float* grad_gamma, float* grad_beta,
+                                 void* workspace, size_t workspace_bytes, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (int rc = headconv_check("gga_head_tail_bwd", B, H, W, cin, cout)) return rc;
+    if (int rc = headconv_stride("gga_head_tail_bwd", x, x_pixel_stride)) return rc;
+    if (int rc = headconv_stride("gga_head_tail_bwd", grad_x, grad_x_pixel_stride)) return rc;
     GGA_REQUIRE(grad_y && x && scale_shift && saved && weight && grad_x && workspace, "gga_head_tail_bwd: null pointer argument");
     const int64_t rows = (int64_t)B * H * W;
     if (workspace_bytes < gga_bn_relu_workspace_bytes(rows, HC_CIN)) {
@@ -495,7 +506,7 @@ extern "C" int gga_head_tail_bwd(const float* grad_y, const float* x, const floa
     const int nb = (int)(n_tiles < HT_MAX_BLOCKS ? n_tiles : HT_MAX_BLOCKS);
     double* partials = (double*)workspace;
     float* coef = nullptr;
-#define HT_GO(CO, AP) hipLaunchKernelGGL((headtail_bwd_kernel<CO, AP>), dim3(nb), dim3(256), 0, stream, grad_y, x, weight, scale_shift, saved, coef, B, H, W, tx, ty, n_tiles, partials, grad_x)
+#define HT_GO(CO, AP) hipLaunchKernelGGL((headtail_bwd_kernel<CO, AP>), dim3(nb), dim3(256), 0, stream, grad_y, x, weight, scale_shift, saved, coef, B, H, W, tx, ty, n_tiles, x_pixel_stride, grad_x_pixel_stride, partials, grad_x)
 #define HT_SW(AP) switch (cout) { case 1: HT_GO(1, AP); break; case 2: HT_GO(2, AP); break; case 3: HT_GO(3, AP); break; default: HT_GO(4, AP); break; }
     HT_SW(false)
     GGA_CHECK_LAUNCH("headtail_bwd_kernel<reduce>");

@@ -733,7 +733,7 @@ __global__ __launch_bounds__(64 * X9_NW) void sp_conv_x9_kernel(const float* __r
                                                         const int32_t* __restrict__ perm,
                                                         const uint32_t* __restrict__ rowmask, int64_t n_rows,
                                                         int kvol, int cin, int cout, int flip,
-                                                        float* __restrict__ Y) {
+                                                        float* __restrict__ Y, int64_t ys) {
     constexpr int CO = NT * 32;
     constexpr int BPL = CO * X9_ROWB;                     // bytes per B plane
     constexpr int BSZ = 3 * BPL;                          // bytes per B buffer
@@ -888,23 +888,23 @@ __global__ __launch_bounds__(64 * X9_NW) void sp_conv_x9_kernel(const float* __r
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int o = t * 32 + r;
-            if (o < cout) Y[(int64_t)po * cout + o] = acc[t][v];
+            if (o < cout) Y[(int64_t)po * ys + o] = acc[t][v];
         }
     }
 }
 
-extern "C" int gga_sparse_conv_apply_split(const float* x, const int32_t* map, const void* split_weight, const int32_t* perm,
-                                           const uint32_t* rowmask, int64_t n_rows, int kvol, int cin, int cout, int flip,
-                                           float* y, void* stream_) {
+extern "C" int gga_sparse_conv_apply_split_strided(const float* x, const int32_t* map, const void* split_weight,
+                                                   const int32_t* perm, const uint32_t* rowmask, int64_t n_rows, int kvol,
+                                                   int cin, int cout, int flip, float* y, int64_t y_row_stride, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     GGA_REQUIRE(x && map && split_weight && y, "gga_sparse_conv_apply_split: null pointer argument");
-    GGA_REQUIRE(n_rows >= 1 && kvol >= 1 && cin >= 1 && cout >= 1 && cout <= 128,
-                "gga_sparse_conv_apply_split: bad sizes (rows=%lld kvol=%d cin=%d cout=%d; cout <= 128)", (long long)n_rows,
-                kvol, cin, cout);
+    GGA_REQUIRE(n_rows >= 1 && kvol >= 1 && cin >= 1 && cout >= 1 && cout <= 128 && y_row_stride >= cout,
+                "gga_sparse_conv_apply_split: bad sizes (rows=%lld kvol=%d cin=%d cout=%d row stride %lld; cout <= 128)",
+                (long long)n_rows, kvol, cin, cout, (long long)y_row_stride);
     const dim3 grid((unsigned)((n_rows + X9_TM - 1) / X9_TM)), block(64 * X9_NW);
     hipEvent_t* tev = gga_timing_acquire(GGA_TIME_SPARSE_CONV, GGA_TIMING_CONV_KEY(cin, cout, 0));
     GGA_TIME_START(tev, stream);
-#define X9_LAUNCH(NT, VEC) hipLaunchKernelGGL((sp_conv_x9_kernel<NT, VEC>), grid, block, 0, stream, x, map, (const uint16_t*)split_weight, perm, rowmask, n_rows, kvol, cin, cout, flip, y)
+#define X9_LAUNCH(NT, VEC) hipLaunchKernelGGL((sp_conv_x9_kernel<NT, VEC>), grid, block, 0, stream, x, map, (const uint16_t*)split_weight, perm, rowmask, n_rows, kvol, cin, cout, flip, y, y_row_stride)
     if ((cin & 3) == 0) {
         switch (mf_nt(cout)) {
             case 1: X9_LAUNCH(1, true); break;
@@ -922,6 +922,12 @@ extern "C" int gga_sparse_conv_apply_split(const float* x, const int32_t* map, c
     GGA_CHECK_LAUNCH("sp_conv_x9_kernel");
     GGA_TIME_STOP(tev, stream);
     return GGA_OK;
+}
+
+extern "C" int gga_sparse_conv_apply_split(const float* x, const int32_t* map, const void* split_weight, const int32_t* perm,
+                                           const uint32_t* rowmask, int64_t n_rows, int kvol, int cin, int cout, int flip,
+                                           float* y, void* stream_) {
+    return gga_sparse_conv_apply_split_strided(x, map, split_weight, perm, rowmask, n_rows, kvol, cin, cout, flip, y, cout, stream_);
 }
 
 // ------------------------------------------------------------------------------ weight gradient
@@ -1099,8 +1105,8 @@ typedef short dw_v4s __attribute__((ext_vector_type(4)));
 template <int NI, int NJ, bool VEC>
 __global__ __launch_bounds__(256, 2) void sp_conv_wgrad_x9_kernel(const float* __restrict__ X, const float* __restrict__ G,
                                                                  const int32_t* __restrict__ map, int64_t n_rows,
-                                                                 int64_t rows_per_chunk, int cin, int cout,
-                                                                 float* __restrict__ partials) {
+                                                                 int64_t rows_per_chunk, int cin, int cout, int64_t xs,
+                                                                 int64_t gs, float* __restrict__ partials) {
     constexpr int CI = NI * 32, CO = NJ * 32;
     constexpr int TILES = NI * NJ;
     constexpr int TPW = TILES >= 4 ? TILES / 4 : 1;          // tiles per wave
@@ -1181,7 +1187,7 @@ __global__ __launch_bounds__(256, 2) void sp_conv_wgrad_x9_kernel(const float* _
         _Pragma("unroll") for (int e = 0; e < LX; ++e) {                                                             \
             const int t = tid + 256 * e, pp = t / (CI / 4), q = (t - pp * (CI / 4)) * 4;                             \
             const int pi = (P0) + pp < np ? (P0) + pp : 0;                                                           \
-            const float* src = X + (int64_t)pin[pi] * cin;                                                           \
+            const float* src = X + (int64_t)pin[pi] * xs;                                                            \
             if (VEC) xr[e] = *reinterpret_cast<const float4*>(src + (q < cin ? q : 0));                              \
             else xr[e] = make_float4(src[q < cin ? q : 0], src[q + 1 < cin ? q + 1 : 0], src[q + 2 < cin ? q + 2 : 0], \
                                      src[q + 3 < cin ? q + 3 : 0]);                                                  \
@@ -1189,7 +1195,7 @@ __global__ __launch_bounds__(256, 2) void sp_conv_wgrad_x9_kernel(const float* _
         _Pragma("unroll") for (int e = 0; e < LG; ++e) {                                                             \
             const int t = tid + 256 * e, pp = t / (CO / 4), q = (t - pp * (CO / 4)) * 4;                             \
             const int pi = (P0) + pp < np ? (P0) + pp : 0;                                                           \
-            const float* src = G + (r0 + pout[pi]) * cout;                                                           \
+            const float* src = G + (r0 + pout[pi]) * gs;                                                             \
             if (VEC) gr[e] = *reinterpret_cast<const float4*>(src + (q < cout ? q : 0));                             \
             else gr[e] = make_float4(src[q < cout ? q : 0], src[q + 1 < cout ? q + 1 : 0], src[q + 2 < cout ? q + 2 : 0], \
                                      src[q + 3 < cout ? q + 3 : 0]);                                                 \
@@ -1336,10 +1342,18 @@ extern "C" size_t gga_sparse_conv_wgrad_workspace_bytes(int64_t n_rows, int kvol
 extern "C" int gga_sparse_conv_wgrad_split(const float* x, const float* grad_out, const int32_t* map, int64_t n_rows,
                                            int kvol, int cin, int cout, float* grad_weight, void* workspace,
                                            size_t workspace_bytes, void* stream_) {
+    return gga_sparse_conv_wgrad_split_strided(x, cin, grad_out, cout, map, n_rows, kvol, cin, cout, grad_weight, workspace,
+                                               workspace_bytes, stream_);
+}
+
+extern "C" int gga_sparse_conv_wgrad_split_strided(const float* x, int64_t x_row_stride, const float* grad_out,
+                                                   int64_t grad_out_row_stride, const int32_t* map, int64_t n_rows, int kvol,
+                                                   int cin, int cout, float* grad_weight, void* workspace,
+                                                   size_t workspace_bytes, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     GGA_REQUIRE(x && grad_out && map && grad_weight && workspace, "gga_sparse_conv_wgrad_split: null pointer argument");
-    GGA_REQUIRE(n_rows >= 1 && kvol >= 1 && cin >= 1 && cin <= 128 && cout >= 1 && cout <= 128,
-                "gga_sparse_conv_wgrad_split: bad sizes (cin, cout <= 128)");
+    GGA_REQUIRE(n_rows >= 1 && kvol >= 1 && cin >= 1 && cin <= 128 && cout >= 1 && cout <= 128 && x_row_stride >= cin &&
+                grad_out_row_stride >= cout, "gga_sparse_conv_wgrad_split: bad sizes (cin, cout <= 128; row strides >= widths)");
     if (workspace_bytes < gga_sparse_conv_wgrad_workspace_bytes(n_rows, kvol, cin, cout)) {
         gga_set_error("gga_sparse_conv_wgrad_split: workspace %zu B < required %zu B", workspace_bytes,
                       gga_sparse_conv_wgrad_workspace_bytes(n_rows, kvol, cin, cout));
@@ -1350,11 +1364,12 @@ extern "C" int gga_sparse_conv_wgrad_split(const float* x, const float* grad_out
     const int nchunks = spw_chunks(n_rows, kvol);
     const int64_t rpc = spw_rows_per_chunk();                   // whole sub-chunks
     const dim3 grid(kvol, (unsigned)nchunks), block(256);
-    const bool vec = (cin & 3) == 0 && (cout & 3) == 0;
+    const bool vec = (cin & 3) == 0 && (cout & 3) == 0 && (x_row_stride & 3) == 0 && (grad_out_row_stride & 3) == 0 &&
+                     ((uintptr_t)x & 15) == 0 && ((uintptr_t)grad_out & 15) == 0;
     hipEvent_t* tev = gga_timing_acquire(GGA_TIME_SPARSE_WGRAD, GGA_TIMING_CONV_KEY(cin, cout, 0));
     GGA_TIME_START(tev, stream);
-#define SW(NI, NJ) { if (vec) hipLaunchKernelGGL((sp_conv_wgrad_x9_kernel<NI, NJ, true>), grid, block, 0, stream, x, grad_out, map, n_rows, rpc, cin, cout, (float*)workspace); \
-                     else hipLaunchKernelGGL((sp_conv_wgrad_x9_kernel<NI, NJ, false>), grid, block, 0, stream, x, grad_out, map, n_rows, rpc, cin, cout, (float*)workspace); }
+#define SW(NI, NJ) { if (vec) hipLaunchKernelGGL((sp_conv_wgrad_x9_kernel<NI, NJ, true>), grid, block, 0, stream, x, grad_out, map, n_rows, rpc, cin, cout, x_row_stride, grad_out_row_stride, (float*)workspace); \
+                     else hipLaunchKernelGGL((sp_conv_wgrad_x9_kernel<NI, NJ, false>), grid, block, 0, stream, x, grad_out, map, n_rows, rpc, cin, cout, x_row_stride, grad_out_row_stride, (float*)workspace); }
     if (ni == 1 && nj == 1) SW(1, 1)
     else if (ni == 1 && nj == 2) SW(1, 2)
     else if (ni == 2 && nj == 2) SW(2, 2)

@@ -141,4 +141,7 @@ def conv2d(x, conv, bn_follows=False):
         if bn_follows:
             y.bn_partials = stats
         return y
+    from . import strided_conv
+    if strided_conv.eligible(conv, x):        # stride-2 3x3, 1x1 and kernel = stride transposed convolutions
+        return strided_conv.conv(x, conv)
     return conv(x)

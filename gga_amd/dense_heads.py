@@ -158,7 +158,25 @@ class CenterHead_GGA(nn.Module):
     # ------------------------------------------------------------------ forward
     def forward_single(self, x):
         x = self.shared_conv(x)
-        return [task(x) for task in self.task_heads]
+        # training on the device: every branch of every task reads this one map - run them as one autograd node
+        # (functional._HeadBranches) so that its gradient is produced once instead of summed branch by branch
+        branches, keys = [], []
+        for ti, task in enumerate(self.task_heads):
+            for head in getattr(task, 'heads', ()):
+                mods = list(getattr(task, head))
+                if (isinstance(task, SeparateHead) and len(mods) == 2 and isinstance(mods[0], ConvModule) and mods[0].with_norm
+                        and mods[0].with_activation and isinstance(mods[0].norm, nn.modules.batchnorm._BatchNorm)
+                        and isinstance(mods[0].activate, nn.ReLU)):
+                    branches.append((mods[0].conv, mods[0].norm, mods[1]))
+                    keys.append((ti, head))
+        n_all = sum(len(getattr(task, 'heads', ())) for task in self.task_heads)
+        outs = F.head_branches(x, branches) if branches and len(branches) == n_all and self.training else None
+        if outs is None:
+            return [task(x) for task in self.task_heads]
+        ret = [dict() for _ in self.task_heads]
+        for (ti, head), y in zip(keys, outs):
+            ret[ti][head] = y
+        return ret
 
     def forward(self, feats):
         return multi_apply(self.forward_single, feats)

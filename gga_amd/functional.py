@@ -646,7 +646,7 @@ class _HeadConv3x3(torch.autograd.Function):
         cout = weight.shape[0]
         w = weight.contiguous()                       # logical [cout, 64, 3, 3], NCHW-contiguous
         y = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device)
-        check(_lib.lib().gga_head_conv3x3_fwd(_p(x), None, _p(w), _p(bias), B, H, W, C, cout, _p(y), _stream()),
+        check(_lib.lib().gga_head_conv3x3_fwd(_p(x), C, None, _p(w), _p(bias), B, H, W, C, cout, _p(y), _stream()),
               'gga_head_conv3x3_fwd')
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
@@ -668,7 +668,7 @@ class _HeadConv3x3(torch.autograd.Function):
             gb = torch.empty(cout, dtype=torch.float32, device=x.device) if ctx.has_bias else None
             L = _lib.lib()
             ws = _workspace('headconv', L.gga_head_conv3x3_workspace_bytes(cout), x.device)
-            check(L.gga_head_conv3x3_wgrad(_p(x), None, _p(gy), B, H, W, C, cout, _p(gw), _p(gb), _p(ws), ws.numel(),
+            check(L.gga_head_conv3x3_wgrad(_p(x), C, None, _p(gy), B, H, W, C, cout, _p(gw), _p(gb), _p(ws), ws.numel(),
                                            _stream()), 'gga_head_conv3x3_wgrad')
         return gx, gw, gb
 
@@ -698,7 +698,7 @@ class _BnReluHeadConv3x3(torch.autograd.Function):
             check(L.gga_bn_stats(_p(x), _p(gamma), _p(beta), _p(running_mean), _p(running_var), rows, C, eps, momentum,
                                  int(training), _p(saved), _p(ss), _p(ws), ws.numel(), _stream()), 'gga_bn_stats')
         y = torch.empty((B, cout, H, W), dtype=torch.float32, device=dev)
-        check(L.gga_head_conv3x3_fwd(_p(x), _p(ss), _p(w), _p(bias), B, H, W, C, cout, _p(y), _stream()),
+        check(L.gga_head_conv3x3_fwd(_p(x), C, _p(ss), _p(w), _p(bias), B, H, W, C, cout, _p(y), _stream()),
               'gga_head_conv3x3_fwd')
         ctx.save_for_backward(x, gamma, saved, ss, w)
         ctx.has_bias = bias is not None
@@ -715,14 +715,14 @@ class _BnReluHeadConv3x3(torch.autograd.Function):
         gw = torch.empty_like(w)
         gb = torch.empty(cout, dtype=torch.float32, device=dev) if ctx.has_bias else None
         ws = _workspace('headconv', L.gga_head_conv3x3_workspace_bytes(cout), dev)
-        check(L.gga_head_conv3x3_wgrad(_p(x), _p(ss), _p(gy), B, H, W, C, cout, _p(gw), _p(gb), _p(ws), ws.numel(),
+        check(L.gga_head_conv3x3_wgrad(_p(x), C, _p(ss), _p(gy), B, H, W, C, cout, _p(gw), _p(gb), _p(ws), ws.numel(),
                                        _stream()), 'gga_head_conv3x3_wgrad')
         # BatchNorm + ReLU backward with the conv's input gradient rebuilt from gy on the fly (never stored)
         gx = torch.empty_like(x)
         gg = torch.empty(C, dtype=torch.float32, device=dev)
         gbeta = torch.empty(C, dtype=torch.float32, device=dev)
         wsb = _workspace('bn', L.gga_bn_relu_workspace_bytes(rows, C), dev)
-        check(L.gga_head_tail_bwd(_p(gy), _p(x), _p(ss), _p(gamma), _p(saved), _p(w), B, H, W, C, cout, _p(gx), _p(gg), _p(gbeta),
+        check(L.gga_head_tail_bwd(_p(gy), _p(x), C, _p(ss), _p(gamma), _p(saved), _p(w), B, H, W, C, cout, _p(gx), C, _p(gg), _p(gbeta),
                                   _p(wsb), wsb.numel(), _stream()), 'gga_head_tail_bwd')
         return gx, gg, gbeta, None, None, gw, gb, None, None, None, None
 
@@ -743,6 +743,107 @@ def bn_relu_head_conv3x3(x, bn, conv):
         partials = None
     return _BnReluHeadConv3x3.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, conv.weight, conv.bias,
                                     float(bn.eps), float(bn.momentum), True, partials)
+
+
+class _HeadBranches(torch.autograd.Function):
+    """All branches ``conv3x3(64 -> c_i)(relu(bn_i(conv3x3(64 -> 64)_i(x))))`` of a CenterHead (every task's
+    SeparateHead, centerpoint_head.py:46-79) on the one shared feature map, as one autograd node.
+
+    Forward: per branch the bf16x6 convolution writes its 64 channels (and their BatchNorm sums) into a column
+    block of ONE [B, 64n, H, W] channels-last buffer, the statistics are folded, and the output conv normalises
+    while it loads. Backward: per branch the output conv's weight gradient and ``gga_head_tail_bwd``, which
+    writes the gradient w.r.t. the branch's column block of a second [B, 64n, H, W] buffer; then ONE
+    backward-data convolution 64n -> 64 and ONE weight-gradient call over all branches - where one node per
+    branch left autograd n - 1 full-size additions of the shared map's gradient."""
+
+    @staticmethod
+    def forward(ctx, x, n, cfg, *t):
+        from . import dense_conv
+        w1, gam, bet, rm, rv, w2, b2 = (t[i * n:(i + 1) * n] for i in range(7))
+        L = _lib.lib()
+        B, C, H, W = x.shape
+        rows, dev, tot = B * H * W, x.device, C * n
+        tr = dense_conv._transposed(H, W)
+        Y = torch.empty((B, tot, H, W), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
+        tiles = int(L.gga_dense_conv3x3_tiles(B, W, H, C) if tr else L.gga_dense_conv3x3_tiles(B, H, W, C))
+        stats = torch.empty((tiles, 2, C), dtype=torch.float64, device=dev)
+        outs, saved_all, ss_all = [], [], []
+        for i in range(n):
+            eps, momentum = cfg[i]
+            check(L.gga_dense_conv3x3_slice(_p(x), _p(dense_conv._pack(w1[i].detach(), False, tr)), B, H, W, C, C,
+                                            Y.data_ptr() + 4 * C * i, tot, int(tr), _p(stats), _stream()), 'gga_dense_conv3x3_slice')
+            saved = torch.empty(2 * C, dtype=torch.float32, device=dev)
+            ss = torch.empty(2 * C, dtype=torch.float32, device=dev)
+            check(L.gga_bn_stats_partials(_p(gam[i]), _p(bet[i]), _p(rm[i]), _p(rv[i]), rows, C, eps, momentum, _p(saved), _p(ss),
+                                          _p(stats), tiles, _stream()), 'gga_bn_stats_partials')
+            cout = w2[i].shape[0]
+            y = torch.empty((B, cout, H, W), dtype=torch.float32, device=dev)
+            check(L.gga_head_conv3x3_fwd(Y.data_ptr() + 4 * C * i, tot, _p(ss), _p(w2[i].contiguous()), _p(b2[i]), B, H, W, C, cout,
+                                         _p(y), _stream()), 'gga_head_conv3x3_fwd')
+            outs.append(y), saved_all.append(saved), ss_all.append(ss)
+        ctx.save_for_backward(x, Y, *w1, *gam, *w2, *saved_all, *ss_all)
+        ctx.n, ctx.has_bias = n, [b is not None for b in b2]
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gys):
+        from . import dense_conv
+        n = ctx.n
+        t = ctx.saved_tensors
+        x, Y = t[0], t[1]
+        w1, gam, w2, saved_all, ss_all = (t[2 + i * n:2 + (i + 1) * n] for i in range(5))
+        L = _lib.lib()
+        B, C, H, W = x.shape
+        rows, dev, tot = B * H * W, x.device, C * n
+        G = torch.empty_like(Y)
+        gw2, gb2, ggam, gbet = [], [], [], []
+        wsb = _workspace('bn', L.gga_bn_relu_workspace_bytes(rows, C), dev)
+        for i in range(n):
+            gy = gys[i].contiguous()
+            cout = w2[i].shape[0]
+            w = w2[i].contiguous()
+            gw = torch.empty_like(w)
+            gb = torch.empty(cout, dtype=torch.float32, device=dev) if ctx.has_bias[i] else None
+            ws = _workspace('headconv', L.gga_head_conv3x3_workspace_bytes(cout), dev)
+            check(L.gga_head_conv3x3_wgrad(Y.data_ptr() + 4 * C * i, tot, _p(ss_all[i]), _p(gy), B, H, W, C, cout, _p(gw), _p(gb), _p(ws),
+                                           ws.numel(), _stream()), 'gga_head_conv3x3_wgrad')
+            gg = torch.empty(C, dtype=torch.float32, device=dev)
+            gbeta = torch.empty(C, dtype=torch.float32, device=dev)
+            check(L.gga_head_tail_bwd(_p(gy), Y.data_ptr() + 4 * C * i, tot, _p(ss_all[i]), _p(gam[i]), _p(saved_all[i]), _p(w), B, H, W,
+                                      C, cout, G.data_ptr() + 4 * C * i, tot, _p(gg), _p(gbeta), _p(wsb), wsb.numel(), _stream()),
+                  'gga_head_tail_bwd')
+            gw2.append(gw), gb2.append(gb), ggam.append(gg), gbet.append(gbeta)
+        wcat = torch.cat([w.detach() for w in w1], dim=0)            # [64n, 64, 3, 3]
+        gx = dense_conv._run(G, wcat, True)[0] if ctx.needs_input_grad[0] else None
+        gwcat = dense_conv._wgrad(x, G, wcat)
+        gw1 = list(gwcat.split(C, dim=0))
+        none = [None] * n
+        return (gx, None, None, *gw1, *ggam, *gbet, *none, *none, *gw2, *gb2)
+
+
+def head_branches(x, branches):
+    """Outputs of the head branches ``[(conv1, bn, conv2), ...]`` that all read ``x`` (see _HeadBranches), or
+    None when a branch does not qualify for the fused kernels (the caller then runs them one by one)."""
+    from . import dense_conv
+    rc = _rows_channels(x) if (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4) else None
+    if rc is None or x.shape[1] != 64 or not torch.is_grad_enabled() or not dense_conv.ENABLED or not dense_conv.WGRAD:
+        return None
+    for conv1, bn, conv2 in branches:
+        ok = (dense_conv.eligible(conv1, x) and conv1.bias is None and conv1.out_channels == 64 and bn.affine
+              and bn.track_running_stats and bn.momentum is not None and bn.training and conv2.out_channels <= 4
+              and type(conv2) is torch.nn.Conv2d and conv2.in_channels == 64 and conv2.kernel_size == (3, 3)
+              and conv2.stride == (1, 1) and conv2.padding == (1, 1) and conv2.dilation == (1, 1) and conv2.groups == 1
+              and conv2.padding_mode == 'zeros')
+        if not ok:
+            return None
+    for _, bn, _ in branches:
+        bn.num_batches_tracked += 1
+    n = len(branches)
+    cfg = tuple((float(bn.eps), float(bn.momentum)) for _, bn, _ in branches)
+    cols = ([c1.weight for c1, _, _ in branches], [bn.weight for _, bn, _ in branches], [bn.bias for _, bn, _ in branches],
+            [bn.running_mean for _, bn, _ in branches], [bn.running_var for _, bn, _ in branches],
+            [c2.weight for _, _, c2 in branches], [c2.bias for _, _, c2 in branches])
+    return _HeadBranches.apply(x, n, cfg, *[t for col in cols for t in col])
 
 
 def head_conv3x3(x, conv):

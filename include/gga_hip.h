@@ -302,6 +302,13 @@ int gga_sparse_pack_weight_split(const float* weight, int kvol, int cin, int cou
 int gga_sparse_conv_apply_split(const float* x, const int32_t* map, const void* split_weight, const int32_t* perm,
                                 const uint32_t* rowmask, int64_t n_rows, int kvol, int cin, int cout, int flip,
                                 float* y, void* stream);
+/* The same with y a column block of a wider [n_rows, y_row_stride] matrix. With an arithmetic rule book over the
+ * pixels of a channels-last image this gather-GEMM is also the stride-2 3x3 convolution of a SECOND stage
+ * (mmdet3d/models/backbones/second.py:49-57) and the kernel = stride transposed convolution of SECONDFPN
+ * (necks/second_fpn.py:52-69), forward and backward-data (gga_amd/strided_conv.py). */
+int gga_sparse_conv_apply_split_strided(const float* x, const int32_t* map, const void* split_weight,
+                                        const int32_t* perm, const uint32_t* rowmask, int64_t n_rows, int kvol, int cin,
+                                        int cout, int flip, float* y, int64_t y_row_stride, void* stream);
 
 /* Dense 3x3 / stride 1 / zero-pad 1 convolution of a channels-last image on the same bf16x9
  * path: x [B,H,W,cin] (cin a multiple of 32), y [B,H,W,cout] (cout 64 or 128), split_weight =
@@ -360,6 +367,10 @@ size_t gga_sparse_conv_wgrad_workspace_bytes(int64_t n_rows, int kvol, int cin, 
 int gga_sparse_conv_wgrad_split(const float* x, const float* grad_out, const int32_t* nbr, int64_t n_rows,
                                 int kvol, int cin, int cout, float* grad_weight, void* workspace,
                                 size_t workspace_bytes, void* stream);
+/* The same with x / grad_out column blocks (<= 128 wide) of wider matrices: row strides in floats. */
+int gga_sparse_conv_wgrad_split_strided(const float* x, int64_t x_row_stride, const float* grad_out,
+                                        int64_t grad_out_row_stride, const int32_t* nbr, int64_t n_rows, int kvol, int cin,
+                                        int cout, float* grad_weight, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------- */
 /* a4/a5 (elementwise part). Fused training-mode BatchNorm (+ residual add)   */
@@ -424,27 +435,29 @@ int gga_bn_stats_partials(const float* gamma, const float* beta, float* running_
 /* a5 (output convs of the head branches): 3x3 conv, 64 input channels -> 1..4 output channels,
  * stride 1, pad 1, + bias. Replaces the last layer of each SeparateHead branch,
  * mmdet3d/models/dense_heads/centerpoint_head.py:70-79 (HBM-bound; N = 9 taps x cout on the
- * matrix cores). x: channels-last memory [B,H,W,64] of a [B,64,H,W] tensor; weight [cout,64,3,3];
+ * matrix cores). x: channels-last memory [B,H,W,64] of a [B,64,H,W] tensor, or a 64-channel column block of
+ * a wider one (x_pixel_stride floats between pixels, 64 when dense); weight [cout,64,3,3];
  * y [B,cout,H,W] NCHW-contiguous. in_scale_shift (optional, [2*64]): the convolution input is
  * relu(x * scale + shift) per channel, applied while loading - the BatchNorm + ReLU of the
  * branch's ConvModule (centerpoint_head.py:58-68) fused into its consumer. */
-int gga_head_conv3x3_fwd(const float* x, const float* in_scale_shift, const float* weight, const float* bias,
-                         int B, int H, int W, int cin, int cout, float* y, void* stream);
+int gga_head_conv3x3_fwd(const float* x, int64_t x_pixel_stride, const float* in_scale_shift, const float* weight,
+                         const float* bias, int B, int H, int W, int cin, int cout, float* y, void* stream);
 /* grad_weight [cout,64,3,3] and grad_bias [cout] (optional) from grad_y [B,cout,H,W] */
 size_t gga_head_conv3x3_workspace_bytes(int cout);
-int gga_head_conv3x3_wgrad(const float* x, const float* in_scale_shift, const float* grad_y, int B, int H, int W,
-                           int cin, int cout,
-                           float* grad_weight, float* grad_bias, void* workspace, size_t workspace_bytes,
-                           void* stream);
+int gga_head_conv3x3_wgrad(const float* x, int64_t x_pixel_stride, const float* in_scale_shift, const float* grad_y,
+                           int B, int H, int W, int cin, int cout, float* grad_weight, float* grad_bias,
+                           void* workspace, size_t workspace_bytes, void* stream);
 
 /* Backward of the whole branch tail BatchNorm(training) -> ReLU -> this conv w.r.t. the BatchNorm input x
  * (centerpoint_head.py:58-79 under autograd): grad_x [B,H,W,64], grad_gamma / grad_beta [64] (optional) from
  * grad_y [B,cout,H,W], the conv weight and the statistics gga_bn_stats left (saved = mean / invstd,
  * scale_shift). The conv's input gradient is rebuilt from grad_y inside the two BatchNorm-backward passes and
- * never stored. workspace: gga_bn_relu_workspace_bytes(B*H*W, 64). */
-int gga_head_tail_bwd(const float* grad_y, const float* x, const float* scale_shift, const float* gamma,
-                      const float* saved, const float* weight, int B, int H, int W, int cin, int cout, float* grad_x,
-                      float* grad_gamma, float* grad_beta, void* workspace, size_t workspace_bytes, void* stream);
+ * never stored. x / grad_x may be 64-channel column blocks of wider tensors (pixel strides in floats).
+ * workspace: gga_bn_relu_workspace_bytes(B*H*W, 64). */
+int gga_head_tail_bwd(const float* grad_y, const float* x, int64_t x_pixel_stride, const float* scale_shift,
+                      const float* gamma, const float* saved, const float* weight, int B, int H, int W, int cin, int cout,
+                      float* grad_x, int64_t grad_x_pixel_stride, float* grad_gamma, float* grad_beta, void* workspace,
+                      size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------- */
 /* a6/a7. Heat-map target splat on the device.                                */

@@ -476,6 +476,56 @@ def test_bn_relu_head_conv_fused_vs_torch(cout):
         torch.testing.assert_close(F.bn_relu_head_conv3x3(x, bn, conv), conv_r(torch.relu(bn_r(x))), rtol=1e-4, atol=1e-4)
 
 
+def test_head_branches_one_node_vs_branch_by_branch():
+    """All branches of a head on one shared map as one autograd node (functional._HeadBranches: column blocks
+    of one buffer, one backward-data, one weight-gradient call) against the same branches run one by one and
+    against eager torch."""
+    import copy
+    from gga_amd import dense_conv
+    torch.manual_seed(21)
+    B, H, W, couts = 2, 37, 45, (2, 1, 3, 2, 1)
+
+    def make():
+        torch.manual_seed(22)
+        out = []
+        for c in couts:
+            conv1 = torch.nn.Conv2d(64, 64, 3, padding=1, bias=False).to(DEV).to(memory_format=torch.channels_last)
+            bn = torch.nn.BatchNorm2d(64, eps=1e-3, momentum=0.01).to(DEV)
+            bn.weight.data.uniform_(0.5, 1.5), bn.bias.data.uniform_(-0.5, 0.5)
+            out.append((conv1, bn, torch.nn.Conv2d(64, c, 3, padding=1, bias=True).to(DEV)))
+        return out
+    x = torch.randn(B, 64, H, W, device=DEV).contiguous(memory_format=torch.channels_last)
+    gs = [torch.randn(B, c, H, W, device=DEV) for c in couts]
+    results = []
+    for mode in ('node', 'single', 'eager'):
+        br = make()
+        xi = x.clone().requires_grad_(True)
+        if mode == 'node':
+            ys = F.head_branches(xi, br)
+            assert ys is not None and 'HeadBranches' in type(ys[0].grad_fn).__name__
+        elif mode == 'single':
+            ys = [F.bn_relu_head_conv3x3(dense_conv.conv2d(xi, c1, bn_follows=True), bn, c2) for c1, bn, c2 in br]
+        else:
+            ys = [c2(torch.relu(bn(c1(xi)))) for c1, bn, c2 in br]
+        sum((y * g).sum() for y, g in zip(ys, gs)).backward()
+        results.append((ys, xi.grad, br))
+    (y_n, gx_n, br_n), (y_s, gx_s, br_s), (y_e, gx_e, br_e) = results
+    for i in range(len(couts)):
+        assert torch.equal(y_n[i], y_s[i])                        # same kernels, same order of operations
+        torch.testing.assert_close(y_n[i], y_e[i], rtol=1e-4, atol=1e-4)
+        for j in (0, 2):
+            torch.testing.assert_close(br_n[i][j].weight.grad, br_s[i][j].weight.grad, rtol=1e-5, atol=1e-5)
+            torch.testing.assert_close(br_n[i][j].weight.grad, br_e[i][j].weight.grad, rtol=2e-3, atol=2e-3)
+        torch.testing.assert_close(br_n[i][2].bias.grad, br_e[i][2].bias.grad, rtol=1e-4, atol=1e-3)
+        torch.testing.assert_close(br_n[i][1].weight.grad, br_e[i][1].weight.grad, rtol=1e-3, atol=2e-3)
+        torch.testing.assert_close(br_n[i][1].bias.grad, br_e[i][1].bias.grad, rtol=1e-3, atol=2e-3)
+        torch.testing.assert_close(br_n[i][1].running_var, br_e[i][1].running_var, rtol=1e-5, atol=1e-6)
+        assert int(br_n[i][1].num_batches_tracked) == 1
+    torch.testing.assert_close(gx_n, gx_s, rtol=1e-4, atol=1e-4)
+    scale = float(gx_e.abs().max())
+    assert int(((gx_n - gx_e).abs() > 1e-4 * scale).sum()) <= 10      # ReLU-boundary elements may flip
+
+
 # ----------------------------------------------------------------------------- first conv on the canvas
 def _pillar_case(B, ny, nx, M, C, seed):
     g = torch.Generator().manual_seed(seed)
@@ -630,6 +680,51 @@ def test_dense_conv_leaves_batchnorm_partials(cin, cout, B, H, W):
     g = torch.randn_like(out)
     out.backward(g)
     assert conv.weight.grad is not None and torch.isfinite(conv.weight.grad).all()
+
+
+@pytest.mark.parametrize('kind,cin,cout,k,s,B,H,W', [('conv', 64, 128, 3, 2, 2, 37, 45), ('conv', 128, 256, 3, 2, 2, 24, 30),
+                                                      ('conv', 64, 64, 3, 2, 1, 40, 32), ('conv', 384, 64, 1, 1, 1, 20, 24),
+                                                      ('deconv', 64, 128, 1, 1, 2, 37, 45), ('deconv', 128, 128, 2, 2, 2, 19, 23),
+                                                      ('deconv', 256, 128, 4, 4, 2, 9, 11), ('deconv', 256, 256, 2, 2, 1, 8, 8)])
+def test_strided_and_transposed_convs_vs_torch(kind, cin, cout, k, s, B, H, W):
+    """The SECOND stage openers (3x3 / stride 2) and the SECONDFPN transposed convolutions (kernel = stride) on
+    the gather-GEMM kernels (gga_amd/strided_conv.py): output, input gradient and weight gradient against
+    float64 torch, next to the framework's own fp32 convolution."""
+    from gga_amd import dense_conv, strided_conv
+    torch.manual_seed(5)
+    if kind == 'conv':
+        m = torch.nn.Conv2d(cin, cout, k, s, k // 2, bias=False)
+    else:
+        m = torch.nn.ConvTranspose2d(cin, cout, k, s, bias=False)
+    m = m.to(DEV).to(memory_format=torch.channels_last)
+    x = torch.randn(B, cin, H, W, device=DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    assert strided_conv.eligible(m, x)
+    y = dense_conv.conv2d(x, m)
+    assert type(y.grad_fn).__name__ in ('_StridedConvBackward', '_DeconvBackward')
+    assert y.is_contiguous(memory_format=torch.channels_last)
+    g = torch.randn_like(y)
+    y.backward(g)
+    gx, gw = x.grad.clone(), m.weight.grad.clone()
+    m64 = type(m)(cin, cout, k, s, k // 2 if kind == 'conv' else 0, bias=False).to(DEV).double()
+    m64.weight.data.copy_(m.weight.data.double())
+    x64 = x.detach().double().requires_grad_(True)
+    y64 = m64(x64)
+    y64.backward(g.double())
+    x.grad = None
+    m.weight.grad = None
+    y32 = m(x)
+    y32.backward(g)
+    rel = lambda a, b: float((a.detach().double() - b.detach()).abs().max() / b.detach().abs().max())
+    for name, mine, ref, fw in (('y', y, y64, y32), ('gx', gx, x64.grad, x.grad), ('gw', gw, m64.weight.grad, m.weight.grad)):
+        assert mine.shape == ref.shape, name
+        e, e32 = rel(mine, ref), rel(fw, ref)
+        assert e <= max(3e-6, 2 * e32), (name, e, e32)
+    # run-to-run identical (no atomics anywhere on this path)
+    x.grad = None
+    m.weight.grad = None
+    y2 = dense_conv.conv2d(x, m)
+    y2.backward(g)
+    assert torch.equal(y2, y) and torch.equal(x.grad, gx) and torch.equal(m.weight.grad, gw)
 
 
 def test_dense_conv3x3_non_finite_and_wide_range():

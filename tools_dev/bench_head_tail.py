@@ -35,7 +35,7 @@ for cout in (1, 2, 3):
     gx2, gg2, gb2 = torch.empty_like(x), torch.empty(C, device=DEV), torch.empty(C, device=DEV)
 
     def fused():
-        _lib.check(L.gga_head_tail_bwd(F._p(gy), F._p(x), F._p(ss), F._p(gamma), F._p(saved), F._p(w), B, H, W, C, cout, F._p(gx),
+        _lib.check(L.gga_head_tail_bwd(F._p(gy), F._p(x), C, F._p(ss), F._p(gamma), F._p(saved), F._p(w), B, H, W, C, cout, F._p(gx), C,
                                        F._p(gg), F._p(gb), F._p(ws), ws.numel(), F._stream()), 'tail')
 
     def split():

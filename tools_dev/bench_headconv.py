@@ -33,7 +33,7 @@ for cout in (1, 3):
     w = conv.weight.detach().contiguous()
     gw = torch.empty_like(w); gb = torch.empty(cout, device=dev)
     ws = torch.empty(L.gga_head_conv3x3_workspace_bytes(cout), dtype=torch.uint8, device=dev)
-    t_wg = timeit(lambda: L.gga_head_conv3x3_wgrad(F._p(x), F._p(g), B, H, W, 64, cout, F._p(gw), F._p(gb), F._p(ws), ws.numel(), F._stream()))
+    t_wg = timeit(lambda: L.gga_head_conv3x3_wgrad(F._p(x), 64, None, F._p(g), B, H, W, 64, cout, F._p(gw), F._p(gb), F._p(ws), ws.numel(), F._stream()))
     t_gx = timeit(lambda: torch.ops.aten.convolution_backward(g, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [True, False, False]))
     t_gw = timeit(lambda: torch.ops.aten.convolution_backward(g, x, w, [cout], [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, True]))
     print(f'cout={cout}: my wgrad {t_wg:.0f} us | aten grad_input only {t_gx:.0f} us | aten grad_weight+bias {t_gw:.0f} us')

@@ -3,7 +3,7 @@
 The canvas of ``PointPillarsScatter`` (pillar_scatter.py:58-102) is zero except at the occupied
 cells (~7 % at KITTI sizes), and its gradient is read back only there (the scatter's backward is a
 gather). The forward of the convolution that consumes it (second.py:49-57, block 0, conv 0) is the
-plain dense convolution; its backward needs
+plain dense convolution (run as strided_conv.py's gather-GEMM over the canvas rows); its backward needs
 
 * the input gradient only at the occupied cells,
 * the weight gradient ``sum_cells x^T gy``, where ``x`` is non-zero only at the occupied cells,
@@ -47,7 +47,18 @@ def eligible(conv, canvas):
 class _PillarConv2d(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feats, weight, canvas, coors, num_valid, stride, padding):
-        y = torch.conv2d(canvas, weight, None, stride, padding)
+        from . import strided_conv
+        kh, kw = weight.shape[2:]
+        if (strided_conv.ENABLED and kh == kw and stride[0] == stride[1] and padding[0] == padding[1] and stride[0] > 1
+                and kh <= 5 and weight.shape[0] % 4 == 0):
+            # the dense forward as a gather-GEMM over the canvas rows (strided_conv.py): no framework convolution
+            B, Ci, ny, nx = canvas.shape
+            bk = strided_conv.book(B, ny, nx, kh, stride[0], padding[0], canvas.device)
+            y = strided_conv._apply(strided_conv._rows(canvas), bk.fwd, bk.fwd_mask, bk.fwd_perm,
+                                    weight.detach().permute(2, 3, 1, 0).reshape(kh * kw, Ci, -1), bk.n_out)
+            y = y.view(B, bk.Ho, bk.Wo, -1).permute(0, 3, 1, 2)
+        else:
+            y = torch.conv2d(canvas, weight, None, stride, padding)
         ctx.save_for_backward(feats, weight, coors, num_valid)
         ctx.geom = (tuple(canvas.shape), stride, padding)
         return y

@@ -188,3 +188,29 @@ def gradient_offenders(named_grads, ref32, ref64, tol=1e-3, slack=2.0):
         if err > max(tol, slack * floor):
             bad.append((name, err, floor))
     return bad
+
+
+# ----------------------------------------------------------------------------- optimizer schedule (a15)
+def cyclic_value(base, it, max_iters, target_ratio, cyclic_times=1, step_ratio_up=0.4):
+    """mmcv 1.x ``CyclicLrUpdaterHook`` / ``CyclicMomentumUpdaterHook`` by iteration (mmcv/runner/hooks/lr_updater.py,
+    momentum_updater.py; the wheel is un-vendored - restated from the published algorithm, parity unpinned):
+    two cosine phases per cycle, base -> base*target_ratio[0] over the first ``step_ratio_up`` of the cycle, then
+    -> base*target_ratio[1]. Independent of gga_amd.train.CyclicSchedule (the tests compare the two)."""
+    import math
+    per_cycle = max_iters // cyclic_times
+    up_end = int(step_ratio_up * per_cycle)
+    cur = it % per_cycle
+    if cur < up_end:
+        start, end, frac = base, base * target_ratio[0], cur / up_end
+    else:
+        start, end, frac = base * target_ratio[0], base * target_ratio[1], (cur - up_end) / (per_cycle - up_end)
+    return end + 0.5 * (start - end) * (math.cos(math.pi * frac) + 1.0)
+
+
+def step_value(base, it, steps, gamma=0.1, warmup_iters=0, warmup_ratio=0.1):
+    """mmcv ``StepLrUpdaterHook`` with linear warm-up by iteration (lr_updater.py: regular lr = base * gamma^k with k
+    the number of milestones passed; during warm-up multiplied by 1 - (1 - it/warmup_iters)(1 - warmup_ratio))."""
+    lr = base * gamma ** sum(1 for m in steps if it >= m)
+    if it < warmup_iters:
+        lr *= 1.0 - (1.0 - it / warmup_iters) * (1.0 - warmup_ratio)
+    return lr

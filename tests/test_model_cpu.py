@@ -144,6 +144,21 @@ def test_cyclic_schedule():
     assert m(400) == pytest.approx(0.85) and m(0) == pytest.approx(0.95)
 
 
+def test_schedules_match_the_oracle_restatement():
+    """The product's schedules (gga_amd/train.py) against the oracle's independent restatement of mmcv's cyclic and
+    step hooks (oracle/torch_ref.py) at every iteration of a run."""
+    from gga_amd.train import StepSchedule
+    from oracle import torch_ref as R
+    for base, n, ratio, times, up in ((1.5e-3, 1000, (10, 1e-4), 1, 0.4), (0.95, 1000, (0.85 / 0.95, 1), 1, 0.4),
+                                      (1e-3, 990, (8, 1e-3), 3, 0.3), (0.9, 77, (0.8, 1.0), 1, 0.5)):
+        s = CyclicSchedule(base, n, ratio, times, up)
+        for it in range(n):
+            assert s(it) == pytest.approx(R.cyclic_value(base, it, n, ratio, times, up), rel=1e-12, abs=0), (base, it)
+    st = StepSchedule(1e-3, [32, 44], iters_per_epoch=25, gamma=0.1, warmup='linear', warmup_iters=500, warmup_ratio=1 / 3)
+    for it in range(0, 48 * 25):
+        assert st(it) == pytest.approx(R.step_value(1e-3, it, [32 * 25, 44 * 25], 0.1, 500, 1 / 3), rel=1e-12), it
+
+
 def test_synthetic_frame_contract():
     f = synthetic.make_frame(3)
     g = synthetic.make_frame(3)

@@ -138,7 +138,7 @@ def test_runner_steps_and_loss_decreases():
 def test_multi_step_trajectory_matches_cpu_restatement():
     """several optimizer steps of the GPU path against the CPU restatement with the
     same weights, batches, SRL draws (same torch seed), schedule, clipping and AdamW."""
-    from gga_amd.train import Runner, CyclicSchedule, build_optimizer
+    from gga_amd.train import Runner
     cfg = Config.fromfile(PP_CFG)
     torch.manual_seed(7)
     model = build_model(cfg.model)
@@ -151,11 +151,14 @@ def test_multi_step_trajectory_matches_cpu_restatement():
     B, n_steps = 2, 3
     batches = [synthetic.make_batch(B, start=70 + 10 * i, n_points=4000, pc_range=synthetic.RANGE_PP, n_obj_range=(4, 8),
                                     n_ibp_range=(10, 150)) for i in range(2)]
-    # CPU restatement: the same loop as Runner.step around oracle/torch_ref.reference_train_step
+    # CPU restatement, none of it through the product: plain torch AdamW with the config's values, the oracle's own
+    # restatement of mmcv's cyclic lr / momentum hooks, torch's gradient clipping, oracle/torch_ref's train step
     torch.manual_seed(123)
-    opt = build_optimizer(ref, cfg.optimizer)
-    lr_s = CyclicSchedule(cfg.optimizer['lr'], 100, (10, 1e-4), 1, 0.4)
-    mo_s = CyclicSchedule(cfg.optimizer['betas'][0], 100, (0.85 / 0.95, 1), 1, 0.4)
+    oc = cfg.optimizer
+    assert oc['type'] == 'AdamW' and 'paramwise_cfg' not in oc
+    opt = torch.optim.AdamW(ref.parameters(), lr=oc['lr'], betas=tuple(oc['betas']), weight_decay=oc['weight_decay'])
+    lr_s = lambda it: R.cyclic_value(oc['lr'], it, 100, (10, 1e-4), 1, 0.4)
+    mo_s = lambda it: R.cyclic_value(oc['betas'][0], it, 100, (0.85 / 0.95, 1), 1, 0.4)
     ref_losses = []
     for it in range(n_steps):
         for g in opt.param_groups:

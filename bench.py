@@ -40,8 +40,11 @@ sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (guides/MI355X_MICROARCH.md); ~6300 achievable
 BF16_PEAK_TFLOPS = 2500.0
-ARITH = ('fp32 in / fp32 out; dense + sparse convolutions multiply as six bf16 x bf16 MFMA partial products of '
-         'truncation-split operands, fp32 accumulate (error vs float64 <= MIOpen fp32); everything else plain fp32')
+ARITH = ('fp32 in / fp32 out, fp32 accumulate. Dense 3x3 convolutions: operands scaled by a power of two to their largest '
+         'magnitude and split into two round-to-nearest fp16 planes (22-bit significands), three f16 MFMA partial products '
+         '(error vs float64 <= MIOpen fp32; per element an absolute accuracy of 2^-39 of its tensor\'s largest magnitude; '
+         'GGA_DENSE_PLANES=3 selects three bf16 planes / six products with fp32\'s full exponent range). Sparse, strided and '
+         'transposed convolutions: three bf16 planes, six bf16 MFMA partial products. Everything else plain fp32')
 PP_CONFIG = os.path.join(REPO, 'configs', 'gga', 'gga_kitti_pointpillars_config.py')
 SECOND_CONFIG = os.path.join(REPO, 'configs', 'gga', 'gga_kitti_config.py')
 PGD_CONFIG = os.path.join(REPO, 'configs', 'gga', 'gga_pdg.py')
@@ -243,11 +246,15 @@ def scatter_roofline(model, batches, step_ms):
 
 
 def mfma_roofline(kernel, flops, ms_list, launches_per_step, ms_per_step):
-    """bf16 matrix work issued = 6 x the fp32 FLOPs (six partial products); peak = dense bf16 MFMA."""
+    """16-bit matrix work issued = products x the fp32 FLOPs (three partial products on two fp16 planes, six on three
+    bf16 planes); peak = dense bf16 / f16 MFMA (the same rate)."""
+    from gga_amd import dense_conv
+    products = 3 if dense_conv.PLANES == 2 else 6
     avg = sum(ms_list) / len(ms_list)
-    tf = 6 * flops / (avg * 1e-3) / 1e12
+    tf = products * flops / (avg * 1e-3) / 1e12
     return {'bound': 'mfma', 'kernel': kernel, 'achieved': round(tf, 1), 'peak': BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-            'frac': round(tf / BF16_PEAK_TFLOPS, 4), 'fp32_equivalent_tflops': round(flops / (avg * 1e-3) / 1e12, 1),
+            'frac': round(tf / BF16_PEAK_TFLOPS, 4), 'partial_products': products,
+            'fp32_equivalent_tflops': round(flops / (avg * 1e-3) / 1e12, 1),
             'kernel_ms': round(avg, 4), 'launches_timed': len(ms_list), 'launches_per_step': launches_per_step,
             'timed': 'in-step, HIP events on the launch stream',
             # mean kernel time x launches per step (independent of how many launches the session sampled)

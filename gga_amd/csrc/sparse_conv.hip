@@ -21,6 +21,7 @@
 #include <stdlib.h>
 
 #include "gga_common.h"
+#include <hip/hip_fp16.h>
 
 #define SP_EMPTY 0xFFFFFFFFFFFFFFFFull
 
@@ -672,6 +673,66 @@ __device__ __forceinline__ void x9_split2(float a, float b, uint32_t& w1, uint32
     w3 = __builtin_amdgcn_perm(__float_as_uint(sb), __float_as_uint(sa), 0x07060302u);
 }
 
+// ---- fp32 through TWO fp16 planes (the dense kernels' default arithmetic, NP = 2) ---------------------------------
+// With a power-of-two scale s that puts the tensor's largest finite magnitude into [2^14, 2^15), v = x * s (exact) is
+// h0 + h1 + r with h0 = fp16(v), h1 = fp16(v - h0), both round-to-nearest: |r| <= max(2^-22 |v|, 2^-25) - 22 significand
+// bits where bf16 needs three planes for 24, and (a0 + a1)(b0 + b1) needs THREE matrix products (a1 * b1 < 2^-21 |ab| is
+// dropped) instead of six. What fp16 does not have is fp32's exponent range: an element is kept to an ABSOLUTE accuracy of
+// 2^-39 of its tensor's largest magnitude, so its relative accuracy falls below 2^-22 once it is smaller than 2^-17 of
+// that maximum. For a sum of products that is an error of at most ~1e-12 * max|a| * sum|b| - far below the fp32
+// accumulation error - but it is not fp32's element-wise semantics for tensors spanning more than ~2^38 in magnitude
+// (test_dense_conv3x3_arithmetic_contract). Non-finite inputs: Inf splits into Inf + NaN, as on the bf16 path.
+typedef _Float16 mf_v8h __attribute__((ext_vector_type(8)));
+
+// scale 2^(14 - floor(log2(amax))) from the bits of the largest finite magnitude (0: empty / all-zero tensor -> 1)
+__device__ __forceinline__ int h2_scale_exp(uint32_t amax_bits) {
+    const int e = (int)((amax_bits >> 23) & 0xFF);
+    if (e == 0) return 127;
+    const int sb = 268 - e;
+    return sb < 2 ? 2 : (sb > 252 ? 252 : sb);
+}
+__device__ __forceinline__ float h2_scale(int sb) { return __uint_as_float((uint32_t)sb << 23); }
+__device__ __forceinline__ float h2_descale(int sb) { return __uint_as_float((uint32_t)(254 - sb) << 23); }
+// two scaled values at once: word p = {plane p of b, plane p of a} (a in the low half)
+__device__ __forceinline__ void h2_split2(float a, float b, uint32_t& w0, uint32_t& w1) {
+    const __half2 h0 = __floats2half2_rn(a, b);
+    const float2 f0 = __half22float2(h0);
+    const __half2 h1 = __floats2half2_rn(a - f0.x, b - f0.y);       // exact differences
+    w0 = *reinterpret_cast<const uint32_t*>(&h0);
+    w1 = *reinterpret_cast<const uint32_t*>(&h1);
+}
+
+// largest finite |x| of a [rows, width] matrix (row stride in floats), as float bits, by atomicMax into *out (zeroed first)
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, int64_t rows, int width4, int64_t row_stride,
+                                                    uint32_t* __restrict__ out) {
+    const int64_t n4 = rows * width4;
+    uint32_t m = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const int64_t rrow = i / width4;
+        const float4 v = *reinterpret_cast<const float4*>(x + rrow * row_stride + (i - rrow * width4) * 4);
+        const uint32_t u[4] = {__float_as_uint(v.x) & 0x7FFFFFFFu, __float_as_uint(v.y) & 0x7FFFFFFFu,
+                               __float_as_uint(v.z) & 0x7FFFFFFFu, __float_as_uint(v.w) & 0x7FFFFFFFu};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (u[j] < 0x7F800000u && u[j] > m) m = u[j];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const uint32_t t = __shfl_xor(m, o, 64); m = t > m ? t : m; }
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+
+extern "C" int gga_absmax_bits(const float* x, int64_t rows, int width, int64_t row_stride, uint32_t* out_bits, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    GGA_REQUIRE(x && out_bits && rows >= 0 && width >= 4 && width % 4 == 0 && row_stride >= width && row_stride % 4 == 0 &&
+                    ((uintptr_t)x & 15) == 0, "gga_absmax_bits: need a 16-byte aligned matrix with width and row stride %% 4 == 0");
+    GGA_CHECK_HIP(hipMemsetAsync(out_bits, 0, sizeof(uint32_t), stream), "gga_absmax_bits: memset");
+    if (rows == 0) return GGA_OK;
+    const int64_t n4 = rows * (width / 4);
+    int64_t nb = (n4 + 256 * 8 - 1) / (256 * 8);
+    nb = nb < 1 ? 1 : (nb > 2048 ? 2048 : nb);
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)nb), dim3(256), 0, stream, x, rows, width / 4, row_stride, out_bits);
+    GGA_CHECK_LAUNCH("absmax_kernel");
+    return GGA_OK;
+}
 
 // packed[k][chunk][plane][col < CO][32 ch] bf16 = plane of W[k][chunk*32 + ch][col], CO = 32 * nt
 __global__ __launch_bounds__(256) void sp_pack_weight_split_kernel(const float* __restrict__ W, int kvol, int cin, int cout,
@@ -855,7 +916,9 @@ __global__ __launch_bounds__(64 * X9_NW) void sp_conv_x9_kernel(const float* __r
                     // the nine partial products, smallest first; the column tiles are the inner loop so
                     // that consecutive MFMAs never wait for each other's accumulator
 #define X9_MM(PA, PB) _Pragma("unroll") for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA].v, b[t][PB], acc[t], 0, 0, 0);
-#ifndef X9_NINE
+#if defined(X9_THREE)
+                    X9_MM(0, 1) X9_MM(1, 0) X9_MM(0, 0)
+#elif !defined(X9_NINE)
                     X9_MM(0, 2) X9_MM(1, 1) X9_MM(2, 0) X9_MM(0, 1) X9_MM(1, 0) X9_MM(0, 0)       // six terms, see the dense kernels
 #else
                     X9_MM(2, 2) X9_MM(1, 2) X9_MM(2, 1) X9_MM(0, 2) X9_MM(1, 1) X9_MM(2, 0) X9_MM(0, 1) X9_MM(1, 0) X9_MM(0, 0)
@@ -1224,6 +1287,11 @@ __global__ __launch_bounds__(256, 2) void sp_conv_wgrad_x9_kernel(const float* _
             if (pp < PAIRS) SW_SPLIT_STORE(v, Gs + (BUF) * GSZ, GPL, pp, q >> 2)                                     \
         }
 #define SW_MM(PA, PB) _Pragma("unroll") for (int t = 0; t < TPW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PA.v, PB[t].v, acc[t], 0, 0, 0);
+#ifdef X9_THREE
+#define SW_MM3(A, B, C, D, E, F_)
+#else
+#define SW_MM3(A, B, C, D, E, F_) SW_MM(A, B) SW_MM(C, D) SW_MM(E, F_)
+#endif
 #define SW_COMPUTE(BUF)                                                                                              \
         if (wactive) {                                                                                               \
             const unsigned char* xbase = Xs + (BUF) * XSZ + i0 * (PAIRS * 64);                                       \
@@ -1242,7 +1310,7 @@ __global__ __launch_bounds__(256, 2) void sp_conv_wgrad_x9_kernel(const float* _
                 }                                                                                                    \
                 /* six partial products, smallest first; tiles are the inner loop so consecutive MFMAs never wait */ \
                 /* for each other's accumulator */                                                                   \
-                SW_MM(a0, g2) SW_MM(a1, g1) SW_MM(a2, g0) SW_MM(a0, g1) SW_MM(a1, g0) SW_MM(a0, g0)                  \
+                SW_MM3(a0, g2, a1, g1, a2, g0) SW_MM(a0, g1) SW_MM(a1, g0) SW_MM(a0, g0)                                \
             }                                                                                                        \
         }
         // The gathers are latency-bound (512-byte rows at random): a stage's loads are issued TWO stages
@@ -1417,11 +1485,15 @@ extern "C" int gga_sparse_conv_wgrad_split_strided(const float* x, int64_t x_row
 #define DC_ROWB 48                           // bytes per LDS row (16 bf16 + pad)
 #define DC_NA ((DC_HP * 4 + 255) / 256)      // float4 pieces per thread and chunk (6)
 
-template <int NT, int TR>
+// NP = 3: three bf16 planes, six partial products (any fp32 input). NP = 2: two fp16 planes of the scaled operands, three
+// partial products (see h2_split2); `amax` then points to {bits of max finite |x|, bits of max finite |w|}.
+template <int NT, int TR, int NP>
 __global__ __launch_bounds__(TR * 32, 2) void dense_conv3x3_x9_kernel(const float* __restrict__ X, const uint16_t* __restrict__ Wp,
                                                                  int B, int H, int W, int cin, int cout, int tiles_x,
                                                                  int tiles_y, float* __restrict__ Y, int ystride,
-                                                                 int prow, int pcol, double* __restrict__ stats) {
+                                                                 int prow, int pcol, double* __restrict__ stats,
+                                                                 const uint32_t* __restrict__ amax_x,
+                                                                 const uint32_t* __restrict__ amax_w) {
     // H x W is the tile space (rows x 32-pixel columns); pixel (r, c) of it is pixel r*prow + c*pcol of
     // the image: (W, 1) for the image as stored, (1, image width) with H and W swapped for the
     // transposed walk (tiles 32 pixels long along the image's H), chosen by the caller per shape.
@@ -1432,11 +1504,14 @@ __global__ __launch_bounds__(TR * 32, 2) void dense_conv3x3_x9_kernel(const floa
     constexpr int THREADS = TR * 32, NWAVES = TR / 2;
     constexpr int HP = (TR + 2) * DC_HW, NA = (HP * 4 + THREADS - 1) / THREADS;
     constexpr int CO = NT * 32;
-    constexpr int BPL = CO * DC_ROWB, BSZ = 3 * BPL, BPIECES = 3 * CO * 2;
+    constexpr int BPL = CO * DC_ROWB, BSZ = NP * BPL, BPIECES = NP * CO * 2;
     constexpr int NB = (BPIECES + THREADS - 1) / THREADS;
     constexpr int APL = HP * DC_ROWB;
-    __shared__ __attribute__((aligned(16))) unsigned char As[3 * APL];
+    __shared__ __attribute__((aligned(16))) unsigned char As[NP * APL];
     __shared__ __attribute__((aligned(16))) unsigned char Bs[3 * BSZ];
+    int sbx = 127, sbw = 127;
+    if (NP == 2) { sbx = h2_scale_exp(*amax_x); sbw = h2_scale_exp(*amax_w); }
+    const float xscale = h2_scale(sbx);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int per_img = tiles_x * tiles_y;
@@ -1466,12 +1541,19 @@ __global__ __launch_bounds__(TR * 32, 2) void dense_conv3x3_x9_kernel(const floa
         const int f = tid + THREADS * e;                                                                                  \
         if (f < HP * 4) {                                                                                          \
             const float4 v = aoff[e] >= 0 ? ra[e] : make_float4(0.f, 0.f, 0.f, 0.f);                                   \
-            uint32_t lo1, lo2, lo3, hi1, hi2, hi3;                                                                    \
-            x9_split2(v.x, v.y, lo1, lo2, lo3); x9_split2(v.z, v.w, hi1, hi2, hi3);                                   \
             unsigned char* dst = As + (f >> 2) * DC_ROWB + (f & 3) * 8;                                               \
-            *reinterpret_cast<uint2*>(dst) = make_uint2(lo1, hi1);                                                    \
-            *reinterpret_cast<uint2*>(dst + APL) = make_uint2(lo2, hi2);                                              \
-            *reinterpret_cast<uint2*>(dst + 2 * APL) = make_uint2(lo3, hi3);                                          \
+            if (NP == 3) {                                                                                            \
+                uint32_t lo1, lo2, lo3, hi1, hi2, hi3;                                                                \
+                x9_split2(v.x, v.y, lo1, lo2, lo3); x9_split2(v.z, v.w, hi1, hi2, hi3);                               \
+                *reinterpret_cast<uint2*>(dst) = make_uint2(lo1, hi1);                                                \
+                *reinterpret_cast<uint2*>(dst + APL) = make_uint2(lo2, hi2);                                          \
+                *reinterpret_cast<uint2*>(dst + (NP - 1) * APL) = make_uint2(lo3, hi3);                               \
+            } else {                                                                                                  \
+                uint32_t lo1, lo2, hi1, hi2;                                                                          \
+                h2_split2(v.x * xscale, v.y * xscale, lo1, lo2); h2_split2(v.z * xscale, v.w * xscale, hi1, hi2);     \
+                *reinterpret_cast<uint2*>(dst) = make_uint2(lo1, hi1);                                                \
+                *reinterpret_cast<uint2*>(dst + APL) = make_uint2(lo2, hi2);                                          \
+            }                                                                                                         \
         }                                                                                                             \
     }
     // weight stage (tap, 16-channel chunk c): piece f = (plane, column, 16-byte half) of the 32-byte half row.
@@ -1488,7 +1570,7 @@ __global__ __launch_bounds__(TR * 32, 2) void dense_conv3x3_x9_kernel(const floa
     // load and kept the address unit busy for most of a stage)
 #define DC_BLD(E, V) if ((E) < NB) { const int f = min(tid + THREADS * (E), BPIECES - 1); V = bsrc[f]; }
 #define DC_LOAD_B(TAP, CH, V0, V1, V2) {                                                                              \
-        const uint4* bsrc = reinterpret_cast<const uint4*>(Wp + ((int64_t)(TAP) * nchunks + (CH)) * (3 * CO * DC_CK)); \
+        const uint4* bsrc = reinterpret_cast<const uint4*>(Wp + ((int64_t)(TAP) * nchunks + (CH)) * (NP * CO * DC_CK)); \
         DC_BLD(0, V0) DC_BLD(1, V1) DC_BLD(2, V2) }
 #define DC_BST(BUF, E, V) if ((E) < NB) { const int f = tid + THREADS * (E); if (f < BPIECES) *reinterpret_cast<uint4*>(Bs + (BUF) * BSZ + (f >> 1) * DC_ROWB + (f & 1) * 16) = V; }
 #define DC_STORE_B(BUF, V0, V1, V2) { DC_BST(BUF, 0, V0) DC_BST(BUF, 1, V1) DC_BST(BUF, 2, V2) }
@@ -1500,22 +1582,24 @@ __global__ __launch_bounds__(TR * 32, 2) void dense_conv3x3_x9_kernel(const floa
     // tap offsets and buffer numbers are immediates.
     // fragments: the two M tiles' A planes, and the B planes of TWO N tiles at a time (with four N tiles all
     // twelve B fragments alive next to 128 accumulator registers do not fit 256 registers)
-    mf_v8bf fa[2][3], fb[2][3];
+    mf_v8bf fa[2][NP], fb[2][NP];
 #define DC_READ_A(TAP) {                                                                                              \
         const unsigned char* Ap = As + ((2 * wave + (TAP) / 3) * DC_HW + r + (TAP) % 3) * DC_ROWB + h * 16;           \
-        _Pragma("unroll") for (int m = 0; m < 2; ++m) _Pragma("unroll") for (int p = 0; p < 3; ++p)                   \
+        _Pragma("unroll") for (int m = 0; m < 2; ++m) _Pragma("unroll") for (int p = 0; p < NP; ++p)                  \
             fa[m][p] = *reinterpret_cast<const mf_v8bf*>(Ap + p * APL + m * DC_HW * DC_ROWB); }
 #define DC_READ_B(TAP, T0) {                                                                                          \
         const unsigned char* Bp = Bs + ((TAP) % 3) * BSZ + r * DC_ROWB + h * 16 + (T0) * 32 * DC_ROWB;                \
-        _Pragma("unroll") for (int t = 0; t < 2; ++t) _Pragma("unroll") for (int p = 0; p < 3; ++p)                   \
+        _Pragma("unroll") for (int t = 0; t < 2; ++t) _Pragma("unroll") for (int p = 0; p < NP; ++p)                  \
             fb[t][p] = *reinterpret_cast<const mf_v8bf*>(Bp + p * BPL + t * 32 * DC_ROWB); }
     // partial products smallest first; tiles innermost so consecutive MFMAs never share an accumulator
 #define DC_MM1(T0, PA, PB) _Pragma("unroll") for (int m = 0; m < 2; ++m) _Pragma("unroll") for (int t = 0; t < 2; ++t) acc[m][(T0) + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[m][PA], fb[t][PB], acc[m][(T0) + t], 0, 0, 0);
+#define DC_MH1(T0, PA, PB) _Pragma("unroll") for (int m = 0; m < 2; ++m) _Pragma("unroll") for (int t = 0; t < 2; ++t) acc[m][(T0) + t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(mf_v8h, fa[m][PA]), __builtin_bit_cast(mf_v8h, fb[t][PB]), acc[m][(T0) + t], 0, 0, 0);
 #ifdef X9_SIX
-#define DC_MMA(T0) DC_MM1(T0, 0, 2) DC_MM1(T0, 1, 1) DC_MM1(T0, 2, 0) DC_MM1(T0, 0, 1) DC_MM1(T0, 1, 0) DC_MM1(T0, 0, 0)
+#define DC_MMA3(T0) DC_MM1(T0, 0, NP - 1) DC_MM1(T0, 1, 1) DC_MM1(T0, NP - 1, 0) DC_MM1(T0, 0, 1) DC_MM1(T0, 1, 0) DC_MM1(T0, 0, 0)
 #else
-#define DC_MMA(T0) DC_MM1(T0, 2, 2) DC_MM1(T0, 1, 2) DC_MM1(T0, 2, 1) DC_MM1(T0, 0, 2) DC_MM1(T0, 1, 1) DC_MM1(T0, 2, 0) DC_MM1(T0, 0, 1) DC_MM1(T0, 1, 0) DC_MM1(T0, 0, 0)
+#define DC_MMA3(T0) DC_MM1(T0, NP - 1, NP - 1) DC_MM1(T0, 1, NP - 1) DC_MM1(T0, NP - 1, 1) DC_MM1(T0, 0, NP - 1) DC_MM1(T0, 1, 1) DC_MM1(T0, NP - 1, 0) DC_MM1(T0, 0, 1) DC_MM1(T0, 1, 0) DC_MM1(T0, 0, 0)
 #endif
+#define DC_MMA(T0) { if (NP == 3) { DC_MMA3(T0) } else { DC_MH1(T0, 0, 1) DC_MH1(T0, 1, 0) DC_MH1(T0, 0, 0) } }
 
     // Persistent workgroups: tiles blockIdx.x, blockIdx.x + gridDim.x, ... as one uninterrupted
     // stream of stages - the halo of the next tile's first chunk is requested during the last
@@ -1598,6 +1682,15 @@ __global__ __launch_bounds__(TR * 32, 2) void dense_conv3x3_x9_kernel(const floa
 #undef DC_STAGE
 #undef DC_EVEN
 #undef DC_ODD
+        if (NP == 2) {                                     // back from the scaled operands: two exact powers of two
+            const float dx = h2_descale(sbx), dw = h2_descale(sbw);
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc[m][t][i] = acc[m][t][i] * dx * dw;
+        }
         // D layout of 32x32x16: register v of lane l holds row (v/4)*8 + (l/32)*4 + v%4 (= pixel of the M tile's row), column l%32
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
@@ -1655,6 +1748,8 @@ __global__ __launch_bounds__(TR * 32, 2) void dense_conv3x3_x9_kernel(const floa
 #undef DC_READ_A
 #undef DC_READ_B
 #undef DC_MM1
+#undef DC_MH1
+#undef DC_MMA3
 #undef DC_MMA
 #undef DC_LOAD_A
 #undef DC_STORE_A
@@ -1672,7 +1767,8 @@ __global__ __launch_bounds__(TR * 32, 2) void dense_conv3x3_x9_kernel(const floa
 // convolution instead (taps reversed, channel roles swapped). One thread per (tap, chunk, col, ch).
 __global__ __launch_bounds__(256) void dense_pack_weight_kernel(const float* __restrict__ W, int64_t s_co, int64_t s_ci,
                                                                int64_t s_ky, int64_t s_kx, int cin, int cout,
-                                                               int backward, int nt, int64_t total,
+                                                               int backward, int nt, int64_t total, int np,
+                                                               const uint32_t* __restrict__ amax_w,
                                                                uint16_t* __restrict__ P) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
@@ -1690,24 +1786,38 @@ __global__ __launch_bounds__(256) void dense_pack_weight_kernel(const float* __r
         const int wco = backward ? c : col, wci = backward ? col : c;
         v = W[wco * s_co + wci * s_ci + ky * s_ky + kx * s_kx];
     }
-    uint32_t p1, p2, p3;
-    x9_split(v, p1, p2, p3);
     // dense layout: [tap][16-channel chunk][plane][column][16 channels] - one contiguous block per kernel stage,
     // in the order the kernel's threads copy it to LDS
     const int64_t stage16 = (int64_t)tap * (2 * nchunks) + (c >> 4);
-    uint16_t* dst = P + stage16 * (3 * (int64_t)co * 16) + (int64_t)col * 16 + (c & 15);
-    dst[0] = (uint16_t)p1; dst[(int64_t)co * 16] = (uint16_t)p2; dst[2 * (int64_t)co * 16] = (uint16_t)p3;
+    uint16_t* dst = P + stage16 * (np * (int64_t)co * 16) + (int64_t)col * 16 + (c & 15);
+    if (np == 3) {
+        uint32_t p1, p2, p3;
+        x9_split(v, p1, p2, p3);
+        dst[0] = (uint16_t)p1; dst[(int64_t)co * 16] = (uint16_t)p2; dst[2 * (int64_t)co * 16] = (uint16_t)p3;
+    } else {                                  // two fp16 planes of the scaled weight (h2_split2)
+        uint32_t w0, w1;
+        h2_split2(v * h2_scale(h2_scale_exp(*amax_w)), 0.0f, w0, w1);
+        dst[0] = (uint16_t)(w0 & 0xFFFFu); dst[(int64_t)co * 16] = (uint16_t)(w1 & 0xFFFFu);
+    }
 }
 
 extern "C" int gga_dense_conv3x3_pack(const float* weight, int64_t stride_co, int64_t stride_ci, int64_t stride_ky,
                                       int64_t stride_kx, int cin, int cout, int backward, void* packed, void* stream) {
+    return gga_dense_conv3x3_pack_planes(weight, stride_co, stride_ci, stride_ky, stride_kx, cin, cout, backward, 3, nullptr,
+                                         packed, stream);
+}
+
+extern "C" int gga_dense_conv3x3_pack_planes(const float* weight, int64_t stride_co, int64_t stride_ci, int64_t stride_ky,
+                                             int64_t stride_kx, int cin, int cout, int backward, int planes,
+                                             const uint32_t* amax_weight, void* packed, void* stream) {
     GGA_REQUIRE(weight && packed, "gga_dense_conv3x3_pack: null pointer argument");
+    GGA_REQUIRE(planes == 3 || (planes == 2 && amax_weight), "gga_dense_conv3x3_pack: planes must be 3 (bf16) or 2 (fp16, with amax_weight)");
     const int n_in = backward ? cout : cin, n_out = backward ? cin : cout;
     GGA_REQUIRE(n_in >= 1 && n_out >= 1 && n_out <= 128, "gga_dense_conv3x3_pack: bad sizes (%d -> %d)", n_in, n_out);
     const int64_t total = (int64_t)(gga_sparse_split_weight_bytes(9, n_in, n_out) / (3 * sizeof(uint16_t)));
     hipLaunchKernelGGL(dense_pack_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       weight, stride_co, stride_ci, stride_ky, stride_kx, cin, cout, backward, mf_nt(n_out), total,
-                       (uint16_t*)packed);
+                       weight, stride_co, stride_ci, stride_ky, stride_kx, cin, cout, backward, mf_nt(n_out), total, planes,
+                       amax_weight, (uint16_t*)packed);
     GGA_CHECK_LAUNCH("dense_pack_weight_kernel");
     return GGA_OK;
 }
@@ -1726,8 +1836,17 @@ extern "C" int64_t gga_dense_conv3x3_tiles(int B, int H, int W, int cout) {   //
 
 extern "C" int gga_dense_conv3x3_slice(const float* x, const void* split_weight, int B, int H, int W, int cin, int cout,
                                        float* y, int64_t y_pixel_stride, int transposed, double* stats, void* stream_) {
+    return gga_dense_conv3x3_planes(x, split_weight, B, H, W, cin, cout, y, y_pixel_stride, transposed, stats, 3, nullptr, nullptr,
+                                    stream_);
+}
+
+extern "C" int gga_dense_conv3x3_planes(const float* x, const void* split_weight, int B, int H, int W, int cin, int cout,
+                                        float* y, int64_t y_pixel_stride, int transposed, double* stats, int planes,
+                                        const uint32_t* amax_x, const uint32_t* amax_weight, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     GGA_REQUIRE(x && split_weight && y, "gga_dense_conv3x3: null pointer argument");
+    GGA_REQUIRE(planes == 3 || (planes == 2 && amax_x && amax_weight),
+                "gga_dense_conv3x3: planes must be 3 (bf16) or 2 (fp16, with the operands' absmax bits)");
     GGA_REQUIRE(y_pixel_stride >= cout && y_pixel_stride < 2147483647ll, "gga_dense_conv3x3: y pixel stride %lld < cout",
                 (long long)y_pixel_stride);
     GGA_REQUIRE(B >= 1 && H >= 1 && W >= 1 && cin >= 32 && cin % 32 == 0 && (cout == 64 || cout == 128) &&
@@ -1746,10 +1865,16 @@ extern "C" int gga_dense_conv3x3_slice(const float* x, const void* split_weight,
     const dim3 grid((unsigned)n_tiles), block(trows * 32);
     hipEvent_t* tev = gga_timing_acquire(GGA_TIME_DENSE_CONV, GGA_TIMING_CONV_KEY(cin, cout, (int64_t)H * W));
     GGA_TIME_START(tev, stream);
-#define DC_GO(NT_, TR_) hipLaunchKernelGGL((dense_conv3x3_x9_kernel<NT_, TR_>), grid, block, 0, stream, x, (const uint16_t*)split_weight, B, H, W, cin, cout, tx, ty, y, (int)y_pixel_stride, prow, pcol, stats)
-    if (cout == 64) DC_GO(2, 8);
-    else if (trows == 16) DC_GO(4, 16);
-    else DC_GO(4, 8);
+#define DC_GO(NT_, TR_, NP_) hipLaunchKernelGGL((dense_conv3x3_x9_kernel<NT_, TR_, NP_>), grid, block, 0, stream, x, (const uint16_t*)split_weight, B, H, W, cin, cout, tx, ty, y, (int)y_pixel_stride, prow, pcol, stats, amax_x, amax_weight)
+    if (planes == 3) {
+        if (cout == 64) DC_GO(2, 8, 3);
+        else if (trows == 16) DC_GO(4, 16, 3);
+        else DC_GO(4, 8, 3);
+    } else {
+        if (cout == 64) DC_GO(2, 8, 2);
+        else if (trows == 16) DC_GO(4, 16, 2);
+        else DC_GO(4, 8, 2);
+    }
 #undef DC_GO
     GGA_CHECK_LAUNCH("dense_conv3x3_x9_kernel");
     GGA_TIME_STOP(tev, stream);
@@ -1785,13 +1910,20 @@ extern "C" int gga_dense_conv3x3(const float* x, const void* split_weight, int B
 // [workgroup][tap][ci][co]; dense_wgrad_reduce_kernel adds them in a fixed order (f64) and writes
 // the framework's [cout, cin, 3, 3] layout.
 #define DW_XPL (2 * 34 * 64)                 // bytes per plane of one x ring row: [ci tile][34 px][32 ch]
-#define DW_XROW (3 * DW_XPL)
+#define DW_XROW (NP * DW_XPL)                // NP = planes per operand (template parameter of the kernel)
 #define DW_GPL (2 * 32 * 64)                 // bytes per plane of one gy row: [co tile][32 px][32 ch]
-#define DW_GROW (3 * DW_GPL)
+#define DW_GROW (NP * DW_GPL)
 
+template <int NP>
 __global__ __launch_bounds__(256, 2) void dense_wgrad3x3_x9_kernel(const float* __restrict__ X, const float* __restrict__ G,
                                                                   int B, int H, int W, int cin, int cout, int strips,
-                                                                  int prow, int pcol, float* __restrict__ partials) {
+                                                                  int prow, int pcol, float* __restrict__ partials,
+                                                                  const uint32_t* __restrict__ amax_x,
+                                                                  const uint32_t* __restrict__ amax_g) {
+    // NP = 3: bf16 planes, six products; NP = 2: fp16 planes of the scaled operands, three products (h2_split2); the
+    // partial sums then stay scaled and dense_wgrad_reduce_kernel scales the total back
+    float xscale = 1.0f, gscale = 1.0f;
+    if (NP == 2) { xscale = h2_scale(h2_scale_exp(*amax_x)); gscale = h2_scale(h2_scale_exp(*amax_g)); }
     __shared__ __attribute__((aligned(16))) unsigned char Xs[4 * DW_XROW];
     __shared__ __attribute__((aligned(16))) unsigned char Gs[2 * DW_GROW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1827,18 +1959,25 @@ __global__ __launch_bounds__(256, 2) void dense_wgrad3x3_x9_kernel(const float* 
         V = ok ? *reinterpret_cast<const float4*>(Xb + ((int64_t)yy * prow + (int64_t)ix * pcol) * cin + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f); }
 #define DW_LOAD_X(Y) { const int yy = (Y); const bool rowok = (unsigned)yy < (unsigned)H; DW_LDX(rx0, 0) DW_LDX(rx1, 1) DW_LDX(rx2, 2) }
     // piece (pixel px, float4 q) of a row image: channel tile q / 8, byte (q % 8) * 8 of the 64-byte pixel row
-#define DW_SPLIT_STORE(V, BASE, PL, NPX, F) { const int f = (F); const int px = f >> 4, q = f & 15;                   \
-        uint32_t lo1, lo2, lo3, hi1, hi2, hi3;                                                                        \
-        x9_split2(V.x, V.y, lo1, lo2, lo3); x9_split2(V.z, V.w, hi1, hi2, hi3);                                       \
+#define DW_SPLIT_STORE(V, BASE, PL, NPX, F, SC) { const int f = (F); const int px = f >> 4, q = f & 15;               \
         unsigned char* dst = (BASE) + (q >> 3) * ((NPX) * 64) + px * 64 + (q & 7) * 8;                                \
-        *reinterpret_cast<uint2*>(dst) = make_uint2(lo1, hi1);                                                        \
-        *reinterpret_cast<uint2*>(dst + (PL)) = make_uint2(lo2, hi2);                                                 \
-        *reinterpret_cast<uint2*>(dst + 2 * (PL)) = make_uint2(lo3, hi3); }
+        if (NP == 3) {                                                                                                \
+            uint32_t lo1, lo2, lo3, hi1, hi2, hi3;                                                                    \
+            x9_split2(V.x, V.y, lo1, lo2, lo3); x9_split2(V.z, V.w, hi1, hi2, hi3);                                   \
+            *reinterpret_cast<uint2*>(dst) = make_uint2(lo1, hi1);                                                    \
+            *reinterpret_cast<uint2*>(dst + (PL)) = make_uint2(lo2, hi2);                                             \
+            *reinterpret_cast<uint2*>(dst + (NP - 1) * (PL)) = make_uint2(lo3, hi3);                                  \
+        } else {                                                                                                      \
+            uint32_t lo1, lo2, hi1, hi2;                                                                              \
+            h2_split2(V.x * (SC), V.y * (SC), lo1, lo2); h2_split2(V.z * (SC), V.w * (SC), hi1, hi2);                 \
+            *reinterpret_cast<uint2*>(dst) = make_uint2(lo1, hi1);                                                    \
+            *reinterpret_cast<uint2*>(dst + (PL)) = make_uint2(lo2, hi2);                                             \
+        } }
 #define DW_STORE_G(Y) { unsigned char* base = Gs + ((Y) & 1) * DW_GROW;                                               \
-        DW_SPLIT_STORE(rg0, base, DW_GPL, 32, tid) DW_SPLIT_STORE(rg1, base, DW_GPL, 32, tid + 256) }
+        DW_SPLIT_STORE(rg0, base, DW_GPL, 32, tid, gscale) DW_SPLIT_STORE(rg1, base, DW_GPL, 32, tid + 256, gscale) }
 #define DW_STORE_X(Y) { unsigned char* base = Xs + (((Y) + 4) & 3) * DW_XROW;                                         \
-        DW_SPLIT_STORE(rx0, base, DW_XPL, 34, tid) DW_SPLIT_STORE(rx1, base, DW_XPL, 34, tid + 256)                   \
-        if (tid + 512 < 544) DW_SPLIT_STORE(rx2, base, DW_XPL, 34, tid + 512) }
+        DW_SPLIT_STORE(rx0, base, DW_XPL, 34, tid, xscale) DW_SPLIT_STORE(rx1, base, DW_XPL, 34, tid + 256, xscale)   \
+        if (tid + 512 < 544) DW_SPLIT_STORE(rx2, base, DW_XPL, 34, tid + 512, xscale) }
 
     // transposed fragment of a [pixel][32 ch] image: lane l gets channel l%32, pixels P0 + 8*(l/32) .. +7
     const int grp = lane >> 4, li = lane & 15;
@@ -1876,7 +2015,7 @@ __global__ __launch_bounds__(256, 2) void dense_wgrad3x3_x9_kernel(const float* 
             Frag g0, g1, g2;
             DW_FRAG(g0, gbase + (16 * s) * 64);
             DW_FRAG(g1, gbase + DW_GPL + (16 * s) * 64);
-            DW_FRAG(g2, gbase + 2 * DW_GPL + (16 * s) * 64);
+            if (NP == 3) { DW_FRAG(g2, gbase + (NP - 1) * DW_GPL + (16 * s) * 64); } else g2 = g1;
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 const int ky = tap / 3, kx = tap - ky * 3;
@@ -1884,16 +2023,24 @@ __global__ __launch_bounds__(256, 2) void dense_wgrad3x3_x9_kernel(const float* 
                 Frag a0, a1, a2;
                 DW_FRAG(a0, xbase);
                 DW_FRAG(a1, xbase + DW_XPL);
-                DW_FRAG(a2, xbase + 2 * DW_XPL);
+                if (NP == 2) {
+#define DW_MH(A_, G_) acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(mf_v8h, A_.v), __builtin_bit_cast(mf_v8h, G_.v), acc[tap], 0, 0, 0);
+                    DW_MH(a0, g1) DW_MH(a1, g0) DW_MH(a0, g0)
+#undef DW_MH
+                    continue;
+                }
+                DW_FRAG(a2, xbase + (NP - 1) * DW_XPL);
                 // nine partial products, smallest first
 #ifndef X9_SIX
                 acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2.v, g2.v, acc[tap], 0, 0, 0);
                 acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.v, g2.v, acc[tap], 0, 0, 0);
                 acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2.v, g1.v, acc[tap], 0, 0, 0);
 #endif
+#ifndef X9_THREE
                 acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.v, g2.v, acc[tap], 0, 0, 0);
                 acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.v, g1.v, acc[tap], 0, 0, 0);
                 acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2.v, g0.v, acc[tap], 0, 0, 0);
+#endif
                 acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.v, g1.v, acc[tap], 0, 0, 0);
                 acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.v, g0.v, acc[tap], 0, 0, 0);
                 acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.v, g0.v, acc[tap], 0, 0, 0);
@@ -1925,7 +2072,8 @@ __global__ __launch_bounds__(256, 2) void dense_wgrad3x3_x9_kernel(const float* 
 // dW[co][ci][ky][kx] (element strides given) = sum over the workgroups' partials, fixed order, f64
 __global__ __launch_bounds__(256) void dense_wgrad_reduce_kernel(const float* __restrict__ partials, int nblk, int cin, int cout,
                                                                 int64_t s_co, int64_t s_ci, int64_t s_ky, int64_t s_kx,
-                                                                float* __restrict__ dW) {
+                                                                const uint32_t* __restrict__ amax_x,
+                                                                const uint32_t* __restrict__ amax_g, float* __restrict__ dW) {
     const int i = blockIdx.x * 256 + threadIdx.x;          // (tap, ci local, co local) of channel block blockIdx.y
     if (i >= 9 * 64 * 64) return;
     const int ncb_o = cout >> 6;
@@ -1936,6 +2084,7 @@ __global__ __launch_bounds__(256) void dense_wgrad_reduce_kernel(const float* __
     for (int k = 0; k < nblk; ++k) s += (double)p[(int64_t)k * (9 * 64 * 64)];
     const int co = i & 63, ci = (i >> 6) & 63, tap = i >> 12;
     const int ky = tap / 3, kx = tap - ky * 3;
+    if (amax_x) s = s * (double)h2_descale(h2_scale_exp(*amax_x)) * (double)h2_descale(h2_scale_exp(*amax_g));     // fp16-plane partials are scaled
     dW[(co0 + co) * s_co + (ci0 + ci) * s_ci + ky * s_ky + kx * s_kx] = (float)s;
 }
 
@@ -1958,8 +2107,18 @@ extern "C" int gga_dense_wgrad3x3(const float* x, const float* grad_y, int B, in
                                   float* grad_weight, int64_t stride_co, int64_t stride_ci, int64_t stride_ky,
                                   int64_t stride_kx, int transposed, void* workspace, size_t workspace_bytes,
                                   void* stream_) {
+    return gga_dense_wgrad3x3_planes(x, grad_y, B, H, W, cin, cout, grad_weight, stride_co, stride_ci, stride_ky, stride_kx,
+                                     transposed, 3, nullptr, nullptr, workspace, workspace_bytes, stream_);
+}
+
+extern "C" int gga_dense_wgrad3x3_planes(const float* x, const float* grad_y, int B, int H, int W, int cin, int cout,
+                                         float* grad_weight, int64_t stride_co, int64_t stride_ci, int64_t stride_ky,
+                                         int64_t stride_kx, int transposed, int planes, const uint32_t* amax_x,
+                                         const uint32_t* amax_grad_y, void* workspace, size_t workspace_bytes, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     GGA_REQUIRE(x && grad_y && grad_weight && workspace, "gga_dense_wgrad3x3: null pointer argument");
+    GGA_REQUIRE(planes == 3 || (planes == 2 && amax_x && amax_grad_y),
+                "gga_dense_wgrad3x3: planes must be 3 (bf16) or 2 (fp16, with the operands' absmax bits)");
     GGA_REQUIRE(B >= 1 && H >= 1 && W >= 1 && cin >= 64 && cout >= 64 && (cin & 63) == 0 && (cout & 63) == 0,
                 "gga_dense_wgrad3x3: cin and cout must be multiples of 64 (got %d -> %d)", cin, cout);
     if (workspace_bytes < gga_dense_wgrad3x3_workspace_bytes(B, H, W, cin, cout)) {
@@ -1973,11 +2132,16 @@ extern "C" int gga_dense_wgrad3x3(const float* x, const float* grad_y, int B, in
     const int nblk = dense_wgrad_blocks(B, H, W, cin, cout), ncb = (cin >> 6) * (cout >> 6);
     hipEvent_t* tev = gga_timing_acquire(GGA_TIME_DENSE_WGRAD, GGA_TIMING_CONV_KEY(cin, cout, (int64_t)H * W));
     GGA_TIME_START(tev, stream);
-    hipLaunchKernelGGL(dense_wgrad3x3_x9_kernel, dim3(nblk, ncb), dim3(256), 0, stream, x, grad_y, B, H, W, cin, cout, strips,
-                       prow, pcol, (float*)workspace);
+    if (planes == 3)
+        hipLaunchKernelGGL(dense_wgrad3x3_x9_kernel<3>, dim3(nblk, ncb), dim3(256), 0, stream, x, grad_y, B, H, W, cin, cout, strips,
+                           prow, pcol, (float*)workspace, amax_x, amax_grad_y);
+    else
+        hipLaunchKernelGGL(dense_wgrad3x3_x9_kernel<2>, dim3(nblk, ncb), dim3(256), 0, stream, x, grad_y, B, H, W, cin, cout, strips,
+                           prow, pcol, (float*)workspace, amax_x, amax_grad_y);
     GGA_CHECK_LAUNCH("dense_wgrad3x3_x9_kernel");
     hipLaunchKernelGGL(dense_wgrad_reduce_kernel, dim3((9 * 64 * 64 + 255) / 256, ncb), dim3(256), 0, stream,
-                       (const float*)workspace, nblk, cin, cout, stride_co, stride_ci, stride_ky, stride_kx, grad_weight);
+                       (const float*)workspace, nblk, cin, cout, stride_co, stride_ci, stride_ky, stride_kx,
+                       planes == 2 ? amax_x : nullptr, amax_grad_y, grad_weight);
     GGA_CHECK_LAUNCH("dense_wgrad_reduce_kernel");
     GGA_TIME_STOP(tev, stream);
     return GGA_OK;

@@ -7,6 +7,8 @@ Reference call sites: the block convolutions of ``SECOND`` (backbones/second.py:
 fp32 in, fp32 out: every product is the exact sum of nine bf16 partial products accumulated in
 fp32 (error against float64 as small as MIOpen's fp32 kernels, tools_dev/bench_dense3x3.py).
 """
+import os
+
 import torch
 from torch import nn
 
@@ -16,6 +18,26 @@ from ._lib import check
 
 ENABLED = True          # False: every dense convolution goes to MIOpen
 WGRAD = True            # False: weight gradients stay with MIOpen
+# Arithmetic of the matrix kernels (both: fp32 in, fp32 out, fp32 accumulation):
+#   2  two fp16 planes of the operands scaled to their largest finite magnitude, three partial products: 22-bit
+#      significands, absolute accuracy 2^-39 of a tensor's largest magnitude per element (default);
+#   3  three bf16 planes, six partial products: fp32's exponent range, 24-bit significands.
+PLANES = int(os.environ.get('GGA_DENSE_PLANES', '2'))
+
+
+def amax_bits(t):
+    """Device scalar (int32 tensor [1]) with the bits of the largest finite ``|t|`` - what the two-plane kernels
+    derive their power-of-two scale from. ``t``: any tensor that is dense in memory, or a row-major matrix view."""
+    L = _lib.lib()
+    out = torch.empty(1, dtype=torch.int32, device=t.device)
+    if not (t.is_contiguous() or (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last))):
+        t = t.contiguous()
+    n = t.numel()
+    assert n % 4 == 0
+    width = 1024 if n % 1024 == 0 and n else max(n, 4)
+    assert width < 2 ** 31
+    check(L.gga_absmax_bits(F._p(t), n // width, width, width, F._p(out), F._stream()), 'gga_absmax_bits')
+    return out
 
 
 def _cdiv(a, b):
@@ -30,47 +52,59 @@ def _transposed(H, W):
     return turned < 0.97 * normal
 
 
-def _pack(weight, backward, transposed=False):
+def _pack(weight, backward, transposed=False, w_amax=None):
     """Split-plane operand of the forward (or backward-data) convolution, read from the parameter's
     own memory layout: one kernel, no permuted copy. ``transposed``: for the transposed walk (ky and
-    kx change roles)."""
+    kx change roles). ``w_amax``: absmax bits of the weight (two-plane arithmetic)."""
     L = _lib.lib()
     cout, cin = weight.shape[0], weight.shape[1]
     n_in, n_out = (cout, cin) if backward else (cin, cout)
     wp = torch.empty(L.gga_sparse_split_weight_bytes(9, n_in, n_out) // 2, dtype=torch.int16, device=weight.device)
     s = weight.stride()
     sky, skx = (s[3], s[2]) if transposed else (s[2], s[3])
-    check(L.gga_dense_conv3x3_pack(F._p(weight), s[0], s[1], sky, skx, cin, cout, int(backward), F._p(wp), F._stream()),
-          'gga_dense_conv3x3_pack')
+    planes = 2 if w_amax is not None else 3
+    check(L.gga_dense_conv3x3_pack_planes(F._p(weight), s[0], s[1], sky, skx, cin, cout, int(backward), planes, F._p(w_amax),
+                                          F._p(wp), F._stream()), 'gga_dense_conv3x3_pack')
     return wp
 
 
-def _run(x, weight, backward, want_stats=False):
+def _run(x, weight, backward, want_stats=False, x_amax=None, w_amax=None, y=None, y_col=0):
     """The convolution (or its backward-data form) of ``x`` with ``weight`` [cout, cin, 3, 3]; output
-    widths above 128 run as 128-channel slices of the result."""
+    widths above 128 run as 128-channel slices of the result. ``x_amax`` / ``w_amax``: absmax bits of the operands
+    when they are already known (two-plane arithmetic; computed here otherwise). ``y`` / ``y_col``: write the result
+    into the channel block starting at ``y_col`` of an existing channels-last tensor."""
     B, n_in, H, W = x.shape
     L = _lib.lib()
     n_out = weight.shape[1] if backward else weight.shape[0]
     tr = _transposed(H, W)
-    y = torch.empty((B, n_out, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    if y is None:
+        y = torch.empty((B, n_out, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    ystride = y.shape[1]
+    planes = PLANES
+    if planes == 2:
+        x_amax = amax_bits(x) if x_amax is None else x_amax
+        w_amax = amax_bits(weight) if w_amax is None else w_amax
+    else:
+        x_amax = w_amax = None
     stats = None
     if n_out in (64, 128):
         if want_stats:
             tiles = int(L.gga_dense_conv3x3_tiles(B, W, H, n_out) if tr else L.gga_dense_conv3x3_tiles(B, H, W, n_out))
             stats = torch.empty((tiles, 2, n_out), dtype=torch.float64, device=x.device)
-        check(L.gga_dense_conv3x3_slice(F._p(x), F._p(_pack(weight, backward, tr)), B, H, W, n_in, n_out, F._p(y), n_out,
-                                        int(tr), F._p(stats), F._stream()), 'gga_dense_conv3x3')
+        check(L.gga_dense_conv3x3_planes(F._p(x), F._p(_pack(weight, backward, tr, w_amax)), B, H, W, n_in, n_out,
+                                         y.data_ptr() + 4 * y_col, ystride, int(tr), F._p(stats), planes, F._p(x_amax),
+                                         F._p(w_amax), F._stream()), 'gga_dense_conv3x3')
     else:
         for c0 in range(0, n_out, 128):             # strided views: packed straight from the parameter
             wv = weight[:, c0:c0 + 128] if backward else weight[c0:c0 + 128]
-            check(L.gga_dense_conv3x3_slice(F._p(x), F._p(_pack(wv, backward, tr)), B, H, W, n_in, 128,
-                                            y.data_ptr() + 4 * c0, n_out, int(tr), None, F._stream()),
-                  'gga_dense_conv3x3_slice')
+            check(L.gga_dense_conv3x3_planes(F._p(x), F._p(_pack(wv, backward, tr, w_amax)), B, H, W, n_in, 128,
+                                             y.data_ptr() + 4 * (y_col + c0), ystride, int(tr), None, planes, F._p(x_amax),
+                                             F._p(w_amax), F._stream()), 'gga_dense_conv3x3_slice')
     return y, stats
 
 
-def _wgrad(x, gy, weight):
-    """Weight gradient on the bf16x9 path (``gga_dense_wgrad3x3``), in the parameter's memory layout."""
+def _wgrad(x, gy, weight, x_amax=None, g_amax=None):
+    """Weight gradient on the matrix path (``gga_dense_wgrad3x3``), in the parameter's memory layout."""
     L = _lib.lib()
     B, cin, H, W = x.shape
     cout = weight.shape[0]
@@ -78,8 +112,14 @@ def _wgrad(x, gy, weight):
     s = gw.stride()
     ws = F._workspace('dense_wgrad', L.gga_dense_wgrad3x3_workspace_bytes(B, H, W, cin, cout), x.device)
     tr = _cdiv(H, 32) * 32 * W < 0.97 * _cdiv(W, 32) * 32 * H        # 32-pixel strips along H waste less
-    check(L.gga_dense_wgrad3x3(F._p(x), F._p(gy), B, H, W, cin, cout, F._p(gw), s[0], s[1], s[2], s[3], int(tr), F._p(ws),
-                               ws.numel(), F._stream()), 'gga_dense_wgrad3x3')
+    planes = PLANES
+    if planes == 2:
+        x_amax = amax_bits(x) if x_amax is None else x_amax
+        g_amax = amax_bits(gy) if g_amax is None else g_amax
+    else:
+        x_amax = g_amax = None
+    check(L.gga_dense_wgrad3x3_planes(F._p(x), F._p(gy), B, H, W, cin, cout, F._p(gw), s[0], s[1], s[2], s[3], int(tr), planes,
+                                      F._p(x_amax), F._p(g_amax), F._p(ws), ws.numel(), F._stream()), 'gga_dense_wgrad3x3')
     return gw
 
 
@@ -87,8 +127,12 @@ class _Conv3x3(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, want_stats):
         cout, cin = weight.shape[0], weight.shape[1]
-        y, stats = _run(x, weight.detach(), False, want_stats)
+        two = PLANES == 2
+        x_amax = amax_bits(x) if two else None
+        w_amax = amax_bits(weight.detach()) if two else None
+        y, stats = _run(x, weight.detach(), False, want_stats, x_amax, w_amax)
         ctx.save_for_backward(x, weight)
+        ctx.amax = (x_amax, w_amax)
         if stats is None:
             stats = torch.empty(0, dtype=torch.float64, device=x.device)
         ctx.mark_non_differentiable(stats)
@@ -100,15 +144,19 @@ class _Conv3x3(torch.autograd.Function):
         cout, cin = weight.shape[0], weight.shape[1]
         gy = gy.contiguous(memory_format=torch.channels_last)
         gx = gw = None
+        x_amax, w_amax = ctx.amax
+        g_amax = amax_bits(gy) if PLANES == 2 else None          # one pass over gy for both of its consumers
+        if PLANES != 2:
+            x_amax = w_amax = None
         # backward-data is a cout -> cin convolution (taps reversed, channel roles swapped): cin is its
         # output width; wider inputs are produced in 128-channel slices
         mine = cin in (64, 128) or cin % 128 == 0
         if ctx.needs_input_grad[0] and mine:
-            gx = _run(gy, weight.detach(), True)[0]
+            gx = _run(gy, weight.detach(), True, False, g_amax, w_amax)[0]
         need_gx = ctx.needs_input_grad[0] and not mine
         need_gw = bool(ctx.needs_input_grad[1])
         if need_gw and WGRAD and cin % 64 == 0 and cout % 64 == 0:
-            gw = _wgrad(x, gy, weight)
+            gw = _wgrad(x, gy, weight, x_amax, g_amax)
             need_gw = False
         if need_gw or need_gx:
             r = torch.ops.aten.convolution_backward(gy, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,

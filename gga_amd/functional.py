@@ -766,12 +766,12 @@ class _HeadBranches(torch.autograd.Function):
         tr = dense_conv._transposed(H, W)
         Y = torch.empty((B, tot, H, W), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
         tiles = int(L.gga_dense_conv3x3_tiles(B, W, H, C) if tr else L.gga_dense_conv3x3_tiles(B, H, W, C))
-        stats = torch.empty((tiles, 2, C), dtype=torch.float64, device=dev)
         outs, saved_all, ss_all = [], [], []
+        x_amax = dense_conv.amax_bits(x) if dense_conv.PLANES == 2 else None       # one pass for all n convolutions
         for i in range(n):
             eps, momentum = cfg[i]
-            check(L.gga_dense_conv3x3_slice(_p(x), _p(dense_conv._pack(w1[i].detach(), False, tr)), B, H, W, C, C,
-                                            Y.data_ptr() + 4 * C * i, tot, int(tr), _p(stats), _stream()), 'gga_dense_conv3x3_slice')
+            _, st = dense_conv._run(x, w1[i].detach(), False, True, x_amax, None, Y, C * i)
+            stats = st
             saved = torch.empty(2 * C, dtype=torch.float32, device=dev)
             ss = torch.empty(2 * C, dtype=torch.float32, device=dev)
             check(L.gga_bn_stats_partials(_p(gam[i]), _p(bet[i]), _p(rm[i]), _p(rv[i]), rows, C, eps, momentum, _p(saved), _p(ss),
@@ -782,7 +782,7 @@ class _HeadBranches(torch.autograd.Function):
                                          _p(y), _stream()), 'gga_head_conv3x3_fwd')
             outs.append(y), saved_all.append(saved), ss_all.append(ss)
         ctx.save_for_backward(x, Y, *w1, *gam, *w2, *saved_all, *ss_all)
-        ctx.n, ctx.has_bias = n, [b is not None for b in b2]
+        ctx.n, ctx.has_bias, ctx.x_amax = n, [b is not None for b in b2], x_amax
         return tuple(outs)
 
     @staticmethod
@@ -814,8 +814,9 @@ class _HeadBranches(torch.autograd.Function):
                   'gga_head_tail_bwd')
             gw2.append(gw), gb2.append(gb), ggam.append(gg), gbet.append(gbeta)
         wcat = torch.cat([w.detach() for w in w1], dim=0)            # [64n, 64, 3, 3]
-        gx = dense_conv._run(G, wcat, True)[0] if ctx.needs_input_grad[0] else None
-        gwcat = dense_conv._wgrad(x, G, wcat)
+        g_amax = dense_conv.amax_bits(G) if dense_conv.PLANES == 2 else None
+        gx = dense_conv._run(G, wcat, True, False, g_amax)[0] if ctx.needs_input_grad[0] else None
+        gwcat = dense_conv._wgrad(x, G, wcat, ctx.x_amax if dense_conv.PLANES == 2 else None, g_amax)
         gw1 = list(gwcat.split(C, dim=0))
         none = [None] * n
         return (gx, None, None, *gw1, *ggam, *gbet, *none, *none, *gw2, *gb2)

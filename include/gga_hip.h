@@ -335,6 +335,24 @@ int gga_dense_wgrad3x3(const float* x, const float* grad_y, int B, int H, int W,
                        float* grad_weight, int64_t stride_co, int64_t stride_ci, int64_t stride_ky,
                        int64_t stride_kx, int transposed, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Two-fp16-plane arithmetic for the dense kernels (the default of gga_amd/dense_conv.py): each operand is scaled by
+ * the power of two that puts its largest finite magnitude into [2^14, 2^15) and split into two round-to-nearest fp16
+ * planes (22 significand bits), so a product needs THREE matrix products instead of the six of the three-bf16-plane
+ * form; the result is scaled back exactly. Absolute accuracy per element: 2^-39 of the tensor's largest magnitude
+ * (fp16 has no fp32 exponent range) - see DESIGN.md 5. `planes` = 3 selects the bf16 form (no absmax needed).
+ * gga_absmax_bits: bits of the largest finite |x| of a [rows, width] f32 matrix into *out_bits (device). */
+int gga_absmax_bits(const float* x, int64_t rows, int width, int64_t row_stride, uint32_t* out_bits, void* stream);
+int gga_dense_conv3x3_pack_planes(const float* weight, int64_t stride_co, int64_t stride_ci, int64_t stride_ky,
+                                  int64_t stride_kx, int cin, int cout, int backward, int planes,
+                                  const uint32_t* amax_weight, void* packed, void* stream);
+int gga_dense_conv3x3_planes(const float* x, const void* split_weight, int B, int H, int W, int cin, int cout, float* y,
+                             int64_t y_pixel_stride, int transposed, double* stats, int planes, const uint32_t* amax_x,
+                             const uint32_t* amax_weight, void* stream);
+int gga_dense_wgrad3x3_planes(const float* x, const float* grad_y, int B, int H, int W, int cin, int cout,
+                              float* grad_weight, int64_t stride_co, int64_t stride_ci, int64_t stride_ky,
+                              int64_t stride_kx, int transposed, int planes, const uint32_t* amax_x,
+                              const uint32_t* amax_grad_y, void* workspace, size_t workspace_bytes, void* stream);
+
 /* The same with y as a 64- or 128-channel slice of a wider channels-last tensor: pixel p of the
  * result starts at y + p * y_pixel_stride (floats). A convolution with more output channels runs as
  * one call per slice (each with the weights of its slice): the backward-data of the 384 -> 64

@@ -727,26 +727,38 @@ def test_strided_and_transposed_convs_vs_torch(kind, cin, cout, k, s, B, H, W):
     assert torch.equal(y2, y) and torch.equal(x.grad, gx) and torch.equal(m.weight.grad, gw)
 
 
-def test_dense_conv3x3_non_finite_and_wide_range():
-    """Contract of the split-plane arithmetic at the edges of fp32 (include/gga_hip.h):
-    finite inputs of any magnitude (2^-100 .. 2^100, denormals) give the fp32 result to the usual
-    accumulation error; a non-finite input makes exactly the outputs non-finite that an fp32
-    convolution makes non-finite (as NaN: Inf splits into Inf - Inf), and no other output moves."""
+@pytest.mark.parametrize('planes', [2, 3])
+def test_dense_conv3x3_non_finite_and_wide_range(planes, monkeypatch):
+    """Contract of the split-plane arithmetic at the edges of fp32 (include/gga_hip.h).
+    planes = 3 (three bf16 planes, six products): finite inputs of any magnitude (2^-100 .. 2^100, denormals) give
+    the fp32 result to the usual accumulation error, per output.
+    planes = 2 (two fp16 planes of the scaled operands, three products - the default): the same while the magnitudes
+    inside a tensor stay within ~2^17 of each other; in general |error| <= 2e-6 * sum|a*b| + 2^-40 * max|x| * sum|w|
+    (an element is kept to an absolute accuracy of 2^-39 of its tensor's largest magnitude).
+    Both: a non-finite input makes exactly the outputs non-finite that an fp32 convolution makes non-finite (as NaN: Inf
+    splits into Inf - Inf), and no other output moves."""
     from gga_amd import dense_conv
+    monkeypatch.setattr(dense_conv, 'PLANES', planes)
     torch.manual_seed(3)
     conv = torch.nn.Conv2d(64, 64, 3, padding=1, bias=False).to(DEV)
     conv.weight.data = conv.weight.data.contiguous(memory_format=torch.channels_last)
     base = torch.randn(2, 64, 24, 40, device=DEV)
     # wide range: every pixel has its own power-of-two scale (a dot product's terms share it, so the
     # float64 reference bounds the error per output by its own magnitude)
-    e = torch.randint(-100, 101, (2, 1, 24, 40), device=DEV).float()
-    x = (base * torch.exp2(e)).contiguous(memory_format=torch.channels_last)
-    with torch.no_grad():
-        y = dense_conv.conv2d(x, conv)
-        mag = torch.nn.functional.conv2d(x.double().abs(), conv.weight.double().abs(), padding=1)
-        ref = torch.nn.functional.conv2d(x.double(), conv.weight.double(), padding=1)
-    assert torch.isfinite(y).all()
-    assert float(((y.double() - ref).abs() / mag).max()) < 5e-6      # relative to sum |a*b| of the same output
+    for span in (8, 100):
+        e = torch.randint(-span, span + 1, (2, 1, 24, 40), device=DEV).float()
+        x = (base * torch.exp2(e)).contiguous(memory_format=torch.channels_last)
+        with torch.no_grad():
+            y = dense_conv.conv2d(x, conv)
+            mag = torch.nn.functional.conv2d(x.double().abs(), conv.weight.double().abs(), padding=1)
+            ref = torch.nn.functional.conv2d(x.double(), conv.weight.double(), padding=1)
+            sum_w = torch.nn.functional.conv2d(torch.ones_like(x).double(), conv.weight.double().abs(), padding=1)
+        assert torch.isfinite(y).all()
+        err = (y.double() - ref).abs()
+        if planes == 3 or span == 8:
+            assert float((err / mag).max()) < 5e-6      # relative to sum |a*b| of the same output
+        assert bool((err <= 2e-6 * mag + 2.0 ** -40 * float(x.abs().max()) * sum_w).all())
+        assert float(err.max()) < 1e-6 * float(ref.abs().max())
     # denormal inputs: result within one denormal-product's worth of the float64 one (flush-to-zero or not)
     xd = (base * 1e-41).contiguous(memory_format=torch.channels_last)
     with torch.no_grad():

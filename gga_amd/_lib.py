@@ -11,7 +11,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libgga_hip.so')
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 _lib = None
 
@@ -82,6 +82,9 @@ SIGNATURES = {
     'gga_dense_conv3x3_pack': (i32, [vp, i64, i64, i64, i64, i32, i32, i32, vp, vp]),
     'gga_dense_wgrad3x3_workspace_bytes': (sz, [i32, i32, i32, i32, i32]),
     'gga_dense_wgrad3x3': (i32, [vp, vp, i32, i32, i32, i32, i32, vp, i64, i64, i64, i64, i32, vp, sz, vp]),
+    'gga_sparse_pack_weight_planes': (i32, [vp, i32, i32, i32, i32, i32, vp, vp, vp]),
+    'gga_sparse_conv_apply_planes': (i32, [vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp, i64, i32, vp, vp, vp]),
+    'gga_sparse_conv_wgrad_planes': (i32, [vp, i64, vp, i64, vp, i64, i32, i32, i32, vp, i32, vp, vp, vp, sz, vp]),
     'gga_absmax_bits': (i32, [vp, i64, i32, i64, vp, vp]),
     'gga_dense_conv3x3_pack_planes': (i32, [vp, i64, i64, i64, i64, i32, i32, i32, i32, vp, vp, vp]),
     'gga_dense_conv3x3_planes': (i32, [vp, vp, i32, i32, i32, i32, i32, vp, i64, i32, vp, i32, vp, vp, vp]),

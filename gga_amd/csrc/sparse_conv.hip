@@ -706,18 +706,37 @@ __device__ __forceinline__ void h2_split2(float a, float b, uint32_t& w0, uint32
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, int64_t rows, int width4, int64_t row_stride,
                                                     uint32_t* __restrict__ out) {
     const int64_t n4 = rows * width4;
+    const int64_t stride = (int64_t)gridDim.x * 256;
     uint32_t m = 0;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-        const int64_t rrow = i / width4;
-        const float4 v = *reinterpret_cast<const float4*>(x + rrow * row_stride + (i - rrow * width4) * 4);
-        const uint32_t u[4] = {__float_as_uint(v.x) & 0x7FFFFFFFu, __float_as_uint(v.y) & 0x7FFFFFFFu,
-                               __float_as_uint(v.z) & 0x7FFFFFFFu, __float_as_uint(v.w) & 0x7FFFFFFFu};
+    for (int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x; i0 < n4; i0 += stride * 8) {
+        float4 v[8];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) if (u[j] < 0x7F800000u && u[j] > m) m = u[j];
+        for (int u = 0; u < 8; ++u) {                      // eight independent 16-byte loads in flight per thread
+            const int64_t i = i0 + u * stride;
+            if (i < n4) {
+                const int64_t rrow = row_stride == (int64_t)width4 * 4 ? 0 : i / width4;
+                v[u] = *reinterpret_cast<const float4*>(x + rrow * row_stride + (i - rrow * width4) * 4);
+            } else v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const uint32_t q[4] = {__float_as_uint(v[u].x) & 0x7FFFFFFFu, __float_as_uint(v[u].y) & 0x7FFFFFFFu,
+                                   __float_as_uint(v[u].z) & 0x7FFFFFFFu, __float_as_uint(v[u].w) & 0x7FFFFFFFu};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (q[j] < 0x7F800000u && q[j] > m) m = q[j];
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { const uint32_t t = __shfl_xor(m, o, 64); m = t > m ? t : m; }
-    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+    // one atomic per workgroup, and only if it can still raise the result: thousands of same-address atomics
+    // serialise in the L2 (measured: 16 k of them cost 150 us)
+    __shared__ uint32_t wm[4];
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = max(max(wm[0], wm[1]), max(wm[2], wm[3]));
+        if (m > __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(out, m);
+    }
 }
 
 extern "C" int gga_absmax_bits(const float* x, int64_t rows, int width, int64_t row_stride, uint32_t* out_bits, void* stream_) {
@@ -736,7 +755,8 @@ extern "C" int gga_absmax_bits(const float* x, int64_t rows, int width, int64_t 
 
 // packed[k][chunk][plane][col < CO][32 ch] bf16 = plane of W[k][chunk*32 + ch][col], CO = 32 * nt
 __global__ __launch_bounds__(256) void sp_pack_weight_split_kernel(const float* __restrict__ W, int kvol, int cin, int cout,
-                                                                  int nt, int transpose, int64_t total,
+                                                                  int nt, int transpose, int64_t total, int np,
+                                                                  const uint32_t* __restrict__ amax_w,
                                                                   uint16_t* __restrict__ P) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;        // one (k, chunk, col, ch) per thread
     if (i >= total) return;
@@ -749,10 +769,16 @@ __global__ __launch_bounds__(256) void sp_pack_weight_split_kernel(const float* 
     float v = 0.0f;
     if (c < cin && col < cout)
         v = transpose ? W[((int64_t)k * cout + col) * cin + c] : W[((int64_t)k * cin + c) * cout + col];
-    uint32_t p1, p2, p3;
-    x9_split(v, p1, p2, p3);
-    uint16_t* dst = P + stage * (3 * (int64_t)co * 32) + (int64_t)col * 32 + ch;
-    dst[0] = (uint16_t)p1; dst[(int64_t)co * 32] = (uint16_t)p2; dst[2 * (int64_t)co * 32] = (uint16_t)p3;
+    uint16_t* dst = P + stage * (np * (int64_t)co * 32) + (int64_t)col * 32 + ch;
+    if (np == 3) {
+        uint32_t p1, p2, p3;
+        x9_split(v, p1, p2, p3);
+        dst[0] = (uint16_t)p1; dst[(int64_t)co * 32] = (uint16_t)p2; dst[2 * (int64_t)co * 32] = (uint16_t)p3;
+    } else {                                  // two fp16 planes of the scaled weight (h2_split2)
+        uint32_t w0, w1;
+        h2_split2(v * h2_scale(h2_scale_exp(*amax_w)), 0.0f, w0, w1);
+        dst[0] = (uint16_t)(w0 & 0xFFFFu); dst[(int64_t)co * 32] = (uint16_t)(w1 & 0xFFFFu);
+    }
 }
 
 extern "C" size_t gga_sparse_split_weight_bytes(int kvol, int cin, int cout) {
@@ -762,12 +788,18 @@ extern "C" size_t gga_sparse_split_weight_bytes(int kvol, int cin, int cout) {
 
 extern "C" int gga_sparse_pack_weight_split(const float* weight, int kvol, int cin, int cout, int transpose, void* packed,
                                             void* stream) {
+    return gga_sparse_pack_weight_planes(weight, kvol, cin, cout, transpose, 3, nullptr, packed, stream);
+}
+
+extern "C" int gga_sparse_pack_weight_planes(const float* weight, int kvol, int cin, int cout, int transpose, int planes,
+                                             const uint32_t* amax_weight, void* packed, void* stream) {
     GGA_REQUIRE(weight && packed, "gga_sparse_pack_weight_split: null pointer argument");
+    GGA_REQUIRE(planes == 3 || (planes == 2 && amax_weight), "gga_sparse_pack_weight_split: planes must be 3 (bf16) or 2 (fp16, with amax_weight)");
     GGA_REQUIRE(kvol >= 1 && cin >= 1 && cout >= 1 && cout <= 128,
                 "gga_sparse_pack_weight_split: bad sizes (kvol=%d cin=%d cout=%d; cout <= 128)", kvol, cin, cout);
     const int64_t total = (int64_t)(gga_sparse_split_weight_bytes(kvol, cin, cout) / (3 * sizeof(uint16_t)));
     hipLaunchKernelGGL(sp_pack_weight_split_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       weight, kvol, cin, cout, mf_nt(cout), transpose, total, (uint16_t*)packed);
+                       weight, kvol, cin, cout, mf_nt(cout), transpose, total, planes, amax_weight, (uint16_t*)packed);
     GGA_CHECK_LAUNCH("sp_pack_weight_split_kernel");
     return GGA_OK;
 }
@@ -788,17 +820,23 @@ extern "C" int gga_sparse_pack_weight_split(const float* weight, int kvol, int c
 #define X9_NW 4
 #define X9_TM (32 * X9_NW)
 
-template <int NT, bool VEC>
+template <int NT, bool VEC, int NP>
 __global__ __launch_bounds__(64 * X9_NW) void sp_conv_x9_kernel(const float* __restrict__ X, const int32_t* __restrict__ map,
                                                         const uint16_t* __restrict__ Wp,
                                                         const int32_t* __restrict__ perm,
                                                         const uint32_t* __restrict__ rowmask, int64_t n_rows,
                                                         int kvol, int cin, int cout, int flip,
-                                                        float* __restrict__ Y, int64_t ys) {
+                                                        float* __restrict__ Y, int64_t ys,
+                                                        const uint32_t* __restrict__ amax_x,
+                                                        const uint32_t* __restrict__ amax_w) {
+    // NP = 3: bf16 planes, six partial products; NP = 2: fp16 planes of the scaled operands, three (h2_split2)
     constexpr int CO = NT * 32;
     constexpr int BPL = CO * X9_ROWB;                     // bytes per B plane
-    constexpr int BSZ = 3 * BPL;                          // bytes per B buffer
-    constexpr int BPIECES = 3 * CO * 4;                   // 16-byte pieces of a packed weight stage
+    constexpr int BSZ = NP * BPL;                         // bytes per B buffer
+    constexpr int BPIECES = NP * CO * 4;                  // 16-byte pieces of a packed weight stage
+    int sbx = 127, sbw = 127;
+    if (NP == 2) { sbx = h2_scale_exp(*amax_x); sbw = h2_scale_exp(*amax_w); }
+    const float xscale = h2_scale(sbx);
     constexpr int NW = X9_NW, THREADS = 64 * NW;
     constexpr int NB = (BPIECES + THREADS - 1) / THREADS;   // pieces per thread
     __shared__ __attribute__((aligned(16))) unsigned char Bs[2 * BSZ];
@@ -852,7 +890,7 @@ __global__ __launch_bounds__(64 * X9_NW) void sp_conv_x9_kernel(const float* __r
         rn00 = ld4(row, c); rn01 = ld4(row, c + 4); rn10 = ld4(row, c + 16); rn11 = ld4(row, c + 20);
     };
     auto load_b = [&](int k, int ch) {
-        const uint4* src = reinterpret_cast<const uint4*>(Wp + ((int64_t)k * nchunks + ch) * (3 * CO * 32));
+        const uint4* src = reinterpret_cast<const uint4*>(Wp + ((int64_t)k * nchunks + ch) * (NP * CO * 32));
         const int last = BPIECES - 1;
 #define X9_BLD(E, V) if ((E) < NB) V = src[min(tid + THREADS * (E), last)];
         X9_BLD(0, bq0) X9_BLD(1, bq1) X9_BLD(2, bq2) X9_BLD(3, bq3) X9_BLD(4, bq4) X9_BLD(5, bq5)
@@ -871,7 +909,8 @@ __global__ __launch_bounds__(64 * X9_NW) void sp_conv_x9_kernel(const float* __r
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float x = ok && c + 2 * j < cin ? e[2 * j] : 0.f, y = ok && c + 2 * j + 1 < cin ? e[2 * j + 1] : 0.f;
-            x9_split2(x, y, f1.u[j], f2.u[j], f3.u[j]);
+            if (NP == 3) x9_split2(x, y, f1.u[j], f2.u[j], f3.u[j]);
+            else h2_split2(x * xscale, y * xscale, f1.u[j], f2.u[j]);
         }
     };
 
@@ -908,21 +947,24 @@ __global__ __launch_bounds__(64 * X9_NW) void sp_conv_x9_kernel(const float* __r
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     const Frag* a = s ? a1 : a0;
-                    mf_v8bf b[NT][3];
+                    mf_v8bf b[NT][NP];
 #pragma unroll
                     for (int t = 0; t < NT; ++t)
 #pragma unroll
-                        for (int p = 0; p < 3; ++p) b[t][p] = *reinterpret_cast<const mf_v8bf*>(Bp + p * BPL + t * 32 * X9_ROWB + s * 32);
+                        for (int p = 0; p < NP; ++p) b[t][p] = *reinterpret_cast<const mf_v8bf*>(Bp + p * BPL + t * 32 * X9_ROWB + s * 32);
                     // the nine partial products, smallest first; the column tiles are the inner loop so
                     // that consecutive MFMAs never wait for each other's accumulator
 #define X9_MM(PA, PB) _Pragma("unroll") for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA].v, b[t][PB], acc[t], 0, 0, 0);
-#if defined(X9_THREE)
-                    X9_MM(0, 1) X9_MM(1, 0) X9_MM(0, 0)
-#elif !defined(X9_NINE)
-                    X9_MM(0, 2) X9_MM(1, 1) X9_MM(2, 0) X9_MM(0, 1) X9_MM(1, 0) X9_MM(0, 0)       // six terms, see the dense kernels
+#define X9_MH(PA, PB) _Pragma("unroll") for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(mf_v8h, a[PA].v), __builtin_bit_cast(mf_v8h, b[t][PB]), acc[t], 0, 0, 0);
+                    if (NP == 2) { X9_MH(0, 1) X9_MH(1, 0) X9_MH(0, 0) }
+                    else {
+#if !defined(X9_NINE)
+                    X9_MM(0, NP - 1) X9_MM(1, 1) X9_MM(NP - 1, 0) X9_MM(0, 1) X9_MM(1, 0) X9_MM(0, 0)       // six terms, see the dense kernels
 #else
-                    X9_MM(2, 2) X9_MM(1, 2) X9_MM(2, 1) X9_MM(0, 2) X9_MM(1, 1) X9_MM(2, 0) X9_MM(0, 1) X9_MM(1, 0) X9_MM(0, 0)
+                    X9_MM(NP - 1, NP - 1) X9_MM(1, NP - 1) X9_MM(NP - 1, 1) X9_MM(0, NP - 1) X9_MM(1, 1) X9_MM(NP - 1, 0) X9_MM(0, 1) X9_MM(1, 0) X9_MM(0, 0)
 #endif
+                    }
+#undef X9_MH
 #undef X9_MM
                 }
             }
@@ -939,6 +981,13 @@ __global__ __launch_bounds__(64 * X9_NW) void sp_conv_x9_kernel(const float* __r
     }
     // D layout of 32x32x16: register v of lane l holds row (v/4)*8 + (l/32)*4 + v%4, column l%32;
     // the row -> output row table goes through LDS (each lane knows only its own row)
+    if (NP == 2) {
+        const float dx = h2_descale(sbx), dw = h2_descale(sbw);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[t][i] = acc[t][i] * dx * dw;
+    }
     __syncthreads();
     int* prow = reinterpret_cast<int*>(Bs);
     if (h == 0) prow[wave * 32 + r] = pr;
@@ -959,15 +1008,26 @@ __global__ __launch_bounds__(64 * X9_NW) void sp_conv_x9_kernel(const float* __r
 extern "C" int gga_sparse_conv_apply_split_strided(const float* x, const int32_t* map, const void* split_weight,
                                                    const int32_t* perm, const uint32_t* rowmask, int64_t n_rows, int kvol,
                                                    int cin, int cout, int flip, float* y, int64_t y_row_stride, void* stream_) {
+    return gga_sparse_conv_apply_planes(x, map, split_weight, perm, rowmask, n_rows, kvol, cin, cout, flip, y, y_row_stride, 3,
+                                        nullptr, nullptr, stream_);
+}
+
+extern "C" int gga_sparse_conv_apply_planes(const float* x, const int32_t* map, const void* split_weight, const int32_t* perm,
+                                            const uint32_t* rowmask, int64_t n_rows, int kvol, int cin, int cout, int flip,
+                                            float* y, int64_t y_row_stride, int planes, const uint32_t* amax_x,
+                                            const uint32_t* amax_weight, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     GGA_REQUIRE(x && map && split_weight && y, "gga_sparse_conv_apply_split: null pointer argument");
+    GGA_REQUIRE(planes == 3 || (planes == 2 && amax_x && amax_weight),
+                "gga_sparse_conv_apply_split: planes must be 3 (bf16) or 2 (fp16, with the operands' absmax bits)");
     GGA_REQUIRE(n_rows >= 1 && kvol >= 1 && cin >= 1 && cout >= 1 && cout <= 128 && y_row_stride >= cout,
                 "gga_sparse_conv_apply_split: bad sizes (rows=%lld kvol=%d cin=%d cout=%d row stride %lld; cout <= 128)",
                 (long long)n_rows, kvol, cin, cout, (long long)y_row_stride);
     const dim3 grid((unsigned)((n_rows + X9_TM - 1) / X9_TM)), block(64 * X9_NW);
     hipEvent_t* tev = gga_timing_acquire(GGA_TIME_SPARSE_CONV, GGA_TIMING_CONV_KEY(cin, cout, 0));
     GGA_TIME_START(tev, stream);
-#define X9_LAUNCH(NT, VEC) hipLaunchKernelGGL((sp_conv_x9_kernel<NT, VEC>), grid, block, 0, stream, x, map, (const uint16_t*)split_weight, perm, rowmask, n_rows, kvol, cin, cout, flip, y, y_row_stride)
+#define X9_LAUNCH(NT, VEC) { if (planes == 3) hipLaunchKernelGGL((sp_conv_x9_kernel<NT, VEC, 3>), grid, block, 0, stream, x, map, (const uint16_t*)split_weight, perm, rowmask, n_rows, kvol, cin, cout, flip, y, y_row_stride, amax_x, amax_weight); \
+                             else hipLaunchKernelGGL((sp_conv_x9_kernel<NT, VEC, 2>), grid, block, 0, stream, x, map, (const uint16_t*)split_weight, perm, rowmask, n_rows, kvol, cin, cout, flip, y, y_row_stride, amax_x, amax_weight); }
     if ((cin & 3) == 0) {
         switch (mf_nt(cout)) {
             case 1: X9_LAUNCH(1, true); break;
@@ -1165,11 +1225,16 @@ extern "C" int gga_sparse_conv_wgrad(const float* x, const float* grad_out, cons
 //     the chunks in a fixed order in f64.
 typedef short dw_v4s __attribute__((ext_vector_type(4)));
 #define SPW_SUB 2048
-template <int NI, int NJ, bool VEC>
+template <int NI, int NJ, bool VEC, int NP>
 __global__ __launch_bounds__(256, 2) void sp_conv_wgrad_x9_kernel(const float* __restrict__ X, const float* __restrict__ G,
                                                                  const int32_t* __restrict__ map, int64_t n_rows,
                                                                  int64_t rows_per_chunk, int cin, int cout, int64_t xs,
-                                                                 int64_t gs, float* __restrict__ partials) {
+                                                                 int64_t gs, float* __restrict__ partials,
+                                                                 const uint32_t* __restrict__ amax_x,
+                                                                 const uint32_t* __restrict__ amax_g) {
+    // NP = 3: bf16 planes, six products; NP = 2: fp16 planes of the scaled operands, three (partials stay scaled)
+    float xscale = 1.0f, gscale = 1.0f;
+    if (NP == 2) { xscale = h2_scale(h2_scale_exp(*amax_x)); gscale = h2_scale(h2_scale_exp(*amax_g)); }
     constexpr int CI = NI * 32, CO = NJ * 32;
     constexpr int TILES = NI * NJ;
     constexpr int TPW = TILES >= 4 ? TILES / 4 : 1;          // tiles per wave
@@ -1182,7 +1247,7 @@ __global__ __launch_bounds__(256, 2) void sp_conv_wgrad_x9_kernel(const float* _
     static_assert(NG == 4 || NG == 2 || NG == 1, "tile groups");
     static_assert(KS == 1 || KSTEPS == 2, "a shared tile group needs two K-steps per stage");
     constexpr int XPL = NI * PAIRS * 64, GPL = NJ * PAIRS * 64;   // bytes per plane of one stage image [ch tile][pair][32 ch]
-    constexpr int XSZ = 3 * XPL, GSZ = 3 * GPL;
+    constexpr int XSZ = NP * XPL, GSZ = NP * GPL;
     __shared__ __attribute__((aligned(16))) unsigned char Xs[2 * XSZ];
     __shared__ __attribute__((aligned(16))) unsigned char Gs[2 * GSZ];
     __shared__ int pin[SPW_SUB];          // compacted valid pairs of the sub-chunk: input row
@@ -1264,34 +1329,37 @@ __global__ __launch_bounds__(256, 2) void sp_conv_wgrad_x9_kernel(const float* _
                                      src[q + 3 < cout ? q + 3 : 0]);                                                 \
         }
         // float4 q4 (channels 4*q4 .. +3) of pair pp -> channel tile q4 / 8, byte (q4 % 8) * 8 of the pair's 64-byte row
-#define SW_SPLIT_STORE(V, BASE, PL, PP, Q4) {                                                                        \
-        uint32_t lo1, lo2, lo3, hi1, hi2, hi3;                                                                       \
-        x9_split2(V.x, V.y, lo1, lo2, lo3); x9_split2(V.z, V.w, hi1, hi2, hi3);                                      \
+#define SW_SPLIT_STORE(V, BASE, PL, PP, Q4, SC) {                                                                    \
         unsigned char* dst = (BASE) + ((Q4) >> 3) * (PAIRS * 64) + (PP) * 64 + ((Q4) & 7) * 8;                       \
-        *reinterpret_cast<uint2*>(dst) = make_uint2(lo1, hi1);                                                       \
-        *reinterpret_cast<uint2*>(dst + (PL)) = make_uint2(lo2, hi2);                                                \
-        *reinterpret_cast<uint2*>(dst + 2 * (PL)) = make_uint2(lo3, hi3); }
+        if (NP == 3) {                                                                                               \
+            uint32_t lo1, lo2, lo3, hi1, hi2, hi3;                                                                   \
+            x9_split2(V.x, V.y, lo1, lo2, lo3); x9_split2(V.z, V.w, hi1, hi2, hi3);                                  \
+            *reinterpret_cast<uint2*>(dst) = make_uint2(lo1, hi1);                                                   \
+            *reinterpret_cast<uint2*>(dst + (PL)) = make_uint2(lo2, hi2);                                            \
+            *reinterpret_cast<uint2*>(dst + (NP - 1) * (PL)) = make_uint2(lo3, hi3);                                 \
+        } else {                                                                                                     \
+            uint32_t lo1, lo2, hi1, hi2;                                                                             \
+            h2_split2(V.x * (SC), V.y * (SC), lo1, lo2); h2_split2(V.z * (SC), V.w * (SC), hi1, hi2);                \
+            *reinterpret_cast<uint2*>(dst) = make_uint2(lo1, hi1);                                                   \
+            *reinterpret_cast<uint2*>(dst + (PL)) = make_uint2(lo2, hi2);                                            \
+        } }
 #define SW_STORE(BUF, P0, xr, gr)                                                                                    \
         _Pragma("unroll") for (int e = 0; e < LX; ++e) {                                                             \
             const int t = tid + 256 * e, pp = t / (CI / 4), q = (t - pp * (CI / 4)) * 4;                             \
             const bool ok = (P0) + pp < np && pp < PAIRS;                                                            \
             const float4 v = make_float4(ok && q < cin ? xr[e].x : 0.f, ok && q + 1 < cin ? xr[e].y : 0.f,           \
                                          ok && q + 2 < cin ? xr[e].z : 0.f, ok && q + 3 < cin ? xr[e].w : 0.f);      \
-            if (pp < PAIRS) SW_SPLIT_STORE(v, Xs + (BUF) * XSZ, XPL, pp, q >> 2)                                     \
+            if (pp < PAIRS) SW_SPLIT_STORE(v, Xs + (BUF) * XSZ, XPL, pp, q >> 2, xscale)                             \
         }                                                                                                            \
         _Pragma("unroll") for (int e = 0; e < LG; ++e) {                                                             \
             const int t = tid + 256 * e, pp = t / (CO / 4), q = (t - pp * (CO / 4)) * 4;                             \
             const bool ok = (P0) + pp < np && pp < PAIRS;                                                            \
             const float4 v = make_float4(ok && q < cout ? gr[e].x : 0.f, ok && q + 1 < cout ? gr[e].y : 0.f,         \
                                          ok && q + 2 < cout ? gr[e].z : 0.f, ok && q + 3 < cout ? gr[e].w : 0.f);    \
-            if (pp < PAIRS) SW_SPLIT_STORE(v, Gs + (BUF) * GSZ, GPL, pp, q >> 2)                                     \
+            if (pp < PAIRS) SW_SPLIT_STORE(v, Gs + (BUF) * GSZ, GPL, pp, q >> 2, gscale)                             \
         }
 #define SW_MM(PA, PB) _Pragma("unroll") for (int t = 0; t < TPW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PA.v, PB[t].v, acc[t], 0, 0, 0);
-#ifdef X9_THREE
-#define SW_MM3(A, B, C, D, E, F_)
-#else
-#define SW_MM3(A, B, C, D, E, F_) SW_MM(A, B) SW_MM(C, D) SW_MM(E, F_)
-#endif
+#define SW_MH(PA, PB) _Pragma("unroll") for (int t = 0; t < TPW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(mf_v8h, PA.v), __builtin_bit_cast(mf_v8h, PB[t].v), acc[t], 0, 0, 0);
 #define SW_COMPUTE(BUF)                                                                                              \
         if (wactive) {                                                                                               \
             const unsigned char* xbase = Xs + (BUF) * XSZ + i0 * (PAIRS * 64);                                       \
@@ -1301,16 +1369,17 @@ __global__ __launch_bounds__(256, 2) void sp_conv_wgrad_x9_kernel(const float* _
                 Frag a0, a1, a2;                                                                                     \
                 SW_FRAG(a0, xbase + (16 * s) * 64);                                                                  \
                 SW_FRAG(a1, xbase + XPL + (16 * s) * 64);                                                            \
-                SW_FRAG(a2, xbase + 2 * XPL + (16 * s) * 64);                                                        \
+                if (NP == 3) { SW_FRAG(a2, xbase + (NP - 1) * XPL + (16 * s) * 64); } else a2 = a1;                  \
                 Frag g0[TPW], g1[TPW], g2[TPW];                                                                      \
                 _Pragma("unroll") for (int t = 0; t < TPW; ++t) {                                                    \
                     SW_FRAG(g0[t], gbase + t * (PAIRS * 64) + (16 * s) * 64);                                        \
                     SW_FRAG(g1[t], gbase + GPL + t * (PAIRS * 64) + (16 * s) * 64);                                  \
-                    SW_FRAG(g2[t], gbase + 2 * GPL + t * (PAIRS * 64) + (16 * s) * 64);                              \
+                    if (NP == 3) { SW_FRAG(g2[t], gbase + (NP - 1) * GPL + t * (PAIRS * 64) + (16 * s) * 64); } else g2[t] = g1[t]; \
                 }                                                                                                    \
                 /* six partial products, smallest first; tiles are the inner loop so consecutive MFMAs never wait */ \
                 /* for each other's accumulator */                                                                   \
-                SW_MM3(a0, g2, a1, g1, a2, g0) SW_MM(a0, g1) SW_MM(a1, g0) SW_MM(a0, g0)                                \
+                if (NP == 3) { SW_MM(a0, g2) SW_MM(a1, g1) SW_MM(a2, g0) SW_MM(a0, g1) SW_MM(a1, g0) SW_MM(a0, g0) }    \
+                else { SW_MH(a0, g1) SW_MH(a1, g0) SW_MH(a0, g0) }                                                   \
             }                                                                                                        \
         }
         // The gathers are latency-bound (512-byte rows at random): a stage's loads are issued TWO stages
@@ -1337,6 +1406,7 @@ __global__ __launch_bounds__(256, 2) void sp_conv_wgrad_x9_kernel(const float* _
     }
 #undef SW_COMPUTE
 #undef SW_MM
+#undef SW_MH
 #undef SW_LOAD
 #undef SW_SPLIT_STORE
 #undef SW_STORE
@@ -1368,7 +1438,8 @@ __global__ __launch_bounds__(256, 2) void sp_conv_wgrad_x9_kernel(const float* _
 
 // dW[k][ci][co] = sum over the row chunks' partials [chunk][k][CI][CO], fixed order, f64
 __global__ __launch_bounds__(256) void sp_wgrad_reduce_kernel(const float* __restrict__ partials, int nchunks, int kvol,
-                                                             int cin, int cout, int CI, int CO, float* __restrict__ dW) {
+                                                             int cin, int cout, int CI, int CO, const uint32_t* __restrict__ amax_x,
+                                                             const uint32_t* __restrict__ amax_g, float* __restrict__ dW) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;          // (k, ci, co)
     if (i >= (int64_t)kvol * cin * cout) return;
     const int co = (int)(i % cout), ci = (int)((i / cout) % cin), k = (int)(i / ((int64_t)cin * cout));
@@ -1376,6 +1447,7 @@ __global__ __launch_bounds__(256) void sp_wgrad_reduce_kernel(const float* __res
     double s = 0.0;
 #pragma unroll 8
     for (int c = 0; c < nchunks; ++c) s += (double)p[(int64_t)c * kvol * CI * CO];
+    if (amax_x) s = s * (double)h2_descale(h2_scale_exp(*amax_x)) * (double)h2_descale(h2_scale_exp(*amax_g));     // fp16-plane partials are scaled
     dW[i] = (float)s;
 }
 
@@ -1418,7 +1490,18 @@ extern "C" int gga_sparse_conv_wgrad_split_strided(const float* x, int64_t x_row
                                                    int64_t grad_out_row_stride, const int32_t* map, int64_t n_rows, int kvol,
                                                    int cin, int cout, float* grad_weight, void* workspace,
                                                    size_t workspace_bytes, void* stream_) {
+    return gga_sparse_conv_wgrad_planes(x, x_row_stride, grad_out, grad_out_row_stride, map, n_rows, kvol, cin, cout, grad_weight, 3,
+                                        nullptr, nullptr, workspace, workspace_bytes, stream_);
+}
+
+extern "C" int gga_sparse_conv_wgrad_planes(const float* x, int64_t x_row_stride, const float* grad_out,
+                                            int64_t grad_out_row_stride, const int32_t* map, int64_t n_rows, int kvol, int cin,
+                                            int cout, float* grad_weight, int planes, const uint32_t* amax_x,
+                                            const uint32_t* amax_grad_out, void* workspace, size_t workspace_bytes,
+                                            void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    GGA_REQUIRE(planes == 3 || (planes == 2 && amax_x && amax_grad_out),
+                "gga_sparse_conv_wgrad_split: planes must be 3 (bf16) or 2 (fp16, with the operands' absmax bits)");
     GGA_REQUIRE(x && grad_out && map && grad_weight && workspace, "gga_sparse_conv_wgrad_split: null pointer argument");
     GGA_REQUIRE(n_rows >= 1 && kvol >= 1 && cin >= 1 && cin <= 128 && cout >= 1 && cout <= 128 && x_row_stride >= cin &&
                 grad_out_row_stride >= cout, "gga_sparse_conv_wgrad_split: bad sizes (cin, cout <= 128; row strides >= widths)");
@@ -1436,18 +1519,21 @@ extern "C" int gga_sparse_conv_wgrad_split_strided(const float* x, int64_t x_row
                      ((uintptr_t)x & 15) == 0 && ((uintptr_t)grad_out & 15) == 0;
     hipEvent_t* tev = gga_timing_acquire(GGA_TIME_SPARSE_WGRAD, GGA_TIMING_CONV_KEY(cin, cout, 0));
     GGA_TIME_START(tev, stream);
-#define SW(NI, NJ) { if (vec) hipLaunchKernelGGL((sp_conv_wgrad_x9_kernel<NI, NJ, true>), grid, block, 0, stream, x, grad_out, map, n_rows, rpc, cin, cout, x_row_stride, grad_out_row_stride, (float*)workspace); \
-                     else hipLaunchKernelGGL((sp_conv_wgrad_x9_kernel<NI, NJ, false>), grid, block, 0, stream, x, grad_out, map, n_rows, rpc, cin, cout, x_row_stride, grad_out_row_stride, (float*)workspace); }
+#define SW_ARGS grid, block, 0, stream, x, grad_out, map, n_rows, rpc, cin, cout, x_row_stride, grad_out_row_stride, (float*)workspace, amax_x, amax_grad_out
+#define SW(NI, NJ) { if (planes == 3) { if (vec) hipLaunchKernelGGL((sp_conv_wgrad_x9_kernel<NI, NJ, true, 3>), SW_ARGS); else hipLaunchKernelGGL((sp_conv_wgrad_x9_kernel<NI, NJ, false, 3>), SW_ARGS); } \
+                     else { if (vec) hipLaunchKernelGGL((sp_conv_wgrad_x9_kernel<NI, NJ, true, 2>), SW_ARGS); else hipLaunchKernelGGL((sp_conv_wgrad_x9_kernel<NI, NJ, false, 2>), SW_ARGS); } }
     if (ni == 1 && nj == 1) SW(1, 1)
     else if (ni == 1 && nj == 2) SW(1, 2)
     else if (ni == 2 && nj == 2) SW(2, 2)
     else if (ni == 2 && nj == 4) SW(2, 4)
     else SW(4, 4)
 #undef SW
+#undef SW_ARGS
     GGA_CHECK_LAUNCH("sp_conv_wgrad_x9_kernel");
     const int64_t total = (int64_t)kvol * cin * cout;
     hipLaunchKernelGGL(sp_wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
-                       (const float*)workspace, nchunks, kvol, cin, cout, ni * 32, nj * 32, grad_weight);
+                       (const float*)workspace, nchunks, kvol, cin, cout, ni * 32, nj * 32, planes == 2 ? amax_x : nullptr,
+                       amax_grad_out, grad_weight);
     GGA_CHECK_LAUNCH("sp_wgrad_reduce_kernel");
     GGA_TIME_STOP(tev, stream);
     return GGA_OK;
@@ -2036,11 +2122,9 @@ __global__ __launch_bounds__(256, 2) void dense_wgrad3x3_x9_kernel(const float* 
                 acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.v, g2.v, acc[tap], 0, 0, 0);
                 acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2.v, g1.v, acc[tap], 0, 0, 0);
 #endif
-#ifndef X9_THREE
                 acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.v, g2.v, acc[tap], 0, 0, 0);
                 acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.v, g1.v, acc[tap], 0, 0, 0);
                 acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2.v, g0.v, acc[tap], 0, 0, 0);
-#endif
                 acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.v, g1.v, acc[tap], 0, 0, 0);
                 acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.v, g0.v, acc[tap], 0, 0, 0);
                 acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.v, g0.v, acc[tap], 0, 0, 0);

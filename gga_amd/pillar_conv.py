@@ -54,8 +54,10 @@ class _PillarConv2d(torch.autograd.Function):
             # the dense forward as a gather-GEMM over the canvas rows (strided_conv.py): no framework convolution
             B, Ci, ny, nx = canvas.shape
             bk = strided_conv.book(B, ny, nx, kh, stride[0], padding[0], canvas.device)
+            # the canvas holds the pillar features and zeros: its largest magnitude is theirs (16 MB instead of 877 MB)
             y = strided_conv._apply(strided_conv._rows(canvas), bk.fwd, bk.fwd_mask, bk.fwd_perm,
-                                    weight.detach().permute(2, 3, 1, 0).reshape(kh * kw, Ci, -1), bk.n_out)
+                                    weight.detach().permute(2, 3, 1, 0).reshape(kh * kw, Ci, -1), bk.n_out,
+                                    strided_conv._amax(feats.detach().contiguous()))
             y = y.view(B, bk.Ho, bk.Wo, -1).permute(0, 3, 1, 2)
         else:
             y = torch.conv2d(canvas, weight, None, stride, padding)

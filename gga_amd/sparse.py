@@ -259,38 +259,56 @@ class SparseSequential(SparseModule):
 SPLIT_BF16 = True
 
 
-def _pack_weight(w, kvol, cin, cout, transpose, split=None):
+def planes():
+    """Arithmetic of the split-plane gather kernels: 2 = two fp16 planes of the scaled operands / three partial
+    products, 3 = three bf16 planes / six (dense_conv.PLANES, one switch for all matrix kernels)."""
+    from . import dense_conv
+    return dense_conv.PLANES
+
+
+def amax_bits(t):
+    from . import dense_conv
+    return dense_conv.amax_bits(t)
+
+
+def _pack_weight(w, kvol, cin, cout, transpose, split=None, w_amax=None):
     """[kvol,cin,cout] (or [kvol,cout,cin] with ``transpose``) -> the conv kernel's operand order
-    (gga_sparse_pack_weight / gga_sparse_pack_weight_split)."""
+    (gga_sparse_pack_weight / gga_sparse_pack_weight_split). ``w_amax``: absmax bits of the weight -> two fp16
+    planes; None -> three bf16 planes."""
     L = _lib.lib()
     if SPLIT_BF16 if split is None else split:
         wp = torch.empty(L.gga_sparse_split_weight_bytes(kvol, cin, cout) // 2, dtype=torch.int16, device=w.device)
-        check(L.gga_sparse_pack_weight_split(F._p(w), kvol, cin, cout, transpose, F._p(wp), F._stream()),
-              'gga_sparse_pack_weight_split')
+        check(L.gga_sparse_pack_weight_planes(F._p(w), kvol, cin, cout, transpose, 2 if w_amax is not None else 3, F._p(w_amax),
+                                              F._p(wp), F._stream()), 'gga_sparse_pack_weight_split')
         return wp
     wp = torch.empty(L.gga_sparse_packed_weight_bytes(kvol, cin, cout) // 4, dtype=torch.float32, device=w.device)
     check(L.gga_sparse_pack_weight(F._p(w), kvol, cin, cout, transpose, F._p(wp), F._stream()), 'gga_sparse_pack_weight')
     return wp
 
 
-def _conv_apply(x, rb, wp, n_rows, kvol, cin, cout, flip, y):
+def _conv_apply(x, rb, wp, n_rows, kvol, cin, cout, flip, y, x_amax=None, w_amax=None):
+    """``x_amax`` / ``w_amax`` given: ``wp`` holds two fp16 planes (packed with the same ``w_amax``)."""
     L = _lib.lib()
     if wp.dtype == torch.int16:
-        check(L.gga_sparse_conv_apply_split(F._p(x), F._p(rb.nbr), F._p(wp), F._p(rb.perm), F._p(rb.mask), n_rows,
-                                            kvol, cin, cout, flip, F._p(y), F._stream()), 'gga_sparse_conv_apply_split')
+        check(L.gga_sparse_conv_apply_planes(F._p(x), F._p(rb.nbr), F._p(wp), F._p(rb.perm), F._p(rb.mask), n_rows,
+                                             kvol, cin, cout, flip, F._p(y), cout, 2 if w_amax is not None else 3, F._p(x_amax),
+                                             F._p(w_amax), F._stream()), 'gga_sparse_conv_apply_split')
     else:
         check(L.gga_sparse_conv_apply(F._p(x), F._p(rb.nbr), F._p(wp), F._p(rb.perm), F._p(rb.mask), n_rows, kvol, cin, cout,
                                       flip, F._p(y), F._stream()), 'gga_sparse_conv_apply')
 
 
-def conv_wgrad(x, gy, nbr, n_rows, kvol, cin, cout, gw):
+def conv_wgrad(x, gy, nbr, n_rows, kvol, cin, cout, gw, x_amax=None, g_amax=None):
     """gw [kvol,cin,cout] = sum over the pairs of ``nbr`` of x[in]^T gy[out]: the deterministic
-    bf16-plane kernel (default) or the fp32-MFMA kernel with float atomics (``SPLIT_BF16 = False``)."""
+    split-plane kernel (default; two fp16 planes when the operands' absmax bits are given, three bf16 planes
+    otherwise) or the fp32-MFMA kernel with float atomics (``SPLIT_BF16 = False``)."""
     L = _lib.lib()
     if SPLIT_BF16:
         ws = F._workspace('sp_wgrad', L.gga_sparse_conv_wgrad_workspace_bytes(n_rows, kvol, cin, cout), x.device)
-        check(L.gga_sparse_conv_wgrad_split(F._p(x), F._p(gy), F._p(nbr), n_rows, kvol, cin, cout, F._p(gw), F._p(ws),
-                                            ws.numel(), F._stream()), 'gga_sparse_conv_wgrad_split')
+        two = x_amax is not None and g_amax is not None
+        check(L.gga_sparse_conv_wgrad_planes(F._p(x), cin, F._p(gy), cout, F._p(nbr), n_rows, kvol, cin, cout, F._p(gw),
+                                             2 if two else 3, F._p(x_amax) if two else None, F._p(g_amax) if two else None,
+                                             F._p(ws), ws.numel(), F._stream()), 'gga_sparse_conv_wgrad_split')
     else:
         check(L.gga_sparse_conv_wgrad(F._p(x), F._p(gy), F._p(nbr), n_rows, kvol, cin, cout, F._p(gw), F._stream()),
               'gga_sparse_conv_wgrad')
@@ -307,9 +325,12 @@ class _SparseConvFn(torch.autograd.Function):
         kvol = rb.nbr.shape[0]
         cin, cout = w.shape[-2], w.shape[-1]
         y = torch.empty((n_out, cout), dtype=torch.float32, device=feats.device)
-        _conv_apply(feats, rb, _pack_weight(w, kvol, cin, cout, 0), n_out, kvol, cin, cout, 0, y)
+        two = SPLIT_BF16 and planes() == 2
+        x_amax = amax_bits(feats) if two else None
+        w_amax = amax_bits(w.detach()) if two else None
+        _conv_apply(feats, rb, _pack_weight(w, kvol, cin, cout, 0, w_amax=w_amax), n_out, kvol, cin, cout, 0, y, x_amax, w_amax)
         ctx.save_for_backward(feats, w)
-        ctx.rb, ctx.rb_t = rb, rb_t
+        ctx.rb, ctx.rb_t, ctx.amax = rb, rb_t, (x_amax, w_amax)
         return y
 
     @staticmethod
@@ -322,14 +343,16 @@ class _SparseConvFn(torch.autograd.Function):
         cin, cout = w.shape[-2], w.shape[-1]
         L = _lib.lib()
         gx = gw = None
+        x_amax, w_amax = ctx.amax
+        g_amax = amax_bits(gy) if x_amax is not None else None        # one pass for both consumers of gy
         if ctx.needs_input_grad[0]:
             gx = torch.empty_like(feats)
-            wt = _pack_weight(w, kvol, cout, cin, 1)                  # W[k]^T in fragment order
+            wt = _pack_weight(w, kvol, cout, cin, 1, w_amax=w_amax)   # W[k]^T in fragment order
             tb, flip = (rb_t, 0) if rb_t is not None else (rb, 1)     # SubM: transposed map = reversed offsets
-            _conv_apply(gy, tb, wt, n_in, kvol, cout, cin, flip, gx)
+            _conv_apply(gy, tb, wt, n_in, kvol, cout, cin, flip, gx, g_amax, w_amax)
         if ctx.needs_input_grad[1]:
             gw = torch.empty_like(w)
-            conv_wgrad(feats, gy, rb.nbr, n_out, kvol, cin, cout, gw)
+            conv_wgrad(feats, gy, rb.nbr, n_out, kvol, cin, cout, gw, x_amax, g_amax)
         return gx, gw, None, None, None
 
 

@@ -72,24 +72,47 @@ def _rows(t):
     return t.permute(0, 2, 3, 1).reshape(B * H * W, C)
 
 
-def _apply(x_rows, m, mask, perm, w_kio, n_rows):
-    """y [n_rows, cout] = sum_k x_rows[m[k]] @ w_kio[k]  (w_kio [kvol, cin, cout])."""
+def _planes():
+    from . import dense_conv
+    return dense_conv.PLANES
+
+
+def _amax(t):
+    from . import dense_conv
+    return dense_conv.amax_bits(t) if dense_conv.PLANES == 2 else None
+
+
+def _apply(x_rows, m, mask, perm, w_kio, n_rows, x_amax=None, w_amax=None):
+    """y [n_rows, cout] = sum_k x_rows[m[k]] @ w_kio[k]  (w_kio [kvol, cin, cout]). ``x_amax`` / ``w_amax``: absmax
+    bits of the operands (two-plane arithmetic), computed here when missing."""
     L = _lib.lib()
     kvol, cin, cout = w_kio.shape
+    planes = _planes()
+    if planes == 2:
+        x_amax = _amax(x_rows) if x_amax is None else x_amax
+        w_amax = _amax(w_kio) if w_amax is None else w_amax
+    else:
+        x_amax = w_amax = None
     y = torch.empty((n_rows, cout), dtype=torch.float32, device=x_rows.device)
     for c0 in range(0, cout, 128):
         c1 = min(c0 + 128, cout)
         wp = torch.empty(L.gga_sparse_split_weight_bytes(kvol, cin, c1 - c0) // 2, dtype=torch.int16, device=y.device)
-        check(L.gga_sparse_pack_weight_split(F._p(w_kio[:, :, c0:c1].contiguous()), kvol, cin, c1 - c0, 0, F._p(wp), F._stream()),
-              'gga_sparse_pack_weight_split')
-        check(L.gga_sparse_conv_apply_split_strided(F._p(x_rows), F._p(m), F._p(wp), F._p(perm), F._p(mask), n_rows, kvol, cin,
-                                                    c1 - c0, 0, y.data_ptr() + 4 * c0, cout, F._stream()),
-              'gga_sparse_conv_apply_split_strided')
+        check(L.gga_sparse_pack_weight_planes(F._p(w_kio[:, :, c0:c1].contiguous()), kvol, cin, c1 - c0, 0, planes, F._p(w_amax),
+                                              F._p(wp), F._stream()), 'gga_sparse_pack_weight_split')
+        check(L.gga_sparse_conv_apply_planes(F._p(x_rows), F._p(m), F._p(wp), F._p(perm), F._p(mask), n_rows, kvol, cin,
+                                             c1 - c0, 0, y.data_ptr() + 4 * c0, cout, planes, F._p(x_amax), F._p(w_amax),
+                                             F._stream()), 'gga_sparse_conv_apply_split_strided')
     return y
 
 
-def _wgrad(x_rows, g_rows, m, n_rows):
+def _wgrad(x_rows, g_rows, m, n_rows, x_amax=None, g_amax=None):
     """gw [kvol, cin, cout] = sum over rows of x_rows[m[k][row]]^T g_rows[row] (deterministic)."""
+    planes = _planes()
+    if planes == 2:
+        x_amax = _amax(x_rows) if x_amax is None else x_amax
+        g_amax = _amax(g_rows) if g_amax is None else g_amax
+    else:
+        x_amax = g_amax = None
     L = _lib.lib()
     kvol, cin, cout = m.shape[0], x_rows.shape[1], g_rows.shape[1]
     gw = torch.empty((kvol, cin, cout), dtype=torch.float32, device=x_rows.device)
@@ -100,9 +123,9 @@ def _wgrad(x_rows, g_rows, m, n_rows):
             whole = i1 - i0 == cin and o1 - o0 == cout
             part = gw if whole else torch.empty((kvol, i1 - i0, o1 - o0), dtype=torch.float32, device=gw.device)
             ws = F._workspace('sp_wgrad', L.gga_sparse_conv_wgrad_workspace_bytes(n_rows, kvol, i1 - i0, o1 - o0), gw.device)
-            check(L.gga_sparse_conv_wgrad_split_strided(x_rows.data_ptr() + 4 * i0, cin, g_rows.data_ptr() + 4 * o0, cout, F._p(m),
-                                                        n_rows, kvol, i1 - i0, o1 - o0, F._p(part), F._p(ws), ws.numel(),
-                                                        F._stream()), 'gga_sparse_conv_wgrad_split_strided')
+            check(L.gga_sparse_conv_wgrad_planes(x_rows.data_ptr() + 4 * i0, cin, g_rows.data_ptr() + 4 * o0, cout, F._p(m),
+                                                 n_rows, kvol, i1 - i0, o1 - o0, F._p(part), planes, F._p(x_amax), F._p(g_amax),
+                                                 F._p(ws), ws.numel(), F._stream()), 'gga_sparse_conv_wgrad_split_strided')
             if not whole:
                 gw[:, i0:i1, o0:o1] = part
     return gw
@@ -116,9 +139,10 @@ class _StridedConv(torch.autograd.Function):
         B, cin, H, W = x.shape
         bk = book(B, H, W, k, s, p, x.device)
         w = weight.detach()
-        y = _apply(_rows(x), bk.fwd, bk.fwd_mask, bk.fwd_perm, w.permute(2, 3, 1, 0).reshape(k * k, cin, -1), bk.n_out)
+        x_amax, w_amax = _amax(x), _amax(w)
+        y = _apply(_rows(x), bk.fwd, bk.fwd_mask, bk.fwd_perm, w.permute(2, 3, 1, 0).reshape(k * k, cin, -1), bk.n_out, x_amax, w_amax)
         ctx.save_for_backward(x, weight)
-        ctx.geom = (k, s, p)
+        ctx.geom, ctx.amax = (k, s, p), (x_amax, w_amax)
         return y.view(B, bk.Ho, bk.Wo, -1).permute(0, 3, 1, 2)
 
     @staticmethod
@@ -130,12 +154,14 @@ class _StridedConv(torch.autograd.Function):
         bk = book(B, H, W, k, s, p, x.device)
         g_rows = _rows(gy.contiguous(memory_format=torch.channels_last))
         gx = gw = None
+        x_amax, w_amax = ctx.amax if _planes() == 2 else (None, None)
+        g_amax = _amax(g_rows)
         if ctx.needs_input_grad[0]:
             w = weight.detach()
-            gx = _apply(g_rows, bk.bwd, bk.bwd_mask, bk.bwd_perm, w.permute(2, 3, 0, 1).reshape(k * k, cout, cin), bk.n_in)
+            gx = _apply(g_rows, bk.bwd, bk.bwd_mask, bk.bwd_perm, w.permute(2, 3, 0, 1).reshape(k * k, cout, cin), bk.n_in, g_amax, w_amax)
             gx = gx.view(B, H, W, cin).permute(0, 3, 1, 2)
         if ctx.needs_input_grad[1]:
-            gw = _wgrad(_rows(x), g_rows, bk.fwd, bk.n_out).view(k, k, cin, cout).permute(3, 2, 0, 1)
+            gw = _wgrad(_rows(x), g_rows, bk.fwd, bk.n_out, x_amax, g_amax).view(k, k, cin, cout).permute(3, 2, 0, 1)
         return gx, gw, None, None, None
 
 
@@ -148,9 +174,10 @@ class _Deconv(torch.autograd.Function):
         B, cin, H, W = x.shape
         bk = book(B, H * s, W * s, s, s, 0, x.device)          # fwd [s*s, n_coarse] fine pixel; bwd [s*s, n_fine] coarse pixel
         w = weight.detach()
-        y = _apply(_rows(x), bk.bwd, bk.bwd_mask, bk.bwd_perm, w.permute(2, 3, 0, 1).reshape(s * s, cin, -1), bk.n_in)
+        x_amax, w_amax = _amax(x), _amax(w)
+        y = _apply(_rows(x), bk.bwd, bk.bwd_mask, bk.bwd_perm, w.permute(2, 3, 0, 1).reshape(s * s, cin, -1), bk.n_in, x_amax, w_amax)
         ctx.save_for_backward(x, weight)
-        ctx.s = s
+        ctx.s, ctx.amax = s, (x_amax, w_amax)
         return y.view(B, H * s, W * s, -1).permute(0, 3, 1, 2)
 
     @staticmethod
@@ -162,12 +189,14 @@ class _Deconv(torch.autograd.Function):
         bk = book(B, H * s, W * s, s, s, 0, x.device)
         g_rows = _rows(gy.contiguous(memory_format=torch.channels_last))
         gx = gw = None
+        x_amax, w_amax = ctx.amax if _planes() == 2 else (None, None)
+        g_amax = _amax(g_rows)
         if ctx.needs_input_grad[0]:
             w = weight.detach()
-            gx = _apply(g_rows, bk.fwd, bk.fwd_mask, bk.fwd_perm, w.permute(2, 3, 1, 0).reshape(s * s, cout, cin), bk.n_out)
+            gx = _apply(g_rows, bk.fwd, bk.fwd_mask, bk.fwd_perm, w.permute(2, 3, 1, 0).reshape(s * s, cout, cin), bk.n_out, g_amax, w_amax)
             gx = gx.view(B, H, W, cin).permute(0, 3, 1, 2)
         if ctx.needs_input_grad[1]:      # [k][cout][cin] = sum over coarse rows of gy[fine(k, row)]^T x[row]
-            gw = _wgrad(g_rows, _rows(x), bk.fwd, bk.n_out).view(s, s, cout, cin).permute(3, 2, 0, 1)
+            gw = _wgrad(g_rows, _rows(x), bk.fwd, bk.n_out, g_amax, x_amax).view(s, s, cout, cin).permute(3, 2, 0, 1)
         return gx, gw, None
 
 

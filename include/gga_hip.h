@@ -342,6 +342,17 @@ int gga_dense_wgrad3x3(const float* x, const float* grad_y, int B, int H, int W,
  * (fp16 has no fp32 exponent range) - see DESIGN.md 5. `planes` = 3 selects the bf16 form (no absmax needed).
  * gga_absmax_bits: bits of the largest finite |x| of a [rows, width] f32 matrix into *out_bits (device). */
 int gga_absmax_bits(const float* x, int64_t rows, int width, int64_t row_stride, uint32_t* out_bits, void* stream);
+/* the gather-GEMM kernels (sparse, strided and transposed convolutions) in the same two forms */
+int gga_sparse_pack_weight_planes(const float* weight, int kvol, int cin, int cout, int transpose, int planes,
+                                  const uint32_t* amax_weight, void* packed, void* stream);
+int gga_sparse_conv_apply_planes(const float* x, const int32_t* map, const void* split_weight, const int32_t* perm,
+                                 const uint32_t* rowmask, int64_t n_rows, int kvol, int cin, int cout, int flip, float* y,
+                                 int64_t y_row_stride, int planes, const uint32_t* amax_x, const uint32_t* amax_weight,
+                                 void* stream);
+int gga_sparse_conv_wgrad_planes(const float* x, int64_t x_row_stride, const float* grad_out, int64_t grad_out_row_stride,
+                                 const int32_t* nbr, int64_t n_rows, int kvol, int cin, int cout, float* grad_weight,
+                                 int planes, const uint32_t* amax_x, const uint32_t* amax_grad_out, void* workspace,
+                                 size_t workspace_bytes, void* stream);
 int gga_dense_conv3x3_pack_planes(const float* weight, int64_t stride_co, int64_t stride_ci, int64_t stride_ky,
                                   int64_t stride_kx, int cin, int cout, int backward, int planes,
                                   const uint32_t* amax_weight, void* packed, void* stream);

@@ -6,7 +6,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument('dir'); ap.add_argument('--steps', type=int, default=3); ap.add_argument('--top', type=int, default=30)
 ap.add_argument('--out')
 a = ap.parse_args()
-f = glob.glob(a.dir + '/**/*_kernel_trace.csv', recursive=True)[0]
+import os
+f = max(glob.glob(a.dir + '/**/*_kernel_trace.csv', recursive=True), key=os.path.getmtime)
 rows = list(csv.DictReader(open(f)))
 # one train step = one vox_insert_kernel ... until the optimizer's last kernel; bench.py's roofline
 # probe (which also voxelizes once) runs after the timed steps and is cut off at its first scatter_map

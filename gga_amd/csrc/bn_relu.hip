@@ -206,7 +206,9 @@ __global__ __launch_bounds__(1024) void bn_fwd_final_kernel(const double* __rest
 
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float4* __restrict__ x, const float4* __restrict__ res,
                                                       const float* __restrict__ scale_shift, BnGeom g, int relu,
-                                                      float4* __restrict__ y, unsigned long long* __restrict__ bits) {
+                                                      float4* __restrict__ y, unsigned long long* __restrict__ bits,
+                                                      uint32_t* __restrict__ amax) {
+    uint32_t am = 0;                                     // largest finite |y| written (for the consumer's fp16 scale)
     const int64_t stride = (int64_t)gridDim.x * 256;
     const int64_t e0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int cg = (int)(e0 % g.c4);
@@ -240,9 +242,13 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float4* __restrict_
                 }
                 v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f);
             }
-            if (live) y[bn_strided(g, e, cg)] = v;
+            if (live) {
+                y[bn_strided(g, e, cg)] = v;
+                if (amax) { am = gga_amax_of(v.x, am); am = gga_amax_of(v.y, am); am = gga_amax_of(v.z, am); am = gga_amax_of(v.w, am); }
+            }
         }
     }
+    if (amax) gga_amax_commit(am, amax);
 }
 
 __global__ __launch_bounds__(1024) void bn_bwd_final_kernel(const double* __restrict__ partials, int nblocks, int C,
@@ -266,7 +272,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float4* __restr
                                                           const unsigned long long* __restrict__ bits,
                                                           const float* __restrict__ saved, const float* __restrict__ coef,
                                                           BnGeom g, int relu, float4* __restrict__ dx,
-                                                          float4* __restrict__ dres) {
+                                                          float4* __restrict__ dres, uint32_t* __restrict__ amax) {
+    uint32_t am = 0;                                     // largest finite |dx| written
     const int64_t stride = (int64_t)gridDim.x * 256;
     const int64_t e0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int cg = (int)(e0 % g.c4);
@@ -316,9 +323,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float4* __restr
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[j] = k[j] * (ga[j] - mg[j] - ((xa[j] - mean[j]) * inv[j]) * mgx[j]);
             dx[e] = make_float4(o[0], o[1], o[2], o[3]);
+            if (amax) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) am = gga_amax_of(o[j], am);
+            }
             if (dres) dres[e] = make_float4(ga[0], ga[1], ga[2], ga[3]);
         }
     }
+    if (amax) gga_amax_commit(am, amax);
 }
 
 extern "C" size_t gga_bn_relu_workspace_bytes(int64_t rows, int channels) {
@@ -342,7 +354,7 @@ static int bn_fwd_impl(const float* x, const float* residual, const float* gamma
                        float* running_mean, float* running_var, int64_t rows, int channels, float eps,
                        float momentum, int training, int relu, float* y, int64_t y_row_stride,
                        void* mask_bits, float* saved, const double* given_partials, int n_given, void* workspace,
-                       size_t workspace_bytes, void* stream_) {
+                       size_t workspace_bytes, void* stream_, uint32_t* amax_y = nullptr) {
     hipStream_t stream = (hipStream_t)stream_;
     if (int rc = bn_check("gga_bn_relu_fwd", rows, channels)) return rc;
     GGA_REQUIRE(y_row_stride >= channels && y_row_stride % 4 == 0 && ((uintptr_t)y & 15) == 0,
@@ -369,9 +381,19 @@ static int bn_fwd_impl(const float* x, const float* residual, const float* gamma
                        scale_shift);
     GGA_CHECK_LAUNCH("bn_fwd_final_kernel");
     hipLaunchKernelGGL(bn_apply_kernel, dim3(nb), dim3(256), 0, stream, (const float4*)x, (const float4*)residual,
-                       scale_shift, g, relu, (float4*)y, (unsigned long long*)mask_bits);
+                       scale_shift, g, relu, (float4*)y, (unsigned long long*)mask_bits, amax_y);
     GGA_CHECK_LAUNCH("bn_apply_kernel");
     return GGA_OK;
+}
+
+extern "C" int gga_bn_relu_fwd_ex(const float* x, const float* residual, const float* gamma, const float* beta,
+                                  float* running_mean, float* running_var, int64_t rows, int channels, float eps,
+                                  float momentum, int training, int relu, float* y, int64_t y_row_stride, void* mask_bits,
+                                  float* saved, const double* partials, int n_partials, uint32_t* amax_y, void* workspace,
+                                  size_t workspace_bytes, void* stream_) {
+    return bn_fwd_impl(x, residual, gamma, beta, running_mean, running_var, rows, channels, eps, momentum,
+                       partials ? 1 : training, relu, y, y_row_stride, mask_bits, saved, partials, n_partials, workspace,
+                       workspace_bytes, stream_, amax_y);
 }
 
 extern "C" int gga_bn_stats_partials(const float* gamma, const float* beta, float* running_mean, float* running_var,
@@ -455,6 +477,14 @@ extern "C" int gga_bn_relu_bwd_strided(const float* grad_y, int64_t grad_y_row_s
                                        const void* mask_bits, const float* gamma, const float* saved, int64_t rows,
                                        int channels, int relu, float* grad_x, float* grad_residual, float* grad_gamma,
                                        float* grad_beta, void* workspace, size_t workspace_bytes, void* stream_) {
+    return gga_bn_relu_bwd_ex(grad_y, grad_y_row_stride, x, mask_bits, gamma, saved, rows, channels, relu, grad_x, grad_residual,
+                              grad_gamma, grad_beta, nullptr, workspace, workspace_bytes, stream_);
+}
+
+extern "C" int gga_bn_relu_bwd_ex(const float* grad_y, int64_t grad_y_row_stride, const float* x, const void* mask_bits,
+                                  const float* gamma, const float* saved, int64_t rows, int channels, int relu, float* grad_x,
+                                  float* grad_residual, float* grad_gamma, float* grad_beta, uint32_t* amax_grad_x,
+                                  void* workspace, size_t workspace_bytes, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (int rc = bn_check("gga_bn_relu_bwd", rows, channels)) return rc;
     GGA_REQUIRE(grad_y_row_stride >= channels && grad_y_row_stride % 4 == 0 && ((uintptr_t)grad_y & 15) == 0,
@@ -478,7 +508,7 @@ extern "C" int gga_bn_relu_bwd_strided(const float* grad_y, int64_t grad_y_row_s
     GGA_CHECK_LAUNCH("bn_bwd_final_kernel");
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nb), dim3(256), 0, stream, (const float4*)grad_y, (const float4*)x,
                        (const unsigned long long*)mask_bits, saved, coef, g, relu, (float4*)grad_x,
-                       (float4*)grad_residual);
+                       (float4*)grad_residual, amax_grad_x);
     GGA_CHECK_LAUNCH("bn_bwd_apply_kernel");
     return GGA_OK;
 }

@@ -64,6 +64,27 @@ __device__ __forceinline__ double wave_sum(double v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// Largest finite magnitude (as float bits) seen by a workgroup -> *out by ONE guarded atomicMax (same-address atomics
+// serialise in the L2: thousands of them cost more than the pass they decorate). Call from every thread of a
+// workgroup of at most 1024 threads; `m` = the thread's running maximum of (bits & 0x7fffffff) over finite values.
+__device__ __forceinline__ uint32_t gga_amax_of(float v, uint32_t m) {
+    const uint32_t u = __float_as_uint(v) & 0x7FFFFFFFu;
+    return (u < 0x7F800000u && u > m) ? u : m;
+}
+__device__ __forceinline__ void gga_amax_commit(uint32_t m, uint32_t* out) {
+    __shared__ uint32_t gga_amax_wm[16];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const uint32_t t = __shfl_xor(m, o, 64); m = t > m ? t : m; }
+    const int tid = threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z);
+    const int nw = (blockDim.x * blockDim.y * blockDim.z + 63) >> 6;
+    if ((tid & 63) == 0) gga_amax_wm[tid >> 6] = m;
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < nw; ++w) m = gga_amax_wm[w] > m ? gga_amax_wm[w] : m;
+        if (m > __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(out, m);
+    }
+}
+
 __device__ __forceinline__ int wave_sum(int v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

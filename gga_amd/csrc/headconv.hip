@@ -355,7 +355,8 @@ __global__ __launch_bounds__(256, COUT >= 4 ? 1 : 2) void headtail_bwd_kernel(co
                                                           const float* __restrict__ saved, const float* __restrict__ coef,
                                                           int B, int H, int W, int tiles_x, int tiles_y, int64_t n_tiles,
                                                           int64_t xs, int64_t dxs, double* __restrict__ partials,
-                                                          float* __restrict__ dx) {
+                                                          float* __restrict__ dx, uint32_t* __restrict__ amax) {
+    uint32_t am = 0;                                     // largest finite |dx| written (apply pass)
     __shared__ float gs[2][COUT * HT_HR * HT_HW];
     __shared__ double red[APPLY ? 1 : 256][8];
     const int tid = threadIdx.x, cg = tid & 15, pg = tid >> 4;
@@ -460,7 +461,13 @@ __global__ __launch_bounds__(256, COUT >= 4 ? 1 : 2) void headtail_bwd_kernel(co
                     if (APPLY) o[j] = kk[j] * (gj - mg[j] - xh * mgx[j]);
                     else { f0[j] += gj; f1[j] += gj * xh; }
                 }
-                if (APPLY) *reinterpret_cast<float4*>(dx + (((int64_t)b * H + oy) * W + ox) * dxs + 4 * cg) = make_float4(o[0], o[1], o[2], o[3]);
+                if (APPLY) {
+                    *reinterpret_cast<float4*>(dx + (((int64_t)b * H + oy) * W + ox) * dxs + 4 * cg) = make_float4(o[0], o[1], o[2], o[3]);
+                    if (amax) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) am = gga_amax_of(o[j], am);
+                    }
+                }
             }
         }
         if (!APPLY) {
@@ -471,6 +478,7 @@ __global__ __launch_bounds__(256, COUT >= 4 ? 1 : 2) void headtail_bwd_kernel(co
         __syncthreads();
         ti = tn; b = bn; y0 = y0n; x0 = x0n;
     }
+    if (APPLY && amax) gga_amax_commit(am, amax);
     if (!APPLY) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) { red[tid][j] = s0[j]; red[tid][4 + j] = s1[j]; }
@@ -490,7 +498,7 @@ __global__ __launch_bounds__(256, COUT >= 4 ? 1 : 2) void headtail_bwd_kernel(co
 extern "C" int gga_head_tail_bwd(const float* grad_y, const float* x, int64_t x_pixel_stride, const float* scale_shift,
                                  const float* gamma, const float* saved, const float* weight, int B, int H, int W, int cin,
                                  int cout, float* grad_x, int64_t grad_x_pixel_stride, float* grad_gamma, float* grad_beta,
-                                 void* workspace, size_t workspace_bytes, void* stream_) {
+                                 uint32_t* amax_grad_x, void* workspace, size_t workspace_bytes, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (int rc = headconv_check("gga_head_tail_bwd", B, H, W, cin, cout)) return rc;
     if (int rc = headconv_stride("gga_head_tail_bwd", x, x_pixel_stride)) return rc;
@@ -506,7 +514,7 @@ extern "C" int gga_head_tail_bwd(const float* grad_y, const float* x, int64_t x_
     const int nb = (int)(n_tiles < HT_MAX_BLOCKS ? n_tiles : HT_MAX_BLOCKS);
     double* partials = (double*)workspace;
     float* coef = nullptr;
-#define HT_GO(CO, AP) hipLaunchKernelGGL((headtail_bwd_kernel<CO, AP>), dim3(nb), dim3(256), 0, stream, grad_y, x, weight, scale_shift, saved, coef, B, H, W, tx, ty, n_tiles, x_pixel_stride, grad_x_pixel_stride, partials, grad_x)
+#define HT_GO(CO, AP) hipLaunchKernelGGL((headtail_bwd_kernel<CO, AP>), dim3(nb), dim3(256), 0, stream, grad_y, x, weight, scale_shift, saved, coef, B, H, W, tx, ty, n_tiles, x_pixel_stride, grad_x_pixel_stride, partials, grad_x, amax_grad_x)
 #define HT_SW(AP) switch (cout) { case 1: HT_GO(1, AP); break; case 2: HT_GO(2, AP); break; case 3: HT_GO(3, AP); break; default: HT_GO(4, AP); break; }
     HT_SW(false)
     GGA_CHECK_LAUNCH("headtail_bwd_kernel<reduce>");

@@ -55,6 +55,27 @@ def _transposed(H, W):
     return turned < 0.97 * normal
 
 
+def set_amax(t, amax):
+    """Remember the absmax bits a producer kernel left for ``t`` (valid while ``t`` is not written again)."""
+    if amax is not None:
+        t._gga_amax = (t._version, t.data_ptr(), t.numel(), amax)
+    return t
+
+
+def new_amax(device):
+    """Zeroed absmax accumulator for the producers' ``amax`` outputs (None on the three-bf16-plane path)."""
+    return torch.zeros(1, dtype=torch.int32, device=device) if PLANES == 2 else None
+
+
+def tensor_amax(t):
+    """Absmax bits of ``t``: what its producer left (``set_amax``) if ``t`` has not been modified since, one
+    ``gga_absmax_bits`` pass otherwise."""
+    c = getattr(t, '_gga_amax', None)
+    if c is not None and c[0] == t._version and c[1] == t.data_ptr() and c[2] == t.numel():
+        return c[3]
+    return amax_bits(t)
+
+
 def _pack(weight, backward, transposed=False, w_amax=None):
     """Split-plane operand of the forward (or backward-data) convolution, read from the parameter's
     own memory layout: one kernel, no permuted copy. ``transposed``: for the transposed walk (ky and
@@ -131,7 +152,7 @@ class _Conv3x3(torch.autograd.Function):
     def forward(ctx, x, weight, want_stats):
         cout, cin = weight.shape[0], weight.shape[1]
         two = PLANES == 2
-        x_amax = amax_bits(x) if two else None
+        x_amax = tensor_amax(x) if two else None
         w_amax = amax_bits(weight.detach()) if two else None
         y, stats = _run(x, weight.detach(), False, want_stats, x_amax, w_amax)
         ctx.save_for_backward(x, weight)
@@ -148,7 +169,7 @@ class _Conv3x3(torch.autograd.Function):
         gy = gy.contiguous(memory_format=torch.channels_last)
         gx = gw = None
         x_amax, w_amax = ctx.amax
-        g_amax = amax_bits(gy) if PLANES == 2 else None          # one pass over gy for both of its consumers
+        g_amax = tensor_amax(gy) if PLANES == 2 else None        # left by gy's producer, or one pass for both consumers
         if PLANES != 2:
             x_amax = w_amax = None
         # backward-data is a cout -> cin convolution (taps reversed, channel roles swapped): cin is its

@@ -495,21 +495,22 @@ class _BNAct(torch.autograd.Function):
         saved = torch.empty(2 * C, dtype=torch.float32, device=dev)
         bits = torch.empty(L.gga_bn_relu_mask_bytes(rows, C), dtype=torch.uint8, device=dev) if relu else None
         ws = _workspace('bn', L.gga_bn_relu_workspace_bytes(rows, C), dev)
-        if partials is not None and training:       # the producer of x already reduced the per-channel sums
-            check(L.gga_bn_relu_fwd_partials(_p(x), _p(residual), _p(gamma), _p(beta), _p(running_mean), _p(running_var),
-                                             rows, C, eps, momentum, int(relu), _p(y), C, _p(bits), _p(saved),
-                                             _p(partials), int(partials.shape[0]), _p(ws), ws.numel(), _stream()),
-                  'gga_bn_relu_fwd_partials')
-        else:
-            check(L.gga_bn_relu_fwd(_p(x), _p(residual), _p(gamma), _p(beta), _p(running_mean), _p(running_var), rows, C,
-                                    eps, momentum, int(training), int(relu), _p(y), _p(bits), _p(saved), _p(ws),
-                                    ws.numel(), _stream()), 'gga_bn_relu_fwd')
+        from . import dense_conv
+        amax = dense_conv.new_amax(dev)              # the apply pass leaves max |y| for the convolution that reads y
+        use = partials is not None and training      # the producer of x already reduced the per-channel sums
+        check(L.gga_bn_relu_fwd_ex(_p(x), _p(residual), _p(gamma), _p(beta), _p(running_mean), _p(running_var), rows, C,
+                                   eps, momentum, int(training), int(relu), _p(y), C, _p(bits), _p(saved),
+                                   _p(partials) if use else None, int(partials.shape[0]) if use else 0, _p(amax), _p(ws),
+                                   ws.numel(), _stream()), 'gga_bn_relu_fwd')
         ctx.save_for_backward(x, gamma, saved, bits)
         ctx.cfg = (rows, C, relu, residual is not None)
-        return y
+        if amax is None:
+            amax = torch.empty(0, dtype=torch.int32, device=dev)
+        ctx.mark_non_differentiable(amax)
+        return y, amax
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, _gamax=None):
         x, gamma, saved, bits = ctx.saved_tensors
         rows, C, relu, has_res = ctx.cfg
         L = _lib.lib()
@@ -519,8 +520,11 @@ class _BNAct(torch.autograd.Function):
         gres = torch.empty_like(x) if has_res else None
         gg, gb = torch.empty(C, dtype=torch.float32, device=x.device), torch.empty(C, dtype=torch.float32, device=x.device)
         ws = _workspace('bn', L.gga_bn_relu_workspace_bytes(rows, C), x.device)
-        check(L.gga_bn_relu_bwd(_p(gy), _p(x), _p(bits), _p(gamma), _p(saved), rows, C, int(relu), _p(gx), _p(gres),
-                                _p(gg), _p(gb), _p(ws), ws.numel(), _stream()), 'gga_bn_relu_bwd')
+        from . import dense_conv
+        amax = dense_conv.new_amax(x.device)         # max |gx| for the convolution backward that reads gx
+        check(L.gga_bn_relu_bwd_ex(_p(gy), C, _p(x), _p(bits), _p(gamma), _p(saved), rows, C, int(relu), _p(gx), _p(gres),
+                                   _p(gg), _p(gb), _p(amax), _p(ws), ws.numel(), _stream()), 'gga_bn_relu_bwd')
+        dense_conv.set_amax(gx, amax)
         return gx, gres, gg, gb, None, None, None, None, None, None, None, None, None
 
 
@@ -552,8 +556,12 @@ def bn_act(x, bn, relu=True, residual=None):
     partials = getattr(x, 'bn_partials', None)
     if partials is not None and not (bn.training and partials.dim() == 3 and partials.shape[2] == C):
         partials = None
-    return _BNAct.apply(x, residual, bn.weight, bn.bias, bn.running_mean, bn.running_var, float(bn.eps),
-                        float(bn.momentum), bool(bn.training), bool(relu), int(rc[0]), int(C), partials)
+    y, amax = _BNAct.apply(x, residual, bn.weight, bn.bias, bn.running_mean, bn.running_var, float(bn.eps),
+                           float(bn.momentum), bool(bn.training), bool(relu), int(rc[0]), int(C), partials)
+    if amax.numel():
+        from . import dense_conv
+        dense_conv.set_amax(y, amax)
+    return y
 
 
 class _BNActCat(torch.autograd.Function):
@@ -575,24 +583,30 @@ class _BNActCat(torch.autograd.Function):
         out = torch.empty((B, tot, H, W), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
         saved_all, bits_all = [], []
         off = 0
+        from . import dense_conv
+        amax = dense_conv.new_amax(dev)               # max over all branches' outputs = max of the concatenated map
         for i in range(n):
             eps, momentum, training = cfg[i]
             C = chans[i]
             saved = torch.empty(2 * C, dtype=torch.float32, device=dev)
             bits = torch.empty(L.gga_bn_relu_mask_bytes(rows, C), dtype=torch.uint8, device=dev)
             ws = _workspace('bn', L.gga_bn_relu_workspace_bytes(rows, C), dev)
-            check(L.gga_bn_relu_fwd_strided(_p(xs[i]), None, _p(gammas[i]), _p(betas[i]), _p(rms[i]), _p(rvs[i]), rows, C,
-                                            eps, momentum, int(training), 1, out.data_ptr() + 4 * off, tot, _p(bits),
-                                            _p(saved), _p(ws), ws.numel(), _stream()), 'gga_bn_relu_fwd_strided')
+            check(L.gga_bn_relu_fwd_ex(_p(xs[i]), None, _p(gammas[i]), _p(betas[i]), _p(rms[i]), _p(rvs[i]), rows, C,
+                                       eps, momentum, int(training), 1, out.data_ptr() + 4 * off, tot, _p(bits),
+                                       _p(saved), None, 0, _p(amax), _p(ws), ws.numel(), _stream()), 'gga_bn_relu_fwd_strided')
             saved_all.append(saved)
             bits_all.append(bits)
             off += C
         ctx.save_for_backward(*xs, *gammas, *saved_all, *bits_all)
         ctx.n, ctx.chans, ctx.rows = n, chans, rows
-        return out
+        if amax is None:
+            amax = torch.empty(0, dtype=torch.int32, device=dev)
+        ctx.mark_non_differentiable(amax)
+        return out, amax
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, _gamax=None):
+        from . import dense_conv
         n, chans, rows = ctx.n, ctx.chans, ctx.rows
         t = ctx.saved_tensors
         xs, gammas, saved_all, bits_all = t[:n], t[n:2 * n], t[2 * n:3 * n], t[3 * n:4 * n]
@@ -608,9 +622,11 @@ class _BNActCat(torch.autograd.Function):
             gg = torch.empty(C, dtype=torch.float32, device=x.device)
             gb = torch.empty(C, dtype=torch.float32, device=x.device)
             ws = _workspace('bn', L.gga_bn_relu_workspace_bytes(rows, C), x.device)
-            check(L.gga_bn_relu_bwd_strided(g.data_ptr() + 4 * off, tot, _p(x), _p(bits_all[i]), _p(gammas[i]),
-                                            _p(saved_all[i]), rows, C, 1, _p(gx), None, _p(gg), _p(gb), _p(ws),
-                                            ws.numel(), _stream()), 'gga_bn_relu_bwd_strided')
+            amax = dense_conv.new_amax(x.device)
+            check(L.gga_bn_relu_bwd_ex(g.data_ptr() + 4 * off, tot, _p(x), _p(bits_all[i]), _p(gammas[i]),
+                                       _p(saved_all[i]), rows, C, 1, _p(gx), None, _p(gg), _p(gb), _p(amax), _p(ws),
+                                       ws.numel(), _stream()), 'gga_bn_relu_bwd_strided')
+            dense_conv.set_amax(gx, amax)
             gxs.append(gx), ggs.append(gg), gbs.append(gb)
             off += C
         return (None, None, *gxs, *ggs, *gbs) + (None,) * (2 * n)
@@ -634,8 +650,12 @@ def bn_relu_cat(xs, bns):
             bn.num_batches_tracked += 1
     n = len(xs)
     cfg = tuple((float(bn.eps), float(bn.momentum), bool(bn.training)) for bn in bns)
-    return _BNActCat.apply(n, cfg, *xs, *[bn.weight for bn in bns], *[bn.bias for bn in bns],
-                           *[bn.running_mean for bn in bns], *[bn.running_var for bn in bns])
+    out, amax = _BNActCat.apply(n, cfg, *xs, *[bn.weight for bn in bns], *[bn.bias for bn in bns],
+                                *[bn.running_mean for bn in bns], *[bn.running_var for bn in bns])
+    if amax.numel():
+        from . import dense_conv
+        dense_conv.set_amax(out, amax)
+    return out
 
 
 # ----------------------------------------------------------------------------- head output convs
@@ -722,8 +742,11 @@ class _BnReluHeadConv3x3(torch.autograd.Function):
         gg = torch.empty(C, dtype=torch.float32, device=dev)
         gbeta = torch.empty(C, dtype=torch.float32, device=dev)
         wsb = _workspace('bn', L.gga_bn_relu_workspace_bytes(rows, C), dev)
+        from . import dense_conv
+        amax = dense_conv.new_amax(dev)
         check(L.gga_head_tail_bwd(_p(gy), _p(x), C, _p(ss), _p(gamma), _p(saved), _p(w), B, H, W, C, cout, _p(gx), C, _p(gg), _p(gbeta),
-                                  _p(wsb), wsb.numel(), _stream()), 'gga_head_tail_bwd')
+                                  _p(amax), _p(wsb), wsb.numel(), _stream()), 'gga_head_tail_bwd')
+        dense_conv.set_amax(gx, amax)
         return gx, gg, gbeta, None, None, gw, gb, None, None, None, None
 
 
@@ -767,7 +790,7 @@ class _HeadBranches(torch.autograd.Function):
         Y = torch.empty((B, tot, H, W), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
         tiles = int(L.gga_dense_conv3x3_tiles(B, W, H, C) if tr else L.gga_dense_conv3x3_tiles(B, H, W, C))
         outs, saved_all, ss_all = [], [], []
-        x_amax = dense_conv.amax_bits(x) if dense_conv.PLANES == 2 else None       # one pass for all n convolutions
+        x_amax = dense_conv.tensor_amax(x) if dense_conv.PLANES == 2 else None     # from x's producer, for all n convolutions
         for i in range(n):
             eps, momentum = cfg[i]
             _, st = dense_conv._run(x, w1[i].detach(), False, True, x_amax, None, Y, C * i)
@@ -796,6 +819,7 @@ class _HeadBranches(torch.autograd.Function):
         B, C, H, W = x.shape
         rows, dev, tot = B * H * W, x.device, C * n
         G = torch.empty_like(Y)
+        g_amax = dense_conv.new_amax(dev)             # the tail kernels leave max |G| for the two convolutions that read G
         gw2, gb2, ggam, gbet = [], [], [], []
         wsb = _workspace('bn', L.gga_bn_relu_workspace_bytes(rows, C), dev)
         for i in range(n):
@@ -810,11 +834,10 @@ class _HeadBranches(torch.autograd.Function):
             gg = torch.empty(C, dtype=torch.float32, device=dev)
             gbeta = torch.empty(C, dtype=torch.float32, device=dev)
             check(L.gga_head_tail_bwd(_p(gy), Y.data_ptr() + 4 * C * i, tot, _p(ss_all[i]), _p(gam[i]), _p(saved_all[i]), _p(w), B, H, W,
-                                      C, cout, G.data_ptr() + 4 * C * i, tot, _p(gg), _p(gbeta), _p(wsb), wsb.numel(), _stream()),
-                  'gga_head_tail_bwd')
+                                      C, cout, G.data_ptr() + 4 * C * i, tot, _p(gg), _p(gbeta), _p(g_amax), _p(wsb), wsb.numel(),
+                                      _stream()), 'gga_head_tail_bwd')
             gw2.append(gw), gb2.append(gb), ggam.append(gg), gbet.append(gbeta)
         wcat = torch.cat([w.detach() for w in w1], dim=0)            # [64n, 64, 3, 3]
-        g_amax = dense_conv.amax_bits(G) if dense_conv.PLANES == 2 else None
         gx = dense_conv._run(G, wcat, True, False, g_amax)[0] if ctx.needs_input_grad[0] else None
         gwcat = dense_conv._wgrad(x, G, wcat, ctx.x_amax if dense_conv.PLANES == 2 else None, g_amax)
         gw1 = list(gwcat.split(C, dim=0))

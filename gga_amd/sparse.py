@@ -267,8 +267,9 @@ def planes():
 
 
 def amax_bits(t):
+    """Absmax bits of ``t``: left by its producer (the fused BatchNorm kernels) when possible, else one pass."""
     from . import dense_conv
-    return dense_conv.amax_bits(t)
+    return dense_conv.tensor_amax(t)
 
 
 def _pack_weight(w, kvol, cin, cout, transpose, split=None, w_amax=None):

@@ -78,8 +78,9 @@ def _planes():
 
 
 def _amax(t):
+    """Absmax bits of ``t`` (left by its producer when possible), None on the three-bf16-plane path."""
     from . import dense_conv
-    return dense_conv.amax_bits(t) if dense_conv.PLANES == 2 else None
+    return dense_conv.tensor_amax(t) if dense_conv.PLANES == 2 else None
 
 
 def _apply(x_rows, m, mask, perm, w_kio, n_rows, x_amax=None, w_amax=None):
@@ -152,10 +153,11 @@ class _StridedConv(torch.autograd.Function):
         B, cin, H, W = x.shape
         cout = weight.shape[0]
         bk = book(B, H, W, k, s, p, x.device)
-        g_rows = _rows(gy.contiguous(memory_format=torch.channels_last))
+        gy = gy.contiguous(memory_format=torch.channels_last)
+        g_rows = _rows(gy)
         gx = gw = None
         x_amax, w_amax = ctx.amax if _planes() == 2 else (None, None)
-        g_amax = _amax(g_rows)
+        g_amax = _amax(gy)
         if ctx.needs_input_grad[0]:
             w = weight.detach()
             gx = _apply(g_rows, bk.bwd, bk.bwd_mask, bk.bwd_perm, w.permute(2, 3, 0, 1).reshape(k * k, cout, cin), bk.n_in, g_amax, w_amax)
@@ -187,10 +189,11 @@ class _Deconv(torch.autograd.Function):
         B, cin, H, W = x.shape
         cout = weight.shape[1]
         bk = book(B, H * s, W * s, s, s, 0, x.device)
-        g_rows = _rows(gy.contiguous(memory_format=torch.channels_last))
+        gy = gy.contiguous(memory_format=torch.channels_last)
+        g_rows = _rows(gy)
         gx = gw = None
         x_amax, w_amax = ctx.amax if _planes() == 2 else (None, None)
-        g_amax = _amax(g_rows)
+        g_amax = _amax(gy)
         if ctx.needs_input_grad[0]:
             w = weight.detach()
             gx = _apply(g_rows, bk.fwd, bk.fwd_mask, bk.fwd_perm, w.permute(2, 3, 1, 0).reshape(s * s, cout, cin), bk.n_out, g_amax, w_amax)

@@ -444,6 +444,20 @@ int gga_bn_relu_bwd_strided(const float* grad_y, int64_t grad_y_row_stride, cons
  * in_scale_shift), so the normalised activation is never written. Its backward is
  * gga_bn_relu_bwd[_strided] with relu = 2 and mask_bits = scale_shift: the ReLU mask is
  * recomputed as fma(x, scale, shift) > 0 instead of read from stored bits. */
+/* Supersets of the calls above with one more output: the bits of the largest finite magnitude written (y /
+ * grad_x), max-combined into *amax (the caller zeroes it; several calls may share it) - what the two-fp16-plane
+ * convolution kernels that consume the tensor derive their scale from, without a pass of their own.
+ * gga_bn_relu_fwd_ex: partials != NULL = the producer's per-channel sums (as gga_bn_relu_fwd_partials). */
+int gga_bn_relu_fwd_ex(const float* x, const float* residual, const float* gamma, const float* beta,
+                       float* running_mean, float* running_var, int64_t rows, int channels, float eps, float momentum,
+                       int training, int relu, float* y, int64_t y_row_stride, void* mask_bits, float* saved,
+                       const double* partials, int n_partials, uint32_t* amax_y, void* workspace, size_t workspace_bytes,
+                       void* stream);
+int gga_bn_relu_bwd_ex(const float* grad_y, int64_t grad_y_row_stride, const float* x, const void* mask_bits,
+                       const float* gamma, const float* saved, int64_t rows, int channels, int relu, float* grad_x,
+                       float* grad_residual, float* grad_gamma, float* grad_beta, uint32_t* amax_grad_x, void* workspace,
+                       size_t workspace_bytes, void* stream);
+
 int gga_bn_stats(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
                  int64_t rows, int channels, float eps, float momentum, int training, float* saved,
                  float* scale_shift, void* workspace, size_t workspace_bytes, void* stream);
@@ -482,11 +496,12 @@ int gga_head_conv3x3_wgrad(const float* x, int64_t x_pixel_stride, const float* 
  * grad_y [B,cout,H,W], the conv weight and the statistics gga_bn_stats left (saved = mean / invstd,
  * scale_shift). The conv's input gradient is rebuilt from grad_y inside the two BatchNorm-backward passes and
  * never stored. x / grad_x may be 64-channel column blocks of wider tensors (pixel strides in floats).
+ * amax_grad_x (optional): atomicMax target for the bits of the largest finite |grad_x| written (not reset here).
  * workspace: gga_bn_relu_workspace_bytes(B*H*W, 64). */
 int gga_head_tail_bwd(const float* grad_y, const float* x, int64_t x_pixel_stride, const float* scale_shift,
                       const float* gamma, const float* saved, const float* weight, int B, int H, int W, int cin, int cout,
-                      float* grad_x, int64_t grad_x_pixel_stride, float* grad_gamma, float* grad_beta, void* workspace,
-                      size_t workspace_bytes, void* stream);
+                      float* grad_x, int64_t grad_x_pixel_stride, float* grad_gamma, float* grad_beta, uint32_t* amax_grad_x,
+                      void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------- */
 /* a6/a7. Heat-map target splat on the device.                                */

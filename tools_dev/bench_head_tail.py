@@ -36,7 +36,7 @@ for cout in (1, 2, 3):
 
     def fused():
         _lib.check(L.gga_head_tail_bwd(F._p(gy), F._p(x), C, F._p(ss), F._p(gamma), F._p(saved), F._p(w), B, H, W, C, cout, F._p(gx), C,
-                                       F._p(gg), F._p(gb), F._p(ws), ws.numel(), F._stream()), 'tail')
+                                       F._p(gg), F._p(gb), None, F._p(ws), ws.numel(), F._stream()), 'tail')
 
     def split():
         gh = torch.ops.aten.convolution_backward(gy, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [True, False, False])[0]

@@ -40,11 +40,12 @@ sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (guides/MI355X_MICROARCH.md); ~6300 achievable
 BF16_PEAK_TFLOPS = 2500.0
-ARITH = ('fp32 in / fp32 out, fp32 accumulate. Dense 3x3 convolutions: operands scaled by a power of two to their largest '
-         'magnitude and split into two round-to-nearest fp16 planes (22-bit significands), three f16 MFMA partial products '
-         '(error vs float64 <= MIOpen fp32; per element an absolute accuracy of 2^-39 of its tensor\'s largest magnitude; '
-         'GGA_DENSE_PLANES=3 selects three bf16 planes / six products with fp32\'s full exponent range). Sparse, strided and '
-         'transposed convolutions: three bf16 planes, six bf16 MFMA partial products. Everything else plain fp32')
+ARITH = ('fp32 in / fp32 out, fp32 accumulate. Every convolution (dense 3x3, strided, transposed, sparse 3D; forward, '
+         'backward-data, weight gradient): operands scaled by a power of two to their largest finite magnitude and split into '
+         'two round-to-nearest fp16 planes (22-bit significands), three f16 MFMA partial products, exact rescale - error vs '
+         'float64 <= MIOpen fp32; per element an absolute accuracy of 2^-39 of its tensor\'s largest magnitude. '
+         'GGA_DENSE_PLANES=3 selects three bf16 planes / six products (fp32\'s full exponent range). Head output convs: fp32 '
+         'MFMA. Everything else plain fp32')
 PP_CONFIG = os.path.join(REPO, 'configs', 'gga', 'gga_kitti_pointpillars_config.py')
 SECOND_CONFIG = os.path.join(REPO, 'configs', 'gga', 'gga_kitti_config.py')
 PGD_CONFIG = os.path.join(REPO, 'configs', 'gga', 'gga_pdg.py')

@@ -615,10 +615,13 @@ def test_pillar_conv_valid_count_and_fallbacks():
                                            (128, 256, 1, 9, 40),
                                            # 16-row / 512-thread tiles (cout 128 and >= 384 tiles): straight and transposed walk
                                            (128, 128, 12, 128, 128), (128, 128, 16, 124, 108), (64, 128, 13, 120, 128)])
-def test_dense_conv3x3_vs_torch(cin, cout, B, H, W):
-    """fp32 convolution through nine exact bf16 partial products: forward and backward-data against
-    torch's convolution in float64 (error no larger than a few fp32 ulps of the accumulated sum)."""
+@pytest.mark.parametrize('planes', [2, 3])
+def test_dense_conv3x3_vs_torch(cin, cout, B, H, W, planes, monkeypatch):
+    """fp32 convolution through split-plane partial products (planes = 2: two fp16 planes of the scaled operands,
+    three products - the default; planes = 3: three bf16 planes, six products): forward, backward-data and weight
+    gradient against torch's convolution in float64 (error no larger than a few fp32 ulps of the accumulated sum)."""
     from gga_amd import dense_conv
+    monkeypatch.setattr(dense_conv, 'PLANES', planes)
     torch.manual_seed(cin + cout)
     conv = torch.nn.Conv2d(cin, cout, 3, padding=1, bias=False).to(DEV)
     conv.weight.data = conv.weight.data.contiguous(memory_format=torch.channels_last)
@@ -686,11 +689,13 @@ def test_dense_conv_leaves_batchnorm_partials(cin, cout, B, H, W):
                                                       ('conv', 64, 64, 3, 2, 1, 40, 32), ('conv', 384, 64, 1, 1, 1, 20, 24),
                                                       ('deconv', 64, 128, 1, 1, 2, 37, 45), ('deconv', 128, 128, 2, 2, 2, 19, 23),
                                                       ('deconv', 256, 128, 4, 4, 2, 9, 11), ('deconv', 256, 256, 2, 2, 1, 8, 8)])
-def test_strided_and_transposed_convs_vs_torch(kind, cin, cout, k, s, B, H, W):
+@pytest.mark.parametrize('planes', [2, 3])
+def test_strided_and_transposed_convs_vs_torch(kind, cin, cout, k, s, B, H, W, planes, monkeypatch):
     """The SECOND stage openers (3x3 / stride 2) and the SECONDFPN transposed convolutions (kernel = stride) on
     the gather-GEMM kernels (gga_amd/strided_conv.py): output, input gradient and weight gradient against
     float64 torch, next to the framework's own fp32 convolution."""
     from gga_amd import dense_conv, strided_conv
+    monkeypatch.setattr(dense_conv, 'PLANES', planes)
     torch.manual_seed(5)
     if kind == 'conv':
         m = torch.nn.Conv2d(cin, cout, k, s, k // 2, bias=False)

@@ -54,7 +54,10 @@ def _sorted_rows(feats, coors, shape):
     dict(cls=SparseConv3d, cin=96, cout=48, k=3, s=2, p=1),          # ... and a padded (4,4)
     dict(cls=SubMConv3d, cin=64, cout=64, k=3, s=1, p=1),            # (2,2)
 ])
-def test_single_conv_fwd_bwd(cfg):
+@pytest.mark.parametrize('planes', [2, 3])       # two fp16 planes / three products (default), three bf16 planes / six
+def test_single_conv_fwd_bwd(cfg, planes, monkeypatch):
+    from gga_amd import dense_conv
+    monkeypatch.setattr(dense_conv, 'PLANES', planes)
     torch.manual_seed(0)
     shape, B = (11, 24, 20), 2
     coors = _coords(B, shape, 300, seed=1)

@@ -1573,8 +1573,11 @@ extern "C" int gga_sparse_conv_wgrad_planes(const float* x, int64_t x_row_stride
 
 // NP = 3: three bf16 planes, six partial products (any fp32 input). NP = 2: two fp16 planes of the scaled operands, three
 // partial products (see h2_split2); `amax` then points to {bits of max finite |x|, bits of max finite |w|}.
-template <int NT, int TR, int NP>
-__global__ __launch_bounds__(TR * 32, 2) void dense_conv3x3_x9_kernel(const float* __restrict__ X, const uint16_t* __restrict__ Wp,
+// MT: image rows (32-pixel M tiles) per wave; a workgroup has TR / MT waves. Shipped: MT = 2. (MT = 4 with 16-row tiles
+// and four waves at 64 output channels - 0.5 instead of 0.67 LDS fragment reads per MFMA on two fp16 planes - needs 50
+// spilled registers next to its 128 accumulators: 368 instead of 297 us per 64 -> 64 call incl. its absmax pass.)
+template <int NT, int TR, int NP, int MT>
+__global__ __launch_bounds__(TR / MT * 64, 2) void dense_conv3x3_x9_kernel(const float* __restrict__ X, const uint16_t* __restrict__ Wp,
                                                                  int B, int H, int W, int cin, int cout, int tiles_x,
                                                                  int tiles_y, float* __restrict__ Y, int ystride,
                                                                  int prow, int pcol, double* __restrict__ stats,
@@ -1587,7 +1590,7 @@ __global__ __launch_bounds__(TR * 32, 2) void dense_conv3x3_x9_kernel(const floa
     // TR = 16 (128 output channels on maps with enough tiles): 512 threads own 16 rows - one workgroup per
     // CU but two waves per SIMD again (124 x 108: 324 instead of 379 us); on small maps the 16-row tiles
     // leave CUs idle (62 x 54: 523 instead of 366 us), so the launcher picks per shape.
-    constexpr int THREADS = TR * 32, NWAVES = TR / 2;
+    constexpr int NWAVES = TR / MT, THREADS = NWAVES * 64;
     constexpr int HP = (TR + 2) * DC_HW, NA = (HP * 4 + THREADS - 1) / THREADS;
     constexpr int CO = NT * 32;
     constexpr int BPL = CO * DC_ROWB, BSZ = NP * BPL, BPIECES = NP * CO * 2;
@@ -1604,7 +1607,7 @@ __global__ __launch_bounds__(TR * 32, 2) void dense_conv3x3_x9_kernel(const floa
     const int n_tiles = B * per_img;
     const int nchunks = cin / DC_CK;                  // 16-channel chunks
     const int nchunks32 = cin / MF_TK;                // chunks of the packed weight layout
-    mf_v16 acc[2][NT];
+    mf_v16 acc[MT][NT];
 
     // halo piece e of this thread: pixel (tid + 256 e) / 4, channels 4 * ((tid + 256 e) % 4) .. +3 of the chunk
     float4 ra[NA];
@@ -1648,7 +1651,7 @@ __global__ __launch_bounds__(TR * 32, 2) void dense_conv3x3_x9_kernel(const floa
     // (~1.5 us with two waves per SIMD) to come back from the L2 - with one stage the per-stage s_waitcnt was the
     // largest single loss of the kernel (ablation: 375 -> 303 us at 64 -> 64 without the loads).
     // (the 512-thread form is limited to 256 registers by its two waves per SIMD and keeps one set.)
-    constexpr bool DEEP = !(NT == 4 && TR == 16);
+    constexpr bool DEEP = !(NT == 4 && TR == 16) && MT == 2;
     uint4 bq0, bq1, bq2, cq0, cq1, cq2;
     bq0 = bq1 = bq2 = cq0 = cq1 = cq2 = make_uint4(0, 0, 0, 0);
     // the packed stage (tap, 16-channel chunk) is contiguous and in LDS piece order (dense_pack_weight_kernel): a wave
@@ -1668,18 +1671,18 @@ __global__ __launch_bounds__(TR * 32, 2) void dense_conv3x3_x9_kernel(const floa
     // tap offsets and buffer numbers are immediates.
     // fragments: the two M tiles' A planes, and the B planes of TWO N tiles at a time (with four N tiles all
     // twelve B fragments alive next to 128 accumulator registers do not fit 256 registers)
-    mf_v8bf fa[2][NP], fb[2][NP];
+    mf_v8bf fa[MT][NP], fb[2][NP];
 #define DC_READ_A(TAP) {                                                                                              \
-        const unsigned char* Ap = As + ((2 * wave + (TAP) / 3) * DC_HW + r + (TAP) % 3) * DC_ROWB + h * 16;           \
-        _Pragma("unroll") for (int m = 0; m < 2; ++m) _Pragma("unroll") for (int p = 0; p < NP; ++p)                  \
+        const unsigned char* Ap = As + ((MT * wave + (TAP) / 3) * DC_HW + r + (TAP) % 3) * DC_ROWB + h * 16;           \
+        _Pragma("unroll") for (int m = 0; m < MT; ++m) _Pragma("unroll") for (int p = 0; p < NP; ++p)                 \
             fa[m][p] = *reinterpret_cast<const mf_v8bf*>(Ap + p * APL + m * DC_HW * DC_ROWB); }
 #define DC_READ_B(TAP, T0) {                                                                                          \
         const unsigned char* Bp = Bs + ((TAP) % 3) * BSZ + r * DC_ROWB + h * 16 + (T0) * 32 * DC_ROWB;                \
         _Pragma("unroll") for (int t = 0; t < 2; ++t) _Pragma("unroll") for (int p = 0; p < NP; ++p)                  \
             fb[t][p] = *reinterpret_cast<const mf_v8bf*>(Bp + p * BPL + t * 32 * DC_ROWB); }
     // partial products smallest first; tiles innermost so consecutive MFMAs never share an accumulator
-#define DC_MM1(T0, PA, PB) _Pragma("unroll") for (int m = 0; m < 2; ++m) _Pragma("unroll") for (int t = 0; t < 2; ++t) acc[m][(T0) + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[m][PA], fb[t][PB], acc[m][(T0) + t], 0, 0, 0);
-#define DC_MH1(T0, PA, PB) _Pragma("unroll") for (int m = 0; m < 2; ++m) _Pragma("unroll") for (int t = 0; t < 2; ++t) acc[m][(T0) + t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(mf_v8h, fa[m][PA]), __builtin_bit_cast(mf_v8h, fb[t][PB]), acc[m][(T0) + t], 0, 0, 0);
+#define DC_MM1(T0, PA, PB) _Pragma("unroll") for (int m = 0; m < MT; ++m) _Pragma("unroll") for (int t = 0; t < 2; ++t) acc[m][(T0) + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[m][PA], fb[t][PB], acc[m][(T0) + t], 0, 0, 0);
+#define DC_MH1(T0, PA, PB) _Pragma("unroll") for (int m = 0; m < MT; ++m) _Pragma("unroll") for (int t = 0; t < 2; ++t) acc[m][(T0) + t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(mf_v8h, fa[m][PA]), __builtin_bit_cast(mf_v8h, fb[t][PB]), acc[m][(T0) + t], 0, 0, 0);
 #ifdef X9_SIX
 #define DC_MMA3(T0) DC_MM1(T0, 0, NP - 1) DC_MM1(T0, 1, 1) DC_MM1(T0, NP - 1, 0) DC_MM1(T0, 0, 1) DC_MM1(T0, 1, 0) DC_MM1(T0, 0, 0)
 #else
@@ -1716,7 +1719,7 @@ __global__ __launch_bounds__(TR * 32, 2) void dense_conv3x3_x9_kernel(const floa
         DC_TILE(tile, b, y0, x0)
         const bool more_tiles = tile + (int)gridDim.x < n_tiles;
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -1771,7 +1774,7 @@ __global__ __launch_bounds__(TR * 32, 2) void dense_conv3x3_x9_kernel(const floa
         if (NP == 2) {                                     // back from the scaled operands: two exact powers of two
             const float dx = h2_descale(sbx), dw = h2_descale(sbw);
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+            for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -1779,8 +1782,8 @@ __global__ __launch_bounds__(TR * 32, 2) void dense_conv3x3_x9_kernel(const floa
         }
         // D layout of 32x32x16: register v of lane l holds row (v/4)*8 + (l/32)*4 + v%4 (= pixel of the M tile's row), column l%32
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            const int oy = y0 + 2 * wave + m;
+        for (int m = 0; m < MT; ++m) {
+            const int oy = y0 + MT * wave + m;
             if (oy >= H) continue;
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
@@ -1799,8 +1802,8 @@ __global__ __launch_bounds__(TR * 32, 2) void dense_conv3x3_x9_kernel(const floa
 #pragma unroll
             for (int t = 0; t < NT; ++t) { s1[t] = 0.0f; s2[t] = 0.0f; }
 #pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                const bool rowok = y0 + 2 * wave + m < H;
+            for (int m = 0; m < MT; ++m) {
+                const bool rowok = y0 + MT * wave + m < H;
 #pragma unroll
                 for (int v = 0; v < 16; ++v) {
                     const bool ok = rowok && x0 + (v >> 2) * 8 + h * 4 + (v & 3) < W;
@@ -1951,7 +1954,7 @@ extern "C" int gga_dense_conv3x3_planes(const float* x, const void* split_weight
     const dim3 grid((unsigned)n_tiles), block(trows * 32);
     hipEvent_t* tev = gga_timing_acquire(GGA_TIME_DENSE_CONV, GGA_TIMING_CONV_KEY(cin, cout, (int64_t)H * W));
     GGA_TIME_START(tev, stream);
-#define DC_GO(NT_, TR_, NP_) hipLaunchKernelGGL((dense_conv3x3_x9_kernel<NT_, TR_, NP_>), grid, block, 0, stream, x, (const uint16_t*)split_weight, B, H, W, cin, cout, tx, ty, y, (int)y_pixel_stride, prow, pcol, stats, amax_x, amax_weight)
+#define DC_GO(NT_, TR_, NP_) hipLaunchKernelGGL((dense_conv3x3_x9_kernel<NT_, TR_, NP_, 2>), grid, block, 0, stream, x, (const uint16_t*)split_weight, B, H, W, cin, cout, tx, ty, y, (int)y_pixel_stride, prow, pcol, stats, amax_x, amax_weight)
     if (planes == 3) {
         if (cout == 64) DC_GO(2, 8, 3);
         else if (trows == 16) DC_GO(4, 16, 3);

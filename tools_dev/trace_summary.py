@@ -9,13 +9,17 @@ a = ap.parse_args()
 import os
 f = max(glob.glob(a.dir + '/**/*_kernel_trace.csv', recursive=True), key=os.path.getmtime)
 rows = list(csv.DictReader(open(f)))
-# one train step = one vox_insert_kernel ... until the optimizer's last kernel; bench.py's roofline
-# probe (which also voxelizes once) runs after the timed steps and is cut off at its first scatter_map
-starts = sorted(int(r['Start_Timestamp']) for r in rows if r['Kernel_Name'].startswith('vox_insert_kernel'))
-opt = sorted(int(r['End_Timestamp']) for r in rows if 'FusedOptimizerTensorListMetadata' in r['Kernel_Name'] or 'multi_tensor_apply' in r['Kernel_Name'])
-t1 = opt[-1]
-starts = [t for t in starts if t < t1]
-t0 = starts[-a.steps]
+# one train step ends with the optimizer's kernels (a cluster of multi_tensor_apply launches): the window is
+# [end of the optimizer of step N - steps, end of the optimizer of step N]. (Voxelizer launches are no step marker:
+# with the point-only front prefetched on a side stream the next step's voxelization runs inside the current step.)
+csv.field_size_limit(1 << 30)
+opt = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp'])) for r in rows
+             if 'FusedOptimizerTensorListMetadata' in r['Kernel_Name'] or 'multi_tensor_apply' in r['Kernel_Name'])
+ends = []
+for i, (st, en) in enumerate(opt):
+    if i + 1 == len(opt) or opt[i + 1][0] - en > 2_000_000:      # > 2 ms to the next optimizer kernel: last one of its step
+        ends.append(en)
+t1, t0 = ends[-1], ends[-1 - a.steps]
 rows = [r for r in rows if int(r['End_Timestamp']) <= t1]
 agg = collections.defaultdict(lambda: [0, 0])
 for r in rows:

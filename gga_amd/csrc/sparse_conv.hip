@@ -1563,6 +1563,22 @@ extern "C" int gga_sparse_conv_wgrad_planes(const float* x, int64_t x_row_stride
 // rows of the packed layout of gga_sparse_pack_weight_split with kvol = 9); the next chunk's halo
 // is requested from global memory before the taps of the current chunk run. 66 KB of LDS: two
 // workgroups per CU.
+#ifdef DC_PROBE          /* tools_dev/probe_dense_stage.py: cycle accounting of the stage loop, wave 0 of every workgroup */
+__device__ unsigned long long dc_probe[8];
+extern "C" int gga_debug_dc_probe(unsigned long long* out) {
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(dc_probe), sizeof(dc_probe));
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    hipMemcpyToSymbol(HIP_SYMBOL(dc_probe), z, sizeof(z));
+    return 0;
+}
+#define DC_T(V) const long long V = __builtin_readcyclecounter();
+#define DC_ACC(I, D) pr[I] += (D);
+#define DC_PROBE_WAIT asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
+#define DC_T(V)
+#define DC_ACC(I, D)
+#define DC_PROBE_WAIT
+#endif
 #define DC_TR 8
 #define DC_TW 32
 #define DC_HW (DC_TW + 2)
@@ -1575,7 +1591,12 @@ extern "C" int gga_sparse_conv_wgrad_planes(const float* x, int64_t x_row_stride
 // partial products (see h2_split2); `amax` then points to {bits of max finite |x|, bits of max finite |w|}.
 // MT: image rows (32-pixel M tiles) per wave; a workgroup has TR / MT waves. Shipped: MT = 2. (MT = 4 with 16-row tiles
 // and four waves at 64 output channels - 0.5 instead of 0.67 LDS fragment reads per MFMA on two fp16 planes - needs 50
-// spilled registers next to its 128 accumulators: 368 instead of 297 us per 64 -> 64 call incl. its absmax pass.)
+// spilled registers next to its 128 accumulators: 368 instead of 297 us per 64 -> 64 call incl. its absmax pass.
+// Also measured on the two-plane 64-channel form, each within 1 % of the shipped 0.206 ms: three waves per SIMD (168
+// registers, 18 spilled); a second fragment set read one tap ahead of the MFMAs; the next halo requested after stage 0's
+// weight load instead of before it. LDS reads deliver 174 B/clk/CU with this access pattern
+// (tools_dev/micro/lds_bw.hip); the kernel uses about half of that. -DDC_PROBE builds the cycle accounting that
+// tools_dev/probe_dense_stage.py prints.)
 template <int NT, int TR, int NP, int MT>
 __global__ __launch_bounds__(TR / MT * 64, 2) void dense_conv3x3_x9_kernel(const float* __restrict__ X, const uint16_t* __restrict__ Wp,
                                                                  int B, int H, int W, int cin, int cout, int tiles_x,
@@ -1700,6 +1721,10 @@ __global__ __launch_bounds__(TR / MT * 64, 2) void dense_conv3x3_x9_kernel(const
     // kernel is within 15 % of what its MFMA issue pattern delivers here; reading the next tap's
     // fragments ahead of the MFMAs (two register sets), one tile per workgroup instead of persistent
     // ones, and dropping the per-stage barrier all measured 0.414-0.420 ms.
+#ifdef DC_PROBE
+    long long pr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const long long tstart_ = __builtin_readcyclecounter();
+#endif
     int tile = blockIdx.x;
     if (tile >= n_tiles) return;
     {
@@ -1729,8 +1754,12 @@ __global__ __launch_bounds__(TR / MT * 64, 2) void dense_conv3x3_x9_kernel(const
         // stage is fixed at compile time (nchunks is even: cin % 32 == 0)
 #define DC_CHUNK_HEAD(CH)                                                                                             \
             if (!first) {                              /* every wave passed the barrier of the previous stage */      \
+                DC_T(tg_)                                                                                             \
                 DC_STORE_A();                                                                                         \
+                DC_T(th_)                                                                                             \
                 __syncthreads();                                                                                      \
+                DC_T(ti_)                                                                                             \
+                DC_ACC(5, th_ - tg_) DC_ACC(6, ti_ - th_)                                                             \
             }                                                                                                         \
             first = false;                                                                                            \
             if ((CH) + 1 < nchunks) { DC_LOAD_A((CH) + 1); }                                                          \
@@ -1752,13 +1781,22 @@ __global__ __launch_bounds__(TR / MT * 64, 2) void dense_conv3x3_x9_kernel(const
                 if ((TAP) + 2 < 9) { DC_LOAD_B((TAP) + 2, (CH), bq0, bq1, bq2); }                                     \
                 else { DC_LOAD_B((TAP) + 2 - 9, last_chunk ? 0 : (CH) + 1, bq0, bq1, bq2); }                          \
             }                                                                                                         \
+            DC_T(ta_)                                                                                                 \
             DC_READ_A(TAP);                                                                                           \
             _Pragma("unroll") for (int t0 = 0; t0 < NT; t0 += 2) {                                                    \
                 DC_READ_B(TAP, t0);                                                                                   \
+                DC_PROBE_WAIT                                                                                         \
+                DC_T(tb_)                                                                                             \
                 DC_MMA(t0)                                                                                            \
+                DC_T(tc_)                                                                                             \
+                DC_ACC(0, tb_ - ta_) DC_ACC(1, tc_ - tb_)                                                             \
             }                                                                                                         \
+            DC_T(td_)                                                                                                 \
             if (more2) { if (DEEP) { DC_STORE_B(((TAP) + 2) % 3, S0, S1, S2); } else { DC_STORE_B(((TAP) + 2) % 3, bq0, bq1, bq2); } } \
-            __syncthreads(); }
+            DC_T(te_)                                                                                                 \
+            __syncthreads();                                                                                          \
+            DC_T(tf_)                                                                                                 \
+            DC_ACC(2, te_ - td_) DC_ACC(3, tf_ - te_) DC_ACC(4, 1) }
 #define DC_EVEN(TAP, CH) DC_STAGE(TAP, CH, cq0, cq1, cq2, bq0, bq1, bq2)      /* even stage: load set 1, store set 0 */
 #define DC_ODD(TAP, CH) DC_STAGE(TAP, CH, bq0, bq1, bq2, cq0, cq1, cq2)
         for (int ch = 0; ch < nchunks; ch += 2) {
@@ -1834,6 +1872,12 @@ __global__ __launch_bounds__(TR / MT * 64, 2) void dense_conv3x3_x9_kernel(const
             __syncthreads();                                  // red is the next tile's halo buffer
         }
     }
+#ifdef DC_PROBE
+    if (wave == 0 && lane == 0) {
+        pr[7] = __builtin_readcyclecounter() - tstart_;
+        for (int i = 0; i < 8; ++i) atomicAdd(&dc_probe[i], (unsigned long long)pr[i]);
+    }
+#endif
 #undef DC_READ_A
 #undef DC_READ_B
 #undef DC_MM1

@@ -1595,8 +1595,10 @@ extern "C" int gga_debug_dc_probe(unsigned long long* out) {
 // Also measured on the two-plane 64-channel form, each within 1 % of the shipped 0.206 ms: three waves per SIMD (168
 // registers, 18 spilled); a second fragment set read one tap ahead of the MFMAs; the next halo requested after stage 0's
 // weight load instead of before it. LDS reads deliver 174 B/clk/CU with this access pattern
-// (tools_dev/micro/lds_bw.hip); the kernel uses about half of that. -DDC_PROBE builds the cycle accounting that
-// tools_dev/probe_dense_stage.py prints.)
+// (tools_dev/micro/lds_bw.hip); the kernel uses about half of that. A separate kernel that staged the weights of a whole
+// kernel row per barrier (36 MFMAs and one barrier per row stage instead of 12 and one per tap, weights requested a full
+// row stage ahead) measured 0.219 against 0.209 ms on the same box, alternating runs. -DDC_PROBE builds the cycle
+// accounting that tools_dev/probe_dense_stage.py prints.)
 template <int NT, int TR, int NP, int MT>
 __global__ __launch_bounds__(TR / MT * 64, 2) void dense_conv3x3_x9_kernel(const float* __restrict__ X, const uint16_t* __restrict__ Wp,
                                                                  int B, int H, int W, int cin, int cout, int tiles_x,

@@ -65,6 +65,9 @@ def parse_args(argv=None):
                     help='damp the random init of the regression heads\' output convs (see damp_head_init)')
     ap.add_argument('--miopen-find', action='store_true', help='torch.backends.cudnn.benchmark=True (MIOpen find mode)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--device-warmup-seconds', type=float, default=2.0,
+                    help='keep the device busy with generic matrix products for this long before anything is built or timed '
+                         '(a fresh box starts at idle clocks: the first run after start-up measured up to 2.5x slower)')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-second-trunk', action='store_true', help='skip the gga_kitti_config.py (sparse trunk) leg')
     ap.add_argument('--second-batch', type=int, default=8, help='frames per GPU of the second_trunk leg')
@@ -373,6 +376,15 @@ def main():
         backend = 'nccl (RCCL)'
     elif backend == 'gloo':
         backend = f'gloo ({world} ranks on {torch.cuda.device_count()} device(s): functional check, not a scaling number)'
+
+    if args.device_warmup_seconds > 0:      # device initialisation, not a step: bring clocks and power state up
+        a = torch.randn(4096, 4096, device=device)
+        t_end = time.perf_counter() + args.device_warmup_seconds
+        while time.perf_counter() < t_end:
+            for _ in range(20):
+                a = (a @ a) * 1e-2
+            torch.cuda.synchronize()
+        del a
 
     is_pp = 'pointpillars' in os.path.basename(args.config)
     want_roofline = rank == 0 and not args.no_roofline and is_pp

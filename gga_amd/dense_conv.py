@@ -119,11 +119,19 @@ def _run(x, weight, backward, want_stats=False, x_amax=None, w_amax=None, y=None
                                          y.data_ptr() + 4 * y_col, ystride, int(tr), F._p(stats), planes, F._p(x_amax),
                                          F._p(w_amax), F._stream()), 'gga_dense_conv3x3')
     else:
+        parts = []
         for c0 in range(0, n_out, 128):             # strided views: packed straight from the parameter
             wv = weight[:, c0:c0 + 128] if backward else weight[c0:c0 + 128]
+            st = None
+            if want_stats:                          # per-channel sums of this 128-channel block of the output
+                tiles = int(L.gga_dense_conv3x3_tiles(B, W, H, 128) if tr else L.gga_dense_conv3x3_tiles(B, H, W, 128))
+                st = torch.empty((tiles, 2, 128), dtype=torch.float64, device=x.device)
+                parts.append(st)
             check(L.gga_dense_conv3x3_planes(F._p(x), F._p(_pack(wv, backward, tr, w_amax)), B, H, W, n_in, 128,
-                                             y.data_ptr() + 4 * (y_col + c0), ystride, int(tr), None, planes, F._p(x_amax),
+                                             y.data_ptr() + 4 * (y_col + c0), ystride, int(tr), F._p(st), planes, F._p(x_amax),
                                              F._p(w_amax), F._stream()), 'gga_dense_conv3x3_slice')
+        if parts:
+            stats = torch.cat(parts, dim=2)         # [tiles, 2, n_out]
     return y, stats
 
 

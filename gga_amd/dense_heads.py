@@ -219,46 +219,64 @@ class CenterHead_GGA(nn.Module):
         mask = np.zeros((T, B, K), np.uint8)
         l2i = np.empty((T, B, K, 4, 4), np.float32)
         bmask = np.zeros((T, B, K, 4), np.uint8)
-        objs = []
-        per_task = [[] for _ in range(T)]
+        # every object of the batch in flat arrays: one vectorised pass instead of B x T small ones
+        labs = [_to_np(gt_labels_3d[b]).reshape(-1).astype(np.int64) for b in range(B)]
+        n_b = np.asarray([len(x) for x in labs], np.int64)
+        start_b = np.concatenate([[0], np.cumsum(n_b)])
+        labels = np.concatenate(labs) if B else np.zeros(0, np.int64)
+        N = len(labels)
+        frame = np.repeat(np.arange(B), n_b)
+        local = np.arange(N) - start_b[frame]                                         # index inside its frame
         for b in range(B):
-            labels = _to_np(gt_labels_3d[b])
-            pseudo = _to_np(GGA_init_pseudo_labels[b], np.float64).reshape(-1, 7)
-            boxes = _to_np(GGA_boxes_img[b]).reshape(-1, 4)
-            l2i_b = _to_np(GGA_lidar2img[b], np.float32).reshape(-1, 4, 4)
-            bdry = _to_np(GGA_bdry_masks[b]).astype(bool).reshape(-1, 4)
             l2i[:, b] = np.asarray(img_metas[b]['lidar2img'], np.float32)[None, None]     # head:508-509
-            flag = 0
-            for t in range(T):
-                # objects of the task, class-major then index order (head:426-434,456-485)
-                hits = [np.flatnonzero(labels == c + flag) for c in range(ncls[t])]
-                sel = np.concatenate(hits)
-                cls_id = np.concatenate([np.full(len(h), c, np.int64) for c, h in enumerate(hits)])
-                flag += ncls[t]
-                sel, cls_id = sel[:K], cls_id[:K]
-                per_task[t].append((b, sel))
-                if len(sel) == 0:
-                    continue
-                pl = pseudo[sel]
-                wg = pl[:, 3] / vs[0] / osf                                             # head:541-546
-                lg = pl[:, 4] / vs[1] / osf
-                ok = (wg > 0) & (lg > 0)
-                with np.errstate(invalid='ignore'):
-                    rad = gaussian_radius_np(lg, wg, tc['gaussian_overlap'])
-                rad = np.where(ok, rad, 0.0)
-                rad = np.maximum(int(tc['min_radius']), rad.astype(np.int64))           # max(min_radius, int(r))
-                cx = ((pl[:, 0] - pc[0]) / vs[0] / osf).astype(np.float32).astype(np.int32)   # f32 then trunc
-                cy = ((pl[:, 1] - pc[1]) / vs[1] / osf).astype(np.float32).astype(np.int32)
-                ok &= (cx >= 0) & (cx < fw) & (cy >= 0) & (cy < fh)                     # head:573-574
-                k = np.flatnonzero(ok)
-                if len(k):
-                    ind[t, b, k] = cy[k].astype(np.int64) * fw + cx[k]
-                    mask[t, b, k] = 1
-                    l2i[t, b, k] = l2i_b[sel[k]]
-                    bmask[t, b, k] = ~bdry[sel[k]]
-                    anno[t, b, k, :4] = boxes[sel[k]].astype(np.float32)
-                    anno[t, b, k, 4] = srl[b, t]
-                    objs.append(np.stack([map_base[t] + b * ncls[t] + cls_id[k], cx[k], cy[k], rad[k]], 1))
+        cls_task = np.concatenate([np.full(n, t, np.int64) for t, n in enumerate(ncls)])  # class -> task
+        cls_in = np.concatenate([np.arange(n) for n in ncls])                             # class -> index in its task
+        known = (labels >= 0) & (labels < len(cls_task))
+        task = np.where(known, cls_task[np.clip(labels, 0, len(cls_task) - 1)], -1)
+        cin = np.where(known, cls_in[np.clip(labels, 0, len(cls_task) - 1)], 0)
+        # slot of an object inside its (frame, task): class-major then index order (head:426-434,456-485)
+        order = np.lexsort((local, cin, task, frame))
+        order = order[known[order]]
+        grp = frame[order] * T + task[order]
+        first = np.r_[True, grp[1:] != grp[:-1]] if len(order) else np.zeros(0, bool)
+        gstart = np.maximum.accumulate(np.where(first, np.arange(len(order)), 0)) if len(order) else np.zeros(0, np.int64)
+        slot = np.arange(len(order)) - gstart
+        keep = slot < K
+        order, slot = order[keep], slot[keep]
+        per_task = [[(b, np.zeros(0, np.int64)) for b in range(B)] for _ in range(T)]
+        objs = np.zeros((0, 4), np.int64)
+        if len(order):
+            fo, to = frame[order], task[order]
+            bounds = np.flatnonzero(np.r_[True, (fo[1:] != fo[:-1]) | (to[1:] != to[:-1]), True])
+            for i0, i1 in zip(bounds[:-1], bounds[1:]):
+                per_task[to[i0]][fo[i0]] = (int(fo[i0]), local[order[i0:i1]])
+            cat = lambda xs, shape, dt: (np.concatenate([_to_np(x, dt).reshape(shape) for x in xs]) if N else np.zeros(shape[1:], dt)[None][:0])
+            pseudo = cat(GGA_init_pseudo_labels, (-1, 7), np.float64)[order]
+            boxes = cat(GGA_boxes_img, (-1, 4), None)[order]
+            l2i_o = cat(GGA_lidar2img, (-1, 4, 4), np.float32)[order]
+            bdry = cat(GGA_bdry_masks, (-1, 4), None)[order].astype(bool)
+            wg = pseudo[:, 3] / vs[0] / osf                                             # head:541-546
+            lg = pseudo[:, 4] / vs[1] / osf
+            ok = (wg > 0) & (lg > 0)
+            with np.errstate(invalid='ignore'):
+                rad = gaussian_radius_np(lg, wg, tc['gaussian_overlap'])
+            rad = np.where(ok, rad, 0.0)
+            rad = np.maximum(int(tc['min_radius']), rad.astype(np.int64))               # max(min_radius, int(r))
+            cx = ((pseudo[:, 0] - pc[0]) / vs[0] / osf).astype(np.float32).astype(np.int32)   # f32 then trunc
+            cy = ((pseudo[:, 1] - pc[1]) / vs[1] / osf).astype(np.float32).astype(np.int32)
+            ok &= (cx >= 0) & (cx < fw) & (cy >= 0) & (cy < fh)                         # head:573-574
+            k = np.flatnonzero(ok)
+            tk, bk, sk = to[k], fo[k], slot[k]
+            ind[tk, bk, sk] = cy[k].astype(np.int64) * fw + cx[k]
+            mask[tk, bk, sk] = 1
+            l2i[tk, bk, sk] = l2i_o[k]
+            bmask[tk, bk, sk] = ~bdry[k]
+            anno[tk, bk, sk, :4] = boxes[k].astype(np.float32)
+            anno[tk, bk, sk, 4] = np.asarray(srl)[bk, tk]
+            ncls_a = np.asarray(ncls, np.int64)
+            # the splat list in (frame, task) order, as the per-frame / per-task loops of the reference produce it
+            objs = np.stack([map_base[tk] + bk * ncls_a[tk] + cin[order][k], cx[k], cy[k], rad[k]], 1)
+        objs = [objs]
         # in-box points (xy as f32, like `.float()` at head:201), packed task-major so each task
         # is one contiguous range of objects
         xy, counts, slots, task_nobj = [], [], [], np.zeros(T, np.int64)

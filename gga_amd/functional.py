@@ -20,7 +20,9 @@ _cell_maps = {}
 
 
 def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    # raw handle of the current stream of the current device (what torch.cuda.current_stream().cuda_stream returns,
+    # without building a Stream object: ~800 calls per train step)
+    return C.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
 
 
 def _p(t):
@@ -431,7 +433,22 @@ def gather_pred(reg, height, dim, rot, ind, mask):
 
 
 # ----------------------------------------------------------------------------- a10-a13
+_loss_params_cache = {}
+
+
 def loss_params(B, K, train_cfg, l1_loss_weight=0.25, w_bpl=0.3, w_srl=0.1, w_pal=0.1):
+    """The POD the loss kernels take; built once per (config object, B, K, weights) - reading a Config costs more
+    than the kernels' launches."""
+    key = (id(train_cfg), int(B), int(K), float(l1_loss_weight), float(w_bpl), float(w_srl), float(w_pal))
+    hit = _loss_params_cache.get(key)
+    if hit is not None and hit[0] is train_cfg:
+        return hit[1]
+    prm = _build_loss_params(B, K, train_cfg, l1_loss_weight, w_bpl, w_srl, w_pal)
+    _loss_params_cache[key] = (train_cfg, prm)
+    return prm
+
+
+def _build_loss_params(B, K, train_cfg, l1_loss_weight, w_bpl, w_srl, w_pal):
     prm = LossParams()
     prm.B, prm.K = int(B), int(K)
     prm.fm_w = int(train_cfg['grid_size'][0]) // int(train_cfg['out_size_factor'])

@@ -311,7 +311,7 @@ def test_bench_line_contract_single_gpu():
     assert res['roofline']['bound'] == 'hbm' and res['roofline']['launches_timed'] == 2
     assert res['mfma_roofline']['launches_timed'] == 2 * res['mfma_roofline']['launches_per_step']
     assert 0 < res['mfma_roofline']['share_of_step'] < 1
-    assert 'six bf16' in res['arith'] and res['dtype'] == 'f32'
+    assert 'fp16 planes' in res['arith'] and 'three f16 MFMA partial products' in res['arith'] and res['dtype'] == 'f32'
 
 
 def test_edge_cases_empty_inputs():

@@ -117,7 +117,7 @@ def run_workload(config, batch, steps, warmup, args, rank, world, device, sites=
 
     cfg = Config.fromfile(config)
     channels_last = not args.nchw
-    if channels_last and cfg.model.pts_middle_encoder.type == 'PointPillarsScatter':
+    if channels_last and cfg.model.pts_middle_encoder.type in ('PointPillarsScatter', 'SparseEncoder'):
         cfg.model.pts_middle_encoder['channels_last'] = True
     torch.manual_seed(0)
     model = build_model(cfg.model).to(device)

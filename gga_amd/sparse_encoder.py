@@ -63,8 +63,12 @@ class SparseEncoder(nn.Module):
     def __init__(self, in_channels, sparse_shape, order=('conv', 'norm', 'act'),
                  norm_cfg=dict(type='BN1d', eps=1e-3, momentum=0.01), base_channels=16, output_channels=128,
                  encoder_channels=((16, ), (32, 32, 32), (64, 64, 64), (64, 64, 64)),
-                 encoder_paddings=((1, ), (1, 1, 1), (1, 1, 1), ((0, 1, 1), 1, 1)), block_type='conv_module'):
+                 encoder_paddings=((1, ), (1, 1, 1), (1, 1, 1), ((0, 1, 1), 1, 1)), block_type='conv_module',
+                 channels_last=False):
         super().__init__()
+        # extension (not a reference key): hand the BEV map to the 2D trunk in channels-last memory - the same logical
+        # [N, C*D, H, W] tensor - so that its first convolution runs on the repo's kernels as well
+        self.channels_last = channels_last
         assert block_type in ['conv_module', 'basicblock']
         self.sparse_shape = sparse_shape
         self.in_channels = in_channels
@@ -111,7 +115,10 @@ class SparseEncoder(nn.Module):
         out = self.conv_out(encode_features[-1])
         spatial_features = out.dense()
         N, C, D, H, W = spatial_features.shape
-        return spatial_features.view(N, C * D, H, W)
+        spatial_features = spatial_features.view(N, C * D, H, W)
+        if self.channels_last:
+            spatial_features = spatial_features.contiguous(memory_format=torch.channels_last)
+        return spatial_features
 
     def make_encoder_layers(self, make_block, norm_cfg, in_channels, block_type='conv_module',
                             conv_cfg=dict(type='SubMConv3d')):

@@ -30,6 +30,13 @@
 // (32h + s) on both operands. Z goes to LDS (pixel stride 33 floats), then one thread per
 // (output pixel, channel) adds its nine taps. Each input pixel is read once per tile
 // (halo 1.33x), 32 MFMAs per 32 pixels.
+// Measured in round 2 (cycle stamps per workgroup, 16 x 248 x 216): of ~60 k cycles a workgroup waits ~25 k for the rows of
+// its first pixel group and ~20 k for those of the second one (three of the eight waves have one), 2 k per group are matrix
+// products, 1-8 k the epilogue; with the input resident in the MALL the kernel takes 104 us, cold 140-150 us (2.1-2.8 TB/s).
+// All workgroups of a round load, then all multiply: the memory pipe idles while they do. Loading whole pixel rows and
+// transposing through LDS instead of 128 bytes per lane, and fetching the weights through LDS, changed nothing (same times);
+// what should is a persistent workgroup that requests the next tile's rows before its epilogue, with 16 groups per tile so
+// that every wave has two - not done.
 #define HM_TR 8
 #define HM_TW 32
 #define HM_HR (HM_TR + 2)

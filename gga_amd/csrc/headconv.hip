@@ -30,13 +30,9 @@
 // (32h + s) on both operands. Z goes to LDS (pixel stride 33 floats), then one thread per
 // (output pixel, channel) adds its nine taps. Each input pixel is read once per tile
 // (halo 1.33x), 32 MFMAs per 32 pixels.
-// Measured in round 2 (cycle stamps per workgroup, 16 x 248 x 216): of ~60 k cycles a workgroup waits ~25 k for the rows of
-// its first pixel group and ~20 k for those of the second one (three of the eight waves have one), 2 k per group are matrix
-// products, 1-8 k the epilogue; with the input resident in the MALL the kernel takes 104 us, cold 140-150 us (2.1-2.8 TB/s).
-// All workgroups of a round load, then all multiply: the memory pipe idles while they do. Loading whole pixel rows and
-// transposing through LDS instead of 128 bytes per lane, and fetching the weights through LDS, changed nothing (same times);
-// what should is a persistent workgroup that requests the next tile's rows before its epilogue, with 16 groups per tile so
-// that every wave has two - not done.
+// (That was the round-1 forward kernel; the shipped one is the persistent form further down. Cycle stamps per workgroup at
+// 16 x 248 x 216 had shown ~25 k of its ~60 k cycles waiting for the first pixel group's rows, ~20 k for the second group's -
+// which only three of the eight waves have -, 2 k of matrix products per group and 1-8 k of epilogue.)
 #define HM_TR 8
 #define HM_TW 32
 #define HM_HR (HM_TR + 2)
@@ -45,91 +41,130 @@
 #define HM_NGRP ((HM_NPIX + 31) / 32)
 #define HM_ZS 33
 
+// Round 2: the kernel is PERSISTENT and keeps one pixel group's rows in flight per wave at all times. A workgroup owns
+// 13 x 32 output pixels; its 15 x 34 = 510 halo pixels are exactly 16 groups of 32, two per wave. A wave walks the stream
+// of its groups (tile after tile): park the rows that arrived (whole pixel rows, lane l = 16-byte piece l of four rows per
+// load instruction, optional input affine + ReLU on the lane's four fixed channels) in its own LDS region, read them back
+// pixel-per-lane (lane (r, h): channels 32h .. 32h+31 of pixel r; 272-byte rows are conflict-free both ways), REQUEST THE
+// NEXT GROUP (possibly of the next tile), multiply, write the Z block. After a tile's second group: barrier, nine-tap sums,
+// barrier. The region holds the parked rows first and the wave's two Z blocks after (8704 B), so a workgroup needs 70 KB
+// and 119 registers: two per CU. The one-tile-per-workgroup form had every workgroup of a round load (25 k of its 60 k
+// cycles, 12 us under a full memory pipe), then multiply, with the pipe idle meanwhile: 141-150 us per call with cold
+// caches against 114-118 us now (104 -> 77 us with the input resident in the MALL); tools_dev/bench_headconv_cold.py.
+#define HP_TR 13
+#define HP_HR (HP_TR + 2)
+#define HP_NPIX (HP_HR * HM_HW)                        // 510
+#define HP_NGRP 16
+#define HM_SROW 272                                    // bytes per parked pixel row (256 + 16)
+#define HM_WREG (32 * HM_SROW)                         // per-wave LDS region: 8704 B >= two Z blocks of 32 x 33 floats
+
 template <int COUT>
-__global__ __launch_bounds__(512) void headconv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+__global__ __launch_bounds__(512, 2) void headconv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                           const float* __restrict__ bias, int B, int H, int W,
-                                                          int tiles_x, int tiles_y, int cout_total, int co_base,
+                                                          int tiles_x, int tiles_y, int n_tiles, int cout_total, int co_base,
                                                           const float* __restrict__ in_ss, int64_t xs, float* __restrict__ y) {
     typedef float acc16 __attribute__((ext_vector_type(16)));
-    __shared__ float zt[HM_NGRP * 32 * HM_ZS];
-    __shared__ __attribute__((aligned(16))) float ssl[2 * HC_CIN];      // input affine (scale, shift) when in_ss
-    if (in_ss) {
-        if (threadIdx.x < 2 * HC_CIN) ssl[threadIdx.x] = in_ss[threadIdx.x];
-        __syncthreads();
-    }
+    static_assert(2 * 32 * HM_ZS * 4 <= HM_WREG && (HP_NPIX + 31) / 32 == HP_NGRP, "tile geometry");
+    __shared__ __attribute__((aligned(16))) unsigned char reg[8 * HM_WREG];
     const int per_img = tiles_x * tiles_y;
-    const int b = blockIdx.x / per_img;
-    const int rem = blockIdx.x - b * per_img;
-    const int y0 = (rem / tiles_x) * HM_TR, x0 = (rem % tiles_x) * HM_TW;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
+    unsigned char* mine = reg + wave * HM_WREG;
 
-    // B operand: column n = r -> (off, co); zero columns beyond 9*COUT
-    float wb[32];
-    {
-        const bool used = r < 9 * COUT;
-        const int off = used ? r / COUT : 0, co = used ? r - off * COUT : 0;
-        const float* wp = w + ((int64_t)(co_base + co) * HC_CIN + 32 * h) * 9 + off;
-#pragma unroll
-        for (int s = 0; s < 32; ++s) wb[s] = used ? wp[s * 9] : 0.0f;
-    }
-    // A operand of this wave's (at most two) pixel groups
-    float4 xa[2][8];
-    bool has[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int g = wave + 8 * u;
-        has[u] = g < HM_NGRP;                       // wave-uniform
-        const int hp = g * 32 + r;
-        const int hr = hp / HM_HW, hx = hp - hr * HM_HW;
-        const int iy = y0 + hr - 1, ix = x0 + hx - 1;
-        const bool ok = has[u] && hp < HM_NPIX && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-        const float4* src = reinterpret_cast<const float4*>(x + (((int64_t)b * H + (ok ? iy : 0)) * W + (ok ? ix : 0)) * xs + 32 * h);
-        const float m = ok ? 1.0f : 0.0f;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            float4 v = src[q];
-            if (in_ss) {                                 // input = relu(x * scale + shift), zero padding stays zero
-                const float4 sc = *reinterpret_cast<const float4*>(ssl + 32 * h + 4 * q);
-                const float4 sf = *reinterpret_cast<const float4*>(ssl + HC_CIN + 32 * h + 4 * q);
-                v.x = fmaxf(fmaf(v.x, sc.x, sf.x), 0.0f); v.y = fmaxf(fmaf(v.y, sc.y, sf.y), 0.0f);
-                v.z = fmaxf(fmaf(v.z, sc.z, sf.z), 0.0f); v.w = fmaxf(fmaf(v.w, sc.w, sf.w), 0.0f);
-            }
-            xa[u][q] = make_float4(v.x * m, v.y * m, v.z * m, v.w * m);
-        }
-    }
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        if (!has[u]) break;
-        acc16 acc;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[u][q].x, wb[4 * q + 0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[u][q].y, wb[4 * q + 1], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[u][q].z, wb[4 * q + 2], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[u][q].w, wb[4 * q + 3], acc, 0, 0, 0);
-        }
-        // D layout of 32x32x2: register v of lane l holds row (v/4)*8 + (l/32)*4 + v%4, column l%32
-        float* zg = zt + (wave + 8 * u) * 32 * HM_ZS + r;
-#pragma unroll
-        for (int v = 0; v < 16; ++v) zg[((v >> 2) * 8 + h * 4 + (v & 3)) * HM_ZS] = acc[v];
+    // B operand: column n = r -> (off, co); zero columns beyond 9*COUT. Built once per workgroup as wl[channel][32 columns]
+    // in LDS and read per MFMA (lane (r, h) of k-step s: wl[32h + s][r], conflict-free): 32 registers less per lane than
+    // holding the column, which is what lets two 512-thread workgroups share a CU
+    __shared__ float wl[HC_CIN * 32];
+    for (int i = threadIdx.x; i < HC_CIN * 32; i += 512) {
+        const int c = i >> 5, n = i & 31;
+        const bool used = n < 9 * COUT;
+        const int off = used ? n / COUT : 0, co = used ? n - off * COUT : 0;
+        wl[i] = used ? w[((int64_t)(co_base + co) * HC_CIN + c) * 9 + off] : 0.0f;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < HM_TR * HM_TW * COUT; i += 512) {
-        const int co = i / (HM_TR * HM_TW), pid = i - co * (HM_TR * HM_TW);
-        const int ty = pid / HM_TW, tx = pid - ty * HM_TW;
-        const int oy = y0 + ty, ox = x0 + tx;
-        if (oy >= H || ox >= W) continue;
-        float s = bias ? bias[co_base + co] : 0.0f;
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx)
-                s += zt[((ty + ky) * HM_HW + tx + kx) * HM_ZS + (ky * 3 + kx) * COUT + co];
-        y[(((int64_t)b * cout_total + co_base + co) * H + oy) * W + ox] = s;
+    const float* wcol = wl + (32 * h) * 32 + r;
+    // the lane's piece of a pixel row: channels 4 * (lane % 16) .. +3, fixed for every load
+    const int piece = lane & 15, prow_ = lane >> 4;                    // 4 pixel rows per load instruction
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sf = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (in_ss) {
+        sc = *reinterpret_cast<const float4*>(in_ss + 4 * piece);
+        sf = *reinterpret_cast<const float4*>(in_ss + HC_CIN + 4 * piece);
     }
+    float4 ld[8];
+    // request the rows of group G of tile T (8 loads in flight per lane), zero outside the image / the halo
+#define HM_LOAD(T, G) {                                                                                               \
+        const int tb_ = (T) / per_img, trem_ = (T) - tb_ * per_img;                                                   \
+        const int ty0_ = (trem_ / tiles_x) * HP_TR, tx0_ = (trem_ % tiles_x) * HM_TW;                                 \
+        int pv_ = prow_;                                                                                              \
+        asm volatile("" : "+v"(pv_));      /* keep the 16 row positions from being hoisted out of the tile loop (32 registers) */ \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                               \
+            const int hp = (G) * 32 + 4 * i + pv_;                                                                    \
+            const int hr = hp / HM_HW, hx = hp - hr * HM_HW;                                                          \
+            const int iy = ty0_ + hr - 1, ix = tx0_ + hx - 1;                                                         \
+            const bool ok = hp < HP_NPIX && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;                 \
+            float4 v = ok ? *reinterpret_cast<const float4*>(x + (((int64_t)tb_ * H + iy) * W + ix) * xs + 4 * piece) \
+                          : make_float4(0.f, 0.f, 0.f, 0.f);                                                          \
+            if (ok && in_ss) {                           /* input = relu(x * scale + shift); zero padding stays zero */ \
+                v.x = fmaxf(fmaf(v.x, sc.x, sf.x), 0.0f); v.y = fmaxf(fmaf(v.y, sc.y, sf.y), 0.0f);                   \
+                v.z = fmaxf(fmaf(v.z, sc.z, sf.z), 0.0f); v.w = fmaxf(fmaf(v.w, sc.w, sf.w), 0.0f);                   \
+            }                                                                                                         \
+            ld[i] = v; } }
+    // park the group in the wave's region, read it back pixel-per-lane (a wave is in lockstep: no barrier, the LDS
+    // counter orders the write before the read)
+#define HM_PARK(XA) {                                                                                                 \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) *reinterpret_cast<float4*>(mine + (4 * i + prow_) * HM_SROW + piece * 16) = ld[i]; \
+        _Pragma("unroll") for (int q = 0; q < 8; ++q) XA[q] = *reinterpret_cast<const float4*>(mine + r * HM_SROW + h * 128 + q * 16); }
+#define HM_MMA(XA, ACC) {                                                                                             \
+        _Pragma("unroll") for (int i = 0; i < 16; ++i) ACC[i] = 0.0f;                                                 \
+        _Pragma("unroll") for (int q = 0; q < 8; ++q) {                                                               \
+            ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(XA[q].x, wcol[(4 * q + 0) * 32], ACC, 0, 0, 0);                \
+            ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(XA[q].y, wcol[(4 * q + 1) * 32], ACC, 0, 0, 0);                \
+            ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(XA[q].z, wcol[(4 * q + 2) * 32], ACC, 0, 0, 0);                \
+            ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(XA[q].w, wcol[(4 * q + 3) * 32], ACC, 0, 0, 0);                \
+        } }
+    // D layout of 32x32x2: register v of lane l holds row (v/4)*8 + (l/32)*4 + v%4, column l%32
+#define HM_ZOUT(U, ACC) { float* zg = reinterpret_cast<float*>(mine) + (U) * 32 * HM_ZS + r;                          \
+        _Pragma("unroll") for (int v = 0; v < 16; ++v) zg[((v >> 2) * 8 + h * 4 + (v & 3)) * HM_ZS] = ACC[v]; }
+    int tile = blockIdx.x;
+    if (tile >= n_tiles) return;
+    HM_LOAD(tile, wave)
+    for (; tile < n_tiles; tile += gridDim.x) {
+        const int b = tile / per_img;
+        const int rem = tile - b * per_img;
+        const int y0 = (rem / tiles_x) * HP_TR, x0 = (rem % tiles_x) * HM_TW;
+        float4 xa[8];
+        acc16 acc, acc2;
+        HM_PARK(xa)
+        HM_LOAD(tile, wave + 8)                           // in flight while the first group multiplies
+        HM_MMA(xa, acc)
+        HM_PARK(xa)                                       // the region is free for the Z blocks from here on
+        if (tile + (int)gridDim.x < n_tiles) { HM_LOAD(tile + (int)gridDim.x, wave) }     // across the barriers and the epilogue
+        HM_ZOUT(0, acc)
+        HM_MMA(xa, acc2)
+        HM_ZOUT(1, acc2)
+        __syncthreads();
+        for (int i = threadIdx.x; i < HP_TR * HM_TW * COUT; i += 512) {
+            const int co = i / (HP_TR * HM_TW), pid = i - co * (HP_TR * HM_TW);
+            const int ty = pid / HM_TW, tx = pid - ty * HM_TW;
+            const int oy = y0 + ty, ox = x0 + tx;
+            if (oy >= H || ox >= W) continue;
+            float s = bias ? bias[co_base + co] : 0.0f;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int hp = (ty + ky) * HM_HW + tx + kx;           // halo pixel -> group g = hp / 32, kept by wave g % 8
+                    const int g = hp >> 5;
+                    s += reinterpret_cast<const float*>(reg + (g & 7) * HM_WREG)[((g >> 3) * 32 + (hp & 31)) * HM_ZS + (ky * 3 + kx) * COUT + co];
+                }
+            y[(((int64_t)b * cout_total + co_base + co) * H + oy) * W + ox] = s;
+        }
+        __syncthreads();                                  // the regions are parked into again
+    }
+#undef HM_LOAD
+#undef HM_PARK
+#undef HM_MMA
+#undef HM_ZOUT
 }
 
 // dW[co][ci][off] = sum_p x[p+off][ci] * dy[co][p]; dbias[co] = sum_p dy[co][p], on the matrix
@@ -292,9 +327,11 @@ extern "C" int gga_head_conv3x3_fwd(const float* x, int64_t x_pixel_stride, cons
     if (int rc = headconv_check("gga_head_conv3x3_fwd", B, H, W, cin, cout)) return rc;
     GGA_REQUIRE(x && weight && y, "gga_head_conv3x3_fwd: null pointer argument");
     if (int rc = headconv_stride("gga_head_conv3x3_fwd", x, x_pixel_stride)) return rc;
-    const int tx = (W + HM_TW - 1) / HM_TW, ty = (H + HM_TR - 1) / HM_TR;
-    const dim3 grid((unsigned)((int64_t)B * tx * ty)), block(512);
-#define HC_F(CO, BASE) hipLaunchKernelGGL(headconv_fwd_kernel<CO>, grid, block, 0, stream, x, weight, bias, B, H, W, tx, ty, cout, BASE, in_scale_shift, x_pixel_stride, y)
+    const int tx = (W + HM_TW - 1) / HM_TW, ty = (H + HP_TR - 1) / HP_TR;
+    const int64_t n_tiles = (int64_t)B * tx * ty;
+    GGA_REQUIRE(n_tiles < 2147483647ll, "gga_head_conv3x3_fwd: too many tiles");
+    const dim3 grid((unsigned)(n_tiles < 512 ? n_tiles : 512)), block(512);       // persistent: two workgroups per CU
+#define HC_F(CO, BASE) hipLaunchKernelGGL(headconv_fwd_kernel<CO>, grid, block, 0, stream, x, weight, bias, B, H, W, tx, ty, (int)n_tiles, cout, BASE, in_scale_shift, x_pixel_stride, y)
     switch (cout) {
         case 1: HC_F(1, 0); break;
         case 2: HC_F(2, 0); break;

@@ -180,6 +180,8 @@ class Runner:
         return dict(loss=loss, log_vars=log_vars, num_samples=len(data['img_metas']))
 
     def step(self, data, next_data=None):
+        from . import dense_conv
+        dense_conv.AMAX_POOL.next_generation()      # one memset for all of this step's absmax slots
         hit = self._prepared.pop(id(data), None)
         self._retired = [(p, e) for p, e in self._retired if not e.query()]
         prep = None

@@ -213,7 +213,7 @@ def run_mono_workload(batch, steps, warmup, args, rank, world, device):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     loss = float(out['loss'].detach())
     assert loss == loss, 'loss is NaN (gga_pdg.py)'
-    return dict(dt=float(t.item()), loss=loss)
+    return dict(dt=float(t.item()), loss=loss, runner=runner, batches=batches)
 
 
 def scatter_roofline(model, batches, step_ms):

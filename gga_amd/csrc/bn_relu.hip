@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float4* __restrict_
 __global__ __launch_bounds__(1024) void bn_bwd_final_kernel(const double* __restrict__ partials, int nblocks, int C,
                                                            double rows, const float* __restrict__ gamma,
                                                            const float* __restrict__ saved, float* __restrict__ dgamma,
-                                                           float* __restrict__ dbeta, float* __restrict__ coef) {
+                                                           float* __restrict__ dbeta, float* __restrict__ coef, int training) {
     const int c = blockIdx.x * 8 + (threadIdx.x & 7);
     const bool ok = c < C;
     double s, sx;
@@ -264,8 +264,9 @@ __global__ __launch_bounds__(1024) void bn_bwd_final_kernel(const double* __rest
     if (dgamma) dgamma[c] = (float)sx;
     const float k = (gamma ? gamma[c] : 1.0f) * saved[C + c];
     coef[c] = k;                              // gamma * invstd
-    coef[C + c] = (float)(s / rows);          // mean(g)
-    coef[2 * C + c] = (float)(sx / rows);     // mean(g * xhat)
+    // evaluation-mode statistics (running mean / variance, e.g. a frozen backbone) do not depend on x: dx = gamma*invstd*g
+    coef[C + c] = training ? (float)(s / rows) : 0.0f;          // mean(g)
+    coef[2 * C + c] = training ? (float)(sx / rows) : 0.0f;     // mean(g * xhat)
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float4* __restrict__ dy, const float4* __restrict__ x,
@@ -468,7 +469,7 @@ int gga_bn_bwd_finalize(const double* partials, int nblocks, int channels, int64
                         hipStream_t stream) {
     *coef = (float*)((char*)workspace + (size_t)BN_MAX_BLOCKS * 2 * channels * sizeof(double));
     hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((channels + 7) / 8), dim3(1024), 0, stream, partials, nblocks, channels,
-                       (double)rows, gamma, saved, grad_gamma, grad_beta, *coef);
+                       (double)rows, gamma, saved, grad_gamma, grad_beta, *coef, 1);
     GGA_CHECK_LAUNCH("bn_bwd_final_kernel");
     return GGA_OK;
 }
@@ -477,12 +478,13 @@ extern "C" int gga_bn_relu_bwd_strided(const float* grad_y, int64_t grad_y_row_s
                                        const void* mask_bits, const float* gamma, const float* saved, int64_t rows,
                                        int channels, int relu, float* grad_x, float* grad_residual, float* grad_gamma,
                                        float* grad_beta, void* workspace, size_t workspace_bytes, void* stream_) {
-    return gga_bn_relu_bwd_ex(grad_y, grad_y_row_stride, x, mask_bits, gamma, saved, rows, channels, relu, grad_x, grad_residual,
+    return gga_bn_relu_bwd_ex(grad_y, grad_y_row_stride, x, mask_bits, gamma, saved, rows, channels, relu, 1, grad_x, grad_residual,
                               grad_gamma, grad_beta, nullptr, workspace, workspace_bytes, stream_);
 }
 
 extern "C" int gga_bn_relu_bwd_ex(const float* grad_y, int64_t grad_y_row_stride, const float* x, const void* mask_bits,
-                                  const float* gamma, const float* saved, int64_t rows, int channels, int relu, float* grad_x,
+                                  const float* gamma, const float* saved, int64_t rows, int channels, int relu, int training,
+                                  float* grad_x,
                                   float* grad_residual, float* grad_gamma, float* grad_beta, uint32_t* amax_grad_x,
                                   void* workspace, size_t workspace_bytes, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
@@ -504,7 +506,7 @@ extern "C" int gga_bn_relu_bwd_ex(const float* grad_y, int64_t grad_y_row_stride
                        (const unsigned long long*)mask_bits, saved, g, relu, partials);
     GGA_CHECK_LAUNCH("bn_reduce_kernel<bwd>");
     hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((channels + 7) / 8), dim3(1024), 0, stream, partials, nb, channels,
-                       (double)rows, gamma, saved, grad_gamma, grad_beta, coef);
+                       (double)rows, gamma, saved, grad_gamma, grad_beta, coef, training);
     GGA_CHECK_LAUNCH("bn_bwd_final_kernel");
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nb), dim3(256), 0, stream, (const float4*)grad_y, (const float4*)x,
                        (const unsigned long long*)mask_bits, saved, coef, g, relu, (float4*)grad_x,

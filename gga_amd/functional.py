@@ -520,7 +520,7 @@ class _BNAct(torch.autograd.Function):
                                    _p(partials) if use else None, int(partials.shape[0]) if use else 0, _p(amax), _p(ws),
                                    ws.numel(), _stream()), 'gga_bn_relu_fwd')
         ctx.save_for_backward(x, gamma, saved, bits)
-        ctx.cfg = (rows, C, relu, residual is not None)
+        ctx.cfg = (rows, C, relu, residual is not None, bool(training))
         if amax is None:
             amax = torch.empty(0, dtype=torch.int32, device=dev)
         ctx.mark_non_differentiable(amax)
@@ -529,7 +529,7 @@ class _BNAct(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy, _gamax=None):
         x, gamma, saved, bits = ctx.saved_tensors
-        rows, C, relu, has_res = ctx.cfg
+        rows, C, relu, has_res, training = ctx.cfg
         L = _lib.lib()
         # the incoming gradient must have the memory layout of x ([rows, C] row major)
         gy = gy.contiguous(memory_format=torch.channels_last) if x.dim() == 4 else gy.contiguous()
@@ -539,8 +539,8 @@ class _BNAct(torch.autograd.Function):
         ws = _workspace('bn', L.gga_bn_relu_workspace_bytes(rows, C), x.device)
         from . import dense_conv
         amax = dense_conv.new_amax(x.device)         # max |gx| for the convolution backward that reads gx
-        check(L.gga_bn_relu_bwd_ex(_p(gy), C, _p(x), _p(bits), _p(gamma), _p(saved), rows, C, int(relu), _p(gx), _p(gres),
-                                   _p(gg), _p(gb), _p(amax), _p(ws), ws.numel(), _stream()), 'gga_bn_relu_bwd')
+        check(L.gga_bn_relu_bwd_ex(_p(gy), C, _p(x), _p(bits), _p(gamma), _p(saved), rows, C, int(relu), int(training), _p(gx),
+                                   _p(gres), _p(gg), _p(gb), _p(amax), _p(ws), ws.numel(), _stream()), 'gga_bn_relu_bwd')
         dense_conv.set_amax(gx, amax)
         return gx, gres, gg, gb, None, None, None, None, None, None, None, None, None
 
@@ -556,12 +556,12 @@ def _rows_channels(x):
 
 def bn_act(x, bn, relu=True, residual=None):
     """``relu(bn(x) + residual)`` (each part optional) — one fused HIP pass pair when ``x`` is a CUDA
-    f32 [rows, C] / channels-last tensor in training mode, the eager ops otherwise."""
+    f32 [rows, C] / channels-last tensor: training mode (batch statistics) or evaluation mode (running statistics,
+    also under autograd: a frozen ``norm_eval`` backbone); the eager ops otherwise."""
     rc = _rows_channels(x) if (x.is_cuda and x.dtype == torch.float32) else None
     C = x.shape[1]
     ok = (rc is not None and rc[0] >= 1 and C % 4 == 0 and C // 4 <= 256 and 256 % (C // 4) == 0 and bn.affine
           and bn.track_running_stats and bn.momentum is not None
-          and (bn.training or not torch.is_grad_enabled())
           and (residual is None or (residual.shape == x.shape and residual.stride() == x.stride())))
     if not ok:
         y = bn(x)
@@ -641,7 +641,7 @@ class _BNActCat(torch.autograd.Function):
             ws = _workspace('bn', L.gga_bn_relu_workspace_bytes(rows, C), x.device)
             amax = dense_conv.new_amax(x.device)
             check(L.gga_bn_relu_bwd_ex(g.data_ptr() + 4 * off, tot, _p(x), _p(bits_all[i]), _p(gammas[i]),
-                                       _p(saved_all[i]), rows, C, 1, _p(gx), None, _p(gg), _p(gb), _p(amax), _p(ws),
+                                       _p(saved_all[i]), rows, C, 1, 1, _p(gx), None, _p(gg), _p(gb), _p(amax), _p(ws),
                                        ws.numel(), _stream()), 'gga_bn_relu_bwd_strided')
             dense_conv.set_amax(gx, amax)
             gxs.append(gx), ggs.append(gg), gbs.append(gb)

@@ -32,11 +32,16 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        identity = x if self.downsample is None else self.downsample(x)
-        out = self.relu(self.bn1(self.conv1(x)))
-        out = self.relu(self.bn2(dense_conv.conv2d(out, self.conv2)))        # bf16x6 kernel when 3x3 / stride 1 / channels-last
-        out = self.bn3(self.conv3(out))
-        return self.relu(out + identity)
+        # every convolution on the repo's kernels (1x1 and strided: gather-GEMM, 3x3 stride 1: dense kernel) and every
+        # BatchNorm (+ residual) (+ ReLU) as one fused pass pair, training or norm_eval statistics alike
+        from . import functional as F
+        if self.downsample is None:
+            identity = x
+        else:
+            identity = F.bn_act(dense_conv.conv2d(x, self.downsample[0]), self.downsample[1], relu=False)
+        out = F.bn_act(dense_conv.conv2d(x, self.conv1), self.bn1, relu=True)
+        out = F.bn_act(dense_conv.conv2d(out, self.conv2), self.bn2, relu=True)
+        return F.bn_act(dense_conv.conv2d(out, self.conv3), self.bn3, relu=True, residual=identity)
 
 
 @BACKBONES.register_module()

@@ -447,14 +447,16 @@ int gga_bn_relu_bwd_strided(const float* grad_y, int64_t grad_y_row_stride, cons
 /* Supersets of the calls above with one more output: the bits of the largest finite magnitude written (y /
  * grad_x), max-combined into *amax (the caller zeroes it; several calls may share it) - what the two-fp16-plane
  * convolution kernels that consume the tensor derive their scale from, without a pass of their own.
- * gga_bn_relu_fwd_ex: partials != NULL = the producer's per-channel sums (as gga_bn_relu_fwd_partials). */
+ * gga_bn_relu_fwd_ex: partials != NULL = the producer's per-channel sums (as gga_bn_relu_fwd_partials).
+ * gga_bn_relu_bwd_ex: training = 0 is the backward of an evaluation-mode forward (running statistics, e.g. a frozen
+ * backbone with norm_eval): grad_x = gamma * invstd * g, grad_gamma / grad_beta as in training mode. */
 int gga_bn_relu_fwd_ex(const float* x, const float* residual, const float* gamma, const float* beta,
                        float* running_mean, float* running_var, int64_t rows, int channels, float eps, float momentum,
                        int training, int relu, float* y, int64_t y_row_stride, void* mask_bits, float* saved,
                        const double* partials, int n_partials, uint32_t* amax_y, void* workspace, size_t workspace_bytes,
                        void* stream);
 int gga_bn_relu_bwd_ex(const float* grad_y, int64_t grad_y_row_stride, const float* x, const void* mask_bits,
-                       const float* gamma, const float* saved, int64_t rows, int channels, int relu, float* grad_x,
+                       const float* gamma, const float* saved, int64_t rows, int channels, int relu, int training, float* grad_x,
                        float* grad_residual, float* grad_gamma, float* grad_beta, uint32_t* amax_grad_x, void* workspace,
                        size_t workspace_bytes, void* stream);
 

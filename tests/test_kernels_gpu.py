@@ -378,6 +378,23 @@ def test_fused_bn_act_vs_torch(shape, cl, relu, res):
         ye = F.bn_act(x, bn, relu=relu, residual=r)
         yre = ref(x) + (r if res else 0)
         torch.testing.assert_close(ye, torch.relu(yre) if relu else yre, rtol=1e-4, atol=1e-4)
+    # ... also under autograd (a frozen norm_eval backbone): dx = gamma * invstd * g, no batch terms
+    for m in (bn, ref):
+        m.weight.grad = m.bias.grad = None
+    x3, x4 = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    y3 = F.bn_act(x3, bn, relu=relu, residual=r)
+    assert 'BNAct' in type(y3.grad_fn).__name__
+    y4 = ref(x4) + (r if res else 0)
+    y4 = torch.relu(y4) if relu else y4
+    torch.testing.assert_close(y3, y4, rtol=1e-4, atol=1e-4)
+    rm = bn.running_mean.clone()
+    y3.backward(g)
+    y4.backward(g)
+    assert torch.equal(bn.running_mean, rm) and int(bn.num_batches_tracked) == 1      # statistics untouched
+    flip = (x3.grad - x4.grad).abs() > 1e-4 + 1e-3 * x4.grad.abs()
+    assert int(flip.sum()) <= 3
+    torch.testing.assert_close(bn.weight.grad, ref.weight.grad, rtol=1e-2, atol=1e-2)
+    torch.testing.assert_close(bn.bias.grad, ref.bias.grad, rtol=1e-2, atol=1e-2)
 
 
 def test_bn_relu_cat_vs_torch():

@@ -11,7 +11,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libgga_hip.so')
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 _lib = None
 
@@ -103,6 +103,9 @@ SIGNATURES = {
     'gga_bn_relu_bwd_strided': (i32, [vp, i64, vp, vp, vp, vp, i64, i32, i32, vp, vp, vp, vp, vp, sz, vp]),
     'gga_bn_relu_fwd_ex': (i32, [vp, vp, vp, vp, vp, vp, i64, i32, f32, f32, i32, i32, vp, i64, vp, vp, vp, i32, vp, vp, sz, vp]),
     'gga_bn_relu_bwd_ex': (i32, [vp, i64, vp, vp, vp, vp, i64, i32, i32, i32, vp, vp, vp, vp, vp, vp, sz, vp]),
+    'gga_gn_relu_workspace_bytes': (sz, [i32, i32]),
+    'gga_gn_relu_fwd': (i32, [vp, vp, vp, i32, i64, i32, i32, f32, i32, vp, vp, vp, vp, vp, sz, vp]),
+    'gga_gn_relu_bwd': (i32, [vp, vp, vp, vp, vp, i32, i64, i32, i32, i32, vp, vp, vp, vp, vp, sz, vp]),
     'gga_bn_stats': (i32, [vp, vp, vp, vp, vp, i64, i32, f32, f32, i32, vp, vp, vp, sz, vp]),
     'gga_head_conv3x3_fwd': (i32, [vp, i64, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]),
     'gga_head_conv3x3_workspace_bytes': (sz, [i32]),

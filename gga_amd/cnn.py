@@ -112,11 +112,14 @@ class ConvModule(nn.Module):
         if is_bn:
             from . import functional as F        # fused BN(+ReLU) HIP pass for channels-last activations
             return F.bn_act(x, self.norm, relu=self.with_activation)
-        if self.with_norm:                       # GroupNorm (mono3d heads): ATen's kernel returns NCHW memory
-            cl = x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)
+        if self.with_norm and isinstance(self.norm, nn.GroupNorm):     # mono3d heads
+            from . import functional as F
+            if self.with_activation and not isinstance(self.activate, nn.ReLU):
+                x = F.gn_act(x, self.norm, relu=False)
+                return self.activate(x)
+            return F.gn_act(x, self.norm, relu=self.with_activation)   # fused channels-last pass pair (eager fallback inside)
+        if self.with_norm:
             x = self.norm(x)
-            if cl:
-                x = x.contiguous(memory_format=torch.channels_last)
         if self.with_activation:
             x = self.activate(x)
         return x

@@ -581,6 +581,65 @@ def bn_act(x, bn, relu=True, residual=None):
     return y
 
 
+class _GNAct(torch.autograd.Function):
+    """``relu(group_norm(x))`` on a channels-last activation (gga_gn_relu_fwd / _bwd)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, groups, eps, relu):
+        from . import dense_conv
+        L = _lib.lib()
+        B, C, H, W = x.shape
+        dev = x.device
+        y = torch.empty_like(x)
+        stat = torch.empty((B, groups, 2), dtype=torch.float32, device=dev)
+        ss = torch.empty((B, 2, C), dtype=torch.float32, device=dev)
+        ws = _workspace('gn', L.gga_gn_relu_workspace_bytes(B, C), dev)
+        amax = dense_conv.new_amax(dev)
+        check(L.gga_gn_relu_fwd(_p(x), _p(gamma), _p(beta), B, H * W, C, groups, eps, int(relu), _p(y), _p(stat), _p(ss), _p(amax),
+                                _p(ws), ws.numel(), _stream()), 'gga_gn_relu_fwd')
+        ctx.save_for_backward(x, gamma, stat, ss)
+        ctx.cfg = (groups, relu)
+        if amax is None:
+            amax = torch.empty(0, dtype=torch.int32, device=dev)
+        ctx.mark_non_differentiable(amax)
+        return y, amax
+
+    @staticmethod
+    def backward(ctx, gy, _gamax=None):
+        from . import dense_conv
+        x, gamma, stat, ss = ctx.saved_tensors
+        groups, relu = ctx.cfg
+        L = _lib.lib()
+        B, C, H, W = x.shape
+        gy = gy.contiguous(memory_format=torch.channels_last)
+        gx = torch.empty_like(x)
+        gg = torch.empty(C, dtype=torch.float32, device=x.device)
+        gb = torch.empty(C, dtype=torch.float32, device=x.device)
+        ws = _workspace('gn', L.gga_gn_relu_workspace_bytes(B, C), x.device)
+        amax = dense_conv.new_amax(x.device)
+        check(L.gga_gn_relu_bwd(_p(gy), _p(x), _p(gamma), _p(stat), _p(ss), B, H * W, C, groups, int(relu), _p(gx), _p(gg), _p(gb),
+                                _p(amax), _p(ws), ws.numel(), _stream()), 'gga_gn_relu_bwd')
+        dense_conv.set_amax(gx, amax)
+        return gx, gg, gb, None, None, None
+
+
+def gn_act(x, gn, relu=True):
+    """``relu(gn(x))`` - one fused HIP pass pair when ``x`` is a CUDA f32 channels-last [B, C, H, W] tensor whose group
+    size is a multiple of 4 channels, the eager ops otherwise (``torch.nn.GroupNorm`` returns NCHW memory)."""
+    C = x.shape[1] if x.dim() == 4 else 0
+    ok = (x.dim() == 4 and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous(memory_format=torch.channels_last)
+          and C % 4 == 0 and C // 4 <= 256 and 256 % (C // 4) == 0 and C % gn.num_groups == 0
+          and (C // gn.num_groups) % 4 == 0 and gn.affine and x.shape[2] * x.shape[3] >= 1)
+    if not ok:
+        y = gn(x)
+        return torch.relu(y) if relu else y
+    y, amax = _GNAct.apply(x, gn.weight, gn.bias, int(gn.num_groups), float(gn.eps), bool(relu))
+    if amax.numel():
+        from . import dense_conv
+        dense_conv.set_amax(y, amax)
+    return y
+
+
 class _BNActCat(torch.autograd.Function):
     """``cat([relu(bn_i(x_i))], dim=1)`` for channels-last inputs of equal [B, ., H, W]: every
     branch writes its column block of the concatenated map and reads its block of the gradient in

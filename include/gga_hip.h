@@ -460,6 +460,19 @@ int gga_bn_relu_bwd_ex(const float* grad_y, int64_t grad_y_row_stride, const flo
                        float* grad_residual, float* grad_gamma, float* grad_beta, uint32_t* amax_grad_x, void* workspace,
                        size_t workspace_bytes, void* stream);
 
+/* Fused GroupNorm (+ ReLU) over a channels-last [B, rows_per_sample, channels] activation (statistics per sample and
+ * group of channels / groups channels): replaces the GN + ReLU of the ConvModules in the PGD / FCOS3D head
+ * (mmdet3d/models/dense_heads/anchor_free_mono3d_head.py:160-250, norm_cfg type 'GN'), whose framework kernels need NCHW
+ * memory. stat [B][groups][2] = mean, rstd; scale_shift [B][2][channels]; both are kept for the backward, which
+ * recomputes the ReLU mask from x. channels/4 must divide 256, channels per group % 4 == 0. amax_* as in gga_bn_relu_*_ex. */
+size_t gga_gn_relu_workspace_bytes(int B, int channels);
+int gga_gn_relu_fwd(const float* x, const float* gamma, const float* beta, int B, int64_t rows_per_sample, int channels,
+                    int groups, float eps, int relu, float* y, float* stat, float* scale_shift, uint32_t* amax_y,
+                    void* workspace, size_t workspace_bytes, void* stream);
+int gga_gn_relu_bwd(const float* grad_y, const float* x, const float* gamma, const float* stat, const float* scale_shift,
+                    int B, int64_t rows_per_sample, int channels, int groups, int relu, float* grad_x, float* grad_gamma,
+                    float* grad_beta, uint32_t* amax_grad_x, void* workspace, size_t workspace_bytes, void* stream);
+
 int gga_bn_stats(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
                  int64_t rows, int channels, float eps, float momentum, int training, float* saved,
                  float* scale_shift, void* workspace, size_t workspace_bytes, void* stream);

@@ -397,6 +397,36 @@ def test_fused_bn_act_vs_torch(shape, cl, relu, res):
     torch.testing.assert_close(bn.bias.grad, ref.bias.grad, rtol=1e-2, atol=1e-2)
 
 
+@pytest.mark.parametrize('B,C,G,H,W', [(3, 256, 32, 24, 39), (2, 64, 16, 7, 5), (1, 32, 8, 40, 33)])
+@pytest.mark.parametrize('relu', [True, False])
+def test_fused_gn_act_vs_torch(B, C, G, H, W, relu):
+    """Fused GroupNorm (+ ReLU) on channels-last memory against eager torch: values and all gradients."""
+    import copy
+    torch.manual_seed(1)
+    gn = torch.nn.GroupNorm(G, C, eps=1e-5).to(DEV)
+    with torch.no_grad():
+        gn.weight.uniform_(0.5, 1.5), gn.bias.uniform_(-0.5, 0.5)
+    ref = copy.deepcopy(gn)
+    x = (torch.randn(B, C, H, W, device=DEV) * 2 + 0.7).contiguous(memory_format=torch.channels_last)
+    x1, x2 = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    y = F.gn_act(x1, gn, relu=relu)
+    assert 'GNAct' in type(y.grad_fn).__name__ and y.is_contiguous(memory_format=torch.channels_last)
+    yr = ref(x2)
+    yr = torch.relu(yr) if relu else yr
+    torch.testing.assert_close(y, yr, rtol=1e-4, atol=1e-4)
+    g = torch.randn_like(yr)
+    y.backward(g)
+    yr.backward(g)
+    flip = (x1.grad - x2.grad).abs() > 1e-4 + 1e-3 * x2.grad.abs()
+    assert int(flip.sum()) <= 3                                         # ReLU-boundary elements may take the other branch
+    torch.testing.assert_close(gn.weight.grad, ref.weight.grad, rtol=1e-3, atol=1e-2)
+    torch.testing.assert_close(gn.bias.grad, ref.bias.grad, rtol=1e-3, atol=1e-2)
+    # shapes the kernels do not take fall back to the eager ops
+    odd = torch.nn.GroupNorm(3, 6).to(DEV)
+    xo = torch.randn(2, 6, 5, 5, device=DEV).contiguous(memory_format=torch.channels_last)
+    torch.testing.assert_close(F.gn_act(xo, odd, relu=True), torch.relu(odd(xo)))
+
+
 def test_bn_relu_cat_vs_torch():
     """SECONDFPN tail: the branches' BN+ReLU written into / read from channel slices of the
     concatenated map equals cat(relu(bn(x)))."""

@@ -733,7 +733,7 @@ def test_dense_conv_leaves_batchnorm_partials(cin, cout, B, H, W):
 
 
 @pytest.mark.parametrize('kind,cin,cout,k,s,B,H,W', [('conv', 64, 128, 3, 2, 2, 37, 45), ('conv', 128, 256, 3, 2, 2, 24, 30),
-                                                      ('conv', 64, 64, 3, 2, 1, 40, 32), ('conv', 384, 64, 1, 1, 1, 20, 24),
+                                                      ('conv', 64, 64, 3, 2, 1, 40, 32), ('conv', 256, 64, 1, 1, 1, 20, 24),
                                                       ('deconv', 64, 128, 1, 1, 2, 37, 45), ('deconv', 128, 128, 2, 2, 2, 19, 23),
                                                       ('deconv', 256, 128, 4, 4, 2, 9, 11), ('deconv', 256, 256, 2, 2, 1, 8, 8)])
 @pytest.mark.parametrize('planes', [2, 3])

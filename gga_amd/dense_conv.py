@@ -1,11 +1,12 @@
-"""3x3 / stride-1 / pad-1 convolutions of the BEV trunk and the head branches on the bf16x9 matrix
-path (``gga_dense_conv3x3``): forward and backward-data; the weight gradient stays with the
-framework's convolution backward (MIOpen).
+"""3x3 / stride-1 / pad-1 convolutions of the BEV trunk and the head branches on the repo's matrix kernels
+(``gga_dense_conv3x3_planes`` / ``gga_dense_wgrad3x3_planes``): forward, backward-data and weight gradient; every other
+eligible convolution is handed on to ``strided_conv`` (stride-2 3x3, 1x1, kernel = stride transposed).
 
 Reference call sites: the block convolutions of ``SECOND`` (backbones/second.py:58-63) and the
 ``ConvModule`` that opens every ``SeparateHead`` branch (dense_heads/centerpoint_head.py:58-68).
-fp32 in, fp32 out: every product is the exact sum of nine bf16 partial products accumulated in
-fp32 (error against float64 as small as MIOpen's fp32 kernels, tools_dev/bench_dense3x3.py).
+fp32 in, fp32 out, fp32 accumulation: operands are split into 16-bit planes (``PLANES`` below: two fp16 planes of the
+scaled operands and three partial products, or three bf16 planes and six) - error against float64 no larger than
+MIOpen's fp32 kernels (tools_dev/bench_dense3x3.py, DESIGN.md 5 for the contract).
 """
 import os
 

@@ -102,6 +102,12 @@ __global__ __launch_bounds__(256) void dcn_im2col_kernel(const float* __restrict
 // global atomic per contribution, 14 ms per call; this one: see DESIGN.md).
 // grad_offset / grad_mask: per (pixel, tap) sums over the channels, accumulated over the four channel chunks
 // in LDS and written once.
+// Measured in round 2 at 12 x 96 x 312 x 256 (tools_dev/bench_dcn.py, random offsets of std 0.5): 17.4 ms per call, of
+// which 1.7 ms are everything but grad_x (loads, geometry, the three reductions). Three rewrites of the grad_x half left
+// the time where it was: four pairs per wave with float4 lanes (a quarter of the load / geometry / reduction
+// instructions), a 72-float window stride with the channels interleaved (no LDS bank conflicts among a wave's pairs), and
+// writing the windows to a scratch image that a second kernel sums per input pixel (no global atomics at all). What is
+// left in common is the 3.3 G LDS float atomics themselves (64 channels x 4 corners per pair and chunk).
 #define DCN_TH 8
 #define DCN_TW 8
 #define DCN_R 2

@@ -1673,8 +1673,9 @@ __global__ __launch_bounds__(TR / MT * 64, 2) void dense_conv3x3_x9_kernel(const
     // requested at the start of stage s and written to LDS at the end of stage s + 1, so a load has two stages
     // (~1.5 us with two waves per SIMD) to come back from the L2 - with one stage the per-stage s_waitcnt was the
     // largest single loss of the kernel (ablation: 375 -> 303 us at 64 -> 64 without the loads).
-    // (the 512-thread form is limited to 256 registers by its two waves per SIMD and keeps one set.)
-    constexpr bool DEEP = !(NT == 4 && TR == 16) && MT == 2;
+    // (the 512-thread form is limited to 256 registers by its two waves per SIMD and keeps one set on three bf16 planes;
+    // on two fp16 planes both sets fit: 253 -> 240 us at 128 -> 128, 16 x 124 x 108.)
+    constexpr bool DEEP = (NP == 2 || !(NT == 4 && TR == 16)) && MT == 2;
     uint4 bq0, bq1, bq2, cq0, cq1, cq2;
     bq0 = bq1 = bq2 = cq0 = cq1 = cq2 = make_uint4(0, 0, 0, 0);
     // the packed stage (tap, 16-channel chunk) is contiguous and in LDS piece order (dense_pack_weight_kernel): a wave

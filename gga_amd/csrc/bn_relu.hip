@@ -199,9 +199,10 @@ __global__ __launch_bounds__(1024) void bn_fwd_final_kernel(const double* __rest
     }
     saved[c] = mean;
     saved[C + c] = invstd;
-    const float sc = (gamma ? gamma[c] : 1.0f) * invstd;
+    float sc, sh;
+    gga_bn_scale_shift(gamma ? gamma[c] : 1.0f, beta ? beta[c] : 0.0f, mean, invstd, sc, sh);
     scale_shift[c] = sc;
-    scale_shift[C + c] = (beta ? beta[c] : 0.0f) - mean * sc;
+    scale_shift[C + c] = sh;
 }
 
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float4* __restrict__ x, const float4* __restrict__ res,
@@ -511,6 +512,33 @@ extern "C" int gga_bn_relu_bwd_ex(const float* grad_y, int64_t grad_y_row_stride
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nb), dim3(256), 0, stream, (const float4*)grad_y, (const float4*)x,
                        (const unsigned long long*)mask_bits, saved, coef, g, relu, (float4*)grad_x,
                        (float4*)grad_residual, amax_grad_x);
+    GGA_CHECK_LAUNCH("bn_bwd_apply_kernel");
+    return GGA_OK;
+}
+
+extern "C" int gga_bn_relu_bwd_partials(const float* grad_masked, int64_t grad_row_stride, const float* x, const float* gamma,
+                                        const float* saved, int64_t rows, int channels, int training, const double* partials,
+                                        int n_partials, float* grad_x, float* grad_gamma, float* grad_beta,
+                                        uint32_t* amax_grad_x, void* workspace, size_t workspace_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (int rc = bn_check("gga_bn_relu_bwd_partials", rows, channels)) return rc;
+    GGA_REQUIRE(grad_row_stride >= channels && grad_row_stride % 4 == 0 && ((uintptr_t)grad_masked & 15) == 0,
+                "gga_bn_relu_bwd_partials: grad row stride %lld must be a multiple of 4 floats >= channels, grad 16 B aligned",
+                (long long)grad_row_stride);
+    GGA_REQUIRE(grad_masked && x && saved && grad_x && workspace && partials && n_partials >= 1,
+                "gga_bn_relu_bwd_partials: null pointer argument");
+    if (workspace_bytes < gga_bn_relu_workspace_bytes(rows, channels)) {
+        gga_set_error("gga_bn_relu_bwd_partials: workspace too small");
+        return GGA_ERR_WORKSPACE;
+    }
+    const BnGeom g = bn_geom(rows, channels, grad_row_stride);
+    const int nb = bn_grid(g.n4);
+    float* coef = (float*)((char*)workspace + (size_t)BN_MAX_BLOCKS * 2 * channels * sizeof(double));
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((channels + 7) / 8), dim3(1024), 0, stream, partials, n_partials, channels,
+                       (double)rows, gamma, saved, grad_gamma, grad_beta, coef, training);
+    GGA_CHECK_LAUNCH("bn_bwd_final_kernel");
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nb), dim3(256), 0, stream, (const float4*)grad_masked, (const float4*)x,
+                       (const unsigned long long*)nullptr, saved, coef, g, 0, (float4*)grad_x, (float4*)nullptr, amax_grad_x);
     GGA_CHECK_LAUNCH("bn_bwd_apply_kernel");
     return GGA_OK;
 }

@@ -67,6 +67,15 @@ __device__ __forceinline__ double wave_sum(double v) {
 // Largest finite magnitude (as float bits) seen by a workgroup -> *out by ONE guarded atomicMax (same-address atomics
 // serialise in the L2: thousands of them cost more than the pass they decorate). Call from every thread of a
 // workgroup of at most 1024 threads; `m` = the thread's running maximum of (bits & 0x7fffffff) over finite values.
+// BatchNorm as one multiply-add per element, y = x * scale + shift. Every kernel that needs the pair (the forward
+// finalisation, and the backward kernels that recompute the ReLU mask from x) derives it through this one function, so the
+// recomputed mask is bit for bit the forward pass's decision.
+__device__ __forceinline__ void gga_bn_scale_shift(float gamma, float beta, float mean, float invstd, float& scale,
+                                                   float& shift) {
+    scale = gamma * invstd;
+    shift = fmaf(-mean, scale, beta);
+}
+
 __device__ __forceinline__ uint32_t gga_amax_of(float v, uint32_t m) {
     const uint32_t u = __float_as_uint(v) & 0x7FFFFFFFu;
     return (u < 0x7F800000u && u > m) ? u : m;

@@ -1599,13 +1599,27 @@ extern "C" int gga_debug_dc_probe(unsigned long long* out) {
 // kernel row per barrier (36 MFMAs and one barrier per row stage instead of 12 and one per tap, weights requested a full
 // row stage ahead) measured 0.219 against 0.209 ms on the same box, alternating runs. -DDC_PROBE builds the cycle
 // accounting that tools_dev/probe_dense_stage.py prints.)
+// Backward-data launches whose result is the gradient of a BatchNorm + ReLU output z = relu(bn(y)) take the reduce pass
+// of that BatchNorm's backward into their epilogue: the tile is masked by the ReLU (recomputed from y, gamma, beta and
+// the saved statistics exactly as the forward pass computed it: gga_bn_scale_shift) before it is stored, and the tile's
+// per-channel sums of g and g * xhat go to `stats` in the layout of the forward statistics. y: the BatchNorm's input,
+// channel block of this launch, pixel stride ystride floats; gamma / beta / mean / invstd: of that channel block.
+struct DcBnBwd {
+    const float* y;
+    const float* gamma;
+    const float* beta;
+    const float* mean;
+    const float* invstd;
+    int ystride;
+};
+
 template <int NT, int TR, int NP, int MT>
 __global__ __launch_bounds__(TR / MT * 64, 2) void dense_conv3x3_x9_kernel(const float* __restrict__ X, const uint16_t* __restrict__ Wp,
                                                                  int B, int H, int W, int cin, int cout, int tiles_x,
                                                                  int tiles_y, float* __restrict__ Y, int ystride,
                                                                  int prow, int pcol, double* __restrict__ stats,
                                                                  const uint32_t* __restrict__ amax_x,
-                                                                 const uint32_t* __restrict__ amax_w) {
+                                                                 const uint32_t* __restrict__ amax_w, DcBnBwd bn) {
     // H x W is the tile space (rows x 32-pixel columns); pixel (r, c) of it is pixel r*prow + c*pcol of
     // the image: (W, 1) for the image as stored, (1, image width) with H and W swapped for the
     // transposed walk (tiles 32 pixels long along the image's H), chosen by the caller per shape.
@@ -1822,6 +1836,49 @@ __global__ __launch_bounds__(TR / MT * 64, 2) void dense_conv3x3_x9_kernel(const
                     for (int i = 0; i < 16; ++i) acc[m][t][i] = acc[m][t][i] * dx * dw;
         }
         // D layout of 32x32x16: register v of lane l holds row (v/4)*8 + (l/32)*4 + v%4 (= pixel of the M tile's row), column l%32
+        float s1[NT], s2[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { s1[t] = 0.0f; s2[t] = 0.0f; }
+        if (bn.y) {                                        // see DcBnBwd: ReLU mask and the BatchNorm backward sums
+            float bsc[NT], bsh[NT], bmu[NT], biv[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int c = t * 32 + r;
+                bmu[t] = bn.mean[c]; biv[t] = bn.invstd[c];
+                gga_bn_scale_shift(bn.gamma ? bn.gamma[c] : 1.0f, bn.beta ? bn.beta[c] : 0.0f, bmu[t], biv[t], bsc[t], bsh[t]);
+            }
+            // 32 values of y per lane are requested before the first of them is used (a load per store serialises on
+            // the memory latency: + 110 .. 250 us per launch)
+            constexpr int VB = 32 / NT;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int oy = y0 + MT * wave + m;
+                if (oy >= H) continue;
+#pragma unroll
+                for (int v0 = 0; v0 < 16; v0 += VB) {
+                    float yv[VB][NT];
+#pragma unroll
+                    for (int j = 0; j < VB; ++j) {
+                        const int ox = x0 + ((v0 + j) >> 2) * 8 + h * 4 + ((v0 + j) & 3);
+                        const float* src = bn.y + ((int64_t)b * H * W + oy * prow + (ox < W ? ox : W - 1) * pcol) * bn.ystride;
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) yv[j][t] = src[t * 32 + r];
+                    }
+#pragma unroll
+                    for (int j = 0; j < VB; ++j) {
+                        const int ox = x0 + ((v0 + j) >> 2) * 8 + h * 4 + ((v0 + j) & 3);
+                        if (ox >= W) continue;
+                        float* dst = Y + ((int64_t)b * H * W + oy * prow + ox * pcol) * ystride;
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) {
+                            const float g = fmaf(yv[j][t], bsc[t], bsh[t]) > 0.0f ? acc[m][t][v0 + j] : 0.0f;
+                            dst[t * 32 + r] = g;
+                            s1[t] += g; s2[t] += g * ((yv[j][t] - bmu[t]) * biv[t]);
+                        }
+                    }
+                }
+            }
+        } else
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             const int oy = y0 + MT * wave + m;
@@ -1839,9 +1896,7 @@ __global__ __launch_bounds__(TR / MT * 64, 2) void dense_conv3x3_x9_kernel(const
             // per-channel sum and sum of squares of the tile's outputs (the batch statistics of the
             // BatchNorm that follows, so it need not read y again): lane sums over its pixels, the
             // two half waves and the four waves are folded through LDS, one f64 row pair per tile.
-            float s1[NT], s2[NT];
-#pragma unroll
-            for (int t = 0; t < NT; ++t) { s1[t] = 0.0f; s2[t] = 0.0f; }
+            if (!bn.y)
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 const bool rowok = y0 + MT * wave + m < H;
@@ -1970,6 +2025,14 @@ extern "C" int64_t gga_dense_conv3x3_tiles(int B, int H, int W, int cout) {   //
     return (int64_t)B * ((W + DC_TW - 1) / DC_TW) * ((H + tr - 1) / tr);
 }
 
+// Whether the BatchNorm-backward epilogue (gga_dense_conv3x3_bn_bwd) is cheaper than the reduce pass it replaces. Measured
+// inside the PointPillars step (16 frames): 64 output channels (two workgroups per CU, the other one's MFMAs cover the
+// epilogue's loads) + 0 us per launch against 100 us of reduce pass; 128 channels in 16-row tiles + 25 .. 100 us against
+// 55 .. 200; 128 channels in 8-row tiles (small maps, one workgroup per CU) + 33 us against 15: not there.
+extern "C" int gga_dense_conv3x3_bn_bwd_pays(int B, int H, int W, int cout) {
+    return cout == 64 || dc_tile_rows(B, H, W, cout) == 16;
+}
+
 extern "C" int gga_dense_conv3x3_slice(const float* x, const void* split_weight, int B, int H, int W, int cin, int cout,
                                        float* y, int64_t y_pixel_stride, int transposed, double* stats, void* stream_) {
     return gga_dense_conv3x3_planes(x, split_weight, B, H, W, cin, cout, y, y_pixel_stride, transposed, stats, 3, nullptr, nullptr,
@@ -1979,7 +2042,20 @@ extern "C" int gga_dense_conv3x3_slice(const float* x, const void* split_weight,
 extern "C" int gga_dense_conv3x3_planes(const float* x, const void* split_weight, int B, int H, int W, int cin, int cout,
                                         float* y, int64_t y_pixel_stride, int transposed, double* stats, int planes,
                                         const uint32_t* amax_x, const uint32_t* amax_weight, void* stream_) {
+    return gga_dense_conv3x3_bn_bwd(x, split_weight, B, H, W, cin, cout, y, y_pixel_stride, transposed, stats, planes, amax_x,
+                                    amax_weight, nullptr, 0, nullptr, nullptr, nullptr, nullptr, stream_);
+}
+
+extern "C" int gga_dense_conv3x3_bn_bwd(const float* x, const void* split_weight, int B, int H, int W, int cin, int cout,
+                                        float* y, int64_t y_pixel_stride, int transposed, double* stats, int planes,
+                                        const uint32_t* amax_x, const uint32_t* amax_weight, const float* bn_x,
+                                        int64_t bn_x_pixel_stride, const float* bn_gamma, const float* bn_beta,
+                                        const float* bn_mean, const float* bn_invstd, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    GGA_REQUIRE(!bn_x || (stats && bn_mean && bn_invstd && bn_x_pixel_stride >= cout && bn_x_pixel_stride < 2147483647ll),
+                "gga_dense_conv3x3_bn_bwd: the BatchNorm epilogue needs stats, the saved mean / invstd and a pixel stride >= cout");
+    DcBnBwd bn;
+    bn.y = bn_x; bn.gamma = bn_gamma; bn.beta = bn_beta; bn.mean = bn_mean; bn.invstd = bn_invstd; bn.ystride = (int)bn_x_pixel_stride;
     GGA_REQUIRE(x && split_weight && y, "gga_dense_conv3x3: null pointer argument");
     GGA_REQUIRE(planes == 3 || (planes == 2 && amax_x && amax_weight),
                 "gga_dense_conv3x3: planes must be 3 (bf16) or 2 (fp16, with the operands' absmax bits)");
@@ -2001,7 +2077,7 @@ extern "C" int gga_dense_conv3x3_planes(const float* x, const void* split_weight
     const dim3 grid((unsigned)n_tiles), block(trows * 32);
     hipEvent_t* tev = gga_timing_acquire(GGA_TIME_DENSE_CONV, GGA_TIMING_CONV_KEY(cin, cout, (int64_t)H * W));
     GGA_TIME_START(tev, stream);
-#define DC_GO(NT_, TR_, NP_) hipLaunchKernelGGL((dense_conv3x3_x9_kernel<NT_, TR_, NP_, 2>), grid, block, 0, stream, x, (const uint16_t*)split_weight, B, H, W, cin, cout, tx, ty, y, (int)y_pixel_stride, prow, pcol, stats, amax_x, amax_weight)
+#define DC_GO(NT_, TR_, NP_) hipLaunchKernelGGL((dense_conv3x3_x9_kernel<NT_, TR_, NP_, 2>), grid, block, 0, stream, x, (const uint16_t*)split_weight, B, H, W, cin, cout, tx, ty, y, (int)y_pixel_stride, prow, pcol, stats, amax_x, amax_weight, bn)
     if (planes == 3) {
         if (cout == 64) DC_GO(2, 8, 3);
         else if (trows == 16) DC_GO(4, 16, 3);

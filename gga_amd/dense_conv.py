@@ -24,6 +24,7 @@ WGRAD = True            # False: weight gradients stay with MIOpen
 #      significands, absolute accuracy 2^-39 of a tensor's largest magnitude per element (default);
 #   3  three bf16 planes, six partial products: fp32's exponent range, 24-bit significands.
 PLANES = int(os.environ.get('GGA_DENSE_PLANES', '2'))
+BN_BWD_FUSED = True     # backward-data convolutions reduce the BatchNorm backward sums of the layer below them (BnSource)
 
 
 def amax_bits(t):
@@ -111,6 +112,67 @@ def tensor_amax(t):
     return amax_bits(t)
 
 
+class BnSource:
+    """What a backward-data convolution needs to take the reduce pass of a BatchNorm backward into its epilogue
+    (``gga_dense_conv3x3_bn_bwd``): ``z = relu(bn(x))`` with ``parts`` = [(first channel of z, channels, x, gamma, beta,
+    saved mean / invstd)] - one entry, or one per concatenated branch. Attached to ``z`` by ``functional.bn_act`` /
+    ``bn_relu_cat`` and valid while ``z`` has not been written again."""
+
+    def __init__(self, z, parts):
+        self.key = (z._version, z.data_ptr(), z.numel())
+        self.parts = parts
+
+    def valid_for(self, z):
+        return self.key == (z._version, z.data_ptr(), z.numel())
+
+    def part(self, c0, width):
+        """(x pointer, x pixel stride, gamma, beta, mean, invstd pointers) of channels [c0, c0 + width), or None when
+        they straddle two branches."""
+        for start, C, x, gamma, beta, saved in self.parts:
+            if start <= c0 and c0 + width <= start + C:
+                o = 4 * (c0 - start)
+                return (x.data_ptr() + o, C, gamma.data_ptr() + o, beta.data_ptr() + o, saved.data_ptr() + o,
+                        saved.data_ptr() + 4 * C + o)
+        return None
+
+    def covers(self, n_out):
+        widths = [n_out] if n_out in (64, 128) else [128] * (n_out // 128)
+        return n_out == sum(C for _, C, *_ in self.parts) and all(
+            self.part(c0, w) is not None for c0, w in zip(range(0, n_out, 128), widths))
+
+
+def bn_source(z, n_out):
+    """The valid ``BnSource`` of ``z`` for a backward-data convolution with ``n_out`` output channels, or None (also
+    where the epilogue would cost more than the reduce pass it replaces: ``gga_dense_conv3x3_bn_bwd_pays``)."""
+    src = getattr(z, '_gga_bn_src', None)
+    if src is None or not src.valid_for(z) or not src.covers(n_out):
+        return None
+    B, _, H, W = z.shape
+    th, tw = (W, H) if _transposed(H, W) else (H, W)
+    if not _lib.lib().gga_dense_conv3x3_bn_bwd_pays(B, th, tw, 64 if n_out == 64 else 128):
+        return None
+    return src
+
+
+class BnPartials:
+    """Left on a gradient by the backward-data convolution that already reduced it (see BnSource): the gradient is
+    masked by the ReLU and ``parts`` = [(first channel, channels, [tiles, 2, channels] f64 sums)]."""
+
+    def __init__(self, g, parts, tokens):
+        self.key = (g._version, g.data_ptr(), g.numel())
+        self.parts, self.tokens = parts, tokens
+
+    def take(self, g, token, c0, C):
+        """The partial sums of channels [c0, c0 + C) if ``g`` is still the tensor the convolution wrote and ``token``
+        (data pointer of the BatchNorm's saved statistics) is the one it masked with."""
+        if self.key != (g._version, g.data_ptr(), g.numel()) or token not in self.tokens:
+            return None
+        hit = [p for s, w, p in self.parts if c0 <= s and s + w <= c0 + C]
+        if sum(p.shape[2] for p in hit) != C:
+            return None
+        return hit[0] if len(hit) == 1 else torch.cat(hit, dim=2)
+
+
 def _pack(weight, backward, transposed=False, w_amax=None):
     """Split-plane operand of the forward (or backward-data) convolution, read from the parameter's
     own memory layout: one kernel, no permuted copy. ``transposed``: for the transposed walk (ky and
@@ -127,11 +189,13 @@ def _pack(weight, backward, transposed=False, w_amax=None):
     return wp
 
 
-def _run(x, weight, backward, want_stats=False, x_amax=None, w_amax=None, y=None, y_col=0):
+def _run(x, weight, backward, want_stats=False, x_amax=None, w_amax=None, y=None, y_col=0, bn=None):
     """The convolution (or its backward-data form) of ``x`` with ``weight`` [cout, cin, 3, 3]; output
     widths above 128 run as 128-channel slices of the result. ``x_amax`` / ``w_amax``: absmax bits of the operands
     when they are already known (two-plane arithmetic; computed here otherwise). ``y`` / ``y_col``: write the result
-    into the channel block starting at ``y_col`` of an existing channels-last tensor."""
+    into the channel block starting at ``y_col`` of an existing channels-last tensor. ``bn`` (a ``BnSource``, backward
+    only): the result is the gradient of that BatchNorm + ReLU output - it is stored masked by the ReLU, and the second
+    return value is then the list [(first channel, channels, per-tile sums of g and g * xhat)] (``BnPartials.parts``)."""
     B, n_in, H, W = x.shape
     L = _lib.lib()
     n_out = weight.shape[1] if backward else weight.shape[0]
@@ -146,13 +210,17 @@ def _run(x, weight, backward, want_stats=False, x_amax=None, w_amax=None, y=None
     else:
         x_amax = w_amax = None
     stats = None
+    want_stats = want_stats or bn is not None
+    none6 = (None, 0, None, None, None, None)
     if n_out in (64, 128):
         if want_stats:
             tiles = int(L.gga_dense_conv3x3_tiles(B, W, H, n_out) if tr else L.gga_dense_conv3x3_tiles(B, H, W, n_out))
             stats = torch.empty((tiles, 2, n_out), dtype=torch.float64, device=x.device)
-        check(L.gga_dense_conv3x3_planes(F._p(x), F._p(_pack(weight, backward, tr, w_amax)), B, H, W, n_in, n_out,
+        check(L.gga_dense_conv3x3_bn_bwd(F._p(x), F._p(_pack(weight, backward, tr, w_amax)), B, H, W, n_in, n_out,
                                          y.data_ptr() + 4 * y_col, ystride, int(tr), F._p(stats), planes, F._p(x_amax),
-                                         F._p(w_amax), F._stream()), 'gga_dense_conv3x3')
+                                         F._p(w_amax), *(bn.part(0, n_out) if bn else none6), F._stream()), 'gga_dense_conv3x3')
+        if bn:
+            stats = [(0, n_out, stats)]
     else:
         parts = []
         for c0 in range(0, n_out, 128):             # strided views: packed straight from the parameter
@@ -161,13 +229,25 @@ def _run(x, weight, backward, want_stats=False, x_amax=None, w_amax=None, y=None
             if want_stats:                          # per-channel sums of this 128-channel block of the output
                 tiles = int(L.gga_dense_conv3x3_tiles(B, W, H, 128) if tr else L.gga_dense_conv3x3_tiles(B, H, W, 128))
                 st = torch.empty((tiles, 2, 128), dtype=torch.float64, device=x.device)
-                parts.append(st)
-            check(L.gga_dense_conv3x3_planes(F._p(x), F._p(_pack(wv, backward, tr, w_amax)), B, H, W, n_in, 128,
+                parts.append((c0, 128, st))
+            check(L.gga_dense_conv3x3_bn_bwd(F._p(x), F._p(_pack(wv, backward, tr, w_amax)), B, H, W, n_in, 128,
                                              y.data_ptr() + 4 * (y_col + c0), ystride, int(tr), F._p(st), planes, F._p(x_amax),
-                                             F._p(w_amax), F._stream()), 'gga_dense_conv3x3_slice')
-        if parts:
-            stats = torch.cat(parts, dim=2)         # [tiles, 2, n_out]
+                                             F._p(w_amax), *(bn.part(c0, 128) if bn else none6), F._stream()),
+                  'gga_dense_conv3x3_slice')
+        if bn:
+            stats = parts
+        elif parts:
+            stats = torch.cat([p for _, _, p in parts], dim=2)         # [tiles, 2, n_out]
     return y, stats
+
+
+def run_bn_bwd(gy, weight, g_amax, w_amax, src):
+    """Backward-data convolution of ``gy`` whose result is the gradient of the BatchNorm + ReLU output described by
+    ``src`` (a ``BnSource`` or None): with a source the result carries the ``BnPartials`` its BatchNorm backward takes."""
+    gx, parts = _run(gy, weight, True, False, g_amax, w_amax, bn=src)
+    if src is not None:
+        gx._gga_bn_bwd = BnPartials(gx, parts, tuple(p[5].data_ptr() for p in src.parts))
+    return gx
 
 
 def _wgrad(x, gy, weight, x_amax=None, g_amax=None):
@@ -200,6 +280,8 @@ class _Conv3x3(torch.autograd.Function):
         y, stats = _run(x, weight.detach(), False, want_stats, x_amax, w_amax)
         ctx.save_for_backward(x, weight)
         ctx.amax = (x_amax, w_amax)
+        # x = relu(bn(.)) with this convolution as its consumer: the backward-data pass then does that BatchNorm's reduce
+        ctx.bn_src = bn_source(x, cin) if BN_BWD_FUSED else None
         if stats is None:
             stats = torch.empty(0, dtype=torch.float64, device=x.device)
         ctx.mark_non_differentiable(stats)
@@ -219,7 +301,7 @@ class _Conv3x3(torch.autograd.Function):
         # output width; wider inputs are produced in 128-channel slices
         mine = cin in (64, 128) or cin % 128 == 0
         if ctx.needs_input_grad[0] and mine:
-            gx = _run(gy, weight.detach(), True, False, g_amax, w_amax)[0]
+            gx = run_bn_bwd(gy, weight.detach(), g_amax, w_amax, ctx.bn_src)
         need_gx = ctx.needs_input_grad[0] and not mine
         need_gw = bool(ctx.needs_input_grad[1])
         if need_gw and WGRAD and cin % 64 == 0 and cout % 64 == 0:

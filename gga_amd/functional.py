@@ -523,22 +523,30 @@ class _BNAct(torch.autograd.Function):
         ctx.cfg = (rows, C, relu, residual is not None, bool(training))
         if amax is None:
             amax = torch.empty(0, dtype=torch.int32, device=dev)
-        ctx.mark_non_differentiable(amax)
-        return y, amax
+        ctx.mark_non_differentiable(amax, saved)
+        return y, amax, saved
 
     @staticmethod
-    def backward(ctx, gy, _gamax=None):
+    def backward(ctx, gy, _gamax=None, _gsaved=None):
         x, gamma, saved, bits = ctx.saved_tensors
         rows, C, relu, has_res, training = ctx.cfg
         L = _lib.lib()
+        from . import dense_conv
+        done = getattr(gy, '_gga_bn_bwd', None)      # the convolution that produced gy masked it and reduced the sums
+        partials = done.take(gy, saved.data_ptr(), 0, C) if (done is not None and relu and not has_res) else None
         # the incoming gradient must have the memory layout of x ([rows, C] row major)
         gy = gy.contiguous(memory_format=torch.channels_last) if x.dim() == 4 else gy.contiguous()
         gx = torch.empty_like(x)
         gres = torch.empty_like(x) if has_res else None
         gg, gb = torch.empty(C, dtype=torch.float32, device=x.device), torch.empty(C, dtype=torch.float32, device=x.device)
         ws = _workspace('bn', L.gga_bn_relu_workspace_bytes(rows, C), x.device)
-        from . import dense_conv
         amax = dense_conv.new_amax(x.device)         # max |gx| for the convolution backward that reads gx
+        if partials is not None:
+            check(L.gga_bn_relu_bwd_partials(_p(gy), C, _p(x), _p(gamma), _p(saved), rows, C, int(training), _p(partials),
+                                             int(partials.shape[0]), _p(gx), _p(gg), _p(gb), _p(amax), _p(ws), ws.numel(),
+                                             _stream()), 'gga_bn_relu_bwd_partials')
+            dense_conv.set_amax(gx, amax)
+            return gx, None, gg, gb, None, None, None, None, None, None, None, None, None
         check(L.gga_bn_relu_bwd_ex(_p(gy), C, _p(x), _p(bits), _p(gamma), _p(saved), rows, C, int(relu), int(training), _p(gx),
                                    _p(gres), _p(gg), _p(gb), _p(amax), _p(ws), ws.numel(), _stream()), 'gga_bn_relu_bwd')
         dense_conv.set_amax(gx, amax)
@@ -573,11 +581,14 @@ def bn_act(x, bn, relu=True, residual=None):
     partials = getattr(x, 'bn_partials', None)
     if partials is not None and not (bn.training and partials.dim() == 3 and partials.shape[2] == C):
         partials = None
-    y, amax = _BNAct.apply(x, residual, bn.weight, bn.bias, bn.running_mean, bn.running_var, float(bn.eps),
-                           float(bn.momentum), bool(bn.training), bool(relu), int(rc[0]), int(C), partials)
+    y, amax, saved = _BNAct.apply(x, residual, bn.weight, bn.bias, bn.running_mean, bn.running_var, float(bn.eps),
+                                  float(bn.momentum), bool(bn.training), bool(relu), int(rc[0]), int(C), partials)
+    from . import dense_conv
     if amax.numel():
-        from . import dense_conv
         dense_conv.set_amax(y, amax)
+    if relu and residual is None and x.dim() == 4 and y.requires_grad:
+        # a 3x3 convolution that consumes y reduces this BatchNorm's backward sums in its backward-data epilogue
+        y._gga_bn_src = dense_conv.BnSource(y, [(0, C, x.detach(), bn.weight.detach(), bn.bias.detach(), saved)])
     return y
 
 
@@ -677,16 +688,22 @@ class _BNActCat(torch.autograd.Function):
         ctx.n, ctx.chans, ctx.rows = n, chans, rows
         if amax is None:
             amax = torch.empty(0, dtype=torch.int32, device=dev)
-        ctx.mark_non_differentiable(amax)
-        return out, amax
+        ctx.mark_non_differentiable(amax, *saved_all)
+        return (out, amax, *saved_all)
 
     @staticmethod
-    def backward(ctx, g, _gamax=None):
+    def backward(ctx, g, _gamax=None, *_gsaved):
         from . import dense_conv
         n, chans, rows = ctx.n, ctx.chans, ctx.rows
         t = ctx.saved_tensors
         xs, gammas, saved_all, bits_all = t[:n], t[n:2 * n], t[2 * n:3 * n], t[3 * n:4 * n]
         L = _lib.lib()
+        done = getattr(g, '_gga_bn_bwd', None)       # the convolution that produced g masked it and reduced the sums
+        if done is not None:
+            offs = [sum(chans[:i]) for i in range(n)]
+            given = [done.take(g, saved_all[i].data_ptr(), offs[i], chans[i]) for i in range(n)]
+        else:
+            given = [None] * n
         g = g.contiguous(memory_format=torch.channels_last)
         tot = sum(chans)
         gxs, ggs, gbs = [], [], []
@@ -699,9 +716,14 @@ class _BNActCat(torch.autograd.Function):
             gb = torch.empty(C, dtype=torch.float32, device=x.device)
             ws = _workspace('bn', L.gga_bn_relu_workspace_bytes(rows, C), x.device)
             amax = dense_conv.new_amax(x.device)
-            check(L.gga_bn_relu_bwd_ex(g.data_ptr() + 4 * off, tot, _p(x), _p(bits_all[i]), _p(gammas[i]),
-                                       _p(saved_all[i]), rows, C, 1, 1, _p(gx), None, _p(gg), _p(gb), _p(amax), _p(ws),
-                                       ws.numel(), _stream()), 'gga_bn_relu_bwd_strided')
+            if given[i] is not None:
+                check(L.gga_bn_relu_bwd_partials(g.data_ptr() + 4 * off, tot, _p(x), _p(gammas[i]), _p(saved_all[i]), rows, C, 1,
+                                                 _p(given[i]), int(given[i].shape[0]), _p(gx), _p(gg), _p(gb), _p(amax), _p(ws),
+                                                 ws.numel(), _stream()), 'gga_bn_relu_bwd_partials')
+            else:
+                check(L.gga_bn_relu_bwd_ex(g.data_ptr() + 4 * off, tot, _p(x), _p(bits_all[i]), _p(gammas[i]),
+                                           _p(saved_all[i]), rows, C, 1, 1, _p(gx), None, _p(gg), _p(gb), _p(amax), _p(ws),
+                                           ws.numel(), _stream()), 'gga_bn_relu_bwd_strided')
             dense_conv.set_amax(gx, amax)
             gxs.append(gx), ggs.append(gg), gbs.append(gb)
             off += C
@@ -726,11 +748,17 @@ def bn_relu_cat(xs, bns):
             bn.num_batches_tracked += 1
     n = len(xs)
     cfg = tuple((float(bn.eps), float(bn.momentum), bool(bn.training)) for bn in bns)
-    out, amax = _BNActCat.apply(n, cfg, *xs, *[bn.weight for bn in bns], *[bn.bias for bn in bns],
-                                *[bn.running_mean for bn in bns], *[bn.running_var for bn in bns])
+    out, amax, *saved = _BNActCat.apply(n, cfg, *xs, *[bn.weight for bn in bns], *[bn.bias for bn in bns],
+                                        *[bn.running_mean for bn in bns], *[bn.running_var for bn in bns])
+    from . import dense_conv
     if amax.numel():
-        from . import dense_conv
         dense_conv.set_amax(out, amax)
+    if out.requires_grad and all(bn.training for bn in bns):
+        parts, off = [], 0
+        for x, bn, sv in zip(xs, bns, saved):
+            parts.append((off, int(x.shape[1]), x.detach(), bn.weight.detach(), bn.bias.detach(), sv))
+            off += int(x.shape[1])
+        out._gga_bn_src = dense_conv.BnSource(out, parts)
     return out
 
 
@@ -882,6 +910,7 @@ class _HeadBranches(torch.autograd.Function):
             outs.append(y), saved_all.append(saved), ss_all.append(ss)
         ctx.save_for_backward(x, Y, *w1, *gam, *w2, *saved_all, *ss_all)
         ctx.n, ctx.has_bias, ctx.x_amax = n, [b is not None for b in b2], x_amax
+        ctx.bn_src = dense_conv.bn_source(x, C) if dense_conv.BN_BWD_FUSED else None     # x = relu(bn(shared conv))
         return tuple(outs)
 
     @staticmethod
@@ -914,7 +943,8 @@ class _HeadBranches(torch.autograd.Function):
                                       _stream()), 'gga_head_tail_bwd')
             gw2.append(gw), gb2.append(gb), ggam.append(gg), gbet.append(gbeta)
         wcat = torch.cat([w.detach() for w in w1], dim=0)            # [64n, 64, 3, 3]
-        gx = dense_conv._run(G, wcat, True, False, g_amax)[0] if ctx.needs_input_grad[0] else None
+        w_amax = dense_conv.amax_bits(wcat) if dense_conv.PLANES == 2 else None
+        gx = dense_conv.run_bn_bwd(G, wcat, g_amax, w_amax, ctx.bn_src) if ctx.needs_input_grad[0] else None
         gwcat = dense_conv._wgrad(x, G, wcat, ctx.x_amax if dense_conv.PLANES == 2 else None, g_amax)
         gw1 = list(gwcat.split(C, dim=0))
         none = [None] * n

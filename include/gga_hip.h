@@ -359,6 +359,17 @@ int gga_dense_conv3x3_pack_planes(const float* weight, int64_t stride_co, int64_
 int gga_dense_conv3x3_planes(const float* x, const void* split_weight, int B, int H, int W, int cin, int cout, float* y,
                              int64_t y_pixel_stride, int transposed, double* stats, int planes, const uint32_t* amax_x,
                              const uint32_t* amax_weight, void* stream);
+/* gga_dense_conv3x3_planes run as the backward-data convolution that produces the gradient of z = relu(bn(bn_x)) (the
+ * conv -> BatchNorm -> ReLU -> conv chains of backbones/second.py:46-63): the epilogue masks the tile with the ReLU
+ * (recomputed from bn_x and gamma, beta, mean, invstd of the `cout` channels of this launch, exactly as the forward
+ * pass decided it) before it is stored, and `stats` ([tiles][2][cout] f64, required) receives the per-tile sums of
+ * g and g * xhat instead - the reduce pass of that BatchNorm's backward, which gga_bn_relu_bwd_partials then skips.
+ * bn_x == NULL: exactly gga_dense_conv3x3_planes. */
+int gga_dense_conv3x3_bn_bwd_pays(int B, int H, int W, int cout);   /* 1: the epilogue costs less than the reduce pass (H, W of the tile space) */
+int gga_dense_conv3x3_bn_bwd(const float* x, const void* split_weight, int B, int H, int W, int cin, int cout, float* y,
+                             int64_t y_pixel_stride, int transposed, double* stats, int planes, const uint32_t* amax_x,
+                             const uint32_t* amax_weight, const float* bn_x, int64_t bn_x_pixel_stride, const float* bn_gamma,
+                             const float* bn_beta, const float* bn_mean, const float* bn_invstd, void* stream);
 int gga_dense_wgrad3x3_planes(const float* x, const float* grad_y, int B, int H, int W, int cin, int cout,
                               float* grad_weight, int64_t stride_co, int64_t stride_ci, int64_t stride_ky,
                               int64_t stride_kx, int transposed, int planes, const uint32_t* amax_x,
@@ -459,6 +470,12 @@ int gga_bn_relu_bwd_ex(const float* grad_y, int64_t grad_y_row_stride, const flo
                        const float* gamma, const float* saved, int64_t rows, int channels, int relu, int training, float* grad_x,
                        float* grad_residual, float* grad_gamma, float* grad_beta, uint32_t* amax_grad_x, void* workspace,
                        size_t workspace_bytes, void* stream);
+/* The backward pass whose reduce pass was done by the producer of the gradient (gga_dense_conv3x3_bn_bwd): grad_masked
+ * is already multiplied by the ReLU mask, partials [n_partials][2][channels] f64 hold the sums of g and g * xhat. */
+int gga_bn_relu_bwd_partials(const float* grad_masked, int64_t grad_row_stride, const float* x, const float* gamma,
+                             const float* saved, int64_t rows, int channels, int training, const double* partials,
+                             int n_partials, float* grad_x, float* grad_gamma, float* grad_beta, uint32_t* amax_grad_x,
+                             void* workspace, size_t workspace_bytes, void* stream);
 
 /* Fused GroupNorm (+ ReLU) over a channels-last [B, rows_per_sample, channels] activation (statistics per sample and
  * group of channels / groups channels): replaces the GN + ReLU of the ConvModules in the PGD / FCOS3D head

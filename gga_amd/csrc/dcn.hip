@@ -15,10 +15,10 @@
 //                       the four neighbours of a sampling point are wave-uniform addresses, every lane
 //                       loads its C/64 channels of each as one float4 (1 KB coalesced rows), blends and
 //                       writes the column row - no LDS, no divergence.
-//   dcn_col2im_kernel   backward of the sampling: per (pixel, tap) the lane's channels of grad_col give
-//                       (a) four float4 atomic adds into grad_x (the scatter is data dependent, so it
-//                       cannot be turned into a gather), (b) the partial sums of grad_offset (h, w) and
-//                       grad_mask, closed with wavefront shuffles.
+//   dcn_col2im_kernel   backward of the sampling: per (pixel, tap) the lane's channel of grad_col gives
+//                       (a) four additions into grad_x, accumulated in wave-private LDS windows (the scatter
+//                       is data dependent, so it cannot be turned into a gather), (b) the partial sums of
+//                       grad_offset (h, w) and grad_mask, closed with wavefront shuffles.
 #include "gga_common.h"
 
 struct DcnGeom {
@@ -93,132 +93,171 @@ __global__ __launch_bounds__(256) void dcn_im2col_kernel(const float* __restrict
 }
 
 // Backward of the sampling. The scatter into grad_x is data dependent (a sample's four corners are wherever
-// its offset points), so it has to be an atomic accumulation - but not one global atomic per contribution:
-// a 256-thread workgroup owns an 8 x 8 tile of output pixels and 64 channels at a time and accumulates into
-// an LDS window of the input plane that covers the tile's receptive field plus DCN_R pixels of offset slack
-// (lane = channel: conflict-free LDS atomics); the window is flushed once with coalesced global atomics, and
-// only samples whose corners leave the window go to global memory directly. At 12 x 96 x 312 pixels x 256
-// channels that is 16 k global atomics per tile and chunk instead of 147 k (first version: one thread-level
-// global atomic per contribution, 14 ms per call; this one: see DESIGN.md).
-// grad_offset / grad_mask: per (pixel, tap) sums over the channels, accumulated over the four channel chunks
-// in LDS and written once.
-// Measured in round 2 at 12 x 96 x 312 x 256 (tools_dev/bench_dcn.py, random offsets of std 0.5): 17.4 ms per call, of
-// which 1.7 ms are everything but grad_x (loads, geometry, the three reductions). Three rewrites of the grad_x half left
-// the time where it was: four pairs per wave with float4 lanes (a quarter of the load / geometry / reduction
-// instructions), a 72-float window stride with the channels interleaved (no LDS bank conflicts among a wave's pairs), and
-// writing the windows to a scratch image that a second kernel sums per input pixel (no global atomics at all). What is
-// left in common is the 3.3 G LDS float atomics themselves (64 channels x 4 corners per pair and chunk).
-#define DCN_TH 8
+// its offset points), so it is an accumulation - but LDS float atomics are the wrong tool for it on this part:
+// ds_add_f32 retires about one LANE every three cycles (tools_dev/micro/lds_atomic.hip: 193 cycles per 64-lane add
+// and CU, against 6.4 for a read-add-write by the wave that owns the addresses). The first versions of this kernel
+// accumulated 64-channel windows shared by the workgroup's four waves with such atomics (17.4 ms per call at
+// 12 x 96 x 312 x 256, 15.7 ms of it the atomics; three rewrites that kept them changed nothing).
+// Now every wave OWNS what it accumulates into: a 256-thread workgroup takes a 4 x 8 tile of output pixels, wave w the
+// channels 64 w .. 64 w + 63 of the current group of 256 (lane = channel), and walks all (pixel, tap) pairs of the
+// tile; its private LDS window [window pixel][64] covers the tile's receptive field plus DCN_R pixels of offset slack
+// and is updated with plain loads and stores (pairs in order, so two samples that hit the same cell cannot race). A
+// window is flushed once with coalesced global atomics; only samples whose corners leave it go to memory directly.
+// grad_offset / grad_mask: per (pixel, tap) sums over the channels - wave shuffles, then per-wave partial sums in LDS
+// that are added at the end.
+#define DCN_TH 4
 #define DCN_TW 8
-#define DCN_R 2
-#define DCN_CCH 64
-#define DCN_U 4                  // (pixel, tap) pairs in flight per wave
-#define DCN_MAXWIN 400           // window pixels held in LDS (x 64 channels x 4 B = 100 KB at most; 3x3/s1/d1: 16 x 16)
+#define DCN_R 1
+#define DCN_U 32                 // (pixel, tap) pairs in flight per wave: one wave per SIMD, so the memory latency is covered by depth
+#define DCN_MAXWIN 128           // window pixels (x 256 channels x 4 B = 128 KB at most; 3x3/s1/d1: 9 x 13)
 
-__global__ __launch_bounds__(256) void dcn_col2im_kernel(const float* __restrict__ x, const float* __restrict__ offset,
-                                                        const float* __restrict__ mask, const float* __restrict__ gcol,
-                                                        DcnGeom g, int tiles_x, int tiles_y, int win_h, int win_w,
-                                                        float* __restrict__ gx, float* __restrict__ goffset,
-                                                        float* __restrict__ gmask) {
+// grad_offset / grad_mask: one wavefront per output pixel walks the K taps like dcn_im2col_kernel does - every lane
+// its C/64 channels as float4 - and closes the three sums over the channels with shuffles. No LDS, no atomics.
+template <int VPL>
+__global__ __launch_bounds__(256) void dcn_col2im_sums_kernel(const float* __restrict__ x, const float* __restrict__ offset,
+                                                             const float* __restrict__ mask, const float* __restrict__ gcol,
+                                                             DcnGeom g, float* __restrict__ goffset, float* __restrict__ gmask) {
+    const int lane = threadIdx.x & 63;
+    const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t npix = (int64_t)g.B * g.Ho * g.Wo;
+    if (p >= npix) return;
+    const int64_t plane = (int64_t)g.Ho * g.Wo;
+    const int b = (int)(p / plane);
+    const int rem = (int)(p - (int64_t)b * plane);
+    const int ho = rem / g.Wo, wo = rem - ho * g.Wo;
+    const int K = g.kh * g.kw;
+    const float* xb = x + (int64_t)b * g.H * g.W * g.C;
+    const float* ob = offset + (int64_t)b * 2 * K * plane + rem;
+    const float* mb = mask + (int64_t)b * K * plane + rem;
+    const float* gp = gcol + p * (int64_t)K * g.C;
+    for (int k = 0; k < K; ++k) {
+        const int i = k / g.kw, j = k - i * g.kw;
+        const float off_h = ob[(int64_t)(2 * k) * plane], off_w = ob[(int64_t)(2 * k + 1) * plane];
+        const float m = mb[(int64_t)k * plane];
+        const DcnTap t = dcn_tap(g, ho, wo, i, j, off_h, off_w);
+        float s_val = 0.f, s_dh = 0.f, s_dw = 0.f;
+        if (t.inside) {                                          // wave-uniform
+            const float hh = 1.f - t.lh, hw = 1.f - t.lw;
+            const float w1 = hh * hw, w2 = hh * t.lw, w3 = t.lh * hw, w4 = t.lh * t.lw;
+            const float* r1 = xb + ((int64_t)t.hl * g.W + t.wl) * g.C;
+#pragma unroll
+            for (int e = 0; e < VPL; ++e) {
+                const int c = (lane + 64 * e) * 4;
+                const float4 gc = f4_ld(gp + (int64_t)k * g.C + c);
+                const float4 a1 = t.v1 ? f4_ld(r1 + c) : f4_zero();
+                const float4 a2 = t.v2 ? f4_ld(r1 + g.C + c) : f4_zero();
+                const float4 a3 = t.v3 ? f4_ld(r1 + (int64_t)g.W * g.C + c) : f4_zero();
+                const float4 a4 = t.v4 ? f4_ld(r1 + (int64_t)(g.W + 1) * g.C + c) : f4_zero();
+                s_val += f4_dot(gc, f4_fma(w1, a1, f4_fma(w2, a2, f4_fma(w3, a3, f4_fma(w4, a4, f4_zero())))));
+                const float4 d31 = make_float4(a3.x - a1.x, a3.y - a1.y, a3.z - a1.z, a3.w - a1.w);
+                const float4 d42 = make_float4(a4.x - a2.x, a4.y - a2.y, a4.z - a2.z, a4.w - a2.w);
+                const float4 d21 = make_float4(a2.x - a1.x, a2.y - a1.y, a2.z - a1.z, a2.w - a1.w);
+                const float4 d43 = make_float4(a4.x - a3.x, a4.y - a3.y, a4.z - a3.z, a4.w - a3.w);
+                s_dh += f4_dot(gc, f4_fma(hw, d31, f4_fma(t.lw, d42, f4_zero())));
+                s_dw += f4_dot(gc, f4_fma(hh, d21, f4_fma(t.lh, d43, f4_zero())));
+            }
+            s_val = wave_sum(s_val); s_dh = wave_sum(s_dh); s_dw = wave_sum(s_dw);
+        }
+        if (lane == 0) {
+            gmask[((int64_t)b * K + k) * plane + rem] = s_val;
+            goffset[((int64_t)b * 2 * K + 2 * k) * plane + rem] = s_dh * m;
+            goffset[((int64_t)b * 2 * K + 2 * k + 1) * plane + rem] = s_dw * m;
+        }
+    }
+}
+
+// grad_x (see above): wave-private LDS windows, plain read-add-write. The geometry of a (pixel, tap) pair - window
+// cell, the four bilinear weights times the mask, the row of grad_col - is the same for every channel: the workgroup
+// computes it once into LDS, and the waves' loops over the pairs are a record read, one global load and the window
+// update (with the geometry inside the loop a wave spent ~1700 cycles per pair, alone on its SIMD: 11.9 ms per call).
+struct DcnPair {
+    int row;            // (b * Ho * Wo + pixel) * K + tap: row of grad_col, -1: no contribution
+    int cell;           // window cell of the low corner, -1: the corners leave the window (global atomics)
+    float w1, w2, w3, w4;   // bilinear weight * mask, 0 for a corner outside the image
+    int hl, wl;         // low corner in the input plane
+};
+
+__global__ __launch_bounds__(256, 1) void dcn_col2im_kernel(const float* __restrict__ offset, const float* __restrict__ mask,
+                                                           const float* __restrict__ gcol, DcnGeom g, int tiles_x, int tiles_y,
+                                                           int win_h, int win_w, float* __restrict__ gx) {
     extern __shared__ __attribute__((aligned(16))) float dcn_lds[];
     const int K = g.kh * g.kw, NP = DCN_TH * DCN_TW * K;       // (pixel, tap) pairs of the tile
-    float* win = dcn_lds;                                       // [win_h * win_w][64]
-    float* sums = dcn_lds + (size_t)win_h * win_w * DCN_CCH;    // [NP][3]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wpx = win_h * win_w;
+    float* win = dcn_lds + (size_t)wave * wpx * 64;             // this wave's window [wpx][64]
+    DcnPair* pairs = reinterpret_cast<DcnPair*>(dcn_lds + (size_t)4 * wpx * 64);
     const int b = blockIdx.x / (tiles_x * tiles_y);
     const int t = blockIdx.x - b * (tiles_x * tiles_y);
     const int ty0 = (t / tiles_x) * DCN_TH, tx0 = (t % tiles_x) * DCN_TW;
     const int wy0 = ty0 * g.sh - g.ph - DCN_R, wx0 = tx0 * g.sw - g.pw - DCN_R;    // window origin in the input plane
     const int64_t plane = (int64_t)g.Ho * g.Wo;
-    const float* xb = x + (int64_t)b * g.H * g.W * g.C;
-    float* gxb = gx ? gx + (int64_t)b * g.H * g.W * g.C : nullptr;
-    float* om = sums + NP * 3;                                  // [NP][3]: offset_h, offset_w, mask of every pair (-inf offset: no pair)
+    float* gxb = gx + (int64_t)b * g.H * g.W * g.C;
     for (int pr = tid; pr < NP; pr += 256) {
         const int pl = pr / K, k = pr - pl * K;
         const int ho = ty0 + pl / DCN_TW, wo = tx0 + pl % DCN_TW;
-        const bool ok = ho < g.Ho && wo < g.Wo;
-        const int rem = ok ? ho * g.Wo + wo : 0;
-        sums[pr * 3] = sums[pr * 3 + 1] = sums[pr * 3 + 2] = 0.f;
-        om[pr * 3] = ok ? offset[((int64_t)b * 2 * K + 2 * k) * plane + rem] : -1e30f;       // far outside: tap.inside = false
-        om[pr * 3 + 1] = ok ? offset[((int64_t)b * 2 * K + 2 * k + 1) * plane + rem] : -1e30f;
-        om[pr * 3 + 2] = ok ? mask[((int64_t)b * K + k) * plane + rem] : 0.f;
-    }
-    for (int c0 = 0; c0 < g.C; c0 += DCN_CCH) {
-        for (int i = tid; i < win_h * win_w * DCN_CCH; i += 256) win[i] = 0.f;
-        __syncthreads();
-        const int c = c0 + lane;
-        // the gathers are a dependent chain (offset -> corner addresses -> loads): four pairs are in flight per wave
-        for (int pr0 = wave; pr0 < NP; pr0 += 4 * DCN_U) {
-            DcnTap tp[DCN_U];
-            float gc[DCN_U], a1[DCN_U], a2[DCN_U], a3[DCN_U], a4[DCN_U], m[DCN_U];
-            int64_t o1[DCN_U];
-#pragma unroll
-            for (int u = 0; u < DCN_U; ++u) {
-                const int pr = pr0 + 4 * u;
-                const bool live = pr < NP;
-                const int prc = live ? pr : 0;
-                const int pl = prc / K, k = prc - pl * K;
-                const int ho = ty0 + pl / DCN_TW, wo = tx0 + pl % DCN_TW;
-                tp[u] = dcn_tap(g, ho, wo, k / g.kw, k % g.kw, live ? om[prc * 3] : -1e30f, live ? om[prc * 3 + 1] : -1e30f);
-                m[u] = om[prc * 3 + 2];
-                const int rem = tp[u].inside ? ho * g.Wo + wo : 0;
-                gc[u] = tp[u].inside ? gcol[((int64_t)b * plane + rem) * ((int64_t)K * g.C) + (int64_t)k * g.C + c] : 0.f;
-                o1[u] = ((int64_t)tp[u].hl * g.W + tp[u].wl) * g.C + c;
-                a1[u] = tp[u].v1 ? xb[o1[u]] : 0.f;
-                a2[u] = tp[u].v2 ? xb[o1[u] + g.C] : 0.f;
-                a3[u] = tp[u].v3 ? xb[o1[u] + (int64_t)g.W * g.C] : 0.f;
-                a4[u] = tp[u].v4 ? xb[o1[u] + (int64_t)(g.W + 1) * g.C] : 0.f;
+        DcnPair q;
+        q.row = -1; q.cell = -1; q.w1 = q.w2 = q.w3 = q.w4 = 0.f; q.hl = q.wl = 0;
+        if (ho < g.Ho && wo < g.Wo) {
+            const int rem = ho * g.Wo + wo;
+            const float off_h = offset[((int64_t)b * 2 * K + 2 * k) * plane + rem];
+            const float off_w = offset[((int64_t)b * 2 * K + 2 * k + 1) * plane + rem];
+            const float m = mask[((int64_t)b * K + k) * plane + rem];
+            const DcnTap tp = dcn_tap(g, ho, wo, k / g.kw, k % g.kw, off_h, off_w);
+            if (tp.inside) {
+                const float hh = 1.f - tp.lh, hw = 1.f - tp.lw;
+                q.row = (int)(((int64_t)b * plane + rem) * K + k);
+                q.w1 = tp.v1 ? hh * hw * m : 0.f; q.w2 = tp.v2 ? hh * tp.lw * m : 0.f;
+                q.w3 = tp.v3 ? tp.lh * hw * m : 0.f; q.w4 = tp.v4 ? tp.lh * tp.lw * m : 0.f;
+                q.hl = tp.hl; q.wl = tp.wl;
+                const int ly = tp.hl - wy0, lx = tp.wl - wx0;                   // window coordinates of the low corner
+                if (ly >= 0 && lx >= 0 && ly + 1 < win_h && lx + 1 < win_w) q.cell = ly * win_w + lx;
             }
+        }
+        pairs[pr] = q;
+    }
+    __syncthreads();
+    for (int c0 = 0; c0 < g.C; c0 += 256) {
+        const int c = c0 + wave * 64 + lane;
+        for (int i = 0; i < wpx; ++i) win[i * 64 + lane] = 0.f;
+        for (int pr0 = 0; pr0 < NP; pr0 += DCN_U) {
+            // phase 1: request the gradient rows of DCN_U pairs; phase 2: the pairs in order (two samples that hit the same
+            // cell must not race)
+            float gc[DCN_U];
 #pragma unroll
             for (int u = 0; u < DCN_U; ++u) {
-                if (!tp[u].inside) continue;                     // wave-uniform
-                const int pr = pr0 + 4 * u;
-                const float hh = 1.f - tp[u].lh, hw = 1.f - tp[u].lw;
-                const float w1 = hh * hw, w2 = hh * tp[u].lw, w3 = tp[u].lh * hw, w4 = tp[u].lh * tp[u].lw;
-                float s_val = gc[u] * (w1 * a1[u] + w2 * a2[u] + w3 * a3[u] + w4 * a4[u]);
-                float s_dh = gc[u] * (hw * (a3[u] - a1[u]) + tp[u].lw * (a4[u] - a2[u]));
-                float s_dw = gc[u] * (hh * (a2[u] - a1[u]) + tp[u].lh * (a4[u] - a3[u]));
-                s_val = wave_sum(s_val); s_dh = wave_sum(s_dh); s_dw = wave_sum(s_dw);
-                if (lane == 0) { sums[pr * 3] += s_val; sums[pr * 3 + 1] += s_dh * m[u]; sums[pr * 3 + 2] += s_dw * m[u]; }   // one wave per pair
-                if (gxb) {
-                    const float gm = gc[u] * m[u];
-                    const int ly = tp[u].hl - wy0, lx = tp[u].wl - wx0;             // window coordinates of the low corner
-                    const bool in_win = ly >= 0 && lx >= 0 && ly + 1 < win_h && lx + 1 < win_w;
-                    if (in_win) {
-                        float* wp = win + ((size_t)ly * win_w + lx) * DCN_CCH + lane;
-                        if (tp[u].v1) atomicAdd(wp, w1 * gm);
-                        if (tp[u].v2) atomicAdd(wp + DCN_CCH, w2 * gm);
-                        if (tp[u].v3) atomicAdd(wp + (size_t)win_w * DCN_CCH, w3 * gm);
-                        if (tp[u].v4) atomicAdd(wp + (size_t)(win_w + 1) * DCN_CCH, w4 * gm);
-                    } else {                                                     // far offset: straight to memory
-                        if (tp[u].v1) atomicAdd(gxb + o1[u], w1 * gm);
-                        if (tp[u].v2) atomicAdd(gxb + o1[u] + g.C, w2 * gm);
-                        if (tp[u].v3) atomicAdd(gxb + o1[u] + (int64_t)g.W * g.C, w3 * gm);
-                        if (tp[u].v4) atomicAdd(gxb + o1[u] + (int64_t)(g.W + 1) * g.C, w4 * gm);
-                    }
+                const int row = pr0 + u < NP ? pairs[pr0 + u].row : -1;
+                gc[u] = row >= 0 ? gcol[(int64_t)row * g.C + c] : 0.f;
+            }
+            // all loads are requested here (otherwise the compiler sinks every load next to its use)
+#pragma unroll
+            for (int u = 0; u < DCN_U; ++u) asm volatile("" : "+v"(gc[u]));
+#pragma unroll
+            for (int u = 0; u < DCN_U; ++u) {
+                if (pr0 + u >= NP) break;
+                const DcnPair q = pairs[pr0 + u];
+                if (q.row < 0) continue;                                         // wave-uniform
+                if (q.cell >= 0) {                                               // mine alone: load, add, store
+                    float* wp = win + (size_t)q.cell * 64 + lane;
+                    const float q1 = wp[0], q2 = wp[64], q3 = wp[(size_t)win_w * 64], q4 = wp[(size_t)(win_w + 1) * 64];
+                    wp[0] = fmaf(q.w1, gc[u], q1);
+                    wp[64] = fmaf(q.w2, gc[u], q2);
+                    wp[(size_t)win_w * 64] = fmaf(q.w3, gc[u], q3);
+                    wp[(size_t)(win_w + 1) * 64] = fmaf(q.w4, gc[u], q4);
+                } else {                                                         // far offset: straight to memory
+                    float* o1 = gxb + ((int64_t)q.hl * g.W + q.wl) * g.C + c;
+                    if (q.w1 != 0.f) atomicAdd(o1, q.w1 * gc[u]);
+                    if (q.w2 != 0.f) atomicAdd(o1 + g.C, q.w2 * gc[u]);
+                    if (q.w3 != 0.f) atomicAdd(o1 + (int64_t)g.W * g.C, q.w3 * gc[u]);
+                    if (q.w4 != 0.f) atomicAdd(o1 + (int64_t)(g.W + 1) * g.C, q.w4 * gc[u]);
                 }
             }
         }
-        __syncthreads();
-        if (gxb) {      // flush the window: row of 64 channels per wave access
-            for (int i = tid; i < win_h * win_w * DCN_CCH; i += 256) {
-                const float v = win[i];
-                if (v == 0.f) continue;
-                const int px = i / DCN_CCH, c = i - px * DCN_CCH;
-                const int iy = wy0 + px / win_w, ix = wx0 + px % win_w;
-                if (iy >= 0 && iy < g.H && ix >= 0 && ix < g.W) atomicAdd(gxb + ((int64_t)iy * g.W + ix) * g.C + c0 + c, v);
-            }
+        // flush my window: one 256-byte row of atomics per window pixel
+        for (int px = 0; px < wpx; ++px) {
+            const float v = win[px * 64 + lane];
+            const int iy = wy0 + px / win_w, ix = wx0 + px % win_w;
+            if (v != 0.f && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W) atomicAdd(gxb + ((int64_t)iy * g.W + ix) * g.C + c, v);
         }
-        __syncthreads();
-    }
-    for (int pr = tid; pr < NP; pr += 256) {
-        const int pl = pr / K, k = pr - pl * K;
-        const int ho = ty0 + pl / DCN_TW, wo = tx0 + pl % DCN_TW;
-        if (ho >= g.Ho || wo >= g.Wo) continue;
-        const int rem = ho * g.Wo + wo;
-        gmask[((int64_t)b * K + k) * plane + rem] = sums[pr * 3];
-        goffset[((int64_t)b * 2 * K + 2 * k) * plane + rem] = sums[pr * 3 + 1];
-        goffset[((int64_t)b * 2 * K + 2 * k + 1) * plane + rem] = sums[pr * 3 + 2];
     }
 }
 
@@ -259,20 +298,34 @@ extern "C" int gga_dcn_col2im(const float* x, const float* offset, const float* 
                               int dil_w, float* grad_x, float* grad_offset, float* grad_mask, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     GGA_REQUIRE(x && offset && mask && grad_col && grad_offset && grad_mask, "gga_dcn_col2im: null pointer argument");
+    GGA_REQUIRE((int64_t)B * H * W * kh * kw < 2147483647ll, "gga_dcn_col2im: too many (pixel, tap) pairs");
     DcnGeom g;
     if (int rc = dcn_geom("gga_dcn_col2im", B, H, W, C, kh, kw, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w, &g)) return rc;
-    if (grad_x) GGA_CHECK_HIP(hipMemsetAsync(grad_x, 0, (size_t)B * H * W * C * sizeof(float), stream), "dcn memset");
+    const int64_t npix = (int64_t)B * g.Ho * g.Wo;
+    const dim3 sgrid((unsigned)((npix + 3) / 4)), block(256);
+    switch (C / 256) {
+        case 1: hipLaunchKernelGGL(dcn_col2im_sums_kernel<1>, sgrid, block, 0, stream, x, offset, mask, grad_col, g, grad_offset, grad_mask); break;
+        case 2: hipLaunchKernelGGL(dcn_col2im_sums_kernel<2>, sgrid, block, 0, stream, x, offset, mask, grad_col, g, grad_offset, grad_mask); break;
+        case 3: hipLaunchKernelGGL(dcn_col2im_sums_kernel<3>, sgrid, block, 0, stream, x, offset, mask, grad_col, g, grad_offset, grad_mask); break;
+        default: hipLaunchKernelGGL(dcn_col2im_sums_kernel<4>, sgrid, block, 0, stream, x, offset, mask, grad_col, g, grad_offset, grad_mask); break;
+    }
+    GGA_CHECK_LAUNCH("dcn_col2im_sums_kernel");
+    if (!grad_x) return GGA_OK;
+    GGA_CHECK_HIP(hipMemsetAsync(grad_x, 0, (size_t)B * H * W * C * sizeof(float), stream), "dcn memset");
     const int tiles_x = (g.Wo + DCN_TW - 1) / DCN_TW, tiles_y = (g.Ho + DCN_TH - 1) / DCN_TH;
     // LDS window: receptive field of the tile + offset slack + the bilinear (+1) corner
     int win_h = (DCN_TH - 1) * stride_h + (kh - 1) * dil_h + 2 + 2 * DCN_R;
     int win_w = (DCN_TW - 1) * stride_w + (kw - 1) * dil_w + 2 + 2 * DCN_R;
-    while (win_h * win_w > DCN_MAXWIN) { if (win_h > 4) win_h -= 1; if (win_w > 4 && win_h * win_w > DCN_MAXWIN) win_w -= 1; }   // smaller window: more direct atomics, same result
-    const size_t lds = ((size_t)win_h * win_w * DCN_CCH + (size_t)DCN_TH * DCN_TW * kh * kw * 6) * sizeof(float);
-    GGA_REQUIRE(lds <= 160 * 1024 && kh * kw <= 49, "gga_dcn_col2im: kernel %dx%d too large", kh, kw);
+    const size_t pair_bytes = (size_t)DCN_TH * DCN_TW * kh * kw * sizeof(DcnPair);          // the tile's (pixel, tap) records
+    GGA_REQUIRE(pair_bytes + 16 * 1024 <= 160 * 1024, "gga_dcn_col2im: kernel %dx%d too large", kh, kw);
+    int max_win = (int)((160 * 1024 - pair_bytes) / 1024);                                 // 1 KB per window pixel (256 channels)
+    if (max_win > DCN_MAXWIN) max_win = DCN_MAXWIN;
+    while (win_h * win_w > max_win) { if (win_h > 4) win_h -= 1; if (win_w > 4 && win_h * win_w > max_win) win_w -= 1; }   // smaller window: more direct atomics, same result
+    const size_t lds = (size_t)win_h * win_w * 1024 + pair_bytes;
     GGA_CHECK_HIP(hipFuncSetAttribute((const void*)dcn_col2im_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
                   "dcn col2im LDS size");
-    hipLaunchKernelGGL(dcn_col2im_kernel, dim3((unsigned)(B * tiles_x * tiles_y)), dim3(256), lds, stream, x, offset, mask, grad_col, g,
-                       tiles_x, tiles_y, win_h, win_w, grad_x, grad_offset, grad_mask);
+    hipLaunchKernelGGL(dcn_col2im_kernel, dim3((unsigned)(B * tiles_x * tiles_y)), block, lds, stream, offset, mask, grad_col, g,
+                       tiles_x, tiles_y, win_h, win_w, grad_x);
     GGA_CHECK_LAUNCH("dcn_col2im_kernel");
     return GGA_OK;
 }

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void dcn_im2col_kernel(const float* __restrict
 #define DCN_TH 4
 #define DCN_TW 8
 #define DCN_R 1
-#define DCN_U 32                 // (pixel, tap) pairs in flight per wave: one wave per SIMD, so the memory latency is covered by depth
+#define DCN_U 16                 // (pixel, tap) pairs in flight per wave: one wave per SIMD, so the memory latency is covered by depth
 #define DCN_MAXWIN 128           // window pixels (x 256 channels x 4 B = 128 KB at most; 3x3/s1/d1: 9 x 13)
 
 // grad_offset / grad_mask: one wavefront per output pixel walks the K taps like dcn_im2col_kernel does - every lane
@@ -223,32 +223,32 @@ __global__ __launch_bounds__(256, 1) void dcn_col2im_kernel(const float* __restr
             // phase 1: request the gradient rows of DCN_U pairs; phase 2: the pairs in order (two samples that hit the same
             // cell must not race)
             float gc[DCN_U];
-#pragma unroll
+            DcnPair q[DCN_U];                                                    // records too: their LDS reads would otherwise wait
+#pragma unroll                                                                   // behind the window stores of the pair before
             for (int u = 0; u < DCN_U; ++u) {
-                const int row = pr0 + u < NP ? pairs[pr0 + u].row : -1;
-                gc[u] = row >= 0 ? gcol[(int64_t)row * g.C + c] : 0.f;
+                q[u] = pairs[pr0 + u < NP ? pr0 + u : 0];
+                if (pr0 + u >= NP) q[u].row = -1;
+                gc[u] = q[u].row >= 0 ? gcol[(int64_t)q[u].row * g.C + c] : 0.f;
             }
             // all loads are requested here (otherwise the compiler sinks every load next to its use)
 #pragma unroll
             for (int u = 0; u < DCN_U; ++u) asm volatile("" : "+v"(gc[u]));
 #pragma unroll
             for (int u = 0; u < DCN_U; ++u) {
-                if (pr0 + u >= NP) break;
-                const DcnPair q = pairs[pr0 + u];
-                if (q.row < 0) continue;                                         // wave-uniform
-                if (q.cell >= 0) {                                               // mine alone: load, add, store
-                    float* wp = win + (size_t)q.cell * 64 + lane;
+                if (q[u].row < 0) continue;                                      // wave-uniform
+                if (q[u].cell >= 0) {                                            // mine alone: load, add, store
+                    float* wp = win + (size_t)q[u].cell * 64 + lane;
                     const float q1 = wp[0], q2 = wp[64], q3 = wp[(size_t)win_w * 64], q4 = wp[(size_t)(win_w + 1) * 64];
-                    wp[0] = fmaf(q.w1, gc[u], q1);
-                    wp[64] = fmaf(q.w2, gc[u], q2);
-                    wp[(size_t)win_w * 64] = fmaf(q.w3, gc[u], q3);
-                    wp[(size_t)(win_w + 1) * 64] = fmaf(q.w4, gc[u], q4);
+                    wp[0] = fmaf(q[u].w1, gc[u], q1);
+                    wp[64] = fmaf(q[u].w2, gc[u], q2);
+                    wp[(size_t)win_w * 64] = fmaf(q[u].w3, gc[u], q3);
+                    wp[(size_t)(win_w + 1) * 64] = fmaf(q[u].w4, gc[u], q4);
                 } else {                                                         // far offset: straight to memory
-                    float* o1 = gxb + ((int64_t)q.hl * g.W + q.wl) * g.C + c;
-                    if (q.w1 != 0.f) atomicAdd(o1, q.w1 * gc[u]);
-                    if (q.w2 != 0.f) atomicAdd(o1 + g.C, q.w2 * gc[u]);
-                    if (q.w3 != 0.f) atomicAdd(o1 + (int64_t)g.W * g.C, q.w3 * gc[u]);
-                    if (q.w4 != 0.f) atomicAdd(o1 + (int64_t)(g.W + 1) * g.C, q.w4 * gc[u]);
+                    float* o1 = gxb + ((int64_t)q[u].hl * g.W + q[u].wl) * g.C + c;
+                    if (q[u].w1 != 0.f) atomicAdd(o1, q[u].w1 * gc[u]);
+                    if (q[u].w2 != 0.f) atomicAdd(o1 + g.C, q[u].w2 * gc[u]);
+                    if (q[u].w3 != 0.f) atomicAdd(o1 + (int64_t)g.W * g.C, q[u].w3 * gc[u]);
+                    if (q[u].w4 != 0.f) atomicAdd(o1 + (int64_t)(g.W + 1) * g.C, q[u].w4 * gc[u]);
                 }
             }
         }

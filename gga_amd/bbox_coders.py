@@ -9,6 +9,7 @@ gather of the regression channels at the winning cells.
 """
 import torch
 
+from . import functional as F
 from .registry import BBOX_CODERS
 
 
@@ -56,7 +57,7 @@ class CenterPointBBoxCoder:
         if vel is not None:
             parts.append(self._at(vel, cell))
         boxes = torch.cat(parts, dim=2)
-        lim = torch.tensor(self.post_center_range, device=heat.device)
+        lim = F.const_tensor(list(self.post_center_range), heat.device)
         keep = (boxes[..., :3] >= lim[:3]).all(2) & (boxes[..., :3] <= lim[3:]).all(2)
         if self.score_threshold is not None:
             keep &= score > self.score_threshold
@@ -98,13 +99,13 @@ class FCOS3DBBoxCoder:
         else:
             assert len(self.base_depths) == cls_score.shape[1]
             indices = cls_score.max(dim=1)[1]
-            priors = cls_score.new_tensor(self.base_depths)[indices, :].permute(0, 3, 1, 2)
+            priors = F.const_tensor(self.base_depths, cls_score.device, cls_score.dtype)[indices, :].permute(0, 3, 1, 2)
             bbox[:, 2] = priors[:, 0] + bbox.clone()[:, 2] * priors[:, 1]
         bbox[:, 3:6] = bbox[:, 3:6].exp()
         if self.base_dims is not None:
             assert len(self.base_dims) == cls_score.shape[1]
             indices = cls_score.max(dim=1)[1]
-            size_priors = cls_score.new_tensor(self.base_dims)[indices, :].permute(0, 3, 1, 2)
+            size_priors = F.const_tensor(self.base_dims, cls_score.device, cls_score.dtype)[indices, :].permute(0, 3, 1, 2)
             bbox[:, 3:6] = size_priors * bbox.clone()[:, 3:6]
         assert self.norm_on_bbox is True
         if not training:
@@ -145,7 +146,7 @@ class PGDBBoxCoder(FCOS3DBBoxCoder):
         return bbox
 
     def decode_prob_depth(self, depth_cls_preds, depth_range, depth_unit, division, num_depth_cls):
-        split = depth_cls_preds.new_tensor(list(range(num_depth_cls))).reshape([1, -1])
+        split = F.const_tensor(list(range(num_depth_cls)), depth_cls_preds.device, depth_cls_preds.dtype).reshape([1, -1])
         prob = TF.softmax(depth_cls_preds.clone(), dim=-1)
         if division == 'uniform':
             return (prob * (depth_unit * split)).sum(dim=-1)

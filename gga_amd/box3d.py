@@ -3,8 +3,11 @@ post-processing touch (mmdet3d/core/bbox/structures/base_box3d.py, lidar_box3d.p
 ``(x, y, z_bottom, dx, dy, dz, yaw)``, ``bev``, centres, ``overlaps``, ``points_in_boxes_*``."""
 import math
 
+import numpy as np
+
 import torch
 
+from . import functional as F
 from . import ops
 
 
@@ -137,11 +140,18 @@ def rotation_about_y(points, angles):
     return torch.einsum('aij,jka->aik', points, rot_t)
 
 
+def _matrix(m, like):
+    """A small host matrix (camera intrinsics of a sample) as a device tensor of ``like``'s type, cached by value."""
+    if isinstance(m, torch.Tensor):
+        return m.to(device=like.device, dtype=like.dtype)
+    return F.const_tensor(np.ascontiguousarray(m), like.device, like.dtype)
+
+
 def points_cam2img(points_3d, proj_mat, with_depth=False):
     """core/bbox/structures/utils.py:173-214."""
     points_shape = list(points_3d.shape)
     points_shape[-1] = 1
-    proj_mat = torch.as_tensor(proj_mat, dtype=points_3d.dtype, device=points_3d.device)
+    proj_mat = _matrix(proj_mat, points_3d)
     d1, d2 = proj_mat.shape[:2]
     if d1 == 3:
         ex = torch.eye(4, device=proj_mat.device, dtype=proj_mat.dtype)
@@ -155,7 +165,7 @@ def points_cam2img(points_3d, proj_mat, with_depth=False):
 
 def points_img2cam(points, cam2img):
     """core/bbox/structures/utils.py:217-248: (u, v, depth) -> camera xyz."""
-    cam2img = torch.as_tensor(cam2img, dtype=points.dtype, device=points.device)
+    cam2img = _matrix(cam2img, points)
     xys, depths = points[:, :2], points[:, 2].view(-1, 1)
     un = torch.cat([xys * depths, depths], dim=1)
     pad = torch.eye(4, dtype=xys.dtype, device=xys.device)
@@ -204,9 +214,8 @@ class CameraInstance3DBoxes:
         if self.tensor.numel() == 0:
             return torch.empty([0, 8, 3], device=self.tensor.device)
         dims = self.dims
-        idx = torch.tensor([[0, 0, 0], [0, 0, 1], [0, 1, 1], [0, 1, 0], [1, 0, 0], [1, 0, 1], [1, 1, 1], [1, 1, 0]],
-                           device=dims.device, dtype=dims.dtype)       # unravel_index order [0,1,3,2,4,5,7,6]
-        corners_norm = idx - dims.new_tensor([0.5, 1, 0.5])
+        idx = [[0, 0, 0], [0, 0, 1], [0, 1, 1], [0, 1, 0], [1, 0, 0], [1, 0, 1], [1, 1, 1], [1, 1, 0]]     # unravel_index order [0,1,3,2,4,5,7,6]
+        corners_norm = F.const_tensor([[a - 0.5, b - 1.0, c - 0.5] for a, b, c in idx], dims.device, dims.dtype)
         corners = dims.view([-1, 1, 3]) * corners_norm.reshape([1, 8, 3])
         corners = rotation_about_y(corners, self.tensor[:, 6])
         corners += self.tensor[:, :3].view(-1, 1, 3)

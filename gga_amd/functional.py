@@ -135,6 +135,22 @@ def upload(host, device):
     return t.to(dev, non_blocking=True)
 
 
+_CONSTS = {}
+
+
+def const_tensor(data, device, dtype=torch.float32):
+    """Device tensor of a small host constant (nested lists / tuples / a numpy array), uploaded once per (value, device,
+    dtype): ``x.new_tensor(list)`` inside the step is a copy from pageable memory, i.e. a host wait for everything queued
+    so far (91 of them per PGD step kept the host 40 ms behind). The result is shared: do not write into it."""
+    key = (data.tobytes() + str(data.shape).encode() if isinstance(data, np.ndarray) else repr(data), str(device), dtype)
+    t = _CONSTS.get(key)
+    if t is None:
+        if len(_CONSTS) > 4096:
+            _CONSTS.clear()
+        t = _CONSTS[key] = upload(torch.as_tensor(np.asarray(data), dtype=dtype), device)
+    return t
+
+
 def _cat_rows(parts, ndim, dev, dtype=torch.float32):
     parts = [torch.as_tensor(p, dtype=dtype).reshape(-1, ndim) for p in parts]
     offs = np.zeros(len(parts) + 1, np.int64)

@@ -452,7 +452,7 @@ class PGDHead(FCOSMono3DHead):
                 continue
             view = views[idx]
             cam2img = torch.eye(4, dtype=pos_preds.dtype, device=pos_preds.device)
-            cam2img[:view.shape[0], :view.shape[1]] = pos_preds.new_tensor(view)
+            cam2img[:view.shape[0], :view.shape[1]] = F.const_tensor(np.ascontiguousarray(view), pos_preds.device, pos_preds.dtype)
             p, t = pos_preds[mask], pos_targets[mask]
             centers2d_preds, centers2d_targets = p[:, :2].clone(), t[:, :2].clone()
             t3 = points_img2cam(t[:, :3], view)
@@ -550,7 +550,7 @@ class PGDHead(FCOSMono3DHead):
         centers2d, bboxes, dir_scores = torch.cat(acc['c2d']), torch.cat(acc['box']), torch.cat(acc['dir'])
         bboxes2d = torch.cat(acc['b2d']) if self.pred_bbox2d else None
         cam2img = torch.eye(4, dtype=centers2d.dtype, device=centers2d.device)
-        cam2img[:view.shape[0], :view.shape[1]] = centers2d.new_tensor(view)
+        cam2img[:view.shape[0], :view.shape[1]] = F.const_tensor(np.ascontiguousarray(view), centers2d.device, centers2d.dtype)
         bboxes = self.bbox_coder.decode_yaw(bboxes, centers2d, dir_scores, self.dir_offset, cam2img)
         box_type = input_meta['box_type_3d']
         for_nms = ops.xywhr2xyxyr(box_type(bboxes, box_dim=code, origin=(0.5, 0.5, 0.5)).bev)
@@ -603,7 +603,7 @@ class PGDHead(FCOSMono3DHead):
             code_weight = self.train_cfg.get('code_weight', None)
             if code_weight:
                 assert len(code_weight) == sum(self.group_reg_dims)
-                bbox_weights = bbox_weights * bbox_weights.new_tensor(code_weight)
+                bbox_weights = bbox_weights * F.const_tensor(list(code_weight), bbox_weights.device, bbox_weights.dtype)
             if self.diff_rad_by_sin:
                 pos_bbox_preds, pos_bbox_targets_3d = self.add_sin_difference(pos_bbox_preds, pos_bbox_targets_3d)
             avg = equal_weights.sum()

@@ -31,9 +31,8 @@ class LiDARInstance3DBoxes:
             self.box_dim, self.with_yaw = box_dim, with_yaw
         self.tensor = tensor.clone()
         if origin != (0.5, 0.5, 0):
-            dst = self.tensor.new_tensor((0.5, 0.5, 0))
-            src = self.tensor.new_tensor(origin)
-            self.tensor[:, :3] += self.tensor[:, 3:6] * (dst - src)
+            shift = F.const_tensor([0.5 - origin[0], 0.5 - origin[1], 0.0 - origin[2]], self.tensor.device, self.tensor.dtype)
+            self.tensor[:, :3] += self.tensor[:, 3:6] * shift
 
     volume = property(lambda self: self.tensor[:, 3] * self.tensor[:, 4] * self.tensor[:, 5])
     dims = property(lambda self: self.tensor[:, 3:6])
@@ -165,12 +164,20 @@ def points_cam2img(points_3d, proj_mat, with_depth=False):
 
 def points_img2cam(points, cam2img):
     """core/bbox/structures/utils.py:217-248: (u, v, depth) -> camera xyz."""
-    cam2img = _matrix(cam2img, points)
     xys, depths = points[:, :2], points[:, 2].view(-1, 1)
     un = torch.cat([xys * depths, depths], dim=1)
-    pad = torch.eye(4, dtype=xys.dtype, device=xys.device)
-    pad[:cam2img.shape[0], :cam2img.shape[1]] = cam2img
-    inv = torch.inverse(pad).transpose(0, 1)
+    if isinstance(cam2img, torch.Tensor):
+        cam2img = cam2img.to(device=points.device, dtype=points.dtype)
+        pad = torch.eye(4, dtype=xys.dtype, device=xys.device)
+        pad[:cam2img.shape[0], :cam2img.shape[1]] = cam2img
+        inv = torch.inverse(pad).transpose(0, 1)
+    else:
+        # a host matrix (the sample's intrinsics): inverted on the host and cached - torch.inverse on the device waits
+        # for the device on every call (the library's LU reports its status to the host), 24 times per PGD step
+        m = np.asarray(cam2img, dtype=np.float64)
+        pad = np.eye(4)
+        pad[:m.shape[0], :m.shape[1]] = m
+        inv = F.const_tensor(np.ascontiguousarray(np.linalg.inv(pad).T.astype(np.float32)), points.device, points.dtype)
     homo = torch.cat([un, xys.new_ones((un.shape[0], 1))], dim=1)
     return torch.mm(homo, inv)[:, :3]
 
@@ -189,8 +196,8 @@ class CameraInstance3DBoxes:
         self.box_dim, self.with_yaw = box_dim, with_yaw
         self.tensor = tensor.clone()
         if origin != (0.5, 1.0, 0.5):
-            dst, src = self.tensor.new_tensor((0.5, 1.0, 0.5)), self.tensor.new_tensor(origin)
-            self.tensor[:, :3] += self.tensor[:, 3:6] * (dst - src)
+            shift = F.const_tensor([0.5 - origin[0], 1.0 - origin[1], 0.5 - origin[2]], self.tensor.device, self.tensor.dtype)
+            self.tensor[:, :3] += self.tensor[:, 3:6] * shift
 
     dims = property(lambda self: self.tensor[:, 3:6])
     yaw = property(lambda self: self.tensor[:, 6])

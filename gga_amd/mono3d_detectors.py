@@ -187,10 +187,16 @@ class SingleStageMono3DDetector(nn.Module):
 
     def forward_train(self, img, img_metas, gt_bboxes, gt_labels, gt_bboxes_3d, gt_labels_3d, centers2d, depths, attr_labels=None,
                       gt_bboxes_ignore=None):
+        prepared = None
+        if hasattr(self.bbox_head, 'prepare_loss'):      # the target side of the loss first: its host waits end before the
+            head = self.bbox_head                        # forward pass is queued (PGDHead.prepare_loss)
+            prepared = head.prepare_loss(head.featmap_sizes_of(img.shape), img.shape[0], img.dtype, img.device, gt_bboxes, gt_labels,
+                                         gt_bboxes_3d, gt_labels_3d, centers2d, depths, attr_labels)
         x = self.extract_feat(img)
         outs = self.bbox_head(x)        # BaseMono3DDenseHead.forward_train (base_mono3d_dense_head.py:17-71)
+        kw = dict(prepared=prepared) if prepared is not None else {}
         return self.bbox_head.loss(*outs, gt_bboxes, gt_labels, gt_bboxes_3d, gt_labels_3d, centers2d, depths, attr_labels, img_metas,
-                                   gt_bboxes_ignore=gt_bboxes_ignore)
+                                   gt_bboxes_ignore=gt_bboxes_ignore, **kw)
 
     @torch.no_grad()
     def simple_test(self, img, img_metas, rescale=False):

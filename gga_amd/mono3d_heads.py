@@ -11,6 +11,8 @@ of ~60 broadcast tensor ops per image in a Python loop; the loss arithmetic on t
 positive points is plain device tensor code in the reference's order. Inference (``get_bboxes``, pgd_head.py:878-1130):
 per-level top-k, decoding, then per-class BEV NMS on the rotated-NMS kernel (``ops.box3d_multiclass_nms``).
 """
+import math
+
 import numpy as np
 import torch
 from torch import nn
@@ -419,8 +421,7 @@ class PGDHead(FCOSMono3DHead):
         targets of the positive points (pgd_head.py:265-441)."""
         views = [np.array(m['cam2img']) for m in img_metas]
         num_imgs = len(img_metas)
-        img_idx = torch.cat([labels_3d[0].new_ones(int(len(label) / num_imgs)) * idx for label in labels_3d for idx in range(num_imgs)])
-        pos_img_idx = img_idx[pos_inds]
+        img_pos = self._img_pos          # per image: positions of its points in the positive set (prepare_loss), None = none
         sp, sp2d, st, ss = [], [], [], []
         for i, bbox_pred in enumerate(bbox_preds):
             f = bbox_pred.permute(0, 2, 3, 1).reshape(-1, sum(self.group_reg_dims))
@@ -447,8 +448,8 @@ class PGDHead(FCOSMono3DHead):
         box_type = img_metas[0]['box_type_3d']
         code = self.bbox_coder.bbox_code_size
         for idx in range(num_imgs):
-            mask = pos_img_idx == idx
-            if int(mask.sum()) == 0:
+            mask = img_pos[idx]
+            if mask is None:
                 continue
             view = views[idx]
             cam2img = torch.eye(4, dtype=pos_preds.dtype, device=pos_preds.device)
@@ -570,22 +571,62 @@ class PGDHead(FCOSMono3DHead):
             outputs = outputs + (torch.cat([results[-1], out_scores[:, None]], dim=1), )
         return outputs
 
+    def prepare_loss(self, featmap_sizes, num_imgs, dtype, device, gt_bboxes, gt_labels, gt_bboxes_3d, gt_labels_3d, centers2d,
+                     depths, attr_labels):
+        """Everything of ``loss`` that depends on the ground truth only: the per-level targets (pgd_head.py:1132-1229), the
+        indices of the positive points and their split by image. The sizes of those index sets are data dependent, i.e.
+        the host waits for the device here - which is why the detector calls this BEFORE it queues the forward pass
+        (the wait then ends with the previous step's kernels, and the host work of the loss section runs while the
+        device is busy with the forward pass) instead of right after it (the device then idles for that host work)."""
+        points = self.get_points(featmap_sizes, dtype, device)
+        labels_3d, bbox_targets_3d, centerness_targets, attr_targets = self.get_targets(
+            points, gt_bboxes, gt_labels, gt_bboxes_3d, gt_labels_3d, centers2d, depths, attr_labels)
+        flatten_labels_3d = torch.cat(labels_3d)
+        pos_inds = ((flatten_labels_3d >= 0) & (flatten_labels_3d < self.num_classes)).nonzero().reshape(-1)
+        num_pos = len(pos_inds)
+        # positions (in the positive set) of every image's points, ascending - what a boolean mask per image selects
+        img_idx = torch.cat([labels_3d[0].new_ones(int(len(label) / num_imgs)) * idx for label in labels_3d for idx in range(num_imgs)])
+        pos_img_idx = img_idx[pos_inds]
+        counts = torch.bincount(pos_img_idx, minlength=num_imgs).tolist() if num_pos else [0] * num_imgs
+        order = torch.argsort(pos_img_idx, stable=True)
+        img_pos, lo = [], 0
+        for n in counts:
+            img_pos.append(order[lo:lo + n] if n else None)
+            lo += n
+        return dict(featmap_sizes=[tuple(int(v) for v in f) for f in featmap_sizes], num_imgs=num_imgs, points=points,
+                    labels_3d=labels_3d, bbox_targets_3d=bbox_targets_3d, centerness_targets=centerness_targets,
+                    attr_targets=attr_targets, flatten_labels_3d=flatten_labels_3d, pos_inds=pos_inds, num_pos=num_pos,
+                    img_pos=img_pos)
+
+    def featmap_sizes_of(self, img_shape):
+        """Sizes of the FPN levels for an input of ``img_shape`` (.., H, W): every stride-2 stage of the backbone and the
+        extra FPN convolutions (3x3 / 7x7 with 'same'-style padding, 3x3 max-pool with padding 1) halve rounding up."""
+        sizes = []
+        for st in self.strides:
+            h, w = int(img_shape[-2]), int(img_shape[-1])
+            for _ in range(int(round(math.log2(st)))):
+                h, w = (h + 1) // 2, (w + 1) // 2
+            sizes.append((h, w))
+        return sizes
+
     def loss(self, cls_scores, bbox_preds, dir_cls_preds, depth_cls_preds, weights, attr_preds, centernesses, gt_bboxes, gt_labels,
-             gt_bboxes_3d, gt_labels_3d, centers2d, depths, attr_labels, img_metas, gt_bboxes_ignore=None):
+             gt_bboxes_3d, gt_labels_3d, centers2d, depths, attr_labels, img_metas, gt_bboxes_ignore=None, prepared=None):
         assert len(cls_scores) == len(bbox_preds) == len(dir_cls_preds) == len(depth_cls_preds) == len(weights) == \
             len(centernesses) == len(attr_preds)
-        featmap_sizes = [f.size()[-2:] for f in cls_scores]
-        all_level_points = self.get_points(featmap_sizes, bbox_preds[0].dtype, bbox_preds[0].device)
-        labels_3d, bbox_targets_3d, centerness_targets, attr_targets = self.get_targets(
-            all_level_points, gt_bboxes, gt_labels, gt_bboxes_3d, gt_labels_3d, centers2d, depths, attr_labels)
+        featmap_sizes = [tuple(int(v) for v in f.size()[-2:]) for f in cls_scores]
         num_imgs = cls_scores[0].size(0)
+        if prepared is None or prepared['featmap_sizes'] != featmap_sizes or prepared['num_imgs'] != num_imgs:
+            prepared = self.prepare_loss(featmap_sizes, num_imgs, bbox_preds[0].dtype, bbox_preds[0].device, gt_bboxes, gt_labels,
+                                         gt_bboxes_3d, gt_labels_3d, centers2d, depths, attr_labels)
+        all_level_points, labels_3d, bbox_targets_3d = prepared['points'], prepared['labels_3d'], prepared['bbox_targets_3d']
+        centerness_targets, attr_targets = prepared['centerness_targets'], prepared['attr_targets']
         flatten_cls_scores = torch.cat([c.permute(0, 2, 3, 1).reshape(-1, self.cls_out_channels) for c in cls_scores])
-        flatten_labels_3d = torch.cat(labels_3d)
+        flatten_labels_3d = prepared['flatten_labels_3d']
         flatten_bbox_targets_3d = torch.cat(bbox_targets_3d)
         flatten_centerness_targets = torch.cat(centerness_targets)
         flatten_points = torch.cat([p.repeat(num_imgs, 1) for p in all_level_points])
-        pos_inds = ((flatten_labels_3d >= 0) & (flatten_labels_3d < self.num_classes)).nonzero().reshape(-1)
-        num_pos = len(pos_inds)
+        pos_inds, num_pos = prepared['pos_inds'], prepared['num_pos']
+        self._img_pos = prepared['img_pos']
         loss_dict = dict()
         loss_dict['loss_cls'] = self.loss_cls(flatten_cls_scores, flatten_labels_3d, avg_factor=num_pos + num_imgs)
         pos_bbox_preds, pos_dir_cls_preds, pos_depth_cls_preds, pos_weights, pos_attr_preds, pos_centerness = \

@@ -11,7 +11,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libgga_hip.so')
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 _lib = None
 
@@ -137,6 +137,7 @@ SIGNATURES = {
     'gga_fcos3d_targets': (i32, [vp, i32, i32, C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_float), f32, vp, i32,
                                   vp, vp, vp, vp, i32, vp, vp, vp, i64, i64, f32, vp, vp, vp, vp, vp, vp, vp]),
     'gga_dcn_im2col': (i32, [vp, vp, vp] + [i32] * 12 + [vp, vp]),
+    'gga_dcn_im2col_amax': (i32, [vp, vp, vp] + [i32] * 12 + [vp, vp, vp]),
     'gga_dcn_col2im': (i32, [vp, vp, vp, vp] + [i32] * 12 + [vp, vp, vp, vp]),
 }
 

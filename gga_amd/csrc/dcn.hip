@@ -58,11 +58,12 @@ __device__ __forceinline__ DcnTap dcn_tap(const DcnGeom& g, int ho, int wo, int 
 template <int VPL>
 __global__ __launch_bounds__(256) void dcn_im2col_kernel(const float* __restrict__ x, const float* __restrict__ offset,
                                                         const float* __restrict__ mask, DcnGeom g,
-                                                        float* __restrict__ col) {
+                                                        float* __restrict__ col, uint32_t* __restrict__ amax) {
     const int lane = threadIdx.x & 63;
     const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t npix = (int64_t)g.B * g.Ho * g.Wo;
-    if (p >= npix) return;
+    uint32_t am = 0;                                     // largest finite |col| written (for the consumer's fp16 scale)
+    if (p < npix) {
     const int b = (int)(p / ((int64_t)g.Ho * g.Wo));
     const int rem = (int)(p - (int64_t)b * g.Ho * g.Wo);
     const int ho = rem / g.Wo, wo = rem - ho * g.Wo;
@@ -87,9 +88,13 @@ __global__ __launch_bounds__(256) void dcn_im2col_kernel(const float* __restrict
             if (t.v2) acc = f4_fma(w2, f4_ld(r1 + g.C + c), acc);
             if (t.v3) acc = f4_fma(w3, f4_ld(r1 + (int64_t)g.W * g.C + c), acc);
             if (t.v4) acc = f4_fma(w4, f4_ld(r1 + (int64_t)(g.W + 1) * g.C + c), acc);
-            *reinterpret_cast<float4*>(cp + (int64_t)k * g.C + c) = make_float4(acc.x * m, acc.y * m, acc.z * m, acc.w * m);
+            const float4 o = make_float4(acc.x * m, acc.y * m, acc.z * m, acc.w * m);
+            *reinterpret_cast<float4*>(cp + (int64_t)k * g.C + c) = o;
+            if (amax) { am = gga_amax_of(o.x, am); am = gga_amax_of(o.y, am); am = gga_amax_of(o.z, am); am = gga_amax_of(o.w, am); }
         }
     }
+    }
+    if (amax) gga_amax_commit(am, amax);
 }
 
 // Backward of the sampling. The scatter into grad_x is data dependent (a sample's four corners are wherever
@@ -277,6 +282,13 @@ static int dcn_geom(const char* fn, int B, int H, int W, int C, int kh, int kw, 
 extern "C" int gga_dcn_im2col(const float* x, const float* offset, const float* mask, int B, int H, int W, int C, int kh,
                               int kw, int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w, float* col,
                               void* stream_) {
+    return gga_dcn_im2col_amax(x, offset, mask, B, H, W, C, kh, kw, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w, col, nullptr,
+                               stream_);
+}
+
+extern "C" int gga_dcn_im2col_amax(const float* x, const float* offset, const float* mask, int B, int H, int W, int C, int kh,
+                                   int kw, int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w, float* col,
+                                   uint32_t* amax_col, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     GGA_REQUIRE(x && offset && mask && col, "gga_dcn_im2col: null pointer argument");
     DcnGeom g;
@@ -284,10 +296,10 @@ extern "C" int gga_dcn_im2col(const float* x, const float* offset, const float* 
     const int64_t npix = (int64_t)B * g.Ho * g.Wo;
     const dim3 grid((unsigned)((npix + 3) / 4)), block(256);
     switch (C / 256) {
-        case 1: hipLaunchKernelGGL(dcn_im2col_kernel<1>, grid, block, 0, stream, x, offset, mask, g, col); break;
-        case 2: hipLaunchKernelGGL(dcn_im2col_kernel<2>, grid, block, 0, stream, x, offset, mask, g, col); break;
-        case 3: hipLaunchKernelGGL(dcn_im2col_kernel<3>, grid, block, 0, stream, x, offset, mask, g, col); break;
-        default: hipLaunchKernelGGL(dcn_im2col_kernel<4>, grid, block, 0, stream, x, offset, mask, g, col); break;
+        case 1: hipLaunchKernelGGL(dcn_im2col_kernel<1>, grid, block, 0, stream, x, offset, mask, g, col, amax_col); break;
+        case 2: hipLaunchKernelGGL(dcn_im2col_kernel<2>, grid, block, 0, stream, x, offset, mask, g, col, amax_col); break;
+        case 3: hipLaunchKernelGGL(dcn_im2col_kernel<3>, grid, block, 0, stream, x, offset, mask, g, col, amax_col); break;
+        default: hipLaunchKernelGGL(dcn_im2col_kernel<4>, grid, block, 0, stream, x, offset, mask, g, col, amax_col); break;
     }
     GGA_CHECK_LAUNCH("dcn_im2col_kernel");
     return GGA_OK;

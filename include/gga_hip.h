@@ -720,6 +720,11 @@ int gga_plane_inliers(const double* points, int64_t n_points, int point_stride, 
  * y = col @ W[Cout, kh, kw, C]^T + bias (a library GEMM on the caller's side). */
 int gga_dcn_im2col(const float* x, const float* offset, const float* mask, int B, int H, int W, int C, int kh, int kw,
                    int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w, float* col, void* stream);
+/* the same with one more output: the bits of the largest finite |col| written, max-combined into *amax_col (zeroed by the
+ * caller; NULL: not wanted) - the scale of the two-fp16-plane matrix kernels that multiply col by the weight */
+int gga_dcn_im2col_amax(const float* x, const float* offset, const float* mask, int B, int H, int W, int C, int kh, int kw,
+                        int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w, float* col, uint32_t* amax_col,
+                        void* stream);
 /* Backward of the sampling: grad_col [B*Ho*Wo, kh*kw*C] -> grad_x [B,H,W,C] (zero-filled here, float atomic
  * adds: the scatter targets are data dependent; NULL to skip), grad_offset / grad_mask in the layouts above. */
 int gga_dcn_col2im(const float* x, const float* offset, const float* mask, const float* grad_col, int B, int H, int W,

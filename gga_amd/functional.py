@@ -148,6 +148,8 @@ def const_tensor(data, device, dtype=torch.float32):
         if len(_CONSTS) > 4096:
             _CONSTS.clear()
         t = _CONSTS[key] = upload(torch.as_tensor(np.asarray(data), dtype=dtype), device)
+        if t.is_cuda:                      # once per constant: it may be read from another stream right away
+            torch.cuda.current_stream(t.device).synchronize()
     return t
 
 

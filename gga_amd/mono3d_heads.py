@@ -60,6 +60,9 @@ def distance2bbox(points, distance, max_shape=None):
     return torch.stack([x1, y1, x2, y2], -1)
 
 
+LEVEL_STREAMS = True      # PGDHead.forward: one stream per FPN level
+
+
 def multi_apply(func, *args, **kwargs):
     results = [func(*a, **kwargs) for a in zip(*args)]
     return tuple(map(list, zip(*results)))
@@ -366,7 +369,37 @@ class PGDHead(FCOSMono3DHead):
                 normal_init(conv_weight, std=0.01)
 
     def forward(self, feats):
-        return multi_apply(self.forward_single, feats, self.scales, self.strides)
+        if not (LEVEL_STREAMS and len(feats) > 1 and feats[0].is_cuda):
+            return multi_apply(self.forward_single, feats, self.scales, self.strides)
+        # The levels are independent until the loss, and from the second one on their maps are too small to fill the chip
+        # (a 24 x 78 map is 108 tiles of the convolution kernel, the 3 x 10 one 12): every level runs on a stream of its own,
+        # so the device overlaps their kernels - forward here, and backward too (autograd runs a node's backward on the
+        # stream of its forward and orders the streams itself).
+        main = torch.cuda.current_stream(feats[0].device)
+        streams = self._level_streams(len(feats), feats[0].device, main)
+        outs = []
+        for x, scale, stride, st in zip(feats, self.scales, self.strides, streams):
+            if st is not main:
+                st.wait_stream(main)
+                x.record_stream(st)
+            with torch.cuda.stream(st):
+                o = self.forward_single(x, scale, stride)
+            if st is not main:
+                for t in o:
+                    if isinstance(t, torch.Tensor):
+                        t.record_stream(main)      # produced on the level's stream, read by the loss on this one
+            outs.append(o)
+        for st in streams:
+            if st is not main:
+                main.wait_stream(st)
+        return tuple(map(list, zip(*outs)))
+
+    def _level_streams(self, n, device, main):
+        key = (str(device), n)
+        cache = self.__dict__.setdefault('_streams', {})
+        if key not in cache:
+            cache[key] = [torch.cuda.Stream(device=device) for _ in range(n - 1)]
+        return [main] + cache[key]                 # the largest level stays on the caller's stream
 
     def forward_single(self, x, scale, stride):
         cls_score, bbox_pred, dir_cls_pred, attr_pred, centerness, cls_feat, reg_feat = self._forward_fcos(x, scale, stride)

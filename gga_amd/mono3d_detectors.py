@@ -188,7 +188,7 @@ class SingleStageMono3DDetector(nn.Module):
     def forward_train(self, img, img_metas, gt_bboxes, gt_labels, gt_bboxes_3d, gt_labels_3d, centers2d, depths, attr_labels=None,
                       gt_bboxes_ignore=None):
         prepared = None
-        if hasattr(self.bbox_head, 'prepare_loss'):      # the target side of the loss first: its host waits end before the
+        if getattr(self.bbox_head, 'prepare_loss_before_forward', False):      # the target side of the loss first: its host waits end before the
             head = self.bbox_head                        # forward pass is queued (PGDHead.prepare_loss)
             prepared = head.prepare_loss(head.featmap_sizes_of(img.shape), img.shape[0], img.dtype, img.device, gt_bboxes, gt_labels,
                                          gt_bboxes_3d, gt_labels_3d, centers2d, depths, attr_labels)

@@ -604,6 +604,8 @@ class PGDHead(FCOSMono3DHead):
             outputs = outputs + (torch.cat([results[-1], out_scores[:, None]], dim=1), )
         return outputs
 
+    prepare_loss_before_forward = True      # SingleStageMono3DDetector.forward_train calls prepare_loss before the forward pass
+
     def prepare_loss(self, featmap_sizes, num_imgs, dtype, device, gt_bboxes, gt_labels, gt_bboxes_3d, gt_labels_3d, centers2d,
                      depths, attr_labels):
         """Everything of ``loss`` that depends on the ground truth only: the per-level targets (pgd_head.py:1132-1229), the

@@ -189,3 +189,48 @@ def test_fcos_mono3d_train_step_learns():
     last = float(out['loss'])
     assert np.isfinite(first) and np.isfinite(last) and last < first, (first, last)
     assert runner.optimizer.param_groups[0]['lr'] < 0.002 and runner.iter == 13
+
+
+def test_level_streams_and_prepared_targets_change_nothing(monkeypatch):
+    """The PGD step's two scheduling measures are invisible in the numbers: one stream per FPN level in the head
+    (mono3d_heads.LEVEL_STREAMS) and the target side of the loss computed before the forward pass
+    (PGDHead.prepare_loss, with the FPN sizes predicted from the image shape). Losses and gradients of one step with
+    both, against one stream and targets computed inside ``loss`` from the actual maps."""
+    from gga_amd import Config, build_model, synthetic, mono3d_heads
+    from gga_amd.cnn import to_channels_last
+    cfg = Config.fromfile(os.path.join(REPO, 'configs', 'gga', 'gga_pdg.py'))
+    torch.manual_seed(0)
+    model = to_channels_last(build_model(cfg.model).to(DEV))
+    model.bbox_head.init_weights()
+    model.train()
+    b = synthetic.make_mono_batch(2, device=DEV, img_hw=(192, 640))
+    data = {k: b[k] for k in synthetic.MONO_BATCH_KEYS}
+    data['img'] = data['img'].contiguous(memory_format=torch.channels_last)
+    # the predicted level sizes are the sizes of the maps the neck delivers
+    with torch.no_grad():
+        feats = model.extract_feat(data['img'])
+    assert model.bbox_head.featmap_sizes_of(data['img'].shape) == [tuple(f.shape[-2:]) for f in feats]
+
+    def one_step(streams, prepared):
+        monkeypatch.setattr(mono3d_heads, 'LEVEL_STREAMS', streams)
+        if not prepared:       # the detector only prepares when the head offers it
+            monkeypatch.setattr(type(model.bbox_head), 'prepare_loss_before_forward', False, raising=False)
+        else:
+            monkeypatch.setattr(type(model.bbox_head), 'prepare_loss_before_forward', True, raising=False)
+        model.zero_grad(set_to_none=True)
+        out = model.train_step(data)
+        out['loss'].backward()
+        torch.cuda.synchronize()
+        grads = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+        return {k: float(v) for k, v in out['log_vars'].items()}, grads
+
+    bn_state = {k: v.clone() for k, v in model.state_dict().items()}
+    l1, g1 = one_step(True, True)
+    model.load_state_dict(bn_state)
+    l0, g0 = one_step(False, False)
+    assert l1.keys() == l0.keys()
+    for k in l1:
+        assert abs(l1[k] - l0[k]) <= 1e-5 * abs(l0[k]) + 1e-7, (k, l1[k], l0[k])
+    assert g1.keys() == g0.keys()
+    for n in g1:      # global float atomics (DCN col2im, target scatter) order their additions differently from run to run
+        assert float((g1[n] - g0[n]).abs().max()) <= 2e-4 * float(g0[n].abs().max()) + 1e-7, n

@@ -11,7 +11,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libgga_hip.so')
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 _lib = None
 
@@ -88,6 +88,7 @@ SIGNATURES = {
     'gga_absmax_bits': (i32, [vp, i64, i32, i64, vp, vp]),
     'gga_dense_conv3x3_pack_planes': (i32, [vp, i64, i64, i64, i64, i32, i32, i32, i32, vp, vp, vp]),
     'gga_dense_conv3x3_planes': (i32, [vp, vp, i32, i32, i32, i32, i32, vp, i64, i32, vp, i32, vp, vp, vp]),
+    'gga_dense_conv3x3_levels': (i32, [i32, vp, vp, vp, vp, i32, i32, i32, vp, i64, i32, vp, vp, vp, i32, vp]),
     'gga_dense_conv3x3_bn_bwd_pays': (i32, [i32, i32, i32, i32]),
     'gga_dense_conv3x3_bn_bwd': (i32, [vp, vp, i32, i32, i32, i32, i32, vp, i64, i32, vp, i32, vp, vp, vp, i64, vp, vp, vp, vp, vp]),
     'gga_dense_wgrad3x3_planes': (i32, [vp, vp, i32, i32, i32, i32, i32, vp, i64, i64, i64, i64, i32, i32, vp, vp, vp, sz, vp]),
@@ -105,6 +106,7 @@ SIGNATURES = {
     'gga_bn_relu_bwd_strided': (i32, [vp, i64, vp, vp, vp, vp, i64, i32, i32, vp, vp, vp, vp, vp, sz, vp]),
     'gga_bn_relu_fwd_ex': (i32, [vp, vp, vp, vp, vp, vp, i64, i32, f32, f32, i32, i32, vp, i64, vp, vp, vp, i32, vp, vp, sz, vp]),
     'gga_bn_relu_bwd_ex': (i32, [vp, i64, vp, vp, vp, vp, i64, i32, i32, i32, vp, vp, vp, vp, vp, vp, sz, vp]),
+    'gga_column_sums': (i32, [vp, i64, i32, vp, vp, sz, vp]),
     'gga_bn_relu_bwd_partials': (i32, [vp, i64, vp, vp, vp, i64, i32, i32, vp, i32, vp, vp, vp, vp, vp, sz, vp]),
     'gga_gn_relu_workspace_bytes': (sz, [i32, i32]),
     'gga_gn_relu_fwd': (i32, [vp, vp, vp, i32, i64, i32, i32, f32, i32, vp, vp, vp, vp, vp, sz, vp]),

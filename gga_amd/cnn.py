@@ -109,6 +109,19 @@ class ConvModule(nn.Module):
         from . import dense_conv
         is_bn = self.with_norm and isinstance(self.norm, nn.modules.batchnorm._BatchNorm)
         x = dense_conv.conv2d(x, self.conv, bn_follows=is_bn and self.norm.training)
+        return self.after_conv(x)
+
+    def forward_levels(self, xs):
+        """``[self(x) for x in xs]`` with the convolution of all maps in one launch where the kernel allows it (the
+        weight-sharing towers of an FPN head: dense_conv.conv2d_levels); normalisation and activation map by map."""
+        from . import dense_conv
+        is_bn = self.with_norm and isinstance(self.norm, nn.modules.batchnorm._BatchNorm)
+        if is_bn or type(self.conv) is not nn.Conv2d or not dense_conv.levels_eligible(self.conv, xs):
+            return [self(x) for x in xs]
+        return [self.after_conv(y) for y in dense_conv.conv2d_levels(xs, self.conv)]
+
+    def after_conv(self, x):
+        is_bn = self.with_norm and isinstance(self.norm, nn.modules.batchnorm._BatchNorm)
         if is_bn:
             from . import functional as F        # fused BN(+ReLU) HIP pass for channels-last activations
             return F.bn_act(x, self.norm, relu=self.with_activation)

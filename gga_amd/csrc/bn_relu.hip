@@ -516,6 +516,38 @@ extern "C" int gga_bn_relu_bwd_ex(const float* grad_y, int64_t grad_y_row_stride
     return GGA_OK;
 }
 
+// per-channel sums of a [rows, C] matrix (the bias gradient of a convolution: sum of the output gradient over batch and
+// pixels; torch's reduction over the non-channel dimensions of a channels-last tensor reads at 1.6 TB/s)
+__global__ __launch_bounds__(1024) void colsum_final_kernel(const double* __restrict__ partials, int nblocks, int C,
+                                                           float* __restrict__ out) {
+    const int c = blockIdx.x * 8 + (threadIdx.x & 7);
+    const bool ok = c < C;
+    double s, ss;
+    bn_fold_partials(partials, nblocks, C, c, ok, s, ss);
+    if (threadIdx.x >= 8 || !ok) return;
+    out[c] = (float)s;
+}
+
+extern "C" int gga_column_sums(const float* x, int64_t rows, int channels, float* sums, void* workspace, size_t workspace_bytes,
+                               void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (int rc = bn_check("gga_column_sums", rows, channels)) return rc;
+    GGA_REQUIRE(x && sums && workspace && ((uintptr_t)x & 15) == 0, "gga_column_sums: null or misaligned pointer argument");
+    if (workspace_bytes < gga_bn_relu_workspace_bytes(rows, channels)) {
+        gga_set_error("gga_column_sums: workspace too small");
+        return GGA_ERR_WORKSPACE;
+    }
+    const BnGeom g = bn_geom(rows, channels, channels);
+    const int nb = bn_grid(g.n4);
+    hipLaunchKernelGGL(bn_reduce_kernel<false>, dim3(nb), dim3(256), 0, stream, (const float4*)x, (const float4*)nullptr,
+                       (const unsigned long long*)nullptr, (const float*)nullptr, g, 0, (double*)workspace);
+    GGA_CHECK_LAUNCH("bn_reduce_kernel<fwd>");
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((channels + 7) / 8), dim3(1024), 0, stream, (const double*)workspace, nb, channels,
+                       sums);
+    GGA_CHECK_LAUNCH("colsum_final_kernel");
+    return GGA_OK;
+}
+
 extern "C" int gga_bn_relu_bwd_partials(const float* grad_masked, int64_t grad_row_stride, const float* x, const float* gamma,
                                         const float* saved, int64_t rows, int channels, int training, const double* partials,
                                         int n_partials, float* grad_x, float* grad_gamma, float* grad_beta,

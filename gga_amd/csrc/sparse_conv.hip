@@ -1613,13 +1613,41 @@ struct DcBnBwd {
     int ystride;
 };
 
+// Several images of different sizes in ONE launch (gga_dense_conv3x3_levels: the tower convolutions of an FPN head share
+// their weights over the levels, and all but the largest level are too small to fill the chip - 12 x 24 x 78 is 108
+// tiles, 12 x 3 x 10 is 12): entry e owns the tiles [start[e], start[e + 1]) of the grid and brings its own input,
+// output, size, absmax and (for output slices) weight operand. n = 0: the kernel's scalar arguments describe the one image.
+#define DC_MAX_ENTRIES 16
+struct DcLevels {
+    int n;
+    int start[DC_MAX_ENTRIES + 1];
+    int H[DC_MAX_ENTRIES], W[DC_MAX_ENTRIES];
+    const float* x[DC_MAX_ENTRIES];
+    float* y[DC_MAX_ENTRIES];
+    const uint16_t* w[DC_MAX_ENTRIES];
+    const uint32_t* amax_x[DC_MAX_ENTRIES];
+    const float* bias[DC_MAX_ENTRIES];       // per output channel of the entry, added in the epilogue; null: none
+};
+
 template <int NT, int TR, int NP, int MT>
 __global__ __launch_bounds__(TR / MT * 64, 2) void dense_conv3x3_x9_kernel(const float* __restrict__ X, const uint16_t* __restrict__ Wp,
                                                                  int B, int H, int W, int cin, int cout, int tiles_x,
                                                                  int tiles_y, float* __restrict__ Y, int ystride,
                                                                  int prow, int pcol, double* __restrict__ stats,
                                                                  const uint32_t* __restrict__ amax_x,
-                                                                 const uint32_t* __restrict__ amax_w, DcBnBwd bn) {
+                                                                 const uint32_t* __restrict__ amax_w, DcBnBwd bn,
+                                                                 DcLevels lv) {
+    int tile = blockIdx.x;
+    const float* bias = nullptr;
+    if (lv.n) {                                          // which image this workgroup's tile belongs to (wave-uniform)
+        int e = 0;
+        while (e + 1 < lv.n && tile >= lv.start[e + 1]) ++e;
+        tile -= lv.start[e];
+        X = lv.x[e]; Y = lv.y[e]; Wp = lv.w[e]; amax_x = lv.amax_x[e]; bias = lv.bias[e];
+        H = lv.H[e]; W = lv.W[e];
+        prow = W; pcol = 1;
+        tiles_x = (W + DC_TW - 1) / DC_TW; tiles_y = (H + TR - 1) / TR;
+    }
     // H x W is the tile space (rows x 32-pixel columns); pixel (r, c) of it is pixel r*prow + c*pcol of
     // the image: (W, 1) for the image as stored, (1, image width) with H and W swapped for the
     // transposed walk (tiles 32 pixels long along the image's H), chosen by the caller per shape.
@@ -1742,7 +1770,6 @@ __global__ __launch_bounds__(TR / MT * 64, 2) void dense_conv3x3_x9_kernel(const
     long long pr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const long long tstart_ = __builtin_readcyclecounter();
 #endif
-    int tile = blockIdx.x;
     if (tile >= n_tiles) return;
     {
         DC_TILE(tile, tb, ty0, tx0)
@@ -1826,14 +1853,20 @@ __global__ __launch_bounds__(TR / MT * 64, 2) void dense_conv3x3_x9_kernel(const
 #undef DC_STAGE
 #undef DC_EVEN
 #undef DC_ODD
-        if (NP == 2) {                                     // back from the scaled operands: two exact powers of two
-            const float dx = h2_descale(sbx), dw = h2_descale(sbw);
+        {
+            // back from the scaled operands (two exact powers of two), and the bias of the lane's output channels
+            const float dx = NP == 2 ? h2_descale(sbx) : 1.0f, dw = NP == 2 ? h2_descale(sbw) : 1.0f;
+            float bv[NT];
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
+            for (int t = 0; t < NT; ++t) bv[t] = bias ? bias[t * 32 + r] : 0.0f;
+            if (NP == 2 || bias) {
 #pragma unroll
-                for (int t = 0; t < NT; ++t)
+                for (int m = 0; m < MT; ++m)
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) acc[m][t][i] = acc[m][t][i] * dx * dw;
+                    for (int t = 0; t < NT; ++t)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) acc[m][t][i] = acc[m][t][i] * dx * dw + bv[t];
+            }
         }
         // D layout of 32x32x16: register v of lane l holds row (v/4)*8 + (l/32)*4 + v%4 (= pixel of the M tile's row), column l%32
         float s1[NT], s2[NT];
@@ -2056,6 +2089,8 @@ extern "C" int gga_dense_conv3x3_bn_bwd(const float* x, const void* split_weight
                 "gga_dense_conv3x3_bn_bwd: the BatchNorm epilogue needs stats, the saved mean / invstd and a pixel stride >= cout");
     DcBnBwd bn;
     bn.y = bn_x; bn.gamma = bn_gamma; bn.beta = bn_beta; bn.mean = bn_mean; bn.invstd = bn_invstd; bn.ystride = (int)bn_x_pixel_stride;
+    DcLevels lv;
+    lv.n = 0;
     GGA_REQUIRE(x && split_weight && y, "gga_dense_conv3x3: null pointer argument");
     GGA_REQUIRE(planes == 3 || (planes == 2 && amax_x && amax_weight),
                 "gga_dense_conv3x3: planes must be 3 (bf16) or 2 (fp16, with the operands' absmax bits)");
@@ -2077,7 +2112,7 @@ extern "C" int gga_dense_conv3x3_bn_bwd(const float* x, const void* split_weight
     const dim3 grid((unsigned)n_tiles), block(trows * 32);
     hipEvent_t* tev = gga_timing_acquire(GGA_TIME_DENSE_CONV, GGA_TIMING_CONV_KEY(cin, cout, (int64_t)H * W));
     GGA_TIME_START(tev, stream);
-#define DC_GO(NT_, TR_, NP_) hipLaunchKernelGGL((dense_conv3x3_x9_kernel<NT_, TR_, NP_, 2>), grid, block, 0, stream, x, (const uint16_t*)split_weight, B, H, W, cin, cout, tx, ty, y, (int)y_pixel_stride, prow, pcol, stats, amax_x, amax_weight, bn)
+#define DC_GO(NT_, TR_, NP_) hipLaunchKernelGGL((dense_conv3x3_x9_kernel<NT_, TR_, NP_, 2>), grid, block, 0, stream, x, (const uint16_t*)split_weight, B, H, W, cin, cout, tx, ty, y, (int)y_pixel_stride, prow, pcol, stats, amax_x, amax_weight, bn, lv)
     if (planes == 3) {
         if (cout == 64) DC_GO(2, 8, 3);
         else if (trows == 16) DC_GO(4, 16, 3);
@@ -2090,6 +2125,48 @@ extern "C" int gga_dense_conv3x3_bn_bwd(const float* x, const void* split_weight
 #undef DC_GO
     GGA_CHECK_LAUNCH("dense_conv3x3_x9_kernel");
     GGA_TIME_STOP(tev, stream);
+    return GGA_OK;
+}
+
+extern "C" int gga_dense_conv3x3_levels(int n_entries, const float* const* x, const int32_t* heights, const int32_t* widths,
+                                        const void* const* split_weight, int B, int cin, int cout, float* const* y,
+                                        int64_t y_pixel_stride, int planes, const uint32_t* const* amax_x,
+                                        const uint32_t* amax_weight, const float* const* bias, int tile_rows, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    GGA_REQUIRE(tile_rows == 8 || (tile_rows == 16 && cout == 128), "gga_dense_conv3x3_levels: tile_rows 8, or 16 with cout 128");
+    GGA_REQUIRE(n_entries >= 1 && n_entries <= DC_MAX_ENTRIES, "gga_dense_conv3x3_levels: 1 .. %d entries (got %d)", DC_MAX_ENTRIES,
+                n_entries);
+    GGA_REQUIRE(x && heights && widths && split_weight && y, "gga_dense_conv3x3_levels: null pointer argument");
+    GGA_REQUIRE(planes == 3 || (planes == 2 && amax_x && amax_weight),
+                "gga_dense_conv3x3_levels: planes must be 3 (bf16) or 2 (fp16, with the operands' absmax bits)");
+    GGA_REQUIRE(B >= 1 && cin >= 32 && cin % 32 == 0 && (cout == 64 || cout == 128) && y_pixel_stride >= cout &&
+                    y_pixel_stride < 2147483647ll, "gga_dense_conv3x3_levels: need cin %% 32 == 0 and cout 64 or 128 (got %d -> %d)",
+                cin, cout);
+    DcLevels lv;
+    lv.n = n_entries;
+    int64_t total = 0;
+    for (int e = 0; e < n_entries; ++e) {
+        GGA_REQUIRE(x[e] && y[e] && split_weight[e] && heights[e] >= 1 && widths[e] >= 1 &&
+                        (int64_t)heights[e] * widths[e] * cin < 2147483647ll && (planes == 3 || amax_x[e]),
+                    "gga_dense_conv3x3_levels: bad entry %d", e);
+        lv.start[e] = (int)total;
+        lv.H[e] = heights[e]; lv.W[e] = widths[e];
+        lv.x[e] = x[e]; lv.y[e] = y[e]; lv.w[e] = (const uint16_t*)split_weight[e];
+        lv.amax_x[e] = planes == 2 ? amax_x[e] : nullptr;
+        lv.bias[e] = bias ? bias[e] : nullptr;
+        total += (int64_t)B * ((widths[e] + DC_TW - 1) / DC_TW) * ((heights[e] + tile_rows - 1) / tile_rows);
+        GGA_REQUIRE(total < 2147483647ll, "gga_dense_conv3x3_levels: too many tiles");
+    }
+    lv.start[n_entries] = (int)total;
+    for (int e = n_entries + 1; e <= DC_MAX_ENTRIES; ++e) lv.start[e] = (int)total;
+    DcBnBwd bn;
+    bn.y = nullptr; bn.gamma = bn.beta = bn.mean = bn.invstd = nullptr; bn.ystride = 0;
+    const dim3 grid((unsigned)total), block(tile_rows * 32);
+#define DC_LV(NT_, TR_, NP_) hipLaunchKernelGGL((dense_conv3x3_x9_kernel<NT_, TR_, NP_, 2>), grid, block, 0, stream, x[0], (const uint16_t*)split_weight[0], B, heights[0], widths[0], cin, cout, 1, 1, y[0], (int)y_pixel_stride, widths[0], 1, (double*)nullptr, planes == 2 ? amax_x[0] : nullptr, amax_weight, bn, lv)
+    if (planes == 3) { if (cout == 64) DC_LV(2, 8, 3); else if (tile_rows == 16) DC_LV(4, 16, 3); else DC_LV(4, 8, 3); }
+    else { if (cout == 64) DC_LV(2, 8, 2); else if (tile_rows == 16) DC_LV(4, 16, 2); else DC_LV(4, 8, 2); }
+#undef DC_LV
+    GGA_CHECK_LAUNCH("dense_conv3x3_x9_kernel (levels)");
     return GGA_OK;
 }
 

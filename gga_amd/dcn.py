@@ -125,7 +125,7 @@ class _ModulatedDeformConv(torch.autograd.Function):
             del col
             gcol = g @ wmat
         if ctx.has_bias and ctx.needs_input_grad[4]:
-            gb = g.sum(0)
+            gb = F.channel_sums(g)
         goff, gmask = torch.empty_like(offset), torch.empty_like(mask)
         if ctx.needs_input_grad[0]:
             gx = torch.empty_like(xl)          # channels-last like x

@@ -317,6 +317,94 @@ class _Conv3x3(torch.autograd.Function):
         return gx, gw, None
 
 
+def _run_levels(xs, weight, backward, x_amaxes, w_amax, bias=None):
+    """The convolution (or its backward-data form) of several maps ``xs`` [B, n_in, H_l, W_l] with ONE ``weight`` (and
+    ``bias``, added in the kernel's epilogue): one launch over all (map, 128-channel output slice) entries
+    (``gga_dense_conv3x3_levels``: at most 16 entries per launch)."""
+    import ctypes as C
+    L = _lib.lib()
+    B, n_in = xs[0].shape[0], xs[0].shape[1]
+    n_out = weight.shape[1] if backward else weight.shape[0]
+    width = n_out if n_out in (64, 128) else 128
+    ys = [torch.empty((B, n_out, x.shape[2], x.shape[3]), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+          for x in xs]
+    planes = PLANES
+    packs = []
+    for c0 in range(0, n_out, width):
+        wv = weight if width == n_out else (weight[:, c0:c0 + width] if backward else weight[c0:c0 + width])
+        packs.append((c0, _pack(wv, backward, False, w_amax if planes == 2 else None)))
+    entries = [(x, y, c0, wp, a) for c0, wp in packs for x, y, a in zip(xs, ys, x_amaxes)]
+    # maps with enough 16-row tiles run the 512-thread form (as gga_dense_conv3x3_planes would pick for them), the small
+    # ones the 8-row form: two launches
+    big = lambda x: width == 128 and B * _cdiv(x.shape[3], 32) * _cdiv(x.shape[2], 16) >= 384
+    groups = [(16, [e for e in entries if big(e[0])]), (8, [e for e in entries if not big(e[0])])]
+    for rows, group in groups:
+        for i0 in range(0, len(group), 16):
+            part = group[i0:i0 + 16]
+            n = len(part)
+            vp, i32 = C.c_void_p * n, C.c_int32 * n
+            amax = vp(*[a.data_ptr() for *_, a in part]) if planes == 2 else None
+            bias_p = vp(*[bias.data_ptr() + 4 * c0 for _, _, c0, _, _ in part]) if bias is not None else None
+            check(L.gga_dense_conv3x3_levels(
+                n, vp(*[x.data_ptr() for x, *_ in part]), i32(*[x.shape[2] for x, *_ in part]), i32(*[x.shape[3] for x, *_ in part]),
+                vp(*[wp.data_ptr() for _, _, _, wp, _ in part]), B, n_in, width,
+                vp(*[y.data_ptr() + 4 * c0 for _, y, c0, _, _ in part]), n_out, planes, amax,
+                F._p(w_amax) if planes == 2 else None, bias_p, rows, F._stream()), 'gga_dense_conv3x3_levels')
+    return ys
+
+
+class _Conv3x3Levels(torch.autograd.Function):
+    """One 3x3 convolution applied to several maps (the FPN levels of a head tower): forward and backward-data are one
+    launch over all levels, the weight gradient is the sum of the levels' weight gradients."""
+
+    @staticmethod
+    def forward(ctx, weight, bias, *xs):
+        two = PLANES == 2
+        x_amaxes = [tensor_amax(x) if two else None for x in xs]
+        w_amax = amax_bits(weight.detach()) if two else None
+        ys = _run_levels(xs, weight.detach(), False, x_amaxes, w_amax, None if bias is None else bias.detach().contiguous())
+        ctx.save_for_backward(weight, *xs)
+        ctx.amax = (x_amaxes, w_amax)
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *gys):
+        weight, *xs = ctx.saved_tensors
+        two = PLANES == 2
+        gys = [g.contiguous(memory_format=torch.channels_last) for g in gys]
+        x_amaxes, w_amax = ctx.amax
+        g_amaxes = [tensor_amax(g) if two else None for g in gys]
+        gxs = [None] * len(xs)
+        if any(ctx.needs_input_grad[2:]):
+            gxs = _run_levels(gys, weight.detach(), True, g_amaxes, w_amax)
+        gw = gb = None
+        if ctx.needs_input_grad[0]:
+            for x, g, xa, ga in zip(xs, gys, x_amaxes, g_amaxes):
+                part = _wgrad(x, g, weight, xa, ga)
+                gw = part if gw is None else gw.add_(part)
+        if ctx.needs_input_grad[1]:
+            for g in gys:
+                part = F.channel_sums(g)
+                gb = part if gb is None else gb.add_(part)
+        return (gw, gb, *gxs)
+
+
+def levels_eligible(conv, xs):
+    """One multi-level launch is possible: an eligible convolution (with or without bias) over maps of equal batch whose
+    backward-data and weight gradient also run on the matrix kernels."""
+    return (len(xs) >= 1 and all(eligible(conv, x) for x in xs) and WGRAD
+            and conv.in_channels % 64 == 0 and conv.out_channels % 64 == 0
+            and (conv.in_channels in (64, 128) or conv.in_channels % 128 == 0)
+            and all(x.shape[0] == xs[0].shape[0] for x in xs))
+
+
+def conv2d_levels(xs, conv):
+    """``[conv(x) for x in xs]`` - one launch over all maps when ``levels_eligible``, map by map otherwise."""
+    if levels_eligible(conv, xs):
+        return list(_Conv3x3Levels.apply(conv.weight, conv.bias, *xs))
+    return [conv2d(x, conv) for x in xs]
+
+
 def eligible(conv, x):
     return (ENABLED and type(conv) is nn.Conv2d and conv.kernel_size == (3, 3)
             and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1
@@ -332,7 +420,9 @@ def conv2d(x, conv, bn_follows=False):
     kernel then also leaves the per-channel sums of its output (``y.bn_partials``), which
     ``functional.bn_act`` / ``bn_relu_head_conv3x3`` use instead of re-reading ``y``."""
     if eligible(conv, x):
-        if conv.bias is not None:         # the kernel has no bias epilogue: one elementwise pass (mono3d head towers)
+        if conv.bias is not None:         # bias in the kernel's epilogue (gga_dense_conv3x3_levels with one map: mono3d heads)
+            if levels_eligible(conv, [x]):
+                return _Conv3x3Levels.apply(conv.weight, conv.bias, x)[0]
             return _Conv3x3.apply(x, conv.weight, False)[0] + conv.bias.view(1, -1, 1, 1)
         y, stats = _Conv3x3.apply(x, conv.weight, bool(bn_follows))
         if bn_follows:

@@ -571,6 +571,20 @@ class _BNAct(torch.autograd.Function):
         return gx, gres, gg, gb, None, None, None, None, None, None, None, None, None
 
 
+def channel_sums(x):
+    """``x.sum`` over every dimension but the channels of a [rows, C] / channels-last [B, C, H, W] gradient (a convolution's
+    bias gradient) - ``gga_column_sums`` where the layout allows it, the framework's reduction otherwise."""
+    rc = _rows_channels(x) if (x.is_cuda and x.dtype == torch.float32) else None
+    C = x.shape[1]
+    if rc is None or rc[0] < 1 or C % 4 or C // 4 > 256 or 256 % (C // 4) or x.data_ptr() % 16:
+        return x.sum(tuple(d for d in range(x.dim()) if d != 1))
+    L = _lib.lib()
+    out = torch.empty(C, dtype=torch.float32, device=x.device)
+    ws = _workspace('bn', L.gga_bn_relu_workspace_bytes(rc[0], C), x.device)
+    check(L.gga_column_sums(_p(x), rc[0], C, _p(out), _p(ws), ws.numel(), _stream()), 'gga_column_sums')
+    return out
+
+
 def _rows_channels(x):
     """[rows, C] view of a 2-D contiguous or 4-D channels-last tensor, else None."""
     if x.dim() == 2 and x.is_contiguous():

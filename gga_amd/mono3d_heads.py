@@ -60,7 +60,10 @@ def distance2bbox(points, distance, max_shape=None):
     return torch.stack([x1, y1, x2, y2], -1)
 
 
-LEVEL_STREAMS = True      # PGDHead.forward: one stream per FPN level
+LEVEL_STREAMS = True      # PGDHead.forward: one stream per FPN level (when LEVEL_BATCH is off)
+LEVEL_BATCH = False       # PGDHead.forward: layer by layer over all levels, weight-sharing convolutions as one launch over the
+                          # maps (measured: 145 ms per head forward + backward against 135 with LEVEL_STREAMS - the largest
+                          # level is three quarters of the work and fills the chip alone)
 
 
 def multi_apply(func, *args, **kwargs):
@@ -369,6 +372,8 @@ class PGDHead(FCOSMono3DHead):
                 normal_init(conv_weight, std=0.01)
 
     def forward(self, feats):
+        if LEVEL_BATCH and len(feats) > 1 and feats[0].is_cuda:
+            return self.forward_levels(feats)
         if not (LEVEL_STREAMS and len(feats) > 1 and feats[0].is_cuda):
             return multi_apply(self.forward_single, feats, self.scales, self.strides)
         # The levels are independent until the loss, and from the second one on their maps are too small to fill the chip
@@ -393,6 +398,42 @@ class PGDHead(FCOSMono3DHead):
             if st is not main:
                 main.wait_stream(st)
         return tuple(map(list, zip(*outs)))
+
+    @staticmethod
+    def _run_lv(branch, xs):
+        for layer in branch:
+            xs = layer.forward_levels(xs) if hasattr(layer, 'forward_levels') else [layer(x) for x in xs]
+        return xs
+
+    def forward_levels(self, feats):
+        """``forward`` layer by layer over all levels instead of level by level over all layers: the same modules on the
+        same tensors (``_forward_base`` / ``_forward_fcos`` / ``forward_single`` with lists), so that every convolution
+        whose weights the levels share is ONE launch over the five maps (ConvModule.forward_levels)."""
+        n, run = len(feats), self._run_lv
+        each = lambda conv, xs: [conv(x) for x in xs]
+        cls_feat = run(self.cls_convs, feats)
+        cls_score = each(self.conv_cls, run(self.conv_cls_prev, cls_feat))
+        reg_feat = run(self.reg_convs, feats)
+        parts = []
+        for i in range(len(self.group_reg_dims)):
+            f = reg_feat if len(self.reg_branch[i]) == 0 else run(self.conv_reg_prevs[i], reg_feat)
+            parts.append(each(self.conv_regs[i], f))
+        bbox_pred = [torch.cat([p[l] for p in parts], dim=1) for l in range(n)]
+        dir_cls_pred = each(self.conv_dir_cls, run(self.conv_dir_cls_prev, reg_feat)) if self.use_direction_classifier else [None] * n
+        attr_pred = each(self.conv_attr, run(self.conv_attr_prev, cls_feat)) if self.pred_attrs else [None] * n
+        centerness = each(self.conv_centerness, run(self.conv_centerness_prev, reg_feat if self.centerness_on_reg else cls_feat))
+        depth_cls_pred = each(self.conv_depth_cls, run(self.conv_depth_cls_prev, reg_feat)) if self.use_depth_classifier else [None] * n
+        weight = [None] * n
+        if self.weight_dim != -1:
+            ws = [each(self.conv_weights[i], reg_feat if len(self.weight_branch[i]) == 0 else run(self.conv_weight_prevs[i], reg_feat))
+                  for i in range(self.weight_dim)]
+            weight = [torch.cat([w[l] for w in ws], dim=1) for l in range(n)]
+        for l, (scale, stride) in enumerate(zip(self.scales, self.strides)):
+            bbox_pred[l] = self.bbox_coder.decode(bbox_pred[l], scale, stride, self.training, cls_score[l])
+            max_regress_range = stride * self.regress_ranges[0][1] / self.strides[0]
+            bbox_pred[l] = self.bbox_coder.decode_2d(bbox_pred[l], scale, stride, max_regress_range, self.training,
+                                                     self.pred_keypoints, self.pred_bbox2d)
+        return cls_score, bbox_pred, dir_cls_pred, depth_cls_pred, weight, attr_pred, centerness
 
     def _level_streams(self, n, device, main):
         key = (str(device), n)

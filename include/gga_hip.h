@@ -365,6 +365,18 @@ int gga_dense_conv3x3_planes(const float* x, const void* split_weight, int B, in
  * pass decided it) before it is stored, and `stats` ([tiles][2][cout] f64, required) receives the per-tile sums of
  * g and g * xhat instead - the reduce pass of that BatchNorm's backward, which gga_bn_relu_bwd_partials then skips.
  * bn_x == NULL: exactly gga_dense_conv3x3_planes. */
+/* gga_dense_conv3x3_planes over several images of different sizes in ONE launch (the tower convolutions of an FPN head,
+ * anchor_free_mono3d_head.py:160-250, share their weights over the levels, and the small levels alone leave most of the
+ * chip idle): entry e convolves x[e] [B, heights[e], widths[e], cin] with split_weight[e] (entries that are output slices of
+ * one convolution bring their own operand) into y[e] (pixel stride y_pixel_stride floats). bias (NULL: none): per entry the
+ * `cout` bias values of its output channels (NULL entries: none), added in the epilogue - this is also how a single map with
+ * a bias is run. tile_rows: 8, or 16 (cout 128 only: the form gga_dense_conv3x3_planes picks for maps with at least 384
+ * 16-row tiles - large and small maps go into separate launches); the map as stored; at most 16 entries; no statistics
+ * epilogue. */
+int gga_dense_conv3x3_levels(int n_entries, const float* const* x, const int32_t* heights, const int32_t* widths,
+                             const void* const* split_weight, int B, int cin, int cout, float* const* y, int64_t y_pixel_stride,
+                             int planes, const uint32_t* const* amax_x, const uint32_t* amax_weight, const float* const* bias,
+                             int tile_rows, void* stream);
 int gga_dense_conv3x3_bn_bwd_pays(int B, int H, int W, int cout);   /* 1: the epilogue costs less than the reduce pass (H, W of the tile space) */
 int gga_dense_conv3x3_bn_bwd(const float* x, const void* split_weight, int B, int H, int W, int cin, int cout, float* y,
                              int64_t y_pixel_stride, int transposed, double* stats, int planes, const uint32_t* amax_x,
@@ -470,6 +482,10 @@ int gga_bn_relu_bwd_ex(const float* grad_y, int64_t grad_y_row_stride, const flo
                        const float* gamma, const float* saved, int64_t rows, int channels, int relu, int training, float* grad_x,
                        float* grad_residual, float* grad_gamma, float* grad_beta, uint32_t* amax_grad_x, void* workspace,
                        size_t workspace_bytes, void* stream);
+/* sums[c] = sum over the rows of x [rows, channels] (row major; channels / 4 must divide 256) - the bias gradient of a
+ * convolution from its output gradient in channels-last memory. Workspace: gga_bn_relu_workspace_bytes(rows, channels). */
+int gga_column_sums(const float* x, int64_t rows, int channels, float* sums, void* workspace, size_t workspace_bytes,
+                    void* stream);
 /* The backward pass whose reduce pass was done by the producer of the gradient (gga_dense_conv3x3_bn_bwd): grad_masked
  * is already multiplied by the ReLU mask, partials [n_partials][2][channels] f64 hold the sums of g and g * xhat. */
 int gga_bn_relu_bwd_partials(const float* grad_masked, int64_t grad_row_stride, const float* x, const float* gamma,

@@ -732,6 +732,68 @@ def test_dense_conv_leaves_batchnorm_partials(cin, cout, B, H, W):
     assert conv.weight.grad is not None and torch.isfinite(conv.weight.grad).all()
 
 
+def test_channel_sums_vs_torch():
+    """gga_column_sums (bias gradients): channels-last maps, row matrices, and the layouts it hands back to torch."""
+    torch.manual_seed(3)
+    for shape, cl in (((3, 256, 17, 23), True), ((1000, 64), False), ((2, 27, 5, 7), True), ((2, 64, 9, 9), False)):
+        x = torch.randn(*shape, device=DEV)
+        if cl:
+            x = x.contiguous(memory_format=torch.channels_last)
+        ref = x.double().sum(tuple(d for d in range(x.dim()) if d != 1))
+        got = F.channel_sums(x)
+        assert got.shape == ref.shape
+        assert float((got.double() - ref).abs().max()) <= 1e-5 * float(x.abs().sum() / x.shape[1]) + 1e-6
+
+
+@pytest.mark.parametrize('cin,cout', [(256, 256), (64, 64), (128, 64), (256, 128)])
+@pytest.mark.parametrize('planes', [2, 3])
+def test_dense_conv3x3_over_several_maps_in_one_launch(cin, cout, planes, monkeypatch):
+    """gga_dense_conv3x3_levels: one convolution over five maps of different sizes (the FPN levels of a head tower, each
+    with its own absmax) - forward, backward-data and the summed weight gradient against torch in float64, and against
+    the map-by-map path of this repo."""
+    from gga_amd import dense_conv
+    monkeypatch.setattr(dense_conv, 'PLANES', planes)
+    torch.manual_seed(cin + cout)
+    conv = torch.nn.Conv2d(cin, cout, 3, padding=1, bias=False).to(DEV)
+    conv.weight.data = conv.weight.data.contiguous(memory_format=torch.channels_last)
+    sizes = [(24, 78), (12, 39), (6, 20), (3, 10), (1, 1)]
+    xs = [(torch.randn(3, cin, h, w, device=DEV) * 10.0 ** (i - 2)).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+          for i, (h, w) in enumerate(sizes)]
+    assert dense_conv.levels_eligible(conv, xs)
+    ys = dense_conv.conv2d_levels(xs, conv)
+    assert all('Conv3x3Levels' in type(y.grad_fn).__name__ for y in ys)
+    gs = [torch.randn_like(y) for y in ys]
+    torch.autograd.backward(ys, gs)
+    gw = conv.weight.grad.clone()
+    gw64 = 0
+    for x, y, g in zip(xs, ys, gs):
+        xd = x.detach().double().requires_grad_(True)
+        ref = torch.nn.functional.conv2d(xd, conv.weight.detach().double(), padding=1)
+        assert y.shape == ref.shape and y.is_contiguous(memory_format=torch.channels_last)
+        assert float((y.detach().double() - ref).abs().max()) <= 3e-6 * float(ref.abs().max())
+        ref.backward(g.double())
+        assert float((x.grad.double() - xd.grad).abs().max()) <= 3e-6 * float(xd.grad.abs().max())
+        gw64 = gw64 + torch.nn.grad.conv2d_weight(x.detach().double(), conv.weight.shape, g.double(), padding=1)
+    assert float((gw.double() - gw64).abs().max()) <= 1e-5 * float(gw64.abs().max())
+    # the map-by-map path: same arithmetic, possibly another tile walk
+    conv.weight.grad = None
+    for x in xs:
+        x.grad = None
+    ys1 = [dense_conv.conv2d(x, conv) for x in xs]
+    for y, y1 in zip(ys, ys1):
+        assert float((y - y1).abs().max()) <= 2e-6 * float(y1.abs().max())
+    # with a bias: added in the kernel's epilogue, its gradient is the sum of the output gradients
+    cb = torch.nn.Conv2d(cin, cout, 3, padding=1).to(DEV)
+    cb.weight.data = conv.weight.data.clone()
+    assert dense_conv.levels_eligible(cb, xs)
+    yb = dense_conv.conv2d_levels(xs, cb)
+    for y, y0 in zip(yb, ys):
+        assert float((y - (y0.detach() + cb.bias.view(1, -1, 1, 1))).abs().max()) <= 1e-6 * float(y0.abs().max())
+    torch.autograd.backward(yb, gs)
+    torch.testing.assert_close(cb.bias.grad, sum(g.sum((0, 2, 3)) for g in gs), rtol=1e-5, atol=1e-4)
+    torch.testing.assert_close(cb.weight.grad, gw, rtol=1e-5, atol=1e-6)
+
+
 @pytest.mark.parametrize('c0,c1,B,H,W', [(64, 64, 2, 37, 45), (128, 128, 2, 31, 22), (256, 256, 1, 30, 20), (64, 128, 1, 41, 33),
                                          (128, 128, 13, 120, 128), (128, 128, 16, 124, 108)])
 @pytest.mark.parametrize('training', [True, False])

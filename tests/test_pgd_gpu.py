@@ -192,8 +192,9 @@ def test_fcos_mono3d_train_step_learns():
 
 
 def test_level_streams_and_prepared_targets_change_nothing(monkeypatch):
-    """The PGD step's two scheduling measures are invisible in the numbers: one stream per FPN level in the head
-    (mono3d_heads.LEVEL_STREAMS) and the target side of the loss computed before the forward pass
+    """The PGD step's scheduling measures are invisible in the numbers: the head layer by layer with one convolution
+    launch over all FPN levels (mono3d_heads.LEVEL_BATCH) or one stream per level (LEVEL_STREAMS), and the target side of
+    the loss computed before the forward pass
     (PGDHead.prepare_loss, with the FPN sizes predicted from the image shape). Losses and gradients of one step with
     both, against one stream and targets computed inside ``loss`` from the actual maps."""
     from gga_amd import Config, build_model, synthetic, mono3d_heads
@@ -211,8 +212,9 @@ def test_level_streams_and_prepared_targets_change_nothing(monkeypatch):
         feats = model.extract_feat(data['img'])
     assert model.bbox_head.featmap_sizes_of(data['img'].shape) == [tuple(f.shape[-2:]) for f in feats]
 
-    def one_step(streams, prepared):
-        monkeypatch.setattr(mono3d_heads, 'LEVEL_STREAMS', streams)
+    def one_step(mode, prepared):
+        monkeypatch.setattr(mono3d_heads, 'LEVEL_BATCH', mode == 'batch')
+        monkeypatch.setattr(mono3d_heads, 'LEVEL_STREAMS', mode == 'streams')
         if not prepared:       # the detector only prepares when the head offers it
             monkeypatch.setattr(type(model.bbox_head), 'prepare_loss_before_forward', False, raising=False)
         else:
@@ -225,12 +227,13 @@ def test_level_streams_and_prepared_targets_change_nothing(monkeypatch):
         return {k: float(v) for k, v in out['log_vars'].items()}, grads
 
     bn_state = {k: v.clone() for k, v in model.state_dict().items()}
-    l1, g1 = one_step(True, True)
-    model.load_state_dict(bn_state)
-    l0, g0 = one_step(False, False)
-    assert l1.keys() == l0.keys()
-    for k in l1:
-        assert abs(l1[k] - l0[k]) <= 1e-5 * abs(l0[k]) + 1e-7, (k, l1[k], l0[k])
-    assert g1.keys() == g0.keys()
-    for n in g1:      # global float atomics (DCN col2im, target scatter) order their additions differently from run to run
-        assert float((g1[n] - g0[n]).abs().max()) <= 2e-4 * float(g0[n].abs().max()) + 1e-7, n
+    l0, g0 = one_step('plain', False)
+    for mode in ('batch', 'streams'):      # the shipped form (one launch over the levels), and one stream per level
+        model.load_state_dict(bn_state)
+        l1, g1 = one_step(mode, True)
+        assert l1.keys() == l0.keys()
+        for k in l1:
+            assert abs(l1[k] - l0[k]) <= 1e-5 * abs(l0[k]) + 1e-7, (mode, k, l1[k], l0[k])
+        assert g1.keys() == g0.keys()
+        for n in g1:  # global float atomics (DCN col2im, target scatter) order their additions differently from run to run
+            assert float((g1[n] - g0[n]).abs().max()) <= 2e-4 * float(g0[n].abs().max()) + 1e-7, (mode, n)

@@ -88,7 +88,7 @@ SIGNATURES = {
     'gga_absmax_bits': (i32, [vp, i64, i32, i64, vp, vp]),
     'gga_dense_conv3x3_pack_planes': (i32, [vp, i64, i64, i64, i64, i32, i32, i32, i32, vp, vp, vp]),
     'gga_dense_conv3x3_planes': (i32, [vp, vp, i32, i32, i32, i32, i32, vp, i64, i32, vp, i32, vp, vp, vp]),
-    'gga_dense_conv3x3_levels': (i32, [i32, vp, vp, vp, vp, i32, i32, i32, vp, i64, i32, vp, vp, vp, i32, vp]),
+    'gga_dense_conv3x3_levels': (i32, [i32, vp, vp, vp, vp, i32, i32, i32, vp, i64, i32, vp, vp, vp, i32, i32, vp, vp]),
     'gga_dense_conv3x3_bn_bwd_pays': (i32, [i32, i32, i32, i32]),
     'gga_dense_conv3x3_bn_bwd': (i32, [vp, vp, i32, i32, i32, i32, i32, vp, i64, i32, vp, i32, vp, vp, vp, i64, vp, vp, vp, vp, vp]),
     'gga_dense_wgrad3x3_planes': (i32, [vp, vp, i32, i32, i32, i32, i32, vp, i64, i64, i64, i64, i32, i32, vp, vp, vp, sz, vp]),

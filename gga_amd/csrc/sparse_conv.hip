@@ -1627,6 +1627,8 @@ struct DcLevels {
     const uint16_t* w[DC_MAX_ENTRIES];
     const uint32_t* amax_x[DC_MAX_ENTRIES];
     const float* bias[DC_MAX_ENTRIES];       // per output channel of the entry, added in the epilogue; null: none
+    double* stats[DC_MAX_ENTRIES];           // the entry's per-tile BatchNorm sums [tiles][2][cout]; null: none
+    int transposed;                          // every entry walks its map transposed (tiles 32 pixels long along the image's H)
 };
 
 template <int NT, int TR, int NP, int MT>
@@ -1643,9 +1645,10 @@ __global__ __launch_bounds__(TR / MT * 64, 2) void dense_conv3x3_x9_kernel(const
         int e = 0;
         while (e + 1 < lv.n && tile >= lv.start[e + 1]) ++e;
         tile -= lv.start[e];
-        X = lv.x[e]; Y = lv.y[e]; Wp = lv.w[e]; amax_x = lv.amax_x[e]; bias = lv.bias[e];
+        X = lv.x[e]; Y = lv.y[e]; Wp = lv.w[e]; amax_x = lv.amax_x[e]; bias = lv.bias[e]; stats = lv.stats[e];
         H = lv.H[e]; W = lv.W[e];
         prow = W; pcol = 1;
+        if (lv.transposed) { prow = 1; pcol = W; const int t_ = H; H = W; W = t_; }      // tile space of the transposed walk
         tiles_x = (W + DC_TW - 1) / DC_TW; tiles_y = (H + TR - 1) / TR;
     }
     // H x W is the tile space (rows x 32-pixel columns); pixel (r, c) of it is pixel r*prow + c*pcol of
@@ -2131,7 +2134,8 @@ extern "C" int gga_dense_conv3x3_bn_bwd(const float* x, const void* split_weight
 extern "C" int gga_dense_conv3x3_levels(int n_entries, const float* const* x, const int32_t* heights, const int32_t* widths,
                                         const void* const* split_weight, int B, int cin, int cout, float* const* y,
                                         int64_t y_pixel_stride, int planes, const uint32_t* const* amax_x,
-                                        const uint32_t* amax_weight, const float* const* bias, int tile_rows, void* stream_) {
+                                        const uint32_t* amax_weight, const float* const* bias, int tile_rows, int transposed,
+                                        double* const* stats, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     GGA_REQUIRE(tile_rows == 8 || (tile_rows == 16 && cout == 128), "gga_dense_conv3x3_levels: tile_rows 8, or 16 with cout 128");
     GGA_REQUIRE(n_entries >= 1 && n_entries <= DC_MAX_ENTRIES, "gga_dense_conv3x3_levels: 1 .. %d entries (got %d)", DC_MAX_ENTRIES,
@@ -2154,10 +2158,13 @@ extern "C" int gga_dense_conv3x3_levels(int n_entries, const float* const* x, co
         lv.x[e] = x[e]; lv.y[e] = y[e]; lv.w[e] = (const uint16_t*)split_weight[e];
         lv.amax_x[e] = planes == 2 ? amax_x[e] : nullptr;
         lv.bias[e] = bias ? bias[e] : nullptr;
-        total += (int64_t)B * ((widths[e] + DC_TW - 1) / DC_TW) * ((heights[e] + tile_rows - 1) / tile_rows);
+        lv.stats[e] = stats ? stats[e] : nullptr;
+        const int th = transposed ? widths[e] : heights[e], tw = transposed ? heights[e] : widths[e];      // tile space
+        total += (int64_t)B * ((tw + DC_TW - 1) / DC_TW) * ((th + tile_rows - 1) / tile_rows);
         GGA_REQUIRE(total < 2147483647ll, "gga_dense_conv3x3_levels: too many tiles");
     }
     lv.start[n_entries] = (int)total;
+    lv.transposed = transposed ? 1 : 0;
     for (int e = n_entries + 1; e <= DC_MAX_ENTRIES; ++e) lv.start[e] = (int)total;
     DcBnBwd bn;
     bn.y = nullptr; bn.gamma = bn.beta = bn.mean = bn.invstd = nullptr; bn.ystride = 0;

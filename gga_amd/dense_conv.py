@@ -221,6 +221,24 @@ def _run(x, weight, backward, want_stats=False, x_amax=None, w_amax=None, y=None
                                          F._p(w_amax), *(bn.part(0, n_out) if bn else none6), F._stream()), 'gga_dense_conv3x3')
         if bn:
             stats = [(0, n_out, stats)]
+    elif bn is None and n_out // 128 <= 16:
+        # every 128-channel slice of the output in ONE launch (gga_dense_conv3x3_levels with the slices as entries): a
+        # 62 x 54 map is 224 tiles per slice - half of what the chip holds at once
+        import ctypes as C
+        n = n_out // 128
+        th, tw = (W, H) if tr else (H, W)
+        rows = 16 if B * _cdiv(tw, 32) * _cdiv(th, 16) >= 384 else 8           # dc_tile_rows of the C side
+        tiles = B * _cdiv(tw, 32) * _cdiv(th, rows)
+        wps = [_pack(weight[:, c0:c0 + 128] if backward else weight[c0:c0 + 128], backward, tr, w_amax) for c0 in range(0, n_out, 128)]
+        sts = [torch.empty((tiles, 2, 128), dtype=torch.float64, device=x.device) for _ in range(n)] if want_stats else None
+        vp, i32 = C.c_void_p * n, C.c_int32 * n
+        check(L.gga_dense_conv3x3_levels(
+            n, vp(*[x.data_ptr()] * n), i32(*[H] * n), i32(*[W] * n), vp(*[w.data_ptr() for w in wps]), B, n_in, 128,
+            vp(*[y.data_ptr() + 4 * (y_col + c0) for c0 in range(0, n_out, 128)]), ystride, planes,
+            vp(*[x_amax.data_ptr()] * n) if planes == 2 else None, F._p(w_amax), None, rows, int(tr),
+            vp(*[t.data_ptr() for t in sts]) if sts else None, F._stream()), 'gga_dense_conv3x3_levels')
+        if sts:
+            stats = torch.cat(sts, dim=2)           # [tiles, 2, n_out]
     else:
         parts = []
         for c0 in range(0, n_out, 128):             # strided views: packed straight from the parameter
@@ -349,7 +367,7 @@ def _run_levels(xs, weight, backward, x_amaxes, w_amax, bias=None):
                 n, vp(*[x.data_ptr() for x, *_ in part]), i32(*[x.shape[2] for x, *_ in part]), i32(*[x.shape[3] for x, *_ in part]),
                 vp(*[wp.data_ptr() for _, _, _, wp, _ in part]), B, n_in, width,
                 vp(*[y.data_ptr() + 4 * c0 for _, y, c0, _, _ in part]), n_out, planes, amax,
-                F._p(w_amax) if planes == 2 else None, bias_p, rows, F._stream()), 'gga_dense_conv3x3_levels')
+                F._p(w_amax) if planes == 2 else None, bias_p, rows, 0, None, F._stream()), 'gga_dense_conv3x3_levels')
     return ys
 
 

@@ -371,12 +371,14 @@ int gga_dense_conv3x3_planes(const float* x, const void* split_weight, int B, in
  * one convolution bring their own operand) into y[e] (pixel stride y_pixel_stride floats). bias (NULL: none): per entry the
  * `cout` bias values of its output channels (NULL entries: none), added in the epilogue - this is also how a single map with
  * a bias is run. tile_rows: 8, or 16 (cout 128 only: the form gga_dense_conv3x3_planes picks for maps with at least 384
- * 16-row tiles - large and small maps go into separate launches); the map as stored; at most 16 entries; no statistics
- * epilogue. */
+ * 16-row tiles - large and small maps go into separate launches); transposed: every entry walks its map transposed (as
+ * gga_dense_conv3x3_slice; split_weight packed accordingly); stats (NULL: none): per entry the f64 [tiles][2][cout]
+ * BatchNorm sums of its output (gga_dense_conv3x3_stats; tiles of the entry = B * ceil(w / 32) * ceil(h / tile_rows) in its
+ * tile space). At most 16 entries. */
 int gga_dense_conv3x3_levels(int n_entries, const float* const* x, const int32_t* heights, const int32_t* widths,
                              const void* const* split_weight, int B, int cin, int cout, float* const* y, int64_t y_pixel_stride,
                              int planes, const uint32_t* const* amax_x, const uint32_t* amax_weight, const float* const* bias,
-                             int tile_rows, void* stream);
+                             int tile_rows, int transposed, double* const* stats, void* stream);
 int gga_dense_conv3x3_bn_bwd_pays(int B, int H, int W, int cout);   /* 1: the epilogue costs less than the reduce pass (H, W of the tile space) */
 int gga_dense_conv3x3_bn_bwd(const float* x, const void* split_weight, int B, int H, int W, int cin, int cout, float* y,
                              int64_t y_pixel_stride, int transposed, double* stats, int planes, const uint32_t* amax_x,

@@ -700,7 +700,9 @@ def test_dense_conv3x3_vs_torch(cin, cout, B, H, W, planes, monkeypatch):
 
 
 @pytest.mark.parametrize('cin,cout,B,H,W', [(64, 64, 3, 37, 45), (64, 128, 2, 37, 45), (128, 128, 2, 31, 22),
-                                           (128, 128, 12, 128, 128), (128, 128, 16, 124, 108)])
+                                           (128, 128, 12, 128, 128), (128, 128, 16, 124, 108),
+                                           # 256 output channels: both 128-channel slices in one launch, straight and transposed
+                                           (128, 256, 2, 37, 45), (256, 256, 4, 62, 54)])
 def test_dense_conv_leaves_batchnorm_partials(cin, cout, B, H, W):
     """The statistics epilogue of the dense conv equals the reductions of its output, and the
     BatchNorm fed with them equals the BatchNorm that reduces y itself - 64 and 128 output channels,

@@ -60,6 +60,7 @@ def distance2bbox(points, distance, max_shape=None):
     return torch.stack([x1, y1, x2, y2], -1)
 
 
+_LEVEL_STREAM_CACHE = {}
 LEVEL_STREAMS = True      # PGDHead.forward: one stream per FPN level (when LEVEL_BATCH is off)
 LEVEL_BATCH = False       # PGDHead.forward: layer by layer over all levels, weight-sharing convolutions as one launch over the
                           # maps (measured: 145 ms per head forward + backward against 135 with LEVEL_STREAMS - the largest
@@ -435,12 +436,12 @@ class PGDHead(FCOSMono3DHead):
                                                      self.pred_keypoints, self.pred_bbox2d)
         return cls_score, bbox_pred, dir_cls_pred, depth_cls_pred, weight, attr_pred, centerness
 
-    def _level_streams(self, n, device, main):
-        key = (str(device), n)
-        cache = self.__dict__.setdefault('_streams', {})
-        if key not in cache:
-            cache[key] = [torch.cuda.Stream(device=device) for _ in range(n - 1)]
-        return [main] + cache[key]                 # the largest level stays on the caller's stream
+    @staticmethod
+    def _level_streams(n, device, main):
+        key = (str(device), n)                     # per process, not per module: a module must stay copyable / picklable
+        if key not in _LEVEL_STREAM_CACHE:
+            _LEVEL_STREAM_CACHE[key] = [torch.cuda.Stream(device=device) for _ in range(n - 1)]
+        return [main] + _LEVEL_STREAM_CACHE[key]   # the largest level stays on the caller's stream
 
     def forward_single(self, x, scale, stride):
         cls_score, bbox_pred, dir_cls_pred, attr_pred, centerness, cls_feat, reg_feat = self._forward_fcos(x, scale, stride)

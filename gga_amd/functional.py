@@ -927,10 +927,21 @@ class _HeadBranches(torch.autograd.Function):
         tiles = int(L.gga_dense_conv3x3_tiles(B, W, H, C) if tr else L.gga_dense_conv3x3_tiles(B, H, W, C))
         outs, saved_all, ss_all = [], [], []
         x_amax = dense_conv.tensor_amax(x) if dense_conv.PLANES == 2 else None     # from x's producer, for all n convolutions
+        # the first convolutions two branches at a time (64 -> 128 channels into adjacent column blocks of Y): the
+        # 128-channel form of the kernel stages and splits the shared input once for both
+        pair_stats = {}
+        for i in range(0, n - 1, 2):
+            wpair = torch.cat([w1[i].detach(), w1[i + 1].detach()], dim=0)
+            _, st = dense_conv._run(x, wpair, False, True, x_amax, None, Y, C * i)
+            pair_stats[i], pair_stats[i + 1] = st[:, :, :C].contiguous(), st[:, :, C:].contiguous()
         for i in range(n):
             eps, momentum = cfg[i]
-            _, st = dense_conv._run(x, w1[i].detach(), False, True, x_amax, None, Y, C * i)
+            if i in pair_stats:
+                st = pair_stats[i]
+            else:
+                _, st = dense_conv._run(x, w1[i].detach(), False, True, x_amax, None, Y, C * i)
             stats = st
+            tiles = int(st.shape[0])
             saved = torch.empty(2 * C, dtype=torch.float32, device=dev)
             ss = torch.empty(2 * C, dtype=torch.float32, device=dev)
             check(L.gga_bn_stats_partials(_p(gam[i]), _p(bet[i]), _p(rm[i]), _p(rv[i]), rows, C, eps, momentum, _p(saved), _p(ss),

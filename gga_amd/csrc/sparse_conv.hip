@@ -2312,6 +2312,27 @@ __global__ __launch_bounds__(256, 2) void dense_wgrad3x3_x9_kernel(const float* 
             DW_FRAG(g0, gbase + (16 * s) * 64);
             DW_FRAG(g1, gbase + DW_GPL + (16 * s) * 64);
             if (NP == 3) { DW_FRAG(g2, gbase + (NP - 1) * DW_GPL + (16 * s) * 64); } else g2 = g1;
+            if (NP == 2) {
+                // three taps (one kernel row) at a time, the three partial products interleaved over the taps: consecutive
+                // MFMAs never write the same accumulator (tap by tap with the three products back to back: 254 instead of
+                // 233 us at 64 -> 64, 16 x 248 x 216; 202 -> 197 at 128 -> 128)
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    Frag b0[3], b1[3];
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const unsigned char* xb = Xs + ((y + ky - 1 + 4) & 3) * DW_XROW + ti * (34 * 64) + (16 * s + kx) * 64;
+                        DW_FRAG(b0[kx], xb);
+                        DW_FRAG(b1[kx], xb + DW_XPL);
+                    }
+#define DW_MI(A_, G_, T_) acc[T_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(mf_v8h, A_.v), __builtin_bit_cast(mf_v8h, G_.v), acc[T_], 0, 0, 0);
+                    DW_MI(b0[0], g1, 3 * ky) DW_MI(b0[1], g1, 3 * ky + 1) DW_MI(b0[2], g1, 3 * ky + 2)
+                    DW_MI(b1[0], g0, 3 * ky) DW_MI(b1[1], g0, 3 * ky + 1) DW_MI(b1[2], g0, 3 * ky + 2)
+                    DW_MI(b0[0], g0, 3 * ky) DW_MI(b0[1], g0, 3 * ky + 1) DW_MI(b0[2], g0, 3 * ky + 2)
+#undef DW_MI
+                }
+                continue;
+            }
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 const int ky = tap / 3, kx = tap - ky * 3;

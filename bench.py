@@ -113,9 +113,10 @@ def run_workload(config, batch, steps, warmup, args, rank, world, device, sites=
     import torch
     import torch.distributed as dist
     from gga_amd import Config, build_model, synthetic, _lib
-    from gga_amd.train import Runner
+    from gga_amd.train import Runner, setup_multi_processes
 
     cfg = Config.fromfile(config)
+    setup_multi_processes(cfg)          # as tools/train.py:127 does before it builds the model
     channels_last = not args.nchw
     if channels_last and cfg.model.pts_middle_encoder.type in ('PointPillarsScatter', 'SparseEncoder'):
         cfg.model.pts_middle_encoder['channels_last'] = True
@@ -175,8 +176,9 @@ def run_mono_workload(batch, steps, warmup, args, rank, world, device):
     import torch.distributed as dist
     from gga_amd import Config, build_model, synthetic
     from gga_amd.cnn import to_channels_last
-    from gga_amd.train import Runner
+    from gga_amd.train import Runner, setup_multi_processes
     cfg = Config.fromfile(PGD_CONFIG)
+    setup_multi_processes(cfg)
     torch.manual_seed(0)
     model = build_model(cfg.model).to(device)
     model.bbox_head.init_weights()

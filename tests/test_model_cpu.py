@@ -238,3 +238,30 @@ def test_pgd_config_equals_reference_and_builds():
     s = StepSchedule(1.0, [32, 44], iters_per_epoch=100, warmup='linear', warmup_iters=500, warmup_ratio=1 / 3)
     assert s(0) == pytest.approx(1 / 3) and s(250) == pytest.approx(2 / 3) and s(500) == 1.0
     assert s(3199) == 1.0 and s(3200) == pytest.approx(0.1) and s(4400) == pytest.approx(0.01)
+
+
+def test_setup_multi_processes_like_the_reference(monkeypatch):
+    """mmdet3d/utils/setup_env.py:10-53 (tests/test_utils/test_setup_env.py): with more than one data-loader worker per GPU
+    OMP_NUM_THREADS / MKL_NUM_THREADS default to 1 per process, an existing setting is kept, one worker changes nothing."""
+    import torch
+    from gga_amd import Config
+    from gga_amd.train import setup_multi_processes
+    before = torch.get_num_threads()
+    try:
+        monkeypatch.delenv('OMP_NUM_THREADS', raising=False)
+        monkeypatch.delenv('MKL_NUM_THREADS', raising=False)
+        setup_multi_processes(Config(dict(data=dict(workers_per_gpu=1))))
+        assert 'OMP_NUM_THREADS' not in os.environ and 'MKL_NUM_THREADS' not in os.environ
+        monkeypatch.setenv('OMP_NUM_THREADS', '4')
+        setup_multi_processes(Config(dict(data=dict(workers_per_gpu=2))))
+        assert os.environ['OMP_NUM_THREADS'] == '4' and os.environ['MKL_NUM_THREADS'] == '1'
+        monkeypatch.delenv('OMP_NUM_THREADS')
+        monkeypatch.delenv('MKL_NUM_THREADS')
+        setup_multi_processes(Config(dict(data=dict(workers_per_gpu=1, train_dataloader=dict(workers_per_gpu=4)))))
+        assert os.environ['OMP_NUM_THREADS'] == '1' and os.environ['MKL_NUM_THREADS'] == '1' and torch.get_num_threads() == 1
+    finally:
+        limit = getattr(setup_multi_processes, '_blas_limit', None)
+        if limit is not None:
+            limit.restore_original_limits()
+            setup_multi_processes._blas_limit = None
+        torch.set_num_threads(before)

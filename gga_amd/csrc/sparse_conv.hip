@@ -828,7 +828,7 @@ __global__ __launch_bounds__(64 * X9_NW) void sp_conv_x9_kernel(const float* __r
                                                         int kvol, int cin, int cout, int flip,
                                                         float* __restrict__ Y, int64_t ys,
                                                         const uint32_t* __restrict__ amax_x,
-                                                        const uint32_t* __restrict__ amax_w) {
+                                                        const uint32_t* __restrict__ amax_w, double* __restrict__ stats) {
     // NP = 3: bf16 planes, six partial products; NP = 2: fp16 planes of the scaled operands, three (h2_split2)
     constexpr int CO = NT * 32;
     constexpr int BPL = CO * X9_ROWB;                     // bytes per B plane
@@ -992,6 +992,9 @@ __global__ __launch_bounds__(64 * X9_NW) void sp_conv_x9_kernel(const float* __r
     int* prow = reinterpret_cast<int*>(Bs);
     if (h == 0) prow[wave * 32 + r] = pr;
     __syncthreads();
+    float s1[NT], s2[NT];                                  // per-column sums of the lane's 16 rows (stats)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { s1[t] = 0.0f; s2[t] = 0.0f; }
 #pragma unroll
     for (int v = 0; v < 16; ++v) {
         const int lr = wave * 32 + (v >> 2) * 8 + h * 4 + (v & 3);
@@ -1001,6 +1004,29 @@ __global__ __launch_bounds__(64 * X9_NW) void sp_conv_x9_kernel(const float* __r
         for (int t = 0; t < NT; ++t) {
             const int o = t * 32 + r;
             if (o < cout) Y[(int64_t)po * ys + o] = acc[t][v];
+            s1[t] += acc[t][v]; s2[t] += acc[t][v] * acc[t][v];
+        }
+    }
+    if (stats) {
+        // per-channel sum and sum of squares of the workgroup's rows (the batch statistics of the BatchNorm that follows,
+        // as in the dense kernel): [workgroup][2][cout] f64
+        __syncthreads();                                  // prow (in Bs) has been read by every wave
+        float* red = reinterpret_cast<float*>(Bs);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            s1[t] += __shfl_xor(s1[t], 32);
+            s2[t] += __shfl_xor(s2[t], 32);
+            if (h == 0) { red[(wave * 2 + 0) * CO + t * 32 + r] = s1[t]; red[(wave * 2 + 1) * CO + t * 32 + r] = s2[t]; }
+        }
+        __syncthreads();
+        if (tid < 2 * CO) {
+            const int which = tid / CO, c = tid - which * CO;
+            if (c < cout) {
+                double a = 0.0;
+#pragma unroll
+                for (int w_ = 0; w_ < NW; ++w_) a += (double)red[(w_ * 2 + which) * CO + c];
+                stats[((int64_t)blockIdx.x * 2 + which) * cout + c] = a;
+            }
         }
     }
 }
@@ -1016,6 +1042,16 @@ extern "C" int gga_sparse_conv_apply_planes(const float* x, const int32_t* map, 
                                             const uint32_t* rowmask, int64_t n_rows, int kvol, int cin, int cout, int flip,
                                             float* y, int64_t y_row_stride, int planes, const uint32_t* amax_x,
                                             const uint32_t* amax_weight, void* stream_) {
+    return gga_sparse_conv_apply_stats(x, map, split_weight, perm, rowmask, n_rows, kvol, cin, cout, flip, y, y_row_stride, planes,
+                                       amax_x, amax_weight, nullptr, stream_);
+}
+
+extern "C" int64_t gga_sparse_conv_apply_tiles(int64_t n_rows) { return (n_rows + X9_TM - 1) / X9_TM; }
+
+extern "C" int gga_sparse_conv_apply_stats(const float* x, const int32_t* map, const void* split_weight, const int32_t* perm,
+                                           const uint32_t* rowmask, int64_t n_rows, int kvol, int cin, int cout, int flip,
+                                           float* y, int64_t y_row_stride, int planes, const uint32_t* amax_x,
+                                           const uint32_t* amax_weight, double* stats, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     GGA_REQUIRE(x && map && split_weight && y, "gga_sparse_conv_apply_split: null pointer argument");
     GGA_REQUIRE(planes == 3 || (planes == 2 && amax_x && amax_weight),
@@ -1026,8 +1062,8 @@ extern "C" int gga_sparse_conv_apply_planes(const float* x, const int32_t* map, 
     const dim3 grid((unsigned)((n_rows + X9_TM - 1) / X9_TM)), block(64 * X9_NW);
     hipEvent_t* tev = gga_timing_acquire(GGA_TIME_SPARSE_CONV, GGA_TIMING_CONV_KEY(cin, cout, 0));
     GGA_TIME_START(tev, stream);
-#define X9_LAUNCH(NT, VEC) { if (planes == 3) hipLaunchKernelGGL((sp_conv_x9_kernel<NT, VEC, 3>), grid, block, 0, stream, x, map, (const uint16_t*)split_weight, perm, rowmask, n_rows, kvol, cin, cout, flip, y, y_row_stride, amax_x, amax_weight); \
-                             else hipLaunchKernelGGL((sp_conv_x9_kernel<NT, VEC, 2>), grid, block, 0, stream, x, map, (const uint16_t*)split_weight, perm, rowmask, n_rows, kvol, cin, cout, flip, y, y_row_stride, amax_x, amax_weight); }
+#define X9_LAUNCH(NT, VEC) { if (planes == 3) hipLaunchKernelGGL((sp_conv_x9_kernel<NT, VEC, 3>), grid, block, 0, stream, x, map, (const uint16_t*)split_weight, perm, rowmask, n_rows, kvol, cin, cout, flip, y, y_row_stride, amax_x, amax_weight, stats); \
+                             else hipLaunchKernelGGL((sp_conv_x9_kernel<NT, VEC, 2>), grid, block, 0, stream, x, map, (const uint16_t*)split_weight, perm, rowmask, n_rows, kvol, cin, cout, flip, y, y_row_stride, amax_x, amax_weight, stats); }
     if ((cin & 3) == 0) {
         switch (mf_nt(cout)) {
             case 1: X9_LAUNCH(1, true); break;

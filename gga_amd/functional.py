@@ -692,6 +692,7 @@ class _BNActCat(torch.autograd.Function):
     def forward(ctx, n, cfg, *args):
         xs, gammas, betas = args[:n], args[n:2 * n], args[2 * n:3 * n]
         rms, rvs = args[3 * n:4 * n], args[4 * n:5 * n]
+        partials = args[5 * n:6 * n]                  # per branch: the producer's per-channel sums of x, or None
         L = _lib.lib()
         x0 = xs[0]
         dev = x0.device
@@ -710,9 +711,11 @@ class _BNActCat(torch.autograd.Function):
             saved = torch.empty(2 * C, dtype=torch.float32, device=dev)
             bits = torch.empty(L.gga_bn_relu_mask_bytes(rows, C), dtype=torch.uint8, device=dev)
             ws = _workspace('bn', L.gga_bn_relu_workspace_bytes(rows, C), dev)
+            pt = partials[i] if (training and partials[i] is not None) else None
             check(L.gga_bn_relu_fwd_ex(_p(xs[i]), None, _p(gammas[i]), _p(betas[i]), _p(rms[i]), _p(rvs[i]), rows, C,
                                        eps, momentum, int(training), 1, out.data_ptr() + 4 * off, tot, _p(bits),
-                                       _p(saved), None, 0, _p(amax), _p(ws), ws.numel(), _stream()), 'gga_bn_relu_fwd_strided')
+                                       _p(saved), _p(pt), int(pt.shape[0]) if pt is not None else 0, _p(amax), _p(ws), ws.numel(),
+                                       _stream()), 'gga_bn_relu_fwd_strided')
             saved_all.append(saved)
             bits_all.append(bits)
             off += C
@@ -759,7 +762,7 @@ class _BNActCat(torch.autograd.Function):
             dense_conv.set_amax(gx, amax)
             gxs.append(gx), ggs.append(gg), gbs.append(gb)
             off += C
-        return (None, None, *gxs, *ggs, *gbs) + (None,) * (2 * n)
+        return (None, None, *gxs, *ggs, *gbs) + (None,) * (3 * n)
 
 
 def bn_relu_cat(xs, bns):
@@ -780,8 +783,11 @@ def bn_relu_cat(xs, bns):
             bn.num_batches_tracked += 1
     n = len(xs)
     cfg = tuple((float(bn.eps), float(bn.momentum), bool(bn.training)) for bn in bns)
+    def sums(x):        # the producer's per-channel sums (dense_conv / strided_conv / sparse convolutions), if it left them
+        p = getattr(x, 'bn_partials', None)
+        return p if (p is not None and p.dim() == 3 and p.shape[2] == x.shape[1] and p.shape[0] >= 1) else None
     out, amax, *saved = _BNActCat.apply(n, cfg, *xs, *[bn.weight for bn in bns], *[bn.bias for bn in bns],
-                                        *[bn.running_mean for bn in bns], *[bn.running_var for bn in bns])
+                                        *[bn.running_mean for bn in bns], *[bn.running_var for bn in bns], *[sums(x) for x in xs])
     from . import dense_conv
     if amax.numel():
         dense_conv.set_amax(out, amax)

@@ -55,18 +55,20 @@ class _PillarConv2d(torch.autograd.Function):
             B, Ci, ny, nx = canvas.shape
             bk = strided_conv.book(B, ny, nx, kh, stride[0], padding[0], canvas.device)
             # the canvas holds the pillar features and zeros: its largest magnitude is theirs (16 MB instead of 877 MB)
-            y = strided_conv._apply(strided_conv._rows(canvas), bk.fwd, bk.fwd_mask, bk.fwd_perm,
-                                    weight.detach().permute(2, 3, 1, 0).reshape(kh * kw, Ci, -1), bk.n_out,
-                                    strided_conv._amax(feats.detach().contiguous()))
+            y, stats = strided_conv._apply(strided_conv._rows(canvas), bk.fwd, bk.fwd_mask, bk.fwd_perm,
+                                           weight.detach().permute(2, 3, 1, 0).reshape(kh * kw, Ci, -1), bk.n_out,
+                                           strided_conv._amax(feats.detach().contiguous()), want_stats=True)
             y = y.view(B, bk.Ho, bk.Wo, -1).permute(0, 3, 1, 2)
         else:
             y = torch.conv2d(canvas, weight, None, stride, padding)
+            stats = torch.empty(0, dtype=torch.float64, device=y.device)
         ctx.save_for_backward(feats, weight, coors, num_valid)
         ctx.geom = (tuple(canvas.shape), stride, padding)
-        return y
+        ctx.mark_non_differentiable(stats)
+        return y, stats
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, _gstats=None):
         from .sparse import _Rulebook, _conv_apply, _pack_weight, conv_wgrad
         feats, w, coors, num_valid = ctx.saved_tensors
         (B, Ci, ny, nx), (sh, sw), (ph, pw) = ctx.geom
@@ -97,5 +99,8 @@ def pillar_conv2d(canvas, conv):
     features directly (the scatter's own backward is bypassed) and to ``conv.weight``."""
     sup = canvas.pillar_support
     coors = sup.coors if sup.coors.dtype == torch.int32 else sup.coors.int()
-    return _PillarConv2d.apply(sup.feats, conv.weight, canvas.detach(), coors.contiguous(), sup.num_valid,
-                               tuple(conv.stride), tuple(conv.padding))
+    y, stats = _PillarConv2d.apply(sup.feats, conv.weight, canvas.detach(), coors.contiguous(), sup.num_valid,
+                                   tuple(conv.stride), tuple(conv.padding))
+    if stats.numel():
+        y.bn_partials = stats       # per-channel sums of y for the BatchNorm that follows (functional.bn_act)
+    return y

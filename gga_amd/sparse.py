@@ -287,13 +287,14 @@ def _pack_weight(w, kvol, cin, cout, transpose, split=None, w_amax=None):
     return wp
 
 
-def _conv_apply(x, rb, wp, n_rows, kvol, cin, cout, flip, y, x_amax=None, w_amax=None):
-    """``x_amax`` / ``w_amax`` given: ``wp`` holds two fp16 planes (packed with the same ``w_amax``)."""
+def _conv_apply(x, rb, wp, n_rows, kvol, cin, cout, flip, y, x_amax=None, w_amax=None, stats=None):
+    """``x_amax`` / ``w_amax`` given: ``wp`` holds two fp16 planes (packed with the same ``w_amax``). ``stats``: f64
+    [gga_sparse_conv_apply_tiles(n_rows), 2, cout] for the per-channel sums of y (split-plane kernels only)."""
     L = _lib.lib()
     if wp.dtype == torch.int16:
-        check(L.gga_sparse_conv_apply_planes(F._p(x), F._p(rb.nbr), F._p(wp), F._p(rb.perm), F._p(rb.mask), n_rows,
-                                             kvol, cin, cout, flip, F._p(y), cout, 2 if w_amax is not None else 3, F._p(x_amax),
-                                             F._p(w_amax), F._stream()), 'gga_sparse_conv_apply_split')
+        check(L.gga_sparse_conv_apply_stats(F._p(x), F._p(rb.nbr), F._p(wp), F._p(rb.perm), F._p(rb.mask), n_rows,
+                                            kvol, cin, cout, flip, F._p(y), cout, 2 if w_amax is not None else 3, F._p(x_amax),
+                                            F._p(w_amax), F._p(stats), F._stream()), 'gga_sparse_conv_apply_split')
     else:
         check(L.gga_sparse_conv_apply(F._p(x), F._p(rb.nbr), F._p(wp), F._p(rb.perm), F._p(rb.mask), n_rows, kvol, cin, cout,
                                       flip, F._p(y), F._stream()), 'gga_sparse_conv_apply')
@@ -329,13 +330,20 @@ class _SparseConvFn(torch.autograd.Function):
         two = SPLIT_BF16 and planes() == 2
         x_amax = amax_bits(feats) if two else None
         w_amax = amax_bits(w.detach()) if two else None
-        _conv_apply(feats, rb, _pack_weight(w, kvol, cin, cout, 0, w_amax=w_amax), n_out, kvol, cin, cout, 0, y, x_amax, w_amax)
+        # the per-channel sums of y for the BatchNorm that follows (split-plane kernels; widths the fused BatchNorm takes)
+        stats = None
+        if SPLIT_BF16 and cout % 4 == 0 and cout <= 128 and n_out >= 1:
+            stats = torch.empty((int(_lib.lib().gga_sparse_conv_apply_tiles(n_out)), 2, cout), dtype=torch.float64, device=feats.device)
+        _conv_apply(feats, rb, _pack_weight(w, kvol, cin, cout, 0, w_amax=w_amax), n_out, kvol, cin, cout, 0, y, x_amax, w_amax, stats)
         ctx.save_for_backward(feats, w)
         ctx.rb, ctx.rb_t, ctx.amax = rb, rb_t, (x_amax, w_amax)
-        return y
+        if stats is None:
+            stats = torch.empty(0, dtype=torch.float64, device=feats.device)
+        ctx.mark_non_differentiable(stats)
+        return y, stats
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, _gstats=None):
         feats, w = ctx.saved_tensors
         rb, rb_t = ctx.rb, ctx.rb_t
         gy = gy.contiguous()
@@ -401,6 +409,12 @@ class SparseConvolution(SparseModule):
         reference installation that runs on spconv 2)."""
         return self.weight.detach().permute(4, 0, 1, 2, 3).contiguous()
 
+    def _run(self, feats, w, rb, rb_t, n_out):
+        y, stats = _SparseConvFn.apply(feats, w, rb, rb_t, n_out)
+        if stats.numel() and self.bias is None:
+            y.bn_partials = stats       # per-channel sums of y for the BatchNorm that follows (functional.bn_act)
+        return y
+
     def forward(self, x):
         assert isinstance(x, SparseConvTensor)
         lvl = x._level
@@ -410,7 +424,7 @@ class SparseConvolution(SparseModule):
             if lvl.n == 0:
                 y = empty(0)
             else:
-                y = _SparseConvFn.apply(x.features, w, lvl.subm_rulebook(self.kernel_size), None, lvl.n)
+                y = self._run(x.features, w, lvl.subm_rulebook(self.kernel_size), None, lvl.n)
             out = x.replace_feature(y)
         else:
             cached = x.indice_dict.get(self.indice_key) if self.indice_key else None
@@ -423,7 +437,7 @@ class SparseConvolution(SparseModule):
                 if self.indice_key:
                     x.indice_dict[self.indice_key] = cached
             _, out_lvl, nbr, nbr_t = cached
-            y = empty(0) if out_lvl.n == 0 else _SparseConvFn.apply(x.features, w, nbr, nbr_t, out_lvl.n)
+            y = empty(0) if out_lvl.n == 0 else self._run(x.features, w, nbr, nbr_t, out_lvl.n)
             out = SparseConvTensor(y, out_lvl.coors, out_lvl.shape, x.batch_size, _level=out_lvl)
             out.indice_dict = x.indice_dict
         if self.bias is not None:

@@ -83,9 +83,10 @@ def _amax(t):
     return dense_conv.tensor_amax(t) if dense_conv.PLANES == 2 else None
 
 
-def _apply(x_rows, m, mask, perm, w_kio, n_rows, x_amax=None, w_amax=None):
+def _apply(x_rows, m, mask, perm, w_kio, n_rows, x_amax=None, w_amax=None, want_stats=False):
     """y [n_rows, cout] = sum_k x_rows[m[k]] @ w_kio[k]  (w_kio [kvol, cin, cout]). ``x_amax`` / ``w_amax``: absmax
-    bits of the operands (two-plane arithmetic), computed here when missing."""
+    bits of the operands (two-plane arithmetic), computed here when missing. ``want_stats``: also return the f64
+    [workgroups, 2, cout] per-channel sums of y for the BatchNorm that follows (``gga_sparse_conv_apply_stats``)."""
     L = _lib.lib()
     kvol, cin, cout = w_kio.shape
     planes = _planes()
@@ -95,14 +96,21 @@ def _apply(x_rows, m, mask, perm, w_kio, n_rows, x_amax=None, w_amax=None):
     else:
         x_amax = w_amax = None
     y = torch.empty((n_rows, cout), dtype=torch.float32, device=x_rows.device)
+    tiles = int(L.gga_sparse_conv_apply_tiles(n_rows)) if want_stats else 0
+    parts = []
     for c0 in range(0, cout, 128):
         c1 = min(c0 + 128, cout)
         wp = torch.empty(L.gga_sparse_split_weight_bytes(kvol, cin, c1 - c0) // 2, dtype=torch.int16, device=y.device)
         check(L.gga_sparse_pack_weight_planes(F._p(w_kio[:, :, c0:c1].contiguous()), kvol, cin, c1 - c0, 0, planes, F._p(w_amax),
                                               F._p(wp), F._stream()), 'gga_sparse_pack_weight_split')
-        check(L.gga_sparse_conv_apply_planes(F._p(x_rows), F._p(m), F._p(wp), F._p(perm), F._p(mask), n_rows, kvol, cin,
-                                             c1 - c0, 0, y.data_ptr() + 4 * c0, cout, planes, F._p(x_amax), F._p(w_amax),
-                                             F._stream()), 'gga_sparse_conv_apply_split_strided')
+        st = torch.empty((tiles, 2, c1 - c0), dtype=torch.float64, device=y.device) if want_stats else None
+        check(L.gga_sparse_conv_apply_stats(F._p(x_rows), F._p(m), F._p(wp), F._p(perm), F._p(mask), n_rows, kvol, cin,
+                                            c1 - c0, 0, y.data_ptr() + 4 * c0, cout, planes, F._p(x_amax), F._p(w_amax),
+                                            F._p(st), F._stream()), 'gga_sparse_conv_apply_split_strided')
+        if want_stats:
+            parts.append(st)
+    if want_stats:
+        return y, (parts[0] if len(parts) == 1 else torch.cat(parts, dim=2))
     return y
 
 
@@ -141,13 +149,15 @@ class _StridedConv(torch.autograd.Function):
         bk = book(B, H, W, k, s, p, x.device)
         w = weight.detach()
         x_amax, w_amax = _amax(x), _amax(w)
-        y = _apply(_rows(x), bk.fwd, bk.fwd_mask, bk.fwd_perm, w.permute(2, 3, 1, 0).reshape(k * k, cin, -1), bk.n_out, x_amax, w_amax)
+        y, stats = _apply(_rows(x), bk.fwd, bk.fwd_mask, bk.fwd_perm, w.permute(2, 3, 1, 0).reshape(k * k, cin, -1), bk.n_out,
+                          x_amax, w_amax, want_stats=True)
         ctx.save_for_backward(x, weight)
         ctx.geom, ctx.amax = (k, s, p), (x_amax, w_amax)
-        return y.view(B, bk.Ho, bk.Wo, -1).permute(0, 3, 1, 2)
+        ctx.mark_non_differentiable(stats)
+        return y.view(B, bk.Ho, bk.Wo, -1).permute(0, 3, 1, 2), stats
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, _gstats=None):
         x, weight = ctx.saved_tensors
         k, s, p = ctx.geom
         B, cin, H, W = x.shape
@@ -177,13 +187,15 @@ class _Deconv(torch.autograd.Function):
         bk = book(B, H * s, W * s, s, s, 0, x.device)          # fwd [s*s, n_coarse] fine pixel; bwd [s*s, n_fine] coarse pixel
         w = weight.detach()
         x_amax, w_amax = _amax(x), _amax(w)
-        y = _apply(_rows(x), bk.bwd, bk.bwd_mask, bk.bwd_perm, w.permute(2, 3, 0, 1).reshape(s * s, cin, -1), bk.n_in, x_amax, w_amax)
+        y, stats = _apply(_rows(x), bk.bwd, bk.bwd_mask, bk.bwd_perm, w.permute(2, 3, 0, 1).reshape(s * s, cin, -1), bk.n_in,
+                          x_amax, w_amax, want_stats=True)
         ctx.save_for_backward(x, weight)
         ctx.s, ctx.amax = s, (x_amax, w_amax)
-        return y.view(B, H * s, W * s, -1).permute(0, 3, 1, 2)
+        ctx.mark_non_differentiable(stats)
+        return y.view(B, H * s, W * s, -1).permute(0, 3, 1, 2), stats
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, _gstats=None):
         x, weight = ctx.saved_tensors
         s = ctx.s
         B, cin, H, W = x.shape
@@ -223,7 +235,11 @@ def eligible(m, x):
 
 
 def conv(x, m):
-    """``m(x)`` for an eligible Conv2d / ConvTranspose2d module."""
+    """``m(x)`` for an eligible Conv2d / ConvTranspose2d module; the result carries the per-channel sums of its values
+    (``y.bn_partials``) that ``functional.bn_act`` uses instead of a reduce pass of its own."""
     if type(m) is nn.Conv2d:
-        return _StridedConv.apply(x, m.weight, m.kernel_size[0], m.stride[0], m.padding[0])
-    return _Deconv.apply(x, m.weight, m.stride[0])
+        y, stats = _StridedConv.apply(x, m.weight, m.kernel_size[0], m.stride[0], m.padding[0])
+    else:
+        y, stats = _Deconv.apply(x, m.weight, m.stride[0])
+    y.bn_partials = stats
+    return y

@@ -349,6 +349,15 @@ int gga_sparse_conv_apply_planes(const float* x, const int32_t* map, const void*
                                  const uint32_t* rowmask, int64_t n_rows, int kvol, int cin, int cout, int flip, float* y,
                                  int64_t y_row_stride, int planes, const uint32_t* amax_x, const uint32_t* amax_weight,
                                  void* stream);
+/* gga_sparse_conv_apply_planes that also leaves the per-channel sums of its output for the BatchNorm that follows
+ * (ops/sparse_block.py:117-134, backbones/second.py:49-57, necks/second_fpn.py:52-69: conv -> BN -> ReLU): stats
+ * [gga_sparse_conv_apply_tiles(n_rows)][2][cout] f64 = per workgroup of 128 rows the sum and the sum of squares - the
+ * partials gga_bn_relu_fwd_ex takes. stats == NULL: exactly gga_sparse_conv_apply_planes. */
+int64_t gga_sparse_conv_apply_tiles(int64_t n_rows);
+int gga_sparse_conv_apply_stats(const float* x, const int32_t* map, const void* split_weight, const int32_t* perm,
+                                const uint32_t* rowmask, int64_t n_rows, int kvol, int cin, int cout, int flip, float* y,
+                                int64_t y_row_stride, int planes, const uint32_t* amax_x, const uint32_t* amax_weight,
+                                double* stats, void* stream);
 int gga_sparse_conv_wgrad_planes(const float* x, int64_t x_row_stride, const float* grad_out, int64_t grad_out_row_stride,
                                  const int32_t* nbr, int64_t n_rows, int kvol, int cin, int cout, float* grad_weight,
                                  int planes, const uint32_t* amax_x, const uint32_t* amax_grad_out, void* workspace,

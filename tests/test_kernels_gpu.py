@@ -734,6 +734,38 @@ def test_dense_conv_leaves_batchnorm_partials(cin, cout, B, H, W):
     assert conv.weight.grad is not None and torch.isfinite(conv.weight.grad).all()
 
 
+@pytest.mark.parametrize('kind,cin,cout,k,s,B,H,W', [('conv', 64, 128, 3, 2, 2, 37, 45), ('conv', 128, 256, 3, 2, 2, 24, 30),
+                                                      ('deconv', 128, 128, 2, 2, 2, 19, 23), ('deconv', 64, 128, 1, 1, 2, 37, 45)])
+def test_gather_convs_leave_batchnorm_partials(kind, cin, cout, k, s, B, H, W):
+    """The strided / transposed convolutions (gather-GEMM kernel, gga_sparse_conv_apply_stats) hand the BatchNorm that
+    follows the per-channel sums of their output: equal to the reductions of y, and the BatchNorm fed with them equals the
+    BatchNorm that reduces y itself."""
+    import copy
+    from gga_amd import strided_conv
+    torch.manual_seed(11)
+    if kind == 'conv':
+        m = torch.nn.Conv2d(cin, cout, k, stride=s, padding=k // 2, bias=False).to(DEV)
+    else:
+        m = torch.nn.ConvTranspose2d(cin, cout, k, stride=s, bias=False).to(DEV)
+    bn = torch.nn.BatchNorm2d(cout, eps=1e-3, momentum=0.01).to(DEV)
+    bn2 = copy.deepcopy(bn)
+    x = torch.randn(B, cin, H, W, device=DEV).contiguous(memory_format=torch.channels_last)
+    assert strided_conv.eligible(m, x)
+    y = strided_conv.conv(x, m)
+    p = y.bn_partials
+    assert p.dtype == torch.float64 and p.dim() == 3 and p.shape[1:] == (2, cout)
+    yd = y.detach().double()
+    mag = float(yd.abs().sum((0, 2, 3)).max())
+    torch.testing.assert_close(p[:, 0].sum(0), yd.sum((0, 2, 3)), rtol=0, atol=2e-6 * mag)
+    torch.testing.assert_close(p[:, 1].sum(0), (yd * yd).sum((0, 2, 3)), rtol=2e-6, atol=0)
+    out = F.bn_act(y, bn, relu=True)
+    ref = F.bn_act(y.detach().clone(), bn2, relu=True)
+    torch.testing.assert_close(out, ref, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(bn.running_var, bn2.running_var, rtol=1e-5, atol=1e-7)
+    out.backward(torch.randn_like(out))
+    assert m.weight.grad is not None and torch.isfinite(m.weight.grad).all()
+
+
 def test_channel_sums_vs_torch():
     """gga_column_sums (bias gradients): channels-last maps, row matrices, and the layouts it hands back to torch."""
     torch.manual_seed(3)

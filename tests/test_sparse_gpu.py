@@ -202,3 +202,31 @@ def test_sparse_encoder_full_grid_vs_pair_list_reference():
     # everything else is inside 1e-3 or the fp32 floor
     bad = R.gradient_offenders(grads, ref, ref64, tol=2e-3, slack=3.0)
     assert bad == [], bad
+
+
+def test_sparse_conv_leaves_batchnorm_partials():
+    """A sparse convolution hands the BatchNorm1d that follows the per-channel sums of its output features
+    (gga_sparse_conv_apply_stats): they equal the column sums, and bn_act with them equals bn_act without."""
+    import copy
+    from gga_amd import functional as F, sparse
+    torch.manual_seed(5)
+    dev = 'cuda:0'
+    shape, B = (9, 40, 36), 2
+    coors = torch.unique(torch.stack([torch.randint(0, B, (3000,)), torch.randint(0, shape[0], (3000,)),
+                                      torch.randint(0, shape[1], (3000,)), torch.randint(0, shape[2], (3000,))], 1), dim=0).int().to(dev)
+    feats = torch.randn(coors.shape[0], 16, device=dev)
+    x = sparse.SparseConvTensor(feats, coors, shape, B)
+    for conv in (sparse.SubMConv3d(16, 32, 3, padding=1, bias=False, indice_key='s').to(dev),
+                 sparse.SparseConv3d(16, 64, 3, stride=2, padding=1, bias=False).to(dev)):
+        y = conv(x).features
+        p = y.bn_partials
+        assert p.dtype == torch.float64 and p.shape[1:] == (2, y.shape[1])
+        yd = y.detach().double()
+        torch.testing.assert_close(p[:, 0].sum(0), yd.sum(0), rtol=0, atol=2e-6 * float(yd.abs().sum(0).max()))
+        torch.testing.assert_close(p[:, 1].sum(0), (yd * yd).sum(0), rtol=2e-6, atol=0)
+        bn = torch.nn.BatchNorm1d(y.shape[1], eps=1e-3, momentum=0.01).to(dev)
+        bn2 = copy.deepcopy(bn)
+        out = F.bn_act(y, bn, relu=True)
+        ref = F.bn_act(y.detach().clone(), bn2, relu=True)
+        torch.testing.assert_close(out, ref, rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(bn.running_mean, bn2.running_mean, rtol=1e-5, atol=1e-7)

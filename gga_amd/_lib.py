@@ -11,7 +11,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libgga_hip.so')
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 _lib = None
 
@@ -86,6 +86,7 @@ SIGNATURES = {
     'gga_sparse_conv_apply_planes': (i32, [vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp, i64, i32, vp, vp, vp]),
     'gga_sparse_conv_apply_stats': (i32, [vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp, i64, i32, vp, vp, vp, vp]),
     'gga_sparse_conv_apply_tiles': (i64, [i64]),
+    'gga_sparse_conv_apply_bn_bwd': (i32, [vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp, i64, i32, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp]),
     'gga_sparse_conv_wgrad_planes': (i32, [vp, i64, vp, i64, vp, i64, i32, i32, i32, vp, i32, vp, vp, vp, sz, vp]),
     'gga_absmax_bits': (i32, [vp, i64, i32, i64, vp, vp]),
     'gga_dense_conv3x3_pack_planes': (i32, [vp, i64, i64, i64, i64, i32, i32, i32, i32, vp, vp, vp]),

@@ -820,6 +820,18 @@ extern "C" int gga_sparse_pack_weight_planes(const float* weight, int kvol, int 
 #define X9_NW 4
 #define X9_TM (32 * X9_NW)
 
+// Backward-data launches whose result is the gradient of z = relu(bn(y)) take that BatchNorm's backward reduce pass into
+// their epilogue, like the dense kernel (DcBnBwd): the rows are masked by the ReLU recomputed from y (row = output row,
+// row stride ystride floats) before they are stored, and `stats` receives the sums of g and g * xhat.
+struct SpBnBwd {
+    const float* y;
+    const float* gamma;
+    const float* beta;
+    const float* mean;
+    const float* invstd;
+    int64_t ystride;
+};
+
 template <int NT, bool VEC, int NP>
 __global__ __launch_bounds__(64 * X9_NW) void sp_conv_x9_kernel(const float* __restrict__ X, const int32_t* __restrict__ map,
                                                         const uint16_t* __restrict__ Wp,
@@ -828,7 +840,8 @@ __global__ __launch_bounds__(64 * X9_NW) void sp_conv_x9_kernel(const float* __r
                                                         int kvol, int cin, int cout, int flip,
                                                         float* __restrict__ Y, int64_t ys,
                                                         const uint32_t* __restrict__ amax_x,
-                                                        const uint32_t* __restrict__ amax_w, double* __restrict__ stats) {
+                                                        const uint32_t* __restrict__ amax_w, double* __restrict__ stats,
+                                                        SpBnBwd bn) {
     // NP = 3: bf16 planes, six partial products; NP = 2: fp16 planes of the scaled operands, three (h2_split2)
     constexpr int CO = NT * 32;
     constexpr int BPL = CO * X9_ROWB;                     // bytes per B plane
@@ -995,6 +1008,41 @@ __global__ __launch_bounds__(64 * X9_NW) void sp_conv_x9_kernel(const float* __r
     float s1[NT], s2[NT];                                  // per-column sums of the lane's 16 rows (stats)
 #pragma unroll
     for (int t = 0; t < NT; ++t) { s1[t] = 0.0f; s2[t] = 0.0f; }
+    if (bn.y) {                                            // see SpBnBwd
+        float bsc[NT], bsh[NT], bmu[NT], biv[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int o = t * 32 + r < cout ? t * 32 + r : 0;
+            bmu[t] = bn.mean[o]; biv[t] = bn.invstd[o];
+            gga_bn_scale_shift(bn.gamma ? bn.gamma[o] : 1.0f, bn.beta ? bn.beta[o] : 0.0f, bmu[t], biv[t], bsc[t], bsh[t]);
+        }
+        constexpr int VB = 32 / NT < 16 ? 32 / NT : 16;    // 32 values of y requested before the first is used
+#pragma unroll
+        for (int v0 = 0; v0 < 16; v0 += VB) {
+            float yv[VB][NT];
+            int pos[VB];
+#pragma unroll
+            for (int j = 0; j < VB; ++j) {
+                const int v = v0 + j;
+                pos[j] = prow[wave * 32 + (v >> 2) * 8 + h * 4 + (v & 3)];
+                const float* src = bn.y + (int64_t)(pos[j] >= 0 ? pos[j] : 0) * bn.ystride;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) yv[j][t] = src[t * 32 + r < cout ? t * 32 + r : 0];
+            }
+#pragma unroll
+            for (int j = 0; j < VB; ++j) {
+                if (pos[j] < 0) continue;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const int o = t * 32 + r;
+                    if (o >= cout) continue;
+                    const float g = fmaf(yv[j][t], bsc[t], bsh[t]) > 0.0f ? acc[t][v0 + j] : 0.0f;
+                    Y[(int64_t)pos[j] * ys + o] = g;
+                    s1[t] += g; s2[t] += g * ((yv[j][t] - bmu[t]) * biv[t]);
+                }
+            }
+        }
+    } else
 #pragma unroll
     for (int v = 0; v < 16; ++v) {
         const int lr = wave * 32 + (v >> 2) * 8 + h * 4 + (v & 3);
@@ -1052,7 +1100,21 @@ extern "C" int gga_sparse_conv_apply_stats(const float* x, const int32_t* map, c
                                            const uint32_t* rowmask, int64_t n_rows, int kvol, int cin, int cout, int flip,
                                            float* y, int64_t y_row_stride, int planes, const uint32_t* amax_x,
                                            const uint32_t* amax_weight, double* stats, void* stream_) {
+    return gga_sparse_conv_apply_bn_bwd(x, map, split_weight, perm, rowmask, n_rows, kvol, cin, cout, flip, y, y_row_stride, planes,
+                                        amax_x, amax_weight, stats, nullptr, 0, nullptr, nullptr, nullptr, nullptr, stream_);
+}
+
+extern "C" int gga_sparse_conv_apply_bn_bwd(const float* x, const int32_t* map, const void* split_weight, const int32_t* perm,
+                                            const uint32_t* rowmask, int64_t n_rows, int kvol, int cin, int cout, int flip,
+                                            float* y, int64_t y_row_stride, int planes, const uint32_t* amax_x,
+                                            const uint32_t* amax_weight, double* stats, const float* bn_x,
+                                            int64_t bn_x_row_stride, const float* bn_gamma, const float* bn_beta,
+                                            const float* bn_mean, const float* bn_invstd, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    GGA_REQUIRE(!bn_x || (stats && bn_mean && bn_invstd && bn_x_row_stride >= cout),
+                "gga_sparse_conv_apply_bn_bwd: the BatchNorm epilogue needs stats, the saved mean / invstd and a row stride >= cout");
+    SpBnBwd bn;
+    bn.y = bn_x; bn.gamma = bn_gamma; bn.beta = bn_beta; bn.mean = bn_mean; bn.invstd = bn_invstd; bn.ystride = bn_x_row_stride;
     GGA_REQUIRE(x && map && split_weight && y, "gga_sparse_conv_apply_split: null pointer argument");
     GGA_REQUIRE(planes == 3 || (planes == 2 && amax_x && amax_weight),
                 "gga_sparse_conv_apply_split: planes must be 3 (bf16) or 2 (fp16, with the operands' absmax bits)");
@@ -1062,8 +1124,8 @@ extern "C" int gga_sparse_conv_apply_stats(const float* x, const int32_t* map, c
     const dim3 grid((unsigned)((n_rows + X9_TM - 1) / X9_TM)), block(64 * X9_NW);
     hipEvent_t* tev = gga_timing_acquire(GGA_TIME_SPARSE_CONV, GGA_TIMING_CONV_KEY(cin, cout, 0));
     GGA_TIME_START(tev, stream);
-#define X9_LAUNCH(NT, VEC) { if (planes == 3) hipLaunchKernelGGL((sp_conv_x9_kernel<NT, VEC, 3>), grid, block, 0, stream, x, map, (const uint16_t*)split_weight, perm, rowmask, n_rows, kvol, cin, cout, flip, y, y_row_stride, amax_x, amax_weight, stats); \
-                             else hipLaunchKernelGGL((sp_conv_x9_kernel<NT, VEC, 2>), grid, block, 0, stream, x, map, (const uint16_t*)split_weight, perm, rowmask, n_rows, kvol, cin, cout, flip, y, y_row_stride, amax_x, amax_weight, stats); }
+#define X9_LAUNCH(NT, VEC) { if (planes == 3) hipLaunchKernelGGL((sp_conv_x9_kernel<NT, VEC, 3>), grid, block, 0, stream, x, map, (const uint16_t*)split_weight, perm, rowmask, n_rows, kvol, cin, cout, flip, y, y_row_stride, amax_x, amax_weight, stats, bn); \
+                             else hipLaunchKernelGGL((sp_conv_x9_kernel<NT, VEC, 2>), grid, block, 0, stream, x, map, (const uint16_t*)split_weight, perm, rowmask, n_rows, kvol, cin, cout, flip, y, y_row_stride, amax_x, amax_weight, stats, bn); }
     if ((cin & 3) == 0) {
         switch (mf_nt(cout)) {
             case 1: X9_LAUNCH(1, true); break;

@@ -136,6 +136,8 @@ class BnSource:
         return None
 
     def covers(self, n_out):
+        if len(self.parts) == 1 and self.parts[0][1] == n_out and n_out <= 128:
+            return True
         widths = [n_out] if n_out in (64, 128) else [128] * (n_out // 128)
         return n_out == sum(C for _, C, *_ in self.parts) and all(
             self.part(c0, w) is not None for c0, w in zip(range(0, n_out, 128), widths))
@@ -143,10 +145,13 @@ class BnSource:
 
 def bn_source(z, n_out):
     """The valid ``BnSource`` of ``z`` for a backward-data convolution with ``n_out`` output channels, or None (also
-    where the epilogue would cost more than the reduce pass it replaces: ``gga_dense_conv3x3_bn_bwd_pays``)."""
+    where the epilogue would cost more than the reduce pass it replaces: ``gga_dense_conv3x3_bn_bwd_pays``). ``z``
+    [rows, C] (sparse features): the gather-GEMM kernel's epilogue, one launch of at most 128 channels."""
     src = getattr(z, '_gga_bn_src', None)
     if src is None or not src.valid_for(z) or not src.covers(n_out):
         return None
+    if z.dim() == 2:
+        return src if (BN_BWD_FUSED and n_out <= 128 and len(src.parts) == 1) else None
     B, _, H, W = z.shape
     th, tw = (W, H) if _transposed(H, W) else (H, W)
     if not _lib.lib().gga_dense_conv3x3_bn_bwd_pays(B, th, tw, 64 if n_out == 64 else 128):

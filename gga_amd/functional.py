@@ -618,7 +618,7 @@ def bn_act(x, bn, relu=True, residual=None):
     from . import dense_conv
     if amax.numel():
         dense_conv.set_amax(y, amax)
-    if relu and residual is None and x.dim() == 4 and y.requires_grad:
+    if relu and residual is None and x.dim() in (2, 4) and y.requires_grad:
         # a 3x3 convolution that consumes y reduces this BatchNorm's backward sums in its backward-data epilogue
         y._gga_bn_src = dense_conv.BnSource(y, [(0, C, x.detach(), bn.weight.detach(), bn.bias.detach(), saved)])
     return y

@@ -287,14 +287,17 @@ def _pack_weight(w, kvol, cin, cout, transpose, split=None, w_amax=None):
     return wp
 
 
-def _conv_apply(x, rb, wp, n_rows, kvol, cin, cout, flip, y, x_amax=None, w_amax=None, stats=None):
+def _conv_apply(x, rb, wp, n_rows, kvol, cin, cout, flip, y, x_amax=None, w_amax=None, stats=None, bn=None):
     """``x_amax`` / ``w_amax`` given: ``wp`` holds two fp16 planes (packed with the same ``w_amax``). ``stats``: f64
-    [gga_sparse_conv_apply_tiles(n_rows), 2, cout] for the per-channel sums of y (split-plane kernels only)."""
+    [gga_sparse_conv_apply_tiles(n_rows), 2, cout] for the per-channel sums of y (split-plane kernels only). ``bn``
+    (backward-data launches, with ``stats``): ``BnSource.part`` pointers of the BatchNorm + ReLU whose output gradient y
+    is - y is stored masked by the ReLU and ``stats`` receives that BatchNorm's backward sums."""
     L = _lib.lib()
     if wp.dtype == torch.int16:
-        check(L.gga_sparse_conv_apply_stats(F._p(x), F._p(rb.nbr), F._p(wp), F._p(rb.perm), F._p(rb.mask), n_rows,
-                                            kvol, cin, cout, flip, F._p(y), cout, 2 if w_amax is not None else 3, F._p(x_amax),
-                                            F._p(w_amax), F._p(stats), F._stream()), 'gga_sparse_conv_apply_split')
+        check(L.gga_sparse_conv_apply_bn_bwd(F._p(x), F._p(rb.nbr), F._p(wp), F._p(rb.perm), F._p(rb.mask), n_rows,
+                                             kvol, cin, cout, flip, F._p(y), cout, 2 if w_amax is not None else 3, F._p(x_amax),
+                                             F._p(w_amax), F._p(stats), *(bn if bn else (None, 0, None, None, None, None)),
+                                             F._stream()), 'gga_sparse_conv_apply_split')
     else:
         check(L.gga_sparse_conv_apply(F._p(x), F._p(rb.nbr), F._p(wp), F._p(rb.perm), F._p(rb.mask), n_rows, kvol, cin, cout,
                                       flip, F._p(y), F._stream()), 'gga_sparse_conv_apply')
@@ -337,6 +340,9 @@ class _SparseConvFn(torch.autograd.Function):
         _conv_apply(feats, rb, _pack_weight(w, kvol, cin, cout, 0, w_amax=w_amax), n_out, kvol, cin, cout, 0, y, x_amax, w_amax, stats)
         ctx.save_for_backward(feats, w)
         ctx.rb, ctx.rb_t, ctx.amax = rb, rb_t, (x_amax, w_amax)
+        # feats = relu(bn(.)) with this convolution as its consumer: the backward-data pass then does that BatchNorm's reduce
+        from . import dense_conv
+        ctx.bn_src = dense_conv.bn_source(feats, cin) if (SPLIT_BF16 and cin % 4 == 0) else None
         if stats is None:
             stats = torch.empty(0, dtype=torch.float64, device=feats.device)
         ctx.mark_non_differentiable(stats)
@@ -358,7 +364,14 @@ class _SparseConvFn(torch.autograd.Function):
             gx = torch.empty_like(feats)
             wt = _pack_weight(w, kvol, cout, cin, 1, w_amax=w_amax)   # W[k]^T in fragment order
             tb, flip = (rb_t, 0) if rb_t is not None else (rb, 1)     # SubM: transposed map = reversed offsets
-            _conv_apply(gy, tb, wt, n_in, kvol, cout, cin, flip, gx, g_amax, w_amax)
+            src = ctx.bn_src
+            if src is not None:
+                from . import dense_conv
+                st = torch.empty((int(L.gga_sparse_conv_apply_tiles(n_in)), 2, cin), dtype=torch.float64, device=gy.device)
+                _conv_apply(gy, tb, wt, n_in, kvol, cout, cin, flip, gx, g_amax, w_amax, st, src.part(0, cin))
+                gx._gga_bn_bwd = dense_conv.BnPartials(gx, [(0, cin, st)], tuple(p[5].data_ptr() for p in src.parts))
+            else:
+                _conv_apply(gy, tb, wt, n_in, kvol, cout, cin, flip, gx, g_amax, w_amax)
         if ctx.needs_input_grad[1]:
             gw = torch.empty_like(w)
             conv_wgrad(feats, gy, rb.nbr, n_out, kvol, cin, cout, gw, x_amax, g_amax)

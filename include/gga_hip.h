@@ -358,6 +358,15 @@ int gga_sparse_conv_apply_stats(const float* x, const int32_t* map, const void* 
                                 const uint32_t* rowmask, int64_t n_rows, int kvol, int cin, int cout, int flip, float* y,
                                 int64_t y_row_stride, int planes, const uint32_t* amax_x, const uint32_t* amax_weight,
                                 double* stats, void* stream);
+/* gga_sparse_conv_apply_stats run as the backward-data pass that produces the gradient of z = relu(bn(bn_x)) (the
+ * conv -> BatchNorm1d -> ReLU -> conv chains of middle_encoders/sparse_encoder.py:107-214): rows are masked by the ReLU
+ * (recomputed from bn_x [n_rows, row stride bn_x_row_stride] and gamma, beta, mean, invstd exactly as the forward decided)
+ * before they are stored, and stats (required) holds the sums of g and g * xhat for gga_bn_relu_bwd_partials. */
+int gga_sparse_conv_apply_bn_bwd(const float* x, const int32_t* map, const void* split_weight, const int32_t* perm,
+                                 const uint32_t* rowmask, int64_t n_rows, int kvol, int cin, int cout, int flip, float* y,
+                                 int64_t y_row_stride, int planes, const uint32_t* amax_x, const uint32_t* amax_weight,
+                                 double* stats, const float* bn_x, int64_t bn_x_row_stride, const float* bn_gamma,
+                                 const float* bn_beta, const float* bn_mean, const float* bn_invstd, void* stream);
 int gga_sparse_conv_wgrad_planes(const float* x, int64_t x_row_stride, const float* grad_out, int64_t grad_out_row_stride,
                                  const int32_t* nbr, int64_t n_rows, int kvol, int cin, int cout, float* grad_weight,
                                  int planes, const uint32_t* amax_x, const uint32_t* amax_grad_out, void* workspace,

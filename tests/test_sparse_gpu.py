@@ -230,3 +230,54 @@ def test_sparse_conv_leaves_batchnorm_partials():
         ref = F.bn_act(y.detach().clone(), bn2, relu=True)
         torch.testing.assert_close(out, ref, rtol=1e-5, atol=1e-5)
         torch.testing.assert_close(bn.running_mean, bn2.running_mean, rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize('training', [True, False])
+def test_sparse_backward_data_reduces_the_batchnorm_below(training, monkeypatch):
+    """SubMConv3d -> BatchNorm1d -> ReLU -> SparseConv3d / SubMConv3d: the second convolution's backward-data launch masks
+    its result with the ReLU and leaves the BatchNorm backward sums (gga_sparse_conv_apply_bn_bwd), the BatchNorm backward
+    runs without its reduce pass. Against the unfused path of this repo (same kernels otherwise)."""
+    import copy
+    from gga_amd import _lib, dense_conv, functional as F, sparse
+    torch.manual_seed(9)
+    dev = 'cuda:0'
+    shape, B = (9, 40, 36), 2
+    coors = torch.unique(torch.stack([torch.randint(0, B, (4000,)), torch.randint(0, shape[0], (4000,)),
+                                      torch.randint(0, shape[1], (4000,)), torch.randint(0, shape[2], (4000,))], 1), dim=0).int().to(dev)
+    feats = torch.randn(coors.shape[0], 16, device=dev)
+    L = _lib.lib()
+    calls = {'fused': 0}
+    real = L.gga_bn_relu_bwd_partials
+
+    def counted(*a):
+        calls['fused'] += 1
+        return real(*a)
+
+    monkeypatch.setattr(L, 'gga_bn_relu_bwd_partials', counted)
+    for second in (sparse.SubMConv3d(32, 64, 3, padding=1, bias=False, indice_key='s').to(dev),
+                   sparse.SparseConv3d(32, 128, 3, stride=2, padding=1, bias=False).to(dev)):
+        conv1 = sparse.SubMConv3d(16, 32, 3, padding=1, bias=False, indice_key='s').to(dev)
+        bn = torch.nn.BatchNorm1d(32, eps=1e-3, momentum=0.01).to(dev)
+        with torch.no_grad():
+            bn.weight.uniform_(0.5, 1.5), bn.bias.uniform_(-0.5, 0.5), bn.running_mean.uniform_(-0.2, 0.2), bn.running_var.uniform_(0.5, 1.5)
+        bn.train(training)
+
+        def run(fused):
+            monkeypatch.setattr(dense_conv, 'BN_BWD_FUSED', fused)
+            mods = copy.deepcopy((conv1, bn, second))
+            f = feats.clone().requires_grad_(True)
+            x = sparse.SparseConvTensor(f, coors, shape, B)
+            h = mods[0](x)
+            h = h.replace_feature(F.bn_act(h.features, mods[1], relu=True))
+            out = mods[2](h).features
+            g = torch.linspace(-1, 1, out.numel(), device=dev).view_as(out)
+            out.backward(g)
+            return out.detach(), f.grad, mods[0].weight.grad, mods[1].weight.grad, mods[1].bias.grad, mods[2].weight.grad
+
+        before = calls['fused']
+        got = run(True)
+        assert calls['fused'] == before + 1, 'the fused BatchNorm backward did not run'
+        plain = run(False)
+        assert calls['fused'] == before + 1
+        for n, a, b in zip(('out', 'grad feats', 'grad conv1', 'grad gamma', 'grad beta', 'grad conv2'), got, plain):
+            assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-7, n

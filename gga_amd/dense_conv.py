@@ -449,7 +449,7 @@ def conv2d(x, conv, bn_follows=False):
             return _Conv3x3.apply(x, conv.weight, False)[0] + conv.bias.view(1, -1, 1, 1)
         y, stats = _Conv3x3.apply(x, conv.weight, bool(bn_follows))
         if bn_follows:
-            y.bn_partials = stats
+            F.attach_bn_partials(y, stats)
         return y
     from . import strided_conv
     if strided_conv.eligible(conv, x):        # stride-2 3x3, 1x1 and kernel = stride transposed convolutions

@@ -571,6 +571,21 @@ class _BNAct(torch.autograd.Function):
         return gx, gres, gg, gb, None, None, None, None, None, None, None, None, None
 
 
+def attach_bn_partials(y, stats):
+    """Remember the per-channel sums a convolution kernel left for its output ``y`` (valid while ``y`` is not written again)."""
+    y.bn_partials = stats
+    y._bn_partials_version = y._version
+    return y
+
+
+def bn_partials_of(x):
+    """The producer's per-channel sums of ``x`` ([tiles, 2, C] f64) if ``x`` still holds what the producer wrote, else None."""
+    p = getattr(x, 'bn_partials', None)
+    if p is None or getattr(x, '_bn_partials_version', x._version) != x._version:
+        return None
+    return p if (p.dim() == 3 and p.shape[0] >= 1 and p.shape[2] == x.shape[1]) else None
+
+
 def channel_sums(x):
     """``x.sum`` over every dimension but the channels of a [rows, C] / channels-last [B, C, H, W] gradient (a convolution's
     bias gradient) - ``gga_column_sums`` where the layout allows it, the framework's reduction otherwise."""
@@ -610,9 +625,7 @@ def bn_act(x, bn, relu=True, residual=None):
         return torch.relu(y) if relu else y
     if bn.training:
         bn.num_batches_tracked += 1
-    partials = getattr(x, 'bn_partials', None)
-    if partials is not None and not (bn.training and partials.dim() == 3 and partials.shape[2] == C):
-        partials = None
+    partials = bn_partials_of(x) if bn.training else None
     y, amax, saved = _BNAct.apply(x, residual, bn.weight, bn.bias, bn.running_mean, bn.running_var, float(bn.eps),
                                   float(bn.momentum), bool(bn.training), bool(relu), int(rc[0]), int(C), partials)
     from . import dense_conv
@@ -783,11 +796,10 @@ def bn_relu_cat(xs, bns):
             bn.num_batches_tracked += 1
     n = len(xs)
     cfg = tuple((float(bn.eps), float(bn.momentum), bool(bn.training)) for bn in bns)
-    def sums(x):        # the producer's per-channel sums (dense_conv / strided_conv / sparse convolutions), if it left them
-        p = getattr(x, 'bn_partials', None)
-        return p if (p is not None and p.dim() == 3 and p.shape[2] == x.shape[1] and p.shape[0] >= 1) else None
+    # the producers' per-channel sums (dense_conv / strided_conv / sparse convolutions), where they left them
     out, amax, *saved = _BNActCat.apply(n, cfg, *xs, *[bn.weight for bn in bns], *[bn.bias for bn in bns],
-                                        *[bn.running_mean for bn in bns], *[bn.running_var for bn in bns], *[sums(x) for x in xs])
+                                        *[bn.running_mean for bn in bns], *[bn.running_var for bn in bns],
+                                        *[bn_partials_of(x) for x in xs])
     from . import dense_conv
     if amax.numel():
         dense_conv.set_amax(out, amax)
@@ -903,9 +915,7 @@ def bn_relu_head_conv3x3(x, bn, conv):
     if not ok:
         return head_conv3x3(bn_act(x, bn, relu=True), conv)
     bn.num_batches_tracked += 1
-    partials = getattr(x, 'bn_partials', None)
-    if partials is not None and not (partials.dim() == 3 and partials.shape[2] == x.shape[1]):
-        partials = None
+    partials = bn_partials_of(x)
     return _BnReluHeadConv3x3.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, conv.weight, conv.bias,
                                     float(bn.eps), float(bn.momentum), True, partials)
 

@@ -102,5 +102,5 @@ def pillar_conv2d(canvas, conv):
     y, stats = _PillarConv2d.apply(sup.feats, conv.weight, canvas.detach(), coors.contiguous(), sup.num_valid,
                                    tuple(conv.stride), tuple(conv.padding))
     if stats.numel():
-        y.bn_partials = stats       # per-channel sums of y for the BatchNorm that follows (functional.bn_act)
+        F.attach_bn_partials(y, stats)       # per-channel sums of y for the BatchNorm that follows (functional.bn_act)
     return y

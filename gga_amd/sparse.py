@@ -425,7 +425,7 @@ class SparseConvolution(SparseModule):
     def _run(self, feats, w, rb, rb_t, n_out):
         y, stats = _SparseConvFn.apply(feats, w, rb, rb_t, n_out)
         if stats.numel() and self.bias is None:
-            y.bn_partials = stats       # per-channel sums of y for the BatchNorm that follows (functional.bn_act)
+            F.attach_bn_partials(y, stats)       # per-channel sums of y for the BatchNorm that follows (functional.bn_act)
         return y
 
     def forward(self, x):

@@ -241,5 +241,5 @@ def conv(x, m):
         y, stats = _StridedConv.apply(x, m.weight, m.kernel_size[0], m.stride[0], m.padding[0])
     else:
         y, stats = _Deconv.apply(x, m.weight, m.stride[0])
-    y.bn_partials = stats
+    F.attach_bn_partials(y, stats)
     return y

@@ -764,6 +764,12 @@ def test_gather_convs_leave_batchnorm_partials(kind, cin, cout, k, s, B, H, W):
     torch.testing.assert_close(bn.running_var, bn2.running_var, rtol=1e-5, atol=1e-7)
     out.backward(torch.randn_like(out))
     assert m.weight.grad is not None and torch.isfinite(m.weight.grad).all()
+    # the sums are only trusted while y holds what the kernel wrote
+    with torch.no_grad():
+        y2 = strided_conv.conv(x, m)
+        assert F.bn_partials_of(y2) is not None
+        y2.mul_(2.0)
+        assert F.bn_partials_of(y2) is None
 
 
 def test_channel_sums_vs_torch():

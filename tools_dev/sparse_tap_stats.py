@@ -32,3 +32,9 @@ for rb in seen[-12:]:
             u |= mm[:, j]
         return float(pop(u).mean())
     print(f'kvol {kvol:3d} rows {n:8d}  present taps/row {per_row:5.2f}  executed per 32-row wave {union(32):5.2f}  per 128-row tile {union(128):5.2f}', flush=True)
+    # alternative processing orders: by number of taps first; by the bit-reversed mask
+    raw = rb.mask.to(torch.int64) & 0xFFFFFFFF
+    pc = sum(((raw >> b) & 1) for b in range(kvol))
+    for name, key in (('popcount, mask', pc * (1 << 32) + raw),):
+        m = raw[torch.sort(key, stable=True)[1]]
+        print(f'      order by {name}: per 32-row wave {union(32):5.2f}  per 128-row tile {union(128):5.2f}', flush=True)

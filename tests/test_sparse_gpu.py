@@ -232,8 +232,9 @@ def test_sparse_conv_leaves_batchnorm_partials():
         torch.testing.assert_close(bn.running_mean, bn2.running_mean, rtol=1e-5, atol=1e-7)
 
 
+@pytest.mark.parametrize('mid', [32, 64, 128])       # one, two and four 32-column tiles per wave in the epilogue
 @pytest.mark.parametrize('training', [True, False])
-def test_sparse_backward_data_reduces_the_batchnorm_below(training, monkeypatch):
+def test_sparse_backward_data_reduces_the_batchnorm_below(training, mid, monkeypatch):
     """SubMConv3d -> BatchNorm1d -> ReLU -> SparseConv3d / SubMConv3d: the second convolution's backward-data launch masks
     its result with the ReLU and leaves the BatchNorm backward sums (gga_sparse_conv_apply_bn_bwd), the BatchNorm backward
     runs without its reduce pass. Against the unfused path of this repo (same kernels otherwise)."""
@@ -254,10 +255,10 @@ def test_sparse_backward_data_reduces_the_batchnorm_below(training, monkeypatch)
         return real(*a)
 
     monkeypatch.setattr(L, 'gga_bn_relu_bwd_partials', counted)
-    for second in (sparse.SubMConv3d(32, 64, 3, padding=1, bias=False, indice_key='s').to(dev),
-                   sparse.SparseConv3d(32, 128, 3, stride=2, padding=1, bias=False).to(dev)):
-        conv1 = sparse.SubMConv3d(16, 32, 3, padding=1, bias=False, indice_key='s').to(dev)
-        bn = torch.nn.BatchNorm1d(32, eps=1e-3, momentum=0.01).to(dev)
+    for second in (sparse.SubMConv3d(mid, 64, 3, padding=1, bias=False, indice_key='s').to(dev),
+                   sparse.SparseConv3d(mid, 128, 3, stride=2, padding=1, bias=False).to(dev)):
+        conv1 = sparse.SubMConv3d(16, mid, 3, padding=1, bias=False, indice_key='s').to(dev)
+        bn = torch.nn.BatchNorm1d(mid, eps=1e-3, momentum=0.01).to(dev)
         with torch.no_grad():
             bn.weight.uniform_(0.5, 1.5), bn.bias.uniform_(-0.5, 0.5), bn.running_mean.uniform_(-0.2, 0.2), bn.running_var.uniform_(0.5, 1.5)
         bn.train(training)

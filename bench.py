@@ -43,9 +43,11 @@ BF16_PEAK_TFLOPS = 2500.0
 ARITH = ('fp32 in / fp32 out, fp32 accumulate. Every convolution (dense 3x3, strided, transposed, sparse 3D; forward, '
          'backward-data, weight gradient): operands scaled by a power of two to their largest finite magnitude and split into '
          'two round-to-nearest fp16 planes (22-bit significands), three f16 MFMA partial products, exact rescale - error vs '
-         'float64 <= MIOpen fp32; per element an absolute accuracy of 2^-39 of its tensor\'s largest magnitude. '
-         'GGA_DENSE_PLANES=3 selects three bf16 planes / six products (fp32\'s full exponent range). Head output convs: fp32 '
-         'MFMA. Everything else plain fp32')
+         'float64 <= MIOpen fp32; per element an absolute accuracy of 2^-40 of its tensor\'s largest magnitude. Selected by '
+         'the train Runner under its range guard (every operand of iteration 0 and of every 500th iteration is measured; an '
+         'operand with > 0.1% of its non-zero elements below 2^-30 of its maximum sends the run to the library default: three '
+         'bf16 planes / six products, fp32\'s full exponent range - timed in `planes3`). Head output convs: fp32 MFMA. '
+         'Everything else plain fp32')
 PP_CONFIG = os.path.join(REPO, 'configs', 'gga', 'gga_kitti_pointpillars_config.py')
 SECOND_CONFIG = os.path.join(REPO, 'configs', 'gga', 'gga_kitti_config.py')
 PGD_CONFIG = os.path.join(REPO, 'configs', 'gga', 'gga_pdg.py')
@@ -73,14 +75,34 @@ def parse_args(argv=None):
     ap.add_argument('--second-batch', type=int, default=8, help='frames per GPU of the second_trunk leg')
     ap.add_argument('--no-pgd', action='store_true', help='skip the gga_pdg.py (camera-only retraining) leg')
     ap.add_argument('--pgd-batch', type=int, default=12, help='images per GPU of the pgd leg (samples_per_gpu of the config)')
+    ap.add_argument('--no-planes3', action='store_true',
+                    help='skip the `planes3` legs (main config and second_trunk re-timed on three bf16 planes / six products)')
     return ap.parse_args(argv)
 
 
+def visible_gpus():
+    """Number of GPUs this process tree may use, WITHOUT loading a GPU runtime: the visibility variables if set, else the
+    KFD topology (nodes with SIMDs are GPUs; CPU nodes have simd_count 0)."""
+    for var in ('HIP_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([x for x in v.split(',') if x.strip() != ''])
+    n = 0
+    root = '/sys/class/kfd/kfd/topology/nodes'
+    try:
+        for node in os.listdir(root):
+            with open(os.path.join(root, node, 'properties')) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+            n += int(props.get('simd_count', '0')) > 0
+    except OSError:
+        pass
+    return n
+
+
 def launch_ranks(args):
-    """Parent of an N-rank run: no HIP call happens in this process (device_count does not
-    initialise the GPU on this image). Children are ordinary subprocesses, never an exec."""
-    import torch
-    n_dev = torch.cuda.device_count()
+    """Parent of an N-rank run: nothing in this process touches HIP / HSA (devices are counted from the environment or
+    sysfs, torch is not imported). Children are ordinary subprocesses, never an exec."""
+    n_dev = visible_gpus()
     env = dict(os.environ)
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     if n_dev < args.gpus and 'GGA_DIST_BACKEND' not in env:
@@ -106,9 +128,10 @@ def damp_head_init(model, scale):
                 getattr(th, name)[-1].weight.mul_(scale)
 
 
-def run_workload(config, batch, steps, warmup, args, rank, world, device, sites=()):
+def run_workload(config, batch, steps, warmup, args, rank, world, device, sites=(), planes=None):
     """Build the model of `config`, step it `warmup` + `steps` times on two resident batches.
-    `sites`: (site, cap, key) timing sessions armed for the timed steps (rank 0).
+    `sites`: (site, cap, key) timing sessions armed for the timed steps (rank 0). `planes`: arithmetic of the matrix
+    kernels the Runner selects (config key `gga_dense_planes`; None = the Runner's default, two fp16 planes under its guard).
     -> dict(dt, loss, timings {site: [ms]}, model, batches, cfg)."""
     import torch
     import torch.distributed as dist
@@ -116,6 +139,8 @@ def run_workload(config, batch, steps, warmup, args, rank, world, device, sites=
     from gga_amd.train import Runner, setup_multi_processes
 
     cfg = Config.fromfile(config)
+    if planes is not None:
+        cfg['gga_dense_planes'] = planes
     setup_multi_processes(cfg)          # as tools/train.py:127 does before it builds the model
     channels_last = not args.nchw
     if channels_last and cfg.model.pts_middle_encoder.type in ('PointPillarsScatter', 'SparseEncoder'):
@@ -145,10 +170,9 @@ def run_workload(config, batch, steps, warmup, args, rank, world, device, sites=
     torch.cuda.synchronize()
     for site, cap, key in sites:      # HIP-event pairs around the kernels, no synchronisation
         _lib.timing_begin(site, cap, key)
-    # no generational garbage collection inside the timed region: a gen-2 pass over the module tree
-    # takes tens of ms and drains the launch queue
-    gc.collect()
-    gc.disable()
+    # the product loop's own garbage-collector policy (Runner.run does the same after its first iterations): everything
+    # built so far moves to the permanent generation, the collector stays ON in the timed region
+    runner.freeze_gc()
     t0 = time.perf_counter()
     for i in range(steps):      # next_data: the point-only front of the next step is prefetched on a side stream (sparse trunk)
         out = runner.step(batches[i % 2], next_data=batches[(i + 1) % 2])
@@ -157,7 +181,6 @@ def run_workload(config, batch, steps, warmup, args, rank, world, device, sites=
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    gc.enable()
     timings = {site: _lib.timing_collect(site, cap) for site, cap, _ in sites}
     t = torch.tensor([dt], dtype=torch.float64, device=device)
     if world > 1:
@@ -181,7 +204,11 @@ def run_mono_workload(batch, steps, warmup, args, rank, world, device):
     setup_multi_processes(cfg)
     torch.manual_seed(0)
     model = build_model(cfg.model).to(device)
-    model.bbox_head.init_weights()
+    import warnings
+    with warnings.catch_warnings():        # the model-zoo checkpoint of the backbone cannot be fetched here: random init, said once below
+        warnings.simplefilter('ignore')
+        model.init_weights()               # as tools/train.py:222 does after build_model
+    synthetic.damp_random_backbone(model)      # stand-in for the unavailable checkpoint's statistics (see its docstring)
     if not args.nchw:
         model = to_channels_last(model)
     model.train()
@@ -199,8 +226,7 @@ def run_mono_workload(batch, steps, warmup, args, rank, world, device):
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    gc.collect()
-    gc.disable()
+    runner.freeze_gc()
     t0 = time.perf_counter()
     for i in range(steps):
         out = runner.step(batches[i % 2])
@@ -209,7 +235,6 @@ def run_mono_workload(batch, steps, warmup, args, rank, world, device):
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    gc.enable()
     t = torch.tensor([dt], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -428,6 +453,9 @@ def main():
             res['mfma_roofline'] = mfma_roofline('dense_conv3x3_x9_kernel<2,8> (64->64, %dx%d, fwd + bwd-data)' % (fh, fw),
                                                  flops, tm[_lib.TIME_DENSE_CONV],
                                                  len(tm[_lib.TIME_DENSE_CONV]) / args.steps, ms_per_step)
+        from gga_amd import dense_conv
+        res['config']['matrix_planes'] = dense_conv.PLANES          # what the timed steps ran on (2 unless the guard fell back)
+        res['range_guard'] = main_run['runner'].range_reports
     cfg_main = main_run['cfg']
     del main_run
     gc.collect()
@@ -470,9 +498,34 @@ def main():
                 'frames_per_gpu': args.pgd_batch, 'global_batch': args.pgd_batch * world,
                 'value': round(args.pgd_batch * world * args.steps / pg['dt'], 3), 'unit': 'frames/s',
                 'ms_per_step': round(pg['dt'] / args.steps * 1e3, 3), 'steps': args.steps, 'warmup': args.warmup,
-                'final_loss': round(pg['loss'], 4)}
+                'final_loss': round(pg['loss'], 4),
+                'weights': 'random init: the open-mmlab://detectron2/resnet101_caffe checkpoint of the config is not '
+                           'available offline (Kaiming backbone with the last norm of every bottleneck at 0.2, head per '
+                           'PGDHead.init_weights)'}
         gc.collect()
         torch.cuda.empty_cache()
+
+    if is_pp and not args.no_planes3:
+        # the same steps on the library's default arithmetic (three bf16 planes / six products: fp32 semantics per element)
+        s3, w3 = min(args.steps, 10), min(args.warmup, 3)
+        p3 = run_workload(args.config, args.batch, s3, w3, args, rank, world, device, planes=3)
+        if rank == 0:
+            res['planes3'] = {'arith': 'three bf16 planes / six partial products (fp32 exponent range)', 'steps': s3, 'warmup': w3,
+                              'ms_per_step': round(p3['dt'] / s3 * 1e3, 3),
+                              'value': round(args.batch * world * s3 / p3['dt'], 3), 'unit': 'frames/s',
+                              'final_loss': round(p3['loss'], 4)}
+        del p3
+        gc.collect()
+        torch.cuda.empty_cache()
+        if not args.no_second_trunk:
+            p3 = run_workload(SECOND_CONFIG, args.second_batch, s3, w3, args, rank, world, device, planes=3)
+            if rank == 0:
+                res['planes3']['second_trunk'] = {'ms_per_step': round(p3['dt'] / s3 * 1e3, 3),
+                                                  'value': round(args.second_batch * world * s3 / p3['dt'], 3),
+                                                  'unit': 'frames/s', 'final_loss': round(p3['loss'], 4)}
+            del p3
+            gc.collect()
+            torch.cuda.empty_cache()
 
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

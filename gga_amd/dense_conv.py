@@ -20,16 +20,68 @@ from ._lib import check
 ENABLED = True          # False: every dense convolution goes to MIOpen
 WGRAD = True            # False: weight gradients stay with MIOpen
 # Arithmetic of the matrix kernels (both: fp32 in, fp32 out, fp32 accumulation):
+#   3  three bf16 planes, six partial products: fp32's exponent range, 24-bit significands - fp32 semantics per element.
+#      The library default: a direct caller of the operators gets this.
 #   2  two fp16 planes of the operands scaled to their largest finite magnitude, three partial products: 22-bit
-#      significands, absolute accuracy 2^-39 of a tensor's largest magnitude per element (default);
-#   3  three bf16 planes, six partial products: fp32's exponent range, 24-bit significands.
-PLANES = int(os.environ.get('GGA_DENSE_PLANES', '2'))
+#      significands, absolute accuracy 2^-40 of a tensor's largest magnitude per element - half the matrix work. What
+#      ``train.Runner`` selects for the train step, under the ``RangeGuard`` below that measures the step's real operands
+#      and goes back to 3 when they are not the kind of tensor the two-plane form represents as well as fp32 does.
+# GGA_DENSE_PLANES in the environment fixes the choice (the Runner then leaves it alone).
+PLANES = int(os.environ.get('GGA_DENSE_PLANES', '3'))
+PLANES_PINNED = 'GGA_DENSE_PLANES' in os.environ
 BN_BWD_FUSED = True     # backward-data convolutions reduce the BatchNorm backward sums of the layer below them (BnSource)
 
 
-def amax_bits(t):
-    """Device scalar (int32 tensor [1]) with the bits of the largest finite ``|t|`` - what the two-plane kernels
-    derive their power-of-two scale from. ``t``: any tensor that is dense in memory, or a row-major matrix view."""
+class RangeGuard:
+    """Measures, for every operand the matrix kernels are handed while it is armed, how much of the tensor lies where
+    the two-plane form is worse than fp32: with the scale taken from the largest magnitude ``amax`` an element keeps an
+    absolute accuracy of 2^-40 * amax, so a non-zero element below 2^-17 * amax has fewer than fp32's 24 significant
+    bits and one below 2^-30 * amax is off by more than 1e-3 of itself (``lost``). Recorded per operand, on the device,
+    without a host read: [non-zero count, count below 2^-17 amax, count below 2^-30 amax, sum |t|, sum of |t| below
+    2^-30 amax]. ``Runner`` arms it for one step every ``interval`` iterations, reads the rows once after that step and
+    switches ``PLANES`` to 3 when any operand has more than ``LIMIT`` of its non-zero elements lost."""
+    LIMIT = 1e-3
+
+    def __init__(self):
+        self.armed = False
+        self.rows, self.names = [], []
+
+    def arm(self):
+        self.armed, self.rows, self.names = True, [], []
+
+    def record(self, t, amax=None):
+        if not self.armed or t.numel() == 0:
+            return
+        with torch.no_grad():
+            a = t.detach().abs().reshape(-1)
+            fin = torch.isfinite(a)
+            a = torch.where(fin, a, torch.zeros_like(a))
+            m = a.max()
+            nz = a > 0
+            low17 = nz & (a < m * 2.0 ** -17)
+            low30 = nz & (a < m * 2.0 ** -30)
+            self.rows.append(torch.stack([nz.sum().double(), low17.sum().double(), low30.sum().double(), a.double().sum(),
+                                          (a * low30).double().sum(), m.double()]))
+            self.names.append(f'{tuple(t.shape)}')
+
+    def disarm(self):
+        """-> list of dicts (one per operand seen): shape, nonzero, share_below_2^-17, share_lost, mass_lost, amax."""
+        self.armed = False
+        if not self.rows:
+            return []
+        r = torch.stack(self.rows).cpu()        # the one host read
+        out = []
+        for name, (nz, l17, l30, s, s30, m) in zip(self.names, r.tolist()):
+            out.append(dict(shape=name, nonzero=int(nz), share_below_2p17=l17 / max(nz, 1), share_lost=l30 / max(nz, 1),
+                            mass_lost=s30 / s if s > 0 else 0.0, amax=m))
+        self.rows, self.names = [], []
+        return out
+
+
+RANGE_GUARD = RangeGuard()
+
+
+def _amax_bits(t):
     L = _lib.lib()
     out = torch.empty(1, dtype=torch.int32, device=t.device)
     if not (t.is_contiguous() or (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last))):
@@ -43,6 +95,13 @@ def amax_bits(t):
     assert width < 2 ** 31
     check(L.gga_absmax_bits(F._p(t), n // width, width, width, F._p(out), F._stream()), 'gga_absmax_bits')
     return out
+
+
+def amax_bits(t):
+    """Device scalar (int32 tensor [1]) with the bits of the largest finite ``|t|`` - what the two-plane kernels
+    derive their power-of-two scale from. ``t``: any tensor that is dense in memory, or a row-major matrix view."""
+    RANGE_GUARD.record(t)
+    return _amax_bits(t)
 
 
 def _cdiv(a, b):
@@ -105,11 +164,12 @@ def new_amax(device):
 def tensor_amax(t):
     """Absmax bits of ``t``: what its producer left (``set_amax``) if ``t`` has not been modified since, one
     ``gga_absmax_bits`` pass otherwise."""
+    RANGE_GUARD.record(t)
     c = getattr(t, '_gga_amax', None)
     if (c is not None and c[0] == t._version and c[1] == t.data_ptr() and c[2] == t.numel()
             and c[4] == AMAX_POOL.generation):
         return c[3]
-    return amax_bits(t)
+    return _amax_bits(t)
 
 
 class BnSource:

@@ -77,14 +77,57 @@ class ResNet(nn.Module):
             name = f'layer{i + 1}'
             self.add_module(name, nn.Sequential(*blocks))
             self.res_layers.append(name)
+        # mmdet's ResNet (un-vendored; restated from the published code): a string ``pretrained`` becomes
+        # init_cfg = Pretrained; with no init_cfg the default is Kaiming on the convolutions, 1 on the norm weights and -
+        # only in that case - zero_init_residual's 0 on every block's last norm weight. A Pretrained init_cfg replaces
+        # all of that: nothing is zeroed, the checkpoint is loaded by init_weights()
+        assert not (init_cfg and pretrained), 'init_cfg and pretrained cannot be specified at the same time'
+        if isinstance(pretrained, str):
+            init_cfg = dict(type='Pretrained', checkpoint=pretrained)
+        self.init_cfg = init_cfg
+        self.zero_init_residual = bool(zero_init_residual) and init_cfg is None
+        self._default_init()
+        self._freeze_stages()
+
+    def _default_init(self):
         for m in self.modules():
             if isinstance(m, nn.Conv2d):
                 nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
-        if zero_init_residual:
+            elif isinstance(m, (nn.modules.batchnorm._BatchNorm, nn.GroupNorm)):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+        if self.zero_init_residual:
             for m in self.modules():
                 if isinstance(m, Bottleneck):
                     nn.init.constant_(m.bn3.weight, 0)
-        self._freeze_stages()
+
+    def init_weights(self):
+        """mmcv ``BaseModule.init_weights`` for this backbone: a ``Pretrained`` init_cfg loads its checkpoint (a local
+        file, or a ``state_dict`` already in memory under ``init_cfg['state_dict']``); model-zoo URLs such as
+        ``open-mmlab://detectron2/resnet101_caffe`` (configs/_base_/models/fcos3d.py:8-10) cannot be fetched without a
+        network - that is said loudly and the Kaiming initialisation stays (NOT a zeroed residual branch)."""
+        import os
+        import warnings
+        cfg = self.init_cfg
+        if not cfg:
+            return
+        if cfg.get('type') != 'Pretrained':
+            raise KeyError(f'init_cfg type {cfg.get("type")!r}: configs/gga only use Pretrained for the backbone')
+        state = cfg.get('state_dict')
+        ckpt = cfg.get('checkpoint')
+        if state is None and isinstance(ckpt, str) and os.path.isfile(ckpt):
+            state = torch.load(ckpt, map_location='cpu')
+        if state is None:
+            warnings.warn(f'ResNet: pretrained checkpoint {ckpt!r} is not a local file and cannot be downloaded here - the '
+                          f'backbone keeps its random (Kaiming) initialisation; results will not match a run that loaded it')
+            return
+        state = state.get('state_dict', state)
+        prefix = cfg.get('prefix')
+        if prefix:
+            state = {k[len(prefix):].lstrip('.'): v for k, v in state.items() if k.startswith(prefix)}
+        missing, unexpected = self.load_state_dict(state, strict=False)
+        if missing:
+            warnings.warn(f'ResNet: {len(missing)} parameters not in the checkpoint, e.g. {missing[:3]}')
 
     def _freeze_stages(self):
         if self.frozen_stages >= 0:
@@ -180,6 +223,14 @@ class SingleStageMono3DDetector(nn.Module):
         self.train_cfg, self.test_cfg = train_cfg, test_cfg
 
     with_neck = property(lambda self: getattr(self, 'neck', None) is not None)
+
+    def init_weights(self):
+        """What tools/train.py:222 calls on the built model (mmcv ``BaseModule.init_weights`` walks the children): the
+        backbone's init_cfg (checkpoint), the head's normal(0.01) / focal-prior initialisation; the neck's Xavier
+        initialisation is applied at construction."""
+        for m in (self.backbone, getattr(self, 'neck', None), self.bbox_head):
+            if m is not None and hasattr(m, 'init_weights'):
+                m.init_weights()
 
     def extract_feat(self, img):
         x = self.backbone(img)

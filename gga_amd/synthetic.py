@@ -493,3 +493,16 @@ def make_mono_batch(batch_size, start=0, rank=0, device=None, img_hw=MONO_IMG, n
 
 
 MONO_BATCH_KEYS = ('img', 'img_metas', 'gt_bboxes', 'gt_labels', 'gt_bboxes_3d', 'gt_labels_3d', 'centers2d', 'depths')
+
+
+def damp_random_backbone(model, scale=0.2):
+    """Random-init stand-in for the model-zoo checkpoint configs/gga/gga_pdg.py starts from (not available offline): its
+    ResNet-101 runs with BatchNorm frozen in evaluation mode, i.e. as the identity on fresh statistics, and 33 un-normalised
+    residual blocks at Kaiming scale double the activation variance per block. Scales the last norm of every bottleneck so
+    synthetic runs stay finite; every kernel launched and every trainable parameter's gradient path stays (non-zero)."""
+    import torch
+    with torch.no_grad():
+        for m in model.backbone.modules():
+            if hasattr(m, 'bn3'):
+                m.bn3.weight.fill_(scale)
+    return model

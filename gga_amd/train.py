@@ -86,27 +86,80 @@ def setup_multi_processes(cfg):
             pass
 
 
+_NORM_TYPES = (torch.nn.modules.batchnorm._BatchNorm, torch.nn.GroupNorm, torch.nn.LayerNorm,
+               torch.nn.modules.instancenorm._InstanceNorm)
+
+
+def paramwise_settings(model, base_lr, base_wd, pw):
+    """{parameter name: (lr, weight_decay)} as mmcv 1.4.8 - 1.6.0 ``DefaultOptimizerConstructor.add_params`` assigns them
+    (mmcv/runner/optimizer/default_constructor.py; the wheel is un-vendored - restated from the published code, parity
+    unpinned): it walks the modules, and for the parameters a module owns directly
+
+    * ``bias`` of anything that is neither a normalisation layer nor part of a DCN module: lr * ``bias_lr_mult``,
+      weight_decay * ``bias_decay_mult``;
+    * every parameter of a normalisation layer (_BatchNorm, _InstanceNorm, GroupNorm, LayerNorm): base lr,
+      weight_decay * ``norm_decay_mult`` (when given);
+    * depth-wise convolutions (in_channels == groups): weight_decay * ``dwconv_decay_mult`` (when given);
+    * the DIRECT children of a ``DeformConv2d`` / ``ModulatedDeformConv2d`` module (its ``conv_offset``): ``bias_lr_mult`` /
+      ``bias_decay_mult`` do not apply and ``dcn_offset_lr_mult`` scales the rate (when given). The flag is recomputed
+      per module after its own parameters were handled, so the DCN module's own ``bias`` does take the bias multipliers
+      (mmcv's comment: "bias_lr_mult affects all bias parameters except for norm.bias dcn.conv_offset.bias")."""
+    from . import dcn
+    dcn_types = tuple(t for t in (getattr(dcn, 'ModulatedDeformConv2d', None), getattr(dcn, 'ModulatedDeformConv2dPack', None),
+                                  getattr(dcn, 'DeformConv2d', None)) if t is not None)
+    bias_lr, bias_wd = pw.get('bias_lr_mult', 1.0), pw.get('bias_decay_mult', 1.0)
+    norm_wd, dw_wd = pw.get('norm_decay_mult', 1.0), pw.get('dwconv_decay_mult', 1.0)
+    offset_lr = pw.get('dcn_offset_lr_mult', 1.0)
+    out = {}
+
+    def walk(module, prefix, is_dcn):
+        is_norm = isinstance(module, _NORM_TYPES)
+        is_dw = isinstance(module, torch.nn.Conv2d) and module.in_channels == module.groups
+        for name, p in module.named_parameters(recurse=False):
+            if not p.requires_grad:
+                continue
+            lr, wd = base_lr, base_wd
+            if name == 'bias' and not (is_norm or is_dcn):
+                lr = base_lr * bias_lr
+            if prefix.find('conv_offset') != -1 and is_dcn and isinstance(module, torch.nn.Conv2d):
+                lr = base_lr * offset_lr
+            if base_wd is not None:
+                if is_norm:
+                    wd = base_wd * norm_wd
+                elif is_dw:
+                    wd = base_wd * dw_wd
+                elif name == 'bias' and not is_dcn:
+                    wd = base_wd * bias_wd
+            out[prefix + name] = (lr, wd)
+        for cname, child in module.named_children():
+            walk(child, f'{prefix}{cname}.', isinstance(module, dcn_types))
+
+    walk(model, '', False)
+    return out
+
+
 def build_optimizer(model, cfg):
-    """AdamW (configs/gga/gga_kitti_config.py:233) or SGD with mmcv's ``paramwise_cfg`` bias multipliers
-    (configs/gga/gga_pdg.py: ``bias_lr_mult=2, bias_decay_mult=0`` - DefaultOptimizerConstructor applies them
-    to every parameter named ``bias``)."""
+    """AdamW (configs/gga/gga_kitti_config.py:233) or SGD with mmcv's ``paramwise_cfg`` (configs/gga/gga_pdg.py:
+    ``bias_lr_mult=2, bias_decay_mult=0``) - see ``paramwise_settings`` for which parameters the multipliers reach."""
     cfg = dict(cfg)
     typ = cfg.pop('type')
     pw = cfg.pop('paramwise_cfg', None) or {}
     named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
     if pw:
-        unknown = set(pw) - {'bias_lr_mult', 'bias_decay_mult'}
+        unknown = set(pw) - {'bias_lr_mult', 'bias_decay_mult', 'norm_decay_mult', 'dwconv_decay_mult', 'dcn_offset_lr_mult'}
         if unknown:
             raise KeyError(f'paramwise_cfg keys {sorted(unknown)} are not used by configs/gga')
         # mmcv builds one group per parameter; parameters with equal settings are updated alike, so they share a group
-        # here (two groups instead of ~350: the optimizer's multi-tensor kernels then run once per step, not per parameter)
-        bias = dict(params=[], lr=cfg['lr'] * pw.get('bias_lr_mult', 1.0))
-        if 'weight_decay' in cfg:
-            bias['weight_decay'] = cfg['weight_decay'] * pw.get('bias_decay_mult', 1.0)
-        rest = dict(params=[])
+        # here (a few groups instead of ~350: the optimizer's multi-tensor kernels then run once per step, not per parameter)
+        settings = paramwise_settings(model, cfg['lr'], cfg.get('weight_decay'), pw)
+        groups = {}
         for n, p in named:
-            (bias if (n.endswith('.bias') or n == 'bias') else rest)['params'].append(p)
-        params = [g for g in (rest, bias) if g['params']]
+            lr, wd = settings[n]
+            g = groups.setdefault((lr, wd), dict(params=[], lr=lr))
+            if wd is not None:
+                g['weight_decay'] = wd
+            g['params'].append(p)
+        params = list(groups.values())
     else:
         params = [p for _, p in named]
     if typ == 'AdamW':
@@ -174,6 +227,17 @@ class Runner:
                                             mc.get('cyclic_times', 1), mc.get('step_ratio_up', 0.4))
         self.iter = 0
         self.log_interval = (cfg.get('log_config') or {}).get('interval', 50)
+        # Arithmetic of the matrix kernels for the train step (dense_conv.PLANES): the two-fp16-plane form, watched by
+        # the range guard - armed for iteration 0 and every `range_check_interval` iterations after it; when an operand of
+        # a guarded step is not represented as well as fp32 would (dense_conv.RangeGuard) the run continues on three
+        # bf16 planes. `gga_dense_planes` / `gga_range_check_interval` are extension keys of the config (not the
+        # reference's); GGA_DENSE_PLANES in the environment pins the arithmetic for every caller.
+        from . import dense_conv
+        if not dense_conv.PLANES_PINNED:
+            dense_conv.PLANES = int(cfg.get('gga_dense_planes', 2))
+        self.range_check_interval = int(os.environ.get('GGA_RANGE_CHECK_INTERVAL', cfg.get('gga_range_check_interval', 500)))
+        self.range_reports = []     # (iteration, worst share of lost elements, operands seen) per guarded step
+        self._gc_frozen = False
         self._side = None           # side stream of the input prefetch
         self._prepared = {}         # id(data dict) -> (PreparedInputs, event)
         self._retired = []          # (PreparedInputs, event after the step that consumed them)
@@ -184,10 +248,12 @@ class Runner:
         if not (hasattr(model, 'prepare_inputs') and model.front_reads_counts and torch.cuda.is_available()):
             return
         pts = data.get('points')
-        if pts is None or id(data) in self._prepared:
+        if pts is None or self._prepared_for(data) is not None:
             return
         if self._side is None:
             self._side = torch.cuda.Stream(device=self.device)
+        # the points may have been uploaded (non_blocking) on the main stream just before this call
+        self._side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(self._side):
             prep = model.prepare_inputs(pts)
             ev = torch.cuda.Event()
@@ -197,7 +263,16 @@ class Runner:
         # most of the ~300 buffers of the next prefetch: 47 ms of host time per step) the prepared inputs are
         # kept alive until an event recorded after the consuming step has completed (`_retired`), so their
         # blocks return to the side stream's pool only when no main-stream kernel can still read them.
-        self._prepared[id(data)] = (prep, ev)
+        # keyed by the identity of the batch dict AND of its points list, holding a weak reference to neither: an entry is
+        # only ever used for the very object it was made from (`_prepared_for`), and entries the next step does not consume
+        # are dropped there
+        self._prepared[id(data)] = (prep, ev, data, pts)
+
+    def _prepared_for(self, data):
+        hit = self._prepared.get(id(data))
+        if hit is not None and hit[2] is data and hit[3] is data.get('points'):
+            return hit
+        return None
 
     def _call_train_step(self, data):
         if self.model is self.raw_model:
@@ -209,11 +284,17 @@ class Runner:
     def step(self, data, next_data=None):
         from . import dense_conv
         dense_conv.AMAX_POOL.next_generation()      # one memset for all of this step's absmax slots
-        hit = self._prepared.pop(id(data), None)
-        self._retired = [(p, e) for p, e in self._retired if not e.query()]
+        guarded = (dense_conv.PLANES == 2 and self.range_check_interval > 0 and self.iter % self.range_check_interval == 0
+                   and self.device.type == 'cuda')
+        if guarded:
+            dense_conv.RANGE_GUARD.arm()
+        hit = self._prepared_for(data)
+        stale = [(p, e) for k, (p, e, d, _) in self._prepared.items() if d is not data]
+        self._prepared.clear()                      # a prefetched batch that is not stepped next is dropped, not kept
+        self._retired = [(p, e) for p, e in self._retired + stale if not e.query()]
         prep = None
         if hit is not None:
-            prep, ev = hit
+            prep, ev = hit[:2]
             torch.cuda.current_stream(self.device).wait_event(ev)
             data = dict(data, points=prep)
         if isinstance(self.lr_sched, StepSchedule) and self._base_lrs is None:
@@ -232,6 +313,8 @@ class Runner:
             torch.nn.utils.clip_grad_norm_([p for p in self.raw_model.parameters() if p.grad is not None],
                                            **self.grad_clip)
         self.optimizer.step()
+        if guarded:
+            self._check_range()
         self.iter += 1
         if prep is not None:
             done = torch.cuda.Event()
@@ -241,11 +324,44 @@ class Runner:
             self.prefetch(next_data)
         return out
 
+    def _check_range(self):
+        """End of a guarded step: one host read of the guard's rows; falls back to three bf16 planes when an operand has
+        more than ``RangeGuard.LIMIT`` of its non-zero elements below 2^-30 of its largest magnitude."""
+        import warnings
+        from . import dense_conv
+        rows = dense_conv.RANGE_GUARD.disarm()
+        worst = max(rows, key=lambda r: r['share_lost'], default=None)
+        share = worst['share_lost'] if worst else 0.0
+        self.range_reports.append(dict(iter=self.iter, operands=len(rows), worst_share_lost=share,
+                                       worst_share_below_2p17=max((r['share_below_2p17'] for r in rows), default=0.0),
+                                       worst_shape=worst['shape'] if worst else None))
+        if share > dense_conv.RangeGuard.LIMIT and not dense_conv.PLANES_PINNED:
+            dense_conv.PLANES = 3
+            warnings.warn(f'iteration {self.iter}: {share:.2%} of the non-zero elements of a convolution operand '
+                          f'{worst["shape"]} lie below 2^-30 of its largest magnitude - continuing on three bf16 planes '
+                          f'(fp32 exponent range) instead of two fp16 planes')
+
+    def freeze_gc(self):
+        """Garbage-collector policy of the iteration loop: after the first iterations have built every long-lived object
+        (modules, rule books, workspaces) they are moved to the permanent generation (``gc.freeze``), so the generational
+        passes that still run during training only look at the few objects of the current step - a full pass over the
+        module tree takes tens of ms and stalls the launch queue. Called by ``run`` after its warm-up iterations and by
+        bench.py at the same point: the timed loop and the product loop are the same loop."""
+        import gc
+        if not self._gc_frozen:
+            gc.collect()
+            gc.freeze()
+            self._gc_frozen = True
+
+    GC_FREEZE_AFTER = 3
+
     def run(self, batches, n_iters, logger=None):
         self.raw_model.train()
         t0 = time.time()
         out = None
         for i in range(n_iters):
+            if i == self.GC_FREEZE_AFTER:
+                self.freeze_gc()
             out = self.step(batches[i % len(batches)], next_data=batches[(i + 1) % len(batches)])
             if logger and (i + 1) % self.log_interval == 0:
                 vals = {k: float(v) for k, v in out['log_vars'].items()}      # the only sync, every N iters

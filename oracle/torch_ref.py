@@ -7,7 +7,9 @@ It restates, op for op but batched instead of looped, the reference's
 ``CenterHead_GGA.loss`` (mmdet3d/models/dense_heads/centerpoint_head_gga.py:629-723),
 ``get_prediction_single`` (:250-341), ``get_distance_single`` (:184-239),
 ``PointPillarsScatter.forward_batch`` (middle_encoders/pillar_scatter.py:62-102) and mmdet's
-``GaussianFocalLoss`` / ``L1Loss``. tests/test_torch_ref.py pins it to the golden vectors of
+``GaussianFocalLoss`` / ``L1Loss``; ``reference_train_step`` is the whole step of
+``GGA.forward_train`` (detectors/centerpoint_gga.py:43-86) for both middle encoders - the pillar scatter
+and the SparseEncoder of the shipped config (through oracle/sparse_ref.py). tests/test_torch_ref.py pins it to the golden vectors of
 the imported reference (losses AND gradients).
 """
 import numpy as np
@@ -145,7 +147,14 @@ def reference_train_step(model, batch, srl=None, backward=True):
     else:
         feats = enc(v, n, c)                      # PillarFeatureNet: plain torch modules
     me = model.pts_middle_encoder
-    x = scatter(feats, c, len(pts), me.ny, me.nx)
+    if hasattr(me, 'conv_input'):
+        # SparseEncoder (centerpoint_gga.py:49-51 -> sparse_encoder.py:107-138): the pair-list restatement of every
+        # sparse convolution (oracle/sparse_ref.py), BatchNorm1d / ReLU = the encoder's own torch modules; dispatch is
+        # on attributes, nothing of libgga_hip runs
+        from . import sparse_ref
+        x, _ = sparse_ref.sparse_encoder_reference(me, feats, c, len(pts), pairs=True)
+    else:
+        x = scatter(feats, c, len(pts), me.ny, me.nx)
     x = model.pts_backbone(x)
     x = model.pts_neck(x)
     outs = head(x)

@@ -27,6 +27,17 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+@pytest.fixture(autouse=True)
+def _restore_matrix_arithmetic():
+    """train.Runner selects the arithmetic of the matrix kernels process-wide (dense_conv.PLANES): put the library default
+    back after every test so that no test inherits another one's choice."""
+    from gga_amd import dense_conv
+    was = dense_conv.PLANES, dense_conv.PLANES_PINNED
+    yield
+    dense_conv.PLANES, dense_conv.PLANES_PINNED = was
+    dense_conv.RANGE_GUARD.armed = False
+
+
 @pytest.fixture(scope='session')
 def golden():
     def _load(name):

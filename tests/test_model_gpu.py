@@ -14,6 +14,7 @@ from oracle import torch_ref as R
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
 PP_CFG = os.path.join(REPO, 'configs', 'gga', 'gga_kitti_pointpillars_config.py')
+SECOND_CFG = os.path.join(REPO, 'configs', 'gga', 'gga_kitti_config.py')
 GRAD_TOL = 1e-3      # per-parameter relative L2 error of the gradients against the float64 CPU restatement
 
 
@@ -22,28 +23,57 @@ def test_graft_smoke():
     g.smoke()
 
 
-@pytest.mark.parametrize('channels_last', [False, True])
-def test_pp_train_step_matches_cpu_reference(channels_last):
-    cfg = Config.fromfile(PP_CFG)
-    if channels_last:
-        cfg.model.pts_middle_encoder['channels_last'] = True
-    torch.manual_seed(1)
-    model = build_model(cfg.model)
-    model.train()
+def _damp_heads(model):
     # Kaiming(fan_out) on the 2/3-channel output convs gives log-dims of std ~5 at init, i.e.
     # boxes of e^10 m: damp the regression outputs so the losses are O(1) and comparable
     with torch.no_grad():
         for th in model.pts_bbox_head.task_heads:
             for name in ('reg', 'height', 'dim', 'rot'):
                 getattr(th, name)[-1].weight.mul_(0.05)
+
+
+_REF_CASES = {}
+
+
+def _reference_case(name):
+    """(model with CPU parameters, batch, srl, fp32 restatement after its step, float64 restatement after its step, losses
+    of the fp32 restatement) of one whole-step parity case; the CPU side (oracle/torch_ref.reference_train_step in float32
+    and float64, nothing of libgga_hip) is evaluated once and shared by the parametrisations of the GPU side."""
+    if name in _REF_CASES:
+        return _REF_CASES[name]
+    if name == 'pp':
+        cfg = Config.fromfile(PP_CFG)
+        seed, kw = 1, dict(start=50, n_points=5000, pc_range=synthetic.RANGE_PP, n_obj_range=(4, 8), n_ibp_range=(10, 200))
+    else:       # the reference's shipped model section, real grid (41 x 1600 x 1408), 20 k points per frame
+        cfg = Config.fromfile(SECOND_CFG)
+        seed, kw = 3, dict(start=50, n_points=20000, pc_range=synthetic.RANGE_SECOND, n_obj_range=(4, 8), n_ibp_range=(10, 200))
+    torch.manual_seed(seed)
+    model = build_model(cfg.model)
+    model.train()
+    _damp_heads(model)
     B = 2
-    batch = synthetic.make_batch(B, start=50, n_points=5000, pc_range=synthetic.RANGE_PP, n_obj_range=(4, 8),
-                                 n_ibp_range=(10, 200))
+    batch = synthetic.make_batch(B, **kw)
     ref = copy.deepcopy(model)
     ref64 = copy.deepcopy(model).double()         # the same step in float64: the yardstick for the gradients
     srl = model.pts_bbox_head.draw_srl(B)
-    ref_losses, _ = R.reference_train_step(ref, batch, srl=srl)
-    R.reference_train_step(ref64, batch, srl=srl)
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    try:
+        ref_losses, _ = R.reference_train_step(ref, batch, srl=srl)
+        R.reference_train_step(ref64, batch, srl=srl)
+    finally:
+        torch.set_num_threads(threads)
+    _REF_CASES[name] = (cfg, model, batch, srl, ref, ref64, {k: float(v) for k, v in ref_losses.items()})
+    return _REF_CASES[name]
+
+
+def _gpu_step_against(case, channels_last, planes, monkeypatch):
+    from gga_amd import dense_conv
+    cfg, cpu_model, batch, srl, ref, ref64, ref_losses = _reference_case(case)
+    monkeypatch.setattr(dense_conv, 'PLANES', planes)
+    model = copy.deepcopy(cpu_model)
+    if channels_last:
+        model.pts_middle_encoder.channels_last = True
     model.to(DEV)
     if channels_last:
         from gga_amd.cnn import to_channels_last
@@ -56,7 +86,7 @@ def test_pp_train_step_matches_cpu_reference(channels_last):
                                       data['GGA_in_box_points'], data['img_metas'], srl=srl)
     assert set(losses) == set(ref_losses) and len(losses) == 18
     for k, v in ref_losses.items():
-        assert float(losses[k]) == pytest.approx(float(v), rel=1e-4, abs=1e-4), k     # north_star: within 1e-4
+        assert float(losses[k]) == pytest.approx(v, rel=1e-4, abs=1e-4), k     # north_star: within 1e-4
     total, log_vars = model._parse_losses(losses)
     total.backward()
     grads = {}
@@ -71,6 +101,132 @@ def test_pp_train_step_matches_cpu_reference(channels_last):
     # further from it than twice the fp32 CPU restatement is
     assert len(grads) > 100
     assert R.gradient_offenders(grads, ref, ref64, tol=GRAD_TOL, slack=2.0) == []
+
+
+@pytest.mark.parametrize('planes', [2, 3])
+@pytest.mark.parametrize('channels_last', [False, True])
+def test_pp_train_step_matches_cpu_reference(channels_last, planes, monkeypatch):
+    _gpu_step_against('pp', channels_last, planes, monkeypatch)
+
+
+@pytest.mark.parametrize('planes', [2, 3])
+def test_second_train_step_matches_restatement(planes, monkeypatch):
+    """The reference's shipped config (configs/gga/gga_kitti_config.py: HardSimpleVFE + SparseEncoder + SECOND + SECONDFPN +
+    CenterHead_GGA; detectors/centerpoint_gga.py:43-86, middle_encoders/sparse_encoder.py:107-138) end to end, sparse trunk in
+    the loop, at its real grid with 2 x 20 000 points: all 18 losses within 1e-4 of oracle/torch_ref.reference_train_step
+    (pair-list restatement of the 21 sparse convolutions, plain torch for the rest), every parameter's gradient within
+    1e-3 of the float64 step or inside twice the fp32 restatement's own distance from it. Both arithmetic forms."""
+    _gpu_step_against('second', True, planes, monkeypatch)
+
+
+def test_operand_ranges_of_real_steps_and_the_two_plane_forms(monkeypatch):
+    """Where do the operands of the matrix kernels of a real step lie relative to what the two-fp16-plane form keeps?
+    For one train step of each config after a few optimizer steps: every convolution operand's share of non-zero
+    elements below 2^-17 of its tensor's maximum (fewer than 24 significant bits kept) and below 2^-30 (off by more than
+    1e-3 of itself: 'lost'), and the loss / gradient differences between the two forms on the same weights and batch.
+    The table goes to gpurun_out/range_probe.json; the guard's limit (RangeGuard.LIMIT) is asserted, i.e. on these
+    tensors the Runner would stay on two planes."""
+    import json
+    from gga_amd import dense_conv
+    from gga_amd.train import Runner
+    report = {}
+    for name, cfg_path, rng, B in (('pp', PP_CFG, synthetic.RANGE_PP, 4), ('second', SECOND_CFG, synthetic.RANGE_SECOND, 2)):
+        cfg = Config.fromfile(cfg_path)
+        cfg.model.pts_middle_encoder['channels_last'] = True
+        torch.manual_seed(0)
+        from gga_amd.cnn import to_channels_last
+        model = to_channels_last(build_model(cfg.model).to(DEV)).train()
+        _damp_heads(model)
+        b = synthetic.make_batch(B, n_points=20000, pc_range=rng)
+        b['points'] = [p.to(DEV) for p in b['points']]
+        data = {k: b[k] for k in synthetic.BATCH_KEYS + ('img_metas',)}
+        monkeypatch.setattr(dense_conv, 'PLANES_PINNED', False)
+        runner = Runner(model, cfg, max_iters=100)
+        assert dense_conv.PLANES == 2
+        for _ in range(6):                          # iteration 0 is guarded; then a few real optimizer steps
+            runner.step(data)
+        assert runner.range_reports and runner.range_reports[0]['iter'] == 0
+        assert dense_conv.PLANES == 2, runner.range_reports       # the guard saw nothing to fall back for
+        # one more step's operands, recorded by hand, on both forms from the same weights
+        srl = model.pts_bbox_head.draw_srl(B)
+        res = {}
+        for planes in (2, 3):
+            monkeypatch.setattr(dense_conv, 'PLANES', planes)
+            dense_conv.AMAX_POOL.next_generation()
+            model.zero_grad(set_to_none=True)
+            if planes == 2:
+                dense_conv.RANGE_GUARD.arm()
+            feats = model.extract_feat(data['points'], None, data['img_metas'])[1]
+            outs = model.pts_bbox_head(feats)
+            losses = model.pts_bbox_head.loss(data['gt_bboxes_3d'], data['gt_labels_3d'], outs, data['GGA_boxes_img'],
+                                              data['GGA_lidar2img'], data['GGA_init_pseudo_labels'], data['GGA_bdry_masks'],
+                                              data['GGA_in_box_points'], data['img_metas'], srl=srl)
+            total, _ = model._parse_losses(losses)
+            total.backward()
+            rows = dense_conv.RANGE_GUARD.disarm() if planes == 2 else None
+            res[planes] = ({k: float(v) for k, v in losses.items()},
+                           {n: p.grad.double().cpu() for n, p in model.named_parameters() if p.grad is not None}, rows)
+        l2, g2, rows = res[2]
+        l3, g3, _ = res[3]
+        loss_diff = max(abs(l2[k] - l3[k]) / max(abs(l3[k]), 1e-4) for k in l3)
+        grad_diff = {n: float((g2[n] - g3[n]).norm() / g3[n].norm()) for n in g3 if float(g3[n].norm()) > 1e-12}
+        worst_grad = max(grad_diff, key=grad_diff.get)
+        report[name] = dict(
+            operands=len(rows), worst_share_below_2p17=max(r['share_below_2p17'] for r in rows),
+            worst_share_lost=max(r['share_lost'] for r in rows), worst_mass_lost=max(r['mass_lost'] for r in rows),
+            operands_with_any_below_2p17=sum(r['share_below_2p17'] > 0 for r in rows),
+            operands_with_any_lost=sum(r['share_lost'] > 0 for r in rows),
+            top_by_share_below_2p17=sorted(rows, key=lambda r: -r['share_below_2p17'])[:8],
+            loss_max_rel_diff_2_vs_3_planes=loss_diff, grad_max_rel_l2_diff_2_vs_3_planes=grad_diff[worst_grad],
+            grad_worst_parameter=worst_grad, guard_reports=runner.range_reports)
+        assert len(rows) > 100
+        assert loss_diff < 1e-5, (name, loss_diff)
+        # gradients of the two forms differ by what two fp32 implementations differ by (the whole-step tests bound each
+        # against float64); 1e-3 here is that bound, not a property of the planes
+        assert grad_diff[worst_grad] < 1e-3, (name, worst_grad, grad_diff[worst_grad])
+        assert report[name]['worst_share_lost'] <= dense_conv.RangeGuard.LIMIT, report[name]
+        del runner, model
+        torch.cuda.empty_cache()
+    os.makedirs(os.path.join(REPO, 'gpurun_out'), exist_ok=True)
+    with open(os.path.join(REPO, 'gpurun_out', 'range_probe.json'), 'w') as f:
+        json.dump(report, f, indent=1)
+    print(json.dumps({k: {a: v for a, v in r.items() if not isinstance(v, list)} for k, r in report.items()}))
+
+
+def test_range_guard_sends_a_heavy_tailed_step_to_three_planes(monkeypatch):
+    """The guard itself: (i) an operand with a third of its non-zero elements 2^-40 below its maximum is reported as such;
+    (ii) a Runner whose guarded step sees an operand over the limit continues on three bf16 planes and says so."""
+    import warnings
+    from gga_amd import dense_conv
+    from gga_amd.train import Runner
+    monkeypatch.setattr(dense_conv, 'PLANES', 2)
+    monkeypatch.setattr(dense_conv, 'PLANES_PINNED', False)
+    torch.manual_seed(0)
+    conv = torch.nn.Conv2d(64, 64, 3, padding=1, bias=False).to(DEV)
+    x = torch.randn(2, 64, 24, 40, device=DEV)
+    x[:, :, ::3] *= 2.0 ** -40
+    x = x.contiguous(memory_format=torch.channels_last)
+    dense_conv.RANGE_GUARD.arm()
+    with torch.no_grad():
+        dense_conv.conv2d(x, conv)
+    rows = dense_conv.RANGE_GUARD.disarm()
+    assert len(rows) == 2                                   # the activation and the weight
+    assert 0.3 < rows[0]['share_lost'] < 0.37 and rows[1]['share_lost'] == 0
+    cfg = Config.fromfile(PP_CFG)
+    model = build_model(cfg.model).to(DEV).train()
+    _damp_heads(model)
+    b = synthetic.make_batch(2, n_points=3000, pc_range=synthetic.RANGE_PP)
+    b['points'] = [p.to(DEV) for p in b['points']]
+    data = {k: b[k] for k in synthetic.BATCH_KEYS + ('img_metas',)}
+    runner = Runner(model, cfg, max_iters=100)
+    assert dense_conv.PLANES == 2
+    monkeypatch.setattr(dense_conv.RangeGuard, 'LIMIT', -1.0)        # every operand is "over the limit"
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        runner.step(data)
+    assert dense_conv.PLANES == 3 and any('three bf16 planes' in str(x.message) for x in w)
+    out = runner.step(data)                                  # and the run goes on, unguarded, on three planes
+    assert np.isfinite(float(out['loss'])) and len(runner.range_reports) == 1
 
 
 def test_loss_path_full_batch_vs_c_oracle():
@@ -306,12 +462,15 @@ def test_bench_line_contract_single_gpu():
     """The default single-GPU line carries every field the driver and the judge read."""
     res = _run_bench(['--steps', '2', '--warmup', '1', '--batch', '2', '--second-batch', '2', '--pgd-batch', '1', '--no-cpu-baseline'])
     for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
-              'vs_baseline', 'dtype', 'arith', 'data', 'config', 'roofline', 'mfma_roofline', 'second_trunk', 'pgd_trunk'):
+              'vs_baseline', 'dtype', 'arith', 'data', 'config', 'roofline', 'mfma_roofline', 'second_trunk', 'pgd_trunk',
+              'planes3', 'range_guard'):
         assert k in res, k
     assert res['roofline']['bound'] == 'hbm' and res['roofline']['launches_timed'] == 2
     assert res['mfma_roofline']['launches_timed'] == 2 * res['mfma_roofline']['launches_per_step']
     assert 0 < res['mfma_roofline']['share_of_step'] < 1
     assert 'fp16 planes' in res['arith'] and 'three f16 MFMA partial products' in res['arith'] and res['dtype'] == 'f32'
+    assert res['config']['matrix_planes'] == 2 and res['range_guard'][0]['iter'] == 0
+    assert res['planes3']['ms_per_step'] > 0 and res['planes3']['second_trunk']['ms_per_step'] > 0
 
 
 def test_edge_cases_empty_inputs():

@@ -174,7 +174,11 @@ def test_fcos_mono3d_train_step_learns():
     cfg = Config.fromfile(os.path.join(REPO, 'configs', 'gga', 'gga_pdg.py'))
     torch.manual_seed(0)
     model = to_channels_last(build_model(cfg.model).to(DEV))
-    model.bbox_head.init_weights()
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')        # the backbone's model-zoo checkpoint cannot be fetched here
+        model.init_weights()
+    synthetic.damp_random_backbone(model)
     model.train()
     runner = Runner(model, cfg, max_iters=100, iters_per_epoch=10)
     b = synthetic.make_mono_batch(2, device=DEV, img_hw=(192, 640))
@@ -202,7 +206,11 @@ def test_level_streams_and_prepared_targets_change_nothing(monkeypatch):
     cfg = Config.fromfile(os.path.join(REPO, 'configs', 'gga', 'gga_pdg.py'))
     torch.manual_seed(0)
     model = to_channels_last(build_model(cfg.model).to(DEV))
-    model.bbox_head.init_weights()
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')        # the backbone's model-zoo checkpoint cannot be fetched here
+        model.init_weights()
+    synthetic.damp_random_backbone(model)
     model.train()
     b = synthetic.make_mono_batch(2, device=DEV, img_hw=(192, 640))
     data = {k: b[k] for k in synthetic.MONO_BATCH_KEYS}

@@ -200,6 +200,8 @@ def test_sparse_encoder_full_grid_vs_pair_list_reference():
     # the BatchNorm parameters at the end of the 21-layer backward chain (conv_input.1, encoder_layer2.0.bn1) come
     # out at 1.2e-3 .. 1.9e-3 on the GPU path where the fp32 restatement has 3e-4 .. 8e-4 (measured, run to run);
     # everything else is inside 1e-3 or the fp32 floor
+    strict = R.gradient_offenders(grads, ref, ref64, tol=1e-3, slack=2.0)
+    print('STRICT_OFFENDERS', strict)
     bad = R.gradient_offenders(grads, ref, ref64, tol=2e-3, slack=3.0)
     assert bad == [], bad
 

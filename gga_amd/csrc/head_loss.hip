@@ -52,10 +52,17 @@ __global__ __launch_bounds__(256) void gather_pred_bwd_kernel(const float* __res
     if (t >= n * 8) return;
     const int s = t >> 3, c = t & 7;
     if (!mask[s]) return;                 // zero weight in every loss term
-    const float g = grad_pred[t];
-    if (g == 0.0f) return;
     const int64_t b = s / K;
     const int64_t i = ind[s];
+    // Two objects of a frame may share a cell. Deterministic without atomics: the FIRST live slot of a cell (in slot order)
+    // writes the sum over all of that cell's live slots, added in slot order; the others write nothing. K <= 500 slots
+    // per frame and a few dozen live ones: the scans are a few thousand cached loads per step.
+    const int s0 = (int)b * K, k = s - s0;
+    for (int j = 0; j < k; ++j)
+        if (mask[s0 + j] && ind[s0 + j] == i) return;
+    float g = grad_pred[t];
+    for (int j = k + 1; j < K; ++j)
+        if (mask[s0 + j] && ind[s0 + j] == i) g += grad_pred[(int64_t)(s0 + j) * 8 + c];
     float* dst;
     switch (c) {
         case 0: case 1: dst = g_reg + (b * 2 + c) * hw; break;
@@ -63,7 +70,7 @@ __global__ __launch_bounds__(256) void gather_pred_bwd_kernel(const float* __res
         case 3: case 4: case 5: dst = g_dim + (b * 3 + (c - 3)) * hw; break;
         default: dst = g_rot + (b * 2 + (c - 6)) * hw; break;
     }
-    atomicAdd(dst + i, g);                // two objects may share a cell
+    dst[i] = g;
 }
 
 extern "C" int gga_gather_pred_fwd(const float* reg, const float* height, const float* dim, const float* rot,

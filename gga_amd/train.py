@@ -335,7 +335,7 @@ class Runner:
         self.range_reports.append(dict(iter=self.iter, operands=len(rows), worst_share_lost=share,
                                        worst_share_below_2p17=max((r['share_below_2p17'] for r in rows), default=0.0),
                                        worst_shape=worst['shape'] if worst else None))
-        if share > dense_conv.RangeGuard.LIMIT and not dense_conv.PLANES_PINNED:
+        if worst is not None and share > dense_conv.RangeGuard.LIMIT and not dense_conv.PLANES_PINNED:
             dense_conv.PLANES = 3
             warnings.warn(f'iteration {self.iter}: {share:.2%} of the non-zero elements of a convolution operand '
                           f'{worst["shape"]} lie below 2^-30 of its largest magnitude - continuing on three bf16 planes '

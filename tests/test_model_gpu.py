@@ -212,8 +212,10 @@ def test_range_guard_sends_a_heavy_tailed_step_to_three_planes(monkeypatch):
     rows = dense_conv.RANGE_GUARD.disarm()
     assert len(rows) == 2                                   # the activation and the weight
     assert 0.3 < rows[0]['share_lost'] < 0.37 and rows[1]['share_lost'] == 0
+    from gga_amd.cnn import to_channels_last
     cfg = Config.fromfile(PP_CFG)
-    model = build_model(cfg.model).to(DEV).train()
+    cfg.model.pts_middle_encoder['channels_last'] = True         # the matrix kernels take channels-last activations
+    model = to_channels_last(build_model(cfg.model).to(DEV)).train()
     _damp_heads(model)
     b = synthetic.make_batch(2, n_points=3000, pc_range=synthetic.RANGE_PP)
     b['points'] = [p.to(DEV) for p in b['points']]
@@ -408,11 +410,10 @@ def test_second_config_prefetched_front_equals_inline_and_empty_batch():
         torch.manual_seed(100 + i)
         lb.append(float(rb.step(batches[i % 2], next_data=batches[(i + 1) % 2])['loss']))
         assert i == 0 or len(rb._prepared) == 1
-    # same kernels, same inputs, only the stream of the front differs. Step 0 is bit-identical; later steps
-    # inherit the run-to-run noise of the few kernels that still sum with float atomics (the head loss's scatter of
-    # gradients into shared cells), which AdamW amplifies step by step (one run in about twenty leaves 1e-5 at step 1)
-    assert la[0] == lb[0] and la[1] == pytest.approx(lb[1], rel=1e-4), (la, lb)
-    assert la[2:] == pytest.approx(lb[2:], rel=2e-2), (la, lb)
+    # same kernels, same inputs, only the stream of the front differs; no kernel of the step sums with float atomics
+    # (the head loss's scatter of gradients into shared cells adds in slot order), so the two runs are the same run
+    print('PREFETCH', la, lb)
+    assert la == lb, (la, lb)
     # all points outside the range: zero voxels, zero sites on every level
     far = dict(batches[0], points=[torch.full((50, 4), 500.0, device=DEV) for _ in range(2)])
     out = ra.step(far)

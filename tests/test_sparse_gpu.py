@@ -103,7 +103,11 @@ def test_dense_and_replace_feature():
     assert y._level is x._level and torch.equal(y.dense().cpu(), d * 2)
 
 
-def test_sparse_encoder_gga_config_vs_dense_reference():
+@pytest.mark.parametrize('planes', [2, 3])
+def test_sparse_encoder_gga_config_vs_dense_reference(planes, monkeypatch):
+    from gga_amd import dense_conv
+    from oracle import torch_ref as R
+    monkeypatch.setattr(dense_conv, 'PLANES', planes)
     torch.manual_seed(0)
     shape, B = (41, 40, 32), 2
     enc = SparseEncoder(in_channels=4, sparse_shape=list(shape), output_channels=128, order=('conv', 'norm', 'act'),
@@ -111,6 +115,7 @@ def test_sparse_encoder_gga_config_vs_dense_reference():
                         encoder_paddings=((0, 0, 1), (0, 0, 1), (0, 0, [0, 1, 1]), (0, 0)), block_type='basicblock')
     enc.train()
     ref = copy.deepcopy(enc)
+    ref64 = copy.deepcopy(enc).double()
     coors = _coords(B, shape, 900, seed=5)
     feats = torch.randn(len(coors), 4)
     yr, _ = SR.sparse_encoder_reference(ref, feats, coors, B)
@@ -121,9 +126,13 @@ def test_sparse_encoder_gga_config_vs_dense_reference():
     g = torch.randn_like(yr)
     yr.backward(g)
     y.backward(g.to(DEV))
-    for (n1, p1), (n2, p2) in zip(enc.named_parameters(), ref.named_parameters()):
-        err = float((p1.grad.cpu() - p2.grad).norm() / (p2.grad.norm() + 1e-12))
-        assert err < 2e-3, (n1, err)      # 21 fp32 conv+BN layers deep; the last levels hold few sites
+    # 21 fp32 conv + BN layers deep and the last levels hold few sites: two fp32 implementations differ by more than 1e-3
+    # in the first layers' gradients, so each is measured against the same encoder in float64
+    # (oracle/torch_ref.gradient_offenders: within 1e-3 of float64, or no further from it than twice the fp32 restatement)
+    y64, _ = SR.sparse_encoder_reference(ref64, feats.double(), coors, B)
+    y64.backward(g.double())
+    grads = {n: p.grad.cpu() for n, p in enc.named_parameters()}
+    assert R.gradient_offenders(grads, ref, ref64, tol=1e-3, slack=2.0) == []
     for (n1, b1), (n2, b2) in zip(enc.named_buffers(), ref.named_buffers()):
         torch.testing.assert_close(b1.cpu(), b2, rtol=1e-4, atol=1e-5, msg=n1)
 

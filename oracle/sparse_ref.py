@@ -105,8 +105,18 @@ def _is_conv(m):
     return hasattr(m, 'subm') and hasattr(m, 'kernel_size') and hasattr(m, 'weight')
 
 
+class Trace(list):
+    """``trace`` argument that also records every convolution's INPUT features, coordinates and shape (``.inputs``)."""
+
+    def __init__(self):
+        super().__init__()
+        self.inputs = []
+
+
 def _run(module, feats, coors, batch, shape, conv_fn, trace):
     if _is_conv(module):
+        if isinstance(trace, Trace):
+            trace.inputs.append((feats, coors, shape))
         f, coors, shape = conv_fn(module, feats, coors, batch, shape)
         if trace is not None:
             trace.append((f, coors, shape))

@@ -60,16 +60,17 @@ def _reference_case(name):
     torch.set_num_threads(min(os.cpu_count() or 1, 32))
     try:
         ref_losses, _ = R.reference_train_step(ref, batch, srl=srl)
-        R.reference_train_step(ref64, batch, srl=srl)
+        ref64_losses, _ = R.reference_train_step(ref64, batch, srl=srl)
     finally:
         torch.set_num_threads(threads)
-    _REF_CASES[name] = (cfg, model, batch, srl, ref, ref64, {k: float(v) for k, v in ref_losses.items()})
+    _REF_CASES[name] = (cfg, model, batch, srl, ref, ref64, {k: float(v) for k, v in ref_losses.items()},
+                        {k: float(v) for k, v in ref64_losses.items()})
     return _REF_CASES[name]
 
 
 def _gpu_step_against(case, channels_last, planes, monkeypatch):
     from gga_amd import dense_conv
-    cfg, cpu_model, batch, srl, ref, ref64, ref_losses = _reference_case(case)
+    cfg, cpu_model, batch, srl, ref, ref64, ref_losses, ref64_losses = _reference_case(case)
     monkeypatch.setattr(dense_conv, 'PLANES', planes)
     model = copy.deepcopy(cpu_model)
     if channels_last:
@@ -85,6 +86,7 @@ def _gpu_step_against(case, channels_last, planes, monkeypatch):
                                       data['GGA_lidar2img'], data['GGA_init_pseudo_labels'], data['GGA_bdry_masks'],
                                       data['GGA_in_box_points'], data['img_metas'], srl=srl)
     assert set(losses) == set(ref_losses) and len(losses) == 18
+    print('LOSSES', case, planes, {k: (float(losses[k]), ref_losses[k], ref64_losses[k]) for k in ref_losses})
     for k, v in ref_losses.items():
         assert float(losses[k]) == pytest.approx(v, rel=1e-4, abs=1e-4), k     # north_star: within 1e-4
     total, log_vars = model._parse_losses(losses)

@@ -103,38 +103,65 @@ def test_dense_and_replace_feature():
     assert y._level is x._level and torch.equal(y.dense().cpu(), d * 2)
 
 
+def _relu_decisions_that_differ(enc, trace, feats, coors, B, y, y64):
+    """Number of post-ReLU elements (the inputs of every convolution after the first, and the encoder's output) that
+    are live on one side and dead on the other. Such an element sat within rounding of zero before the ReLU: the forward
+    values agree, but its gradient is passed on one side and stopped on the other - a kink of the function, not an error
+    of either side. On the small grids of these tests one such element moves a layer's gradient by ~1e-2."""
+    n = int(((y.detach().cpu() > 0) != (y64.detach() > 0)).sum())
+    for (f1, c1, s1), (f2, c2, s2) in list(zip(enc._conv_inputs, trace.inputs))[1:]:
+        a, _ = _sorted_rows(f1, c1, s1)
+        b, _ = _sorted_rows(f2.detach(), c2, s2)
+        n += int(((a > 0) != (b > 0)).sum())
+    return n
+
+
 @pytest.mark.parametrize('planes', [2, 3])
 def test_sparse_encoder_gga_config_vs_dense_reference(planes, monkeypatch):
     from gga_amd import dense_conv
+    from gga_amd.sparse import SparseConvolution
     from oracle import torch_ref as R
     monkeypatch.setattr(dense_conv, 'PLANES', planes)
-    torch.manual_seed(0)
     shape, B = (41, 40, 32), 2
-    enc = SparseEncoder(in_channels=4, sparse_shape=list(shape), output_channels=128, order=('conv', 'norm', 'act'),
-                        encoder_channels=((16, 16, 32), (32, 32, 64), (64, 64, 128), (128, 128)),
-                        encoder_paddings=((0, 0, 1), (0, 0, 1), (0, 0, [0, 1, 1]), (0, 0)), block_type='basicblock')
-    enc.train()
-    ref = copy.deepcopy(enc)
-    ref64 = copy.deepcopy(enc).double()
-    coors = _coords(B, shape, 900, seed=5)
-    feats = torch.randn(len(coors), 4)
-    yr, _ = SR.sparse_encoder_reference(ref, feats, coors, B)
-    enc.to(DEV)
-    y = enc(feats.to(DEV), coors.to(DEV), B)
-    assert y.shape == yr.shape == (B, 256, 5, 4)
-    torch.testing.assert_close(y.detach().cpu(), yr.detach(), rtol=1e-3, atol=1e-3)
-    g = torch.randn_like(yr)
-    yr.backward(g)
-    y.backward(g.to(DEV))
-    # 21 fp32 conv + BN layers deep and the last levels hold few sites: two fp32 implementations differ by more than 1e-3
-    # in the first layers' gradients, so each is measured against the same encoder in float64
-    # (oracle/torch_ref.gradient_offenders: within 1e-3 of float64, or no further from it than twice the fp32 restatement)
-    y64, _ = SR.sparse_encoder_reference(ref64, feats.double(), coors, B)
-    y64.backward(g.double())
-    grads = {n: p.grad.cpu() for n, p in enc.named_parameters()}
-    assert R.gradient_offenders(grads, ref, ref64, tol=1e-3, slack=2.0) == []
-    for (n1, b1), (n2, b2) in zip(enc.named_buffers(), ref.named_buffers()):
-        torch.testing.assert_close(b1.cpu(), b2, rtol=1e-4, atol=1e-5, msg=n1)
+    clean = 0
+    for seed in range(4):
+        torch.manual_seed(seed)
+        enc = SparseEncoder(in_channels=4, sparse_shape=list(shape), output_channels=128, order=('conv', 'norm', 'act'),
+                            encoder_channels=((16, 16, 32), (32, 32, 64), (64, 64, 128), (128, 128)),
+                            encoder_paddings=((0, 0, 1), (0, 0, 1), (0, 0, [0, 1, 1]), (0, 0)), block_type='basicblock')
+        enc.train()
+        ref = copy.deepcopy(enc)
+        ref64 = copy.deepcopy(enc).double()
+        coors = _coords(B, shape, 900, seed=5 + seed)
+        feats = torch.randn(len(coors), 4)
+        yr, _ = SR.sparse_encoder_reference(ref, feats, coors, B)
+        enc.to(DEV)
+        enc._conv_inputs = []
+        hooks = [m.register_forward_pre_hook(lambda mod, inp: enc._conv_inputs.append(
+            (inp[0].features.detach().cpu(), inp[0].indices.cpu(), tuple(inp[0].spatial_shape))))
+            for m in enc.modules() if isinstance(m, SparseConvolution)]
+        y = enc(feats.to(DEV), coors.to(DEV), B)
+        for h in hooks:
+            h.remove()
+        assert y.shape == yr.shape == (B, 256, 5, 4)
+        torch.testing.assert_close(y.detach().cpu(), yr.detach(), rtol=1e-3, atol=1e-3)
+        g = torch.randn_like(yr)
+        yr.backward(g)
+        y.backward(g.to(DEV))
+        for (n1, b1), (n2, b2) in zip(enc.named_buffers(), ref.named_buffers()):
+            torch.testing.assert_close(b1.cpu(), b2, rtol=1e-4, atol=1e-5, msg=n1)
+        # 21 fp32 conv + BN layers deep and the last levels hold few sites: two fp32 implementations differ by more than 1e-3
+        # in the first layers' gradients, so each is measured against the same encoder in float64
+        # (oracle/torch_ref.gradient_offenders: within 1e-3 of float64, or no further from it than twice the fp32 restatement)
+        trace = SR.Trace()
+        y64, _ = SR.sparse_encoder_reference(ref64, feats.double(), coors, B, trace=trace)
+        y64.backward(g.double())
+        if _relu_decisions_that_differ(enc, trace, feats, coors, B, y, y64):
+            continue            # a ReLU decision within rounding of zero: this draw cannot be compared (see the helper)
+        clean += 1
+        grads = {n: p.grad.cpu() for n, p in enc.named_parameters()}
+        assert R.gradient_offenders(grads, ref, ref64, tol=1e-3, slack=2.0) == [], seed
+    assert clean >= 1, 'every one of four draws had a ReLU decision within rounding of zero'
 
 
 def test_reference_shape_test():
@@ -149,7 +176,8 @@ def test_reference_shape_test():
     assert ret.shape == torch.Size([4, 256, 128, 128])
 
 
-def test_sparse_encoder_full_grid_vs_pair_list_reference():
+@pytest.mark.parametrize('planes', [2, 3])
+def test_sparse_encoder_full_grid_vs_pair_list_reference(planes, monkeypatch):
     """The SparseEncoder of configs/gga/gga_kitti_config.py at its real grid (41 x 1600 x 1408) on four
     voxelized synthetic KITTI frames (> 50 k input sites): after EVERY convolution the site set
     equals the pair-list restatement's exactly and the features agree; then the gradients of every
@@ -161,6 +189,8 @@ def test_sparse_encoder_full_grid_vs_pair_list_reference():
     from gga_amd import functional as F
     from gga_amd.registry import build_middle_encoder
     from gga_amd.sparse import SparseConvolution
+    from gga_amd import dense_conv
+    monkeypatch.setattr(dense_conv, 'PLANES', planes)
     cfg = Config.fromfile(os.path.join(REPO, 'configs', 'gga', 'gga_kitti_config.py'))
     torch.manual_seed(0)
     enc = build_middle_encoder(cfg.model.pts_middle_encoder)
@@ -206,12 +236,8 @@ def test_sparse_encoder_full_grid_vs_pair_list_reference():
     y64, _ = SR.sparse_encoder_reference(ref64, feats.double(), c, B, pairs=True)
     y64.backward(g.double())
     grads = {n: p.grad for n, p in enc.named_parameters()}
-    # the BatchNorm parameters at the end of the 21-layer backward chain (conv_input.1, encoder_layer2.0.bn1) come
-    # out at 1.2e-3 .. 1.9e-3 on the GPU path where the fp32 restatement has 3e-4 .. 8e-4 (measured, run to run);
-    # everything else is inside 1e-3 or the fp32 floor
-    strict = R.gradient_offenders(grads, ref, ref64, tol=1e-3, slack=2.0)
-    print('STRICT_OFFENDERS', strict)
-    bad = R.gradient_offenders(grads, ref, ref64, tol=2e-3, slack=3.0)
+    bad = R.gradient_offenders(grads, ref, ref64, tol=1e-3, slack=2.0)
+    print('FULL_GRID_OFFENDERS', planes, bad)
     assert bad == [], bad
 
 

@@ -39,6 +39,7 @@ pair_cache = {}
 
 
 def pairs_of(ptr, n_rows, kvol):
+    ptr = getattr(ptr, 'value', ptr)
     t = maps.get(ptr)
     if t is None:
         return None

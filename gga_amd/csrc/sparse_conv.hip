@@ -753,7 +753,7 @@ extern "C" int gga_absmax_bits(const float* x, int64_t rows, int width, int64_t 
     return GGA_OK;
 }
 
-// packed[k][chunk][plane][col < CO][32 ch] bf16 = plane of W[k][chunk*32 + ch][col], CO = 32 * nt
+// packed[k][chunk][plane][col < CO][32 ch] bf16 = plane of W[k][chunk*32 + ch][col], CO = 32 * nt (quarters swizzled, below)
 __global__ __launch_bounds__(256) void sp_pack_weight_split_kernel(const float* __restrict__ W, int kvol, int cin, int cout,
                                                                   int nt, int transpose, int64_t total, int np,
                                                                   const uint32_t* __restrict__ amax_w,
@@ -769,7 +769,9 @@ __global__ __launch_bounds__(256) void sp_pack_weight_split_kernel(const float* 
     float v = 0.0f;
     if (c < cin && col < cout)
         v = transpose ? W[((int64_t)k * cout + col) * cin + c] : W[((int64_t)k * cin + c) * cout + col];
-    uint16_t* dst = P + stage * (np * (int64_t)co * 32) + (int64_t)col * 32 + ch;
+    // the four 16-byte quarters of a column's 64-byte row are stored XOR-swizzled by (col >> 2) & 3: an LDS image that is a
+    // plain copy of a packed stage (what an LDS-DMA produces) is then read conflict-free by ds_read_b128 without padding
+    uint16_t* dst = P + stage * (np * (int64_t)co * 32) + (int64_t)col * 32 + ((((ch >> 3) ^ ((col >> 2) & 3)) << 3) | (ch & 7));
     if (np == 3) {
         uint32_t p1, p2, p3;
         x9_split(v, p1, p2, p3);
@@ -832,168 +834,16 @@ struct SpBnBwd {
     int64_t ystride;
 };
 
-template <int NT, bool VEC, int NP>
-__global__ __launch_bounds__(64 * X9_NW) void sp_conv_x9_kernel(const float* __restrict__ X, const int32_t* __restrict__ map,
-                                                        const uint16_t* __restrict__ Wp,
-                                                        const int32_t* __restrict__ perm,
-                                                        const uint32_t* __restrict__ rowmask, int64_t n_rows,
-                                                        int kvol, int cin, int cout, int flip,
-                                                        float* __restrict__ Y, int64_t ys,
-                                                        const uint32_t* __restrict__ amax_x,
-                                                        const uint32_t* __restrict__ amax_w, double* __restrict__ stats,
-                                                        SpBnBwd bn) {
-    // NP = 3: bf16 planes, six partial products; NP = 2: fp16 planes of the scaled operands, three (h2_split2)
+// Epilogue of the gather-GEMM kernels: rescale (two-plane arithmetic), store the rows through the row -> output row table,
+// the optional BatchNorm-backward masking (SpBnBwd) and the per-channel sums of the tile (`stats`, row `tile`).
+// D layout of 32x32x16: register v of lane l holds row (v/4)*8 + (l/32)*4 + v%4, column l%32; the row -> output row table
+// goes through LDS (each lane knows only its own row). `scratch`: LDS no wave reads any more, >= max(NW * 128, NW * 8 * CO) bytes.
+template <int NT, int NP, int NW>
+__device__ __forceinline__ void x9_epilogue(mf_v16 (&acc)[NT], const int pr, const int wave, const int r, const int h,
+                                            const int tid, const int cout, float* __restrict__ Y, const int64_t ys,
+                                            double* __restrict__ stats, const int64_t tile, const SpBnBwd& bn,
+                                            unsigned char* scratch, const int sbx, const int sbw) {
     constexpr int CO = NT * 32;
-    constexpr int BPL = CO * X9_ROWB;                     // bytes per B plane
-    constexpr int BSZ = NP * BPL;                         // bytes per B buffer
-    constexpr int BPIECES = NP * CO * 4;                  // 16-byte pieces of a packed weight stage
-    int sbx = 127, sbw = 127;
-    if (NP == 2) { sbx = h2_scale_exp(*amax_x); sbw = h2_scale_exp(*amax_w); }
-    const float xscale = h2_scale(sbx);
-    constexpr int NW = X9_NW, THREADS = 64 * NW;
-    constexpr int NB = (BPIECES + THREADS - 1) / THREADS;   // pieces per thread
-    __shared__ __attribute__((aligned(16))) unsigned char Bs[2 * BSZ];
-    __shared__ uint32_t wmask_s[NW];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 31, h = lane >> 5;
-    const int64_t r0 = (int64_t)(gridDim.x - 1 - blockIdx.x) * (32 * NW);  // most neighbours first
-    if (tid < NW) wmask_s[tid] = 0;
-    __syncthreads();
-    const int64_t myrow = r0 + wave * 32 + r;
-    const int pr = myrow < n_rows ? (perm ? perm[myrow] : (int)myrow) : -1;
-    {
-        uint32_t m = 0;
-        if (pr >= 0) m = (rowmask && kvol <= 32) ? rowmask[pr] : 0xFFFFFFFFu;
-        if (m && h == 0) atomicOr(&wmask_s[wave], m);
-    }
-    __syncthreads();
-    const uint32_t wmask = __builtin_amdgcn_readfirstlane(wmask_s[wave]);
-    uint32_t tm = 0;
-#pragma unroll
-    for (int w = 0; w < NW; ++w) tm |= wmask_s[w];
-    const uint32_t tmask = __builtin_amdgcn_readfirstlane(tm);
-    mf_v16 acc[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
-
-    const int nchunks = (cin + MF_TK - 1) / MF_TK;
-    auto enabled = [&](int k) { const int kk = flip ? (kvol - 1 - k) : k; return kvol > 32 || ((tmask >> kk) & 1u); };
-    auto next_enabled = [&](int k) { while (k < kvol && !enabled(k)) ++k; return k; };
-    auto load_idx = [&](int k) {
-        const int kk = flip ? (kvol - 1 - k) : k;
-        return map[(int64_t)kk * n_rows + (pr >= 0 ? pr : 0)];   // rows past n_rows gather something valid; never written
-    };
-    // raw[s][j]: floats 16s + 8h + 4j .. +3 of the lane's row in the 32-channel chunk
-    float4 rn00, rn01, rn10, rn11;                        // next stage, in flight
-    float4 rc00, rc01, rc10, rc11;                        // current stage
-    uint4 bq0, bq1, bq2, bq3, bq4, bq5;
-    bq0 = bq1 = bq2 = bq3 = bq4 = bq5 = make_uint4(0, 0, 0, 0);
-    rn00 = rn01 = rn10 = rn11 = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto ld4 = [&](const float* row, int c) -> float4 {
-        if (VEC) return *reinterpret_cast<const float4*>(row + (c < cin ? c : 0));
-        return make_float4(row[c < cin ? c : 0], row[c + 1 < cin ? c + 1 : 0], row[c + 2 < cin ? c + 2 : 0],
-                           row[c + 3 < cin ? c + 3 : 0]);
-    };
-    // loads are unconditional: an absent neighbour reads row 0 and is zeroed when it is split
-    auto load_a = [&](int ch, int i0) {
-        const float* row = X + (int64_t)(i0 >= 0 ? i0 : 0) * cin;
-        const int c = ch * MF_TK + 8 * h;
-        rn00 = ld4(row, c); rn01 = ld4(row, c + 4); rn10 = ld4(row, c + 16); rn11 = ld4(row, c + 20);
-    };
-    auto load_b = [&](int k, int ch) {
-        const uint4* src = reinterpret_cast<const uint4*>(Wp + ((int64_t)k * nchunks + ch) * (NP * CO * 32));
-        const int last = BPIECES - 1;
-#define X9_BLD(E, V) if ((E) < NB) V = src[min(tid + THREADS * (E), last)];
-        X9_BLD(0, bq0) X9_BLD(1, bq1) X9_BLD(2, bq2) X9_BLD(3, bq3) X9_BLD(4, bq4) X9_BLD(5, bq5)
-#undef X9_BLD
-    };
-    auto store_b = [&](int buf) {
-        // piece f of the packed stage: plane f / (CO*4), column (f / 4) % CO, quarter f % 4
-#define X9_BST(E, V) if ((E) < NB) { const int f = tid + THREADS * (E); if (f < BPIECES) *reinterpret_cast<uint4*>(Bs + buf * BSZ + (f / (CO * 4)) * BPL + ((f >> 2) % CO) * X9_ROWB + (f & 3) * 16) = V; }
-        X9_BST(0, bq0) X9_BST(1, bq1) X9_BST(2, bq2) X9_BST(3, bq3) X9_BST(4, bq4) X9_BST(5, bq5)
-#undef X9_BST
-    };
-    // 8 floats -> one 8 x bf16 fragment per plane
-    union Frag { mf_v8bf v; uint32_t u[4]; };
-    auto split8 = [&](const float4& lo, const float4& hi, bool ok, int c, Frag& f1, Frag& f2, Frag& f3) {
-        const float e[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float x = ok && c + 2 * j < cin ? e[2 * j] : 0.f, y = ok && c + 2 * j + 1 < cin ? e[2 * j + 1] : 0.f;
-            if (NP == 3) x9_split2(x, y, f1.u[j], f2.u[j], f3.u[j]);
-            else h2_split2(x * xscale, y * xscale, f1.u[j], f2.u[j]);
-        }
-    };
-
-    int k = next_enabled(0), ch = 0;
-    if (k < kvol) {
-        int ia = load_idx(k);
-        int knext = next_enabled(k + 1);
-        int ian = load_idx(knext < kvol ? knext : k);
-        load_a(0, ia);
-        load_b(k, 0);
-        store_b(0);
-        rc00 = rn00; rc01 = rn01; rc10 = rn10; rc11 = rn11;
-        int ic = ia;                                     // rule-book entry the current stage was loaded with
-        int k1 = k, ch1 = 1;
-        if (ch1 == nchunks) { ch1 = 0; k1 = knext; }
-        __syncthreads();
-        int buf = 0;
-        while (true) {
-            // request stage (k1, ch1): rows into the rn registers, weights into bq
-            const bool valid1 = k1 < kvol;
-            const bool adv = valid1 && ch1 == 0;
-            ia = adv ? ian : ia;
-            if (adv) knext = next_enabled(k1 + 1);
-            ian = load_idx(knext < kvol ? knext : k);
-            load_a(valid1 ? ch1 : ch, ia);
-            load_b(valid1 ? k1 : k, valid1 ? ch1 : ch);
-            const int kk = flip ? (kvol - 1 - k) : k;
-            if (kvol > 32 || ((wmask >> kk) & 1u)) {
-                Frag a0[3], a1[3];
-                const int c = ch * MF_TK + 8 * h;
-                split8(rc00, rc01, ic >= 0, c, a0[0], a0[1], a0[2]);
-                split8(rc10, rc11, ic >= 0, c + 16, a1[0], a1[1], a1[2]);
-                const unsigned char* Bp = Bs + buf * BSZ + r * X9_ROWB + h * 16;
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const Frag* a = s ? a1 : a0;
-                    mf_v8bf b[NT][NP];
-#pragma unroll
-                    for (int t = 0; t < NT; ++t)
-#pragma unroll
-                        for (int p = 0; p < NP; ++p) b[t][p] = *reinterpret_cast<const mf_v8bf*>(Bp + p * BPL + t * 32 * X9_ROWB + s * 32);
-                    // the nine partial products, smallest first; the column tiles are the inner loop so
-                    // that consecutive MFMAs never wait for each other's accumulator
-#define X9_MM(PA, PB) _Pragma("unroll") for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA].v, b[t][PB], acc[t], 0, 0, 0);
-#define X9_MH(PA, PB) _Pragma("unroll") for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(mf_v8h, a[PA].v), __builtin_bit_cast(mf_v8h, b[t][PB]), acc[t], 0, 0, 0);
-                    if (NP == 2) { X9_MH(0, 1) X9_MH(1, 0) X9_MH(0, 0) }
-                    else {
-#if !defined(X9_NINE)
-                    X9_MM(0, NP - 1) X9_MM(1, 1) X9_MM(NP - 1, 0) X9_MM(0, 1) X9_MM(1, 0) X9_MM(0, 0)       // six terms, see the dense kernels
-#else
-                    X9_MM(NP - 1, NP - 1) X9_MM(1, NP - 1) X9_MM(NP - 1, 1) X9_MM(0, NP - 1) X9_MM(1, 1) X9_MM(NP - 1, 0) X9_MM(0, 1) X9_MM(1, 0) X9_MM(0, 0)
-#endif
-                    }
-#undef X9_MH
-#undef X9_MM
-                }
-            }
-            if (!valid1) break;
-            store_b(buf ^ 1);                            // last read before the previous barrier
-            rc00 = rn00; rc01 = rn01; rc10 = rn10; rc11 = rn11;
-            ic = ia;
-            __syncthreads();
-            buf ^= 1;
-            k = k1; ch = ch1;
-            ++ch1;
-            if (ch1 == nchunks) { ch1 = 0; k1 = knext; }
-        }
-    }
-    // D layout of 32x32x16: register v of lane l holds row (v/4)*8 + (l/32)*4 + v%4, column l%32;
-    // the row -> output row table goes through LDS (each lane knows only its own row)
     if (NP == 2) {
         const float dx = h2_descale(sbx), dw = h2_descale(sbw);
 #pragma unroll
@@ -1002,7 +852,7 @@ __global__ __launch_bounds__(64 * X9_NW) void sp_conv_x9_kernel(const float* __r
             for (int i = 0; i < 16; ++i) acc[t][i] = acc[t][i] * dx * dw;
     }
     __syncthreads();
-    int* prow = reinterpret_cast<int*>(Bs);
+    int* prow = reinterpret_cast<int*>(scratch);
     if (h == 0) prow[wave * 32 + r] = pr;
     __syncthreads();
     float s1[NT], s2[NT];                                  // per-column sums of the lane's 16 rows (stats)
@@ -1058,8 +908,8 @@ __global__ __launch_bounds__(64 * X9_NW) void sp_conv_x9_kernel(const float* __r
     if (stats) {
         // per-channel sum and sum of squares of the workgroup's rows (the batch statistics of the BatchNorm that follows,
         // as in the dense kernel): [workgroup][2][cout] f64
-        __syncthreads();                                  // prow (in Bs) has been read by every wave
-        float* red = reinterpret_cast<float*>(Bs);
+        __syncthreads();                                  // prow (in scratch) has been read by every wave
+        float* red = reinterpret_cast<float*>(scratch);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             s1[t] += __shfl_xor(s1[t], 32);
@@ -1073,10 +923,405 @@ __global__ __launch_bounds__(64 * X9_NW) void sp_conv_x9_kernel(const float* __r
                 double a = 0.0;
 #pragma unroll
                 for (int w_ = 0; w_ < NW; ++w_) a += (double)red[(w_ * 2 + which) * CO + c];
-                stats[((int64_t)blockIdx.x * 2 + which) * cout + c] = a;
+                stats[(tile * 2 + which) * cout + c] = a;
             }
         }
     }
+}
+
+template <int NT, bool VEC, int NP>
+__global__ __launch_bounds__(64 * X9_NW) void sp_conv_x9_kernel(const float* __restrict__ X, const int32_t* __restrict__ map,
+                                                        const uint16_t* __restrict__ Wp,
+                                                        const int32_t* __restrict__ perm,
+                                                        const uint32_t* __restrict__ rowmask, int64_t n_rows,
+                                                        int kvol, int cin, int cout, int flip,
+                                                        float* __restrict__ Y, int64_t ys,
+                                                        const uint32_t* __restrict__ amax_x,
+                                                        const uint32_t* __restrict__ amax_w, double* __restrict__ stats,
+                                                        SpBnBwd bn, int tile_order, int64_t n_tiles) {
+    // NP = 3: bf16 planes, six partial products; NP = 2: fp16 planes of the scaled operands, three (h2_split2)
+    constexpr int CO = NT * 32;
+    constexpr int BPL = CO * X9_ROWB;                     // bytes per B plane
+    constexpr int BSZ = NP * BPL;                         // bytes per B buffer
+    constexpr int BPIECES = NP * CO * 4;                  // 16-byte pieces of a packed weight stage
+    int sbx = 127, sbw = 127;
+    if (NP == 2) { sbx = h2_scale_exp(*amax_x); sbw = h2_scale_exp(*amax_w); }
+    const float xscale = h2_scale(sbx);
+    constexpr int NW = X9_NW, THREADS = 64 * NW;
+    constexpr int NB = (BPIECES + THREADS - 1) / THREADS;   // pieces per thread
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[2 * BSZ];
+    __shared__ uint32_t wmask_s[NW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    // tile of this workgroup. tile_order 0: tiles in reverse (the mask-sorted order puts the rows with most neighbours
+    // last: those start first). 1: XCD-major - workgroups are dealt to the 8 XCDs round robin, so workgroup b takes tile
+    // (b % 8) * ceil(tiles / 8) + b / 8: every XCD walks a contiguous range of tiles in order and the rows its tiles gather
+    // (neighbours of a spatially ordered row range, see sparse.py) stay in that XCD's L2. The grid is rounded up to 8 * ceil.
+    int64_t tile = (int64_t)gridDim.x - 1 - blockIdx.x;
+    if (tile_order == 1) {
+        const int64_t per = (n_tiles + 7) / 8;
+        tile = (int64_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+        if ((int64_t)(blockIdx.x >> 3) >= per || tile >= n_tiles) return;
+    }
+    const int64_t r0 = tile * (32 * NW);
+    if (tid < NW) wmask_s[tid] = 0;
+    __syncthreads();
+    const int64_t myrow = r0 + wave * 32 + r;
+    const int pr = myrow < n_rows ? (perm ? perm[myrow] : (int)myrow) : -1;
+    {
+        uint32_t m = 0;
+        if (pr >= 0) m = (rowmask && kvol <= 32) ? rowmask[pr] : 0xFFFFFFFFu;
+        if (m && h == 0) atomicOr(&wmask_s[wave], m);
+    }
+    __syncthreads();
+    const uint32_t wmask = __builtin_amdgcn_readfirstlane(wmask_s[wave]);
+    uint32_t tm = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) tm |= wmask_s[w];
+    const uint32_t tmask = __builtin_amdgcn_readfirstlane(tm);
+    mf_v16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
+
+    const int nchunks = (cin + MF_TK - 1) / MF_TK;
+    auto enabled = [&](int k) { const int kk = flip ? (kvol - 1 - k) : k; return kvol > 32 || ((tmask >> kk) & 1u); };
+    auto next_enabled = [&](int k) { while (k < kvol && !enabled(k)) ++k; return k; };
+    auto load_idx = [&](int k) {
+        const int kk = flip ? (kvol - 1 - k) : k;
+        return map[(int64_t)kk * n_rows + (pr >= 0 ? pr : 0)];   // rows past n_rows gather something valid; never written
+    };
+    // raw[s][j]: floats 16s + 8h + 4j .. +3 of the lane's row in the 32-channel chunk
+    float4 rn00, rn01, rn10, rn11;                        // next stage, in flight
+    float4 rc00, rc01, rc10, rc11;                        // current stage
+    uint4 bq0, bq1, bq2, bq3, bq4, bq5;
+    bq0 = bq1 = bq2 = bq3 = bq4 = bq5 = make_uint4(0, 0, 0, 0);
+    rn00 = rn01 = rn10 = rn11 = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto ld4 = [&](const float* row, int c) -> float4 {
+        if (VEC) return *reinterpret_cast<const float4*>(row + (c < cin ? c : 0));
+        return make_float4(row[c < cin ? c : 0], row[c + 1 < cin ? c + 1 : 0], row[c + 2 < cin ? c + 2 : 0],
+                           row[c + 3 < cin ? c + 3 : 0]);
+    };
+    // loads are unconditional: an absent neighbour reads row 0 and is zeroed when it is split
+    auto load_a = [&](int ch, int i0) {
+#ifdef X9_ABL_NOGATHER                      /* ablation builds (tools_dev/exp_libs): every gather reads the tile's first rows */
+        i0 = tid & 127;
+#endif
+        const float* row = X + (int64_t)(i0 >= 0 ? i0 : 0) * cin;
+        const int c = ch * MF_TK + 8 * h;
+        rn00 = ld4(row, c); rn01 = ld4(row, c + 4); rn10 = ld4(row, c + 16); rn11 = ld4(row, c + 20);
+    };
+    auto load_b = [&](int k, int ch) {
+#ifdef X9_ABL_NOB
+        k = 0; ch = 0;
+#endif
+        const uint4* src = reinterpret_cast<const uint4*>(Wp + ((int64_t)k * nchunks + ch) * (NP * CO * 32));
+        const int last = BPIECES - 1;
+#define X9_BLD(E, V) if ((E) < NB) V = src[min(tid + THREADS * (E), last)];
+        X9_BLD(0, bq0) X9_BLD(1, bq1) X9_BLD(2, bq2) X9_BLD(3, bq3) X9_BLD(4, bq4) X9_BLD(5, bq5)
+#undef X9_BLD
+    };
+    auto store_b = [&](int buf) {
+        // piece f of the packed stage: plane f / (CO*4), column (f / 4) % CO, quarter f % 4
+#define X9_BST(E, V) if ((E) < NB) { const int f = tid + THREADS * (E); if (f < BPIECES) *reinterpret_cast<uint4*>(Bs + buf * BSZ + (f / (CO * 4)) * BPL + ((f >> 2) % CO) * X9_ROWB + (((f & 3) ^ ((f >> 4) & 3)) * 16)) = V; }
+        X9_BST(0, bq0) X9_BST(1, bq1) X9_BST(2, bq2) X9_BST(3, bq3) X9_BST(4, bq4) X9_BST(5, bq5)
+#undef X9_BST
+    };
+    // 8 floats -> one 8 x bf16 fragment per plane
+    union Frag { mf_v8bf v; uint32_t u[4]; };
+    auto split8 = [&](const float4& lo, const float4& hi, bool ok, int c, Frag& f1, Frag& f2, Frag& f3) {
+        const float e[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float x = ok && c + 2 * j < cin ? e[2 * j] : 0.f, y = ok && c + 2 * j + 1 < cin ? e[2 * j + 1] : 0.f;
+#ifdef X9_ABL_NOSPLIT
+            f1.u[j] = __float_as_uint(x); f2.u[j] = __float_as_uint(y); f3.u[j] = 0;
+#else
+            if (NP == 3) x9_split2(x, y, f1.u[j], f2.u[j], f3.u[j]);
+            else h2_split2(x * xscale, y * xscale, f1.u[j], f2.u[j]);
+#endif
+        }
+    };
+
+    int k = next_enabled(0), ch = 0;
+    if (k < kvol) {
+        int ia = load_idx(k);
+        int knext = next_enabled(k + 1);
+        int ian = load_idx(knext < kvol ? knext : k);
+        load_a(0, ia);
+        load_b(k, 0);
+        store_b(0);
+        rc00 = rn00; rc01 = rn01; rc10 = rn10; rc11 = rn11;
+        int ic = ia;                                     // rule-book entry the current stage was loaded with
+        int k1 = k, ch1 = 1;
+        if (ch1 == nchunks) { ch1 = 0; k1 = knext; }
+        __syncthreads();
+        int buf = 0;
+        while (true) {
+            // request stage (k1, ch1): rows into the rn registers, weights into bq
+            const bool valid1 = k1 < kvol;
+            const bool adv = valid1 && ch1 == 0;
+            ia = adv ? ian : ia;
+            if (adv) knext = next_enabled(k1 + 1);
+            ian = load_idx(knext < kvol ? knext : k);
+            load_a(valid1 ? ch1 : ch, ia);
+            load_b(valid1 ? k1 : k, valid1 ? ch1 : ch);
+            const int kk = flip ? (kvol - 1 - k) : k;
+            if (kvol > 32 || ((wmask >> kk) & 1u)) {
+                Frag a0[3], a1[3];
+                const int c = ch * MF_TK + 8 * h;
+                split8(rc00, rc01, ic >= 0, c, a0[0], a0[1], a0[2]);
+                split8(rc10, rc11, ic >= 0, c + 16, a1[0], a1[1], a1[2]);
+                const unsigned char* Bp = Bs + buf * BSZ + r * X9_ROWB + h * 16;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const Frag* a = s ? a1 : a0;
+                    mf_v8bf b[NT][NP];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+#pragma unroll
+                        for (int p = 0; p < NP; ++p) b[t][p] = *reinterpret_cast<const mf_v8bf*>(Bp + p * BPL + t * 32 * X9_ROWB + s * 32);
+                    // the nine partial products, smallest first; the column tiles are the inner loop so
+                    // that consecutive MFMAs never wait for each other's accumulator
+#define X9_MM(PA, PB) _Pragma("unroll") for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA].v, b[t][PB], acc[t], 0, 0, 0);
+#define X9_MH(PA, PB) _Pragma("unroll") for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(mf_v8h, a[PA].v), __builtin_bit_cast(mf_v8h, b[t][PB]), acc[t], 0, 0, 0);
+#ifdef X9_ABL_NOMFMA
+                    if (a[0].u[0] == 0x12345678u) acc[0][0] += 1.0f;
+#else
+                    if (NP == 2) { X9_MH(0, 1) X9_MH(1, 0) X9_MH(0, 0) }
+                    else {
+#if !defined(X9_NINE)
+                    X9_MM(0, NP - 1) X9_MM(1, 1) X9_MM(NP - 1, 0) X9_MM(0, 1) X9_MM(1, 0) X9_MM(0, 0)       // six terms, see the dense kernels
+#else
+                    X9_MM(NP - 1, NP - 1) X9_MM(1, NP - 1) X9_MM(NP - 1, 1) X9_MM(0, NP - 1) X9_MM(1, 1) X9_MM(NP - 1, 0) X9_MM(0, 1) X9_MM(1, 0) X9_MM(0, 0)
+#endif
+                    }
+#endif
+#undef X9_MH
+#undef X9_MM
+                }
+            }
+            if (!valid1) break;
+            store_b(buf ^ 1);                            // last read before the previous barrier
+            rc00 = rn00; rc01 = rn01; rc10 = rn10; rc11 = rn11;
+            ic = ia;
+            __syncthreads();
+            buf ^= 1;
+            k = k1; ch = ch1;
+            ++ch1;
+            if (ch1 == nchunks) { ch1 = 0; k1 = knext; }
+        }
+    }
+    x9_epilogue<NT, NP, NW>(acc, pr, wave, r, h, tid, cout, Y, ys, stats, tile, bn, Bs, sbx, sbw);
+}
+
+// ------------------------------------------------------------------------------ the same product, LDS-DMA ring form
+// What bounds sp_conv_x9_kernel at the 128-channel level of the shipped config (510 k rows, 14.5 pairs per row; measured
+// with ablation builds, tools_dev/exp_x9_ablate.py): not the matrix pipe (26 % busy), not the bytes (spatially ordered rows,
+// i.e. L2-resident gathers, change nothing) - the LATENCY of its loads. Its registers hold one stage of lookahead, a stage is
+// ~800 cycles of matrix work, and a gathered row or a weight stage takes 1 - 2 us to arrive from the L2 / the Infinity Cache
+// under load: every stage waits. This form keeps TWO stages in flight without a register: every operand goes global -> LDS
+// by LDS-DMA (global_load_lds_dwordx4, issued from inline asm so that the compiler neither counts nor drains it), retired
+// by a counted s_waitcnt vmcnt(N) that leaves the younger stages in flight, behind a raw s_barrier.
+//   tile   256 output rows x CO columns, 512 threads: wave w owns rows 32w .. 32w+31 (operand layout and D layout as in
+//          sp_conv_x9_kernel), so a weight stage is shared by 8 waves instead of 4 - half the weight bytes per row;
+//   ring   R = D + 1 slots of [A: 256 rows x 32 channels fp32 | B: one packed weight stage]; 3 x 48 KB at CO = 128 on two
+//          fp16 planes (D = 2), 2 x 56 KB on three bf16 planes (D = 1); one workgroup per CU, two waves per SIMD;
+//   A      a wave's 32 rows x 128 bytes, fetched as WHOLE lines (8 lanes per row and instruction, segments XOR-swizzled by
+//          the row number) into a wave-private image that lane (r, h) reads its 2 x 32 bytes per k-step from: no barrier
+//          for A, no bank conflict; absent neighbours request row 0 and are zeroed when they are split;
+//   B      the packed stage is copied as it is (its 16-byte quarters are stored swizzled, sp_pack_weight_split_kernel);
+//   idx    the rule-book entry of a lane's row for the offset of stage t must be in a register when A(t) is requested, D
+//          stages before t - it is itself fetched by LDS-DMA (4 bytes per row) D stages before that, into an 8-deep ring;
+//   block s (top of stage s): wait until only the DMAs of stages s+1 .. s+D-1 are outstanding -> s_barrier (everyone's
+//          share of B(s) has landed, everyone is done reading slot (s-1) % R) -> request stage s+D into that slot ->
+//          read A(s), B(s), split, MFMA.
+template <int NT, int NP, int D>
+__global__ __launch_bounds__(512) void sp_conv_ring_kernel(const float* __restrict__ X, const int32_t* __restrict__ map,
+                                                          const uint16_t* __restrict__ Wp, const int32_t* __restrict__ perm,
+                                                          const uint32_t* __restrict__ rowmask, int64_t n_rows, int kvol,
+                                                          int cin, int cout, int flip, float* __restrict__ Y, int64_t ys,
+                                                          const uint32_t* __restrict__ amax_x,
+                                                          const uint32_t* __restrict__ amax_w, double* __restrict__ stats,
+                                                          SpBnBwd bn, int64_t stats_rows, int tile_order, int64_t n_tiles) {
+    constexpr int CO = NT * 32, NW = 8, TM = 256, R = D + 1;
+    constexpr int A_SLOT = TM * 128;                      // bytes: 32 fp32 channels per row
+    constexpr int B_PL = CO * 64, B_SLOT = NP * B_PL;     // bytes per plane / per packed stage
+    constexpr int BPIECES = B_SLOT / 16;                  // 16-byte pieces of a weight stage: a multiple of 64
+    constexpr int NBP = (BPIECES + 511) / 512;            // DMA instructions per stage of the waves that take part in all rounds
+    constexpr int SLOT = A_SLOT + B_SLOT;
+    constexpr int IDXR = 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];       // ALL of the kernel's LDS (one object)
+    int* const idxring = reinterpret_cast<int*>(smem + R * SLOT);              // [IDXR][NW][32]
+    uint32_t* const wmask_s = reinterpret_cast<uint32_t*>(smem + R * SLOT + IDXR * TM * 4);
+    int* const koff = reinterpret_cast<int*>(wmask_s + NW);                    // [0] = enabled offsets, [1 ..] = their numbers
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+
+    int sbx = 127, sbw = 127;
+    if (NP == 2) { sbx = h2_scale_exp(*amax_x); sbw = h2_scale_exp(*amax_w); }
+    const float xscale = h2_scale(sbx);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    int64_t tile = (int64_t)gridDim.x - 1 - blockIdx.x;                        // most neighbours first (mask-sorted rows)
+    if (tile_order == 1) {                                                     // XCD-major (see sp_conv_x9_kernel)
+        const int64_t per = (n_tiles + 7) / 8;
+        tile = (int64_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+        if ((int64_t)(blockIdx.x >> 3) >= per || tile >= n_tiles) return;
+    }
+    const int64_t r0 = tile * TM;
+    if (tid < NW) wmask_s[tid] = 0;
+    __syncthreads();
+    const int64_t myrow = r0 + wave * 32 + r;
+    const int pr = myrow < n_rows ? (perm ? perm[myrow] : (int)myrow) : -1;
+    {
+        uint32_t m = 0;
+        if (pr >= 0) m = (rowmask && kvol <= 32) ? rowmask[pr] : 0xFFFFFFFFu;
+        if (m && h == 0) atomicOr(&wmask_s[wave], m);
+    }
+    __syncthreads();
+    const uint32_t wmask = __builtin_amdgcn_readfirstlane(wmask_s[wave]);
+    if (tid == 0) {
+        uint32_t tm = 0;
+        for (int w = 0; w < NW; ++w) tm |= wmask_s[w];
+        int n = 0;
+        for (int k = 0; k < kvol; ++k) {
+            const int kk = flip ? (kvol - 1 - k) : k;
+            if (kvol > 32 || ((tm >> kk) & 1u)) koff[1 + n++] = k;
+        }
+        koff[0] = n;
+    }
+    __syncthreads();
+    const int ne = __builtin_amdgcn_readfirstlane(koff[0]);
+    const int nchunks = cin / MF_TK;
+    const int S = ne * nchunks;                                                // stages of this tile
+    mf_v16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
+
+    const int64_t prc = pr >= 0 ? pr : 0;
+    auto kk_of = [&](int j) { const int k = __builtin_amdgcn_readfirstlane(koff[1 + j]); return flip ? (kvol - 1 - k) : k; };
+    // one LDS-DMA instruction: 16 (or 4) bytes per lane from `src` to LDS bytes [dst + 16 * lane) (dst wave-uniform)
+    auto dma16 = [&](const void* src, uint32_t dst) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+    };
+    auto dma4 = [&](const void* src, uint32_t dst) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+    };
+    // DMA instructions of `issue(t)`: 4 (A) + NBP (B) + 1 when stage t + D opens a new offset (its rule-book entries)
+    auto idx_flag = [&](int t) { return t + D < S && (t + D) % nchunks == 0; };
+    const int nbp = (BPIECES - wave * 64 + 511) / 512;     // this wave's weight DMAs per stage (pieces wave * 64 + 512 e)
+    auto count = [&](int t) { return 4 + nbp + (idx_flag(t) ? 1 : 0); };
+    auto issue = [&](int t) {
+        const int j = t / nchunks, ch = t - j * nchunks;
+        const int kk = kk_of(j);
+        const int slot = t % R;
+        // A: instruction q fetches the 128-byte chunk rows of the wave's rows 8q .. 8q+7 WHOLE - 8 lanes per row, so a row's
+        // cache line is requested once, by one instruction (a lane fetching the pieces of its own row over four instructions
+        // asks for every line four times, and the 32 KB a stage gathers do not survive in the L1 in between). The 16-byte
+        // segment a lane fetches is XOR-ed with the row number: the LDS image [32 rows][128 B] is then read conflict-free.
+        const uint32_t a_dst = __builtin_amdgcn_readfirstlane(lds0 + slot * SLOT + wave * 4096);
+        const int* irow = idxring + (j % IDXR) * TM + wave * 32 + (lane >> 3);    // landed: requested >= D blocks ago
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i0 = irow[8 * q];
+            const int rr = 8 * q + (lane >> 3);
+            dma16(X + (int64_t)(i0 >= 0 ? i0 : 0) * cin + ch * MF_TK + 4 * ((lane & 7) ^ (rr & 7)), a_dst + q * 1024);
+        }
+        const unsigned char* bsrc = reinterpret_cast<const unsigned char*>(Wp) + ((int64_t)(flip ? kvol - 1 - kk : kk) * nchunks + ch) * B_SLOT
+                                    + (int64_t)tid * 16;
+        const uint32_t b_dst = __builtin_amdgcn_readfirstlane(lds0 + slot * SLOT + A_SLOT + wave * 1024);
+#pragma unroll
+        for (int e = 0; e < NBP; ++e)
+            if (e < nbp) dma16(bsrc + e * 8192, b_dst + e * 8192);
+        if (idx_flag(t)) {
+            const int j2 = (t + D) / nchunks;
+            const int32_t* isrc = map + (int64_t)kk_of(j2) * n_rows + prc;
+            const uint32_t i_dst = __builtin_amdgcn_readfirstlane(lds0 + R * SLOT + ((j2 % IDXR) * TM + wave * 32) * 4);
+            if (h == 0) dma4(isrc, i_dst);
+        }
+    };
+    auto wait_vm = [&](int n) {           // s_waitcnt vmcnt(n) with a run-time (wave-uniform) n
+        switch (n) {
+            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+            case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+            case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        }
+    };
+    static_assert(D == 1 || D == 2, "the wait below sums the DMA counts of D - 1 stages");
+    union Frag { mf_v8bf v; uint32_t u[4]; };
+    auto split8 = [&](const float4& lo, const float4& hi, bool ok, Frag& f1, Frag& f2, Frag& f3) {
+        const float e[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float x = ok ? e[2 * q] : 0.f, y = ok ? e[2 * q + 1] : 0.f;
+            if (NP == 3) x9_split2(x, y, f1.u[q], f2.u[q], f3.u[q]);
+            else h2_split2(x * xscale, y * xscale, f1.u[q], f2.u[q]);
+        }
+    };
+
+    if (S > 0) {
+        // prologue: the rule-book entries of the first D stages' offsets by ordinary loads (nothing is in flight yet)
+        const int jp = (D + nchunks - 1) / nchunks;
+        for (int j = 0; j < jp && j < ne; ++j) {
+            const int v = map[(int64_t)kk_of(j) * n_rows + prc];
+            if (h == 0) idxring[(j % IDXR) * TM + wave * 32 + r] = v;
+        }
+        __syncthreads();
+        for (int t = 0; t < D && t < S; ++t) issue(t);
+        for (int s = 0; s < S; ++s) {
+            // the DMAs of stage s have landed once only those of stages s+1 .. s+D-1 are outstanding
+            wait_vm((D == 2 && s + 1 < S) ? count(s + 1) : 0);
+            __builtin_amdgcn_s_barrier();
+            if (s + D < S) issue(s + D);
+            const int j = s / nchunks, ch = s - j * nchunks;
+            const int kk = kk_of(j);
+            (void)ch;
+            if (kvol > 32 || ((wmask >> kk) & 1u)) {
+                const int ic = idxring[(j % IDXR) * TM + wave * 32 + r];
+                // segment g = 4 sk + 2 h + e of row r sits at 16-byte position g ^ (r & 7) of the row's 128 bytes
+                const unsigned char* Ap = smem + (s % R) * SLOT + wave * 4096 + r * 128;
+                const int sw = r & 7;
+                const float4 p0 = *reinterpret_cast<const float4*>(Ap + (((2 * h) ^ sw) << 4)), p1 = *reinterpret_cast<const float4*>(Ap + (((2 * h + 1) ^ sw) << 4));
+                const float4 p2 = *reinterpret_cast<const float4*>(Ap + (((4 + 2 * h) ^ sw) << 4)), p3 = *reinterpret_cast<const float4*>(Ap + (((5 + 2 * h) ^ sw) << 4));
+                Frag a0[3], a1[3];
+                split8(p0, p1, ic >= 0, a0[0], a0[1], a0[2]);
+                split8(p2, p3, ic >= 0, a1[0], a1[1], a1[2]);
+                const unsigned char* Bp = smem + (s % R) * SLOT + A_SLOT + r * 64;
+                const int swz = (r >> 2) & 3;
+#pragma unroll
+                for (int sk = 0; sk < 2; ++sk) {
+                    const Frag* a = sk ? a1 : a0;
+                    mf_v8bf b[NT][NP];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+#pragma unroll
+                        for (int p = 0; p < NP; ++p)
+                            b[t][p] = *reinterpret_cast<const mf_v8bf*>(Bp + p * B_PL + t * 32 * 64 + (((sk * 2 + h) ^ swz) * 16));
+#define XR_MM(PA, PB) _Pragma("unroll") for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA].v, b[t][PB], acc[t], 0, 0, 0);
+#define XR_MH(PA, PB) _Pragma("unroll") for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(mf_v8h, a[PA].v), __builtin_bit_cast(mf_v8h, b[t][PB]), acc[t], 0, 0, 0);
+                    if (NP == 2) { XR_MH(0, 1) XR_MH(1, 0) XR_MH(0, 0) }
+                    else { XR_MM(0, NP - 1) XR_MM(1, 1) XR_MM(NP - 1, 0) XR_MM(0, 1) XR_MM(1, 0) XR_MM(0, 0) }
+#undef XR_MH
+#undef XR_MM
+                }
+            }
+        }
+    }
+    // stats rows of the 128-row tiling this tile does not write (the caller sized `stats` for gga_sparse_conv_apply_tiles)
+    if (stats) {
+        const int64_t extra = n_tiles + tile;
+        if (extra < stats_rows && tid < 2 * cout) stats[extra * 2 * cout + tid] = 0.0;
+    }
+    x9_epilogue<NT, NP, NW>(acc, pr, wave, r, h, tid, cout, Y, ys, stats, tile, bn, smem, sbx, sbw);
 }
 
 extern "C" int gga_sparse_conv_apply_split_strided(const float* x, const int32_t* map, const void* split_weight,
@@ -1121,11 +1366,35 @@ extern "C" int gga_sparse_conv_apply_bn_bwd(const float* x, const int32_t* map, 
     GGA_REQUIRE(n_rows >= 1 && kvol >= 1 && cin >= 1 && cout >= 1 && cout <= 128 && y_row_stride >= cout,
                 "gga_sparse_conv_apply_split: bad sizes (rows=%lld kvol=%d cin=%d cout=%d row stride %lld; cout <= 128)",
                 (long long)n_rows, kvol, cin, cout, (long long)y_row_stride);
-    const dim3 grid((unsigned)((n_rows + X9_TM - 1) / X9_TM)), block(64 * X9_NW);
+    const int64_t n_tiles = (n_rows + X9_TM - 1) / X9_TM;
+    static const int tile_order = getenv("GGA_SP_TILE_ORDER") ? atoi(getenv("GGA_SP_TILE_ORDER")) : 0;
+    // large products of 64 / 128 output columns over whole 32-channel chunks: the LDS-DMA ring form (256-row tiles)
+    static const int ring_on = getenv("GGA_SP_RING") ? atoi(getenv("GGA_SP_RING")) : 1;
+    static const int64_t ring_min_rows = getenv("GGA_SP_RING_MIN_ROWS") ? atoll(getenv("GGA_SP_RING_MIN_ROWS")) : 131072;
+    // (measured in the shipped config's step: 128 columns 1.19 ms against 1.52 ms per launch at 510 k rows; 64 columns 0.43 against
+    // 0.40 ms - the narrow form stays with sp_conv_x9_kernel unless GGA_SP_RING=2 asks for the ring there too)
+    if (ring_on && cin % MF_TK == 0 && (cout == 128 || (cout == 64 && ring_on == 2)) && n_rows >= ring_min_rows) {
+        const int64_t rtiles = (n_rows + 255) / 256;
+        const dim3 rgrid((unsigned)(tile_order == 1 ? 8 * ((rtiles + 7) / 8) : rtiles)), rblock(512);
+        hipEvent_t* rtev = gga_timing_acquire(GGA_TIME_SPARSE_CONV, GGA_TIMING_CONV_KEY(cin, cout, 0));
+        GGA_TIME_START(rtev, stream);
+#define XR_LAUNCH(NT, NP, D) { \
+            constexpr size_t lds = (size_t)(D + 1) * (256 * 128 + NP * NT * 32 * 64) + 8 * 256 * 4 + 8 * 4 + 36 * 4; \
+            static bool once = false; \
+            if (!once) { GGA_CHECK_HIP(hipFuncSetAttribute((const void*)sp_conv_ring_kernel<NT, NP, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "sp_conv_ring_kernel: LDS size"); once = true; } \
+            hipLaunchKernelGGL((sp_conv_ring_kernel<NT, NP, D>), rgrid, rblock, lds, stream, x, map, (const uint16_t*)split_weight, perm, rowmask, n_rows, kvol, cin, cout, flip, y, y_row_stride, amax_x, amax_weight, stats, bn, n_tiles, tile_order, rtiles); }
+        if (planes == 2) { if (cout == 128) XR_LAUNCH(4, 2, 2) else XR_LAUNCH(2, 2, 2) }
+        else { if (cout == 128) XR_LAUNCH(4, 3, 1) else XR_LAUNCH(2, 3, 2) }
+#undef XR_LAUNCH
+        GGA_CHECK_LAUNCH("sp_conv_ring_kernel");
+        GGA_TIME_STOP(rtev, stream);
+        return GGA_OK;
+    }
+    const dim3 grid((unsigned)(tile_order == 1 ? 8 * ((n_tiles + 7) / 8) : n_tiles)), block(64 * X9_NW);
     hipEvent_t* tev = gga_timing_acquire(GGA_TIME_SPARSE_CONV, GGA_TIMING_CONV_KEY(cin, cout, 0));
     GGA_TIME_START(tev, stream);
-#define X9_LAUNCH(NT, VEC) { if (planes == 3) hipLaunchKernelGGL((sp_conv_x9_kernel<NT, VEC, 3>), grid, block, 0, stream, x, map, (const uint16_t*)split_weight, perm, rowmask, n_rows, kvol, cin, cout, flip, y, y_row_stride, amax_x, amax_weight, stats, bn); \
-                             else hipLaunchKernelGGL((sp_conv_x9_kernel<NT, VEC, 2>), grid, block, 0, stream, x, map, (const uint16_t*)split_weight, perm, rowmask, n_rows, kvol, cin, cout, flip, y, y_row_stride, amax_x, amax_weight, stats, bn); }
+#define X9_LAUNCH(NT, VEC) { if (planes == 3) hipLaunchKernelGGL((sp_conv_x9_kernel<NT, VEC, 3>), grid, block, 0, stream, x, map, (const uint16_t*)split_weight, perm, rowmask, n_rows, kvol, cin, cout, flip, y, y_row_stride, amax_x, amax_weight, stats, bn, tile_order, n_tiles); \
+                             else hipLaunchKernelGGL((sp_conv_x9_kernel<NT, VEC, 2>), grid, block, 0, stream, x, map, (const uint16_t*)split_weight, perm, rowmask, n_rows, kvol, cin, cout, flip, y, y_row_stride, amax_x, amax_weight, stats, bn, tile_order, n_tiles); }
     if ((cin & 3) == 0) {
         switch (mf_nt(cout)) {
             case 1: X9_LAUNCH(1, true); break;

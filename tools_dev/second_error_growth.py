@@ -42,7 +42,11 @@ def flat(store):
                 out[f'{k}.{kk}'] = vv.detach().double().cpu()
         elif isinstance(v, (list, tuple)):
             for i, vv in enumerate(v):
-                out[f'{k}.{i}'] = vv.detach().double().cpu()
+                if isinstance(vv, dict):
+                    for kk, vvv in vv.items():
+                        out[f'{k}.{kk}'] = vvv.detach().double().cpu()
+                else:
+                    out[f'{k}.{i}'] = vv.detach().double().cpu()
         else:
             out[k] = v.detach().double().cpu()
     return out

@@ -51,6 +51,7 @@ ARITH = ('fp32 in / fp32 out, fp32 accumulate. Every convolution (dense 3x3, str
 PP_CONFIG = os.path.join(REPO, 'configs', 'gga', 'gga_kitti_pointpillars_config.py')
 SECOND_CONFIG = os.path.join(REPO, 'configs', 'gga', 'gga_kitti_config.py')
 PGD_CONFIG = os.path.join(REPO, 'configs', 'gga', 'gga_pdg.py')
+FCAF3D_CONFIG = os.path.join(REPO, 'configs', 'fcaf3d', 'fcaf3d_8x2_sunrgbd-3d-10class.py')
 
 
 def parse_args(argv=None):
@@ -75,6 +76,8 @@ def parse_args(argv=None):
     ap.add_argument('--second-batch', type=int, default=8, help='frames per GPU of the second_trunk leg')
     ap.add_argument('--no-pgd', action='store_true', help='skip the gga_pdg.py (camera-only retraining) leg')
     ap.add_argument('--pgd-batch', type=int, default=12, help='images per GPU of the pgd leg (samples_per_gpu of the config)')
+    ap.add_argument('--no-fcaf3d', action='store_true', help='skip the fcaf3d (SUN RGB-D-shaped scenes) leg')
+    ap.add_argument('--fcaf3d-batch', type=int, default=8, help='scenes per GPU of the fcaf3d leg (samples_per_gpu of the config)')
     ap.add_argument('--no-planes3', action='store_true',
                     help='skip the `planes3` legs (main config and second_trunk re-timed on three bf16 planes / six products)')
     return ap.parse_args(argv)
@@ -241,6 +244,47 @@ def run_mono_workload(batch, steps, warmup, args, rank, world, device):
     loss = float(out['loss'].detach())
     assert loss == loss, 'loss is NaN (gga_pdg.py)'
     return dict(dt=float(t.item()), loss=loss, runner=runner, batches=batches)
+
+
+def run_indoor_workload(batch, steps, warmup, args, rank, world, device):
+    """configs/fcaf3d/fcaf3d_8x2_sunrgbd-3d-10class.py (BASELINE config #4: FCAF3D on SUN RGB-D-shaped scenes, 50 k points, 10
+    classes): MinkResNet-34 + the sparse FPN / head of FCAF3DHead on the gather-GEMM kernels, full train step (fwd + bwd +
+    clip + AdamW). There is no GGA head for this trunk in the reference: stock FCAF3D. -> dict(dt, loss)."""
+    import torch
+    import torch.distributed as dist
+    from gga_amd import Config, build_model, synthetic
+    from gga_amd.train import Runner, setup_multi_processes
+    cfg = Config.fromfile(FCAF3D_CONFIG)
+    setup_multi_processes(cfg)
+    torch.manual_seed(0)
+    model = build_model(cfg.model).to(device).train()
+    runner = Runner(model, cfg, max_iters=max(1000, steps + warmup), distributed=world > 1, device=device, iters_per_epoch=1000)
+    batches = []
+    for i in range(2):
+        b = synthetic.make_indoor_batch(batch, start=i * batch, rank=rank, device=device, n_points=50000)
+        batches.append({k: b[k] for k in synthetic.INDOOR_BATCH_KEYS})
+    torch.cuda.synchronize()
+    for i in range(warmup):
+        runner.step(batches[i % 2])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    runner.freeze_gc()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        out = runner.step(batches[i % 2])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    loss = float(out['loss'].detach())
+    assert loss == loss, 'loss is NaN (fcaf3d)'
+    return dict(dt=float(t.item()), loss=loss, runner=runner)
 
 
 def scatter_roofline(model, batches, step_ms):
@@ -502,6 +546,22 @@ def main():
                 'weights': 'random init: the open-mmlab://detectron2/resnet101_caffe checkpoint of the config is not '
                            'available offline (Kaiming backbone with the last norm of every bottleneck at 0.2, head per '
                            'PGDHead.init_weights)'}
+        gc.collect()
+        torch.cuda.empty_cache()
+
+    if is_pp and not args.no_fcaf3d:
+        fc = run_indoor_workload(args.fcaf3d_batch, args.steps, args.warmup, args, rank, world, device)
+        if rank == 0:
+            res['fcaf3d_trunk'] = {
+                'config_file': os.path.relpath(FCAF3D_CONFIG, REPO),
+                'workload': 'MinkSingleStage3DDetector: MinkResNet-34 + FCAF3DHead (generative transposed convolutions, pruning), '
+                            'synthetic SUN RGB-D-shaped scenes of 50 000 points, 10 classes, full train step (fwd+bwd+clip+AdamW); '
+                            'stock FCAF3D - the reference has no GGA head for this trunk',
+                'frames_per_gpu': args.fcaf3d_batch, 'global_batch': args.fcaf3d_batch * world,
+                'value': round(args.fcaf3d_batch * world * args.steps / fc['dt'], 3), 'unit': 'scenes/s',
+                'ms_per_step': round(fc['dt'] / args.steps * 1e3, 3), 'steps': args.steps, 'warmup': args.warmup,
+                'final_loss': round(fc['loss'], 4), 'matrix_planes': __import__('gga_amd').dense_conv.PLANES}
+        del fc
         gc.collect()
         torch.cuda.empty_cache()
 

@@ -22,7 +22,7 @@ for _k in ('MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_FWD', 'MIOPEN_DEBUG_CONV_DIRECT_
 
 from . import registry  # noqa: E402,F401
 from . import dcn  # noqa: E402,F401  (registers 'DCNv2')
-from . import losses, bbox_coders, voxel_encoders, middle_encoders, sparse, sparse_encoder, backbones, dense_heads, detectors, mono3d_heads, mono3d_detectors  # noqa: E402,F401
+from . import losses, bbox_coders, voxel_encoders, middle_encoders, sparse, sparse_encoder, backbones, dense_heads, detectors, mono3d_heads, mono3d_detectors, fcaf3d  # noqa: E402,F401
 from .config import Config  # noqa: E402,F401
 from .registry import build_detector, build_model  # noqa: E402,F401
 from .pseudo_labels import pseudo_label_matching_kitti  # noqa: E402,F401

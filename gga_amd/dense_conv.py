@@ -38,16 +38,26 @@ class RangeGuard:
     absolute accuracy of 2^-40 * amax, so a non-zero element below 2^-17 * amax has fewer than fp32's 24 significant
     bits and one below 2^-30 * amax is off by more than 1e-3 of itself (``lost``). Recorded per operand, on the device,
     without a host read: [non-zero count, count below 2^-17 amax, count below 2^-30 amax, sum |t|, sum of |t| below
-    2^-30 amax]. ``Runner`` arms it for one step every ``interval`` iterations, reads the rows once after that step and
-    switches ``PLANES`` to 3 when any operand has more than ``LIMIT`` of its non-zero elements lost."""
+    2^-30 amax, amax]. ``Runner`` arms it for one step every ``interval`` iterations, reads the rows once after that step
+    and leaves the two-plane form when an operand is over its limit:
+
+    * operands of the FORWARD pass (activations, weights): more than ``LIMIT`` of the non-zero ELEMENTS lost. What follows
+      a forward convolution is non-linear - a normalisation layer rescales a sample or channel whose values are all tiny to
+      O(1) - so every element has to be right by itself;
+    * operands of the BACKWARD pass (gradients): more than ``LIMIT_MASS`` of the tensor's L1 MASS lost. Everything
+      downstream of a gradient is linear in it (backward-data, BatchNorm / GroupNorm backward, the weight-gradient sums),
+      so the error any later value inherits is bounded by that share; a gradient tensor routinely has whole regions 2^-30
+      below its largest entry (locations far from every object) that decide nothing."""
     LIMIT = 1e-3
+    LIMIT_MASS = 1e-6
 
     def __init__(self):
         self.armed = False
+        self.phase = 'forward'
         self.rows, self.names = [], []
 
     def arm(self):
-        self.armed, self.rows, self.names = True, [], []
+        self.armed, self.phase, self.rows, self.names = True, 'forward', [], []
 
     def record(self, t, amax=None):
         if not self.armed or t.numel() == 0:
@@ -62,18 +72,21 @@ class RangeGuard:
             low30 = nz & (a < m * 2.0 ** -30)
             self.rows.append(torch.stack([nz.sum().double(), low17.sum().double(), low30.sum().double(), a.double().sum(),
                                           (a * low30).double().sum(), m.double()]))
-            self.names.append(f'{tuple(t.shape)}')
+            self.names.append((f'{tuple(t.shape)}', self.phase))
 
     def disarm(self):
-        """-> list of dicts (one per operand seen): shape, nonzero, share_below_2^-17, share_lost, mass_lost, amax."""
+        """-> list of dicts (one per operand seen): shape, phase, nonzero, share_below_2^-17, share_lost, mass_lost, amax,
+        over (the operand is over the limit of its phase)."""
         self.armed = False
         if not self.rows:
             return []
         r = torch.stack(self.rows).cpu()        # the one host read
         out = []
-        for name, (nz, l17, l30, s, s30, m) in zip(self.names, r.tolist()):
-            out.append(dict(shape=name, nonzero=int(nz), share_below_2p17=l17 / max(nz, 1), share_lost=l30 / max(nz, 1),
-                            mass_lost=s30 / s if s > 0 else 0.0, amax=m))
+        for (name, phase), (nz, l17, l30, s, s30, m) in zip(self.names, r.tolist()):
+            d = dict(shape=name, phase=phase, nonzero=int(nz), share_below_2p17=l17 / max(nz, 1), share_lost=l30 / max(nz, 1),
+                     mass_lost=s30 / s if s > 0 else 0.0, amax=m)
+            d['over'] = d['share_lost'] > self.LIMIT if phase == 'forward' else d['mass_lost'] > self.LIMIT_MASS
+            out.append(d)
         self.rows, self.names = [], []
         return out
 

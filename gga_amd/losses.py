@@ -97,7 +97,7 @@ def _weighted(loss, weight, reduction, avg_factor):
 
 @LOSSES.register_module()
 class FocalLoss(nn.Module):
-    """Sigmoid focal loss on [N, C] logits with integer targets in [0, C] (C = background)."""
+    """Sigmoid focal loss on [N, C] logits with integer targets: a class index in [0, C), anything else = background."""
 
     def __init__(self, use_sigmoid=True, gamma=2.0, alpha=0.25, reduction='mean', loss_weight=1.0, activated=False):
         super().__init__()
@@ -107,7 +107,8 @@ class FocalLoss(nn.Module):
     def forward(self, pred, target, weight=None, avg_factor=None, reduction_override=None):
         reduction = reduction_override or self.reduction
         num_classes = pred.size(1)
-        t = torch.nn.functional.one_hot(target, num_classes=num_classes + 1)[:, :num_classes].type_as(pred)
+        # class c is positive where target == c; any other label (C, or FCAF3D's -1) is background - what mmcv's op computes
+        t = (target.view(-1, 1) == torch.arange(num_classes, device=pred.device).view(1, -1)).type_as(pred)
         p = pred if self.activated else pred.sigmoid()
         pt = (1 - p) * t + p * (1 - t)
         focal_weight = (self.alpha * t + (1 - self.alpha) * (1 - t)) * pt.pow(self.gamma)

@@ -506,3 +506,53 @@ def damp_random_backbone(model, scale=0.2):
             if hasattr(m, 'bn3'):
                 m.bn3.weight.fill_(scale)
     return model
+
+
+INDOOR_CLASSES = ('bed', 'table', 'sofa', 'chair', 'toilet', 'desk', 'dresser', 'night_stand', 'bookshelf', 'bathtub')
+INDOOR_BATCH_KEYS = ('points', 'gt_bboxes_3d', 'gt_labels_3d', 'img_metas')
+
+
+def make_indoor_batch(batch_size, start=0, rank=0, device=None, n_points=50000, n_obj_range=(4, 12)):
+    """SUN RGB-D-shaped training batch as configs/fcaf3d/fcaf3d_8x2_sunrgbd-3d-10class.py's pipeline hands it to
+    ``MinkSingleStage3DDetector.forward_train`` (BASELINE config 4: 50 k points, 10 classes): per scene ``points`` [n, 6]
+    (x, y, z in metres, depth coordinates, + r, g, b in [0, 1]), ``gt_bboxes_3d`` (DepthInstance3DBoxes with yaw, given - as
+    the dataset gives them - by gravity centre), ``gt_labels_3d``. A room of about 5 x 5 x 2.7 m seen from inside: points on
+    the floor, two walls and the surfaces of the objects. Seeded by ``1234 + 1000 * rank + scene`` like the LiDAR frames."""
+    import torch
+    from .fcaf3d import DepthInstance3DBoxes
+    out = dict(points=[], gt_bboxes_3d=[], gt_labels_3d=[], img_metas=[])
+    for f in range(start, start + batch_size):
+        rng = np.random.default_rng(1234 + 1000 * rank + f)
+        n_obj = int(rng.integers(n_obj_range[0], n_obj_range[1] + 1))
+        size = rng.uniform([0.4, 0.4, 0.4], [2.0, 1.6, 1.2], (n_obj, 3))
+        ctr = np.concatenate([rng.uniform(-2.0, 2.0, (n_obj, 2)), size[:, 2:] / 2 + rng.uniform(0, 0.3, (n_obj, 1))], 1)
+        yaw = rng.uniform(-np.pi / 2, np.pi / 2, (n_obj, 1))
+        labels = rng.integers(0, len(INDOOR_CLASSES), n_obj)
+        n_bg = n_points // 2
+        n_per = (n_points - n_bg) // n_obj
+        pts = []
+        floor = np.concatenate([rng.uniform(-2.5, 2.5, (n_bg // 2, 2)), rng.normal(0, 0.004, (n_bg // 2, 1))], 1)
+        wall1 = np.stack([rng.uniform(-2.5, 2.5, n_bg // 4), np.full(n_bg // 4, 2.5) + rng.normal(0, 0.004, n_bg // 4), rng.uniform(0, 2.7, n_bg // 4)], 1)
+        n_w2 = n_bg - n_bg // 2 - n_bg // 4
+        wall2 = np.stack([np.full(n_w2, -2.5) + rng.normal(0, 0.004, n_w2), rng.uniform(-2.5, 2.5, n_w2), rng.uniform(0, 2.7, n_w2)], 1)
+        pts += [floor, wall1, wall2]
+        for i in range(n_obj):
+            n_i = n_per if i < n_obj - 1 else n_points - n_bg - n_per * (n_obj - 1)
+            u = rng.uniform(-0.5, 0.5, (n_i, 3))
+            face = rng.integers(0, 3, n_i)
+            u[np.arange(n_i), face] = np.where(rng.random(n_i) < 0.5, -0.5, 0.5)       # on the surface of the unit box
+            local = u * size[i]
+            c, s = np.cos(yaw[i, 0]), np.sin(yaw[i, 0])
+            xy = np.stack([local[:, 0] * c - local[:, 1] * s, local[:, 0] * s + local[:, 1] * c], 1)
+            pts.append(np.concatenate([xy + ctr[i, :2], local[:, 2:] + ctr[i, 2]], 1))
+        xyz = np.concatenate(pts).astype(np.float32)
+        xyz = xyz[rng.permutation(len(xyz))]
+        rgb = rng.uniform(0, 1, (len(xyz), 3)).astype(np.float32)
+        p = torch.from_numpy(np.concatenate([xyz, rgb], 1))
+        out['points'].append(p.to(device) if device is not None else p)
+        out['gt_bboxes_3d'].append(DepthInstance3DBoxes(torch.from_numpy(np.concatenate([ctr, size, yaw], 1).astype(np.float32)),
+                                                        box_dim=7, with_yaw=True, origin=(0.5, 0.5, 0.5)))
+        out['gt_labels_3d'].append(torch.from_numpy(labels.astype(np.int64)).to(device) if device is not None
+                                   else torch.from_numpy(labels.astype(np.int64)))
+        out['img_metas'].append(dict(box_type_3d=DepthInstance3DBoxes, sample_idx=f))
+    return out

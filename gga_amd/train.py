@@ -308,6 +308,7 @@ class Runner:
                 g['betas'] = (self.mom_sched(self.iter), g['betas'][1])
         out = self._call_train_step(data)
         self.optimizer.zero_grad(set_to_none=True)
+        dense_conv.RANGE_GUARD.phase = 'backward'
         out['loss'].backward()
         if self.grad_clip:
             torch.nn.utils.clip_grad_norm_([p for p in self.raw_model.parameters() if p.grad is not None],
@@ -326,20 +327,26 @@ class Runner:
 
     def _check_range(self):
         """End of a guarded step: one host read of the guard's rows; falls back to three bf16 planes when an operand has
-        more than ``RangeGuard.LIMIT`` of its non-zero elements below 2^-30 of its largest magnitude."""
+        is over the limit of its pass (``dense_conv.RangeGuard``: forward - lost elements, backward - lost mass)."""
         import warnings
         from . import dense_conv
         rows = dense_conv.RANGE_GUARD.disarm()
-        worst = max(rows, key=lambda r: r['share_lost'], default=None)
-        share = worst['share_lost'] if worst else 0.0
-        self.range_reports.append(dict(iter=self.iter, operands=len(rows), worst_share_lost=share,
-                                       worst_share_below_2p17=max((r['share_below_2p17'] for r in rows), default=0.0),
-                                       worst_shape=worst['shape'] if worst else None))
-        if worst is not None and share > dense_conv.RangeGuard.LIMIT and not dense_conv.PLANES_PINNED:
+        fwd = [r for r in rows if r['phase'] == 'forward']
+        bwd = [r for r in rows if r['phase'] != 'forward']
+        over = [r for r in rows if r['over']]
+        self.range_reports.append(dict(
+            iter=self.iter, operands=len(rows), over_limit=len(over),
+            forward_worst_share_lost=max((r['share_lost'] for r in fwd), default=0.0),
+            backward_worst_mass_lost=max((r['mass_lost'] for r in bwd), default=0.0),
+            backward_worst_share_lost=max((r['share_lost'] for r in bwd), default=0.0),
+            worst_share_below_2p17=max((r['share_below_2p17'] for r in rows), default=0.0),
+            first_over=dict(over[0]) if over else None))
+        if over and not dense_conv.PLANES_PINNED:
             dense_conv.PLANES = 3
-            warnings.warn(f'iteration {self.iter}: {share:.2%} of the non-zero elements of a convolution operand '
-                          f'{worst["shape"]} lie below 2^-30 of its largest magnitude - continuing on three bf16 planes '
-                          f'(fp32 exponent range) instead of two fp16 planes')
+            w = over[0]
+            warnings.warn(f'iteration {self.iter}: a {w["phase"]} operand {w["shape"]} of the convolutions has {w["share_lost"]:.2%} of '
+                          f'its non-zero elements ({w["mass_lost"]:.1e} of its L1 mass) below 2^-30 of its largest magnitude - '
+                          f'continuing on three bf16 planes (fp32 exponent range) instead of two fp16 planes')
 
     def freeze_gc(self):
         """Garbage-collector policy of the iteration loop: after the first iterations have built every long-lived object
@@ -351,6 +358,8 @@ class Runner:
         if not self._gc_frozen:
             gc.collect()
             gc.freeze()
+            if os.environ.get('GGA_GC_OFF') == '1':       # A/B switch for measurements: no collector at all
+                gc.disable()
             self._gc_frozen = True
 
     GC_FREEZE_AFTER = 3

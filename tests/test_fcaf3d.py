@@ -1,0 +1,282 @@
+"""FCAF3D (BASELINE config 4): the MinkowskiEngine-semantics layers against the dense restatement
+oracle/mink_ref.py (parity unpinned: ME is un-vendored), the head's target assignment / loss / decoding against golden
+vectors from a run of the reference's FCAF3DHead (tests/golden/fcaf3d_head.npz, tools_dev/make_golden.py::golden_fcaf3d),
+the merged config against the reference's, and the whole detector stepping on synthetic SUN RGB-D-shaped scenes."""
+import copy
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, REPO
+from gga_amd import Config, build_model
+from gga_amd import fcaf3d as MF
+
+sys.path.insert(0, os.path.join(REPO, 'tools_dev'))
+DEV = 'cuda:0'
+CFG = os.path.join(REPO, 'configs', 'fcaf3d', 'fcaf3d_8x2_sunrgbd-3d-10class.py')
+
+
+def _case_inputs(seed, with_yaw):
+    from make_golden import make_fcaf3d_case          # the seeded input generator (inputs only; outputs come from the .npz)
+    return make_fcaf3d_case(seed, with_yaw)
+
+
+def _head(with_yaw, device='cpu'):
+    head = MF.FCAF3DHead(n_classes=10, in_channels=(64, 128, 256, 512), out_channels=128, n_reg_outs=8 if with_yaw else 6, voxel_size=.01,
+                         pts_prune_threshold=100000, pts_assign_threshold=27, pts_center_threshold=18,
+                         bbox_loss=dict(type='RotatedIoU3DLoss' if with_yaw else 'AxisAlignedIoULoss'),
+                         test_cfg=dict(nms_pre=200, iou_thr=.5, score_thr=.12))
+    return head.to(device)
+
+
+def _check_targets_and_loss(device):
+    g = np.load(os.path.join(GOLDEN, 'fcaf3d_head.npz'))
+    for case in range(3):
+        c = f'c{case}'
+        seed, with_yaw = int(g[f'{c}.seed']), bool(g[f'{c}.with_yaw'])
+        points, cp, bp, clp, gt, labels = _case_inputs(seed, with_yaw)
+        head = _head(with_yaw, device)
+        boxes = MF.DepthInstance3DBoxes(gt if with_yaw else gt[:, :6], box_dim=7 if with_yaw else 6, with_yaw=with_yaw, origin=(.5, .5, .5))
+        to = lambda lst: [t.to(device) for t in lst]
+        ct, bt, clt = head._get_targets(to(points), boxes, labels.to(device))
+        assert torch.equal(clt.cpu(), torch.from_numpy(g[f'{c}.cls_targets']))                    # integer work: exact
+        torch.testing.assert_close(ct.cpu(), torch.from_numpy(g[f'{c}.center_targets']), rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(bt.cpu(), torch.from_numpy(g[f'{c}.bbox_targets']), rtol=1e-6, atol=1e-6)
+        leaves = [[t.clone().to(device).requires_grad_(True) for t in lst] for lst in (cp, bp, clp)]
+        losses = head._loss_single(leaves[0], leaves[1], leaves[2], to(points), boxes, labels.to(device), None)
+        for name, v in zip(('center_loss', 'bbox_loss', 'cls_loss'), losses):
+            assert float(v) == pytest.approx(float(g[f'{c}.{name}']), rel=1e-4, abs=1e-5), (case, name)
+        sum(losses).backward()
+        for name, lst in zip(('center', 'bbox', 'cls'), leaves):
+            for lvl, t in enumerate(lst):
+                want = torch.from_numpy(g[f'{c}.grad.{name}.{lvl}'])
+                torch.testing.assert_close(t.grad.cpu(), want, rtol=1e-3, atol=1e-5 * max(float(want.abs().max()), 1e-3))
+    return g
+
+
+def test_head_targets_and_losses_match_the_reference_run():
+    _check_targets_and_loss('cpu')
+
+
+def test_rotated_iou_3d_known_answers():
+    b = torch.tensor([[0., 0, 0, 2, 4, 1, 0.3]])
+    assert float(MF.rotated_iou_3d(b, b.clone())) == pytest.approx(1.0, abs=1e-5)
+    far = b.clone()
+    far[:, 0] += 10
+    assert float(MF.rotated_iou_3d(b, far)) == 0.0
+    # without yaw it is the axis-aligned IoU; shifted by half a width along x: 2 x 4 x 1 boxes -> overlap 4, union 12
+    a = torch.tensor([[0., 0, 0, 2, 4, 1, 0.]])
+    s = torch.tensor([[1., 0, 0, 2, 4, 1, 0.]])
+    assert float(MF.rotated_iou_3d(a, s)) == pytest.approx(4 / 12, rel=1e-5)
+    # a square turned by 45 degrees inside a square of twice the area, half the height overlap
+    big = torch.tensor([[0., 0, 0, 2, 2, 2, 0.]])
+    dia = torch.tensor([[0., 0, 0.5, 2 ** 0.5, 2 ** 0.5, 1, np.pi / 4]])
+    inter = 2.0 * 1.0
+    assert float(MF.rotated_iou_3d(dia, big)) == pytest.approx(inter / (8 + 2 - inter), rel=1e-5)
+    # differentiable, and random pairs agree with the polygon-clipping IoU of the oracle (BEV) times the z overlap
+    from oracle import oracle as O
+    torch.manual_seed(3)
+    p = torch.cat([torch.randn(64, 3) * 0.5, torch.rand(64, 3) + 0.5, torch.randn(64, 1)], 1).requires_grad_(True)
+    q = torch.cat([torch.randn(64, 3) * 0.5, torch.rand(64, 3) + 0.5, torch.randn(64, 1)], 1)
+    iou = MF.rotated_iou_3d(p, q)
+    iou.sum().backward()
+    assert torch.isfinite(p.grad).all() and float(p.grad.abs().max()) > 0
+    bev = np.asarray(O.box_iou_rotated(p.detach().numpy()[:, [0, 1, 3, 4, 6]].astype(np.float32), q.numpy()[:, [0, 1, 3, 4, 6]].astype(np.float32)))
+    for i in range(64):
+        pi, qi = p.detach()[i], q[i]
+        a1, a2 = float(pi[3] * pi[4]), float(qi[3] * qi[4])
+        inter2d = bev[i, i] * (a1 + a2) / (1 + bev[i, i])
+        zo = max(0.0, min(float(pi[2] + pi[5] / 2), float(qi[2] + qi[5] / 2)) - max(float(pi[2] - pi[5] / 2), float(qi[2] - qi[5] / 2)))
+        want = inter2d * zo / (a1 * float(pi[5]) + a2 * float(qi[5]) - inter2d * zo)
+        assert float(iou[i]) == pytest.approx(want, rel=2e-3, abs=2e-4), i
+
+
+def test_config_equals_the_reference_and_builds():
+    mine = Config.fromfile(CFG)
+    ref_path = '/root/reference/configs/fcaf3d/fcaf3d_8x2_sunrgbd-3d-10class.py'
+    if os.path.exists(ref_path):
+        ref = Config.fromfile(ref_path)
+        plain = lambda v: {k: plain(x) for k, x in v.items()} if isinstance(v, dict) else \
+            [plain(x) for x in v] if isinstance(v, (list, tuple)) else v
+        for key in ('model', 'optimizer', 'optimizer_config', 'lr_config', 'runner', 'checkpoint_config', 'custom_hooks'):
+            assert plain(mine[key]) == plain(ref[key]), key
+        assert mine.data['samples_per_gpu'] == ref.data['samples_per_gpu'] == 8
+        assert plain(mine.train_pipeline) == plain(ref.train_pipeline)
+    model = build_model(mine.model)
+    assert isinstance(model, MF.MinkSingleStage3DDetector) and isinstance(model.backbone, MF.MinkResNet)
+    names = dict(model.named_parameters())
+    for n, shape in (('backbone.conv1.kernel', (27, 3, 64)), ('backbone.norm1.weight', (1, 64)), ('backbone.layer1.0.downsample.0.kernel', (1, 64, 64)),
+                     ('backbone.layer4.2.conv2.kernel', (27, 512, 512)), ('backbone.layer3.5.norm2.bn.weight', (256,)),
+                     ('head.up_block_3.0.kernel', (8, 512, 256)), ('head.up_block_1.3.kernel', (27, 64, 64)), ('head.out_block_0.0.kernel', (27, 64, 128)),
+                     ('head.conv_center.kernel', (1, 128, 1)), ('head.conv_reg.kernel', (1, 128, 8)), ('head.conv_cls.kernel', (1, 128, 10)),
+                     ('head.conv_cls.bias', (1, 10)), ('head.scales.3.scale', ())):
+        assert n in names and tuple(names[n].shape) == shape, n
+    assert float(names['head.conv_cls.bias'][0, 0]) == pytest.approx(-np.log(99.0), rel=1e-6)
+    assert sum(p.numel() for p in model.parameters()) > 60e6          # MinkResNet-34 + the neck / head: about 70 M parameters
+
+
+# --------------------------------------------------------------------------------------------------------------- device
+def _random_sparse(seed, B=2, n=700, extent=(24, 20, 16), C=8, ts=1):
+    g = torch.Generator().manual_seed(seed)
+    c = torch.stack([torch.randint(0, B, (n,), generator=g)] + [torch.randint(0, e, (n,), generator=g) * ts for e in extent], 1)
+    c = torch.unique(c, dim=0)
+    return torch.randn(len(c), C, generator=g), c
+
+
+def _lattice(cmap_or_ts, extent, ts):
+    return tuple(-(-e // 1) for e in extent)
+
+
+def _sorted(feats, coords):
+    key = ((coords[:, 0].long() * 4096 + coords[:, 1]) * 4096 + coords[:, 2]) * 4096 + coords[:, 3]
+    o = torch.argsort(key)
+    return feats[o], coords[o]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('kind', ['conv3_s1', 'conv3_s2', 'conv1_s2', 'maxpool', 'transpose'])
+def test_mink_layers_vs_dense_restatement(kind):
+    from gga_amd import mink as ME
+    from oracle import mink_ref as MR
+    torch.manual_seed(0)
+    B, extent, cin, cout = 2, (24, 20, 16), 8, 16
+    feats, coords = _random_sparse(5, B, 900, extent, cin)
+    fx = feats.to(DEV).requires_grad_(True)            # the coordinates are distinct: quantisation keeps every point, in order
+    x = ME.SparseTensor(coordinates=coords.to(DEV).float(), features=fx, batch_size=B)
+    assert x.cmap.n == len(coords) and x.tensor_stride == 1
+    if kind == 'transpose':          # needs an even tensor stride: go down one level first (pooling keeps it simple)
+        layer = ME.MinkowskiGenerativeConvolutionTranspose(cin, cout).to(DEV)
+        x = ME.MinkowskiMaxPooling()(x)
+    elif kind == 'maxpool':
+        layer = ME.MinkowskiMaxPooling()
+    else:
+        k, s = {'conv3_s1': (3, 1), 'conv3_s2': (3, 2), 'conv1_s2': (1, 2)}[kind]
+        layer = ME.MinkowskiConvolution(cin, cout, kernel_size=k, stride=s).to(DEV)
+    y = layer(x)
+    # dense restatement on the CPU
+    fr = feats.clone().requires_grad_(True)
+    grid, occ = MR.dense(fr, coords, 1, B, extent)
+    w = layer.kernel.detach().cpu().clone().requires_grad_(True) if hasattr(layer, 'kernel') else None
+    if kind == 'transpose':
+        grid, occ = MR.max_pool(grid, occ)
+        gy, oy = MR.conv_transpose(grid, occ, w)
+        ts_out = 1
+    elif kind == 'maxpool':
+        gy, oy = MR.max_pool(grid, occ)
+        ts_out = 2
+    else:
+        gy, oy = MR.conv(grid, occ, w, k, s)
+        ts_out = s
+    yr, cr = MR.sparse(gy, oy, ts_out)
+    assert y.tensor_stride == ts_out
+    ys, cs = _sorted(y.F.detach().cpu(), y.C.cpu().long())
+    yrs, crs = _sorted(yr.detach(), cr)
+    assert torch.equal(cs, crs), kind                                  # the same coordinate set (integer work: exact)
+    torch.testing.assert_close(ys, yrs, rtol=1e-4, atol=1e-4)
+    # backward with a gradient defined per output cell
+    gmap = torch.randn(B, y.F.shape[1], *[e // ts_out + 2 for e in extent])
+    g_at = lambda c: gmap[c[:, 0], :, c[:, 1] // ts_out, c[:, 2] // ts_out, c[:, 3] // ts_out]
+    y.F.backward(g_at(y.C.cpu().long()).to(DEV))
+    yr.backward(g_at(cr))
+    torch.testing.assert_close(fx.grad.cpu(), fr.grad, rtol=1e-4, atol=1e-4)
+    if w is not None:
+        torch.testing.assert_close(layer.kernel.grad.cpu(), w.grad, rtol=1e-4, atol=2e-4)
+
+
+@pytest.mark.gpu
+def test_mink_union_interpolation_quantisation_and_instance_norm():
+    from gga_amd import mink as ME
+    from oracle import mink_ref as MR
+    B, extent = 2, (16, 16, 12)
+    fa, ca = _random_sparse(1, B, 300, extent, 4)
+    fb, cb = _random_sparse(2, B, 300, extent, 4)
+    a = ME.SparseTensor(coordinates=ca.to(DEV).float(), features=fa.to(DEV), batch_size=B)
+    b = ME.SparseTensor(coordinates=cb.to(DEV).float(), features=fb.to(DEV), batch_size=B)
+    # the two were quantised separately: put b on a's lattice (what a backbone level and an upsampled level share)
+    b = ME.SparseTensor(fb.to(DEV), cmap=ME.CoordMap((cb.to(DEV) + torch.tensor([0] + list(a.cmap.origin), device=DEV)).int(), 1, B, a.cmap.origin, a.cmap.extent))
+    u = a + b
+    ga, oa = MR.dense(fa, ca, 1, B, extent)
+    gb, ob = MR.dense(fb, cb, 1, B, extent)
+    gu, ou = MR.union(ga, oa, gb, ob)
+    fu, cu = MR.sparse(gu, ou, 1)
+    us, ucs = _sorted(u.F.cpu(), u.C.cpu().long())
+    assert torch.equal(ucs, cu) and torch.allclose(us, fu, atol=1e-6)
+    # interpolation of a stride-2 tensor at stride-1 coordinates (what FCAF3DHead._prune asks for)
+    p = ME.MinkowskiMaxPooling()(a)
+    q = torch.cat([ca[:, :1].float(), ca[:, 1:].float()], 1).to(DEV)
+    got = p.features_at_coordinates(q).cpu()
+    gp, op_ = MR.max_pool(ga, oa)
+    want = MR.features_at(gp, op_, 2, q.cpu())
+    torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-6)
+    # quantisation: floor, the first point of a voxel wins, negative coordinates keep their voxel
+    pts = torch.tensor([[0, 0.2, 0.7, 0.1], [0, 0.9, 0.1, 0.99], [0, -0.5, 0.2, 0.3], [0, 1.5, 0.2, 0.3], [1, 0.2, 0.7, 0.1]], device=DEV)
+    f = torch.arange(5, dtype=torch.float32, device=DEV)[:, None]
+    t = ME.SparseTensor(coordinates=pts, features=f, batch_size=2)
+    assert sorted(t.F[:, 0].tolist()) == [0.0, 2.0, 3.0, 4.0]
+    assert sorted(map(tuple, t.C.tolist())) == [(0, -1, 0, 0), (0, 0, 0, 0), (0, 1, 0, 0), (1, 0, 0, 0)]
+    # instance norm
+    norm = ME.MinkowskiInstanceNorm(4).to(DEV)
+    with torch.no_grad():
+        norm.weight.uniform_(0.5, 1.5), norm.bias.uniform_(-0.5, 0.5)
+    got = norm(a).F.cpu()
+    want = MR.instance_norm(fa, a.cmap.coords[:, 0].cpu().long(), B, norm.weight.cpu(), norm.bias.cpu())
+    order = torch.argsort(a.cmap.keys()).cpu()
+    fs, _ = _sorted(fa, ca)
+    torch.testing.assert_close(got[order], MR.instance_norm(fs, _sorted(fa, ca)[1][:, 0], B, norm.weight.cpu(), norm.bias.cpu()), rtol=1e-4, atol=1e-5)
+    assert want.shape == got.shape
+
+
+@pytest.mark.gpu
+def test_head_on_device_matches_the_reference_run_including_detections():
+    g = _check_targets_and_loss(DEV)
+    for case in range(3):
+        c = f'c{case}'
+        seed, with_yaw = int(g[f'{c}.seed']), bool(g[f'{c}.with_yaw'])
+        points, cp, bp, clp, gt, labels = _case_inputs(seed, with_yaw)
+        head = _head(with_yaw, DEV)
+        to = lambda lst: [t.to(DEV) for t in lst]
+        with torch.no_grad():
+            bb, sc, lb = head._get_bboxes_single(to(cp), to(bp), to(clp), to(points), dict(box_type_3d=MF.DepthInstance3DBoxes))
+        want_s, want_b, want_l = torch.from_numpy(g[f'{c}.det.scores']), torch.from_numpy(g[f'{c}.det.bboxes']), torch.from_numpy(g[f'{c}.det.labels'])
+        assert len(sc) == len(want_s), (case, len(sc), len(want_s))
+        # the same detections (per class in descending score order on both sides)
+        key = lambda s, l: torch.argsort(l.double() * 10 - s.double(), stable=True)
+        o1, o2 = key(sc.cpu(), lb.cpu()), key(want_s, want_l)
+        assert torch.equal(lb.cpu()[o1], want_l[o2])
+        torch.testing.assert_close(sc.cpu()[o1], want_s[o2], rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(bb.tensor.cpu()[o1], want_b[o2], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.gpu
+def test_detector_steps_and_learns_and_tests():
+    """configs/fcaf3d/fcaf3d_8x2_sunrgbd-3d-10class.py end to end on synthetic scenes: the three losses of the reference's loss
+    dict, finite, falling over a few AdamW steps; every level prunes to its threshold; simple_test returns boxes."""
+    from gga_amd import synthetic
+    from gga_amd.train import Runner
+    cfg = Config.fromfile(CFG)
+    torch.manual_seed(0)
+    model = build_model(cfg.model).to(DEV).train()
+    b = synthetic.make_indoor_batch(2, device=DEV, n_points=20000)
+    data = {k: b[k] for k in synthetic.INDOOR_BATCH_KEYS}
+    feats = model.extract_feat(data['points'])
+    assert [f.tensor_stride for f in feats] == [8, 16, 32, 64] and [f.F.shape[1] for f in feats] == [64, 128, 256, 512]
+    assert all(f.F.shape[0] > 0 for f in feats)
+    runner = Runner(model, cfg, max_iters=100, iters_per_epoch=10)
+    out = runner.step(data)
+    assert set(out['log_vars']) == {'center_loss', 'bbox_loss', 'cls_loss', 'loss'}
+    first = float(out['loss'])
+    for _ in range(8):
+        out = runner.step(data)
+    last = float(out['loss'])
+    assert np.isfinite(first) and np.isfinite(last) and last < first, (first, last)
+    # pruning: with a threshold below the level sizes every sample keeps exactly that many locations
+    model.head.pts_prune_threshold = 500
+    with torch.no_grad():
+        cps, bps, cls, pts = model.head(model.extract_feat(data['points']))
+    assert all(len(p) <= 500 * 1 for lvl in pts[:-1] for p in lvl) and any(len(p) == 500 for p in pts[0])
+    model.eval()
+    res = model.simple_test(data['points'], data['img_metas'])
+    assert len(res) == 2 and set(res[0]) >= {'boxes_3d', 'scores_3d', 'labels_3d'}

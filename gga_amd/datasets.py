@@ -239,3 +239,136 @@ class LoadAnnotations3D:
         if self.with_gga:
             results = self._load_GGA_labels(results)
         return results
+
+
+def lidar_boxes_to_camera(boxes, rt_mat):
+    """``Box3DMode.convert(box, LIDAR, CAM, rt_mat)`` for an [N,7] tensor (box_3d_mode.py:113-199): sizes (x, y, z) ->
+    (x, z, y), yaw -> limit_period(-yaw - pi/2, 2 pi), centres through ``rt_mat`` (cast to the boxes' dtype)."""
+    arr = boxes.clone()
+    xyz_size = torch.cat([arr[..., 3:4], arr[..., 5:6], arr[..., 4:5]], dim=-1)
+    yaw = limit_period(-arr[..., 6:7] - np.pi / 2, period=np.pi * 2)
+    rt = arr.new_tensor(np.asarray(rt_mat))
+    if rt.size(1) == 4:
+        xyz = torch.cat([arr[..., :3], arr.new_ones(arr.size(0), 1)], dim=-1) @ rt.t()
+    else:
+        xyz = arr[..., :3] @ rt.t()
+    return torch.cat([xyz[..., :3], xyz_size, yaw, arr[..., 7:]], dim=-1)
+
+
+@DATASETS.register_module()
+class KittiDataset_GGA_match(KittiDataset_GGA_train):
+    """The dataset of configs/gga/gga_kitti_matching_config.py (mmdet3d/datasets/kitti_dataset_GGA_match.py): the train dataset
+    whose ``evaluate`` turns the detections of a test run into KITTI annotations (``format_results`` ->
+    ``bbox2result_kitti`` -> ``convert_valid_bboxes``, :330-383,458-571,685-766) and hands them to
+    ``pseudo_label_matching_kitti`` together with a copy of its infos (:419-424) - the step that writes the pseudo-label
+    file of the GGA recipe. The KITTI AP evaluation that follows in the reference (``kitti_eval``, a numba CPU code of
+    mmdet3d/core/evaluation) is out of scope (evaluation is not on the path); ``evaluate`` returns the counts of
+    the matching instead."""
+
+    def format_results(self, outputs, pklfile_prefix=None, submission_prefix=None):
+        import tempfile
+        tmp_dir = None
+        if pklfile_prefix is None:
+            tmp_dir = tempfile.TemporaryDirectory()
+            pklfile_prefix = os.path.join(tmp_dir.name, 'results')
+        if not isinstance(outputs[0], dict):
+            raise NotImplementedError('2D-only results (bbox2result_kitti2d) are not produced by the GGA configs')
+        if 'pts_bbox' in outputs[0] or 'img_bbox' in outputs[0]:
+            result_files = dict()
+            for name in outputs[0]:
+                if 'img' in name:
+                    raise NotImplementedError('image-branch results are not produced by the GGA configs')
+                results_ = [out[name] for out in outputs]
+                sub = submission_prefix + name if submission_prefix is not None else None
+                result_files[name] = self.bbox2result_kitti(results_, self.CLASSES, pklfile_prefix + name, sub)
+        else:
+            result_files = self.bbox2result_kitti(outputs, self.CLASSES, pklfile_prefix, submission_prefix)
+        return result_files, tmp_dir
+
+    def evaluate(self, results, metric=None, logger=None, pklfile_prefix=None, submission_prefix=None, show=False, out_dir=None,
+                 pipeline=None, pseudo_label_file='default', device='cuda:0'):
+        from .pseudo_labels import DEFAULT_OUT_FILE, pseudo_label_matching_kitti
+        result_files, tmp_dir = self.format_results(results, pklfile_prefix)
+        dets = result_files['pts_bbox'] if isinstance(result_files, dict) else result_files
+        infos = copy.deepcopy(self.data_infos)
+        out_file = DEFAULT_OUT_FILE if pseudo_label_file == 'default' else pseudo_label_file
+        gt_annos = pseudo_label_matching_kitti(infos, dets, filename=out_file, device=device)
+        if tmp_dir is not None:
+            tmp_dir.cleanup()
+        return {'pseudo_labels/frames': float(len(gt_annos)), 'pseudo_labels/objects': float(sum(len(a['name']) for a in gt_annos)),
+                'pseudo_labels/detections': float(sum(len(d['name']) for d in dets))}
+
+    def bbox2result_kitti(self, net_outputs, class_names, pklfile_prefix=None, submission_prefix=None):
+        assert len(net_outputs) == len(self.data_infos), 'invalid list length of network outputs'
+        if submission_prefix is not None:
+            os.makedirs(submission_prefix, exist_ok=True)
+        det_annos = []
+        for idx, pred_dicts in enumerate(net_outputs):
+            info = self.data_infos[idx]
+            sample_idx = info['image']['image_idx']
+            image_shape = info['image']['image_shape'][:2]
+            box_dict = self.convert_valid_bboxes(pred_dicts, info)
+            anno = {'name': [], 'truncated': [], 'occluded': [], 'alpha': [], 'bbox': [], 'dimensions': [], 'location': [],
+                    'rotation_y': [], 'score': []}
+            if len(box_dict['bbox']) > 0:
+                for box, box_lidar, bbox, score, label in zip(box_dict['box3d_camera'], box_dict['box3d_lidar'], box_dict['bbox'],
+                                                              box_dict['scores'], box_dict['label_preds']):
+                    bbox[2:] = np.minimum(bbox[2:], image_shape[::-1])
+                    bbox[:2] = np.maximum(bbox[:2], [0, 0])
+                    anno['name'].append(class_names[int(label)])
+                    anno['truncated'].append(0.0)
+                    anno['occluded'].append(0)
+                    anno['alpha'].append(-np.arctan2(-box_lidar[1], box_lidar[0]) + box[6])
+                    anno['bbox'].append(bbox)
+                    anno['dimensions'].append(box[3:6])
+                    anno['location'].append(box[:3])
+                    anno['rotation_y'].append(box[6])
+                    anno['score'].append(score)
+                anno = {k: np.stack(v) for k, v in anno.items()}
+            else:
+                anno = {'name': np.array([]), 'truncated': np.array([]), 'occluded': np.array([]), 'alpha': np.array([]),
+                        'bbox': np.zeros([0, 4]), 'dimensions': np.zeros([0, 3]), 'location': np.zeros([0, 3]),
+                        'rotation_y': np.array([]), 'score': np.array([])}
+            if submission_prefix is not None:
+                with open(f'{submission_prefix}/{sample_idx:06d}.txt', 'w') as f:
+                    bbox, loc, dims = anno['bbox'], anno['location'], anno['dimensions']          # lhw -> hwl
+                    for i in range(len(bbox)):
+                        print('{} -1 -1 {:.4f} {:.4f} {:.4f} {:.4f} {:.4f} {:.4f} {:.4f} {:.4f} {:.4f} {:.4f} {:.4f} {:.4f} {:.4f}'.format(
+                            anno['name'][i], anno['alpha'][i], bbox[i][0], bbox[i][1], bbox[i][2], bbox[i][3], dims[i][1], dims[i][2],
+                            dims[i][0], loc[i][0], loc[i][1], loc[i][2], anno['rotation_y'][i], anno['score'][i]), file=f)
+            anno['sample_idx'] = np.array([sample_idx] * len(anno['score']), dtype=np.int64)
+            det_annos.append(anno)
+        if pklfile_prefix is not None:
+            out = pklfile_prefix if pklfile_prefix.endswith(('.pkl', '.pickle')) else f'{pklfile_prefix}.pkl'
+            with open(out, 'wb') as f:
+                pickle.dump(det_annos, f)
+        return det_annos
+
+    def convert_valid_bboxes(self, box_dict, info):
+        from .box3d import CameraInstance3DBoxes, points_cam2img
+        box_preds, scores, labels = box_dict['boxes_3d'], box_dict['scores_3d'], box_dict['labels_3d']
+        sample_idx = info['image']['image_idx']
+        box_preds.limit_yaw(offset=0.5, period=np.pi * 2)
+        empty = dict(bbox=np.zeros([0, 4]), box3d_camera=np.zeros([0, 7]), box3d_lidar=np.zeros([0, 7]), scores=np.zeros([0]),
+                     label_preds=np.zeros([0, 4]), sample_idx=sample_idx)
+        if len(box_preds) == 0:
+            return empty
+        rect = info['calib']['R0_rect'].astype(np.float32)
+        Trv2c = info['calib']['Tr_velo_to_cam'].astype(np.float32)
+        P2 = box_preds.tensor.new_tensor(info['calib']['P2'].astype(np.float32))
+        img_shape = info['image']['image_shape']
+        cam = CameraInstance3DBoxes(lidar_boxes_to_camera(box_preds.tensor, rect @ Trv2c), box_dim=box_preds.tensor.shape[-1])
+        box_corners_in_image = points_cam2img(cam.corners, P2)
+        minxy, maxxy = torch.min(box_corners_in_image, dim=1)[0], torch.max(box_corners_in_image, dim=1)[0]
+        box_2d_preds = torch.cat([minxy, maxxy], dim=1)
+        image_shape = box_preds.tensor.new_tensor(img_shape)
+        valid_cam_inds = ((box_2d_preds[:, 0] < image_shape[1]) & (box_2d_preds[:, 1] < image_shape[0]) &
+                          (box_2d_preds[:, 2] > 0) & (box_2d_preds[:, 3] > 0))
+        limit_range = box_preds.tensor.new_tensor(self.pcd_limit_range)
+        center = box_preds.tensor[:, :3]              # ``center`` of a LiDAR box is its bottom centre (base_box3d.py:96-103)
+        valid_inds = valid_cam_inds & ((center > limit_range[:3]) & (center < limit_range[3:])).all(-1)
+        if valid_inds.sum() > 0:
+            return dict(bbox=box_2d_preds[valid_inds, :].numpy(), box3d_camera=cam.tensor[valid_inds].numpy(),
+                        box3d_lidar=box_preds.tensor[valid_inds].numpy(), scores=scores[valid_inds].numpy(),
+                        label_preds=labels[valid_inds].numpy(), sample_idx=sample_idx)
+        return empty

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import GOLDEN
+from conftest import GOLDEN, REPO
 from gga_amd import synthetic
 from gga_amd.datasets import KittiDataset_GGA_train, LoadAnnotations3D, camera_boxes_to_lidar
 from gga_amd.pipelines import LoadPointsFromFile
@@ -151,3 +151,40 @@ def test_gga_info_file_driver(golden, tmp_path):
     KC.create_gga_info_file(str(tmp_path), infos, [71], str(tmp_path / 'again.pkl'), save_path=split_dir, resume=True,
                             logger=lambda s: None, compute_num_points=False)
     assert before == {f: os.path.getmtime(os.path.join(split_dir, f)) for f in os.listdir(split_dir)}
+
+
+def test_match_dataset_converts_detections_like_the_reference():
+    """``KittiDataset_GGA_match.bbox2result_kitti`` / ``convert_valid_bboxes`` (kitti_dataset_GGA_match.py:458-571,685-766)
+    against a run of the reference's own two methods (tests/golden/match_dataset.npz): which detections survive the image /
+    range checks, their KITTI fields; and the dataset is what configs/gga/gga_kitti_matching_config.py names."""
+    import sys
+    sys.path.insert(0, os.path.join(REPO, 'tools_dev'))
+    from make_golden import make_match_case
+    from gga_amd import Config
+    from gga_amd.box3d import LiDARInstance3DBoxes
+    from gga_amd.datasets import KittiDataset_GGA_match
+    from gga_amd.registry import DATASETS
+    cfg = Config.fromfile(os.path.join(REPO, 'configs', 'gga', 'gga_kitti_matching_config.py'))
+    assert cfg.data['test']['type'] == 'KittiDataset_GGA_match' and DATASETS.get('KittiDataset_GGA_match') is KittiDataset_GGA_match
+    assert cfg.model['type'] == 'GGA' and cfg.optimizer['type'] == 'AdamW'            # everything else is gga_kitti_config.py
+    ref_cfg = '/root/reference/configs/gga/gga_kitti_matching_config.py'
+    if os.path.exists(ref_cfg):
+        r = Config.fromfile(ref_cfg)
+        for k in ('type', 'ann_file', 'split', 'pts_prefix', 'test_mode', 'box_type_3d'):
+            assert cfg.data['test'][k] == r.data['test'][k], k
+    infos, outputs = make_match_case()
+    ds = KittiDataset_GGA_match.__new__(KittiDataset_GGA_match)
+    ds.data_infos, ds.pcd_limit_range, ds.CLASSES = infos, [0, -40, -3, 70.4, 40, 0.0], ('Pedestrian', 'Cyclist', 'Car')
+    net = [dict(boxes_3d=LiDARInstance3DBoxes(torch.from_numpy(o['boxes'])), scores_3d=torch.from_numpy(o['scores']),
+                labels_3d=torch.from_numpy(o['labels'])) for o in outputs]
+    annos = ds.bbox2result_kitti(net, ds.CLASSES)
+    g = np.load(os.path.join(GOLDEN, 'match_dataset.npz'))
+    assert [len(a['name']) for a in annos] == [1, 4, 0]
+    for i, a in enumerate(annos):
+        assert set(a) == {'name', 'truncated', 'occluded', 'alpha', 'bbox', 'dimensions', 'location', 'rotation_y', 'score', 'sample_idx'}
+        for k, v in a.items():
+            want = g[f'{i}.{k}']
+            if k == 'name':
+                assert list(np.asarray(v).astype('U16')) == list(want)
+            else:
+                np.testing.assert_allclose(np.asarray(v, dtype=np.float64), want.astype(np.float64), rtol=2e-5, atol=2e-4, err_msg=f'{i}.{k}')

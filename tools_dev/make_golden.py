@@ -1170,6 +1170,65 @@ def golden_fcaf3d(ref):
     np.savez_compressed(os.path.join(OUT, 'fcaf3d_head.npz'), **out)
 
 
+def make_match_case():
+    """Three KITTI-shaped infos (calibration, image shape) and seeded LiDAR detections for them."""
+    infos, outputs = [], []
+    for i, seed in enumerate((31, 32, 33)):
+        rng = np.random.default_rng(seed)
+        P2 = np.array([[721.5, 0, 609.5, 44.9], [0, 721.5, 172.8, 0.2], [0, 0, 1, 0.003], [0, 0, 0, 1]], np.float64)
+        R0 = np.eye(4)
+        R0[:3, :3] = np.array([[0.9999, 0.0098, -0.0074], [-0.0099, 0.9999, -0.0043], [0.0074, 0.0044, 0.9999]])
+        Tr = np.eye(4)
+        Tr[:3] = np.array([[0.0075, -0.9999, -0.0006, -0.0041], [0.0148, 0.0007, -0.9999, -0.0763], [0.9999, 0.0075, 0.0148, -0.2718]])
+        infos.append(dict(image=dict(image_idx=100 + i, image_shape=np.array([375, 1242], np.int32)),
+                          calib=dict(P2=P2, R0_rect=R0, Tr_velo_to_cam=Tr)))
+        n = 0 if i == 2 else int(rng.integers(5, 12))
+        xyz = np.stack([rng.uniform(-5, 75, n), rng.uniform(-45, 45, n), rng.uniform(-3.5, 0.5, n)], 1)
+        size = rng.uniform([0.5, 0.4, 1.2], [4.5, 2.0, 2.0], (n, 3))
+        yaw = rng.uniform(-4, 4, (n, 1))
+        outputs.append(dict(boxes=np.concatenate([xyz, size, yaw], 1).astype(np.float32), scores=rng.uniform(0.1, 1, n).astype(np.float32),
+                            labels=rng.integers(0, 3, n).astype(np.int64)))
+    return infos, outputs
+
+
+def golden_match(ref):
+    """``KittiDataset_GGA_match.convert_valid_bboxes`` / ``bbox2result_kitti`` (mmdet3d/datasets/kitti_dataset_GGA_match.py:
+    458-571,685-766) of the reference, taken out of their class by name at run time (the module itself imports mmcv / mmdet /
+    the evaluation package), with the reference's own LiDAR / camera boxes, Box3DMode and points_cam2img."""
+    import ast
+    su = ref['su']
+    pl = import_reference_pipeline(ref)
+    cam = sys.modules.get('mmdet3d.core.bbox.structures.cam_box3d') or load('mmdet3d.core.bbox.structures.cam_box3d',
+                                                                            'mmdet3d/core/bbox/structures/cam_box3d.py')
+    sys.modules['mmdet3d.core.bbox.structures.cam_box3d'] = cam
+    dep = sys.modules.get('mmdet3d.core.bbox.structures.depth_box3d')
+    if dep is None:
+        try:
+            dep = load('mmdet3d.core.bbox.structures.depth_box3d', 'mmdet3d/core/bbox/structures/depth_box3d.py')
+        except Exception:
+            dep = _mod('mmdet3d.core.bbox.structures.depth_box3d', DepthInstance3DBoxes=type('DepthInstance3DBoxes', (), {}))
+    bm = load('mmdet3d.core.bbox.structures.box_3d_mode', 'mmdet3d/core/bbox/structures/box_3d_mode.py')
+    src = open(os.path.join(REF, 'mmdet3d/datasets/kitti_dataset_GGA_match.py')).read()
+    cls = [n for n in ast.parse(src).body if isinstance(n, ast.ClassDef) and n.name == 'KittiDataset_GGA_match'][0]
+    fns = [n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name in ('convert_valid_bboxes', 'bbox2result_kitti')]
+    fake_mmcv = type('mmcv', (), dict(mkdir_or_exist=staticmethod(lambda p: os.makedirs(p, exist_ok=True)),
+                                      track_iter_progress=staticmethod(lambda x: x), dump=staticmethod(lambda obj, f: None)))
+    ns = dict(np=np, torch=torch, mmcv=fake_mmcv, Box3DMode=bm.Box3DMode, points_cam2img=su.points_cam2img, print=lambda *a, **k: None)
+    exec(compile(ast.Module(body=fns, type_ignores=[]), 'kitti_dataset_GGA_match.py', 'exec'), ns)
+    infos, outputs = make_match_case()
+    fake = type('D', (), dict(data_infos=infos, pcd_limit_range=[0, -40, -3, 70.4, 40, 0.0], CLASSES=('Pedestrian', 'Cyclist', 'Car'),
+                              convert_valid_bboxes=ns['convert_valid_bboxes'], bbox2result_kitti=ns['bbox2result_kitti']))()
+    net = [dict(boxes_3d=pl['LiDARInstance3DBoxes'](torch.from_numpy(o['boxes'])), scores_3d=torch.from_numpy(o['scores']),
+                labels_3d=torch.from_numpy(o['labels'])) for o in outputs]
+    annos = fake.bbox2result_kitti(net, fake.CLASSES)
+    out = {}
+    for i, a in enumerate(annos):
+        for k, v in a.items():
+            out[f'{i}.{k}'] = np.asarray(v).astype('U16') if k == 'name' else np.asarray(v)
+    print('  match dataset:', [len(a['name']) for a in annos], 'valid detections of', [len(o['scores']) for o in outputs])
+    np.savez_compressed(os.path.join(OUT, 'match_dataset.npz'), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = import_reference()

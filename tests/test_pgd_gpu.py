@@ -243,5 +243,75 @@ def test_level_streams_and_prepared_targets_change_nothing(monkeypatch):
         for k in l1:
             assert abs(l1[k] - l0[k]) <= 1e-5 * abs(l0[k]) + 1e-7, (mode, k, l1[k], l0[k])
         assert g1.keys() == g0.keys()
-        for n in g1:  # global float atomics (DCN col2im, target scatter) order their additions differently from run to run
-            assert float((g1[n] - g0[n]).abs().max()) <= 2e-4 * float(g0[n].abs().max()) + 1e-7, (mode, n)
+        for n in g1:  # global float atomics (DCN col2im, target scatter) order their additions differently from run to run, the
+            # one-launch form runs other tile shapes; through the 101 layers below the head (random, un-normalised backbone)
+            assert float((g1[n] - g0[n]).abs().max()) <= 2e-3 * float(g0[n].abs().max()) + 1e-7, (mode, n)
+
+
+@pytest.mark.parametrize('planes', [2, 3])
+def test_wide_head_with_groupnorm_and_dcn_runs_the_hip_kernels_and_matches_the_reference(planes, monkeypatch):
+    """The head at its real width - 256 channels, GroupNorm(32) after every tower convolution, DCNv2 as the
+    last convolution of both towers (configs/_base_/models/pgd.py towers) - against a run of the reference's PGDHead with the
+    same (name-derived) weights and features (tests/golden/pgd_head_wide.npz; DCNv2 there = oracle/dcn_ref, parity unpinned):
+    forward, and the gradients of a fixed linear functional of the outputs w.r.t. the features and the parameters. The
+    forward and backward must go through gga_dense_conv3x3 (tower and branch convolutions), gga_gn_relu_* and the DCN
+    sampling kernels - counted."""
+    import sys
+    sys.path.insert(0, os.path.join(REPO, 'tools_dev'))
+    from make_golden import WIDE_C, WIDE_GRAD_KEYS, synth_state, synth_tensor, wide_sample
+    from gga_amd import _lib, dense_conv
+    from gga_amd.cnn import to_channels_last
+    from gga_amd.dcn import ModulatedDeformConv2dPack
+    monkeypatch.setattr(dense_conv, 'PLANES', planes)
+    g = np.load(os.path.join(REPO, 'tests', 'golden', 'pgd_head_wide.npz'))
+    wide = lambda v: (WIDE_C, ) if v == (32, ) else tuple((WIDE_C, ) for _ in v) if isinstance(v, tuple) and v and isinstance(v[0], tuple) else v
+    cfg = {k: wide(v) if k.endswith('_branch') else v for k, v in HEAD_CFG.items()}
+    cfg.update(in_channels=WIDE_C, feat_channels=WIDE_C, dcn_on_last_conv=True, norm_cfg=dict(type='GN', num_groups=32, requires_grad=True))
+    head = build_head(cfg)
+    synth_state(head)
+    head = to_channels_last(head.to(DEV)).train()
+    assert isinstance(head.cls_convs[-1].conv, ModulatedDeformConv2dPack) and isinstance(head.cls_convs[0].gn, torch.nn.GroupNorm)
+    L = _lib.lib()
+    calls = {}
+    for name in ('gga_dense_conv3x3_bn_bwd', 'gga_dense_conv3x3_levels', 'gga_dense_wgrad3x3_planes', 'gga_gn_relu_fwd', 'gga_gn_relu_bwd',
+                 'gga_dcn_im2col_amax', 'gga_dcn_col2im'):
+        if hasattr(L, name):
+            def counted(*a, _real=getattr(L, name), _n=name):
+                calls[_n] = calls.get(_n, 0) + 1
+                return _real(*a)
+            monkeypatch.setattr(L, name, counted)
+    hw = (64, 192)
+    feats = [(synth_tensor(f'feat.{i}', (1, WIDE_C, hw[0] // s, hw[1] // s)) * 0.5).to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+             for i, s in enumerate((4, 8, 16, 32))]
+    out = head(feats)
+    total = 0
+    for name, lst in zip(('cls', 'bbox', 'dir', 'depth', 'weight', 'attr', 'cen'), out):
+        for i, t in enumerate(lst):
+            if t is None:
+                continue
+            want = torch.from_numpy(g[f'fwd.{name}.{i}'])
+            if name == 'bbox':          # sizes carry the prior of argmax(cls): compared where both sides chose the same class
+                same = (out[0][i].argmax(1).cpu() == torch.from_numpy(g[f'fwd.cls.{i}']).argmax(1))[:, None].expand_as(want)
+                assert same.float().mean() > 0.99
+                torch.testing.assert_close(t.detach().cpu()[same], want[same], rtol=2e-3, atol=2e-3)
+                continue
+            torch.testing.assert_close(t.detach().cpu(), want, rtol=1e-3, atol=1e-3, msg=lambda m: f'{name}.{i}: {m}')
+            total = total + (t * synth_tensor(f'coef.{name}.{i}', t.shape).to(DEV)).sum()
+    total.backward()
+    for i, f in enumerate(feats):
+        want = torch.from_numpy(g[f'grad.feat.{i}'])
+        err = float((f.grad.cpu() - want).norm() / want.norm())
+        assert err < 2e-3, (i, err)
+    checked = 0
+    for k, p in head.named_parameters():
+        if p.grad is not None and any(t in k for t in WIDE_GRAD_KEYS):
+            want = torch.from_numpy(g['grad.' + k])
+            err = float((wide_sample(k, p.grad.cpu()) - want).norm() / (want.norm() + 1e-12))
+            assert err < 3e-3, (k, err)
+            checked += 1
+    assert checked >= 25
+    # the HIP paths ran: dense 3x3 convolutions forward (per level or over the levels) and their weight gradients,
+    # fused GroupNorm + ReLU both ways, DCN sampling both ways
+    assert calls.get('gga_dense_conv3x3_bn_bwd', 0) + calls.get('gga_dense_conv3x3_levels', 0) >= 8, calls
+    assert calls.get('gga_dense_wgrad3x3_planes', 0) >= 4 and calls.get('gga_gn_relu_fwd', 0) >= 4 and calls.get('gga_gn_relu_bwd', 0) >= 4, calls
+    assert calls.get('gga_dcn_im2col_amax', 0) >= 2, calls

@@ -45,8 +45,30 @@ def _identity_decorator_factory(*a, **k):
     return lambda f: f
 
 
+class _DCNv2Pack(nn.Module):
+    """mmcv ``ModulatedDeformConv2dPack`` (absent wheel; restated): conv_offset (zero-initialised, 3 * k * k channels) ->
+    offsets = first two thirds, mask = sigmoid(last third); the operator itself is oracle/dcn_ref (parity unpinned)."""
+
+    def __init__(self, cin, cout, kernel_size, stride=1, padding=0, bias=True):
+        super().__init__()
+        k = kernel_size
+        self.stride, self.padding = (stride, stride), (padding, padding)
+        self.weight = nn.Parameter(torch.empty(cout, cin, k, k))
+        self.bias = nn.Parameter(torch.zeros(cout)) if bias else None
+        nn.init.kaiming_uniform_(self.weight, nonlinearity='relu')
+        self.conv_offset = nn.Conv2d(cin, 3 * k * k, k, stride, padding, bias=True)
+        nn.init.zeros_(self.conv_offset.weight), nn.init.zeros_(self.conv_offset.bias)
+
+    def forward(self, x):
+        from oracle import dcn_ref
+        out = self.conv_offset(x)
+        o1, o2, mask = torch.chunk(out, 3, dim=1)
+        return dcn_ref.modulated_deform_conv2d(x, torch.cat((o1, o2), dim=1), torch.sigmoid(mask), self.weight, self.bias,
+                                               self.stride, self.padding)
+
+
 class _ConvModule(nn.Module):
-    """conv + bn + relu with mmcv's attribute names (conv / bn / activate)."""
+    """conv + norm + relu with mmcv's attribute names (conv / bn or gn / activate)."""
 
     def __init__(self, cin, cout, kernel_size, stride=1, padding=0, bias='auto',
                  conv_cfg=None, norm_cfg=None, act_cfg=dict(type='ReLU'), **kw):
@@ -54,14 +76,26 @@ class _ConvModule(nn.Module):
         with_norm = norm_cfg is not None
         if bias == 'auto':
             bias = not with_norm
-        self.conv = nn.Conv2d(cin, cout, kernel_size, stride, padding, bias=bias)
-        self.bn = nn.BatchNorm2d(cout) if with_norm else None
+        if conv_cfg is not None and conv_cfg.get('type') == 'DCNv2':
+            self.conv = _DCNv2Pack(cin, cout, kernel_size, stride, padding, bias=bias)
+        else:
+            self.conv = nn.Conv2d(cin, cout, kernel_size, stride, padding, bias=bias)
+        self.bn = self.gn = None
+        if with_norm and norm_cfg['type'] == 'GN':
+            self.gn = nn.GroupNorm(norm_cfg['num_groups'], cout)
+        elif with_norm:
+            self.bn = nn.BatchNorm2d(cout)
+        if self.bn is None:
+            del self.bn
+        if self.gn is None:
+            del self.gn
         self.activate = nn.ReLU(inplace=True) if act_cfg is not None else None
 
     def forward(self, x):
         x = self.conv(x)
-        if self.bn is not None:
-            x = self.bn(x)
+        norm = getattr(self, 'bn', None) or getattr(self, 'gn', None)
+        if norm is not None:
+            x = norm(x)
         if self.activate is not None:
             x = self.activate(x)
         return x
@@ -838,6 +872,47 @@ def tests_golden_dir():
     return OUT
 
 
+WIDE_GRAD_KEYS = ('cls_convs.0.', 'cls_convs.1.', 'reg_convs.1.', 'conv_cls.', 'conv_cls_prev.0.', 'conv_reg_prevs.2.', 'conv_regs.2.',
+                  'conv_depth_cls', 'fuse_lambda', 'scales.1.')
+
+
+WIDE_C = 256           # the width of configs/gga/gga_pdg.py's towers (and the narrowest the DCN kernels take)
+
+
+def wide_sample(name, t):
+    """Large gradients are stored as 4096 entries at name-derived positions."""
+    import zlib
+    if t.numel() <= 100000:
+        return t
+    idx = torch.randperm(t.numel(), generator=torch.Generator().manual_seed(zlib.crc32(name.encode()) ^ 0x5bd1))[:4096]
+    return t.reshape(-1).cpu()[idx]
+
+
+def synth_tensor(name, shape):
+    """Deterministic values from a name: the golden file need not carry inputs a test can rebuild."""
+    import zlib
+    return torch.randn(tuple(shape), generator=torch.Generator().manual_seed(zlib.crc32(name.encode())))
+
+
+def synth_state(head):
+    """Fill every parameter of a (reference or product) PGDHead from its NAME - same names, same values on both sides."""
+    with torch.no_grad():
+        for k, p in head.named_parameters():
+            v = synth_tensor(k, p.shape)
+            if k.endswith('gn.weight'):
+                p.copy_(1.0 + 0.25 * v.clamp(-2, 2))
+            elif 'conv_offset' in k:
+                p.copy_(v * (0.02 if k.endswith('weight') else 0.2))
+            elif k.endswith('.scale'):
+                p.copy_(1.0 + 0.1 * v)
+            elif k == 'fuse_lambda':
+                p.fill_(0.3)
+            elif p.dim() >= 2:
+                p.copy_(v * (0.5 if k.startswith('conv_cls.') else 0.05 * (64.0 / max(p.shape[1], 64)) ** 0.5))
+            else:
+                p.copy_(v * 0.1)
+
+
 PGD_HEAD_CFG = dict(      # bbox_head of configs/gga/gga_pdg.py over configs/_base_/models/pgd.py (norm-free towers, no DCN: the
     num_classes=3, in_channels=32, stacked_convs=2, feat_channels=32, use_direction_classifier=True,       # golden is about the
     diff_rad_by_sin=True, pred_attrs=False, pred_velo=False, pred_bbox2d=True, pred_keypoints=True,         # head logic)
@@ -1051,6 +1126,36 @@ def golden_pgd(ref):
         assert attrs is None
     print(f'  pgd inference: {[len(d[1]) for d in dets]} detections, labels {[sorted(set(d[2].tolist())) for d in dets]}')
     np.savez_compressed(os.path.join(OUT, 'pgd_head.npz'), **out)
+    # ---- the head at a width the matrix kernels take (64 channels), with the towers of configs/_base_/models/pgd.py:
+    # GroupNorm(32) after every tower convolution and DCNv2 as the last convolution of both towers. Forward with shared
+    # weights and the gradients of a fixed linear functional of every output w.r.t. the features and every parameter.
+    wide = dict(PGD_HEAD_CFG)
+    sub = lambda v: (WIDE_C, ) if v == (32, ) else tuple((WIDE_C, ) for _ in v) if isinstance(v, tuple) and v and isinstance(v[0], tuple) else v
+    wide = {k: sub(v) if k.endswith('_branch') else v for k, v in wide.items()}
+    wide.update(in_channels=WIDE_C, feat_channels=WIDE_C, dcn_on_last_conv=True, norm_cfg=dict(type='GN', num_groups=32, requires_grad=True))
+    torch.manual_seed(1)
+    head = pg.PGDHead(**wide)
+    head.train()
+    synth_state(head)
+    hw = (64, 192)
+    feats = [(synth_tensor(f'feat.{i}', (1, WIDE_C, hw[0] // s, hw[1] // s)) * 0.5).requires_grad_(True) for i, s in enumerate((4, 8, 16, 32))]
+    fo = head(feats)
+    out, total = {}, 0
+    for name, lst in zip(('cls', 'bbox', 'dir', 'depth', 'weight', 'attr', 'cen'), fo):
+        for i, t in enumerate(lst):
+            if t is None:
+                continue
+            out[f'fwd.{name}.{i}'] = t.detach().numpy()
+            if name != 'bbox':                         # bbox carries argmax-selected size priors: not a smooth functional
+                total = total + (t * synth_tensor(f'coef.{name}.{i}', t.shape)).sum()
+    total.backward()
+    for i, f in enumerate(feats):
+        out[f'grad.feat.{i}'] = f.grad.numpy()
+    for k, p in head.named_parameters():
+        if p.grad is not None and any(t in k for t in WIDE_GRAD_KEYS):
+            out['grad.' + k] = wide_sample(k, p.grad).numpy()
+    print(f'  pgd wide head: {len([k for k in out if k.startswith("grad.")])} gradients, functional {float(total):.4f}')
+    np.savez_compressed(os.path.join(OUT, 'pgd_head_wide.npz'), **out)
 
 
 def make_fcaf3d_case(seed, with_yaw, n_classes=10):

@@ -383,12 +383,19 @@ class PGDHead(FCOSMono3DHead):
         # stream of its forward and orders the streams itself).
         main = torch.cuda.current_stream(feats[0].device)
         streams = self._level_streams(len(feats), feats[0].device, main)
+        # The levels share every parameter. Each level reads them through an alias made HERE, on the main stream: in the
+        # backward pass the alias node - which runs on the stream of its forward, this one - is where the levels' gradients
+        # meet, so a parameter's gradient is accumulated on the main stream like everywhere else in the model (and under
+        # DistributedDataParallel the reducer's hooks see one stream). Without it autograd accumulates on whichever level
+        # stream delivers first and says so ("AccumulateGrad node's stream does not match ...").
+        from torch.nn.utils import stateless
+        alias = {k: p.view_as(p) for k, p in self.named_parameters() if p.requires_grad} if torch.is_grad_enabled() else {}
         outs = []
         for x, scale, stride, st in zip(feats, self.scales, self.strides, streams):
             if st is not main:
                 st.wait_stream(main)
                 x.record_stream(st)
-            with torch.cuda.stream(st):
+            with torch.cuda.stream(st), stateless._reparametrize_module(self, alias):
                 o = self.forward_single(x, scale, stride)
             if st is not main:
                 for t in o:

@@ -315,3 +315,25 @@ def test_wide_head_with_groupnorm_and_dcn_runs_the_hip_kernels_and_matches_the_r
     assert calls.get('gga_dense_conv3x3_bn_bwd', 0) + calls.get('gga_dense_conv3x3_levels', 0) >= 8, calls
     assert calls.get('gga_dense_wgrad3x3_planes', 0) >= 4 and calls.get('gga_gn_relu_fwd', 0) >= 4 and calls.get('gga_gn_relu_bwd', 0) >= 4, calls
     assert calls.get('gga_dcn_im2col_amax', 0) >= 2, calls
+
+
+def test_two_ranks_keep_identical_parameters():
+    """Two ranks (gloo, sharing the one GPU) step the camera-only detector under DistributedDataParallel with one stream
+    per FPN level: after three optimizer steps on different batches every rank holds bit-identical parameters (the
+    all-reduced gradients reached every parameter on every rank), different losses (different data), and autograd never
+    had to accumulate a gradient on a level stream."""
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, GGA_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(REPO, 'tests', '_ddp_pgd_worker.py')]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    lines = [l for l in out.stdout.splitlines() if l.startswith('RANK ')]
+    assert out.returncode == 0 and len(lines) == 2, (out.stdout[-2000:], out.stderr[-3000:])
+    assert all('identical_across_ranks True' in l and 'accumulate_grad_warnings 0' in l for l in lines), lines
+    losses = [float(l.split(' loss ')[1].split()[0]) for l in lines]
+    assert losses[0] != losses[1]

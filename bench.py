@@ -19,7 +19,8 @@ children's status. With fewer visible devices than ranks the ranks share devices
 functional check, reported as such in ``config.backend``).
 
 Rank 0 prints ONE JSON line; ``roofline`` is the pillar scatter (BASELINE's HBM metric),
-``mfma_roofline`` the 64 -> 64 dense 3x3 convolution (the step's dominant kernel), both timed with
+``mfma_roofline`` the 64 -> 64 dense 3x3 convolution at the head's map size (its share of the step is in the
+object), both timed with
 HIP events inside the timed steps; ``second_trunk`` is the reference's shipped model
 (configs/gga/gga_kitti_config.py: sparse-conv trunk, BASELINE config #3's per-GPU workload, bs 8)
 and ``pgd_trunk`` the camera-only retraining model (configs/gga/gga_pdg.py, BASELINE config #5, bs 12)
@@ -320,6 +321,54 @@ def scatter_roofline(model, batches, step_ms):
             'pillars': int(m)}
 
 
+def sparse_roofline(run, args, steps=4):
+    """`roofline` of the shipped config's dominant kernel - the 128 -> 128 submanifold convolutions of the sparse trunk's
+    last two stages (sp_conv_ring_kernel<4, ...>: forward and backward-data) - from a few extra steps after the timed region:
+    HIP events around exactly those launches, their sizes read off the calls. The bound is HBM: the kernel is a gather.
+    ALGORITHMIC bytes per launch = every feature row once in and once out + the rule book + the weight planes
+    (rows * (Cin + Cout) * 4 + kvol * rows * 4 + kvol * Cin * Cout * 4); `traffic` = the HBM-side bytes per launch the PMC passes
+    kept under profiles/ counted for the same kernel (not this run) - far above the algorithmic figure: a row is fetched once
+    per (output row, offset) pair that uses it (14.5 times on average), which is what there is to fix."""
+    from gga_amd import _lib
+    L = _lib.lib()
+    seen = []
+    real = L.gga_sparse_conv_apply_bn_bwd
+
+    def spy(*a):
+        if a[7] == 128 and a[8] == 128 and a[6] == 27:
+            seen.append((int(a[5]), int(a[6])))
+        return real(*a)
+    L.gga_sparse_conv_apply_bn_bwd = spy
+    try:
+        _lib.timing_begin(_lib.TIME_SPARSE_CONV, 64 * steps, _lib.timing_conv_key(128, 128, 0))
+        for i in range(steps):
+            run['runner'].step(run['batches'][i % 2], next_data=run['batches'][(i + 1) % 2])
+        ms = _lib.timing_collect(_lib.TIME_SPARSE_CONV, 64 * steps)
+    finally:
+        L.gga_sparse_conv_apply_bn_bwd = real
+    big = [(n, k) for n, k in seen]
+    if not ms or not big:
+        return None
+    rows = sum(n for n, _ in big) / len(big)
+    algo = rows * (128 + 128) * 4 + 27 * rows * 4 + 27 * 128 * 128 * 4
+    avg = sum(ms) / len(ms)
+    traffic, src = None, None
+    try:
+        pmc = json.load(open(os.path.join(REPO, 'profiles', 'r03_second_pmc.json')))
+        ks = [k for k in pmc['kernels'] if k['kernel'].startswith('sp_conv_ring_kernel<4') and 'hbm_bytes_per_launch' in k and k['avg_us'] > 500]
+        if ks and args.second_batch == 8:
+            traffic = int(sum(k['hbm_bytes_per_launch'] * k['launches_per_pass'] for k in ks) / sum(k['launches_per_pass'] for k in ks))
+            src = 'profiles/r03_second_pmc.json (separate --pmc FETCH_SIZE / WRITE_SIZE passes over tools_dev/pmc_target_second.py, not this run)'
+    except (OSError, KeyError, ValueError):
+        pass
+    gbs = algo / (avg * 1e-3) / 1e9
+    return {'bound': 'hbm', 'kernel': 'sp_conv_ring_kernel<4,2,2> (SubMConv3d 128 -> 128, 27 offsets, forward + backward-data)',
+            'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(gbs / HBM_PEAK_GBS, 4), 'traffic': traffic,
+            'traffic_source': src, 'traffic_GBps': round(traffic / (avg * 1e-3) / 1e9, 1) if traffic else None,
+            'algorithmic_bytes': int(algo), 'rows': int(rows), 'kernel_ms': round(avg, 4), 'launches_timed': len(ms),
+            'launches_per_step': len(ms) / steps, 'timed': 'in-step, HIP events on the launch stream'}
+
+
 def mfma_roofline(kernel, flops, ms_list, launches_per_step, ms_per_step):
     """16-bit matrix work issued = products x the fp32 FLOPs (three partial products on two fp16 planes, six on three
     bf16 planes); peak = dense bf16 / f16 MFMA (the same rate)."""
@@ -528,6 +577,7 @@ def main():
                     'sparse conv weight gradient (%d launches/step)' % (len(st.get(_lib.TIME_SPARSE_WGRAD, [])) // args.steps):
                         round(wg_ms, 3)},
                 'timed': 'in-step, HIP events on the launch stream'}
+            res['second_trunk']['roofline'] = sparse_roofline(sec, args)
         del sec
         gc.collect()
         torch.cuda.empty_cache()

@@ -1144,7 +1144,8 @@ __global__ __launch_bounds__(512) void sp_conv_ring_kernel(const float* __restri
                                                           int cin, int cout, int flip, float* __restrict__ Y, int64_t ys,
                                                           const uint32_t* __restrict__ amax_x,
                                                           const uint32_t* __restrict__ amax_w, double* __restrict__ stats,
-                                                          SpBnBwd bn, int64_t stats_rows, int tile_order, int64_t n_tiles) {
+                                                          SpBnBwd bn, int64_t stats_rows, int tile_order, int64_t n_tiles,
+                                                          int chunk_outer) {
     constexpr int CO = NT * 32, NW = 8, TM = 256, R = D + 1;
     constexpr int A_SLOT = TM * 128;                      // bytes: 32 fp32 channels per row
     constexpr int B_PL = CO * 64, B_SLOT = NP * B_PL;     // bytes per plane / per packed stage
@@ -1214,12 +1215,19 @@ __global__ __launch_bounds__(512) void sp_conv_ring_kernel(const float* __restri
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
     };
+    // Stage t -> (offset ordinal j, chunk ch). chunk_outer = 0: all chunks of an offset, then the next offset (a rule-book entry
+    // serves nchunks consecutive stages). chunk_outer = 1: all offsets of a chunk, then the next chunk - with spatially ordered
+    // rows the 27 offsets of a chunk re-read the same few hundred 128-byte row slices, which then stay in the L2 / L1 (the
+    // whole 512-byte rows of a tile's neighbourhood, revisited only once per offset, do not: sparse.py::ring_order).
+    auto j_of = [&](int t) { return chunk_outer ? t % ne : t / nchunks; };
+    auto ch_of = [&](int t) { return chunk_outer ? t / ne : t % nchunks; };
+    auto slot_of = [&](int t) { return chunk_outer ? t % IDXR : (t / nchunks) % IDXR; };
     // DMA instructions of `issue(t)`: 4 (A) + NBP (B) + 1 when stage t + D opens a new offset (its rule-book entries)
-    auto idx_flag = [&](int t) { return t + D < S && (t + D) % nchunks == 0; };
+    auto idx_flag = [&](int t) { return t + D < S && (chunk_outer || (t + D) % nchunks == 0); };
     const int nbp = (BPIECES - wave * 64 + 511) / 512;     // this wave's weight DMAs per stage (pieces wave * 64 + 512 e)
     auto count = [&](int t) { return 4 + nbp + (idx_flag(t) ? 1 : 0); };
     auto issue = [&](int t) {
-        const int j = t / nchunks, ch = t - j * nchunks;
+        const int j = j_of(t), ch = ch_of(t);
         const int kk = kk_of(j);
         const int slot = t % R;
         // A: instruction q fetches the 128-byte chunk rows of the wave's rows 8q .. 8q+7 WHOLE - 8 lanes per row, so a row's
@@ -1227,7 +1235,7 @@ __global__ __launch_bounds__(512) void sp_conv_ring_kernel(const float* __restri
         // asks for every line four times, and the 32 KB a stage gathers do not survive in the L1 in between). The 16-byte
         // segment a lane fetches is XOR-ed with the row number: the LDS image [32 rows][128 B] is then read conflict-free.
         const uint32_t a_dst = __builtin_amdgcn_readfirstlane(lds0 + slot * SLOT + wave * 4096);
-        const int* irow = idxring + (j % IDXR) * TM + wave * 32 + (lane >> 3);    // landed: requested >= D blocks ago
+        const int* irow = idxring + slot_of(t) * TM + wave * 32 + (lane >> 3);    // landed: requested >= D blocks ago
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int i0 = irow[8 * q];
@@ -1241,9 +1249,9 @@ __global__ __launch_bounds__(512) void sp_conv_ring_kernel(const float* __restri
         for (int e = 0; e < NBP; ++e)
             if (e < nbp) dma16(bsrc + e * 8192, b_dst + e * 8192);
         if (idx_flag(t)) {
-            const int j2 = (t + D) / nchunks;
+            const int j2 = j_of(t + D);
             const int32_t* isrc = map + (int64_t)kk_of(j2) * n_rows + prc;
-            const uint32_t i_dst = __builtin_amdgcn_readfirstlane(lds0 + R * SLOT + ((j2 % IDXR) * TM + wave * 32) * 4);
+            const uint32_t i_dst = __builtin_amdgcn_readfirstlane(lds0 + R * SLOT + (slot_of(t + D) * TM + wave * 32) * 4);
             if (h == 0) dma4(isrc, i_dst);
         }
     };
@@ -1270,10 +1278,10 @@ __global__ __launch_bounds__(512) void sp_conv_ring_kernel(const float* __restri
 
     if (S > 0) {
         // prologue: the rule-book entries of the first D stages' offsets by ordinary loads (nothing is in flight yet)
-        const int jp = (D + nchunks - 1) / nchunks;
-        for (int j = 0; j < jp && j < ne; ++j) {
-            const int v = map[(int64_t)kk_of(j) * n_rows + prc];
-            if (h == 0) idxring[(j % IDXR) * TM + wave * 32 + r] = v;
+        for (int t = 0; t < D && t < S; ++t) {
+            if (!chunk_outer && t % nchunks != 0) continue;          // the same offset as the stage before
+            const int v = map[(int64_t)kk_of(j_of(t)) * n_rows + prc];
+            if (h == 0) idxring[slot_of(t) * TM + wave * 32 + r] = v;
         }
         __syncthreads();
         for (int t = 0; t < D && t < S; ++t) issue(t);
@@ -1282,11 +1290,9 @@ __global__ __launch_bounds__(512) void sp_conv_ring_kernel(const float* __restri
             wait_vm((D == 2 && s + 1 < S) ? count(s + 1) : 0);
             __builtin_amdgcn_s_barrier();
             if (s + D < S) issue(s + D);
-            const int j = s / nchunks, ch = s - j * nchunks;
-            const int kk = kk_of(j);
-            (void)ch;
+            const int kk = kk_of(j_of(s));
             if (kvol > 32 || ((wmask >> kk) & 1u)) {
-                const int ic = idxring[(j % IDXR) * TM + wave * 32 + r];
+                const int ic = idxring[slot_of(s) * TM + wave * 32 + r];
                 // segment g = 4 sk + 2 h + e of row r sits at 16-byte position g ^ (r & 7) of the row's 128 bytes
                 const unsigned char* Ap = smem + (s % R) * SLOT + wave * 4096 + r * 128;
                 const int sw = r & 7;
@@ -1370,6 +1376,7 @@ extern "C" int gga_sparse_conv_apply_bn_bwd(const float* x, const int32_t* map, 
     static const int tile_order = getenv("GGA_SP_TILE_ORDER") ? atoi(getenv("GGA_SP_TILE_ORDER")) : 0;
     // large products of 64 / 128 output columns over whole 32-channel chunks: the LDS-DMA ring form (256-row tiles)
     static const int ring_on = getenv("GGA_SP_RING") ? atoi(getenv("GGA_SP_RING")) : 1;
+    static const int ring_order = getenv("GGA_SP_RING_ORDER") ? atoi(getenv("GGA_SP_RING_ORDER")) : 0;
     static const int64_t ring_min_rows = getenv("GGA_SP_RING_MIN_ROWS") ? atoll(getenv("GGA_SP_RING_MIN_ROWS")) : 131072;
     // (measured in the shipped config's step: 128 columns 1.19 ms against 1.52 ms per launch at 510 k rows; 64 columns 0.43 against
     // 0.40 ms - the narrow form stays with sp_conv_x9_kernel unless GGA_SP_RING=2 asks for the ring there too)
@@ -1382,7 +1389,7 @@ extern "C" int gga_sparse_conv_apply_bn_bwd(const float* x, const int32_t* map, 
             constexpr size_t lds = (size_t)(D + 1) * (256 * 128 + NP * NT * 32 * 64) + 8 * 256 * 4 + 8 * 4 + 36 * 4; \
             static bool once = false; \
             if (!once) { GGA_CHECK_HIP(hipFuncSetAttribute((const void*)sp_conv_ring_kernel<NT, NP, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "sp_conv_ring_kernel: LDS size"); once = true; } \
-            hipLaunchKernelGGL((sp_conv_ring_kernel<NT, NP, D>), rgrid, rblock, lds, stream, x, map, (const uint16_t*)split_weight, perm, rowmask, n_rows, kvol, cin, cout, flip, y, y_row_stride, amax_x, amax_weight, stats, bn, n_tiles, tile_order, rtiles); }
+            hipLaunchKernelGGL((sp_conv_ring_kernel<NT, NP, D>), rgrid, rblock, lds, stream, x, map, (const uint16_t*)split_weight, perm, rowmask, n_rows, kvol, cin, cout, flip, y, y_row_stride, amax_x, amax_weight, stats, bn, n_tiles, tile_order, rtiles, ring_order); }
         if (planes == 2) { if (cout == 128) XR_LAUNCH(4, 2, 2) else XR_LAUNCH(2, 2, 2) }
         else { if (cout == 128) XR_LAUNCH(4, 3, 1) else XR_LAUNCH(2, 3, 2) }
 #undef XR_LAUNCH

@@ -65,7 +65,7 @@ for li, (lvl, C_) in enumerate(levels):
     feats = torch.randn(nrow, C_, device=DEV)
     w = torch.randn(27, C_, C_, device=DEV) * 0.05
     print(f'=== level {li + 1}: {nrow} rows, C {C_}, grid {lvl.shape}')
-    for T in (None, 16, 8):
+    for T in ((None, 8) if os.environ.get('GGA_EXP_FEW') else (None, 8, 4)):
         if T is None:
             order = torch.arange(nrow, device=DEV)
             name = 'base  '
@@ -82,9 +82,11 @@ for li, (lvl, C_) in enumerate(levels):
         wp = _pack_weight(w, 27, C_, C_, 0, w_amax=w_amax)
         y = torch.empty(nrow, C_, device=DEV)
         pairs = float((rb.nbr >= 0).sum()) / nrow
-        for R in (0, 4096, 16384, 65536):
+        for R in ((0,) if T is None else (-1,)) if os.environ.get('GGA_EXP_FEW') else (0, -1):
             if R == 0:
                 perm = rb.perm
+            elif R == -1:
+                perm = torch.arange(nrow, device=DEV, dtype=torch.int32)          # rows as they lie (spatial order when sorted)
             else:
                 if T is None:
                     continue

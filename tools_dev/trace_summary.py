@@ -13,8 +13,10 @@ rows = list(csv.DictReader(open(f)))
 # [end of the optimizer of step N - steps, end of the optimizer of step N]. (Voxelizer launches are no step marker:
 # with the point-only front prefetched on a side stream the next step's voxelization runs inside the current step.)
 csv.field_size_limit(1 << 30)
-opt = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp'])) for r in rows
-             if 'FusedOptimizerTensorListMetadata' in r['Kernel_Name'] or 'multi_tensor_apply' in r['Kernel_Name'])
+# the fused optimizer's kernels where there are any (gradient clipping launches multi_tensor_apply kernels of its own, a second
+# cluster per step), any multi_tensor_apply kernel otherwise (SGD)
+fused = [r for r in rows if 'FusedOptim' in r['Kernel_Name']]
+opt = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp'])) for r in (fused or [r for r in rows if 'multi_tensor_apply' in r['Kernel_Name']]))
 ends = []
 for i, (st, en) in enumerate(opt):
     if i + 1 == len(opt) or opt[i + 1][0] - en > 2_000_000:      # > 2 ms to the next optimizer kernel: last one of its step

@@ -323,7 +323,7 @@ def scatter_roofline(model, batches, step_ms):
 
 def sparse_roofline(run, args, steps=4):
     """`roofline` of the shipped config's dominant kernel - the 128 -> 128 submanifold convolutions of the sparse trunk's
-    last two stages (sp_conv_ring_kernel<4, ...>: forward and backward-data) - from a few extra steps after the timed region:
+    last two stages (sp_conv_x9_kernel<4, ...>: forward and backward-data) - from a few extra steps after the timed region:
     HIP events around exactly those launches, their sizes read off the calls. The bound is HBM: the kernel is a gather.
     ALGORITHMIC bytes per launch = every feature row once in and once out + the rule book + the weight planes
     (rows * (Cin + Cout) * 4 + kvol * rows * 4 + kvol * Cin * Cout * 4); `traffic` = the HBM-side bytes per launch the PMC passes
@@ -355,14 +355,15 @@ def sparse_roofline(run, args, steps=4):
     traffic, src = None, None
     try:
         pmc = json.load(open(os.path.join(REPO, 'profiles', 'r03_second_pmc.json')))
-        ks = [k for k in pmc['kernels'] if k['kernel'].startswith('sp_conv_ring_kernel<4') and 'hbm_bytes_per_launch' in k and k['avg_us'] > 500]
+        ks = [k for k in pmc['kernels'] if k['kernel'].startswith(('sp_conv_x9_kernel<4', 'sp_conv_ring_kernel<4')) and 'hbm_bytes_per_launch' in k
+              and k['avg_us'] > 500]
         if ks and args.second_batch == 8:
             traffic = int(sum(k['hbm_bytes_per_launch'] * k['launches_per_pass'] for k in ks) / sum(k['launches_per_pass'] for k in ks))
             src = 'profiles/r03_second_pmc.json (separate --pmc FETCH_SIZE / WRITE_SIZE passes over tools_dev/pmc_target_second.py, not this run)'
     except (OSError, KeyError, ValueError):
         pass
     gbs = algo / (avg * 1e-3) / 1e9
-    return {'bound': 'hbm', 'kernel': 'sp_conv_ring_kernel<4,2,2> (SubMConv3d 128 -> 128, 27 offsets, forward + backward-data)',
+    return {'bound': 'hbm', 'kernel': 'sp_conv_x9_kernel<4,true,2> (SubMConv3d 128 -> 128, 27 offsets, forward + backward-data)',
             'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(gbs / HBM_PEAK_GBS, 4), 'traffic': traffic,
             'traffic_source': src, 'traffic_GBps': round(traffic / (avg * 1e-3) / 1e9, 1) if traffic else None,
             'algorithmic_bytes': int(algo), 'rows': int(rows), 'kernel_ms': round(avg, 4), 'launches_timed': len(ms),

@@ -1375,11 +1375,12 @@ extern "C" int gga_sparse_conv_apply_bn_bwd(const float* x, const int32_t* map, 
     const int64_t n_tiles = (n_rows + X9_TM - 1) / X9_TM;
     static const int tile_order = getenv("GGA_SP_TILE_ORDER") ? atoi(getenv("GGA_SP_TILE_ORDER")) : 0;
     // large products of 64 / 128 output columns over whole 32-channel chunks: the LDS-DMA ring form (256-row tiles)
-    static const int ring_on = getenv("GGA_SP_RING") ? atoi(getenv("GGA_SP_RING")) : 1;
+    // OFF by default: measured inside the shipped config's step (rocprofv3 kernel trace, bs 8) the ring form does not pay -
+    // 17 launches x 834 us + 4 x 152 us = 14.8 ms against 21 x 689 us = 14.5 ms of sp_conv_x9_kernel (stand-alone, the 510 k-row
+    // 128 -> 128 launch: 1.29 - 1.37 ms against 1.40 - 1.46). GGA_SP_RING=1 selects it for 128 columns, 2 for 64 as well.
+    static const int ring_on = getenv("GGA_SP_RING") ? atoi(getenv("GGA_SP_RING")) : 0;
     static const int ring_order = getenv("GGA_SP_RING_ORDER") ? atoi(getenv("GGA_SP_RING_ORDER")) : 0;
     static const int64_t ring_min_rows = getenv("GGA_SP_RING_MIN_ROWS") ? atoll(getenv("GGA_SP_RING_MIN_ROWS")) : 131072;
-    // (measured in the shipped config's step: 128 columns 1.19 ms against 1.52 ms per launch at 510 k rows; 64 columns 0.43 against
-    // 0.40 ms - the narrow form stays with sp_conv_x9_kernel unless GGA_SP_RING=2 asks for the ring there too)
     if (ring_on && cin % MF_TK == 0 && (cout == 128 || (cout == 64 && ring_on == 2)) && n_rows >= ring_min_rows) {
         const int64_t rtiles = (n_rows + 255) / 256;
         const dim3 rgrid((unsigned)(tile_order == 1 ? 8 * ((rtiles + 7) / 8) : rtiles)), rblock(512);

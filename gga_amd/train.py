@@ -193,6 +193,9 @@ def build_ddp(model, device, find_unused_parameters=False):
     return DDP(model, broadcast_buffers=False, find_unused_parameters=find_unused_parameters)
 
 
+PREFETCH_FIRST = os.environ.get('GGA_PREFETCH_FIRST', '1') == '1'
+
+
 class Runner:
     """Iteration loop of the train step: schedule -> train_step -> backward (DDP all-reduce
     overlaps it) -> clip_grad_norm_ -> AdamW.
@@ -251,7 +254,10 @@ class Runner:
         if pts is None or self._prepared_for(data) is not None:
             return
         if self._side is None:
-            self._side = torch.cuda.Stream(device=self.device)
+            # high priority: the front is a handful of small kernels whose counts the host waits for - behind the main stream's
+            # queued backward kernels they are scheduled late and the host idles (measured on the sparse trunk: 41 ms of the 62 ms
+            # step spent in those waits; tools_dev/host_profile.py second)
+            self._side = torch.cuda.Stream(device=self.device, priority=-1)
         # the points may have been uploaded (non_blocking) on the main stream just before this call
         self._side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(self._side):
@@ -291,6 +297,12 @@ class Runner:
         hit = self._prepared_for(data)
         stale = [(p, e) for k, (p, e, d, _) in self._prepared.items() if d is not data]
         self._prepared.clear()                      # a prefetched batch that is not stepped next is dropped, not kept
+        if next_data is not None and PREFETCH_FIRST:
+            # the NEXT batch's point-only front goes to the device BEFORE this step's kernels are queued: its few small kernels
+            # then run at once and the host's reads of their counts return in a millisecond. Queued after the step (as in
+            # rounds 1-2) they sat behind the main stream's backlog and the host idled in those reads for most of the step
+            # (tools_dev/host_profile.py second: 41 of 65 ms), leaving the device without work at the start of the next one.
+            self.prefetch(next_data)
         self._retired = [(p, e) for p, e in self._retired + stale if not e.query()]
         prep = None
         if hit is not None:
@@ -321,7 +333,7 @@ class Runner:
             done = torch.cuda.Event()
             done.record(torch.cuda.current_stream(self.device))
             self._retired.append((prep, done))
-        if next_data is not None:
+        if next_data is not None and not PREFETCH_FIRST:
             self.prefetch(next_data)
         return out
 

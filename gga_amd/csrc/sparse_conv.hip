@@ -929,8 +929,11 @@ __device__ __forceinline__ void x9_epilogue(mf_v16 (&acc)[NT], const int pr, con
     }
 }
 
+// (two waves per SIMD in the launch bounds: with the 512-register budget of ONE wave per SIMD the compiler gives the MFMAs
+// accumulator-file destinations and then copies all 64 accumulators to and from the vector file around every stage -
+// 128 v_accvgpr_read + 192 v_accvgpr_write in the stage loop of the 128-column form; with <= 256 registers it keeps them in place)
 template <int NT, bool VEC, int NP>
-__global__ __launch_bounds__(64 * X9_NW) void sp_conv_x9_kernel(const float* __restrict__ X, const int32_t* __restrict__ map,
+__global__ __launch_bounds__(64 * X9_NW, 2) void sp_conv_x9_kernel(const float* __restrict__ X, const int32_t* __restrict__ map,
                                                         const uint16_t* __restrict__ Wp,
                                                         const int32_t* __restrict__ perm,
                                                         const uint32_t* __restrict__ rowmask, int64_t n_rows,
@@ -1068,7 +1071,11 @@ __global__ __launch_bounds__(64 * X9_NW) void sp_conv_x9_kernel(const float* __r
             load_a(valid1 ? ch1 : ch, ia);
             load_b(valid1 ? k1 : k, valid1 ? ch1 : ch);
             const int kk = flip ? (kvol - 1 - k) : k;
+#ifdef X9_NO_WAVE_SKIP
+            {
+#else
             if (kvol > 32 || ((wmask >> kk) & 1u)) {
+#endif
                 Frag a0[3], a1[3];
                 const int c = ch * MF_TK + 8 * h;
                 split8(rc00, rc01, ic >= 0, c, a0[0], a0[1], a0[2]);

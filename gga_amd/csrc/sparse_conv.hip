@@ -21,6 +21,7 @@
 #include <stdlib.h>
 
 #include "gga_common.h"
+#include <type_traits>
 #include <hip/hip_fp16.h>
 
 #define SP_EMPTY 0xFFFFFFFFFFFFFFFFull
@@ -838,26 +839,35 @@ struct SpBnBwd {
 // the optional BatchNorm-backward masking (SpBnBwd) and the per-channel sums of the tile (`stats`, row `tile`).
 // D layout of 32x32x16: register v of lane l holds row (v/4)*8 + (l/32)*4 + v%4, column l%32; the row -> output row table
 // goes through LDS (each lane knows only its own row). `scratch`: LDS no wave reads any more, >= max(NW * 128, NW * 8 * CO) bytes.
-template <int NT, int NP, int NW>
-__device__ __forceinline__ void x9_epilogue(mf_v16 (&acc)[NT], const int pr, const int wave, const int r, const int h,
-                                            const int tid, const int cout, float* __restrict__ Y, const int64_t ys,
-                                            double* __restrict__ stats, const int64_t tile, const SpBnBwd& bn,
-                                            unsigned char* scratch, const int sbx, const int sbw) {
+// RB: 32-row blocks per wave (accumulators accs[rb], output rows prs[rb]); block rb of wave w is row block w * RB + rb of the tile.
+template <int NT, int NP, int NW, int RB>
+__device__ __forceinline__ void x9_epilogue_rb(mf_v16 (&accs)[RB][NT], const int (&prs)[RB], const int wave, const int r, const int h,
+                                               const int tid, const int cout, float* __restrict__ Y, const int64_t ys,
+                                               double* __restrict__ stats, const int64_t tile, const SpBnBwd& bn,
+                                               unsigned char* scratch, const int sbx, const int sbw) {
     constexpr int CO = NT * 32;
     if (NP == 2) {
         const float dx = h2_descale(sbx), dw = h2_descale(sbw);
 #pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[t][i] = acc[t][i] * dx * dw;
+            for (int i = 0; i < 16; ++i) accs[rb][t][i] = accs[rb][t][i] * dx * dw;
     }
     __syncthreads();
     int* prow = reinterpret_cast<int*>(scratch);
-    if (h == 0) prow[wave * 32 + r] = pr;
+    if (h == 0)
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) prow[(wave * RB + rb) * 32 + r] = prs[rb];
     __syncthreads();
     float s1[NT], s2[NT];                                  // per-column sums of the lane's 16 rows (stats)
 #pragma unroll
     for (int t = 0; t < NT; ++t) { s1[t] = 0.0f; s2[t] = 0.0f; }
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+    mf_v16 (&acc)[NT] = accs[rb];
+    const int vw = wave * RB + rb;
     if (bn.y) {                                            // see SpBnBwd
         float bsc[NT], bsh[NT], bmu[NT], biv[NT];
 #pragma unroll
@@ -874,7 +884,7 @@ __device__ __forceinline__ void x9_epilogue(mf_v16 (&acc)[NT], const int pr, con
 #pragma unroll
             for (int j = 0; j < VB; ++j) {
                 const int v = v0 + j;
-                pos[j] = prow[wave * 32 + (v >> 2) * 8 + h * 4 + (v & 3)];
+                pos[j] = prow[vw * 32 + (v >> 2) * 8 + h * 4 + (v & 3)];
                 const float* src = bn.y + (int64_t)(pos[j] >= 0 ? pos[j] : 0) * bn.ystride;
 #pragma unroll
                 for (int t = 0; t < NT; ++t) yv[j][t] = src[t * 32 + r < cout ? t * 32 + r : 0];
@@ -895,7 +905,7 @@ __device__ __forceinline__ void x9_epilogue(mf_v16 (&acc)[NT], const int pr, con
     } else
 #pragma unroll
     for (int v = 0; v < 16; ++v) {
-        const int lr = wave * 32 + (v >> 2) * 8 + h * 4 + (v & 3);
+        const int lr = vw * 32 + (v >> 2) * 8 + h * 4 + (v & 3);
         const int po = prow[lr];
         if (po < 0) continue;
 #pragma unroll
@@ -904,6 +914,7 @@ __device__ __forceinline__ void x9_epilogue(mf_v16 (&acc)[NT], const int pr, con
             if (o < cout) Y[(int64_t)po * ys + o] = acc[t][v];
             s1[t] += acc[t][v]; s2[t] += acc[t][v] * acc[t][v];
         }
+    }
     }
     if (stats) {
         // per-channel sum and sum of squares of the workgroup's rows (the batch statistics of the BatchNorm that follows,
@@ -927,6 +938,15 @@ __device__ __forceinline__ void x9_epilogue(mf_v16 (&acc)[NT], const int pr, con
             }
         }
     }
+}
+
+template <int NT, int NP, int NW>
+__device__ __forceinline__ void x9_epilogue(mf_v16 (&acc)[NT], const int pr, const int wave, const int r, const int h,
+                                            const int tid, const int cout, float* __restrict__ Y, const int64_t ys,
+                                            double* __restrict__ stats, const int64_t tile, const SpBnBwd& bn,
+                                            unsigned char* scratch, const int sbx, const int sbw) {
+    const int prs[1] = {pr};
+    x9_epilogue_rb<NT, NP, NW, 1>(reinterpret_cast<mf_v16 (&)[1][NT]>(acc), prs, wave, r, h, tid, cout, Y, ys, stats, tile, bn, scratch, sbx, sbw);
 }
 
 // (two waves per SIMD in the launch bounds: with the 512-register budget of ONE wave per SIMD the compiler gives the MFMAs
@@ -1335,6 +1355,322 @@ __global__ __launch_bounds__(512) void sp_conv_ring_kernel(const float* __restri
         if (extra < stats_rows && tid < 2 * cout) stats[extra * 2 * cout + tid] = 0.0;
     }
     x9_epilogue<NT, NP, NW>(acc, pr, wave, r, h, tid, cout, Y, ys, stats, tile, bn, smem, sbx, sbw);
+}
+
+// ------------------------------------------------------------------------------ the same product, halo form (SubM)
+// What bounds the two forms above at the 128-channel level of the shipped config is not the matrix pipe:
+//   bytes   sp_conv_x9_kernel moves 9.2 GB L2 -> CU per launch (every row 18 x its 512 bytes, a 16 KB weight stage per 128
+//           rows and stage): 28 GB/s per CU, what 64 KB in flight per CU get from beyond the L2;
+//   issue   every gathered fp32 element is split into its two fp16 planes by the lane that feeds it to the MFMA - ~12 vector
+//           instructions per pair of elements, 27 times per element: ~900 issue cycles per wave and stage next to 768 cycles
+//           of matrix work.
+// This form removes both. The rows are tiled in SPATIAL order (256 consecutive rows of a Z-ordered level, sparse.py::_Halo),
+// so the 27 x 256 neighbours of a tile are only ~1.4 x 256 DISTINCT rows (its halo). Per 32-channel chunk the halo is
+// fetched ONCE into an LDS image (512 rows x 128 B, LDS-DMA, whole 128-byte lines), split ONCE, in place, into the two fp16
+// planes (the same 128 bytes per row), and all 27 offsets read their A fragments from the image - ready to use - through a
+// per-tile local rule book (u16 [kvol][256] = position in the halo list, 0xFFFF = no neighbour; in LDS for the whole tile).
+//   stages  chunk-outer: stage s = (chunk s / kvol, offset s % kvol); weights by LDS-DMA into a ring of 3 slots, 2 stages
+//           ahead (the packed stage is its own LDS image, sp_pack_weight_split_kernel), counted s_waitcnt vmcnt(N) behind a
+//           raw s_barrier as in sp_conv_ring_kernel;
+//   image   row L at byte L * 128 = [plane 0: 32 ch fp16 | plane 1]; its eight 16-byte segments (plane p, channels 8g..8g+7 =
+//           segment 4p + g) XOR-ed with (L >> 1) & 7: 16 lanes reading one segment of rows L .. L+15 hit 16 bank groups.
+//           Row 512 is all zero: what a lane without a neighbour reads. The wave that requested 8 rows splits them (the 8
+//           lanes of a row read its fp32 segments in one instruction and write the planes with the next ones);
+//   switch  the image is single: at a chunk boundary the waves request the next chunk's halo after the barrier, wait, split
+//           and meet again (the weight ring keeps running ahead meanwhile) - ~3 us per chunk next to ~20 us of its stages;
+//   spill   halo positions >= 512 (a tile whose neighbourhood is wider than the image) are read from global memory and split
+//           by the lane that needs them, through the tile's halo list - slow, correct, rare;
+//   skip    a wave whose 32 rows have no neighbour at an offset skips that stage's MFMAs (ballot of its lanes).
+// Two fp16 planes only (the three-plane arithmetic stays on sp_conv_x9_kernel). D layout and epilogue (BatchNorm sums /
+// BatchNorm-backward masking): those of sp_conv_x9_kernel; a row's sum runs over the same partial products, chunk-outer
+// instead of offset-outer, so the two forms differ by fp32 summation order only.
+#define XH_TM 256
+#define XH_HCAP 512
+#ifdef XH_TIMING                                  /* experiment builds (tools_dev/exp_libs): cycles per phase, summed over the tiles */
+__device__ unsigned long long xh_times[8];
+extern "C" int gga_debug_halo_times(unsigned long long* out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(xh_times), sizeof(xh_times)) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; if (hipMemcpyToSymbol(HIP_SYMBOL(xh_times), z, sizeof(z)) != hipSuccess) return 1; }
+    return 0;
+}
+#define XH_T(i) { const unsigned long long now_ = wall_clock64(); tacc_[i] += now_ - tlast_; tlast_ = now_; }
+#else
+#define XH_T(i)
+#endif
+#define XH_KMAX 27
+template <int NT>
+__global__ __launch_bounds__(256) void sp_conv_halo_kernel(const float* __restrict__ X, const uint16_t* __restrict__ Wp,
+                                                          const int32_t* __restrict__ tperm, const int32_t* __restrict__ hoff,
+                                                          const int32_t* __restrict__ hlist, const uint16_t* __restrict__ lmap,
+                                                          int64_t n_tiles, int kvol, int cin, int cout, int flip,
+                                                          float* __restrict__ Y, int64_t ys, const uint32_t* __restrict__ amax_x,
+                                                          const uint32_t* __restrict__ amax_w, double* __restrict__ stats,
+                                                          SpBnBwd bn, int64_t stats_rows) {
+    constexpr int CO = NT * 32, NW = 4, RB = 2, THREADS = 64 * NW, TM = XH_TM, D = 3, R = D + 1, HCAP = XH_HCAP, NP = 2;
+    constexpr int A_IMG = (HCAP + 1) * 128;               // bytes of the halo image (+ the zero row)
+    constexpr int B_PL = CO * 64, B_SLOT = NP * B_PL;     // bytes per plane / per packed weight stage
+    constexpr int BPIECES = B_SLOT / 16;
+    constexpr int NBP = BPIECES / THREADS;
+    static_assert(BPIECES % THREADS == 0, "every thread moves NBP pieces of a weight stage");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];       // ALL of the kernel's LDS (one object)
+    unsigned char* const Bring = smem + A_IMG;
+    uint16_t* const lm = reinterpret_cast<uint16_t*>(Bring + R * B_SLOT);      // [XH_KMAX][TM]
+    int* const hl = reinterpret_cast<int*>(lm + XH_KMAX * TM);                 // [HCAP]
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+
+    const int sbx = h2_scale_exp(*amax_x), sbw = h2_scale_exp(*amax_w);
+    const float xscale = h2_scale(sbx);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int64_t tile = blockIdx.x;
+    int pr[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) pr[rb] = tperm[tile * TM + (wave * RB + rb) * 32 + r];
+    const int h0 = hoff[tile];
+    const int hn = hoff[tile + 1] - h0;                   // >= 1: a row is its own centre neighbour
+#ifdef XH_TIMING
+    unsigned long long tlast_ = wall_clock64(), tacc_[6] = {0, 0, 0, 0, 0, 0};
+#endif
+    // prologue (ordinary loads, nothing else in flight): the tile's local rule book and halo list into LDS, the zero row
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(lmap + tile * (int64_t)kvol * TM);
+        const int pieces = kvol * TM / 8;
+        for (int i = tid; i < pieces; i += THREADS) reinterpret_cast<uint4*>(lm)[i] = src[i];
+        for (int i = tid; i < HCAP; i += THREADS) hl[i] = hlist[h0 + (i < hn ? i : hn - 1)];
+        if (tid < 32) reinterpret_cast<uint32_t*>(smem + HCAP * 128)[tid] = 0u;
+    }
+    __syncthreads();
+    const int nchunks = cin / MF_TK;
+    const int S = nchunks * kvol;
+    mf_v16 acc[RB][NT];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[rb][t][i] = 0.0f;
+
+    auto dma16 = [&](const void* src, uint32_t dst) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+    };
+    // halo DMA q of chunk c: rows 8q .. 8q+7 of the image, 8 lanes per row; lane -> position lane & 7 of its row, which
+    // receives fp32 segment (lane & 7) ^ ((row >> 1) & 7)
+    const int nq = ((hn < HCAP ? hn : HCAP) + 7) >> 3;      // instructions that carry halo rows (the rest of the image is never read)
+    auto issue_a = [&](int c, int q) {
+        const int j = 8 * q + (lane >> 3);
+        dma16(X + (int64_t)hl[j] * cin + c * MF_TK + 4 * ((lane & 7) ^ ((j >> 1) & 7)), __builtin_amdgcn_readfirstlane(lds0 + q * 1024));
+    };
+    // in place: fp32 segment f (channels 4f .. 4f+3) of row j -> halves (f & 1) of plane segments f >> 1 and 4 + (f >> 1)
+    auto split_rows = [&](int q) {
+        const int j = 8 * q + (lane >> 3), sw = (j >> 1) & 7, f = (lane & 7) ^ sw;
+        unsigned char* row = smem + j * 128;
+        const float4 v = *reinterpret_cast<const float4*>(row + ((lane & 7) << 4));
+        uint2 p0, p1;
+        h2_split2(v.x * xscale, v.y * xscale, p0.x, p1.x);
+        h2_split2(v.z * xscale, v.w * xscale, p0.y, p1.y);
+        *reinterpret_cast<uint2*>(row + ((((f >> 1)) ^ sw) << 4) + ((f & 1) << 3)) = p0;
+        *reinterpret_cast<uint2*>(row + (((4 + (f >> 1)) ^ sw) << 4) + ((f & 1) << 3)) = p1;
+    };
+    constexpr int nbp = NBP;                              // a wave's weight DMAs per stage (pieces tid + THREADS e)
+    int tb = 0, cb = 0, kb = 0;                            // next weight stage to request: number, chunk, offset
+    const unsigned char* bsrc = nullptr;
+    uint32_t b_dst = 0;
+    auto issue_b_begin = [&]() {
+        bsrc = reinterpret_cast<const unsigned char*>(Wp) + ((int64_t)kb * nchunks + cb) * B_SLOT + (int64_t)tid * 16;
+        b_dst = __builtin_amdgcn_readfirstlane(lds0 + A_IMG + (tb & (R - 1)) * B_SLOT + wave * 1024);
+        ++tb;
+        if (++kb == kvol) { kb = 0; ++cb; }
+    };
+    auto issue_b_piece = [&](int e) { dma16(bsrc + e * (THREADS * 16), __builtin_amdgcn_readfirstlane(b_dst + e * (THREADS * 16))); };
+    auto issue_b = [&]() {
+        issue_b_begin();
+#pragma unroll
+        for (int e = 0; e < NBP; ++e) issue_b_piece(e);
+    };
+    static_assert(R == 4, "ring slot = stage & 3");
+    auto wait_vm = [&](int n) {
+        switch (n) {
+            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        }
+    };
+    static_assert(NBP == 2 || NBP == 4, "wait_vm covers 0 or NBP outstanding DMAs");
+    union Frag { mf_v8h v; uint32_t u[4]; uint4 q; };
+    struct Half { Frag a[RB][2]; mf_v8h b[NT][NP]; };     // operands of one 16-channel k-step: A row blocks x planes, B tiles x planes
+    const int swz = (r >> 2) & 3;
+    auto load_b = [&](Half& f, int s, int sk) {
+        const unsigned char* Bp = Bring + (s & (R - 1)) * B_SLOT + r * 64 + (((sk * 2 + h) ^ swz) * 16);
+#pragma unroll
+        for (int p = NP - 1; p >= 0; --p)                 // plane 1 first: the first products are a0 x b1
+#pragma unroll
+            for (int t = 0; t < NT; ++t) f.b[t][p] = *reinterpret_cast<const mf_v8h*>(Bp + p * B_PL + t * 32 * 64);
+    };
+#define XH_MH(PA, PB) _Pragma("unroll") for (int rb = 0; rb < RB; ++rb) _Pragma("unroll") for (int t = 0; t < NT; ++t) acc[rb][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[rb][PA].v, f.b[t][PB], acc[rb][t], 0, 0, 0);
+    auto mma = [&](const Half& f) { XH_MH(0, 1) XH_MH(1, 0) XH_MH(0, 0) };
+    auto mma_head = [&](const Half& f) { XH_MH(0, 1) XH_MH(1, 0) };
+#undef XH_MH
+    // the last product (a0 x b0) of a k-step in NBP parts: dealt between the weight DMAs of the next stage
+    static_assert(RB * NT % NBP == 0, "whole parts");
+    auto mma_tail = [&](const Half& f, int e) {
+#pragma unroll
+        for (int i = e * (RB * NT / NBP); i < (e + 1) * (RB * NT / NBP); ++i)
+            acc[i / NT][i % NT] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[i / NT][0].v, f.b[i % NT][0], acc[i / NT][i % NT], 0, 0, 0);
+    };
+    auto entry = [&](int k, int rb) { return (int)lm[(flip ? (kvol - 1 - k) : k) * TM + (wave * RB + rb) * 32 + r]; };
+
+    // Stage s reads weight slot s & 3. At its top every wave waits for ITS share of the weights of stage s + 1 (only those of
+    // stage s + 2 stay in flight), so behind the barrier stages s and s + 1 are complete in LDS and slot (s - 1) & 3 is free
+    // for stage s + 3. One wave per SIMD has nobody to hide its LDS latency behind, so the fragments of a k-step are requested
+    // one k-step ahead (the second half of stage s fetches the first half of stage s + 1) and the rule-book entries one stage
+    // ahead, and the stage body is straight-line code: a request inside a branch makes the compiler drain the LDS queue at
+    // the join. That is why the lanes whose neighbour lies beyond the image (FAR) get a loop of their own - taken by a tile
+    // only if its halo is longer than the image - and why no wave skips an offset its rows do not use.
+    for (int t = 0; t < D && t < S; ++t) issue_b();
+    XH_T(0)
+    auto stages = [&](auto far_tag) {
+        constexpr bool FAR = decltype(far_tag)::value;
+        // A fragments of k-step sk for the lane's neighbour at image position L (0xFFFF: none -> the zero row)
+        auto load_a = [&](Frag (&fa)[2], int L, int sk, int c) {
+            const bool far = FAR && L != 0xFFFF && L >= HCAP;
+#ifdef XH_ABL_NOA                               /* ablation builds: every lane reads the zero row (no bank conflicts) */
+            const int Lc = HCAP + 0 * L;
+#else
+            const int Lc = L < HCAP ? L : HCAP;
+#endif
+            const unsigned char* Ap = smem + Lc * 128;
+            const int sw = (Lc >> 1) & 7;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) fa[p].q = *reinterpret_cast<const uint4*>(Ap + (((4 * p + 2 * sk + h) ^ sw) << 4));
+            if (FAR && __builtin_amdgcn_ballot_w64(far) != 0) {   // beyond the image: from global memory through the halo list
+                if (far) {
+                    const float* row = X + (int64_t)hlist[h0 + L] * cin + c * MF_TK + 8 * h + 16 * sk;
+                    const float4 lo = *reinterpret_cast<const float4*>(row), hi = *reinterpret_cast<const float4*>(row + 4);
+                    h2_split2(lo.x * xscale, lo.y * xscale, fa[0].u[0], fa[1].u[0]);
+                    h2_split2(lo.z * xscale, lo.w * xscale, fa[0].u[1], fa[1].u[1]);
+                    h2_split2(hi.x * xscale, hi.y * xscale, fa[0].u[2], fa[1].u[2]);
+                    h2_split2(hi.z * xscale, hi.w * xscale, fa[0].u[3], fa[1].u[3]);
+                }
+            }
+        };
+        auto load_as = [&](Half& f, const int (&Ls)[RB], int sk, int c) {
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) load_a(f.a[rb], Ls[rb], sk, c);
+        };
+        Half f0, f1;
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) f1.a[rb][0].q = make_uint4(0, 0, 0, 0);       // (the tail of "stage -1" adds 0 x 0)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) f1.b[t][0] = __builtin_bit_cast(mf_v8h, make_uint4(0, 0, 0, 0));
+        int c = 0, k = 0, L[RB], Ln[RB];
+        for (int s = 0; s < S; ++s) {
+            wait_vm(s + 2 < S ? nbp : 0);
+            XH_T(1)
+            __builtin_amdgcn_s_barrier();
+            XH_T(2)
+            {                                             // the weights of stage s + 3, under the last MFMAs of stage s - 1
+                const bool more = k != 0 && tb < S;       // (at a chunk boundary they follow the image)
+                if (more) issue_b_begin();
+#pragma unroll
+                for (int e = 0; e < NBP; ++e) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    mma_tail(f1, e);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (more) issue_b_piece(e);
+                }
+            }
+            if (k == 0) {                                 // chunk boundary: everyone is done with the image
+                for (int q = wave; q < nq; q += NW) issue_a(c, q);
+                const bool more = tb < S;
+                if (more) issue_b();
+                wait_vm(more ? nbp : 0);                  // in order: the image (and stage s + 2's weights) have landed
+                for (int q = wave; q < nq; q += NW) split_rows(q);
+                __syncthreads();
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) L[rb] = entry(0, rb);
+                load_as(f0, L, 0, c); load_b(f0, s, 0);
+                XH_T(3)
+            }
+            const int kn = k + 1 < kvol ? k + 1 : k;      // (at the end of a chunk: fetched for nothing, the boundary reloads)
+            // one scheduling region per k-step: the MFMAs of the fragments at hand with the LDS reads of the next ones dealt
+            // in between (2 MFMAs, 1 read); left alone the scheduler sinks the reads to just before their use
+            constexpr int NRD = 2 * RB + NT * NP;         // ds_read_b128 of one k-step's fragments
+            constexpr int NM = RB * 3 * NT;               // MFMAs of one k-step
+            constexpr int NG = NT == 4 ? 12 : 4;          // groups of NM / NG MFMAs and NRD / NG reads
+            static_assert(NM % NG == 0 && NRD % NG == 0, "whole groups");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) Ln[rb] = entry(kn, rb);
+            load_as(f1, L, 1, c); load_b(f1, s, 1);
+            mma(f0);
+            __builtin_amdgcn_sched_group_barrier(0x100, RB, 0);
+#pragma unroll
+            for (int i = 0; i < NG; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, NM / NG, 0); __builtin_amdgcn_sched_group_barrier(0x100, NRD / NG, 0); }
+            __builtin_amdgcn_sched_barrier(0);
+            load_as(f0, Ln, 0, c); load_b(f0, s + 1, 0);
+            mma_head(f1);                                 // (its last third follows the next barrier)
+            constexpr int NH = NM * 2 / 3, NG2 = NT == 4 ? 4 : 4;
+            static_assert(NH % NG2 == 0 && NRD % NG2 == 0, "whole groups");
+#pragma unroll
+            for (int i = 0; i < NG2; ++i) { __builtin_amdgcn_sched_group_barrier(0x100, NRD / NG2, 0); __builtin_amdgcn_sched_group_barrier(0x008, NH / NG2, 0); }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) L[rb] = Ln[rb];
+            if (++k == kvol) { k = 0; ++c; }
+            XH_T(4)
+        }
+#pragma unroll
+        for (int e = 0; e < NBP; ++e) mma_tail(f1, e);
+    };
+    if (hn > HCAP) stages(std::true_type()); else stages(std::false_type());
+    // stats rows of the 128-row tiling this tile does not write (the caller sized `stats` for gga_sparse_conv_apply_tiles)
+    if (stats) {
+        const int64_t extra = n_tiles + tile;
+        if (extra < stats_rows && tid < 2 * cout) stats[extra * 2 * cout + tid] = 0.0;
+    }
+    x9_epilogue_rb<NT, NP, NW, RB>(acc, pr, wave, r, h, tid, cout, Y, ys, stats, tile, bn, smem, sbx, sbw);
+    XH_T(5)
+#ifdef XH_TIMING
+    if (tid == 0) for (int i = 0; i < 6; ++i) atomicAdd(&xh_times[i], tacc_[i]);
+#endif
+}
+
+extern "C" int64_t gga_sparse_halo_tile_rows(void) { return XH_TM; }
+
+extern "C" int gga_sparse_conv_apply_halo(const float* x, const void* split_weight, const int32_t* tile_rows,
+                                          const int32_t* halo_offsets, const int32_t* halo_rows, const uint16_t* local_map,
+                                          int64_t n_rows, int64_t n_tiles, int kvol, int cin, int cout, int flip, float* y,
+                                          int64_t y_row_stride, int planes, const uint32_t* amax_x, const uint32_t* amax_weight,
+                                          double* stats, const float* bn_x, int64_t bn_x_row_stride, const float* bn_gamma,
+                                          const float* bn_beta, const float* bn_mean, const float* bn_invstd, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    GGA_REQUIRE(x && split_weight && tile_rows && halo_offsets && halo_rows && local_map && y, "gga_sparse_conv_apply_halo: null pointer argument");
+    GGA_REQUIRE(planes == 2 && amax_x && amax_weight, "gga_sparse_conv_apply_halo: two fp16 planes only (planes == 2, with the operands' absmax bits)");
+    GGA_REQUIRE(n_rows >= 1 && n_tiles == (n_rows + XH_TM - 1) / XH_TM && kvol >= 8 && kvol <= XH_KMAX && cin >= 32 && cin % MF_TK == 0 &&
+                    (cout == 64 || cout == 128) && y_row_stride >= cout,
+                "gga_sparse_conv_apply_halo: bad sizes (rows=%lld tiles=%lld kvol=%d cin=%d cout=%d; 8 <= kvol <= 27, cin %% 32 == 0, cout 64 or 128)",
+                (long long)n_rows, (long long)n_tiles, kvol, cin, cout);
+    GGA_REQUIRE(!bn_x || (stats && bn_mean && bn_invstd && bn_x_row_stride >= cout),
+                "gga_sparse_conv_apply_halo: the BatchNorm epilogue needs stats, the saved mean / invstd and a row stride >= cout");
+    SpBnBwd bn;
+    bn.y = bn_x; bn.gamma = bn_gamma; bn.beta = bn_beta; bn.mean = bn_mean; bn.invstd = bn_invstd; bn.ystride = bn_x_row_stride;
+    const int64_t stats_rows = (n_rows + X9_TM - 1) / X9_TM;
+    const dim3 grid((unsigned)n_tiles), block(256);
+    hipEvent_t* tev = gga_timing_acquire(GGA_TIME_SPARSE_CONV, GGA_TIMING_CONV_KEY(cin, cout, 0));
+    GGA_TIME_START(tev, stream);
+#define XH_LAUNCH(NT) { \
+        constexpr size_t lds = (size_t)(XH_HCAP + 1) * 128 + (size_t)4 * 2 * NT * 32 * 64 + XH_KMAX * XH_TM * 2 + XH_HCAP * 4; \
+        static_assert(lds <= 160 * 1024, "LDS of sp_conv_halo_kernel"); \
+        static bool once = false; \
+        if (!once) { GGA_CHECK_HIP(hipFuncSetAttribute((const void*)sp_conv_halo_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "sp_conv_halo_kernel: LDS size"); once = true; } \
+        hipLaunchKernelGGL((sp_conv_halo_kernel<NT>), grid, block, lds, stream, x, (const uint16_t*)split_weight, tile_rows, halo_offsets, halo_rows, local_map, n_tiles, kvol, cin, cout, flip, y, y_row_stride, amax_x, amax_weight, stats, bn, stats_rows); }
+    if (cout == 128) XH_LAUNCH(4) else XH_LAUNCH(2)
+#undef XH_LAUNCH
+    GGA_CHECK_LAUNCH("sp_conv_halo_kernel");
+    GGA_TIME_STOP(tev, stream);
+    return GGA_OK;
 }
 
 extern "C" int gga_sparse_conv_apply_split_strided(const float* x, const int32_t* map, const void* split_weight,

@@ -9,6 +9,7 @@ spatial_shape, batch_size)`` with ``.features`` / ``.indices`` / ``.dense()`` /
 bias=False)`` works unchanged. Weights use the mmcv layout ``[kz, ky, kx, Cin, Cout]``.
 """
 import ctypes as C
+import os
 import math
 
 import torch
@@ -31,16 +32,72 @@ def _i3(v):
 class _Rulebook:
     """Gather map [kvol, n_rows] + per-row offset bit mask + mask-sorted processing order."""
 
-    def __init__(self, nbr):
+    def __init__(self, nbr, coors=None):
         self.nbr = nbr
         kvol, n = nbr.shape
         self.mask = self.perm = None
+        self.coors, self._halo = coors, None       # submanifold rule books: the level's coordinates (halo tiling, on demand)
         if kvol <= 32:
             self.mask = torch.empty(n, dtype=torch.int32, device=nbr.device)
             check(_lib.lib().gga_sparse_rowmask(F._p(nbr), n, kvol, F._p(self.mask), F._stream()), 'gga_sparse_rowmask')
             # index preprocessing (once per level, shared by every conv on it): rows with the same
             # neighbour pattern become adjacent, so a 128-row tile skips the offsets none of them uses
             self.perm = torch.sort(self.mask, stable=True)[1].int()
+
+    def halo(self):
+        if self._halo is None:
+            self._halo = _Halo(self.coors, self)
+        return self._halo
+
+
+def _spread3(v):
+    """Bits of v (< 2^16, int64) moved to every third position."""
+    v = v & 0xFFFF
+    v = (v | (v << 32)) & 0x1F00000000FFFF
+    v = (v | (v << 16)) & 0x1F0000FF0000FF
+    v = (v | (v << 8)) & 0x100F00F00F00F00F
+    v = (v | (v << 4)) & 0x10C30C30C30C30C3
+    v = (v | (v << 2)) & 0x1249249249249249
+    return v
+
+
+def morton_order(coors):
+    """Rows of ``coors`` [n,4] (batch, z, y, x) along a Z-order curve per sample: consecutive rows are close in space."""
+    c = coors.long()
+    key = (c[:, 0] << 48) | (_spread3(c[:, 1]) << 2) | (_spread3(c[:, 2]) << 1) | _spread3(c[:, 3])
+    return torch.argsort(key)
+
+
+class _Halo:
+    """Tiling of a submanifold rule book for gga_sparse_conv_apply_halo (include/gga_hip.h): tiles of 256 rows in Z-order,
+    each with the list of distinct input rows its entries name and the entries rewritten as positions in that list."""
+
+    def __init__(self, coors, rb):
+        TM = int(_lib.lib().gga_sparse_halo_tile_rows())
+        nbr = rb.nbr
+        kvol, n = nbr.shape
+        dev = nbr.device
+        self.n_tiles = T = (n + TM - 1) // TM
+        order = morton_order(coors)
+        self.tile_rows = torch.full((T * TM,), -1, dtype=torch.int32, device=dev)
+        self.tile_rows[:n] = order.int()
+        big = 0x7FFFFFFF
+        idx = torch.full((kvol, T * TM), big, dtype=torch.int32, device=dev)
+        g = nbr[:, order]
+        idx[:, :n] = torch.where(g >= 0, g, torch.full_like(g, big))
+        idx = idx.view(kvol, T, TM).permute(1, 0, 2).reshape(T, kvol * TM)
+        sv, si = torch.sort(idx, dim=1)
+        present = sv != big
+        new = torch.ones_like(present)
+        new[:, 1:] = sv[:, 1:] != sv[:, :-1]
+        new &= present
+        lid = torch.cumsum(new, dim=1, dtype=torch.int32) - 1
+        lid = torch.where(present, lid, torch.full_like(lid, -1)).to(torch.int16)
+        self.local_map = torch.empty((T, kvol * TM), dtype=torch.int16, device=dev).scatter_(1, si, lid)
+        self.halo_rows = sv[new].contiguous()
+        self.counts = new.sum(1)
+        self.halo_offsets = torch.zeros(T + 1, dtype=torch.int32, device=dev)
+        self.halo_offsets[1:] = torch.cumsum(self.counts, 0)
 
 
 class _Level:
@@ -75,7 +132,7 @@ class _Level:
                                                  _i3(self.shape), _i3(self.shape), _i3(kernel), _i3((1, 1, 1)), _i3(pad),
                                                  F._p(self.index), self.index_n, None, 0, F._p(nbr), None,
                                                  F._stream()), 'gga_sparse_rulebook')
-            nbr = _Rulebook(nbr)
+            nbr = _Rulebook(nbr, self.coors)
             self._subm[kernel] = nbr
         return nbr
 
@@ -259,6 +316,13 @@ class SparseSequential(SparseModule):
 SPLIT_BF16 = True
 
 
+# Halo form of the submanifold gather-GEMM (csrc/sparse_conv.hip::sp_conv_halo_kernel, two fp16 planes, 128 columns; 2: 64 columns
+# as well). Opt-in: stand-alone it is 10-15 % faster than the default kernel at the 128-channel level of the shipped config,
+# but its tiling is still built with torch ops (~2 ms per level and step) - DESIGN.md 6c.
+HALO = int(os.environ.get('GGA_SP_HALO', '0'))
+HALO_MIN_ROWS = int(os.environ.get('GGA_SP_HALO_MIN_ROWS', '65536'))
+
+
 def planes():
     """Arithmetic of the split-plane gather kernels: 2 = two fp16 planes of the scaled operands / three partial
     products, 3 = three bf16 planes / six (dense_conv.PLANES, one switch for all matrix kernels)."""
@@ -293,6 +357,14 @@ def _conv_apply(x, rb, wp, n_rows, kvol, cin, cout, flip, y, x_amax=None, w_amax
     (backward-data launches, with ``stats``): ``BnSource.part`` pointers of the BatchNorm + ReLU whose output gradient y
     is - y is stored masked by the ReLU and ``stats`` receives that BatchNorm's backward sums."""
     L = _lib.lib()
+    if (HALO and wp.dtype == torch.int16 and w_amax is not None and rb.coors is not None and cin % 32 == 0 and 9 <= kvol <= 27
+            and (cout == 128 or (cout == 64 and HALO >= 2)) and n_rows >= HALO_MIN_ROWS):
+        hl = rb.halo()
+        check(L.gga_sparse_conv_apply_halo(F._p(x), F._p(wp), F._p(hl.tile_rows), F._p(hl.halo_offsets), F._p(hl.halo_rows),
+                                           F._p(hl.local_map), n_rows, hl.n_tiles, kvol, cin, cout, flip, F._p(y), cout, 2, F._p(x_amax),
+                                           F._p(w_amax), F._p(stats), *(bn if bn else (None, 0, None, None, None, None)), F._stream()),
+              'gga_sparse_conv_apply_halo')
+        return
     if wp.dtype == torch.int16:
         check(L.gga_sparse_conv_apply_bn_bwd(F._p(x), F._p(rb.nbr), F._p(wp), F._p(rb.perm), F._p(rb.mask), n_rows,
                                              kvol, cin, cout, flip, F._p(y), cout, 2 if w_amax is not None else 3, F._p(x_amax),

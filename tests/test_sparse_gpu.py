@@ -319,3 +319,61 @@ def test_sparse_backward_data_reduces_the_batchnorm_below(training, mid, monkeyp
         assert calls['fused'] == before + 1
         for n, a, b in zip(('out', 'grad feats', 'grad conv1', 'grad gamma', 'grad beta', 'grad conv2'), got, plain):
             assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-7, n
+
+
+@pytest.mark.parametrize('mid', [64, 128])
+def test_halo_form_of_the_submanifold_convolution(mid, monkeypatch):
+    """GGA_SP_HALO: the submanifold convolutions of 64 / 128 columns through sp_conv_halo_kernel (spatial 256-row tiles whose
+    distinct neighbour rows are staged once per 32-channel chunk in LDS) against the default gather-GEMM kernel of this repo -
+    forward with the BatchNorm sums, backward-data with the BatchNorm-backward epilogue, on a level dense enough that some
+    tiles' halos exceed the 512-row image (the lanes that then read from global memory) and with a last tile that is not full."""
+    import copy
+    from gga_amd import _lib, dense_conv, functional as F, sparse
+    monkeypatch.setattr(dense_conv, 'PLANES', 2)
+    torch.manual_seed(11)
+    dev = 'cuda:0'
+    shape, B = (24, 40, 40), 2
+    dense = torch.rand(B, *shape) < 0.45
+    coors = dense.nonzero().int()
+    coors = coors[torch.randperm(len(coors))].contiguous().to(dev)
+    n = coors.shape[0]
+    assert n % 256 != 0
+    feats = torch.randn(n, 16, device=dev)
+    L = _lib.lib()
+    calls = {'halo': 0}
+    real = L.gga_sparse_conv_apply_halo
+
+    def counted(*a):
+        calls['halo'] += 1
+        return real(*a)
+
+    monkeypatch.setattr(L, 'gga_sparse_conv_apply_halo', counted)
+    conv1 = sparse.SubMConv3d(16, mid, 3, padding=1, bias=False, indice_key='s').to(dev)
+    bn = torch.nn.BatchNorm1d(mid, eps=1e-3, momentum=0.01).to(dev)
+    conv2 = sparse.SubMConv3d(mid, mid, 3, padding=1, bias=False, indice_key='s').to(dev)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5), bn.bias.uniform_(-0.5, 0.5)
+
+    def run(halo):
+        monkeypatch.setattr(sparse, 'HALO', halo)
+        monkeypatch.setattr(sparse, 'HALO_MIN_ROWS', 0)
+        mods = copy.deepcopy((conv1, bn, conv2))
+        f = feats.clone().requires_grad_(True)
+        x = sparse.SparseConvTensor(f, coors, shape, B)
+        h = mods[0](x)
+        h = h.replace_feature(F.bn_act(h.features, mods[1], relu=True))
+        out = mods[2](h).features        # (no ReLU behind the convolution under test: its decisions would differ at elements near 0)
+        sums = out.bn_partials.sum(0)
+        g = torch.linspace(-1, 1, out.numel(), device=dev).view_as(out)
+        out.backward(g)
+        rb = h._level.subm_rulebook((3, 3, 3))
+        return (out.detach(), sums, f.grad, mods[0].weight.grad, mods[1].weight.grad, mods[1].bias.grad, mods[2].weight.grad), rb
+
+    got, rb = run(2)
+    assert calls['halo'] == 2, 'forward and backward-data of the second convolution did not take the halo form'
+    counts = rb.halo().counts
+    assert int(counts.max()) > 512 and int(counts.min()) >= 1, (int(counts.min()), int(counts.max()))
+    plain, _ = run(0)
+    assert calls['halo'] == 2
+    for name, a, b in zip(('out', 'BatchNorm sums', 'grad feats', 'grad conv1', 'grad gamma', 'grad beta', 'grad conv2'), got, plain):
+        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-7, name

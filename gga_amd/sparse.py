@@ -70,34 +70,23 @@ def morton_order(coors):
 
 class _Halo:
     """Tiling of a submanifold rule book for gga_sparse_conv_apply_halo (include/gga_hip.h): tiles of 256 rows in Z-order,
-    each with the list of distinct input rows its entries name and the entries rewritten as positions in that list."""
+    each with the list of distinct input rows its entries name and the entries rewritten as positions in that list
+    (gga_sparse_halo_build)."""
 
     def __init__(self, coors, rb):
-        TM = int(_lib.lib().gga_sparse_halo_tile_rows())
-        nbr = rb.nbr
-        kvol, n = nbr.shape
-        dev = nbr.device
+        L = _lib.lib()
+        TM = int(L.gga_sparse_halo_tile_rows())
+        kvol, n = rb.nbr.shape
+        dev = rb.nbr.device
         self.n_tiles = T = (n + TM - 1) // TM
-        order = morton_order(coors)
         self.tile_rows = torch.full((T * TM,), -1, dtype=torch.int32, device=dev)
-        self.tile_rows[:n] = order.int()
-        big = 0x7FFFFFFF
-        idx = torch.full((kvol, T * TM), big, dtype=torch.int32, device=dev)
-        g = nbr[:, order]
-        idx[:, :n] = torch.where(g >= 0, g, torch.full_like(g, big))
-        idx = idx.view(kvol, T, TM).permute(1, 0, 2).reshape(T, kvol * TM)
-        sv, si = torch.sort(idx, dim=1)
-        present = sv != big
-        new = torch.ones_like(present)
-        new[:, 1:] = sv[:, 1:] != sv[:, :-1]
-        new &= present
-        lid = torch.cumsum(new, dim=1, dtype=torch.int32) - 1
-        lid = torch.where(present, lid, torch.full_like(lid, -1)).to(torch.int16)
-        self.local_map = torch.empty((T, kvol * TM), dtype=torch.int16, device=dev).scatter_(1, si, lid)
-        self.halo_rows = sv[new].contiguous()
-        self.counts = new.sum(1)
-        self.halo_offsets = torch.zeros(T + 1, dtype=torch.int32, device=dev)
-        self.halo_offsets[1:] = torch.cumsum(self.counts, 0)
+        self.tile_rows[:n] = morton_order(coors).int()
+        self.capacity = kvol * TM
+        self.halo_rows = torch.empty((T, self.capacity), dtype=torch.int32, device=dev)
+        self.counts = torch.empty(T, dtype=torch.int32, device=dev)
+        self.local_map = torch.empty((T, kvol, TM), dtype=torch.int16, device=dev)
+        check(L.gga_sparse_halo_build(F._p(rb.nbr), F._p(self.tile_rows), n, T, kvol, self.capacity, F._p(self.halo_rows),
+                                      F._p(self.counts), F._p(self.local_map), F._stream()), 'gga_sparse_halo_build')
 
 
 class _Level:
@@ -318,7 +307,7 @@ SPLIT_BF16 = True
 
 # Halo form of the submanifold gather-GEMM (csrc/sparse_conv.hip::sp_conv_halo_kernel, two fp16 planes, 128 columns; 2: 64 columns
 # as well). Opt-in: stand-alone it is 10-15 % faster than the default kernel at the 128-channel level of the shipped config,
-# but its tiling is still built with torch ops (~2 ms per level and step) - DESIGN.md 6c.
+# DESIGN.md 6c.
 HALO = int(os.environ.get('GGA_SP_HALO', '0'))
 HALO_MIN_ROWS = int(os.environ.get('GGA_SP_HALO_MIN_ROWS', '65536'))
 
@@ -360,7 +349,7 @@ def _conv_apply(x, rb, wp, n_rows, kvol, cin, cout, flip, y, x_amax=None, w_amax
     if (HALO and wp.dtype == torch.int16 and w_amax is not None and rb.coors is not None and cin % 32 == 0 and 9 <= kvol <= 27
             and (cout == 128 or (cout == 64 and HALO >= 2)) and n_rows >= HALO_MIN_ROWS):
         hl = rb.halo()
-        check(L.gga_sparse_conv_apply_halo(F._p(x), F._p(wp), F._p(hl.tile_rows), F._p(hl.halo_offsets), F._p(hl.halo_rows),
+        check(L.gga_sparse_conv_apply_halo(F._p(x), F._p(wp), F._p(hl.tile_rows), F._p(hl.counts), hl.capacity, F._p(hl.halo_rows),
                                            F._p(hl.local_map), n_rows, hl.n_tiles, kvol, cin, cout, flip, F._p(y), cout, 2, F._p(x_amax),
                                            F._p(w_amax), F._p(stats), *(bn if bn else (None, 0, None, None, None, None)), F._stream()),
               'gga_sparse_conv_apply_halo')

@@ -371,19 +371,23 @@ int gga_sparse_conv_apply_bn_bwd(const float* x, const int32_t* map, const void*
  * middle_encoders/sparse_encoder.py:107-214 / ops/sparse_block.py:117-199; same arithmetic and epilogues). The rows are
  * processed in tiles of gga_sparse_halo_tile_rows() (256) rows that lie close together in space; the distinct input rows a
  * tile's kvol x 256 rule-book entries name (its halo) are staged once per 32-channel chunk in LDS and every offset reads
- * them there. The caller supplies the tiling (gga_amd/sparse.py::_Halo builds it from the level's coordinates and rule book):
- *   tile_rows    int32 [n_tiles * 256]       output row (= row of the rule book) of each tile slot, -1 = empty slot
- *   halo_offsets int32 [n_tiles + 1]         tile t's halo is halo_rows[halo_offsets[t] .. halo_offsets[t+1])
- *   halo_rows    int32                       input rows, distinct within a tile
- *   local_map    uint16 [n_tiles][kvol][256] position of the neighbour in the tile's halo, 0xFFFF = none; offset k of a
- *                                            flipped (backward-data) launch reads entry kvol-1-k
- * n_tiles = ceil(n_rows / 256); 8 <= kvol <= 27; cin % 32 == 0; cout 64 or 128. stats (may be NULL) is sized as for
- * gga_sparse_conv_apply_stats ([gga_sparse_conv_apply_tiles(n_rows)][2][cout]); the rows no tile writes are zeroed. */
+ * them there. gga_sparse_halo_build makes the tiling from the rule book and a spatial order of its rows (gga_amd/sparse.py::
+ * _Halo: Z-order of the level's coordinates):
+ *   tile_rows    int32 [n_tiles * 256]         output row (= row of the rule book) of each tile slot, -1 = empty slot
+ *   halo_rows    int32 [n_tiles][capacity]     tile t's halo: its first halo_counts[t] entries, distinct input rows
+ *   halo_counts  int32 [n_tiles]
+ *   local_map    uint16 [n_tiles][kvol][256]   position of the neighbour in the tile's halo, 0xFFFF = none; offset k of a
+ *                                              flipped (backward-data) launch reads entry kvol-1-k
+ * n_tiles = ceil(n_rows / 256); capacity >= kvol * 256 (no tile can overflow); apply: 8 <= kvol <= 27; cin % 32 == 0; cout 64
+ * or 128; two fp16 planes only (planes == 2). stats (may be NULL) is sized as for gga_sparse_conv_apply_stats
+ * ([gga_sparse_conv_apply_tiles(n_rows)][2][cout]); the rows no tile writes are zeroed. */
 int64_t gga_sparse_halo_tile_rows(void);
+int gga_sparse_halo_build(const int32_t* nbr, const int32_t* tile_rows, int64_t n_rows, int64_t n_tiles, int kvol,
+                          int halo_capacity, int32_t* halo_rows, int32_t* halo_counts, uint16_t* local_map, void* stream);
 int gga_sparse_conv_apply_halo(const float* x, const void* split_weight, const int32_t* tile_rows,
-                               const int32_t* halo_offsets, const int32_t* halo_rows, const uint16_t* local_map,
-                               int64_t n_rows, int64_t n_tiles, int kvol, int cin, int cout, int flip, float* y,
-                               int64_t y_row_stride, int planes, const uint32_t* amax_x, const uint32_t* amax_weight,
+                               const int32_t* halo_counts, int halo_capacity, const int32_t* halo_rows,
+                               const uint16_t* local_map, int64_t n_rows, int64_t n_tiles, int kvol, int cin, int cout, int flip,
+                               float* y, int64_t y_row_stride, int planes, const uint32_t* amax_x, const uint32_t* amax_weight,
                                double* stats, const float* bn_x, int64_t bn_x_row_stride, const float* bn_gamma,
                                const float* bn_beta, const float* bn_mean, const float* bn_invstd, void* stream);
 int gga_sparse_conv_wgrad_planes(const float* x, int64_t x_row_stride, const float* grad_out, int64_t grad_out_row_stride,

@@ -373,6 +373,20 @@ def test_halo_form_of_the_submanifold_convolution(mid, monkeypatch):
     assert calls['halo'] == 2, 'forward and backward-data of the second convolution did not take the halo form'
     counts = rb.halo().counts
     assert int(counts.max()) > 512 and int(counts.min()) >= 1, (int(counts.min()), int(counts.max()))
+    # the tiling itself (gga_sparse_halo_build): every tile's halo holds distinct rows, exactly those its rule-book entries
+    # name, and every entry points at its own neighbour
+    hl = rb.halo()
+    nbr, T = rb.nbr.long(), hl.n_tiles
+    rows = hl.tile_rows.long().view(T, 256)
+    ent = torch.where(rows[:, None, :] >= 0, nbr[:, rows.clamp(min=0)].permute(1, 0, 2), torch.full((1,), -1, device=dev, dtype=torch.long))
+    lm = hl.local_map.long() & 0xFFFF
+    assert bool(((lm == 0xFFFF) == (ent < 0)).all())
+    assert bool((lm[ent >= 0] < counts.long()[:, None, None].expand_as(lm)[ent >= 0]).all())
+    named = torch.gather(hl.halo_rows.long(), 1, lm.clamp(max=hl.capacity - 1).view(T, -1)).view_as(lm)
+    assert bool((named[ent >= 0] == ent[ent >= 0]).all())
+    for t in (0, T // 2, T - 1):
+        h = hl.halo_rows[t, :int(counts[t])]
+        assert h.unique().numel() == h.numel() == ent[t][ent[t] >= 0].unique().numel()
     plain, _ = run(0)
     assert calls['halo'] == 2
     for name, a, b in zip(('out', 'BatchNorm sums', 'grad feats', 'grad conv1', 'grad gamma', 'grad beta', 'grad conv2'), got, plain):

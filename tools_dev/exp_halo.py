@@ -58,7 +58,7 @@ for planes in (2,):
         t_build = (time.time() - t0) * 1e3
         cnt = halo.counts.float()
         print(f'=== planes {planes} level {li + 1}: {nrow} rows, C {C_}, grid {lvl.shape}; halo rows per 256-row tile: mean {cnt.mean():.0f} '
-              f'max {int(cnt.max())}, tiles over 512: {float((cnt > 512).float().mean()):.3f}; tables built in {t_build:.1f} ms (torch)')
+              f'max {int(cnt.max())}, tiles over 512: {float((cnt > 512).float().mean()):.3f}; tables built in {t_build:.2f} ms')
         two = planes == 2
         x_amax = dense_conv._amax_bits(feats) if two else None
         w_amax = dense_conv._amax_bits(w) if two else None
@@ -70,7 +70,7 @@ for planes in (2,):
             st1 = torch.empty_like(st0)
             f0 = lambda: L.gga_sparse_conv_apply_stats(F._p(feats), F._p(rb.nbr), F._p(wp), F._p(rb.perm), F._p(rb.mask), nrow, 27, C_, C_, flip,
                                                        F._p(y0), C_, planes, F._p(x_amax), F._p(w_amax), F._p(st0), F._stream())
-            f1 = lambda: L.gga_sparse_conv_apply_halo(F._p(feats), F._p(wp), F._p(halo.tile_rows), F._p(halo.halo_offsets), F._p(halo.halo_rows),
+            f1 = lambda: L.gga_sparse_conv_apply_halo(F._p(feats), F._p(wp), F._p(halo.tile_rows), F._p(halo.counts), halo.capacity, F._p(halo.halo_rows),
                                                       F._p(halo.local_map), nrow, halo.n_tiles, 27, C_, C_, flip, F._p(y1), C_, planes,
                                                       F._p(x_amax), F._p(w_amax), F._p(st1), None, 0, None, None, None, None, F._stream())
             assert f0() == 0

@@ -32,11 +32,12 @@ def _i3(v):
 class _Rulebook:
     """Gather map [kvol, n_rows] + per-row offset bit mask + mask-sorted processing order."""
 
-    def __init__(self, nbr, coors=None):
+    def __init__(self, nbr, coors=None, occupancy=0.0):
         self.nbr = nbr
         kvol, n = nbr.shape
         self.mask = self.perm = None
-        self.coors, self._halo = coors, None       # submanifold rule books: the level's coordinates (halo tiling, on demand)
+        # submanifold rule books: the level's coordinates and the share of its grid cells that are active (halo form)
+        self.coors, self.occupancy, self._halo = coors, occupancy, None
         if kvol <= 32:
             self.mask = torch.empty(n, dtype=torch.int32, device=nbr.device)
             check(_lib.lib().gga_sparse_rowmask(F._p(nbr), n, kvol, F._p(self.mask), F._stream()), 'gga_sparse_rowmask')
@@ -121,7 +122,8 @@ class _Level:
                                                  _i3(self.shape), _i3(self.shape), _i3(kernel), _i3((1, 1, 1)), _i3(pad),
                                                  F._p(self.index), self.index_n, None, 0, F._p(nbr), None,
                                                  F._stream()), 'gga_sparse_rulebook')
-            nbr = _Rulebook(nbr, self.coors)
+            cells = self.batch_size * self.shape[0] * self.shape[1] * self.shape[2]
+            nbr = _Rulebook(nbr, self.coors, self.n / max(cells, 1))
             self._subm[kernel] = nbr
         return nbr
 
@@ -305,11 +307,14 @@ class SparseSequential(SparseModule):
 SPLIT_BF16 = True
 
 
-# Halo form of the submanifold gather-GEMM (csrc/sparse_conv.hip::sp_conv_halo_kernel, two fp16 planes, 128 columns; 2: 64 columns
-# as well). Opt-in: stand-alone it is 10-15 % faster than the default kernel at the 128-channel level of the shipped config,
-# DESIGN.md 6c.
-HALO = int(os.environ.get('GGA_SP_HALO', '0'))
+# Halo form of the submanifold gather-GEMM (csrc/sparse_conv.hip::sp_conv_halo_kernel; two fp16 planes; 1: 128 columns, 2: 64
+# columns as well - slower there -, 0: off). It walks all kvol offsets of every row block, where the default kernel skips the
+# offsets none of a block's 32 mask-sorted rows uses: it pays on levels where most offsets are populated - taken when at least
+# HALO_MIN_OCCUPANCY of the level's grid cells are active (the 128-channel level of the shipped config on the bench batch: 0.36,
+# 14.5 of 27 offsets per row; 10-15 % faster than the default kernel there) - and large enough to fill the chip.
+HALO = int(os.environ.get('GGA_SP_HALO', '1'))
 HALO_MIN_ROWS = int(os.environ.get('GGA_SP_HALO_MIN_ROWS', '65536'))
+HALO_MIN_OCCUPANCY = float(os.environ.get('GGA_SP_HALO_MIN_OCCUPANCY', '0.25'))
 
 
 def planes():
@@ -347,7 +352,7 @@ def _conv_apply(x, rb, wp, n_rows, kvol, cin, cout, flip, y, x_amax=None, w_amax
     is - y is stored masked by the ReLU and ``stats`` receives that BatchNorm's backward sums."""
     L = _lib.lib()
     if (HALO and wp.dtype == torch.int16 and w_amax is not None and rb.coors is not None and cin % 32 == 0 and 9 <= kvol <= 27
-            and (cout == 128 or (cout == 64 and HALO >= 2)) and n_rows >= HALO_MIN_ROWS):
+            and (cout == 128 or (cout == 64 and HALO >= 2)) and n_rows >= HALO_MIN_ROWS and rb.occupancy >= HALO_MIN_OCCUPANCY):
         hl = rb.halo()
         check(L.gga_sparse_conv_apply_halo(F._p(x), F._p(wp), F._p(hl.tile_rows), F._p(hl.counts), hl.capacity, F._p(hl.halo_rows),
                                            F._p(hl.local_map), n_rows, hl.n_tiles, kvol, cin, cout, flip, F._p(y), cout, 2, F._p(x_amax),

@@ -244,6 +244,7 @@ class Runner:
         self._side = None           # side stream of the input prefetch
         self._prepared = {}         # id(data dict) -> (PreparedInputs, event)
         self._retired = []          # (PreparedInputs, event after the step that consumed them)
+        self._ready = {}            # id(data dict) -> (event after its upload, the dict): inputs_ready
 
     def prefetch(self, data):
         """Run the point-only front of the step that will consume ``data`` now, on the side stream."""
@@ -258,8 +259,16 @@ class Runner:
             # queued backward kernels they are scheduled late and the host idles (measured on the sparse trunk: 41 ms of the 62 ms
             # step spent in those waits; tools_dev/host_profile.py second)
             self._side = torch.cuda.Stream(device=self.device, priority=-1)
-        # the points may have been uploaded (non_blocking) on the main stream just before this call
-        self._side.wait_stream(torch.cuda.current_stream(self.device))
+        # The side stream must see the batch's points complete. A batch announced with `inputs_ready` waits for that event
+        # only; any other batch may have been uploaded (non_blocking) on the main stream just before this call, and the side
+        # stream then waits for everything queued there - which is the whole previous step when the host runs ahead of the
+        # device: the front no longer overlaps the step and the device idles while the host reads the front's counts
+        # (measured on the sparse trunk, bs 8: 63.7 against 59.5 ms per step).
+        ready = self._ready.get(id(data))
+        if ready is not None and ready[1] is data:
+            self._side.wait_event(ready[0])
+        else:
+            self._side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(self._side):
             prep = model.prepare_inputs(pts)
             ev = torch.cuda.Event()
@@ -273,6 +282,17 @@ class Runner:
         # only ever used for the very object it was made from (`_prepared_for`), and entries the next step does not consume
         # are dropped there
         self._prepared[id(data)] = (prep, ev, data, pts)
+
+    def inputs_ready(self, *batches):
+        """Declare that the tensors of ``batches`` are (or will be, in stream order) complete on the current stream NOW:
+        one event, which ``prefetch`` of such a batch waits for instead of the whole main stream. Call it once after the
+        uploads of the batches a loop cycles through (``run`` does)."""
+        if self.device.type != 'cuda':
+            return
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        for b in batches:
+            self._ready[id(b)] = (ev, b)
 
     def _prepared_for(self, data):
         hit = self._prepared.get(id(data))
@@ -380,6 +400,7 @@ class Runner:
         self.raw_model.train()
         t0 = time.time()
         out = None
+        self.inputs_ready(*batches)
         for i in range(n_iters):
             if i == self.GC_FREEZE_AFTER:
                 self.freeze_gc()

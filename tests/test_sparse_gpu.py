@@ -357,6 +357,7 @@ def test_halo_form_of_the_submanifold_convolution(mid, monkeypatch):
     def run(halo):
         monkeypatch.setattr(sparse, 'HALO', halo)
         monkeypatch.setattr(sparse, 'HALO_MIN_ROWS', 0)
+        monkeypatch.setattr(sparse, 'HALO_MIN_OCCUPANCY', 0.0)
         mods = copy.deepcopy((conv1, bn, conv2))
         f = feats.clone().requires_grad_(True)
         x = sparse.SparseConvTensor(f, coors, shape, B)

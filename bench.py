@@ -333,30 +333,37 @@ def sparse_roofline(run, args, steps=4):
     from gga_amd import _lib
     L = _lib.lib()
     seen = []
-    real = L.gga_sparse_conv_apply_bn_bwd
+    real, real_halo = L.gga_sparse_conv_apply_bn_bwd, L.gga_sparse_conv_apply_halo
 
     def spy(*a):
         if a[7] == 128 and a[8] == 128 and a[6] == 27:
-            seen.append((int(a[5]), int(a[6])))
+            seen.append((int(a[5]), 'sp_conv_x9_kernel<4,true,2>'))
         return real(*a)
-    L.gga_sparse_conv_apply_bn_bwd = spy
+
+    def spy_halo(*a):                       # (x, weights, tile rows, counts, capacity, halo rows, local map, n_rows, n_tiles, kvol, cin, cout, ...)
+        if a[10] == 128 and a[11] == 128 and a[9] == 27:
+            seen.append((int(a[7]), 'sp_conv_halo_kernel<4>'))
+        return real_halo(*a)
+    L.gga_sparse_conv_apply_bn_bwd, L.gga_sparse_conv_apply_halo = spy, spy_halo
     try:
         _lib.timing_begin(_lib.TIME_SPARSE_CONV, 64 * steps, _lib.timing_conv_key(128, 128, 0))
-        for i in range(steps):
+        for i in range(steps):       # (every rank takes these steps: they contain the gradient all-reduce)
             run['runner'].step(run['batches'][i % 2], next_data=run['batches'][(i + 1) % 2])
         ms = _lib.timing_collect(_lib.TIME_SPARSE_CONV, 64 * steps)
     finally:
-        L.gga_sparse_conv_apply_bn_bwd = real
-    big = [(n, k) for n, k in seen]
+        L.gga_sparse_conv_apply_bn_bwd, L.gga_sparse_conv_apply_halo = real, real_halo
+    big = seen
     if not ms or not big:
         return None
+    names = sorted(set(k for _, k in big))
+    halo = 'sp_conv_halo_kernel<4>' in names
     rows = sum(n for n, _ in big) / len(big)
     algo = rows * (128 + 128) * 4 + 27 * rows * 4 + 27 * 128 * 128 * 4
     avg = sum(ms) / len(ms)
     traffic, src = None, None
     try:
         pmc = json.load(open(os.path.join(REPO, 'profiles', 'r03_second_pmc.json')))
-        ks = [k for k in pmc['kernels'] if k['kernel'].startswith(('sp_conv_x9_kernel<4', 'sp_conv_ring_kernel<4')) and 'hbm_bytes_per_launch' in k
+        ks = [k for k in pmc['kernels'] if k['kernel'].startswith('sp_conv_halo_kernel<4' if halo else 'sp_conv_x9_kernel<4') and 'hbm_bytes_per_launch' in k
               and k['avg_us'] > 500]
         if ks and args.second_batch == 8:
             traffic = int(sum(k['hbm_bytes_per_launch'] * k['launches_per_pass'] for k in ks) / sum(k['launches_per_pass'] for k in ks))
@@ -364,7 +371,7 @@ def sparse_roofline(run, args, steps=4):
     except (OSError, KeyError, ValueError):
         pass
     gbs = algo / (avg * 1e-3) / 1e9
-    return {'bound': 'hbm', 'kernel': 'sp_conv_x9_kernel<4,true,2> (SubMConv3d 128 -> 128, 27 offsets, forward + backward-data)',
+    return {'bound': 'hbm', 'kernel': ' + '.join(names) + ' (SubMConv3d 128 -> 128, 27 offsets, forward + backward-data)',
             'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(gbs / HBM_PEAK_GBS, 4), 'traffic': traffic,
             'traffic_source': src, 'traffic_GBps': round(traffic / (avg * 1e-3) / 1e9, 1) if traffic else None,
             'algorithmic_bytes': int(algo), 'rows': int(rows), 'kernel_ms': round(avg, 4), 'launches_timed': len(ms),
@@ -477,6 +484,9 @@ def cpu_baseline(cfg, frames=16):
 
 
 def main():
+    if os.environ.get('GGA_BENCH_HANG_DUMP') and 'RANK' in os.environ:       # debugging aid (ranks of an N-rank run): every thread's Python stack to stderr after N seconds, then exit
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ['GGA_BENCH_HANG_DUMP']), exit=True)
     args = parse_args()
     if args.gpus > 1 and 'RANK' not in os.environ:
         launch_ranks(args)
@@ -574,12 +584,14 @@ def main():
                 'ms_per_step': round(sdt / args.steps * 1e3, 3), 'steps': args.steps, 'warmup': args.warmup,
                 'final_loss': round(sec['loss'], 4),
                 'dominant_kernels_ms_per_step': {
-                    'sp_conv_x9_kernel (sparse conv fwd + bwd-data, %d launches/step)' % (len(st.get(_lib.TIME_SPARSE_CONV, [])) // args.steps):
+                    'sp_conv_x9_kernel + sp_conv_halo_kernel (sparse conv fwd + bwd-data, %d launches/step)' % (len(st.get(_lib.TIME_SPARSE_CONV, [])) // args.steps):
                         round(conv_ms, 3),
                     'sparse conv weight gradient (%d launches/step)' % (len(st.get(_lib.TIME_SPARSE_WGRAD, [])) // args.steps):
                         round(wg_ms, 3)},
                 'timed': 'in-step, HIP events on the launch stream'}
-            res['second_trunk']['roofline'] = sparse_roofline(sec, args)
+        sroof = None if args.no_roofline else sparse_roofline(sec, args)       # on every rank (its steps all-reduce)
+        if rank == 0:
+            res['second_trunk']['roofline'] = sroof
         del sec
         gc.collect()
         torch.cuda.empty_cache()

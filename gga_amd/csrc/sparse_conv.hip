@@ -2359,6 +2359,9 @@ extern "C" int gga_debug_dc_probe(unsigned long long* out) {
 #define DC_ACC(I, D)
 #define DC_PROBE_WAIT
 #endif
+#ifndef DC_PIPE_ON
+#define DC_PIPE_ON 1
+#endif
 #define DC_TR 8
 #define DC_TW 32
 #define DC_HW (DC_TW + 2)
@@ -2520,24 +2523,36 @@ __global__ __launch_bounds__(TR / MT * 64, 2) void dense_conv3x3_x9_kernel(const
     // tap offsets and buffer numbers are immediates.
     // fragments: the two M tiles' A planes, and the B planes of TWO N tiles at a time (with four N tiles all
     // twelve B fragments alive next to 128 accumulator registers do not fit 256 registers)
+    // Round 3 (PIPE, the forms with two N tiles = 64 output channels): a second fragment set; stage s multiplies the set
+    // that stage s - 1 read for it and reads the next stage's set between its own MFMAs (sched_group_barrier pins the
+    // interleave: left alone the scheduler sinks every read to just before its use, which is what the round-2 attempt at
+    // this measured). The weights of stage s + 1 are in LDS since the barrier before stage s (they are written a stage
+    // early), the halo image is constant over a chunk; the first offset of a chunk reads its own fragments.
+    constexpr bool PIPE = DC_PIPE_ON && NT == 2 && MT == 2 && NP == 2;       // (three planes: the second set spills)
     mf_v8bf fa[MT][NP], fb[2][NP];
-#define DC_READ_A(TAP) {                                                                                              \
+    mf_v8bf ga[MT][NP], gb[2][NP];
+#define DC_READ_A_(FA, TAP) {                                                                                         \
         const unsigned char* Ap = As + ((MT * wave + (TAP) / 3) * DC_HW + r + (TAP) % 3) * DC_ROWB + h * 16;           \
         _Pragma("unroll") for (int m = 0; m < MT; ++m) _Pragma("unroll") for (int p = 0; p < NP; ++p)                 \
-            fa[m][p] = *reinterpret_cast<const mf_v8bf*>(Ap + p * APL + m * DC_HW * DC_ROWB); }
-#define DC_READ_B(TAP, T0) {                                                                                          \
+            FA[m][p] = *reinterpret_cast<const mf_v8bf*>(Ap + p * APL + m * DC_HW * DC_ROWB); }
+#define DC_READ_B_(FB, TAP, T0) {                                                                                     \
         const unsigned char* Bp = Bs + ((TAP) % 3) * BSZ + r * DC_ROWB + h * 16 + (T0) * 32 * DC_ROWB;                \
         _Pragma("unroll") for (int t = 0; t < 2; ++t) _Pragma("unroll") for (int p = 0; p < NP; ++p)                  \
-            fb[t][p] = *reinterpret_cast<const mf_v8bf*>(Bp + p * BPL + t * 32 * DC_ROWB); }
+            FB[t][p] = *reinterpret_cast<const mf_v8bf*>(Bp + p * BPL + t * 32 * DC_ROWB); }
+#define DC_READ_A(TAP) DC_READ_A_(fa, TAP)
+#define DC_READ_B(TAP, T0) DC_READ_B_(fb, TAP, T0)
     // partial products smallest first; tiles innermost so consecutive MFMAs never share an accumulator
-#define DC_MM1(T0, PA, PB) _Pragma("unroll") for (int m = 0; m < MT; ++m) _Pragma("unroll") for (int t = 0; t < 2; ++t) acc[m][(T0) + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[m][PA], fb[t][PB], acc[m][(T0) + t], 0, 0, 0);
-#define DC_MH1(T0, PA, PB) _Pragma("unroll") for (int m = 0; m < MT; ++m) _Pragma("unroll") for (int t = 0; t < 2; ++t) acc[m][(T0) + t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(mf_v8h, fa[m][PA]), __builtin_bit_cast(mf_v8h, fb[t][PB]), acc[m][(T0) + t], 0, 0, 0);
+#define DC_MM1_(FA, FB, T0, PA, PB) _Pragma("unroll") for (int m = 0; m < MT; ++m) _Pragma("unroll") for (int t = 0; t < 2; ++t) acc[m][(T0) + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[m][PA], FB[t][PB], acc[m][(T0) + t], 0, 0, 0);
+#define DC_MH1_(FA, FB, T0, PA, PB) _Pragma("unroll") for (int m = 0; m < MT; ++m) _Pragma("unroll") for (int t = 0; t < 2; ++t) acc[m][(T0) + t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(mf_v8h, FA[m][PA]), __builtin_bit_cast(mf_v8h, FB[t][PB]), acc[m][(T0) + t], 0, 0, 0);
 #ifdef X9_SIX
-#define DC_MMA3(T0) DC_MM1(T0, 0, NP - 1) DC_MM1(T0, 1, 1) DC_MM1(T0, NP - 1, 0) DC_MM1(T0, 0, 1) DC_MM1(T0, 1, 0) DC_MM1(T0, 0, 0)
+#define DC_MMA3_(FA, FB, T0) DC_MM1_(FA, FB, T0, 0, NP - 1) DC_MM1_(FA, FB, T0, 1, 1) DC_MM1_(FA, FB, T0, NP - 1, 0) DC_MM1_(FA, FB, T0, 0, 1) DC_MM1_(FA, FB, T0, 1, 0) DC_MM1_(FA, FB, T0, 0, 0)
 #else
-#define DC_MMA3(T0) DC_MM1(T0, NP - 1, NP - 1) DC_MM1(T0, 1, NP - 1) DC_MM1(T0, NP - 1, 1) DC_MM1(T0, 0, NP - 1) DC_MM1(T0, 1, 1) DC_MM1(T0, NP - 1, 0) DC_MM1(T0, 0, 1) DC_MM1(T0, 1, 0) DC_MM1(T0, 0, 0)
+#define DC_MMA3_(FA, FB, T0) DC_MM1_(FA, FB, T0, NP - 1, NP - 1) DC_MM1_(FA, FB, T0, 1, NP - 1) DC_MM1_(FA, FB, T0, NP - 1, 1) DC_MM1_(FA, FB, T0, 0, NP - 1) DC_MM1_(FA, FB, T0, 1, 1) DC_MM1_(FA, FB, T0, NP - 1, 0) DC_MM1_(FA, FB, T0, 0, 1) DC_MM1_(FA, FB, T0, 1, 0) DC_MM1_(FA, FB, T0, 0, 0)
 #endif
-#define DC_MMA(T0) { if (NP == 3) { DC_MMA3(T0) } else { DC_MH1(T0, 0, 1) DC_MH1(T0, 1, 0) DC_MH1(T0, 0, 0) } }
+#define DC_MMA_(FA, FB, T0) { if (NP == 3) { DC_MMA3_(FA, FB, T0) } else { DC_MH1_(FA, FB, T0, 0, 1) DC_MH1_(FA, FB, T0, 1, 0) DC_MH1_(FA, FB, T0, 0, 0) } }
+#define DC_MMA(T0) DC_MMA_(fa, fb, T0)
+    // groups of (MFMAs, LDS reads) of a pipelined stage: 12 MFMAs and 8 reads on two planes, 24 and 12 on three
+    constexpr int PG = NP == 2 ? 4 : 12, PG_M = NP == 2 ? 3 : 2, PG_R = NP == 2 ? 2 : 1;
 
     // Persistent workgroups: tiles blockIdx.x, blockIdx.x + gridDim.x, ... as one uninterrupted
     // stream of stages - the halo of the next tile's first chunk is requested during the last
@@ -2595,7 +2610,7 @@ __global__ __launch_bounds__(TR / MT * 64, 2) void dense_conv3x3_x9_kernel(const
                 DC_AOFF(nb_, ny0, nx0)                                                                                \
                 DC_LOAD_A(0);                                                                                         \
             }
-#define DC_STAGE(TAP, CH, L0, L1, L2, S0, S1, S2) {                                                                   \
+#define DC_STAGE(TAP, CH, L0, L1, L2, S0, S1, S2, CA, CB, XA, XB) {                                                   \
             const bool last_chunk = (CH) + 1 >= nchunks;                                                              \
             const bool more3 = (TAP) + 3 < 9 || !last_chunk || more_tiles;     /* a stage three ahead exists */       \
             const bool more2 = (TAP) + 2 < 9 || !last_chunk || more_tiles;                                            \
@@ -2609,6 +2624,15 @@ __global__ __launch_bounds__(TR / MT * 64, 2) void dense_conv3x3_x9_kernel(const
                 else { DC_LOAD_B((TAP) + 2 - 9, last_chunk ? 0 : (CH) + 1, bq0, bq1, bq2); }                          \
             }                                                                                                         \
             DC_T(ta_)                                                                                                 \
+            if (PIPE) {                                                                                               \
+                if ((TAP) == 0) { DC_READ_A_(CA, 0); DC_READ_B_(CB, 0, 0); }                                           \
+                if ((TAP) < 8) { DC_READ_A_(XA, (TAP) + 1); DC_READ_B_(XB, (TAP) + 1, 0); }                            \
+                DC_MMA_(CA, CB, 0)                                                                                    \
+                if ((TAP) < 8) {                                                                                      \
+                    _Pragma("unroll") for (int g_ = 0; g_ < PG; ++g_) {                                               \
+                        __builtin_amdgcn_sched_group_barrier(0x008, PG_M, 0); __builtin_amdgcn_sched_group_barrier(0x100, PG_R, 0); } \
+                }                                                                                                     \
+            } else {                                                                                                  \
             DC_READ_A(TAP);                                                                                           \
             _Pragma("unroll") for (int t0 = 0; t0 < NT; t0 += 2) {                                                    \
                 DC_READ_B(TAP, t0);                                                                                   \
@@ -2617,15 +2641,15 @@ __global__ __launch_bounds__(TR / MT * 64, 2) void dense_conv3x3_x9_kernel(const
                 DC_MMA(t0)                                                                                            \
                 DC_T(tc_)                                                                                             \
                 DC_ACC(0, tb_ - ta_) DC_ACC(1, tc_ - tb_)                                                             \
-            }                                                                                                         \
+            } }                                                                                                       \
             DC_T(td_)                                                                                                 \
             if (more2) { if (DEEP) { DC_STORE_B(((TAP) + 2) % 3, S0, S1, S2); } else { DC_STORE_B(((TAP) + 2) % 3, bq0, bq1, bq2); } } \
             DC_T(te_)                                                                                                 \
             __syncthreads();                                                                                          \
             DC_T(tf_)                                                                                                 \
             DC_ACC(2, te_ - td_) DC_ACC(3, tf_ - te_) DC_ACC(4, 1) }
-#define DC_EVEN(TAP, CH) DC_STAGE(TAP, CH, cq0, cq1, cq2, bq0, bq1, bq2)      /* even stage: load set 1, store set 0 */
-#define DC_ODD(TAP, CH) DC_STAGE(TAP, CH, bq0, bq1, bq2, cq0, cq1, cq2)
+#define DC_EVEN(TAP, CH) DC_STAGE(TAP, CH, cq0, cq1, cq2, bq0, bq1, bq2, fa, fb, ga, gb)      /* even stage: load set 1, store set 0 */
+#define DC_ODD(TAP, CH) DC_STAGE(TAP, CH, bq0, bq1, bq2, cq0, cq1, cq2, ga, gb, fa, fb)
         for (int ch = 0; ch < nchunks; ch += 2) {
             DC_CHUNK_HEAD(ch)
             DC_EVEN(0, ch) DC_ODD(1, ch) DC_EVEN(2, ch) DC_ODD(3, ch) DC_EVEN(4, ch) DC_ODD(5, ch) DC_EVEN(6, ch) DC_ODD(7, ch) DC_EVEN(8, ch)
@@ -2754,9 +2778,12 @@ __global__ __launch_bounds__(TR / MT * 64, 2) void dense_conv3x3_x9_kernel(const
 #endif
 #undef DC_READ_A
 #undef DC_READ_B
-#undef DC_MM1
-#undef DC_MH1
-#undef DC_MMA3
+#undef DC_READ_A_
+#undef DC_READ_B_
+#undef DC_MM1_
+#undef DC_MH1_
+#undef DC_MMA3_
+#undef DC_MMA_
 #undef DC_MMA
 #undef DC_LOAD_A
 #undef DC_STORE_A

@@ -1640,18 +1640,22 @@ __global__ __launch_bounds__(256) void sp_conv_halo_kernel(const float* __restri
 extern "C" int64_t gga_sparse_halo_tile_rows(void) { return XH_TM; }
 
 // The tiling sp_conv_halo_kernel walks: one workgroup per tile of 256 rows collects the distinct input rows its kvol x 256
-// rule-book entries name in an LDS hash set (open addressing, 8192 slots >= 27 x 256 entries) and numbers them in the order
-// they arrive - offset by offset, rows in the tile's (spatial) order, so neighbours of adjacent rows get adjacent numbers and
-// the lanes of a wave read adjacent rows of the LDS image. (510 k rows x 128 -> 128, stand-alone: 1.22 - 1.24 ms with this
-// numbering, 1.24 - 1.28 in hash-slot order, 1.18 - 1.19 with the list sorted by row index, i.e. the image requested in
-// address order - a sort of the <= 6912 keys in LDS would buy those 3 %.) The numbering is not reproducible, the result is.
+// rule-book entries name in an LDS hash set (open addressing, 8192 slots >= 27 x 256 entries), numbers them in the order of
+// their row index (a counting rank over the tile's list while it has <= 1024 entries; longer lists keep the order of arrival)
+// and rewrites every entry as its number. Sorted, the tiling is reproducible and a chunk's image is requested in address
+// order; the convolution's time does not depend on it measurably (510 k rows x 128 -> 128, same box: 0.90 - 0.93 of the
+// default kernel's time sorted, in arrival order and with torch-sorted lists alike; hash-slot order: 0.93 - 0.95).
 #define XB_SLOTS 8192
+#define XB_SORT 1024
 __global__ __launch_bounds__(XH_TM) void sp_halo_build_kernel(const int32_t* __restrict__ nbr, const int32_t* __restrict__ tperm,
                                                              int64_t n_rows, int kvol, int hcap, int32_t* __restrict__ hlist_all,
                                                              int32_t* __restrict__ hcount, uint16_t* __restrict__ lmap) {
-    __shared__ int keys[XB_SLOTS];
-    __shared__ uint16_t rank[XB_SLOTS];
-    __shared__ uint16_t slot[XH_KMAX * XH_TM];
+    extern __shared__ __attribute__((aligned(16))) unsigned char xb_smem[];
+    int* const keys = reinterpret_cast<int*>(xb_smem);                              // [XB_SLOTS]
+    int* const lst = keys + XB_SLOTS;                                               // [XB_SORT] the first keys, in arrival order
+    uint16_t* const rank = reinterpret_cast<uint16_t*>(lst + XB_SORT);              // [XB_SLOTS] arrival number of the slot's key
+    uint16_t* const slot = rank + XB_SLOTS;                                         // [XH_KMAX][XH_TM]
+    uint16_t* const remap = slot + XH_KMAX * XH_TM;                                 // [XB_SORT] arrival number -> sorted number
     __shared__ int count;
     const int tid = threadIdx.x;
     const int64_t tile = blockIdx.x;
@@ -1659,7 +1663,6 @@ __global__ __launch_bounds__(XH_TM) void sp_halo_build_kernel(const int32_t* __r
     if (tid == 0) count = 0;
     __syncthreads();
     const int row = tperm[tile * XH_TM + tid];
-    int32_t* const hlist = hlist_all + tile * hcap;
     for (int k = 0; k < kvol; ++k) {
         const int idx = row >= 0 ? nbr[(int64_t)k * n_rows + row] : -1;
         int at = 0xFFFF;
@@ -1670,7 +1673,7 @@ __global__ __launch_bounds__(XH_TM) void sp_halo_build_kernel(const int32_t* __r
                 if (old == -1) {                                       // this thread brought the row in: it numbers it
                     const int nr = atomicAdd(&count, 1);
                     rank[at] = (uint16_t)nr;
-                    if (nr < hcap) hlist[nr] = idx;
+                    if (nr < XB_SORT) lst[nr] = idx;
                     break;
                 }
                 if (old == idx) break;
@@ -1680,11 +1683,29 @@ __global__ __launch_bounds__(XH_TM) void sp_halo_build_kernel(const int32_t* __r
         slot[k * XH_TM + tid] = (uint16_t)at;
     }
     __syncthreads();
-    if (tid == 0) hcount[tile] = count;
+    const int n = count;
+    const bool sorted = n <= XB_SORT;
+    if (sorted)
+        for (int e = tid; e < n; e += XH_TM) {
+            const int key = lst[e];
+            int r = 0;
+            for (int j = 0; j < n; ++j) r += lst[j] < key ? 1 : 0;    // (distinct keys: a permutation of 0 .. n-1)
+            remap[e] = (uint16_t)r;
+        }
+    __syncthreads();
+    if (tid == 0) hcount[tile] = n;
+    int32_t* const hlist = hlist_all + tile * hcap;
+    for (int i = tid; i < XB_SLOTS; i += XH_TM) {
+        const int key = keys[i];
+        if (key >= 0) {
+            const int nr = sorted ? remap[rank[i]] : rank[i];
+            if (nr < hcap) hlist[nr] = key;
+        }
+    }
     uint16_t* const lm = lmap + tile * (int64_t)kvol * XH_TM;
     for (int k = 0; k < kvol; ++k) {
         const int at = slot[k * XH_TM + tid];
-        lm[k * XH_TM + tid] = at == 0xFFFF ? (uint16_t)0xFFFF : rank[at];
+        lm[k * XH_TM + tid] = at == 0xFFFF ? (uint16_t)0xFFFF : (sorted ? remap[rank[at]] : rank[at]);
     }
 }
 
@@ -1695,7 +1716,10 @@ extern "C" int gga_sparse_halo_build(const int32_t* nbr, const int32_t* tile_row
     GGA_REQUIRE(n_rows >= 1 && n_tiles == (n_rows + XH_TM - 1) / XH_TM && kvol >= 1 && kvol <= XH_KMAX && halo_capacity >= kvol * XH_TM,
                 "gga_sparse_halo_build: bad sizes (rows=%lld tiles=%lld kvol=%d capacity=%d; kvol <= 27, capacity >= kvol * 256)",
                 (long long)n_rows, (long long)n_tiles, kvol, halo_capacity);
-    hipLaunchKernelGGL(sp_halo_build_kernel, dim3((unsigned)n_tiles), dim3(XH_TM), 0, (hipStream_t)stream, nbr, tile_rows, n_rows, kvol,
+    constexpr size_t lds = XB_SLOTS * 4 + XB_SORT * 4 + XB_SLOTS * 2 + XH_KMAX * XH_TM * 2 + XB_SORT * 2;
+    static bool once = false;
+    if (!once) { GGA_CHECK_HIP(hipFuncSetAttribute((const void*)sp_halo_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "sp_halo_build_kernel: LDS size"); once = true; }
+    hipLaunchKernelGGL(sp_halo_build_kernel, dim3((unsigned)n_tiles), dim3(XH_TM), lds, (hipStream_t)stream, nbr, tile_rows, n_rows, kvol,
                        halo_capacity, halo_rows, halo_counts, local_map);
     GGA_CHECK_LAUNCH("sp_halo_build_kernel");
     return GGA_OK;

@@ -243,9 +243,19 @@ def test_level_streams_and_prepared_targets_change_nothing(monkeypatch):
         for k in l1:
             assert abs(l1[k] - l0[k]) <= 1e-5 * abs(l0[k]) + 1e-7, (mode, k, l1[k], l0[k])
         assert g1.keys() == g0.keys()
-        for n in g1:  # global float atomics (DCN col2im, target scatter) order their additions differently from run to run, the
-            # one-launch form runs other tile shapes; through the 101 layers below the head (random, un-normalised backbone)
-            assert float((g1[n] - g0[n]).abs().max()) <= 2e-3 * float(g0[n].abs().max()) + 1e-7, (mode, n)
+        # Two steps of the same inputs are not bit-identical (global float atomics in DCN col2im and the target scatter order
+        # their additions differently from run to run; the one-launch form runs other tile shapes), and below the head sit 101
+        # random, un-normalised layers: the run-to-run floor is 2e-3 of a parameter's largest gradient element
+        # (tools_dev/dbg_pgd_modes.py, the same mode twice) - until ONE ReLU decision at an element near zero falls the other
+        # way, which it does in about half the runs whatever the mode: the same alternate gradient then appears (up to 0.1 of
+        # the largest element in ~50 backbone parameters, 2.3e-2 of a parameter's norm, 6.7e-4 of the whole gradient's norm).
+        # The test therefore bounds norms, which a flipped decision moves little and a scheduling bug (a level read before
+        # its stream finished, targets of the wrong level sizes) would not respect.
+        num = sum(float((g1[n] - g0[n]).double().pow(2).sum()) for n in g1) ** 0.5
+        den = sum(float(g0[n].double().pow(2).sum()) for n in g0) ** 0.5
+        assert num <= 2e-3 * den, (mode, num / den)
+        for n in g1:
+            assert float((g1[n] - g0[n]).norm()) <= 5e-2 * float(g0[n].norm()) + 1e-7, (mode, n)
 
 
 @pytest.mark.parametrize('planes', [2, 3])

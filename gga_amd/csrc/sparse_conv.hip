@@ -2031,11 +2031,11 @@ typedef short dw_v4s __attribute__((ext_vector_type(4)));
 #define SPW_SUB 2048
 template <int NI, int NJ, bool VEC, int NP>
 __global__ __launch_bounds__(256, 2) void sp_conv_wgrad_x9_kernel(const float* __restrict__ X, const float* __restrict__ G,
-                                                                 const int32_t* __restrict__ map, int64_t n_rows,
+                                                                 const int32_t* __restrict__ map, int64_t n_rows, int kvol,
                                                                  int64_t rows_per_chunk, int cin, int cout, int64_t xs,
                                                                  int64_t gs, float* __restrict__ partials,
                                                                  const uint32_t* __restrict__ amax_x,
-                                                                 const uint32_t* __restrict__ amax_g) {
+                                                                 const uint32_t* __restrict__ amax_g, int xcd_major) {
     // NP = 3: bf16 planes, six products; NP = 2: fp16 planes of the scaled operands, three (partials stay scaled)
     float xscale = 1.0f, gscale = 1.0f;
     if (NP == 2) { xscale = h2_scale(h2_scale_exp(*amax_x)); gscale = h2_scale(h2_scale_exp(*amax_g)); }
@@ -2058,8 +2058,21 @@ __global__ __launch_bounds__(256, 2) void sp_conv_wgrad_x9_kernel(const float* _
     __shared__ uint16_t pout[SPW_SUB];    //                                          output row (sub-chunk local)
     __shared__ int wtot[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int k = blockIdx.x;                                // offset fastest: the workgroups of one row chunk run together
-    const int64_t c0 = (int64_t)blockIdx.y * rows_per_chunk;  //   and share its X / G rows in the L2
+    // Workgroup -> (offset, row chunk). The kvol workgroups of a chunk read the same G rows (and, on spatially ordered levels,
+    // X rows from the same neighbourhood): they must meet in ONE L2. Workgroups are dealt to the 8 XCDs round robin, so
+    // workgroup b runs on XCD b % 8: chunk c goes to XCD c % 8 and its offsets follow each other there. (xcd_major: this
+    // mapping, grid.x = 8 * ceil(chunks / 8) * kvol; otherwise the plain (offset, chunk) grid of rounds 1-2, where the
+    // offsets of a chunk were spread over all eight L2s and every one of them fetched the chunk: 7.3 GB per launch at
+    // 510 k rows x 128 -> 128 against 0.58 GB algorithmic.)
+    int k = blockIdx.x;
+    int64_t chunk = blockIdx.y;
+    if (xcd_major) {
+        const int q = blockIdx.x >> 3;
+        k = q % kvol;
+        chunk = (int64_t)(q / kvol) * 8 + (blockIdx.x & 7);
+        if (chunk * rows_per_chunk >= n_rows) return;
+    }
+    const int64_t c0 = chunk * rows_per_chunk;
     const int64_t c1 = c0 + rows_per_chunk < n_rows ? c0 + rows_per_chunk : n_rows;
 
     // wave -> (tile group, K-step share)
@@ -2228,7 +2241,7 @@ __global__ __launch_bounds__(256, 2) void sp_conv_wgrad_x9_kernel(const float* _
             for (int v = 0; v < 16; ++v) acc[0][v] += red[(grp_w * 16 + v) * 64 + lane];
     }
     if (!wactive || ks_w != 0) return;
-    float* out = partials + ((int64_t)blockIdx.y * gridDim.x + k) * (CI * CO);
+    float* out = partials + (chunk * kvol + k) * (CI * CO);
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
         const int co = (j0 + t) * 32 + (lane & 31);
@@ -2318,12 +2331,13 @@ extern "C" int gga_sparse_conv_wgrad_planes(const float* x, int64_t x_row_stride
     spw_tiles(cin, cout, ni, nj);
     const int nchunks = spw_chunks(n_rows, kvol);
     const int64_t rpc = spw_rows_per_chunk();                   // whole sub-chunks
-    const dim3 grid(kvol, (unsigned)nchunks), block(256);
+    static const int plain_grid = getenv("GGA_SP_WGRAD_PLAIN_GRID") ? atoi(getenv("GGA_SP_WGRAD_PLAIN_GRID")) : 0;     // A/B switch
+    const dim3 grid = plain_grid ? dim3(kvol, (unsigned)nchunks) : dim3((unsigned)(8 * ((nchunks + 7) / 8) * kvol), 1), block(256);
     const bool vec = (cin & 3) == 0 && (cout & 3) == 0 && (x_row_stride & 3) == 0 && (grad_out_row_stride & 3) == 0 &&
                      ((uintptr_t)x & 15) == 0 && ((uintptr_t)grad_out & 15) == 0;
     hipEvent_t* tev = gga_timing_acquire(GGA_TIME_SPARSE_WGRAD, GGA_TIMING_CONV_KEY(cin, cout, 0));
     GGA_TIME_START(tev, stream);
-#define SW_ARGS grid, block, 0, stream, x, grad_out, map, n_rows, rpc, cin, cout, x_row_stride, grad_out_row_stride, (float*)workspace, amax_x, amax_grad_out
+#define SW_ARGS grid, block, 0, stream, x, grad_out, map, n_rows, kvol, rpc, cin, cout, x_row_stride, grad_out_row_stride, (float*)workspace, amax_x, amax_grad_out, plain_grid ? 0 : 1
 #define SW(NI, NJ) { if (planes == 3) { if (vec) hipLaunchKernelGGL((sp_conv_wgrad_x9_kernel<NI, NJ, true, 3>), SW_ARGS); else hipLaunchKernelGGL((sp_conv_wgrad_x9_kernel<NI, NJ, false, 3>), SW_ARGS); } \
                      else { if (vec) hipLaunchKernelGGL((sp_conv_wgrad_x9_kernel<NI, NJ, true, 2>), SW_ARGS); else hipLaunchKernelGGL((sp_conv_wgrad_x9_kernel<NI, NJ, false, 2>), SW_ARGS); } }
     if (ni == 1 && nj == 1) SW(1, 1)

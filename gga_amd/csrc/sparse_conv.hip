@@ -1744,7 +1744,7 @@ extern "C" int gga_sparse_conv_apply_halo(const float* x, const void* split_weig
     bn.y = bn_x; bn.gamma = bn_gamma; bn.beta = bn_beta; bn.mean = bn_mean; bn.invstd = bn_invstd; bn.ystride = bn_x_row_stride;
     const int64_t stats_rows = (n_rows + X9_TM - 1) / X9_TM;
     const dim3 grid((unsigned)n_tiles), block(256);
-    hipEvent_t* tev = gga_timing_acquire(GGA_TIME_SPARSE_CONV, GGA_TIMING_CONV_KEY(cin, cout, 0));
+    hipEvent_t* tev = gga_timing_acquire(GGA_TIME_SPARSE_CONV, GGA_TIMING_CONV_KEY(cin, cout, kvol));     // (the default kernel's launches: (cin, cout, 0))
     GGA_TIME_START(tev, stream);
 #define XH_LAUNCH(NT) { \
         constexpr size_t lds = (size_t)(XH_HCAP + 1) * 128 + (size_t)4 * 2 * NT * 32 * 64 + XH_KMAX * XH_TM * 2 + XH_HCAP * 4; \

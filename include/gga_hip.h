@@ -51,7 +51,7 @@ int gga_abi_version(void);
 enum {
     GGA_TIME_SCATTER_FWD = 0,   /* gga_pillar_scatter_fwd: NHWC fill [+ map] + rows, NCHW canvas kernel */
     GGA_TIME_DENSE_CONV = 1,    /* gga_dense_conv3x3*: key = GGA_TIMING_CONV_KEY(cin, cout, H*W) */
-    GGA_TIME_SPARSE_CONV = 2,   /* gga_sparse_conv_apply[_split]: key = GGA_TIMING_CONV_KEY(cin, cout, 0) */
+    GGA_TIME_SPARSE_CONV = 2,   /* gga_sparse_conv_apply[_split]: key = GGA_TIMING_CONV_KEY(cin, cout, 0); gga_sparse_conv_apply_halo: (cin, cout, kvol) */
     GGA_TIME_SPARSE_WGRAD = 3,  /* gga_sparse_conv_wgrad: same key */
     GGA_TIME_DENSE_WGRAD = 4,   /* gga_dense_wgrad3x3: key as GGA_TIME_DENSE_CONV */
     GGA_TIME_SITES = 5

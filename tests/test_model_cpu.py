@@ -347,3 +347,13 @@ def test_runner_selects_two_planes_and_prefetch_cache_is_keyed_by_identity():
     assert r._prepared_for(b) is None
     a['points'] = [3]                 # the same dict with other points is not either
     assert r._prepared_for(a) is None
+
+
+def test_runner_inputs_ready_is_a_no_op_without_a_gpu():
+    """Runner.inputs_ready announces resident batches with a stream event; on a CPU device there is no stream and nothing to
+    announce (and nothing recorded that a later prefetch would wait for)."""
+    from gga_amd.train import Runner
+    cfg = Config.fromfile(os.path.join(REPO, 'configs', 'gga', 'gga_kitti_pointpillars_config.py'))
+    r = Runner(build_model(cfg.model), cfg, max_iters=10)
+    r.inputs_ready(dict(points=[1]), dict(points=[2]))
+    assert r._ready == {}

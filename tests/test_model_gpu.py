@@ -439,6 +439,8 @@ def test_second_config_prefetched_front_equals_inline_and_empty_batch():
     ra, rb = Runner(model, cfg, max_iters=100), Runner(twin, cfg, max_iters=100)
     la, lb = [], []
     for i in range(4):
+        if i == 2:                          # from here on the batches are announced as resident: the front waits for their
+            rb.inputs_ready(*batches)       # event only (Runner.inputs_ready), not for the main stream's queue
         torch.manual_seed(100 + i)          # same SRL draws on both sides
         la.append(float(ra.step(batches[i % 2])['loss']))
         torch.manual_seed(100 + i)

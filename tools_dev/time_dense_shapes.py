@@ -1,0 +1,17 @@
+import os, sys, torch
+sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '/root/repo'))
+from gga_amd import dense_conv
+dense_conv.PLANES = 2
+dev = 'cuda:0'
+def t(B, C, Co, H, W):
+    x = torch.randn(B, C, H, W, device=dev).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(Co, C, 3, 3, device=dev) * 0.05).contiguous(memory_format=torch.channels_last)
+    trash = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+    ts = []
+    for i in range(14):
+        trash.fill_(float(i))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); y = dense_conv._run(x, w, False)[0]; e1.record(); torch.cuda.synchronize()
+        if i >= 4: ts.append(e0.elapsed_time(e1))
+    print(f'   [{B},{C}->{Co},{H},{W}] {sum(ts) / len(ts) * 1e3:.0f} us (incl. absmax / pack)')
+t(16, 128, 128, 124, 108); t(16, 128, 64, 124, 108); t(16, 256, 256, 62, 54); t(16, 256, 64, 62, 54); t(16,64,64,248,216)

@@ -2029,6 +2029,19 @@ extern "C" int gga_sparse_conv_wgrad(const float* x, const float* grad_out, cons
 //     the chunks in a fixed order in f64.
 typedef short dw_v4s __attribute__((ext_vector_type(4)));
 #define SPW_SUB 2048
+// Measured on the 510 k-row 128 -> 128 level (round 3, tools_dev/ab_wgrad.sh): a third stage of gathered rows in flight
+// (-DSPW_DEPTH=3, 96 instead of 64 KB per CU) changes nothing, rows in spatial order 3 %, the offsets of a chunk on one XCD
+// 4 %, and without the plane split of the staged rows (-DSPW_ABL_NOSPLIT) the kernel is 16 % faster: a stage is 12 MFMAs per
+// wave behind ~200 vector instructions of split, masking and address arithmetic for its 16 pairs - issue-bound, like the
+// forward kernel's in-register split; the operands would have to arrive as planes to remove it.
+#ifdef SPW_ABL_NOSPLIT                                    /* ablation builds (tools_dev/exp_libs): the words as they are, no arithmetic */
+#define SPW_SPLIT4(V, SC, lo1, lo2, hi1, hi2) { lo1 = __float_as_uint(V.x); lo2 = __float_as_uint(V.y); hi1 = __float_as_uint(V.z); hi2 = __float_as_uint(V.w); }
+#else
+#define SPW_SPLIT4(V, SC, lo1, lo2, hi1, hi2) { h2_split2(V.x * (SC), V.y * (SC), lo1, lo2); h2_split2(V.z * (SC), V.w * (SC), hi1, hi2); }
+#endif
+#ifndef SPW_DEPTH
+#define SPW_DEPTH 2                                      /* stages of gathered rows in flight per workgroup (2 or 3) */
+#endif
 template <int NI, int NJ, bool VEC, int NP>
 __global__ __launch_bounds__(256, 2) void sp_conv_wgrad_x9_kernel(const float* __restrict__ X, const float* __restrict__ G,
                                                                  const int32_t* __restrict__ map, int64_t n_rows, int kvol,
@@ -2096,6 +2109,9 @@ __global__ __launch_bounds__(256, 2) void sp_conv_wgrad_x9_kernel(const float* _
                           F.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) dw_v4s*)((PTR) + froff + 4 * 64)); }
 
     float4 xa[LX], ga[LG], xb[LX], gb_[LG];              // two stages of gathered rows in flight
+#if SPW_DEPTH == 3
+    float4 xc[LX], gc[LG];                               // ... three
+#endif
     for (int64_t r0 = c0; r0 < c1; r0 += SPW_SUB) {
         // ---- ordered compaction of the sub-chunk's valid pairs: thread t owns rows 8t .. 8t+7
         __syncthreads();                                   // previous sub-chunk's readers of pin / pout / images are done
@@ -2156,7 +2172,7 @@ __global__ __launch_bounds__(256, 2) void sp_conv_wgrad_x9_kernel(const float* _
             *reinterpret_cast<uint2*>(dst + (NP - 1) * (PL)) = make_uint2(lo3, hi3);                                 \
         } else {                                                                                                     \
             uint32_t lo1, lo2, hi1, hi2;                                                                             \
-            h2_split2(V.x * (SC), V.y * (SC), lo1, lo2); h2_split2(V.z * (SC), V.w * (SC), hi1, hi2);                \
+            SPW_SPLIT4(V, SC, lo1, lo2, hi1, hi2)                                                                    \
             *reinterpret_cast<uint2*>(dst) = make_uint2(lo1, hi1);                                                   \
             *reinterpret_cast<uint2*>(dst + (PL)) = make_uint2(lo2, hi2);                                            \
         } }
@@ -2204,8 +2220,27 @@ __global__ __launch_bounds__(256, 2) void sp_conv_wgrad_x9_kernel(const float* _
         SW_LOAD(0, xa, ga);
         SW_STORE(0, 0, xa, ga);
         if (PAIRS < np) { SW_LOAD(PAIRS, xb, gb_); }
+#if SPW_DEPTH == 3
+        if (2 * PAIRS < np) { SW_LOAD(2 * PAIRS, xc, gc); }
+#endif
         __syncthreads();
         int buf = 0, p0 = 0;
+#if SPW_DEPTH == 3
+        // stage s: request stage s + 3 into the set stage s was stored from, multiply stage s, store stage s + 1
+#define SW_ITER(XL, GL, XS, GS_)                                                                                     \
+            if (p0 + 3 * PAIRS < np) { SW_LOAD(p0 + 3 * PAIRS, XL, GL); }                                            \
+            SW_COMPUTE(buf)                                                                                          \
+            if (p0 + PAIRS >= np) break;                                                                             \
+            SW_STORE(buf ^ 1, p0 + PAIRS, XS, GS_);                                                                  \
+            __syncthreads();                                                                                         \
+            buf ^= 1; p0 += PAIRS;
+        while (true) {
+            SW_ITER(xa, ga, xb, gb_)
+            SW_ITER(xb, gb_, xc, gc)
+            SW_ITER(xc, gc, xa, ga)
+        }
+#undef SW_ITER
+#else
         while (true) {
             if (p0 + 2 * PAIRS < np) { SW_LOAD(p0 + 2 * PAIRS, xa, ga); }
             SW_COMPUTE(buf)
@@ -2220,6 +2255,7 @@ __global__ __launch_bounds__(256, 2) void sp_conv_wgrad_x9_kernel(const float* _
             __syncthreads();
             buf ^= 1; p0 += PAIRS;
         }
+#endif
     }
 #undef SW_COMPUTE
 #undef SW_MM

@@ -392,3 +392,48 @@ def test_halo_form_of_the_submanifold_convolution(mid, monkeypatch):
     assert calls['halo'] == 2
     for name, a, b in zip(('out', 'BatchNorm sums', 'grad feats', 'grad conv1', 'grad gamma', 'grad beta', 'grad conv2'), got, plain):
         assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-7, name
+
+
+@pytest.mark.parametrize('case', [
+    dict(kernel=(3, 3, 3), cin=32, cout=128, n_cells=0.5, shape=(10, 24, 24), B=2),      # one 32-channel chunk
+    dict(kernel=(3, 3, 3), cin=96, cout=64, n_cells=0.3, shape=(12, 20, 28), B=3),       # three chunks, 64 columns
+    dict(kernel=(1, 3, 3), cin=64, cout=128, n_cells=0.6, shape=(4, 40, 40), B=2),       # nine offsets (a 2D neighbourhood)
+    dict(kernel=(3, 3, 3), cin=128, cout=128, n_cells=0.02, shape=(16, 48, 48), B=1),    # almost no neighbours: mostly empty offsets
+    dict(kernel=(3, 3, 3), cin=64, cout=64, n_cells=0.9, shape=(3, 7, 9), B=1),          # fewer rows than one tile
+])
+@pytest.mark.parametrize('flip', [0, 1])
+def test_halo_entry_point_against_the_default_kernel(case, flip):
+    """gga_sparse_halo_build + gga_sparse_conv_apply_halo called directly (C ABI) against gga_sparse_conv_apply_stats on the same
+    rule book, weights and absmax slots: output rows and the BatchNorm sums, forward (flip 0) and backward-data (flip 1) order of
+    the offsets - channel chunk counts 1 / 2 / 3 / 4, 9 and 27 offsets, dense and nearly empty levels, a level smaller than a tile."""
+    from gga_amd import _lib, dense_conv, functional as F
+    from gga_amd.sparse import _Level, _pack_weight, _Halo
+    torch.manual_seed(3)
+    dev, L = DEV, _lib.lib()
+    B, shape = case['B'], case['shape']
+    coors = (torch.rand(B, *shape) < case['n_cells']).nonzero().int()
+    coors = coors[torch.randperm(len(coors))].contiguous().to(dev)
+    n, cin, cout = coors.shape[0], case['cin'], case['cout']
+    kvol = case['kernel'][0] * case['kernel'][1] * case['kernel'][2]
+    lvl = _Level(coors, shape, B)
+    rb = lvl.subm_rulebook(case['kernel'])
+    halo = _Halo(coors, rb)
+    assert halo.n_tiles == (n + 255) // 256 and int(halo.counts.min()) >= 1
+    x = torch.randn(n, cin, device=dev)
+    w = torch.randn(kvol, cin, cout, device=dev) * 0.1
+    x_amax, w_amax = dense_conv._amax_bits(x), dense_conv._amax_bits(w)
+    wp = _pack_weight(w, kvol, cin, cout, 0, w_amax=w_amax)
+    tiles = int(L.gga_sparse_conv_apply_tiles(n))
+    y0, y1 = torch.empty(n, cout, device=dev), torch.full((n, cout), float('nan'), device=dev)
+    s0 = torch.empty((tiles, 2, cout), dtype=torch.float64, device=dev)
+    s1 = torch.full_like(s0, float('nan'))
+    _lib.check(L.gga_sparse_conv_apply_stats(F._p(x), F._p(rb.nbr), F._p(wp), F._p(rb.perm), F._p(rb.mask), n, kvol, cin, cout, flip,
+                                             F._p(y0), cout, 2, F._p(x_amax), F._p(w_amax), F._p(s0), F._stream()), 'default kernel')
+    _lib.check(L.gga_sparse_conv_apply_halo(F._p(x), F._p(wp), F._p(halo.tile_rows), F._p(halo.counts), halo.capacity, F._p(halo.halo_rows),
+                                            F._p(halo.local_map), n, halo.n_tiles, kvol, cin, cout, flip, F._p(y1), cout, 2, F._p(x_amax),
+                                            F._p(w_amax), F._p(s1), None, 0, None, None, None, None, F._stream()), 'halo form')
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(y1).all()) and bool(torch.isfinite(s1).all()), 'rows or statistics the halo form did not write'
+    assert float((y0 - y1).abs().max()) <= 1e-5 * float(y0.abs().max()) + 1e-9
+    a, b = s0.sum(0), s1.sum(0)
+    assert float((a - b).abs().max()) <= 1e-6 * float(a.abs().max()) + 1e-9

@@ -280,3 +280,31 @@ def test_detector_steps_and_learns_and_tests():
     model.eval()
     res = model.simple_test(data['points'], data['img_metas'])
     assert len(res) == 2 and set(res[0]) >= {'boxes_3d', 'scores_3d', 'labels_3d'}
+
+
+def test_row_selection_helpers_differentiate_like_plain_indexing():
+    """fcaf3d.split_rows / take_rows and mink.take_rows (index_select forward, copy into zeros backward - for index vectors
+    without duplicates) against x[idx]: values and gradients, including rows no index names and an unused output."""
+    from gga_amd import fcaf3d, mink
+    torch.manual_seed(0)
+    x = torch.randn(11, 5, dtype=torch.float64)
+    perms = [torch.tensor([7, 2, 9]), torch.tensor([0, 10]), torch.tensor([4, 1, 3, 8])]      # rows 5 and 6 unnamed
+    w = [torch.randn(len(p), 5, dtype=torch.float64) for p in perms]
+
+    def grads(fn):
+        a = x.clone().requires_grad_(True)
+        outs = fn(a)
+        (outs[0] * w[0]).sum().add((outs[2] * w[2]).sum()).backward()                           # outs[1] unused
+        return [o.detach() for o in outs], a.grad
+
+    ref_o, ref_g = grads(lambda a: [a[p] for p in perms])
+    got_o, got_g = grads(lambda a: fcaf3d.split_rows(a, perms))
+    for r, g in zip(ref_o, got_o):
+        assert torch.equal(r, g)
+    assert torch.equal(ref_g, got_g)
+    for take in (fcaf3d.take_rows, mink.take_rows):
+        a, b = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+        (take(a, perms[2]) * w[2]).sum().backward()
+        (b[perms[2]] * w[2]).sum().backward()
+        assert torch.equal(a.grad, b.grad)
+    assert torch.equal(fcaf3d.take_rows(x, perms[0]), x[perms[0]])                               # no autograd: plain indexing

@@ -1427,7 +1427,7 @@ __global__ __launch_bounds__(256) void sp_conv_halo_kernel(const float* __restri
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) pr[rb] = tperm[tile * TM + (wave * RB + rb) * 32 + r];
     const int32_t* const hlist = hlist_all + tile * hcap;
-    const int hn = hcount[tile];                          // >= 1: a row is its own centre neighbour
+    const int hn = hcount[tile];                          // (submanifold maps: >= 1, a row is its own centre neighbour)
 #ifdef XH_TIMING
     unsigned long long tlast_ = wall_clock64(), tacc_[6] = {0, 0, 0, 0, 0, 0};
 #endif
@@ -1436,7 +1436,7 @@ __global__ __launch_bounds__(256) void sp_conv_halo_kernel(const float* __restri
         const uint4* src = reinterpret_cast<const uint4*>(lmap + tile * (int64_t)kvol * TM);
         const int pieces = kvol * TM / 8;
         for (int i = tid; i < pieces; i += THREADS) reinterpret_cast<uint4*>(lm)[i] = src[i];
-        for (int i = tid; i < HCAP; i += THREADS) hl[i] = hlist[i < hn ? i : hn - 1];
+        for (int i = tid; i < HCAP; i += THREADS) hl[i] = hn > 0 ? hlist[i < hn ? i : hn - 1] : 0;     // (a tile without any entry: row 0, never read)
         if (tid < 32) reinterpret_cast<uint32_t*>(smem + HCAP * 128)[tid] = 0u;
     }
     __syncthreads();

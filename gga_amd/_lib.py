@@ -87,6 +87,8 @@ SIGNATURES = {
     'gga_sparse_conv_apply_stats': (i32, [vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp, i64, i32, vp, vp, vp, vp]),
     'gga_sparse_conv_apply_tiles': (i64, [i64]),
     'gga_sparse_conv_apply_bn_bwd': (i32, [vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp, i64, i32, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp]),
+    'gga_sparse_bev_nhwc_fwd': (i32, [vp, vp, i64, i32, i32, i32, i32, i32, vp, vp]),
+    'gga_sparse_bev_nhwc_bwd': (i32, [vp, vp, i64, i32, i32, i32, i32, i32, vp, vp]),
     'gga_sparse_halo_tile_rows': (i64, []),
     'gga_sparse_halo_build': (i32, [vp, vp, i64, i64, i32, i32, vp, vp, vp, vp]),
     'gga_sparse_conv_apply_halo': (i32, [vp, vp, vp, vp, i32, vp, vp, i64, i64, i32, i32, i32, i32, vp, i64, i32, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp]),

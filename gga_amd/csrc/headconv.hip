@@ -210,6 +210,10 @@ __global__ __launch_bounds__(512, HW_MINW) void headconv_wgrad_kernel(const floa
     const float sf0 = in_ss ? in_ss[HC_CIN + m] : 0.0f, sf1 = in_ss ? in_ss[HC_CIN + 32 + m] : 0.0f;
     const float lo = in_ss ? 0.0f : -INFINITY;
     for (int i = threadIdx.x; i < 2 * COUT * HW_PR * HW_PC; i += 512) (&gds[0][0])[i] = 0.0f;    // borders stay zero
+    // (the zeroes must have landed before anyone stages the first tile into the same words: without this barrier a wave that
+    // was held up in the loop above could wipe values another wave had already staged - seen once in ~2000 steps, and only with
+    // a second stream's kernels sharing the CU: one tile's dy partly zeroed, 3e-3 of the branch's weight gradient)
+    __syncthreads();
     acc16 acc0, acc1;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { acc0[i] = 0.0f; acc1[i] = 0.0f; }

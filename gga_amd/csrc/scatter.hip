@@ -379,6 +379,66 @@ __global__ __launch_bounds__(256) void pillar_conv_map_kernel(const int4* __rest
     map[(int64_t)k * m + r] = v;
 }
 
+// ------------------------------------------------------------------------------ sparse sites -> channels-last BEV map
+// SparseEncoder's handover (middle_encoders/sparse_encoder.py:134-138: out.dense() -> view(N, C * D, H, W)) written straight
+// into channels-last memory: site (b, d, y, x) with features f[c] owns out[b][y][x][c * D + d], c < C - 4-byte stores at a
+// stride of D floats inside the pixel's C * D-float row. The canvas is zeroed by the caller's stream-ordered memset. Before,
+// the map was scattered in NCHW (322 us at 8 x 256 x 200 x 176), copied to channels-last, and its gradient copied back and
+// gathered with a stride of H * W floats per channel (635 us): 1.2 ms of the shipped config's 58 ms step.
+__global__ __launch_bounds__(256) void sparse_bev_nhwc_fwd_kernel(const float4* __restrict__ f, const int4* __restrict__ coors,
+                                                                int64_t n, int c4n, int D, int H, int W, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n * c4n) return;
+    const int64_t row = i / c4n;
+    const int c4 = (int)(i - row * c4n);
+    const int4 c = coors[row];                               // (b, z, y, x)
+    const float4 v = f[i];
+    float* dst = out + (((int64_t)c.x * H + c.z) * W + c.w) * (4 * c4n * D) + (int64_t)(4 * c4) * D + c.y;
+    dst[0] = v.x; dst[D] = v.y; dst[2 * D] = v.z; dst[3 * D] = v.w;
+}
+
+__global__ __launch_bounds__(256) void sparse_bev_nhwc_bwd_kernel(const float* __restrict__ g, const int4* __restrict__ coors,
+                                                                int64_t n, int c4n, int D, int H, int W, float4* __restrict__ gf) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n * c4n) return;
+    const int64_t row = i / c4n;
+    const int c4 = (int)(i - row * c4n);
+    const int4 c = coors[row];
+    const float* src = g + (((int64_t)c.x * H + c.z) * W + c.w) * (4 * c4n * D) + (int64_t)(4 * c4) * D + c.y;
+    gf[i] = make_float4(src[0], src[D], src[2 * D], src[3 * D]);
+}
+
+extern "C" int gga_sparse_bev_nhwc_fwd(const float* feats, const int32_t* coors, int64_t n, int batch, int channels, int depth,
+                                       int height, int width, float* out, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    GGA_REQUIRE(out && batch >= 1 && channels >= 4 && channels % 4 == 0 && depth >= 1 && height >= 1 && width >= 1 && n >= 0,
+                "gga_sparse_bev_nhwc_fwd: bad sizes (channels %% 4 == 0)");
+    GGA_CHECK_HIP(hipMemsetAsync(out, 0, (size_t)batch * height * width * channels * depth * sizeof(float), stream),
+                  "gga_sparse_bev_nhwc_fwd: memset");
+    if (n == 0) return GGA_OK;
+    GGA_REQUIRE(feats && coors && ((uintptr_t)feats & 15) == 0 && ((uintptr_t)coors & 15) == 0, "gga_sparse_bev_nhwc_fwd: null or unaligned pointer");
+    const int64_t total = n * (channels / 4);
+    hipLaunchKernelGGL(sparse_bev_nhwc_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
+                       (const float4*)feats, (const int4*)coors, n, channels / 4, depth, height, width, out);
+    GGA_CHECK_LAUNCH("sparse_bev_nhwc_fwd_kernel");
+    return GGA_OK;
+}
+
+extern "C" int gga_sparse_bev_nhwc_bwd(const float* grad_out, const int32_t* coors, int64_t n, int batch, int channels, int depth,
+                                       int height, int width, float* grad_feats, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    GGA_REQUIRE(batch >= 1 && channels >= 4 && channels % 4 == 0 && depth >= 1 && height >= 1 && width >= 1 && n >= 0,
+                "gga_sparse_bev_nhwc_bwd: bad sizes (channels %% 4 == 0)");
+    if (n == 0) return GGA_OK;
+    GGA_REQUIRE(grad_out && coors && grad_feats && ((uintptr_t)grad_feats & 15) == 0 && ((uintptr_t)coors & 15) == 0,
+                "gga_sparse_bev_nhwc_bwd: null or unaligned pointer");
+    const int64_t total = n * (channels / 4);
+    hipLaunchKernelGGL(sparse_bev_nhwc_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, grad_out,
+                       (const int4*)coors, n, channels / 4, depth, height, width, (float4*)grad_feats);
+    GGA_CHECK_LAUNCH("sparse_bev_nhwc_bwd_kernel");
+    return GGA_OK;
+}
+
 extern "C" int gga_pillar_conv_map(const int32_t* coors, int64_t m, const int32_t* num_valid, int batch, int ny, int nx,
                                    int kh, int kw, int stride_h, int stride_w, int pad_h, int pad_w, int32_t* map,
                                    void* stream) {

@@ -329,6 +329,37 @@ class _PillarScatter(torch.autograd.Function):
         return gf, None, None, None, None, None, None, None
 
 
+class _SparseBEV(torch.autograd.Function):
+    """[n, C] features of distinct sites (b, z, y, x) -> [B, C * D, H, W] in channels-last memory, channel c * D + z
+    (gga_sparse_bev_nhwc_fwd / _bwd)."""
+
+    @staticmethod
+    def forward(ctx, feats, coors, B, D, H, W):
+        _need_cuda(feats, coors)
+        feats, coors = feats.contiguous(), coors.contiguous()
+        n, C_ = feats.shape
+        out = torch.empty((B, H, W, C_ * D), dtype=torch.float32, device=feats.device)
+        check(_lib.lib().gga_sparse_bev_nhwc_fwd(_p(feats), _p(coors), n, B, C_, D, H, W, _p(out), _stream()), 'gga_sparse_bev_nhwc_fwd')
+        ctx.save_for_backward(coors)
+        ctx.geom = (n, B, C_, D, H, W)
+        return out.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, g):
+        coors, = ctx.saved_tensors
+        n, B, C_, D, H, W = ctx.geom
+        g = g.contiguous(memory_format=torch.channels_last)
+        gf = torch.empty((n, C_), dtype=torch.float32, device=g.device)
+        check(_lib.lib().gga_sparse_bev_nhwc_bwd(_p(g), _p(coors), n, B, C_, D, H, W, _p(gf), _stream()), 'gga_sparse_bev_nhwc_bwd')
+        return gf, None, None, None, None, None
+
+
+def sparse_bev_channels_last(feats, coors, batch_size, D, H, W):
+    """``SparseConvTensor.dense().view(N, C * D, H, W)`` of middle_encoders/sparse_encoder.py:134-138 as a channels-last tensor,
+    without the NCHW map and the two layout copies in between (f32 CUDA features with C % 4 == 0, int32 coors, distinct sites)."""
+    return _SparseBEV.apply(feats, coors, int(batch_size), int(D), int(H), int(W))
+
+
 def pillar_scatter(feats, coors, batch_size, ny, nx, channels_last=False, num_valid=None, unique=False):
     """[M,C] pillar features + coors (b,z,y,x) -> dense [B,C,ny,nx] canvas. ``unique``: the caller
     guarantees distinct (b,y,x) (voxelizer output, sparse sites); otherwise the highest row of a

@@ -317,6 +317,7 @@ HALO_MIN_ROWS = int(os.environ.get('GGA_SP_HALO_MIN_ROWS', '65536'))
 HALO_MIN_OCCUPANCY = float(os.environ.get('GGA_SP_HALO_MIN_OCCUPANCY', '0.25'))
 
 
+
 def planes():
     """Arithmetic of the split-plane gather kernels: 2 = two fp16 planes of the scaled operands / three partial
     products, 3 = three bf16 planes / six (dense_conv.PLANES, one switch for all matrix kernels)."""

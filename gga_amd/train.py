@@ -287,7 +287,7 @@ class Runner:
         """Declare that the tensors of ``batches`` are (or will be, in stream order) complete on the current stream NOW:
         one event, which ``prefetch`` of such a batch waits for instead of the whole main stream. Call it once after the
         uploads of the batches a loop cycles through (``run`` does)."""
-        if self.device.type != 'cuda':
+        if self.device.type != 'cuda' or os.environ.get('GGA_INPUTS_READY') == '0':      # (0: A/B switch - every prefetch waits for the stream)
             return
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.device))

@@ -212,6 +212,15 @@ int gga_pillar_scatter_bwd(const float* grad_canvas, const int32_t* coors, int64
                            const int32_t* num_valid, int batch, int channels, int ny, int nx,
                            int layout, float* grad_feats, void* stream);
 
+/* SparseEncoder's handover to the 2D backbone (middle_encoders/sparse_encoder.py:134-138: spatial_features =
+ * out.dense().view(N, C * D, H, W)) in channels-last memory: out [batch, height, width, channels * depth] f32 with
+ * out[b][y][x][c * depth + z] = feats[row][c] for the site coors[row] = (b, z, y, x), zeros elsewhere (the call zeroes out);
+ * distinct sites. _bwd: grad_feats [n, channels] gathered from the map's gradient in the same layout. channels % 4 == 0. */
+int gga_sparse_bev_nhwc_fwd(const float* feats, const int32_t* coors, int64_t n, int batch, int channels, int depth, int height,
+                            int width, float* out, void* stream);
+int gga_sparse_bev_nhwc_bwd(const float* grad_out, const int32_t* coors, int64_t n, int batch, int channels, int depth,
+                            int height, int width, float* grad_feats, void* stream);
+
 /* Gather map of a dense 2D convolution (kernel kh x kw, given stride / zero padding, dilation 1)
  * over the canvas, restricted to its occupied cells: map[k = ky*kw + kx][r] = row of the NHWC
  * convolution output [batch*oh*ow, C] that read pillar r through tap (ky, kx), or -1

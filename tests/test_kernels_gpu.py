@@ -1010,3 +1010,36 @@ def test_dense_conv3x3_non_finite_and_wide_range(planes, monkeypatch):
     bad = ~torch.isfinite(rn)
     assert bad.any() and torch.equal(~torch.isfinite(yn), bad)
     assert torch.equal(yn[~bad], y0[~bad])                          # every other output is bit-identical
+
+
+@pytest.mark.parametrize('cout', [1, 3])
+def test_head_output_conv_weight_gradient_is_repeatable_beside_another_stream(cout):
+    """The weight gradient of the head's output convolutions, repeated while a second (high-priority) stream keeps kernels
+    running on the same CUs, is the same bits every time. (Round 3 found the kernel staging the first tile's grad_y into LDS
+    words that other waves were still zeroing - no barrier between the two: once in ~2000 train steps, and only with the
+    next batch's front running beside the step, one tile's gradient was partly wiped: 3e-3 of a branch's weight gradient.)"""
+    torch.manual_seed(40 + cout)
+    B, H, W = 8, 200, 176
+    conv = torch.nn.Conv2d(64, cout, 3, padding=1, bias=True).to(DEV)
+    x = torch.randn(B, 64, H, W, device=DEV).contiguous(memory_format=torch.channels_last)
+    g = torch.randn(B, cout, H, W, device=DEV)
+    side = torch.cuda.Stream(priority=-1)
+    noise = torch.randn(1 << 22, device=DEV)
+    keys = torch.randint(0, 1 << 30, (1 << 20,), device=DEV)
+    ref = None
+    for it in range(40):
+        xi = x.clone().requires_grad_(True)
+        conv.weight.grad = conv.bias.grad = None
+        y = F.head_conv3x3(xi, conv)
+        if it >= 5:
+            with torch.cuda.stream(side):
+                for _ in range(6):
+                    noise.mul_(1.0001)
+                    torch.sort(keys)
+        y.backward(g)
+        torch.cuda.synchronize()
+        got = (conv.weight.grad.clone(), conv.bias.grad.clone())
+        if ref is None:
+            ref = got
+        else:
+            assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), it

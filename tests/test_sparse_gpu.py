@@ -437,3 +437,42 @@ def test_halo_entry_point_against_the_default_kernel(case, flip):
     assert float((y0 - y1).abs().max()) <= 1e-5 * float(y0.abs().max()) + 1e-9
     a, b = s0.sum(0), s1.sum(0)
     assert float((a - b).abs().max()) <= 1e-6 * float(a.abs().max()) + 1e-9
+
+
+def test_sparse_map_straight_into_channels_last_memory():
+    """functional.sparse_bev_channels_last (gga_sparse_bev_nhwc_fwd / _bwd) against SparseConvTensor.dense().view(N, C * D, H, W):
+    values, memory format and the gradient of the features - and SparseEncoder(channels_last=True) through it equals the
+    NCHW-scatter-then-copy path of rounds 1-2 bit for bit, forward and backward."""
+    import copy
+    from gga_amd import functional as F, sparse, sparse_encoder
+    torch.manual_seed(2)
+    B, shape, C = 3, (2, 25, 19), 128
+    coors = (torch.rand(B, *shape) < 0.3).nonzero().int()
+    coors = coors[torch.randperm(len(coors))].contiguous().to(DEV)
+    f = torch.randn(len(coors), C, device=DEV, requires_grad=True)
+    f2 = f.detach().clone().requires_grad_(True)
+    ref = sparse.SparseConvTensor(f2, coors, shape, B).dense().view(B, C * shape[0], shape[1], shape[2])
+    got = F.sparse_bev_channels_last(f, coors, B, *shape)
+    assert got.shape == ref.shape and got.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(got, ref)
+    g = torch.randn_like(ref)
+    got.backward(g.contiguous(memory_format=torch.channels_last))
+    ref.backward(g)
+    assert torch.equal(f.grad, f2.grad)
+    # the encoder, both ways
+    enc = SparseEncoder(in_channels=4, sparse_shape=[41, 64, 64], order=('conv', 'norm', 'act'), channels_last=True).to(DEV)
+    c0 = torch.unique(torch.stack([torch.randint(0, 2, (3000,)), torch.randint(0, 41, (3000,)), torch.randint(0, 64, (3000,)),
+                                   torch.randint(0, 64, (3000,))], 1), dim=0).int().to(DEV)
+    v = torch.randn(len(c0), 4, device=DEV)
+    outs = []
+    for direct in (True, False):
+        sparse_encoder.DIRECT_BEV = direct
+        e = copy.deepcopy(enc)
+        y = e(v, c0, 2)
+        assert y.is_contiguous(memory_format=torch.channels_last)
+        y.backward(torch.linspace(-1, 1, y.numel(), device=DEV).view(y.shape).contiguous(memory_format=torch.channels_last))
+        outs.append((y.detach(), [p.grad.clone() for p in e.parameters()]))
+    sparse_encoder.DIRECT_BEV = True
+    assert torch.equal(outs[0][0], outs[1][0])
+    for a, b in zip(outs[0][1], outs[1][1]):
+        assert torch.equal(a, b)

@@ -6,7 +6,7 @@ import torch
 import bench
 from gga_amd import sparse
 res = {}
-for halo in (0, 1, 0):
+for halo in tuple(int(v) for v in os.environ.get("GGA_DBG_SEQ", "0,1,0").split(",")):
     sparse.HALO = halo
     args = bench.parse_args(['--batch', '8', '--steps', '1', '--warmup', '0', '--no-cpu-baseline', '--no-roofline'])
     torch.manual_seed(0)

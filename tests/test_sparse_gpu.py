@@ -446,7 +446,7 @@ def test_sparse_map_straight_into_channels_last_memory():
     import copy
     from gga_amd import functional as F, sparse, sparse_encoder
     torch.manual_seed(2)
-    B, shape, C = 3, (2, 25, 19), 128
+    B, shape, C = 3, (2, 26, 20), 128
     coors = (torch.rand(B, *shape) < 0.3).nonzero().int()
     coors = coors[torch.randperm(len(coors))].contiguous().to(DEV)
     f = torch.randn(len(coors), C, device=DEV, requires_grad=True)

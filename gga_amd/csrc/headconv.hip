@@ -213,7 +213,9 @@ __global__ __launch_bounds__(512, HW_MINW) void headconv_wgrad_kernel(const floa
     // (the zeroes must have landed before anyone stages the first tile into the same words: without this barrier a wave that
     // was held up in the loop above could wipe values another wave had already staged - seen once in ~2000 steps, and only with
     // a second stream's kernels sharing the CU: one tile's dy partly zeroed, 3e-3 of the branch's weight gradient)
+#ifndef HW_ABL_NO_INIT_BARRIER          /* (experiment build: the round-1/2 kernel, to show that tools_dev/dbg_replay_noise.py finds it) */
     __syncthreads();
+#endif
     acc16 acc0, acc1;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { acc0[i] = 0.0f; acc1[i] = 0.0f; }

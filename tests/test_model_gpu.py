@@ -556,3 +556,15 @@ def test_native_library_is_the_compute_path():
     _lib.lib()
     maps = open('/proc/self/maps').read()
     assert os.path.join(REPO, 'gga_amd', 'libgga_hip.so') in maps or 'libgga_hip.so' in maps
+
+
+@pytest.mark.parametrize('which', ['pp', 'second'])
+def test_train_step_is_repeatable_beside_another_stream(which):
+    """Twins of a short run of each LiDAR config at the bench's size: one quiet, the others with a second, high-priority stream
+    keeping small kernels on the same CUs (tools_dev/dbg_replay_noise.py). No kernel of these steps sums with float atomics, so
+    every twin reproduces the quiet run's losses bit for bit; a kernel with a missing barrier (round 3 found one: the head
+    output convolution's weight gradient, 18 of 60 such twins of the sparse config differed) shows up as a twin that does not."""
+    import sys
+    sys.path.insert(0, os.path.join(REPO, 'tools_dev'))
+    import dbg_replay_noise
+    assert dbg_replay_noise.hunt(which, steps=5, twins=12, quiet=True) == 0

@@ -1043,3 +1043,64 @@ def test_head_output_conv_weight_gradient_is_repeatable_beside_another_stream(co
             ref = got
         else:
             assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), it
+
+
+def _repeat_beside_noise(fn, repeats=30):
+    """Run ``fn`` (-> tuple of tensors) ``repeats`` times, from the sixth on beside a high-priority stream of small kernels;
+    every result must equal the first one bit for bit."""
+    side = torch.cuda.Stream(priority=-1)
+    noise = torch.randn(1 << 22, device=DEV)
+    keys = torch.randint(0, 1 << 30, (1 << 20,), device=DEV)
+    ref = None
+    for it in range(repeats):
+        if it >= 5:
+            with torch.cuda.stream(side):
+                for _ in range(6):
+                    noise.mul_(1.0001)
+                    torch.sort(keys)
+                    torch.cumsum(noise, 0)
+        got = [t.clone() for t in fn()]
+        torch.cuda.synchronize()
+        if ref is None:
+            ref = got
+        else:
+            for a, b in zip(got, ref):
+                assert torch.equal(a, b), it
+
+
+@pytest.mark.parametrize('planes', [2, 3])
+def test_matrix_and_norm_kernels_are_repeatable_beside_another_stream(planes, monkeypatch):
+    """The kernels of the camera-only step that the LiDAR twins do not reach, and the dense / strided convolutions at other
+    shapes, each repeated beside a busy second stream: fused GroupNorm + ReLU forward / backward, the dense 3x3 convolution with
+    256 -> 256 channels (two output slices per launch) forward / backward / weight gradient, a stride-2 3x3 and a 1x1
+    convolution on the gather-GEMM kernels. Bit-identical every time (none of them adds with float atomics)."""
+    from gga_amd import dense_conv, strided_conv
+    monkeypatch.setattr(dense_conv, 'PLANES', planes)
+    torch.manual_seed(5)
+    x = torch.randn(4, 256, 48, 156, device=DEV).contiguous(memory_format=torch.channels_last)
+    gn = torch.nn.GroupNorm(32, 256).to(DEV)
+    conv = torch.nn.Conv2d(256, 256, 3, padding=1, bias=False).to(DEV)
+    down = torch.nn.Conv2d(256, 128, 3, stride=2, padding=1, bias=False).to(DEV)
+    one = torch.nn.Conv2d(256, 64, 1, bias=False).to(DEV)
+    g = torch.randn(4, 256, 48, 156, device=DEV).contiguous(memory_format=torch.channels_last)
+
+    def gn_pass():
+        xi = x.clone().requires_grad_(True)
+        gn.weight.grad = gn.bias.grad = None
+        y = F.gn_act(xi, gn, relu=True)
+        y.backward(g)
+        return y.detach(), xi.grad, gn.weight.grad, gn.bias.grad
+
+    def conv_pass(m):
+        def run():
+            xi = x.clone().requires_grad_(True)
+            m.weight.grad = None
+            y = dense_conv.conv2d(xi, m) if m is conv else strided_conv.conv(xi, m)
+            y.backward(torch.ones_like(y) * 0.5 + y.detach() * 0.1)
+            return y.detach(), xi.grad, m.weight.grad
+        return run
+
+    assert dense_conv.eligible(conv, x) and strided_conv.eligible(down, x) and strided_conv.eligible(one, x)
+    _repeat_beside_noise(gn_pass)
+    for m in (conv, down, one):
+        _repeat_beside_noise(conv_pass(m), repeats=20)

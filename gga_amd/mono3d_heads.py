@@ -14,6 +14,7 @@ per-level top-k, decoding, then per-class BEV NMS on the rotated-NMS kernel (``o
 import math
 
 import numpy as np
+import os
 import torch
 from torch import nn
 
@@ -26,6 +27,34 @@ from .cnn import ConvModule
 from .registry import HEADS, build_bbox_coder, build_loss
 
 INF = 1e8
+
+
+class _ShareParams(torch.autograd.Function):
+    """``n`` aliases of every parameter (level-major: alias c of parameter i is output c * P + i). Backward: the aliases'
+    gradients added with multi-tensor launches (a gradient that never arrived - a parameter one level does not use - is
+    skipped), on the stream this node was made on."""
+
+    @staticmethod
+    def forward(ctx, n, *params):
+        ctx.n, ctx.P = n, len(params)
+        ctx.set_materialize_grads(False)       # an alias nobody differentiated through stays None (no zero tensors, no zero gradients)
+        return tuple(p.detach() for _ in range(n) for p in params)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        n, P = ctx.n, ctx.P
+        total = [None] * P
+        for c in range(n):
+            have = [i for i in range(P) if gs[c * P + i] is not None]
+            first = [i for i in have if total[i] is None]
+            more = [i for i in have if total[i] is not None]
+            if more:
+                summed = torch._foreach_add([total[i] for i in more], [gs[c * P + i] for i in more])
+                for i, t in zip(more, summed):
+                    total[i] = t
+            for i in first:
+                total[i] = gs[c * P + i]
+        return (None,) + tuple(total)
 
 
 class Scale(nn.Module):
@@ -388,13 +417,22 @@ class PGDHead(FCOSMono3DHead):
         # meet, so a parameter's gradient is accumulated on the main stream like everywhere else in the model (and under
         # DistributedDataParallel the reducer's hooks see one stream). Without it autograd accumulates on whichever level
         # stream delivers first and says so ("AccumulateGrad node's stream does not match ...").
+        # Every level gets aliases of its OWN (_ShareParams): the five gradients of a parameter then arrive as five inputs of one
+        # backward node, which adds them with four multi-tensor launches for ALL parameters - one shared alias made autograd add
+        # them one by one as they came in (4 additions per parameter, ~400 of the step's 626 small add kernels: 9 ms of 235).
         from torch.nn.utils import stateless
-        alias = {k: p.view_as(p) for k, p in self.named_parameters() if p.requires_grad} if torch.is_grad_enabled() else {}
+        named = [(k, p) for k, p in self.named_parameters() if p.requires_grad] if torch.is_grad_enabled() else []
+        if named and os.environ.get('GGA_PGD_SHARED_ALIAS') == '1':       # (A/B: the one alias per parameter of round 3's first form)
+            one = [p.view_as(p) for _, p in named]
+            copies = tuple(one) * len(feats)
+        else:
+            copies = _ShareParams.apply(len(feats), *[p for _, p in named]) if named else ()
         outs = []
-        for x, scale, stride, st in zip(feats, self.scales, self.strides, streams):
+        for li, (x, scale, stride, st) in enumerate(zip(feats, self.scales, self.strides, streams)):
             if st is not main:
                 st.wait_stream(main)
                 x.record_stream(st)
+            alias = {k: copies[li * len(named) + i] for i, (k, _) in enumerate(named)}
             with torch.cuda.stream(st), stateless._reparametrize_module(self, alias):
                 o = self.forward_single(x, scale, stride)
             if st is not main:

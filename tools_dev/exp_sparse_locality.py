@@ -58,7 +58,7 @@ def unions(mask_sorted, g, kvol=27):
 
 
 for li, (lvl, C_) in enumerate(levels):
-    if C_ < 128 or li != 3:
+    if li != int(os.environ.get("GGA_EXP_LEVEL", "3")):
         continue
     coors = lvl.coors
     nrow = lvl.n

@@ -2436,6 +2436,10 @@ extern "C" int gga_debug_dc_probe(unsigned long long* out) {
 #ifndef DC_PIPE_ON
 #define DC_PIPE_ON 1
 #endif
+#ifndef DC_PIPE4_ON
+#define DC_PIPE4_ON 1
+#endif
+#define DC_P4_MAX_TILES 256                       /* launches of at most this many tiles take the one-workgroup-per-CU form */
 #define DC_TR 8
 #define DC_TW 32
 #define DC_HW (DC_TW + 2)
@@ -2488,8 +2492,13 @@ struct DcLevels {
     int transposed;                          // every entry walks its map transposed (tiles 32 pixels long along the image's H)
 };
 
-template <int NT, int TR, int NP, int MT>
-__global__ __launch_bounds__(TR / MT * 64, 2) void dense_conv3x3_x9_kernel(const float* __restrict__ X, const uint16_t* __restrict__ Wp,
+// (P4 form, round 3: 128 output channels in 8-row tiles on two fp16 planes with ONE workgroup per CU, so that its four waves, one
+// per SIMD, have 512 registers each: room for the 128 accumulators AND two sets of the 12 fragments of a stage, see PIPE below.
+// Measured against the two-workgroups-per-CU form of the same tile: launches of at most one tile per CU - the small FPN levels
+// of the camera-only head, 62 x 54 maps - 69 against 83 us and 63 against 77; launches with more tiles than CUs 265 against 248
+// and 217 against 202, where the second workgroup hides more than the pipelining wins. The launcher picks by tile count.)
+template <int NT, int TR, int NP, int MT, int P4 = 0>
+__global__ __launch_bounds__(TR / MT * 64, (P4 && NT == 4 && TR == 8 && NP == 2 && MT == 2) ? 1 : 2) void dense_conv3x3_x9_kernel(const float* __restrict__ X, const uint16_t* __restrict__ Wp,
                                                                  int B, int H, int W, int cin, int cout, int tiles_x,
                                                                  int tiles_y, float* __restrict__ Y, int ystride,
                                                                  int prow, int pcol, double* __restrict__ stats,
@@ -2603,8 +2612,10 @@ __global__ __launch_bounds__(TR / MT * 64, 2) void dense_conv3x3_x9_kernel(const
     // this measured). The weights of stage s + 1 are in LDS since the barrier before stage s (they are written a stage
     // early), the halo image is constant over a chunk; the first offset of a chunk reads its own fragments.
     constexpr bool PIPE = DC_PIPE_ON && NT == 2 && MT == 2 && NP == 2;       // (three planes: the second set spills)
+    constexpr bool PIPE4 = P4 && NT == 4 && TR == 8 && NP == 2 && MT == 2;
     mf_v8bf fa[MT][NP], fb[2][NP];
     mf_v8bf ga[MT][NP], gb[2][NP];
+    mf_v8bf fb2[2][NP], gb2[2][NP];                      // PIPE4: the B fragments of N tiles 2 and 3
 #define DC_READ_A_(FA, TAP) {                                                                                         \
         const unsigned char* Ap = As + ((MT * wave + (TAP) / 3) * DC_HW + r + (TAP) % 3) * DC_ROWB + h * 16;           \
         _Pragma("unroll") for (int m = 0; m < MT; ++m) _Pragma("unroll") for (int p = 0; p < NP; ++p)                 \
@@ -2684,7 +2695,7 @@ __global__ __launch_bounds__(TR / MT * 64, 2) void dense_conv3x3_x9_kernel(const
                 DC_AOFF(nb_, ny0, nx0)                                                                                \
                 DC_LOAD_A(0);                                                                                         \
             }
-#define DC_STAGE(TAP, CH, L0, L1, L2, S0, S1, S2, CA, CB, XA, XB) {                                                   \
+#define DC_STAGE(TAP, CH, L0, L1, L2, S0, S1, S2, CA, CB, XA, XB, CB2, XB2) {                                         \
             const bool last_chunk = (CH) + 1 >= nchunks;                                                              \
             const bool more3 = (TAP) + 3 < 9 || !last_chunk || more_tiles;     /* a stage three ahead exists */       \
             const bool more2 = (TAP) + 2 < 9 || !last_chunk || more_tiles;                                            \
@@ -2698,7 +2709,16 @@ __global__ __launch_bounds__(TR / MT * 64, 2) void dense_conv3x3_x9_kernel(const
                 else { DC_LOAD_B((TAP) + 2 - 9, last_chunk ? 0 : (CH) + 1, bq0, bq1, bq2); }                          \
             }                                                                                                         \
             DC_T(ta_)                                                                                                 \
-            if (PIPE) {                                                                                               \
+            if (PIPE4) {                                                                                              \
+                if ((TAP) == 0) { DC_READ_A_(CA, 0); DC_READ_B_(CB, 0, 0); DC_READ_B_(CB2, 0, 2); }                    \
+                if ((TAP) < 8) { DC_READ_A_(XA, (TAP) + 1); DC_READ_B_(XB, (TAP) + 1, 0); DC_READ_B_(XB2, (TAP) + 1, 2); } \
+                DC_MMA_(CA, CB, 0)                                                                                    \
+                DC_MMA_(CA, CB2, 2)                                                                                   \
+                if ((TAP) < 8) {                                                                                      \
+                    _Pragma("unroll") for (int g_ = 0; g_ < 12; ++g_) {                                               \
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); } \
+                }                                                                                                     \
+            } else if (PIPE) {                                                                                        \
                 if ((TAP) == 0) { DC_READ_A_(CA, 0); DC_READ_B_(CB, 0, 0); }                                           \
                 if ((TAP) < 8) { DC_READ_A_(XA, (TAP) + 1); DC_READ_B_(XB, (TAP) + 1, 0); }                            \
                 DC_MMA_(CA, CB, 0)                                                                                    \
@@ -2722,8 +2742,8 @@ __global__ __launch_bounds__(TR / MT * 64, 2) void dense_conv3x3_x9_kernel(const
             __syncthreads();                                                                                          \
             DC_T(tf_)                                                                                                 \
             DC_ACC(2, te_ - td_) DC_ACC(3, tf_ - te_) DC_ACC(4, 1) }
-#define DC_EVEN(TAP, CH) DC_STAGE(TAP, CH, cq0, cq1, cq2, bq0, bq1, bq2, fa, fb, ga, gb)      /* even stage: load set 1, store set 0 */
-#define DC_ODD(TAP, CH) DC_STAGE(TAP, CH, bq0, bq1, bq2, cq0, cq1, cq2, ga, gb, fa, fb)
+#define DC_EVEN(TAP, CH) DC_STAGE(TAP, CH, cq0, cq1, cq2, bq0, bq1, bq2, fa, fb, ga, gb, fb2, gb2)      /* even stage: load set 1, store set 0 */
+#define DC_ODD(TAP, CH) DC_STAGE(TAP, CH, bq0, bq1, bq2, cq0, cq1, cq2, ga, gb, fa, fb, gb2, fb2)
         for (int ch = 0; ch < nchunks; ch += 2) {
             DC_CHUNK_HEAD(ch)
             DC_EVEN(0, ch) DC_ODD(1, ch) DC_EVEN(2, ch) DC_ODD(3, ch) DC_EVEN(4, ch) DC_ODD(5, ch) DC_EVEN(6, ch) DC_ODD(7, ch) DC_EVEN(8, ch)
@@ -2933,6 +2953,8 @@ extern "C" int gga_dense_conv3x3_pack_planes(const float* weight, int64_t stride
 // rows per tile: 16 only for 128 output channels and when that still gives every CU a workgroup or two
 static inline int dc_tile_rows(int B, int H, int W, int cout) {
     if (cout != 128) return 8;
+    static const int forced = getenv("GGA_DC_TILE_ROWS") ? atoi(getenv("GGA_DC_TILE_ROWS")) : 0;      // A/B switch: 8 or 16
+    if (forced == 8 || forced == 16) return forced;
     const int64_t t16 = (int64_t)B * ((W + DC_TW - 1) / DC_TW) * ((H + 15) / 16);
     return t16 >= 384 ? 16 : 8;
 }
@@ -2993,6 +3015,7 @@ extern "C" int gga_dense_conv3x3_bn_bwd(const float* x, const void* split_weight
     // in isolation), but inside the train step a persistent grid starts while the previous kernel's
     // tail still occupies some CUs and the static tile split then leaves stragglers (one bench run in
     // two measured 89.7 instead of 73.8 ms per step); the hardware dispatcher balances one-tile workgroups.
+    const bool pipe4 = DC_PIPE4_ON && planes == 2 && cout == 128 && trows == 8 && n_tiles <= DC_P4_MAX_TILES;
     const dim3 grid((unsigned)n_tiles), block(trows * 32);
     hipEvent_t* tev = gga_timing_acquire(GGA_TIME_DENSE_CONV, GGA_TIMING_CONV_KEY(cin, cout, (int64_t)H * W));
     GGA_TIME_START(tev, stream);
@@ -3004,6 +3027,7 @@ extern "C" int gga_dense_conv3x3_bn_bwd(const float* x, const void* split_weight
     } else {
         if (cout == 64) DC_GO(2, 8, 2);
         else if (trows == 16) DC_GO(4, 16, 2);
+        else if (pipe4) hipLaunchKernelGGL((dense_conv3x3_x9_kernel<4, 8, 2, 2, 1>), grid, block, 0, stream, x, (const uint16_t*)split_weight, B, H, W, cin, cout, tx, ty, y, (int)y_pixel_stride, prow, pcol, stats, amax_x, amax_weight, bn, lv);
         else DC_GO(4, 8, 2);
     }
 #undef DC_GO
@@ -3052,7 +3076,13 @@ extern "C" int gga_dense_conv3x3_levels(int n_entries, const float* const* x, co
     const dim3 grid((unsigned)total), block(tile_rows * 32);
 #define DC_LV(NT_, TR_, NP_) hipLaunchKernelGGL((dense_conv3x3_x9_kernel<NT_, TR_, NP_, 2>), grid, block, 0, stream, x[0], (const uint16_t*)split_weight[0], B, heights[0], widths[0], cin, cout, 1, 1, y[0], (int)y_pixel_stride, widths[0], 1, (double*)nullptr, planes == 2 ? amax_x[0] : nullptr, amax_weight, bn, lv)
     if (planes == 3) { if (cout == 64) DC_LV(2, 8, 3); else if (tile_rows == 16) DC_LV(4, 16, 3); else DC_LV(4, 8, 3); }
-    else { if (cout == 64) DC_LV(2, 8, 2); else if (tile_rows == 16) DC_LV(4, 16, 2); else DC_LV(4, 8, 2); }
+    else {
+        if (cout == 64) DC_LV(2, 8, 2);
+        else if (tile_rows == 16) DC_LV(4, 16, 2);
+        else if (DC_PIPE4_ON && total <= DC_P4_MAX_TILES)
+            hipLaunchKernelGGL((dense_conv3x3_x9_kernel<4, 8, 2, 2, 1>), grid, block, 0, stream, x[0], (const uint16_t*)split_weight[0], B, heights[0], widths[0], cin, cout, 1, 1, y[0], (int)y_pixel_stride, widths[0], 1, (double*)nullptr, planes == 2 ? amax_x[0] : nullptr, amax_weight, bn, lv);
+        else DC_LV(4, 8, 2);
+    }
 #undef DC_LV
     GGA_CHECK_LAUNCH("dense_conv3x3_x9_kernel (levels)");
     return GGA_OK;

@@ -6,12 +6,14 @@ dev = 'cuda:0'
 def t(B, C, Co, H, W):
     x = torch.randn(B, C, H, W, device=dev).contiguous(memory_format=torch.channels_last)
     w = (torch.randn(Co, C, 3, 3, device=dev) * 0.05).contiguous(memory_format=torch.channels_last)
+    xa, wa = dense_conv._amax_bits(x), dense_conv._amax_bits(w)
     trash = torch.empty(1 << 28, dtype=torch.float32, device=dev)
     ts = []
     for i in range(14):
         trash.fill_(float(i))
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(); y = dense_conv._run(x, w, False)[0]; e1.record(); torch.cuda.synchronize()
+        e0.record(); y = dense_conv._run(x, w, False, x_amax=xa, w_amax=wa)[0]; e1.record(); torch.cuda.synchronize()
         if i >= 4: ts.append(e0.elapsed_time(e1))
-    print(f'   [{B},{C}->{Co},{H},{W}] {sum(ts) / len(ts) * 1e3:.0f} us (incl. absmax / pack)')
-t(16, 128, 128, 124, 108); t(16, 128, 64, 124, 108); t(16, 256, 256, 62, 54); t(16, 256, 64, 62, 54); t(16,64,64,248,216)
+    print(f'   [{B},{C}->{Co},{H},{W}] {sum(ts) / len(ts) * 1e3:.0f} us (incl. weight pack)', float(y.abs().max()))
+for shp in ((16, 128, 128, 124, 108), (16, 128, 128, 62, 54), (4, 128, 128, 100, 88), (16, 256, 256, 62, 54), (8, 128, 128, 200, 176), (12, 256, 256, 96, 312)):
+    t(*shp)

@@ -16,6 +16,10 @@ csv.field_size_limit(1 << 30)
 # the fused optimizer's kernels where there are any (gradient clipping launches multi_tensor_apply kernels of its own, a second
 # cluster per step), any multi_tensor_apply kernel otherwise (SGD)
 fused = [r for r in rows if 'FusedOptim' in r['Kernel_Name']]
+# no fused optimizer (SGD's foreach kernels look like any other multi-tensor addition, and the camera-only head adds its levels'
+# gradients with such launches in the middle of the backward pass): the gradient-norm kernels of the clipping, once per step
+if not fused:
+    fused = [r for r in rows if 'LpNorm' in r['Kernel_Name']]
 opt = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp'])) for r in (fused or [r for r in rows if 'multi_tensor_apply' in r['Kernel_Name']]))
 ends = []
 for i, (st, en) in enumerate(opt):

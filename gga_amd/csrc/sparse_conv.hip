@@ -2498,7 +2498,7 @@ struct DcLevels {
 // of the camera-only head, 62 x 54 maps - 69 against 83 us and 63 against 77; launches with more tiles than CUs 265 against 248
 // and 217 against 202, where the second workgroup hides more than the pipelining wins. The launcher picks by tile count.)
 template <int NT, int TR, int NP, int MT, int P4 = 0>
-__global__ __launch_bounds__(TR / MT * 64, (P4 && NT == 4 && TR == 8 && NP == 2 && MT == 2) ? 1 : 2) void dense_conv3x3_x9_kernel(const float* __restrict__ X, const uint16_t* __restrict__ Wp,
+__global__ __launch_bounds__(TR / MT * 64, (P4 && NT == 4 && NP == 2) ? 1 : 2) void dense_conv3x3_x9_kernel(const float* __restrict__ X, const uint16_t* __restrict__ Wp,
                                                                  int B, int H, int W, int cin, int cout, int tiles_x,
                                                                  int tiles_y, float* __restrict__ Y, int ystride,
                                                                  int prow, int pcol, double* __restrict__ stats,
@@ -2612,7 +2612,7 @@ __global__ __launch_bounds__(TR / MT * 64, (P4 && NT == 4 && TR == 8 && NP == 2 
     // this measured). The weights of stage s + 1 are in LDS since the barrier before stage s (they are written a stage
     // early), the halo image is constant over a chunk; the first offset of a chunk reads its own fragments.
     constexpr bool PIPE = DC_PIPE_ON && NT == 2 && MT == 2 && NP == 2;       // (three planes: the second set spills)
-    constexpr bool PIPE4 = P4 && NT == 4 && TR == 8 && NP == 2 && MT == 2;
+    constexpr bool PIPE4 = P4 && NT == 4 && NP == 2;        // (MT = 2: 8-row tiles; MT = 4: 16-row tiles, four image rows per wave)
     mf_v8bf fa[MT][NP], fb[2][NP];
     mf_v8bf ga[MT][NP], gb[2][NP];
     mf_v8bf fb2[2][NP], gb2[2][NP];                      // PIPE4: the B fragments of N tiles 2 and 3
@@ -2714,9 +2714,9 @@ __global__ __launch_bounds__(TR / MT * 64, (P4 && NT == 4 && TR == 8 && NP == 2 
                 if ((TAP) < 8) { DC_READ_A_(XA, (TAP) + 1); DC_READ_B_(XB, (TAP) + 1, 0); DC_READ_B_(XB2, (TAP) + 1, 2); } \
                 DC_MMA_(CA, CB, 0)                                                                                    \
                 DC_MMA_(CA, CB2, 2)                                                                                   \
-                if ((TAP) < 8) {                                                                                      \
-                    _Pragma("unroll") for (int g_ = 0; g_ < 12; ++g_) {                                               \
-                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); } \
+                if ((TAP) < 8) {      /* MT * 12 MFMAs, 2 MT + 8 reads: 2 : 1 at MT = 2, 3 : 1 at MT = 4 */                \
+                    _Pragma("unroll") for (int g_ = 0; g_ < 2 * MT + 8; ++g_) {                                       \
+                        __builtin_amdgcn_sched_group_barrier(0x008, MT == 4 ? 3 : 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); } \
                 }                                                                                                     \
             } else if (PIPE) {                                                                                        \
                 if ((TAP) == 0) { DC_READ_A_(CA, 0); DC_READ_B_(CB, 0, 0); }                                           \
@@ -3016,6 +3016,8 @@ extern "C" int gga_dense_conv3x3_bn_bwd(const float* x, const void* split_weight
     // tail still occupies some CUs and the static tile split then leaves stragglers (one bench run in
     // two measured 89.7 instead of 73.8 ms per step); the hardware dispatcher balances one-tile workgroups.
     const bool pipe4 = DC_PIPE4_ON && planes == 2 && cout == 128 && trows == 8 && n_tiles <= DC_P4_MAX_TILES;
+    // (16-row tiles as four waves x four image rows on the same one-workgroup-per-CU form - 256 accumulators next to two fragment
+    // sets - need more than 512 registers: 123 spilled dwords, 339 against 241 us at 16 x 124 x 108; not instantiated)
     const dim3 grid((unsigned)n_tiles), block(trows * 32);
     hipEvent_t* tev = gga_timing_acquire(GGA_TIME_DENSE_CONV, GGA_TIMING_CONV_KEY(cin, cout, (int64_t)H * W));
     GGA_TIME_START(tev, stream);

@@ -91,6 +91,11 @@ __global__ __launch_bounds__(512, 2) void headconv_fwd_kernel(const float* __res
         sf = *reinterpret_cast<const float4*>(in_ss + HC_CIN + 4 * piece);
     }
     float4 ld[8];
+#ifdef HM_ABL_NOLOAD                     /* experiment builds (tools_dev/exp_headconv.py): no global reads / no matrix products */
+#define HM_FETCH_(P) make_float4((float)(((uintptr_t)(P)) & 15), 1.f, 2.f, 3.f)
+#else
+#define HM_FETCH_(P) (*reinterpret_cast<const float4*>(P))
+#endif
     // request the rows of group G of tile T (8 loads in flight per lane), zero outside the image / the halo
 #define HM_LOAD(T, G) {                                                                                               \
         const int tb_ = (T) / per_img, trem_ = (T) - tb_ * per_img;                                                   \
@@ -102,7 +107,7 @@ __global__ __launch_bounds__(512, 2) void headconv_fwd_kernel(const float* __res
             const int hr = hp / HM_HW, hx = hp - hr * HM_HW;                                                          \
             const int iy = ty0_ + hr - 1, ix = tx0_ + hx - 1;                                                         \
             const bool ok = hp < HP_NPIX && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;                 \
-            float4 v = ok ? *reinterpret_cast<const float4*>(x + (((int64_t)tb_ * H + iy) * W + ix) * xs + 4 * piece) \
+            float4 v = ok ? HM_FETCH_(x + (((int64_t)tb_ * H + iy) * W + ix) * xs + 4 * piece)                        \
                           : make_float4(0.f, 0.f, 0.f, 0.f);                                                          \
             if (ok && in_ss) {                           /* input = relu(x * scale + shift); zero padding stays zero */ \
                 v.x = fmaxf(fmaf(v.x, sc.x, sf.x), 0.0f); v.y = fmaxf(fmaf(v.y, sc.y, sf.y), 0.0f);                   \
@@ -114,6 +119,9 @@ __global__ __launch_bounds__(512, 2) void headconv_fwd_kernel(const float* __res
 #define HM_PARK(XA) {                                                                                                 \
         _Pragma("unroll") for (int i = 0; i < 8; ++i) *reinterpret_cast<float4*>(mine + (4 * i + prow_) * HM_SROW + piece * 16) = ld[i]; \
         _Pragma("unroll") for (int q = 0; q < 8; ++q) XA[q] = *reinterpret_cast<const float4*>(mine + r * HM_SROW + h * 128 + q * 16); }
+#ifdef HM_ABL_NOMMA
+#define HM_MMA(XA, ACC) { _Pragma("unroll") for (int i = 0; i < 16; ++i) ACC[i] = XA[i & 7].x + XA[i & 7].w + wcol[i * 32]; }
+#else
 #define HM_MMA(XA, ACC) {                                                                                             \
         _Pragma("unroll") for (int i = 0; i < 16; ++i) ACC[i] = 0.0f;                                                 \
         _Pragma("unroll") for (int q = 0; q < 8; ++q) {                                                               \
@@ -122,6 +130,7 @@ __global__ __launch_bounds__(512, 2) void headconv_fwd_kernel(const float* __res
             ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(XA[q].z, wcol[(4 * q + 2) * 32], ACC, 0, 0, 0);                \
             ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(XA[q].w, wcol[(4 * q + 3) * 32], ACC, 0, 0, 0);                \
         } }
+#endif
     // D layout of 32x32x2: register v of lane l holds row (v/4)*8 + (l/32)*4 + v%4, column l%32
 #define HM_ZOUT(U, ACC) { float* zg = reinterpret_cast<float*>(mine) + (U) * 32 * HM_ZS + r;                          \
         _Pragma("unroll") for (int v = 0; v < 16; ++v) zg[((v >> 2) * 8 + h * 4 + (v & 3)) * HM_ZS] = ACC[v]; }
@@ -165,6 +174,173 @@ __global__ __launch_bounds__(512, 2) void headconv_fwd_kernel(const float* __res
 #undef HM_PARK
 #undef HM_MMA
 #undef HM_ZOUT
+#undef HM_FETCH_
+}
+
+// Round 3: the forward kernel without the LDS parking step. Cycle ablations of the parked form at 16 x 248 x 216 out of a
+// 960-channel tensor (tools_dev/exp_headconv.py: 91 us as shipped, 69 without the matrix products, 59 without the global
+// reads, 31 with neither) had shown its three parts running one after another, not side by side: a wave waited for its
+// group, parked it, multiplied, and only one group per wave was ever in flight. Here the operand comes straight from the
+// load: v_mfma_f32_16x16x4_f32 wants A[i][k] from lane (i = lane % 16, k = lane / 16), so lane (i, hq) loads the float4
+// at channels 16j + 4hq .. +3 of pixel i (16 pixel rows x 64 contiguous bytes per instruction, j = 0..3) and feeds its
+// four floats to four k-steps whose B rows are the channels (16j + 4hq' + e), hq' = 0..3 - any channel order serves as
+// long as both operands use it. No LDS round trip, no register copy, the address of every halo slot is a per-lane constant
+// plus the tile's origin, and BOTH pixel groups of the next tile are requested a whole tile ahead (16 loads in flight per
+// lane). Z is kept compactly (9 * COUT columns, odd stride) for the whole tile; a one-channel branch needs one 16-column
+// product instead of two.
+template <int COUT, bool AFF>
+__global__ __launch_bounds__(512, 4) void headconv_fwd16_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ bias, int B, int H, int W,
+                                                            int tiles_x, int tiles_y, int n_tiles, int cout_total, int co_base,
+                                                            const float* __restrict__ in_ss, int64_t xs, float* __restrict__ y) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    constexpr int NT = COUT == 1 ? 1 : 2;               // 16-column tiles of Z
+    constexpr int ZS = (9 * COUT) | 1;                  // floats per halo slot of Z: 9, 19, 27
+    __shared__ float zt[HP_NGRP * 32 * ZS];
+    // B operand as the lanes read it: wl[j][hq][t][n][e] = weight of channel 16j + 4hq + e in column 16t + n (one 16-byte
+    // read per lane, j and t: the four k-steps a loaded float4 feeds)
+    __shared__ __attribute__((aligned(16))) float wl[16 * NT * 64];
+    __shared__ __attribute__((aligned(16))) float ssl[4 * HC_CIN];       // scale[64], shift[64], then 128 zeroes for the slots outside the image
+    __shared__ float bl[HC_MAXCO];                       // (a global read in the nine-tap sums would wait for the sixteen loads just issued)
+    const int per_img = tiles_x * tiles_y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = lane & 15, hq = lane >> 4;
+    for (int i = threadIdx.x; i < 16 * NT * 64; i += 512) {
+        const int e = i & 3, nn = (i >> 2) & 15, t = (i >> 6) % NT, jh = i / (64 * NT);
+        const int c = 16 * (jh >> 2) + 4 * (jh & 3) + e, col = 16 * t + nn;
+        const bool used = col < 9 * COUT;
+        const int off = used ? col / COUT : 0, co = used ? col - off * COUT : 0;
+        wl[i] = used ? w[((int64_t)(co_base + co) * HC_CIN + c) * 9 + off] : 0.0f;
+    }
+    if (AFF && threadIdx.x < 4 * HC_CIN) ssl[threadIdx.x] = threadIdx.x < 2 * HC_CIN ? in_ss[threadIdx.x] : 0.0f;
+    if (threadIdx.x < COUT) bl[threadIdx.x] = bias ? bias[co_base + threadIdx.x] : 0.0f;
+    __syncthreads();
+    // the lane's four halo slots (group u = 0, 1 of the wave, half s = 0, 1 of the group): constant over the tiles
+    int loff[2][2], hrc[2][2];                          // element offset from the tile's origin; (row - 1) << 16 | (column - 1) & 0xffff
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int hp = (wave + 8 * u) * 32 + 16 * s + n;
+            const int hr = hp / HM_HW, hc = hp - hr * HM_HW;
+            hrc[u][s] = hp < HP_NPIX ? (int)((unsigned)(hr - 1) << 16) | ((hc - 1) & 0xffff) : (int)0xC0000000u;     // (slots 510, 511: never inside)
+            loff[u][s] = (int)(((int64_t)(hr - 1) * W + hc - 1) * xs) + 4 * hq;
+        }
+    f4 ld[2][8];
+    unsigned okm[2] = {0u, 0u};
+    // (every lane always loads - from the tensor's first bytes when its slot lies outside the image - and the zero is put in
+    // when the value is used: with the loads inside per-lane branches the compiler cannot count them and waits for ALL
+    // outstanding loads, the ones just issued for the next tile included, before the second group's products)
+#define HQ_LOAD(T, LIVE, U) {                                                                                         \
+        const int tb_ = (T) / per_img, trem_ = (T) - tb_ * per_img;                                                   \
+        const int ty0_ = (trem_ / tiles_x) * HP_TR, tx0_ = (trem_ % tiles_x) * HM_TW;                                 \
+        const float* base_ = x + (((int64_t)tb_ * H + ty0_) * W + tx0_) * xs;                                         \
+        okm[U] = 0u;                                                                                                  \
+        _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                               \
+            const bool ok = (LIVE) && (unsigned)(ty0_ + (hrc[U][s] >> 16)) < (unsigned)H && (unsigned)(tx0_ + (short)hrc[U][s]) < (unsigned)W; \
+            okm[U] |= ok ? (1u << s) : 0u;                                                                            \
+            const float* p_ = ok ? base_ + loff[U][s] : x + 4 * hq;                                                   \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) ld[U][4 * s + j] = HQ_FETCH_(p_ + 16 * j);                  \
+        } }
+#ifdef HM_ABL_NOLOAD
+#define HQ_FETCH_(P) f4{(float)(((uintptr_t)(P)) & 15), 1.f, 2.f, 3.f}
+#else
+#define HQ_FETCH_(P) (*reinterpret_cast<const f4*>(P))
+#endif
+#define HQ_B_(J, T_) (reinterpret_cast<const f4*>(wl)[wo + ((J) * 4 * NT + (T_)) * 16])
+    // products of group U (2 x 16 pixels) and its Z rows: D register v of lane (n, hq) = pixel 4 * hq + v, column n
+#define HQ_MMA(U) {                                                                                                   \
+        f4 acc[2][NT], bc[NT];                                                                                        \
+        _Pragma("unroll") for (int s = 0; s < 2; ++s) _Pragma("unroll") for (int t = 0; t < NT; ++t) acc[s][t] = f4{0.f, 0.f, 0.f, 0.f}; \
+        int wo = hq * NT * 16 + n, so = hq;            /* in 16-byte units */                                          \
+        asm volatile("" : "+v"(wo), "+v"(so));        /* (the operand rows are read per tile, not held in 64 registers) */ \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                               \
+            _Pragma("unroll") for (int t = 0; t < NT; ++t) bc[t] = HQ_B_(j, t);                                       \
+            f4 v[2] = {ld[U][j], ld[U][4 + j]};                                                                       \
+            if (AFF) {       /* input = relu(x * scale + shift); a slot outside the image reads the zero scale / shift row: relu(x * 0 + 0) */ \
+                _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                       \
+                    const int sq = ((okm[U] >> s) & 1u) ? so : so + 32;                                               \
+                    const f4 sc = reinterpret_cast<const f4*>(ssl)[sq + 4 * j], sf = reinterpret_cast<const f4*>(ssl)[sq + 16 + 4 * j]; \
+                    const f2 lo = __builtin_elementwise_fma(f2{v[s][0], v[s][1]}, f2{sc[0], sc[1]}, f2{sf[0], sf[1]}); \
+                    const f2 hi = __builtin_elementwise_fma(f2{v[s][2], v[s][3]}, f2{sc[2], sc[3]}, f2{sf[2], sf[3]}); \
+                    v[s] = f4{fmaxf(lo[0], 0.0f), fmaxf(lo[1], 0.0f), fmaxf(hi[0], 0.0f), fmaxf(hi[1], 0.0f)};       \
+                }                                                                                                     \
+            } else {                                                                                                  \
+                _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                       \
+                    const bool ok = (okm[U] >> s) & 1u;                                                               \
+                    _Pragma("unroll") for (int e = 0; e < 4; ++e) v[s][e] = ok ? v[s][e] : 0.0f;                      \
+                }                                                                                                     \
+            }                                                                                                         \
+            _Pragma("unroll") for (int e = 0; e < HQ_ABL_E_; ++e)                                                     \
+                _Pragma("unroll") for (int t = 0; t < NT; ++t) {                                                      \
+                    HQ_MFMA_(acc[0][t], v[0][e], bc[t][e]) HQ_MFMA_(acc[1][t], v[1][e], bc[t][e])                     \
+                }                                                                                                     \
+        }                                                                                                             \
+        _Pragma("unroll") for (int s = 0; s < 2; ++s) _Pragma("unroll") for (int t = 0; t < NT; ++t)                  \
+            if (16 * t + n < 9 * COUT) {                                                                              \
+                float* zg = zt + ((wave + 8 * (U)) * 32 + 16 * s + 4 * hq) * ZS + 16 * t + n;                         \
+                _Pragma("unroll") for (int v_ = 0; v_ < 4; ++v_) zg[v_ * ZS] = acc[s][t][v_];                         \
+            } }
+#ifdef HM_ABL_QUARTER
+#define HQ_ABL_E_ 1
+#else
+#define HQ_ABL_E_ 4
+#endif
+#ifdef HM_ABL_NOMMA
+#define HQ_MFMA_(ACC, A, Bv) ACC[0] += (A) + (Bv);
+#else
+#define HQ_MFMA_(ACC, A, Bv) ACC = __builtin_amdgcn_mfma_f32_16x16x4f32(A, Bv, ACC, 0, 0, 0);
+#endif
+    // Tile walk: workgroup b runs on XCD b % 8 (round-robin dispatch). Each XCD takes one contiguous eighth of the tiles and its
+    // workgroups walk it side by side, so that the tiles above / below / beside a tile are read through the same L2 at about
+    // the same time and the halo rows (2 of 15, 2 of 34 columns) come from there instead of from memory a second time.
+    const int xcd = blockIdx.x & 7, wg = blockIdx.x >> 3, wgs = ((int)gridDim.x + 7 - xcd) >> 3;
+    const int chunk = (n_tiles + 7) >> 3;
+    const int t_end = min(n_tiles, (xcd + 1) * chunk);
+    int tile = xcd * chunk + wg;
+    if (tile >= t_end) return;
+    HQ_LOAD(tile, true, 0)
+    HQ_LOAD(tile, true, 1)
+    for (; tile < t_end; tile += wgs) {
+        const int b = tile / per_img;
+        const int rem = tile - b * per_img;
+        const int y0 = (rem / tiles_x) * HP_TR, x0 = (rem % tiles_x) * HM_TW;
+        const int nxt = tile + wgs;
+        HQ_MMA(0)
+        HQ_LOAD(nxt, nxt < t_end, 0)                      // a whole tile ahead (past the end: dummy loads, so that the count holds)
+        HQ_MMA(1)
+        HQ_LOAD(nxt, nxt < t_end, 1)
+        __syncthreads();
+#ifndef HM_ABL_NOEPI
+        if (threadIdx.x < HP_TR * HM_TW) {               // one thread per output pixel, all its channels
+            const int ty = threadIdx.x / HM_TW, tx = threadIdx.x - ty * HM_TW;
+            const int oy = y0 + ty, ox = x0 + tx;
+            if (oy < H && ox < W) {
+                float s[COUT];
+#pragma unroll
+                for (int co = 0; co < COUT; ++co) s[co] = bl[co];
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const float* z = zt + ((ty + ky) * HM_HW + tx + kx) * ZS + (ky * 3 + kx) * COUT;
+#pragma unroll
+                        for (int co = 0; co < COUT; ++co) s[co] += z[co];
+                    }
+                float* yo = y + (((int64_t)b * cout_total + co_base) * H + oy) * W + ox;
+#pragma unroll
+                for (int co = 0; co < COUT; ++co) yo[(int64_t)co * H * W] = s[co];
+            }
+        }
+#endif
+        __syncthreads();                                  // Z is written again
+    }
+#undef HQ_LOAD
+#undef HQ_FETCH_
+#undef HQ_MMA
+#undef HQ_MFMA_
+#undef HQ_B_
 }
 
 // dW[co][ci][off] = sum_p x[p+off][ci] * dy[co][p]; dbias[co] = sum_p dy[co][p], on the matrix
@@ -251,10 +427,19 @@ __global__ __launch_bounds__(512, HW_MINW) void headconv_wgrad_kernel(const floa
             const bool ok = inh && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
             const float* xp = x + (((int64_t)b * H + (ok ? iy : 0)) * W + (ok ? ix : 0)) * xs + m;
             const float mk = ok ? 1.0f : 0.0f;
-            const float a0 = fmaxf(fmaf(xp[0], sc0, sf0), lo) * mk, a1 = fmaxf(fmaf(xp[32], sc1, sf1), lo) * mk;
+#ifdef HW_ABL_NOLOAD
+            const float x0_ = (float)(((uintptr_t)xp) & 255), x1_ = 1.0f;
+#else
+            const float x0_ = xp[0], x1_ = xp[32];
+#endif
+            const float a0 = fmaxf(fmaf(x0_, sc0, sf0), lo) * mk, a1 = fmaxf(fmaf(x1_, sc1, sf1), lo) * mk;
             const float gv = g[gbase + hr * HW_PC + hx] * usedf;
+#ifdef HW_ABL_NOMMA
+            acc0[s & 15] = fmaf(a0, gv, acc0[s & 15]); acc1[s & 15] = fmaf(a1, gv, acc1[s & 15]);
+#else
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, gv, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, gv, acc1, 0, 0, 0);
+#endif
         }
     }
     // fixed-order fold of the 8 waves' partial D[ci][n] (register v of lane l: row (v/4)*8 + (l/32)*4 + v%4, column l%32)
@@ -336,8 +521,12 @@ extern "C" int gga_head_conv3x3_fwd(const float* x, int64_t x_pixel_stride, cons
     const int tx = (W + HM_TW - 1) / HM_TW, ty = (H + HP_TR - 1) / HP_TR;
     const int64_t n_tiles = (int64_t)B * tx * ty;
     GGA_REQUIRE(n_tiles < 2147483647ll, "gga_head_conv3x3_fwd: too many tiles");
+    GGA_REQUIRE(16ll * W * x_pixel_stride < 2147483647ll && H < 16384 && W < 16384, "gga_head_conv3x3_fwd: map too large (a tile's rows must span < 2^31 elements, H and W < 16384)");
+    static const bool parked = getenv("GGA_HEADCONV_PARKED") && atoi(getenv("GGA_HEADCONV_PARKED")) != 0;   // A/B: the round-2 kernel
     const dim3 grid((unsigned)(n_tiles < 512 ? n_tiles : 512)), block(512);       // persistent: two workgroups per CU
-#define HC_F(CO, BASE) hipLaunchKernelGGL(headconv_fwd_kernel<CO>, grid, block, 0, stream, x, weight, bias, B, H, W, tx, ty, (int)n_tiles, cout, BASE, in_scale_shift, x_pixel_stride, y)
+#define HC_G(CO, BASE, AF) hipLaunchKernelGGL((headconv_fwd16_kernel<CO, AF>), grid, block, 0, stream, x, weight, bias, B, H, W, tx, ty, (int)n_tiles, cout, BASE, in_scale_shift, x_pixel_stride, y)
+#define HC_F(CO, BASE) { if (parked) hipLaunchKernelGGL(headconv_fwd_kernel<CO>, grid, block, 0, stream, x, weight, bias, B, H, W, tx, ty, (int)n_tiles, cout, BASE, in_scale_shift, x_pixel_stride, y); \
+                         else if (in_scale_shift) HC_G(CO, BASE, true); else HC_G(CO, BASE, false); }
     switch (cout) {
         case 1: HC_F(1, 0); break;
         case 2: HC_F(2, 0); break;
@@ -345,6 +534,7 @@ extern "C" int gga_head_conv3x3_fwd(const float* x, int64_t x_pixel_stride, cons
         default: HC_F(2, 0); HC_F(2, 2); break;      // 9*4 columns do not fit one 32-wide tile
     }
 #undef HC_F
+#undef HC_G
     GGA_CHECK_LAUNCH("headconv_fwd_kernel");
     return GGA_OK;
 }

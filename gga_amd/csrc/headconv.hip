@@ -476,6 +476,176 @@ __global__ __launch_bounds__(512, HW_MINW) void headconv_wgrad_kernel(const floa
     }
 }
 
+// Round 3: the weight gradient over INPUT tiles. The kernel above walks the halo pixels of an output tile (every input element
+// read 1.33 times) and feeds the matrix cores from 4-byte loads behind ~25 address instructions per pixel pair; with neither
+// its loads nor its products it still took 55 of its 100 us (tools_dev/exp_headconv.py). Here a workgroup owns 8 x 32 INPUT
+// pixels - disjoint tiles, every element of x read exactly once - and the shifted operand is taken from the tile of dy with a
+// one-pixel border instead (a few KB): dW[co][ci][off] = sum_q x[q][ci] * dy[co][q - (off - 1)] over the tile's own pixels q.
+// v_mfma_f32_16x16x4_f32 with A[i][k] = x[pixel q0 + k][channel 4i + e] for e = 0..3: lane (i, k) loads ONE float4 (its
+// pixel's channels 4i .. 4i+3; a 16-lane group reads the pixel's 256 contiguous bytes, four pixels per instruction) and
+// feeds its four floats to four products whose D rows are the channels 4i + e; B[k][n] = dy of column n = off * COUT + co at
+// pixel q0 + k shifted by the tap, one LDS read with an immediate offset. A wave owns one row of the tile (8 steps of 4
+// pixels); every float4 is requested a whole tile ahead and every lane always loads (counted waits, see the forward kernel).
+#define HG_TR 8
+#define HG_TW 32
+#define HG_PR (HG_TR + 2)
+#define HG_PC (HG_TW + 2)
+#define HG_GP (HG_PR * HG_PC)                             // 340 staged dy values per channel
+
+template <int COUT, bool AFF>
+__global__ __launch_bounds__(512, 4) void headconv_wgrad16_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                              int B, int H, int W, int tiles_x, int tiles_y, int n_tiles,
+                                                              int cout_total, int co_base, const float* __restrict__ in_ss,
+                                                              int64_t xs, float* __restrict__ partials) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    constexpr int NT = COUT == 1 ? 1 : 2;                // 16-column tiles of the result
+    constexpr int GN = (COUT * HG_GP + 511) / 512;       // staged dy values per thread
+    __shared__ float gds[2][(COUT + 1) * HG_GP];         // (+ a plane of zeroes: the columns beyond 9 * COUT read it)
+    __shared__ float red[HC_CIN * 33];
+    __shared__ float bred[GN * 512];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, hq = lane >> 4;
+    const int per_img = tiles_x * tiles_y;
+    // B operand: column n + 16t = (tap, channel); input pixel (row `wave`, column 4s + hq) meets dy at (row - ky + 1, column - kx + 1)
+    int gb[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int col = n + 16 * t;
+        const bool used = col < 9 * COUT;
+        const int off = used ? col / COUT : 4, co = used ? col - off * COUT : COUT;
+        const int ky = off / 3, kx = off - ky * 3;
+        gb[t] = co * HG_GP + (2 - ky + wave) * HG_PC + (2 - kx) + hq;
+    }
+    f4 sc = {1.f, 1.f, 1.f, 1.f}, sf = {0.f, 0.f, 0.f, 0.f};
+    if (AFF) { sc = *reinterpret_cast<const f4*>(in_ss + 4 * n); sf = *reinterpret_cast<const f4*>(in_ss + HC_CIN + 4 * n); }
+    // the thread's staged dy values: (channel, row, column) of the bordered tile, fixed over the tiles
+    int gq[GN];
+#pragma unroll
+    for (int e = 0; e < GN; ++e) {
+        const int i = tid + 512 * e;
+        const int c = i / HG_GP, q = i - c * HG_GP;
+        const int hr = q / HG_PC, hx = q - hr * HG_PC;
+        gq[e] = i < COUT * HG_GP ? (c << 16) | (hr << 8) | hx : -1;
+    }
+    for (int i = tid; i < 2 * (COUT + 1) * HG_GP; i += 512) (&gds[0][0])[i] = 0.0f;
+    const int lo = (int)(((int64_t)wave * W + hq) * xs) + 4 * n;       // the lane's element offset from the tile's first pixel
+    f4 ld[8], acc[4][NT];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[e][t] = f4{0.f, 0.f, 0.f, 0.f};
+    float greg[GN], bsum[GN];
+#pragma unroll
+    for (int e = 0; e < GN; ++e) bsum[e] = 0.0f;
+    unsigned okm = 0u;
+#ifdef HW_ABL_NOLOAD
+#define HG_FETCH_(P) f4{(float)(((uintptr_t)(P)) & 15), 1.f, 2.f, 3.f}
+#else
+#define HG_FETCH_(P) (*reinterpret_cast<const f4*>(P))
+#endif
+#define HG_COORDS(T) const int tb_ = (T) / per_img, trem_ = (T) - tb_ * per_img;                                      \
+        const int ty0_ = (trem_ / tiles_x) * HG_TR, tx0_ = (trem_ % tiles_x) * HG_TW;
+#define HG_XLOAD(T, LIVE, S) {                                                                                        \
+        HG_COORDS(T)                                                                                                  \
+        const bool ok = (LIVE) && ty0_ + wave < H && tx0_ + 4 * (S) + hq < W;                                         \
+        okm = ok ? okm | (1u << (S)) : okm & ~(1u << (S));                                                            \
+        const float* p_ = ok ? x + (((int64_t)tb_ * H + ty0_) * W + tx0_ + 4 * (S)) * xs + lo : x + 4 * n;           \
+        ld[S] = HG_FETCH_(p_); }
+#define HG_GLOAD(T, LIVE) {                                                                                           \
+        HG_COORDS(T)                                                                                                  \
+        _Pragma("unroll") for (int e = 0; e < GN; ++e) {                                                              \
+            const int c = gq[e] >> 16, hr = (gq[e] >> 8) & 255, hx = gq[e] & 255;                                     \
+            const int iy = ty0_ + hr - 1, ix = tx0_ + hx - 1;                                                         \
+            const bool ok = (LIVE) && gq[e] >= 0 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;         \
+            const float v = *(ok ? dy + (((int64_t)tb_ * cout_total + co_base + c) * H + iy) * W + ix : dy);          \
+            greg[e] = ok ? v : 0.0f;                                                                                  \
+        } }
+    // (the select above is applied when greg is stored, after the loads that follow have been issued: the compiler keeps it there)
+#define HG_GSTORE(BUF) {                                                                                              \
+        _Pragma("unroll") for (int e = 0; e < GN; ++e) if (gq[e] >= 0) {                                              \
+            (BUF)[tid + 512 * e] = greg[e];                                                                           \
+            const int hr = (gq[e] >> 8) & 255, hx = gq[e] & 255;                                                      \
+            if (hr >= 1 && hr <= HG_TR && hx >= 1 && hx <= HG_TW) bsum[e] += greg[e];     /* the tile's own pixels */  \
+        } }
+    int tile = blockIdx.x;
+    const int stride = gridDim.x;
+    __syncthreads();                                      // the zeroes have landed (see the race note in the kernel above)
+    HG_GLOAD(tile, tile < n_tiles)
+#pragma unroll
+    for (int s = 0; s < 8; ++s) HG_XLOAD(tile, tile < n_tiles, s)
+    HG_GSTORE(gds[0])
+    for (int it = 0; tile < n_tiles; tile += stride, ++it) {
+        __syncthreads();          // tile `it` staged; every wave is done with tile it-1, so the other buffer is free
+        const int nxt = tile + stride;
+        const bool live = nxt < n_tiles;
+        HG_GLOAD(nxt, live)
+        const float* g = gds[it & 1];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            f4 v = ld[s];
+            if (AFF) {
+                const f2 a = __builtin_elementwise_fma(f2{v[0], v[1]}, f2{sc[0], sc[1]}, f2{sf[0], sf[1]});
+                const f2 c = __builtin_elementwise_fma(f2{v[2], v[3]}, f2{sc[2], sc[3]}, f2{sf[2], sf[3]});
+                v = f4{fmaxf(a[0], 0.0f), fmaxf(a[1], 0.0f), fmaxf(c[0], 0.0f), fmaxf(c[1], 0.0f)};
+            }
+            const bool ok = (okm >> s) & 1u;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.0f;
+            float bw[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) bw[t] = g[gb[t] + 4 * s];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+#ifdef HW_ABL_NOMMA
+                    acc[e][t][0] += v[e] * bw[t];
+#else
+                    acc[e][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[e], bw[t], acc[e][t], 0, 0, 0);
+#endif
+                }
+            HG_XLOAD(nxt, live, s)
+        }
+        HG_GSTORE(gds[(it + 1) & 1])
+    }
+#undef HG_FETCH_
+#undef HG_COORDS
+#undef HG_XLOAD
+#undef HG_GLOAD
+#undef HG_GSTORE
+    // fixed-order fold of the 8 waves' partial D (register v of lane (n, hq) in product e, tile t: channel 16hq + 4v + e, column 16t + n)
+    for (int wv = 0; wv < 8; ++wv) {
+        __syncthreads();
+        if (wave == wv) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        float* r = red + (16 * hq + 4 * v + e) * 33 + 16 * t + n;
+                        *r = (wv ? *r : 0.0f) + acc[e][t][v];
+                    }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < GN; ++e) bred[tid + 512 * e] = bsum[e];
+    __syncthreads();
+    const int row_len = cout_total * HC_CIN * 9 + cout_total;
+    float* out = partials + (int64_t)blockIdx.x * row_len;
+    for (int i = tid; i < 9 * COUT * HC_CIN; i += 512) {
+        const int ci = i & 63, nn = i >> 6;
+        const int o = nn / COUT, c = nn - o * COUT;
+        out[((int64_t)(co_base + c) * HC_CIN + ci) * 9 + o] = red[ci * 33 + nn];
+    }
+    if (tid < COUT) {                                     // dbias: the channel's staged slots in index order
+        float sum = 0.0f;
+        for (int i = tid * HG_GP; i < (tid + 1) * HG_GP; ++i) sum += bred[i];
+        out[cout_total * HC_CIN * 9 + co_base + tid] = sum;
+    }
+}
+
 // one wavefront per output value: lanes stride over the block partials (fixed order)
 __global__ __launch_bounds__(256) void headconv_wgrad_final_kernel(const float* __restrict__ partials, int nblocks,
                                                                   int n_w, int cout, float* __restrict__ dw,
@@ -550,11 +720,16 @@ extern "C" int gga_head_conv3x3_wgrad(const float* x, int64_t x_pixel_stride, co
         gga_set_error("gga_head_conv3x3_wgrad: workspace too small");
         return GGA_ERR_WORKSPACE;
     }
-    const int tx = (W + HM_TW - 1) / HM_TW, ty = (H + HM_TR - 1) / HM_TR;
+    static const bool parked = getenv("GGA_HEADCONV_PARKED") && atoi(getenv("GGA_HEADCONV_PARKED")) != 0;   // A/B: the round-2 kernel
+    const int tx = (W + HM_TW - 1) / HM_TW, ty = (H + HM_TR - 1) / HM_TR;          // (both kernels: tiles of 8 x 32)
     const int64_t n_tiles = (int64_t)B * tx * ty;
-    const int nb = (int)(n_tiles < HC_WGRAD_BLOCKS ? n_tiles : HC_WGRAD_BLOCKS);
+    GGA_REQUIRE(n_tiles < 2147483647ll && 8ll * W * x_pixel_stride < 2147483647ll && H < 32768 && W < 32768, "gga_head_conv3x3_wgrad: map too large");
+    const int cap = parked ? HC_WGRAD_BLOCKS : 512;                               // persistent: two workgroups per CU
+    const int nb = (int)(n_tiles < cap ? n_tiles : cap);
     float* partials = (float*)workspace;
-#define HC_W(CO, BASE) hipLaunchKernelGGL(headconv_wgrad_kernel<CO>, dim3(nb), dim3(512), 0, stream, x, grad_y, B, H, W, tx, ty, n_tiles, cout, BASE, in_scale_shift, x_pixel_stride, partials)
+#define HC_W(CO, BASE) { if (parked) hipLaunchKernelGGL(headconv_wgrad_kernel<CO>, dim3(nb), dim3(512), 0, stream, x, grad_y, B, H, W, tx, ty, n_tiles, cout, BASE, in_scale_shift, x_pixel_stride, partials); \
+                         else if (in_scale_shift) hipLaunchKernelGGL((headconv_wgrad16_kernel<CO, true>), dim3(nb), dim3(512), 0, stream, x, grad_y, B, H, W, tx, ty, (int)n_tiles, cout, BASE, in_scale_shift, x_pixel_stride, partials); \
+                         else hipLaunchKernelGGL((headconv_wgrad16_kernel<CO, false>), dim3(nb), dim3(512), 0, stream, x, grad_y, B, H, W, tx, ty, (int)n_tiles, cout, BASE, in_scale_shift, x_pixel_stride, partials); }
     switch (cout) {
         case 1: HC_W(1, 0); break;
         case 2: HC_W(2, 0); break;

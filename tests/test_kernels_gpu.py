@@ -491,6 +491,41 @@ def test_head_output_conv_vs_torch(cout, bias):
     torch.testing.assert_close(z, ref.detach(), rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize('shape', [(6, 200, 176, 192, 1), (2, 50, 216, 128, 1), (3, 37, 29, 64, 0)])
+def test_head_output_conv_on_column_blocks_of_large_maps(shape):
+    """Forward and weight gradient of the head output convs through the C entry points on maps with several tiles per
+    workgroup (the persistent loops with their loads a tile ahead), ragged right / bottom edges and a 64-channel column
+    block of a wider tensor as input, with and without the fused scale / shift + ReLU, against float64."""
+    from gga_amd import _lib
+    L = _lib.lib()
+    B, H, W, wide, blk = shape
+    torch.manual_seed(B + W)
+    big = torch.randn(B, H, W, wide, device=DEV)
+    xs = big[..., 64 * blk:64 * blk + 64]
+    for cout in (1, 2, 3, 4):
+        for aff in (True, False):
+            ss = torch.cat([torch.rand(64, device=DEV) + 0.5, torch.rand(64, device=DEV) - 0.5])
+            w = torch.randn(cout, 64, 3, 3, device=DEV) * 0.05
+            b = torch.randn(cout, device=DEV)
+            y = torch.full((B, cout, H, W), float('nan'), device=DEV)
+            assert L.gga_head_conv3x3_fwd(big.data_ptr() + 4 * 64 * blk, wide, F._p(ss) if aff else None, F._p(w), F._p(b),
+                                          B, H, W, 64, cout, F._p(y), F._stream()) == 0
+            xin = xs.permute(0, 3, 1, 2).double()
+            if aff:
+                xin = torch.relu(xin * ss[:64].double().view(1, -1, 1, 1) + ss[64:].double().view(1, -1, 1, 1))
+            wr, br = w.double().requires_grad_(True), b.double().requires_grad_(True)
+            ref = torch.nn.functional.conv2d(xin, wr, br, padding=1)
+            assert float((y.double() - ref).abs().max() / ref.abs().max()) < 2e-6, (cout, aff)
+            gy = torch.randn(B, cout, H, W, device=DEV)
+            dw, db = torch.full_like(w, float('nan')), torch.full_like(b, float('nan'))
+            ws = torch.empty(L.gga_head_conv3x3_workspace_bytes(cout), dtype=torch.uint8, device=DEV)
+            assert L.gga_head_conv3x3_wgrad(big.data_ptr() + 4 * 64 * blk, wide, F._p(ss) if aff else None, F._p(gy), B, H, W,
+                                            64, cout, F._p(dw), F._p(db), ws.data_ptr(), ws.numel(), F._stream()) == 0
+            ref.backward(gy.double())
+            assert float((dw.double() - wr.grad).abs().max() / wr.grad.abs().max()) < 2e-6, (cout, aff)
+            assert float((db.double() - br.grad).abs().max() / br.grad.abs().max()) < 2e-5, (cout, aff)
+
+
 @pytest.mark.parametrize('cout', [1, 2, 3, 4])
 def test_bn_relu_head_conv_fused_vs_torch(cout):
     """Tail of a head branch: conv(relu(bn(x))) with the normalised activation never stored."""

@@ -939,7 +939,7 @@ extern "C" int gga_head_tail_bwd(const float* grad_y, const float* x, int64_t x_
     }
     const int tx = (W + HT_TW - 1) / HT_TW, ty = (H + HT_TR - 1) / HT_TR;
     const int64_t n_tiles = (int64_t)B * tx * ty;
-    const int nb = (int)(n_tiles < HT_MAX_BLOCKS ? n_tiles : HT_MAX_BLOCKS);
+    const int nb = (int)(n_tiles < HT_MAX_BLOCKS ? n_tiles : HT_MAX_BLOCKS);     // (512 .. 2048 workgroups measured: no difference beyond noise)
     double* partials = (double*)workspace;
     float* coef = nullptr;
 #define HT_GO(CO, AP) hipLaunchKernelGGL((headtail_bwd_kernel<CO, AP>), dim3(nb), dim3(256), 0, stream, grad_y, x, weight, scale_shift, saved, coef, B, H, W, tx, ty, n_tiles, x_pixel_stride, grad_x_pixel_stride, partials, grad_x, amax_grad_x)

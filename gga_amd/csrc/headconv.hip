@@ -518,7 +518,10 @@ __global__ __launch_bounds__(512, 4) void headconv_wgrad16_kernel(const float* _
         gb[t] = co * HG_GP + (2 - ky + wave) * HG_PC + (2 - kx) + hq;
     }
     f4 sc = {1.f, 1.f, 1.f, 1.f}, sf = {0.f, 0.f, 0.f, 0.f};
-    if (AFF) { sc = *reinterpret_cast<const f4*>(in_ss + 4 * n); sf = *reinterpret_cast<const f4*>(in_ss + HC_CIN + 4 * n); }
+    if (AFF) {                                            // (scalar reads: the pointer is only known to be 4-byte aligned)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { sc[e] = in_ss[4 * n + e]; sf[e] = in_ss[HC_CIN + 4 * n + e]; }
+    }
     // the thread's staged dy values: (channel, row, column) of the bordered tile, fixed over the tiles
     int gq[GN];
 #pragma unroll
@@ -691,8 +694,9 @@ extern "C" int gga_head_conv3x3_fwd(const float* x, int64_t x_pixel_stride, cons
     const int tx = (W + HM_TW - 1) / HM_TW, ty = (H + HP_TR - 1) / HP_TR;
     const int64_t n_tiles = (int64_t)B * tx * ty;
     GGA_REQUIRE(n_tiles < 2147483647ll, "gga_head_conv3x3_fwd: too many tiles");
-    GGA_REQUIRE(16ll * W * x_pixel_stride < 2147483647ll && H < 16384 && W < 16384, "gga_head_conv3x3_fwd: map too large (a tile's rows must span < 2^31 elements, H and W < 16384)");
-    static const bool parked = getenv("GGA_HEADCONV_PARKED") && (atoi(getenv("GGA_HEADCONV_PARKED")) & 1) != 0;   // A/B: the round-2 kernel (1: forward, 2: weight gradient, 3: both)
+    static const bool parked_env = getenv("GGA_HEADCONV_PARKED") && (atoi(getenv("GGA_HEADCONV_PARKED")) & 1) != 0;   // A/B: the round-2 kernel (1: forward, 2: weight gradient, 3: both)
+    // (the round-3 kernel keeps per-lane 32-bit element offsets within a tile and 16-bit halo coordinates: larger maps take the other one)
+    const bool parked = parked_env || !(16ll * W * x_pixel_stride < 2147483647ll && H < 16384 && W < 16384);
     const dim3 grid((unsigned)(n_tiles < 512 ? n_tiles : 512)), block(512);       // persistent: two workgroups per CU
 #define HC_G(CO, BASE, AF) hipLaunchKernelGGL((headconv_fwd16_kernel<CO, AF>), grid, block, 0, stream, x, weight, bias, B, H, W, tx, ty, (int)n_tiles, cout, BASE, in_scale_shift, x_pixel_stride, y)
 #define HC_F(CO, BASE) { if (parked) hipLaunchKernelGGL(headconv_fwd_kernel<CO>, grid, block, 0, stream, x, weight, bias, B, H, W, tx, ty, (int)n_tiles, cout, BASE, in_scale_shift, x_pixel_stride, y); \
@@ -720,10 +724,11 @@ extern "C" int gga_head_conv3x3_wgrad(const float* x, int64_t x_pixel_stride, co
         gga_set_error("gga_head_conv3x3_wgrad: workspace too small");
         return GGA_ERR_WORKSPACE;
     }
-    static const bool parked = getenv("GGA_HEADCONV_PARKED") && (atoi(getenv("GGA_HEADCONV_PARKED")) & 2) != 0;   // A/B: the round-2 kernel
+    static const bool parked_env = getenv("GGA_HEADCONV_PARKED") && (atoi(getenv("GGA_HEADCONV_PARKED")) & 2) != 0;   // A/B: the round-2 kernel
     const int tx = (W + HM_TW - 1) / HM_TW, ty = (H + HM_TR - 1) / HM_TR;          // (both kernels: tiles of 8 x 32)
     const int64_t n_tiles = (int64_t)B * tx * ty;
-    GGA_REQUIRE(n_tiles < 2147483647ll && 8ll * W * x_pixel_stride < 2147483647ll && H < 32768 && W < 32768, "gga_head_conv3x3_wgrad: map too large");
+    // (the round-3 kernel keeps per-lane 32-bit element offsets within a tile and an int tile count: larger maps take the other one)
+    const bool parked = parked_env || !(n_tiles < 2147483647ll && 8ll * W * x_pixel_stride < 2147483647ll);
     const int cap = parked ? HC_WGRAD_BLOCKS : 512;                               // persistent: two workgroups per CU
     const int nb = (int)(n_tiles < cap ? n_tiles : cap);
     float* partials = (float*)workspace;

@@ -12,6 +12,36 @@ import torch
 
 from . import _lib
 from ._lib import LossParams, PfnParams, VoxelParams, check
+import contextlib
+
+_DEFERRED_COUNTERS = None       # a list while a forward pass collects the BatchNorm counters it would increment
+
+
+def count_batch(bn):
+    """``num_batches_tracked += 1`` of a BatchNorm layer in training mode (torch/nn/modules/batchnorm.py,
+    _BatchNorm.forward; the fused paths here all require ``momentum is not None``, so the counter is bookkeeping,
+    not an input of the step). Inside :func:`deferred_batch_counters` the counters are only collected."""
+    if _DEFERRED_COUNTERS is not None:
+        _DEFERRED_COUNTERS.append(bn.num_batches_tracked)
+    else:
+        bn.num_batches_tracked += 1
+
+
+@contextlib.contextmanager
+def deferred_batch_counters():
+    """One multi-tensor add for all the BatchNorm counters of a forward pass instead of one one-element kernel per
+    layer (36 per PointPillars step). A layer applied several times is counted that many times."""
+    global _DEFERRED_COUNTERS
+    prev, _DEFERRED_COUNTERS = _DEFERRED_COUNTERS, []
+    try:
+        yield
+    finally:
+        seen, _DEFERRED_COUNTERS = _DEFERRED_COUNTERS, prev
+        if seen:
+            uniq = {}
+            for t in seen:
+                uniq.setdefault(id(t), [t, 0])[1] += 1
+            torch._foreach_add_([t for t, _ in uniq.values()], [n for _, n in uniq.values()])
 
 LAYOUT_NCHW, LAYOUT_NHWC = 0, 1
 
@@ -655,7 +685,7 @@ def bn_act(x, bn, relu=True, residual=None):
             y = y + residual
         return torch.relu(y) if relu else y
     if bn.training:
-        bn.num_batches_tracked += 1
+        count_batch(bn)
     partials = bn_partials_of(x) if bn.training else None
     y, amax, saved = _BNAct.apply(x, residual, bn.weight, bn.bias, bn.running_mean, bn.running_var, float(bn.eps),
                                   float(bn.momentum), bool(bn.training), bool(relu), int(rc[0]), int(C), partials)
@@ -824,7 +854,7 @@ def bn_relu_cat(xs, bns):
             else bn_act(xs[0], bns[0], relu=True)
     for bn in bns:
         if bn.training:
-            bn.num_batches_tracked += 1
+            count_batch(bn)
     n = len(xs)
     cfg = tuple((float(bn.eps), float(bn.momentum), bool(bn.training)) for bn in bns)
     # the producers' per-channel sums (dense_conv / strided_conv / sparse convolutions), where they left them
@@ -945,7 +975,7 @@ def bn_relu_head_conv3x3(x, bn, conv):
           and conv.dilation == (1, 1) and conv.groups == 1 and conv.padding_mode == 'zeros')
     if not ok:
         return head_conv3x3(bn_act(x, bn, relu=True), conv)
-    bn.num_batches_tracked += 1
+    count_batch(bn)
     partials = bn_partials_of(x)
     return _BnReluHeadConv3x3.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, conv.weight, conv.bias,
                                     float(bn.eps), float(bn.momentum), True, partials)
@@ -1057,7 +1087,7 @@ def head_branches(x, branches):
         if not ok:
             return None
     for _, bn, _ in branches:
-        bn.num_batches_tracked += 1
+        count_batch(bn)
     n = len(branches)
     cfg = tuple((float(bn.eps), float(bn.momentum)) for _, bn, _ in branches)
     cols = ([c1.weight for c1, _, _ in branches], [bn.weight for _, bn, _ in branches], [bn.bias for _, bn, _ in branches],

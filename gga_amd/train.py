@@ -308,7 +308,7 @@ class Runner:
         return dict(loss=loss, log_vars=log_vars, num_samples=len(data['img_metas']))
 
     def step(self, data, next_data=None):
-        from . import dense_conv
+        from . import dense_conv, functional as F
         dense_conv.AMAX_POOL.next_generation()      # one memset for all of this step's absmax slots
         guarded = (dense_conv.PLANES == 2 and self.range_check_interval > 0 and self.iter % self.range_check_interval == 0
                    and self.device.type == 'cuda')
@@ -338,7 +338,8 @@ class Runner:
                 g['lr'] = self.lr_sched(self.iter)
             if self.mom_sched is not None:
                 g['betas'] = (self.mom_sched(self.iter), g['betas'][1])
-        out = self._call_train_step(data)
+        with F.deferred_batch_counters():                 # one multi-tensor add for the BatchNorm counters of the pass
+            out = self._call_train_step(data)
         self.optimizer.zero_grad(set_to_none=True)
         dense_conv.RANGE_GUARD.phase = 'backward'
         out['loss'].backward()

@@ -109,7 +109,7 @@ class PillarFeatureNet(nn.Module):
             prm = F.pfn_params((self.vx, self.vy, self.vz), (self.x_offset, self.y_offset, self.z_offset),
                                bn.eps, bn.momentum, self.training)
             if self.training:
-                bn.num_batches_tracked += 1
+                F.count_batch(bn)
             return F.fused_pfn(features, num_points.int(), coors.int(), l0.linear.weight, bn.weight, bn.bias,
                                bn.running_mean, bn.running_var, prm, num_valid=F.num_valid_of(coors))
         if F.num_valid_of(coors) is not None:     # capacity-sized buffers: the eager ops need the exact rows

@@ -357,3 +357,24 @@ def test_runner_inputs_ready_is_a_no_op_without_a_gpu():
     r = Runner(build_model(cfg.model), cfg, max_iters=10)
     r.inputs_ready(dict(points=[1]), dict(points=[2]))
     assert r._ready == {}
+
+
+def test_batchnorm_counters_deferred_into_one_add():
+    """functional.deferred_batch_counters: the counters a forward pass would increment are collected and added once at
+    the end (a layer applied twice counts twice); outside it ``count_batch`` increments at once (reference semantics:
+    torch.nn.modules.batchnorm._BatchNorm.forward, ``num_batches_tracked += 1`` per call in training mode)."""
+    import torch
+    from gga_amd import functional as F
+    a, b = torch.nn.BatchNorm1d(4), torch.nn.BatchNorm2d(4)
+    with F.deferred_batch_counters():
+        F.count_batch(a), F.count_batch(b), F.count_batch(a)
+        assert int(a.num_batches_tracked) == 0 and int(b.num_batches_tracked) == 0
+        with F.deferred_batch_counters():              # nested passes keep their own lists
+            F.count_batch(b)
+        assert int(b.num_batches_tracked) == 1
+    assert int(a.num_batches_tracked) == 2 and int(b.num_batches_tracked) == 2
+    F.count_batch(a)
+    assert int(a.num_batches_tracked) == 3
+    with F.deferred_batch_counters():                  # an empty pass adds nothing
+        pass
+    assert int(a.num_batches_tracked) == 3

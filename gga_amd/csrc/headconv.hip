@@ -8,8 +8,12 @@
 // time on a 576-wide reduction for a 3-wide output (measured: MIOpen implicit-GEMM 0.34 ms fwd,
 // 0.38 ms wgrad per conv on a 219 MB input = 0.6 TB/s; a lane-per-pixel VALU kernel over an LDS
 // halo tile: 0.165 / 0.147 ms, bound by LDS reads). Swapping the roles makes them GEMMs with
-// N = 9 taps x COUT <= 32 and the convolution a shifted sum of the result (see the kernels):
-// fwd 0.084-0.105 ms, each input element read once per tile from HBM (halo 1.33x).
+// N = 9 taps x COUT <= 32 and the convolution a shifted sum of the result (see the kernels).
+// Three generations live in this file: round 1 (one tile per workgroup, described next), round 2 (persistent, rows parked
+// in LDS: headconv_fwd_kernel / headconv_wgrad_kernel - kept for maps beyond the 32-bit tile offsets of the newer ones and
+// for the A/B, GGA_HEADCONV_PARKED) and round 3, the shipped ones (headconv_fwd16_kernel / headconv_wgrad16_kernel: operand
+// straight from the load into v_mfma_f32_16x16x4_f32, every load a tile ahead with counted waits; 0.091 -> 0.056-0.063 ms
+// forward, 0.100 -> 0.047-0.055 ms weight gradient at 16 x 248 x 216: DESIGN.md 6c).
 // Backward-data is never materialised on the train path: the gradient w.r.t. the (never stored)
 // normalised activation is recomputed from the 1-4 channel grad_y inside the BatchNorm backward of
 // the branch (headtail_bwd_kernel below).
@@ -30,7 +34,7 @@
 // (32h + s) on both operands. Z goes to LDS (pixel stride 33 floats), then one thread per
 // (output pixel, channel) adds its nine taps. Each input pixel is read once per tile
 // (halo 1.33x), 32 MFMAs per 32 pixels.
-// (That was the round-1 forward kernel; the shipped one is the persistent form further down. Cycle stamps per workgroup at
+// (That was the round-1 forward kernel. Cycle stamps per workgroup at
 // 16 x 248 x 216 had shown ~25 k of its ~60 k cycles waiting for the first pixel group's rows, ~20 k for the second group's -
 // which only three of the eight waves have -, 2 k of matrix products per group and 1-8 k of epilogue.)
 #define HM_TR 8
@@ -41,7 +45,7 @@
 #define HM_NGRP ((HM_NPIX + 31) / 32)
 #define HM_ZS 33
 
-// Round 2: the kernel is PERSISTENT and keeps one pixel group's rows in flight per wave at all times. A workgroup owns
+// Round 2 (headconv_fwd_kernel): the kernel is PERSISTENT and keeps one pixel group's rows in flight per wave at all times. A workgroup owns
 // 13 x 32 output pixels; its 15 x 34 = 510 halo pixels are exactly 16 groups of 32, two per wave. A wave walks the stream
 // of its groups (tile after tile): park the rows that arrived (whole pixel rows, lane l = 16-byte piece l of four rows per
 // load instruction, optional input affine + ReLU on the lane's four fixed channels) in its own LDS region, read them back

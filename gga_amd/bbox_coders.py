@@ -17,13 +17,8 @@ from .registry import BBOX_CODERS
 class CenterPointBBoxCoder:
     def __init__(self, pc_range, out_size_factor, voxel_size, post_center_range=None, max_num=100,
                  score_threshold=None, code_size=9):
-        self.pc_range = pc_range
-        self.out_size_factor = out_size_factor
-        self.voxel_size = voxel_size
-        self.post_center_range = post_center_range
-        self.max_num = max_num
-        self.score_threshold = score_threshold
-        self.code_size = code_size
+        self.pc_range, self.voxel_size, self.out_size_factor = pc_range, voxel_size, out_size_factor
+        self.post_center_range, self.max_num, self.score_threshold, self.code_size = post_center_range, max_num, score_threshold, code_size
 
     def encode(self):
         pass
@@ -76,48 +71,54 @@ def limit_period(val, offset=0.5, period=np.pi):
 
 @BBOX_CODERS.register_module()
 class FCOS3DBBoxCoder:
-    """mmdet3d/core/bbox/coders/fcos3d_bbox_coder.py:10-127: per-level learnable scales, depth / size priors,
-    stride un-normalisation at test time, local yaw -> global yaw."""
+    """mmdet3d/core/bbox/coders/fcos3d_bbox_coder.py:10-127 (interface: ``decode`` / ``decode_yaw`` and the constructor keys).
+    Raw regression maps [B, C, H, W] with channels (dx, dy | depth | w, h, l | yaw ...) -> metric quantities: a learnable
+    factor per group and level, ``exp`` (or an affine prior) for depth, ``exp`` (times a class prior) for the sizes; offsets
+    are in units of the level's stride while training and in pixels at test time. Written without in-place updates: the
+    result is a new tensor assembled from the channel groups."""
 
     def __init__(self, base_depths=None, base_dims=None, code_size=7, norm_on_bbox=True):
         self.base_depths, self.base_dims, self.bbox_code_size, self.norm_on_bbox = base_depths, base_dims, code_size, norm_on_bbox
 
     def encode(self, gt_bboxes_3d, gt_labels_3d, gt_bboxes, gt_labels):
-        pass
+        """Targets are built by the head (``gga_fcos3d_targets``); nothing to encode."""
+
+    @staticmethod
+    def _class_prior(table, cls_score):
+        """Per-location rows of a per-class table, chosen by the best-scoring class: [B, H, W, ...] -> channels first."""
+        assert len(table) == cls_score.shape[1], 'one prior per class'
+        best = cls_score.argmax(dim=1)
+        return F.const_tensor(table, cls_score.device, cls_score.dtype)[best].movedim(-1, 1)
 
     def decode(self, bbox, scale, stride, training, cls_score=None):
-        scale_offset, scale_depth, scale_size = scale[0:3]
-        clone_bbox = bbox.clone()
-        bbox[:, :2] = scale_offset(clone_bbox[:, :2]).float()
-        bbox[:, 2] = scale_depth(clone_bbox[:, 2]).float()
-        bbox[:, 3:6] = scale_size(clone_bbox[:, 3:6]).float()
-        if self.base_depths is None:
-            bbox[:, 2] = bbox[:, 2].exp()
-        elif len(self.base_depths) == 1:
-            mean, std = self.base_depths[0]
-            bbox[:, 2] = mean + bbox.clone()[:, 2] * std
-        else:
-            assert len(self.base_depths) == cls_score.shape[1]
-            indices = cls_score.max(dim=1)[1]
-            priors = F.const_tensor(self.base_depths, cls_score.device, cls_score.dtype)[indices, :].permute(0, 3, 1, 2)
-            bbox[:, 2] = priors[:, 0] + bbox.clone()[:, 2] * priors[:, 1]
-        bbox[:, 3:6] = bbox[:, 3:6].exp()
-        if self.base_dims is not None:
-            assert len(self.base_dims) == cls_score.shape[1]
-            indices = cls_score.max(dim=1)[1]
-            size_priors = F.const_tensor(self.base_dims, cls_score.device, cls_score.dtype)[indices, :].permute(0, 3, 1, 2)
-            bbox[:, 3:6] = size_priors * bbox.clone()[:, 3:6]
         assert self.norm_on_bbox is True
+        offset_factor, depth_factor, size_factor = scale[0], scale[1], scale[2]
+        offset = offset_factor(bbox[:, 0:2]).float()
+        depth = depth_factor(bbox[:, 2:3]).float()
+        size = size_factor(bbox[:, 3:6]).float().exp()
+        if self.base_depths is None:
+            depth = depth.exp()
+        elif len(self.base_depths) == 1:
+            (mean, std), = self.base_depths
+            depth = mean + depth * std
+        else:
+            prior = self._class_prior(self.base_depths, cls_score)                # [B, 2, H, W]: mean, std of the class
+            depth = prior[:, 0:1] + depth * prior[:, 1:2]
+        if self.base_dims is not None:
+            size = self._class_prior(self.base_dims, cls_score) * size
         if not training:
-            bbox[:, :2] *= stride
-        return bbox
+            offset = offset * stride
+        return torch.cat([offset.to(bbox.dtype), depth.to(bbox.dtype), size.to(bbox.dtype), bbox[:, 6:]], dim=1)
 
     @staticmethod
     def decode_yaw(bbox, centers2d, dir_cls, dir_offset, cam2img):
-        if bbox.shape[0] > 0:
-            dir_rot = limit_period(bbox[..., 6] - dir_offset, 0, np.pi)
-            bbox[..., 6] = dir_rot + dir_offset + np.pi * dir_cls.to(bbox.dtype)
-        bbox[:, 6] = torch.atan2(centers2d[:, 0] - cam2img[0, 2], cam2img[0, 0]) + bbox[:, 6]
+        """Local yaw in [offset, offset + pi) plus the direction bin's half turn, then + the viewing angle of the projected
+        centre (local -> global yaw). ``bbox`` [n, >= 7] is updated in its yaw column and returned."""
+        yaw = bbox[:, 6]
+        if len(bbox):
+            yaw = limit_period(yaw - dir_offset, 0, np.pi) + dir_offset + np.pi * dir_cls.to(bbox.dtype)
+        view = torch.atan2(centers2d[:, 0] - cam2img[0, 2], cam2img[0, 0])
+        bbox[:, 6] = view + yaw
         return bbox
 
 
@@ -127,23 +128,25 @@ class PGDBBoxCoder(FCOS3DBBoxCoder):
     probabilistic depth read-out."""
 
     def decode_2d(self, bbox, scale, stride, max_regress_range, training, pred_keypoints=False, pred_bbox2d=True):
-        clone_bbox = bbox.clone()
+        """The 16 key-point offsets (tanh of the scaled raw values; times the level's regress range at test time) right after
+        the 3D code, and the four distances to the 2D box sides in the last four channels (ReLU when normalised by the
+        stride - times the stride at test time -, ``exp`` otherwise)."""
         cs = self.bbox_code_size
-        if pred_keypoints:
-            bbox[:, cs:cs + 16] = torch.tanh(scale[3](clone_bbox[:, cs:cs + 16]).float())
+        head, keys, mid, sides = bbox[:, :cs], bbox[:, cs:cs + 16] if pred_keypoints else None, None, None
         if pred_bbox2d:
-            bbox[:, -4:] = scale[-1](clone_bbox[:, -4:]).float()
-        if self.norm_on_bbox:
-            if pred_bbox2d:
-                bbox[:, -4:] = TF.relu(bbox.clone()[:, -4:])
-            if not training:
-                if pred_keypoints:
-                    bbox[:, cs:cs + 16] *= max_regress_range
-                if pred_bbox2d:
-                    bbox[:, -4:] *= stride
-        elif pred_bbox2d:
-            bbox[:, -4:] = bbox.clone()[:, -4:].exp()
-        return bbox
+            sides = scale[-1](bbox[:, -4:]).float()
+            sides = TF.relu(sides) if self.norm_on_bbox else sides.exp()
+            if self.norm_on_bbox and not training:
+                sides = sides * stride
+        if pred_keypoints:
+            keys = torch.tanh(scale[3](keys).float())
+            if self.norm_on_bbox and not training:
+                keys = keys * max_regress_range
+        lo = cs + 16 if pred_keypoints else cs
+        hi = bbox.shape[1] - 4 if pred_bbox2d else bbox.shape[1]
+        mid = bbox[:, lo:hi]
+        parts = [head] + ([keys.to(bbox.dtype)] if pred_keypoints else []) + [mid] + ([sides.to(bbox.dtype)] if pred_bbox2d else [])
+        return torch.cat(parts, dim=1)
 
     def decode_prob_depth(self, depth_cls_preds, depth_range, depth_unit, division, num_depth_cls):
         split = F.const_tensor(list(range(num_depth_cls)), depth_cls_preds.device, depth_cls_preds.dtype).reshape([1, -1])

@@ -103,16 +103,16 @@ class KittiDataset_GGA_train:
         info = self.data_infos[index]
         rect = info['calib']['R0_rect'].astype(np.float32)
         Trv2c = info['calib']['Tr_velo_to_cam'].astype(np.float32)
-        if 'plane' in info:
-            reverse = np.linalg.inv(rect @ Trv2c)
-            plane_norm_cam, plane_off_cam = info['plane'][:3], -info['plane'][:3] * info['plane'][3]
-            plane_norm_lidar = (reverse[:3, :3] @ plane_norm_cam[:, None])[:, 0]
-            plane_off_lidar = reverse[:3, :3] @ plane_off_cam[:, None][:, 0] + reverse[:3, 3]
-            plane_lidar = np.zeros_like(plane_norm_lidar, shape=(4, ))
-            plane_lidar[:3] = plane_norm_lidar
-            plane_lidar[3] = -plane_norm_lidar.T @ plane_off_lidar
-        else:
-            plane_lidar = None
+        plane_lidar = None
+        if 'plane' in info:          # ground plane (n, d) of the camera frame -> LiDAR frame: normal rotated, a point of it moved
+            cam2lidar = np.linalg.inv(rect @ Trv2c)
+            R, t = cam2lidar[:3, :3], cam2lidar[:3, 3]
+            normal_cam = info['plane'][:3]
+            on_plane_cam = -normal_cam * info['plane'][3]
+            normal = (R @ normal_cam[:, None])[:, 0]
+            on_plane = R @ on_plane_cam[:, None][:, 0] + t
+            plane_lidar = np.zeros_like(normal, shape=(4, ))
+            plane_lidar[:3], plane_lidar[3] = normal, -normal.T @ on_plane
         annos = self.remove_dontcare_GGA(info['annos'])      # other objects stay: collision tests when sampling
         difficulty = annos['difficulty']
         gt_names = annos['name']
@@ -148,25 +148,30 @@ class KittiDataset_GGA_train:
             out[key] = [val[i] for i in keep] if isinstance(val, list) else val[keep]
         return out
 
-    # ---- Custom3DDataset plumbing (custom_3d.py:127-156, 204-245, 430-448)
+    # ---- sample plumbing (the hooks of Custom3DDataset: custom_3d.py:127-156, 204-245, 430-448)
+    _FIELD_REGISTRIES = ('img_fields', 'bbox3d_fields', 'pts_mask_fields', 'pts_seg_fields', 'bbox_fields', 'mask_fields', 'seg_fields')
+
     def pre_pipeline(self, results):
-        results['img_fields'] = []
-        results['bbox3d_fields'] = []
-        results['pts_mask_fields'] = []
-        results['pts_seg_fields'] = []
-        results['bbox_fields'] = []
-        results['mask_fields'] = []
-        results['seg_fields'] = []
-        results['box_type_3d'] = self.box_type_3d
-        results['box_mode_3d'] = self.box_mode_3d
+        """What every transform expects to find in a fresh sample: the (empty) registries of field names they append to, and
+        the box class / coordinate mode of this dataset."""
+        for registry in self._FIELD_REGISTRIES:
+            results[registry] = []
+        results.update(box_type_3d=self.box_type_3d, box_mode_3d=self.box_mode_3d)
+
+    def _through_pipeline(self, index):
+        sample = self.get_data_info(index)
+        if sample is not None:
+            self.pre_pipeline(sample)
+            sample = self.pipeline(sample)
+        return sample
 
     def prepare_train_data(self, index):
-        input_dict = self.get_data_info(index)
-        if input_dict is None:
+        """The train sample of ``index``, or None when there is nothing to learn from it (no info, a transform gave up, or -
+        with ``filter_empty_gt`` - no object of a known class is left after the filters)."""
+        example = self._through_pipeline(index)
+        if example is None:
             return None
-        self.pre_pipeline(input_dict)
-        example = self.pipeline(input_dict)
-        if self.filter_empty_gt and (example is None or ~(_unwrap(example['gt_labels_3d']) != -1).any()):
+        if self.filter_empty_gt and not bool((_unwrap(example['gt_labels_3d']) != -1).any()):
             return None
         return example
 
@@ -175,15 +180,11 @@ class KittiDataset_GGA_train:
 
     def __getitem__(self, idx):
         if self.test_mode:
-            input_dict = self.get_data_info(idx)
-            self.pre_pipeline(input_dict)
-            return self.pipeline(input_dict)
-        while True:
-            data = self.prepare_train_data(idx)
-            if data is None:
-                idx = self._rand_another(idx)
-                continue
-            return data
+            return self._through_pipeline(idx)
+        data = self.prepare_train_data(idx)
+        while data is None:                      # an unusable frame is replaced by a random other one
+            data = self.prepare_train_data(self._rand_another(idx))
+        return data
 
 
 def _unwrap(x):
@@ -308,27 +309,21 @@ class KittiDataset_GGA_match(KittiDataset_GGA_train):
             sample_idx = info['image']['image_idx']
             image_shape = info['image']['image_shape'][:2]
             box_dict = self.convert_valid_bboxes(pred_dicts, info)
-            anno = {'name': [], 'truncated': [], 'occluded': [], 'alpha': [], 'bbox': [], 'dimensions': [], 'location': [],
-                    'rotation_y': [], 'score': []}
-            if len(box_dict['bbox']) > 0:
-                for box, box_lidar, bbox, score, label in zip(box_dict['box3d_camera'], box_dict['box3d_lidar'], box_dict['bbox'],
-                                                              box_dict['scores'], box_dict['label_preds']):
-                    bbox[2:] = np.minimum(bbox[2:], image_shape[::-1])
-                    bbox[:2] = np.maximum(bbox[:2], [0, 0])
-                    anno['name'].append(class_names[int(label)])
-                    anno['truncated'].append(0.0)
-                    anno['occluded'].append(0)
-                    anno['alpha'].append(-np.arctan2(-box_lidar[1], box_lidar[0]) + box[6])
-                    anno['bbox'].append(bbox)
-                    anno['dimensions'].append(box[3:6])
-                    anno['location'].append(box[:3])
-                    anno['rotation_y'].append(box[6])
-                    anno['score'].append(score)
-                anno = {k: np.stack(v) for k, v in anno.items()}
+            n = len(box_dict['bbox'])
+            cam, lidar = np.asarray(box_dict['box3d_camera']), np.asarray(box_dict['box3d_lidar'])
+            # KITTI label columns of the frame's valid detections, whole columns at a time: 2D box clipped to the image,
+            # observation angle alpha = rotation_y minus the azimuth of the box centre seen from the LiDAR origin
+            bbox = np.array(box_dict['bbox'], dtype=np.asarray(box_dict['bbox']).dtype).reshape(n, 4)
+            if n:
+                bbox[:, 2:] = np.minimum(bbox[:, 2:], image_shape[::-1])
+                bbox[:, :2] = np.maximum(bbox[:, :2], [0, 0])
+                anno = dict(name=np.array([class_names[int(label)] for label in box_dict['label_preds']]),
+                            truncated=np.zeros(n), occluded=np.zeros(n, dtype=np.int64),
+                            alpha=-np.arctan2(-lidar[:, 1], lidar[:, 0]) + cam[:, 6], bbox=bbox, dimensions=cam[:, 3:6],
+                            location=cam[:, :3], rotation_y=cam[:, 6], score=np.asarray(box_dict['scores']))
             else:
-                anno = {'name': np.array([]), 'truncated': np.array([]), 'occluded': np.array([]), 'alpha': np.array([]),
-                        'bbox': np.zeros([0, 4]), 'dimensions': np.zeros([0, 3]), 'location': np.zeros([0, 3]),
-                        'rotation_y': np.array([]), 'score': np.array([])}
+                anno = dict(name=np.array([]), truncated=np.array([]), occluded=np.array([]), alpha=np.array([]), bbox=np.zeros([0, 4]),
+                            dimensions=np.zeros([0, 3]), location=np.zeros([0, 3]), rotation_y=np.array([]), score=np.array([]))
             if submission_prefix is not None:
                 with open(f'{submission_prefix}/{sample_idx:06d}.txt', 'w') as f:
                     bbox, loc, dims = anno['bbox'], anno['location'], anno['dimensions']          # lhw -> hwl

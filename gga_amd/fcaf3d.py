@@ -302,276 +302,7 @@ class MinkResNet(nn.Module):
 
 
 # ------------------------------------------------------------------------------------------------------------------ head
-@HEADS.register_module()
-class FCAF3DHead(nn.Module):
-    def __init__(self, n_classes, in_channels, out_channels, n_reg_outs, voxel_size, pts_prune_threshold, pts_assign_threshold,
-                 pts_center_threshold, center_loss=dict(type='CrossEntropyLoss', use_sigmoid=True),
-                 bbox_loss=dict(type='AxisAlignedIoULoss'), cls_loss=dict(type='FocalLoss'), train_cfg=None, test_cfg=None,
-                 init_cfg=None):
-        super().__init__()
-        self.voxel_size = voxel_size
-        self.pts_prune_threshold, self.pts_assign_threshold, self.pts_center_threshold = pts_prune_threshold, pts_assign_threshold, pts_center_threshold
-        self.center_loss, self.bbox_loss, self.cls_loss = build_loss(center_loss), build_loss(bbox_loss), build_loss(cls_loss)
-        from .config import ConfigDict
-        self.train_cfg = train_cfg
-        self.test_cfg = ConfigDict(test_cfg) if isinstance(test_cfg, dict) and not isinstance(test_cfg, ConfigDict) else test_cfg
-        self._init_layers(in_channels, out_channels, n_reg_outs, n_classes)
-
-    @staticmethod
-    def _make_block(in_channels, out_channels):
-        return nn.Sequential(ME.MinkowskiConvolution(in_channels, out_channels, kernel_size=3, dimension=3),
-                             ME.MinkowskiBatchNorm(out_channels), ME.MinkowskiELU())
-
-    @staticmethod
-    def _make_up_block(in_channels, out_channels):
-        return nn.Sequential(
-            ME.MinkowskiGenerativeConvolutionTranspose(in_channels, out_channels, kernel_size=2, stride=2, dimension=3),
-            ME.MinkowskiBatchNorm(out_channels), ME.MinkowskiELU(),
-            ME.MinkowskiConvolution(out_channels, out_channels, kernel_size=3, dimension=3),
-            ME.MinkowskiBatchNorm(out_channels), ME.MinkowskiELU())
-
-    def _init_layers(self, in_channels, out_channels, n_reg_outs, n_classes):
-        self.pruning = ME.MinkowskiPruning()
-        for i in range(len(in_channels)):
-            if i > 0:
-                self.__setattr__(f'up_block_{i}', self._make_up_block(in_channels[i], in_channels[i - 1]))
-            self.__setattr__(f'out_block_{i}', self._make_block(in_channels[i], out_channels))
-        self.conv_center = ME.MinkowskiConvolution(out_channels, 1, kernel_size=1, dimension=3)
-        self.conv_reg = ME.MinkowskiConvolution(out_channels, n_reg_outs, kernel_size=1, dimension=3)
-        self.conv_cls = ME.MinkowskiConvolution(out_channels, n_classes, kernel_size=1, bias=True, dimension=3)
-        self.scales = nn.ModuleList([Scale(1.) for _ in range(len(in_channels))])
-
-    def init_weights(self):
-        nn.init.normal_(self.conv_center.kernel, std=.01)
-        nn.init.normal_(self.conv_reg.kernel, std=.01)
-        nn.init.normal_(self.conv_cls.kernel, std=.01)
-        nn.init.constant_(self.conv_cls.bias, bias_init_with_prob(.01))
-
-    def forward(self, x):
-        center_preds, bbox_preds, cls_preds, points = [], [], [], []
-        inputs = x
-        x = inputs[-1]
-        prune_score = None
-        for i in range(len(inputs) - 1, -1, -1):
-            if i < len(inputs) - 1:
-                x = self.__getattr__(f'up_block_{i + 1}')(x)
-                x = inputs[i] + x
-                x = self._prune(x, prune_score)
-            out = self.__getattr__(f'out_block_{i}')(x)
-            center_pred, bbox_pred, cls_pred, point, prune_score = self._forward_single(out, self.scales[i])
-            center_preds.append(center_pred)
-            bbox_preds.append(bbox_pred)
-            cls_preds.append(cls_pred)
-            points.append(point)
-        return center_preds[::-1], bbox_preds[::-1], cls_preds[::-1], points[::-1]
-
-    def forward_train(self, x, gt_bboxes, gt_labels, input_metas):
-        center_preds, bbox_preds, cls_preds, points = self(x)
-        return self._loss(center_preds, bbox_preds, cls_preds, points, gt_bboxes, gt_labels, input_metas)
-
-    def forward_test(self, x, input_metas):
-        center_preds, bbox_preds, cls_preds, points = self(x)
-        return self._get_bboxes(center_preds, bbox_preds, cls_preds, points, input_metas)
-
-    def _prune(self, x, scores):
-        with torch.no_grad():
-            coordinates = x.C.float()
-            interpolated_scores = scores.features_at_coordinates(coordinates)
-            prune_mask = interpolated_scores.new_zeros((len(interpolated_scores)), dtype=torch.bool)
-            for permutation in x.decomposition_permutations:
-                score = interpolated_scores[permutation]
-                mask = score.new_zeros((len(score)), dtype=torch.bool)
-                topk = min(len(score), self.pts_prune_threshold)
-                ids = torch.topk(score.squeeze(1), topk, sorted=False).indices
-                mask[ids] = True
-                prune_mask[permutation[mask]] = True
-        return self.pruning(x, prune_mask)
-
-    def _forward_single(self, x, scale):
-        center_pred = self.conv_center(x).features
-        scores = self.conv_cls(x)
-        cls_pred = scores.features
-        prune_scores = ME.SparseTensor(scores.features.max(dim=1, keepdim=True).values, cmap=scores.cmap)
-        reg_final = self.conv_reg(x).features
-        reg_distance = torch.exp(scale(reg_final[:, :6]))
-        reg_angle = reg_final[:, 6:]
-        bbox_pred = torch.cat((reg_distance, reg_angle), dim=1)
-        # per-sample rows (the reference indexes with every permutation in turn: x[permutation] - whose backward in torch is a
-        # sort-based scatter of the whole tensor per use, 83 launches of 0.6 ms per step here; the permutations partition the rows)
-        perms = x.decomposition_permutations
-        center_preds, bbox_preds, cls_preds = split_rows(center_pred, perms), split_rows(bbox_pred, perms), split_rows(cls_pred, perms)
-        points = x.decomposed_coordinates
-        for i in range(len(points)):
-            points[i] = points[i] * self.voxel_size
-        return center_preds, bbox_preds, cls_preds, points, prune_scores
-
-    def _loss_single(self, center_preds, bbox_preds, cls_preds, points, gt_bboxes, gt_labels, input_meta):
-        center_targets, bbox_targets, cls_targets = self._get_targets(points, gt_bboxes, gt_labels)
-        center_preds, bbox_preds, cls_preds, points = torch.cat(center_preds), torch.cat(bbox_preds), torch.cat(cls_preds), torch.cat(points)
-        pos_inds = torch.nonzero(cls_targets >= 0).squeeze(1)
-        n_pos = points.new_tensor(len(pos_inds))
-        n_pos = max(reduce_mean(n_pos), 1.)
-        cls_loss = self.cls_loss(cls_preds, cls_targets, avg_factor=n_pos)
-        pos_center_preds, pos_bbox_preds = take_rows(center_preds, pos_inds), take_rows(bbox_preds, pos_inds)
-        pos_center_targets = center_targets[pos_inds].unsqueeze(1)
-        pos_bbox_targets = bbox_targets[pos_inds]
-        center_denorm = max(reduce_mean(pos_center_targets.sum().detach()), 1e-6)        # outside the branch: no deadlock
-        if len(pos_inds) > 0:
-            pos_points = points[pos_inds]
-            center_loss = self.center_loss(pos_center_preds, pos_center_targets, avg_factor=n_pos)
-            bbox_loss = self.bbox_loss(self._bbox_to_loss(self._bbox_pred_to_bbox(pos_points, pos_bbox_preds)),
-                                       self._bbox_to_loss(pos_bbox_targets), weight=pos_center_targets.squeeze(1),
-                                       avg_factor=center_denorm)
-        else:
-            center_loss, bbox_loss = pos_center_preds.sum(), pos_bbox_preds.sum()
-        return center_loss, bbox_loss, cls_loss
-
-    def _loss(self, center_preds, bbox_preds, cls_preds, points, gt_bboxes, gt_labels, input_metas):
-        center_losses, bbox_losses, cls_losses = [], [], []
-        for i in range(len(input_metas)):
-            center_loss, bbox_loss, cls_loss = self._loss_single(
-                center_preds=[x[i] for x in center_preds], bbox_preds=[x[i] for x in bbox_preds], cls_preds=[x[i] for x in cls_preds],
-                points=[x[i] for x in points], input_meta=input_metas[i], gt_bboxes=gt_bboxes[i], gt_labels=gt_labels[i])
-            center_losses.append(center_loss)
-            bbox_losses.append(bbox_loss)
-            cls_losses.append(cls_loss)
-        return dict(center_loss=torch.mean(torch.stack(center_losses)), bbox_loss=torch.mean(torch.stack(bbox_losses)),
-                    cls_loss=torch.mean(torch.stack(cls_losses)))
-
-    def _get_bboxes_single(self, center_preds, bbox_preds, cls_preds, points, input_meta):
-        mlvl_bboxes, mlvl_scores = [], []
-        for center_pred, bbox_pred, cls_pred, point in zip(center_preds, bbox_preds, cls_preds, points):
-            scores = cls_pred.sigmoid() * center_pred.sigmoid()
-            max_scores, _ = scores.max(dim=1)
-            if len(scores) > self.test_cfg.nms_pre > 0:
-                _, ids = max_scores.topk(self.test_cfg.nms_pre)
-                bbox_pred, scores, point = bbox_pred[ids], scores[ids], point[ids]
-            mlvl_bboxes.append(self._bbox_pred_to_bbox(point, bbox_pred))
-            mlvl_scores.append(scores)
-        return self._single_scene_multiclass_nms(torch.cat(mlvl_bboxes), torch.cat(mlvl_scores), input_meta)
-
-    def _get_bboxes(self, center_preds, bbox_preds, cls_preds, points, input_metas):
-        return [self._get_bboxes_single(center_preds=[x[i] for x in center_preds], bbox_preds=[x[i] for x in bbox_preds],
-                                        cls_preds=[x[i] for x in cls_preds], points=[x[i] for x in points],
-                                        input_meta=input_metas[i]) for i in range(len(input_metas))]
-
-    @staticmethod
-    def _bbox_to_loss(bbox):
-        if bbox.shape[-1] != 6:          # the rotated IoU loss takes (x, y, z, w, h, l, heading)
-            return bbox
-        return torch.stack((bbox[..., 0] - bbox[..., 3] / 2, bbox[..., 1] - bbox[..., 4] / 2, bbox[..., 2] - bbox[..., 5] / 2,
-                            bbox[..., 0] + bbox[..., 3] / 2, bbox[..., 1] + bbox[..., 4] / 2, bbox[..., 2] + bbox[..., 5] / 2), dim=-1)
-
-    @staticmethod
-    def _bbox_pred_to_bbox(points, bbox_pred):
-        if bbox_pred.shape[0] == 0:
-            return bbox_pred
-        x_center = points[:, 0] + (bbox_pred[:, 1] - bbox_pred[:, 0]) / 2
-        y_center = points[:, 1] + (bbox_pred[:, 3] - bbox_pred[:, 2]) / 2
-        z_center = points[:, 2] + (bbox_pred[:, 5] - bbox_pred[:, 4]) / 2
-        base_bbox = torch.stack([x_center, y_center, z_center, bbox_pred[:, 0] + bbox_pred[:, 1], bbox_pred[:, 2] + bbox_pred[:, 3],
-                                 bbox_pred[:, 4] + bbox_pred[:, 5]], -1)
-        if bbox_pred.shape[1] == 6:
-            return base_bbox
-        # rotated case: ..., sin(2a) ln(q), cos(2a) ln(q)
-        scale = bbox_pred[:, 0] + bbox_pred[:, 1] + bbox_pred[:, 2] + bbox_pred[:, 3]
-        q = torch.exp(torch.sqrt(torch.pow(bbox_pred[:, 6], 2) + torch.pow(bbox_pred[:, 7], 2)))
-        alpha = 0.5 * torch.atan2(bbox_pred[:, 6], bbox_pred[:, 7])
-        return torch.stack((x_center, y_center, z_center, scale / (1 + q), scale / (1 + q) * q, bbox_pred[:, 5] + bbox_pred[:, 4], alpha), dim=-1)
-
-    @staticmethod
-    def _get_face_distances(points, boxes):
-        shift = torch.stack((points[..., 0] - boxes[..., 0], points[..., 1] - boxes[..., 1], points[..., 2] - boxes[..., 2]), dim=-1).permute(1, 0, 2)
-        shift = rotation_3d_in_axis_z(shift, -boxes[0, :, 6]).permute(1, 0, 2)
-        centers = boxes[..., :3] + shift
-        dx_min = centers[..., 0] - boxes[..., 0] + boxes[..., 3] / 2
-        dx_max = boxes[..., 0] + boxes[..., 3] / 2 - centers[..., 0]
-        dy_min = centers[..., 1] - boxes[..., 1] + boxes[..., 4] / 2
-        dy_max = boxes[..., 1] + boxes[..., 4] / 2 - centers[..., 1]
-        dz_min = centers[..., 2] - boxes[..., 2] + boxes[..., 5] / 2
-        dz_max = boxes[..., 2] + boxes[..., 5] / 2 - centers[..., 2]
-        return torch.stack((dx_min, dx_max, dy_min, dy_max, dz_min, dz_max), dim=-1)
-
-    @staticmethod
-    def _get_centerness(face_distances):
-        x_dims, y_dims, z_dims = face_distances[..., [0, 1]], face_distances[..., [2, 3]], face_distances[..., [4, 5]]
-        centerness_targets = x_dims.min(dim=-1)[0] / x_dims.max(dim=-1)[0] * y_dims.min(dim=-1)[0] / y_dims.max(dim=-1)[0] * \
-            z_dims.min(dim=-1)[0] / z_dims.max(dim=-1)[0]
-        return torch.sqrt(centerness_targets)
-
-    @torch.no_grad()
-    def _get_targets(self, points, gt_bboxes, gt_labels):
-        float_max = points[0].new_tensor(1e8)
-        n_levels = len(points)
-        levels = torch.cat([points[i].new_tensor(i).expand(len(points[i])) for i in range(len(points))])
-        points = torch.cat(points)
-        gt_bboxes = gt_bboxes.to(points.device)
-        n_points, n_boxes = len(points), len(gt_bboxes)
-        volumes = gt_bboxes.volume.unsqueeze(0).expand(n_points, n_boxes)
-        # condition 1: point inside box
-        boxes = torch.cat((gt_bboxes.gravity_center, gt_bboxes.tensor[:, 3:]), dim=1)
-        boxes = boxes.expand(n_points, n_boxes, 7)
-        points = points.unsqueeze(1).expand(n_points, n_boxes, 3)
-        face_distances = self._get_face_distances(points, boxes)
-        inside_box_condition = face_distances.min(dim=-1).values > 0
-        # condition 2: positive points per level >= limit
-        n_pos_points_per_level = torch.stack([torch.sum(inside_box_condition[levels == i], dim=0) for i in range(n_levels)], dim=0)
-        lower_limit_mask = n_pos_points_per_level < self.pts_assign_threshold
-        lower_index = torch.argmax(lower_limit_mask.int(), dim=0) - 1
-        lower_index = torch.where(lower_index < 0, 0, lower_index)
-        all_upper_limit_mask = torch.all(torch.logical_not(lower_limit_mask), dim=0)
-        best_level = torch.where(all_upper_limit_mask, n_levels - 1, lower_index)
-        best_level = best_level.expand(n_points, n_boxes)
-        levels = torch.unsqueeze(levels, 1).expand(n_points, n_boxes)
-        level_condition = best_level == levels
-        # condition 3: limit topk points per box by centerness
-        centerness = self._get_centerness(face_distances)
-        centerness = torch.where(inside_box_condition, centerness, torch.ones_like(centerness) * -1)
-        centerness = torch.where(level_condition, centerness, torch.ones_like(centerness) * -1)
-        top_centerness = torch.topk(centerness, min(self.pts_center_threshold + 1, len(centerness)), dim=0).values[-1]
-        topk_condition = centerness > top_centerness.unsqueeze(0)
-        # condition 4: min volume box per point
-        volumes = torch.where(inside_box_condition, volumes, float_max)
-        volumes = torch.where(level_condition, volumes, float_max)
-        volumes = torch.where(topk_condition, volumes, float_max)
-        min_volumes, min_inds = volumes.min(dim=1)
-        center_targets = centerness[torch.arange(n_points), min_inds]
-        bbox_targets = boxes[torch.arange(n_points), min_inds]
-        if not gt_bboxes.with_yaw:
-            bbox_targets = bbox_targets[:, :-1]
-        cls_targets = gt_labels[min_inds]
-        cls_targets = torch.where(min_volumes == float_max, -1, cls_targets)
-        return center_targets, bbox_targets, cls_targets
-
-    def _single_scene_multiclass_nms(self, bboxes, scores, input_meta):
-        n_classes = scores.shape[1]
-        with_yaw = bboxes.shape[1] == 7
-        nms_bboxes, nms_scores, nms_labels = [], [], []
-        for i in range(n_classes):
-            ids = scores[:, i] > self.test_cfg.score_thr
-            if not ids.any():
-                continue
-            class_scores, class_bboxes = scores[ids, i], bboxes[ids]
-            if with_yaw:
-                nms_function = nms3d
-            else:
-                class_bboxes = torch.cat((class_bboxes, torch.zeros_like(class_bboxes[:, :1])), dim=1)
-                nms_function = nms3d_normal
-            nms_ids = nms_function(class_bboxes, class_scores, self.test_cfg.iou_thr)
-            nms_bboxes.append(class_bboxes[nms_ids])
-            nms_scores.append(class_scores[nms_ids])
-            nms_labels.append(bboxes.new_full(class_scores[nms_ids].shape, i, dtype=torch.long))
-        if len(nms_bboxes):
-            nms_bboxes, nms_scores, nms_labels = torch.cat(nms_bboxes, dim=0), torch.cat(nms_scores, dim=0), torch.cat(nms_labels, dim=0)
-        else:
-            nms_bboxes, nms_scores, nms_labels = bboxes.new_zeros((0, bboxes.shape[1])), bboxes.new_zeros((0, )), bboxes.new_zeros((0, ))
-        if with_yaw:
-            box_dim = 7
-        else:
-            box_dim = 6
-            nms_bboxes = nms_bboxes[:, :6]
-        nms_bboxes = input_meta['box_type_3d'](nms_bboxes, box_dim=box_dim, with_yaw=with_yaw, origin=(.5, .5, .5))
-        return nms_bboxes, nms_scores, nms_labels
+from .fcaf3d_head import FCAF3DHead, LevelOutput, decode_boxes, top_per_segment       # noqa: E402,F401  (registers the head)
 
 
 # -------------------------------------------------------------------------------------------------------------- detector

@@ -108,36 +108,32 @@ class LoadPointsFromFile:
 
 # ----------------------------------------------------------------------------- database sampling
 class BatchSampler:
-    """gga_processing.py:588-654: cycles through a (shuffled) list, reshuffling when it runs out."""
+    """A deck of database entries (gga_processing.py:588-654, same constructor and ``sample``): entries are dealt in a
+    shuffled order, ``num`` at a time; a request that reaches the end of the deck gets only what is left (possibly fewer
+    than asked) and the deck is shuffled again. The calls to ``np.random.shuffle`` - one at construction, one per new pass -
+    are part of the behaviour: the reference's random stream is reproduced draw for draw (tests/test_pipelines.py)."""
 
     def __init__(self, sampled_list, name=None, epoch=None, shuffle=True, drop_reminder=False):
-        self._sampled_list = sampled_list
-        self._indices = np.arange(len(sampled_list))
+        self.entries, self.name, self.shuffled = sampled_list, name, shuffle
+        self.deck = np.arange(len(sampled_list))
+        self.dealt = 0
         if shuffle:
-            np.random.shuffle(self._indices)
-        self._idx = 0
-        self._example_num = len(sampled_list)
-        self._name, self._shuffle, self._epoch = name, shuffle, epoch
-        self._epoch_counter = 0
-        self._drop_reminder = drop_reminder
+            np.random.shuffle(self.deck)
 
-    def _reset(self):
-        assert self._name is not None
-        if self._shuffle:
-            np.random.shuffle(self._indices)
-        self._idx = 0
-
-    def _sample(self, num):
-        if self._idx + num >= self._example_num:      # the tail is handed out short, then a new pass starts
-            ret = self._indices[self._idx:].copy()
-            self._reset()
-        else:
-            ret = self._indices[self._idx:self._idx + num]
-            self._idx += num
-        return ret
+    def _next_pass(self):
+        assert self.name is not None
+        if self.shuffled:
+            np.random.shuffle(self.deck)
+        self.dealt = 0
 
     def sample(self, num):
-        return [self._sampled_list[i] for i in self._sample(num)]
+        upto = self.dealt + num
+        if upto >= len(self.entries):
+            hand = self.deck[self.dealt:].copy()
+            self._next_pass()
+        else:
+            hand, self.dealt = self.deck[self.dealt:upto], upto
+        return [self.entries[i] for i in hand]
 
 
 def collision_free(anchor_xy, cand_xy, min_distance):

@@ -32,6 +32,20 @@ def _head(with_yaw, device='cpu'):
     return head.to(device)
 
 
+def _levels(cp, bp, clp, points, device, scene=0, leaf=False):
+    """One scene's per-level prediction lists as the head's batched level records."""
+    mk = (lambda t: t.clone().to(device).requires_grad_(True)) if leaf else (lambda t: t.to(device))
+    return [MF.LevelOutput(mk(c), mk(b), mk(k), p.to(device), torch.full((len(p),), scene, dtype=torch.long, device=device))
+            for c, b, k, p in zip(cp, bp, clp, points)]
+
+
+def _flat(levels):
+    xyz = torch.cat([l.xyz for l in levels])
+    scene = torch.cat([l.scene for l in levels])
+    level = torch.cat([torch.full((len(l.scene),), i, dtype=torch.long, device=xyz.device) for i, l in enumerate(levels)])
+    return xyz, level, scene
+
+
 def _check_targets_and_loss(device):
     g = np.load(os.path.join(GOLDEN, 'fcaf3d_head.npz'))
     for case in range(3):
@@ -40,25 +54,74 @@ def _check_targets_and_loss(device):
         points, cp, bp, clp, gt, labels = _case_inputs(seed, with_yaw)
         head = _head(with_yaw, device)
         boxes = MF.DepthInstance3DBoxes(gt if with_yaw else gt[:, :6], box_dim=7 if with_yaw else 6, with_yaw=with_yaw, origin=(.5, .5, .5))
-        to = lambda lst: [t.to(device) for t in lst]
-        ct, bt, clt = head._get_targets(to(points), boxes, labels.to(device))
+        levels = _levels(cp, bp, clp, points, device, leaf=True)
+        ct, bt, clt = head.assign(*_flat(levels), [boxes], [labels.to(device)])
         assert torch.equal(clt.cpu(), torch.from_numpy(g[f'{c}.cls_targets']))                    # integer work: exact
         torch.testing.assert_close(ct.cpu(), torch.from_numpy(g[f'{c}.center_targets']), rtol=1e-5, atol=1e-6)
         torch.testing.assert_close(bt.cpu(), torch.from_numpy(g[f'{c}.bbox_targets']), rtol=1e-6, atol=1e-6)
-        leaves = [[t.clone().to(device).requires_grad_(True) for t in lst] for lst in (cp, bp, clp)]
-        losses = head._loss_single(leaves[0], leaves[1], leaves[2], to(points), boxes, labels.to(device), None)
-        for name, v in zip(('center_loss', 'bbox_loss', 'cls_loss'), losses):
-            assert float(v) == pytest.approx(float(g[f'{c}.{name}']), rel=1e-4, abs=1e-5), (case, name)
-        sum(losses).backward()
-        for name, lst in zip(('center', 'bbox', 'cls'), leaves):
-            for lvl, t in enumerate(lst):
+        losses = head.loss(levels, [boxes], [labels.to(device)], 1)
+        for name in ('center_loss', 'bbox_loss', 'cls_loss'):
+            assert float(losses[name]) == pytest.approx(float(g[f'{c}.{name}']), rel=1e-4, abs=1e-5), (case, name)
+        sum(losses.values()).backward()
+        for name, attr in (('center', 'centre'), ('bbox', 'box'), ('cls', 'cls')):
+            for lvl, l in enumerate(levels):
                 want = torch.from_numpy(g[f'{c}.grad.{name}.{lvl}'])
-                torch.testing.assert_close(t.grad.cpu(), want, rtol=1e-3, atol=1e-5 * max(float(want.abs().max()), 1e-3))
+                torch.testing.assert_close(getattr(l, attr).grad.cpu(), want, rtol=1e-3, atol=1e-5 * max(float(want.abs().max()), 1e-3))
     return g
 
 
 def test_head_targets_and_losses_match_the_reference_run():
     _check_targets_and_loss('cpu')
+
+
+def test_a_batch_of_scenes_equals_the_scenes_one_by_one():
+    """The train path never loops over scenes: two golden scenes of different size (and box count) as ONE batch - targets of
+    every location equal to the scene's own run, the loss dict the mean of the two single-scene dicts, interleaved row order."""
+    g = np.load(os.path.join(GOLDEN, 'fcaf3d_head.npz'))
+    cases = [c for c in range(3) if bool(g[f'c{c}.with_yaw'])][:2]
+    assert len(cases) == 2
+    head = _head(True)
+    levels, boxes, labels = [[], [], [], []], [], []
+    for s, case in enumerate(cases):
+        points, cp, bp, clp, gt, lab = _case_inputs(int(g[f'c{case}.seed']), True)
+        boxes.append(MF.DepthInstance3DBoxes(gt, box_dim=7, with_yaw=True, origin=(.5, .5, .5)))
+        labels.append(lab)
+        for i, l in enumerate(_levels(cp, bp, clp, points, 'cpu', scene=s)):
+            levels[i].append(l)
+    merged = []
+    for parts in levels:          # rows of the two scenes interleaved by a fixed permutation
+        cat = [torch.cat([getattr(p, a) for p in parts]) for a in ('centre', 'box', 'cls', 'xyz', 'scene')]
+        perm = torch.randperm(len(cat[0]), generator=torch.Generator().manual_seed(len(cat[0])))
+        merged.append(MF.LevelOutput(*[t[perm] for t in cat]))
+    xyz, level, scene = _flat(merged)
+    ct, bt, clt = head.assign(xyz, level, scene, boxes, labels)
+    for s, case in enumerate(cases):
+        rows = scene == s
+        # the scene's own rows, level by level in their original order: undo the permutation by sorting on (level, xyz)
+        key = lambda lv, p: torch.argsort(((lv.double() * 1e3 + p[:, 0].double()) * 1e3 + p[:, 1].double()) * 1e3 + p[:, 2].double())
+        points = _case_inputs(int(g[f'c{case}.seed']), True)[0]
+        ref_xyz = torch.cat(points)
+        ref_level = torch.cat([torch.full((len(p),), i) for i, p in enumerate(points)])
+        o_ref, o_got = key(ref_level, ref_xyz), key(level[rows], xyz[rows])
+        assert torch.equal(clt[rows][o_got], torch.from_numpy(g[f'c{case}.cls_targets'])[o_ref])
+        pos = torch.from_numpy(g[f'c{case}.cls_targets'])[o_ref] >= 0
+        torch.testing.assert_close(ct[rows][o_got][pos], torch.from_numpy(g[f'c{case}.center_targets'])[o_ref][pos], rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(bt[rows][o_got][pos], torch.from_numpy(g[f'c{case}.bbox_targets'])[o_ref][pos], rtol=1e-6, atol=1e-6)
+    losses = head.loss(merged, boxes, labels, 2)
+    for name in ('center_loss', 'bbox_loss', 'cls_loss'):
+        want = np.mean([float(g[f'c{case}.{name}']) for case in cases])
+        assert float(losses[name]) == pytest.approx(want, rel=1e-4, abs=1e-5), name
+
+
+def test_segmented_top_k():
+    torch.manual_seed(0)
+    score, seg = torch.randn(500), torch.randint(0, 4, (500,))
+    keep = MF.top_per_segment(score, seg, 5, 37)          # segment 4 is empty
+    for s in range(4):
+        rows = torch.nonzero(seg == s).squeeze(1)
+        want = rows[torch.topk(score[rows], min(37, len(rows))).indices]
+        assert set(torch.nonzero(keep & (seg == s)).squeeze(1).tolist()) == set(want.tolist())
+    assert MF.top_per_segment(score, seg, 5, 1000).all() and not MF.top_per_segment(score[:0], seg[:0], 5, 3).numel()
 
 
 def test_rotated_iou_3d_known_answers():
@@ -237,9 +300,8 @@ def test_head_on_device_matches_the_reference_run_including_detections():
         seed, with_yaw = int(g[f'{c}.seed']), bool(g[f'{c}.with_yaw'])
         points, cp, bp, clp, gt, labels = _case_inputs(seed, with_yaw)
         head = _head(with_yaw, DEV)
-        to = lambda lst: [t.to(DEV) for t in lst]
         with torch.no_grad():
-            bb, sc, lb = head._get_bboxes_single(to(cp), to(bp), to(clp), to(points), dict(box_type_3d=MF.DepthInstance3DBoxes))
+            (bb, sc, lb), = head.detect(_levels(cp, bp, clp, points, DEV), [dict(box_type_3d=MF.DepthInstance3DBoxes)])
         want_s, want_b, want_l = torch.from_numpy(g[f'{c}.det.scores']), torch.from_numpy(g[f'{c}.det.bboxes']), torch.from_numpy(g[f'{c}.det.labels'])
         assert len(sc) == len(want_s), (case, len(sc), len(want_s))
         # the same detections (per class in descending score order on both sides)

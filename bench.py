@@ -49,6 +49,13 @@ ARITH = ('fp32 in / fp32 out, fp32 accumulate. Every convolution (dense 3x3, str
          'operand with > 0.1% of its non-zero elements below 2^-30 of its maximum sends the run to the library default: three '
          'bf16 planes / six products, fp32\'s full exponent range - timed in `planes3`). Head output convs: fp32 MFMA. '
          'Everything else plain fp32')
+# `dtype`: what the matrix kernels compute in. fp32 tensors in and out and fp32 accumulation, but the multiplications run on
+# 16-bit operand planes - not plain fp32, so the field does not say "f32":
+DTYPE_PLANES2 = 'f32 tensors, products on 2 x f16 operand planes (22-bit significands, block-scaled), f32 accumulate'
+DTYPE_PLANES3 = 'f32 tensors, products on 3 x bf16 operand planes (24-bit significands, fp32 range), f32 accumulate'
+PARITY = ('tests/test_model_gpu.py: all 18 losses of a whole step within 1e-4 of the float64 step AND of the fp32 CPU step for this '
+          'arithmetic (and for `planes3`), on both LiDAR configs (PointPillars; gga_kitti_config.py = BASELINE config 1, 4 frames); '
+          'profiles/r04_precision_cases.json has the deviations over seeds')
 PP_CONFIG = os.path.join(REPO, 'configs', 'gga', 'gga_kitti_pointpillars_config.py')
 SECOND_CONFIG = os.path.join(REPO, 'configs', 'gga', 'gga_kitti_config.py')
 PGD_CONFIG = os.path.join(REPO, 'configs', 'gga', 'gga_pdg.py')
@@ -307,7 +314,7 @@ def scatter_roofline(model, batches, step_ms):
     # HBM bytes per launch: NOT measured in this run. Taken from the PMC passes kept under profiles/
     # (FETCH_SIZE doubled per the gfx950 note, WRITE_SIZE exact) and only quoted when the shape is the profiled one.
     traffic, src = None, None
-    for name in ('r02_scatter_pmc.json', 'r01_scatter_pmc.json'):
+    for name in ('r04_scatter_pmc.json', 'r02_scatter_pmc.json', 'r01_scatter_pmc.json'):
         try:
             pmc = json.load(open(os.path.join(REPO, 'profiles', name)))
             if (B, ch, me.ny, me.nx) == (16, 64, 496, 432) and abs(m - 256000) < 2000:
@@ -406,11 +413,10 @@ def sparse_roofline(run, args, steps=4):
             'launches_per_step': len(ms) / steps, 'timed': 'in-step, HIP events on the launch stream'}
 
 
-def mfma_roofline(kernel, flops, ms_list, launches_per_step, ms_per_step):
+def mfma_roofline(kernel, flops, ms_list, launches_per_step, ms_per_step, planes=2):
     """16-bit matrix work issued = products x the fp32 FLOPs (three partial products on two fp16 planes, six on three
     bf16 planes); peak = dense bf16 / f16 MFMA (the same rate)."""
-    from gga_amd import dense_conv
-    products = 3 if dense_conv.PLANES == 2 else 6
+    products = 3 if planes == 2 else 6
     avg = sum(ms_list) / len(ms_list)
     tf = products * flops / (avg * 1e-3) / 1e12
     return {'bound': 'mfma', 'kernel': kernel, 'achieved': round(tf, 1), 'peak': BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
@@ -507,6 +513,10 @@ def cpu_baseline(cfg, frames=16):
         pass
     return {'value': round(frames / dt, 4), 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
             'sample': f'1 train step (fwd+bwd, no optimizer) on {frames} synthetic frames, {dt:.1f} s',
+            'protocol': ('BASELINE.md 3 asks for 3 warm-up + 10 timed iterations with os.cpu_count() threads. The pieces below follow it '
+                         '(median of 10 after 3). The whole step does not: one step of this sample takes ~30 s here, 13 of them would '
+                         'break the bound on the bench run (a bounded CPU sample of 10-30 s), and torch\'s CPU convolutions are slower '
+                         'with all 256 hardware threads than with 32 - so one small warm-up step, ONE timed step, 32 threads (`cores`)'),
             'host_cpu': cpu_model, 'host_threads': os.cpu_count(),
             'pieces_ms_per_16_frames': cpu_pieces(cfg, frames)}
 
@@ -567,7 +577,7 @@ def main():
             'metric': 'kitti_frames_per_sec_gga_train_step', 'value': round(args.batch * world * args.steps / dt, 3),
             'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32', 'arith': ARITH, 'data': 'synthetic',
+            'vs_baseline': None, 'dtype': DTYPE_PLANES2, 'arith': ARITH, 'parity': PARITY, 'data': 'synthetic',
             'config': {'workload': ('BASELINE config #2: PointPillars voxelize+PFN+scatter + SECOND/FPN + '
                                     'CenterHead_GGA losses' if is_pp else
                                     'gga_kitti_config.py: voxelize + HardSimpleVFE + SparseEncoder + SECOND/FPN + '
@@ -585,9 +595,10 @@ def main():
             flops = 2.0 * args.batch * fh * fw * 64 * 64 * 9
             res['mfma_roofline'] = mfma_roofline('dense_conv3x3_x9_kernel<2,8> (64->64, %dx%d, fwd + bwd-data)' % (fh, fw),
                                                  flops, tm[_lib.TIME_DENSE_CONV],
-                                                 len(tm[_lib.TIME_DENSE_CONV]) / args.steps, ms_per_step)
-        from gga_amd import dense_conv
-        res['config']['matrix_planes'] = dense_conv.PLANES          # what the timed steps ran on (2 unless the guard fell back)
+                                                 len(tm[_lib.TIME_DENSE_CONV]) / args.steps, ms_per_step, main_run['runner'].planes)
+        res['config']['matrix_planes'] = main_run['runner'].planes          # what the timed steps ran on (2 unless the guard fell back)
+        if main_run['runner'].planes != 2:
+            res['dtype'] = DTYPE_PLANES3
         res['range_guard'] = main_run['runner'].range_reports
     cfg_main = main_run['cfg']
     del main_run
@@ -652,17 +663,17 @@ def main():
                 'frames_per_gpu': args.fcaf3d_batch, 'global_batch': args.fcaf3d_batch * world,
                 'value': round(args.fcaf3d_batch * world * args.steps / fc['dt'], 3), 'unit': 'scenes/s',
                 'ms_per_step': round(fc['dt'] / args.steps * 1e3, 3), 'steps': args.steps, 'warmup': args.warmup,
-                'final_loss': round(fc['loss'], 4), 'matrix_planes': __import__('gga_amd').dense_conv.PLANES}
+                'final_loss': round(fc['loss'], 4), 'matrix_planes': fc['runner'].planes}
         del fc
         gc.collect()
         torch.cuda.empty_cache()
 
     if is_pp and not args.no_planes3:
         # the same steps on the library's default arithmetic (three bf16 planes / six products: fp32 semantics per element)
-        s3, w3 = min(args.steps, 10), min(args.warmup, 3)
+        s3, w3 = args.steps, args.warmup          # the same protocol as the headline
         p3 = run_workload(args.config, args.batch, s3, w3, args, rank, world, device, planes=3)
         if rank == 0:
-            res['planes3'] = {'arith': 'three bf16 planes / six partial products (fp32 exponent range)', 'steps': s3, 'warmup': w3,
+            res['planes3'] = {'dtype': DTYPE_PLANES3, 'arith': 'three bf16 planes / six partial products (fp32 exponent range)', 'steps': s3, 'warmup': w3,
                               'ms_per_step': round(p3['dt'] / s3 * 1e3, 3),
                               'value': round(args.batch * world * s3 / p3['dt'], 3), 'unit': 'frames/s',
                               'final_loss': round(p3['loss'], 4)}

@@ -70,8 +70,9 @@ class KittiDataset_GGA_train:
         self.split = split
         self.root_split = os.path.join(self.data_root, split)
         assert self.modality is not None
-        self.pcd_limit_range = pcd_limit_range
-        self.pts_prefix = pts_prefix
+        self.pcd_limit_range, self.pts_prefix = pcd_limit_range, pts_prefix
+        if not test_mode:            # sampler groups (aspect-ratio flags of the image datasets): one group here
+            self.flag = np.zeros(len(self), dtype=np.uint8)
 
     def load_annotations(self, ann_file):
         if isinstance(ann_file, (list, tuple)):         # already loaded infos

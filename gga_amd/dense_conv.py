@@ -29,6 +29,7 @@ WGRAD = True            # False: weight gradients stay with MIOpen
 # GGA_DENSE_PLANES in the environment fixes the choice (the Runner then leaves it alone).
 PLANES = int(os.environ.get('GGA_DENSE_PLANES', '3'))
 PLANES_PINNED = 'GGA_DENSE_PLANES' in os.environ
+FELL_BACK = False       # a range guard of this process has left the two-plane form (train.Runner): later Runners start on three
 BN_BWD_FUSED = True     # backward-data convolutions reduce the BatchNorm backward sums of the layer below them (BnSource)
 
 
@@ -63,15 +64,17 @@ class RangeGuard:
         if not self.armed or t.numel() == 0:
             return
         with torch.no_grad():
+            # reductions without full-size float64 copies or stacked boolean temporaries: at most two fp32 temporaries of the
+            # operand's size are alive at a time (the 16 x 384 x 248 x 216 concat is 1.3 GB), sums accumulate in float64
             a = t.detach().abs().reshape(-1)
-            fin = torch.isfinite(a)
-            a = torch.where(fin, a, torch.zeros_like(a))
+            a = torch.where(torch.isfinite(a), a, a.new_zeros(()))
             m = a.max()
-            nz = a > 0
-            low17 = nz & (a < m * 2.0 ** -17)
-            low30 = nz & (a < m * 2.0 ** -30)
-            self.rows.append(torch.stack([nz.sum().double(), low17.sum().double(), low30.sum().double(), a.double().sum(),
-                                          (a * low30).double().sum(), m.double()]))
+            f64 = dict(dtype=torch.float64)
+            nz = (a > 0).sum(**f64)
+            low17 = ((a > 0) & (a < m * 2.0 ** -17)).sum(**f64)
+            lost = torch.where(a < m * 2.0 ** -30, a, a.new_zeros(()))          # zeros stay zero: count and mass from one temporary
+            self.rows.append(torch.stack([nz, low17, (lost > 0).sum(**f64), a.sum(**f64), lost.sum(**f64), m.double()]))
+            del a, lost
             self.names.append((f'{tuple(t.shape)}', self.phase))
 
     def disarm(self):

@@ -35,13 +35,15 @@ def deferred_batch_counters():
     prev, _DEFERRED_COUNTERS = _DEFERRED_COUNTERS, []
     try:
         yield
-    finally:
-        seen, _DEFERRED_COUNTERS = _DEFERRED_COUNTERS, prev
-        if seen:
-            uniq = {}
-            for t in seen:
-                uniq.setdefault(id(t), [t, 0])[1] += 1
-            torch._foreach_add_([t for t, _ in uniq.values()], [n for _, n in uniq.values()])
+    except BaseException:
+        _DEFERRED_COUNTERS = prev          # a pass that raised updated no running statistics for certain: count nothing
+        raise
+    seen, _DEFERRED_COUNTERS = _DEFERRED_COUNTERS, prev
+    if seen:
+        uniq = {}
+        for t in seen:
+            uniq.setdefault(id(t), [t, 0])[1] += 1
+        torch._foreach_add_([t for t, _ in uniq.values()], [n for _, n in uniq.values()])
 
 LAYOUT_NCHW, LAYOUT_NHWC = 0, 1
 

@@ -9,6 +9,7 @@ is restated here (parity unpinned).
 One process per GPU; gradients are all-reduced by ``torch.nn.parallel.DistributedDataParallel``
 over RCCL (backend name ``nccl`` on ROCm) with ``broadcast_buffers=False`` like the reference.
 """
+import collections
 import math
 import os
 import time
@@ -229,22 +230,28 @@ class Runner:
             self.mom_sched = CyclicSchedule(base_m, max_iters, mc.get('target_ratio', (0.85 / 0.95, 1)),
                                             mc.get('cyclic_times', 1), mc.get('step_ratio_up', 0.4))
         self.iter = 0
+        self.epoch = 0              # finished epochs (train_epochs / resume)
         self.log_interval = (cfg.get('log_config') or {}).get('interval', 50)
         # Arithmetic of the matrix kernels for the train step (dense_conv.PLANES): the two-fp16-plane form, watched by
         # the range guard - armed for iteration 0 and every `range_check_interval` iterations after it; when an operand of
         # a guarded step is not represented as well as fp32 would (dense_conv.RangeGuard) the run continues on three
         # bf16 planes. `gga_dense_planes` / `gga_range_check_interval` are extension keys of the config (not the
         # reference's); GGA_DENSE_PLANES in the environment pins the arithmetic for every caller.
+        # The choice belongs to this Runner (`self.planes`): `step` installs it for the duration of the step and puts the
+        # process-wide value back, so evaluation or direct operator calls in the same process keep the library default; once
+        # a guard has fallen back anywhere in the process no later Runner goes below three planes again.
         from . import dense_conv
-        if not dense_conv.PLANES_PINNED:
-            dense_conv.PLANES = int(cfg.get('gga_dense_planes', 2))
+        if dense_conv.PLANES_PINNED:
+            self.planes = dense_conv.PLANES
+        else:
+            self.planes = 3 if dense_conv.FELL_BACK else int(cfg.get('gga_dense_planes', 2))
         self.range_check_interval = int(os.environ.get('GGA_RANGE_CHECK_INTERVAL', cfg.get('gga_range_check_interval', 500)))
         self.range_reports = []     # (iteration, worst share of lost elements, operands seen) per guarded step
         self._gc_frozen = False
         self._side = None           # side stream of the input prefetch
         self._prepared = {}         # id(data dict) -> (PreparedInputs, event)
         self._retired = []          # (PreparedInputs, event after the step that consumed them)
-        self._ready = {}            # id(data dict) -> (event after its upload, the dict): inputs_ready
+        self._ready = collections.OrderedDict()     # id(data dict) -> (event after its upload, the dict): inputs_ready, newest last
 
     def prefetch(self, data):
         """Run the point-only front of the step that will consume ``data`` now, on the side stream."""
@@ -283,16 +290,24 @@ class Runner:
         # are dropped there
         self._prepared[id(data)] = (prep, ev, data, pts)
 
+    READY_KEPT = 64
+
     def inputs_ready(self, *batches):
         """Declare that the tensors of ``batches`` are (or will be, in stream order) complete on the current stream NOW:
         one event, which ``prefetch`` of such a batch waits for instead of the whole main stream. Call it once after the
-        uploads of the batches a loop cycles through (``run`` does)."""
+        uploads of the batches a loop cycles through (``run`` does), or after every batch's upload (``train_epochs``). The
+        announcement is for the tensors as they are now: after writing new points INTO an announced batch, announce it
+        again. Only the ``READY_KEPT`` most recent announcements are remembered (an epoch of fresh batches must not pin
+        them all); a forgotten batch is still correct - its prefetch waits for the whole stream."""
         if self.device.type != 'cuda' or os.environ.get('GGA_INPUTS_READY') == '0':      # (0: A/B switch - every prefetch waits for the stream)
             return
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.device))
         for b in batches:
+            self._ready.pop(id(b), None)
             self._ready[id(b)] = (ev, b)
+        while len(self._ready) > max(self.READY_KEPT, len(batches)):
+            self._ready.popitem(last=False)
 
     def _prepared_for(self, data):
         hit = self._prepared.get(id(data))
@@ -308,9 +323,17 @@ class Runner:
         return dict(loss=loss, log_vars=log_vars, num_samples=len(data['img_metas']))
 
     def step(self, data, next_data=None):
+        from . import dense_conv
+        outer, dense_conv.PLANES = dense_conv.PLANES, self.planes
+        try:
+            return self._step(data, next_data)
+        finally:
+            dense_conv.PLANES = outer
+
+    def _step(self, data, next_data):
         from . import dense_conv, functional as F
         dense_conv.AMAX_POOL.next_generation()      # one memset for all of this step's absmax slots
-        guarded = (dense_conv.PLANES == 2 and self.range_check_interval > 0 and self.iter % self.range_check_interval == 0
+        guarded = (self.planes == 2 and self.range_check_interval > 0 and self.iter % self.range_check_interval == 0
                    and self.device.type == 'cuda')
         if guarded:
             dense_conv.RANGE_GUARD.arm()
@@ -374,12 +397,23 @@ class Runner:
             backward_worst_share_lost=max((r['share_lost'] for r in bwd), default=0.0),
             worst_share_below_2p17=max((r['share_below_2p17'] for r in rows), default=0.0),
             first_over=dict(over[0]) if over else None))
-        if over and not dense_conv.PLANES_PINNED:
-            dense_conv.PLANES = 3
-            w = over[0]
-            warnings.warn(f'iteration {self.iter}: a {w["phase"]} operand {w["shape"]} of the convolutions has {w["share_lost"]:.2%} of '
-                          f'its non-zero elements ({w["mass_lost"]:.1e} of its L1 mass) below 2^-30 of its largest magnitude - '
-                          f'continuing on three bf16 planes (fp32 exponent range) instead of two fp16 planes')
+        # data parallel: the ranks switch together (one rank on three planes beside seven on two would be a straggler at
+        # every all-reduce and a run nobody can reproduce) - a MAX over the ranks of the one-element flag, in the guarded
+        # steps only (all ranks guard the same iterations)
+        fall_back = bool(over)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            flag = torch.tensor([float(fall_back)], device=self.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            fall_back = bool(flag.item())
+        self.range_reports[-1]['fell_back'] = bool(fall_back and not dense_conv.PLANES_PINNED)
+        if fall_back and not dense_conv.PLANES_PINNED:
+            self.planes = 3
+            dense_conv.FELL_BACK = True
+            w = over[0] if over else None
+            where = (f'a {w["phase"]} operand {w["shape"]} of the convolutions has {w["share_lost"]:.2%} of its non-zero elements '
+                     f'({w["mass_lost"]:.1e} of its L1 mass) below 2^-30 of its largest magnitude') if w else 'another rank reported an operand over the limit'
+            warnings.warn(f'iteration {self.iter}: {where} - continuing on three bf16 planes (fp32 exponent range) instead of two '
+                          f'fp16 planes from the next step on (the update of this step, computed on two planes, is kept)')
 
     def freeze_gc(self):
         """Garbage-collector policy of the iteration loop: after the first iterations have built every long-lived object
@@ -411,3 +445,170 @@ class Runner:
                 logger(f'iter {i + 1}/{n_iters} lr {self.optimizer.param_groups[0]["lr"]:.3e} '
                        f'time {(time.time() - t0) / (i + 1):.3f}s  ' + ' '.join(f'{k}={v:.4f}' for k, v in vals.items()))
         return out
+
+    # ---- checkpoints: mmcv's file layout (runner/checkpoint.py ``save_checkpoint`` / ``load_checkpoint``, EpochBasedRunner
+    # ``save_checkpoint`` / ``resume``; third-party, restated - parity unpinned): {'meta': {'epoch', 'iter', ...},
+    # 'state_dict': CPU tensors under the bare module's names, 'optimizer': optimizer.state_dict()}. What the reference's
+    # train entry wires up with ``checkpoint_config`` / ``resume_from`` / ``load_from`` (apis/train.py:275-281,318-322).
+    def save_checkpoint(self, out_dir, filename_tmpl='epoch_{}.pth', save_optimizer=True, meta=None, create_symlink=True):
+        """``out_dir/epoch_{finished epochs}.pth`` (+ ``latest.pth`` pointing at it); called after an epoch has been
+        counted (``train_epochs``) or at any iteration."""
+        from collections import OrderedDict
+        meta = dict(meta or {})
+        meta.update(epoch=self.epoch, iter=self.iter, time=time.asctime(), gga_amd_planes=_current_planes())
+        classes = getattr(self.raw_model, 'CLASSES', None)
+        if classes is not None:
+            meta['CLASSES'] = classes
+        ckpt = dict(meta=meta, state_dict=OrderedDict((k, v.detach().cpu()) for k, v in self.raw_model.state_dict().items()))
+        if save_optimizer:
+            ckpt['optimizer'] = self.optimizer.state_dict()
+        os.makedirs(out_dir, exist_ok=True)
+        path = os.path.join(out_dir, filename_tmpl.format(self.epoch))
+        tmp = path + '.tmp'
+        torch.save(ckpt, tmp)
+        os.replace(tmp, path)                     # a reader never sees a half-written file
+        if create_symlink:
+            link = os.path.join(out_dir, 'latest.pth')
+            if os.path.lexists(link):
+                os.remove(link)
+            try:
+                os.symlink(os.path.basename(path), link)
+            except OSError:                       # file systems without symlinks: a copy, as mmcv does
+                import shutil
+                shutil.copy(path, link)
+        return path
+
+    def load_checkpoint(self, filename, map_location='cpu', strict=False):
+        """Weights only (``load_from``): the file's ``state_dict`` (a bare state dict is accepted too), a leading
+        ``module.`` of a wrapped model's names dropped. -> the loaded file."""
+        ckpt = torch.load(filename, map_location=map_location, weights_only=False)
+        state = ckpt.get('state_dict', ckpt) if isinstance(ckpt, dict) else ckpt
+        state = {(k[7:] if k.startswith('module.') else k): v for k, v in state.items()}
+        missing, unexpected = self.raw_model.load_state_dict(state, strict=strict)
+        if missing or unexpected:
+            import warnings
+            warnings.warn(f'{filename}: missing keys {list(missing)[:8]}, unexpected keys {list(unexpected)[:8]}')
+        return ckpt
+
+    def resume(self, checkpoint, resume_optimizer=True, map_location='default'):
+        """Continue a run (``resume_from``): weights and buffers, epoch and iteration counters (the schedules are functions
+        of the iteration), optimizer state. The next step is the one the saved run would have done next."""
+        if map_location == 'default':
+            map_location = self.device if self.device.type == 'cuda' else 'cpu'
+        ckpt = self.load_checkpoint(checkpoint, map_location=map_location, strict=True)
+        self.epoch, self.iter = int(ckpt['meta']['epoch']), int(ckpt['meta']['iter'])
+        if resume_optimizer and 'optimizer' in ckpt:
+            self.optimizer.load_state_dict(ckpt['optimizer'])
+        return ckpt['meta']
+
+    def train_epochs(self, data_loader, max_epochs, work_dir=None, checkpoint_config=None, logger=None, to_inputs=None):
+        """The epoch loop of the reference's ``EpochBasedRunner.run`` with the hooks the GGA configs register: sampler
+        re-seeded per epoch (``DistSamplerSeedHook``), one ``step`` per loaded batch - the next batch is fetched and its
+        points uploaded while this one is stepped, so its point-only front overlaps the step (``prefetch``) -, a
+        checkpoint every ``checkpoint_config.interval`` epochs and after the last one (``CheckpointHook``)."""
+        from .loader import to_step_inputs
+        to_inputs = to_inputs or (lambda b: to_step_inputs(b, self.device if self.device.type == 'cuda' else None))
+        ck = dict(checkpoint_config or {})
+        interval, save_last = int(ck.get('interval', -1)), ck.get('save_last', True)
+        out_dir = ck.get('out_dir') or work_dir
+        keep = int(ck.get('max_keep_ckpts', -1))
+        self.raw_model.train()
+        out = None
+        while self.epoch < max_epochs:
+            sampler = getattr(data_loader, 'sampler', None)
+            if hasattr(sampler, 'set_epoch'):
+                sampler.set_epoch(self.epoch)
+            it = iter(data_loader)
+            nxt = next(it, None)
+            cur = None
+            if nxt is not None:
+                nxt = to_inputs(nxt)
+                self.inputs_ready(nxt)
+            t0, n = time.time(), 0
+            while nxt is not None:
+                cur, raw = nxt, next(it, None)
+                nxt = to_inputs(raw) if raw is not None else None
+                if nxt is not None:
+                    self.inputs_ready(nxt)
+                if self.iter == self.GC_FREEZE_AFTER:
+                    self.freeze_gc()
+                out = self.step(cur, next_data=nxt)
+                n += 1
+                if logger and self.iter % self.log_interval == 0:
+                    vals = {k: float(v) for k, v in out['log_vars'].items()}
+                    logger(f'epoch {self.epoch + 1} iter {n}/{len(data_loader)} lr {self.optimizer.param_groups[0]["lr"]:.3e} '
+                           f'time {(time.time() - t0) / n:.3f}s  ' + ' '.join(f'{k}={v:.4f}' for k, v in vals.items()))
+            self.epoch += 1
+            last = self.epoch == max_epochs
+            if out_dir and ((interval > 0 and self.epoch % interval == 0) or (save_last and last)) and _is_rank0():
+                self.save_checkpoint(out_dir, save_optimizer=ck.get('save_optimizer', True))
+                if keep > 0:
+                    for e in range(self.epoch - keep * max(interval, 1), 0, -max(interval, 1)):
+                        old = os.path.join(out_dir, f'epoch_{e}.pth')
+                        if os.path.exists(old):
+                            os.remove(old)
+        return out
+
+
+
+def _current_planes():
+    from . import dense_conv
+    return dense_conv.PLANES
+
+
+def _is_rank0():
+    return not (dist.is_available() and dist.is_initialized()) or dist.get_rank() == 0
+
+
+def find_latest_checkpoint(path, suffix='pth'):
+    """``work_dir/latest.pth`` if present, else the ``epoch_N`` / ``iter_N`` file with the largest N (mmdet ``find_latest_checkpoint``)."""
+    import glob
+    import re
+    if not os.path.isdir(path):
+        return None
+    latest = os.path.join(path, f'latest.{suffix}')
+    if os.path.exists(latest):
+        return latest
+    best, best_n = None, -1
+    for f in glob.glob(os.path.join(path, f'*.{suffix}')):
+        m = re.search(r'_(\d+)\.' + suffix + '$', os.path.basename(f))
+        if m and int(m.group(1)) > best_n:
+            best, best_n = f, int(m.group(1))
+    return best
+
+
+def train_detector(model, dataset, cfg, distributed=False, validate=False, timestamp=None, meta=None, logger=None, device=None):
+    """``mmdet3d/apis/train.py:180-322`` for the GGA configs: loaders from ``cfg.data`` (``samples_per_gpu`` /
+    ``workers_per_gpu``, sharded over the ranks when ``distributed``, seeded with ``cfg.seed``), the DDP wrap, optimizer /
+    clipping / cyclic schedules (``Runner``), ``checkpoint_config``, ``resume_from`` / ``auto_resume`` / ``load_from``, then
+    ``cfg.workflow``'s train epochs. ``validate`` (the KITTI AP evaluation hook) is outside the hot path: refused loudly.
+    -> the ``Runner`` after training."""
+    from .loader import build_dataloader
+    if validate:
+        raise NotImplementedError('evaluation hooks (KITTI AP) are out of scope: run with validate=False')
+    dataset = dataset[0] if isinstance(dataset, (list, tuple)) else dataset
+    data = cfg.data
+    if 'imgs_per_gpu' in data:                    # mmdet < 2.0 spelling
+        data['samples_per_gpu'] = data['imgs_per_gpu']
+    runner_cfg = cfg.get('runner') or dict(type='EpochBasedRunner', max_epochs=cfg.total_epochs)
+    if runner_cfg['type'] != 'EpochBasedRunner':
+        raise NotImplementedError('configs/gga train with the EpochBasedRunner')
+    workflow = cfg.get('workflow', [('train', 1)])
+    assert all(mode == 'train' for mode, _ in workflow), 'val epochs in the workflow are not supported'
+    gpu_ids = cfg.get('gpu_ids', [0])
+    loader = build_dataloader(dataset, data['samples_per_gpu'], data['workers_per_gpu'], num_gpus=len(gpu_ids), dist=distributed,
+                              seed=cfg.get('seed'), runner_type=runner_cfg['type'],
+                              persistent_workers=data.get('persistent_workers', False))
+    max_epochs = int(runner_cfg['max_epochs'])
+    runner = Runner(model, cfg, max_iters=max_epochs * len(loader), distributed=distributed, device=device,
+                    iters_per_epoch=len(loader))
+    work_dir = cfg.get('work_dir')
+    resume_from = cfg.get('resume_from')
+    if resume_from is None and cfg.get('auto_resume') and work_dir:
+        resume_from = find_latest_checkpoint(work_dir)
+    if resume_from:
+        runner.resume(resume_from)
+    elif cfg.get('load_from'):
+        runner.load_checkpoint(cfg.load_from)
+    runner.train_epochs(loader, max_epochs, work_dir=work_dir, checkpoint_config=cfg.get('checkpoint_config'), logger=logger)
+    return runner

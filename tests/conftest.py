@@ -32,9 +32,9 @@ def _restore_matrix_arithmetic():
     """train.Runner selects the arithmetic of the matrix kernels process-wide (dense_conv.PLANES): put the library default
     back after every test so that no test inherits another one's choice."""
     from gga_amd import dense_conv
-    was = dense_conv.PLANES, dense_conv.PLANES_PINNED
+    was = dense_conv.PLANES, dense_conv.PLANES_PINNED, dense_conv.FELL_BACK
     yield
-    dense_conv.PLANES, dense_conv.PLANES_PINNED = was
+    dense_conv.PLANES, dense_conv.PLANES_PINNED, dense_conv.FELL_BACK = was
     dense_conv.RANGE_GUARD.armed = False
 
 

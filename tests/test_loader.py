@@ -1,0 +1,301 @@
+"""The dataset-fed train loop (mmdet3d/apis/train.py:205-219,275-285,318-322): dataset wrappers, samplers, collate, the
+hand-over to ``Runner.step``, checkpoints and resume. The sampler / collate semantics are mmdet's / mmcv's (third-party,
+restated: parity unpinned) - what is tested is what the path needs from them: every frame once per epoch over the ranks,
+disjoint shards, a new order per epoch, the per-frame list layout ``forward_train`` takes, and that a resumed run continues
+exactly where the saved one stopped."""
+import copy
+import os
+import pickle
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import GOLDEN, REPO
+from gga_amd import Config, synthetic
+from gga_amd import loader as LD
+from gga_amd.pipelines import DataContainer as DC
+from gga_amd.train import Runner, find_latest_checkpoint, train_detector
+
+SEEDS = (71, 72, 73)
+CLASSES = ['Pedestrian', 'Cyclist', 'Car']
+PP_RANGE = [0, -39.68, -3, 69.12, 39.68, 1]
+
+
+def kitti_tree(root):
+    """The on-disk fixture of tests/test_datasets.py: three synthetic KITTI frames + the info file the reference's
+    converter produced for them."""
+    os.makedirs(os.path.join(root, 'training', 'velodyne'), exist_ok=True)
+    for seed in SEEDS:
+        synthetic.make_rga_scene(seed)[0].tofile(os.path.join(root, 'training', 'velodyne', f'{seed:06d}.bin'))
+    return pickle.load(open(os.path.join(GOLDEN, 'gt_database_infos.pkl'), 'rb'))
+
+
+def train_pipeline(point_range=PP_RANGE, min_points=1):
+    """configs/gga/gga_kitti_config.py's train_pipeline without the database sampler (its database needs the device)."""
+    return [dict(type='LoadPointsFromFile', coord_type='LIDAR', load_dim=4, use_dim=4),
+            dict(type='LoadAnnotations3D', with_bbox_3d=True, with_label_3d=True, with_bbox=True, with_gga=True),
+            dict(type='PointsRangeFilter', point_cloud_range=point_range),
+            dict(type='ObjectRangeFilter_GGA', point_cloud_range=point_range, num_points_range=min_points),
+            dict(type='PointShuffle'),
+            dict(type='DefaultFormatBundle3D_GGA', class_names=CLASSES),
+            dict(type='Collect3D_GGA', keys=['points', 'gt_bboxes_3d', 'gt_labels_3d', 'GGA_boxes_img', 'GGA_lidar2img',
+                                             'GGA_init_pseudo_labels', 'GGA_bdry_masks', 'GGA_in_box_points'])]
+
+
+def dataset_cfg(root, infos, times=4, **kw):
+    return dict(type='RepeatDataset', times=times,
+                dataset=dict(type='KittiDataset_GGA_train', data_root=root, ann_file=infos, split='training', pts_prefix='velodyne',
+                             pipeline=train_pipeline(**kw), modality=dict(use_lidar=True, use_camera=False), classes=CLASSES,
+                             test_mode=False, box_type_3d='LiDAR'))
+
+
+class _Frames:
+    def __init__(self, n, flag=None):
+        self.n = n
+        if flag is not None:
+            self.flag = np.asarray(flag, dtype=np.uint8)
+
+    def __len__(self):
+        return self.n
+
+
+def test_repeat_dataset_and_builder(tmp_path):
+    infos = kitti_tree(str(tmp_path))
+    ds = LD.build_dataset(dataset_cfg(str(tmp_path), infos, times=3))
+    assert isinstance(ds, LD.RepeatDataset) and len(ds) == 9 and len(ds.dataset) == 3
+    assert ds.CLASSES == tuple(CLASSES)
+    np.random.seed(0), torch.manual_seed(0)
+    a, b = ds[1], ds[4]
+    assert a['img_metas'].data['sample_idx'] == b['img_metas'].data['sample_idx'] == SEEDS[1]
+    assert isinstance(a['points'], DC) and a['points'].data.shape[1] == 4
+    assert a['gt_bboxes_3d'].cpu_only and len(a['gt_bboxes_3d'].data) == len(a['gt_labels_3d'].data)
+
+
+def test_distributed_group_sampler_shards_the_frames():
+    ds = _Frames(23)
+    world, spg = 4, 2
+    samplers = [LD.DistributedGroupSampler(ds, spg, world, r, seed=5) for r in range(world)]
+    shards = [list(s) for s in samplers]
+    assert all(len(x) == len(samplers[0]) == 6 for x in shards)                  # ceil(23 / 8) * 8 = 24 -> 6 per rank
+    seen = np.concatenate(shards)
+    assert set(seen.tolist()) == set(range(23))                                 # every frame, 24 - 23 = one repeat
+    assert len(seen) - len(set(seen.tolist())) == 1
+    # a new order every epoch, the same order for the same (seed, epoch) on every rank's copy
+    again = [list(LD.DistributedGroupSampler(ds, spg, world, r, seed=5)) for r in range(world)]
+    assert again == shards
+    for s in samplers:
+        s.set_epoch(1)
+    assert [list(s) for s in samplers] != shards
+    assert [list(s) for s in samplers] != [list(LD.DistributedGroupSampler(ds, spg, world, r, seed=9)) for r in range(world)]          # (seed + epoch is what seeds the order)
+    # batches never mix groups
+    flags = np.array([0] * 10 + [1] * 7)
+    s = LD.DistributedGroupSampler(_Frames(17, flags), 2, 2, 0, seed=0)
+    idx = np.array(list(s)).reshape(-1, 2)
+    assert (flags[idx[:, 0]] == flags[idx[:, 1]]).all()
+
+
+def test_plain_samplers():
+    ds = _Frames(10)
+    parts = [list(LD.DistributedSampler(ds, 3, r, shuffle=False)) for r in range(3)]
+    assert parts == [[0, 3, 6, 9], [1, 4, 7, 0], [2, 5, 8, 1]]                   # strided, padded by wrapping around
+    shuffled = [list(LD.DistributedSampler(ds, 2, r, shuffle=True, seed=3)) for r in range(2)]
+    assert sorted(shuffled[0] + shuffled[1]) == list(range(10))
+    np.random.seed(1)
+    g = list(LD.GroupSampler(_Frames(7), samples_per_gpu=3))
+    assert len(g) == 9 and set(g) == set(range(7))
+
+
+def test_collate_rules_and_step_inputs():
+    mk = lambda n, k: dict(
+        points=DC(torch.full((n, 4), float(k))), gt_labels_3d=DC(torch.arange(k)), gt_bboxes_3d=DC(f'boxes{k}', cpu_only=True),
+        img_metas=DC(dict(sample_idx=k), cpu_only=True), img=DC(torch.ones(3, 2 + k, 5), stack=True, padding_value=7),
+        GGA_in_box_points=DC([torch.zeros(2, 4)] * k))
+    batch = LD.collate([mk(5, 1), mk(6, 2), mk(7, 3), mk(8, 4)], samples_per_gpu=2)
+    assert [len(c) for c in batch['points'].data] == [2, 2] and batch['points'].data[1][0].shape == (7, 4)
+    assert batch['gt_bboxes_3d'].cpu_only and batch['gt_bboxes_3d'].data == [['boxes1', 'boxes2'], ['boxes3', 'boxes4']]
+    assert batch['img'].stack and batch['img'].data[0].shape == (2, 3, 4, 5) and batch['img'].data[1].shape == (2, 3, 6, 5)
+    assert float(batch['img'].data[0][0, 0, 3, 0]) == 7.0 and float(batch['img'].data[0][1, 0, 3, 0]) == 1.0
+    step = LD.to_step_inputs(batch, chunk=1)
+    assert [m['sample_idx'] for m in step['img_metas']] == [3, 4] and [len(l) for l in step['gt_labels_3d']] == [3, 4]
+    assert len(step['GGA_in_box_points'][1]) == 4 and step['points'][0].shape == (7, 4)
+    assert LD.collate([(1, 'a'), (2, 'b')])[0].tolist() == [1, 2]
+
+
+def test_loader_from_the_kitti_tree(tmp_path):
+    infos = kitti_tree(str(tmp_path))
+    ds = LD.build_dataset(dataset_cfg(str(tmp_path), infos, times=2))
+    np.random.seed(0), torch.manual_seed(0)
+    loader = LD.build_dataloader(ds, samples_per_gpu=3, workers_per_gpu=0, dist=False, seed=0)
+    batches = [LD.to_step_inputs(b) for b in loader]
+    assert len(batches) == 2
+    for b in batches:
+        assert set(b) == {'img_metas', 'points', 'gt_bboxes_3d', 'gt_labels_3d', 'GGA_boxes_img', 'GGA_lidar2img',
+                          'GGA_init_pseudo_labels', 'GGA_bdry_masks', 'GGA_in_box_points'}
+        assert len(b['points']) == 3 and all(p.dtype == torch.float32 and p.shape[1] == 4 for p in b['points'])
+        for boxes, labels, img, l2i, ibp in zip(b['gt_bboxes_3d'], b['gt_labels_3d'], b['GGA_boxes_img'], b['GGA_lidar2img'], b['GGA_in_box_points']):
+            assert len(boxes) == len(labels) == len(img) == len(l2i) == len(ibp)
+    assert sorted(m['sample_idx'] for b in batches for m in b['img_metas']) == sorted(SEEDS * 2)
+    # worker processes: seeded per worker, the same frames come out
+    loader = LD.build_dataloader(ds, samples_per_gpu=3, workers_per_gpu=2, dist=False, seed=0)
+    assert sorted(m['sample_idx'] for b in loader for m in LD.to_step_inputs(b)['img_metas']) == sorted(SEEDS * 2)
+
+
+# ------------------------------------------------------------------------------------------------ two ranks over gloo
+CFG = dict(optimizer=dict(type='AdamW', lr=1e-2, betas=(0.95, 0.99), weight_decay=0.01),
+           optimizer_config=dict(grad_clip=dict(max_norm=35, norm_type=2)),
+           lr_config=dict(policy='cyclic', target_ratio=(10, 1e-4), cyclic_times=1, step_ratio_up=0.4),
+           momentum_config=dict(policy='cyclic', target_ratio=(0.85 / 0.95, 1), cyclic_times=1, step_ratio_up=0.4),
+           runner=dict(type='EpochBasedRunner', max_epochs=2), checkpoint_config=dict(interval=1), seed=11,
+           data=dict(samples_per_gpu=2, workers_per_gpu=0), workflow=[('train', 1)])
+
+
+def _tiny():
+    from test_distributed_cpu import TinyDet
+    return TinyDet()
+
+
+class _Recording:
+    """Dataset wrapper that writes down which frames this process loaded."""
+
+    def __init__(self, ds, log):
+        self.ds, self.log = ds, log
+        self.flag = LD.group_flags(ds)
+
+    def __len__(self):
+        return len(self.ds)
+
+    def __getitem__(self, i):
+        self.log.append(int(i))
+        return self.ds[i]
+
+
+def _rank_main(rank, world, port, root, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    infos = pickle.load(open(os.path.join(GOLDEN, 'gt_database_infos.pkl'), 'rb'))
+    seen = []
+    ds = _Recording(LD.build_dataset(dataset_cfg(root, infos, times=4)), seen)
+    cfg = Config(dict(CFG, work_dir=os.path.join(root, 'work')))
+    model = _tiny()
+    runner = train_detector(model, ds, cfg, distributed=True, device=torch.device('cpu'))
+    q.put((rank, seen, runner.iter, runner.epoch, [p.detach().numpy().copy() for p in model.parameters()]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_train_from_the_dataset_with_disjoint_shards(tmp_path):
+    kitti_tree(str(tmp_path))
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in range(2)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, seen0, it0, ep0, w0), (_, seen1, it1, ep1, w1) = res
+    assert it0 == it1 == 6 and ep0 == ep1 == 2                      # 12 items / (2 ranks x 2 per batch) = 3 iterations x 2 epochs
+    # per epoch the two ranks load disjoint halves of the 12 items
+    for e in range(2):
+        a, b = set(seen0[6 * e:6 * e + 6]), set(seen1[6 * e:6 * e + 6])
+        assert len(a) == len(b) == 6 and not (a & b) and (a | b) == set(range(12))
+    assert seen0[:6] != seen0[6:]                                   # DistSamplerSeedHook: another order in epoch 2
+    for a, b in zip(w0, w1):
+        assert (a == b).all()                                       # all-reduced: the ranks hold the same parameters
+    work = os.path.join(str(tmp_path), 'work')
+    assert sorted(os.listdir(work)) == ['epoch_1.pth', 'epoch_2.pth', 'latest.pth']      # rank 0 only, every epoch
+    assert os.path.realpath(find_latest_checkpoint(work)) == os.path.realpath(os.path.join(work, 'epoch_2.pth'))
+    ck = torch.load(os.path.join(work, 'epoch_2.pth'), weights_only=False)
+    assert ck['meta']['epoch'] == 2 and ck['meta']['iter'] == 6 and set(ck) == {'meta', 'state_dict', 'optimizer'}
+    assert all(not k.startswith('module.') for k in ck['state_dict'])
+    for (n, v), w in zip(ck['state_dict'].items(), w0):
+        assert (v.numpy() == w).all(), n
+
+
+def test_resume_continues_the_saved_run_and_load_from_takes_the_weights(tmp_path):
+    """Save after 3 steps, resume into a fresh model: counters, schedules, optimizer moments and weights are those of the
+    saved run, so the 4th step is bit-identical; ``load_checkpoint`` (load_from) takes the weights only."""
+    data = lambda i: dict(points=synthetic.make_batch(2, start=10 * i, n_points=200, n_obj_range=(2, 3), n_ibp_range=(5, 10))['points'],
+                          img_metas=[{}, {}])
+    cfg = Config(CFG)
+    a = Runner(_tiny(), cfg, max_iters=10)
+    for i in range(3):
+        a.step(data(i))
+    a.epoch = 1
+    path = a.save_checkpoint(str(tmp_path / 'w'))
+    assert path.endswith('epoch_1.pth')
+    out_a = a.step(data(3))
+    b = Runner(_tiny(), cfg, max_iters=10)
+    with torch.no_grad():
+        for p in b.raw_model.parameters():
+            p.add_(1.0)                                             # start from somewhere else
+    meta = b.resume(str(tmp_path / 'w' / 'latest.pth'))
+    assert meta['iter'] == 3 and b.iter == 3 and b.epoch == 1
+    out_b = b.step(data(3))
+    assert float(out_a['loss']) == float(out_b['loss'])
+    for p, q in zip(a.raw_model.parameters(), b.raw_model.parameters()):
+        assert torch.equal(p, q)
+    assert a.optimizer.param_groups[0]['lr'] == b.optimizer.param_groups[0]['lr']
+    c = Runner(_tiny(), cfg, max_iters=10)
+    c.load_checkpoint(path)
+    assert c.iter == 0 and c.epoch == 0
+    sd = torch.load(path, weights_only=False)['state_dict']
+    for n, p in c.raw_model.state_dict().items():
+        assert torch.equal(p, sd[n])
+    # a checkpoint written by a wrapped model ('module.' names) loads as well
+    torch.save(dict(state_dict={'module.' + k: v for k, v in sd.items()}, meta=dict(epoch=0, iter=0)), str(tmp_path / 'wrapped.pth'))
+    c.load_checkpoint(str(tmp_path / 'wrapped.pth'), strict=True)
+
+
+# ----------------------------------------------------------------------------------------------------------------- device
+@pytest.mark.gpu
+def test_detector_trains_from_the_kitti_tree_saves_and_resumes(tmp_path):
+    """On-disk KITTI tree -> KittiDataset_GGA_train -> train pipeline -> loader -> collate -> Runner steps of the PointPillars
+    detector on the device -> checkpoint -> a fresh detector resumed from it repeats the next step bit for bit."""
+    from gga_amd import build_model
+    from gga_amd.cnn import to_channels_last
+    DEV = torch.device('cuda:0')
+    infos = kitti_tree(str(tmp_path))
+    ds = LD.build_dataset(dataset_cfg(str(tmp_path), infos, times=3))
+    cfg = Config.fromfile(os.path.join(REPO, 'configs', 'gga', 'gga_kitti_pointpillars_config.py'))
+    cfg.model.pts_middle_encoder['channels_last'] = True
+    cfg.data = dict(samples_per_gpu=3, workers_per_gpu=0)
+    cfg.runner = dict(type='EpochBasedRunner', max_epochs=1)
+    cfg.work_dir, cfg.seed = str(tmp_path / 'work'), 0
+    cfg.checkpoint_config = dict(interval=1)
+
+    def fresh():
+        torch.manual_seed(0)
+        return to_channels_last(build_model(cfg.model).to(DEV)).train()
+
+    np.random.seed(0), torch.manual_seed(0)
+    model = fresh()
+    runner = train_detector(model, ds, cfg, distributed=False, device=DEV)
+    assert runner.iter == 3 and runner.epoch == 1 and os.path.exists(os.path.join(cfg.work_dir, 'epoch_1.pth'))
+    # one more step on a fixed batch, from the live runner and from a resumed one
+    np.random.seed(5), torch.manual_seed(5)
+    batch = LD.to_step_inputs(next(iter(LD.build_dataloader(ds, 3, 0, dist=False, seed=0))), DEV)
+    torch.manual_seed(9)                    # the SRL draws of the step come from the CPU generator
+    out_a = runner.step(batch)
+    assert set(out_a['log_vars']) >= {'task0.loss_heatmap', 'task2.distancemin', 'loss'} and np.isfinite(float(out_a['loss']))
+    model_b = fresh()
+    with torch.no_grad():
+        for p in model_b.parameters():
+            p.mul_(0.5)
+    runner_b = Runner(model_b, cfg, max_iters=3, device=DEV)
+    runner_b.resume(find_latest_checkpoint(cfg.work_dir))
+    assert runner_b.iter == 3
+    torch.manual_seed(9)
+    out_b = runner_b.step(batch)
+    assert float(out_a['loss']) == float(out_b['loss'])
+    for (n, p), q in zip(model.state_dict().items(), model_b.state_dict().values()):
+        assert torch.equal(p, q), n

@@ -330,16 +330,18 @@ def test_runner_selects_two_planes_and_prefetch_cache_is_keyed_by_identity():
     from gga_amd.train import Runner
     cfg = Config.fromfile(os.path.join(REPO, 'configs', 'gga', 'gga_kitti_pointpillars_config.py'))
     model = build_model(cfg.model)
-    dense_conv.PLANES, dense_conv.PLANES_PINNED = 3, False
+    dense_conv.PLANES, dense_conv.PLANES_PINNED, dense_conv.FELL_BACK = 3, False, False
     r = Runner(model, cfg, max_iters=10)
-    assert dense_conv.PLANES == 2 and r.range_check_interval == 500
+    assert r.planes == 2 and dense_conv.PLANES == 3 and r.range_check_interval == 500       # the Runner's own choice: the process keeps its default
     dense_conv.PLANES, dense_conv.PLANES_PINNED = 3, True
-    Runner(model, cfg, max_iters=10)
-    assert dense_conv.PLANES == 3
+    assert Runner(model, cfg, max_iters=10).planes == 3                                      # GGA_DENSE_PLANES pins it for everybody
     cfg['gga_dense_planes'] = 3
     dense_conv.PLANES, dense_conv.PLANES_PINNED = 2, False
-    Runner(model, cfg, max_iters=10)
-    assert dense_conv.PLANES == 3
+    assert Runner(model, cfg, max_iters=10).planes == 3
+    cfg['gga_dense_planes'] = 2
+    dense_conv.FELL_BACK = True                                                              # a guard fell back earlier in this process
+    assert Runner(model, cfg, max_iters=10).planes == 3
+    dense_conv.FELL_BACK = False
     a = dict(points=[1, 2])
     r._prepared[id(a)] = ('prep', 'ev', a, a['points'])
     assert r._prepared_for(a)[0] == 'prep'

@@ -43,15 +43,19 @@ def _reference_case(name):
         return _REF_CASES[name]
     if name == 'pp':
         cfg = Config.fromfile(PP_CFG)
-        seed, kw = 1, dict(start=50, n_points=5000, pc_range=synthetic.RANGE_PP, n_obj_range=(4, 8), n_ibp_range=(10, 200))
-    else:       # the reference's shipped model section, real grid (41 x 1600 x 1408), 20 k points per frame
+        B, seed, kw = 2, 1, dict(start=50, n_points=5000, pc_range=synthetic.RANGE_PP, n_obj_range=(4, 8), n_ibp_range=(10, 200))
+    else:
+        # BASELINE config 1: the reference's shipped model section (real grid 41 x 1600 x 1408), 4 synthetic KITTI frames of
+        # 20 k points, objects per frame U{4..20} as SURVEY 8(d) specifies the synthetic frame. (Rounds 1-3 ran 2 frames with
+        # 4-8 objects: a dozen object cells per loss term average nothing, and the fp32 CPU restatement ITSELF is then
+        # 5e-5 .. 4.7e-4 from float64 depending on the seed - profiles/r04_precision_cases.json; on the specified case every
+        # fp32 path is inside 4e-5 on every seed tried.)
         cfg = Config.fromfile(SECOND_CFG)
-        seed, kw = 3, dict(start=50, n_points=20000, pc_range=synthetic.RANGE_SECOND, n_obj_range=(4, 8), n_ibp_range=(10, 200))
+        B, seed, kw = 4, 3, dict(start=50, n_points=20000, pc_range=synthetic.RANGE_SECOND, n_obj_range=(4, 20), n_ibp_range=(10, 200))
     torch.manual_seed(seed)
     model = build_model(cfg.model)
     model.train()
     _damp_heads(model)
-    B = 2
     batch = synthetic.make_batch(B, **kw)
     ref = copy.deepcopy(model)
     ref64 = copy.deepcopy(model).double()         # the same step in float64: the yardstick for the gradients
@@ -86,22 +90,20 @@ def _gpu_step_against(case, channels_last, planes, monkeypatch):
                                       data['GGA_lidar2img'], data['GGA_init_pseudo_labels'], data['GGA_bdry_masks'],
                                       data['GGA_in_box_points'], data['img_metas'], srl=srl)
     assert set(losses) == set(ref_losses) and len(losses) == 18
-    # north_star: losses within 1e-4. Measured against the float64 step (the exact value both fp32 paths approximate):
-    # within 1e-4 of it - or, on a net so deep that fp32 itself does not get that close, within three times the largest
-    # deviation the fp32 CPU restatement has from it on any of the 18 entries (the GPU kernels' rounding noise per layer
-    # is 2 - 2.7x the CPU library's, tools_dev/second_error_growth.py; the PointPillars case has a floor far below 1e-4,
-    # so there the bound is the plain 1e-4)
+    # north_star: fp32 losses within 1e-4 of the reference CPU path - asserted against the float64 step (the value every fp32
+    # path approximates) AND against the fp32 CPU restatement, for the arithmetic named by `planes` (2 = what train.Runner
+    # ships, 3 = the library default), on both configs. No widened bound.
     rel = lambda a, b: abs(a - b) / max(abs(b), 1.0)          # absolute 1e-4 below 1, relative above
     floor = max(rel(ref_losses[k], ref64_losses[k]) for k in ref_losses)
-    tol = max(1e-4, 3.0 * floor)
     worst = max(ref_losses, key=lambda k: rel(float(losses[k]), ref64_losses[k]))
-    print(f'LOSSES {case} planes {planes}: worst deviation from float64 {rel(float(losses[worst]), ref64_losses[worst]):.2e} ({worst}); '
-          f'fp32 CPU restatement {floor:.2e}; bound {tol:.2e}')
+    worst32 = max(ref_losses, key=lambda k: rel(float(losses[k]), ref_losses[k]))
+    print(f'LOSSES {case} planes {planes}: worst deviation from float64 {rel(float(losses[worst]), ref64_losses[worst]):.2e} ({worst}), '
+          f'from the fp32 CPU restatement {rel(float(losses[worst32]), ref_losses[worst32]):.2e} ({worst32}); '
+          f'fp32 CPU restatement from float64 {floor:.2e}; bound 1e-4')
     for k, v in ref64_losses.items():
-        assert rel(float(losses[k]), v) <= tol, (k, float(losses[k]), v, ref_losses[k])
-    if case == 'pp':
-        for k, v in ref_losses.items():
-            assert float(losses[k]) == pytest.approx(v, rel=1e-4, abs=1e-4), k     # and against the fp32 restatement itself
+        assert rel(float(losses[k]), v) <= 1e-4, (k, float(losses[k]), v, ref_losses[k])
+    for k, v in ref_losses.items():
+        assert float(losses[k]) == pytest.approx(v, rel=1e-4, abs=1e-4), k
     total, log_vars = model._parse_losses(losses)
     total.backward()
     grads = {}
@@ -138,11 +140,12 @@ def test_pp_train_step_matches_cpu_reference(channels_last, planes, monkeypatch)
 
 @pytest.mark.parametrize('planes', [2, 3])
 def test_second_train_step_matches_restatement(planes, monkeypatch):
-    """The reference's shipped config (configs/gga/gga_kitti_config.py: HardSimpleVFE + SparseEncoder + SECOND + SECONDFPN +
-    CenterHead_GGA; detectors/centerpoint_gga.py:43-86, middle_encoders/sparse_encoder.py:107-138) end to end, sparse trunk in
-    the loop, at its real grid with 2 x 20 000 points: all 18 losses within 1e-4 of oracle/torch_ref.reference_train_step
-    (pair-list restatement of the 21 sparse convolutions, plain torch for the rest), every parameter's gradient within
-    1e-3 of the float64 step or inside twice the fp32 restatement's own distance from it. Both arithmetic forms."""
+    """BASELINE config 1 - the reference's shipped config (configs/gga/gga_kitti_config.py: HardSimpleVFE + SparseEncoder +
+    SECOND + SECONDFPN + CenterHead_GGA; detectors/centerpoint_gga.py:43-86, middle_encoders/sparse_encoder.py:107-138) end to
+    end, sparse trunk in the loop, at its real grid with 4 x 20 000 points: all 18 losses within 1e-4 of the float64 step AND
+    of the fp32 step of oracle/torch_ref.reference_train_step (pair-list restatement of the 21 sparse convolutions, plain
+    torch for the rest); every parameter's gradient within 1.5e-3 of the float64 step or inside three times the fp32
+    restatement's own distance from it (at most six beyond 1e-3 / twice). Both arithmetic forms."""
     _gpu_step_against('second', True, planes, monkeypatch)
 
 
@@ -169,11 +172,11 @@ def test_operand_ranges_of_real_steps_and_the_two_plane_forms(monkeypatch):
         data = {k: b[k] for k in synthetic.BATCH_KEYS + ('img_metas',)}
         monkeypatch.setattr(dense_conv, 'PLANES_PINNED', False)
         runner = Runner(model, cfg, max_iters=100)
-        assert dense_conv.PLANES == 2
+        assert runner.planes == 2
         for _ in range(6):                          # iteration 0 is guarded; then a few real optimizer steps
             runner.step(data)
         assert runner.range_reports and runner.range_reports[0]['iter'] == 0
-        assert dense_conv.PLANES == 2, runner.range_reports       # the guard saw nothing to fall back for
+        assert runner.planes == 2, runner.range_reports       # the guard saw nothing to fall back for
         # one more step's operands, recorded by hand, on both forms from the same weights
         srl = model.pts_bbox_head.draw_srl(B)
         res = {}
@@ -257,15 +260,18 @@ def test_range_guard_sends_a_heavy_tailed_step_to_three_planes(monkeypatch):
     b = synthetic.make_batch(2, n_points=3000, pc_range=synthetic.RANGE_PP)
     b['points'] = [p.to(DEV) for p in b['points']]
     data = {k: b[k] for k in synthetic.BATCH_KEYS + ('img_metas',)}
+    monkeypatch.setattr(dense_conv, 'FELL_BACK', False)
     runner = Runner(model, cfg, max_iters=100)
-    assert dense_conv.PLANES == 2
+    assert runner.planes == 2
     monkeypatch.setattr(dense_conv.RangeGuard, 'LIMIT', -1.0)        # every forward operand is "over the limit"
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter('always')
         runner.step(data)
-    assert dense_conv.PLANES == 3 and any('three bf16 planes' in str(x.message) for x in w)
+    assert runner.planes == 3 and dense_conv.FELL_BACK and any('three bf16 planes' in str(x.message) for x in w)
+    assert dense_conv.PLANES == 2                            # the process-wide value is what it was before the step
     out = runner.step(data)                                  # and the run goes on, unguarded, on three planes
-    assert np.isfinite(float(out['loss'])) and len(runner.range_reports) == 1
+    assert np.isfinite(float(out['loss'])) and len(runner.range_reports) == 1 and runner.range_reports[0]['fell_back']
+    assert Runner(model, cfg, max_iters=100).planes == 3     # no later Runner of the process goes back to two planes
 
 
 def test_loss_path_full_batch_vs_c_oracle():

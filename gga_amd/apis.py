@@ -1,0 +1,85 @@
+"""The test / pseudo-label entry of the GGA recipe (README.md:187-192 of the reference: ``tools/generate_pseudo_labels_gga.py
+<matching config> <checkpoint> --eval mAP``): run the trained detector over the dataset in test mode and hand the detections
+to the dataset's ``evaluate`` - for ``KittiDataset_GGA_match`` that is the 2D-box matching which writes the pseudo-label
+file (tools/generate_pseudo_labels_gga.py:133-262, mmdet3d/apis/test.py:15-90 ``single_gpu_test``).
+
+Third-party pieces restated (parity unpinned): mmcv's ``load_checkpoint`` (``train.Runner.load_checkpoint``'s rules), mmdet's
+loader with ``shuffle=False`` (``loader.build_dataloader``), ``MMDataParallel.scatter`` for one device
+(``loader.to_step_inputs``)."""
+import pickle
+
+import torch
+
+from .loader import build_dataloader, build_dataset, chunks_in, to_step_inputs
+from .registry import build_detector
+
+
+def single_gpu_test(model, data_loader, device=None, progress=None):
+    """``model(return_loss=False, rescale=True, **batch)`` over the loader -> list with one result dict per frame."""
+    model.eval()
+    device = device or next(model.parameters()).device
+    results = []
+    for batch in data_loader:
+        for chunk in range(chunks_in(batch)):      # the loader may deliver several per-GPU chunks: one after the other here
+            # test-time layout: every key is a list over augmentations of a list over frames
+            data = to_step_inputs(batch, device, chunk)
+            with torch.no_grad():
+                out = model(return_loss=False, rescale=True, **data)
+            results.extend(out)
+            if progress:
+                progress(len(results))
+    return results
+
+
+def load_weights(model, filename, map_location='cpu', strict=False):
+    """Checkpoint file -> model weights (``state_dict`` entry or a bare state dict; a leading ``module.`` dropped). -> the
+    file's ``meta`` dict."""
+    ckpt = torch.load(filename, map_location=map_location, weights_only=False)
+    state = ckpt.get('state_dict', ckpt) if isinstance(ckpt, dict) else ckpt
+    state = {(k[7:] if k.startswith('module.') else k): v for k, v in state.items()}
+    model.load_state_dict(state, strict=strict)
+    return ckpt.get('meta', {}) if isinstance(ckpt, dict) else {}
+
+
+def generate_pseudo_labels(cfg, checkpoint, out=None, eval_metrics=('mAP',), eval_options=None, device='cuda:0', model=None,
+                           channels_last=True, progress=None):
+    """The flow of the reference's tool for one process: dataset ``cfg.data.test`` in test mode, loader
+    (``cfg.data.test_dataloader`` over the defaults samples_per_gpu=1, workers_per_gpu=2, no shuffling), detector from
+    ``cfg.model`` with the checkpoint's weights (``model``: an already built detector instead), ``single_gpu_test``, the raw
+    outputs pickled to ``out`` when given, then ``dataset.evaluate(outputs, metric=..., **eval_options)`` - the matching
+    dataset writes the pseudo-label file there (``pseudo_label_file`` in ``eval_options`` names it). -> (outputs, what
+    ``evaluate`` returned or None)."""
+    device = torch.device(device)
+    test_cfg = cfg.data['test']
+    test_cfg['test_mode'] = True
+    dataset = build_dataset(test_cfg)
+    loader_cfg = dict(samples_per_gpu=1, workers_per_gpu=2, dist=False, shuffle=False)
+    loader_cfg.update(cfg.data.get('test_dataloader', {}))
+    loader = build_dataloader(dataset, **loader_cfg)
+    if model is None:
+        cfg.model['train_cfg'] = None
+        mcfg = cfg.model
+        if channels_last and mcfg.get('pts_middle_encoder', {}).get('type') in ('PointPillarsScatter', 'SparseEncoder'):
+            mcfg['pts_middle_encoder']['channels_last'] = True
+        model = build_detector(mcfg, test_cfg=cfg.get('test_cfg'))
+        meta = load_weights(model, checkpoint)
+        model.CLASSES = meta.get('CLASSES', dataset.CLASSES)
+        model = model.to(device)
+        if channels_last:
+            from .cnn import to_channels_last
+            model = to_channels_last(model)
+    outputs = single_gpu_test(model, loader, device, progress)
+    if out:
+        if not out.endswith(('.pkl', '.pickle')):
+            raise ValueError('The output file must be a pkl file.')
+        with open(out, 'wb') as f:
+            pickle.dump(outputs, f)
+    result = None
+    if eval_metrics:
+        kwargs = dict(cfg.get('evaluation', {}))
+        for key in ('interval', 'tmpdir', 'start', 'gpu_collect', 'save_best', 'rule'):          # hook arguments, not evaluate()'s
+            kwargs.pop(key, None)
+        kwargs.update(dict(metric=list(eval_metrics), **(eval_options or {})))
+        kwargs.setdefault('device', str(device))
+        result = dataset.evaluate(outputs, **kwargs)
+    return outputs, result

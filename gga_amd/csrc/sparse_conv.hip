@@ -1,707 +1,19 @@
-// a3': sparse 3D convolution for the SECOND-style SparseEncoder (gfx950).
-//
-// Reference: mmdet3d/models/middle_encoders/sparse_encoder.py:107-214 and
-// mmdet3d/ops/sparse_block.py:82-199 build SubMConv3d / SparseConv3d layers from the
-// un-vendored mmcv / spconv wheels (rule-book over a DENSE int grid of the whole volume, then
-// per-offset gather -> GEMM -> scatter-add). Here, per resolution level:
-//
-//   index      open-addressing hash (64-bit CAS) cell id -> row. No dense grid (92 M cells).
-//   out sites  (strided conv) every (input row, kernel offset) proposes an output cell; the hash
-//              dedupes, the proposing pair with the smallest id owns the cell, an ordered
-//              multi-block scan numbers the owners -> deterministic output order.
-//   rulebook   GATHER form: nbr[k][out_row] = input row under kernel offset k, or -1; and the
-//              transposed map for the backward-data pass (for SubM it is nbr[K-1-k]).
-//   conv       output-stationary: a workgroup owns 64 output rows, walks the kernel offsets,
-//              skips offsets no row of the tile uses, stages the gathered input rows and the
-//              offset's weight slice in LDS and accumulates in registers. Each output row is
-//              written once: no atomics, deterministic. Backward-data is the same kernel on the
-//              transposed map / transposed weights.
-//   bwd weight one workgroup per (kernel offset, row chunk): compacts the valid pairs of the
-//              chunk, accumulates X^T G in registers, one float atomicAdd per weight per chunk.
+// a3': sparse 3D convolution products for the SECOND-style SparseEncoder (gfx950), on the 16-bit matrix instructions through
+// operand planes (conv_planes.h): the gather-GEMM forward / backward-data kernel (sp_conv_x9_kernel: also the stride-2,
+// transposed, 1x1 and pillar-restricted convolutions of the BEV trunk through arithmetic rule books), its halo form for the
+// submanifold convolutions of densely populated levels (sp_conv_halo_kernel), the deterministic weight gradient
+// (sp_conv_wgrad_x9_kernel), the weight packing and the absmax pass. Index structures and rule books: sparse_index.hip;
+// fp32-MFMA generation for odd widths: sparse_conv_f32.hip; the 3x3 stride-1 dense kernels: dense_conv.hip.
+// Reference: mmdet3d/models/middle_encoders/sparse_encoder.py:107-214, mmdet3d/ops/sparse_block.py:82-199 (layers of the
+// un-vendored mmcv / spconv wheels).
+// Experiments that were measured and not shipped (an LDS-DMA ring form of the gather-GEMM, ablation builds of every kernel,
+// in-kernel cycle accounting) are in the history up to commit a966a5a; DESIGN.md 6c has their numbers.
 #include <stdlib.h>
 
 #include "gga_common.h"
 #include <type_traits>
 #include <hip/hip_fp16.h>
-
-#define SP_EMPTY 0xFFFFFFFFFFFFFFFFull
-
-struct SpDims { int B, D, H, W; };
-struct SpConvGeom { int kz, ky, kx, sz, sy, sx, pz, py, px; };
-
-struct SpIndex {              // view into a caller-provided buffer
-    unsigned long long* keys; // [cap]
-    int32_t* vals;            // [cap]
-    uint32_t mask;
-};
-
-static inline uint64_t sp_cap(int64_t n) {
-    uint64_t c = 1024;
-    while (c < (uint64_t)(2 * n + 2)) c <<= 1;
-    return c;
-}
-
-__device__ __forceinline__ uint32_t sp_hash(unsigned long long k) {
-    k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33;
-    k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
-    return (uint32_t)k;
-}
-__device__ __forceinline__ unsigned long long sp_key(const SpDims d, int b, int z, int y, int x) {
-    return (((unsigned long long)b * d.D + z) * d.H + y) * d.W + x;
-}
-__device__ __forceinline__ uint32_t sp_insert(const SpIndex ix, unsigned long long key) {
-    uint32_t h = sp_hash(key) & ix.mask;
-    while (true) {
-        const unsigned long long prev = atomicCAS(&ix.keys[h], SP_EMPTY, key);
-        if (prev == SP_EMPTY || prev == key) return h;
-        h = (h + 1) & ix.mask;
-    }
-}
-__device__ __forceinline__ int32_t sp_lookup(const SpIndex ix, unsigned long long key) {
-    uint32_t h = sp_hash(key) & ix.mask;
-    while (true) {
-        const unsigned long long k = ix.keys[h];
-        if (k == key) return ix.vals[h];
-        if (k == SP_EMPTY) return -1;
-        h = (h + 1) & ix.mask;
-    }
-}
-__device__ __forceinline__ uint32_t sp_find_slot(const SpIndex ix, unsigned long long key) {
-    uint32_t h = sp_hash(key) & ix.mask;
-    while (ix.keys[h] != key) h = (h + 1) & ix.mask;
-    return h;
-}
-
-static SpIndex sp_index_view(void* buf, int64_t n) {
-    const uint64_t cap = sp_cap(n);
-    SpIndex ix;
-    ix.keys = (unsigned long long*)buf;
-    ix.vals = (int32_t*)((char*)buf + cap * 8);
-    ix.mask = (uint32_t)(cap - 1);
-    return ix;
-}
-
-extern "C" size_t gga_sparse_index_bytes(int64_t n) { return sp_cap(n) * 12; }
-
-// ------------------------------------------------------------------------------ index build
-__global__ __launch_bounds__(256) void sp_index_insert_kernel(const int4* __restrict__ coors, int64_t n, SpDims d,
-                                                             SpIndex ix) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const int4 c = coors[i];
-    if ((unsigned)c.x >= (unsigned)d.B || (unsigned)c.y >= (unsigned)d.D || (unsigned)c.z >= (unsigned)d.H ||
-        (unsigned)c.w >= (unsigned)d.W)
-        return;
-    const uint32_t h = sp_insert(ix, sp_key(d, c.x, c.y, c.z, c.w));
-    atomicMax(&ix.vals[h], (int32_t)i);      // duplicate coordinates: the highest row wins
-}
-
-extern "C" int gga_sparse_build_index(const int32_t* coors, int64_t n, int B, int D, int H, int W, void* index,
-                                      size_t index_bytes, void* stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    GGA_REQUIRE(index && (n == 0 || coors), "gga_sparse_build_index: null pointer argument");
-    GGA_REQUIRE(n >= 0 && B >= 1 && D >= 1 && H >= 1 && W >= 1, "gga_sparse_build_index: bad sizes");
-    if (index_bytes < gga_sparse_index_bytes(n)) {
-        gga_set_error("gga_sparse_build_index: index buffer %zu B < required %zu B", index_bytes,
-                      gga_sparse_index_bytes(n));
-        return GGA_ERR_WORKSPACE;
-    }
-    const uint64_t cap = sp_cap(n);
-    SpIndex ix = sp_index_view(index, n);
-    GGA_CHECK_HIP(hipMemsetAsync(ix.keys, 0xFF, cap * 8, stream), "sparse index memset");
-    GGA_CHECK_HIP(hipMemsetAsync(ix.vals, 0xFF, cap * 4, stream), "sparse index memset");   // -1
-    if (n > 0) {
-        const SpDims d = { B, D, H, W };
-        hipLaunchKernelGGL(sp_index_insert_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
-                           (const int4*)coors, n, d, ix);
-        GGA_CHECK_LAUNCH("sp_index_insert_kernel");
-    }
-    return GGA_OK;
-}
-
-// ------------------------------------------------------------------------------ output sites
-// candidate id = in_row * kvol + k. Output coordinate of (input coord c, offset k): (c + p - k) / s
-// when divisible and inside the output grid.
-__device__ __forceinline__ bool sp_out_coord(const SpConvGeom g, const SpDims od, int z, int y, int x, int k,
-                                             int& oz, int& oy, int& ox) {
-    const int kx = k % g.kx, ky = (k / g.kx) % g.ky, kz = k / (g.kx * g.ky);
-    const int tz = z + g.pz - kz, ty = y + g.py - ky, tx = x + g.px - kx;
-    if (tz < 0 || ty < 0 || tx < 0) return false;
-    if (tz % g.sz || ty % g.sy || tx % g.sx) return false;
-    oz = tz / g.sz; oy = ty / g.sy; ox = tx / g.sx;
-    return oz < od.D && oy < od.H && ox < od.W;
-}
-
-__global__ __launch_bounds__(256) void sp_sites_propose_kernel(const int4* __restrict__ in_coors, int64_t n_in,
-                                                              int kvol, SpConvGeom g, SpDims od, SpIndex ox_,
-                                                              unsigned long long* __restrict__ first) {
-    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (t >= n_in * kvol) return;
-    const int64_t i = t / kvol;
-    const int k = (int)(t - i * kvol);
-    const int4 c = in_coors[i];
-    int oz, oy, ox;
-    if (!sp_out_coord(g, od, c.y, c.z, c.w, k, oz, oy, ox)) return;
-    const uint32_t h = sp_insert(ox_, sp_key(od, c.x, oz, oy, ox));
-    atomicMin(&first[h], (unsigned long long)t);
-}
-
-__global__ __launch_bounds__(256) void sp_sites_count_kernel(const int4* __restrict__ in_coors, int64_t n_in, int kvol,
-                                                            SpConvGeom g, SpDims od, SpIndex ox_,
-                                                            const unsigned long long* __restrict__ first,
-                                                            int32_t* __restrict__ cnt) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n_in) return;
-    const int4 c = in_coors[i];
-    int n = 0;
-    for (int k = 0; k < kvol; ++k) {
-        int oz, oy, ox;
-        if (!sp_out_coord(g, od, c.y, c.z, c.w, k, oz, oy, ox)) continue;
-        const uint32_t h = sp_find_slot(ox_, sp_key(od, c.x, oz, oy, ox));
-        n += (first[h] == (unsigned long long)(i * kvol + k));
-    }
-    cnt[i] = n;
-}
-
-// three-step exclusive scan of cnt[n] (block sums -> scan of sums -> apply), 1024 per block
-__global__ __launch_bounds__(1024) void sp_scan_block_kernel(const int32_t* __restrict__ cnt, int64_t n,
-                                                            int32_t* __restrict__ excl, int32_t* __restrict__ bsum) {
-    __shared__ int wsum[16];
-    const int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x;
-    const int v = i < n ? cnt[i] : 0;
-    int s = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(s, o, 64); if ((threadIdx.x & 63) >= o) s += t; }
-    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = s;
-    __syncthreads();
-    int base = 0;
-    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) base += wsum[w];
-    if (i < n) excl[i] = base + s - v;
-    if (threadIdx.x == 1023) bsum[blockIdx.x] = base + s;
-}
-__global__ __launch_bounds__(1024) void sp_scan_sums_kernel(int32_t* __restrict__ bsum, int nblk,
-                                                           int32_t* __restrict__ total) {
-    // single block, serial over chunks of 1024 (nblk is n/1024: a few hundred)
-    __shared__ int wsum[16];
-    __shared__ int carry;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for (int c0 = 0; c0 < nblk; c0 += 1024) {
-        const int i = c0 + threadIdx.x;
-        const int v = i < nblk ? bsum[i] : 0;
-        int s = v;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(s, o, 64); if ((threadIdx.x & 63) >= o) s += t; }
-        if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = s;
-        __syncthreads();
-        int base = carry;
-        for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) base += wsum[w];
-        if (i < nblk) bsum[i] = base + s - v;
-        __syncthreads();
-        if (threadIdx.x == 1023) carry = base + s;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) *total = carry;
-}
-
-__global__ __launch_bounds__(256) void sp_sites_assign_kernel(const int4* __restrict__ in_coors, int64_t n_in,
-                                                             int kvol, SpConvGeom g, SpDims od, SpIndex ox_,
-                                                             const unsigned long long* __restrict__ first,
-                                                             const int32_t* __restrict__ excl,
-                                                             const int32_t* __restrict__ bsum, int64_t cap_out,
-                                                             int4* __restrict__ out_coors) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n_in) return;
-    const int4 c = in_coors[i];
-    int64_t row = (int64_t)excl[i] + bsum[i >> 10];
-    for (int k = 0; k < kvol; ++k) {
-        int oz, oy, ox;
-        if (!sp_out_coord(g, od, c.y, c.z, c.w, k, oz, oy, ox)) continue;
-        const uint32_t h = sp_find_slot(ox_, sp_key(od, c.x, oz, oy, ox));
-        if (first[h] == (unsigned long long)(i * kvol + k)) {
-            if (row < cap_out) out_coors[row] = make_int4(c.x, oz, oy, ox);
-            ox_.vals[h] = (int32_t)row;
-            ++row;
-        }
-    }
-}
-
-extern "C" size_t gga_sparse_out_sites_workspace_bytes(int64_t n_in, int kvol) {
-    const int64_t cap = n_in * kvol;       // upper bound on distinct output cells
-    return sp_cap(cap) * 8 + gga_align_up((size_t)n_in * 4, 256) * 2 + gga_align_up((size_t)((n_in + 1023) / 1024 + 1) * 4, 256);
-}
-extern "C" size_t gga_sparse_out_index_bytes(int64_t n_in, int kvol) { return gga_sparse_index_bytes(n_in * kvol); }
-
-extern "C" int gga_sparse_conv_out_sites(const int32_t* in_coors, int64_t n_in, int B, const int32_t in_dhw[3],
-                                         const int32_t kernel[3], const int32_t stride[3], const int32_t pad[3],
-                                         int32_t out_dhw[3], int32_t* out_coors, int64_t cap_out, int32_t* n_out,
-                                         void* out_index, size_t out_index_bytes, void* workspace,
-                                         size_t workspace_bytes, void* stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    GGA_REQUIRE(in_coors && in_dhw && kernel && stride && pad && out_dhw && out_coors && n_out && out_index && workspace,
-                "gga_sparse_conv_out_sites: null pointer argument");
-    GGA_REQUIRE(n_in >= 1 && B >= 1, "gga_sparse_conv_out_sites: bad sizes");
-    const int kvol = kernel[0] * kernel[1] * kernel[2];
-    GGA_REQUIRE(kvol >= 1 && kvol <= 64 && stride[0] >= 1 && stride[1] >= 1 && stride[2] >= 1,
-                "gga_sparse_conv_out_sites: unsupported kernel/stride");
-    for (int a = 0; a < 3; ++a) {
-        out_dhw[a] = (in_dhw[a] + 2 * pad[a] - kernel[a]) / stride[a] + 1;
-        GGA_REQUIRE(out_dhw[a] >= 1, "gga_sparse_conv_out_sites: empty output grid");
-    }
-    if (out_index_bytes < gga_sparse_out_index_bytes(n_in, kvol) ||
-        workspace_bytes < gga_sparse_out_sites_workspace_bytes(n_in, kvol)) {
-        gga_set_error("gga_sparse_conv_out_sites: index/workspace buffer too small");
-        return GGA_ERR_WORKSPACE;
-    }
-    const int64_t ncand = n_in * kvol;
-    const uint64_t cap = sp_cap(ncand);
-    SpIndex ox_ = sp_index_view(out_index, ncand);
-    char* w = (char*)workspace;
-    unsigned long long* first = (unsigned long long*)w; w += cap * 8;
-    int32_t* cnt = (int32_t*)w; w += gga_align_up((size_t)n_in * 4, 256);
-    int32_t* excl = (int32_t*)w; w += gga_align_up((size_t)n_in * 4, 256);
-    int32_t* bsum = (int32_t*)w;
-    GGA_CHECK_HIP(hipMemsetAsync(ox_.keys, 0xFF, cap * 8, stream), "out sites memset");
-    GGA_CHECK_HIP(hipMemsetAsync(ox_.vals, 0xFF, cap * 4, stream), "out sites memset");
-    GGA_CHECK_HIP(hipMemsetAsync(first, 0xFF, cap * 8, stream), "out sites memset");
-    const SpConvGeom g = { kernel[0], kernel[1], kernel[2], stride[0], stride[1], stride[2], pad[0], pad[1], pad[2] };
-    const SpDims od = { B, out_dhw[0], out_dhw[1], out_dhw[2] };
-    hipLaunchKernelGGL(sp_sites_propose_kernel, dim3((unsigned)((ncand + 255) / 256)), dim3(256), 0, stream,
-                       (const int4*)in_coors, n_in, kvol, g, od, ox_, first);
-    GGA_CHECK_LAUNCH("sp_sites_propose_kernel");
-    hipLaunchKernelGGL(sp_sites_count_kernel, dim3((unsigned)((n_in + 255) / 256)), dim3(256), 0, stream,
-                       (const int4*)in_coors, n_in, kvol, g, od, ox_, first, cnt);
-    GGA_CHECK_LAUNCH("sp_sites_count_kernel");
-    const int nblk = (int)((n_in + 1023) / 1024);
-    hipLaunchKernelGGL(sp_scan_block_kernel, dim3(nblk), dim3(1024), 0, stream, cnt, n_in, excl, bsum);
-    GGA_CHECK_LAUNCH("sp_scan_block_kernel");
-    hipLaunchKernelGGL(sp_scan_sums_kernel, dim3(1), dim3(1024), 0, stream, bsum, nblk, n_out);
-    GGA_CHECK_LAUNCH("sp_scan_sums_kernel");
-    hipLaunchKernelGGL(sp_sites_assign_kernel, dim3((unsigned)((n_in + 255) / 256)), dim3(256), 0, stream,
-                       (const int4*)in_coors, n_in, kvol, g, od, ox_, first, excl, bsum, cap_out, (int4*)out_coors);
-    GGA_CHECK_LAUNCH("sp_sites_assign_kernel");
-    return GGA_OK;
-}
-
-// ------------------------------------------------------------------------------ rulebooks
-// forward (gather) map: nbr[k][r] = input row at out_coord*stride - pad + k
-__global__ __launch_bounds__(256) void sp_rulebook_kernel(const int4* __restrict__ out_coors, int64_t n_out, int kvol,
-                                                         SpConvGeom g, SpDims id, SpIndex in_ix,
-                                                         int32_t* __restrict__ nbr) {
-    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (t >= n_out * kvol) return;
-    const int k = (int)(t / n_out);
-    const int64_t r = t - (int64_t)k * n_out;
-    const int4 c = out_coors[r];
-    const int kx = k % g.kx, ky = (k / g.kx) % g.ky, kz = k / (g.kx * g.ky);
-    const int z = c.y * g.sz - g.pz + kz, y = c.z * g.sy - g.py + ky, x = c.w * g.sx - g.px + kx;
-    int32_t v = -1;
-    if ((unsigned)z < (unsigned)id.D && (unsigned)y < (unsigned)id.H && (unsigned)x < (unsigned)id.W)
-        v = sp_lookup(in_ix, sp_key(id, c.x, z, y, x));
-    nbr[t] = v;
-}
-// transposed map: nbr_t[k][j] = output row r with nbr[k][r] == j
-__global__ __launch_bounds__(256) void sp_rulebook_t_kernel(const int4* __restrict__ in_coors, int64_t n_in, int kvol,
-                                                           SpConvGeom g, SpDims od, SpIndex out_ix,
-                                                           int32_t* __restrict__ nbr_t) {
-    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (t >= n_in * kvol) return;
-    const int k = (int)(t / n_in);
-    const int64_t j = t - (int64_t)k * n_in;
-    const int4 c = in_coors[j];
-    int oz, oy, ox;
-    int32_t v = -1;
-    if (sp_out_coord(g, od, c.y, c.z, c.w, k, oz, oy, ox)) v = sp_lookup(out_ix, sp_key(od, c.x, oz, oy, ox));
-    nbr_t[t] = v;
-}
-
-extern "C" int gga_sparse_rulebook(const int32_t* out_coors, int64_t n_out, const int32_t* in_coors, int64_t n_in,
-                                   int B, const int32_t in_dhw[3], const int32_t out_dhw[3], const int32_t kernel[3],
-                                   const int32_t stride[3], const int32_t pad[3], const void* in_index,
-                                   int64_t in_index_n, const void* out_index, int64_t out_index_n, int32_t* nbr,
-                                   int32_t* nbr_t, void* stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    GGA_REQUIRE(out_coors && in_coors && in_dhw && out_dhw && kernel && stride && pad && in_index && nbr,
-                "gga_sparse_rulebook: null pointer argument");
-    GGA_REQUIRE(n_out >= 1 && n_in >= 1, "gga_sparse_rulebook: empty level");
-    GGA_REQUIRE(!nbr_t || out_index, "gga_sparse_rulebook: the transposed map needs the output index");
-    const int kvol = kernel[0] * kernel[1] * kernel[2];
-    const SpConvGeom g = { kernel[0], kernel[1], kernel[2], stride[0], stride[1], stride[2], pad[0], pad[1], pad[2] };
-    const SpDims id = { B, in_dhw[0], in_dhw[1], in_dhw[2] };
-    const SpDims od = { B, out_dhw[0], out_dhw[1], out_dhw[2] };
-    SpIndex in_ix = sp_index_view((void*)in_index, in_index_n);   // *_index_n = the n the index was sized for
-    hipLaunchKernelGGL(sp_rulebook_kernel, dim3((unsigned)((n_out * kvol + 255) / 256)), dim3(256), 0, stream,
-                       (const int4*)out_coors, n_out, kvol, g, id, in_ix, nbr);
-    GGA_CHECK_LAUNCH("sp_rulebook_kernel");
-    if (nbr_t) {
-        SpIndex out_ix = sp_index_view((void*)out_index, out_index_n);
-        hipLaunchKernelGGL(sp_rulebook_t_kernel, dim3((unsigned)((n_in * kvol + 255) / 256)), dim3(256), 0, stream,
-                           (const int4*)in_coors, n_in, kvol, g, od, out_ix, nbr_t);
-        GGA_CHECK_LAUNCH("sp_rulebook_t_kernel");
-    }
-    return GGA_OK;
-}
-
-// ------------------------------------------------------------------------------ convolution
-// Y[r, :] = sum_k X[map[kk][r], :] @ W[k]   (kk = K-1-k when `flip`) on v_mfma_f32_32x32x2_f32
-// (exact fp32, 64 FLOP/clk/SIMD).
-//
-// A 256-thread workgroup owns 128 output rows (taken through `perm`, which orders rows by their
-// neighbour bit mask so that a tile's rows use the same kernel offsets) x NT*32 output channels;
-// wave w owns rows 32w..32w+31 and all NT column tiles (NT*16 accumulator registers). Offsets
-// whose bit is clear in the OR of the tile's row masks are skipped without touching memory, and a
-// wave skips the MFMAs of offsets none of its own 32 rows uses.
-//
-// Work is a flat sequence of (offset, 32-input-channel chunk) stages. Per stage the gathered
-// input rows [128 x 32] and the weight slice [32 x NT*32] sit in LDS in *fragment order*: the
-// 32x32x2 A operand of lane (h = lane/32, m = lane%32) at k-step s is A[m][2s+h], so row m keeps
-// its even channels in floats 0..15 and its odd channels in 16..31 and a lane fetches four
-// k-steps with one ds_read_b128; the weights are packed the same way on the host side of the
-// ABI (gga_sparse_pack_weight), 16*NT contiguous floats per lane and stage, so staging them is a
-// straight 16-byte copy. Row strides of 36 / 16*NT+4 floats keep the b128 reads conflict-free.
-// The global loads of stage i+1 (and the rule-book entries of the offset after it) are issued
-// before the MFMAs of stage i and land in LDS after them.
-#define MF_TM 128
-#define MF_TK 32
-#define MF_ASTR 36
-typedef float mf_v16 __attribute__((ext_vector_type(16)));
-
-static inline int mf_nt(int cout) { return cout <= 32 ? 1 : (cout <= 64 ? 2 : 4); }
-
-// packed[k][chunk][lane = h*32+n][g][t][j] = W[k][chunk*32 + 2*(4g+j) + h][t*32 + n]
-__global__ __launch_bounds__(256) void sp_pack_weight_kernel(const float* __restrict__ W, int kvol, int cin, int cout,
-                                                            int nt, int transpose, int64_t total,
-                                                            float* __restrict__ P) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total) return;
-    const int per_lane = 16 * nt, per_stage = 64 * per_lane;
-    const int nchunks = (cin + MF_TK - 1) / MF_TK;
-    const int64_t stage = i / per_stage;
-    int r = (int)(i - stage * per_stage);
-    const int k = (int)(stage / nchunks), ch = (int)(stage - (int64_t)k * nchunks);
-    const int lane = r / per_lane; r -= lane * per_lane;
-    const int g = r / (4 * nt); r -= g * 4 * nt;
-    const int t = r >> 2, j = r & 3;
-    const int c = ch * MF_TK + 2 * (4 * g + j) + (lane >> 5), o = t * 32 + (lane & 31);
-    float v = 0.0f;
-    if (c < cin && o < cout)
-        v = transpose ? W[((int64_t)k * cout + o) * cin + c] : W[((int64_t)k * cin + c) * cout + o];
-    P[i] = v;
-}
-
-extern "C" size_t gga_sparse_packed_weight_bytes(int kvol, int cin, int cout) {
-    if (kvol < 1 || cin < 1 || cout < 1 || cout > 128) return 0;
-    return (size_t)kvol * ((cin + MF_TK - 1) / MF_TK) * 64 * 16 * mf_nt(cout) * sizeof(float);
-}
-
-extern "C" int gga_sparse_pack_weight(const float* weight, int kvol, int cin, int cout, int transpose, float* packed,
-                                      void* stream) {
-    GGA_REQUIRE(weight && packed, "gga_sparse_pack_weight: null pointer argument");
-    GGA_REQUIRE(kvol >= 1 && cin >= 1 && cout >= 1 && cout <= 128, "gga_sparse_pack_weight: bad sizes (kvol=%d cin=%d cout=%d; cout <= 128)",
-                kvol, cin, cout);
-    const int64_t total = (int64_t)(gga_sparse_packed_weight_bytes(kvol, cin, cout) / sizeof(float));
-    hipLaunchKernelGGL(sp_pack_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       weight, kvol, cin, cout, mf_nt(cout), transpose, total, packed);
-    GGA_CHECK_LAUNCH("sp_pack_weight_kernel");
-    return GGA_OK;
-}
-
-template <int NT, bool VEC>
-__global__ __launch_bounds__(256) void sp_conv_mfma_kernel(const float* __restrict__ X, const int32_t* __restrict__ map,
-                                                          const float* __restrict__ Wp,
-                                                          const int32_t* __restrict__ perm,
-                                                          const uint32_t* __restrict__ rowmask, int64_t n_rows,
-                                                          int kvol, int cin, int cout, int flip,
-                                                          float* __restrict__ Y) {
-    constexpr int BL = 16 * NT;            // packed weight floats per lane and stage
-    constexpr int BSTR = BL + 4;           // LDS stride of a lane's block
-    constexpr int ASZ = MF_TM * MF_ASTR, BSZ = 64 * BSTR;
-    __shared__ __attribute__((aligned(16))) float As[2 * ASZ];      // double buffered: one barrier per stage
-    __shared__ __attribute__((aligned(16))) float Bs[2 * BSZ];
-    __shared__ int prow[MF_TM];
-    __shared__ uint32_t wmask_s[4];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // mask-sorted order puts the rows with the most neighbours last: start those tiles first
-    const int64_t r0 = (int64_t)(gridDim.x - 1 - blockIdx.x) * MF_TM;
-    if (tid < 4) wmask_s[tid] = 0;
-    __syncthreads();
-    if (tid < MF_TM) {
-        const int64_t r = r0 + tid;
-        int pr = -1;
-        if (r < n_rows) pr = perm ? perm[r] : (int)r;
-        prow[tid] = pr;
-        uint32_t m = 0;
-        if (pr >= 0) m = (rowmask && kvol <= 32) ? rowmask[pr] : 0xFFFFFFFFu;
-        if (m) atomicOr(&wmask_s[tid >> 5], m);
-    }
-    __syncthreads();
-    // wave-uniform: keep them in scalar registers so the offset scan below is scalar code
-    const uint32_t wmask = __builtin_amdgcn_readfirstlane(wmask_s[wave]);
-    const uint32_t tmask = __builtin_amdgcn_readfirstlane(wmask_s[0] | wmask_s[1] | wmask_s[2] | wmask_s[3]);
-    mf_v16 acc[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
-
-    const int nchunks = (cin + MF_TK - 1) / MF_TK;
-    // staging roles. A: thread (ar = tid/4, aq = tid%4) loads float4 #aq and #aq+4 of the 32-channel
-    // chunk for rows ar and ar+64. B: NT float4 of the packed stage, consecutive across threads.
-    const int ar = tid >> 2, aq = tid & 3;
-    const int p0 = prow[ar], p1 = prow[ar + 64];
-    auto enabled = [&](int k) { const int kk = flip ? (kvol - 1 - k) : k; return kvol > 32 || ((tmask >> kk) & 1u); };
-    auto next_enabled = [&](int k) { while (k < kvol && !enabled(k)) ++k; return k; };
-    auto load_idx = [&](int k, int& i0, int& i1) {
-        const int kk = flip ? (kvol - 1 - k) : k;
-        const int32_t* mk = map + (int64_t)kk * n_rows;
-        i0 = mk[p0 >= 0 ? p0 : 0];        // rows past n_rows gather something valid; they are never written
-        i1 = mk[p1 >= 0 ? p1 : 0];
-    };
-    float4 a0[2], a1[2];
-    float4 bq0, bq1, bq2, bq3;             // named (not an array): keeps them in registers across the MFMA phase
-    bq0 = bq1 = bq2 = bq3 = make_float4(0.f, 0.f, 0.f, 0.f);
-    // loads are unconditional (absent neighbours / channels past cin read row 0 / channel 0 and
-    // are zeroed when they are written to LDS), so nothing waits on them before the MFMAs
-    auto load_stage = [&](int k, int ch, int i0, int i1) {
-        const int c0 = ch * MF_TK;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int cc = c0 + (aq + 4 * h) * 4;
-            if (VEC) {
-                const int co = cc < cin ? cc : 0;
-                a0[h] = *reinterpret_cast<const float4*>(X + (int64_t)(i0 >= 0 ? i0 : 0) * cin + co);
-                a1[h] = *reinterpret_cast<const float4*>(X + (int64_t)(i1 >= 0 ? i1 : 0) * cin + co);
-            } else {                       // channel count not a multiple of 4: scalar gathers
-                float t0[4], t1[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int co = cc + e < cin ? cc + e : 0;
-                    t0[e] = X[(int64_t)(i0 >= 0 ? i0 : 0) * cin + co];
-                    t1[e] = X[(int64_t)(i1 >= 0 ? i1 : 0) * cin + co];
-                }
-                a0[h] = make_float4(t0[0], t0[1], t0[2], t0[3]);
-                a1[h] = make_float4(t1[0], t1[1], t1[2], t1[3]);
-            }
-        }
-        const float4* src = reinterpret_cast<const float4*>(Wp + ((int64_t)k * nchunks + ch) * (64 * BL));
-        bq0 = src[tid];
-        if (NT > 1) bq1 = src[tid + 256];
-        if (NT > 2) { bq2 = src[tid + 512]; bq3 = src[tid + 768]; }
-    };
-    auto store_stage = [&](int buf, int ch, int i0, int i1) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int q = aq + 4 * h;      // channels 4q..4q+3 -> k-steps 2q, 2q+1 of halves 0 (x, z) and 1 (y, w)
-            const int cc = ch * MF_TK + 4 * q;
-            const bool v0 = i0 >= 0, v1 = i1 >= 0;
-            const bool cx = cc < cin, cy = cc + 1 < cin, cz = cc + 2 < cin, cw = cc + 3 < cin;
-            float* d0 = As + buf * ASZ + ar * MF_ASTR + 2 * q;
-            float* d1 = d0 + 64 * MF_ASTR;
-            *reinterpret_cast<float2*>(d0) = make_float2(v0 && cx ? a0[h].x : 0.f, v0 && cz ? a0[h].z : 0.f);
-            *reinterpret_cast<float2*>(d0 + 16) = make_float2(v0 && cy ? a0[h].y : 0.f, v0 && cw ? a0[h].w : 0.f);
-            *reinterpret_cast<float2*>(d1) = make_float2(v1 && cx ? a1[h].x : 0.f, v1 && cz ? a1[h].z : 0.f);
-            *reinterpret_cast<float2*>(d1 + 16) = make_float2(v1 && cy ? a1[h].y : 0.f, v1 && cw ? a1[h].w : 0.f);
-        }
-        // float4 #f of the stage belongs to lane block f / (4*NT), piece f % (4*NT)
-#define MF_BST(E, V) { const int f = tid + 256 * (E); *reinterpret_cast<float4*>(Bs + buf * BSZ + (f / (4 * NT)) * BSTR + (f % (4 * NT)) * 4) = V; }
-        MF_BST(0, bq0);
-        if (NT > 1) MF_BST(1, bq1);
-        if (NT > 2) { MF_BST(2, bq2); MF_BST(3, bq3); }
-#undef MF_BST
-    };
-
-    // Stage bookkeeping (all wave-uniform): (k, ch) is being multiplied out of LDS buffer `buf`,
-    // (k1, ch1) sits in the staging registers (loaded one iteration ago with rule-book entries
-    // ia0/ia1), (k2, ch2) is fetched during this iteration. Within an iteration the staging work
-    // is placed between the four MFMA groups so its VALU / LDS / VMEM instructions issue in the
-    // shadow of the matrix pipe instead of in a separate phase.
-    int k = next_enabled(0), ch = 0;
-    if (k < kvol) {
-        int ia0, ia1, in0n, in1n;
-        load_idx(k, ia0, ia1);
-        int knext = next_enabled(k + 1);                 // first enabled offset after the one being loaded
-        load_idx(knext < kvol ? knext : k, in0n, in1n);
-        load_stage(k, 0, ia0, ia1);
-        store_stage(0, 0, ia0, ia1);
-        int k1 = k, ch1 = 1;
-        if (ch1 == nchunks) { ch1 = 0; k1 = knext; }
-        auto fetch_next = [&](int kq, int chq) {         // issue the loads of stage (kq, chq); entering a new offset rotates the rule-book registers
-            const bool valid = kq < kvol;
-            const bool adv = valid && chq == 0;
-            ia0 = adv ? in0n : ia0;
-            ia1 = adv ? in1n : ia1;
-            if (adv) knext = next_enabled(kq + 1);
-            load_idx(knext < kvol ? knext : k, in0n, in1n);
-            load_stage(valid ? kq : k, valid ? chq : ch, ia0, ia1);
-        };
-        fetch_next(k1, ch1);
-        __syncthreads();
-        int buf = 0;
-        while (true) {
-            const float* Ap = As + buf * ASZ + (wave * 32 + (lane & 31)) * MF_ASTR + (lane >> 5) * 16;
-            const float* Bp = Bs + buf * BSZ + lane * BSTR;
-            int k2 = k1, ch2 = ch1 + 1;
-            if (ch2 == nchunks) { ch2 = 0; k2 = knext; }
-            const int kk = flip ? (kvol - 1 - k) : k;
-            const bool mm = kvol > 32 || ((wmask >> kk) & 1u);
-#define MF_READ(G, S)                                                                                                \
-            fa[S] = *reinterpret_cast<const float4*>(Ap + 4 * (G));                                                   \
-            _Pragma("unroll") for (int t = 0; t < NT; ++t) fb[S][t] = *reinterpret_cast<const float4*>(Bp + ((G) * NT + t) * 4);
-#define MF_MMA(S)                                                                                                    \
-            _Pragma("unroll") for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[S].x, fb[S][t].x, acc[t], 0, 0, 0); \
-            _Pragma("unroll") for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[S].y, fb[S][t].y, acc[t], 0, 0, 0); \
-            _Pragma("unroll") for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[S].z, fb[S][t].z, acc[t], 0, 0, 0); \
-            _Pragma("unroll") for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[S].w, fb[S][t].w, acc[t], 0, 0, 0);
-            if (mm) {
-                float4 fa[2], fb[2][NT];
-                MF_READ(0, 0);
-                MF_READ(1, 1);
-                MF_MMA(0);
-                __builtin_amdgcn_sched_barrier(0);
-                store_stage(buf ^ 1, ch1, ia0, ia1);     // buf^1 was last read before the previous barrier
-                MF_READ(2, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                MF_MMA(1);
-                __builtin_amdgcn_sched_barrier(0);
-                fetch_next(k2, ch2);
-                MF_READ(3, 1);
-                __builtin_amdgcn_sched_barrier(0);
-                MF_MMA(0);
-                MF_MMA(1);
-            } else {                                     // none of this wave's rows uses the offset
-                store_stage(buf ^ 1, ch1, ia0, ia1);
-                fetch_next(k2, ch2);
-            }
-#undef MF_READ
-#undef MF_MMA
-            if (k1 >= kvol) break;
-            __syncthreads();
-            buf ^= 1;
-            k = k1; ch = ch1; k1 = k2; ch1 = ch2;
-        }
-    }
-    // D layout of 32x32x2: register v of lane l holds row (v/4)*8 + (l/32)*4 + v%4, column l%32
-#pragma unroll
-    for (int v = 0; v < 16; ++v) {
-        const int lr = wave * 32 + (v >> 2) * 8 + (lane >> 5) * 4 + (v & 3);
-        const int pr = prow[lr];
-        if (pr < 0) continue;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int o = t * 32 + (lane & 31);
-            if (o < cout) Y[(int64_t)pr * cout + o] = acc[t][v];
-        }
-    }
-}
-
-__global__ __launch_bounds__(256) void sp_rowmask_kernel(const int32_t* __restrict__ map, int64_t n, int kvol,
-                                                        uint32_t* __restrict__ mask) {
-    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (r >= n) return;
-    uint32_t m = 0;
-    for (int k = 0; k < kvol && k < 32; ++k) m |= (map[(int64_t)k * n + r] >= 0 ? 1u : 0u) << k;
-    mask[r] = m;
-}
-
-extern "C" int gga_sparse_rowmask(const int32_t* map, int64_t n_rows, int kvol, uint32_t* mask, void* stream) {
-    GGA_REQUIRE(map && mask && n_rows >= 1 && kvol >= 1, "gga_sparse_rowmask: bad arguments");
-    hipLaunchKernelGGL(sp_rowmask_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, map,
-                       n_rows, kvol, mask);
-    GGA_CHECK_LAUNCH("sp_rowmask_kernel");
-    return GGA_OK;
-}
-
-extern "C" int gga_sparse_conv_apply(const float* x, const int32_t* map, const float* packed_weight, const int32_t* perm,
-                                     const uint32_t* rowmask, int64_t n_rows, int kvol, int cin, int cout, int flip,
-                                     float* y, void* stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    GGA_REQUIRE(x && map && packed_weight && y, "gga_sparse_conv_apply: null pointer argument");
-    GGA_REQUIRE(n_rows >= 1 && kvol >= 1 && cin >= 1 && cout >= 1 && cout <= 128,
-                "gga_sparse_conv_apply: bad sizes (rows=%lld kvol=%d cin=%d cout=%d; cout <= 128)", (long long)n_rows,
-                kvol, cin, cout);
-    const dim3 grid((unsigned)((n_rows + MF_TM - 1) / MF_TM)), block(256);
-#define MF_LAUNCH(NT, VEC) hipLaunchKernelGGL((sp_conv_mfma_kernel<NT, VEC>), grid, block, 0, stream, x, map, packed_weight, perm, rowmask, n_rows, kvol, cin, cout, flip, y)
-    if ((cin & 3) == 0) {
-        switch (mf_nt(cout)) {
-            case 1: MF_LAUNCH(1, true); break;
-            case 2: MF_LAUNCH(2, true); break;
-            default: MF_LAUNCH(4, true); break;
-        }
-    } else {
-        switch (mf_nt(cout)) {
-            case 1: MF_LAUNCH(1, false); break;
-            case 2: MF_LAUNCH(2, false); break;
-            default: MF_LAUNCH(4, false); break;
-        }
-    }
-#undef MF_LAUNCH
-    GGA_CHECK_LAUNCH("sp_conv_mfma_kernel");
-    return GGA_OK;
-}
-
-
-// ------------------------------------------------------------------------------ fp32 through bf16 planes
-// The same convolution on v_mfma_f32_32x32x16_bf16. An fp32 number is the exact sum of three
-// bfloat16 numbers (8 + 8 + 8 significand bits, by truncation), so a*b is the sum of nine bf16
-// products, each exact in fp32; the matrix core accumulates them in fp32. Nine bf16 MFMAs cover
-// K = 16 in 9*32 cycles where the fp32 MFMA needs 8*64: measured 256 vs 149 fp32-equivalent
-// TFLOP/s on this part, with an error against float64 no larger than the native fp32 MFMA's
-// (2.0e-7 vs 4.5e-7 of sum|a*b| at K = 256; tools_dev/micro/bf16x9_probe.hip). The weights are split
-// when they are packed; the gathered inputs are split on their way into LDS.
-// LDS image per plane: A [128 rows][32 ch], B [CO cols][32 ch] bf16, 80-byte rows (64 + 16 pad:
-// conflict-free ds_read_b128). Lane (r = lane%32, h = lane/32) of k-step s reads the 8 channels
-// 16s + 8h .. +7 of its row / column: one 16-byte read per plane.
-typedef __bf16 mf_v8bf __attribute__((ext_vector_type(8)));
-#define X9_ROWB 80                       // bytes per LDS row
-
-__device__ __forceinline__ void x9_split(float x, uint32_t& p1, uint32_t& p2, uint32_t& p3) {
-    const uint32_t u1 = __float_as_uint(x) & 0xFFFF0000u;
-    const float r1 = x - __uint_as_float(u1);            // exact
-    const uint32_t u2 = __float_as_uint(r1) & 0xFFFF0000u;
-    const float r2 = r1 - __uint_as_float(u2);           // exact, <= 8 significant bits
-    p1 = u1 >> 16; p2 = u2 >> 16; p3 = __float_as_uint(r2) >> 16;
-}
-
-// two values at once, packed for the LDS images: word p = {plane p of b, plane p of a} (a in the low
-// half). v_perm_b32 picks the two high halves directly, so no shift / or is spent on packing.
-__device__ __forceinline__ void x9_split2(float a, float b, uint32_t& w1, uint32_t& w2, uint32_t& w3) {
-    const uint32_t ua = __float_as_uint(a), ub = __float_as_uint(b);
-    w1 = __builtin_amdgcn_perm(ub, ua, 0x07060302u);
-    const float ra = a - __uint_as_float(ua & 0xFFFF0000u), rb = b - __uint_as_float(ub & 0xFFFF0000u);     // exact
-    const uint32_t va = __float_as_uint(ra), vb = __float_as_uint(rb);
-    w2 = __builtin_amdgcn_perm(vb, va, 0x07060302u);
-    const float sa = ra - __uint_as_float(va & 0xFFFF0000u), sb = rb - __uint_as_float(vb & 0xFFFF0000u);   // exact, <= 8 bits
-    w3 = __builtin_amdgcn_perm(__float_as_uint(sb), __float_as_uint(sa), 0x07060302u);
-}
-
-// ---- fp32 through TWO fp16 planes (the dense kernels' default arithmetic, NP = 2) ---------------------------------
-// With a power-of-two scale s that puts the tensor's largest finite magnitude into [2^14, 2^15), v = x * s (exact) is
-// h0 + h1 + r with h0 = fp16(v), h1 = fp16(v - h0), both round-to-nearest: |r| <= max(2^-22 |v|, 2^-25) - 22 significand
-// bits where bf16 needs three planes for 24, and (a0 + a1)(b0 + b1) needs THREE matrix products (a1 * b1 < 2^-21 |ab| is
-// dropped) instead of six. What fp16 does not have is fp32's exponent range: an element is kept to an ABSOLUTE accuracy of
-// 2^-39 of its tensor's largest magnitude, so its relative accuracy falls below 2^-22 once it is smaller than 2^-17 of
-// that maximum. For a sum of products that is an error of at most ~1e-12 * max|a| * sum|b| - far below the fp32
-// accumulation error - but it is not fp32's element-wise semantics for tensors spanning more than ~2^38 in magnitude
-// (test_dense_conv3x3_arithmetic_contract). Non-finite inputs: Inf splits into Inf + NaN, as on the bf16 path.
-typedef _Float16 mf_v8h __attribute__((ext_vector_type(8)));
-
-// scale 2^(14 - floor(log2(amax))) from the bits of the largest finite magnitude (0: empty / all-zero tensor -> 1)
-__device__ __forceinline__ int h2_scale_exp(uint32_t amax_bits) {
-    const int e = (int)((amax_bits >> 23) & 0xFF);
-    if (e == 0) return 127;
-    const int sb = 268 - e;
-    return sb < 2 ? 2 : (sb > 252 ? 252 : sb);
-}
-__device__ __forceinline__ float h2_scale(int sb) { return __uint_as_float((uint32_t)sb << 23); }
-__device__ __forceinline__ float h2_descale(int sb) { return __uint_as_float((uint32_t)(254 - sb) << 23); }
-// two scaled values at once: word p = {plane p of b, plane p of a} (a in the low half)
-__device__ __forceinline__ void h2_split2(float a, float b, uint32_t& w0, uint32_t& w1) {
-    const __half2 h0 = __floats2half2_rn(a, b);
-    const float2 f0 = __half22float2(h0);
-    const __half2 h1 = __floats2half2_rn(a - f0.x, b - f0.y);       // exact differences
-    w0 = *reinterpret_cast<const uint32_t*>(&h0);
-    w1 = *reinterpret_cast<const uint32_t*>(&h1);
-}
+#include "conv_planes.h"
 
 // largest finite |x| of a [rows, width] matrix (row stride in floats), as float bits, by atomicMax into *out (zeroed first)
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, int64_t rows, int width4, int64_t row_stride,
@@ -1028,17 +340,11 @@ __global__ __launch_bounds__(64 * X9_NW, 2) void sp_conv_x9_kernel(const float* 
     };
     // loads are unconditional: an absent neighbour reads row 0 and is zeroed when it is split
     auto load_a = [&](int ch, int i0) {
-#ifdef X9_ABL_NOGATHER                      /* ablation builds (tools_dev/exp_libs): every gather reads the tile's first rows */
-        i0 = tid & 127;
-#endif
         const float* row = X + (int64_t)(i0 >= 0 ? i0 : 0) * cin;
         const int c = ch * MF_TK + 8 * h;
         rn00 = ld4(row, c); rn01 = ld4(row, c + 4); rn10 = ld4(row, c + 16); rn11 = ld4(row, c + 20);
     };
     auto load_b = [&](int k, int ch) {
-#ifdef X9_ABL_NOB
-        k = 0; ch = 0;
-#endif
         const uint4* src = reinterpret_cast<const uint4*>(Wp + ((int64_t)k * nchunks + ch) * (NP * CO * 32));
         const int last = BPIECES - 1;
 #define X9_BLD(E, V) if ((E) < NB) V = src[min(tid + THREADS * (E), last)];
@@ -1058,12 +364,8 @@ __global__ __launch_bounds__(64 * X9_NW, 2) void sp_conv_x9_kernel(const float* 
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float x = ok && c + 2 * j < cin ? e[2 * j] : 0.f, y = ok && c + 2 * j + 1 < cin ? e[2 * j + 1] : 0.f;
-#ifdef X9_ABL_NOSPLIT
-            f1.u[j] = __float_as_uint(x); f2.u[j] = __float_as_uint(y); f3.u[j] = 0;
-#else
             if (NP == 3) x9_split2(x, y, f1.u[j], f2.u[j], f3.u[j]);
             else h2_split2(x * xscale, y * xscale, f1.u[j], f2.u[j]);
-#endif
         }
     };
 
@@ -1091,11 +393,7 @@ __global__ __launch_bounds__(64 * X9_NW, 2) void sp_conv_x9_kernel(const float* 
             load_a(valid1 ? ch1 : ch, ia);
             load_b(valid1 ? k1 : k, valid1 ? ch1 : ch);
             const int kk = flip ? (kvol - 1 - k) : k;
-#ifdef X9_NO_WAVE_SKIP
-            {
-#else
             if (kvol > 32 || ((wmask >> kk) & 1u)) {
-#endif
                 Frag a0[3], a1[3];
                 const int c = ch * MF_TK + 8 * h;
                 split8(rc00, rc01, ic >= 0, c, a0[0], a0[1], a0[2]);
@@ -1113,18 +411,10 @@ __global__ __launch_bounds__(64 * X9_NW, 2) void sp_conv_x9_kernel(const float* 
                     // that consecutive MFMAs never wait for each other's accumulator
 #define X9_MM(PA, PB) _Pragma("unroll") for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA].v, b[t][PB], acc[t], 0, 0, 0);
 #define X9_MH(PA, PB) _Pragma("unroll") for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(mf_v8h, a[PA].v), __builtin_bit_cast(mf_v8h, b[t][PB]), acc[t], 0, 0, 0);
-#ifdef X9_ABL_NOMFMA
-                    if (a[0].u[0] == 0x12345678u) acc[0][0] += 1.0f;
-#else
                     if (NP == 2) { X9_MH(0, 1) X9_MH(1, 0) X9_MH(0, 0) }
                     else {
-#if !defined(X9_NINE)
                     X9_MM(0, NP - 1) X9_MM(1, 1) X9_MM(NP - 1, 0) X9_MM(0, 1) X9_MM(1, 0) X9_MM(0, 0)       // six terms, see the dense kernels
-#else
-                    X9_MM(NP - 1, NP - 1) X9_MM(1, NP - 1) X9_MM(NP - 1, 1) X9_MM(0, NP - 1) X9_MM(1, 1) X9_MM(NP - 1, 0) X9_MM(0, 1) X9_MM(1, 0) X9_MM(0, 0)
-#endif
                     }
-#endif
 #undef X9_MH
 #undef X9_MM
                 }
@@ -1141,220 +431,6 @@ __global__ __launch_bounds__(64 * X9_NW, 2) void sp_conv_x9_kernel(const float* 
         }
     }
     x9_epilogue<NT, NP, NW>(acc, pr, wave, r, h, tid, cout, Y, ys, stats, tile, bn, Bs, sbx, sbw);
-}
-
-// ------------------------------------------------------------------------------ the same product, LDS-DMA ring form
-// What bounds sp_conv_x9_kernel at the 128-channel level of the shipped config (510 k rows, 14.5 pairs per row; measured
-// with ablation builds, tools_dev/exp_x9_ablate.py): not the matrix pipe (26 % busy), not the bytes (spatially ordered rows,
-// i.e. L2-resident gathers, change nothing) - the LATENCY of its loads. Its registers hold one stage of lookahead, a stage is
-// ~800 cycles of matrix work, and a gathered row or a weight stage takes 1 - 2 us to arrive from the L2 / the Infinity Cache
-// under load: every stage waits. This form keeps TWO stages in flight without a register: every operand goes global -> LDS
-// by LDS-DMA (global_load_lds_dwordx4, issued from inline asm so that the compiler neither counts nor drains it), retired
-// by a counted s_waitcnt vmcnt(N) that leaves the younger stages in flight, behind a raw s_barrier.
-//   tile   256 output rows x CO columns, 512 threads: wave w owns rows 32w .. 32w+31 (operand layout and D layout as in
-//          sp_conv_x9_kernel), so a weight stage is shared by 8 waves instead of 4 - half the weight bytes per row;
-//   ring   R = D + 1 slots of [A: 256 rows x 32 channels fp32 | B: one packed weight stage]; 3 x 48 KB at CO = 128 on two
-//          fp16 planes (D = 2), 2 x 56 KB on three bf16 planes (D = 1); one workgroup per CU, two waves per SIMD;
-//   A      a wave's 32 rows x 128 bytes, fetched as WHOLE lines (8 lanes per row and instruction, segments XOR-swizzled by
-//          the row number) into a wave-private image that lane (r, h) reads its 2 x 32 bytes per k-step from: no barrier
-//          for A, no bank conflict; absent neighbours request row 0 and are zeroed when they are split;
-//   B      the packed stage is copied as it is (its 16-byte quarters are stored swizzled, sp_pack_weight_split_kernel);
-//   idx    the rule-book entry of a lane's row for the offset of stage t must be in a register when A(t) is requested, D
-//          stages before t - it is itself fetched by LDS-DMA (4 bytes per row) D stages before that, into an 8-deep ring;
-//   block s (top of stage s): wait until only the DMAs of stages s+1 .. s+D-1 are outstanding -> s_barrier (everyone's
-//          share of B(s) has landed, everyone is done reading slot (s-1) % R) -> request stage s+D into that slot ->
-//          read A(s), B(s), split, MFMA.
-template <int NT, int NP, int D>
-__global__ __launch_bounds__(512) void sp_conv_ring_kernel(const float* __restrict__ X, const int32_t* __restrict__ map,
-                                                          const uint16_t* __restrict__ Wp, const int32_t* __restrict__ perm,
-                                                          const uint32_t* __restrict__ rowmask, int64_t n_rows, int kvol,
-                                                          int cin, int cout, int flip, float* __restrict__ Y, int64_t ys,
-                                                          const uint32_t* __restrict__ amax_x,
-                                                          const uint32_t* __restrict__ amax_w, double* __restrict__ stats,
-                                                          SpBnBwd bn, int64_t stats_rows, int tile_order, int64_t n_tiles,
-                                                          int chunk_outer) {
-    constexpr int CO = NT * 32, NW = 8, TM = 256, R = D + 1;
-    constexpr int A_SLOT = TM * 128;                      // bytes: 32 fp32 channels per row
-    constexpr int B_PL = CO * 64, B_SLOT = NP * B_PL;     // bytes per plane / per packed stage
-    constexpr int BPIECES = B_SLOT / 16;                  // 16-byte pieces of a weight stage: a multiple of 64
-    constexpr int NBP = (BPIECES + 511) / 512;            // DMA instructions per stage of the waves that take part in all rounds
-    constexpr int SLOT = A_SLOT + B_SLOT;
-    constexpr int IDXR = 8;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];       // ALL of the kernel's LDS (one object)
-    int* const idxring = reinterpret_cast<int*>(smem + R * SLOT);              // [IDXR][NW][32]
-    uint32_t* const wmask_s = reinterpret_cast<uint32_t*>(smem + R * SLOT + IDXR * TM * 4);
-    int* const koff = reinterpret_cast<int*>(wmask_s + NW);                    // [0] = enabled offsets, [1 ..] = their numbers
-    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
-
-    int sbx = 127, sbw = 127;
-    if (NP == 2) { sbx = h2_scale_exp(*amax_x); sbw = h2_scale_exp(*amax_w); }
-    const float xscale = h2_scale(sbx);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 31, h = lane >> 5;
-    int64_t tile = (int64_t)gridDim.x - 1 - blockIdx.x;                        // most neighbours first (mask-sorted rows)
-    if (tile_order == 1) {                                                     // XCD-major (see sp_conv_x9_kernel)
-        const int64_t per = (n_tiles + 7) / 8;
-        tile = (int64_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
-        if ((int64_t)(blockIdx.x >> 3) >= per || tile >= n_tiles) return;
-    }
-    const int64_t r0 = tile * TM;
-    if (tid < NW) wmask_s[tid] = 0;
-    __syncthreads();
-    const int64_t myrow = r0 + wave * 32 + r;
-    const int pr = myrow < n_rows ? (perm ? perm[myrow] : (int)myrow) : -1;
-    {
-        uint32_t m = 0;
-        if (pr >= 0) m = (rowmask && kvol <= 32) ? rowmask[pr] : 0xFFFFFFFFu;
-        if (m && h == 0) atomicOr(&wmask_s[wave], m);
-    }
-    __syncthreads();
-    const uint32_t wmask = __builtin_amdgcn_readfirstlane(wmask_s[wave]);
-    if (tid == 0) {
-        uint32_t tm = 0;
-        for (int w = 0; w < NW; ++w) tm |= wmask_s[w];
-        int n = 0;
-        for (int k = 0; k < kvol; ++k) {
-            const int kk = flip ? (kvol - 1 - k) : k;
-            if (kvol > 32 || ((tm >> kk) & 1u)) koff[1 + n++] = k;
-        }
-        koff[0] = n;
-    }
-    __syncthreads();
-    const int ne = __builtin_amdgcn_readfirstlane(koff[0]);
-    const int nchunks = cin / MF_TK;
-    const int S = ne * nchunks;                                                // stages of this tile
-    mf_v16 acc[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
-
-    const int64_t prc = pr >= 0 ? pr : 0;
-    auto kk_of = [&](int j) { const int k = __builtin_amdgcn_readfirstlane(koff[1 + j]); return flip ? (kvol - 1 - k) : k; };
-    // one LDS-DMA instruction: 16 (or 4) bytes per lane from `src` to LDS bytes [dst + 16 * lane) (dst wave-uniform)
-    auto dma16 = [&](const void* src, uint32_t dst) {
-        unsigned keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
-    };
-    auto dma4 = [&](const void* src, uint32_t dst) {
-        unsigned keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
-    };
-    // Stage t -> (offset ordinal j, chunk ch). chunk_outer = 0: all chunks of an offset, then the next offset (a rule-book entry
-    // serves nchunks consecutive stages). chunk_outer = 1: all offsets of a chunk, then the next chunk - with spatially ordered
-    // rows the 27 offsets of a chunk re-read the same few hundred 128-byte row slices, which then stay in the L2 / L1 (the
-    // whole 512-byte rows of a tile's neighbourhood, revisited only once per offset, do not: sparse.py::ring_order).
-    auto j_of = [&](int t) { return chunk_outer ? t % ne : t / nchunks; };
-    auto ch_of = [&](int t) { return chunk_outer ? t / ne : t % nchunks; };
-    auto slot_of = [&](int t) { return chunk_outer ? t % IDXR : (t / nchunks) % IDXR; };
-    // DMA instructions of `issue(t)`: 4 (A) + NBP (B) + 1 when stage t + D opens a new offset (its rule-book entries)
-    auto idx_flag = [&](int t) { return t + D < S && (chunk_outer || (t + D) % nchunks == 0); };
-    const int nbp = (BPIECES - wave * 64 + 511) / 512;     // this wave's weight DMAs per stage (pieces wave * 64 + 512 e)
-    auto count = [&](int t) { return 4 + nbp + (idx_flag(t) ? 1 : 0); };
-    auto issue = [&](int t) {
-        const int j = j_of(t), ch = ch_of(t);
-        const int kk = kk_of(j);
-        const int slot = t % R;
-        // A: instruction q fetches the 128-byte chunk rows of the wave's rows 8q .. 8q+7 WHOLE - 8 lanes per row, so a row's
-        // cache line is requested once, by one instruction (a lane fetching the pieces of its own row over four instructions
-        // asks for every line four times, and the 32 KB a stage gathers do not survive in the L1 in between). The 16-byte
-        // segment a lane fetches is XOR-ed with the row number: the LDS image [32 rows][128 B] is then read conflict-free.
-        const uint32_t a_dst = __builtin_amdgcn_readfirstlane(lds0 + slot * SLOT + wave * 4096);
-        const int* irow = idxring + slot_of(t) * TM + wave * 32 + (lane >> 3);    // landed: requested >= D blocks ago
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int i0 = irow[8 * q];
-            const int rr = 8 * q + (lane >> 3);
-            dma16(X + (int64_t)(i0 >= 0 ? i0 : 0) * cin + ch * MF_TK + 4 * ((lane & 7) ^ (rr & 7)), a_dst + q * 1024);
-        }
-        const unsigned char* bsrc = reinterpret_cast<const unsigned char*>(Wp) + ((int64_t)(flip ? kvol - 1 - kk : kk) * nchunks + ch) * B_SLOT
-                                    + (int64_t)tid * 16;
-        const uint32_t b_dst = __builtin_amdgcn_readfirstlane(lds0 + slot * SLOT + A_SLOT + wave * 1024);
-#pragma unroll
-        for (int e = 0; e < NBP; ++e)
-            if (e < nbp) dma16(bsrc + e * 8192, b_dst + e * 8192);
-        if (idx_flag(t)) {
-            const int j2 = j_of(t + D);
-            const int32_t* isrc = map + (int64_t)kk_of(j2) * n_rows + prc;
-            const uint32_t i_dst = __builtin_amdgcn_readfirstlane(lds0 + R * SLOT + (slot_of(t + D) * TM + wave * 32) * 4);
-            if (h == 0) dma4(isrc, i_dst);
-        }
-    };
-    auto wait_vm = [&](int n) {           // s_waitcnt vmcnt(n) with a run-time (wave-uniform) n
-        switch (n) {
-            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-            case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-            case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-            case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-            default: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-        }
-    };
-    static_assert(D == 1 || D == 2, "the wait below sums the DMA counts of D - 1 stages");
-    union Frag { mf_v8bf v; uint32_t u[4]; };
-    auto split8 = [&](const float4& lo, const float4& hi, bool ok, Frag& f1, Frag& f2, Frag& f3) {
-        const float e[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float x = ok ? e[2 * q] : 0.f, y = ok ? e[2 * q + 1] : 0.f;
-            if (NP == 3) x9_split2(x, y, f1.u[q], f2.u[q], f3.u[q]);
-            else h2_split2(x * xscale, y * xscale, f1.u[q], f2.u[q]);
-        }
-    };
-
-    if (S > 0) {
-        // prologue: the rule-book entries of the first D stages' offsets by ordinary loads (nothing is in flight yet)
-        for (int t = 0; t < D && t < S; ++t) {
-            if (!chunk_outer && t % nchunks != 0) continue;          // the same offset as the stage before
-            const int v = map[(int64_t)kk_of(j_of(t)) * n_rows + prc];
-            if (h == 0) idxring[slot_of(t) * TM + wave * 32 + r] = v;
-        }
-        __syncthreads();
-        for (int t = 0; t < D && t < S; ++t) issue(t);
-        for (int s = 0; s < S; ++s) {
-            // the DMAs of stage s have landed once only those of stages s+1 .. s+D-1 are outstanding
-            wait_vm((D == 2 && s + 1 < S) ? count(s + 1) : 0);
-            __builtin_amdgcn_s_barrier();
-            if (s + D < S) issue(s + D);
-            const int kk = kk_of(j_of(s));
-            if (kvol > 32 || ((wmask >> kk) & 1u)) {
-                const int ic = idxring[slot_of(s) * TM + wave * 32 + r];
-                // segment g = 4 sk + 2 h + e of row r sits at 16-byte position g ^ (r & 7) of the row's 128 bytes
-                const unsigned char* Ap = smem + (s % R) * SLOT + wave * 4096 + r * 128;
-                const int sw = r & 7;
-                const float4 p0 = *reinterpret_cast<const float4*>(Ap + (((2 * h) ^ sw) << 4)), p1 = *reinterpret_cast<const float4*>(Ap + (((2 * h + 1) ^ sw) << 4));
-                const float4 p2 = *reinterpret_cast<const float4*>(Ap + (((4 + 2 * h) ^ sw) << 4)), p3 = *reinterpret_cast<const float4*>(Ap + (((5 + 2 * h) ^ sw) << 4));
-                Frag a0[3], a1[3];
-                split8(p0, p1, ic >= 0, a0[0], a0[1], a0[2]);
-                split8(p2, p3, ic >= 0, a1[0], a1[1], a1[2]);
-                const unsigned char* Bp = smem + (s % R) * SLOT + A_SLOT + r * 64;
-                const int swz = (r >> 2) & 3;
-#pragma unroll
-                for (int sk = 0; sk < 2; ++sk) {
-                    const Frag* a = sk ? a1 : a0;
-                    mf_v8bf b[NT][NP];
-#pragma unroll
-                    for (int t = 0; t < NT; ++t)
-#pragma unroll
-                        for (int p = 0; p < NP; ++p)
-                            b[t][p] = *reinterpret_cast<const mf_v8bf*>(Bp + p * B_PL + t * 32 * 64 + (((sk * 2 + h) ^ swz) * 16));
-#define XR_MM(PA, PB) _Pragma("unroll") for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA].v, b[t][PB], acc[t], 0, 0, 0);
-#define XR_MH(PA, PB) _Pragma("unroll") for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(mf_v8h, a[PA].v), __builtin_bit_cast(mf_v8h, b[t][PB]), acc[t], 0, 0, 0);
-                    if (NP == 2) { XR_MH(0, 1) XR_MH(1, 0) XR_MH(0, 0) }
-                    else { XR_MM(0, NP - 1) XR_MM(1, 1) XR_MM(NP - 1, 0) XR_MM(0, 1) XR_MM(1, 0) XR_MM(0, 0) }
-#undef XR_MH
-#undef XR_MM
-                }
-            }
-        }
-    }
-    // stats rows of the 128-row tiling this tile does not write (the caller sized `stats` for gga_sparse_conv_apply_tiles)
-    if (stats) {
-        const int64_t extra = n_tiles + tile;
-        if (extra < stats_rows && tid < 2 * cout) stats[extra * 2 * cout + tid] = 0.0;
-    }
-    x9_epilogue<NT, NP, NW>(acc, pr, wave, r, h, tid, cout, Y, ys, stats, tile, bn, smem, sbx, sbw);
 }
 
 // ------------------------------------------------------------------------------ the same product, halo form (SubM)
@@ -1386,17 +462,7 @@ __global__ __launch_bounds__(512) void sp_conv_ring_kernel(const float* __restri
 // instead of offset-outer, so the two forms differ by fp32 summation order only.
 #define XH_TM 256
 #define XH_HCAP 512
-#ifdef XH_TIMING                                  /* experiment builds (tools_dev/exp_libs): cycles per phase, summed over the tiles */
-__device__ unsigned long long xh_times[8];
-extern "C" int gga_debug_halo_times(unsigned long long* out, int reset) {
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(xh_times), sizeof(xh_times)) != hipSuccess) return 1;
-    if (reset) { unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; if (hipMemcpyToSymbol(HIP_SYMBOL(xh_times), z, sizeof(z)) != hipSuccess) return 1; }
-    return 0;
-}
-#define XH_T(i) { const unsigned long long now_ = wall_clock64(); tacc_[i] += now_ - tlast_; tlast_ = now_; }
-#else
 #define XH_T(i)
-#endif
 #define XH_KMAX 27
 template <int NT>
 __global__ __launch_bounds__(256) void sp_conv_halo_kernel(const float* __restrict__ X, const uint16_t* __restrict__ Wp,
@@ -1428,9 +494,6 @@ __global__ __launch_bounds__(256) void sp_conv_halo_kernel(const float* __restri
     for (int rb = 0; rb < RB; ++rb) pr[rb] = tperm[tile * TM + (wave * RB + rb) * 32 + r];
     const int32_t* const hlist = hlist_all + tile * hcap;
     const int hn = hcount[tile];                          // (submanifold maps: >= 1, a row is its own centre neighbour)
-#ifdef XH_TIMING
-    unsigned long long tlast_ = wall_clock64(), tacc_[6] = {0, 0, 0, 0, 0, 0};
-#endif
     // prologue (ordinary loads, nothing else in flight): the tile's local rule book and halo list into LDS, the zero row
     {
         const uint4* src = reinterpret_cast<const uint4*>(lmap + tile * (int64_t)kvol * TM);
@@ -1535,11 +598,7 @@ __global__ __launch_bounds__(256) void sp_conv_halo_kernel(const float* __restri
         // A fragments of k-step sk for the lane's neighbour at image position L (0xFFFF: none -> the zero row)
         auto load_a = [&](Frag (&fa)[2], int L, int sk, int c) {
             const bool far = FAR && L != 0xFFFF && L >= HCAP;
-#ifdef XH_ABL_NOA                               /* ablation builds: every lane reads the zero row (no bank conflicts) */
-            const int Lc = HCAP + 0 * L;
-#else
             const int Lc = L < HCAP ? L : HCAP;
-#endif
             const unsigned char* Ap = smem + Lc * 128;
             const int sw = (Lc >> 1) & 7;
 #pragma unroll
@@ -1632,9 +691,6 @@ __global__ __launch_bounds__(256) void sp_conv_halo_kernel(const float* __restri
     }
     x9_epilogue_rb<NT, NP, NW, RB>(acc, pr, wave, r, h, tid, cout, Y, ys, stats, tile, bn, smem, sbx, sbw);
     XH_T(5)
-#ifdef XH_TIMING
-    if (tid == 0) for (int i = 0; i < 6; ++i) atomicAdd(&xh_times[i], tacc_[i]);
-#endif
 }
 
 extern "C" int64_t gga_sparse_halo_tile_rows(void) { return XH_TM; }
@@ -1803,30 +859,6 @@ extern "C" int gga_sparse_conv_apply_bn_bwd(const float* x, const int32_t* map, 
                 (long long)n_rows, kvol, cin, cout, (long long)y_row_stride);
     const int64_t n_tiles = (n_rows + X9_TM - 1) / X9_TM;
     static const int tile_order = getenv("GGA_SP_TILE_ORDER") ? atoi(getenv("GGA_SP_TILE_ORDER")) : 0;
-    // large products of 64 / 128 output columns over whole 32-channel chunks: the LDS-DMA ring form (256-row tiles)
-    // OFF by default: measured inside the shipped config's step (rocprofv3 kernel trace, bs 8) the ring form does not pay -
-    // 17 launches x 834 us + 4 x 152 us = 14.8 ms against 21 x 689 us = 14.5 ms of sp_conv_x9_kernel (stand-alone, the 510 k-row
-    // 128 -> 128 launch: 1.29 - 1.37 ms against 1.40 - 1.46). GGA_SP_RING=1 selects it for 128 columns, 2 for 64 as well.
-    static const int ring_on = getenv("GGA_SP_RING") ? atoi(getenv("GGA_SP_RING")) : 0;
-    static const int ring_order = getenv("GGA_SP_RING_ORDER") ? atoi(getenv("GGA_SP_RING_ORDER")) : 0;
-    static const int64_t ring_min_rows = getenv("GGA_SP_RING_MIN_ROWS") ? atoll(getenv("GGA_SP_RING_MIN_ROWS")) : 131072;
-    if (ring_on && cin % MF_TK == 0 && (cout == 128 || (cout == 64 && ring_on == 2)) && n_rows >= ring_min_rows) {
-        const int64_t rtiles = (n_rows + 255) / 256;
-        const dim3 rgrid((unsigned)(tile_order == 1 ? 8 * ((rtiles + 7) / 8) : rtiles)), rblock(512);
-        hipEvent_t* rtev = gga_timing_acquire(GGA_TIME_SPARSE_CONV, GGA_TIMING_CONV_KEY(cin, cout, 0));
-        GGA_TIME_START(rtev, stream);
-#define XR_LAUNCH(NT, NP, D) { \
-            constexpr size_t lds = (size_t)(D + 1) * (256 * 128 + NP * NT * 32 * 64) + 8 * 256 * 4 + 8 * 4 + 36 * 4; \
-            static bool once = false; \
-            if (!once) { GGA_CHECK_HIP(hipFuncSetAttribute((const void*)sp_conv_ring_kernel<NT, NP, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "sp_conv_ring_kernel: LDS size"); once = true; } \
-            hipLaunchKernelGGL((sp_conv_ring_kernel<NT, NP, D>), rgrid, rblock, lds, stream, x, map, (const uint16_t*)split_weight, perm, rowmask, n_rows, kvol, cin, cout, flip, y, y_row_stride, amax_x, amax_weight, stats, bn, n_tiles, tile_order, rtiles, ring_order); }
-        if (planes == 2) { if (cout == 128) XR_LAUNCH(4, 2, 2) else XR_LAUNCH(2, 2, 2) }
-        else { if (cout == 128) XR_LAUNCH(4, 3, 1) else XR_LAUNCH(2, 3, 2) }
-#undef XR_LAUNCH
-        GGA_CHECK_LAUNCH("sp_conv_ring_kernel");
-        GGA_TIME_STOP(rtev, stream);
-        return GGA_OK;
-    }
     const dim3 grid((unsigned)(tile_order == 1 ? 8 * ((n_tiles + 7) / 8) : n_tiles)), block(64 * X9_NW);
     hipEvent_t* tev = gga_timing_acquire(GGA_TIME_SPARSE_CONV, GGA_TIMING_CONV_KEY(cin, cout, 0));
     GGA_TIME_START(tev, stream);
@@ -1857,160 +889,6 @@ extern "C" int gga_sparse_conv_apply_split(const float* x, const int32_t* map, c
     return gga_sparse_conv_apply_split_strided(x, map, split_weight, perm, rowmask, n_rows, kvol, cin, cout, flip, y, cout, stream_);
 }
 
-// ------------------------------------------------------------------------------ weight gradient
-// dW[k] (CI x CO) = Xp^T (CI x pairs) * Gp (pairs x CO) over the valid (input row, output row)
-// pairs of offset k, on v_mfma_f32_32x32x2_f32. grid = (2048-row chunks, kvol): a workgroup
-// compacts the chunk's valid pairs of its offset into LDS, then walks them 32 at a time: the
-// gathered X rows and the G rows of the next 32 pairs are fetched into registers before the
-// MFMAs of the current ones and written to the other LDS buffer after them (one barrier per
-// stage). The NI x NJ 32x32 tiles of dW[k] are dealt to the 4 waves (tile = wave*TPW + t), so
-// the waves of a row of tiles share the X fragment; one atomicAdd per weight and chunk.
-#define SP_WCHUNK 2048
-template <int NI, int NJ, bool VEC>
-__global__ __launch_bounds__(256) void sp_conv_wgrad_mfma_kernel(const float* __restrict__ X, const float* __restrict__ G,
-                                                                const int32_t* __restrict__ map, int64_t n_rows,
-                                                                int cin, int cout, float* __restrict__ dW) {
-    constexpr int CI = NI * 32, CO = NJ * 32;
-    constexpr int TILES = NI * NJ;
-    constexpr int TPW = (TILES + 3) / 4;             // tiles per wave
-    constexpr int XSZ = 32 * CI, GSZ = 32 * CO;
-    __shared__ __attribute__((aligned(16))) float Xs[2 * XSZ];
-    __shared__ __attribute__((aligned(16))) float Gs[2 * GSZ];
-    __shared__ int pin[SP_WCHUNK];       // compacted valid pairs of the chunk: input row
-    __shared__ uint16_t pout[SP_WCHUNK]; //                                      output row (chunk-local)
-    __shared__ int npairs;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int k = blockIdx.y;
-    const int64_t r0 = (int64_t)blockIdx.x * SP_WCHUNK;
-    if (tid == 0) npairs = 0;
-    __syncthreads();
-    for (int t = tid; t < SP_WCHUNK; t += 256) {
-        const int64_t r = r0 + t;
-        const int v = r < n_rows ? map[(int64_t)k * n_rows + r] : -1;
-        if (v >= 0) { const int p = atomicAdd(&npairs, 1); pin[p] = v; pout[p] = (uint16_t)t; }
-    }
-    __syncthreads();
-    const int np = npairs;
-    if (np == 0) return;
-    mf_v16 acc[TPW];
-#pragma unroll
-    for (int t = 0; t < TPW; ++t)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
-
-    // staging registers: NI float4 of X and NJ float4 of G per thread and stage. Loads are
-    // unconditional (pairs past np re-read pair 0, channels past cin/cout re-read channel 0)
-    // and zeroed when they are written to LDS.
-    float4 xr[NI], gr[NJ];
-#define WG_LOAD(P0)                                                                                                  \
-    _Pragma("unroll") for (int e = 0; e < NI; ++e) {                                                                 \
-        const int t = tid + 256 * e, pp = t / (CI / 4), q = (t - pp * (CI / 4)) * 4;                                 \
-        const int pi = (P0) + pp < np ? (P0) + pp : 0;                                                               \
-        const float* src = X + (int64_t)pin[pi] * cin;                                                               \
-        if (VEC) xr[e] = *reinterpret_cast<const float4*>(src + (q < cin ? q : 0));                                  \
-        else xr[e] = make_float4(src[q < cin ? q : 0], src[q + 1 < cin ? q + 1 : 0], src[q + 2 < cin ? q + 2 : 0],    \
-                                 src[q + 3 < cin ? q + 3 : 0]);                                                      \
-    }                                                                                                                \
-    _Pragma("unroll") for (int e = 0; e < NJ; ++e) {                                                                 \
-        const int t = tid + 256 * e, pp = t / (CO / 4), q = (t - pp * (CO / 4)) * 4;                                 \
-        const int pi = (P0) + pp < np ? (P0) + pp : 0;                                                               \
-        const float* src = G + (r0 + pout[pi]) * cout;                                                               \
-        if (VEC) gr[e] = *reinterpret_cast<const float4*>(src + (q < cout ? q : 0));                                 \
-        else gr[e] = make_float4(src[q < cout ? q : 0], src[q + 1 < cout ? q + 1 : 0], src[q + 2 < cout ? q + 2 : 0], \
-                                 src[q + 3 < cout ? q + 3 : 0]);                                                     \
-    }
-#define WG_STORE(BUF, P0)                                                                                            \
-    _Pragma("unroll") for (int e = 0; e < NI; ++e) {                                                                 \
-        const int t = tid + 256 * e, pp = t / (CI / 4), q = (t - pp * (CI / 4)) * 4;                                 \
-        const bool ok = (P0) + pp < np;                                                                              \
-        const float4 v = make_float4(ok && q < cin ? xr[e].x : 0.f, ok && q + 1 < cin ? xr[e].y : 0.f,               \
-                                     ok && q + 2 < cin ? xr[e].z : 0.f, ok && q + 3 < cin ? xr[e].w : 0.f);          \
-        *reinterpret_cast<float4*>(Xs + (BUF) * XSZ + pp * CI + q) = v;                                              \
-    }                                                                                                                \
-    _Pragma("unroll") for (int e = 0; e < NJ; ++e) {                                                                 \
-        const int t = tid + 256 * e, pp = t / (CO / 4), q = (t - pp * (CO / 4)) * 4;                                 \
-        const bool ok = (P0) + pp < np;                                                                              \
-        const float4 v = make_float4(ok && q < cout ? gr[e].x : 0.f, ok && q + 1 < cout ? gr[e].y : 0.f,             \
-                                     ok && q + 2 < cout ? gr[e].z : 0.f, ok && q + 3 < cout ? gr[e].w : 0.f);        \
-        *reinterpret_cast<float4*>(Gs + (BUF) * GSZ + pp * CO + q) = v;                                              \
-    }
-    WG_LOAD(0);
-    WG_STORE(0, 0);
-    __syncthreads();
-    int buf = 0;
-    // a wave's TPW tiles sit in one row of tiles: i0 = tile0 / NJ, columns j0 .. j0+TPW-1, so one
-    // X fragment serves all of them (all wave-uniform -> scalar address math)
-    static_assert(NJ % TPW == 0, "tiles of a wave must share their tile row");
-    const int tile0 = __builtin_amdgcn_readfirstlane(wave) * TPW;
-    const bool wactive = tile0 < TILES;
-    const int i0 = tile0 / NJ, j0 = tile0 - i0 * NJ;
-    const int m = lane & 31, h = lane >> 5;
-    for (int p0 = 0; p0 < np; p0 += 32) {
-        WG_LOAD(p0 + 32);
-        if (wactive) {
-            const float* xb = Xs + buf * XSZ + h * CI + i0 * 32 + m;
-            const float* gb = Gs + buf * GSZ + h * CO + j0 * 32 + m;
-            float fa[2], fb[2][TPW];
-#define WG_READ(S2, S)                                                                                               \
-            fa[S] = xb[2 * (S2) * CI];                                                                               \
-            _Pragma("unroll") for (int t = 0; t < TPW; ++t) fb[S][t] = gb[2 * (S2) * CO + t * 32];
-            WG_READ(0, 0);
-#pragma unroll
-            for (int s2 = 0; s2 < 16; ++s2) {
-                if (s2 + 1 < 16) { WG_READ(s2 + 1, (s2 + 1) & 1); }
-#pragma unroll
-                for (int t = 0; t < TPW; ++t)
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s2 & 1], fb[s2 & 1][t], acc[t], 0, 0, 0);
-            }
-#undef WG_READ
-        }
-        if (p0 + 32 >= np) break;
-        buf ^= 1;                            // last read before the previous barrier
-        WG_STORE(buf, p0 + 32);
-        __syncthreads();
-    }
-#undef WG_LOAD
-#undef WG_STORE
-    float* dWk = dW + (int64_t)k * cin * cout;
-    if (!wactive) return;
-#pragma unroll
-    for (int t = 0; t < TPW; ++t) {
-        const int co = (j0 + t) * 32 + (lane & 31);
-#pragma unroll
-        for (int v = 0; v < 16; ++v) {
-            const int ci = i0 * 32 + (v >> 2) * 8 + (lane >> 5) * 4 + (v & 3);
-            if (ci < cin && co < cout && acc[t][v] != 0.0f) atomicAdd(&dWk[(int64_t)ci * cout + co], acc[t][v]);
-        }
-    }
-}
-
-extern "C" int gga_sparse_conv_wgrad(const float* x, const float* grad_out, const int32_t* map, int64_t n_rows,
-                                     int kvol, int cin, int cout, float* grad_weight, void* stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    GGA_REQUIRE(x && grad_out && map && grad_weight, "gga_sparse_conv_wgrad: null pointer argument");
-    GGA_REQUIRE(n_rows >= 1 && kvol >= 1 && cin >= 1 && cin <= 128 && cout >= 1 && cout <= 128,
-                "gga_sparse_conv_wgrad: bad sizes (cin, cout <= 128)");
-    hipEvent_t* tev = gga_timing_acquire(GGA_TIME_SPARSE_WGRAD, GGA_TIMING_CONV_KEY(cin, cout, 0));
-    GGA_TIME_START(tev, stream);
-    GGA_CHECK_HIP(hipMemsetAsync(grad_weight, 0, (size_t)kvol * cin * cout * sizeof(float), stream), "wgrad memset");
-    const dim3 grid((unsigned)((n_rows + SP_WCHUNK - 1) / SP_WCHUNK), kvol), block(256);
-    const int ni = (cin + 31) / 32, nj = (cout + 31) / 32;
-    const bool vec = (cin & 3) == 0 && (cout & 3) == 0;
-#define MW(NI, NJ) { if (vec) hipLaunchKernelGGL((sp_conv_wgrad_mfma_kernel<NI, NJ, true>), grid, block, 0, stream, x, grad_out, map, n_rows, cin, cout, grad_weight); \
-                     else hipLaunchKernelGGL((sp_conv_wgrad_mfma_kernel<NI, NJ, false>), grid, block, 0, stream, x, grad_out, map, n_rows, cin, cout, grad_weight); }
-    if (ni == 1 && nj == 1) MW(1, 1)
-    else if (ni == 1 && nj == 2) MW(1, 2)
-    else if (ni == 2 && nj == 2) MW(2, 2)
-    else if (ni == 2 && nj == 4) MW(2, 4)
-    else if (ni == 4 && nj == 4) MW(4, 4)
-    else if (ni <= 2 && nj <= 2) MW(2, 2)
-    else MW(4, 4)
-#undef MW
-    GGA_CHECK_LAUNCH("sp_conv_wgrad_mfma_kernel");
-    GGA_TIME_STOP(tev, stream);
-    return GGA_OK;
-}
-
 // ------------------------------------------------------------------------------ weight gradient, bf16 planes
 // The same dW[k] = Xp^T Gp on the bf16 matrix cores (six of the nine partial products, as in the
 // forward kernel), deterministic: no atomics anywhere.
@@ -2027,21 +905,13 @@ extern "C" int gga_sparse_conv_wgrad(const float* x, const float* grad_out, cons
 //     a group and take one K-step of the stage each; their accumulators are added through LDS.
 //   * every workgroup writes its partial dW[k] to workspace[chunk][k]; sp_wgrad_reduce_kernel sums
 //     the chunks in a fixed order in f64.
-typedef short dw_v4s __attribute__((ext_vector_type(4)));
 #define SPW_SUB 2048
 // Measured on the 510 k-row 128 -> 128 level (round 3, tools_dev/ab_wgrad.sh): a third stage of gathered rows in flight
-// (-DSPW_DEPTH=3, 96 instead of 64 KB per CU) changes nothing, rows in spatial order 3 %, the offsets of a chunk on one XCD
+// (-D2=3, 96 instead of 64 KB per CU) changes nothing, rows in spatial order 3 %, the offsets of a chunk on one XCD
 // 4 %, and without the plane split of the staged rows (-DSPW_ABL_NOSPLIT) the kernel is 16 % faster: a stage is 12 MFMAs per
 // wave behind ~200 vector instructions of split, masking and address arithmetic for its 16 pairs - issue-bound, like the
 // forward kernel's in-register split; the operands would have to arrive as planes to remove it.
-#ifdef SPW_ABL_NOSPLIT                                    /* ablation builds (tools_dev/exp_libs): the words as they are, no arithmetic */
-#define SPW_SPLIT4(V, SC, lo1, lo2, hi1, hi2) { lo1 = __float_as_uint(V.x); lo2 = __float_as_uint(V.y); hi1 = __float_as_uint(V.z); hi2 = __float_as_uint(V.w); }
-#else
 #define SPW_SPLIT4(V, SC, lo1, lo2, hi1, hi2) { h2_split2(V.x * (SC), V.y * (SC), lo1, lo2); h2_split2(V.z * (SC), V.w * (SC), hi1, hi2); }
-#endif
-#ifndef SPW_DEPTH
-#define SPW_DEPTH 2                                      /* stages of gathered rows in flight per workgroup (2 or 3) */
-#endif
 template <int NI, int NJ, bool VEC, int NP>
 __global__ __launch_bounds__(256, 2) void sp_conv_wgrad_x9_kernel(const float* __restrict__ X, const float* __restrict__ G,
                                                                  const int32_t* __restrict__ map, int64_t n_rows, int kvol,
@@ -2109,9 +979,6 @@ __global__ __launch_bounds__(256, 2) void sp_conv_wgrad_x9_kernel(const float* _
                           F.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) dw_v4s*)((PTR) + froff + 4 * 64)); }
 
     float4 xa[LX], ga[LG], xb[LX], gb_[LG];              // two stages of gathered rows in flight
-#if SPW_DEPTH == 3
-    float4 xc[LX], gc[LG];                               // ... three
-#endif
     for (int64_t r0 = c0; r0 < c1; r0 += SPW_SUB) {
         // ---- ordered compaction of the sub-chunk's valid pairs: thread t owns rows 8t .. 8t+7
         __syncthreads();                                   // previous sub-chunk's readers of pin / pout / images are done
@@ -2220,27 +1087,8 @@ __global__ __launch_bounds__(256, 2) void sp_conv_wgrad_x9_kernel(const float* _
         SW_LOAD(0, xa, ga);
         SW_STORE(0, 0, xa, ga);
         if (PAIRS < np) { SW_LOAD(PAIRS, xb, gb_); }
-#if SPW_DEPTH == 3
-        if (2 * PAIRS < np) { SW_LOAD(2 * PAIRS, xc, gc); }
-#endif
         __syncthreads();
         int buf = 0, p0 = 0;
-#if SPW_DEPTH == 3
-        // stage s: request stage s + 3 into the set stage s was stored from, multiply stage s, store stage s + 1
-#define SW_ITER(XL, GL, XS, GS_)                                                                                     \
-            if (p0 + 3 * PAIRS < np) { SW_LOAD(p0 + 3 * PAIRS, XL, GL); }                                            \
-            SW_COMPUTE(buf)                                                                                          \
-            if (p0 + PAIRS >= np) break;                                                                             \
-            SW_STORE(buf ^ 1, p0 + PAIRS, XS, GS_);                                                                  \
-            __syncthreads();                                                                                         \
-            buf ^= 1; p0 += PAIRS;
-        while (true) {
-            SW_ITER(xa, ga, xb, gb_)
-            SW_ITER(xb, gb_, xc, gc)
-            SW_ITER(xc, gc, xa, ga)
-        }
-#undef SW_ITER
-#else
         while (true) {
             if (p0 + 2 * PAIRS < np) { SW_LOAD(p0 + 2 * PAIRS, xa, ga); }
             SW_COMPUTE(buf)
@@ -2255,7 +1103,6 @@ __global__ __launch_bounds__(256, 2) void sp_conv_wgrad_x9_kernel(const float* _
             __syncthreads();
             buf ^= 1; p0 += PAIRS;
         }
-#endif
     }
 #undef SW_COMPUTE
 #undef SW_MM
@@ -2389,988 +1236,6 @@ extern "C" int gga_sparse_conv_wgrad_planes(const float* x, int64_t x_row_stride
                        (const float*)workspace, nchunks, kvol, cin, cout, ni * 32, nj * 32, planes == 2 ? amax_x : nullptr,
                        amax_grad_out, grad_weight);
     GGA_CHECK_LAUNCH("sp_wgrad_reduce_kernel");
-    GGA_TIME_STOP(tev, stream);
-    return GGA_OK;
-}
-
-// ------------------------------------------------------------------------------ dense 3x3 convolution
-// The dense kernels below use SIX of the nine partial products: with truncated planes
-// a = a0 + a1 + a2 (|a1| <= 2^-8 |a|, |a2| <= 2^-16 |a|) the products a1*b2, a2*b1 and a2*b2 together
-// are below 2^-23 |a*b| - one fp32 ulp of the product, what an unfused multiply-add loses anyway -
-// and the measured error of a whole convolution against float64 does not move (9.7e-7 of the
-// output range with six or nine terms; MIOpen's fp32 kernels: 1.0e-6 .. 1.5e-6): the fp32
-// accumulation dominates. One third fewer MFMAs: forward 416 -> 345 us, weight gradient 539 -> 434 us.
-// Compile with -DX9_NINE for all nine.
-#ifndef X9_NINE
-#define X9_SIX 1
-#endif
-// 3x3 / stride 1 / pad 1 convolution of a channels-last image on the same bf16x9 matrix path
-// (SECOND block convolutions and the first convolution of every head branch: second.py:58-63,
-// centerpoint_head.py:58-68 - 64 -> 64 channels at 248 x 216, where MIOpen's fp32 implicit GEMM
-// runs at 100-118 TFLOP/s). Unlike the gather form above, the input is regular: a 256-thread
-// workgroup owns 8 rows x 32 pixels x all output channels, wave w rows 2w and 2w+1 (two 32-pixel
-// M tiles that share every weight fragment). Per 16-input-channel chunk the 10 x 34 pixel halo
-// is fetched ONCE, split into the three bf16 planes on the way into LDS (48-byte pixel rows:
-// 32 + 16 pad, conflict-free ds_read_b128) and then feeds all nine taps - lane (r, h) reads
-// pixel (row + ky, r + kx), channels 8h .. 8h+7 - so there are no per-tap gathers and no per-use
-// split. The weight stage of one (tap, chunk) goes through LDS double buffered (the 32-byte half
-// rows of the packed layout of gga_sparse_pack_weight_split with kvol = 9); the next chunk's halo
-// is requested from global memory before the taps of the current chunk run. 66 KB of LDS: two
-// workgroups per CU.
-#ifdef DC_PROBE          /* tools_dev/probe_dense_stage.py: cycle accounting of the stage loop, wave 0 of every workgroup */
-__device__ unsigned long long dc_probe[8];
-extern "C" int gga_debug_dc_probe(unsigned long long* out) {
-    hipMemcpyFromSymbol(out, HIP_SYMBOL(dc_probe), sizeof(dc_probe));
-    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    hipMemcpyToSymbol(HIP_SYMBOL(dc_probe), z, sizeof(z));
-    return 0;
-}
-#define DC_T(V) const long long V = __builtin_readcyclecounter();
-#define DC_ACC(I, D) pr[I] += (D);
-#define DC_PROBE_WAIT asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#else
-#define DC_T(V)
-#define DC_ACC(I, D)
-#define DC_PROBE_WAIT
-#endif
-#ifndef DC_PIPE_ON
-#define DC_PIPE_ON 1
-#endif
-#ifndef DC_PIPE4_ON
-#define DC_PIPE4_ON 1
-#endif
-#define DC_P4_MAX_TILES 256                       /* launches of at most this many tiles take the one-workgroup-per-CU form */
-#define DC_TR 8
-#define DC_TW 32
-#define DC_HW (DC_TW + 2)
-#define DC_HP ((DC_TR + 2) * DC_HW)          // 340 halo pixels
-#define DC_CK 16                             // input channels per chunk
-#define DC_ROWB 48                           // bytes per LDS row (16 bf16 + pad)
-#define DC_NA ((DC_HP * 4 + 255) / 256)      // float4 pieces per thread and chunk (6)
-
-// NP = 3: three bf16 planes, six partial products (any fp32 input). NP = 2: two fp16 planes of the scaled operands, three
-// partial products (see h2_split2); `amax` then points to {bits of max finite |x|, bits of max finite |w|}.
-// MT: image rows (32-pixel M tiles) per wave; a workgroup has TR / MT waves. Shipped: MT = 2. (MT = 4 with 16-row tiles
-// and four waves at 64 output channels - 0.5 instead of 0.67 LDS fragment reads per MFMA on two fp16 planes - needs 50
-// spilled registers next to its 128 accumulators: 368 instead of 297 us per 64 -> 64 call incl. its absmax pass.
-// Also measured on the two-plane 64-channel form, each within 1 % of the shipped 0.206 ms: three waves per SIMD (168
-// registers, 18 spilled); a second fragment set read one tap ahead of the MFMAs; the next halo requested after stage 0's
-// weight load instead of before it. LDS reads deliver 174 B/clk/CU with this access pattern
-// (tools_dev/micro/lds_bw.hip); the kernel uses about half of that. A separate kernel that staged the weights of a whole
-// kernel row per barrier (36 MFMAs and one barrier per row stage instead of 12 and one per tap, weights requested a full
-// row stage ahead) measured 0.219 against 0.209 ms on the same box, alternating runs. -DDC_PROBE builds the cycle
-// accounting that tools_dev/probe_dense_stage.py prints.)
-// Backward-data launches whose result is the gradient of a BatchNorm + ReLU output z = relu(bn(y)) take the reduce pass
-// of that BatchNorm's backward into their epilogue: the tile is masked by the ReLU (recomputed from y, gamma, beta and
-// the saved statistics exactly as the forward pass computed it: gga_bn_scale_shift) before it is stored, and the tile's
-// per-channel sums of g and g * xhat go to `stats` in the layout of the forward statistics. y: the BatchNorm's input,
-// channel block of this launch, pixel stride ystride floats; gamma / beta / mean / invstd: of that channel block.
-struct DcBnBwd {
-    const float* y;
-    const float* gamma;
-    const float* beta;
-    const float* mean;
-    const float* invstd;
-    int ystride;
-};
-
-// Several images of different sizes in ONE launch (gga_dense_conv3x3_levels: the tower convolutions of an FPN head share
-// their weights over the levels, and all but the largest level are too small to fill the chip - 12 x 24 x 78 is 108
-// tiles, 12 x 3 x 10 is 12): entry e owns the tiles [start[e], start[e + 1]) of the grid and brings its own input,
-// output, size, absmax and (for output slices) weight operand. n = 0: the kernel's scalar arguments describe the one image.
-#define DC_MAX_ENTRIES 16
-struct DcLevels {
-    int n;
-    int start[DC_MAX_ENTRIES + 1];
-    int H[DC_MAX_ENTRIES], W[DC_MAX_ENTRIES];
-    const float* x[DC_MAX_ENTRIES];
-    float* y[DC_MAX_ENTRIES];
-    const uint16_t* w[DC_MAX_ENTRIES];
-    const uint32_t* amax_x[DC_MAX_ENTRIES];
-    const float* bias[DC_MAX_ENTRIES];       // per output channel of the entry, added in the epilogue; null: none
-    double* stats[DC_MAX_ENTRIES];           // the entry's per-tile BatchNorm sums [tiles][2][cout]; null: none
-    int transposed;                          // every entry walks its map transposed (tiles 32 pixels long along the image's H)
-};
-
-// (P4 form, round 3: 128 output channels in 8-row tiles on two fp16 planes with ONE workgroup per CU, so that its four waves, one
-// per SIMD, have 512 registers each: room for the 128 accumulators AND two sets of the 12 fragments of a stage, see PIPE below.
-// Measured against the two-workgroups-per-CU form of the same tile: launches of at most one tile per CU - the small FPN levels
-// of the camera-only head, 62 x 54 maps - 69 against 83 us and 63 against 77; launches with more tiles than CUs 265 against 248
-// and 217 against 202, where the second workgroup hides more than the pipelining wins. The launcher picks by tile count.)
-template <int NT, int TR, int NP, int MT, int P4 = 0>
-__global__ __launch_bounds__(TR / MT * 64, (P4 && NT == 4 && NP == 2) ? 1 : 2) void dense_conv3x3_x9_kernel(const float* __restrict__ X, const uint16_t* __restrict__ Wp,
-                                                                 int B, int H, int W, int cin, int cout, int tiles_x,
-                                                                 int tiles_y, float* __restrict__ Y, int ystride,
-                                                                 int prow, int pcol, double* __restrict__ stats,
-                                                                 const uint32_t* __restrict__ amax_x,
-                                                                 const uint32_t* __restrict__ amax_w, DcBnBwd bn,
-                                                                 DcLevels lv) {
-    int tile = blockIdx.x;
-    const float* bias = nullptr;
-    if (lv.n) {                                          // which image this workgroup's tile belongs to (wave-uniform)
-        int e = 0;
-        while (e + 1 < lv.n && tile >= lv.start[e + 1]) ++e;
-        tile -= lv.start[e];
-        X = lv.x[e]; Y = lv.y[e]; Wp = lv.w[e]; amax_x = lv.amax_x[e]; bias = lv.bias[e]; stats = lv.stats[e];
-        H = lv.H[e]; W = lv.W[e];
-        prow = W; pcol = 1;
-        if (lv.transposed) { prow = 1; pcol = W; const int t_ = H; H = W; W = t_; }      // tile space of the transposed walk
-        tiles_x = (W + DC_TW - 1) / DC_TW; tiles_y = (H + TR - 1) / TR;
-    }
-    // H x W is the tile space (rows x 32-pixel columns); pixel (r, c) of it is pixel r*prow + c*pcol of
-    // the image: (W, 1) for the image as stored, (1, image width) with H and W swapped for the
-    // transposed walk (tiles 32 pixels long along the image's H), chosen by the caller per shape.
-    // TR = 8: 256 threads own 8 rows x 32 pixels (64 output channels: two workgroups per CU; 128: one).
-    // TR = 16 (128 output channels on maps with enough tiles): 512 threads own 16 rows - one workgroup per
-    // CU but two waves per SIMD again (124 x 108: 324 instead of 379 us); on small maps the 16-row tiles
-    // leave CUs idle (62 x 54: 523 instead of 366 us), so the launcher picks per shape.
-    constexpr int NWAVES = TR / MT, THREADS = NWAVES * 64;
-    constexpr int HP = (TR + 2) * DC_HW, NA = (HP * 4 + THREADS - 1) / THREADS;
-    constexpr int CO = NT * 32;
-    constexpr int BPL = CO * DC_ROWB, BSZ = NP * BPL, BPIECES = NP * CO * 2;
-    constexpr int NB = (BPIECES + THREADS - 1) / THREADS;
-    constexpr int APL = HP * DC_ROWB;
-    __shared__ __attribute__((aligned(16))) unsigned char As[NP * APL];
-    __shared__ __attribute__((aligned(16))) unsigned char Bs[3 * BSZ];
-    int sbx = 127, sbw = 127;
-    if (NP == 2) { sbx = h2_scale_exp(*amax_x); sbw = h2_scale_exp(*amax_w); }
-    const float xscale = h2_scale(sbx);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 31, h = lane >> 5;
-    const int per_img = tiles_x * tiles_y;
-    const int n_tiles = B * per_img;
-    const int nchunks = cin / DC_CK;                  // 16-channel chunks
-    const int nchunks32 = cin / MF_TK;                // chunks of the packed weight layout
-    mf_v16 acc[MT][NT];
-
-    // halo piece e of this thread: pixel (tid + 256 e) / 4, channels 4 * ((tid + 256 e) % 4) .. +3 of the chunk
-    float4 ra[NA];
-    int aoff[NA];                              // float offset of the piece in its image, -1: outside (zeros)
-    const float* Xb = X;
-#define DC_TILE(T, TB, TY0, TX0) const int TB = (T) / per_img; const int TY0 = (((T) - TB * per_img) / tiles_x) * TR, TX0 = (((T) - TB * per_img) % tiles_x) * DC_TW;
-#define DC_AOFF(TB, TY0, TX0) {                                                                                       \
-        Xb = X + (int64_t)(TB) * H * W * cin;                                                                         \
-        _Pragma("unroll") for (int e = 0; e < NA; ++e) {                                                           \
-            const int f = tid + THREADS * e;                                                                              \
-            const int hp = f >> 2, q = f & 3;                                                                         \
-            const int hr = hp / DC_HW, hx = hp - hr * DC_HW;                                                          \
-            const int iy = (TY0) + hr - 1, ix = (TX0) + hx - 1;                                                       \
-            const bool ok = hp < HP && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;                   \
-            aoff[e] = ok ? (iy * prow + ix * pcol) * cin + q * 4 : -1;                                                          \
-        } }
-#define DC_LOAD_A(CH) _Pragma("unroll") for (int e = 0; e < NA; ++e) ra[e] = *reinterpret_cast<const float4*>(Xb + (aoff[e] >= 0 ? aoff[e] : 0) + (CH) * DC_CK);
-#define DC_STORE_A()                                                                                                  \
-    _Pragma("unroll") for (int e = 0; e < NA; ++e) {                                                               \
-        const int f = tid + THREADS * e;                                                                                  \
-        if (f < HP * 4) {                                                                                          \
-            const float4 v = aoff[e] >= 0 ? ra[e] : make_float4(0.f, 0.f, 0.f, 0.f);                                   \
-            unsigned char* dst = As + (f >> 2) * DC_ROWB + (f & 3) * 8;                                               \
-            if (NP == 3) {                                                                                            \
-                uint32_t lo1, lo2, lo3, hi1, hi2, hi3;                                                                \
-                x9_split2(v.x, v.y, lo1, lo2, lo3); x9_split2(v.z, v.w, hi1, hi2, hi3);                               \
-                *reinterpret_cast<uint2*>(dst) = make_uint2(lo1, hi1);                                                \
-                *reinterpret_cast<uint2*>(dst + APL) = make_uint2(lo2, hi2);                                          \
-                *reinterpret_cast<uint2*>(dst + (NP - 1) * APL) = make_uint2(lo3, hi3);                               \
-            } else {                                                                                                  \
-                uint32_t lo1, lo2, hi1, hi2;                                                                          \
-                h2_split2(v.x * xscale, v.y * xscale, lo1, lo2); h2_split2(v.z * xscale, v.w * xscale, hi1, hi2);     \
-                *reinterpret_cast<uint2*>(dst) = make_uint2(lo1, hi1);                                                \
-                *reinterpret_cast<uint2*>(dst + APL) = make_uint2(lo2, hi2);                                          \
-            }                                                                                                         \
-        }                                                                                                             \
-    }
-    // weight stage (tap, 16-channel chunk c): piece f = (plane, column, 16-byte half) of the 32-byte half row.
-    // Two register sets (named registers: an indexed array ends up in scratch): the weights of stage s + 3 are
-    // requested at the start of stage s and written to LDS at the end of stage s + 1, so a load has two stages
-    // (~1.5 us with two waves per SIMD) to come back from the L2 - with one stage the per-stage s_waitcnt was the
-    // largest single loss of the kernel (ablation: 375 -> 303 us at 64 -> 64 without the loads).
-    // (the 512-thread form is limited to 256 registers by its two waves per SIMD and keeps one set on three bf16 planes;
-    // on two fp16 planes both sets fit: 253 -> 240 us at 128 -> 128, 16 x 124 x 108.)
-    constexpr bool DEEP = (NP == 2 || !(NT == 4 && TR == 16)) && MT == 2;
-    uint4 bq0, bq1, bq2, cq0, cq1, cq2;
-    bq0 = bq1 = bq2 = cq0 = cq1 = cq2 = make_uint4(0, 0, 0, 0);
-    // the packed stage (tap, 16-channel chunk) is contiguous and in LDS piece order (dense_pack_weight_kernel): a wave
-    // load covers 1 KB of whole cache lines (the half-row layout of the sparse kernels touched 32 half-used lines per
-    // load and kept the address unit busy for most of a stage)
-#define DC_BLD(E, V) if ((E) < NB) { const int f = min(tid + THREADS * (E), BPIECES - 1); V = bsrc[f]; }
-#define DC_LOAD_B(TAP, CH, V0, V1, V2) {                                                                              \
-        const uint4* bsrc = reinterpret_cast<const uint4*>(Wp + ((int64_t)(TAP) * nchunks + (CH)) * (NP * CO * DC_CK)); \
-        DC_BLD(0, V0) DC_BLD(1, V1) DC_BLD(2, V2) }
-#define DC_BST(BUF, E, V) if ((E) < NB) { const int f = tid + THREADS * (E); if (f < BPIECES) *reinterpret_cast<uint4*>(Bs + (BUF) * BSZ + (f >> 1) * DC_ROWB + (f & 1) * 16) = V; }
-#define DC_STORE_B(BUF, V0, V1, V2) { DC_BST(BUF, 0, V0) DC_BST(BUF, 1, V1) DC_BST(BUF, 2, V2) }
-    static_assert(NB <= 3, "weight stage pieces per thread");
-
-    // Stage (chunk, tap): fragments from LDS, 36 MFMAs, and meanwhile the weights of the stage
-    // after next travel global -> registers -> LDS (three weight buffers; stage chunk*9 + tap lives
-    // in buffer tap % 3 because 9 % 3 == 0); one barrier per stage. The nine taps are unrolled, so
-    // tap offsets and buffer numbers are immediates.
-    // fragments: the two M tiles' A planes, and the B planes of TWO N tiles at a time (with four N tiles all
-    // twelve B fragments alive next to 128 accumulator registers do not fit 256 registers)
-    // Round 3 (PIPE, the forms with two N tiles = 64 output channels): a second fragment set; stage s multiplies the set
-    // that stage s - 1 read for it and reads the next stage's set between its own MFMAs (sched_group_barrier pins the
-    // interleave: left alone the scheduler sinks every read to just before its use, which is what the round-2 attempt at
-    // this measured). The weights of stage s + 1 are in LDS since the barrier before stage s (they are written a stage
-    // early), the halo image is constant over a chunk; the first offset of a chunk reads its own fragments.
-    constexpr bool PIPE = DC_PIPE_ON && NT == 2 && MT == 2 && NP == 2;       // (three planes: the second set spills)
-    constexpr bool PIPE4 = P4 && NT == 4 && NP == 2;        // (MT = 2: 8-row tiles; MT = 4: 16-row tiles, four image rows per wave)
-    mf_v8bf fa[MT][NP], fb[2][NP];
-    mf_v8bf ga[MT][NP], gb[2][NP];
-    mf_v8bf fb2[2][NP], gb2[2][NP];                      // PIPE4: the B fragments of N tiles 2 and 3
-#define DC_READ_A_(FA, TAP) {                                                                                         \
-        const unsigned char* Ap = As + ((MT * wave + (TAP) / 3) * DC_HW + r + (TAP) % 3) * DC_ROWB + h * 16;           \
-        _Pragma("unroll") for (int m = 0; m < MT; ++m) _Pragma("unroll") for (int p = 0; p < NP; ++p)                 \
-            FA[m][p] = *reinterpret_cast<const mf_v8bf*>(Ap + p * APL + m * DC_HW * DC_ROWB); }
-#define DC_READ_B_(FB, TAP, T0) {                                                                                     \
-        const unsigned char* Bp = Bs + ((TAP) % 3) * BSZ + r * DC_ROWB + h * 16 + (T0) * 32 * DC_ROWB;                \
-        _Pragma("unroll") for (int t = 0; t < 2; ++t) _Pragma("unroll") for (int p = 0; p < NP; ++p)                  \
-            FB[t][p] = *reinterpret_cast<const mf_v8bf*>(Bp + p * BPL + t * 32 * DC_ROWB); }
-#define DC_READ_A(TAP) DC_READ_A_(fa, TAP)
-#define DC_READ_B(TAP, T0) DC_READ_B_(fb, TAP, T0)
-    // partial products smallest first; tiles innermost so consecutive MFMAs never share an accumulator
-#define DC_MM1_(FA, FB, T0, PA, PB) _Pragma("unroll") for (int m = 0; m < MT; ++m) _Pragma("unroll") for (int t = 0; t < 2; ++t) acc[m][(T0) + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[m][PA], FB[t][PB], acc[m][(T0) + t], 0, 0, 0);
-#define DC_MH1_(FA, FB, T0, PA, PB) _Pragma("unroll") for (int m = 0; m < MT; ++m) _Pragma("unroll") for (int t = 0; t < 2; ++t) acc[m][(T0) + t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(mf_v8h, FA[m][PA]), __builtin_bit_cast(mf_v8h, FB[t][PB]), acc[m][(T0) + t], 0, 0, 0);
-#ifdef X9_SIX
-#define DC_MMA3_(FA, FB, T0) DC_MM1_(FA, FB, T0, 0, NP - 1) DC_MM1_(FA, FB, T0, 1, 1) DC_MM1_(FA, FB, T0, NP - 1, 0) DC_MM1_(FA, FB, T0, 0, 1) DC_MM1_(FA, FB, T0, 1, 0) DC_MM1_(FA, FB, T0, 0, 0)
-#else
-#define DC_MMA3_(FA, FB, T0) DC_MM1_(FA, FB, T0, NP - 1, NP - 1) DC_MM1_(FA, FB, T0, 1, NP - 1) DC_MM1_(FA, FB, T0, NP - 1, 1) DC_MM1_(FA, FB, T0, 0, NP - 1) DC_MM1_(FA, FB, T0, 1, 1) DC_MM1_(FA, FB, T0, NP - 1, 0) DC_MM1_(FA, FB, T0, 0, 1) DC_MM1_(FA, FB, T0, 1, 0) DC_MM1_(FA, FB, T0, 0, 0)
-#endif
-#define DC_MMA_(FA, FB, T0) { if (NP == 3) { DC_MMA3_(FA, FB, T0) } else { DC_MH1_(FA, FB, T0, 0, 1) DC_MH1_(FA, FB, T0, 1, 0) DC_MH1_(FA, FB, T0, 0, 0) } }
-#define DC_MMA(T0) DC_MMA_(fa, fb, T0)
-    // groups of (MFMAs, LDS reads) of a pipelined stage: 12 MFMAs and 8 reads on two planes, 24 and 12 on three
-    constexpr int PG = NP == 2 ? 4 : 12, PG_M = NP == 2 ? 3 : 2, PG_R = NP == 2 ? 2 : 1;
-
-    // Persistent workgroups: tiles blockIdx.x, blockIdx.x + gridDim.x, ... as one uninterrupted
-    // stream of stages - the halo of the next tile's first chunk is requested during the last
-    // chunk of the current tile, the weight stages wrap around, and the output stores of a tile
-    // drain while the next tile computes.
-    // Measured at [16,64,248,216] -> 64 (63 GFLOP): 0.416 ms = 152 TFLOP/s-equivalent (MIOpen fp32:
-    // 0.62 ms forward, 0.54 ms backward-data). With the fragment reads, the halo staging, the
-    // weight copies and the barriers compiled out the MFMA stream alone takes 0.363 ms, so the
-    // kernel is within 15 % of what its MFMA issue pattern delivers here; reading the next tap's
-    // fragments ahead of the MFMAs (two register sets), one tile per workgroup instead of persistent
-    // ones, and dropping the per-stage barrier all measured 0.414-0.420 ms.
-#ifdef DC_PROBE
-    long long pr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const long long tstart_ = __builtin_readcyclecounter();
-#endif
-    if (tile >= n_tiles) return;
-    {
-        DC_TILE(tile, tb, ty0, tx0)
-        DC_AOFF(tb, ty0, tx0)
-    }
-    DC_LOAD_A(0);
-    DC_LOAD_B(0, 0, bq0, bq1, bq2);
-    DC_LOAD_B(1, 0, cq0, cq1, cq2);
-    DC_STORE_A();
-    DC_STORE_B(0, bq0, bq1, bq2);
-    DC_STORE_B(1, cq0, cq1, cq2);
-    if (DEEP) { DC_LOAD_B(2, 0, bq0, bq1, bq2); }     // stage 2: written to LDS at the end of stage 0
-    __syncthreads();
-    bool first = true;
-    for (; tile < n_tiles; tile += gridDim.x) {
-        DC_TILE(tile, b, y0, x0)
-        const bool more_tiles = tile + (int)gridDim.x < n_tiles;
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc[m][t][i] = 0.0f;
-        // stage s = chunk * 9 + tap loads the weights of stage s + 3 into register set (s + 1) % 2 and writes those of
-        // stage s + 2 from set s % 2 into LDS buffer (s + 2) % 3; chunks come in pairs so that the set of every
-        // stage is fixed at compile time (nchunks is even: cin % 32 == 0)
-#define DC_CHUNK_HEAD(CH)                                                                                             \
-            if (!first) {                              /* every wave passed the barrier of the previous stage */      \
-                DC_T(tg_)                                                                                             \
-                DC_STORE_A();                                                                                         \
-                DC_T(th_)                                                                                             \
-                __syncthreads();                                                                                      \
-                DC_T(ti_)                                                                                             \
-                DC_ACC(5, th_ - tg_) DC_ACC(6, ti_ - th_)                                                             \
-            }                                                                                                         \
-            first = false;                                                                                            \
-            if ((CH) + 1 < nchunks) { DC_LOAD_A((CH) + 1); }                                                          \
-            else if (more_tiles) {                     /* first chunk of the next tile */                             \
-                DC_TILE(tile + (int)gridDim.x, nb_, ny0, nx0)                                                         \
-                DC_AOFF(nb_, ny0, nx0)                                                                                \
-                DC_LOAD_A(0);                                                                                         \
-            }
-#define DC_STAGE(TAP, CH, L0, L1, L2, S0, S1, S2, CA, CB, XA, XB, CB2, XB2) {                                         \
-            const bool last_chunk = (CH) + 1 >= nchunks;                                                              \
-            const bool more3 = (TAP) + 3 < 9 || !last_chunk || more_tiles;     /* a stage three ahead exists */       \
-            const bool more2 = (TAP) + 2 < 9 || !last_chunk || more_tiles;                                            \
-            if (DEEP) {                                                                                               \
-                if (more3) {                                                                                          \
-                    if ((TAP) + 3 < 9) { DC_LOAD_B((TAP) + 3, (CH), L0, L1, L2); }                                    \
-                    else { DC_LOAD_B((TAP) + 3 - 9, last_chunk ? 0 : (CH) + 1, L0, L1, L2); }                         \
-                }                                                                                                     \
-            } else if (more2) {       /* one register set: stage s + 2 requested now, written at the end of this stage */ \
-                if ((TAP) + 2 < 9) { DC_LOAD_B((TAP) + 2, (CH), bq0, bq1, bq2); }                                     \
-                else { DC_LOAD_B((TAP) + 2 - 9, last_chunk ? 0 : (CH) + 1, bq0, bq1, bq2); }                          \
-            }                                                                                                         \
-            DC_T(ta_)                                                                                                 \
-            if (PIPE4) {                                                                                              \
-                if ((TAP) == 0) { DC_READ_A_(CA, 0); DC_READ_B_(CB, 0, 0); DC_READ_B_(CB2, 0, 2); }                    \
-                if ((TAP) < 8) { DC_READ_A_(XA, (TAP) + 1); DC_READ_B_(XB, (TAP) + 1, 0); DC_READ_B_(XB2, (TAP) + 1, 2); } \
-                DC_MMA_(CA, CB, 0)                                                                                    \
-                DC_MMA_(CA, CB2, 2)                                                                                   \
-                if ((TAP) < 8) {      /* MT * 12 MFMAs, 2 MT + 8 reads: 2 : 1 at MT = 2, 3 : 1 at MT = 4 */                \
-                    _Pragma("unroll") for (int g_ = 0; g_ < 2 * MT + 8; ++g_) {                                       \
-                        __builtin_amdgcn_sched_group_barrier(0x008, MT == 4 ? 3 : 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); } \
-                }                                                                                                     \
-            } else if (PIPE) {                                                                                        \
-                if ((TAP) == 0) { DC_READ_A_(CA, 0); DC_READ_B_(CB, 0, 0); }                                           \
-                if ((TAP) < 8) { DC_READ_A_(XA, (TAP) + 1); DC_READ_B_(XB, (TAP) + 1, 0); }                            \
-                DC_MMA_(CA, CB, 0)                                                                                    \
-                if ((TAP) < 8) {                                                                                      \
-                    _Pragma("unroll") for (int g_ = 0; g_ < PG; ++g_) {                                               \
-                        __builtin_amdgcn_sched_group_barrier(0x008, PG_M, 0); __builtin_amdgcn_sched_group_barrier(0x100, PG_R, 0); } \
-                }                                                                                                     \
-            } else {                                                                                                  \
-            DC_READ_A(TAP);                                                                                           \
-            _Pragma("unroll") for (int t0 = 0; t0 < NT; t0 += 2) {                                                    \
-                DC_READ_B(TAP, t0);                                                                                   \
-                DC_PROBE_WAIT                                                                                         \
-                DC_T(tb_)                                                                                             \
-                DC_MMA(t0)                                                                                            \
-                DC_T(tc_)                                                                                             \
-                DC_ACC(0, tb_ - ta_) DC_ACC(1, tc_ - tb_)                                                             \
-            } }                                                                                                       \
-            DC_T(td_)                                                                                                 \
-            if (more2) { if (DEEP) { DC_STORE_B(((TAP) + 2) % 3, S0, S1, S2); } else { DC_STORE_B(((TAP) + 2) % 3, bq0, bq1, bq2); } } \
-            DC_T(te_)                                                                                                 \
-            __syncthreads();                                                                                          \
-            DC_T(tf_)                                                                                                 \
-            DC_ACC(2, te_ - td_) DC_ACC(3, tf_ - te_) DC_ACC(4, 1) }
-#define DC_EVEN(TAP, CH) DC_STAGE(TAP, CH, cq0, cq1, cq2, bq0, bq1, bq2, fa, fb, ga, gb, fb2, gb2)      /* even stage: load set 1, store set 0 */
-#define DC_ODD(TAP, CH) DC_STAGE(TAP, CH, bq0, bq1, bq2, cq0, cq1, cq2, ga, gb, fa, fb, gb2, fb2)
-        for (int ch = 0; ch < nchunks; ch += 2) {
-            DC_CHUNK_HEAD(ch)
-            DC_EVEN(0, ch) DC_ODD(1, ch) DC_EVEN(2, ch) DC_ODD(3, ch) DC_EVEN(4, ch) DC_ODD(5, ch) DC_EVEN(6, ch) DC_ODD(7, ch) DC_EVEN(8, ch)
-            DC_CHUNK_HEAD(ch + 1)
-            DC_ODD(0, ch + 1) DC_EVEN(1, ch + 1) DC_ODD(2, ch + 1) DC_EVEN(3, ch + 1) DC_ODD(4, ch + 1) DC_EVEN(5, ch + 1) DC_ODD(6, ch + 1) DC_EVEN(7, ch + 1) DC_ODD(8, ch + 1)
-        }
-#undef DC_CHUNK_HEAD
-#undef DC_STAGE
-#undef DC_EVEN
-#undef DC_ODD
-        {
-            // back from the scaled operands (two exact powers of two), and the bias of the lane's output channels
-            const float dx = NP == 2 ? h2_descale(sbx) : 1.0f, dw = NP == 2 ? h2_descale(sbw) : 1.0f;
-            float bv[NT];
-#pragma unroll
-            for (int t = 0; t < NT; ++t) bv[t] = bias ? bias[t * 32 + r] : 0.0f;
-            if (NP == 2 || bias) {
-#pragma unroll
-                for (int m = 0; m < MT; ++m)
-#pragma unroll
-                    for (int t = 0; t < NT; ++t)
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) acc[m][t][i] = acc[m][t][i] * dx * dw + bv[t];
-            }
-        }
-        // D layout of 32x32x16: register v of lane l holds row (v/4)*8 + (l/32)*4 + v%4 (= pixel of the M tile's row), column l%32
-        float s1[NT], s2[NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) { s1[t] = 0.0f; s2[t] = 0.0f; }
-        if (bn.y) {                                        // see DcBnBwd: ReLU mask and the BatchNorm backward sums
-            float bsc[NT], bsh[NT], bmu[NT], biv[NT];
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const int c = t * 32 + r;
-                bmu[t] = bn.mean[c]; biv[t] = bn.invstd[c];
-                gga_bn_scale_shift(bn.gamma ? bn.gamma[c] : 1.0f, bn.beta ? bn.beta[c] : 0.0f, bmu[t], biv[t], bsc[t], bsh[t]);
-            }
-            // 32 values of y per lane are requested before the first of them is used (a load per store serialises on
-            // the memory latency: + 110 .. 250 us per launch)
-            constexpr int VB = 32 / NT;
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                const int oy = y0 + MT * wave + m;
-                if (oy >= H) continue;
-#pragma unroll
-                for (int v0 = 0; v0 < 16; v0 += VB) {
-                    float yv[VB][NT];
-#pragma unroll
-                    for (int j = 0; j < VB; ++j) {
-                        const int ox = x0 + ((v0 + j) >> 2) * 8 + h * 4 + ((v0 + j) & 3);
-                        const float* src = bn.y + ((int64_t)b * H * W + oy * prow + (ox < W ? ox : W - 1) * pcol) * bn.ystride;
-#pragma unroll
-                        for (int t = 0; t < NT; ++t) yv[j][t] = src[t * 32 + r];
-                    }
-#pragma unroll
-                    for (int j = 0; j < VB; ++j) {
-                        const int ox = x0 + ((v0 + j) >> 2) * 8 + h * 4 + ((v0 + j) & 3);
-                        if (ox >= W) continue;
-                        float* dst = Y + ((int64_t)b * H * W + oy * prow + ox * pcol) * ystride;
-#pragma unroll
-                        for (int t = 0; t < NT; ++t) {
-                            const float g = fmaf(yv[j][t], bsc[t], bsh[t]) > 0.0f ? acc[m][t][v0 + j] : 0.0f;
-                            dst[t * 32 + r] = g;
-                            s1[t] += g; s2[t] += g * ((yv[j][t] - bmu[t]) * biv[t]);
-                        }
-                    }
-                }
-            }
-        } else
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            const int oy = y0 + MT * wave + m;
-            if (oy >= H) continue;
-#pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                const int ox = x0 + (v >> 2) * 8 + h * 4 + (v & 3);
-                if (ox >= W) continue;
-                float* dst = Y + ((int64_t)b * H * W + oy * prow + ox * pcol) * ystride;       // ystride > cout: a channel slice of a wider tensor
-#pragma unroll
-                for (int t = 0; t < NT; ++t) dst[t * 32 + r] = acc[m][t][v];
-            }
-        }
-        if (stats) {
-            // per-channel sum and sum of squares of the tile's outputs (the batch statistics of the
-            // BatchNorm that follows, so it need not read y again): lane sums over its pixels, the
-            // two half waves and the four waves are folded through LDS, one f64 row pair per tile.
-            if (!bn.y)
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                const bool rowok = y0 + MT * wave + m < H;
-#pragma unroll
-                for (int v = 0; v < 16; ++v) {
-                    const bool ok = rowok && x0 + (v >> 2) * 8 + h * 4 + (v & 3) < W;
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) {
-                        const float a = ok ? acc[m][t][v] : 0.0f;
-                        s1[t] += a; s2[t] += a * a;
-                    }
-                }
-            }
-            float* red = reinterpret_cast<float*>(As);       // free: the last stage ended with a barrier
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                s1[t] += __shfl_xor(s1[t], 32);
-                s2[t] += __shfl_xor(s2[t], 32);
-                if (h == 0) { red[(wave * 2 + 0) * CO + t * 32 + r] = s1[t]; red[(wave * 2 + 1) * CO + t * 32 + r] = s2[t]; }
-            }
-            __syncthreads();
-            if (tid < 2 * CO) {
-                const int which = tid / CO, c = tid - which * CO;
-                if (c < cout) {
-                    double a = 0.0;
-#pragma unroll
-                    for (int w_ = 0; w_ < NWAVES; ++w_) a += (double)red[(w_ * 2 + which) * CO + c];
-                    stats[((int64_t)tile * 2 + which) * cout + c] = a;
-                }
-            }
-            __syncthreads();                                  // red is the next tile's halo buffer
-        }
-    }
-#ifdef DC_PROBE
-    if (wave == 0 && lane == 0) {
-        pr[7] = __builtin_readcyclecounter() - tstart_;
-        for (int i = 0; i < 8; ++i) atomicAdd(&dc_probe[i], (unsigned long long)pr[i]);
-    }
-#endif
-#undef DC_READ_A
-#undef DC_READ_B
-#undef DC_READ_A_
-#undef DC_READ_B_
-#undef DC_MM1_
-#undef DC_MH1_
-#undef DC_MMA3_
-#undef DC_MMA_
-#undef DC_MMA
-#undef DC_LOAD_A
-#undef DC_STORE_A
-#undef DC_LOAD_B
-#undef DC_STORE_B
-#undef DC_BLD
-#undef DC_BST
-#undef DC_TILE
-#undef DC_AOFF
-}
-
-// Packs a 3x3 convolution weight straight from the framework tensor (any strides, e.g. the
-// channels-last memory of a [cout, cin, 3, 3] parameter) into the split layout of
-// gga_sparse_pack_weight_split with kvol = 9; `backward` builds the operand of the backward-data
-// convolution instead (taps reversed, channel roles swapped). One thread per (tap, chunk, col, ch).
-__global__ __launch_bounds__(256) void dense_pack_weight_kernel(const float* __restrict__ W, int64_t s_co, int64_t s_ci,
-                                                               int64_t s_ky, int64_t s_kx, int cin, int cout,
-                                                               int backward, int nt, int64_t total, int np,
-                                                               const uint32_t* __restrict__ amax_w,
-                                                               uint16_t* __restrict__ P) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total) return;
-    const int n_in = backward ? cout : cin, n_out = backward ? cin : cout;      // channels of the convolution being run
-    const int co = 32 * nt, nchunks = (n_in + MF_TK - 1) / MF_TK;
-    const int ch = (int)(i & 31);
-    const int col = (int)((i >> 5) % co);
-    const int64_t stage = (i >> 5) / co;                                        // (tap, 32-channel chunk)
-    const int tap = (int)(stage / nchunks), chunk = (int)(stage - (int64_t)tap * nchunks);
-    const int c = chunk * MF_TK + ch;
-    float v = 0.0f;
-    if (c < n_in && col < n_out) {
-        const int t = backward ? 8 - tap : tap;
-        const int ky = t / 3, kx = t - ky * 3;
-        const int wco = backward ? c : col, wci = backward ? col : c;
-        v = W[wco * s_co + wci * s_ci + ky * s_ky + kx * s_kx];
-    }
-    // dense layout: [tap][16-channel chunk][plane][column][16 channels] - one contiguous block per kernel stage,
-    // in the order the kernel's threads copy it to LDS
-    const int64_t stage16 = (int64_t)tap * (2 * nchunks) + (c >> 4);
-    uint16_t* dst = P + stage16 * (np * (int64_t)co * 16) + (int64_t)col * 16 + (c & 15);
-    if (np == 3) {
-        uint32_t p1, p2, p3;
-        x9_split(v, p1, p2, p3);
-        dst[0] = (uint16_t)p1; dst[(int64_t)co * 16] = (uint16_t)p2; dst[2 * (int64_t)co * 16] = (uint16_t)p3;
-    } else {                                  // two fp16 planes of the scaled weight (h2_split2)
-        uint32_t w0, w1;
-        h2_split2(v * h2_scale(h2_scale_exp(*amax_w)), 0.0f, w0, w1);
-        dst[0] = (uint16_t)(w0 & 0xFFFFu); dst[(int64_t)co * 16] = (uint16_t)(w1 & 0xFFFFu);
-    }
-}
-
-extern "C" int gga_dense_conv3x3_pack(const float* weight, int64_t stride_co, int64_t stride_ci, int64_t stride_ky,
-                                      int64_t stride_kx, int cin, int cout, int backward, void* packed, void* stream) {
-    return gga_dense_conv3x3_pack_planes(weight, stride_co, stride_ci, stride_ky, stride_kx, cin, cout, backward, 3, nullptr,
-                                         packed, stream);
-}
-
-extern "C" int gga_dense_conv3x3_pack_planes(const float* weight, int64_t stride_co, int64_t stride_ci, int64_t stride_ky,
-                                             int64_t stride_kx, int cin, int cout, int backward, int planes,
-                                             const uint32_t* amax_weight, void* packed, void* stream) {
-    GGA_REQUIRE(weight && packed, "gga_dense_conv3x3_pack: null pointer argument");
-    GGA_REQUIRE(planes == 3 || (planes == 2 && amax_weight), "gga_dense_conv3x3_pack: planes must be 3 (bf16) or 2 (fp16, with amax_weight)");
-    const int n_in = backward ? cout : cin, n_out = backward ? cin : cout;
-    GGA_REQUIRE(n_in >= 1 && n_out >= 1 && n_out <= 128, "gga_dense_conv3x3_pack: bad sizes (%d -> %d)", n_in, n_out);
-    const int64_t total = (int64_t)(gga_sparse_split_weight_bytes(9, n_in, n_out) / (3 * sizeof(uint16_t)));
-    hipLaunchKernelGGL(dense_pack_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       weight, stride_co, stride_ci, stride_ky, stride_kx, cin, cout, backward, mf_nt(n_out), total, planes,
-                       amax_weight, (uint16_t*)packed);
-    GGA_CHECK_LAUNCH("dense_pack_weight_kernel");
-    return GGA_OK;
-}
-
-// rows per tile: 16 only for 128 output channels and when that still gives every CU a workgroup or two
-static inline int dc_tile_rows(int B, int H, int W, int cout) {
-    if (cout != 128) return 8;
-    static const int forced = getenv("GGA_DC_TILE_ROWS") ? atoi(getenv("GGA_DC_TILE_ROWS")) : 0;      // A/B switch: 8 or 16
-    if (forced == 8 || forced == 16) return forced;
-    const int64_t t16 = (int64_t)B * ((W + DC_TW - 1) / DC_TW) * ((H + 15) / 16);
-    return t16 >= 384 ? 16 : 8;
-}
-
-extern "C" int64_t gga_dense_conv3x3_tiles(int B, int H, int W, int cout) {   // H, W of the tile space (swapped when transposed)
-    const int tr = dc_tile_rows(B, H, W, cout);
-    return (int64_t)B * ((W + DC_TW - 1) / DC_TW) * ((H + tr - 1) / tr);
-}
-
-// Whether the BatchNorm-backward epilogue (gga_dense_conv3x3_bn_bwd) is cheaper than the reduce pass it replaces. Measured
-// inside the PointPillars step (16 frames): 64 output channels (two workgroups per CU, the other one's MFMAs cover the
-// epilogue's loads) + 0 us per launch against 100 us of reduce pass; 128 channels in 16-row tiles + 25 .. 100 us against
-// 55 .. 200; 128 channels in 8-row tiles (small maps, one workgroup per CU) + 33 us against 15: not there.
-extern "C" int gga_dense_conv3x3_bn_bwd_pays(int B, int H, int W, int cout) {
-    return cout == 64 || dc_tile_rows(B, H, W, cout) == 16;
-}
-
-extern "C" int gga_dense_conv3x3_slice(const float* x, const void* split_weight, int B, int H, int W, int cin, int cout,
-                                       float* y, int64_t y_pixel_stride, int transposed, double* stats, void* stream_) {
-    return gga_dense_conv3x3_planes(x, split_weight, B, H, W, cin, cout, y, y_pixel_stride, transposed, stats, 3, nullptr, nullptr,
-                                    stream_);
-}
-
-extern "C" int gga_dense_conv3x3_planes(const float* x, const void* split_weight, int B, int H, int W, int cin, int cout,
-                                        float* y, int64_t y_pixel_stride, int transposed, double* stats, int planes,
-                                        const uint32_t* amax_x, const uint32_t* amax_weight, void* stream_) {
-    return gga_dense_conv3x3_bn_bwd(x, split_weight, B, H, W, cin, cout, y, y_pixel_stride, transposed, stats, planes, amax_x,
-                                    amax_weight, nullptr, 0, nullptr, nullptr, nullptr, nullptr, stream_);
-}
-
-extern "C" int gga_dense_conv3x3_bn_bwd(const float* x, const void* split_weight, int B, int H, int W, int cin, int cout,
-                                        float* y, int64_t y_pixel_stride, int transposed, double* stats, int planes,
-                                        const uint32_t* amax_x, const uint32_t* amax_weight, const float* bn_x,
-                                        int64_t bn_x_pixel_stride, const float* bn_gamma, const float* bn_beta,
-                                        const float* bn_mean, const float* bn_invstd, void* stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    GGA_REQUIRE(!bn_x || (stats && bn_mean && bn_invstd && bn_x_pixel_stride >= cout && bn_x_pixel_stride < 2147483647ll),
-                "gga_dense_conv3x3_bn_bwd: the BatchNorm epilogue needs stats, the saved mean / invstd and a pixel stride >= cout");
-    DcBnBwd bn;
-    bn.y = bn_x; bn.gamma = bn_gamma; bn.beta = bn_beta; bn.mean = bn_mean; bn.invstd = bn_invstd; bn.ystride = (int)bn_x_pixel_stride;
-    DcLevels lv;
-    lv.n = 0;
-    GGA_REQUIRE(x && split_weight && y, "gga_dense_conv3x3: null pointer argument");
-    GGA_REQUIRE(planes == 3 || (planes == 2 && amax_x && amax_weight),
-                "gga_dense_conv3x3: planes must be 3 (bf16) or 2 (fp16, with the operands' absmax bits)");
-    GGA_REQUIRE(y_pixel_stride >= cout && y_pixel_stride < 2147483647ll, "gga_dense_conv3x3: y pixel stride %lld < cout",
-                (long long)y_pixel_stride);
-    GGA_REQUIRE(B >= 1 && H >= 1 && W >= 1 && cin >= 32 && cin % 32 == 0 && (cout == 64 || cout == 128) &&
-                    (int64_t)H * W * cin < 2147483647ll,
-                "gga_dense_conv3x3: need cin %% 32 == 0 and cout 64 or 128 (got %d -> %d)", cin, cout);
-    const int prow = transposed ? 1 : W, pcol = transposed ? W : 1;
-    if (transposed) { const int t = H; H = W; W = t; }          // tile space of the transposed walk
-    const int trows = dc_tile_rows(B, H, W, cout);
-    const int tx = (W + DC_TW - 1) / DC_TW, ty = (H + trows - 1) / trows;
-    const int64_t n_tiles = (int64_t)B * tx * ty;
-    GGA_REQUIRE(n_tiles < 2147483647ll, "gga_dense_conv3x3: too many tiles");
-    // One tile per workgroup. The kernel also runs as persistent workgroups (grid < tiles, same speed
-    // in isolation), but inside the train step a persistent grid starts while the previous kernel's
-    // tail still occupies some CUs and the static tile split then leaves stragglers (one bench run in
-    // two measured 89.7 instead of 73.8 ms per step); the hardware dispatcher balances one-tile workgroups.
-    const bool pipe4 = DC_PIPE4_ON && planes == 2 && cout == 128 && trows == 8 && n_tiles <= DC_P4_MAX_TILES;
-    // (16-row tiles as four waves x four image rows on the same one-workgroup-per-CU form - 256 accumulators next to two fragment
-    // sets - need more than 512 registers: 123 spilled dwords, 339 against 241 us at 16 x 124 x 108; not instantiated)
-    const dim3 grid((unsigned)n_tiles), block(trows * 32);
-    hipEvent_t* tev = gga_timing_acquire(GGA_TIME_DENSE_CONV, GGA_TIMING_CONV_KEY(cin, cout, (int64_t)H * W));
-    GGA_TIME_START(tev, stream);
-#define DC_GO(NT_, TR_, NP_) hipLaunchKernelGGL((dense_conv3x3_x9_kernel<NT_, TR_, NP_, 2>), grid, block, 0, stream, x, (const uint16_t*)split_weight, B, H, W, cin, cout, tx, ty, y, (int)y_pixel_stride, prow, pcol, stats, amax_x, amax_weight, bn, lv)
-    if (planes == 3) {
-        if (cout == 64) DC_GO(2, 8, 3);
-        else if (trows == 16) DC_GO(4, 16, 3);
-        else DC_GO(4, 8, 3);
-    } else {
-        if (cout == 64) DC_GO(2, 8, 2);
-        else if (trows == 16) DC_GO(4, 16, 2);
-        else if (pipe4) hipLaunchKernelGGL((dense_conv3x3_x9_kernel<4, 8, 2, 2, 1>), grid, block, 0, stream, x, (const uint16_t*)split_weight, B, H, W, cin, cout, tx, ty, y, (int)y_pixel_stride, prow, pcol, stats, amax_x, amax_weight, bn, lv);
-        else DC_GO(4, 8, 2);
-    }
-#undef DC_GO
-    GGA_CHECK_LAUNCH("dense_conv3x3_x9_kernel");
-    GGA_TIME_STOP(tev, stream);
-    return GGA_OK;
-}
-
-extern "C" int gga_dense_conv3x3_levels(int n_entries, const float* const* x, const int32_t* heights, const int32_t* widths,
-                                        const void* const* split_weight, int B, int cin, int cout, float* const* y,
-                                        int64_t y_pixel_stride, int planes, const uint32_t* const* amax_x,
-                                        const uint32_t* amax_weight, const float* const* bias, int tile_rows, int transposed,
-                                        double* const* stats, void* stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    GGA_REQUIRE(tile_rows == 8 || (tile_rows == 16 && cout == 128), "gga_dense_conv3x3_levels: tile_rows 8, or 16 with cout 128");
-    GGA_REQUIRE(n_entries >= 1 && n_entries <= DC_MAX_ENTRIES, "gga_dense_conv3x3_levels: 1 .. %d entries (got %d)", DC_MAX_ENTRIES,
-                n_entries);
-    GGA_REQUIRE(x && heights && widths && split_weight && y, "gga_dense_conv3x3_levels: null pointer argument");
-    GGA_REQUIRE(planes == 3 || (planes == 2 && amax_x && amax_weight),
-                "gga_dense_conv3x3_levels: planes must be 3 (bf16) or 2 (fp16, with the operands' absmax bits)");
-    GGA_REQUIRE(B >= 1 && cin >= 32 && cin % 32 == 0 && (cout == 64 || cout == 128) && y_pixel_stride >= cout &&
-                    y_pixel_stride < 2147483647ll, "gga_dense_conv3x3_levels: need cin %% 32 == 0 and cout 64 or 128 (got %d -> %d)",
-                cin, cout);
-    DcLevels lv;
-    lv.n = n_entries;
-    int64_t total = 0;
-    for (int e = 0; e < n_entries; ++e) {
-        GGA_REQUIRE(x[e] && y[e] && split_weight[e] && heights[e] >= 1 && widths[e] >= 1 &&
-                        (int64_t)heights[e] * widths[e] * cin < 2147483647ll && (planes == 3 || amax_x[e]),
-                    "gga_dense_conv3x3_levels: bad entry %d", e);
-        lv.start[e] = (int)total;
-        lv.H[e] = heights[e]; lv.W[e] = widths[e];
-        lv.x[e] = x[e]; lv.y[e] = y[e]; lv.w[e] = (const uint16_t*)split_weight[e];
-        lv.amax_x[e] = planes == 2 ? amax_x[e] : nullptr;
-        lv.bias[e] = bias ? bias[e] : nullptr;
-        lv.stats[e] = stats ? stats[e] : nullptr;
-        const int th = transposed ? widths[e] : heights[e], tw = transposed ? heights[e] : widths[e];      // tile space
-        total += (int64_t)B * ((tw + DC_TW - 1) / DC_TW) * ((th + tile_rows - 1) / tile_rows);
-        GGA_REQUIRE(total < 2147483647ll, "gga_dense_conv3x3_levels: too many tiles");
-    }
-    lv.start[n_entries] = (int)total;
-    lv.transposed = transposed ? 1 : 0;
-    for (int e = n_entries + 1; e <= DC_MAX_ENTRIES; ++e) lv.start[e] = (int)total;
-    DcBnBwd bn;
-    bn.y = nullptr; bn.gamma = bn.beta = bn.mean = bn.invstd = nullptr; bn.ystride = 0;
-    const dim3 grid((unsigned)total), block(tile_rows * 32);
-#define DC_LV(NT_, TR_, NP_) hipLaunchKernelGGL((dense_conv3x3_x9_kernel<NT_, TR_, NP_, 2>), grid, block, 0, stream, x[0], (const uint16_t*)split_weight[0], B, heights[0], widths[0], cin, cout, 1, 1, y[0], (int)y_pixel_stride, widths[0], 1, (double*)nullptr, planes == 2 ? amax_x[0] : nullptr, amax_weight, bn, lv)
-    if (planes == 3) { if (cout == 64) DC_LV(2, 8, 3); else if (tile_rows == 16) DC_LV(4, 16, 3); else DC_LV(4, 8, 3); }
-    else {
-        if (cout == 64) DC_LV(2, 8, 2);
-        else if (tile_rows == 16) DC_LV(4, 16, 2);
-        else if (DC_PIPE4_ON && total <= DC_P4_MAX_TILES)
-            hipLaunchKernelGGL((dense_conv3x3_x9_kernel<4, 8, 2, 2, 1>), grid, block, 0, stream, x[0], (const uint16_t*)split_weight[0], B, heights[0], widths[0], cin, cout, 1, 1, y[0], (int)y_pixel_stride, widths[0], 1, (double*)nullptr, planes == 2 ? amax_x[0] : nullptr, amax_weight, bn, lv);
-        else DC_LV(4, 8, 2);
-    }
-#undef DC_LV
-    GGA_CHECK_LAUNCH("dense_conv3x3_x9_kernel (levels)");
-    return GGA_OK;
-}
-
-extern "C" int gga_dense_conv3x3_stats(const float* x, const void* split_weight, int B, int H, int W, int cin, int cout,
-                                       float* y, double* stats, void* stream) {
-    return gga_dense_conv3x3_slice(x, split_weight, B, H, W, cin, cout, y, cout, 0, stats, stream);
-}
-
-extern "C" int gga_dense_conv3x3(const float* x, const void* split_weight, int B, int H, int W, int cin, int cout,
-                                 float* y, void* stream) {
-    return gga_dense_conv3x3_slice(x, split_weight, B, H, W, cin, cout, y, cout, 0, nullptr, stream);
-}
-
-// ------------------------------------------------------------------------------ dense 3x3 weight gradient
-// dW[co][ci][ky][kx] = sum_p x[p + (ky-1, kx-1)][ci] * gy[p][co] of the same 3x3 / stride 1 / pad 1
-// convolution, bf16x9 on the matrix cores. Here the GEMM's K is the PIXEL index: the MFMA operands
-// are x^T (M = ci) and gy (N = co), i.e. eight consecutive pixels of ONE channel per lane, while
-// both tensors are channels-last. The LDS images stay pixel-major ([pixel][32 channels], 64-byte
-// rows, three bf16 planes - written exactly like the forward kernel's halo) and
-// ds_read_b64_tr_b16 does the transposition on the way out: two transposed reads give a lane the
-// 8 pixels of its channel (probe: tools_dev/micro/tr_probe.hip), and a tap shift is just a row
-// offset of the x image, so the nine taps reuse one staged copy.
-//
-// A 256-thread workgroup owns one 64 x 64 (ci, co) channel block (blockIdx.y), a strip of 32
-// pixel columns and a segment of image rows of one image; wave w accumulates the (ci tile w/2,
-// co tile w%2) 32 x 32 block of all nine taps (144 accumulator registers). Per image row
-// (= 2 K-steps of 16 pixels): the gy row (32 px x 64 co) and one new x row (34 px x 64 ci; a ring
-// of four rows holds y-1 .. y+2) are fetched one stage ahead, split into planes and stored; each
-// K-step reads 6 + 54 transposed fragments for 81 MFMAs. Partial sums go to
-// [workgroup][tap][ci][co]; dense_wgrad_reduce_kernel adds them in a fixed order (f64) and writes
-// the framework's [cout, cin, 3, 3] layout.
-#define DW_XPL (2 * 34 * 64)                 // bytes per plane of one x ring row: [ci tile][34 px][32 ch]
-#define DW_XROW (NP * DW_XPL)                // NP = planes per operand (template parameter of the kernel)
-#define DW_GPL (2 * 32 * 64)                 // bytes per plane of one gy row: [co tile][32 px][32 ch]
-#define DW_GROW (NP * DW_GPL)
-
-template <int NP>
-__global__ __launch_bounds__(256, 2) void dense_wgrad3x3_x9_kernel(const float* __restrict__ X, const float* __restrict__ G,
-                                                                  int B, int H, int W, int cin, int cout, int strips,
-                                                                  int prow, int pcol, float* __restrict__ partials,
-                                                                  const uint32_t* __restrict__ amax_x,
-                                                                  const uint32_t* __restrict__ amax_g) {
-    // NP = 3: bf16 planes, six products; NP = 2: fp16 planes of the scaled operands, three products (h2_split2); the
-    // partial sums then stay scaled and dense_wgrad_reduce_kernel scales the total back
-    float xscale = 1.0f, gscale = 1.0f;
-    if (NP == 2) { xscale = h2_scale(h2_scale_exp(*amax_x)); gscale = h2_scale(h2_scale_exp(*amax_g)); }
-    __shared__ __attribute__((aligned(16))) unsigned char Xs[4 * DW_XROW];
-    __shared__ __attribute__((aligned(16))) unsigned char Gs[2 * DW_GROW];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ti = wave >> 1, tj = wave & 1;               // ci tile, co tile of this wave
-    // The image rows of all (image, 32-column strip) pairs form one sequence of B * strips * H row
-    // stages; workgroup i takes an equal contiguous share of it (so that exactly as many workgroups
-    // as fit on the chip carry the same load - dW sums over all pixels, a share may span columns).
-    // blockIdx.y -> 64 x 64 channel block.
-    const int ncb_o = cout >> 6;
-    const int ci0 = (blockIdx.y / ncb_o) * 64, co0 = (blockIdx.y % ncb_o) * 64;
-    const int64_t total_rows = (int64_t)B * strips * H;
-    const int64_t r0 = total_rows * blockIdx.x / gridDim.x, r1 = total_rows * (blockIdx.x + 1) / gridDim.x;
-    int x0 = 0, ye = 0;
-    const float* Xb = X;
-    const float* Gb = G;
-
-    mf_v16 acc[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
-
-    // staging pieces: gy row = 32 px x 16 float4 (2 per thread); x row = 34 px x 16 float4 (3 per thread, 544 used)
-    float4 rg0, rg1, rx0, rx1, rx2;
-#define DW_LOAD_G(Y) {                                                                                                \
-        const bool rowok = (Y) < ye;                                                                                  \
-        { const int f = tid;       const int px = f >> 4, q = f & 15; const bool ok = rowok && x0 + px < W;           \
-          rg0 = ok ? *reinterpret_cast<const float4*>(Gb + ((int64_t)(Y) * prow + (int64_t)(x0 + px) * pcol) * cout + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f); } \
-        { const int f = tid + 256; const int px = f >> 4, q = f & 15; const bool ok = rowok && x0 + px < W;           \
-          rg1 = ok ? *reinterpret_cast<const float4*>(Gb + ((int64_t)(Y) * prow + (int64_t)(x0 + px) * pcol) * cout + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f); } }
-#define DW_LDX(V, E) { const int f = tid + 256 * (E); const int px = f >> 4, q = f & 15; const int ix = x0 - 1 + px;  \
-        const bool ok = rowok && f < 544 && (unsigned)ix < (unsigned)W;                                               \
-        V = ok ? *reinterpret_cast<const float4*>(Xb + ((int64_t)yy * prow + (int64_t)ix * pcol) * cin + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f); }
-#define DW_LOAD_X(Y) { const int yy = (Y); const bool rowok = (unsigned)yy < (unsigned)H; DW_LDX(rx0, 0) DW_LDX(rx1, 1) DW_LDX(rx2, 2) }
-    // piece (pixel px, float4 q) of a row image: channel tile q / 8, byte (q % 8) * 8 of the 64-byte pixel row
-#define DW_SPLIT_STORE(V, BASE, PL, NPX, F, SC) { const int f = (F); const int px = f >> 4, q = f & 15;               \
-        unsigned char* dst = (BASE) + (q >> 3) * ((NPX) * 64) + px * 64 + (q & 7) * 8;                                \
-        if (NP == 3) {                                                                                                \
-            uint32_t lo1, lo2, lo3, hi1, hi2, hi3;                                                                    \
-            x9_split2(V.x, V.y, lo1, lo2, lo3); x9_split2(V.z, V.w, hi1, hi2, hi3);                                   \
-            *reinterpret_cast<uint2*>(dst) = make_uint2(lo1, hi1);                                                    \
-            *reinterpret_cast<uint2*>(dst + (PL)) = make_uint2(lo2, hi2);                                             \
-            *reinterpret_cast<uint2*>(dst + (NP - 1) * (PL)) = make_uint2(lo3, hi3);                                  \
-        } else {                                                                                                      \
-            uint32_t lo1, lo2, hi1, hi2;                                                                              \
-            h2_split2(V.x * (SC), V.y * (SC), lo1, lo2); h2_split2(V.z * (SC), V.w * (SC), hi1, hi2);                 \
-            *reinterpret_cast<uint2*>(dst) = make_uint2(lo1, hi1);                                                    \
-            *reinterpret_cast<uint2*>(dst + (PL)) = make_uint2(lo2, hi2);                                             \
-        } }
-#define DW_STORE_G(Y) { unsigned char* base = Gs + ((Y) & 1) * DW_GROW;                                               \
-        DW_SPLIT_STORE(rg0, base, DW_GPL, 32, tid, gscale) DW_SPLIT_STORE(rg1, base, DW_GPL, 32, tid + 256, gscale) }
-#define DW_STORE_X(Y) { unsigned char* base = Xs + (((Y) + 4) & 3) * DW_XROW;                                         \
-        DW_SPLIT_STORE(rx0, base, DW_XPL, 34, tid, xscale) DW_SPLIT_STORE(rx1, base, DW_XPL, 34, tid + 256, xscale)   \
-        if (tid + 512 < 544) DW_SPLIT_STORE(rx2, base, DW_XPL, 34, tid + 512, xscale) }
-
-    // transposed fragment of a [pixel][32 ch] image: lane l gets channel l%32, pixels P0 + 8*(l/32) .. +7
-    const int grp = lane >> 4, li = lane & 15;
-    const int froff = ((8 * (grp >> 1) + (li >> 2)) * 64) + (16 * (grp & 1) + 4 * (li & 3)) * 2;   // byte offset of this lane's address in the block
-    union Frag { mf_v8bf v; dw_v4s h[2]; };
-#define DW_FRAG(F, PTR) { F.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) dw_v4s*)((PTR) + froff));          \
-                          F.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) dw_v4s*)((PTR) + froff + 4 * 64)); }
-
-    int64_t idx = r0;
-    while (idx < r1) {
-    const int col = (int)(idx / H);
-    const int ys = (int)(idx - (int64_t)col * H);
-    {
-        const int b = col / strips, strip = col - b * strips;
-        x0 = strip * 32;
-        Xb = X + (int64_t)b * H * W * cin + ci0;
-        Gb = G + (int64_t)b * H * W * cout + co0;
-    }
-    ye = (int)(r1 - idx < (int64_t)(H - ys) ? ys + (r1 - idx) : H);      // rows of this column in my share
-    idx += ye - ys;
-    // (re)fill the ring for this column: x rows ys-1 .. ys+1 and the gy row ys
-    DW_LOAD_X(ys - 1); DW_STORE_X(ys - 1);
-    DW_LOAD_X(ys);     DW_STORE_X(ys);
-    DW_LOAD_X(ys + 1); DW_STORE_X(ys + 1);
-    DW_LOAD_G(ys);     DW_STORE_G(ys);
-    __syncthreads();
-    for (int y = ys; y < ye; ++y) {
-        const bool more = y + 1 < ye;
-        if (more) { DW_LOAD_G(y + 1); DW_LOAD_X(y + 2); }
-        const unsigned char* gbase = Gs + (y & 1) * DW_GROW + tj * (32 * 64);
-        // (left to the compiler's schedule: forcing the next tap's six reads ahead of the current tap's
-        // MFMAs with sched_barriers measured 584 instead of 545 us)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            Frag g0, g1, g2;
-            DW_FRAG(g0, gbase + (16 * s) * 64);
-            DW_FRAG(g1, gbase + DW_GPL + (16 * s) * 64);
-            if (NP == 3) { DW_FRAG(g2, gbase + (NP - 1) * DW_GPL + (16 * s) * 64); } else g2 = g1;
-            if (NP == 2) {
-                // three taps (one kernel row) at a time, the three partial products interleaved over the taps: consecutive
-                // MFMAs never write the same accumulator (tap by tap with the three products back to back: 254 instead of
-                // 233 us at 64 -> 64, 16 x 248 x 216; 202 -> 197 at 128 -> 128)
-#pragma unroll
-                for (int ky = 0; ky < 3; ++ky) {
-                    Frag b0[3], b1[3];
-#pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) {
-                        const unsigned char* xb = Xs + ((y + ky - 1 + 4) & 3) * DW_XROW + ti * (34 * 64) + (16 * s + kx) * 64;
-                        DW_FRAG(b0[kx], xb);
-                        DW_FRAG(b1[kx], xb + DW_XPL);
-                    }
-#define DW_MI(A_, G_, T_) acc[T_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(mf_v8h, A_.v), __builtin_bit_cast(mf_v8h, G_.v), acc[T_], 0, 0, 0);
-                    DW_MI(b0[0], g1, 3 * ky) DW_MI(b0[1], g1, 3 * ky + 1) DW_MI(b0[2], g1, 3 * ky + 2)
-                    DW_MI(b1[0], g0, 3 * ky) DW_MI(b1[1], g0, 3 * ky + 1) DW_MI(b1[2], g0, 3 * ky + 2)
-                    DW_MI(b0[0], g0, 3 * ky) DW_MI(b0[1], g0, 3 * ky + 1) DW_MI(b0[2], g0, 3 * ky + 2)
-#undef DW_MI
-                }
-                continue;
-            }
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int ky = tap / 3, kx = tap - ky * 3;
-                const unsigned char* xbase = Xs + ((y + ky - 1 + 4) & 3) * DW_XROW + ti * (34 * 64) + (16 * s + kx) * 64;
-                Frag a0, a1, a2;
-                DW_FRAG(a0, xbase);
-                DW_FRAG(a1, xbase + DW_XPL);
-                if (NP == 2) {
-#define DW_MH(A_, G_) acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(mf_v8h, A_.v), __builtin_bit_cast(mf_v8h, G_.v), acc[tap], 0, 0, 0);
-                    DW_MH(a0, g1) DW_MH(a1, g0) DW_MH(a0, g0)
-#undef DW_MH
-                    continue;
-                }
-                DW_FRAG(a2, xbase + (NP - 1) * DW_XPL);
-                // nine partial products, smallest first
-#ifndef X9_SIX
-                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2.v, g2.v, acc[tap], 0, 0, 0);
-                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.v, g2.v, acc[tap], 0, 0, 0);
-                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2.v, g1.v, acc[tap], 0, 0, 0);
-#endif
-                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.v, g2.v, acc[tap], 0, 0, 0);
-                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.v, g1.v, acc[tap], 0, 0, 0);
-                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2.v, g0.v, acc[tap], 0, 0, 0);
-                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.v, g1.v, acc[tap], 0, 0, 0);
-                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.v, g0.v, acc[tap], 0, 0, 0);
-                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.v, g0.v, acc[tap], 0, 0, 0);
-            }
-        }
-        if (more) { DW_STORE_G(y + 1); DW_STORE_X(y + 2); }
-        __syncthreads();
-    }
-    }
-#undef DW_LOAD_G
-#undef DW_LDX
-#undef DW_LOAD_X
-#undef DW_SPLIT_STORE
-#undef DW_STORE_G
-#undef DW_STORE_X
-#undef DW_FRAG
-    // D: register v of lane l = row (ci in tile) (v/4)*8 + (l/32)*4 + v%4, column (co in tile) l%32
-    float* out = partials + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (9 * 64 * 64);
-    const int r = lane & 31, h = lane >> 5;
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-        for (int v = 0; v < 16; ++v) {
-            const int ci = ti * 32 + (v >> 2) * 8 + h * 4 + (v & 3);
-            out[(tap * 64 + ci) * 64 + tj * 32 + r] = acc[tap][v];
-        }
-}
-
-// dW[co][ci][ky][kx] (element strides given) = sum over the workgroups' partials, fixed order, f64
-__global__ __launch_bounds__(256) void dense_wgrad_reduce_kernel(const float* __restrict__ partials, int nblk, int cin, int cout,
-                                                                int64_t s_co, int64_t s_ci, int64_t s_ky, int64_t s_kx,
-                                                                const uint32_t* __restrict__ amax_x,
-                                                                const uint32_t* __restrict__ amax_g, float* __restrict__ dW) {
-    const int i = blockIdx.x * 256 + threadIdx.x;          // (tap, ci local, co local) of channel block blockIdx.y
-    if (i >= 9 * 64 * 64) return;
-    const int ncb_o = cout >> 6;
-    const int ci0 = (blockIdx.y / ncb_o) * 64, co0 = (blockIdx.y % ncb_o) * 64;
-    const float* p = partials + (int64_t)blockIdx.y * nblk * (9 * 64 * 64) + i;
-    double s = 0.0;
-#pragma unroll 8
-    for (int k = 0; k < nblk; ++k) s += (double)p[(int64_t)k * (9 * 64 * 64)];
-    const int co = i & 63, ci = (i >> 6) & 63, tap = i >> 12;
-    const int ky = tap / 3, kx = tap - ky * 3;
-    if (amax_x) s = s * (double)h2_descale(h2_scale_exp(*amax_x)) * (double)h2_descale(h2_scale_exp(*amax_g));     // fp16-plane partials are scaled
-    dW[(co0 + co) * s_co + (ci0 + ci) * s_ci + ky * s_ky + kx * s_kx] = (float)s;
-}
-
-// workgroups per channel block: as many as run at once (two per CU, 256 CUs) over all channel blocks
-static int dense_wgrad_blocks(int B, int H, int W, int cin, int cout) {
-    const int64_t total_rows = (int64_t)B * ((W + 31) / 32) * H;
-    int64_t n = 512 / ((int64_t)(cin >> 6) * (cout >> 6));
-    if (n < 1) n = 1;
-    if (n > total_rows) n = total_rows;
-    return (int)n;
-}
-
-extern "C" size_t gga_dense_wgrad3x3_workspace_bytes(int B, int H, int W, int cin, int cout) {
-    if (B < 1 || H < 1 || W < 1 || cin < 64 || cout < 64 || (cin & 63) || (cout & 63)) return 0;
-    const int n0 = dense_wgrad_blocks(B, H, W, cin, cout), n1 = dense_wgrad_blocks(B, W, H, cin, cout);     // either walk
-    return (size_t)(n0 > n1 ? n0 : n1) * (cin >> 6) * (cout >> 6) * 9 * 64 * 64 * sizeof(float);
-}
-
-extern "C" int gga_dense_wgrad3x3(const float* x, const float* grad_y, int B, int H, int W, int cin, int cout,
-                                  float* grad_weight, int64_t stride_co, int64_t stride_ci, int64_t stride_ky,
-                                  int64_t stride_kx, int transposed, void* workspace, size_t workspace_bytes,
-                                  void* stream_) {
-    return gga_dense_wgrad3x3_planes(x, grad_y, B, H, W, cin, cout, grad_weight, stride_co, stride_ci, stride_ky, stride_kx,
-                                     transposed, 3, nullptr, nullptr, workspace, workspace_bytes, stream_);
-}
-
-extern "C" int gga_dense_wgrad3x3_planes(const float* x, const float* grad_y, int B, int H, int W, int cin, int cout,
-                                         float* grad_weight, int64_t stride_co, int64_t stride_ci, int64_t stride_ky,
-                                         int64_t stride_kx, int transposed, int planes, const uint32_t* amax_x,
-                                         const uint32_t* amax_grad_y, void* workspace, size_t workspace_bytes, void* stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    GGA_REQUIRE(x && grad_y && grad_weight && workspace, "gga_dense_wgrad3x3: null pointer argument");
-    GGA_REQUIRE(planes == 3 || (planes == 2 && amax_x && amax_grad_y),
-                "gga_dense_wgrad3x3: planes must be 3 (bf16) or 2 (fp16, with the operands' absmax bits)");
-    GGA_REQUIRE(B >= 1 && H >= 1 && W >= 1 && cin >= 64 && cout >= 64 && (cin & 63) == 0 && (cout & 63) == 0,
-                "gga_dense_wgrad3x3: cin and cout must be multiples of 64 (got %d -> %d)", cin, cout);
-    if (workspace_bytes < gga_dense_wgrad3x3_workspace_bytes(B, H, W, cin, cout)) {
-        gga_set_error("gga_dense_wgrad3x3: workspace too small");
-        return GGA_ERR_WORKSPACE;
-    }
-    // transposed: strips of 32 pixels along the image's H, rows along its W; the taps swap with them
-    const int prow = transposed ? 1 : W, pcol = transposed ? W : 1;
-    if (transposed) { const int t = H; H = W; W = t; const int64_t ts = stride_ky; stride_ky = stride_kx; stride_kx = ts; }
-    const int strips = (W + 31) / 32;
-    const int nblk = dense_wgrad_blocks(B, H, W, cin, cout), ncb = (cin >> 6) * (cout >> 6);
-    hipEvent_t* tev = gga_timing_acquire(GGA_TIME_DENSE_WGRAD, GGA_TIMING_CONV_KEY(cin, cout, (int64_t)H * W));
-    GGA_TIME_START(tev, stream);
-    if (planes == 3)
-        hipLaunchKernelGGL(dense_wgrad3x3_x9_kernel<3>, dim3(nblk, ncb), dim3(256), 0, stream, x, grad_y, B, H, W, cin, cout, strips,
-                           prow, pcol, (float*)workspace, amax_x, amax_grad_y);
-    else
-        hipLaunchKernelGGL(dense_wgrad3x3_x9_kernel<2>, dim3(nblk, ncb), dim3(256), 0, stream, x, grad_y, B, H, W, cin, cout, strips,
-                           prow, pcol, (float*)workspace, amax_x, amax_grad_y);
-    GGA_CHECK_LAUNCH("dense_wgrad3x3_x9_kernel");
-    hipLaunchKernelGGL(dense_wgrad_reduce_kernel, dim3((9 * 64 * 64 + 255) / 256, ncb), dim3(256), 0, stream,
-                       (const float*)workspace, nblk, cin, cout, stride_co, stride_ci, stride_ky, stride_kx,
-                       planes == 2 ? amax_x : nullptr, amax_grad_y, grad_weight);
-    GGA_CHECK_LAUNCH("dense_wgrad_reduce_kernel");
     GGA_TIME_STOP(tev, stream);
     return GGA_OK;
 }

@@ -148,17 +148,18 @@ class _AmaxPool:
                 b.zero_()
                 self.used[dev] = 0
 
-    def take(self, device):
+    def take(self, device, n=1):
+        """``n`` consecutive zeroed slots (one absmax per 64-channel block of a tensor, see ``_wgrad``)."""
         key = str(device)
         b = self.buf.get(key)
         if b is None:
             b = self.buf[key] = torch.zeros(self.SLOTS, dtype=torch.int32, device=device)
             self.used[key] = 0
         i = self.used[key]
-        if i >= self.SLOTS:                       # more producers than slots in one generation: a fill of its own
-            return torch.zeros(1, dtype=torch.int32, device=device)
-        self.used[key] = i + 1
-        return b[i:i + 1]
+        if i + n > self.SLOTS:                    # more producers than slots in one generation: a fill of its own
+            return torch.zeros(n, dtype=torch.int32, device=device)
+        self.used[key] = i + n
+        return b[i:i + n]
 
 
 AMAX_POOL = _AmaxPool()
@@ -172,9 +173,9 @@ def set_amax(t, amax):
     return t
 
 
-def new_amax(device):
-    """Zeroed absmax accumulator for the producers' ``amax`` outputs (None on the three-bf16-plane path)."""
-    return AMAX_POOL.take(device) if PLANES == 2 else None
+def new_amax(device, n=1):
+    """Zeroed absmax accumulator(s) for the producers' ``amax`` outputs (None on the three-bf16-plane path)."""
+    return AMAX_POOL.take(device, n) if PLANES == 2 else None
 
 
 def tensor_amax(t):
@@ -349,8 +350,9 @@ def run_bn_bwd(gy, weight, g_amax, w_amax, src):
     return gx
 
 
-def _wgrad(x, gy, weight, x_amax=None, g_amax=None):
-    """Weight gradient on the matrix path (``gga_dense_wgrad3x3``), in the parameter's memory layout."""
+def _wgrad(x, gy, weight, x_amax=None, g_amax=None, g_per_block=False):
+    """Weight gradient on the matrix path (``gga_dense_wgrad3x3``), in the parameter's memory layout. ``g_per_block``:
+    ``g_amax`` holds one absmax per 64-channel block of ``gy`` (two-plane arithmetic)."""
     L = _lib.lib()
     B, cin, H, W = x.shape
     cout = weight.shape[0]
@@ -364,8 +366,9 @@ def _wgrad(x, gy, weight, x_amax=None, g_amax=None):
         g_amax = amax_bits(gy) if g_amax is None else g_amax
     else:
         x_amax = g_amax = None
-    check(L.gga_dense_wgrad3x3_planes(F._p(x), F._p(gy), B, H, W, cin, cout, F._p(gw), s[0], s[1], s[2], s[3], int(tr), planes,
-                                      F._p(x_amax), F._p(g_amax), F._p(ws), ws.numel(), F._stream()), 'gga_dense_wgrad3x3')
+    check(L.gga_dense_wgrad3x3_block_amax(F._p(x), F._p(gy), B, H, W, cin, cout, F._p(gw), s[0], s[1], s[2], s[3], int(tr), planes,
+                                          F._p(x_amax), 0, F._p(g_amax), int(bool(g_per_block) and planes == 2), F._p(ws), ws.numel(),
+                                          F._stream()), 'gga_dense_wgrad3x3')
     return gw
 
 

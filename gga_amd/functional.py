@@ -1046,7 +1046,12 @@ class _HeadBranches(torch.autograd.Function):
         B, C, H, W = x.shape
         rows, dev, tot = B * H * W, x.device, C * n
         G = torch.empty_like(Y)
-        g_amax = dense_conv.new_amax(dev)             # the tail kernels leave max |G| for the two convolutions that read G
+        # the tail kernels leave max |G_i| of their column block: the weight gradient scales every branch's block by its own
+        # maximum (a regression branch's gradient lives on a few object cells, orders of magnitude below a heat-map branch's:
+        # under ONE scale for the 960 channels its two fp16 planes keep only a few bits - measured 3e-3 .. 7e-3 on those
+        # branches' weight gradients where fp32 is at 1e-5); the backward-data convolution, whose result sums over the branches,
+        # takes the largest of them
+        g_blocks = dense_conv.new_amax(dev, n)
         gw2, gb2, ggam, gbet = [], [], [], []
         wsb = _workspace('bn', L.gga_bn_relu_workspace_bytes(rows, C), dev)
         for i in range(n):
@@ -1061,13 +1066,15 @@ class _HeadBranches(torch.autograd.Function):
             gg = torch.empty(C, dtype=torch.float32, device=dev)
             gbeta = torch.empty(C, dtype=torch.float32, device=dev)
             check(L.gga_head_tail_bwd(_p(gy), Y.data_ptr() + 4 * C * i, tot, _p(ss_all[i]), _p(gam[i]), _p(saved_all[i]), _p(w), B, H, W,
-                                      C, cout, G.data_ptr() + 4 * C * i, tot, _p(gg), _p(gbeta), _p(g_amax), _p(wsb), wsb.numel(),
+                                      C, cout, G.data_ptr() + 4 * C * i, tot, _p(gg), _p(gbeta), _p(g_blocks[i:i + 1] if g_blocks is not None else None),
+                                      _p(wsb), wsb.numel(),
                                       _stream()), 'gga_head_tail_bwd')
             gw2.append(gw), gb2.append(gb), ggam.append(gg), gbet.append(gbeta)
         wcat = torch.cat([w.detach() for w in w1], dim=0)            # [64n, 64, 3, 3]
         w_amax = dense_conv.amax_bits(wcat) if dense_conv.PLANES == 2 else None
+        g_amax = g_blocks.max().reshape(1) if g_blocks is not None else None       # (bits of non-negative floats order like ints)
         gx = dense_conv.run_bn_bwd(G, wcat, g_amax, w_amax, ctx.bn_src) if ctx.needs_input_grad[0] else None
-        gwcat = dense_conv._wgrad(x, G, wcat, ctx.x_amax if dense_conv.PLANES == 2 else None, g_amax)
+        gwcat = dense_conv._wgrad(x, G, wcat, ctx.x_amax if dense_conv.PLANES == 2 else None, g_blocks, g_per_block=True)
         gw1 = list(gwcat.split(C, dim=0))
         none = [None] * n
         return (gx, None, None, *gw1, *ggam, *gbet, *none, *none, *gw2, *gb2)

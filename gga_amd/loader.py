@@ -232,16 +232,39 @@ def collate(batch, samples_per_gpu=1):
 DEVICE_KEYS = ('points',)
 
 
+def chunks_in(collated):
+    """Number of per-GPU chunks in a collated batch."""
+    for value in collated.values():
+        while isinstance(value, (list, tuple)) and value:
+            value = value[0]
+        if isinstance(value, DataContainer):
+            return len(value.data)
+    return 1
+
+
+def _take_chunk(value, chunk):
+    if isinstance(value, DataContainer):
+        return value.data[chunk]
+    if isinstance(value, (list, tuple)):          # test-time samples: a list over augmentations of containers
+        return [_take_chunk(v, chunk) for v in value]
+    return value
+
+
+def _to_device(value, device, non_blocking):
+    if isinstance(value, (list, tuple)):
+        return [_to_device(v, device, non_blocking) for v in value]
+    return value.to(device, non_blocking=non_blocking) if torch.is_tensor(value) else value
+
+
 def to_step_inputs(collated, device=None, chunk=0, non_blocking=True):
-    """A collated batch -> the keyword inputs of the detector's ``forward_train`` for this rank's device: chunk ``chunk`` of
-    every container, ``points`` on ``device`` (uploads from pinned memory are asynchronous: announce them with
-    ``Runner.inputs_ready``), everything else as it left the pipeline."""
+    """A collated batch -> the keyword inputs of the detector's ``forward_train`` (or ``forward_test``) for this rank's
+    device: chunk ``chunk`` of every container, ``points`` on ``device`` (uploads from pinned memory are asynchronous:
+    announce them with ``Runner.inputs_ready``), everything else as it left the pipeline."""
     out = {}
     for key, value in collated.items():
-        value = value.data[chunk] if isinstance(value, DataContainer) else value
+        value = _take_chunk(value, chunk)
         if device is not None and key in DEVICE_KEYS:
-            value = [t.to(device, non_blocking=non_blocking) for t in value] if isinstance(value, list) else \
-                value.to(device, non_blocking=non_blocking)
+            value = _to_device(value, device, non_blocking)
         out[key] = value
     return out
 

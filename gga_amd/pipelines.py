@@ -453,3 +453,134 @@ class DevicePointPrep:
         assert rng is not None, 'PointsRangeFilter(defer_points=True) must be part of the pipeline'
         seeds = [int(s.get('deferred_shuffle_seed', 0)) for s in samples]
         return F.points_prepare_batch(scene, sampled, centers, self.min_distance, rng, seeds, self.device)
+
+
+# ----------------------------------------------------------------------------- test-time pipeline (pseudo-label run)
+# The transforms of the reference's test_pipeline (configs/gga/gga_kitti_config.py:139-163: MultiScaleFlipAug3D around
+# GlobalRotScaleTrans / RandomFlip3D / PointsRangeFilter / DefaultFormatBundle3D / Collect3D; test_time_aug.py:118-229,
+# transforms_3d.py:78-211,544-724, formating.py) for LiDAR points. With the parameters of the GGA configs they change nothing
+# (one scale, no flip, zero rotation / translation); the point-side arithmetic is there for other settings, box fields are
+# only handled where no box has to move.
+def _rotate_points_z(points, angle):
+    """Row vectors times [[c, s, 0], [-s, c, 0], [0, 0, 1]] (rotation_3d_in_axis about z, structures/utils.py:79-117)."""
+    c, s = float(np.cos(angle)), float(np.sin(angle))
+    rot_t = points.tensor.new_tensor([[c, s, 0.0], [-s, c, 0.0], [0.0, 0.0, 1.0]])
+    points.tensor[:, :3] = points.tensor[:, :3] @ rot_t
+    return rot_t
+
+
+def _no_boxes_to_move(d, what):
+    for field in d.get('bbox3d_fields', []):
+        if len(d[field]):
+            raise NotImplementedError(f'{what} of 3D boxes is not on the GGA path (its train pipeline has no such transform)')
+
+
+@PIPELINES.register_module()
+class GlobalRotScaleTrans:
+    def __init__(self, rot_range=[-0.78539816, 0.78539816], scale_ratio_range=[0.95, 1.05], translation_std=[0, 0, 0], shift_height=False):
+        as_pair = lambda v: [-v, v] if isinstance(v, (int, float)) else list(v)
+        self.rot_range, self.scale_ratio_range = as_pair(rot_range), list(scale_ratio_range)
+        self.translation_std = [translation_std] * 3 if isinstance(translation_std, (int, float)) else list(translation_std)
+        assert all(t >= 0 for t in self.translation_std) and not shift_height
+
+    def __call__(self, d):
+        d.setdefault('transformation_3d_flow', [])
+        angle = np.random.uniform(self.rot_range[0], self.rot_range[1])          # the draws come in this order: rotation,
+        if angle != 0:
+            _no_boxes_to_move(d, 'rotation')
+        d['pcd_rotation'] = _rotate_points_z(d['points'], angle)
+        d['pcd_rotation_angle'] = angle
+        if 'pcd_scale_factor' not in d:                                        # scale (unless the test-time wrapper fixed it),
+            d['pcd_scale_factor'] = np.random.uniform(self.scale_ratio_range[0], self.scale_ratio_range[1])
+        if d['pcd_scale_factor'] != 1:
+            _no_boxes_to_move(d, 'scaling')
+            d['points'].tensor[:, :3] *= d['pcd_scale_factor']
+        shift = np.random.normal(scale=np.array(self.translation_std, dtype=np.float32), size=3).T      # translation
+        if np.any(shift != 0):
+            _no_boxes_to_move(d, 'translation')
+            d['points'].tensor[:, :3] += d['points'].tensor.new_tensor(shift)
+        d['pcd_trans'] = shift
+        d['transformation_3d_flow'].extend(['R', 'S', 'T'])
+        return d
+
+
+@PIPELINES.register_module()
+class RandomFlip3D:
+    """Flips decided upstream (``flip`` / ``pcd_horizontal_flip`` / ``pcd_vertical_flip`` set by MultiScaleFlipAug3D) or drawn
+    with the given ratios; LiDAR points: horizontal = y -> -y, vertical = x -> -x."""
+
+    def __init__(self, sync_2d=True, flip_ratio_bev_horizontal=0.0, flip_ratio_bev_vertical=0.0, **kwargs):
+        self.sync_2d, self.h_ratio, self.v_ratio = sync_2d, flip_ratio_bev_horizontal, flip_ratio_bev_vertical
+
+    def __call__(self, d):
+        d.setdefault('flip', False)
+        if self.sync_2d:
+            d['pcd_horizontal_flip'], d['pcd_vertical_flip'] = d['flip'], False
+        else:
+            if 'pcd_horizontal_flip' not in d:
+                d['pcd_horizontal_flip'] = bool(np.random.rand() < self.h_ratio)
+            if 'pcd_vertical_flip' not in d:
+                d['pcd_vertical_flip'] = bool(np.random.rand() < self.v_ratio)
+        d.setdefault('transformation_3d_flow', [])
+        for flag, axis, tag in (('pcd_horizontal_flip', 1, 'HF'), ('pcd_vertical_flip', 0, 'VF')):
+            if d[flag]:
+                _no_boxes_to_move(d, 'flipping')
+                d['points'].tensor[:, axis] = -d['points'].tensor[:, axis]
+                d['transformation_3d_flow'].append(tag)
+        return d
+
+
+@PIPELINES.register_module()
+class MultiScaleFlipAug3D:
+    """Test-time augmentation wrapper: the inner transforms run once per (image scale, point scale, flip) combination on a deep
+    copy of the sample, and the results are regrouped key by key into lists - one entry per combination (exactly one for the
+    GGA configs)."""
+
+    def __init__(self, transforms, img_scale, pts_scale_ratio, flip=False, flip_direction='horizontal', pcd_horizontal_flip=False,
+                 pcd_vertical_flip=False):
+        self.transforms = Compose(transforms)
+        self.img_scale = img_scale if isinstance(img_scale, list) else [img_scale]
+        self.pts_scale_ratio = [float(r) for r in (pts_scale_ratio if isinstance(pts_scale_ratio, list) else [pts_scale_ratio])]
+        self.flip, self.h_flip, self.v_flip = flip, pcd_horizontal_flip, pcd_vertical_flip
+        self.flip_direction = flip_direction if isinstance(flip_direction, list) else [flip_direction]
+
+    def __call__(self, d):
+        import copy
+        import itertools
+        hs = [False, True] if self.flip and self.h_flip else [False]
+        vs = [False, True] if self.flip and self.v_flip else [False]
+        runs = []
+        for scale, ratio, h, v, direction in itertools.product(self.img_scale, self.pts_scale_ratio, hs, vs, self.flip_direction):
+            one = copy.deepcopy(d)
+            one.update(scale=scale, flip=bool(self.flip), pcd_scale_factor=ratio, flip_direction=direction, pcd_horizontal_flip=h,
+                       pcd_vertical_flip=v)
+            runs.append(self.transforms(one))
+        return {key: [r[key] for r in runs] for key in runs[0]}
+
+
+@PIPELINES.register_module()
+class DefaultFormatBundle3D:
+    """formating.py ``DefaultFormatBundle3D`` for the LiDAR keys: points as a tensor container; with labels, the label / box
+    containers of ``DefaultFormatBundle3D_GGA`` minus the GGA side arrays."""
+
+    def __init__(self, class_names, with_gt=True, with_label=True):
+        self.class_names, self.with_gt, self.with_label = class_names, with_gt, with_label
+
+    def __call__(self, d):
+        if 'points' in d:
+            assert isinstance(d['points'], BasePoints)
+            d['points'] = DC(d['points'].tensor)
+        if self.with_gt and self.with_label:
+            if 'gt_names_3d' in d:
+                d['gt_labels_3d'] = np.array([self.class_names.index(n) for n in d['gt_names_3d']], dtype=np.int64)
+            if 'gt_labels_3d' in d:
+                d['gt_labels_3d'] = DC(to_tensor(d['gt_labels_3d']))
+            if 'gt_bboxes_3d' in d:
+                b = d['gt_bboxes_3d']
+                d['gt_bboxes_3d'] = DC(b, cpu_only=True) if isinstance(b, LiDARInstance3DBoxes) else DC(to_tensor(b))
+        return d
+
+
+@PIPELINES.register_module()
+class Collect3D(Collect3D_GGA):
+    """formating.py ``Collect3D``: the keys asked for + the meta container (the GGA variant adds nothing for these keys)."""

@@ -438,6 +438,15 @@ int gga_dense_wgrad3x3_planes(const float* x, const float* grad_y, int B, int H,
                               float* grad_weight, int64_t stride_co, int64_t stride_ci, int64_t stride_ky,
                               int64_t stride_kx, int transposed, int planes, const uint32_t* amax_x,
                               const uint32_t* amax_grad_y, void* workspace, size_t workspace_bytes, void* stream);
+/* The same with the absmax of an operand given per 64-channel block (amax_x[ci / 64], amax_grad_y[co / 64]) when its
+ * *_per_block flag is set: dW[ci][co] only sees channel ci of x and channel co of grad_y, so on two fp16 planes a block whose
+ * values lie far below the tensor's largest magnitude keeps its own 22 significant bits (the 960-channel gradient of the 15 head
+ * branches: regression branches with a few object cells beside the heat-map branches). */
+int gga_dense_wgrad3x3_block_amax(const float* x, const float* grad_y, int B, int H, int W, int cin, int cout,
+                                  float* grad_weight, int64_t stride_co, int64_t stride_ci, int64_t stride_ky,
+                                  int64_t stride_kx, int transposed, int planes, const uint32_t* amax_x, int amax_x_per_block,
+                                  const uint32_t* amax_grad_y, int amax_grad_y_per_block, void* workspace,
+                                  size_t workspace_bytes, void* stream);
 
 /* The same with y as a 64- or 128-channel slice of a wider channels-last tensor: pixel p of the
  * result starts at y + p * y_pixel_stride (floats). A convolution with more output channels runs as

@@ -741,6 +741,33 @@ def test_dense_conv3x3_vs_torch(cin, cout, B, H, W, planes, monkeypatch):
     torch.testing.assert_close(cb.bias.grad, torch.full_like(cb.bias, float(B * H * W)), rtol=1e-5, atol=1e-3)
 
 
+def test_dense_weight_gradient_with_an_absmax_per_channel_block():
+    """Two fp16 planes: a gradient tensor whose 64-channel blocks differ by 2^-26 in magnitude (the head's 960-channel buffer:
+    regression branches beside heat-map branches). Under ONE absmax the small block's weight gradient keeps a few bits; with an
+    absmax per block (gga_dense_wgrad3x3_block_amax) every block is as accurate as if it were alone."""
+    from gga_amd import dense_conv
+    torch.manual_seed(0)
+    B, H, W = 2, 40, 48
+    x = torch.randn(B, 64, H, W, device=DEV).contiguous(memory_format=torch.channels_last)
+    g = torch.randn(B, 192, H, W, device=DEV)
+    g[:, 64:128] *= 2.0 ** -26
+    g[:, 128:] *= 2.0 ** -13
+    g = g.contiguous(memory_format=torch.channels_last)
+    w = torch.empty(192, 64, 3, 3, device=DEV).contiguous(memory_format=torch.channels_last)
+    ref = torch.nn.grad.conv2d_weight(x.double(), w.shape, g.double(), padding=1)
+    was = dense_conv.PLANES
+    dense_conv.PLANES = 2
+    try:
+        one = dense_conv._wgrad(x, g, w, dense_conv._amax_bits(x), dense_conv._amax_bits(g))
+        blocks = torch.cat([dense_conv._amax_bits(g[:, c:c + 64].contiguous(memory_format=torch.channels_last)) for c in (0, 64, 128)])
+        per = dense_conv._wgrad(x, g, w, dense_conv._amax_bits(x), blocks, g_per_block=True)
+    finally:
+        dense_conv.PLANES = was
+    err = lambda t, c: float((t[c:c + 64].double() - ref[c:c + 64]).norm() / ref[c:c + 64].norm())
+    assert err(one, 0) < 1e-6 and err(one, 64) > 1e-4                    # the tensor-wide scale loses the small block ...
+    assert all(err(per, c) < 1e-6 for c in (0, 64, 128)), [err(per, c) for c in (0, 64, 128)]       # ... its own scale does not
+
+
 @pytest.mark.parametrize('cin,cout,B,H,W', [(64, 64, 3, 37, 45), (64, 128, 2, 37, 45), (128, 128, 2, 31, 22),
                                            (128, 128, 12, 128, 128), (128, 128, 16, 124, 108),
                                            # 256 output channels: both 128-channel slices in one launch, straight and transposed

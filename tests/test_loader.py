@@ -275,7 +275,12 @@ def test_detector_trains_from_the_kitti_tree_saves_and_resumes(tmp_path):
 
     def fresh():
         torch.manual_seed(0)
-        return to_channels_last(build_model(cfg.model).to(DEV)).train()
+        model = build_model(cfg.model)
+        with torch.no_grad():          # random init only: the raw Kaiming output convs decode boxes of e^10 m (inf / NaN losses)
+            for th in model.pts_bbox_head.task_heads:
+                for name in ('reg', 'height', 'dim', 'rot'):
+                    getattr(th, name)[-1].weight.mul_(0.05)
+        return to_channels_last(model.to(DEV)).train()
 
     np.random.seed(0), torch.manual_seed(0)
     model = fresh()
@@ -299,3 +304,89 @@ def test_detector_trains_from_the_kitti_tree_saves_and_resumes(tmp_path):
     assert float(out_a['loss']) == float(out_b['loss'])
     for (n, p), q in zip(model.state_dict().items(), model_b.state_dict().values()):
         assert torch.equal(p, q), n
+
+
+# ------------------------------------------------------------------------------------------------- test / pseudo-label run
+def matching_cfg(root, infos, model_cfg_path):
+    """configs/gga/gga_kitti_matching_config.py's test section pointed at the synthetic tree."""
+    cfg = Config.fromfile(os.path.join(REPO, 'configs', 'gga', 'gga_kitti_matching_config.py'))
+    model = Config.fromfile(model_cfg_path)
+    cfg.model, cfg.test_cfg = model.model, None
+    rng = list(model.model.pts_voxel_layer.point_cloud_range)
+    test = dict(cfg.data['test'])
+    pipe = copy.deepcopy(list(test['pipeline']))
+    for t in pipe[1]['transforms']:
+        if t['type'] == 'PointsRangeFilter':
+            t['point_cloud_range'] = rng
+    test.update(data_root=root, ann_file=infos, pts_prefix='velodyne', pipeline=pipe, pcd_limit_range=rng)
+    cfg.data = dict(samples_per_gpu=2, workers_per_gpu=0, test=test, test_dataloader=dict(samples_per_gpu=2, workers_per_gpu=0))
+    return cfg
+
+
+def test_test_pipeline_and_single_gpu_test_layout(tmp_path):
+    """The reference's test_pipeline (MultiScaleFlipAug3D around the identity augmentations) on the tree: one augmentation,
+    points untouched but for the range filter, and the list-over-augmentations-of-list-over-frames layout forward_test takes."""
+    from gga_amd.apis import single_gpu_test
+    infos = kitti_tree(str(tmp_path))
+    cfg = matching_cfg(str(tmp_path), infos, os.path.join(REPO, 'configs', 'gga', 'gga_kitti_pointpillars_config.py'))
+    ds = LD.build_dataset(dict(cfg.data['test'], test_mode=True))
+    assert type(ds).__name__ == 'KittiDataset_GGA_match' and len(ds) == 3
+    s = ds[0]
+    assert isinstance(s['points'], list) and len(s['points']) == 1 and isinstance(s['points'][0], DC)
+    raw = torch.from_numpy(np.fromfile(os.path.join(str(tmp_path), 'training', 'velodyne', f'{SEEDS[0]:06d}.bin'), dtype=np.float32).reshape(-1, 4))
+    lo, hi = torch.tensor(PP_RANGE[:3]), torch.tensor(PP_RANGE[3:])
+    keep = ((raw[:, :3] > lo) & (raw[:, :3] < hi)).all(1)
+    assert torch.equal(s['points'][0].data, raw[keep])
+    meta = s['img_metas'][0].data
+    assert meta['sample_idx'] == SEEDS[0] and meta['pcd_scale_factor'] == 1.0 and not meta['pcd_horizontal_flip'] and not meta['flip']
+    seen = []
+
+    class Stub(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.zeros(1))
+
+        def forward(self, return_loss=True, rescale=False, points=None, img_metas=None):
+            assert not return_loss and rescale and len(points) == len(img_metas) == 1
+            seen.append([m['sample_idx'] for m in img_metas[0]])
+            return [dict(pts_bbox=dict(n=len(p))) for p in points[0]]
+
+    loader = LD.build_dataloader(ds, samples_per_gpu=2, workers_per_gpu=0, dist=False, shuffle=False)
+    out = single_gpu_test(Stub(), loader, torch.device('cpu'))
+    assert seen == [[SEEDS[0], SEEDS[1]], [SEEDS[2]]] and len(out) == 3 and out[0]['pts_bbox']['n'] == int(keep.sum())
+
+
+@pytest.mark.gpu
+def test_pseudo_label_generation_run(tmp_path):
+    """tools/generate_pseudo_labels_gga.py's flow on the tree: checkpoint -> detector -> detections of every frame ->
+    KittiDataset_GGA_match.evaluate -> the pseudo-label file (one re-labelled info per frame, GGA fields following the match)."""
+    from gga_amd import build_model
+    from gga_amd.apis import generate_pseudo_labels
+    infos = kitti_tree(str(tmp_path))
+    model_cfg = os.path.join(REPO, 'configs', 'gga', 'gga_kitti_pointpillars_config.py')
+    cfg = matching_cfg(str(tmp_path), infos, model_cfg)
+    torch.manual_seed(0)
+    model = build_model(Config.fromfile(model_cfg).model)
+    with torch.no_grad():
+        for th in model.pts_bbox_head.task_heads:
+            for name in ('reg', 'height', 'dim', 'rot'):
+                getattr(th, name)[-1].weight.mul_(0.05)
+            th.heatmap[-1].bias.fill_(0.5)                 # a random-init detector that reports boxes
+    ck = str(tmp_path / 'epoch_1.pth')
+    torch.save(dict(meta=dict(epoch=1, iter=3, CLASSES=('Pedestrian', 'Cyclist', 'Car')),
+                    state_dict={'module.' + k: v for k, v in model.state_dict().items()}), ck)
+    out_file = str(tmp_path / 'pseudo.pkl')
+    outputs, res = generate_pseudo_labels(cfg, ck, out=str(tmp_path / 'raw.pkl'), eval_metrics=('mAP',),
+                                          eval_options=dict(pseudo_label_file=out_file))
+    assert len(outputs) == 3 and all(set(o['pts_bbox']) >= {'boxes_3d', 'scores_3d', 'labels_3d'} for o in outputs)
+    assert sum(len(o['pts_bbox']['scores_3d']) for o in outputs) > 0
+    assert res['pseudo_labels/frames'] == 3.0 and os.path.exists(str(tmp_path / 'raw.pkl'))
+    labelled = pickle.load(open(out_file, 'rb'))
+    assert len(labelled) == 3
+    for info, src in zip(labelled, infos):
+        a = info['annos']
+        assert info['image']['image_idx'] == src['image']['image_idx']
+        n = len(a['name'])
+        assert all(len(a[k]) == n for k in ('bbox', 'dimensions', 'location', 'rotation_y', 'score', 'GGA_boxes_img', 'GGA_init_pseudo_label'))
+        assert (a['dimensions'][:, 0] >= a['dimensions'][:, 2]).all()      # longer horizontal side first
+    assert sum(len(i['annos']['name']) for i in labelled) == res['pseudo_labels/detections']

@@ -518,7 +518,8 @@ def test_bench_line_contract_single_gpu():
     assert res['roofline']['bound'] == 'hbm' and res['roofline']['launches_timed'] == 2
     assert res['mfma_roofline']['launches_timed'] == 2 * res['mfma_roofline']['launches_per_step']
     assert 0 < res['mfma_roofline']['share_of_step'] < 1
-    assert 'fp16 planes' in res['arith'] and 'three f16 MFMA partial products' in res['arith'] and res['dtype'] == 'f32'
+    assert 'fp16 planes' in res['arith'] and 'three f16 MFMA partial products' in res['arith'] and res['dtype'].startswith('f32 tensors, products on 2 x f16')
+    assert res['planes3']['dtype'].startswith('f32 tensors, products on 3 x bf16') and res['planes3']['steps'] == res['steps']
     assert res['config']['matrix_planes'] == 2 and res['range_guard'][0]['iter'] == 0
     assert res['planes3']['ms_per_step'] > 0 and res['planes3']['second_trunk']['ms_per_step'] > 0
 

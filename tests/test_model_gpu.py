@@ -120,16 +120,19 @@ def _gpu_step_against(case, channels_last, planes, monkeypatch):
     if case == 'pp':
         assert R.gradient_offenders(grads, ref, ref64, tol=GRAD_TOL, slack=2.0) == []
     else:
-        # the 40-layer step of the shipped config: the same criterion lets a handful of parameters through at 1.1e-3 ..
-        # 1.2e-3 - head-branch convolutions whose gradient comes from a few object cells (one ReLU decision within rounding
-        # of zero moves them by that much: tests/test_sparse_gpu.py::_relu_decisions_that_differ) and the first sparse
-        # block's BatchNorm biases at 2.6x the fp32 restatement's own distance (the kernels' rounding noise per layer is
-        # 2 - 2.7x the CPU library's). Measured: two planes task_heads.2.reg.0.conv.weight 1.12e-3; three planes
-        # encoder_layer1.0.bn2.bias 1.15e-3. Bound for this case: 1.5e-3 or three times the fp32 floor.
         bad = R.gradient_offenders(grads, ref, ref64, tol=1.5e-3, slack=3.0)
         strict = R.gradient_offenders(grads, ref, ref64, tol=GRAD_TOL, slack=2.0)
         print(f'GRADS {case} planes {planes}: over 1e-3 / twice the floor: {[(n, round(e, 5), round(f, 6)) for n, e, f in strict]}')
-        assert bad == [] and len(strict) <= 6, (bad, strict)
+        if planes == 2:
+            # the arithmetic train.Runner ships: the same criterion as the PointPillars case, no exceptions (round 3 let six
+            # through - head-branch convolutions whose gradient blocks shared ONE scale with the heat-map branches' in the
+            # 960-channel buffer; with an absmax per branch block, functional._HeadBranches, nothing is over)
+            assert strict == [], strict
+        else:
+            # three bf16 planes issue six products per k-step - sqrt(2) of the two-plane form's accumulator roundings
+            # (profiles/r04_precision_cases.json) - and two parameters sit at 1.3e-3 .. 1.5e-3, 2.4 - 4.4 times the fp32 CPU
+            # step's own distance from float64: bounded at 1.5e-3 / three times the floor, at most six beyond 1e-3 / twice
+            assert bad == [] and len(strict) <= 6, (bad, strict)
 
 
 @pytest.mark.parametrize('planes', [2, 3])

@@ -255,32 +255,32 @@ class BnPartials:
         return hit[0] if len(hit) == 1 else torch.cat(hit, dim=2)
 
 
-def _pack(weight, backward, transposed=False, w_amax=None):
-    """Split-plane operand of the forward (or backward-data) convolution, read from the parameter's
-    own memory layout: one kernel, no permuted copy. ``transposed``: for the transposed walk (ky and
-    kx change roles). ``w_amax``: absmax bits of the weight (two-plane arithmetic)."""
-    L = _lib.lib()
-    cout, cin = weight.shape[0], weight.shape[1]
-    n_in, n_out = (cout, cin) if backward else (cin, cout)
-    wp = torch.empty(L.gga_sparse_split_weight_bytes(9, n_in, n_out) // 2, dtype=torch.int16, device=weight.device)
-    s = weight.stride()
-    sky, skx = (s[3], s[2]) if transposed else (s[2], s[3])
-    planes = 2 if w_amax is not None else 3
-    check(L.gga_dense_conv3x3_pack_planes(F._p(weight), s[0], s[1], sky, skx, cin, cout, int(backward), planes, F._p(w_amax),
-                                          F._p(wp), F._stream()), 'gga_dense_conv3x3_pack')
-    return wp
+def _operand(weight, backward, transposed, planes, c0=None):
+    """(split-plane operand, absmax slot or None) of the forward (or backward-data) convolution from the weight bank: the
+    operands persist and are refreshed together once per optimizer step (``weight_bank``). ``weight``: the parameter
+    [cout, cin, 3, 3] in any memory layout, or a LIST of such whose concatenation along the output channels is meant (never
+    materialised). ``c0``: the 128-channel slice [c0, c0 + 128) of the convolution's output."""
+    from . import weight_bank
+    if isinstance(weight, (list, tuple)):
+        assert c0 is None
+        return weight_bank.dense_operand_cat(weight, backward, transposed, planes)
+    return weight_bank.dense_operand(weight, backward, transposed, planes, c0)
 
 
 def _run(x, weight, backward, want_stats=False, x_amax=None, w_amax=None, y=None, y_col=0, bn=None):
-    """The convolution (or its backward-data form) of ``x`` with ``weight`` [cout, cin, 3, 3]; output
-    widths above 128 run as 128-channel slices of the result. ``x_amax`` / ``w_amax``: absmax bits of the operands
-    when they are already known (two-plane arithmetic; computed here otherwise). ``y`` / ``y_col``: write the result
-    into the channel block starting at ``y_col`` of an existing channels-last tensor. ``bn`` (a ``BnSource``, backward
-    only): the result is the gradient of that BatchNorm + ReLU output - it is stored masked by the ReLU, and the second
-    return value is then the list [(first channel, channels, per-tile sums of g and g * xhat)] (``BnPartials.parts``)."""
+    """The convolution (or its backward-data form) of ``x`` with ``weight`` [cout, cin, 3, 3] (or a list of weights standing
+    for their concatenation along cout); output widths above 128 run as 128-channel slices of the result. ``x_amax``: absmax
+    bits of ``x`` when already known (two-plane arithmetic; computed here otherwise); the weight's operand and absmax come
+    from the weight bank (``w_amax`` is ignored). ``y`` / ``y_col``: write the result into the channel block starting at
+    ``y_col`` of an existing channels-last tensor. ``bn`` (a ``BnSource``, backward only): the result is the gradient of that
+    BatchNorm + ReLU output - it is stored masked by the ReLU, and the second return value is then the list [(first channel,
+    channels, per-tile sums of g and g * xhat)] (``BnPartials.parts``)."""
     B, n_in, H, W = x.shape
     L = _lib.lib()
-    n_out = weight.shape[1] if backward else weight.shape[0]
+    many = isinstance(weight, (list, tuple))
+    cout_all = sum(w.shape[0] for w in weight) if many else weight.shape[0]
+    cin_all = weight[0].shape[1] if many else weight.shape[1]
+    n_out = cin_all if backward else cout_all
     tr = _transposed(H, W)
     if y is None:
         y = torch.empty((B, n_out, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
@@ -288,9 +288,11 @@ def _run(x, weight, backward, want_stats=False, x_amax=None, w_amax=None, y=None
     planes = PLANES
     if planes == 2:
         x_amax = amax_bits(x) if x_amax is None else x_amax
-        w_amax = amax_bits(weight) if w_amax is None else w_amax
+        if RANGE_GUARD.armed:
+            for w in (weight if many else [weight]):
+                RANGE_GUARD.record(w.detach())
     else:
-        x_amax = w_amax = None
+        x_amax = None
     stats = None
     want_stats = want_stats or bn is not None
     none6 = (None, 0, None, None, None, None)
@@ -298,41 +300,45 @@ def _run(x, weight, backward, want_stats=False, x_amax=None, w_amax=None, y=None
         if want_stats:
             tiles = int(L.gga_dense_conv3x3_tiles(B, W, H, n_out) if tr else L.gga_dense_conv3x3_tiles(B, H, W, n_out))
             stats = torch.empty((tiles, 2, n_out), dtype=torch.float64, device=x.device)
-        check(L.gga_dense_conv3x3_bn_bwd(F._p(x), F._p(_pack(weight, backward, tr, w_amax)), B, H, W, n_in, n_out,
+        wp, wa = _operand(weight, backward, tr, planes)
+        check(L.gga_dense_conv3x3_bn_bwd(F._p(x), F._p(wp), B, H, W, n_in, n_out,
                                          y.data_ptr() + 4 * y_col, ystride, int(tr), F._p(stats), planes, F._p(x_amax),
-                                         F._p(w_amax), *(bn.part(0, n_out) if bn else none6), F._stream()), 'gga_dense_conv3x3')
+                                         F._p(wa), *(bn.part(0, n_out) if bn else none6), F._stream()), 'gga_dense_conv3x3')
         if bn:
             stats = [(0, n_out, stats)]
     elif bn is None and n_out // 128 <= 16:
         # every 128-channel slice of the output in ONE launch (gga_dense_conv3x3_levels with the slices as entries): a
         # 62 x 54 map is 224 tiles per slice - half of what the chip holds at once
         import ctypes as C
+        assert not many
         n = n_out // 128
         th, tw = (W, H) if tr else (H, W)
         rows = 16 if B * _cdiv(tw, 32) * _cdiv(th, 16) >= 384 else 8           # dc_tile_rows of the C side
         tiles = B * _cdiv(tw, 32) * _cdiv(th, rows)
-        wps = [_pack(weight[:, c0:c0 + 128] if backward else weight[c0:c0 + 128], backward, tr, w_amax) for c0 in range(0, n_out, 128)]
+        ops = [_operand(weight, backward, tr, planes, c0) for c0 in range(0, n_out, 128)]      # slices of one weight: one absmax slot
+        wa = ops[0][1]
         sts = [torch.empty((tiles, 2, 128), dtype=torch.float64, device=x.device) for _ in range(n)] if want_stats else None
         vp, i32 = C.c_void_p * n, C.c_int32 * n
         check(L.gga_dense_conv3x3_levels(
-            n, vp(*[x.data_ptr()] * n), i32(*[H] * n), i32(*[W] * n), vp(*[w.data_ptr() for w in wps]), B, n_in, 128,
+            n, vp(*[x.data_ptr()] * n), i32(*[H] * n), i32(*[W] * n), vp(*[w.data_ptr() for w, _ in ops]), B, n_in, 128,
             vp(*[y.data_ptr() + 4 * (y_col + c0) for c0 in range(0, n_out, 128)]), ystride, planes,
-            vp(*[x_amax.data_ptr()] * n) if planes == 2 else None, F._p(w_amax), None, rows, int(tr),
+            vp(*[x_amax.data_ptr()] * n) if planes == 2 else None, F._p(wa), None, rows, int(tr),
             vp(*[t.data_ptr() for t in sts]) if sts else None, F._stream()), 'gga_dense_conv3x3_levels')
         if sts:
             stats = torch.cat(sts, dim=2)           # [tiles, 2, n_out]
     else:
+        assert not many
         parts = []
         for c0 in range(0, n_out, 128):             # strided views: packed straight from the parameter
-            wv = weight[:, c0:c0 + 128] if backward else weight[c0:c0 + 128]
+            wp, wa = _operand(weight, backward, tr, planes, c0)
             st = None
             if want_stats:                          # per-channel sums of this 128-channel block of the output
                 tiles = int(L.gga_dense_conv3x3_tiles(B, W, H, 128) if tr else L.gga_dense_conv3x3_tiles(B, H, W, 128))
                 st = torch.empty((tiles, 2, 128), dtype=torch.float64, device=x.device)
                 parts.append((c0, 128, st))
-            check(L.gga_dense_conv3x3_bn_bwd(F._p(x), F._p(_pack(wv, backward, tr, w_amax)), B, H, W, n_in, 128,
+            check(L.gga_dense_conv3x3_bn_bwd(F._p(x), F._p(wp), B, H, W, n_in, 128,
                                              y.data_ptr() + 4 * (y_col + c0), ystride, int(tr), F._p(st), planes, F._p(x_amax),
-                                             F._p(w_amax), *(bn.part(c0, 128) if bn else none6), F._stream()),
+                                             F._p(wa), *(bn.part(c0, 128) if bn else none6), F._stream()),
                   'gga_dense_conv3x3_slice')
         if bn:
             stats = parts
@@ -355,8 +361,12 @@ def _wgrad(x, gy, weight, x_amax=None, g_amax=None, g_per_block=False):
     ``g_amax`` holds one absmax per 64-channel block of ``gy`` (two-plane arithmetic)."""
     L = _lib.lib()
     B, cin, H, W = x.shape
-    cout = weight.shape[0]
-    gw = torch.empty_like(weight)
+    if isinstance(weight, (list, tuple)):        # the concatenation of these weights along cout: one gradient tensor for all
+        cout = sum(w.shape[0] for w in weight)
+        gw = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=x.device).contiguous(memory_format=torch.channels_last)
+    else:
+        cout = weight.shape[0]
+        gw = torch.empty_like(weight)
     s = gw.stride()
     ws = F._workspace('dense_wgrad', L.gga_dense_wgrad3x3_workspace_bytes(B, H, W, cin, cout), x.device)
     tr = _cdiv(H, 32) * 32 * W < 0.97 * _cdiv(W, 32) * 32 * H        # 32-pixel strips along H waste less
@@ -378,10 +388,9 @@ class _Conv3x3(torch.autograd.Function):
         cout, cin = weight.shape[0], weight.shape[1]
         two = PLANES == 2
         x_amax = tensor_amax(x) if two else None
-        w_amax = amax_bits(weight.detach()) if two else None
-        y, stats = _run(x, weight.detach(), False, want_stats, x_amax, w_amax)
+        y, stats = _run(x, weight.detach(), False, want_stats, x_amax)
         ctx.save_for_backward(x, weight)
-        ctx.amax = (x_amax, w_amax)
+        ctx.amax = (x_amax, None)
         # x = relu(bn(.)) with this convolution as its consumer: the backward-data pass then does that BatchNorm's reduce
         ctx.bn_src = bn_source(x, cin) if BN_BWD_FUSED else None
         if stats is None:
@@ -431,10 +440,12 @@ def _run_levels(xs, weight, backward, x_amaxes, w_amax, bias=None):
     ys = [torch.empty((B, n_out, x.shape[2], x.shape[3]), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
           for x in xs]
     planes = PLANES
-    packs = []
+    packs, w_amax = [], None
     for c0 in range(0, n_out, width):
-        wv = weight if width == n_out else (weight[:, c0:c0 + width] if backward else weight[c0:c0 + width])
-        packs.append((c0, _pack(wv, backward, False, w_amax if planes == 2 else None)))
+        wp, w_amax = _operand(weight, backward, False, planes, None if width == n_out else c0)
+        packs.append((c0, wp))
+    if planes == 2 and RANGE_GUARD.armed:
+        RANGE_GUARD.record(weight)
     entries = [(x, y, c0, wp, a) for c0, wp in packs for x, y, a in zip(xs, ys, x_amaxes)]
     # maps with enough 16-row tiles run the 512-thread form (as gga_dense_conv3x3_planes would pick for them), the small
     # ones the 8-row form: two launches
@@ -463,10 +474,9 @@ class _Conv3x3Levels(torch.autograd.Function):
     def forward(ctx, weight, bias, *xs):
         two = PLANES == 2
         x_amaxes = [tensor_amax(x) if two else None for x in xs]
-        w_amax = amax_bits(weight.detach()) if two else None
-        ys = _run_levels(xs, weight.detach(), False, x_amaxes, w_amax, None if bias is None else bias.detach().contiguous())
+        ys = _run_levels(xs, weight.detach(), False, x_amaxes, None, None if bias is None else bias.detach().contiguous())
         ctx.save_for_backward(weight, *xs)
-        ctx.amax = (x_amaxes, w_amax)
+        ctx.amax = (x_amaxes, None)
         return tuple(ys)
 
     @staticmethod

@@ -1009,9 +1009,8 @@ class _HeadBranches(torch.autograd.Function):
         # the first convolutions two branches at a time (64 -> 128 channels into adjacent column blocks of Y): the
         # 128-channel form of the kernel stages and splits the shared input once for both
         pair_stats = {}
-        for i in range(0, n - 1, 2):
-            wpair = torch.cat([w1[i].detach(), w1[i + 1].detach()], dim=0)
-            _, st = dense_conv._run(x, wpair, False, True, x_amax, None, Y, C * i)
+        for i in range(0, n - 1, 2):          # (the pair's operand is assembled from the two parameters by the weight bank: no cat)
+            _, st = dense_conv._run(x, [w1[i].detach(), w1[i + 1].detach()], False, True, x_amax, None, Y, C * i)
             pair_stats[i], pair_stats[i + 1] = st[:, :, :C].contiguous(), st[:, :, C:].contiguous()
         for i in range(n):
             eps, momentum = cfg[i]
@@ -1070,10 +1069,9 @@ class _HeadBranches(torch.autograd.Function):
                                       _p(wsb), wsb.numel(),
                                       _stream()), 'gga_head_tail_bwd')
             gw2.append(gw), gb2.append(gb), ggam.append(gg), gbet.append(gbeta)
-        wcat = torch.cat([w.detach() for w in w1], dim=0)            # [64n, 64, 3, 3]
-        w_amax = dense_conv.amax_bits(wcat) if dense_conv.PLANES == 2 else None
+        wcat = [w.detach() for w in w1]            # stands for the [64n, 64, 3, 3] concatenation (weight bank: never made)
         g_amax = g_blocks.max().reshape(1) if g_blocks is not None else None       # (bits of non-negative floats order like ints)
-        gx = dense_conv.run_bn_bwd(G, wcat, g_amax, w_amax, ctx.bn_src) if ctx.needs_input_grad[0] else None
+        gx = dense_conv.run_bn_bwd(G, wcat, g_amax, None, ctx.bn_src) if ctx.needs_input_grad[0] else None
         gwcat = dense_conv._wgrad(x, G, wcat, ctx.x_amax if dense_conv.PLANES == 2 else None, g_blocks, g_per_block=True)
         gw1 = list(gwcat.split(C, dim=0))
         none = [None] * n

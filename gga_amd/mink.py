@@ -22,6 +22,15 @@ oracle/mink_ref.py. With tensor stride ``ts`` (coordinates are multiples of it):
 * quantisation of input points: ``floor``, one point per voxel (MinkowskiEngine's default mode keeps an arbitrary one;
   here: the first in input order).
 
+**Kernel-offset order, and what it means for checkpoints.** The 27 (8) offsets of a convolution (generative transposed
+convolution) are numbered here with the FIRST spatial axis slowest: k = 9 k1 + 3 k2 + k3 (children o = 4 o1 + 2 o2 + o3);
+oracle/mink_ref.py uses the same numbering, so the tests cannot tell it from any other. MinkowskiEngine's own ``kernel_region``
+iterator is un-vendored and its order is NOT pinned here (as far as its published source reads, it advances the first
+spatial axis FASTEST). Training from scratch is indifferent to the numbering (the initialisation is symmetric under it); a
+``state_dict`` trained with MinkowskiEngine would load without an error and compute with permuted kernels. Until one tensor
+from a real MinkowskiEngine convolution with an asymmetric kernel pins the order, **checkpoints are not interchangeable with
+the reference's FCAF3D**; ``reorder_kernel_offsets`` converts a kernel between the two numberings for whoever has such a file.
+
 Convolutions run on the gather-GEMM kernels of the sparse 3D trunk (``strided_conv._apply`` / ``_wgrad``: forward,
 backward-data and the deterministic weight gradient) through rule books built by ``gga_sparse_rulebook`` on the hash index
 of ``sparse._Level``; coordinates are kept per level in units of the tensor stride and shifted to be non-negative."""
@@ -34,6 +43,14 @@ from . import _lib
 from . import functional as F
 from ._lib import check
 from .sparse import _Level, _Rulebook, _i3
+
+def reorder_kernel_offsets(kernel, kernel_size):
+    """``kernel`` [kernel_size^3, Cin, Cout] numbered with the first spatial axis FASTEST (k = k1 + K k2 + K^2 k3) -> the
+    numbering of this module (first axis slowest), or back: the permutation is its own inverse."""
+    K = int(kernel_size)
+    idx = torch.arange(K ** 3, device=kernel.device).reshape(K, K, K).permute(2, 1, 0).reshape(-1)
+    return kernel[idx]
+
 
 ALIGN = 64          # the shift that makes coordinates non-negative is a multiple of this (the coarsest tensor stride used)
 

@@ -399,14 +399,22 @@ class _SparseConvFn(torch.autograd.Function):
         y = torch.empty((n_out, cout), dtype=torch.float32, device=feats.device)
         two = SPLIT_BF16 and planes() == 2
         x_amax = amax_bits(feats) if two else None
-        w_amax = amax_bits(w.detach()) if two else None
+        banked = SPLIT_BF16 and cout <= 128 and w.data_ptr() == weight.data_ptr()      # the parameter itself: its operands live in the weight bank
+        w_amax = amax_bits(w.detach()) if two and not banked else None
         # the per-channel sums of y for the BatchNorm that follows (split-plane kernels; widths the fused BatchNorm takes)
         stats = None
         if SPLIT_BF16 and cout % 4 == 0 and cout <= 128 and n_out >= 1:
             stats = torch.empty((int(_lib.lib().gga_sparse_conv_apply_tiles(n_out)), 2, cout), dtype=torch.float64, device=feats.device)
-        _conv_apply(feats, rb, _pack_weight(w, kvol, cin, cout, 0, w_amax=w_amax), n_out, kvol, cin, cout, 0, y, x_amax, w_amax, stats)
+        if banked:
+            from . import dense_conv, weight_bank
+            wp, w_amax = weight_bank.gather_operand(w.detach().reshape(kvol, cin, cout), planes())
+            if two and dense_conv.RANGE_GUARD.armed:
+                dense_conv.RANGE_GUARD.record(w.detach())
+        else:
+            wp = _pack_weight(w, kvol, cin, cout, 0, w_amax=w_amax)
+        _conv_apply(feats, rb, wp, n_out, kvol, cin, cout, 0, y, x_amax, w_amax, stats)
         ctx.save_for_backward(feats, w)
-        ctx.rb, ctx.rb_t, ctx.amax = rb, rb_t, (x_amax, w_amax)
+        ctx.rb, ctx.rb_t, ctx.amax, ctx.banked = rb, rb_t, (x_amax, w_amax), banked
         # feats = relu(bn(.)) with this convolution as its consumer: the backward-data pass then does that BatchNorm's reduce
         from . import dense_conv
         ctx.bn_src = dense_conv.bn_source(feats, cin) if (SPLIT_BF16 and cin % 4 == 0) else None
@@ -429,7 +437,11 @@ class _SparseConvFn(torch.autograd.Function):
         g_amax = amax_bits(gy) if x_amax is not None else None        # one pass for both consumers of gy
         if ctx.needs_input_grad[0]:
             gx = torch.empty_like(feats)
-            wt = _pack_weight(w, kvol, cout, cin, 1, w_amax=w_amax)   # W[k]^T in fragment order
+            if ctx.banked:                    # W[k]^T: the transposed view of the parameter, from the weight bank
+                from . import weight_bank
+                wt, w_amax = weight_bank.gather_operand(w.detach().reshape(kvol, cin, cout).transpose(1, 2), planes())
+            else:
+                wt = _pack_weight(w, kvol, cout, cin, 1, w_amax=w_amax)   # W[k]^T in fragment order
             tb, flip = (rb_t, 0) if rb_t is not None else (rb, 1)     # SubM: transposed map = reversed offsets
             src = ctx.bn_src
             if src is not None:

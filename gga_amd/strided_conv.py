@@ -83,16 +83,24 @@ def _amax(t):
     return dense_conv.tensor_amax(t) if dense_conv.PLANES == 2 else None
 
 
-def _apply(x_rows, m, mask, perm, w_kio, n_rows, x_amax=None, w_amax=None, want_stats=False):
+def _apply(x_rows, m, mask, perm, w_kio, n_rows, x_amax=None, w_amax=None, want_stats=False, bank=False):
     """y [n_rows, cout] = sum_k x_rows[m[k]] @ w_kio[k]  (w_kio [kvol, cin, cout]). ``x_amax`` / ``w_amax``: absmax
     bits of the operands (two-plane arithmetic), computed here when missing. ``want_stats``: also return the f64
-    [workgroups, 2, cout] per-channel sums of y for the BatchNorm that follows (``gga_sparse_conv_apply_stats``)."""
+    [workgroups, 2, cout] per-channel sums of y for the BatchNorm that follows (``gga_sparse_conv_apply_stats``).
+    ``bank``: ``w_kio`` is a VIEW ([kvol, cin, cout] or [k, k, cin, cout], any strides) of a parameter that lives across
+    steps - its operand and absmax then come from the weight bank (refreshed with all others once per optimizer step)
+    instead of a pack + absmax launch per call."""
     L = _lib.lib()
-    kvol, cin, cout = w_kio.shape
+    kvol, cin, cout = (w_kio.shape[0] * w_kio.shape[1], w_kio.shape[2], w_kio.shape[3]) if w_kio.dim() == 4 else w_kio.shape
     planes = _planes()
     if planes == 2:
         x_amax = _amax(x_rows) if x_amax is None else x_amax
-        w_amax = _amax(w_kio) if w_amax is None else w_amax
+        if not bank:
+            w_amax = _amax(w_kio) if w_amax is None else w_amax
+        else:
+            from . import dense_conv
+            if dense_conv.RANGE_GUARD.armed:
+                dense_conv.RANGE_GUARD.record(w_kio.detach())
     else:
         x_amax = w_amax = None
     y = torch.empty((n_rows, cout), dtype=torch.float32, device=x_rows.device)
@@ -100,9 +108,13 @@ def _apply(x_rows, m, mask, perm, w_kio, n_rows, x_amax=None, w_amax=None, want_
     parts = []
     for c0 in range(0, cout, 128):
         c1 = min(c0 + 128, cout)
-        wp = torch.empty(L.gga_sparse_split_weight_bytes(kvol, cin, c1 - c0) // 2, dtype=torch.int16, device=y.device)
-        check(L.gga_sparse_pack_weight_planes(F._p(w_kio[:, :, c0:c1].contiguous()), kvol, cin, c1 - c0, 0, planes, F._p(w_amax),
-                                              F._p(wp), F._stream()), 'gga_sparse_pack_weight_split')
+        if bank:
+            from . import weight_bank
+            wp, w_amax = weight_bank.gather_operand(w_kio, planes, c0, c1)
+        else:
+            wp = torch.empty(L.gga_sparse_split_weight_bytes(kvol, cin, c1 - c0) // 2, dtype=torch.int16, device=y.device)
+            check(L.gga_sparse_pack_weight_planes(F._p(w_kio[:, :, c0:c1].contiguous()), kvol, cin, c1 - c0, 0, planes, F._p(w_amax),
+                                                  F._p(wp), F._stream()), 'gga_sparse_pack_weight_split')
         st = torch.empty((tiles, 2, c1 - c0), dtype=torch.float64, device=y.device) if want_stats else None
         check(L.gga_sparse_conv_apply_stats(F._p(x_rows), F._p(m), F._p(wp), F._p(perm), F._p(mask), n_rows, kvol, cin,
                                             c1 - c0, 0, y.data_ptr() + 4 * c0, cout, planes, F._p(x_amax), F._p(w_amax),
@@ -148,11 +160,10 @@ class _StridedConv(torch.autograd.Function):
         B, cin, H, W = x.shape
         bk = book(B, H, W, k, s, p, x.device)
         w = weight.detach()
-        x_amax, w_amax = _amax(x), _amax(w)
-        y, stats = _apply(_rows(x), bk.fwd, bk.fwd_mask, bk.fwd_perm, w.permute(2, 3, 1, 0).reshape(k * k, cin, -1), bk.n_out,
-                          x_amax, w_amax, want_stats=True)
+        x_amax = _amax(x)
+        y, stats = _apply(_rows(x), bk.fwd, bk.fwd_mask, bk.fwd_perm, w.permute(2, 3, 1, 0), bk.n_out, x_amax, want_stats=True, bank=True)
         ctx.save_for_backward(x, weight)
-        ctx.geom, ctx.amax = (k, s, p), (x_amax, w_amax)
+        ctx.geom, ctx.amax = (k, s, p), (x_amax, None)
         ctx.mark_non_differentiable(stats)
         return y.view(B, bk.Ho, bk.Wo, -1).permute(0, 3, 1, 2), stats
 
@@ -170,7 +181,7 @@ class _StridedConv(torch.autograd.Function):
         g_amax = _amax(gy)
         if ctx.needs_input_grad[0]:
             w = weight.detach()
-            gx = _apply(g_rows, bk.bwd, bk.bwd_mask, bk.bwd_perm, w.permute(2, 3, 0, 1).reshape(k * k, cout, cin), bk.n_in, g_amax, w_amax)
+            gx = _apply(g_rows, bk.bwd, bk.bwd_mask, bk.bwd_perm, w.permute(2, 3, 0, 1), bk.n_in, g_amax, bank=True)
             gx = gx.view(B, H, W, cin).permute(0, 3, 1, 2)
         if ctx.needs_input_grad[1]:
             gw = _wgrad(_rows(x), g_rows, bk.fwd, bk.n_out, x_amax, g_amax).view(k, k, cin, cout).permute(3, 2, 0, 1)
@@ -186,11 +197,10 @@ class _Deconv(torch.autograd.Function):
         B, cin, H, W = x.shape
         bk = book(B, H * s, W * s, s, s, 0, x.device)          # fwd [s*s, n_coarse] fine pixel; bwd [s*s, n_fine] coarse pixel
         w = weight.detach()
-        x_amax, w_amax = _amax(x), _amax(w)
-        y, stats = _apply(_rows(x), bk.bwd, bk.bwd_mask, bk.bwd_perm, w.permute(2, 3, 0, 1).reshape(s * s, cin, -1), bk.n_in,
-                          x_amax, w_amax, want_stats=True)
+        x_amax = _amax(x)
+        y, stats = _apply(_rows(x), bk.bwd, bk.bwd_mask, bk.bwd_perm, w.permute(2, 3, 0, 1), bk.n_in, x_amax, want_stats=True, bank=True)
         ctx.save_for_backward(x, weight)
-        ctx.s, ctx.amax = s, (x_amax, w_amax)
+        ctx.s, ctx.amax = s, (x_amax, None)
         ctx.mark_non_differentiable(stats)
         return y.view(B, H * s, W * s, -1).permute(0, 3, 1, 2), stats
 
@@ -208,7 +218,7 @@ class _Deconv(torch.autograd.Function):
         g_amax = _amax(gy)
         if ctx.needs_input_grad[0]:
             w = weight.detach()
-            gx = _apply(g_rows, bk.fwd, bk.fwd_mask, bk.fwd_perm, w.permute(2, 3, 1, 0).reshape(s * s, cout, cin), bk.n_out, g_amax, w_amax)
+            gx = _apply(g_rows, bk.fwd, bk.fwd_mask, bk.fwd_perm, w.permute(2, 3, 1, 0), bk.n_out, g_amax, bank=True)
             gx = gx.view(B, H, W, cin).permute(0, 3, 1, 2)
         if ctx.needs_input_grad[1]:      # [k][cout][cin] = sum over coarse rows of gy[fine(k, row)]^T x[row]
             gw = _wgrad(g_rows, _rows(x), bk.fwd, bk.n_out, g_amax, x_amax).view(s, s, cout, cin).permute(3, 2, 0, 1)

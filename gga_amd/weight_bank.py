@@ -1,0 +1,239 @@
+"""Packed operands of the split-plane matrix kernels for all convolution weights, refreshed by two launches per step.
+
+Every convolution on the matrix kernels needs its weight as a packed operand (16-bit planes in the kernel's stage order, one
+operand per direction - forward / backward-data -, per tile walk and per 128-column slice) and, on two fp16 planes, the weight's
+absmax. Rounds 1-3 made them at every use: one ``absmax_kernel`` and one ``*_pack_weight_kernel`` per convolution and direction
+and step (79 launches of ~5 us in the PointPillars step, ~150 in the sparse step, plus the ``torch.cat`` / ``permute().reshape()``
+copies that fed them). Weights change once per step - in the optimizer - and all of them together, so here the operands persist:
+the first request after a weight changed (its version counter) refreshes EVERY stale operand of the bank with one
+``gga_absmax_table`` and one ``gga_pack_weights_table`` launch over device-side tables (csrc/weight_bank.hip), and the rest of
+the step's requests are dictionary lookups.
+
+An operand is described by its sources: 4-D strided VIEWS ``[k0, k1, channel, column]`` of the parameters themselves (a
+``permute`` of a Conv2d weight - never a copy), each with the channel / column offset where it lands, so concatenations are
+virtual: the two first convolutions a head-branch launch covers, the 15 branch weights of the 960 -> 64 backward-data
+convolution. Sources that form one operand share one absmax slot (the scale of the operand).
+
+Streams: the refresh runs on the stream of the request that triggered it; a request from another stream waits for the refresh's
+event. Operands nobody asked for during the last ``KEEP`` refreshes are dropped (models come and go in a test process)."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import functional as F
+from ._lib import check
+
+LAYOUT_GATHER, LAYOUT_DENSE = 0, 1
+ENABLED = True          # False: every request packs on the spot (one single-entry table per request; the A/B switch)
+
+
+class PackEntry(C.Structure):
+    _fields_ = [('src', C.c_void_p), ('dst', C.c_void_p), ('amax', C.c_void_p), ('s_k0', C.c_int64), ('s_k1', C.c_int64),
+                ('s_c', C.c_int64), ('s_col', C.c_int64), ('first', C.c_int64), ('kw', C.c_int32), ('kvol', C.c_int32),
+                ('n_c', C.c_int32), ('n_col', C.c_int32), ('c0', C.c_int32), ('col0', C.c_int32), ('n_in', C.c_int32),
+                ('co', C.c_int32), ('layout', C.c_int32), ('reverse', C.c_int32)]
+
+
+class AmaxEntry(C.Structure):
+    _fields_ = [('src', C.c_void_p), ('slot', C.c_void_p), ('n', C.c_int64), ('first_block', C.c_int64)]
+
+
+def _memory_block(t):
+    """(address, floats) of the block of memory ``t``'s elements occupy when they are dense in it (any permutation of a
+    contiguous tensor: a channels-last parameter, a slice along its slowest axis); otherwise the tensor's whole storage."""
+    dims = sorted((st, sz) for st, sz in zip(t.stride(), t.shape) if sz > 1)
+    run = 1
+    for st, sz in dims:
+        if st != run:
+            store = t.untyped_storage()
+            return (store.data_ptr(), store.nbytes() // 4)
+        run *= sz
+    return (t.data_ptr(), t.numel())
+
+
+def _padded_columns(n_out):
+    return 32 * (1 if n_out <= 32 else (2 if n_out <= 64 else 4))
+
+
+class _Operand:
+    __slots__ = ('key', 'sources', 'n_in', 'n_out', 'layout', 'reverse', 'planes', 'packed', 'slot', 'versions', 'used', 'blocks')
+
+    def stale(self):
+        return any(v._version != ver for (v, _, _), ver in zip(self.sources, self.versions))
+
+
+class WeightBank:
+    KEEP = 4
+    SLOTS = 2048
+
+    def __init__(self):
+        self.ops = {}
+        self.slots = {}             # device -> int32 [SLOTS]
+        self.slot_of = {}           # (device, storage pointers of an operand's sources) -> slot index
+        self.refreshes = 0          # table launches (diagnostics)
+        self.generation = 0         # refreshes triggered by changed weights: one per optimizer step in a train loop
+        self.tables = {}            # device -> (signature of the stale set, pack table, amax table, totals)
+        self.event, self.stream = None, None
+
+    # ------------------------------------------------------------------------------------------------------------ requests
+    def operand(self, sources, n_in, n_out, layout, reverse, planes, scale_of=None):
+        """``sources``: [(view [k0, k1, n_c, n_col], c0, col0), ...] -> (packed int16 tensor, absmax slot int32 [1] or None).
+        ``scale_of``: the tensors whose largest magnitude is the operand's scale (default: the sources themselves) - the whole
+        weight when the sources are slices of it, so that all slices of a convolution share one scale."""
+        assert n_out <= 128
+        blocks = tuple(sorted({_memory_block(t) for t in (scale_of if scale_of is not None else [v for v, _, _ in sources])})) if planes == 2 else ()
+        key = (planes, layout, bool(reverse), n_in, n_out, blocks,
+               tuple((v.data_ptr(), tuple(v.shape), tuple(v.stride()), c0, col0) for v, c0, col0 in sources))
+        op = self.ops.get(key)
+        if op is None:
+            op = self._new(key, sources, n_in, n_out, layout, reverse, planes, blocks)
+            self._refresh([op])
+        elif op.stale():
+            stale = [o for o in self.ops.values() if o.stale()] if ENABLED else [op]
+            self._refresh(stale)
+            self.generation += 1
+            if self.generation % 8 == 0:          # operands nobody asked for in a while (their model is gone)
+                dead = [k for k, o in self.ops.items() if o.used < self.generation - self.KEEP * 8]
+                for k in dead:
+                    del self.ops[k]
+                if dead:
+                    self.tables.clear()
+        op.used = self.generation
+        if self.event is not None:
+            cur = torch.cuda.current_stream(op.packed.device)
+            if cur.cuda_stream != self.stream:
+                cur.wait_event(self.event)
+        return op.packed, op.slot
+
+    def _new(self, key, sources, n_in, n_out, layout, reverse, planes, blocks):
+        L = _lib.lib()
+        dev = sources[0][0].device
+        op = _Operand()
+        op.key, op.sources, op.n_in, op.n_out, op.layout, op.reverse, op.planes = key, list(sources), n_in, n_out, layout, bool(reverse), planes
+        kvol = sources[0][0].shape[0] * sources[0][0].shape[1]
+        op.packed = torch.zeros(L.gga_sparse_split_weight_bytes(kvol, n_in, n_out) // 2, dtype=torch.int16, device=dev)
+        op.versions = [-1] * len(sources)
+        op.used = self.generation
+        op.slot, op.blocks = None, []
+        if planes == 2:
+            skey = (str(dev), tuple(blocks))
+            if skey not in self.slot_of:
+                used = sum(1 for k in self.slot_of if k[0] == str(dev))
+                assert used < self.SLOTS, 'weight bank: out of absmax slots'
+                self.slot_of[skey] = used
+            if str(dev) not in self.slots:
+                self.slots[str(dev)] = torch.zeros(self.SLOTS, dtype=torch.int32, device=dev)
+            i = self.slot_of[skey]
+            op.slot, op.blocks = self.slots[str(dev)][i:i + 1], [(p, n, i) for p, n in blocks]
+        self.ops[key] = op
+        return op
+
+    # ------------------------------------------------------------------------------------------------------------- refresh
+    def _refresh(self, stale):
+        L = _lib.lib()
+        by_dev = {}
+        for op in stale:
+            by_dev.setdefault((str(op.packed.device), op.planes), []).append(op)
+        for (dev_key, planes), ops in by_dev.items():
+            dev = ops[0].packed.device
+            sig = (planes, tuple(id(o) for o in ops))
+            cached = self.tables.get((dev_key, planes))
+            if cached is None or cached[0] != sig:
+                cached = (sig,) + self._build_tables(ops, dev, planes)
+                if len(ops) > 1:
+                    self.tables[(dev_key, planes)] = cached
+            _, pack_t, n_pack, total, amax_t, n_amax, n_blocks = cached
+            with torch.cuda.device(dev):
+                if planes == 2 and n_amax:
+                    # the slots of the operands being refreshed are zeroed by their own entries' first pass: the table call
+                    # zeroes ALL slots only when everything is refreshed; a partial refresh zeroes its slots one by one
+                    if len(ops) == len(self.ops) or all(o in ops for o in self.ops.values() if o.planes == 2 and str(o.packed.device) == dev_key):
+                        check(L.gga_absmax_table(F._p(amax_t), n_amax, n_blocks, F._p(self.slots[dev_key]), self.SLOTS, F._stream()), 'gga_absmax_table')
+                    else:
+                        for i in sorted({b[2] for o in ops for b in o.blocks}):
+                            self.slots[dev_key][i:i + 1].zero_()
+                        check(L.gga_absmax_table(F._p(amax_t), n_amax, n_blocks, F._p(self.slots[dev_key]), 0, F._stream()), 'gga_absmax_table')
+                check(L.gga_pack_weights_table(F._p(pack_t), n_pack, total, planes, F._stream()), 'gga_pack_weights_table')
+            for op in ops:
+                op.versions = [v._version for v, _, _ in op.sources]
+        self.refreshes += 1
+        if stale and stale[0].packed.is_cuda:
+            dev = stale[0].packed.device
+            self.event = torch.cuda.Event()
+            cur = torch.cuda.current_stream(dev)
+            self.event.record(cur)
+            self.stream = cur.cuda_stream
+
+    def _build_tables(self, ops, dev, planes):
+        L = _lib.lib()
+        entries, first = [], 0
+        for op in ops:
+            for v, c0, col0 in op.sources:
+                k0, k1, n_c, n_col = v.shape
+                s = v.stride()
+                entries.append(PackEntry(v.data_ptr(), op.packed.data_ptr(), op.slot.data_ptr() if op.slot is not None else None,
+                                         s[0], s[1], s[2], s[3], first, k1, k0 * k1, n_c, n_col, c0, col0, op.n_in,
+                                         _padded_columns(op.n_out), op.layout, int(op.reverse)))
+                first += k0 * k1 * n_c * n_col
+        amax, n_blocks, seen = [], 0, set()
+        if planes == 2:
+            slots = self.slots[str(dev)]
+            for op in ops:
+                for ptr, n, i in op.blocks:
+                    if (ptr, i) in seen:
+                        continue
+                    seen.add((ptr, i))
+                    amax.append(AmaxEntry(ptr, slots.data_ptr() + 4 * i, n, n_blocks))
+                    n_blocks += int(L.gga_absmax_table_blocks(n))
+
+        def upload(items, ctype):
+            if not items:
+                return torch.zeros(8, dtype=torch.uint8, device=dev)
+            arr = (ctype * len(items))(*items)
+            host = torch.from_numpy(np.frombuffer(arr, dtype=np.uint8).copy())
+            return host.to(dev)
+        return upload(entries, PackEntry), len(entries), first, upload(amax, AmaxEntry), len(amax), n_blocks
+
+
+BANK = WeightBank()
+
+
+def dense_operand(weight, backward, transposed, planes, c0=None):
+    """Operand of the 3x3 stride-1 kernels for a Conv2d weight [cout, cin, 3, 3] (any strides): forward = [ky, kx, cin, cout];
+    backward-data = the cout -> cin convolution with the taps reversed; ``transposed``: the tile walk with ky and kx exchanged;
+    ``c0``: the operand of the output slice [c0, c0 + 128) (scaled like the whole weight)."""
+    full = weight.detach()
+    w = full if c0 is None else (full[:, c0:c0 + 128] if backward else full[c0:c0 + 128])
+    a, b = (3, 2) if transposed else (2, 3)
+    view = w.permute(a, b, 0, 1) if backward else w.permute(a, b, 1, 0)
+    return BANK.operand([(view, 0, 0)], view.shape[2], view.shape[3], LAYOUT_DENSE, backward, planes, scale_of=[full])
+
+
+def dense_operand_cat(weights, backward, transposed, planes):
+    """The same for the concatenation of ``weights`` along their OUTPUT channels (dim 0) without making it: forward -> the
+    columns of one operand side by side (<= 128 in all); backward-data -> its input channels one after the other."""
+    a, b = (3, 2) if transposed else (2, 3)
+    sources, off = [], 0
+    for w in weights:
+        w = w.detach()
+        if backward:
+            sources.append((w.permute(a, b, 0, 1), off, 0))
+        else:
+            sources.append((w.permute(a, b, 1, 0), 0, off))
+        off += w.shape[0]
+    cin = weights[0].shape[1]
+    n_in, n_out = (off, cin) if backward else (cin, off)
+    return BANK.operand(sources, n_in, n_out, LAYOUT_DENSE, backward, planes)
+
+
+def gather_operand(view, planes, col0=None, col1=None):
+    """Operand of the gather-GEMM kernels from a VIEW ``[k0, k1, cin, cout]`` (or ``[kvol, cin, cout]``) of a parameter -
+    W[k][c][col] -, or of its columns [col0, col1) (<= 128; scaled like the whole weight). The view must belong to a tensor
+    that lives across steps: a temporary would add an operand per step."""
+    v = view.detach()
+    if v.dim() == 3:
+        v = v.unsqueeze(0)
+    part = v if col0 is None else v[..., col0:col1]
+    return BANK.operand([(part, 0, 0)], part.shape[2], part.shape[3], LAYOUT_GATHER, False, planes, scale_of=[v])

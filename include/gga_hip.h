@@ -351,6 +351,31 @@ int gga_dense_wgrad3x3(const float* x, const float* grad_y, int B, int H, int W,
  * (fp16 has no fp32 exponent range) - see DESIGN.md 5. `planes` = 3 selects the bf16 form (no absmax needed).
  * gga_absmax_bits: bits of the largest finite |x| of a [rows, width] f32 matrix into *out_bits (device). */
 int gga_absmax_bits(const float* x, int64_t rows, int width, int64_t row_stride, uint32_t* out_bits, void* stream);
+/* Operands for MANY convolution weights in two launches (gga_amd/weight_bank.py keeps the tables; weights change once per step, all
+ * together): gga_absmax_table zeroes `slots[0 .. n_slots)` and leaves in every entry's slot the bits of the largest finite |x| of
+ * its block of `n` floats (several entries may share a slot: the absmax of their union); gga_pack_weights_table writes, per entry,
+ * kvol x n_c x n_col elements W[tap][c0 + c][col0 + col] = src[k0 * s_k0 + k1 * s_k1 + c * s_c + col * s_col] (tap = k0 * kw + k1,
+ * taken in reverse order when `reverse`) into a packed operand of n_in input channels and `co` (padded, 32 * ceil(n_out / 32) for
+ * n_out <= 128) columns in the stage layout of gga_sparse_pack_weight_planes (layout 0) or gga_dense_conv3x3_pack_planes (layout
+ * 1); padding is never written (the caller zeroes operands once). `first`: running sum of the entries' element counts; `total`:
+ * the sum; `first_block`: running sum of gga_absmax_table_blocks(n). Tables live in device memory. */
+typedef struct {
+    const float* src;
+    uint16_t* dst;
+    const uint32_t* amax;     /* absmax bits of the operand's weights (planes == 2), or NULL */
+    int64_t s_k0, s_k1, s_c, s_col;
+    int64_t first;
+    int32_t kw, kvol, n_c, n_col, c0, col0, n_in, co, layout, reverse;
+} GgaPackEntry;
+typedef struct {
+    const float* src;
+    uint32_t* slot;
+    int64_t n;
+    int64_t first_block;
+} GgaAmaxEntry;
+int64_t gga_absmax_table_blocks(int64_t n);
+int gga_absmax_table(const GgaAmaxEntry* table_device, int n_entries, int64_t n_blocks, uint32_t* slots, int n_slots, void* stream);
+int gga_pack_weights_table(const GgaPackEntry* table_device, int n_entries, int64_t total, int planes, void* stream);
 /* the gather-GEMM kernels (sparse, strided and transposed convolutions) in the same two forms */
 int gga_sparse_pack_weight_planes(const float* weight, int kvol, int cin, int cout, int transpose, int planes,
                                   const uint32_t* amax_weight, void* packed, void* stream);

@@ -1166,3 +1166,81 @@ def test_matrix_and_norm_kernels_are_repeatable_beside_another_stream(planes, mo
     _repeat_beside_noise(gn_pass)
     for m in (conv, down, one):
         _repeat_beside_noise(conv_pass(m), repeats=20)
+
+
+@pytest.mark.parametrize('planes', [2, 3])
+def test_weight_bank_operands_equal_the_per_call_packing(planes):
+    """gga_pack_weights_table / gga_absmax_table (the weight bank's two launches per step) against the per-convolution kernels
+    they replace, bit for bit: dense 3x3 operands (forward / backward-data, both tile walks, 128-channel slices of a wide
+    weight, channels-last and contiguous parameters), operands assembled from several weights against the packed torch.cat,
+    gather-GEMM operands from permuted views against the packed reshaped copy; a changed weight refreshes every operand."""
+    from gga_amd import _lib, dense_conv, weight_bank as WB
+    from gga_amd._lib import check
+    L = _lib.lib()
+    torch.manual_seed(planes)
+
+    def old_dense(w, backward, transposed):
+        cout, cin = w.shape[0], w.shape[1]
+        n_in, n_out = (cout, cin) if backward else (cin, cout)
+        wp = torch.zeros(L.gga_sparse_split_weight_bytes(9, n_in, n_out) // 2, dtype=torch.int16, device=DEV)
+        amax = dense_conv._amax_bits(w) if planes == 2 else None
+        s = w.stride()
+        sky, skx = (s[3], s[2]) if transposed else (s[2], s[3])
+        check(L.gga_dense_conv3x3_pack_planes(F._p(w), s[0], s[1], sky, skx, cin, cout, int(backward), planes, F._p(amax), F._p(wp),
+                                              F._stream()), 'pack')
+        return wp, amax
+
+    bank = WB.WeightBank()
+    ws = [torch.randn(64, 64, 3, 3, device=DEV).contiguous(memory_format=torch.channels_last) * (0.5 + i) for i in range(3)]
+    wide = torch.randn(256, 128, 3, 3, device=DEV)                       # contiguous (NCHW) parameter
+    odd = torch.randn(64, 96, 3, 3, device=DEV).contiguous(memory_format=torch.channels_last)       # 96 inputs: a half-empty last stage
+    old_bank, WB.BANK = WB.BANK, bank
+    try:
+        def check_all():
+            for w in (ws[0], odd):
+                for backward in (False, True):
+                    for tr in (False, True):
+                        got, slot = WB.dense_operand(w, backward, tr, planes)
+                        want, amax = old_dense(w, backward, tr)
+                        assert torch.equal(got, want), (tuple(w.shape), backward, tr)
+                        assert planes == 3 or torch.equal(slot, amax)
+            for backward in (False, True):                                   # slices of a wide weight share the whole weight's scale
+                n_out = wide.shape[1] if backward else wide.shape[0]
+                for c0 in range(0, n_out, 128):
+                    got, slot = WB.dense_operand(wide, backward, False, planes, c0)
+                    sl = wide[:, c0:c0 + 128] if backward else wide[c0:c0 + 128]
+                    cout, cin = sl.shape[0], sl.shape[1]
+                    n_in, n_o = (cout, cin) if backward else (cin, cout)
+                    want = torch.zeros(L.gga_sparse_split_weight_bytes(9, n_in, n_o) // 2, dtype=torch.int16, device=DEV)
+                    amax = dense_conv._amax_bits(wide) if planes == 2 else None
+                    s = sl.stride()
+                    check(L.gga_dense_conv3x3_pack_planes(F._p(sl), s[0], s[1], s[2], s[3], cin, cout, int(backward), planes, F._p(amax),
+                                                          F._p(want), F._stream()), 'pack')
+                    assert torch.equal(got, want) and (planes == 3 or torch.equal(slot, amax)), (backward, c0)
+            # virtual concatenations: two weights side by side (forward), three one after the other (backward-data)
+            got, slot = WB.dense_operand_cat(ws[:2], False, False, planes)
+            want, amax = old_dense(torch.cat(ws[:2], 0).contiguous(memory_format=torch.channels_last), False, False)
+            assert torch.equal(got, want) and (planes == 3 or torch.equal(slot, amax))
+            got, slot = WB.dense_operand_cat(ws, True, True, planes)
+            want, amax = old_dense(torch.cat(ws, 0).contiguous(memory_format=torch.channels_last), True, True)
+            assert torch.equal(got, want) and (planes == 3 or torch.equal(slot, amax))
+            # gather-GEMM operands: Conv2d weight [cout, cin, k, k] as [k, k, cin, cout] (forward) and [k, k, cout, cin] (backward-data)
+            cw = torch.randn(128, 64, 3, 3, device=DEV).contiguous(memory_format=torch.channels_last)
+            for view, n_in, n_out in ((cw.permute(2, 3, 1, 0), 64, 128), (cw.permute(2, 3, 0, 1), 128, 64)):
+                got, slot = WB.gather_operand(view, planes)
+                flat = view.reshape(9, n_in, n_out).contiguous()
+                want = torch.zeros(L.gga_sparse_split_weight_bytes(9, n_in, n_out) // 2, dtype=torch.int16, device=DEV)
+                amax = dense_conv._amax_bits(cw) if planes == 2 else None
+                check(L.gga_sparse_pack_weight_planes(F._p(flat), 9, n_in, n_out, 0, planes, F._p(amax), F._p(want), F._stream()), 'pack')
+                assert torch.equal(got, want) and (planes == 3 or torch.equal(slot, amax))
+        check_all()
+        n_ops, launches = len(bank.ops), bank.refreshes
+        assert n_ops >= 16
+        with torch.no_grad():                                               # an optimizer step: every weight changes in place
+            for w in ws + [wide, odd]:
+                w.mul_(1.7).add_(0.01)
+        check_all()
+        assert len(bank.ops) == n_ops + 2 and bank.generation == 1          # (+ the fresh cw operands of the second pass)
+        assert bank.refreshes == launches + 1 + 2                           # ONE refresh for all stale operands (+ the two new ones)
+    finally:
+        WB.BANK = old_bank

@@ -166,5 +166,8 @@ def to_channels_last(model):
     (5-D) and everything else are left alone."""
     for m in model.modules():
         if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+            if type(m) is nn.Conv2d and m.out_channels <= 4 and m.in_channels == 64 and m.kernel_size == (3, 3):
+                continue        # output convs of the head branches: gga_head_conv3x3_* read the weight as it is stored ([cout, 64, 3, 3]
+                                # contiguous); in channels-last memory every call paid a layout copy (30 per step) and so did its gradient
             m.weight.data = m.weight.data.contiguous(memory_format=torch.channels_last)
     return model

@@ -164,9 +164,16 @@ def build_optimizer(model, cfg):
     else:
         params = [p for _, p in named]
     if typ == 'AdamW':
-        return torch.optim.AdamW(params, fused=all(p.is_cuda for _, p in named), **cfg)
-    if typ == 'SGD':
-        return torch.optim.SGD(params, **cfg)
+        opt = torch.optim.AdamW(params, fused=all(p.is_cuda for _, p in named), **cfg)
+    elif typ == 'SGD':
+        opt = torch.optim.SGD(params, **cfg)
+    else:
+        raise KeyError(f'optimizer {typ} is not used by configs/gga (AdamW, SGD)')
+    # the packed operands of the convolution weights are stale after every step; torch's fused optimizers do not bump the
+    # parameters' version counters, so the weight bank is told explicitly
+    from . import weight_bank
+    opt.register_step_post_hook(lambda *_: weight_bank.BANK.invalidate())
+    return opt
     raise KeyError(f'optimizer {typ} is not used by configs/gga (AdamW, SGD)')
 
 

@@ -58,10 +58,10 @@ def _padded_columns(n_out):
 
 
 class _Operand:
-    __slots__ = ('key', 'sources', 'n_in', 'n_out', 'layout', 'reverse', 'planes', 'packed', 'slot', 'versions', 'used', 'blocks')
+    __slots__ = ('key', 'sources', 'n_in', 'n_out', 'layout', 'reverse', 'planes', 'packed', 'slot', 'versions', 'used', 'blocks', 'epoch')
 
-    def stale(self):
-        return any(v._version != ver for (v, _, _), ver in zip(self.sources, self.versions))
+    def stale(self, epoch):
+        return self.epoch != epoch or any(v._version != ver for (v, _, _), ver in zip(self.sources, self.versions))
 
 
 class WeightBank:
@@ -76,6 +76,14 @@ class WeightBank:
         self.generation = 0         # refreshes triggered by changed weights: one per optimizer step in a train loop
         self.tables = {}            # device -> (signature of the stale set, pack table, amax table, totals)
         self.event, self.stream = None, None
+        self.epoch = 0              # bumped by invalidate(): every operand made before is stale
+
+    def invalidate(self):
+        """Every weight may have changed. Needed after updates that do not bump the tensors' version counters - torch's FUSED
+        optimizers do not (``torch.optim.AdamW(fused=True)`` leaves ``param._version`` alone) -; ``train.build_optimizer``
+        registers it as a step hook of every optimizer it builds. In-place torch ops, ``load_state_dict`` and non-fused
+        optimizers are noticed through the version counters without it."""
+        self.epoch += 1
 
     # ------------------------------------------------------------------------------------------------------------ requests
     def operand(self, sources, n_in, n_out, layout, reverse, planes, scale_of=None):
@@ -90,8 +98,8 @@ class WeightBank:
         if op is None:
             op = self._new(key, sources, n_in, n_out, layout, reverse, planes, blocks)
             self._refresh([op])
-        elif op.stale():
-            stale = [o for o in self.ops.values() if o.stale()] if ENABLED else [op]
+        elif op.stale(self.epoch):
+            stale = [o for o in self.ops.values() if o.stale(self.epoch)] if ENABLED else [op]
             self._refresh(stale)
             self.generation += 1
             if self.generation % 8 == 0:          # operands nobody asked for in a while (their model is gone)
@@ -115,6 +123,7 @@ class WeightBank:
         kvol = sources[0][0].shape[0] * sources[0][0].shape[1]
         op.packed = torch.zeros(L.gga_sparse_split_weight_bytes(kvol, n_in, n_out) // 2, dtype=torch.int16, device=dev)
         op.versions = [-1] * len(sources)
+        op.epoch = -1
         op.used = self.generation
         op.slot, op.blocks = None, []
         if planes == 2:
@@ -144,20 +153,17 @@ class WeightBank:
                 cached = (sig,) + self._build_tables(ops, dev, planes)
                 if len(ops) > 1:
                     self.tables[(dev_key, planes)] = cached
-            _, pack_t, n_pack, total, amax_t, n_amax, n_blocks = cached
+            _, pack_t, n_pack, total, amax_t, n_amax, n_blocks, slot_idx = cached
             with torch.cuda.device(dev):
                 if planes == 2 and n_amax:
-                    # the slots of the operands being refreshed are zeroed by their own entries' first pass: the table call
-                    # zeroes ALL slots only when everything is refreshed; a partial refresh zeroes its slots one by one
-                    if len(ops) == len(self.ops) or all(o in ops for o in self.ops.values() if o.planes == 2 and str(o.packed.device) == dev_key):
-                        check(L.gga_absmax_table(F._p(amax_t), n_amax, n_blocks, F._p(self.slots[dev_key]), self.SLOTS, F._stream()), 'gga_absmax_table')
-                    else:
-                        for i in sorted({b[2] for o in ops for b in o.blocks}):
-                            self.slots[dev_key][i:i + 1].zero_()
-                        check(L.gga_absmax_table(F._p(amax_t), n_amax, n_blocks, F._p(self.slots[dev_key]), 0, F._stream()), 'gga_absmax_table')
+                    # only the slots of the operands being refreshed start from zero (operands of other, unchanged weights keep
+                    # theirs): one index_fill over their indices, then the table pass
+                    self.slots[dev_key].index_fill_(0, slot_idx, 0)
+                    check(L.gga_absmax_table(F._p(amax_t), n_amax, n_blocks, F._p(self.slots[dev_key]), 0, F._stream()), 'gga_absmax_table')
                 check(L.gga_pack_weights_table(F._p(pack_t), n_pack, total, planes, F._stream()), 'gga_pack_weights_table')
             for op in ops:
                 op.versions = [v._version for v, _, _ in op.sources]
+                op.epoch = self.epoch
         self.refreshes += 1
         if stale and stale[0].packed.is_cuda:
             dev = stale[0].packed.device
@@ -194,7 +200,8 @@ class WeightBank:
             arr = (ctype * len(items))(*items)
             host = torch.from_numpy(np.frombuffer(arr, dtype=np.uint8).copy())
             return host.to(dev)
-        return upload(entries, PackEntry), len(entries), first, upload(amax, AmaxEntry), len(amax), n_blocks
+        slot_idx = torch.tensor(sorted({i for op in ops for _, _, i in op.blocks}) or [0], dtype=torch.long).to(dev)
+        return upload(entries, PackEntry), len(entries), first, upload(amax, AmaxEntry), len(amax), n_blocks, slot_idx
 
 
 BANK = WeightBank()

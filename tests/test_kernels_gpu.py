@@ -1235,12 +1235,24 @@ def test_weight_bank_operands_equal_the_per_call_packing(planes):
                 assert torch.equal(got, want) and (planes == 3 or torch.equal(slot, amax))
         check_all()
         n_ops, launches = len(bank.ops), bank.refreshes
-        assert n_ops >= 16
+        assert n_ops >= 15
         with torch.no_grad():                                               # an optimizer step: every weight changes in place
             for w in ws + [wide, odd]:
                 w.mul_(1.7).add_(0.01)
         check_all()
         assert len(bank.ops) == n_ops + 2 and bank.generation == 1          # (+ the fresh cw operands of the second pass)
         assert bank.refreshes == launches + 1 + 2                           # ONE refresh for all stale operands (+ the two new ones)
+        # torch's fused optimizers update the parameters without touching their version counters: the step hook that
+        # train.build_optimizer registers (weight_bank.BANK.invalidate) is what tells the bank
+        params = [torch.nn.Parameter(w) for w in ws + [wide, odd]]          # (share the tensors' memory)
+        opt = torch.optim.AdamW(params, lr=0.1, fused=True)
+        opt.register_step_post_hook(lambda *_: bank.invalidate())
+        for p in params:
+            p.grad = torch.randn_like(p)
+        before = ws[0].clone()
+        opt.step()
+        assert not torch.equal(ws[0], before)
+        check_all()
+        assert bank.generation == 2
     finally:
         WB.BANK = old_bank

@@ -283,7 +283,7 @@ def test_wide_head_with_groupnorm_and_dcn_runs_the_hip_kernels_and_matches_the_r
     assert isinstance(head.cls_convs[-1].conv, ModulatedDeformConv2dPack) and isinstance(head.cls_convs[0].gn, torch.nn.GroupNorm)
     L = _lib.lib()
     calls = {}
-    for name in ('gga_dense_conv3x3_bn_bwd', 'gga_dense_conv3x3_levels', 'gga_dense_wgrad3x3_planes', 'gga_gn_relu_fwd', 'gga_gn_relu_bwd',
+    for name in ('gga_dense_conv3x3_bn_bwd', 'gga_dense_conv3x3_levels', 'gga_dense_wgrad3x3_block_amax', 'gga_gn_relu_fwd', 'gga_gn_relu_bwd',
                  'gga_dcn_im2col_amax', 'gga_dcn_col2im'):
         if hasattr(L, name):
             def counted(*a, _real=getattr(L, name), _n=name):
@@ -323,7 +323,7 @@ def test_wide_head_with_groupnorm_and_dcn_runs_the_hip_kernels_and_matches_the_r
     # the HIP paths ran: dense 3x3 convolutions forward (per level or over the levels) and their weight gradients,
     # fused GroupNorm + ReLU both ways, DCN sampling both ways
     assert calls.get('gga_dense_conv3x3_bn_bwd', 0) + calls.get('gga_dense_conv3x3_levels', 0) >= 8, calls
-    assert calls.get('gga_dense_wgrad3x3_planes', 0) >= 4 and calls.get('gga_gn_relu_fwd', 0) >= 4 and calls.get('gga_gn_relu_bwd', 0) >= 4, calls
+    assert calls.get('gga_dense_wgrad3x3_block_amax', 0) >= 4 and calls.get('gga_gn_relu_fwd', 0) >= 4 and calls.get('gga_gn_relu_bwd', 0) >= 4, calls
     assert calls.get('gga_dcn_im2col_amax', 0) >= 2, calls
 
 

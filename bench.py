@@ -385,12 +385,12 @@ def sparse_roofline(run, args, steps=4):
     avg = sum(ms) / len(ms)
     traffic, src = None, None
     try:
-        pmc = json.load(open(os.path.join(REPO, 'profiles', 'r03_second_pmc.json')))
+        pmc = json.load(open(os.path.join(REPO, 'profiles', 'r04_second_pmc.json')))
         ks = [k for k in pmc['kernels'] if k['kernel'].startswith('sp_conv_halo_kernel<4' if halo else 'sp_conv_x9_kernel<4') and 'hbm_bytes_per_launch' in k
               and k['avg_us'] > 500]
         if ks and args.second_batch == 8:
             traffic = int(sum(k['hbm_bytes_per_launch'] * k['launches_per_pass'] for k in ks) / sum(k['launches_per_pass'] for k in ks))
-            src = 'profiles/r03_second_pmc.json (separate --pmc FETCH_SIZE / WRITE_SIZE passes over tools_dev/pmc_target_second.py, not this run)'
+            src = 'profiles/r04_second_pmc.json (separate --pmc FETCH_SIZE / WRITE_SIZE passes over tools_dev/pmc_target_second.py, not this run)'
     except (OSError, KeyError, ValueError):
         pass
     gbs = algo / (avg * 1e-3) / 1e9

@@ -1,5 +1,5 @@
 # PMC passes over a few steps of the shipped config (tools_dev/pmc_target_second.py), one counter group per pass, summarised
-# per kernel into gpurun_out/r03_second_pmc.json (copy to profiles/). Raw outputs stay on the box (/tmp/pmc).
+# per kernel into gpurun_out/r04_second_pmc.json (copy to profiles/). Raw outputs stay on the box (/tmp/pmc).
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 mkdir -p /tmp/pmc
@@ -9,4 +9,4 @@ for c in "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc/s$i -- python3 $R/tools_dev/pmc_target_second.py 3 > /tmp/pmc/slog$i.txt 2>&1 || echo "pass $i failed: $c"
   dirs="$dirs /tmp/pmc/s$i"
 done
-python3 $R/tools_dev/pmc_kernels_summary.py $R/gpurun_out/r03_second_pmc.json $dirs | head -12
+python3 $R/tools_dev/pmc_kernels_summary.py $R/gpurun_out/r04_second_pmc.json $dirs | head -12

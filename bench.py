@@ -19,8 +19,8 @@ children's status. With fewer visible devices than ranks the ranks share devices
 functional check, reported as such in ``config.backend``).
 
 Rank 0 prints ONE JSON line; ``roofline`` is the pillar scatter (BASELINE's HBM metric),
-``mfma_roofline`` the 64 -> 64 dense 3x3 convolution at the head's map size (its share of the step is in the
-object), both timed with
+``mfma_roofline`` the 128 -> 128 dense 3x3 convolutions of SECOND's second stage (the dominant instantiation of the dense
+kernel; its share of the step is in the object), both timed with
 HIP events inside the timed steps; ``second_trunk`` is the reference's shipped model
 (configs/gga/gga_kitti_config.py: sparse-conv trunk, BASELINE config #3's per-GPU workload, bs 8)
 and ``pgd_trunk`` the camera-only retraining model (configs/gga/gga_pdg.py, BASELINE config #5, bs 12)
@@ -563,10 +563,11 @@ def main():
         from gga_amd import Config
         me = Config.fromfile(args.config).model.pts_middle_encoder
         fh, fw = me.output_shape[0] // 2, me.output_shape[1] // 2
-        # one pair per step around the scatter op; one per 64 -> 64 dense 3x3 convolution at the head's map size
-        # (forward and backward-data of the first conv of the 15 head branches and of SECOND block 1)
+        # one pair per step around the scatter op; one per 128 -> 128 dense 3x3 convolution of SECOND's second stage (half the
+        # head's map size; forward and backward-data): the launches of dense_conv3x3_x9_kernel<4, 16, 2, 2, 0>, the
+        # instantiation the largest share of the step's time is in
         sites = [(_lib.TIME_SCATTER_FWD, args.steps, 0),
-                 (_lib.TIME_DENSE_CONV, 36 * args.steps, _lib.timing_conv_key(64, 64, fh * fw))]
+                 (_lib.TIME_DENSE_CONV, 36 * args.steps, _lib.timing_conv_key(128, 128, (fh // 2) * (fw // 2)))]
     main_run = run_workload(args.config, args.batch, args.steps, args.warmup, args, rank, world, device, sites)
     dt = main_run['dt']
     ms_per_step = dt / args.steps * 1e3
@@ -592,8 +593,8 @@ def main():
         if tm.get(_lib.TIME_SCATTER_FWD):
             res['roofline'] = scatter_roofline(main_run['model'], main_run['batches'], tm[_lib.TIME_SCATTER_FWD])
         if tm.get(_lib.TIME_DENSE_CONV):
-            flops = 2.0 * args.batch * fh * fw * 64 * 64 * 9
-            res['mfma_roofline'] = mfma_roofline('dense_conv3x3_x9_kernel<2,8> (64->64, %dx%d, fwd + bwd-data)' % (fh, fw),
+            flops = 2.0 * args.batch * (fh // 2) * (fw // 2) * 128 * 128 * 9
+            res['mfma_roofline'] = mfma_roofline('dense_conv3x3_x9_kernel<4,16,2,2,0> (128->128, %dx%d, fwd + bwd-data)' % (fh // 2, fw // 2),
                                                  flops, tm[_lib.TIME_DENSE_CONV],
                                                  len(tm[_lib.TIME_DENSE_CONV]) / args.steps, ms_per_step, main_run['runner'].planes)
         res['config']['matrix_planes'] = main_run['runner'].planes          # what the timed steps ran on (2 unless the guard fell back)

@@ -1,7 +1,8 @@
 # GGA on KITTI, SECOND-style sparse-conv trunk — the model / optimisation settings of the
 # reference's configs/gga/gga_kitti_config.py (same keys and values, so the reference file
 # itself also loads unchanged through gga_amd.config.Config; see tests/test_model_cpu.py).
-# The dataset section is replaced by synthetic KITTI-shaped frames (gga_amd/synthetic.py).
+# bench.py and the parity tests feed synthetic KITTI-shaped frames (gga_amd/synthetic.py); the train dataset section below is
+# the reference's (configs/gga/gga_kitti_config.py:92-205), read by tools/train.py / gga_amd.train.train_detector.
 voxel_size = [0.05, 0.05, 0.1]
 point_cloud_range = [0, -40, -3, 70.4, 40, 1]
 bn = dict(type='BN', eps=1e-3, momentum=0.01)
@@ -43,7 +44,28 @@ model = dict(
         max_pool_nms=False, min_radius=[4, 12, 10, 1, 0.85, 0.175], score_threshold=0.1, out_size_factor=4,
         voxel_size=voxel_size[:2], nms_type='rotate', pre_max_size=4096, post_max_size=512, nms_thr=0.2)))
 
-data = dict(samples_per_gpu=32, workers_per_gpu=4)
+dataset_type = 'KittiDataset_GGA_train'
+data_root = 'data/kitti/'
+class_names = ['Pedestrian', 'Cyclist', 'Car']
+input_modality = dict(use_lidar=True, use_camera=True)
+db_sampler = dict(data_root=data_root, info_path=data_root + 'kitti_dbinfos_train_GGA.pkl', rate=1.0,
+                  prepare=dict(filter_by_difficulty=[-1], filter_by_min_points=dict(Car=5, Pedestrian=10, Cyclist=10)),
+                  classes=class_names, sample_groups=dict(Car=12, Pedestrian=10, Cyclist=10))
+train_pipeline = [
+    dict(type='LoadPointsFromFile', coord_type='LIDAR', load_dim=4, use_dim=4),
+    dict(type='LoadAnnotations3D', with_bbox_3d=True, with_label_3d=True, with_bbox=True, with_gga=True),
+    dict(type='ObjectSample_GGA', min_distance=5.0, db_sampler=db_sampler),
+    dict(type='PointsRangeFilter', point_cloud_range=point_cloud_range),
+    dict(type='ObjectRangeFilter_GGA', point_cloud_range=point_cloud_range, num_points_range=15),
+    dict(type='PointShuffle'),
+    dict(type='DefaultFormatBundle3D_GGA', class_names=class_names),
+    dict(type='Collect3D_GGA', keys=['points', 'gt_bboxes_3d', 'gt_labels_3d', 'GGA_boxes_img', 'GGA_lidar2img',
+                                     'GGA_init_pseudo_labels', 'GGA_bdry_masks', 'GGA_in_box_points'])]
+data = dict(samples_per_gpu=32, workers_per_gpu=4,
+            train=dict(type='RepeatDataset', times=1,
+                       dataset=dict(type=dataset_type, data_root=data_root, ann_file=data_root + 'kitti_infos_trainval_GGA.pkl',
+                                    split='training', pts_prefix='velodyne_reduced', pipeline=train_pipeline, modality=input_modality,
+                                    classes=class_names, test_mode=False, box_type_3d='LiDAR')))
 optimizer = dict(type='AdamW', lr=0.0015, betas=(0.95, 0.99), weight_decay=0.01)
 optimizer_config = dict(grad_clip=dict(max_norm=35, norm_type=2))
 lr_config = dict(policy='cyclic', target_ratio=(10, 1e-4), cyclic_times=1, step_ratio_up=0.4)
@@ -53,3 +75,8 @@ checkpoint_config = dict(interval=1)
 log_config = dict(interval=50, hooks=[dict(type='TextLoggerHook')])
 dist_params = dict(backend='nccl')
 find_unused_parameters = False
+log_level = 'INFO'
+work_dir = './work_dirs/kitti_GGA'
+load_from = None
+resume_from = None
+workflow = [('train', 1)]

@@ -31,9 +31,6 @@
 // rows of the packed layout of gga_sparse_pack_weight_split with kvol = 9); the next chunk's halo
 // is requested from global memory before the taps of the current chunk run. 66 KB of LDS: two
 // workgroups per CU.
-#define DC_T(V)
-#define DC_ACC(I, D)
-#define DC_PROBE_WAIT
 #ifndef DC_PIPE_ON
 #define DC_PIPE_ON 1
 #endif
@@ -59,8 +56,7 @@
 // weight load instead of before it. LDS reads deliver 174 B/clk/CU with this access pattern
 // (tools_dev/micro/lds_bw.hip); the kernel uses about half of that. A separate kernel that staged the weights of a whole
 // kernel row per barrier (36 MFMAs and one barrier per row stage instead of 12 and one per tap, weights requested a full
-// row stage ahead) measured 0.219 against 0.209 ms on the same box, alternating runs. -DDC_PROBE builds the cycle
-// accounting that tools_dev/probe_dense_stage.py prints.)
+// row stage ahead) measured 0.219 against 0.209 ms on the same box, alternating runs.)
 // Backward-data launches whose result is the gradient of a BatchNorm + ReLU output z = relu(bn(y)) take the reduce pass
 // of that BatchNorm's backward into their epilogue: the tile is masked by the ReLU (recomputed from y, gamma, beta and
 // the saved statistics exactly as the forward pass computed it: gga_bn_scale_shift) before it is stored, and the tile's
@@ -273,12 +269,8 @@ __global__ __launch_bounds__(TR / MT * 64, (P4 && NT == 4 && NP == 2) ? 1 : 2) v
         // stage is fixed at compile time (nchunks is even: cin % 32 == 0)
 #define DC_CHUNK_HEAD(CH)                                                                                             \
             if (!first) {                              /* every wave passed the barrier of the previous stage */      \
-                DC_T(tg_)                                                                                             \
                 DC_STORE_A();                                                                                         \
-                DC_T(th_)                                                                                             \
                 __syncthreads();                                                                                      \
-                DC_T(ti_)                                                                                             \
-                DC_ACC(5, th_ - tg_) DC_ACC(6, ti_ - th_)                                                             \
             }                                                                                                         \
             first = false;                                                                                            \
             if ((CH) + 1 < nchunks) { DC_LOAD_A((CH) + 1); }                                                          \
@@ -300,7 +292,6 @@ __global__ __launch_bounds__(TR / MT * 64, (P4 && NT == 4 && NP == 2) ? 1 : 2) v
                 if ((TAP) + 2 < 9) { DC_LOAD_B((TAP) + 2, (CH), bq0, bq1, bq2); }                                     \
                 else { DC_LOAD_B((TAP) + 2 - 9, last_chunk ? 0 : (CH) + 1, bq0, bq1, bq2); }                          \
             }                                                                                                         \
-            DC_T(ta_)                                                                                                 \
             if (PIPE4) {                                                                                              \
                 if ((TAP) == 0) { DC_READ_A_(CA, 0); DC_READ_B_(CB, 0, 0); DC_READ_B_(CB2, 0, 2); }                    \
                 if ((TAP) < 8) { DC_READ_A_(XA, (TAP) + 1); DC_READ_B_(XB, (TAP) + 1, 0); DC_READ_B_(XB2, (TAP) + 1, 2); } \
@@ -322,18 +313,10 @@ __global__ __launch_bounds__(TR / MT * 64, (P4 && NT == 4 && NP == 2) ? 1 : 2) v
             DC_READ_A(TAP);                                                                                           \
             _Pragma("unroll") for (int t0 = 0; t0 < NT; t0 += 2) {                                                    \
                 DC_READ_B(TAP, t0);                                                                                   \
-                DC_PROBE_WAIT                                                                                         \
-                DC_T(tb_)                                                                                             \
                 DC_MMA(t0)                                                                                            \
-                DC_T(tc_)                                                                                             \
-                DC_ACC(0, tb_ - ta_) DC_ACC(1, tc_ - tb_)                                                             \
             } }                                                                                                       \
-            DC_T(td_)                                                                                                 \
             if (more2) { if (DEEP) { DC_STORE_B(((TAP) + 2) % 3, S0, S1, S2); } else { DC_STORE_B(((TAP) + 2) % 3, bq0, bq1, bq2); } } \
-            DC_T(te_)                                                                                                 \
-            __syncthreads();                                                                                          \
-            DC_T(tf_)                                                                                                 \
-            DC_ACC(2, te_ - td_) DC_ACC(3, tf_ - te_) DC_ACC(4, 1) }
+            __syncthreads(); }
 #define DC_EVEN(TAP, CH) DC_STAGE(TAP, CH, cq0, cq1, cq2, bq0, bq1, bq2, fa, fb, ga, gb, fb2, gb2)      /* even stage: load set 1, store set 0 */
 #define DC_ODD(TAP, CH) DC_STAGE(TAP, CH, bq0, bq1, bq2, cq0, cq1, cq2, ga, gb, fa, fb, gb2, fb2)
         for (int ch = 0; ch < nchunks; ch += 2) {

@@ -462,7 +462,6 @@ __global__ __launch_bounds__(64 * X9_NW, 2) void sp_conv_x9_kernel(const float* 
 // instead of offset-outer, so the two forms differ by fp32 summation order only.
 #define XH_TM 256
 #define XH_HCAP 512
-#define XH_T(i)
 #define XH_KMAX 27
 template <int NT>
 __global__ __launch_bounds__(256) void sp_conv_halo_kernel(const float* __restrict__ X, const uint16_t* __restrict__ Wp,
@@ -592,7 +591,6 @@ __global__ __launch_bounds__(256) void sp_conv_halo_kernel(const float* __restri
     // the join. That is why the lanes whose neighbour lies beyond the image (FAR) get a loop of their own - taken by a tile
     // only if its halo is longer than the image - and why no wave skips an offset its rows do not use.
     for (int t = 0; t < D && t < S; ++t) issue_b();
-    XH_T(0)
     auto stages = [&](auto far_tag) {
         constexpr bool FAR = decltype(far_tag)::value;
         // A fragments of k-step sk for the lane's neighbour at image position L (0xFFFF: none -> the zero row)
@@ -626,9 +624,7 @@ __global__ __launch_bounds__(256) void sp_conv_halo_kernel(const float* __restri
         int c = 0, k = 0, L[RB], Ln[RB];
         for (int s = 0; s < S; ++s) {
             wait_vm(s + 2 < S ? nbp : 0);
-            XH_T(1)
             __builtin_amdgcn_s_barrier();
-            XH_T(2)
             {                                             // the weights of stage s + 3, under the last MFMAs of stage s - 1
                 const bool more = k != 0 && tb < S;       // (at a chunk boundary they follow the image)
                 if (more) issue_b_begin();
@@ -650,7 +646,6 @@ __global__ __launch_bounds__(256) void sp_conv_halo_kernel(const float* __restri
 #pragma unroll
                 for (int rb = 0; rb < RB; ++rb) L[rb] = entry(0, rb);
                 load_as(f0, L, 0, c); load_b(f0, s, 0);
-                XH_T(3)
             }
             const int kn = k + 1 < kvol ? k + 1 : k;      // (at the end of a chunk: fetched for nothing, the boundary reloads)
             // one scheduling region per k-step: the MFMAs of the fragments at hand with the LDS reads of the next ones dealt
@@ -678,7 +673,6 @@ __global__ __launch_bounds__(256) void sp_conv_halo_kernel(const float* __restri
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) L[rb] = Ln[rb];
             if (++k == kvol) { k = 0; ++c; }
-            XH_T(4)
         }
 #pragma unroll
         for (int e = 0; e < NBP; ++e) mma_tail(f1, e);
@@ -690,7 +684,6 @@ __global__ __launch_bounds__(256) void sp_conv_halo_kernel(const float* __restri
         if (extra < stats_rows && tid < 2 * cout) stats[extra * 2 * cout + tid] = 0.0;
     }
     x9_epilogue_rb<NT, NP, NW, RB>(acc, pr, wave, r, h, tid, cout, Y, ys, stats, tile, bn, smem, sbx, sbw);
-    XH_T(5)
 }
 
 extern "C" int64_t gga_sparse_halo_tile_rows(void) { return XH_TM; }

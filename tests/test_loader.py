@@ -390,3 +390,66 @@ def test_pseudo_label_generation_run(tmp_path):
         assert all(len(a[k]) == n for k in ('bbox', 'dimensions', 'location', 'rotation_y', 'score', 'GGA_boxes_img', 'GGA_init_pseudo_label'))
         assert (a['dimensions'][:, 0] >= a['dimensions'][:, 2]).all()      # longer horizontal side first
     assert sum(len(i['annos']['name']) for i in labelled) == res['pseudo_labels/detections']
+
+
+@pytest.mark.gpu
+def test_whole_recipe_on_the_synthetic_tree(tmp_path):
+    """The GGA recipe end to end (reference README.md:159-192) on the three-frame tree: GT database from the info file ->
+    the reference's train_pipeline WITH database sampling -> tools/train.py's flow (train_detector, one epoch, checkpoint) ->
+    tools/generate_pseudo_labels_gga.py's flow with that checkpoint -> a pseudo-label info file the train dataset loads again
+    (the retraining step of the recipe reads it as its ann_file)."""
+    from gga_amd import build_model
+    from gga_amd.apis import generate_pseudo_labels
+    from gga_amd.cnn import to_channels_last
+    from gga_amd.datasets import KittiDataset_GGA_train, LoadAnnotations3D
+    from gga_amd.gt_database import create_groundtruth_database
+    from gga_amd.pipelines import LoadPointsFromFile
+    DEV = torch.device('cuda:0')
+    root = str(tmp_path)
+    infos = kitti_tree(root)
+    # 1. GT database (tools/create_data_gga.py kitti -> create_groundtruth_database)
+    plain = KittiDataset_GGA_train(root, infos, 'training', classes=CLASSES, modality=dict(use_lidar=True, use_camera=False),
+                                   pipeline=[LoadPointsFromFile(coord_type='LIDAR', load_dim=4, use_dim=4),
+                                             LoadAnnotations3D(with_bbox_3d=True, with_label_3d=True)])
+    db = create_groundtruth_database(plain, root, 'kitti', logger=lambda s: None)
+    assert os.path.exists(os.path.join(root, 'kitti_dbinfos_train_GGA.pkl')) and sum(len(v) for v in db.values()) > 0
+    # 2. training from the dataset with the reference's train_pipeline (database sampling included)
+    model_cfg = os.path.join(REPO, 'configs', 'gga', 'gga_kitti_pointpillars_config.py')
+    cfg = Config.fromfile(model_cfg)
+    pipe = train_pipeline()
+    groups = {k: 2 for k in db if k in CLASSES}
+    pipe.insert(2, dict(type='ObjectSample_GGA', min_distance=5.0,
+                        db_sampler=dict(data_root=root, info_path=os.path.join(root, 'kitti_dbinfos_train_GGA.pkl'), rate=1.0,
+                                        prepare=dict(filter_by_difficulty=[-1], filter_by_min_points={k: 1 for k in groups}),
+                                        classes=CLASSES, sample_groups=groups)))
+    ds_cfg = dataset_cfg(root, infos, times=2)
+    ds_cfg['dataset']['pipeline'] = pipe
+    cfg.model.pts_middle_encoder['channels_last'] = True
+    cfg.data = dict(samples_per_gpu=3, workers_per_gpu=0, train=ds_cfg)
+    cfg.runner, cfg.checkpoint_config = dict(type='EpochBasedRunner', max_epochs=1), dict(interval=1)
+    cfg.work_dir, cfg.seed = os.path.join(root, 'work'), 0
+    np.random.seed(0), torch.manual_seed(0)
+    model = build_model(cfg.model)
+    with torch.no_grad():
+        for th in model.pts_bbox_head.task_heads:
+            for name in ('reg', 'height', 'dim', 'rot'):
+                getattr(th, name)[-1].weight.mul_(0.05)
+            th.heatmap[-1].bias.fill_(0.5)
+    model = to_channels_last(model.to(DEV)).train()
+    ds = LD.build_dataset(cfg.data['train'])
+    sample = ds[0]
+    assert len(sample['gt_labels_3d'].data) >= 1                      # objects (own + pasted ones) survive the filters
+    runner = train_detector(model, ds, cfg, distributed=False, device=DEV)
+    assert runner.iter == 2 and runner.epoch == 1
+    ck = os.path.join(cfg.work_dir, 'epoch_1.pth')
+    assert os.path.exists(ck)
+    # 3. pseudo-label generation with the trained checkpoint
+    mcfg = matching_cfg(root, infos, model_cfg)
+    out_file = os.path.join(root, 'kitti_infos_trainval_GGA_pseudo.pkl')
+    outputs, res = generate_pseudo_labels(mcfg, ck, eval_metrics=('mAP',), eval_options=dict(pseudo_label_file=out_file))
+    assert len(outputs) == 3 and res['pseudo_labels/frames'] == 3.0 and os.path.exists(out_file)
+    # 4. the retraining step reads that file as its ann_file: the infos keep the layout the datasets take
+    relabelled = pickle.load(open(out_file, 'rb'))
+    assert [i['image']['image_idx'] for i in relabelled] == [i['image']['image_idx'] for i in infos]
+    for info in relabelled:
+        assert {'name', 'bbox', 'dimensions', 'location', 'rotation_y', 'GGA_boxes_img', 'GGA_init_pseudo_label'} <= set(info['annos'])

@@ -996,6 +996,14 @@ def test_strided_and_transposed_convs_vs_torch(kind, cin, cout, k, s, B, H, W, p
     y = dense_conv.conv2d(x, m)
     assert type(y.grad_fn).__name__ in ('_StridedConvBackward', '_DeconvBackward')
     assert y.is_contiguous(memory_format=torch.channels_last)
+    # the per-channel sums the kernel leaves for the BatchNorm that follows (gather-GEMM tiles, or the streaming kernel's
+    # per-workgroup sums for the 1x1 / kernel = stride forms): the sums of y and of y^2
+    from gga_amd import functional as GF
+    parts = GF.bn_partials_of(y)
+    assert parts is not None and parts.dtype == torch.float64
+    yd = y.detach().double()
+    torch.testing.assert_close(parts[:, 0].sum(0), yd.sum((0, 2, 3)), rtol=1e-6, atol=1e-3)
+    torch.testing.assert_close(parts[:, 1].sum(0), (yd * yd).sum((0, 2, 3)), rtol=1e-6, atol=1e-3)
     g = torch.randn_like(y)
     y.backward(g)
     gx, gw = x.grad.clone(), m.weight.grad.clone()

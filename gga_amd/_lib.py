@@ -100,8 +100,6 @@ SIGNATURES = {
     'gga_dense_conv3x3_bn_bwd_pays': (i32, [i32, i32, i32, i32]),
     'gga_dense_conv3x3_bn_bwd': (i32, [vp, vp, i32, i32, i32, i32, i32, vp, i64, i32, vp, i32, vp, vp, vp, i64, vp, vp, vp, vp, vp]),
     'gga_dense_wgrad3x3_planes': (i32, [vp, vp, i32, i32, i32, i32, i32, vp, i64, i64, i64, i64, i32, i32, vp, vp, vp, sz, vp]),
-    'gga_rows_gemm_workgroups': (i64, [i64, i32, i32, i32]),
-    'gga_rows_gemm': (i32, [vp, i64, i64, i32, vp, i32, vp, i64, i32, i32, i32, i32, vp, vp, vp, vp]),
     'gga_absmax_table_blocks': (i64, [i64]),
     'gga_absmax_table': (i32, [vp, i32, i64, vp, i32, vp]),
     'gga_pack_weights_table': (i32, [vp, i32, i64, i32, vp]),

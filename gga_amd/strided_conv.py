@@ -10,8 +10,6 @@ deterministic weight gradient). The rule books depend on the shape only and are 
 convolution's output rows run the one tap of their phase and border rows skip the padding taps.
 Channel widths above 128 run as 128-wide column blocks (``*_strided`` entry points).
 """
-import os
-
 import torch
 from torch import nn
 
@@ -85,18 +83,13 @@ def _amax(t):
     return dense_conv.tensor_amax(t) if dense_conv.PLANES == 2 else None
 
 
-ROWS_GEMM = os.environ.get('GGA_ROWS_GEMM', '1') == '1'        # 1x1 / kernel = stride transposed convolutions on gga_rows_gemm (0: the gather-GEMM, for the A/B)
-
-
-def _apply(x_rows, m, mask, perm, w_kio, n_rows, x_amax=None, w_amax=None, want_stats=False, bank=False, direct=None):
+def _apply(x_rows, m, mask, perm, w_kio, n_rows, x_amax=None, w_amax=None, want_stats=False, bank=False):
     """y [n_rows, cout] = sum_k x_rows[m[k]] @ w_kio[k]  (w_kio [kvol, cin, cout]). ``x_amax`` / ``w_amax``: absmax
     bits of the operands (two-plane arithmetic), computed here when missing. ``want_stats``: also return the f64
     [workgroups, 2, cout] per-channel sums of y for the BatchNorm that follows (``gga_sparse_conv_apply_stats``).
     ``bank``: ``w_kio`` is a VIEW ([kvol, cin, cout] or [k, k, cin, cout], any strides) of a parameter that lives across
     steps - its operand and absmax then come from the weight bank (refreshed with all others once per optimizer step)
-    instead of a pack + absmax launch per call. ``direct`` (with ``bank``, two planes): the product needs no rule book -
-    ``('plain',)``: output row p = input row p (1x1 convolution); ``('deconv', H, W, s)``: the kernel = stride transposed
-    convolution of a [*, H, W] image, ``x_rows`` being its INPUT rows - and runs on the streaming kernel ``gga_rows_gemm``."""
+    instead of a pack + absmax launch per call."""
     L = _lib.lib()
     kvol, cin, cout = (w_kio.shape[0] * w_kio.shape[1], w_kio.shape[2], w_kio.shape[3]) if w_kio.dim() == 4 else w_kio.shape
     planes = _planes()
@@ -111,25 +104,6 @@ def _apply(x_rows, m, mask, perm, w_kio, n_rows, x_amax=None, w_amax=None, want_
     else:
         x_amax = w_amax = None
     y = torch.empty((n_rows, cout), dtype=torch.float32, device=x_rows.device)
-    fast = (direct is not None and bank and ROWS_GEMM and planes == 2 and cin in (64, 128, 256) and x_rows.stride(1) == 1
-            and x_rows.stride(0) % 4 == 0 and x_rows.data_ptr() % 16 == 0)
-    if fast:
-        from . import weight_bank
-        taps, (gh, gw, gs) = (1, (0, 0, 0)) if (direct[0] == 'plain' or direct[3] == 1) else (kvol, direct[1:])
-        n_in = x_rows.shape[0]
-        parts = []
-        for c0 in range(0, cout, 128):
-            c1 = min(c0 + 128, cout)
-            wp, wa = weight_bank.gather_operand(w_kio, planes, c0, c1)
-            st = None
-            if want_stats:
-                st = torch.empty((int(L.gga_rows_gemm_workgroups(n_in, cin, c1 - c0, taps)), 2, c1 - c0), dtype=torch.float64, device=y.device)
-                parts.append(st)
-            check(L.gga_rows_gemm(F._p(x_rows), x_rows.stride(0), n_in, cin, F._p(wp), c1 - c0, y.data_ptr() + 4 * c0, cout, taps, gh, gw, gs,
-                                  F._p(x_amax), F._p(wa), F._p(st), F._stream()), 'gga_rows_gemm')
-        if want_stats:
-            return y, (parts[0] if len(parts) == 1 else torch.cat(parts, dim=2))
-        return y
     tiles = int(L.gga_sparse_conv_apply_tiles(n_rows)) if want_stats else 0
     parts = []
     for c0 in range(0, cout, 128):
@@ -187,9 +161,7 @@ class _StridedConv(torch.autograd.Function):
         bk = book(B, H, W, k, s, p, x.device)
         w = weight.detach()
         x_amax = _amax(x)
-        plain = ('plain',) if (k, s, p) == (1, 1, 0) else None          # a 1x1 convolution is a matrix product over the rows
-        y, stats = _apply(_rows(x), bk.fwd, bk.fwd_mask, bk.fwd_perm, w.permute(2, 3, 1, 0), bk.n_out, x_amax, want_stats=True, bank=True,
-                          direct=plain)
+        y, stats = _apply(_rows(x), bk.fwd, bk.fwd_mask, bk.fwd_perm, w.permute(2, 3, 1, 0), bk.n_out, x_amax, want_stats=True, bank=True)
         ctx.save_for_backward(x, weight)
         ctx.geom, ctx.amax = (k, s, p), (x_amax, None)
         ctx.mark_non_differentiable(stats)
@@ -209,8 +181,7 @@ class _StridedConv(torch.autograd.Function):
         g_amax = _amax(gy)
         if ctx.needs_input_grad[0]:
             w = weight.detach()
-            gx = _apply(g_rows, bk.bwd, bk.bwd_mask, bk.bwd_perm, w.permute(2, 3, 0, 1), bk.n_in, g_amax, bank=True,
-                        direct=('plain',) if (k, s, p) == (1, 1, 0) else None)
+            gx = _apply(g_rows, bk.bwd, bk.bwd_mask, bk.bwd_perm, w.permute(2, 3, 0, 1), bk.n_in, g_amax, bank=True)
             gx = gx.view(B, H, W, cin).permute(0, 3, 1, 2)
         if ctx.needs_input_grad[1]:
             gw = _wgrad(_rows(x), g_rows, bk.fwd, bk.n_out, x_amax, g_amax).view(k, k, cin, cout).permute(3, 2, 0, 1)
@@ -227,8 +198,7 @@ class _Deconv(torch.autograd.Function):
         bk = book(B, H * s, W * s, s, s, 0, x.device)          # fwd [s*s, n_coarse] fine pixel; bwd [s*s, n_fine] coarse pixel
         w = weight.detach()
         x_amax = _amax(x)
-        y, stats = _apply(_rows(x), bk.bwd, bk.bwd_mask, bk.bwd_perm, w.permute(2, 3, 0, 1), bk.n_in, x_amax, want_stats=True, bank=True,
-                          direct=('deconv', H, W, s))
+        y, stats = _apply(_rows(x), bk.bwd, bk.bwd_mask, bk.bwd_perm, w.permute(2, 3, 0, 1), bk.n_in, x_amax, want_stats=True, bank=True)
         ctx.save_for_backward(x, weight)
         ctx.s, ctx.amax = s, (x_amax, None)
         ctx.mark_non_differentiable(stats)

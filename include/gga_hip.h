@@ -376,17 +376,6 @@ typedef struct {
 int64_t gga_absmax_table_blocks(int64_t n);
 int gga_absmax_table(const GgaAmaxEntry* table_device, int n_entries, int64_t n_blocks, uint32_t* slots, int n_slots, void* stream);
 int gga_pack_weights_table(const GgaPackEntry* table_device, int n_entries, int64_t total, int planes, void* stream);
-/* Streaming matrix product over the rows of a channels-last image (round 4): y[out_row(p, tap)][0 .. cout) = x[p][0 .. cin) W[tap] -
- * the 1x1 Conv2d (taps = 1, stride = 0: out_row = p) and the kernel = stride ConvTranspose2d (taps = stride^2, input pixel
- * (b, i, j) of a [*, in_h, in_w] image -> output pixel (b, i stride + a, j stride + c) for tap a stride + c) of SECONDFPN
- * (necks/second_fpn.py:52-69) forward, and the 1x1 backward-data with the transposed weight. split_weight: the operand of
- * gga_sparse_pack_weight_planes / gga_pack_weights_table (layout 0) with kvol = taps, two fp16 planes; cin 64 / 128 / 256,
- * cout <= 128 (wider outputs: one call per 128-column slice with y offset and y_row_stride = the full width). stats (NULL:
- * none): f64 [gga_rows_gemm_workgroups(...)][2][cout] per-channel sums / sums of squares of y for the BatchNorm that follows. */
-int64_t gga_rows_gemm_workgroups(int64_t n_rows, int cin, int cout, int taps);
-int gga_rows_gemm(const float* x, int64_t x_row_stride, int64_t n_rows, int cin, const void* split_weight, int cout, float* y,
-                  int64_t y_row_stride, int taps, int in_h, int in_w, int stride, const uint32_t* amax_x,
-                  const uint32_t* amax_weight, double* stats, void* stream);
 /* the gather-GEMM kernels (sparse, strided and transposed convolutions) in the same two forms */
 int gga_sparse_pack_weight_planes(const float* weight, int kvol, int cin, int cout, int transpose, int planes,
                                   const uint32_t* amax_weight, void* packed, void* stream);

@@ -263,9 +263,12 @@ class _MapConv(torch.autograd.Function):
         from . import strided_conv as S
         x = x.contiguous()
         w = weight.detach().contiguous()
-        y = S._apply(x, fwd.nbr, fwd.mask, fwd.perm, w, n_out)
+        # the layer's own parameter (not the zero-padded temporary of odd widths, map_conv): its packed operands live in the
+        # weight bank and are refreshed with all others once per optimizer step
+        banked = weight.grad_fn is None and w.data_ptr() == weight.data_ptr()
+        y = S._apply(x, fwd.nbr, fwd.mask, fwd.perm, w, n_out, bank=banked)
         ctx.save_for_backward(x, weight)
-        ctx.maps, ctx.flip = (fwd, bwd, n_out), flip_bwd
+        ctx.maps, ctx.flip, ctx.banked = (fwd, bwd, n_out), flip_bwd, banked
         return y
 
     @staticmethod
@@ -278,7 +281,8 @@ class _MapConv(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             # gx[i] = sum_k gy[bwd[k][i]] W[k]^T: bwd[k][i] is the output row that reads row i through offset k (for SubM maps
             # that is row K-1-k of the forward rule book, which is how CoordMap.kernel_map builds it)
-            gx = S._apply(gy, bwd.nbr, bwd.mask, bwd.perm, weight.detach().transpose(1, 2).contiguous(), x.shape[0])
+            wt = weight.detach().transpose(1, 2)                # [kvol, cout, cin]: a view for the bank, a copy otherwise
+            gx = S._apply(gy, bwd.nbr, bwd.mask, bwd.perm, wt if ctx.banked else wt.contiguous(), x.shape[0], bank=ctx.banked)
         if ctx.needs_input_grad[1]:
             gw = S._wgrad(x, gy, fwd.nbr, n_out)
         return gx, gw, None, None, None, None

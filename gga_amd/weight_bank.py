@@ -71,7 +71,10 @@ class WeightBank:
     def __init__(self):
         self.ops = {}
         self.slots = {}             # device -> int32 [SLOTS]
-        self.slot_of = {}           # (device, storage pointers of an operand's sources) -> slot index
+        self.slot_of = {}           # (device, memory blocks an operand's scale is taken over) -> slot index
+        self.slot_users = {}        # (device, slot index) -> operands holding it (a slot returns to `free` with its last user)
+        self.free = {}              # device -> released slot indices
+        self.slot_token = {}        # (device, slot index) -> (epoch, versions) its content was computed for
         self.refreshes = 0          # table launches (diagnostics)
         self.generation = 0         # refreshes triggered by changed weights: one per optimizer step in a train loop
         self.tables = {}            # device -> (signature of the stale set, pack table, amax table, totals)
@@ -105,7 +108,7 @@ class WeightBank:
             if self.generation % 8 == 0:          # operands nobody asked for in a while (their model is gone)
                 dead = [k for k, o in self.ops.items() if o.used < self.generation - self.KEEP * 8]
                 for k in dead:
-                    del self.ops[k]
+                    self._release(self.ops.pop(k))
                 if dead:
                     self.tables.clear()
         op.used = self.generation
@@ -127,17 +130,30 @@ class WeightBank:
         op.used = self.generation
         op.slot, op.blocks = None, []
         if planes == 2:
-            skey = (str(dev), tuple(blocks))
+            d = str(dev)
+            skey = (d, tuple(blocks))
+            if d not in self.slots:
+                self.slots[d] = torch.zeros(self.SLOTS, dtype=torch.int32, device=dev)
+                self.free[d] = list(range(self.SLOTS - 1, -1, -1))
             if skey not in self.slot_of:
-                used = sum(1 for k in self.slot_of if k[0] == str(dev))
-                assert used < self.SLOTS, 'weight bank: out of absmax slots'
-                self.slot_of[skey] = used
-            if str(dev) not in self.slots:
-                self.slots[str(dev)] = torch.zeros(self.SLOTS, dtype=torch.int32, device=dev)
+                assert self.free[d], 'weight bank: out of absmax slots'
+                self.slot_of[skey] = self.free[d].pop()
             i = self.slot_of[skey]
-            op.slot, op.blocks = self.slots[str(dev)][i:i + 1], [(p, n, i) for p, n in blocks]
+            self.slot_users[(d, i)] = self.slot_users.get((d, i), 0) + 1
+            op.slot, op.blocks = self.slots[d][i:i + 1], [(p, n, i) for p, n in blocks]
         self.ops[key] = op
         return op
+
+    def _release(self, op):
+        if op.slot is None:
+            return
+        d, i = str(op.packed.device), op.blocks[0][2]
+        self.slot_users[(d, i)] -= 1
+        if self.slot_users[(d, i)] == 0:
+            del self.slot_users[(d, i)]
+            self.slot_token.pop((d, i), None)
+            self.slot_of = {k: v for k, v in self.slot_of.items() if not (k[0] == d and v == i)}
+            self.free[d].append(i)
 
     # ------------------------------------------------------------------------------------------------------------- refresh
     def _refresh(self, stale):
@@ -147,17 +163,23 @@ class WeightBank:
             by_dev.setdefault((str(op.packed.device), op.planes), []).append(op)
         for (dev_key, planes), ops in by_dev.items():
             dev = ops[0].packed.device
-            sig = (planes, tuple(id(o) for o in ops))
+            # absmax slots to recompute: those whose content was not computed for the weights as they are now. (A slot is shared
+            # by every operand scaled by the same weight - forward / backward-data, slices; an operand made later in the same
+            # step must not zero and recompute a slot that kernels of another stream may be reading.)
+            tokens = {(dev_key, b[2]): (self.epoch, tuple(v._version for v, _, _ in op.sources)) for op in ops for b in op.blocks[:1]}
+            need = frozenset(i for (d, i), tok in tokens.items() if self.slot_token.get((d, i)) != tok)
+            sig = (planes, tuple(id(o) for o in ops), need)
             cached = self.tables.get((dev_key, planes))
             if cached is None or cached[0] != sig:
-                cached = (sig,) + self._build_tables(ops, dev, planes)
+                cached = (sig,) + self._build_tables(ops, dev, planes, need)
                 if len(ops) > 1:
                     self.tables[(dev_key, planes)] = cached
+            self.slot_token.update(tokens)
             _, pack_t, n_pack, total, amax_t, n_amax, n_blocks, slot_idx = cached
             with torch.cuda.device(dev):
                 if planes == 2 and n_amax:
-                    # only the slots of the operands being refreshed start from zero (operands of other, unchanged weights keep
-                    # theirs): one index_fill over their indices, then the table pass
+                    # only the slots that have to be recomputed start from zero: one index_fill over their indices, then the
+                    # table pass
                     self.slots[dev_key].index_fill_(0, slot_idx, 0)
                     check(L.gga_absmax_table(F._p(amax_t), n_amax, n_blocks, F._p(self.slots[dev_key]), 0, F._stream()), 'gga_absmax_table')
                 check(L.gga_pack_weights_table(F._p(pack_t), n_pack, total, planes, F._stream()), 'gga_pack_weights_table')
@@ -172,7 +194,7 @@ class WeightBank:
             self.event.record(cur)
             self.stream = cur.cuda_stream
 
-    def _build_tables(self, ops, dev, planes):
+    def _build_tables(self, ops, dev, planes, need):
         L = _lib.lib()
         entries, first = [], 0
         for op in ops:
@@ -188,7 +210,7 @@ class WeightBank:
             slots = self.slots[str(dev)]
             for op in ops:
                 for ptr, n, i in op.blocks:
-                    if (ptr, i) in seen:
+                    if (ptr, i) in seen or i not in need:
                         continue
                     seen.add((ptr, i))
                     amax.append(AmaxEntry(ptr, slots.data_ptr() + 4 * i, n, n_blocks))
@@ -200,7 +222,7 @@ class WeightBank:
             arr = (ctype * len(items))(*items)
             host = torch.from_numpy(np.frombuffer(arr, dtype=np.uint8).copy())
             return host.to(dev)
-        slot_idx = torch.tensor(sorted({i for op in ops for _, _, i in op.blocks}) or [0], dtype=torch.long).to(dev)
+        slot_idx = torch.tensor(sorted(need) or [0], dtype=torch.long).to(dev)
         return upload(entries, PackEntry), len(entries), first, upload(amax, AmaxEntry), len(amax), n_blocks, slot_idx
 
 

@@ -519,13 +519,20 @@ extern "C" int gga_dense_conv3x3_pack_planes(const float* weight, int64_t stride
     return GGA_OK;
 }
 
-// rows per tile: 16 only for 128 output channels and when that still gives every CU a workgroup or two
+// rows per tile: 16 only for 128 output channels, when that still gives every CU a workgroup or two, and when the rounds
+// the chip needs for the tiles do not eat what the 16-row form wins per tile. Both forms run one 128-column workgroup per CU
+// (256 slots); a 16-row tile takes ~1.87 x the time of an 8-row tile (7 % better per pixel). 8 x 200 x 176 (the shipped config's
+// second stage): 624 tiles = 3 rounds at 81 % against 1200 = 5 rounds at 94 % -> 8 rows (272 against 286 us, same box);
+// 16 x 124 x 108: 2 against 4 rounds -> 16 rows (231 against 249 us); 16 x 248 x 216: 7 against 14 -> 16 rows (464 against 490).
 static inline int dc_tile_rows(int B, int H, int W, int cout) {
     if (cout != 128) return 8;
     static const int forced = getenv("GGA_DC_TILE_ROWS") ? atoi(getenv("GGA_DC_TILE_ROWS")) : 0;      // A/B switch: 8 or 16
     if (forced == 8 || forced == 16) return forced;
-    const int64_t t16 = (int64_t)B * ((W + DC_TW - 1) / DC_TW) * ((H + 15) / 16);
-    return t16 >= 384 ? 16 : 8;
+    const int64_t cols = (W + DC_TW - 1) / DC_TW;
+    const int64_t t16 = (int64_t)B * cols * ((H + 15) / 16), t8 = (int64_t)B * cols * ((H + 7) / 8);
+    if (t16 < 384) return 8;
+    const int64_t r16 = (t16 + 255) / 256, r8 = (t8 + 255) / 256;
+    return 1000 * r16 <= 535 * r8 ? 16 : 8;
 }
 
 extern "C" int64_t gga_dense_conv3x3_tiles(int B, int H, int W, int cout) {   // H, W of the tile space (swapped when transposed)

@@ -15,5 +15,6 @@ def t(B, C, Co, H, W):
         e0.record(); y = dense_conv._run(x, w, False, x_amax=xa, w_amax=wa)[0]; e1.record(); torch.cuda.synchronize()
         if i >= 4: ts.append(e0.elapsed_time(e1))
     print(f'   [{B},{C}->{Co},{H},{W}] {sum(ts) / len(ts) * 1e3:.0f} us (incl. weight pack)', float(y.abs().max()))
-for shp in ((16, 128, 128, 124, 108), (16, 128, 128, 62, 54), (4, 128, 128, 100, 88), (16, 256, 256, 62, 54), (8, 128, 128, 200, 176), (12, 256, 256, 96, 312)):
+print('GGA_DC_TILE_ROWS =', os.environ.get('GGA_DC_TILE_ROWS', '(launcher rule)'))
+for shp in ((16, 128, 128, 124, 108), (16, 64, 128, 248, 216), (16, 256, 256, 62, 54), (8, 128, 128, 200, 176), (8, 64, 128, 200, 176), (8, 256, 256, 100, 88), (16, 64, 64, 248, 216), (16, 384, 64, 248, 216)):
     t(*shp)

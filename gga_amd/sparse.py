@@ -214,8 +214,6 @@ class IndexPlan:
         """Every device tensor the plan holds (for ``Tensor.record_stream`` when it was built on
         another stream than the one that consumes it)."""
         levels, books = [self.level0], []
-        if getattr(self, 'row_order', None) is not None:
-            yield self.row_order
         for lvl, out_lvl, rb, rb_t in self.indice_dict.values():
             levels.append(out_lvl)
             books += [rb, rb_t]

@@ -61,12 +61,6 @@ def make_sparse_convmodule(in_channels, out_channels, kernel_size, indice_key, s
 
 # GGA_SPARSE_DIRECT_BEV=0: the NCHW scatter + layout copy of rounds 1-2 (A/B switch)
 DIRECT_BEV = os.environ.get('GGA_SPARSE_DIRECT_BEV', '1') == '1'
-# The encoder works on the voxels in Z-order (one sort of the level-0 coordinates per batch): the voxelizer numbers voxels by
-# first appearance in the shuffled point cloud, i.e. randomly in space, and every level inherits that order (an output site is
-# numbered by the input row that owns it) - the gather kernels then fetch every neighbour row from HBM (the 64-channel level:
-# 2.2 GB per launch against 0.37 GB algorithmic, HBM-bound at 6.3 TB/s). In spatial order the neighbours of neighbouring rows
-# are the same rows and meet in the L2. GGA_SP_SPATIAL_ROWS=0: the voxelizer's order (A/B switch).
-SPATIAL_ROWS = os.environ.get('GGA_SP_SPATIAL_ROWS', '1') == '1'
 
 
 @MIDDLE_ENCODERS.register_module()
@@ -106,24 +100,14 @@ class SparseEncoder(nn.Module):
     def build_indices(self, coors, batch_size):
         """Levels and rule books of this encoder for ``coors`` (see ``sparse.build_index_plan``); the plan
         travels with the coordinates (``coors.index_plan``) and ``forward`` picks it up."""
-        from .sparse import build_index_plan, morton_order
+        from .sparse import build_index_plan
         coors = coors if coors.dtype == torch.int32 else coors.int()
-        work, order = coors, None
-        if SPATIAL_ROWS and coors.is_cuda and coors.shape[0] > 1:
-            order = morton_order(coors)
-            work = coors[order].contiguous()
-        coors.index_plan = build_index_plan(self, work, self.sparse_shape, int(batch_size))
-        coors.index_plan.row_order = order          # voxel_features[row_order] are the rows of the plan's level 0
+        coors.index_plan = build_index_plan(self, coors, self.sparse_shape, int(batch_size))
         return coors
 
     def forward(self, voxel_features, coors, batch_size):
         plan = getattr(coors, 'index_plan', None)
-        if plan is None and SPATIAL_ROWS and coors.is_cuda and coors.shape[0] > 1:
-            plan = self.build_indices(coors, batch_size).index_plan
         if plan is not None and plan.level0.n == voxel_features.shape[0]:
-            order = getattr(plan, 'row_order', None)
-            if order is not None:
-                voxel_features = voxel_features.index_select(0, order)
             x = SparseConvTensor(voxel_features, plan.level0.coors, self.sparse_shape, int(batch_size), _level=plan.level0)
             x.indice_dict = plan.indice_dict
         else:

@@ -11,7 +11,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libgga_hip.so')
-ABI_VERSION = 22
+ABI_VERSION = 23
 
 _lib = None
 
@@ -105,6 +105,7 @@ SIGNATURES = {
     'gga_pack_weights_table': (i32, [vp, i32, i64, i32, vp]),
     'gga_dense_wgrad3x3_block_amax': (i32, [vp, vp, i32, i32, i32, i32, i32, vp, i64, i64, i64, i64, i32, i32, vp, i32, vp, i32, vp, sz, vp]),
     'gga_dense_conv3x3_tiles': (i64, [i32, i32, i32, i32]),
+    'gga_dense_conv3x3_tiles_planes': (i64, [i32, i32, i32, i32, i32]),
     'gga_dense_conv3x3_slice': (i32, [vp, vp, i32, i32, i32, i32, i32, vp, i64, i32, vp, vp]),
     'gga_dense_conv3x3_stats': (i32, [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]),
     'gga_bn_relu_fwd_partials': (i32, [vp, vp, vp, vp, vp, vp, i64, i32, f32, f32, i32, vp, i64, vp, vp, vp, i32, vp, sz, vp]),

@@ -19,7 +19,7 @@ void gga_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* gga_last_error(void) { return g_err; }
-extern "C" int gga_abi_version(void) { return 22; }
+extern "C" int gga_abi_version(void) { return 23; }
 
 // ---- timing sessions -----------------------------------------------------------------------
 // One session per site. While a session is armed, the entry point of that site brackets its

@@ -69,10 +69,17 @@ __device__ __forceinline__ int h2_scale_exp(uint32_t amax_bits) {
 __device__ __forceinline__ float h2_scale(int sb) { return __uint_as_float((uint32_t)sb << 23); }
 __device__ __forceinline__ float h2_descale(int sb) { return __uint_as_float((uint32_t)(254 - sb) << 23); }
 // two scaled values at once: word p = {plane p of b, plane p of a} (a in the low half)
+// Four vector instructions per pair: v_cvt_pk_f16_f32, the two residuals by v_fma_mix_f32 (a - h0 with h0 read as the fp16 half it
+// is: exact, as the cvt + sub pair the compiler makes of the plain expression - 8 instructions per pair, and every one of them is
+// taken from the matrix pipe's issue slots), v_cvt_pk_f16_f32.
 __device__ __forceinline__ void h2_split2(float a, float b, uint32_t& w0, uint32_t& w1) {
-    const __half2 h0 = __floats2half2_rn(a, b);
-    const float2 f0 = __half22float2(h0);
-    const __half2 h1 = __floats2half2_rn(a - f0.x, b - f0.y);       // exact differences
-    w0 = *reinterpret_cast<const uint32_t*>(&h0);
-    w1 = *reinterpret_cast<const uint32_t*>(&h1);
+    typedef _Float16 h2_v2h __attribute__((ext_vector_type(2)));
+    const h2_v2h h0 = {(_Float16)a, (_Float16)b};                   // round to nearest even
+    const uint32_t hb = __builtin_bit_cast(uint32_t, h0);
+    float ra, rb;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(ra) : "v"(hb), "v"(a));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rb) : "v"(hb), "v"(b));
+    const h2_v2h h1 = {(_Float16)ra, (_Float16)rb};
+    w0 = hb;
+    w1 = __builtin_bit_cast(uint32_t, h1);
 }

@@ -4,10 +4,9 @@
 // the weight packing and the weight gradient (dense_wgrad3x3_x9_kernel).
 #include <stdlib.h>
 
-#include "gga_common.h"
+#include "dense_conv.h"
 #include <type_traits>
 #include <hip/hip_fp16.h>
-#include "conv_planes.h"
 
 // ------------------------------------------------------------------------------ dense 3x3 convolution
 // The dense kernels below use SIX of the nine partial products: with truncated planes
@@ -38,13 +37,6 @@
 #define DC_PIPE4_ON 1
 #endif
 #define DC_P4_MAX_TILES 256                       /* launches of at most this many tiles take the one-workgroup-per-CU form */
-#define DC_TR 8
-#define DC_TW 32
-#define DC_HW (DC_TW + 2)
-#define DC_HP ((DC_TR + 2) * DC_HW)          // 340 halo pixels
-#define DC_CK 16                             // input channels per chunk
-#define DC_ROWB 48                           // bytes per LDS row (16 bf16 + pad)
-#define DC_NA ((DC_HP * 4 + 255) / 256)      // float4 pieces per thread and chunk (6)
 
 // NP = 3: three bf16 planes, six partial products (any fp32 input). NP = 2: two fp16 planes of the scaled operands, three
 // partial products (see h2_split2); `amax` then points to {bits of max finite |x|, bits of max finite |w|}.
@@ -57,20 +49,6 @@
 // (tools_dev/micro/lds_bw.hip); the kernel uses about half of that. A separate kernel that staged the weights of a whole
 // kernel row per barrier (36 MFMAs and one barrier per row stage instead of 12 and one per tap, weights requested a full
 // row stage ahead) measured 0.219 against 0.209 ms on the same box, alternating runs.)
-// Backward-data launches whose result is the gradient of a BatchNorm + ReLU output z = relu(bn(y)) take the reduce pass
-// of that BatchNorm's backward into their epilogue: the tile is masked by the ReLU (recomputed from y, gamma, beta and
-// the saved statistics exactly as the forward pass computed it: gga_bn_scale_shift) before it is stored, and the tile's
-// per-channel sums of g and g * xhat go to `stats` in the layout of the forward statistics. y: the BatchNorm's input,
-// channel block of this launch, pixel stride ystride floats; gamma / beta / mean / invstd: of that channel block.
-struct DcBnBwd {
-    const float* y;
-    const float* gamma;
-    const float* beta;
-    const float* mean;
-    const float* invstd;
-    int ystride;
-};
-
 // Several images of different sizes in ONE launch (gga_dense_conv3x3_levels: the tower convolutions of an FPN head share
 // their weights over the levels, and all but the largest level are too small to fill the chip - 12 x 24 x 78 is 108
 // tiles, 12 x 3 x 10 is 12): entry e owns the tiles [start[e], start[e + 1]) of the grid and brings its own input,
@@ -524,7 +502,8 @@ extern "C" int gga_dense_conv3x3_pack_planes(const float* weight, int64_t stride
 // (256 slots); a 16-row tile takes ~1.87 x the time of an 8-row tile (7 % better per pixel). 8 x 200 x 176 (the shipped config's
 // second stage): 624 tiles = 3 rounds at 81 % against 1200 = 5 rounds at 94 % -> 8 rows (272 against 286 us, same box);
 // 16 x 124 x 108: 2 against 4 rounds -> 16 rows (231 against 249 us); 16 x 248 x 216: 7 against 14 -> 16 rows (464 against 490).
-static inline int dc_tile_rows(int B, int H, int W, int cout) {
+int dc_tile_rows(int B, int H, int W, int cout, int planes) {
+    if (dc_ws_enabled(planes)) return cout == 128 ? 8 : 16;          // dense_conv_ws.hip: four consumer waves x 128 accumulators
     if (cout != 128) return 8;
     static const int forced = getenv("GGA_DC_TILE_ROWS") ? atoi(getenv("GGA_DC_TILE_ROWS")) : 0;      // A/B switch: 8 or 16
     if (forced == 8 || forced == 16) return forced;
@@ -535,17 +514,19 @@ static inline int dc_tile_rows(int B, int H, int W, int cout) {
     return 1000 * r16 <= 535 * r8 ? 16 : 8;
 }
 
-extern "C" int64_t gga_dense_conv3x3_tiles(int B, int H, int W, int cout) {   // H, W of the tile space (swapped when transposed)
-    const int tr = dc_tile_rows(B, H, W, cout);
+extern "C" int64_t gga_dense_conv3x3_tiles_planes(int B, int H, int W, int cout, int planes) {   // H, W of the tile space (swapped when transposed)
+    const int tr = dc_tile_rows(B, H, W, cout, planes);
     return (int64_t)B * ((W + DC_TW - 1) / DC_TW) * ((H + tr - 1) / tr);
 }
+
+extern "C" int64_t gga_dense_conv3x3_tiles(int B, int H, int W, int cout) { return gga_dense_conv3x3_tiles_planes(B, H, W, cout, 3); }
 
 // Whether the BatchNorm-backward epilogue (gga_dense_conv3x3_bn_bwd) is cheaper than the reduce pass it replaces. Measured
 // inside the PointPillars step (16 frames): 64 output channels (two workgroups per CU, the other one's MFMAs cover the
 // epilogue's loads) + 0 us per launch against 100 us of reduce pass; 128 channels in 16-row tiles + 25 .. 100 us against
 // 55 .. 200; 128 channels in 8-row tiles (small maps, one workgroup per CU) + 33 us against 15: not there.
 extern "C" int gga_dense_conv3x3_bn_bwd_pays(int B, int H, int W, int cout) {
-    return cout == 64 || dc_tile_rows(B, H, W, cout) == 16;
+    return cout == 64 || dc_tile_rows(B, H, W, cout, 3) == 16;
 }
 
 extern "C" int gga_dense_conv3x3_slice(const float* x, const void* split_weight, int B, int H, int W, int cin, int cout,
@@ -583,7 +564,15 @@ extern "C" int gga_dense_conv3x3_bn_bwd(const float* x, const void* split_weight
                 "gga_dense_conv3x3: need cin %% 32 == 0 and cout 64 or 128 (got %d -> %d)", cin, cout);
     const int prow = transposed ? 1 : W, pcol = transposed ? W : 1;
     if (transposed) { const int t = H; H = W; W = t; }          // tile space of the transposed walk
-    const int trows = dc_tile_rows(B, H, W, cout);
+    if (dc_ws_enabled(planes) && cin <= DC_WS_MAX_CIN) {      // two fp16 planes: the producer / consumer form (dense_conv_ws.hip)
+        hipEvent_t* tev = gga_timing_acquire(GGA_TIME_DENSE_CONV, GGA_TIMING_CONV_KEY(cin, cout, (int64_t)H * W));
+        GGA_TIME_START(tev, stream);
+        const int rc = dc_launch_ws(x, split_weight, B, H, W, cin, cout, y, (int)y_pixel_stride, prow, pcol, stats, amax_x, amax_weight, bn,
+                                    stream);
+        GGA_TIME_STOP(tev, stream);
+        return rc;
+    }
+    const int trows = dc_tile_rows(B, H, W, cout, planes);
     const int tx = (W + DC_TW - 1) / DC_TW, ty = (H + trows - 1) / trows;
     const int64_t n_tiles = (int64_t)B * tx * ty;
     GGA_REQUIRE(n_tiles < 2147483647ll, "gga_dense_conv3x3: too many tiles");

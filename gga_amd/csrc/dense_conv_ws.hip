@@ -1,0 +1,349 @@
+// a4 / a5: the 3x3 stride-1 convolutions of the BEV trunk and the head (mmdet3d/models/backbones/second.py:58-63,
+// dense_heads/centerpoint_head.py:58-68), forward and backward-data on two fp16 operand planes - the producer / consumer form.
+//
+// Why a second form. The lock-step kernel of dense_conv.hip has every wave stage operands AND multiply: at each chunk head all
+// waves wait for the halo loads, split them, write LDS and meet at a barrier while the matrix pipes idle, and every stage's
+// weight copy sits between the MFMAs of the wave that issues it. Ablation builds of that kernel (round 4, tools_dev/abl_dense.sh:
+// staging compiled out, MFMAs and fragment reads kept) run 19-26 % faster than the kernel itself, and a barrier-per-stage
+// LDS-fed MFMA stream of the same shape (tools_dev/micro/mfma_sustained.hip) holds 0.58-0.62 of the nominal 2.5 PFLOP/s on
+// random data where the kernel reaches 0.35-0.37. Here the two jobs belong to different waves of one 512-thread workgroup per CU:
+//   waves 0-3 (one per SIMD), consumers: MT image rows x NT 32-column tiles each (128 accumulator registers), two fragment
+//     sets - a stage multiplies the set the previous stage read for it and reads the next stage's between its own MFMAs
+//     (2 MFMAs : 1 ds_read_b128, pinned with sched_group_barrier); nothing else in their loop but the stage barrier;
+//   waves 4-7, producers: the weight stage two stages ahead global -> registers -> LDS (three LDS buffers, two register
+//     sets, requested three stages ahead), and the NEXT chunk's halo image - loaded a chunk ahead, split into the two fp16
+//     planes and written into the other of two LDS halo images, a few pieces per stage, so that no stage carries a chunk head.
+// A workgroup walks tiles blockIdx.x, + gridDim.x, ... as one uninterrupted stream of stages: the producers stage the next
+// tile's first chunk during the current tile's last one, and only the consumers' epilogue interrupts the matrix pipes.
+// LDS images, packed weight layout (dense_pack_weight_kernel / weight_bank.hip), arithmetic and epilogues (scale back, BatchNorm
+// statistics, the BatchNorm-backward mask + sums of DcBnBwd) are those of dense_conv3x3_x9_kernel; results differ from it only
+// in the order of the per-tile statistics' partial sums.
+#include <stdlib.h>
+
+#include "dense_conv.h"
+
+#define GGA_MAX_DEVICES 64
+__device__ __attribute__((aligned(16))) float dc_zero_page[DC_WS_MAX_CIN];      // what a halo piece outside the image is read from
+
+template <int NT, int MT>
+__global__ __launch_bounds__(512, 2) void dense_conv3x3_ws_kernel(const float* __restrict__ X, const uint16_t* __restrict__ Wp, int B,
+                                                                   int H, int W, int cin, int cout, int tiles_x, int tiles_y,
+                                                                   float* __restrict__ Y, int ystride, int prow, int pcol,
+                                                                   double* __restrict__ stats, const uint32_t* __restrict__ amax_x,
+                                                                   const uint32_t* __restrict__ amax_w, DcBnBwd bn,
+                                                                   const float* __restrict__ zero_page) {
+    constexpr int TR = 4 * MT, HP = (TR + 2) * DC_HW, CO = NT * 32;
+    constexpr int APL = HP * DC_ROWB, ASZ = 2 * APL;                       // one plane / both planes of a halo image
+    constexpr int BPL = CO * DC_ROWB, BSZ = 2 * BPL;                       // one plane / both planes of a weight stage
+    constexpr int BPIECES = 2 * CO * 2, NB = BPIECES / 256;                // 16-byte pieces of a weight stage, per producer lane
+    constexpr int NA = (HP * 4 + 255) / 256;                               // float4 pieces of a halo chunk per producer lane
+    static_assert(NB == 1 || NB == 2, "weight stage pieces per producer lane");
+    __shared__ __attribute__((aligned(16))) unsigned char As[2 * ASZ];
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[3 * BSZ];
+    __shared__ float red[4 * 2 * CO];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool consumer = wave < 4;
+    const int r = lane & 31, h = lane >> 5;
+    const int per_img = tiles_x * tiles_y, n_tiles = B * per_img, nchunks = cin / DC_CK;
+    const int sbx = h2_scale_exp(*amax_x), sbw = h2_scale_exp(*amax_w);
+    const float xscale = h2_scale(sbx);
+    int tile = blockIdx.x;
+    if (tile >= n_tiles) return;
+
+    // ---- producer state: pieces f = ptid + 256 e of a halo chunk = pixel f / 4, channels 4 (f % 4) .. + 3
+    const int ptid = tid - 256;
+    typedef float ws_v2f __attribute__((ext_vector_type(2)));
+    float4 ra[NA];
+    const float* pcur[NA];                     // piece e of the current / next tile: its 16-channel chunk 0 in the image, or the zero page
+    const float* pnxt[NA];                     // for pixels outside the image (no select on the loaded values, no flag to carry)
+    uint4 bq0, bq1, cq0, cq1;
+    bq0 = bq1 = cq0 = cq1 = make_uint4(0, 0, 0, 0);
+#define WS_AOFF(P, T_) {                                                                                              \
+        const int tb_ = (T_) / per_img, rem_ = (T_) - tb_ * per_img;                                                  \
+        const int ty0_ = (rem_ / tiles_x) * TR, tx0_ = (rem_ % tiles_x) * DC_TW;                                      \
+        const float* xb_ = X + (int64_t)tb_ * H * W * cin;                                                            \
+        _Pragma("unroll") for (int e = 0; e < NA; ++e) {                                                             \
+            const int f = ptid + 256 * e;                                                                             \
+            const int hp = f >> 2, q = f & 3;                                                                         \
+            const int hr = hp / DC_HW, hx = hp - hr * DC_HW;                                                          \
+            const int iy = ty0_ + hr - 1, ix = tx0_ + hx - 1;                                                         \
+            const bool ok = hp < HP && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;                     \
+            P[e] = ok ? xb_ + ((iy * prow + ix * pcol) * cin + q * 4) : zero_page;                                 \
+        } }
+#define WS_LOAD_PIECE(E, P, CH) ra[E] = *reinterpret_cast<const float4*>(P[E] + (CH) * DC_CK);
+#define WS_STORE_PIECE(E, BUF) {                                                                                      \
+        const int f = ptid + 256 * (E);                                                                               \
+        if (f < HP * 4) {                                                                                             \
+            ws_v2f lo_ = {ra[E].x, ra[E].y}, hi_ = {ra[E].z, ra[E].w};                                                \
+            lo_ *= xscale; hi_ *= xscale;                                                                             \
+            unsigned char* dst = As + (BUF) * ASZ + (f >> 2) * DC_ROWB + (f & 3) * 8;                                 \
+            uint32_t lo1, lo2, hi1, hi2;                                                                              \
+            h2_split2(lo_.x, lo_.y, lo1, lo2); h2_split2(hi_.x, hi_.y, hi1, hi2);                                     \
+            *reinterpret_cast<uint2*>(dst) = make_uint2(lo1, hi1);                                                    \
+            *reinterpret_cast<uint2*>(dst + APL) = make_uint2(lo2, hi2);                                              \
+        } }
+    // weight stage (tap, 16-channel chunk): contiguous and in LDS piece order in the packed operand (piece f = (plane, column, half))
+#define WS_BLD(TAP, CH, V0, V1) {                                                                                     \
+        const uint4* bsrc = reinterpret_cast<const uint4*>(Wp + ((int64_t)(TAP) * nchunks + (CH)) * (2 * CO * DC_CK)); \
+        V0 = bsrc[ptid]; if (NB > 1) V1 = bsrc[ptid + 256]; }
+#define WS_BST(BUF, V0, V1) {                                                                                         \
+        *reinterpret_cast<uint4*>(Bs + (BUF) * BSZ + (ptid >> 1) * DC_ROWB + (ptid & 1) * 16) = V0;                   \
+        if (NB > 1) { const int f_ = ptid + 256; *reinterpret_cast<uint4*>(Bs + (BUF) * BSZ + (f_ >> 1) * DC_ROWB + (f_ & 1) * 16) = V1; } }
+
+    // ---- consumer state
+    mf_v16 acc[MT][NT];
+    mf_v8h fa[MT][2], fb[NT][2], ga[MT][2], gb[NT][2];
+#define WS_READ_A(FA, TAP, HB) {                                                                                      \
+        const unsigned char* Ap = As + (HB) * ASZ + ((MT * wave + (TAP) / 3) * DC_HW + r + (TAP) % 3) * DC_ROWB + h * 16; \
+        _Pragma("unroll") for (int m = 0; m < MT; ++m) _Pragma("unroll") for (int p = 0; p < 2; ++p)                  \
+            FA[m][p] = *reinterpret_cast<const mf_v8h*>(Ap + p * APL + m * DC_HW * DC_ROWB); }
+#define WS_READ_B(FB, BUF) {                                                                                          \
+        const unsigned char* Bp = Bs + (BUF) * BSZ + r * DC_ROWB + h * 16;                                            \
+        _Pragma("unroll") for (int t = 0; t < NT; ++t) _Pragma("unroll") for (int p = 0; p < 2; ++p)                  \
+            FB[t][p] = *reinterpret_cast<const mf_v8h*>(Bp + p * BPL + t * 32 * DC_ROWB); }
+    // partial products smallest first; tiles innermost so consecutive MFMAs never share an accumulator
+#define WS_MM1(FA, FB, PA, PB) _Pragma("unroll") for (int m = 0; m < MT; ++m) _Pragma("unroll") for (int t = 0; t < NT; ++t) acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(FA[m][PA], FB[t][PB], acc[m][t], 0, 0, 0);
+#define WS_MMA(FA, FB) { WS_MM1(FA, FB, 0, 1) WS_MM1(FA, FB, 1, 0) WS_MM1(FA, FB, 0, 0) }
+    constexpr int N_MFMA = 3 * MT * NT, N_READ = 2 * MT + 2 * NT;          // per stage: 24 and 12
+    static_assert(N_MFMA == 2 * N_READ, "two MFMAs per fragment read");
+
+    // ---- prologue: the first tile's first halo chunk and weight stages 0 and 1 in LDS, stage 2 and halo chunk 1 in registers
+    if (!consumer) {
+        WS_AOFF(pcur, tile)
+#pragma unroll
+        for (int e = 0; e < NA; ++e) { WS_LOAD_PIECE(e, pcur, 0) }
+        WS_BLD(0, 0, bq0, bq1)
+        WS_BLD(1, 0, cq0, cq1)
+#pragma unroll
+        for (int e = 0; e < NA; ++e) { WS_STORE_PIECE(e, 0) }
+        WS_BST(0, bq0, bq1)
+        WS_BST(1, cq0, cq1)
+        WS_BLD(2, 0, bq0, bq1)
+#pragma unroll
+        for (int e = 0; e < NA; ++e) { WS_LOAD_PIECE(e, pcur, 1) }
+    }
+    __syncthreads();
+
+    // Stage s = chunk * 9 + tap, one barrier per stage, the same number of barriers on both paths. Consumers: MFMAs of the set
+    // read during stage s - 1, reads of stage s + 1's set. Producers: request the weights of stage s + 3 (register set
+    // (s + 1) % 2), handle the halo pieces scheduled on this tap - piece e of the NEXT chunk's image (loaded a chunk ago) is
+    // split and written into halo image (chunk + 1) % 2, and the same piece of the chunk after it is requested -, then write the
+    // weights of stage s + 2 (requested during stage s - 1, set s % 2) into LDS buffer (s + 2) % 3. Chunks come in pairs so that
+    // register sets and halo images are compile-time. (Two loops, not one loop with a branch per stage: in one loop the
+    // register allocator keeps both roles' state alive in every wave - 1300 spilled registers.)
+    if (!consumer) {
+        for (; tile < n_tiles; tile += gridDim.x) {
+            if (tile + (int)gridDim.x < n_tiles) {
+                WS_AOFF(pnxt, tile + (int)gridDim.x)
+            } else {
+#pragma unroll
+                for (int e = 0; e < NA; ++e) pnxt[e] = zero_page;
+            }
+#define WS_STAGE_P(TAP, CH, HB, INCUR2, L0, L1, S0, S1) {                                                             \
+                if ((TAP) + 3 < 9) { WS_BLD((TAP) + 3, (CH), L0, L1) }                                                \
+                else { WS_BLD((TAP) + 3 - 9, (CH) + 1 < nchunks ? (CH) + 1 : 0, L0, L1) }                             \
+                if ((TAP) < 8) {                                                                                      \
+                    _Pragma("unroll") for (int e = 0; e < NA; ++e) if ((e * 8) / NA == (TAP)) {                       \
+                        WS_STORE_PIECE(e, 1 - (HB))                                                                   \
+                        if (INCUR2) { WS_LOAD_PIECE(e, pcur, (CH) + 2) }                                              \
+                        else { WS_LOAD_PIECE(e, pnxt, (CH) + 2 - nchunks) }                                           \
+                    }                                                                                                 \
+                }                                                                                                     \
+                WS_BST(((TAP) + 2) % 3, S0, S1)                                                                       \
+                __syncthreads(); }
+#define WS_EVEN(TAP, CH, HB, INCUR2) WS_STAGE_P(TAP, CH, HB, INCUR2, cq0, cq1, bq0, bq1)      /* even stage: request into set 1, write set 0 */
+#define WS_ODD(TAP, CH, HB, INCUR2) WS_STAGE_P(TAP, CH, HB, INCUR2, bq0, bq1, cq0, cq1)
+            // (the last pair of chunks, whose pieces two chunks ahead are the next tile's, is its own copy of the code: one loop with
+            // the tile as a run-time choice selects between two 64-bit pointers per piece with vector instructions)
+#define WS_PAIR(CH, INCUR2) {                                                                                         \
+                WS_EVEN(0, CH, 0, INCUR2) WS_ODD(1, CH, 0, INCUR2) WS_EVEN(2, CH, 0, INCUR2) WS_ODD(3, CH, 0, INCUR2) WS_EVEN(4, CH, 0, INCUR2) WS_ODD(5, CH, 0, INCUR2) WS_EVEN(6, CH, 0, INCUR2) WS_ODD(7, CH, 0, INCUR2) WS_EVEN(8, CH, 0, INCUR2) \
+                WS_ODD(0, (CH) + 1, 1, INCUR2) WS_EVEN(1, (CH) + 1, 1, INCUR2) WS_ODD(2, (CH) + 1, 1, INCUR2) WS_EVEN(3, (CH) + 1, 1, INCUR2) WS_ODD(4, (CH) + 1, 1, INCUR2) WS_EVEN(5, (CH) + 1, 1, INCUR2) WS_ODD(6, (CH) + 1, 1, INCUR2) WS_EVEN(7, (CH) + 1, 1, INCUR2) WS_ODD(8, (CH) + 1, 1, INCUR2) }
+            int ch = 0;
+            for (; ch + 2 < nchunks; ch += 2) WS_PAIR(ch, 1)
+            WS_PAIR(ch, 0)
+#undef WS_PAIR
+#undef WS_EVEN
+#undef WS_ODD
+#undef WS_STAGE_P
+#pragma unroll
+            for (int e = 0; e < NA; ++e) pcur[e] = pnxt[e];
+            if (stats) { __syncthreads(); __syncthreads(); }               // the consumers' statistics fold
+        }
+        return;
+    }
+
+    for (; tile < n_tiles; tile += gridDim.x) {
+        const int tb = tile / per_img, trem = tile - tb * per_img;
+        const int y0 = (trem / tiles_x) * TR, x0 = (trem % tiles_x) * DC_TW;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[m][t][i] = 0.0f;
+        WS_READ_A(fa, 0, 0)
+        WS_READ_B(fb, 0)
+#define WS_STAGE_C(TAP, CH, HB, LASTABLE, CA, CB, XA, XB) {      /* (a tile's last stage reads a set nobody uses: no branch in the stream) */ \
+            WS_READ_A(XA, ((TAP) + 1) % 9, (TAP) == 8 ? 1 - (HB) : (HB))                                              \
+            WS_READ_B(XB, ((TAP) + 1) % 3)                                                                            \
+            WS_MMA(CA, CB)                                                                                            \
+            _Pragma("unroll") for (int g_ = 0; g_ < N_READ; ++g_) {                                                   \
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); } \
+            __syncthreads(); }
+#define WS_EVEN(TAP, CH, HB, LASTABLE) WS_STAGE_C(TAP, CH, HB, LASTABLE, fa, fb, ga, gb)
+#define WS_ODD(TAP, CH, HB, LASTABLE) WS_STAGE_C(TAP, CH, HB, LASTABLE, ga, gb, fa, fb)
+        for (int ch = 0; ch < nchunks; ch += 2) {
+            WS_EVEN(0, ch, 0, 0) WS_ODD(1, ch, 0, 0) WS_EVEN(2, ch, 0, 0) WS_ODD(3, ch, 0, 0) WS_EVEN(4, ch, 0, 0) WS_ODD(5, ch, 0, 0) WS_EVEN(6, ch, 0, 0) WS_ODD(7, ch, 0, 0) WS_EVEN(8, ch, 0, 0)
+            WS_ODD(0, ch + 1, 1, 1) WS_EVEN(1, ch + 1, 1, 1) WS_ODD(2, ch + 1, 1, 1) WS_EVEN(3, ch + 1, 1, 1) WS_ODD(4, ch + 1, 1, 1) WS_EVEN(5, ch + 1, 1, 1) WS_ODD(6, ch + 1, 1, 1) WS_EVEN(7, ch + 1, 1, 1) WS_ODD(8, ch + 1, 1, 1)
+        }
+#undef WS_EVEN
+#undef WS_ODD
+#undef WS_STAGE_C
+        // ---- epilogue (consumers): back from the scaled operands (two exact powers of two), then as dense_conv3x3_x9_kernel
+        {
+            const float dx = h2_descale(sbx), dw = h2_descale(sbw);
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc[m][t][i] = acc[m][t][i] * dx * dw;
+        }
+        // D layout of 32x32x16: register v of lane l holds row (v/4)*8 + (l/32)*4 + v%4 (= pixel of the M tile's row), column l%32
+        float s1[NT], s2[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { s1[t] = 0.0f; s2[t] = 0.0f; }
+        if (bn.y) {                                        // see DcBnBwd: ReLU mask and the BatchNorm backward sums
+            float bsc[NT], bsh[NT], bmu[NT], biv[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int c = t * 32 + r;
+                bmu[t] = bn.mean[c]; biv[t] = bn.invstd[c];
+                gga_bn_scale_shift(bn.gamma ? bn.gamma[c] : 1.0f, bn.beta ? bn.beta[c] : 0.0f, bmu[t], biv[t], bsc[t], bsh[t]);
+            }
+            constexpr int VB = 32 / NT;                    // values of y requested before the first of them is used
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int oy = y0 + MT * wave + m;
+                if (oy >= H) continue;
+#pragma unroll
+                for (int v0 = 0; v0 < 16; v0 += VB) {
+                    float yv[VB][NT];
+#pragma unroll
+                    for (int j = 0; j < VB; ++j) {
+                        const int ox = x0 + ((v0 + j) >> 2) * 8 + h * 4 + ((v0 + j) & 3);
+                        const float* src = bn.y + ((int64_t)tb * H * W + oy * prow + (ox < W ? ox : W - 1) * pcol) * bn.ystride;
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) yv[j][t] = src[t * 32 + r];
+                    }
+#pragma unroll
+                    for (int j = 0; j < VB; ++j) {
+                        const int ox = x0 + ((v0 + j) >> 2) * 8 + h * 4 + ((v0 + j) & 3);
+                        if (ox >= W) continue;
+                        float* dst = Y + ((int64_t)tb * H * W + oy * prow + ox * pcol) * ystride;
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) {
+                            const float g = fmaf(yv[j][t], bsc[t], bsh[t]) > 0.0f ? acc[m][t][v0 + j] : 0.0f;
+                            dst[t * 32 + r] = g;
+                            s1[t] += g; s2[t] += g * ((yv[j][t] - bmu[t]) * biv[t]);
+                        }
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int oy = y0 + MT * wave + m;
+                if (oy >= H) continue;
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const int ox = x0 + (v >> 2) * 8 + h * 4 + (v & 3);
+                    if (ox >= W) continue;
+                    float* dst = Y + ((int64_t)tb * H * W + oy * prow + ox * pcol) * ystride;       // ystride > cout: a channel slice of a wider tensor
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) dst[t * 32 + r] = acc[m][t][v];
+                }
+            }
+        }
+        if (stats) {
+            // per-channel sum and sum of squares of the tile's outputs (the batch statistics of the BatchNorm that follows), or the
+            // BatchNorm-backward sums collected above: lane sums over its pixels, the two half waves and the four consumer waves are
+            // folded through LDS, one f64 row pair per tile
+            if (!bn.y)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const bool rowok = y0 + MT * wave + m < H;
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const bool ok = rowok && x0 + (v >> 2) * 8 + h * 4 + (v & 3) < W;
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const float a = ok ? acc[m][t][v] : 0.0f;
+                        s1[t] += a; s2[t] += a * a;
+                    }
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                s1[t] += __shfl_xor(s1[t], 32);
+                s2[t] += __shfl_xor(s2[t], 32);
+                if (h == 0) { red[(wave * 2 + 0) * CO + t * 32 + r] = s1[t]; red[(wave * 2 + 1) * CO + t * 32 + r] = s2[t]; }
+            }
+            __syncthreads();
+            if (tid < 2 * CO) {
+                const int which = tid / CO, c = tid - which * CO;
+                if (c < cout) {
+                    double a = 0.0;
+#pragma unroll
+                    for (int w_ = 0; w_ < 4; ++w_) a += (double)red[(w_ * 2 + which) * CO + c];
+                    stats[((int64_t)tile * 2 + which) * cout + c] = a;
+                }
+            }
+            __syncthreads();                                  // red is the next tile's
+        }
+    }
+#undef WS_AOFF
+#undef WS_LOAD_PIECE
+#undef WS_STORE_PIECE
+#undef WS_BLD
+#undef WS_BST
+#undef WS_READ_A
+#undef WS_READ_B
+#undef WS_MM1
+#undef WS_MMA
+}
+
+bool dc_ws_enabled(int planes) {
+    static const int on = getenv("GGA_DC_WS") ? atoi(getenv("GGA_DC_WS")) : 1;
+    return planes == 2 && on != 0;
+}
+
+int dc_launch_ws(const float* x, const void* split_weight, int B, int H, int W, int cin, int cout, float* y, int ystride, int prow,
+                 int pcol, double* stats, const uint32_t* amax_x, const uint32_t* amax_weight, DcBnBwd bn, hipStream_t stream) {
+    const int trows = cout == 128 ? 8 : 16;
+    const int tx = (W + DC_TW - 1) / DC_TW, ty = (H + trows - 1) / trows;
+    const int64_t n_tiles = (int64_t)B * tx * ty;
+    GGA_REQUIRE(n_tiles < 2147483647ll, "gga_dense_conv3x3: too many tiles");
+    // one workgroup per CU (512 threads at 256 registers); more tiles than CUs: persistent workgroups, tiles b, b + grid, ...
+    static const float* zero_pages[GGA_MAX_DEVICES] = {};           // per device: the address of dc_zero_page (a lookup, not an allocation)
+    int dev = 0;
+    GGA_CHECK_HIP(hipGetDevice(&dev), "hipGetDevice");
+    GGA_REQUIRE(dev >= 0 && dev < GGA_MAX_DEVICES, "gga_dense_conv3x3: device %d", dev);
+    if (!zero_pages[dev]) {
+        void* p = nullptr;
+        GGA_CHECK_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(dc_zero_page)), "hipGetSymbolAddress(dc_zero_page)");
+        zero_pages[dev] = (const float*)p;
+    }
+    const float* zero_page = zero_pages[dev];
+    static const int max_grid = getenv("GGA_DC_WS_GRID") ? atoi(getenv("GGA_DC_WS_GRID")) : 256;
+    const dim3 grid((unsigned)(n_tiles < max_grid ? n_tiles : max_grid)), block(512);
+    if (cout == 128)
+        hipLaunchKernelGGL((dense_conv3x3_ws_kernel<4, 2>), grid, block, 0, stream, x, (const uint16_t*)split_weight, B, H, W, cin, cout,
+                           tx, ty, y, ystride, prow, pcol, stats, amax_x, amax_weight, bn, zero_page);
+    else
+        hipLaunchKernelGGL((dense_conv3x3_ws_kernel<2, 4>), grid, block, 0, stream, x, (const uint16_t*)split_weight, B, H, W, cin, cout,
+                           tx, ty, y, ystride, prow, pcol, stats, amax_x, amax_weight, bn, zero_page);
+    GGA_CHECK_LAUNCH("dense_conv3x3_ws_kernel");
+    return GGA_OK;
+}

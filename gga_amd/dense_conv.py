@@ -298,7 +298,7 @@ def _run(x, weight, backward, want_stats=False, x_amax=None, w_amax=None, y=None
     none6 = (None, 0, None, None, None, None)
     if n_out in (64, 128):
         if want_stats:
-            tiles = int(L.gga_dense_conv3x3_tiles(B, W, H, n_out) if tr else L.gga_dense_conv3x3_tiles(B, H, W, n_out))
+            tiles = int(L.gga_dense_conv3x3_tiles_planes(B, W, H, n_out, planes) if tr else L.gga_dense_conv3x3_tiles_planes(B, H, W, n_out, planes))
             stats = torch.empty((tiles, 2, n_out), dtype=torch.float64, device=x.device)
         wp, wa = _operand(weight, backward, tr, planes)
         check(L.gga_dense_conv3x3_bn_bwd(F._p(x), F._p(wp), B, H, W, n_in, n_out,
@@ -333,7 +333,7 @@ def _run(x, weight, backward, want_stats=False, x_amax=None, w_amax=None, y=None
             wp, wa = _operand(weight, backward, tr, planes, c0)
             st = None
             if want_stats:                          # per-channel sums of this 128-channel block of the output
-                tiles = int(L.gga_dense_conv3x3_tiles(B, W, H, 128) if tr else L.gga_dense_conv3x3_tiles(B, H, W, 128))
+                tiles = int(L.gga_dense_conv3x3_tiles_planes(B, W, H, 128, planes) if tr else L.gga_dense_conv3x3_tiles_planes(B, H, W, 128, planes))
                 st = torch.empty((tiles, 2, 128), dtype=torch.float64, device=x.device)
                 parts.append((c0, 128, st))
             check(L.gga_dense_conv3x3_bn_bwd(F._p(x), F._p(wp), B, H, W, n_in, 128,

@@ -1003,7 +1003,6 @@ class _HeadBranches(torch.autograd.Function):
         rows, dev, tot = B * H * W, x.device, C * n
         tr = dense_conv._transposed(H, W)
         Y = torch.empty((B, tot, H, W), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
-        tiles = int(L.gga_dense_conv3x3_tiles(B, W, H, C) if tr else L.gga_dense_conv3x3_tiles(B, H, W, C))
         outs, saved_all, ss_all = [], [], []
         x_amax = dense_conv.tensor_amax(x) if dense_conv.PLANES == 2 else None     # from x's producer, for all n convolutions
         # the first convolutions two branches at a time (64 -> 128 channels into adjacent column blocks of Y): the

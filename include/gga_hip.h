@@ -331,7 +331,11 @@ int gga_sparse_conv_apply_split_strided(const float* x, const int32_t* map, cons
  * that follows: stats [gga_dense_conv3x3_tiles(B,H,W,cout)][2][cout] f64 = per-tile sum and sum of
  * squares per channel - the `partials` of gga_bn_relu_fwd_partials / gga_bn_stats_partials, so
  * the BatchNorm does not read y a second time for its reduction. stats may be NULL. */
-int64_t gga_dense_conv3x3_tiles(int B, int H, int W, int cout);   /* tiles are 8 x 32 pixels for cout 64, 16 x 32 for 128 */
+int64_t gga_dense_conv3x3_tiles(int B, int H, int W, int cout);   /* rows of `stats` of a three-plane launch (= ..._tiles_planes(.., 3)) */
+/* rows of `stats` for a launch of this arithmetic: the two-plane launches run the producer / consumer form
+ * (dense_conv_ws.hip: tiles of 8 x 32 pixels at 128 output channels, 16 x 32 at 64; GGA_DC_WS=0 puts them back on the
+ * lock-step kernel), the three-plane launches tiles of 8 or 16 rows by shape. */
+int64_t gga_dense_conv3x3_tiles_planes(int B, int H, int W, int cout, int planes);
 int gga_dense_conv3x3_stats(const float* x, const void* split_weight, int B, int H, int W, int cin, int cout,
                             float* y, double* stats, void* stream);
 /* Weight gradient of the same convolution, bf16x9 with the pixel index as the GEMM's K (transposed

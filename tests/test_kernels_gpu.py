@@ -595,10 +595,9 @@ def test_head_branches_one_node_vs_branch_by_branch(planes, monkeypatch):
         results.append((ys, xi.grad, br))
     (y_n, gx_n, br_n), (y_s, gx_s, br_s), (y_e, gx_e, br_e) = results
     for i in range(len(couts)):
-        if planes == 2:
-            assert torch.equal(y_n[i], y_s[i])                    # same kernels, same order of operations
-        else:       # the node runs branch pairs on the 128-column form of the kernel, whose six-product order per tile differs
-            torch.testing.assert_close(y_n[i], y_s[i], rtol=1e-5, atol=1e-5)
+        # the node runs branch pairs on the 128-column form of the kernel: the convolution's values are the same, but its tiles
+        # (8 rows against the 64-column form's 16), and with them the order of the BatchNorm statistics' partial sums, are not
+        torch.testing.assert_close(y_n[i], y_s[i], rtol=1e-5, atol=1e-5)
         torch.testing.assert_close(y_n[i], y_e[i], rtol=1e-4, atol=1e-4)
         for j in (0, 2):
             torch.testing.assert_close(br_n[i][j].weight.grad, br_s[i][j].weight.grad, rtol=1e-5, atol=1e-5)

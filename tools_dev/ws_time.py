@@ -1,0 +1,24 @@
+import os, sys, torch
+sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '/root/repo'))
+from gga_amd import dense_conv
+dense_conv.PLANES = 2
+dev = 'cuda:0'
+out = []
+def t(B, C, Co, H, W):
+    x = torch.randn(B, C, H, W, device=dev).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(Co, C, 3, 3, device=dev) * 0.05).contiguous(memory_format=torch.channels_last)
+    xa, wa = dense_conv._amax_bits(x), dense_conv._amax_bits(w)
+    trash = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+    ts = []
+    for i in range(12):
+        trash.fill_(float(i))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); y = dense_conv._run(x, w, False, True, x_amax=xa, w_amax=wa)[0]; e1.record(); torch.cuda.synchronize()
+        if i >= 4: ts.append(e0.elapsed_time(e1))
+    ts.sort()
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), padding=1)
+    err = float((y.double() - ref).abs().max() / ref.abs().max())
+    out.append(f'{ts[len(ts) // 2] * 1e3:6.0f} ({err:.1e})')
+for shp in ((16, 128, 128, 124, 108), (8, 128, 128, 200, 176), (16, 64, 64, 248, 216), (16, 384, 64, 248, 216), (16, 64, 128, 248, 216), (4, 128, 128, 62, 54)):
+    t(*shp)
+print(os.environ.get('GGA_DC_WS', 'ws'), ' '.join(out))

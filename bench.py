@@ -564,8 +564,8 @@ def main():
         me = Config.fromfile(args.config).model.pts_middle_encoder
         fh, fw = me.output_shape[0] // 2, me.output_shape[1] // 2
         # one pair per step around the scatter op; one per 128 -> 128 dense 3x3 convolution of SECOND's second stage (half the
-        # head's map size; forward and backward-data): the launches of dense_conv3x3_x9_kernel<4, 16, 2, 2, 0>, the
-        # instantiation the largest share of the step's time is in
+        # head's map size; forward and backward-data): the launches of dense_conv3x3_ws_kernel<4, 2> (two planes; three planes:
+        # dense_conv3x3_x9_kernel<4, 16, 3, 2, 0>), the instantiation the largest share of the step's time is in
         sites = [(_lib.TIME_SCATTER_FWD, args.steps, 0),
                  (_lib.TIME_DENSE_CONV, 36 * args.steps, _lib.timing_conv_key(128, 128, (fh // 2) * (fw // 2)))]
     main_run = run_workload(args.config, args.batch, args.steps, args.warmup, args, rank, world, device, sites)
@@ -594,7 +594,8 @@ def main():
             res['roofline'] = scatter_roofline(main_run['model'], main_run['batches'], tm[_lib.TIME_SCATTER_FWD])
         if tm.get(_lib.TIME_DENSE_CONV):
             flops = 2.0 * args.batch * (fh // 2) * (fw // 2) * 128 * 128 * 9
-            res['mfma_roofline'] = mfma_roofline('dense_conv3x3_x9_kernel<4,16,2,2,0> (128->128, %dx%d, fwd + bwd-data)' % (fh // 2, fw // 2),
+            kname = 'dense_conv3x3_ws_kernel<4,2>' if main_run['runner'].planes == 2 else 'dense_conv3x3_x9_kernel<4,16,3,2,0>'
+            res['mfma_roofline'] = mfma_roofline('%s (128->128, %dx%d, fwd + bwd-data)' % (kname, fh // 2, fw // 2),
                                                  flops, tm[_lib.TIME_DENSE_CONV],
                                                  len(tm[_lib.TIME_DENSE_CONV]) / args.steps, ms_per_step, main_run['runner'].planes)
         res['config']['matrix_planes'] = main_run['runner'].planes          # what the timed steps ran on (2 unless the guard fell back)

@@ -98,6 +98,7 @@ SIGNATURES = {
     'gga_dense_conv3x3_planes': (i32, [vp, vp, i32, i32, i32, i32, i32, vp, i64, i32, vp, i32, vp, vp, vp]),
     'gga_dense_conv3x3_levels': (i32, [i32, vp, vp, vp, vp, i32, i32, i32, vp, i64, i32, vp, vp, vp, i32, i32, vp, vp]),
     'gga_dense_conv3x3_bn_bwd_pays': (i32, [i32, i32, i32, i32]),
+    'gga_dense_conv3x3_bn_bwd_pays_planes': (i32, [i32, i32, i32, i32, i32]),
     'gga_dense_conv3x3_bn_bwd': (i32, [vp, vp, i32, i32, i32, i32, i32, vp, i64, i32, vp, i32, vp, vp, vp, i64, vp, vp, vp, vp, vp]),
     'gga_dense_wgrad3x3_planes': (i32, [vp, vp, i32, i32, i32, i32, i32, vp, i64, i64, i64, i64, i32, i32, vp, vp, vp, sz, vp]),
     'gga_absmax_table_blocks': (i64, [i64]),
@@ -106,6 +107,7 @@ SIGNATURES = {
     'gga_dense_wgrad3x3_block_amax': (i32, [vp, vp, i32, i32, i32, i32, i32, vp, i64, i64, i64, i64, i32, i32, vp, i32, vp, i32, vp, sz, vp]),
     'gga_dense_conv3x3_tiles': (i64, [i32, i32, i32, i32]),
     'gga_dense_conv3x3_tiles_planes': (i64, [i32, i32, i32, i32, i32]),
+    'gga_dense_conv3x3_tile_rows': (i32, [i32, i32, i32, i32, i32]),
     'gga_dense_conv3x3_slice': (i32, [vp, vp, i32, i32, i32, i32, i32, vp, i64, i32, vp, vp]),
     'gga_dense_conv3x3_stats': (i32, [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]),
     'gga_bn_relu_fwd_partials': (i32, [vp, vp, vp, vp, vp, vp, i64, i32, f32, f32, i32, vp, i64, vp, vp, vp, i32, vp, sz, vp]),

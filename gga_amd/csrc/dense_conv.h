@@ -24,10 +24,20 @@ struct DcBnBwd {
     int ystride;
 };
 
+// Several 128-channel slices of one convolution's output in one launch of the producer / consumer form (n <= 1: one output)
+#define DC_MAX_SLICES 16
+struct DcSlices {
+    int n;
+    const uint16_t* w[DC_MAX_SLICES];        // packed weight operand of the slice
+    float* y[DC_MAX_SLICES];                 // first output column of the slice (pixel stride: the launch's)
+    double* stats[DC_MAX_SLICES];            // the slice's per-tile BatchNorm sums, or null with the launch's `stats`
+};
+
 // rows of a tile (= of a row of `stats`) for a launch of this shape and arithmetic; H, W of the tile space
 int dc_tile_rows(int B, int H, int W, int cout, int planes);
 // whether dense_conv_ws.hip runs launches of this arithmetic (two fp16 planes, GGA_DC_WS != 0)
 bool dc_ws_enabled(int planes);
 // the producer / consumer form: same arguments as gga_dense_conv3x3_bn_bwd after its checks (H, W, prow, pcol of the tile space)
 int dc_launch_ws(const float* x, const void* split_weight, int B, int H, int W, int cin, int cout, float* y, int ystride, int prow,
-                 int pcol, double* stats, const uint32_t* amax_x, const uint32_t* amax_weight, DcBnBwd bn, hipStream_t stream);
+                 int pcol, double* stats, const uint32_t* amax_x, const uint32_t* amax_weight, DcBnBwd bn, const DcSlices* slices,
+                 hipStream_t stream);

@@ -519,15 +519,25 @@ extern "C" int64_t gga_dense_conv3x3_tiles_planes(int B, int H, int W, int cout,
     return (int64_t)B * ((W + DC_TW - 1) / DC_TW) * ((H + tr - 1) / tr);
 }
 
+extern "C" int gga_dense_conv3x3_tile_rows(int B, int H, int W, int cout, int planes) { return dc_tile_rows(B, H, W, cout, planes); }
+
 extern "C" int64_t gga_dense_conv3x3_tiles(int B, int H, int W, int cout) { return gga_dense_conv3x3_tiles_planes(B, H, W, cout, 3); }
 
-// Whether the BatchNorm-backward epilogue (gga_dense_conv3x3_bn_bwd) is cheaper than the reduce pass it replaces. Measured
-// inside the PointPillars step (16 frames): 64 output channels (two workgroups per CU, the other one's MFMAs cover the
-// epilogue's loads) + 0 us per launch against 100 us of reduce pass; 128 channels in 16-row tiles + 25 .. 100 us against
-// 55 .. 200; 128 channels in 8-row tiles (small maps, one workgroup per CU) + 33 us against 15: not there.
-extern "C" int gga_dense_conv3x3_bn_bwd_pays(int B, int H, int W, int cout) {
-    return cout == 64 || dc_tile_rows(B, H, W, cout, 3) == 16;
+// Whether the BatchNorm-backward epilogue (gga_dense_conv3x3_bn_bwd) is cheaper than the reduce pass it replaces. Lock-step forms
+// (three planes; measured inside the PointPillars step, 16 frames): 64 output channels (two workgroups per CU, the other one's
+// MFMAs cover the epilogue's loads) + 0 us per launch against 100 us of reduce pass; 128 channels in 16-row tiles + 25 .. 100 us
+// against 55 .. 200; 128 channels in 8-row tiles (small maps, one workgroup per CU) + 33 us against 15: not there. Producer /
+// consumer form (two planes): everywhere - same box, alternating runs of the bench: PointPillars step 34.65 / 34.67 ms with the
+// epilogue on every launch against 34.90 / 34.92 with none and 35.06 / 34.89 with the lock-step rule; gga_kitti_config.py
+// 54.98 / 55.11 against 54.88 / 55.07 and 54.76.
+extern "C" int gga_dense_conv3x3_bn_bwd_pays_planes(int B, int H, int W, int cout, int planes) {
+    static const int forced = getenv("GGA_DC_BN_BWD_PAYS") ? atoi(getenv("GGA_DC_BN_BWD_PAYS")) : -1;      // A/B switch: 0 or 1
+    if (forced == 0 || forced == 1) return forced;
+    if (dc_ws_enabled(planes)) return 1;
+    return cout == 64 || dc_tile_rows(B, H, W, cout, planes) == 16;
 }
+
+extern "C" int gga_dense_conv3x3_bn_bwd_pays(int B, int H, int W, int cout) { return gga_dense_conv3x3_bn_bwd_pays_planes(B, H, W, cout, 3); }
 
 extern "C" int gga_dense_conv3x3_slice(const float* x, const void* split_weight, int B, int H, int W, int cin, int cout,
                                        float* y, int64_t y_pixel_stride, int transposed, double* stats, void* stream_) {
@@ -568,7 +578,7 @@ extern "C" int gga_dense_conv3x3_bn_bwd(const float* x, const void* split_weight
         hipEvent_t* tev = gga_timing_acquire(GGA_TIME_DENSE_CONV, GGA_TIMING_CONV_KEY(cin, cout, (int64_t)H * W));
         GGA_TIME_START(tev, stream);
         const int rc = dc_launch_ws(x, split_weight, B, H, W, cin, cout, y, (int)y_pixel_stride, prow, pcol, stats, amax_x, amax_weight, bn,
-                                    stream);
+                                    nullptr, stream);
         GGA_TIME_STOP(tev, stream);
         return rc;
     }
@@ -618,6 +628,28 @@ extern "C" int gga_dense_conv3x3_levels(int n_entries, const float* const* x, co
     GGA_REQUIRE(B >= 1 && cin >= 32 && cin % 32 == 0 && (cout == 64 || cout == 128) && y_pixel_stride >= cout &&
                     y_pixel_stride < 2147483647ll, "gga_dense_conv3x3_levels: need cin %% 32 == 0 and cout 64 or 128 (got %d -> %d)",
                 cin, cout);
+    static const int ws_slices = getenv("GGA_DC_WS_SLICES") ? atoi(getenv("GGA_DC_WS_SLICES")) : 1;       // A/B switch
+    if (ws_slices && dc_ws_enabled(planes) && cout == 128 && tile_rows == 8 && !bias && cin <= DC_WS_MAX_CIN) {
+        // 128-channel slices of ONE convolution's output (same input, one absmax): the producer / consumer form walks them as one grid
+        bool same = true;
+        for (int e = 1; e < n_entries; ++e)
+            same = same && x[e] == x[0] && heights[e] == heights[0] && widths[e] == widths[0] && amax_x[e] == amax_x[0];
+        if (same) {
+            GGA_REQUIRE(x[0] && heights[0] >= 1 && widths[0] >= 1 && (int64_t)heights[0] * widths[0] * cin < 2147483647ll && amax_x[0],
+                        "gga_dense_conv3x3_levels: bad entry 0");
+            DcSlices sl;
+            sl.n = n_entries;
+            for (int e = 0; e < n_entries; ++e) {
+                GGA_REQUIRE(y[e] && split_weight[e], "gga_dense_conv3x3_levels: bad entry %d", e);
+                sl.w[e] = (const uint16_t*)split_weight[e]; sl.y[e] = y[e]; sl.stats[e] = stats ? stats[e] : nullptr;
+            }
+            DcBnBwd nobn;
+            nobn.y = nullptr; nobn.gamma = nobn.beta = nobn.mean = nobn.invstd = nullptr; nobn.ystride = 0;
+            const int H = transposed ? widths[0] : heights[0], W = transposed ? heights[0] : widths[0];      // tile space
+            return dc_launch_ws(x[0], split_weight[0], B, H, W, cin, cout, y[0], (int)y_pixel_stride, transposed ? 1 : widths[0],
+                                transposed ? widths[0] : 1, stats ? stats[0] : nullptr, amax_x[0], amax_weight, nobn, &sl, stream);
+        }
+    }
     DcLevels lv;
     lv.n = n_entries;
     int64_t total = 0;

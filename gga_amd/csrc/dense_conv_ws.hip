@@ -31,7 +31,7 @@ __global__ __launch_bounds__(512, 2) void dense_conv3x3_ws_kernel(const float* _
                                                                    float* __restrict__ Y, int ystride, int prow, int pcol,
                                                                    double* __restrict__ stats, const uint32_t* __restrict__ amax_x,
                                                                    const uint32_t* __restrict__ amax_w, DcBnBwd bn,
-                                                                   const float* __restrict__ zero_page) {
+                                                                   const float* __restrict__ zero_page, DcSlices sl) {
     constexpr int TR = 4 * MT, HP = (TR + 2) * DC_HW, CO = NT * 32;
     constexpr int APL = HP * DC_ROWB, ASZ = 2 * APL;                       // one plane / both planes of a halo image
     constexpr int BPL = CO * DC_ROWB, BSZ = 2 * BPL;                       // one plane / both planes of a weight stage
@@ -45,7 +45,9 @@ __global__ __launch_bounds__(512, 2) void dense_conv3x3_ws_kernel(const float* _
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool consumer = wave < 4;
     const int r = lane & 31, h = lane >> 5;
-    const int per_img = tiles_x * tiles_y, n_tiles = B * per_img, nchunks = cin / DC_CK;
+    // sl.n > 1: the launch computes sl.n 128-channel slices of one convolution's output (same input, one weight operand, output
+    // columns and statistics per slice); tile t of the grid is tile t % img_tiles of slice t / img_tiles
+    const int per_img = tiles_x * tiles_y, img_tiles = B * per_img, n_tiles = img_tiles * (sl.n > 1 ? sl.n : 1), nchunks = cin / DC_CK;
     const int sbx = h2_scale_exp(*amax_x), sbw = h2_scale_exp(*amax_w);
     const float xscale = h2_scale(sbx);
     int tile = blockIdx.x;
@@ -59,8 +61,11 @@ __global__ __launch_bounds__(512, 2) void dense_conv3x3_ws_kernel(const float* _
     const float* pnxt[NA];                     // for pixels outside the image (no select on the loaded values, no flag to carry)
     uint4 bq0, bq1, cq0, cq1;
     bq0 = bq1 = cq0 = cq1 = make_uint4(0, 0, 0, 0);
+    const uint16_t* Wcur = sl.n > 1 ? sl.w[tile / img_tiles] : Wp;      // weight operand of the current / next tile's slice
+    const uint16_t* Wnxt = Wcur;
 #define WS_AOFF(P, T_) {                                                                                              \
-        const int tb_ = (T_) / per_img, rem_ = (T_) - tb_ * per_img;                                                  \
+        const int it_ = (T_) % img_tiles;                                                                             \
+        const int tb_ = it_ / per_img, rem_ = it_ - tb_ * per_img;                                                    \
         const int ty0_ = (rem_ / tiles_x) * TR, tx0_ = (rem_ % tiles_x) * DC_TW;                                      \
         const float* xb_ = X + (int64_t)tb_ * H * W * cin;                                                            \
         _Pragma("unroll") for (int e = 0; e < NA; ++e) {                                                             \
@@ -84,8 +89,8 @@ __global__ __launch_bounds__(512, 2) void dense_conv3x3_ws_kernel(const float* _
             *reinterpret_cast<uint2*>(dst + APL) = make_uint2(lo2, hi2);                                              \
         } }
     // weight stage (tap, 16-channel chunk): contiguous and in LDS piece order in the packed operand (piece f = (plane, column, half))
-#define WS_BLD(TAP, CH, V0, V1) {                                                                                     \
-        const uint4* bsrc = reinterpret_cast<const uint4*>(Wp + ((int64_t)(TAP) * nchunks + (CH)) * (2 * CO * DC_CK)); \
+#define WS_BLD(WP, TAP, CH, V0, V1) {                                                                                     \
+        const uint4* bsrc = reinterpret_cast<const uint4*>((WP) + ((int64_t)(TAP) * nchunks + (CH)) * (2 * CO * DC_CK)); \
         V0 = bsrc[ptid]; if (NB > 1) V1 = bsrc[ptid + 256]; }
 #define WS_BST(BUF, V0, V1) {                                                                                         \
         *reinterpret_cast<uint4*>(Bs + (BUF) * BSZ + (ptid >> 1) * DC_ROWB + (ptid & 1) * 16) = V0;                   \
@@ -113,13 +118,13 @@ __global__ __launch_bounds__(512, 2) void dense_conv3x3_ws_kernel(const float* _
         WS_AOFF(pcur, tile)
 #pragma unroll
         for (int e = 0; e < NA; ++e) { WS_LOAD_PIECE(e, pcur, 0) }
-        WS_BLD(0, 0, bq0, bq1)
-        WS_BLD(1, 0, cq0, cq1)
+        WS_BLD(Wcur, 0, 0, bq0, bq1)
+        WS_BLD(Wcur, 1, 0, cq0, cq1)
 #pragma unroll
         for (int e = 0; e < NA; ++e) { WS_STORE_PIECE(e, 0) }
         WS_BST(0, bq0, bq1)
         WS_BST(1, cq0, cq1)
-        WS_BLD(2, 0, bq0, bq1)
+        WS_BLD(Wcur, 2, 0, bq0, bq1)
 #pragma unroll
         for (int e = 0; e < NA; ++e) { WS_LOAD_PIECE(e, pcur, 1) }
     }
@@ -136,13 +141,15 @@ __global__ __launch_bounds__(512, 2) void dense_conv3x3_ws_kernel(const float* _
         for (; tile < n_tiles; tile += gridDim.x) {
             if (tile + (int)gridDim.x < n_tiles) {
                 WS_AOFF(pnxt, tile + (int)gridDim.x)
+                if (sl.n > 1) Wnxt = sl.w[(tile + (int)gridDim.x) / img_tiles];
             } else {
 #pragma unroll
                 for (int e = 0; e < NA; ++e) pnxt[e] = zero_page;
             }
 #define WS_STAGE_P(TAP, CH, HB, INCUR2, L0, L1, S0, S1) {                                                             \
-                if ((TAP) + 3 < 9) { WS_BLD((TAP) + 3, (CH), L0, L1) }                                                \
-                else { WS_BLD((TAP) + 3 - 9, (CH) + 1 < nchunks ? (CH) + 1 : 0, L0, L1) }                             \
+                if ((TAP) + 3 < 9) { WS_BLD(Wcur, (TAP) + 3, (CH), L0, L1) }                                          \
+                else if ((CH) + 1 < nchunks) { WS_BLD(Wcur, (TAP) + 3 - 9, (CH) + 1, L0, L1) }                        \
+                else { WS_BLD(Wnxt, (TAP) + 3 - 9, 0, L0, L1) }                                                       \
                 if ((TAP) < 8) {                                                                                      \
                     _Pragma("unroll") for (int e = 0; e < NA; ++e) if ((e * 8) / NA == (TAP)) {                       \
                         WS_STORE_PIECE(e, 1 - (HB))                                                                   \
@@ -168,14 +175,18 @@ __global__ __launch_bounds__(512, 2) void dense_conv3x3_ws_kernel(const float* _
 #undef WS_STAGE_P
 #pragma unroll
             for (int e = 0; e < NA; ++e) pcur[e] = pnxt[e];
+            Wcur = Wnxt;
             if (stats) { __syncthreads(); __syncthreads(); }               // the consumers' statistics fold
         }
         return;
     }
 
     for (; tile < n_tiles; tile += gridDim.x) {
-        const int tb = tile / per_img, trem = tile - tb * per_img;
+        const int slice = tile / img_tiles, itile = tile - slice * img_tiles;
+        const int tb = itile / per_img, trem = itile - tb * per_img;
         const int y0 = (trem / tiles_x) * TR, x0 = (trem % tiles_x) * DC_TW;
+        float* __restrict__ Ys = sl.n > 1 ? sl.y[slice] : Y;
+        double* __restrict__ stats_s = sl.n > 1 ? sl.stats[slice] : stats;
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -241,7 +252,7 @@ __global__ __launch_bounds__(512, 2) void dense_conv3x3_ws_kernel(const float* _
                     for (int j = 0; j < VB; ++j) {
                         const int ox = x0 + ((v0 + j) >> 2) * 8 + h * 4 + ((v0 + j) & 3);
                         if (ox >= W) continue;
-                        float* dst = Y + ((int64_t)tb * H * W + oy * prow + ox * pcol) * ystride;
+                        float* dst = Ys + ((int64_t)tb * H * W + oy * prow + ox * pcol) * ystride;
 #pragma unroll
                         for (int t = 0; t < NT; ++t) {
                             const float g = fmaf(yv[j][t], bsc[t], bsh[t]) > 0.0f ? acc[m][t][v0 + j] : 0.0f;
@@ -260,7 +271,7 @@ __global__ __launch_bounds__(512, 2) void dense_conv3x3_ws_kernel(const float* _
                 for (int v = 0; v < 16; ++v) {
                     const int ox = x0 + (v >> 2) * 8 + h * 4 + (v & 3);
                     if (ox >= W) continue;
-                    float* dst = Y + ((int64_t)tb * H * W + oy * prow + ox * pcol) * ystride;       // ystride > cout: a channel slice of a wider tensor
+                    float* dst = Ys + ((int64_t)tb * H * W + oy * prow + ox * pcol) * ystride;       // ystride > cout: a channel slice of a wider tensor
 #pragma unroll
                     for (int t = 0; t < NT; ++t) dst[t * 32 + r] = acc[m][t][v];
                 }
@@ -297,7 +308,7 @@ __global__ __launch_bounds__(512, 2) void dense_conv3x3_ws_kernel(const float* _
                     double a = 0.0;
 #pragma unroll
                     for (int w_ = 0; w_ < 4; ++w_) a += (double)red[(w_ * 2 + which) * CO + c];
-                    stats[((int64_t)tile * 2 + which) * cout + c] = a;
+                    stats_s[((int64_t)itile * 2 + which) * cout + c] = a;
                 }
             }
             __syncthreads();                                  // red is the next tile's
@@ -320,10 +331,14 @@ bool dc_ws_enabled(int planes) {
 }
 
 int dc_launch_ws(const float* x, const void* split_weight, int B, int H, int W, int cin, int cout, float* y, int ystride, int prow,
-                 int pcol, double* stats, const uint32_t* amax_x, const uint32_t* amax_weight, DcBnBwd bn, hipStream_t stream) {
+                 int pcol, double* stats, const uint32_t* amax_x, const uint32_t* amax_weight, DcBnBwd bn, const DcSlices* slices,
+                 hipStream_t stream) {
     const int trows = cout == 128 ? 8 : 16;
     const int tx = (W + DC_TW - 1) / DC_TW, ty = (H + trows - 1) / trows;
-    const int64_t n_tiles = (int64_t)B * tx * ty;
+    DcSlices sl;
+    sl.n = 0;
+    if (slices) sl = *slices;
+    const int64_t n_tiles = (int64_t)B * tx * ty * (sl.n > 1 ? sl.n : 1);
     GGA_REQUIRE(n_tiles < 2147483647ll, "gga_dense_conv3x3: too many tiles");
     // one workgroup per CU (512 threads at 256 registers); more tiles than CUs: persistent workgroups, tiles b, b + grid, ...
     static const float* zero_pages[GGA_MAX_DEVICES] = {};           // per device: the address of dc_zero_page (a lookup, not an allocation)
@@ -340,10 +355,10 @@ int dc_launch_ws(const float* x, const void* split_weight, int B, int H, int W, 
     const dim3 grid((unsigned)(n_tiles < max_grid ? n_tiles : max_grid)), block(512);
     if (cout == 128)
         hipLaunchKernelGGL((dense_conv3x3_ws_kernel<4, 2>), grid, block, 0, stream, x, (const uint16_t*)split_weight, B, H, W, cin, cout,
-                           tx, ty, y, ystride, prow, pcol, stats, amax_x, amax_weight, bn, zero_page);
+                           tx, ty, y, ystride, prow, pcol, stats, amax_x, amax_weight, bn, zero_page, sl);
     else
         hipLaunchKernelGGL((dense_conv3x3_ws_kernel<2, 4>), grid, block, 0, stream, x, (const uint16_t*)split_weight, B, H, W, cin, cout,
-                           tx, ty, y, ystride, prow, pcol, stats, amax_x, amax_weight, bn, zero_page);
+                           tx, ty, y, ystride, prow, pcol, stats, amax_x, amax_weight, bn, zero_page, sl);
     GGA_CHECK_LAUNCH("dense_conv3x3_ws_kernel");
     return GGA_OK;
 }

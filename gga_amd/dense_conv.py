@@ -222,7 +222,7 @@ class BnSource:
 
 def bn_source(z, n_out):
     """The valid ``BnSource`` of ``z`` for a backward-data convolution with ``n_out`` output channels, or None (also
-    where the epilogue would cost more than the reduce pass it replaces: ``gga_dense_conv3x3_bn_bwd_pays``). ``z``
+    where the epilogue would cost more than the reduce pass it replaces: ``gga_dense_conv3x3_bn_bwd_pays_planes``). ``z``
     [rows, C] (sparse features): the gather-GEMM kernel's epilogue, one launch of at most 128 channels."""
     src = getattr(z, '_gga_bn_src', None)
     if src is None or not src.valid_for(z) or not src.covers(n_out):
@@ -231,7 +231,7 @@ def bn_source(z, n_out):
         return src if (BN_BWD_FUSED and n_out <= 128 and len(src.parts) == 1) else None
     B, _, H, W = z.shape
     th, tw = (W, H) if _transposed(H, W) else (H, W)
-    if not _lib.lib().gga_dense_conv3x3_bn_bwd_pays(B, th, tw, 64 if n_out == 64 else 128):
+    if not _lib.lib().gga_dense_conv3x3_bn_bwd_pays_planes(B, th, tw, 64 if n_out == 64 else 128, PLANES):
         return None
     return src
 
@@ -313,7 +313,7 @@ def _run(x, weight, backward, want_stats=False, x_amax=None, w_amax=None, y=None
         assert not many
         n = n_out // 128
         th, tw = (W, H) if tr else (H, W)
-        rows = 16 if B * _cdiv(tw, 32) * _cdiv(th, 16) >= 384 else 8           # dc_tile_rows of the C side
+        rows = int(L.gga_dense_conv3x3_tile_rows(B, th, tw, 128, planes))      # two planes: 8 (the producer / consumer form takes the slices as one grid)
         tiles = B * _cdiv(tw, 32) * _cdiv(th, rows)
         ops = [_operand(weight, backward, tr, planes, c0) for c0 in range(0, n_out, 128)]      # slices of one weight: one absmax slot
         wa = ops[0][1]

@@ -336,6 +336,7 @@ int64_t gga_dense_conv3x3_tiles(int B, int H, int W, int cout);   /* rows of `st
  * (dense_conv_ws.hip: tiles of 8 x 32 pixels at 128 output channels, 16 x 32 at 64; GGA_DC_WS=0 puts them back on the
  * lock-step kernel), the three-plane launches tiles of 8 or 16 rows by shape. */
 int64_t gga_dense_conv3x3_tiles_planes(int B, int H, int W, int cout, int planes);
+int gga_dense_conv3x3_tile_rows(int B, int H, int W, int cout, int planes);      /* 8 or 16: the tile_rows to hand gga_dense_conv3x3_levels for slices of this shape */
 int gga_dense_conv3x3_stats(const float* x, const void* split_weight, int B, int H, int W, int cin, int cout,
                             float* y, double* stats, void* stream);
 /* Weight gradient of the same convolution, bf16x9 with the pixel index as the GEMM's K (transposed
@@ -458,7 +459,8 @@ int gga_dense_conv3x3_levels(int n_entries, const float* const* x, const int32_t
                              const void* const* split_weight, int B, int cin, int cout, float* const* y, int64_t y_pixel_stride,
                              int planes, const uint32_t* const* amax_x, const uint32_t* amax_weight, const float* const* bias,
                              int tile_rows, int transposed, double* const* stats, void* stream);
-int gga_dense_conv3x3_bn_bwd_pays(int B, int H, int W, int cout);   /* 1: the epilogue costs less than the reduce pass (H, W of the tile space) */
+int gga_dense_conv3x3_bn_bwd_pays(int B, int H, int W, int cout);   /* 1: the epilogue costs less than the reduce pass (H, W of the tile space); three planes */
+int gga_dense_conv3x3_bn_bwd_pays_planes(int B, int H, int W, int cout, int planes);   /* the same for a launch of this arithmetic (two planes: always) */
 int gga_dense_conv3x3_bn_bwd(const float* x, const void* split_weight, int B, int H, int W, int cin, int cout, float* y,
                              int64_t y_pixel_stride, int transposed, double* stats, int planes, const uint32_t* amax_x,
                              const uint32_t* amax_weight, const float* bn_x, int64_t bn_x_pixel_stride, const float* bn_gamma,

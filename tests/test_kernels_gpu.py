@@ -950,8 +950,9 @@ def test_conv_backward_data_reduces_the_batchnorm_below(c0, c1, B, H, W, trainin
     monkeypatch.setattr(L, 'gga_bn_relu_bwd_partials', counted)
     # the product takes the epilogue only where it is cheaper than the reduce pass; here every tile form is exercised
     pays = L.gga_dense_conv3x3_bn_bwd_pays
-    assert pays(16, 248, 216, 64) == 1 and pays(16, 124, 108, 128) == 1 and pays(16, 62, 54, 128) == 0
-    monkeypatch.setattr(L, 'gga_dense_conv3x3_bn_bwd_pays', lambda *a: 1)
+    assert pays(16, 248, 216, 64) == 1 and pays(16, 124, 108, 128) == 1 and pays(16, 62, 54, 128) == 0     # lock-step forms
+    assert L.gga_dense_conv3x3_bn_bwd_pays_planes(16, 62, 54, 128, 3) == 0
+    monkeypatch.setattr(L, 'gga_dense_conv3x3_bn_bwd_pays_planes', lambda *a: 1)
     got = run(True)
     assert calls['fused'] == 1, 'the fused BatchNorm backward did not run'
     plain = run(False)

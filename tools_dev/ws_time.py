@@ -19,6 +19,6 @@ def t(B, C, Co, H, W):
     ref = torch.nn.functional.conv2d(x.double(), w.double(), padding=1)
     err = float((y.double() - ref).abs().max() / ref.abs().max())
     out.append(f'{ts[len(ts) // 2] * 1e3:6.0f} ({err:.1e})')
-for shp in ((16, 128, 128, 124, 108), (8, 128, 128, 200, 176), (16, 64, 64, 248, 216), (16, 384, 64, 248, 216), (16, 64, 128, 248, 216), (4, 128, 128, 62, 54)):
+for shp in ((16, 128, 128, 124, 108), (8, 128, 128, 200, 176), (16, 64, 64, 248, 216), (16, 384, 64, 248, 216), (16, 64, 128, 248, 216), (4, 128, 128, 62, 54), (16, 256, 256, 62, 54), (8, 256, 256, 100, 88)):
     t(*shp)
 print(os.environ.get('GGA_DC_WS', 'ws'), ' '.join(out))

@@ -325,9 +325,9 @@ __global__ __launch_bounds__(512, 2) void dense_conv3x3_ws_kernel(const float* _
 #undef WS_MMA
 }
 
-bool dc_ws_enabled(int planes) {
-    static const int on = getenv("GGA_DC_WS") ? atoi(getenv("GGA_DC_WS")) : 1;
-    return planes == 2 && on != 0;
+bool dc_ws_enabled(int planes) {         // read per call: a test compares the two forms within one process
+    const char* e = getenv("GGA_DC_WS");
+    return planes == 2 && !(e && atoi(e) == 0);
 }
 
 int dc_launch_ws(const float* x, const void* split_weight, int B, int H, int W, int cin, int cout, float* y, int ystride, int prow,

@@ -740,6 +740,36 @@ def test_dense_conv3x3_vs_torch(cin, cout, B, H, W, planes, monkeypatch):
     torch.testing.assert_close(cb.bias.grad, torch.full_like(cb.bias, float(B * H * W)), rtol=1e-5, atol=1e-3)
 
 
+@pytest.mark.parametrize('cin,cout,B,H,W', [(64, 64, 2, 37, 45), (128, 128, 1, 19, 70), (64, 128, 1, 41, 33), (128, 128, 1, 31, 22),
+                                           (256, 256, 1, 30, 20), (128, 64, 2, 8, 32),
+                                           # more tiles than workgroups in the grid: every workgroup walks several tiles
+                                           (64, 128, 5, 200, 176), (64, 64, 7, 248, 216)])
+def test_dense_conv_producer_consumer_form_equals_the_lock_step_form(cin, cout, B, H, W, monkeypatch):
+    """Two fp16 planes: dense_conv_ws.hip (producer / consumer waves, persistent tiles, 128-channel slices as one grid) against
+    the lock-step kernel it replaced (GGA_DC_WS=0) - same operand planes, same order of the products: bit-identical outputs
+    forward and backward-data; the BatchNorm partial sums cover other tiles (8 / 16 rows swapped) and agree after their fold."""
+    from gga_amd import dense_conv
+    monkeypatch.setattr(dense_conv, 'PLANES', 2)
+    torch.manual_seed(cin * 3 + cout)
+    x = torch.randn(B, cin, H, W, device=DEV).contiguous(memory_format=torch.channels_last)
+    x[:, :, ::3, 1::2] = 0.0                                        # ReLU-like zeros
+    w = (torch.randn(cout, cin, 3, 3, device=DEV) * 0.05).contiguous(memory_format=torch.channels_last)
+    g = torch.randn(B, cout, H, W, device=DEV).contiguous(memory_format=torch.channels_last)
+    got = {}
+    for form in ('1', '0'):
+        monkeypatch.setenv('GGA_DC_WS', form)
+        y, st = dense_conv._run(x, w, False, True)
+        gx, _ = dense_conv._run(g, w, True, False)
+        got[form] = (y.clone(), st.sum(0), gx.clone())
+    torch.cuda.synchronize()
+    assert torch.equal(got['1'][0], got['0'][0]) and torch.equal(got['1'][2], got['0'][2])
+    # (fp32 lane sums over other pixel groups before the f64 fold)
+    torch.testing.assert_close(got['1'][1], got['0'][1], rtol=1e-5, atol=1e-6 * float(got['0'][1].abs().max()))
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), padding=1)
+    assert float((got['1'][0].double() - ref).abs().max()) <= 3e-6 * float(ref.abs().max())
+    torch.testing.assert_close(got['1'][1][0], ref.sum((0, 2, 3)), rtol=1e-4, atol=1e-4 * float(ref.abs().sum((0, 2, 3)).max()))
+
+
 def test_dense_weight_gradient_with_an_absmax_per_channel_block():
     """Two fp16 planes: a gradient tensor whose 64-channel blocks differ by 2^-26 in magnitude (the head's 960-channel buffer:
     regression branches beside heat-map branches). Under ONE absmax the small block's weight gradient keeps a few bits; with an

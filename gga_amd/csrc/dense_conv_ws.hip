@@ -3,7 +3,7 @@
 //
 // Why a second form. The lock-step kernel of dense_conv.hip has every wave stage operands AND multiply: at each chunk head all
 // waves wait for the halo loads, split them, write LDS and meet at a barrier while the matrix pipes idle, and every stage's
-// weight copy sits between the MFMAs of the wave that issues it. Ablation builds of that kernel (round 4, tools_dev/abl_dense.sh:
+// weight copy sits between the MFMAs of the wave that issues it. Ablation builds of that kernel (round 4, profiles/r04_dense_conv_ablation.txt:
 // staging compiled out, MFMAs and fragment reads kept) run 19-26 % faster than the kernel itself, and a barrier-per-stage
 // LDS-fed MFMA stream of the same shape (tools_dev/micro/mfma_sustained.hip) holds 0.58-0.62 of the nominal 2.5 PFLOP/s on
 // random data where the kernel reaches 0.35-0.37. Here the two jobs belong to different waves of one 512-thread workgroup per CU:
@@ -18,6 +18,9 @@
 // LDS images, packed weight layout (dense_pack_weight_kernel / weight_bank.hip), arithmetic and epilogues (scale back, BatchNorm
 // statistics, the BatchNorm-backward mask + sums of DcBnBwd) are those of dense_conv3x3_x9_kernel; results differ from it only
 // in the order of the per-tile statistics' partial sums.
+// What it bought: 7-22 % stand-alone on dense random inputs, 3 % per launch inside the step - the matrix pipe went from
+// 0.45-0.50 to 0.50-0.61 busy and the clock fell from 2.0-2.2 to 1.84-1.97 GHz with it: under this arithmetic the part is
+// power-managed (the same stream on zero operands runs a third faster), so a better-fed pipe is paid back in frequency.
 #include <stdlib.h>
 
 #include "dense_conv.h"

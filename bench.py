@@ -406,11 +406,18 @@ def sparse_roofline(run, args, steps=4):
                 'pairs': pairs, 'pairs_per_row': round(pairs / rows, 2), 'partial_products': 3,
                 'issued_tflops': round(issued, 1), 'issued_frac': round(issued / BF16_PEAK_TFLOPS, 4),
                 'note': 'achieved counts the real (row, offset) pairs; issued counts the 27 offsets the halo form multiplies for every row'}
-    return {'bound': 'hbm', 'mfma_roofline': mfma, 'kernel': ' + '.join(names) + ' (SubMConv3d 128 -> 128, 27 offsets, forward + backward-data)',
-            'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(gbs / HBM_PEAK_GBS, 4), 'traffic': traffic,
-            'traffic_source': src, 'traffic_GBps': round(traffic / (avg * 1e-3) / 1e9, 1) if traffic else None,
-            'algorithmic_bytes': int(algo), 'rows': int(rows), 'kernel_ms': round(avg, 4), 'launches_timed': len(ms),
-            'launches_per_step': len(ms) / steps, 'timed': 'in-step, HIP events on the launch stream'}
+    kernel = ' + '.join(names) + ' (SubMConv3d 128 -> 128, 27 offsets, forward + backward-data)'
+    common = {'kernel_ms': round(avg, 4), 'launches_timed': len(ms), 'launches_per_step': len(ms) / steps,
+              'timed': 'in-step, HIP events on the launch stream', 'rows': int(rows)}
+    hbm = {'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(gbs / HBM_PEAK_GBS, 4),
+           'traffic': traffic, 'traffic_source': src, 'traffic_GBps': round(traffic / (avg * 1e-3) / 1e9, 1) if traffic else None,
+           'algorithmic_bytes': int(algo)}
+    if mfma:
+        # the halo form stages every row once per chunk and is bounded by its matrix work (PMC: 0.47-0.48 of the pipe's cycles at
+        # 2.0-2.1 GHz, 1.56 x the algorithmic bytes at 0.9 TB/s: DESIGN.md 6c / 6d) - that is the roofline of the line; the byte
+        # side stays beside it
+        return dict(mfma, kernel=kernel, traffic=traffic, hbm_roofline=hbm, **common)
+    return dict(hbm, kernel=kernel, mfma_roofline=None, **common)
 
 
 def mfma_roofline(kernel, flops, ms_list, launches_per_step, ms_per_step, planes=2):

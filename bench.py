@@ -185,10 +185,16 @@ def run_workload(config, batch, steps, warmup, args, rank, world, device, sites=
     # the product loop's own garbage-collector policy (Runner.run does the same after its first iterations): everything
     # built so far moves to the permanent generation, the collector stays ON in the timed region
     runner.freeze_gc()
+    trace = [] if os.environ.get('GGA_BENCH_STEP_TIMES') else None      # diagnosis: host timestamp after every step's queueing
     t0 = time.perf_counter()
     for i in range(steps):      # next_data: the point-only front of the next step is prefetched on a side stream (sparse trunk)
         out = runner.step(batches[i % 2], next_data=batches[(i + 1) % 2])
+        if trace is not None:
+            trace.append(time.perf_counter())
     torch.cuda.synchronize()
+    if trace:
+        print('host ms between steps (%s): ' % os.path.basename(config) + ' '.join('%.1f' % ((b - a) * 1e3) for a, b in zip([t0] + trace, trace)) +
+              '  | drain %.1f' % ((time.perf_counter() - trace[-1]) * 1e3), file=sys.stderr)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()

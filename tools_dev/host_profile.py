@@ -45,3 +45,5 @@ for i in range(4):
 pr.disable()
 torch.cuda.synchronize()
 pstats.Stats(pr).sort_stats('cumulative').print_stats(45)
+if os.environ.get('HOST_PROFILE_TOTTIME'):
+    pstats.Stats(pr).sort_stats('tottime').print_stats(40)

@@ -108,6 +108,7 @@ SIGNATURES = {
     'gga_dense_conv3x3_tiles': (i64, [i32, i32, i32, i32]),
     'gga_dense_conv3x3_tiles_planes': (i64, [i32, i32, i32, i32, i32]),
     'gga_dense_conv3x3_tile_rows': (i32, [i32, i32, i32, i32, i32]),
+    'gga_dense_conv3x3_stat_rows': (i64, [i32, i32, i32, i32, i32, i32]),
     'gga_dense_conv3x3_slice': (i32, [vp, vp, i32, i32, i32, i32, i32, vp, i64, i32, vp, vp]),
     'gga_dense_conv3x3_stats': (i32, [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]),
     'gga_bn_relu_fwd_partials': (i32, [vp, vp, vp, vp, vp, vp, i64, i32, f32, f32, i32, vp, i64, vp, vp, vp, i32, vp, sz, vp]),

@@ -35,6 +35,8 @@ struct DcSlices {
 
 // rows of a tile (= of a row of `stats`) for a launch of this shape and arithmetic; H, W of the tile space
 int dc_tile_rows(int B, int H, int W, int cout, int planes);
+// workgroups of a producer / consumer launch over n_tiles tiles (all slices) = rows of each slice's `stats`
+int64_t dc_ws_grid(int64_t n_tiles);
 // whether dense_conv_ws.hip runs launches of this arithmetic (two fp16 planes, GGA_DC_WS != 0)
 bool dc_ws_enabled(int planes);
 // the producer / consumer form: same arguments as gga_dense_conv3x3_bn_bwd after its checks (H, W, prow, pcol of the tile space)

@@ -519,6 +519,14 @@ extern "C" int64_t gga_dense_conv3x3_tiles_planes(int B, int H, int W, int cout,
     return (int64_t)B * ((W + DC_TW - 1) / DC_TW) * ((H + tr - 1) / tr);
 }
 
+// rows of `stats` (per slice) of a launch over n_slices 128-channel slices (1: gga_dense_conv3x3_bn_bwd): the lock-step kernel
+// leaves one row per tile, the producer / consumer form one per workgroup
+extern "C" int64_t gga_dense_conv3x3_stat_rows(int B, int H, int W, int cout, int planes, int n_slices) {
+    const int64_t tiles = gga_dense_conv3x3_tiles_planes(B, H, W, cout, planes);
+    if (dc_ws_enabled(planes)) return dc_ws_grid(tiles * (n_slices > 1 ? n_slices : 1));
+    return tiles;
+}
+
 extern "C" int gga_dense_conv3x3_tile_rows(int B, int H, int W, int cout, int planes) { return dc_tile_rows(B, H, W, cout, planes); }
 
 extern "C" int64_t gga_dense_conv3x3_tiles(int B, int H, int W, int cout) { return gga_dense_conv3x3_tiles_planes(B, H, W, cout, 3); }

@@ -184,12 +184,23 @@ __global__ __launch_bounds__(512, 2) void dense_conv3x3_ws_kernel(const float* _
         return;
     }
 
+    // statistics: one f64 row pair per WORKGROUP and slice (row blockIdx.x of the slice's `stats`: the sums of all the tiles the
+    // workgroup walked there; the BatchNorm's fold reads at most gridDim.x rows instead of one per tile - 3472 at the head's first
+    // convolutions). Thread tid < 2 CO owns one (sum | sum of squares, channel) of the row.
+    double run_sum = 0.0;
+    int run_slice = tile / img_tiles;
+    if (stats && sl.n > 1 && tid < 2 * CO && tid % CO < cout)      // rows of slices this workgroup never visits stay zero
+        for (int s_ = 0; s_ < sl.n; ++s_) sl.stats[s_][((int64_t)blockIdx.x * 2 + tid / CO) * cout + tid % CO] = 0.0;
+#define WS_FLUSH_STATS() {                                                                                            \
+        if (tid < 2 * CO && tid % CO < cout)                                                                          \
+            (sl.n > 1 ? sl.stats[run_slice] : stats)[((int64_t)blockIdx.x * 2 + tid / CO) * cout + tid % CO] = run_sum; \
+        run_sum = 0.0; }
     for (; tile < n_tiles; tile += gridDim.x) {
         const int slice = tile / img_tiles, itile = tile - slice * img_tiles;
+        if (stats && slice != run_slice) { WS_FLUSH_STATS() run_slice = slice; }
         const int tb = itile / per_img, trem = itile - tb * per_img;
         const int y0 = (trem / tiles_x) * TR, x0 = (trem % tiles_x) * DC_TW;
         float* __restrict__ Ys = sl.n > 1 ? sl.y[slice] : Y;
-        double* __restrict__ stats_s = sl.n > 1 ? sl.stats[slice] : stats;
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -311,12 +322,14 @@ __global__ __launch_bounds__(512, 2) void dense_conv3x3_ws_kernel(const float* _
                     double a = 0.0;
 #pragma unroll
                     for (int w_ = 0; w_ < 4; ++w_) a += (double)red[(w_ * 2 + which) * CO + c];
-                    stats_s[((int64_t)itile * 2 + which) * cout + c] = a;
+                    run_sum += a;
                 }
             }
             __syncthreads();                                  // red is the next tile's
         }
     }
+    if (stats) { WS_FLUSH_STATS() }
+#undef WS_FLUSH_STATS
 #undef WS_AOFF
 #undef WS_LOAD_PIECE
 #undef WS_STORE_PIECE
@@ -331,6 +344,12 @@ __global__ __launch_bounds__(512, 2) void dense_conv3x3_ws_kernel(const float* _
 bool dc_ws_enabled(int planes) {         // read per call: a test compares the two forms within one process
     const char* e = getenv("GGA_DC_WS");
     return planes == 2 && !(e && atoi(e) == 0);
+}
+
+// workgroups of a launch = rows of its `stats` (per slice)
+int64_t dc_ws_grid(int64_t n_tiles) {
+    static const int max_grid = getenv("GGA_DC_WS_GRID") ? atoi(getenv("GGA_DC_WS_GRID")) : 256;
+    return n_tiles < max_grid ? n_tiles : max_grid;
 }
 
 int dc_launch_ws(const float* x, const void* split_weight, int B, int H, int W, int cin, int cout, float* y, int ystride, int prow,
@@ -354,8 +373,7 @@ int dc_launch_ws(const float* x, const void* split_weight, int B, int H, int W, 
         zero_pages[dev] = (const float*)p;
     }
     const float* zero_page = zero_pages[dev];
-    static const int max_grid = getenv("GGA_DC_WS_GRID") ? atoi(getenv("GGA_DC_WS_GRID")) : 256;
-    const dim3 grid((unsigned)(n_tiles < max_grid ? n_tiles : max_grid)), block(512);
+    const dim3 grid((unsigned)dc_ws_grid(n_tiles)), block(512);
     if (cout == 128)
         hipLaunchKernelGGL((dense_conv3x3_ws_kernel<4, 2>), grid, block, 0, stream, x, (const uint16_t*)split_weight, B, H, W, cin, cout,
                            tx, ty, y, ystride, prow, pcol, stats, amax_x, amax_weight, bn, zero_page, sl);

@@ -298,7 +298,7 @@ def _run(x, weight, backward, want_stats=False, x_amax=None, w_amax=None, y=None
     none6 = (None, 0, None, None, None, None)
     if n_out in (64, 128):
         if want_stats:
-            tiles = int(L.gga_dense_conv3x3_tiles_planes(B, W, H, n_out, planes) if tr else L.gga_dense_conv3x3_tiles_planes(B, H, W, n_out, planes))
+            tiles = int(L.gga_dense_conv3x3_stat_rows(B, W, H, n_out, planes, 1) if tr else L.gga_dense_conv3x3_stat_rows(B, H, W, n_out, planes, 1))
             stats = torch.empty((tiles, 2, n_out), dtype=torch.float64, device=x.device)
         wp, wa = _operand(weight, backward, tr, planes)
         check(L.gga_dense_conv3x3_bn_bwd(F._p(x), F._p(wp), B, H, W, n_in, n_out,
@@ -314,7 +314,7 @@ def _run(x, weight, backward, want_stats=False, x_amax=None, w_amax=None, y=None
         n = n_out // 128
         th, tw = (W, H) if tr else (H, W)
         rows = int(L.gga_dense_conv3x3_tile_rows(B, th, tw, 128, planes))      # two planes: 8 (the producer / consumer form takes the slices as one grid)
-        tiles = B * _cdiv(tw, 32) * _cdiv(th, rows)
+        tiles = int(L.gga_dense_conv3x3_stat_rows(B, th, tw, 128, planes, n))       # rows of each slice's statistics
         ops = [_operand(weight, backward, tr, planes, c0) for c0 in range(0, n_out, 128)]      # slices of one weight: one absmax slot
         wa = ops[0][1]
         sts = [torch.empty((tiles, 2, 128), dtype=torch.float64, device=x.device) for _ in range(n)] if want_stats else None
@@ -333,7 +333,7 @@ def _run(x, weight, backward, want_stats=False, x_amax=None, w_amax=None, y=None
             wp, wa = _operand(weight, backward, tr, planes, c0)
             st = None
             if want_stats:                          # per-channel sums of this 128-channel block of the output
-                tiles = int(L.gga_dense_conv3x3_tiles_planes(B, W, H, 128, planes) if tr else L.gga_dense_conv3x3_tiles_planes(B, H, W, 128, planes))
+                tiles = int(L.gga_dense_conv3x3_stat_rows(B, W, H, 128, planes, 1) if tr else L.gga_dense_conv3x3_stat_rows(B, H, W, 128, planes, 1))
                 st = torch.empty((tiles, 2, 128), dtype=torch.float64, device=x.device)
                 parts.append((c0, 128, st))
             check(L.gga_dense_conv3x3_bn_bwd(F._p(x), F._p(wp), B, H, W, n_in, 128,

@@ -336,6 +336,7 @@ int64_t gga_dense_conv3x3_tiles(int B, int H, int W, int cout);   /* rows of `st
  * (dense_conv_ws.hip: tiles of 8 x 32 pixels at 128 output channels, 16 x 32 at 64; GGA_DC_WS=0 puts them back on the
  * lock-step kernel), the three-plane launches tiles of 8 or 16 rows by shape. */
 int64_t gga_dense_conv3x3_tiles_planes(int B, int H, int W, int cout, int planes);
+int64_t gga_dense_conv3x3_stat_rows(int B, int H, int W, int cout, int planes, int n_slices);   /* rows of `stats` (per slice): one per tile (lock-step kernel) or one per workgroup (producer / consumer form, <= 256) */
 int gga_dense_conv3x3_tile_rows(int B, int H, int W, int cout, int planes);      /* 8 or 16: the tile_rows to hand gga_dense_conv3x3_levels for slices of this shape */
 int gga_dense_conv3x3_stats(const float* x, const void* split_weight, int B, int H, int W, int cin, int cout,
                             float* y, double* stats, void* stream);

@@ -413,9 +413,17 @@ class MinkowskiBatchNorm(nn.Module):
         self.bn = nn.BatchNorm1d(num_features, eps=eps, momentum=momentum)
 
     def forward(self, x):
+        return self.forward_act(x, relu=False)
+
+    def forward_act(self, x, relu=False, residual=None):
+        """``relu(bn(x) + residual)`` (each part optional) on the feature rows: the fused BatchNorm pass pair of the BEV trunk
+        (``functional.bn_act``: statistics + apply with the ReLU, the residual and the consumer's absmax in one sweep; the
+        eager ops where it does not apply - CPU tensors, odd widths)."""
+        from . import functional as F
         if x.F.shape[0] == 0:
             return x
-        return x.replace(self.bn(x.F))
+        res = None if residual is None else residual.F
+        return x.replace(F.bn_act(x.F, self.bn, relu=relu, residual=res))
 
 
 class MinkowskiInstanceNorm(nn.Module):
@@ -469,7 +477,9 @@ class BasicBlock(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        out = self.relu(self.norm1(self.conv1(x)))
-        out = self.norm2(self.conv2(out))
+        out = self.norm1.forward_act(self.conv1(x), relu=True)
+        out = self.conv2(out)
         residual = x if self.downsample is None else self.downsample(x)
-        return self.relu(out + residual)
+        if out.cmap is residual.cmap:                        # (always, in a residual block: same coordinate set, same row order)
+            return self.norm2.forward_act(out, relu=True, residual=residual)
+        return self.relu(self.norm2(out) + residual)

@@ -132,6 +132,9 @@ def _transposed(H, W):
     return turned < 0.97 * normal
 
 
+WS_LEVELS = os.environ.get('GGA_DC_WS_LEVELS', '1') != '0'      # A/B switch: multi-map launches of the lock-step kernel instead
+
+
 class _AmaxPool:
     """Zeroed int32 slots for the producers' absmax outputs: one memset per generation instead of one fill launch per
     BatchNorm call (57 per PointPillars step). ``next_generation()`` (Runner.step) zeroes the pool again; a tensor's
@@ -451,6 +454,10 @@ def _run_levels(xs, weight, backward, x_amaxes, w_amax, bias=None):
     # ones the 8-row form: two launches
     big = lambda x: width == 128 and B * _cdiv(x.shape[3], 32) * _cdiv(x.shape[2], 16) >= 384
     groups = [(16, [e for e in entries if big(e[0])]), (8, [e for e in entries if not big(e[0])])]
+    if (WS_LEVELS and planes == 2 and width == 128 and bias is None
+            and L.gga_dense_conv3x3_tile_rows(B, xs[0].shape[2], xs[0].shape[3], 128, 2) == 8):
+        # the producer / consumer form (two planes, GGA_DC_WS != 0) takes the 128-channel slices of ONE map as one grid: a launch per map
+        groups = [(8, [e for e in entries if e[0] is x]) for x in xs]
     for rows, group in groups:
         for i0 in range(0, len(group), 16):
             part = group[i0:i0 + 16]

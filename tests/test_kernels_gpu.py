@@ -741,7 +741,7 @@ def test_dense_conv3x3_vs_torch(cin, cout, B, H, W, planes, monkeypatch):
 
 
 @pytest.mark.parametrize('cin,cout,B,H,W', [(64, 64, 2, 37, 45), (128, 128, 1, 19, 70), (64, 128, 1, 41, 33), (128, 128, 1, 31, 22),
-                                           (256, 256, 1, 30, 20), (128, 64, 2, 8, 32),
+                                           (256, 256, 1, 30, 20), (128, 64, 2, 8, 32), (32, 64, 3, 16, 33), (32, 128, 2, 9, 40),
                                            # more tiles than workgroups in the grid: every workgroup walks several tiles
                                            (64, 128, 5, 200, 176), (64, 64, 7, 248, 216)])
 def test_dense_conv_producer_consumer_form_equals_the_lock_step_form(cin, cout, B, H, W, monkeypatch):
@@ -759,7 +759,7 @@ def test_dense_conv_producer_consumer_form_equals_the_lock_step_form(cin, cout, 
     for form in ('1', '0'):
         monkeypatch.setenv('GGA_DC_WS', form)
         y, st = dense_conv._run(x, w, False, True)
-        gx, _ = dense_conv._run(g, w, True, False)
+        gx = dense_conv._run(g, w, True, False)[0] if cin % 64 == 0 else y      # (two input chunks: forward only - 32 outputs are not a tile)
         got[form] = (y.clone(), st.sum(0), gx.clone())
     torch.cuda.synchronize()
     assert torch.equal(got['1'][0], got['0'][0]) and torch.equal(got['1'][2], got['0'][2])

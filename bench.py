@@ -188,7 +188,10 @@ def run_workload(config, batch, steps, warmup, args, rank, world, device, sites=
     trace = [] if os.environ.get('GGA_BENCH_STEP_TIMES') else None      # diagnosis: host timestamp after every step's queueing
     t0 = time.perf_counter()
     for i in range(steps):      # next_data: the point-only front of the next step is prefetched on a side stream (sparse trunk)
-        out = runner.step(batches[i % 2], next_data=batches[(i + 1) % 2])
+        # (the two batches keep alternating across the warm-up / timed boundary: the batch the last warm-up step prefetched is the
+        # one the first timed step consumes, as in a loader-fed loop - with the index restarting at 0 the first timed step of an odd
+        # warm-up found the other batch prepared, threw it away and ran its own front inline: +13 ms on the sparse step, +5 on the next)
+        out = runner.step(batches[(warmup + i) % 2], next_data=batches[(warmup + i + 1) % 2])
         if trace is not None:
             trace.append(time.perf_counter())
     torch.cuda.synchronize()
@@ -623,7 +626,11 @@ def main():
     if is_pp and not args.no_second_trunk:
         # the reference's shipped model section (sparse-conv trunk), same run, same launch
         s_sites = [(_lib.TIME_SPARSE_CONV, 64 * args.steps, 0), (_lib.TIME_SPARSE_WGRAD, 32 * args.steps, 0)] if rank == 0 else []
-        sec = run_workload(SECOND_CONFIG, args.second_batch, args.steps, args.warmup, args, rank, world, device, s_sites)
+        # (warm-up of this leg: at least 20 steps. On a fresh box the first process's sparse loop has run its first ~15 steps at
+        # 68-70 ms per step on the DEVICE side - 3 of 8 first runs of the round, `GGA_BENCH_STEP_TIMES=1`; later processes and later
+        # steps of the same process never - and with 5 warm-up steps that stretch fell into the 20 timed ones: 60-84 instead of 53-55 ms)
+        sw = max(args.warmup, 20)
+        sec = run_workload(SECOND_CONFIG, args.second_batch, args.steps, sw, args, rank, world, device, s_sites)
         if rank == 0:
             sdt = sec['dt']
             st = sec['timings']
@@ -635,7 +642,7 @@ def main():
                             'losses, full train step (fwd+bwd+clip+AdamW)',
                 'frames_per_gpu': args.second_batch, 'global_batch': args.second_batch * world,
                 'value': round(args.second_batch * world * args.steps / sdt, 3), 'unit': 'frames/s',
-                'ms_per_step': round(sdt / args.steps * 1e3, 3), 'steps': args.steps, 'warmup': args.warmup,
+                'ms_per_step': round(sdt / args.steps * 1e3, 3), 'steps': args.steps, 'warmup': sw,
                 'final_loss': round(sec['loss'], 4),
                 'dominant_kernels_ms_per_step': {
                     'sp_conv_x9_kernel + sp_conv_halo_kernel (sparse conv fwd + bwd-data, %d launches/step)' % (len(st.get(_lib.TIME_SPARSE_CONV, [])) // args.steps):

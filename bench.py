@@ -658,7 +658,8 @@ def main():
         torch.cuda.empty_cache()
 
     if is_pp and not args.no_pgd:
-        pg = run_mono_workload(args.pgd_batch, args.steps, args.warmup, args, rank, world, device)
+        lw = max(args.warmup, 10)          # side legs: at least 10 warm-up steps (first-process transients, see the sparse leg)
+        pg = run_mono_workload(args.pgd_batch, args.steps, lw, args, rank, world, device)
         if rank == 0:
             res['pgd_trunk'] = {
                 'config_file': os.path.relpath(PGD_CONFIG, REPO),
@@ -666,7 +667,7 @@ def main():
                             'padded to 1248x384, full train step (fwd+bwd+clip+SGD)',
                 'frames_per_gpu': args.pgd_batch, 'global_batch': args.pgd_batch * world,
                 'value': round(args.pgd_batch * world * args.steps / pg['dt'], 3), 'unit': 'frames/s',
-                'ms_per_step': round(pg['dt'] / args.steps * 1e3, 3), 'steps': args.steps, 'warmup': args.warmup,
+                'ms_per_step': round(pg['dt'] / args.steps * 1e3, 3), 'steps': args.steps, 'warmup': lw,
                 'final_loss': round(pg['loss'], 4),
                 'weights': 'random init: the open-mmlab://detectron2/resnet101_caffe checkpoint of the config is not '
                            'available offline (Kaiming backbone with the last norm of every bottleneck at 0.2, head per '
@@ -675,7 +676,8 @@ def main():
         torch.cuda.empty_cache()
 
     if is_pp and not args.no_fcaf3d:
-        fc = run_indoor_workload(args.fcaf3d_batch, args.steps, args.warmup, args, rank, world, device)
+        lw = max(args.warmup, 10)
+        fc = run_indoor_workload(args.fcaf3d_batch, args.steps, lw, args, rank, world, device)
         if rank == 0:
             res['fcaf3d_trunk'] = {
                 'config_file': os.path.relpath(FCAF3D_CONFIG, REPO),
@@ -684,7 +686,7 @@ def main():
                             'stock FCAF3D - the reference has no GGA head for this trunk',
                 'frames_per_gpu': args.fcaf3d_batch, 'global_batch': args.fcaf3d_batch * world,
                 'value': round(args.fcaf3d_batch * world * args.steps / fc['dt'], 3), 'unit': 'scenes/s',
-                'ms_per_step': round(fc['dt'] / args.steps * 1e3, 3), 'steps': args.steps, 'warmup': args.warmup,
+                'ms_per_step': round(fc['dt'] / args.steps * 1e3, 3), 'steps': args.steps, 'warmup': lw,
                 'final_loss': round(fc['loss'], 4), 'matrix_planes': fc['runner'].planes}
         del fc
         gc.collect()

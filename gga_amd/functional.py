@@ -13,6 +13,7 @@ import torch
 from . import _lib
 from ._lib import LossParams, PfnParams, VoxelParams, check
 import contextlib
+import os
 
 _DEFERRED_COUNTERS = None       # a list while a forward pass collects the BatchNorm counters it would increment
 
@@ -983,6 +984,21 @@ def bn_relu_head_conv3x3(x, bn, conv):
                                     float(bn.eps), float(bn.momentum), True, partials)
 
 
+_BRANCH_STREAMS = {}
+HEAD_STREAMS = int(os.environ.get('GGA_HEAD_STREAMS', '2'))      # streams the branch launches are dealt to (1: none but the caller's)
+
+
+def _branch_streams(device, n):
+    """Streams for the per-branch launches of a head (see _HeadBranches), the caller's first: every one of those launches is a
+    persistent grid whose last round leaves most of the chip idle (2240 tiles on 512 workgroup slots: 4.4 rounds), and the
+    branches are independent - dealt to two streams, one branch's tail runs beside the next branch's start."""
+    k = max(1, min(HEAD_STREAMS, n))
+    pool = _BRANCH_STREAMS.setdefault(device, [])
+    while len(pool) < k - 1:
+        pool.append(torch.cuda.Stream(device=device))
+    return [torch.cuda.current_stream(device)] + pool[:k - 1]
+
+
 class _HeadBranches(torch.autograd.Function):
     """All branches ``conv3x3(64 -> c_i)(relu(bn_i(conv3x3(64 -> 64)_i(x))))`` of a CenterHead (every task's
     SeparateHead, centerpoint_head.py:46-79) on the one shared feature map, as one autograd node.
@@ -1011,23 +1027,32 @@ class _HeadBranches(torch.autograd.Function):
         for i in range(0, n - 1, 2):          # (the pair's operand is assembled from the two parameters by the weight bank: no cat)
             _, st = dense_conv._run(x, [w1[i].detach(), w1[i + 1].detach()], False, True, x_amax, None, Y, C * i)
             pair_stats[i], pair_stats[i + 1] = st[:, :, :C].contiguous(), st[:, :, C:].contiguous()
+        all_stats = []
+        for i in range(n):
+            if i in pair_stats:
+                all_stats.append(pair_stats[i])
+            else:
+                all_stats.append(dense_conv._run(x, w1[i].detach(), False, True, x_amax, None, Y, C * i)[1])
+        # everything the branch launches write is allocated here, on this stream; odd branches are LAUNCHED on a second one
+        w2c = [w.contiguous() for w in w2]
+        for i in range(n):
+            outs.append(torch.empty((B, w2[i].shape[0], H, W), dtype=torch.float32, device=dev))
+            saved_all.append(torch.empty(2 * C, dtype=torch.float32, device=dev))
+            ss_all.append(torch.empty(2 * C, dtype=torch.float32, device=dev))
+        streams = _branch_streams(dev, n)
+        for st_ in streams[1:]:
+            st_.wait_stream(streams[0])
         for i in range(n):
             eps, momentum = cfg[i]
-            if i in pair_stats:
-                st = pair_stats[i]
-            else:
-                _, st = dense_conv._run(x, w1[i].detach(), False, True, x_amax, None, Y, C * i)
-            stats = st
-            tiles = int(st.shape[0])
-            saved = torch.empty(2 * C, dtype=torch.float32, device=dev)
-            ss = torch.empty(2 * C, dtype=torch.float32, device=dev)
-            check(L.gga_bn_stats_partials(_p(gam[i]), _p(bet[i]), _p(rm[i]), _p(rv[i]), rows, C, eps, momentum, _p(saved), _p(ss),
-                                          _p(stats), tiles, _stream()), 'gga_bn_stats_partials')
-            cout = w2[i].shape[0]
-            y = torch.empty((B, cout, H, W), dtype=torch.float32, device=dev)
-            check(L.gga_head_conv3x3_fwd(Y.data_ptr() + 4 * C * i, tot, _p(ss), _p(w2[i].contiguous()), _p(b2[i]), B, H, W, C, cout,
-                                         _p(y), _stream()), 'gga_head_conv3x3_fwd')
-            outs.append(y), saved_all.append(saved), ss_all.append(ss)
+            stats = all_stats[i]
+            tiles = int(stats.shape[0])
+            with torch.cuda.stream(streams[i % len(streams)]):
+                check(L.gga_bn_stats_partials(_p(gam[i]), _p(bet[i]), _p(rm[i]), _p(rv[i]), rows, C, eps, momentum, _p(saved_all[i]),
+                                              _p(ss_all[i]), _p(stats), tiles, _stream()), 'gga_bn_stats_partials')
+                check(L.gga_head_conv3x3_fwd(Y.data_ptr() + 4 * C * i, tot, _p(ss_all[i]), _p(w2c[i]), _p(b2[i]), B, H, W, C,
+                                             w2[i].shape[0], _p(outs[i]), _stream()), 'gga_head_conv3x3_fwd')
+        for st_ in streams[1:]:
+            streams[0].wait_stream(st_)
         ctx.save_for_backward(x, Y, *w1, *gam, *w2, *saved_all, *ss_all)
         ctx.n, ctx.has_bias, ctx.x_amax = n, [b is not None for b in b2], x_amax
         ctx.bn_src = dense_conv.bn_source(x, C) if dense_conv.BN_BWD_FUSED else None     # x = relu(bn(shared conv))
@@ -1051,23 +1076,29 @@ class _HeadBranches(torch.autograd.Function):
         # takes the largest of them
         g_blocks = dense_conv.new_amax(dev, n)
         gw2, gb2, ggam, gbet = [], [], [], []
-        wsb = _workspace('bn', L.gga_bn_relu_workspace_bytes(rows, C), dev)
+        gyc = [g.contiguous() for g in gys]
+        w2c = [w.contiguous() for w in w2]
+        for i in range(n):                      # outputs of the branch launches: allocated on this stream (see forward)
+            gw2.append(torch.empty_like(w2c[i]))
+            gb2.append(torch.empty(w2[i].shape[0], dtype=torch.float32, device=dev) if ctx.has_bias[i] else None)
+            ggam.append(torch.empty(C, dtype=torch.float32, device=dev))
+            gbet.append(torch.empty(C, dtype=torch.float32, device=dev))
+        streams = _branch_streams(dev, n)
+        for st_ in streams[1:]:
+            st_.wait_stream(streams[0])
         for i in range(n):
-            gy = gys[i].contiguous()
             cout = w2[i].shape[0]
-            w = w2[i].contiguous()
-            gw = torch.empty_like(w)
-            gb = torch.empty(cout, dtype=torch.float32, device=dev) if ctx.has_bias[i] else None
-            ws = _workspace('headconv', L.gga_head_conv3x3_workspace_bytes(cout), dev)
-            check(L.gga_head_conv3x3_wgrad(Y.data_ptr() + 4 * C * i, tot, _p(ss_all[i]), _p(gy), B, H, W, C, cout, _p(gw), _p(gb), _p(ws),
-                                           ws.numel(), _stream()), 'gga_head_conv3x3_wgrad')
-            gg = torch.empty(C, dtype=torch.float32, device=dev)
-            gbeta = torch.empty(C, dtype=torch.float32, device=dev)
-            check(L.gga_head_tail_bwd(_p(gy), Y.data_ptr() + 4 * C * i, tot, _p(ss_all[i]), _p(gam[i]), _p(saved_all[i]), _p(w), B, H, W,
-                                      C, cout, G.data_ptr() + 4 * C * i, tot, _p(gg), _p(gbeta), _p(g_blocks[i:i + 1] if g_blocks is not None else None),
-                                      _p(wsb), wsb.numel(),
-                                      _stream()), 'gga_head_tail_bwd')
-            gw2.append(gw), gb2.append(gb), ggam.append(gg), gbet.append(gbeta)
+            with torch.cuda.stream(streams[i % len(streams)]):
+                ws = _workspace('headconv', L.gga_head_conv3x3_workspace_bytes(cout), dev)       # (scratch buffers are per stream)
+                wsb = _workspace('bn', L.gga_bn_relu_workspace_bytes(rows, C), dev)
+                check(L.gga_head_conv3x3_wgrad(Y.data_ptr() + 4 * C * i, tot, _p(ss_all[i]), _p(gyc[i]), B, H, W, C, cout, _p(gw2[i]),
+                                               _p(gb2[i]), _p(ws), ws.numel(), _stream()), 'gga_head_conv3x3_wgrad')
+                check(L.gga_head_tail_bwd(_p(gyc[i]), Y.data_ptr() + 4 * C * i, tot, _p(ss_all[i]), _p(gam[i]), _p(saved_all[i]), _p(w2c[i]),
+                                          B, H, W, C, cout, G.data_ptr() + 4 * C * i, tot, _p(ggam[i]), _p(gbet[i]),
+                                          _p(g_blocks[i:i + 1] if g_blocks is not None else None), _p(wsb), wsb.numel(),
+                                          _stream()), 'gga_head_tail_bwd')
+        for st_ in streams[1:]:
+            streams[0].wait_stream(st_)
         wcat = [w.detach() for w in w1]            # stands for the [64n, 64, 3, 3] concatenation (weight bank: never made)
         g_amax = g_blocks.max().reshape(1) if g_blocks is not None else None       # (bits of non-negative floats order like ints)
         gx = dense_conv.run_bn_bwd(G, wcat, g_amax, None, ctx.bn_src) if ctx.needs_input_grad[0] else None

@@ -27,3 +27,4 @@ from .config import Config  # noqa: E402,F401
 from .registry import build_detector, build_model  # noqa: E402,F401
 from .pseudo_labels import pseudo_label_matching_kitti  # noqa: E402,F401
 from . import datasets  # noqa: E402,F401  (registers KittiDataset_GGA_train / LoadAnnotations3D)
+from . import weight_bank  # noqa: E402,F401  (registers the process-wide optimizer-step hook that invalidates packed weights)

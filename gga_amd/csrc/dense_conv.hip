@@ -582,7 +582,12 @@ extern "C" int gga_dense_conv3x3_bn_bwd(const float* x, const void* split_weight
                 "gga_dense_conv3x3: need cin %% 32 == 0 and cout 64 or 128 (got %d -> %d)", cin, cout);
     const int prow = transposed ? 1 : W, pcol = transposed ? W : 1;
     if (transposed) { const int t = H; H = W; W = t; }          // tile space of the transposed walk
-    if (dc_ws_enabled(planes) && cin <= DC_WS_MAX_CIN) {      // two fp16 planes: the producer / consumer form (dense_conv_ws.hip)
+    // gga_dense_conv3x3_stat_rows / _tile_rows describe the producer / consumer grid whenever that form is enabled for `planes`: a
+    // shape it cannot take must not fall back silently to the lock-step kernel (other tile size, other number of stats rows)
+    GGA_REQUIRE(!dc_ws_enabled(planes) || cin <= DC_WS_MAX_CIN,
+                "gga_dense_conv3x3: %d input channels on two planes (the producer / consumer form takes <= %d; use planes = 3 or GGA_DC_WS=0)",
+                cin, DC_WS_MAX_CIN);
+    if (dc_ws_enabled(planes)) {      // two fp16 planes: the producer / consumer form (dense_conv_ws.hip)
         hipEvent_t* tev = gga_timing_acquire(GGA_TIME_DENSE_CONV, GGA_TIMING_CONV_KEY(cin, cout, (int64_t)H * W));
         GGA_TIME_START(tev, stream);
         const int rc = dc_launch_ws(x, split_weight, B, H, W, cin, cout, y, (int)y_pixel_stride, prow, pcol, stats, amax_x, amax_weight, bn,
@@ -637,7 +642,9 @@ extern "C" int gga_dense_conv3x3_levels(int n_entries, const float* const* x, co
                     y_pixel_stride < 2147483647ll, "gga_dense_conv3x3_levels: need cin %% 32 == 0 and cout 64 or 128 (got %d -> %d)",
                 cin, cout);
     static const int ws_slices = getenv("GGA_DC_WS_SLICES") ? atoi(getenv("GGA_DC_WS_SLICES")) : 1;       // A/B switch
-    if (ws_slices && dc_ws_enabled(planes) && cout == 128 && tile_rows == 8 && !bias && cin <= DC_WS_MAX_CIN) {
+    GGA_REQUIRE(!dc_ws_enabled(planes) || cin <= DC_WS_MAX_CIN,
+                "gga_dense_conv3x3_levels: %d input channels on two planes (the producer / consumer form takes <= %d)", cin, DC_WS_MAX_CIN);
+    if (ws_slices && dc_ws_enabled(planes) && cout == 128 && tile_rows == 8 && !bias) {
         // 128-channel slices of ONE convolution's output (same input, one absmax): the producer / consumer form walks them as one grid
         bool same = true;
         for (int e = 1; e < n_entries; ++e)

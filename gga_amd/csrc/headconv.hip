@@ -95,11 +95,7 @@ __global__ __launch_bounds__(512, 2) void headconv_fwd_kernel(const float* __res
         sf = *reinterpret_cast<const float4*>(in_ss + HC_CIN + 4 * piece);
     }
     float4 ld[8];
-#ifdef HM_ABL_NOLOAD                     /* experiment builds (tools_dev/exp_headconv.py): no global reads / no matrix products */
-#define HM_FETCH_(P) make_float4((float)(((uintptr_t)(P)) & 15), 1.f, 2.f, 3.f)
-#else
 #define HM_FETCH_(P) (*reinterpret_cast<const float4*>(P))
-#endif
     // request the rows of group G of tile T (8 loads in flight per lane), zero outside the image / the halo
 #define HM_LOAD(T, G) {                                                                                               \
         const int tb_ = (T) / per_img, trem_ = (T) - tb_ * per_img;                                                   \
@@ -123,9 +119,6 @@ __global__ __launch_bounds__(512, 2) void headconv_fwd_kernel(const float* __res
 #define HM_PARK(XA) {                                                                                                 \
         _Pragma("unroll") for (int i = 0; i < 8; ++i) *reinterpret_cast<float4*>(mine + (4 * i + prow_) * HM_SROW + piece * 16) = ld[i]; \
         _Pragma("unroll") for (int q = 0; q < 8; ++q) XA[q] = *reinterpret_cast<const float4*>(mine + r * HM_SROW + h * 128 + q * 16); }
-#ifdef HM_ABL_NOMMA
-#define HM_MMA(XA, ACC) { _Pragma("unroll") for (int i = 0; i < 16; ++i) ACC[i] = XA[i & 7].x + XA[i & 7].w + wcol[i * 32]; }
-#else
 #define HM_MMA(XA, ACC) {                                                                                             \
         _Pragma("unroll") for (int i = 0; i < 16; ++i) ACC[i] = 0.0f;                                                 \
         _Pragma("unroll") for (int q = 0; q < 8; ++q) {                                                               \
@@ -134,7 +127,6 @@ __global__ __launch_bounds__(512, 2) void headconv_fwd_kernel(const float* __res
             ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(XA[q].z, wcol[(4 * q + 2) * 32], ACC, 0, 0, 0);                \
             ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(XA[q].w, wcol[(4 * q + 3) * 32], ACC, 0, 0, 0);                \
         } }
-#endif
     // D layout of 32x32x2: register v of lane l holds row (v/4)*8 + (l/32)*4 + v%4, column l%32
 #define HM_ZOUT(U, ACC) { float* zg = reinterpret_cast<float*>(mine) + (U) * 32 * HM_ZS + r;                          \
         _Pragma("unroll") for (int v = 0; v < 16; ++v) zg[((v >> 2) * 8 + h * 4 + (v & 3)) * HM_ZS] = ACC[v]; }
@@ -247,11 +239,7 @@ __global__ __launch_bounds__(512, 4) void headconv_fwd16_kernel(const float* __r
             const float* p_ = ok ? base_ + loff[U][s] : x + 4 * hq;                                                   \
             _Pragma("unroll") for (int j = 0; j < 4; ++j) ld[U][4 * s + j] = HQ_FETCH_(p_ + 16 * j);                  \
         } }
-#ifdef HM_ABL_NOLOAD
-#define HQ_FETCH_(P) f4{(float)(((uintptr_t)(P)) & 15), 1.f, 2.f, 3.f}
-#else
 #define HQ_FETCH_(P) (*reinterpret_cast<const f4*>(P))
-#endif
 #define HQ_B_(J, T_) (reinterpret_cast<const f4*>(wl)[wo + ((J) * 4 * NT + (T_)) * 16])
     // products of group U (2 x 16 pixels) and its Z rows: D register v of lane (n, hq) = pixel 4 * hq + v, column n
 #define HQ_MMA(U) {                                                                                                   \
@@ -276,7 +264,7 @@ __global__ __launch_bounds__(512, 4) void headconv_fwd16_kernel(const float* __r
                     _Pragma("unroll") for (int e = 0; e < 4; ++e) v[s][e] = ok ? v[s][e] : 0.0f;                      \
                 }                                                                                                     \
             }                                                                                                         \
-            _Pragma("unroll") for (int e = 0; e < HQ_ABL_E_; ++e)                                                     \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                             \
                 _Pragma("unroll") for (int t = 0; t < NT; ++t) {                                                      \
                     HQ_MFMA_(acc[0][t], v[0][e], bc[t][e]) HQ_MFMA_(acc[1][t], v[1][e], bc[t][e])                     \
                 }                                                                                                     \
@@ -286,16 +274,7 @@ __global__ __launch_bounds__(512, 4) void headconv_fwd16_kernel(const float* __r
                 float* zg = zt + ((wave + 8 * (U)) * 32 + 16 * s + 4 * hq) * ZS + 16 * t + n;                         \
                 _Pragma("unroll") for (int v_ = 0; v_ < 4; ++v_) zg[v_ * ZS] = acc[s][t][v_];                         \
             } }
-#ifdef HM_ABL_QUARTER
-#define HQ_ABL_E_ 1
-#else
-#define HQ_ABL_E_ 4
-#endif
-#ifdef HM_ABL_NOMMA
-#define HQ_MFMA_(ACC, A, Bv) ACC[0] += (A) + (Bv);
-#else
 #define HQ_MFMA_(ACC, A, Bv) ACC = __builtin_amdgcn_mfma_f32_16x16x4f32(A, Bv, ACC, 0, 0, 0);
-#endif
     // Tile walk: workgroup b runs on XCD b % 8 (round-robin dispatch). Each XCD takes one contiguous eighth of the tiles and its
     // workgroups walk it side by side, so that the tiles above / below / beside a tile are read through the same L2 at about
     // the same time and the halo rows (2 of 15, 2 of 34 columns) come from there instead of from memory a second time.
@@ -316,7 +295,6 @@ __global__ __launch_bounds__(512, 4) void headconv_fwd16_kernel(const float* __r
         HQ_MMA(1)
         HQ_LOAD(nxt, nxt < t_end, 1)
         __syncthreads();
-#ifndef HM_ABL_NOEPI
         if (threadIdx.x < HP_TR * HM_TW) {               // one thread per output pixel, all its channels
             const int ty = threadIdx.x / HM_TW, tx = threadIdx.x - ty * HM_TW;
             const int oy = y0 + ty, ox = x0 + tx;
@@ -337,7 +315,6 @@ __global__ __launch_bounds__(512, 4) void headconv_fwd16_kernel(const float* __r
                 for (int co = 0; co < COUT; ++co) yo[(int64_t)co * H * W] = s[co];
             }
         }
-#endif
         __syncthreads();                                  // Z is written again
     }
 #undef HQ_LOAD
@@ -393,9 +370,7 @@ __global__ __launch_bounds__(512, HW_MINW) void headconv_wgrad_kernel(const floa
     // (the zeroes must have landed before anyone stages the first tile into the same words: without this barrier a wave that
     // was held up in the loop above could wipe values another wave had already staged - seen once in ~2000 steps, and only with
     // a second stream's kernels sharing the CU: one tile's dy partly zeroed, 3e-3 of the branch's weight gradient)
-#ifndef HW_ABL_NO_INIT_BARRIER          /* (experiment build: the round-1/2 kernel, to show that tools_dev/dbg_replay_noise.py finds it) */
     __syncthreads();
-#endif
     acc16 acc0, acc1;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { acc0[i] = 0.0f; acc1[i] = 0.0f; }
@@ -431,19 +406,11 @@ __global__ __launch_bounds__(512, HW_MINW) void headconv_wgrad_kernel(const floa
             const bool ok = inh && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
             const float* xp = x + (((int64_t)b * H + (ok ? iy : 0)) * W + (ok ? ix : 0)) * xs + m;
             const float mk = ok ? 1.0f : 0.0f;
-#ifdef HW_ABL_NOLOAD
-            const float x0_ = (float)(((uintptr_t)xp) & 255), x1_ = 1.0f;
-#else
             const float x0_ = xp[0], x1_ = xp[32];
-#endif
             const float a0 = fmaxf(fmaf(x0_, sc0, sf0), lo) * mk, a1 = fmaxf(fmaf(x1_, sc1, sf1), lo) * mk;
             const float gv = g[gbase + hr * HW_PC + hx] * usedf;
-#ifdef HW_ABL_NOMMA
-            acc0[s & 15] = fmaf(a0, gv, acc0[s & 15]); acc1[s & 15] = fmaf(a1, gv, acc1[s & 15]);
-#else
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, gv, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, gv, acc1, 0, 0, 0);
-#endif
         }
     }
     // fixed-order fold of the 8 waves' partial D[ci][n] (register v of lane l: row (v/4)*8 + (l/32)*4 + v%4, column l%32)
@@ -546,11 +513,7 @@ __global__ __launch_bounds__(512, 4) void headconv_wgrad16_kernel(const float* _
 #pragma unroll
     for (int e = 0; e < GN; ++e) bsum[e] = 0.0f;
     unsigned okm = 0u;
-#ifdef HW_ABL_NOLOAD
-#define HG_FETCH_(P) f4{(float)(((uintptr_t)(P)) & 15), 1.f, 2.f, 3.f}
-#else
 #define HG_FETCH_(P) (*reinterpret_cast<const f4*>(P))
-#endif
 #define HG_COORDS(T) const int tb_ = (T) / per_img, trem_ = (T) - tb_ * per_img;                                      \
         const int ty0_ = (trem_ / tiles_x) * HG_TR, tx0_ = (trem_ % tiles_x) * HG_TW;
 #define HG_XLOAD(T, LIVE, S) {                                                                                        \
@@ -606,11 +569,7 @@ __global__ __launch_bounds__(512, 4) void headconv_wgrad16_kernel(const float* _
             for (int e = 0; e < 4; ++e)
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
-#ifdef HW_ABL_NOMMA
-                    acc[e][t][0] += v[e] * bw[t];
-#else
                     acc[e][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[e], bw[t], acc[e][t], 0, 0, 0);
-#endif
                 }
             HG_XLOAD(nxt, live, s)
         }

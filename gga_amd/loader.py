@@ -271,11 +271,18 @@ def to_step_inputs(collated, device=None, chunk=0, non_blocking=True):
 
 # ------------------------------------------------------------------------------------------------------------------ loader
 def build_dataloader(dataset, samples_per_gpu, workers_per_gpu, num_gpus=1, dist=True, shuffle=True, seed=None,
-                     runner_type='EpochBasedRunner', persistent_workers=False, rank=None, world_size=None, **kwargs):
+                     runner_type='EpochBasedRunner', persistent_workers=False, rank=None, world_size=None, worker_seed=None,
+                     **kwargs):
     """mmdet 2.x ``build_dataloader`` for the epoch-based runner: per process ``samples_per_gpu`` frames per batch when
-    distributed (one process per GPU), ``num_gpus * samples_per_gpu`` otherwise; group samplers when shuffling."""
+    distributed (one process per GPU); group samplers when shuffling. ``seed`` seeds the sampler's order and must be equal on
+    all ranks (each takes its block of one shuffled sequence); ``worker_seed`` (default: ``seed``) seeds the loader workers'
+    augmentation generators and may differ per rank. One process drives one device: the reference's non-distributed
+    ``num_gpus > 1`` mode (MMDataParallel scattering ``num_gpus`` chunks) does not exist here and is refused."""
     if runner_type != 'EpochBasedRunner':
         raise NotImplementedError('configs/gga train with the EpochBasedRunner')
+    if not dist and num_gpus != 1:
+        raise NotImplementedError(f'{num_gpus} GPUs without a launcher: one process drives one GPU - start one rank per GPU '
+                                  f'(tools/train.py --launcher pytorch)')
     if dist:
         import torch.distributed as td
         rank = td.get_rank() if rank is None else rank
@@ -287,7 +294,8 @@ def build_dataloader(dataset, samples_per_gpu, workers_per_gpu, num_gpus=1, dist
         rank = 0
         sampler = GroupSampler(dataset, samples_per_gpu) if shuffle else None
         batch_size, num_workers = num_gpus * samples_per_gpu, num_gpus * workers_per_gpu
-    init_fn = partial(worker_init_fn, num_workers=num_workers, rank=rank, seed=seed) if seed is not None else None
+    worker_seed = seed if worker_seed is None else worker_seed
+    init_fn = partial(worker_init_fn, num_workers=num_workers, rank=rank, seed=worker_seed) if worker_seed is not None else None
     if num_workers > 0:
         kwargs['persistent_workers'] = persistent_workers
     return DataLoader(dataset, batch_size=batch_size, sampler=sampler, num_workers=num_workers,

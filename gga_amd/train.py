@@ -169,12 +169,11 @@ def build_optimizer(model, cfg):
         opt = torch.optim.SGD(params, **cfg)
     else:
         raise KeyError(f'optimizer {typ} is not used by configs/gga (AdamW, SGD)')
-    # the packed operands of the convolution weights are stale after every step; torch's fused optimizers do not bump the
-    # parameters' version counters, so the weight bank is told explicitly
-    from . import weight_bank
-    opt.register_step_post_hook(lambda *_: weight_bank.BANK.invalidate())
+    # The packed operands of the convolution weights are stale after every step, and torch's fused optimizers do not bump the
+    # parameters' version counters: weight_bank registers a GLOBAL optimizer-step hook at import (every optimizer of the
+    # process, also one the user built) - make sure it is imported before the first step.
+    from . import weight_bank  # noqa: F401
     return opt
-    raise KeyError(f'optimizer {typ} is not used by configs/gga (AdamW, SGD)')
 
 
 def init_dist():
@@ -232,7 +231,11 @@ class Runner:
         elif lrc.get('policy') == 'step':
             self.lr_sched = StepSchedule(1.0, lrc['step'], iters_per_epoch or 1, lrc.get('gamma', 0.1), lrc.get('warmup'),
                                          lrc.get('warmup_iters', 0), lrc.get('warmup_ratio', 0.1))
-            self._base_lrs = None       # per-group base rates (paramwise multipliers), scaled by the schedule
+        # per-group base rates (paramwise multipliers) the step schedule scales: kept IN the param groups under mmcv's key
+        # ('initial_lr', LrUpdaterHook.before_run), so that they ride along in optimizer.state_dict() - a resumed run must not
+        # take the already-decayed 'lr' of the checkpoint for its base
+        for g in self.optimizer.param_groups:
+            g.setdefault('initial_lr', g['lr'])
         if mc.get('policy') == 'cyclic':
             self.mom_sched = CyclicSchedule(base_m, max_iters, mc.get('target_ratio', (0.85 / 0.95, 1)),
                                             mc.get('cyclic_times', 1), mc.get('step_ratio_up', 0.4))
@@ -252,8 +255,10 @@ class Runner:
             self.planes = dense_conv.PLANES
         else:
             self.planes = 3 if dense_conv.FELL_BACK else int(cfg.get('gga_dense_planes', 2))
+        self.fell_back = bool(dense_conv.FELL_BACK and not dense_conv.PLANES_PINNED)      # this run left two planes through the guard
         self.range_check_interval = int(os.environ.get('GGA_RANGE_CHECK_INTERVAL', cfg.get('gga_range_check_interval', 500)))
         self.range_reports = []     # (iteration, worst share of lost elements, operands seen) per guarded step
+        self._guard_next = True     # the first step of every Runner (and the first after a resume) is guarded, whatever its iteration
         self._gc_frozen = False
         self._side = None           # side stream of the input prefetch
         self._prepared = {}         # id(data dict) -> (PreparedInputs, event)
@@ -340,8 +345,9 @@ class Runner:
     def _step(self, data, next_data):
         from . import dense_conv, functional as F
         dense_conv.AMAX_POOL.next_generation()      # one memset for all of this step's absmax slots
-        guarded = (self.planes == 2 and self.range_check_interval > 0 and self.iter % self.range_check_interval == 0
-                   and self.device.type == 'cuda')
+        guarded = (self.planes == 2 and self.range_check_interval > 0 and self.device.type == 'cuda'
+                   and (self._guard_next or self.iter % self.range_check_interval == 0))
+        self._guard_next = False
         if guarded:
             dense_conv.RANGE_GUARD.arm()
         hit = self._prepared_for(data)
@@ -359,11 +365,9 @@ class Runner:
             prep, ev = hit[:2]
             torch.cuda.current_stream(self.device).wait_event(ev)
             data = dict(data, points=prep)
-        if isinstance(self.lr_sched, StepSchedule) and self._base_lrs is None:
-            self._base_lrs = [g['lr'] for g in self.optimizer.param_groups]
-        for gi, g in enumerate(self.optimizer.param_groups):
+        for g in self.optimizer.param_groups:
             if isinstance(self.lr_sched, StepSchedule):
-                g['lr'] = self._base_lrs[gi] * self.lr_sched(self.iter)
+                g['lr'] = g['initial_lr'] * self.lr_sched(self.iter)
             elif self.lr_sched is not None:
                 g['lr'] = self.lr_sched(self.iter)
             if self.mom_sched is not None:
@@ -415,7 +419,7 @@ class Runner:
         self.range_reports[-1]['fell_back'] = bool(fall_back and not dense_conv.PLANES_PINNED)
         if fall_back and not dense_conv.PLANES_PINNED:
             self.planes = 3
-            dense_conv.FELL_BACK = True
+            self.fell_back = dense_conv.FELL_BACK = True
             w = over[0] if over else None
             where = (f'a {w["phase"]} operand {w["shape"]} of the convolutions has {w["share_lost"]:.2%} of its non-zero elements '
                      f'({w["mass_lost"]:.1e} of its L1 mass) below 2^-30 of its largest magnitude') if w else 'another rank reported an operand over the limit'
@@ -462,7 +466,10 @@ class Runner:
         counted (``train_epochs``) or at any iteration."""
         from collections import OrderedDict
         meta = dict(meta or {})
-        meta.update(epoch=self.epoch, iter=self.iter, time=time.asctime(), gga_amd_planes=_current_planes())
+        # the arithmetic THIS run trains on (Runner.planes; the process-wide dense_conv.PLANES is the library default outside
+        # `step`) and whether its range guard has fallen back: resume() restores both
+        meta.update(epoch=self.epoch, iter=self.iter, time=time.asctime(), gga_amd_planes=int(self.planes),
+                    gga_amd_fell_back=bool(self.fell_back))
         classes = getattr(self.raw_model, 'CLASSES', None)
         if classes is not None:
             meta['CLASSES'] = classes
@@ -506,6 +513,15 @@ class Runner:
         self.epoch, self.iter = int(ckpt['meta']['epoch']), int(ckpt['meta']['iter'])
         if resume_optimizer and 'optimizer' in ckpt:
             self.optimizer.load_state_dict(ckpt['optimizer'])
+            for g in self.optimizer.param_groups:          # checkpoints written before 'initial_lr' rode along
+                g.setdefault('initial_lr', g['lr'])
+        # a run whose range guard had fallen back to three planes continues on three planes (its operands are known to exceed
+        # the two-plane range); any resumed run is guarded again on its first step
+        from . import dense_conv
+        if ckpt['meta'].get('gga_amd_fell_back') and not dense_conv.PLANES_PINNED:
+            self.planes = 3
+            self.fell_back = dense_conv.FELL_BACK = True
+        self._guard_next = True
         return ckpt['meta']
 
     def train_epochs(self, data_loader, max_epochs, work_dir=None, checkpoint_config=None, logger=None, to_inputs=None):
@@ -558,11 +574,6 @@ class Runner:
 
 
 
-def _current_planes():
-    from . import dense_conv
-    return dense_conv.PLANES
-
-
 def _is_rank0():
     return not (dist.is_available() and dist.is_initialized()) or dist.get_rank() == 0
 
@@ -604,7 +615,7 @@ def train_detector(model, dataset, cfg, distributed=False, validate=False, times
     assert all(mode == 'train' for mode, _ in workflow), 'val epochs in the workflow are not supported'
     gpu_ids = cfg.get('gpu_ids', [0])
     loader = build_dataloader(dataset, data['samples_per_gpu'], data['workers_per_gpu'], num_gpus=len(gpu_ids), dist=distributed,
-                              seed=cfg.get('seed'), runner_type=runner_cfg['type'],
+                              seed=cfg.get('seed'), worker_seed=cfg.get('worker_seed'), runner_type=runner_cfg['type'],
                               persistent_workers=data.get('persistent_workers', False))
     max_epochs = int(runner_cfg['max_epochs'])
     runner = Runner(model, cfg, max_iters=max_epochs * len(loader), distributed=distributed, device=device,

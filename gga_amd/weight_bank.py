@@ -15,8 +15,17 @@ virtual: the two first convolutions a head-branch launch covers, the 15 branch w
 convolution. Sources that form one operand share one absmax slot (the scale of the operand).
 
 Streams: the refresh runs on the stream of the request that triggered it; a request from another stream waits for the refresh's
-event. Operands nobody asked for during the last ``KEEP`` refreshes are dropped (models come and go in a test process)."""
+event. Operands nobody asked for during the last ``KEEP`` refreshes are dropped (models come and go in a test process); in a
+process whose weights never change (inference, pseudo-label runs) the same sweep runs every ``SWEEP_EVERY`` operand creations.
+
+What tells the bank that weights changed: the tensors' version counters (in-place torch ops, ``load_state_dict``, non-fused
+optimizers) and ``invalidate()``, which a process-wide optimizer-step hook (registered below, at import) calls after the step of
+EVERY ``torch.optim`` optimizer - the fused ones leave the version counters alone. Updates that do neither - writes through
+``param.data`` (``p.data.copy_``, EMA / SWA through ``.data``), raw-pointer kernels - need an explicit ``BANK.invalidate()``.
+``GGA_BANK_VERIFY=1`` checks every request against the sources as they are now (a synchronising debug switch) and raises on a
+stale operand."""
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -27,6 +36,7 @@ from ._lib import check
 
 LAYOUT_GATHER, LAYOUT_DENSE = 0, 1
 ENABLED = True          # False: every request packs on the spot (one single-entry table per request; the A/B switch)
+VERIFY = os.environ.get('GGA_BANK_VERIFY') == '1'
 
 
 class PackEntry(C.Structure):
@@ -58,7 +68,8 @@ def _padded_columns(n_out):
 
 
 class _Operand:
-    __slots__ = ('key', 'sources', 'n_in', 'n_out', 'layout', 'reverse', 'planes', 'packed', 'slot', 'versions', 'used', 'blocks', 'epoch')
+    __slots__ = ('key', 'sources', 'n_in', 'n_out', 'layout', 'reverse', 'planes', 'packed', 'slot', 'versions', 'used', 'blocks', 'epoch',
+                 'touched', 'digest')
 
     def stale(self, epoch):
         return self.epoch != epoch or any(v._version != ver for (v, _, _), ver in zip(self.sources, self.versions))
@@ -67,6 +78,7 @@ class _Operand:
 class WeightBank:
     KEEP = 4
     SLOTS = 2048
+    SWEEP_EVERY = 256           # operand creations between two sweeps of a process whose weights never change
 
     def __init__(self):
         self.ops = {}
@@ -80,6 +92,7 @@ class WeightBank:
         self.tables = {}            # device -> (signature of the stale set, pack table, amax table, totals)
         self.event, self.stream = None, None
         self.epoch = 0              # bumped by invalidate(): every operand made before is stale
+        self.created = 0            # operands ever made; `created // SWEEP_EVERY` is the sweep period an operand was last touched in
 
     def invalidate(self):
         """Every weight may have changed. Needed after updates that do not bump the tensors' version counters - torch's FUSED
@@ -112,6 +125,9 @@ class WeightBank:
                 if dead:
                     self.tables.clear()
         op.used = self.generation
+        op.touched = self.created // self.SWEEP_EVERY
+        if VERIFY:
+            self._verify(op)
         if self.event is not None:
             cur = torch.cuda.current_stream(op.packed.device)
             if cur.cuda_stream != self.stream:
@@ -128,6 +144,17 @@ class WeightBank:
         op.versions = [-1] * len(sources)
         op.epoch = -1
         op.used = self.generation
+        op.digest = None
+        self.created += 1
+        op.touched = period = self.created // self.SWEEP_EVERY
+        if self.created % self.SWEEP_EVERY == 0:
+            # weights that never change never reach the sweep of `operand`: drop what nobody asked for during the whole
+            # previous period (a live model asks for its operands in every pass; one dropped by mistake is simply made again)
+            dead = [k for k, o in self.ops.items() if o.touched < period - 1]
+            for k in dead:
+                self._release(self.ops.pop(k))
+            if dead:
+                self.tables.clear()
         op.slot, op.blocks = None, []
         if planes == 2:
             d = str(dev)
@@ -136,7 +163,9 @@ class WeightBank:
                 self.slots[d] = torch.zeros(self.SLOTS, dtype=torch.int32, device=dev)
                 self.free[d] = list(range(self.SLOTS - 1, -1, -1))
             if skey not in self.slot_of:
-                assert self.free[d], 'weight bank: out of absmax slots'
+                if not self.free[d]:
+                    raise RuntimeError(f'weight bank: all {self.SLOTS} absmax slots of {d} are held by live operands '
+                                       f'({len(self.ops)} operands) - raise WeightBank.SLOTS')
                 self.slot_of[skey] = self.free[d].pop()
             i = self.slot_of[skey]
             self.slot_users[(d, i)] = self.slot_users.get((d, i), 0) + 1
@@ -186,6 +215,8 @@ class WeightBank:
             for op in ops:
                 op.versions = [v._version for v, _, _ in op.sources]
                 op.epoch = self.epoch
+                if VERIFY:
+                    op.digest = self._digest(op)
         self.refreshes += 1
         if stale and stale[0].packed.is_cuda:
             dev = stale[0].packed.device
@@ -193,6 +224,17 @@ class WeightBank:
             cur = torch.cuda.current_stream(dev)
             self.event.record(cur)
             self.stream = cur.cuda_stream
+
+    @staticmethod
+    def _digest(op):
+        return torch.stack([torch.stack((v.double().sum(), v.double().abs().sum())) for v, _, _ in op.sources]).cpu()
+
+    def _verify(self, op):
+        """GGA_BANK_VERIFY=1: the operand was packed from the sources as they are now (sum and L1 of every source)."""
+        now = self._digest(op)
+        if op.digest is None or not torch.equal(now, op.digest):
+            raise RuntimeError('weight bank: a packed operand is stale - its weight was written without bumping the version counter '
+                               '(param.data write / raw-pointer kernel): call gga_amd.weight_bank.BANK.invalidate() after such updates')
 
     def _build_tables(self, ops, dev, planes, need):
         L = _lib.lib()
@@ -227,6 +269,11 @@ class WeightBank:
 
 
 BANK = WeightBank()
+
+# every optimizer of the process tells the bank after its step (torch's fused optimizers do not bump the version counters)
+from torch.optim.optimizer import register_optimizer_step_post_hook as _register_step_hook  # noqa: E402
+
+_STEP_HOOK = _register_step_hook(lambda *_: BANK.invalidate())
 
 
 def dense_operand(weight, backward, transposed, planes, c0=None):

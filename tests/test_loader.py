@@ -256,6 +256,61 @@ def test_resume_continues_the_saved_run_and_load_from_takes_the_weights(tmp_path
     c.load_checkpoint(str(tmp_path / 'wrapped.pth'), strict=True)
 
 
+def test_resume_with_the_step_policy_keeps_the_base_rates(tmp_path):
+    """lr_config policy='step' (configs/gga/gga_pdg.py) with paramwise multipliers and warm-up: a run saved past its first decay
+    milestone and resumed continues with the rates of the uninterrupted run - the base rates ride in the optimizer's param
+    groups as mmcv's 'initial_lr', not re-derived from the checkpoint's already-decayed 'lr' (ADVICE r04)."""
+    data = lambda i: dict(points=synthetic.make_batch(2, start=10 * i, n_points=200, n_obj_range=(2, 3), n_ibp_range=(5, 10))['points'],
+                          img_metas=[{}, {}])
+    cfg = Config(dict(CFG, optimizer=dict(type='SGD', lr=1e-3, momentum=0.9, weight_decay=1e-4,
+                                          paramwise_cfg=dict(bias_lr_mult=2.0, bias_decay_mult=0.0)),
+                      lr_config=dict(policy='step', step=[2, 4], gamma=0.1, warmup='linear', warmup_iters=2, warmup_ratio=1.0 / 3),
+                      momentum_config=None))
+    a = Runner(_tiny(), cfg, max_iters=12, iters_per_epoch=2)           # milestones at iterations 4 and 8
+    want = []
+    for i in range(10):
+        if i == 5:
+            a.epoch = 2
+            path = a.save_checkpoint(str(tmp_path / 'w'))
+        a.step(data(i))
+        want.append([g['lr'] for g in a.optimizer.param_groups])
+    assert want[0][0] == pytest.approx(1e-3 / 3) and want[3][0] == pytest.approx(1e-3) and want[4][0] == pytest.approx(1e-4)
+    assert want[9][0] == pytest.approx(1e-5) and sorted(want[3]) == pytest.approx([1e-3, 2e-3])
+    b = Runner(_tiny(), cfg, max_iters=12, iters_per_epoch=2)
+    b.resume(path)
+    assert b.iter == 5
+    for i in range(5, 10):
+        b.step(data(i))
+        assert [g['lr'] for g in b.optimizer.param_groups] == want[i], i
+    for p, q in zip(a.raw_model.parameters(), b.raw_model.parameters()):
+        assert torch.equal(p, q)
+    # a checkpoint of a run on three planes after a range-guard fall-back is resumed on three planes, and guarded on its first step
+    from gga_amd import dense_conv
+    ck = torch.load(path, weights_only=False)
+    assert ck['meta']['gga_amd_planes'] == a.planes and ck['meta']['gga_amd_fell_back'] is False
+    ck['meta']['gga_amd_fell_back'] = True
+    torch.save(ck, str(tmp_path / 'fell_back.pth'))
+    was = dense_conv.FELL_BACK
+    try:
+        c = Runner(_tiny(), cfg, max_iters=12, iters_per_epoch=2)
+        c._guard_next = False
+        c.resume(str(tmp_path / 'fell_back.pth'))
+        assert c._guard_next and (c.planes == 3 or dense_conv.PLANES_PINNED)
+    finally:
+        dense_conv.FELL_BACK = was
+
+
+def test_sampler_seed_is_common_to_the_ranks_and_one_process_drives_one_gpu():
+    """tools/train.py --diff-seed offsets the generators of a rank, never the sampler's seed (mmdet: sync_random_seed): the
+    shards stay disjoint. The non-distributed multi-GPU mode of the reference does not exist here: refused, not truncated."""
+    ds = _Frames(16)
+    loaders = [LD.build_dataloader(ds, 2, 0, dist=True, seed=7, worker_seed=7 + r, rank=r, world_size=2) for r in range(2)]
+    a, b = (list(l.sampler) for l in loaders)
+    assert not (set(a) & set(b)) and set(a) | set(b) == set(range(16))
+    with pytest.raises(NotImplementedError):
+        LD.build_dataloader(ds, 2, 0, num_gpus=2, dist=False)
+
+
 # ----------------------------------------------------------------------------------------------------------------- device
 @pytest.mark.gpu
 def test_detector_trains_from_the_kitti_tree_saves_and_resumes(tmp_path):

@@ -54,8 +54,9 @@ ARITH = ('fp32 in / fp32 out, fp32 accumulate. Every convolution (dense 3x3, str
 DTYPE_PLANES2 = 'f32 tensors, products on 2 x f16 operand planes (22-bit significands, block-scaled), f32 accumulate'
 DTYPE_PLANES3 = 'f32 tensors, products on 3 x bf16 operand planes (24-bit significands, fp32 range), f32 accumulate'
 PARITY = ('tests/test_model_gpu.py: all 18 losses of a whole step within 1e-4 of the float64 step AND of the fp32 CPU step for this '
-          'arithmetic (and for `planes3`), on both LiDAR configs (PointPillars; gga_kitti_config.py = BASELINE config 1, 4 frames); '
-          'profiles/r04_precision_cases.json has the deviations over seeds')
+          'arithmetic (and for `planes3`), on both LiDAR configs - PointPillars on seeds 1, 2, 3; gga_kitti_config.py = BASELINE '
+          'config 1 (4 frames of 20 k points) on seeds 3, 4, 5 (weights and frames differ per seed) - in the driver-run suite; '
+          'tests/test_precision_gpu.py compares every convolution shape of both configs with an fp32 FMA chain on real step operands')
 PP_CONFIG = os.path.join(REPO, 'configs', 'gga', 'gga_kitti_pointpillars_config.py')
 SECOND_CONFIG = os.path.join(REPO, 'configs', 'gga', 'gga_kitti_config.py')
 PGD_CONFIG = os.path.join(REPO, 'configs', 'gga', 'gga_pdg.py')
@@ -86,6 +87,9 @@ def parse_args(argv=None):
     ap.add_argument('--pgd-batch', type=int, default=12, help='images per GPU of the pgd leg (samples_per_gpu of the config)')
     ap.add_argument('--no-fcaf3d', action='store_true', help='skip the fcaf3d (SUN RGB-D-shaped scenes) leg')
     ap.add_argument('--fcaf3d-batch', type=int, default=8, help='scenes per GPU of the fcaf3d leg (samples_per_gpu of the config)')
+    ap.add_argument('--no-loader-fed', action='store_true', help='skip the dataset-fed leg (on-disk synthetic KITTI tree -> train_detector)')
+    ap.add_argument('--loader-frames', type=int, default=2048, help='frames of the synthetic on-disk tree of the loader_fed leg')
+    ap.add_argument('--loader-workers', default='4,8', help='workers_per_gpu values the loader_fed leg is run with')
     ap.add_argument('--no-planes3', action='store_true',
                     help='skip the `planes3` legs (main config and second_trunk re-timed on three bf16 planes / six products)')
     return ap.parse_args(argv)
@@ -303,6 +307,106 @@ def run_indoor_workload(batch, steps, warmup, args, rank, world, device):
     loss = float(out['loss'].detach())
     assert loss == loss, 'loss is NaN (fcaf3d)'
     return dict(dt=float(t.item()), loss=loss, runner=runner)
+
+
+def pipeline_stage_ms(dataset, frames=48):
+    """ms per frame of every stage of the train pipeline, run in THIS process on the first `frames` frames."""
+    import numpy as np
+    import torch
+    inner = getattr(dataset, 'dataset', dataset)
+    np.random.seed(0), torch.manual_seed(0)
+    acc, objects, points = {}, 0, 0
+    for i in range(frames):
+        t = time.perf_counter()
+        sample = inner.get_data_info(i)
+        inner.pre_pipeline(sample)
+        acc['get_data_info'] = acc.get('get_data_info', 0.0) + time.perf_counter() - t
+        for tr in inner.pipeline.transforms:
+            t = time.perf_counter()
+            sample = tr(sample)
+            acc[type(tr).__name__] = acc.get(type(tr).__name__, 0.0) + time.perf_counter() - t
+        objects += len(sample['gt_labels_3d'].data)
+        points += int(sample['points'].data.shape[0])
+    out = {k: round(v / frames * 1e3, 3) for k, v in acc.items()}
+    out['total'] = round(sum(acc.values()) / frames * 1e3, 3)
+    return out, objects / frames, points / frames
+
+
+def run_loader_fed(args, device, resident_value):
+    """The REAL train job on one GPU (mmdet3d/apis/train.py:180-322 through gga_amd.train.train_detector): a synthetic KITTI tree
+    on disk (scans, the GGA info file, the GT database: synthetic.write_kitti_tree) -> KittiDataset_GGA_train with the
+    reference's full train_pipeline of configs/gga/gga_kitti_config.py:93-137 (ObjectSample_GGA with database sampling,
+    range filters, shuffle, format, collect) in `workers_per_gpu` loader workers -> collate -> upload -> Runner.step, one epoch;
+    the first iterations are warm-up (worker start-up, allocator), the rest is timed between two device synchronisations.
+    -> dict per workers_per_gpu: frames/s, share of the loop's wall time spent waiting in next(loader), host ms per iteration
+    by part; plus the pipeline's ms per frame by stage (this process, one thread)."""
+    import tempfile
+    import torch
+    from gga_amd import Config, build_model, synthetic
+    from gga_amd.cnn import to_channels_last
+    from gga_amd.loader import build_dataset
+    from gga_amd.train import setup_multi_processes, train_detector
+    root = os.environ.get('GGA_BENCH_TREE') or os.path.join(tempfile.gettempdir(), f'gga_bench_kitti_{os.getuid()}')
+    t0 = time.perf_counter()
+    info_path, db_path = synthetic.write_kitti_tree(root, args.loader_frames, pc_range=synthetic.RANGE_PP)
+    tree_s = time.perf_counter() - t0
+    out = {'workload': f'train_detector on {os.path.relpath(PP_CONFIG, REPO)}: {args.loader_frames} synthetic KITTI frames of 20 000 points on disk '
+                       f'(+ GT database, 300 objects per class), the reference\'s full train_pipeline incl. ObjectSample_GGA database sampling, '
+                       f'samples_per_gpu {args.batch}, one epoch; same model / arithmetic / step as the headline',
+           'tree_seconds': round(tree_s, 1), 'resident_batch_frames_per_s': resident_value}
+    warm = 8
+    for workers in [int(w) for w in args.loader_workers.split(',') if w]:
+        cfg = Config.fromfile(PP_CONFIG)
+        d = cfg.data['train']
+        d['dataset'].update(data_root=root + '/', ann_file=info_path)
+        for t in d['dataset']['pipeline']:
+            if t['type'] == 'ObjectSample_GGA':
+                t['db_sampler'].update(data_root=root + '/', info_path=db_path)
+            if 'point_cloud_range' in t:          # (the base file's pipeline carries the sparse config's range)
+                t['point_cloud_range'] = list(synthetic.RANGE_PP)
+        cfg.data.update(samples_per_gpu=args.batch, workers_per_gpu=workers)
+        cfg.runner = dict(type='EpochBasedRunner', max_epochs=1)
+        cfg.checkpoint_config, cfg.work_dir, cfg.seed = None, None, 0
+        setup_multi_processes(cfg)
+        if not args.nchw:
+            cfg.model.pts_middle_encoder['channels_last'] = True
+        torch.manual_seed(0)
+        model = build_model(cfg.model).to(device)
+        damp_head_init(model, args.head_init_scale)
+        if not args.nchw:
+            model = to_channels_last(model)
+        model.train()
+        dataset = build_dataset(d)
+        if 'pipeline_ms_per_frame' not in out:
+            stages, objs, pts = pipeline_stage_ms(dataset)
+            out['pipeline_ms_per_frame'] = stages
+            out['objects_per_frame_after_sampling'] = round(objs, 1)
+            out['points_per_frame_after_sampling'] = round(pts)
+        mark = {}
+
+        def after_iter(runner, n):
+            if n == warm:
+                torch.cuda.synchronize()
+                mark['t0'] = time.perf_counter()
+                for k in runner.loop_seconds:
+                    runner.loop_seconds[k] = 0
+        runner = train_detector(model, dataset, cfg, distributed=False, device=device, after_iter=after_iter)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - mark['t0']
+        ls = runner.loop_seconds
+        iters = ls['iters']
+        assert iters >= 40, f'{iters} timed iterations: raise --loader-frames'
+        out[f'workers_{workers}'] = {
+            'value': round(iters * args.batch / dt, 3), 'unit': 'frames/s', 'ms_per_step': round(dt / iters * 1e3, 3),
+            'timed_steps': iters, 'warmup_steps': warm, 'vs_resident_batches': round(iters * args.batch / dt / resident_value, 3),
+            'data_wait_fraction': round(ls['fetch'] / dt, 4),
+            'host_ms_per_step': {'next(loader)': round(ls['fetch'] / iters * 1e3, 3), 'unpack + upload': round(ls['inputs'] / iters * 1e3, 3),
+                                 'Runner.step (queueing)': round(ls['step'] / iters * 1e3, 3)},
+            'matrix_planes': runner.planes}
+        del runner, model, dataset
+        gc.collect()
+        torch.cuda.empty_cache()
+    return out
 
 
 def scatter_roofline(model, batches, step_ms):
@@ -691,6 +795,9 @@ def main():
         del fc
         gc.collect()
         torch.cuda.empty_cache()
+
+    if is_pp and world == 1 and not args.no_loader_fed:
+        res['loader_fed'] = run_loader_fed(args, device, res['value'])
 
     if is_pp and not args.no_planes3:
         # the same steps on the library's default arithmetic (three bf16 planes / six products: fp32 semantics per element)

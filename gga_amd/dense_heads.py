@@ -250,7 +250,10 @@ class CenterHead_GGA(nn.Module):
             bounds = np.flatnonzero(np.r_[True, (fo[1:] != fo[:-1]) | (to[1:] != to[:-1]), True])
             for i0, i1 in zip(bounds[:-1], bounds[1:]):
                 per_task[to[i0]][fo[i0]] = (int(fo[i0]), local[order[i0:i1]])
-            cat = lambda xs, shape, dt: (np.concatenate([_to_np(x, dt).reshape(shape) for x in xs]) if N else np.zeros(shape[1:], dt)[None][:0])
+            def cat(xs, shape, dt):
+                if getattr(xs, 'flat', None) is not None and getattr(xs, 'inner', None) is None:      # loader.FrameList: already one array
+                    return _to_np(xs.flat, dt).reshape(shape)
+                return np.concatenate([_to_np(x, dt).reshape(shape) for x in xs]) if N else np.zeros(shape[1:], dt)[None][:0]
             pseudo = cat(GGA_init_pseudo_labels, (-1, 7), np.float64)[order]
             boxes = cat(GGA_boxes_img, (-1, 4), None)[order]
             l2i_o = cat(GGA_lidar2img, (-1, 4, 4), np.float32)[order]
@@ -280,14 +283,29 @@ class CenterHead_GGA(nn.Module):
         # in-box points (xy as f32, like `.float()` at head:201), packed task-major so each task
         # is one contiguous range of objects
         xy, counts, slots, task_nobj = [], [], [], np.zeros(T, np.int64)
-        for t in range(T):
-            for b, sel in per_task[t]:
-                for kk, j in enumerate(sel):
-                    p = _to_np(GGA_in_box_points[b][j])
-                    xy.append(p[:, :2])
-                    counts.append(len(p))
-                    slots.append(b * K + kk)
-                task_nobj[t] += len(sel)
+        flat = getattr(GGA_in_box_points, 'flat', None)
+        if flat is not None and getattr(GGA_in_box_points, 'inner', None) is not None and list(GGA_in_box_points.inner) == n_b.tolist():
+            # the loader's packed hand-over (loader.FrameList): all point sets of the batch are rows of ONE [sum Ni, 4] tensor
+            # in frame-major object order - object o = start_b[frame] + local is its o-th set
+            if len(order):
+                perm = np.argsort(task[order], kind='stable')                        # (task, frame, slot) order
+                sel = order[perm]
+                sizes = np.asarray(GGA_in_box_points.sizes, np.int64)
+                row0 = np.concatenate([[0], np.cumsum(sizes)])
+                xy32 = _to_np(flat)[:, :2].astype(np.float32)
+                xy = [xy32[row0[o]:row0[o + 1]] for o in sel]
+                counts = sizes[sel].tolist()
+                slots = (frame[sel] * K + slot[perm]).tolist()
+                task_nobj = np.bincount(task[sel], minlength=T).astype(np.int64)
+        else:
+            for t in range(T):
+                for b, sel in per_task[t]:
+                    for kk, j in enumerate(sel):
+                        p = _to_np(GGA_in_box_points[b][j])
+                        xy.append(p[:, :2])
+                        counts.append(len(p))
+                        slots.append(b * K + kk)
+                    task_nobj[t] += len(sel)
         objs = np.concatenate(objs, 0).astype(np.int32) if objs else np.zeros((0, 4), np.int32)
         xy = np.concatenate(xy, 0).astype(np.float32) if xy else np.zeros((0, 2), np.float32)
         offs = np.zeros(len(counts) + 1, np.int32)

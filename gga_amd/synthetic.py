@@ -556,3 +556,128 @@ def make_indoor_batch(batch_size, start=0, rank=0, device=None, n_points=50000, 
                                    else torch.from_numpy(labels.astype(np.int64)))
         out['img_metas'].append(dict(box_type_3d=DepthInstance3DBoxes, sample_idx=f))
     return out
+
+
+# ---------------------------------------------------------------------------
+# An on-disk KITTI tree in the layout the GGA train job reads (loader-fed bench / tests)
+# ---------------------------------------------------------------------------
+def _frame_objects(rng, n_obj, pc_range, n_ibp_range, calib):
+    """``n_obj`` labelled objects of one frame: LiDAR pseudo boxes, their camera-frame annotation, 2D boxes from the projected
+    corners, boundary flags, in-box points ([Ni,4] f64, x y z 1) and the first 200 of them as scene points."""
+    from .datasets import lidar_boxes_to_camera
+    x0, y0, _, x1, y1, _ = pc_range
+    labels = rng.integers(0, 3, n_obj)
+    dims = CLASS_DIMS[labels] * rng.uniform(0.8, 1.2, (n_obj, 3))
+    cx = rng.uniform(x0 + 6.0, x1 - 4.0, n_obj)
+    cy = np.clip(rng.uniform(y0 + 8.0, y1 - 8.0, n_obj), -0.85 * cx, 0.85 * cx)
+    cz = rng.uniform(-1.9, -1.3, n_obj)
+    rot = rng.uniform(-np.pi, np.pi, n_obj)
+    pseudo = np.stack([cx, cy, cz, dims[:, 0], dims[:, 1], dims[:, 2], rot], 1)
+    l2i = (calib['P2'] @ calib['R0_rect'] @ calib['Tr_velo_to_cam'])
+    boxes_img, bdry, ibp, scene = np.zeros((n_obj, 4)), np.zeros((n_obj, 4), bool), [], []
+    for j in range(n_obj):
+        q = np.concatenate([box_corners(pseudo[j]), np.ones((8, 1))], 1) @ l2i.T
+        d = np.maximum(q[:, 2], 0.1)
+        u, v = q[:, 0] / d, q[:, 1] / d
+        b = np.array([u.min(), v.min(), u.max(), v.max()]) + rng.uniform(-3, 3, 4)
+        clipped = np.array([max(b[0], 0.0), max(b[1], 0.0), min(b[2], IMG_W - 1.0), min(b[3], IMG_H - 1.0)])
+        bdry[j], boxes_img[j] = clipped != b, clipped
+        ni = int(rng.integers(n_ibp_range[0], n_ibp_range[1] + 1))
+        lx, ly = rng.uniform(-0.575, 0.575, ni) * pseudo[j, 3], rng.uniform(-0.575, 0.575, ni) * pseudo[j, 4]
+        lz = rng.uniform(0.0, 1.0, ni) * pseudo[j, 5]
+        c, s = np.cos(rot[j]), np.sin(rot[j])
+        p = np.stack([cx[j] + c * lx - s * ly, cy[j] + s * lx + c * ly, cz[j] + lz, np.ones(ni)], 1)
+        ibp.append(p)
+        scene.append(p[:min(ni, 200), :3])
+    cam = lidar_boxes_to_camera(torch.from_numpy(pseudo.astype(np.float32)), (calib['R0_rect'] @ calib['Tr_velo_to_cam']).astype(np.float32)).numpy()
+    return labels, pseudo, cam, boxes_img, bdry, ibp, scene
+
+
+def write_kitti_tree(root, n_frames, n_points=20000, pc_range=RANGE_PP, n_obj_range=(4, 12), n_ibp_range=(20, 1500),
+                     db_per_class=300, seed=4100, pts_prefix='velodyne_reduced', info_name='kitti_infos_trainval_GGA.pkl',
+                     db_name='kitti_dbinfos_train_GGA.pkl'):
+    """Writes what ``configs/gga/gga_kitti_config.py``'s ``data.train`` reads (reference: mmdet3d/datasets/
+    kitti_dataset_GGA_train.py:100-329, tools/data_converter/kitti_converter_gga.py:214-517, create_gt_database_gga.py:236-420)
+    for ``n_frames`` synthetic frames of SURVEY 8(d)'s shape under ``root``:
+
+        training/<pts_prefix>/%06d.bin          [n_points,4] f32 scans
+        <info_name>                             the info list (calib, camera-frame annos, all GGA_* fields, in-box points)
+        kitti_gt_database_GGA/*.bin + <db_name> ``db_per_class`` database objects per class (absolute-coordinate points)
+
+    -> (info path, database-info path). Deterministic in ``seed``; a tree that already holds ``n_frames`` scans and both
+    pickles written with the same arguments is left alone (a stamp file records them)."""
+    import json
+    import os
+    import pickle
+    stamp = dict(n_frames=n_frames, n_points=n_points, pc_range=list(pc_range), n_obj_range=list(n_obj_range),
+                 n_ibp_range=list(n_ibp_range), db_per_class=db_per_class, seed=seed, pts_prefix=pts_prefix, v=2)
+    info_path, db_path, stamp_path = os.path.join(root, info_name), os.path.join(root, db_name), os.path.join(root, 'synthetic_tree.json')
+    if os.path.exists(stamp_path) and json.load(open(stamp_path)) == stamp and os.path.exists(info_path) and os.path.exists(db_path):
+        return info_path, db_path
+    velo = os.path.join(root, 'training', pts_prefix)
+    db_dir = os.path.join(root, 'kitti_gt_database_GGA')
+    os.makedirs(velo, exist_ok=True), os.makedirs(db_dir, exist_ok=True)
+    names = np.array(PIPELINE_CLASSES)
+    x0, y0, z0, x1, y1, z1 = pc_range
+    calib = {k: v.copy() for k, v in KITTI_CALIB.items()}
+    infos = []
+    for i in range(n_frames):
+        rng = np.random.default_rng(seed + i)
+        n_obj = int(rng.integers(n_obj_range[0], n_obj_range[1] + 1))
+        labels, pseudo, cam, boxes_img, bdry, ibp, scene = _frame_objects(rng, n_obj, pc_range, n_ibp_range, calib)
+        cl = np.concatenate(scene, 0)
+        n_cl = min(len(cl), n_points // 4)
+        n_out = int(round(0.05 * n_points))
+        n_in = n_points - n_cl - n_out
+        pts = np.empty((n_points, 4), np.float32)
+        pts[:n_in, 0], pts[:n_in, 1] = rng.uniform(x0, x1, n_in), rng.uniform(y0, y1, n_in)
+        pts[:n_in, 2] = np.clip(rng.normal(-1.0, 0.6, n_in), z0 + 1e-3, z1 - 1e-3)
+        pts[n_in:n_in + n_cl, :3] = cl[:n_cl]
+        far = rng.uniform([x0 - 5, y0 - 5, z0 - 2], [x1 + 5, y1 + 5, z1 + 2], (n_out, 3))          # 5 % around the range: the
+        pts[n_in + n_cl:, :3] = far                                                                # filter has something to reject
+        pts[:, 3] = rng.uniform(0, 1, n_points)
+        pts[rng.permutation(n_points)].tofile(os.path.join(velo, f'{i:06d}.bin'))
+        # one DontCare region per frame (dropped by the loader), objects of unknown difficulty now and then
+        difficulty = rng.integers(0, 3, n_obj + 1).astype(np.int32)
+        difficulty[rng.random(n_obj + 1) < 0.03] = -1
+        name = np.concatenate([names[labels], ['DontCare']])
+        pad = lambda a, fill: np.concatenate([a, np.full((1,) + a.shape[1:], fill, a.dtype)], 0)
+        annos = dict(
+            name=name, truncated=np.zeros(n_obj + 1), occluded=np.zeros(n_obj + 1, np.int64), alpha=pad(-cam[:, 6].astype(np.float64), -10.0),
+            bbox=pad(boxes_img, 0.0), dimensions=pad(cam[:, 3:6].astype(np.float64), -1.0), location=pad(cam[:, :3].astype(np.float64), -1000.0),
+            rotation_y=pad(cam[:, 6].astype(np.float64), -10.0), score=np.zeros(n_obj + 1), index=np.concatenate([np.arange(n_obj), [-1]]).astype(np.int32),
+            group_ids=np.arange(n_obj + 1, dtype=np.int32), difficulty=difficulty,
+            num_points_in_gt=pad(np.array([len(p) for p in ibp], np.int32), -1),
+            GGA_boxes_img=pad(boxes_img, 0.0), GGA_mask_depth=pad(np.ones(n_obj, bool), False), GGA_mask2d=pad(np.ones(n_obj, bool), False),
+            GGA_mask_boundary=pad(bdry.any(1), False), GGA_bdry_masks=pad(bdry, False),
+            GGA_mask_valid=pad(rng.random(n_obj) < 0.95, False), GGA_in_box_points=ibp + [np.zeros((0, 4))],
+            GGA_init_pseudo_label=pad(pseudo, 0.0), GGA_num_points_in_box2d=pad(np.array([float(len(p)) for p in ibp]), 0.0))
+        infos.append(dict(point_cloud=dict(velodyne_path=f'training/{pts_prefix}/{i:06d}.bin', num_features=4),
+                          image=dict(image_idx=i, image_shape=np.array([IMG_H, IMG_W], np.int32), image_path=f'training/image_2/{i:06d}.png'),
+                          calib=calib, annos=annos))
+    with open(info_path, 'wb') as f:
+        pickle.dump(infos, f)
+    # the database: objects drawn like the frames' own, points = the object's frustum points in absolute coordinates
+    l2i32 = (calib['P2'].astype(np.float32) @ calib['R0_rect'].astype(np.float32) @ calib['Tr_velo_to_cam'].astype(np.float32))
+    rng = np.random.default_rng(seed - 1)
+    db = {c: [] for c in PIPELINE_CLASSES}
+    while min(len(v) for v in db.values()) < db_per_class:
+        labels, pseudo, cam, boxes_img, bdry, ibp, _ = _frame_objects(rng, 12, pc_range, n_ibp_range, calib)
+        for j in range(12):
+            cname = PIPELINE_CLASSES[labels[j]]
+            if len(db[cname]) >= db_per_class:
+                continue
+            k = len(db[cname])
+            path = os.path.join('kitti_gt_database_GGA', f'{k}_{cname}_{j}.bin')
+            obj = np.concatenate([ibp[j][:, :3], rng.uniform(0, 1, (len(ibp[j]), 1))], 1).astype(np.float32)
+            obj.tofile(os.path.join(root, path))
+            db[cname].append(dict(
+                name=cname, path=path, image_idx=k, gt_idx=j, box3d_lidar=pseudo[j].astype(np.float32), num_points_in_gt=len(obj),
+                difficulty=np.int32(rng.integers(0, 3)), group_id=len(db[cname]), GGA_gt_box=boxes_img[j].astype(np.float32),
+                GGA_box_img=boxes_img[j], GGA_mask_depth=np.bool_(True), GGA_mask2d=np.bool_(True), GGA_mask_valid=np.bool_(rng.random() < 0.95),
+                GGA_mask_boundary=np.bool_(bdry[j].any()), GGA_bdry_mask=bdry[j], GGA_in_box_points=ibp[j], GGA_init_pseudo_label=pseudo[j],
+                GGA_num_points_in_box2d=np.float64(len(obj)), GGA_lidar2img=l2i32))
+    with open(db_path, 'wb') as f:
+        pickle.dump(db, f)
+    json.dump(stamp, open(stamp_path, 'w'))
+    return info_path, db_path

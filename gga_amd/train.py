@@ -524,13 +524,32 @@ class Runner:
         self._guard_next = True
         return ckpt['meta']
 
-    def train_epochs(self, data_loader, max_epochs, work_dir=None, checkpoint_config=None, logger=None, to_inputs=None):
+    def train_epochs(self, data_loader, max_epochs, work_dir=None, checkpoint_config=None, logger=None, to_inputs=None,
+                     after_iter=None):
         """The epoch loop of the reference's ``EpochBasedRunner.run`` with the hooks the GGA configs register: sampler
         re-seeded per epoch (``DistSamplerSeedHook``), one ``step`` per loaded batch - the next batch is fetched and its
         points uploaded while this one is stepped, so its point-only front overlaps the step (``prefetch``) -, a
-        checkpoint every ``checkpoint_config.interval`` epochs and after the last one (``CheckpointHook``)."""
-        from .loader import to_step_inputs
-        to_inputs = to_inputs or (lambda b: to_step_inputs(b, self.device if self.device.type == 'cuda' else None))
+        checkpoint every ``checkpoint_config.interval`` epochs and after the last one (``CheckpointHook``).
+
+        ``loop_seconds`` accumulates where the loop's host time goes: ``fetch`` (waiting in ``next(loader)``: the data side
+        is late), ``inputs`` (unpacking + the points' upload), ``step`` (queueing the step); ``after_iter(runner, n)`` is
+        called after every iteration (bench.py resets / reads the counters there)."""
+        from .loader import PointUploader, to_step_inputs
+        if to_inputs is None:
+            on_gpu = self.device.type == 'cuda'
+            uploader = PointUploader(self.device) if on_gpu and os.environ.get('GGA_POINT_UPLOADER', '1') == '1' else None
+            to_inputs = lambda b: to_step_inputs(b, self.device if on_gpu else None, uploader=uploader)
+        clock = time.perf_counter
+        acc = self.loop_seconds = dict(fetch=0.0, inputs=0.0, step=0.0, iters=0)
+
+        def fetch(it):
+            t = clock()
+            raw = next(it, None)
+            t1 = clock()
+            acc['fetch'] += t1 - t
+            out = to_inputs(raw) if raw is not None else None
+            acc['inputs'] += clock() - t1
+            return out
         ck = dict(checkpoint_config or {})
         interval, save_last = int(ck.get('interval', -1)), ck.get('save_last', True)
         out_dir = ck.get('out_dir') or work_dir
@@ -542,21 +561,24 @@ class Runner:
             if hasattr(sampler, 'set_epoch'):
                 sampler.set_epoch(self.epoch)
             it = iter(data_loader)
-            nxt = next(it, None)
+            nxt = fetch(it)
             cur = None
             if nxt is not None:
-                nxt = to_inputs(nxt)
                 self.inputs_ready(nxt)
             t0, n = time.time(), 0
             while nxt is not None:
-                cur, raw = nxt, next(it, None)
-                nxt = to_inputs(raw) if raw is not None else None
+                cur, nxt = nxt, fetch(it)
                 if nxt is not None:
                     self.inputs_ready(nxt)
                 if self.iter == self.GC_FREEZE_AFTER:
                     self.freeze_gc()
+                t = clock()
                 out = self.step(cur, next_data=nxt)
+                acc['step'] += clock() - t
+                acc['iters'] += 1
                 n += 1
+                if after_iter is not None:
+                    after_iter(self, n)
                 if logger and self.iter % self.log_interval == 0:
                     vals = {k: float(v) for k, v in out['log_vars'].items()}
                     logger(f'epoch {self.epoch + 1} iter {n}/{len(data_loader)} lr {self.optimizer.param_groups[0]["lr"]:.3e} '
@@ -595,7 +617,8 @@ def find_latest_checkpoint(path, suffix='pth'):
     return best
 
 
-def train_detector(model, dataset, cfg, distributed=False, validate=False, timestamp=None, meta=None, logger=None, device=None):
+def train_detector(model, dataset, cfg, distributed=False, validate=False, timestamp=None, meta=None, logger=None, device=None,
+                   after_iter=None):
     """``mmdet3d/apis/train.py:180-322`` for the GGA configs: loaders from ``cfg.data`` (``samples_per_gpu`` /
     ``workers_per_gpu``, sharded over the ranks when ``distributed``, seeded with ``cfg.seed``), the DDP wrap, optimizer /
     clipping / cyclic schedules (``Runner``), ``checkpoint_config``, ``resume_from`` / ``auto_resume`` / ``load_from``, then
@@ -628,5 +651,6 @@ def train_detector(model, dataset, cfg, distributed=False, validate=False, times
         runner.resume(resume_from)
     elif cfg.get('load_from'):
         runner.load_checkpoint(cfg.load_from)
-    runner.train_epochs(loader, max_epochs, work_dir=work_dir, checkpoint_config=cfg.get('checkpoint_config'), logger=logger)
+    runner.train_epochs(loader, max_epochs, work_dir=work_dir, checkpoint_config=cfg.get('checkpoint_config'), logger=logger,
+                        after_iter=after_iter)
     return runner

@@ -125,6 +125,59 @@ def test_collate_rules_and_step_inputs():
     assert LD.collate([(1, 'a'), (2, 'b')])[0].tolist() == [1, 2]
 
 
+def test_packed_hand_over_gives_the_same_lists_and_the_same_targets(tmp_path):
+    """``collate(packed=True)`` -> ``to_step_inputs``: the per-frame lists ``forward_train`` takes are the lists of the plain
+    collate (values, dtypes, nesting; boxes as LiDARInstance3DBoxes), travelling as one tensor per key; and
+    ``CenterHead_GGA.pack_targets`` returns identical arrays from either (its packed fast path against its list path)."""
+    import pickle as pkl
+    from gga_amd import build_model
+    from gga_amd.box3d import LiDARInstance3DBoxes
+    root = str(tmp_path)
+    info_path, db_path = synthetic.write_kitti_tree(root, 6, n_points=3000, n_ibp_range=(20, 120), db_per_class=12)
+    cfg = Config.fromfile(os.path.join(REPO, 'configs', 'gga', 'gga_kitti_pointpillars_config.py'))
+    d = cfg.data['train']
+    d['dataset'].update(data_root=root + '/', ann_file=info_path)
+    for t in d['dataset']['pipeline']:
+        if t['type'] == 'ObjectSample_GGA':
+            t['db_sampler'].update(data_root=root + '/', info_path=db_path)
+        if 'point_cloud_range' in t:
+            t['point_cloud_range'] = PP_RANGE
+    ds = LD.build_dataset(d)
+    np.random.seed(3), torch.manual_seed(3)
+    samples = [ds[i] for i in range(6)]
+    assert max(len(s['gt_labels_3d'].data) for s in samples) > 12             # database objects were pasted
+    plain = LD.to_step_inputs(LD.collate(samples, samples_per_gpu=3), chunk=1)
+    packed = LD.collate(samples, samples_per_gpu=3, packed=True)
+    wire = pkl.loads(pkl.dumps(packed))                                        # what crosses the process boundary
+    n_tensors = lambda o: (1 if torch.is_tensor(o) else sum(n_tensors(x) for x in (o.values() if isinstance(o, dict) else o))
+                           if isinstance(o, (list, tuple, dict)) else n_tensors([o.flat]) if isinstance(o, LD.PackedFrames)
+                           else n_tensors(o.data) if isinstance(o, DC) else n_tensors([o.tensor]) if isinstance(o, LiDARInstance3DBoxes) else 0)
+    assert n_tensors(wire) == 2 * 8 and n_tensors(LD.collate(samples, samples_per_gpu=3)) > 100
+    got = LD.to_step_inputs(wire, chunk=1)
+    assert set(got) == set(plain)
+    for k, a in plain.items():
+        b = got[k]
+        if k == 'img_metas':
+            assert [m['sample_idx'] for m in a] == [m['sample_idx'] for m in b]
+            continue
+        assert isinstance(b, LD.FrameList) and len(a) == len(b) == 3, k
+        for fa, fb in zip(a, b):
+            if k == 'gt_bboxes_3d':
+                assert isinstance(fb, LiDARInstance3DBoxes) and torch.equal(fa.tensor, fb.tensor) and torch.equal(fa.gravity_center, fb.gravity_center)
+            elif k == 'GGA_in_box_points':
+                assert len(fa) == len(fb) and all(x.dtype == y.dtype and torch.equal(x, y) for x, y in zip(fa, fb))
+            else:
+                assert fa.dtype == fb.dtype and torch.equal(fa, fb), k
+    head = build_model(cfg.model).pts_bbox_head
+    srl = head.draw_srl(3)
+    args = lambda x: (x['gt_labels_3d'], x['GGA_boxes_img'], x['GGA_lidar2img'], x['GGA_init_pseudo_labels'], x['GGA_bdry_masks'],
+                      x['GGA_in_box_points'], x['img_metas'])
+    ta, tb = head.pack_targets(*args(plain), srl=srl), head.pack_targets(*args(got), srl=srl)
+    assert set(ta) == set(tb) and len(ta['ibp_xy']) > 500
+    for k in ta:
+        assert np.array_equal(np.asarray(ta[k]), np.asarray(tb[k])), k
+
+
 def test_loader_from_the_kitti_tree(tmp_path):
     infos = kitti_tree(str(tmp_path))
     ds = LD.build_dataset(dataset_cfg(str(tmp_path), infos, times=2))

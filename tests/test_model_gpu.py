@@ -35,15 +35,19 @@ def _damp_heads(model):
 _REF_CASES = {}
 
 
-def _reference_case(name):
+PP_SEEDS, SECOND_SEEDS = (1, 2, 3), (3, 4, 5)      # weights (torch.manual_seed) AND frames (start = 50 * seed) differ per seed
+
+
+def _reference_case(name, seed):
     """(model with CPU parameters, batch, srl, fp32 restatement after its step, float64 restatement after its step, losses
     of the fp32 restatement) of one whole-step parity case; the CPU side (oracle/torch_ref.reference_train_step in float32
-    and float64, nothing of libgga_hip) is evaluated once and shared by the parametrisations of the GPU side."""
-    if name in _REF_CASES:
-        return _REF_CASES[name]
+    and float64, nothing of libgga_hip) is evaluated once per (case, seed) and shared by the parametrisations of the GPU side."""
+    if (name, seed) in _REF_CASES:
+        return _REF_CASES[(name, seed)]
+    first = 50 if seed == (1 if name == 'pp' else 3) else 50 * seed + 7        # (the first seed keeps the frames of rounds 1-4)
     if name == 'pp':
         cfg = Config.fromfile(PP_CFG)
-        B, seed, kw = 2, 1, dict(start=50, n_points=5000, pc_range=synthetic.RANGE_PP, n_obj_range=(4, 8), n_ibp_range=(10, 200))
+        B, kw = 2, dict(start=first, n_points=5000, pc_range=synthetic.RANGE_PP, n_obj_range=(4, 8), n_ibp_range=(10, 200))
     else:
         # BASELINE config 1: the reference's shipped model section (real grid 41 x 1600 x 1408), 4 synthetic KITTI frames of
         # 20 k points, objects per frame U{4..20} as SURVEY 8(d) specifies the synthetic frame. (Rounds 1-3 ran 2 frames with
@@ -51,7 +55,7 @@ def _reference_case(name):
         # 5e-5 .. 4.7e-4 from float64 depending on the seed - profiles/r04_precision_cases.json; on the specified case every
         # fp32 path is inside 4e-5 on every seed tried.)
         cfg = Config.fromfile(SECOND_CFG)
-        B, seed, kw = 4, 3, dict(start=50, n_points=20000, pc_range=synthetic.RANGE_SECOND, n_obj_range=(4, 20), n_ibp_range=(10, 200))
+        B, kw = 4, dict(start=first, n_points=20000, pc_range=synthetic.RANGE_SECOND, n_obj_range=(4, 20), n_ibp_range=(10, 200))
     torch.manual_seed(seed)
     model = build_model(cfg.model)
     model.train()
@@ -67,14 +71,15 @@ def _reference_case(name):
         ref64_losses, _ = R.reference_train_step(ref64, batch, srl=srl)
     finally:
         torch.set_num_threads(threads)
-    _REF_CASES[name] = (cfg, model, batch, srl, ref, ref64, {k: float(v) for k, v in ref_losses.items()},
-                        {k: float(v) for k, v in ref64_losses.items()})
-    return _REF_CASES[name]
+    _REF_CASES[(name, seed)] = (cfg, model, batch, srl, ref, ref64, {k: float(v) for k, v in ref_losses.items()},
+                                {k: float(v) for k, v in ref64_losses.items()})
+    return _REF_CASES[(name, seed)]
 
 
-def _gpu_step_against(case, channels_last, planes, monkeypatch):
+def _gpu_step_against(case, channels_last, planes, monkeypatch, seed=None):
     from gga_amd import dense_conv
-    cfg, cpu_model, batch, srl, ref, ref64, ref_losses, ref64_losses = _reference_case(case)
+    seed = (1 if case == 'pp' else 3) if seed is None else seed
+    cfg, cpu_model, batch, srl, ref, ref64, ref_losses, ref64_losses = _reference_case(case, seed)
     monkeypatch.setattr(dense_conv, 'PLANES', planes)
     model = copy.deepcopy(cpu_model)
     if channels_last:
@@ -97,7 +102,7 @@ def _gpu_step_against(case, channels_last, planes, monkeypatch):
     floor = max(rel(ref_losses[k], ref64_losses[k]) for k in ref_losses)
     worst = max(ref_losses, key=lambda k: rel(float(losses[k]), ref64_losses[k]))
     worst32 = max(ref_losses, key=lambda k: rel(float(losses[k]), ref_losses[k]))
-    print(f'LOSSES {case} planes {planes}: worst deviation from float64 {rel(float(losses[worst]), ref64_losses[worst]):.2e} ({worst}), '
+    print(f'LOSSES {case} seed {seed} planes {planes}: worst deviation from float64 {rel(float(losses[worst]), ref64_losses[worst]):.2e} ({worst}), '
           f'from the fp32 CPU restatement {rel(float(losses[worst32]), ref_losses[worst32]):.2e} ({worst32}); '
           f'fp32 CPU restatement from float64 {floor:.2e}; bound 1e-4')
     for k, v in ref64_losses.items():
@@ -122,7 +127,7 @@ def _gpu_step_against(case, channels_last, planes, monkeypatch):
     else:
         bad = R.gradient_offenders(grads, ref, ref64, tol=1.5e-3, slack=3.0)
         strict = R.gradient_offenders(grads, ref, ref64, tol=GRAD_TOL, slack=2.0)
-        print(f'GRADS {case} planes {planes}: over 1e-3 / twice the floor: {[(n, round(e, 5), round(f, 6)) for n, e, f in strict]}')
+        print(f'GRADS {case} seed {seed} planes {planes}: over 1e-3 / twice the floor: {[(n, round(e, 5), round(f, 6)) for n, e, f in strict]}')
         if planes == 2:
             # the arithmetic train.Runner ships: the same criterion as the PointPillars case, no exceptions (round 3 let six
             # through - head-branch convolutions whose gradient blocks shared ONE scale with the heat-map branches' in the
@@ -136,20 +141,26 @@ def _gpu_step_against(case, channels_last, planes, monkeypatch):
 
 
 @pytest.mark.parametrize('planes', [2, 3])
-@pytest.mark.parametrize('channels_last', [False, True])
-def test_pp_train_step_matches_cpu_reference(channels_last, planes, monkeypatch):
-    _gpu_step_against('pp', channels_last, planes, monkeypatch)
+@pytest.mark.parametrize('channels_last,seed', [(False, PP_SEEDS[0])] + [(True, s) for s in PP_SEEDS])
+def test_pp_train_step_matches_cpu_reference(channels_last, seed, planes, monkeypatch):
+    """BASELINE config 2's model on two 5 000-point frames, three seeds (weights and frames), both arithmetic forms, plain
+    1e-4 on the 18 losses against float64 and fp32; the fp32 CPU floor is printed beside each (-s)."""
+    _gpu_step_against('pp', channels_last, planes, monkeypatch, seed)
 
 
 @pytest.mark.parametrize('planes', [2, 3])
-def test_second_train_step_matches_restatement(planes, monkeypatch):
+@pytest.mark.parametrize('seed', SECOND_SEEDS)
+def test_second_train_step_matches_restatement(seed, planes, monkeypatch):
     """BASELINE config 1 - the reference's shipped config (configs/gga/gga_kitti_config.py: HardSimpleVFE + SparseEncoder +
     SECOND + SECONDFPN + CenterHead_GGA; detectors/centerpoint_gga.py:43-86, middle_encoders/sparse_encoder.py:107-138) end to
     end, sparse trunk in the loop, at its real grid with 4 x 20 000 points: all 18 losses within 1e-4 of the float64 step AND
     of the fp32 step of oracle/torch_ref.reference_train_step (pair-list restatement of the 21 sparse convolutions, plain
     torch for the rest); every parameter's gradient within 1.5e-3 of the float64 step or inside three times the fp32
-    restatement's own distance from it (at most six beyond 1e-3 / twice). Both arithmetic forms."""
-    _gpu_step_against('second', True, planes, monkeypatch)
+    restatement's own distance from it (at most six beyond 1e-3 / twice). Both arithmetic forms, three seeds (weights and
+    frames): the tolerance claim of the shipped arithmetic does not rest on one draw (VERDICT r04 weak #1)."""
+    _gpu_step_against('second', True, planes, monkeypatch, seed)
+    if planes == 3:
+        _REF_CASES.pop(('second', seed), None)           # (parametrisation order: seed outer, planes inner - free the CPU models)
 
 
 def test_operand_ranges_of_real_steps_and_the_two_plane_forms(monkeypatch):
@@ -488,7 +499,7 @@ def test_bench_gpus2_plain_command_starts_its_own_ranks():
     the PointPillars trunk as the main line, the shipped sparse trunk as `second_trunk`."""
     res = _run_bench(['--gpus', '2', '--steps', '2', '--warmup', '1', '--batch', '2', '--second-batch', '2', '--pgd-batch', '1',
                       '--fcaf3d-batch', '1', '--no-roofline', '--no-planes3'])
-    assert res['n_gpus'] == 2 and res['value'] > 0 and res['config']['global_batch'] == 4
+    assert res['n_gpus'] == 2 and 'loader_fed' not in res and res['value'] > 0 and res['config']['global_batch'] == 4
     assert res['config']['parallelism'] == 'dp2'
     n_dev = torch.cuda.device_count()
     assert res['config']['backend'].startswith('nccl' if n_dev >= 2 else 'gloo')
@@ -510,14 +521,37 @@ def test_two_rank_rccl_both_configs():
     assert res['value'] > 0 and res['second_trunk']['value'] > 0
 
 
+def test_ddp_over_rccl_one_rank_is_bit_identical():
+    """backend 'nccl' (= RCCL) with a world of one on the box's one device - DistributedDataParallel's reducer, bucket hooks and
+    RCCL-stream all-reduces around the real PointPillars and SECOND detectors, head branches on two streams, prefetch stream and
+    a noise stream on: five optimizer steps leave the same bits as the plain Runner (tests/_ddp_nccl_worker.py; the reference's
+    wrap: mmdet3d/apis/train.py:222-231, utils/util_distribution.py:38-65). gloo's host-side all-reduce cannot show a missing
+    stream dependency; this can."""
+    import subprocess
+    import sys
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_PORT=str(port), GGA_HEAD_STREAMS='2')
+    out = subprocess.run([sys.executable, os.path.join(REPO, 'tests', '_ddp_nccl_worker.py')], env=env, capture_output=True, text=True,
+                         timeout=900)
+    lines = [l for l in out.stdout.splitlines() if l.startswith('NCCL1')]
+    print('\n'.join(lines))
+    assert out.returncode == 0 and len(lines) == 2 and all(l.endswith('ok True') for l in lines), (out.stdout[-2000:], out.stderr[-3000:])
+
+
 def test_bench_line_contract_single_gpu():
     """The default single-GPU line carries every field the driver and the judge read."""
     res = _run_bench(['--steps', '2', '--warmup', '1', '--batch', '2', '--second-batch', '2', '--pgd-batch', '1', '--fcaf3d-batch', '1',
-                      '--no-cpu-baseline'])
+                      '--no-cpu-baseline', '--loader-frames', '100', '--loader-workers', '2'])
     for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
               'vs_baseline', 'dtype', 'arith', 'data', 'config', 'roofline', 'mfma_roofline', 'second_trunk', 'pgd_trunk',
-              'planes3', 'range_guard', 'fcaf3d_trunk'):
+              'planes3', 'range_guard', 'fcaf3d_trunk', 'loader_fed'):
         assert k in res, k
+    lf = res['loader_fed']
+    assert lf['workers_2']['timed_steps'] == 42 and lf['workers_2']['value'] > 0 and 0 <= lf['workers_2']['data_wait_fraction'] <= 1
+    assert {'ObjectSample_GGA', 'PointShuffle', 'total'} <= set(lf['pipeline_ms_per_frame']) and lf['objects_per_frame_after_sampling'] > 8
     assert res['roofline']['bound'] == 'hbm' and res['roofline']['launches_timed'] == 2
     assert res['mfma_roofline']['launches_timed'] == 2 * res['mfma_roofline']['launches_per_step']
     assert 0 < res['mfma_roofline']['share_of_step'] < 1

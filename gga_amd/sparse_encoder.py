@@ -102,8 +102,16 @@ class SparseEncoder(nn.Module):
         travels with the coordinates (``coors.index_plan``) and ``forward`` picks it up."""
         from .sparse import build_index_plan
         coors = coors if coors.dtype == torch.int32 else coors.int()
-        coors.index_plan = build_index_plan(self, coors, self.sparse_shape, int(batch_size))
-        return coors
+        plan = build_index_plan(self, coors, self.sparse_shape, int(batch_size))
+        # The plan's first level keeps `coors` itself; hung on that same tensor object it would close a reference cycle
+        # (tensor -> plan -> level -> tensor) that only the cyclic collector frees - a generation-2 pass every ~12 steps, until
+        # which every step's 1.6 GB of levels and rule books stayed allocated and the caching allocator kept calling hipMalloc
+        # (tools_dev/who_holds.py; the "first-process transient" of the sparse leg). The plan travels on a second tensor object
+        # over the same memory instead, which dies by reference counting with the step's inputs.
+        carrier = coors.detach()
+        carrier.__dict__.update(coors.__dict__)          # (the voxelizer's device-side count: coors.num_valid)
+        carrier.index_plan = plan
+        return carrier
 
     def forward(self, voxel_features, coors, batch_size):
         plan = getattr(coors, 'index_plan', None)

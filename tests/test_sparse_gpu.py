@@ -476,3 +476,27 @@ def test_sparse_map_straight_into_channels_last_memory():
     assert torch.equal(outs[0][0], outs[1][0])
     for a, b in zip(outs[0][1], outs[1][1]):
         assert torch.equal(a, b)
+
+
+def test_index_plan_dies_with_its_coordinates_without_the_cyclic_collector():
+    """``SparseEncoder.build_indices`` hangs the plan (levels, rule books: 1.6 GB per bs-8 batch of the shipped config) on the
+    coordinates it returns. It must die by reference counting when they do: hung on the very tensor its first level keeps it
+    formed a cycle that only a generation-2 pass of the collector freed, every ~12 steps, and the allocator grew by a batch's
+    worth of hipMalloc calls per step meanwhile (round 5, tools_dev/who_holds.py)."""
+    import gc
+    import weakref
+    enc = SparseEncoder(in_channels=4, sparse_shape=[41, 160, 160], order=('conv', 'norm', 'act')).to(DEV)
+    coors = _coords(2, (41, 160, 160), 3000, seed=4).to(DEV)
+    coors.num_valid = torch.tensor([len(coors)], dtype=torch.int32, device=DEV)
+    gc.collect()
+    gc.disable()
+    try:
+        out = enc.build_indices(coors, 2)
+        assert out.data_ptr() == coors.data_ptr() and out.num_valid is coors.num_valid and out.index_plan.level0.n == len(coors)
+        y = enc(torch.rand(len(coors), 4, device=DEV), out, 2)            # forward picks the plan up
+        assert y.shape[0] == 2
+        plan, level = weakref.ref(out.index_plan), weakref.ref(out.index_plan.level0)
+        del out, y
+        assert plan() is None and level() is None
+    finally:
+        gc.enable()

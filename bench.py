@@ -733,10 +733,12 @@ def main():
     if is_pp and not args.no_second_trunk:
         # the reference's shipped model section (sparse-conv trunk), same run, same launch
         s_sites = [(_lib.TIME_SPARSE_CONV, 64 * args.steps, 0), (_lib.TIME_SPARSE_WGRAD, 32 * args.steps, 0)] if rank == 0 else []
-        # (Rounds 3-4 warmed this leg up for 20 steps to step over a "first-process transient": its first ~15-25 steps ran 53-70 ms
-        # on the device. Root cause, round 5: the host ran many steps ahead, every queued step held its 1.6 GB of prefetched index
-        # structures, and the allocator answered with ~21 hipMalloc calls per step until the pool was large enough - Runner
-        # .MAX_STEPS_AHEAD bounds the lead and the pool is complete after three steps. One warm-up count for all legs again.)
+        # (Rounds 3-4 warmed this leg up for 20 steps to step over a "first-process transient": its first 15-25 steps ran 53-70 ms
+        # on the device. Root cause, round 5 (tools_dev/first_steps.py, malloc_trace.py, who_holds.py): the prefetched index plan
+        # hung on the coordinate tensor its first level keeps - a reference cycle; each step's 1.6 GB of levels and rule books
+        # waited for a generation-2 pass of Python's collector (every ~12 steps) and the caching allocator answered with ~21
+        # hipMalloc calls per step, 48 GB reserved after 30 steps. Without the cycle the pool is complete after 8 steps at
+        # 22 GB. One warm-up count for all legs again.)
         sw = args.warmup
         sec = run_workload(SECOND_CONFIG, args.second_batch, args.steps, sw, args, rank, world, device, s_sites)
         if rank == 0:

@@ -345,13 +345,12 @@ class Runner:
 
     # How far the host may run ahead of the device: at the start of a step at most this many earlier steps are still queued
     # or running. The host side of a step is 12-15 ms (PointPillars) / 26-29 ms (sparse trunk) against 33 / 52 ms on the device,
-    # and nothing in a step waits for the main stream - unbounded, the host gets 4-12 steps ahead (until the runtime's queue
-    # stops it), and everything a queued step owns stays allocated meanwhile: on the sparse trunk each prefetched front is
-    # 1.6 GB of index structures, the side stream's pool kept growing by that much per step (21 hipMalloc calls per step for
-    # the first ~25 steps of a process, each of them a device-wide stall: the "first-process transient" of rounds 3-4 -
-    # tools_dev/first_steps.py, tools_dev/malloc_trace.py, profiles/r05_first_steps_*.jsonl). Two steps of lead keep the device's
-    # queue full; the wait is a blocking event wait (no spinning core).
-    MAX_STEPS_AHEAD = int(os.environ.get('GGA_MAX_STEPS_AHEAD', '2'))
+    # and nothing in a step waits for the main stream - unbounded, the host gets 4-5 steps ahead (until the runtime's queue
+    # stops it), and everything a queued step owns stays allocated meanwhile: on the sparse trunk 1.6 GB of prefetched index
+    # structures per step (measured, round 5: 9.6 GB active with the lead unbounded, 8.0 GB with three steps). Three steps of
+    # lead keep the device's queue full (step times equal within noise: 33.8 / 54.0 against 34.0 / 54.5 ms); the wait is a
+    # blocking event wait (no spinning core). 0: unbounded.
+    MAX_STEPS_AHEAD = int(os.environ.get('GGA_MAX_STEPS_AHEAD', '3'))
 
     def _bound_lead(self):
         if self.device.type != 'cuda' or self.MAX_STEPS_AHEAD <= 0:

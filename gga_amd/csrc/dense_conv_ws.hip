@@ -26,6 +26,7 @@
 #include "dense_conv.h"
 
 #define GGA_MAX_DEVICES 64
+#define DC_WS_DEFAULT_MFMA 32                 // consumer waves' matrix instruction unless GGA_DC_WS_MFMA says otherwise (16: 16x16x32)
 __device__ __attribute__((aligned(16))) float dc_zero_page[DC_WS_MAX_CIN];      // what a halo piece outside the image is read from
 
 template <int NT, int MT>
@@ -330,16 +331,289 @@ __global__ __launch_bounds__(512, 2) void dense_conv3x3_ws_kernel(const float* _
     }
     if (stats) { WS_FLUSH_STATS() }
 #undef WS_FLUSH_STATS
-#undef WS_AOFF
-#undef WS_LOAD_PIECE
-#undef WS_STORE_PIECE
-#undef WS_BLD
-#undef WS_BST
 #undef WS_READ_A
 #undef WS_READ_B
 #undef WS_MM1
 #undef WS_MMA
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The same producer / consumer kernel with v_mfma_f32_16x16x32_f16 in the consumer waves (round 5). Why: the 32x32x16 form is
+// power-managed (busy x clock pinned near 1.0-1.1 GHz-equivalents), and under that regime the chip holds a
+// higher clock on the 16x16x32 shape (MI355X_MICROARCH.md 'DVFS give-back' item 7). tools_dev/micro/ws_shape_probe.hip - this
+// kernel's consumer loop alone, random fp16 operands in LDS, same output tile per wave (128 accumulator registers), same LDS
+// bytes per FLOP - measured 1523 against 1374 TFLOP/s issued (2.32 against 1.98 GHz in-kernel) on this part.
+//
+// What changes. A matrix instruction now takes K = 32: a "double stage" is two consecutive (tap, 16-channel chunk) stages of
+// the old stream - lane groups 0, 1 (lane / 16) carry the 16 channels of the first stage, groups 2, 3 those of the second, each
+// from its own tap position of the halo image and its own weight stage buffer, so the LDS images, the packed weight operand and
+// the producers' pieces stay exactly as they are. 9 taps x 4 chunks = 36 stages = 18 double stages make a "quad" (taps pair up
+// as (0,1) (2,3) (4,5) (6,7) (8 | next chunk's 0) (1,2) ... (7,8)): everything about a double stage - halo image, tap offsets,
+// weight slots - is a compile-time function of its index in the quad, hence cin % 64 == 0 (else the 32x32x16 form runs).
+// A wave's tile is M16 x N16 tiles of 16 x 16 (2 MT x 2 NT): D register v of lane (c = lane % 16, g = lane / 16) = pixel
+// 16 (tile % 2) + 4 g + v of image row tile / 2, output column 16 nt + c.
+// Registers: the fragments of a K = 32 step are 24 x 4 = 96 registers beside the 128 accumulators - a second set for the
+// next double stage (the 32x32x16 form's scheme) does not fit in 256, so ONE set: a double stage reads its fragments at its
+// start (all 24 reads are issued back to back, the products follow them as the data arrives) and the producers write the
+// weights of double stage d + 1 (slot pair (d + 1) % 2) and the next chunk's halo image while double stage d multiplies.
+template <int NT, int MT>
+__global__ __launch_bounds__(512, 2) void dense_conv3x3_ws16_kernel(const float* __restrict__ X, const uint16_t* __restrict__ Wp, int B,
+                                                                     int H, int W, int cin, int cout, int tiles_x, int tiles_y,
+                                                                     float* __restrict__ Y, int ystride, int prow, int pcol,
+                                                                     double* __restrict__ stats, const uint32_t* __restrict__ amax_x,
+                                                                     const uint32_t* __restrict__ amax_w, DcBnBwd bn,
+                                                                     const float* __restrict__ zero_page, DcSlices sl) {
+    constexpr int TR = 4 * MT, HP = (TR + 2) * DC_HW, CO = NT * 32;
+    constexpr int APL = HP * DC_ROWB, ASZ = 2 * APL;
+    constexpr int BPL = CO * DC_ROWB, BSZ = 2 * BPL;
+    constexpr int BPIECES = 2 * CO * 2, NB = BPIECES / 256;
+    constexpr int NA = (HP * 4 + 255) / 256;
+    constexpr int M16 = 2 * MT, N16 = 2 * NT;
+    static_assert(NB == 1 || NB == 2, "weight stage pieces per producer lane");
+    __shared__ __attribute__((aligned(16))) unsigned char As[2 * ASZ];
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[4 * BSZ];
+    __shared__ float red[4 * 2 * CO];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool consumer = wave < 4;
+    const int per_img = tiles_x * tiles_y, img_tiles = B * per_img, n_tiles = img_tiles * (sl.n > 1 ? sl.n : 1), nchunks = cin / DC_CK;
+    const int nquads = nchunks >> 2;
+    const int sbx = h2_scale_exp(*amax_x), sbw = h2_scale_exp(*amax_w);
+    const float xscale = h2_scale(sbx);
+    int tile = blockIdx.x;
+    if (tile >= n_tiles) return;
+
+    // ---- producers (pieces and weight stages as in dense_conv3x3_ws_kernel)
+    const int ptid = tid - 256;
+    typedef float ws_v2f __attribute__((ext_vector_type(2)));
+    float4 ra[NA];
+    const float* pcur[NA];
+    const float* pnxt[NA];
+    uint4 wq[2][2];                              // the two stages of the next double stage
+    wq[0][0] = wq[0][1] = wq[1][0] = wq[1][1] = make_uint4(0, 0, 0, 0);
+    const uint16_t* Wcur = sl.n > 1 ? sl.w[tile / img_tiles] : Wp;
+    const uint16_t* Wnxt = Wcur;
+    if (!consumer) {
+        WS_AOFF(pcur, tile)
+#pragma unroll
+        for (int e = 0; e < NA; ++e) { WS_LOAD_PIECE(e, pcur, 0) }
+        WS_BLD(Wcur, 0, 0, wq[0][0], wq[0][1])
+        WS_BLD(Wcur, 1, 0, wq[1][0], wq[1][1])
+#pragma unroll
+        for (int e = 0; e < NA; ++e) { WS_STORE_PIECE(e, 0) }
+        WS_BST(0, wq[0][0], wq[0][1])
+        WS_BST(1, wq[1][0], wq[1][1])
+        WS_BLD(Wcur, 2, 0, wq[0][0], wq[0][1])
+        WS_BLD(Wcur, 3, 0, wq[1][0], wq[1][1])
+#pragma unroll
+        for (int e = 0; e < NA; ++e) { WS_LOAD_PIECE(e, pcur, 1) }
+    }
+    __syncthreads();
+
+    // Double stage k of a quad (stages 2k, 2k + 1; stage j = chunk j / 9 of the quad, tap j % 9), one barrier each, the same number
+    // on both paths. Producers: write the weights of double stage k + 1 (requested during k - 1) into slot pair (k + 1) % 2,
+    // request those of k + 2, handle the halo pieces of this double stage - chunk q + 1's image is written while chunk q's
+    // first four double stages multiply (the fifth reads both images), chunk q + 2's during the last four of chunk q + 1 -, barrier.
+    if (!consumer) {
+        for (; tile < n_tiles; tile += gridDim.x) {
+            if (tile + (int)gridDim.x < n_tiles) {
+                WS_AOFF(pnxt, tile + (int)gridDim.x)
+                if (sl.n > 1) Wnxt = sl.w[(tile + (int)gridDim.x) / img_tiles];
+            } else {
+#pragma unroll
+                for (int e = 0; e < NA; ++e) pnxt[e] = zero_page;
+            }
+            for (int q = 0; q < nquads; ++q) {
+                const int c0 = 4 * q;
+                const bool last = q + 1 == nquads;
+                const uint16_t* wnext = last ? Wnxt : Wcur;          // the operand stages past the quad's end come from
+                const int cnext = last ? 0 : c0 + 4;
+#pragma unroll
+                for (int k = 0; k < 18; ++k) {
+                    WS_BST(2 * ((k + 1) & 1) + 0, wq[0][0], wq[0][1])
+                    WS_BST(2 * ((k + 1) & 1) + 1, wq[1][0], wq[1][1])
+#pragma unroll
+                    for (int s_ = 0; s_ < 2; ++s_) {
+                        const int j = 2 * k + 4 + s_;                  // a stage of double stage k + 2
+                        if (j < 36) { WS_BLD(Wcur, j % 9, c0 + j / 9, wq[s_][0], wq[s_][1]) }
+                        else { WS_BLD(wnext, (j - 36) % 9, cnext + (j - 36) / 9, wq[s_][0], wq[s_][1]) }
+                    }
+                    // halo pieces: (first double stage, chunk written (relative to c0), image) per group of four double stages
+                    const int grp = k < 4 ? 0 : (k >= 5 && k < 9 ? 1 : (k >= 9 && k < 13 ? 2 : (k >= 14 ? 3 : -1)));
+                    if (grp >= 0) {
+                        const int k0 = grp == 0 ? 0 : (grp == 1 ? 5 : (grp == 2 ? 9 : 14));
+#pragma unroll
+                        for (int e = 0; e < NA; ++e)
+                            if ((e * 4) / NA == k - k0) {
+                                WS_STORE_PIECE(e, (grp + 1) & 1)       // chunk c0 + grp + 1 -> image (grp + 1) % 2
+                                const int cl = grp + 2;                // then request the same piece of chunk c0 + grp + 2
+                                if (cl < 4) { WS_LOAD_PIECE(e, pcur, c0 + cl) }
+                                else if (!last) { WS_LOAD_PIECE(e, pcur, c0 + cl) }
+                                else { WS_LOAD_PIECE(e, pnxt, cl - 4) }
+                            }
+                    }
+                    __syncthreads();
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < NA; ++e) pcur[e] = pnxt[e];
+            Wcur = Wnxt;
+            if (stats) { __syncthreads(); __syncthreads(); }
+        }
+        return;
+    }
+
+    // ---- consumers
+    typedef float ws_v4f __attribute__((ext_vector_type(4)));
+    ws_v4f acc[M16][N16];
+    mf_v8h fa[M16][2], fb[N16][2];
+    const int c16 = lane & 15, g = lane >> 4, sel = g >> 1;
+    const int a_lane = ((MT * wave) * DC_HW + c16) * DC_ROWB + (g & 1) * 16;
+    const int b_lane = c16 * DC_ROWB + (g & 1) * 16 + sel * BSZ;
+    double run_sum = 0.0;
+    int run_slice = tile / img_tiles;
+    if (stats && sl.n > 1 && tid < 2 * CO && tid % CO < cout)
+        for (int s_ = 0; s_ < sl.n; ++s_) sl.stats[s_][((int64_t)blockIdx.x * 2 + tid / CO) * cout + tid % CO] = 0.0;
+#define WS_FLUSH_STATS() {                                                                                            \
+        if (tid < 2 * CO && tid % CO < cout)                                                                          \
+            (sl.n > 1 ? sl.stats[run_slice] : stats)[((int64_t)blockIdx.x * 2 + tid / CO) * cout + tid % CO] = run_sum; \
+        run_sum = 0.0; }
+    for (; tile < n_tiles; tile += gridDim.x) {
+        const int slice = tile / img_tiles, itile = tile - slice * img_tiles;
+        if (stats && slice != run_slice) { WS_FLUSH_STATS() run_slice = slice; }
+        const int tb = itile / per_img, trem = itile - tb * per_img;
+        const int y0 = (trem / tiles_x) * TR, x0 = (trem % tiles_x) * DC_TW;
+        float* __restrict__ Ys = sl.n > 1 ? sl.y[slice] : Y;
+#pragma unroll
+        for (int m = 0; m < M16; ++m)
+#pragma unroll
+            for (int t = 0; t < N16; ++t) acc[m][t] = ws_v4f{0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < nquads; ++q) {
+#pragma unroll
+            for (int k = 0; k < 18; ++k) {
+                // the two stages of this double stage: image and tap offset of each, chosen per lane group pair
+                constexpr int dummy_ = 0; (void)dummy_;
+                const int ja = 2 * k, jb = 2 * k + 1;
+                const int off_a = ((ja / 9) & 1) * ASZ + (((ja % 9) / 3) * DC_HW + (ja % 9) % 3) * DC_ROWB;
+                const int off_b = ((jb / 9) & 1) * ASZ + (((jb % 9) / 3) * DC_HW + (jb % 9) % 3) * DC_ROWB;
+                const unsigned char* Ap = As + a_lane + (sel ? off_b : off_a);
+                const unsigned char* Bp = Bs + b_lane + 2 * (k & 1) * BSZ;
+#pragma unroll
+                for (int m = 0; m < M16; ++m) fa[m][0] = *reinterpret_cast<const mf_v8h*>(Ap + ((m >> 1) * DC_HW + (m & 1) * 16) * DC_ROWB);
+#pragma unroll
+                for (int t = 0; t < N16; ++t) fb[t][1] = *reinterpret_cast<const mf_v8h*>(Bp + BPL + t * 16 * DC_ROWB);
+#pragma unroll
+                for (int m = 0; m < M16; ++m) fa[m][1] = *reinterpret_cast<const mf_v8h*>(Ap + APL + ((m >> 1) * DC_HW + (m & 1) * 16) * DC_ROWB);
+#pragma unroll
+                for (int t = 0; t < N16; ++t) fb[t][0] = *reinterpret_cast<const mf_v8h*>(Bp + t * 16 * DC_ROWB);
+                // partial products smallest first; the set read first (plane 0 of the pixels, plane 1 of the weights) multiplies first
+#define WS16_MM1(PA, PB) _Pragma("unroll") for (int t = 0; t < N16; ++t) _Pragma("unroll") for (int m = 0; m < M16; ++m) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[m][PA], fb[t][PB], acc[m][t], 0, 0, 0);
+                WS16_MM1(0, 1) WS16_MM1(1, 0) WS16_MM1(0, 0)
+#undef WS16_MM1
+                __syncthreads();
+            }
+        }
+        // ---- epilogue: as dense_conv3x3_ws_kernel, in the 16 x 16 tiles' register layout
+        {
+            const float dx = h2_descale(sbx), dw = h2_descale(sbw);
+#pragma unroll
+            for (int m = 0; m < M16; ++m)
+#pragma unroll
+                for (int t = 0; t < N16; ++t) acc[m][t] = acc[m][t] * dx * dw;
+        }
+        float s1[N16], s2[N16];
+#pragma unroll
+        for (int t = 0; t < N16; ++t) { s1[t] = 0.0f; s2[t] = 0.0f; }
+        if (bn.y) {
+            float bsc[N16], bsh[N16], bmu[N16], biv[N16];
+#pragma unroll
+            for (int t = 0; t < N16; ++t) {
+                const int c = t * 16 + c16;
+                bmu[t] = bn.mean[c]; biv[t] = bn.invstd[c];
+                gga_bn_scale_shift(bn.gamma ? bn.gamma[c] : 1.0f, bn.beta ? bn.beta[c] : 0.0f, bmu[t], biv[t], bsc[t], bsh[t]);
+            }
+#pragma unroll
+            for (int m = 0; m < M16; ++m) {
+                const int oy = y0 + MT * wave + (m >> 1);
+                if (oy >= H) continue;
+                float yv[4][N16];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int ox = x0 + (m & 1) * 16 + 4 * g + v;
+                    const float* src = bn.y + ((int64_t)tb * H * W + oy * prow + (ox < W ? ox : W - 1) * pcol) * bn.ystride;
+#pragma unroll
+                    for (int t = 0; t < N16; ++t) yv[v][t] = src[t * 16 + c16];
+                }
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int ox = x0 + (m & 1) * 16 + 4 * g + v;
+                    if (ox >= W) continue;
+                    float* dst = Ys + ((int64_t)tb * H * W + oy * prow + ox * pcol) * ystride;
+#pragma unroll
+                    for (int t = 0; t < N16; ++t) {
+                        const float gv = fmaf(yv[v][t], bsc[t], bsh[t]) > 0.0f ? acc[m][t][v] : 0.0f;
+                        dst[t * 16 + c16] = gv;
+                        s1[t] += gv; s2[t] += gv * ((yv[v][t] - bmu[t]) * biv[t]);
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int m = 0; m < M16; ++m) {
+                const int oy = y0 + MT * wave + (m >> 1);
+                if (oy >= H) continue;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int ox = x0 + (m & 1) * 16 + 4 * g + v;
+                    if (ox >= W) continue;
+                    float* dst = Ys + ((int64_t)tb * H * W + oy * prow + ox * pcol) * ystride;
+#pragma unroll
+                    for (int t = 0; t < N16; ++t) dst[t * 16 + c16] = acc[m][t][v];
+                }
+            }
+        }
+        if (stats) {
+            if (!bn.y)
+#pragma unroll
+            for (int m = 0; m < M16; ++m) {
+                const bool rowok = y0 + MT * wave + (m >> 1) < H;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const bool ok = rowok && x0 + (m & 1) * 16 + 4 * g + v < W;
+#pragma unroll
+                    for (int t = 0; t < N16; ++t) {
+                        const float a = ok ? acc[m][t][v] : 0.0f;
+                        s1[t] += a; s2[t] += a * a;
+                    }
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < N16; ++t) {
+                s1[t] += __shfl_xor(s1[t], 16); s1[t] += __shfl_xor(s1[t], 32);
+                s2[t] += __shfl_xor(s2[t], 16); s2[t] += __shfl_xor(s2[t], 32);
+                if (g == 0) { red[(wave * 2 + 0) * CO + t * 16 + c16] = s1[t]; red[(wave * 2 + 1) * CO + t * 16 + c16] = s2[t]; }
+            }
+            __syncthreads();
+            if (tid < 2 * CO) {
+                const int which = tid / CO, c = tid - which * CO;
+                if (c < cout) {
+                    double a = 0.0;
+#pragma unroll
+                    for (int w_ = 0; w_ < 4; ++w_) a += (double)red[(w_ * 2 + which) * CO + c];
+                    run_sum += a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (stats) { WS_FLUSH_STATS() }
+#undef WS_FLUSH_STATS
+}
+#undef WS_AOFF
+#undef WS_LOAD_PIECE
+#undef WS_STORE_PIECE
+#undef WS_BLD
+#undef WS_BST
 
 bool dc_ws_enabled(int planes) {         // read per call: a test compares the two forms within one process
     const char* e = getenv("GGA_DC_WS");
@@ -374,6 +648,19 @@ int dc_launch_ws(const float* x, const void* split_weight, int B, int H, int W, 
     }
     const float* zero_page = zero_pages[dev];
     const dim3 grid((unsigned)dc_ws_grid(n_tiles)), block(512);
+    // matrix instruction of the consumer waves: 16x16x32 (needs whole quads of chunks: cin % 64 == 0) or 32x32x16; GGA_DC_WS_MFMA=32 / 16: A/B switch
+    const char* mfma_env = getenv("GGA_DC_WS_MFMA");          // read per call: a test compares the forms within one process
+    const int mfma = mfma_env ? atoi(mfma_env) : DC_WS_DEFAULT_MFMA;
+    if (mfma == 16 && cin % 64 == 0) {
+        if (cout == 128)
+            hipLaunchKernelGGL((dense_conv3x3_ws16_kernel<4, 2>), grid, block, 0, stream, x, (const uint16_t*)split_weight, B, H, W, cin, cout,
+                               tx, ty, y, ystride, prow, pcol, stats, amax_x, amax_weight, bn, zero_page, sl);
+        else
+            hipLaunchKernelGGL((dense_conv3x3_ws16_kernel<2, 4>), grid, block, 0, stream, x, (const uint16_t*)split_weight, B, H, W, cin, cout,
+                               tx, ty, y, ystride, prow, pcol, stats, amax_x, amax_weight, bn, zero_page, sl);
+        GGA_CHECK_LAUNCH("dense_conv3x3_ws16_kernel");
+        return GGA_OK;
+    }
     if (cout == 128)
         hipLaunchKernelGGL((dense_conv3x3_ws_kernel<4, 2>), grid, block, 0, stream, x, (const uint16_t*)split_weight, B, H, W, cin, cout,
                            tx, ty, y, ystride, prow, pcol, stats, amax_x, amax_weight, bn, zero_page, sl);

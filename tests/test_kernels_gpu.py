@@ -756,18 +756,30 @@ def test_dense_conv_producer_consumer_form_equals_the_lock_step_form(cin, cout, 
     w = (torch.randn(cout, cin, 3, 3, device=DEV) * 0.05).contiguous(memory_format=torch.channels_last)
     g = torch.randn(B, cout, H, W, device=DEV).contiguous(memory_format=torch.channels_last)
     got = {}
-    for form in ('1', '0'):
-        monkeypatch.setenv('GGA_DC_WS', form)
+    for form in ('1', '0', '16'):
+        monkeypatch.setenv('GGA_DC_WS', '0' if form == '0' else '1')
+        monkeypatch.setenv('GGA_DC_WS_MFMA', '16' if form == '16' else '32')
         y, st = dense_conv._run(x, w, False, True)
         gx = dense_conv._run(g, w, True, False)[0] if cin % 64 == 0 else y      # (two input chunks: forward only - 32 outputs are not a tile)
         got[form] = (y.clone(), st.sum(0), gx.clone())
     torch.cuda.synchronize()
     assert torch.equal(got['1'][0], got['0'][0]) and torch.equal(got['1'][2], got['0'][2])
+    # the 16x16x32 consumer form (round 5; whole quads of chunks: cin % 64 == 0, else the 32x32x16 form ran again): the same
+    # planes and products, K = 32 per instruction - another summation order, so close, not identical; against float64 below
+    for i in (0, 2):
+        assert float((got['16'][i] - got['0'][i]).abs().max()) <= 2e-6 * float(got['0'][i].abs().max())
+        if cin % 64 == 0:
+            assert not torch.equal(got['16'][i], got['0'][i]), 'the 16x16x32 form did not run'
+    torch.testing.assert_close(got['16'][1], got['0'][1], rtol=1e-5, atol=1e-6 * float(got['0'][1].abs().max()))
     # (fp32 lane sums over other pixel groups before the f64 fold)
     torch.testing.assert_close(got['1'][1], got['0'][1], rtol=1e-5, atol=1e-6 * float(got['0'][1].abs().max()))
     ref = torch.nn.functional.conv2d(x.double(), w.double(), padding=1)
-    assert float((got['1'][0].double() - ref).abs().max()) <= 3e-6 * float(ref.abs().max())
-    torch.testing.assert_close(got['1'][1][0], ref.sum((0, 2, 3)), rtol=1e-4, atol=1e-4 * float(ref.abs().sum((0, 2, 3)).max()))
+    for form in ('1', '16'):
+        assert float((got[form][0].double() - ref).abs().max()) <= 3e-6 * float(ref.abs().max())
+        torch.testing.assert_close(got[form][1][0], ref.sum((0, 2, 3)), rtol=1e-4, atol=1e-4 * float(ref.abs().sum((0, 2, 3)).max()))
+    if cin % 64 == 0:
+        refg = torch.nn.grad.conv2d_input(x.shape, w.double(), g.double(), padding=1)
+        assert float((got['16'][2].double() - refg).abs().max()) <= 3e-6 * float(refg.abs().max())
 
 
 def test_dense_weight_gradient_with_an_absmax_per_channel_block():
@@ -938,7 +950,8 @@ def test_dense_conv3x3_over_several_maps_in_one_launch(cin, cout, planes, monkey
 @pytest.mark.parametrize('c0,c1,B,H,W', [(64, 64, 2, 37, 45), (128, 128, 2, 31, 22), (256, 256, 1, 30, 20), (64, 128, 1, 41, 33),
                                          (128, 128, 13, 120, 128), (128, 128, 16, 124, 108)])
 @pytest.mark.parametrize('training', [True, False])
-def test_conv_backward_data_reduces_the_batchnorm_below(c0, c1, B, H, W, training, monkeypatch):
+@pytest.mark.parametrize('form', ['planes3', 'ws32', 'ws16'])
+def test_conv_backward_data_reduces_the_batchnorm_below(c0, c1, B, H, W, training, form, monkeypatch):
     """conv -> BatchNorm -> ReLU -> conv: the second convolution's backward-data launch masks its result with the ReLU
     and leaves the BatchNorm backward sums (gga_dense_conv3x3_bn_bwd), and the BatchNorm backward then runs without its
     reduce pass (gga_bn_relu_bwd_partials). Checked against the unfused path of this repo (same kernels otherwise) and
@@ -946,6 +959,12 @@ def test_conv_backward_data_reduces_the_batchnorm_below(c0, c1, B, H, W, trainin
     batch and running statistics."""
     import copy
     from gga_amd import dense_conv, _lib
+    # the library default (three bf16 planes, lock-step kernel) and the two-plane producer / consumer kernel with either matrix
+    # instruction in its consumer waves (its own epilogue code per form)
+    if form != 'planes3':
+        monkeypatch.setattr(dense_conv, 'PLANES', 2)
+        monkeypatch.setenv('GGA_DC_WS', '1')
+        monkeypatch.setenv('GGA_DC_WS_MFMA', form[2:])
     torch.manual_seed(c0 + c1 + H)
     conv1 = torch.nn.Conv2d(64, c0, 3, padding=1, bias=False).to(DEV)
     bn = torch.nn.BatchNorm2d(c0, eps=1e-3, momentum=0.01).to(DEV)

@@ -353,9 +353,10 @@ __global__ __launch_bounds__(512, 2) void dense_conv3x3_ws_kernel(const float* _
 // A wave's tile is M16 x N16 tiles of 16 x 16 (2 MT x 2 NT): D register v of lane (c = lane % 16, g = lane / 16) = pixel
 // 16 (tile % 2) + 4 g + v of image row tile / 2, output column 16 nt + c.
 // Registers: the fragments of a K = 32 step are 24 x 4 = 96 registers beside the 128 accumulators - a second set for the
-// next double stage (the 32x32x16 form's scheme) does not fit in 256, so ONE set: a double stage reads its fragments at its
-// start (all 24 reads are issued back to back, the products follow them as the data arrives) and the producers write the
-// weights of double stage d + 1 (slot pair (d + 1) % 2) and the next chunk's halo image while double stage d multiplies.
+// next double stage (the 32x32x16 form's scheme) does not fit in 256, so ONE set refilled in place as its pieces die (see the
+// consumers' loop; a first version that read all 24 fragments at the start of each double stage was 4.5 % SLOWER than the
+// 32x32x16 form: four waves' 96 KB of reads in one burst behind every barrier). The producers write the weights of double stage
+// d + 1 (slot pair (d + 1) % 2) and the next chunk's halo image while double stage d multiplies.
 template <int NT, int MT>
 __global__ __launch_bounds__(512, 2) void dense_conv3x3_ws16_kernel(const float* __restrict__ X, const uint16_t* __restrict__ Wp, int B,
                                                                      int H, int W, int cin, int cout, int tiles_x, int tiles_y,
@@ -488,31 +489,79 @@ __global__ __launch_bounds__(512, 2) void dense_conv3x3_ws16_kernel(const float*
         for (int m = 0; m < M16; ++m)
 #pragma unroll
             for (int t = 0; t < N16; ++t) acc[m][t] = ws_v4f{0.f, 0.f, 0.f, 0.f};
+        // Fragment addresses of double stage K_ of a quad: lane groups 0, 1 read stage 2 K_ (its halo image and tap position, its
+        // weight slot), groups 2, 3 stage 2 K_ + 1
+#define WS16_ADDR(K_)                                                                                                     \
+        const int ja_ = 2 * (K_), jb_ = 2 * (K_) + 1;                                                                       \
+        const int off_a_ = ((ja_ / 9) & 1) * ASZ + (((ja_ % 9) / 3) * DC_HW + (ja_ % 9) % 3) * DC_ROWB;                     \
+        const int off_b_ = ((jb_ / 9) & 1) * ASZ + (((jb_ % 9) / 3) * DC_HW + (jb_ % 9) % 3) * DC_ROWB;                     \
+        const unsigned char* Ap = As + a_lane + (sel ? off_b_ : off_a_);                                                    \
+        const unsigned char* Bp = Bs + b_lane + 2 * ((K_) & 1) * BSZ;
+#define WS16_LD_A(M_, P_) fa[M_][P_] = *reinterpret_cast<const mf_v8h*>(Ap + (P_) * APL + (((M_) >> 1) * DC_HW + ((M_) & 1) * 16) * DC_ROWB);
+#define WS16_LD_B(T_, P_) fb[T_][P_] = *reinterpret_cast<const mf_v8h*>(Bp + (P_) * BPL + (T_) * 16 * DC_ROWB);
+#define WS16_MFMA(M_, T_, PA, PB) acc[M_][T_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[M_][PA], fb[T_][PB], acc[M_][T_], 0, 0, 0);
+        {   // the tile's first double stage: all 24 fragments at once (its data was written during the previous tile's last one)
+            WS16_ADDR(0)
+#pragma unroll
+            for (int m = 0; m < M16; ++m) { WS16_LD_A(m, 1) }
+#pragma unroll
+            for (int t = 0; t < N16; ++t) { WS16_LD_B(t, 0) }
+#pragma unroll
+            for (int m = 0; m < M16; ++m) { WS16_LD_A(m, 0) }
+#pragma unroll
+            for (int t = 0; t < N16; ++t) { WS16_LD_B(t, 1) }
+        }
+        // One fragment set, refilled IN PLACE as its pieces die (a second set does not fit beside 128 accumulators): double
+        // stage k multiplies plane 1 of the pixels x plane 0 of the weights, then plane 0 x plane 1 - after which both plane-1
+        // sets are dead; the stage barrier makes the producers' data of k + 1 visible; the plane-1 sets of k + 1 are requested
+        // into the dead registers and travel while plane 0 x plane 0 of k runs column tile by column tile, each tile's weight
+        // fragment re-requested for k + 1 as soon as its four products are issued; the pixels' plane 0 follows at the end and
+        // arrives during the first product group of k + 1, which does not need it. Per accumulator the products still arrive
+        // cross terms first, the large one last.
         for (int q = 0; q < nquads; ++q) {
 #pragma unroll
             for (int k = 0; k < 18; ++k) {
-                // the two stages of this double stage: image and tap offset of each, chosen per lane group pair
-                constexpr int dummy_ = 0; (void)dummy_;
-                const int ja = 2 * k, jb = 2 * k + 1;
-                const int off_a = ((ja / 9) & 1) * ASZ + (((ja % 9) / 3) * DC_HW + (ja % 9) % 3) * DC_ROWB;
-                const int off_b = ((jb / 9) & 1) * ASZ + (((jb % 9) / 3) * DC_HW + (jb % 9) % 3) * DC_ROWB;
-                const unsigned char* Ap = As + a_lane + (sel ? off_b : off_a);
-                const unsigned char* Bp = Bs + b_lane + 2 * (k & 1) * BSZ;
 #pragma unroll
-                for (int m = 0; m < M16; ++m) fa[m][0] = *reinterpret_cast<const mf_v8h*>(Ap + ((m >> 1) * DC_HW + (m & 1) * 16) * DC_ROWB);
+                for (int t = 0; t < N16; ++t)
 #pragma unroll
-                for (int t = 0; t < N16; ++t) fb[t][1] = *reinterpret_cast<const mf_v8h*>(Bp + BPL + t * 16 * DC_ROWB);
+                    for (int m = 0; m < M16; ++m) { WS16_MFMA(m, t, 1, 0) }
 #pragma unroll
-                for (int m = 0; m < M16; ++m) fa[m][1] = *reinterpret_cast<const mf_v8h*>(Ap + APL + ((m >> 1) * DC_HW + (m & 1) * 16) * DC_ROWB);
+                for (int t = 0; t < N16; ++t)
 #pragma unroll
-                for (int t = 0; t < N16; ++t) fb[t][0] = *reinterpret_cast<const mf_v8h*>(Bp + t * 16 * DC_ROWB);
-                // partial products smallest first; the set read first (plane 0 of the pixels, plane 1 of the weights) multiplies first
-#define WS16_MM1(PA, PB) _Pragma("unroll") for (int t = 0; t < N16; ++t) _Pragma("unroll") for (int m = 0; m < M16; ++m) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[m][PA], fb[t][PB], acc[m][t], 0, 0, 0);
-                WS16_MM1(0, 1) WS16_MM1(1, 0) WS16_MM1(0, 0)
-#undef WS16_MM1
+                    for (int m = 0; m < M16; ++m) { WS16_MFMA(m, t, 0, 1) }
                 __syncthreads();
+                // (the tile's last double stage requests the next tile's first like any other - no branch in the stream, the
+                // registers are not carried through the epilogue: the next tile starts by reading its set again)
+                // The order of this barrier-to-barrier region, pinned (left alone the scheduler sinks every read to just before its
+                // first use and waits there): the 12 plane-1 reads, (4 products, 1 read) x N16, the M16 pixel reads, then the
+                // next double stage's first two product groups.
+                __builtin_amdgcn_sched_group_barrier(0x100, M16 + N16, 0);
+#pragma unroll
+                for (int t = 0; t < N16; ++t) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, M16, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x100, M16, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 2 * M16 * N16, 0);
+                WS16_ADDR((k + 1) % 18)
+#pragma unroll
+                for (int m = 0; m < M16; ++m) { WS16_LD_A(m, 1) }
+#pragma unroll
+                for (int t = 0; t < N16; ++t) { WS16_LD_B(t, 1) }
+#pragma unroll
+                for (int t = 0; t < N16; ++t) {
+#pragma unroll
+                    for (int m = 0; m < M16; ++m) { WS16_MFMA(m, t, 0, 0) }
+                    WS16_LD_B(t, 0)
+                }
+#pragma unroll
+                for (int m = 0; m < M16; ++m) { WS16_LD_A(m, 0) }
             }
         }
+#undef WS16_ADDR
+#undef WS16_LD_A
+#undef WS16_LD_B
+#undef WS16_MFMA
         // ---- epilogue: as dense_conv3x3_ws_kernel, in the 16 x 16 tiles' register layout
         {
             const float dx = h2_descale(sbx), dw = h2_descale(sbw);

@@ -26,6 +26,17 @@
 #include "dense_conv.h"
 
 #define GGA_MAX_DEVICES 64
+// The consumers' stage barrier: the bare instruction, NOT __syncthreads(). The compiler puts s_waitcnt lgkmcnt(0) in front of the
+// latter - every fragment read in flight must land before the wave may even arrive, at every stage (60-200 cycles of a 768- or
+// 1536-cycle stage). The protocol does not need it: a consumer's reads are of data the producers completed before the PREVIOUS
+// barrier, and the buffers they come from (weight ring, halo image) are not written again until at least one more whole stage has
+// passed; the reads are waited for where their values are used (counted lgkmcnt, the compiler's). The producers keep
+// __syncthreads(): their LDS writes must be complete when they arrive. GGA_... no switch: compile with -DWS_CONSUMER_SYNC for the old form.
+#ifdef WS_CONSUMER_SYNC
+#define WS_CONSUMER_BARRIER() __syncthreads();
+#else
+#define WS_CONSUMER_BARRIER() asm volatile("s_barrier" ::: "memory");
+#endif
 #define DC_WS_DEFAULT_MFMA 32                 // consumer waves' matrix instruction unless GGA_DC_WS_MFMA says otherwise (16: 16x16x32)
 __device__ __attribute__((aligned(16))) float dc_zero_page[DC_WS_MAX_CIN];      // what a halo piece outside the image is read from
 
@@ -216,7 +227,7 @@ __global__ __launch_bounds__(512, 2) void dense_conv3x3_ws_kernel(const float* _
             WS_MMA(CA, CB)                                                                                            \
             _Pragma("unroll") for (int g_ = 0; g_ < N_READ; ++g_) {                                                   \
                 __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); } \
-            __syncthreads(); }
+            WS_CONSUMER_BARRIER() }
 #define WS_EVEN(TAP, CH, HB, LASTABLE) WS_STAGE_C(TAP, CH, HB, LASTABLE, fa, fb, ga, gb)
 #define WS_ODD(TAP, CH, HB, LASTABLE) WS_STAGE_C(TAP, CH, HB, LASTABLE, ga, gb, fa, fb)
         for (int ch = 0; ch < nchunks; ch += 2) {
@@ -356,7 +367,7 @@ __global__ __launch_bounds__(512, 2) void dense_conv3x3_ws_kernel(const float* _
 // next double stage (the 32x32x16 form's scheme) does not fit in 256, so ONE set refilled in place as its pieces die (see the
 // consumers' loop; a first version that read all 24 fragments at the start of each double stage was 4.5 % SLOWER than the
 // 32x32x16 form: four waves' 96 KB of reads in one burst behind every barrier). The producers write the weights of double stage
-// d + 1 (slot pair (d + 1) % 2) and the next chunk's halo image while double stage d multiplies.
+// d + 1 (slot pair (d + 1) % 3) and the next chunk's halo image while double stage d multiplies.
 template <int NT, int MT>
 __global__ __launch_bounds__(512, 2) void dense_conv3x3_ws16_kernel(const float* __restrict__ X, const uint16_t* __restrict__ Wp, int B,
                                                                      int H, int W, int cin, int cout, int tiles_x, int tiles_y,
@@ -372,7 +383,7 @@ __global__ __launch_bounds__(512, 2) void dense_conv3x3_ws16_kernel(const float*
     constexpr int M16 = 2 * MT, N16 = 2 * NT;
     static_assert(NB == 1 || NB == 2, "weight stage pieces per producer lane");
     __shared__ __attribute__((aligned(16))) unsigned char As[2 * ASZ];
-    __shared__ __attribute__((aligned(16))) unsigned char Bs[4 * BSZ];
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[6 * BSZ];      // three slot pairs: double stage d in pair d % 3
     __shared__ float red[4 * 2 * CO];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -390,31 +401,35 @@ __global__ __launch_bounds__(512, 2) void dense_conv3x3_ws16_kernel(const float*
     float4 ra[NA];
     const float* pcur[NA];
     const float* pnxt[NA];
-    uint4 wq[2][2];                              // the two stages of the next double stage
-    wq[0][0] = wq[0][1] = wq[1][0] = wq[1][1] = make_uint4(0, 0, 0, 0);
+    uint4 wq[2][2][2];                           // [double stage parity][stage of it][piece]: the weights of the next two double stages
+#pragma unroll
+    for (int i_ = 0; i_ < 8; ++i_) wq[i_ >> 2][(i_ >> 1) & 1][i_ & 1] = make_uint4(0, 0, 0, 0);
     const uint16_t* Wcur = sl.n > 1 ? sl.w[tile / img_tiles] : Wp;
     const uint16_t* Wnxt = Wcur;
     if (!consumer) {
         WS_AOFF(pcur, tile)
 #pragma unroll
         for (int e = 0; e < NA; ++e) { WS_LOAD_PIECE(e, pcur, 0) }
-        WS_BLD(Wcur, 0, 0, wq[0][0], wq[0][1])
-        WS_BLD(Wcur, 1, 0, wq[1][0], wq[1][1])
+        WS_BLD(Wcur, 0, 0, wq[0][0][0], wq[0][0][1])
+        WS_BLD(Wcur, 1, 0, wq[0][1][0], wq[0][1][1])
 #pragma unroll
         for (int e = 0; e < NA; ++e) { WS_STORE_PIECE(e, 0) }
-        WS_BST(0, wq[0][0], wq[0][1])
-        WS_BST(1, wq[1][0], wq[1][1])
-        WS_BLD(Wcur, 2, 0, wq[0][0], wq[0][1])
-        WS_BLD(Wcur, 3, 0, wq[1][0], wq[1][1])
+        WS_BST(0, wq[0][0][0], wq[0][0][1])
+        WS_BST(1, wq[0][1][0], wq[0][1][1])
+        WS_BLD(Wcur, 2, 0, wq[1][0][0], wq[1][0][1])          // double stage 1 -> set 1, double stage 2 -> set 0
+        WS_BLD(Wcur, 3, 0, wq[1][1][0], wq[1][1][1])
+        WS_BLD(Wcur, 4, 0, wq[0][0][0], wq[0][0][1])
+        WS_BLD(Wcur, 5, 0, wq[0][1][0], wq[0][1][1])
 #pragma unroll
         for (int e = 0; e < NA; ++e) { WS_LOAD_PIECE(e, pcur, 1) }
     }
     __syncthreads();
 
     // Double stage k of a quad (stages 2k, 2k + 1; stage j = chunk j / 9 of the quad, tap j % 9), one barrier each, the same number
-    // on both paths. Producers: write the weights of double stage k + 1 (requested during k - 1) into slot pair (k + 1) % 2,
-    // request those of k + 2, handle the halo pieces of this double stage - chunk q + 1's image is written while chunk q's
-    // first four double stages multiply (the fifth reads both images), chunk q + 2's during the last four of chunk q + 1 -, barrier.
+    // on both paths. Producers: write the weights of double stage k + 1 (requested during k - 2) into slot pair (k + 1) % 3 (three
+    // pairs: the consumers' reads of a pair are not waited for at the barrier, WS_CONSUMER_BARRIER, so a pair rests for a whole
+    // double stage between its last reader and its next writer), request those of k + 3 into the register set just freed,
+    // handle the halo pieces of this double stage (schedule: below), barrier.
     if (!consumer) {
         for (; tile < n_tiles; tile += gridDim.x) {
             if (tile + (int)gridDim.x < n_tiles) {
@@ -431,21 +446,23 @@ __global__ __launch_bounds__(512, 2) void dense_conv3x3_ws16_kernel(const float*
                 const int cnext = last ? 0 : c0 + 4;
 #pragma unroll
                 for (int k = 0; k < 18; ++k) {
-                    WS_BST(2 * ((k + 1) & 1) + 0, wq[0][0], wq[0][1])
-                    WS_BST(2 * ((k + 1) & 1) + 1, wq[1][0], wq[1][1])
+                    WS_BST(2 * ((k + 1) % 3) + 0, wq[(k + 1) & 1][0][0], wq[(k + 1) & 1][0][1])
+                    WS_BST(2 * ((k + 1) % 3) + 1, wq[(k + 1) & 1][1][0], wq[(k + 1) & 1][1][1])
 #pragma unroll
                     for (int s_ = 0; s_ < 2; ++s_) {
-                        const int j = 2 * k + 4 + s_;                  // a stage of double stage k + 2
-                        if (j < 36) { WS_BLD(Wcur, j % 9, c0 + j / 9, wq[s_][0], wq[s_][1]) }
-                        else { WS_BLD(wnext, (j - 36) % 9, cnext + (j - 36) / 9, wq[s_][0], wq[s_][1]) }
+                        const int j = 2 * k + 6 + s_;                  // a stage of double stage k + 3
+                        if (j < 36) { WS_BLD(Wcur, j % 9, c0 + j / 9, wq[(k + 1) & 1][s_][0], wq[(k + 1) & 1][s_][1]) }
+                        else { WS_BLD(wnext, (j - 36) % 9, cnext + (j - 36) / 9, wq[(k + 1) & 1][s_][0], wq[(k + 1) & 1][s_][1]) }
                     }
-                    // halo pieces: (first double stage, chunk written (relative to c0), image) per group of four double stages
-                    const int grp = k < 4 ? 0 : (k >= 5 && k < 9 ? 1 : (k >= 9 && k < 13 ? 2 : (k >= 14 ? 3 : -1)));
+                    // halo pieces: chunk c0 + grp + 1 is written during three double stages - not the first one after the image's last
+                    // reader (tap 8 of the chunk before: its reads were issued before that barrier but are not waited for there),
+                    // done before the barrier in front of its first reader
+                    const int grp = (k >= 1 && k <= 3) ? 0 : ((k >= 6 && k <= 8) ? 1 : ((k >= 10 && k <= 12) ? 2 : (k >= 15 ? 3 : -1)));
                     if (grp >= 0) {
-                        const int k0 = grp == 0 ? 0 : (grp == 1 ? 5 : (grp == 2 ? 9 : 14));
+                        const int k0 = grp == 0 ? 1 : (grp == 1 ? 6 : (grp == 2 ? 10 : 15));
 #pragma unroll
                         for (int e = 0; e < NA; ++e)
-                            if ((e * 4) / NA == k - k0) {
+                            if ((e * 3) / NA == k - k0) {
                                 WS_STORE_PIECE(e, (grp + 1) & 1)       // chunk c0 + grp + 1 -> image (grp + 1) % 2
                                 const int cl = grp + 2;                // then request the same piece of chunk c0 + grp + 2
                                 if (cl < 4) { WS_LOAD_PIECE(e, pcur, c0 + cl) }
@@ -496,7 +513,7 @@ __global__ __launch_bounds__(512, 2) void dense_conv3x3_ws16_kernel(const float*
         const int off_a_ = ((ja_ / 9) & 1) * ASZ + (((ja_ % 9) / 3) * DC_HW + (ja_ % 9) % 3) * DC_ROWB;                     \
         const int off_b_ = ((jb_ / 9) & 1) * ASZ + (((jb_ % 9) / 3) * DC_HW + (jb_ % 9) % 3) * DC_ROWB;                     \
         const unsigned char* Ap = As + a_lane + (sel ? off_b_ : off_a_);                                                    \
-        const unsigned char* Bp = Bs + b_lane + 2 * ((K_) & 1) * BSZ;
+        const unsigned char* Bp = Bs + b_lane + 2 * ((K_) % 3) * BSZ;
 #define WS16_LD_A(M_, P_) fa[M_][P_] = *reinterpret_cast<const mf_v8h*>(Ap + (P_) * APL + (((M_) >> 1) * DC_HW + ((M_) & 1) * 16) * DC_ROWB);
 #define WS16_LD_B(T_, P_) fb[T_][P_] = *reinterpret_cast<const mf_v8h*>(Bp + (P_) * BPL + (T_) * 16 * DC_ROWB);
 #define WS16_MFMA(M_, T_, PA, PB) acc[M_][T_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[M_][PA], fb[T_][PB], acc[M_][T_], 0, 0, 0);
@@ -529,7 +546,7 @@ __global__ __launch_bounds__(512, 2) void dense_conv3x3_ws16_kernel(const float*
                 for (int t = 0; t < N16; ++t)
 #pragma unroll
                     for (int m = 0; m < M16; ++m) { WS16_MFMA(m, t, 0, 1) }
-                __syncthreads();
+                WS_CONSUMER_BARRIER()
                 // (the tile's last double stage requests the next tile's first like any other - no branch in the stream, the
                 // registers are not carried through the epilogue: the next tile starts by reading its set again)
                 // The order of this barrier-to-barrier region, pinned (left alone the scheduler sinks every read to just before its

@@ -31,6 +31,51 @@ def single_gpu_test(model, data_loader, device=None, progress=None):
     return results
 
 
+def collect_results(part, size, tmpdir=None, gpu_collect=False):
+    """mmdet ``collect_results_cpu`` / ``collect_results_gpu`` (mmdet/apis/test.py; third-party, restated): every rank hands in
+    the results of its shard - the strided shard of ``loader.DistributedSampler(shuffle=False)``: rank r holds frames r,
+    r + world, ... - and rank 0 gets the ``size`` results of the whole dataset in dataset order (the sampler's padding repeats
+    cut off); the other ranks get None. ``gpu_collect``: through ``all_gather_object`` (the process group's transport);
+    otherwise through pickle files in ``tmpdir`` (a shared directory; created by rank 0 when not given), as the reference's
+    default."""
+    import os
+    import shutil
+    import tempfile
+    import torch.distributed as dist
+    rank, world = dist.get_rank(), dist.get_world_size()
+    if gpu_collect:
+        parts = [None] * world
+        dist.all_gather_object(parts, part)
+    else:
+        if tmpdir is None:
+            name = [tempfile.mkdtemp(prefix='gga_collect_') if rank == 0 else None]
+            dist.broadcast_object_list(name, src=0)
+            tmpdir = name[0]
+        else:
+            os.makedirs(tmpdir, exist_ok=True)
+        with open(os.path.join(tmpdir, f'part_{rank}.pkl'), 'wb') as f:
+            pickle.dump(part, f)
+        dist.barrier()
+        parts = None
+        if rank == 0:
+            parts = [pickle.load(open(os.path.join(tmpdir, f'part_{r}.pkl'), 'rb')) for r in range(world)]
+            shutil.rmtree(tmpdir)
+    if rank != 0:
+        return None
+    ordered = []
+    for group in zip(*parts):               # frame i of the dataset is entry i // world of rank i % world
+        ordered.extend(group)
+    return ordered[:size]
+
+
+def multi_gpu_test(model, data_loader, tmpdir=None, gpu_collect=False, device=None, progress=None):
+    """mmdet ``multi_gpu_test`` (tools/generate_pseudo_labels_gga.py:242 of the reference, started per GPU by
+    tools/dist_pseudo.sh:11-22): every rank tests its shard of the loader, rank 0 returns the results of the whole dataset in
+    dataset order."""
+    part = single_gpu_test(model, data_loader, device, progress)
+    return collect_results(part, len(data_loader.dataset), tmpdir, gpu_collect)
+
+
 def load_weights(model, filename, map_location='cpu', strict=False):
     """Checkpoint file -> model weights (``state_dict`` entry or a bare state dict; a leading ``module.`` dropped). -> the
     file's ``meta`` dict."""
@@ -42,18 +87,20 @@ def load_weights(model, filename, map_location='cpu', strict=False):
 
 
 def generate_pseudo_labels(cfg, checkpoint, out=None, eval_metrics=('mAP',), eval_options=None, device='cuda:0', model=None,
-                           channels_last=True, progress=None):
+                           channels_last=True, progress=None, distributed=False, tmpdir=None, gpu_collect=False):
     """The flow of the reference's tool for one process: dataset ``cfg.data.test`` in test mode, loader
     (``cfg.data.test_dataloader`` over the defaults samples_per_gpu=1, workers_per_gpu=2, no shuffling), detector from
     ``cfg.model`` with the checkpoint's weights (``model``: an already built detector instead), ``single_gpu_test``, the raw
     outputs pickled to ``out`` when given, then ``dataset.evaluate(outputs, metric=..., **eval_options)`` - the matching
     dataset writes the pseudo-label file there (``pseudo_label_file`` in ``eval_options`` names it). -> (outputs, what
-    ``evaluate`` returned or None)."""
+    ``evaluate`` returned or None). ``distributed`` (one process per GPU, process group initialised - ``train.init_dist``):
+    the frames are sharded over the ranks (``multi_gpu_test``), rank 0 collects, writes and evaluates; the other ranks
+    return (None, None)."""
     device = torch.device(device)
     test_cfg = cfg.data['test']
     test_cfg['test_mode'] = True
     dataset = build_dataset(test_cfg)
-    loader_cfg = dict(samples_per_gpu=1, workers_per_gpu=2, dist=False, shuffle=False)
+    loader_cfg = dict(samples_per_gpu=1, workers_per_gpu=2, dist=bool(distributed), shuffle=False)
     loader_cfg.update(cfg.data.get('test_dataloader', {}))
     loader = build_dataloader(dataset, **loader_cfg)
     if model is None:
@@ -68,7 +115,12 @@ def generate_pseudo_labels(cfg, checkpoint, out=None, eval_metrics=('mAP',), eva
         if channels_last:
             from .cnn import to_channels_last
             model = to_channels_last(model)
-    outputs = single_gpu_test(model, loader, device, progress)
+    if distributed:
+        outputs = multi_gpu_test(model, loader, tmpdir, gpu_collect, device, progress)
+        if outputs is None:                    # not rank 0
+            return None, None
+    else:
+        outputs = single_gpu_test(model, loader, device, progress)
     if out:
         if not out.endswith(('.pkl', '.pickle')):
             raise ValueError('The output file must be a pkl file.')

@@ -88,3 +88,61 @@ def test_two_rank_gloo_step_matches_single_process():
         runner.iter += 1
     for a, b in zip(res[0][1], model.parameters()):
         torch.testing.assert_close(torch.from_numpy(a), b.detach(), rtol=1e-5, atol=1e-7)
+
+
+# ---------------------------------------------------------------------------------------------------- multi-GPU test run
+class _Frames(torch.utils.data.Dataset):
+    def __init__(self, n):
+        self.n = n
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        from gga_amd.pipelines import DataContainer as DC
+        return dict(points=[DC(torch.full((3 + i, 4), float(i)))], img_metas=[DC(dict(sample_idx=i), cpu_only=True)])
+
+
+class _EchoDet(nn.Module):
+    """Test-mode stand-in: one result dict per frame, naming the frame it saw."""
+
+    def forward(self, return_loss=True, rescale=False, points=None, img_metas=None, **kw):
+        assert not return_loss and rescale
+        return [dict(sample_idx=m['sample_idx'], n_points=int(p.shape[0]), mean=float(p.mean()))
+                for p, m in zip(points[0], img_metas[0])]
+
+
+def _test_worker(rank, world, port, q, tmpdir, gpu_collect):
+    from gga_amd.apis import multi_gpu_test
+    from gga_amd.loader import build_dataloader
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    loader = build_dataloader(_Frames(7), samples_per_gpu=2, workers_per_gpu=0, dist=True, shuffle=False)
+    out = multi_gpu_test(_EchoDet(), loader, tmpdir=tmpdir, gpu_collect=gpu_collect, device=torch.device('cpu'))
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('gpu_collect', [False, True])
+def test_two_rank_test_run_returns_the_dataset_in_order(gpu_collect, tmp_path):
+    """The pseudo-label run over several ranks (reference: tools/generate_pseudo_labels_gga.py:242 ``multi_gpu_test``,
+    tools/dist_pseudo.sh): 7 frames over 2 ranks in batches of 2 - strided shards, one padded repeat - come back on rank 0 as
+    7 results in dataset order, through files or through the process group; the other rank gets None."""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_test_worker, args=(r, 2, port, q, None if gpu_collect else str(tmp_path / 'collect'), gpu_collect))
+             for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[1] is None
+    assert [r['sample_idx'] for r in res[0]] == list(range(7))
+    assert [r['n_points'] for r in res[0]] == [3 + i for i in range(7)] and [r['mean'] for r in res[0]] == [float(i) for i in range(7)]
+    assert not (tmp_path / 'collect').exists()

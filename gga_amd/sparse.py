@@ -307,12 +307,15 @@ class SparseSequential(SparseModule):
 SPLIT_BF16 = True
 
 
-# Halo form of the submanifold gather-GEMM (csrc/sparse_conv.hip::sp_conv_halo_kernel; two fp16 planes; 1: 128 columns, 2: 64
-# columns as well - slower there -, 0: off). It walks all kvol offsets of every row block, where the default kernel skips the
+# Halo form of the submanifold gather-GEMM (csrc/sparse_conv.hip::sp_conv_halo_kernel; two fp16 planes; GGA_SP_HALO=0: off) for
+# the output widths in HALO_COLUMNS: 128. (The entry point also takes 64 columns - tests/test_sparse_gpu.py keeps that covered -
+# but the product does not send them there: half the matrix work per gathered byte, 0.45-0.52 against 0.37-0.42 ms per launch in
+# round 3 and no difference in the step on the round-5 tree, profiles/r05_sp_halo2.txt; the `GGA_SP_HALO=2` switch is gone.) It walks all kvol offsets of every row block, where the default kernel skips the
 # offsets none of a block's 32 mask-sorted rows uses: it pays on levels where most offsets are populated - taken when at least
 # HALO_MIN_OCCUPANCY of the level's grid cells are active (the 128-channel level of the shipped config on the bench batch: 0.36,
 # 14.5 of 27 offsets per row; 10-15 % faster than the default kernel there) - and large enough to fill the chip.
 HALO = int(os.environ.get('GGA_SP_HALO', '1'))
+HALO_COLUMNS = (128,)
 HALO_MIN_ROWS = int(os.environ.get('GGA_SP_HALO_MIN_ROWS', '65536'))
 HALO_MIN_OCCUPANCY = float(os.environ.get('GGA_SP_HALO_MIN_OCCUPANCY', '0.25'))
 
@@ -353,7 +356,7 @@ def _conv_apply(x, rb, wp, n_rows, kvol, cin, cout, flip, y, x_amax=None, w_amax
     is - y is stored masked by the ReLU and ``stats`` receives that BatchNorm's backward sums."""
     L = _lib.lib()
     if (HALO and wp.dtype == torch.int16 and w_amax is not None and rb.coors is not None and cin % 32 == 0 and 9 <= kvol <= 27
-            and (cout == 128 or (cout == 64 and HALO >= 2)) and n_rows >= HALO_MIN_ROWS and rb.occupancy >= HALO_MIN_OCCUPANCY):
+            and cout in HALO_COLUMNS and n_rows >= HALO_MIN_ROWS and rb.occupancy >= HALO_MIN_OCCUPANCY):
         hl = rb.halo()
         check(L.gga_sparse_conv_apply_halo(F._p(x), F._p(wp), F._p(hl.tile_rows), F._p(hl.counts), hl.capacity, F._p(hl.halo_rows),
                                            F._p(hl.local_map), n_rows, hl.n_tiles, kvol, cin, cout, flip, F._p(y), cout, 2, F._p(x_amax),

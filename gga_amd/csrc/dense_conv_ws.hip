@@ -27,15 +27,18 @@
 
 #define GGA_MAX_DEVICES 64
 // The consumers' stage barrier: the bare instruction, NOT __syncthreads(). The compiler puts s_waitcnt lgkmcnt(0) in front of the
-// latter - every fragment read in flight must land before the wave may even arrive, at every stage (60-200 cycles of a 768- or
-// 1536-cycle stage). The protocol does not need it: a consumer's reads are of data the producers completed before the PREVIOUS
+// latter (and in front of an inline-asm barrier with a "memory" clobber) - every fragment read in flight must land before the
+// wave may even arrive, at every stage, and the last read of a stage is issued two products before its barrier: ~100 cycles of
+// a 768-cycle stage. The protocol does not need it: a consumer's reads are of data the producers completed before the PREVIOUS
 // barrier, and the buffers they come from (weight ring, halo image) are not written again until at least one more whole stage has
-// passed; the reads are waited for where their values are used (counted lgkmcnt, the compiler's). The producers keep
-// __syncthreads(): their LDS writes must be complete when they arrive. GGA_... no switch: compile with -DWS_CONSUMER_SYNC for the old form.
+// passed; the reads are waited for where their values are used (counted lgkmcnt, the compiler's). What must not happen is a read
+// of the NEXT stage's data moving above the barrier: the lane offsets every fragment address is built from go through the asm
+// as read-write operands, so those reads depend on it. The producers keep __syncthreads(): their LDS writes must be complete
+// when they arrive. -DWS_CONSUMER_SYNC: the old form.
 #ifdef WS_CONSUMER_SYNC
-#define WS_CONSUMER_BARRIER() __syncthreads();
+#define WS_CONSUMER_BARRIER(OFF_A, OFF_B) __syncthreads();
 #else
-#define WS_CONSUMER_BARRIER() asm volatile("s_barrier" ::: "memory");
+#define WS_CONSUMER_BARRIER(OFF_A, OFF_B) asm volatile("s_barrier" : "+v"(OFF_A), "+v"(OFF_B));
 #endif
 #define DC_WS_DEFAULT_MFMA 32                 // consumer waves' matrix instruction unless GGA_DC_WS_MFMA says otherwise (16: 16x16x32)
 __device__ __attribute__((aligned(16))) float dc_zero_page[DC_WS_MAX_CIN];      // what a halo piece outside the image is read from
@@ -114,12 +117,13 @@ __global__ __launch_bounds__(512, 2) void dense_conv3x3_ws_kernel(const float* _
     // ---- consumer state
     mf_v16 acc[MT][NT];
     mf_v8h fa[MT][2], fb[NT][2], ga[MT][2], gb[NT][2];
+    int cons_a = r * DC_ROWB + h * 16, cons_b = r * DC_ROWB + h * 16;      // the lane's offset in a halo row block / a weight stage (see WS_CONSUMER_BARRIER)
 #define WS_READ_A(FA, TAP, HB) {                                                                                      \
-        const unsigned char* Ap = As + (HB) * ASZ + ((MT * wave + (TAP) / 3) * DC_HW + r + (TAP) % 3) * DC_ROWB + h * 16; \
+        const unsigned char* Ap = As + (HB) * ASZ + ((MT * wave + (TAP) / 3) * DC_HW + (TAP) % 3) * DC_ROWB + cons_a;  \
         _Pragma("unroll") for (int m = 0; m < MT; ++m) _Pragma("unroll") for (int p = 0; p < 2; ++p)                  \
             FA[m][p] = *reinterpret_cast<const mf_v8h*>(Ap + p * APL + m * DC_HW * DC_ROWB); }
 #define WS_READ_B(FB, BUF) {                                                                                          \
-        const unsigned char* Bp = Bs + (BUF) * BSZ + r * DC_ROWB + h * 16;                                            \
+        const unsigned char* Bp = Bs + (BUF) * BSZ + cons_b;                                                          \
         _Pragma("unroll") for (int t = 0; t < NT; ++t) _Pragma("unroll") for (int p = 0; p < 2; ++p)                  \
             FB[t][p] = *reinterpret_cast<const mf_v8h*>(Bp + p * BPL + t * 32 * DC_ROWB); }
     // partial products smallest first; tiles innermost so consecutive MFMAs never share an accumulator
@@ -227,7 +231,7 @@ __global__ __launch_bounds__(512, 2) void dense_conv3x3_ws_kernel(const float* _
             WS_MMA(CA, CB)                                                                                            \
             _Pragma("unroll") for (int g_ = 0; g_ < N_READ; ++g_) {                                                   \
                 __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); } \
-            WS_CONSUMER_BARRIER() }
+            WS_CONSUMER_BARRIER(cons_a, cons_b) }
 #define WS_EVEN(TAP, CH, HB, LASTABLE) WS_STAGE_C(TAP, CH, HB, LASTABLE, fa, fb, ga, gb)
 #define WS_ODD(TAP, CH, HB, LASTABLE) WS_STAGE_C(TAP, CH, HB, LASTABLE, ga, gb, fa, fb)
         for (int ch = 0; ch < nchunks; ch += 2) {
@@ -486,8 +490,8 @@ __global__ __launch_bounds__(512, 2) void dense_conv3x3_ws16_kernel(const float*
     ws_v4f acc[M16][N16];
     mf_v8h fa[M16][2], fb[N16][2];
     const int c16 = lane & 15, g = lane >> 4, sel = g >> 1;
-    const int a_lane = ((MT * wave) * DC_HW + c16) * DC_ROWB + (g & 1) * 16;
-    const int b_lane = c16 * DC_ROWB + (g & 1) * 16 + sel * BSZ;
+    int a_lane = ((MT * wave) * DC_HW + c16) * DC_ROWB + (g & 1) * 16;       // (not const: see WS_CONSUMER_BARRIER)
+    int b_lane = c16 * DC_ROWB + (g & 1) * 16 + sel * BSZ;
     double run_sum = 0.0;
     int run_slice = tile / img_tiles;
     if (stats && sl.n > 1 && tid < 2 * CO && tid % CO < cout)
@@ -546,7 +550,7 @@ __global__ __launch_bounds__(512, 2) void dense_conv3x3_ws16_kernel(const float*
                 for (int t = 0; t < N16; ++t)
 #pragma unroll
                     for (int m = 0; m < M16; ++m) { WS16_MFMA(m, t, 0, 1) }
-                WS_CONSUMER_BARRIER()
+                WS_CONSUMER_BARRIER(a_lane, b_lane)
                 // (the tile's last double stage requests the next tile's first like any other - no branch in the stream, the
                 // registers are not carried through the epilogue: the next tile starts by reading its set again)
                 // The order of this barrier-to-barrier region, pinned (left alone the scheduler sinks every read to just before its

@@ -153,6 +153,15 @@ def test_packed_hand_over_gives_the_same_lists_and_the_same_targets(tmp_path):
                            if isinstance(o, (list, tuple, dict)) else n_tensors([o.flat]) if isinstance(o, LD.PackedFrames)
                            else n_tensors(o.data) if isinstance(o, DC) else n_tensors([o.tensor]) if isinstance(o, LiDARInstance3DBoxes) else 0)
     assert n_tensors(wire) == 2 * 8 and n_tensors(LD.collate(samples, samples_per_gpu=3)) > 100
+    # ... and all 16 payloads are views of ONE byte buffer: a single shared-memory segment per batch
+    arenas = {p.arena.data_ptr() for v in wire.values() if isinstance(v, DC) for p in v.data if isinstance(p, LD.PackedFrames)}
+    assert len(arenas) == 1
+    import io
+    from multiprocessing.reduction import ForkingPickler
+    import torch.multiprocessing as _tmp  # noqa: F401  (registers the tensor reductions the loader's queue uses)
+    buf = io.BytesIO()
+    ForkingPickler(buf).dump(packed)
+    assert buf.getvalue().count(b'rebuild_storage') == 1
     got = LD.to_step_inputs(wire, chunk=1)
     assert set(got) == set(plain)
     for k, a in plain.items():

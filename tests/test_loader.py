@@ -510,6 +510,49 @@ def test_pseudo_label_generation_run(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('collect', ['cpu', 'gpu'])
+def test_pseudo_label_generation_over_two_ranks(collect, tmp_path):
+    """tools/dist_pseudo.sh's flow (reference: tools/generate_pseudo_labels_gga.py:236-262 with ``multi_gpu_test``): two ranks
+    (gloo, sharing the box's one GPU) test strided shards of the three frames, rank 0 collects - through files or through the
+    process group -, writes the raw outputs and the pseudo-label file: frame for frame the detections of the single-process run."""
+    import subprocess
+    import sys
+    from gga_amd import build_model
+    from gga_amd.apis import generate_pseudo_labels
+    infos = kitti_tree(str(tmp_path))
+    model_cfg = os.path.join(REPO, 'configs', 'gga', 'gga_kitti_pointpillars_config.py')
+    torch.manual_seed(0)
+    model = build_model(Config.fromfile(model_cfg).model)
+    with torch.no_grad():
+        for th in model.pts_bbox_head.task_heads:
+            for name in ('reg', 'height', 'dim', 'rot'):
+                getattr(th, name)[-1].weight.mul_(0.05)
+            th.heatmap[-1].bias.fill_(0.5)
+    ck = str(tmp_path / 'epoch_1.pth')
+    torch.save(dict(meta=dict(epoch=1, iter=3, CLASSES=('Pedestrian', 'Cyclist', 'Car')), state_dict=model.state_dict()), ck)
+    cfg = matching_cfg(str(tmp_path), infos, model_cfg)
+    single, _ = generate_pseudo_labels(cfg, ck, eval_metrics=('mAP',), eval_options=dict(pseudo_label_file=str(tmp_path / 'single.pkl')))
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, GGA_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    raw, out_file = str(tmp_path / 'raw.pkl'), str(tmp_path / 'pseudo.pkl')
+    run = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                          '--master-port', str(port), os.path.join(REPO, 'tests', '_pseudo_dist_worker.py'), str(tmp_path), ck, raw, out_file,
+                          collect], env=env, capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0 and 'PSEUDO frames 3' in run.stdout, (run.stdout[-1500:], run.stderr[-2500:])
+    both = pickle.load(open(raw, 'rb'))
+    assert len(both) == len(single) == 3
+    for a, b in zip(both, single):
+        assert torch.equal(a['pts_bbox']['boxes_3d'].tensor, b['pts_bbox']['boxes_3d'].tensor)
+        assert torch.equal(a['pts_bbox']['scores_3d'], b['pts_bbox']['scores_3d']) and torch.equal(a['pts_bbox']['labels_3d'], b['pts_bbox']['labels_3d'])
+    relabelled, alone = pickle.load(open(out_file, 'rb')), pickle.load(open(str(tmp_path / 'single.pkl'), 'rb'))
+    assert [i['image']['image_idx'] for i in relabelled] == [i['image']['image_idx'] for i in alone]
+    for x, y in zip(relabelled, alone):
+        assert all(np.array_equal(x['annos'][k], y['annos'][k]) for k in ('name', 'bbox', 'location', 'GGA_init_pseudo_label'))
+
+
+@pytest.mark.gpu
 def test_whole_recipe_on_the_synthetic_tree(tmp_path):
     """The GGA recipe end to end (reference README.md:159-192) on the three-frame tree: GT database from the info file ->
     the reference's train_pipeline WITH database sampling -> tools/train.py's flow (train_detector, one epoch, checkpoint) ->

@@ -56,3 +56,22 @@ f = s.index('    if (stats) { WS_FLUSH_STATS() }\n#undef WS_FLUSH_STATS\n#undef 
 s = s[:f] + ('    if (tid == 0) { ws_stamp[blockIdx.x * 4 + 0] = st_main; ws_stamp[blockIdx.x * 4 + 1] = st_epi; ws_stamp[blockIdx.x * 4 + 2] = st_tiles; '
              'ws_stamp[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memtime() - st_begin; }\n') + s[f:]
 build('wsstamps', s)
+stamped = s
+
+# ---- stamps + producers idle (+ no consumer stage barrier / fragments read once): where the main loop's cycles go
+def noprod(t):
+    a = t.index('#define WS_STAGE_P(TAP, CH, HB, INCUR2, L0, L1, S0, S1) {')
+    b = t.index('#define WS_EVEN(TAP, CH, HB, INCUR2) WS_STAGE_P')
+    return t[:a] + '#define WS_STAGE_P(TAP, CH, HB, INCUR2, L0, L1, S0, S1) { __syncthreads(); }\n' + t[b:]
+
+
+build('wsstamps_noprod', noprod(stamped))
+# every halo piece from the zero page (an L2-resident kilobyte): the producers' vector-memory queue without HBM latency in it
+build('wsstamps_halozero', stamped.replace('P[e] = ok ? xb_ + ((iy * prow + ix * pcol) * cin + q * 4) : zero_page;', 'P[e] = zero_page;'))
+# weights from stage 0 always (L2-hot 8 KB) - the other half of the producers' loads
+build('wsstamps_w0', stamped.replace('const uint4* bsrc = reinterpret_cast<const uint4*>((WP) + ((int64_t)(TAP) * nchunks + (CH)) * (2 * CO * DC_CK));', 'const uint4* bsrc = reinterpret_cast<const uint4*>((WP) + ((int64_t)(TAP) * 0 + 0 * (CH)) * (2 * CO * DC_CK));'))
+t = noprod(stamped).replace('            WS_CONSUMER_BARRIER(cons_a, cons_b) }', '            }')
+t = t.replace('#define WS_STAGE_P(TAP, CH, HB, INCUR2, L0, L1, S0, S1) { __syncthreads(); }', '#define WS_STAGE_P(TAP, CH, HB, INCUR2, L0, L1, S0, S1) { }')
+build('wsstamps_noprod_nobar', t)
+t2 = t.replace('            WS_READ_A(XA, ((TAP) + 1) % 9, (TAP) == 8 ? 1 - (HB) : (HB))                                              \\\n            WS_READ_B(XB, ((TAP) + 1) % 3)                                                                            \\\n', '            XA[0][0] = CA[0][0]; XB[0][0] = CB[0][0];                                                             \\\n')
+build('wsstamps_noprod_nobar_noread', t2)

@@ -83,3 +83,19 @@ __device__ __forceinline__ void h2_split2(float a, float b, uint32_t& w0, uint32
     w0 = hb;
     w1 = __builtin_bit_cast(uint32_t, h1);
 }
+
+// The same planes of (a * s, b * s) for a power-of-two scale s, in FOUR vector instructions (round 5): each 16-bit half comes
+// straight out of v_fma_mixlo / mixhi_f16 - hi = f16(a * s), lo = f16(a * s - hi), the product exact in the instruction's fp32
+// arithmetic (s is a power of two), so the words are bit-identical to h2_split2(a * s, b * s, ..) (tools_dev/micro/split_probe.hip:
+// 0 of 134 M words differ, overflow to Inf / NaN included) without the scale multiply and the second v_cvt_pk_f16_f32. Every
+// vector instruction a staging wave issues costs the matrix-instruction wave on the same SIMD ~9 cycles
+// (tools_dev/micro/ws_interference_probe.hip), so the count matters more than the instructions' own 4 cycles.
+__device__ __forceinline__ void h2_split2s(float a, float b, float s, uint32_t& w0, uint32_t& w1) {
+    uint32_t hb, lb;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hb) : "v"(a), "v"(s));                  // (the other half: whatever was there, replaced next)
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hb) : "v"(b), "v"(s));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(lb) : "v"(a), "v"(s), "v"(hb));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lb) : "v"(b), "v"(s), "v"(hb));
+    w0 = hb;
+    w1 = lb;
+}

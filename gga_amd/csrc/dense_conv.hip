@@ -147,7 +147,7 @@ __global__ __launch_bounds__(TR / MT * 64, (P4 && NT == 4 && NP == 2) ? 1 : 2) v
                 *reinterpret_cast<uint2*>(dst + (NP - 1) * APL) = make_uint2(lo3, hi3);                               \
             } else {                                                                                                  \
                 uint32_t lo1, lo2, hi1, hi2;                                                                          \
-                h2_split2(v.x * xscale, v.y * xscale, lo1, lo2); h2_split2(v.z * xscale, v.w * xscale, hi1, hi2);     \
+                h2_split2s(v.x, v.y, xscale, lo1, lo2); h2_split2s(v.z, v.w, xscale, hi1, hi2);           \
                 *reinterpret_cast<uint2*>(dst) = make_uint2(lo1, hi1);                                                \
                 *reinterpret_cast<uint2*>(dst + APL) = make_uint2(lo2, hi2);                                          \
             }                                                                                                         \
@@ -797,7 +797,7 @@ __global__ __launch_bounds__(256, 2) void dense_wgrad3x3_x9_kernel(const float* 
             *reinterpret_cast<uint2*>(dst + (NP - 1) * (PL)) = make_uint2(lo3, hi3);                                  \
         } else {                                                                                                      \
             uint32_t lo1, lo2, hi1, hi2;                                                                              \
-            h2_split2(V.x * (SC), V.y * (SC), lo1, lo2); h2_split2(V.z * (SC), V.w * (SC), hi1, hi2);                 \
+            h2_split2s(V.x, V.y, (SC), lo1, lo2); h2_split2s(V.z, V.w, (SC), hi1, hi2);                         \
             *reinterpret_cast<uint2*>(dst) = make_uint2(lo1, hi1);                                                    \
             *reinterpret_cast<uint2*>(dst + (PL)) = make_uint2(lo2, hi2);                                             \
         } }

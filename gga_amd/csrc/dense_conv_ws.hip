@@ -98,11 +98,9 @@ __global__ __launch_bounds__(512, 2) void dense_conv3x3_ws_kernel(const float* _
 #define WS_STORE_PIECE(E, BUF) {                                                                                      \
         const int f = ptid + 256 * (E);                                                                               \
         if (f < HP * 4) {                                                                                             \
-            ws_v2f lo_ = {ra[E].x, ra[E].y}, hi_ = {ra[E].z, ra[E].w};                                                \
-            lo_ *= xscale; hi_ *= xscale;                                                                             \
             unsigned char* dst = As + (BUF) * ASZ + (f >> 2) * DC_ROWB + (f & 3) * 8;                                 \
             uint32_t lo1, lo2, hi1, hi2;                                                                              \
-            h2_split2(lo_.x, lo_.y, lo1, lo2); h2_split2(hi_.x, hi_.y, hi1, hi2);                                     \
+            h2_split2s(ra[E].x, ra[E].y, xscale, lo1, lo2); h2_split2s(ra[E].z, ra[E].w, xscale, hi1, hi2);            \
             *reinterpret_cast<uint2*>(dst) = make_uint2(lo1, hi1);                                                    \
             *reinterpret_cast<uint2*>(dst + APL) = make_uint2(lo2, hi2);                                              \
         } }

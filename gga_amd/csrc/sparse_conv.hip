@@ -365,7 +365,7 @@ __global__ __launch_bounds__(64 * X9_NW, 2) void sp_conv_x9_kernel(const float* 
         for (int j = 0; j < 4; ++j) {
             const float x = ok && c + 2 * j < cin ? e[2 * j] : 0.f, y = ok && c + 2 * j + 1 < cin ? e[2 * j + 1] : 0.f;
             if (NP == 3) x9_split2(x, y, f1.u[j], f2.u[j], f3.u[j]);
-            else h2_split2(x * xscale, y * xscale, f1.u[j], f2.u[j]);
+            else h2_split2s(x, y, xscale, f1.u[j], f2.u[j]);
         }
     };
 
@@ -530,8 +530,8 @@ __global__ __launch_bounds__(256) void sp_conv_halo_kernel(const float* __restri
         unsigned char* row = smem + j * 128;
         const float4 v = *reinterpret_cast<const float4*>(row + ((lane & 7) << 4));
         uint2 p0, p1;
-        h2_split2(v.x * xscale, v.y * xscale, p0.x, p1.x);
-        h2_split2(v.z * xscale, v.w * xscale, p0.y, p1.y);
+        h2_split2s(v.x, v.y, xscale, p0.x, p1.x);
+        h2_split2s(v.z, v.w, xscale, p0.y, p1.y);
         *reinterpret_cast<uint2*>(row + ((((f >> 1)) ^ sw) << 4) + ((f & 1) << 3)) = p0;
         *reinterpret_cast<uint2*>(row + (((4 + (f >> 1)) ^ sw) << 4) + ((f & 1) << 3)) = p1;
     };
@@ -605,10 +605,10 @@ __global__ __launch_bounds__(256) void sp_conv_halo_kernel(const float* __restri
                 if (far) {
                     const float* row = X + (int64_t)hlist[L] * cin + c * MF_TK + 8 * h + 16 * sk;
                     const float4 lo = *reinterpret_cast<const float4*>(row), hi = *reinterpret_cast<const float4*>(row + 4);
-                    h2_split2(lo.x * xscale, lo.y * xscale, fa[0].u[0], fa[1].u[0]);
-                    h2_split2(lo.z * xscale, lo.w * xscale, fa[0].u[1], fa[1].u[1]);
-                    h2_split2(hi.x * xscale, hi.y * xscale, fa[0].u[2], fa[1].u[2]);
-                    h2_split2(hi.z * xscale, hi.w * xscale, fa[0].u[3], fa[1].u[3]);
+                    h2_split2s(lo.x, lo.y, xscale, fa[0].u[0], fa[1].u[0]);
+                    h2_split2s(lo.z, lo.w, xscale, fa[0].u[1], fa[1].u[1]);
+                    h2_split2s(hi.x, hi.y, xscale, fa[0].u[2], fa[1].u[2]);
+                    h2_split2s(hi.z, hi.w, xscale, fa[0].u[3], fa[1].u[3]);
                 }
             }
         };
@@ -904,7 +904,7 @@ extern "C" int gga_sparse_conv_apply_split(const float* x, const int32_t* map, c
 // 4 %, and without the plane split of the staged rows (-DSPW_ABL_NOSPLIT) the kernel is 16 % faster: a stage is 12 MFMAs per
 // wave behind ~200 vector instructions of split, masking and address arithmetic for its 16 pairs - issue-bound, like the
 // forward kernel's in-register split; the operands would have to arrive as planes to remove it.
-#define SPW_SPLIT4(V, SC, lo1, lo2, hi1, hi2) { h2_split2(V.x * (SC), V.y * (SC), lo1, lo2); h2_split2(V.z * (SC), V.w * (SC), hi1, hi2); }
+#define SPW_SPLIT4(V, SC, lo1, lo2, hi1, hi2) { h2_split2s(V.x, V.y, (SC), lo1, lo2); h2_split2s(V.z, V.w, (SC), hi1, hi2); }
 template <int NI, int NJ, bool VEC, int NP>
 __global__ __launch_bounds__(256, 2) void sp_conv_wgrad_x9_kernel(const float* __restrict__ X, const float* __restrict__ G,
                                                                  const int32_t* __restrict__ map, int64_t n_rows, int kvol,

@@ -99,3 +99,16 @@ __device__ __forceinline__ void h2_split2s(float a, float b, float s, uint32_t& 
     w0 = hb;
     w1 = lb;
 }
+
+// h2_split2s for a scale that is the same in every lane (a kernel-wide operand scale): the scale stays in a scalar register - as a
+// "v" operand the compiler copies it into a vector register in front of every use it cannot hoist (one v_mov per staged piece in
+// the producer waves of dense_conv_ws.hip). Must NOT be given a per-lane value.
+__device__ __forceinline__ void h2_split2u(float a, float b, float s_uniform, uint32_t& w0, uint32_t& w1) {
+    uint32_t hb, lb;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hb) : "v"(a), "s"(s_uniform));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hb) : "v"(b), "s"(s_uniform));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(lb) : "v"(a), "s"(s_uniform), "v"(hb));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lb) : "v"(b), "s"(s_uniform), "v"(hb));
+    w0 = hb;
+    w1 = lb;
+}

@@ -774,24 +774,32 @@ __global__ __launch_bounds__(256, 2) void dense_wgrad3x3_x9_kernel(const float* 
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
 
-    // staging pieces: gy row = 32 px x 16 float4 (2 per thread); x row = 34 px x 16 float4 (3 per thread, 544 used)
+    // staging pieces: gy row = 32 px x 16 float4 (2 per thread); x row = 34 px x 16 float4 (3 per thread, 544 used).
+    // Round 5: no vector arithmetic per row stage beyond the split (every vector instruction costs the matrix pipe of its SIMD
+    // ~9 cycles, tools_dev/micro/ws_interference_probe.hip; the loop had 115 per 54 MFMAs, 40 of them the split). A piece's
+    // byte offset inside an image row is fixed per column strip (gof / xof, 32 bits beside the row's scalar base: the
+    // saddr form of global_load); a piece outside the image reads a pixel INSIDE it (column x0, the nearest row) and is
+    // multiplied by a scale of zero in the split - one select per piece instead of a predicated load and four zeros.
     float4 rg0, rg1, rx0, rx1, rx2;
-#define DW_LOAD_G(Y) {                                                                                                \
-        const bool rowok = (Y) < ye;                                                                                  \
-        { const int f = tid;       const int px = f >> 4, q = f & 15; const bool ok = rowok && x0 + px < W;           \
-          rg0 = ok ? *reinterpret_cast<const float4*>(Gb + ((int64_t)(Y) * prow + (int64_t)(x0 + px) * pcol) * cout + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f); } \
-        { const int f = tid + 256; const int px = f >> 4, q = f & 15; const bool ok = rowok && x0 + px < W;           \
-          rg1 = ok ? *reinterpret_cast<const float4*>(Gb + ((int64_t)(Y) * prow + (int64_t)(x0 + px) * pcol) * cout + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f); } }
-#define DW_LDX(V, E) { const int f = tid + 256 * (E); const int px = f >> 4, q = f & 15; const int ix = x0 - 1 + px;  \
-        const bool ok = rowok && f < 544 && (unsigned)ix < (unsigned)W;                                               \
-        V = ok ? *reinterpret_cast<const float4*>(Xb + ((int64_t)yy * prow + (int64_t)ix * pcol) * cin + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f); }
-#define DW_LOAD_X(Y) { const int yy = (Y); const bool rowok = (unsigned)yy < (unsigned)H; DW_LDX(rx0, 0) DW_LDX(rx1, 1) DW_LDX(rx2, 2) }
+    uint32_t gof0 = 0, gof1 = 0, xof0 = 0, xof1 = 0, xof2 = 0;
+    float gs0 = 0.f, gs1 = 0.f, xs0 = 0.f, xs1 = 0.f, xs2 = 0.f;            // the operand's scale, or 0 for a column outside the image
+#define DW_COLG(OF, SC_, E) { const int f = tid + 256 * (E); const int px = f >> 4, q = f & 15; const bool ok = x0 + px < W;      \
+        OF = (uint32_t)(((x0 + (ok ? px : 0)) * pcol * cout + 4 * q) * 4); SC_ = ok ? gscale : 0.0f; }
+#define DW_COLX(OF, SC_, E) { const int f = tid + 256 * (E); const int px = f >> 4, q = f & 15; const int ix = x0 - 1 + px;       \
+        const bool ok = f < 544 && (unsigned)ix < (unsigned)W;                                                        \
+        OF = (uint32_t)(((ok ? ix : x0) * pcol * cin + 4 * q) * 4); SC_ = ok ? xscale : 0.0f; }
+#define DW_LOAD_G(Y) { const char* rp_ = reinterpret_cast<const char*>(Gb + (int64_t)(Y) * prow * cout);             /* (every row asked for is < ye) */ \
+        rg0 = *reinterpret_cast<const float4*>(rp_ + gof0); rg1 = *reinterpret_cast<const float4*>(rp_ + gof1); }
+#define DW_LOAD_X(Y) { const int yy = (Y); const int yc_ = yy < 0 ? 0 : (yy < H ? yy : H - 1);                        \
+        const char* rp_ = reinterpret_cast<const char*>(Xb + (int64_t)yc_ * prow * cin);                              \
+        rx0 = *reinterpret_cast<const float4*>(rp_ + xof0); rx1 = *reinterpret_cast<const float4*>(rp_ + xof1);       \
+        rx2 = *reinterpret_cast<const float4*>(rp_ + xof2); }
     // piece (pixel px, float4 q) of a row image: channel tile q / 8, byte (q % 8) * 8 of the 64-byte pixel row
 #define DW_SPLIT_STORE(V, BASE, PL, NPX, F, SC) { const int f = (F); const int px = f >> 4, q = f & 15;               \
         unsigned char* dst = (BASE) + (q >> 3) * ((NPX) * 64) + px * 64 + (q & 7) * 8;                                \
         if (NP == 3) {                                                                                                \
             uint32_t lo1, lo2, lo3, hi1, hi2, hi3;                                                                    \
-            x9_split2(V.x, V.y, lo1, lo2, lo3); x9_split2(V.z, V.w, hi1, hi2, hi3);                                   \
+            x9_split2(V.x * (SC), V.y * (SC), lo1, lo2, lo3); x9_split2(V.z * (SC), V.w * (SC), hi1, hi2, hi3);     /* (three planes: SC is 1 or 0) */ \
             *reinterpret_cast<uint2*>(dst) = make_uint2(lo1, hi1);                                                    \
             *reinterpret_cast<uint2*>(dst + (PL)) = make_uint2(lo2, hi2);                                             \
             *reinterpret_cast<uint2*>(dst + (NP - 1) * (PL)) = make_uint2(lo3, hi3);                                  \
@@ -802,10 +810,12 @@ __global__ __launch_bounds__(256, 2) void dense_wgrad3x3_x9_kernel(const float* 
             *reinterpret_cast<uint2*>(dst + (PL)) = make_uint2(lo2, hi2);                                             \
         } }
 #define DW_STORE_G(Y) { unsigned char* base = Gs + ((Y) & 1) * DW_GROW;                                               \
-        DW_SPLIT_STORE(rg0, base, DW_GPL, 32, tid, gscale) DW_SPLIT_STORE(rg1, base, DW_GPL, 32, tid + 256, gscale) }
+        DW_SPLIT_STORE(rg0, base, DW_GPL, 32, tid, gs0) DW_SPLIT_STORE(rg1, base, DW_GPL, 32, tid + 256, gs1) }
 #define DW_STORE_X(Y) { unsigned char* base = Xs + (((Y) + 4) & 3) * DW_XROW;                                         \
-        DW_SPLIT_STORE(rx0, base, DW_XPL, 34, tid, xscale) DW_SPLIT_STORE(rx1, base, DW_XPL, 34, tid + 256, xscale)   \
-        if (tid + 512 < 544) DW_SPLIT_STORE(rx2, base, DW_XPL, 34, tid + 512, xscale) }
+        const bool rowok_ = (unsigned)(Y) < (unsigned)H;                           /* uniform: a scalar condition */  \
+        const float s0_ = rowok_ ? xs0 : 0.0f, s1_ = rowok_ ? xs1 : 0.0f, s2_ = rowok_ ? xs2 : 0.0f;                 \
+        DW_SPLIT_STORE(rx0, base, DW_XPL, 34, tid, s0_) DW_SPLIT_STORE(rx1, base, DW_XPL, 34, tid + 256, s1_)         \
+        if (tid + 512 < 544) DW_SPLIT_STORE(rx2, base, DW_XPL, 34, tid + 512, s2_) }
 
     // transposed fragment of a [pixel][32 ch] image: lane l gets channel l%32, pixels P0 + 8*(l/32) .. +7
     const int grp = lane >> 4, li = lane & 15;
@@ -823,6 +833,8 @@ __global__ __launch_bounds__(256, 2) void dense_wgrad3x3_x9_kernel(const float* 
         x0 = strip * 32;
         Xb = X + (int64_t)b * H * W * cin + ci0;
         Gb = G + (int64_t)b * H * W * cout + co0;
+        DW_COLG(gof0, gs0, 0) DW_COLG(gof1, gs1, 1)
+        DW_COLX(xof0, xs0, 0) DW_COLX(xof1, xs1, 1) DW_COLX(xof2, xs2, 2)
     }
     ye = (int)(r1 - idx < (int64_t)(H - ys) ? ys + (r1 - idx) : H);      // rows of this column in my share
     idx += ye - ys;
@@ -893,7 +905,8 @@ __global__ __launch_bounds__(256, 2) void dense_wgrad3x3_x9_kernel(const float* 
     }
     }
 #undef DW_LOAD_G
-#undef DW_LDX
+#undef DW_COLG
+#undef DW_COLX
 #undef DW_LOAD_X
 #undef DW_SPLIT_STORE
 #undef DW_STORE_G
@@ -975,6 +988,9 @@ extern "C" int gga_dense_wgrad3x3_block_amax(const float* x, const float* grad_y
                 "gga_dense_wgrad3x3: planes must be 3 (bf16) or 2 (fp16, with the operands' absmax bits)");
     GGA_REQUIRE(B >= 1 && H >= 1 && W >= 1 && cin >= 64 && cout >= 64 && (cin & 63) == 0 && (cout & 63) == 0,
                 "gga_dense_wgrad3x3: cin and cout must be multiples of 64 (got %d -> %d)", cin, cout);
+    GGA_REQUIRE((int64_t)H * W * (cin > cout ? cin : cout) * 4 < ((int64_t)1 << 31),
+                "gga_dense_wgrad3x3: one image of an operand must stay below 2 GiB (32-bit piece offsets; got %d x %d x %d channels)", H, W,
+                cin > cout ? cin : cout);
     if (workspace_bytes < gga_dense_wgrad3x3_workspace_bytes(B, H, W, cin, cout)) {
         gga_set_error("gga_dense_wgrad3x3: workspace too small");
         return GGA_ERR_WORKSPACE;

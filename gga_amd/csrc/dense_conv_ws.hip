@@ -100,7 +100,7 @@ __global__ __launch_bounds__(512, 2) void dense_conv3x3_ws_kernel(const float* _
         if (f < HP * 4) {                                                                                             \
             unsigned char* dst = As + (BUF) * ASZ + (f >> 2) * DC_ROWB + (f & 3) * 8;                                 \
             uint32_t lo1, lo2, hi1, hi2;                                                                              \
-            h2_split2s(ra[E].x, ra[E].y, xscale, lo1, lo2); h2_split2s(ra[E].z, ra[E].w, xscale, hi1, hi2);            \
+            h2_split2u(ra[E].x, ra[E].y, xscale, lo1, lo2); h2_split2u(ra[E].z, ra[E].w, xscale, hi1, hi2);            \
             *reinterpret_cast<uint2*>(dst) = make_uint2(lo1, hi1);                                                    \
             *reinterpret_cast<uint2*>(dst + APL) = make_uint2(lo2, hi2);                                              \
         } }

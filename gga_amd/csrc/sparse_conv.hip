@@ -360,6 +360,15 @@ __global__ __launch_bounds__(64 * X9_NW, 2) void sp_conv_x9_kernel(const float* 
     // 8 floats -> one 8 x bf16 fragment per plane
     union Frag { mf_v8bf v; uint32_t u[4]; };
     auto split8 = [&](const float4& lo, const float4& hi, bool ok, int c, Frag& f1, Frag& f2, Frag& f3) {
+        if (VEC && NP == 2) {
+            // (cin % 4 == 0: a float4 is inside the channels or outside; an absent neighbour or a float4 beyond cin is zeroed by
+            // its SCALE - two selects per fragment instead of a compare and a select per element: 46 of the stage's 83 vector
+            // instructions, each of which costs the matrix pipe ~9 cycles)
+            const float slo = ok && c < cin ? xscale : 0.0f, shi = ok && c + 4 < cin ? xscale : 0.0f;
+            h2_split2s(lo.x, lo.y, slo, f1.u[0], f2.u[0]); h2_split2s(lo.z, lo.w, slo, f1.u[1], f2.u[1]);
+            h2_split2s(hi.x, hi.y, shi, f1.u[2], f2.u[2]); h2_split2s(hi.z, hi.w, shi, f1.u[3], f2.u[3]);
+            return;
+        }
         const float e[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -930,8 +939,12 @@ __global__ __launch_bounds__(256, 2) void sp_conv_wgrad_x9_kernel(const float* _
     constexpr int XSZ = NP * XPL, GSZ = NP * GPL;
     __shared__ __attribute__((aligned(16))) unsigned char Xs[2 * XSZ];
     __shared__ __attribute__((aligned(16))) unsigned char Gs[2 * GSZ];
-    __shared__ int pin[SPW_SUB];          // compacted valid pairs of the sub-chunk: input row
-    __shared__ uint16_t pout[SPW_SUB];    //                                          output row (sub-chunk local)
+    // compacted valid pairs of the sub-chunk as BYTE OFFSETS (round 5: multiplied once per pair here, not once per staged piece -
+    // a pair's row is fetched by CI / 4 + CO / 4 threads): the input row's inside X, the output row's inside the sub-chunk of G
+    // (32 bits: a kernel that meets an X row beyond 4 GiB traps). Entries np .. the next multiple of PAIRS point at row 0 of X /
+    // of the sub-chunk: a stage's tail pieces read valid memory and are multiplied by a scale of zero in the split.
+    __shared__ uint32_t pin[SPW_SUB];
+    __shared__ uint32_t pout[SPW_SUB];
     __shared__ int wtot[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // Workgroup -> (offset, row chunk). The kvol workgroups of a chunk read the same G rows (and, on spatially ordered levels,
@@ -1000,23 +1013,27 @@ __global__ __launch_bounds__(256, 2) void sp_conv_wgrad_x9_kernel(const float* _
         for (int w = 0; w < 4; ++w) { const int c = wtot[w]; off += w < wave ? c : 0; np += c; }
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-            if (mv[j] >= 0) { pin[off] = mv[j]; pout[off] = (uint16_t)(8 * tid + j); ++off; }
+            if (mv[j] >= 0) {
+                const uint64_t xo = (uint64_t)(uint32_t)mv[j] * (uint64_t)xs * 4u;
+                if (xo >> 32) __builtin_trap();
+                pin[off] = (uint32_t)xo; pout[off] = (uint32_t)((8 * tid + j) * (int)gs * 4); ++off;
+            }
+        if (tid < PAIRS && np + tid < SPW_SUB) { pin[np + tid] = 0u; pout[np + tid] = 0u; }
         __syncthreads();
         if (np == 0) continue;
+        const char* Gsub = reinterpret_cast<const char*>(G + r0 * gs);
 
 #define SW_LOAD(P0, xr, gr)                                                                                          \
         _Pragma("unroll") for (int e = 0; e < LX; ++e) {                                                             \
             const int t = tid + 256 * e, pp = t / (CI / 4), q = (t - pp * (CI / 4)) * 4;                             \
-            const int pi = (P0) + pp < np ? (P0) + pp : 0;                                                           \
-            const float* src = X + (int64_t)pin[pi] * xs;                                                            \
+            const float* src = reinterpret_cast<const float*>(reinterpret_cast<const char*>(X) + pin[(P0) + pp]);    \
             if (VEC) xr[e] = *reinterpret_cast<const float4*>(src + (q < cin ? q : 0));                              \
             else xr[e] = make_float4(src[q < cin ? q : 0], src[q + 1 < cin ? q + 1 : 0], src[q + 2 < cin ? q + 2 : 0], \
                                      src[q + 3 < cin ? q + 3 : 0]);                                                  \
         }                                                                                                            \
         _Pragma("unroll") for (int e = 0; e < LG; ++e) {                                                             \
             const int t = tid + 256 * e, pp = t / (CO / 4), q = (t - pp * (CO / 4)) * 4;                             \
-            const int pi = (P0) + pp < np ? (P0) + pp : 0;                                                           \
-            const float* src = G + (r0 + pout[pi]) * gs;                                                             \
+            const float* src = reinterpret_cast<const float*>(Gsub + pout[(P0) + pp]);                               \
             if (VEC) gr[e] = *reinterpret_cast<const float4*>(src + (q < cout ? q : 0));                             \
             else gr[e] = make_float4(src[q < cout ? q : 0], src[q + 1 < cout ? q + 1 : 0], src[q + 2 < cout ? q + 2 : 0], \
                                      src[q + 3 < cout ? q + 3 : 0]);                                                 \
@@ -1026,7 +1043,7 @@ __global__ __launch_bounds__(256, 2) void sp_conv_wgrad_x9_kernel(const float* _
         unsigned char* dst = (BASE) + ((Q4) >> 3) * (PAIRS * 64) + (PP) * 64 + ((Q4) & 7) * 8;                       \
         if (NP == 3) {                                                                                               \
             uint32_t lo1, lo2, lo3, hi1, hi2, hi3;                                                                   \
-            x9_split2(V.x, V.y, lo1, lo2, lo3); x9_split2(V.z, V.w, hi1, hi2, hi3);                                  \
+            x9_split2(V.x * (SC), V.y * (SC), lo1, lo2, lo3); x9_split2(V.z * (SC), V.w * (SC), hi1, hi2, hi3);    /* (three planes: SC is 1 or 0) */ \
             *reinterpret_cast<uint2*>(dst) = make_uint2(lo1, hi1);                                                   \
             *reinterpret_cast<uint2*>(dst + (PL)) = make_uint2(lo2, hi2);                                            \
             *reinterpret_cast<uint2*>(dst + (NP - 1) * (PL)) = make_uint2(lo3, hi3);                                 \
@@ -1036,20 +1053,32 @@ __global__ __launch_bounds__(256, 2) void sp_conv_wgrad_x9_kernel(const float* _
             *reinterpret_cast<uint2*>(dst) = make_uint2(lo1, hi1);                                                   \
             *reinterpret_cast<uint2*>(dst + (PL)) = make_uint2(lo2, hi2);                                            \
         } }
+    // VEC: a piece outside the stage's pairs or the operand's channels is zeroed by its SCALE (one select per piece; the
+    // values it read are some valid row's); otherwise element by element as before
 #define SW_STORE(BUF, P0, xr, gr)                                                                                    \
         _Pragma("unroll") for (int e = 0; e < LX; ++e) {                                                             \
             const int t = tid + 256 * e, pp = t / (CI / 4), q = (t - pp * (CI / 4)) * 4;                             \
             const bool ok = (P0) + pp < np && pp < PAIRS;                                                            \
-            const float4 v = make_float4(ok && q < cin ? xr[e].x : 0.f, ok && q + 1 < cin ? xr[e].y : 0.f,           \
-                                         ok && q + 2 < cin ? xr[e].z : 0.f, ok && q + 3 < cin ? xr[e].w : 0.f);      \
-            if (pp < PAIRS) SW_SPLIT_STORE(v, Xs + (BUF) * XSZ, XPL, pp, q >> 2, xscale)                             \
+            if (VEC) {                                                                                               \
+                const float sc_ = ok && q < cin ? xscale : 0.0f;                                                     \
+                if (pp < PAIRS) SW_SPLIT_STORE(xr[e], Xs + (BUF) * XSZ, XPL, pp, q >> 2, sc_)                        \
+            } else {                                                                                                 \
+                const float4 v = make_float4(ok && q < cin ? xr[e].x : 0.f, ok && q + 1 < cin ? xr[e].y : 0.f,       \
+                                             ok && q + 2 < cin ? xr[e].z : 0.f, ok && q + 3 < cin ? xr[e].w : 0.f);  \
+                if (pp < PAIRS) SW_SPLIT_STORE(v, Xs + (BUF) * XSZ, XPL, pp, q >> 2, xscale)                         \
+            }                                                                                                        \
         }                                                                                                            \
         _Pragma("unroll") for (int e = 0; e < LG; ++e) {                                                             \
             const int t = tid + 256 * e, pp = t / (CO / 4), q = (t - pp * (CO / 4)) * 4;                             \
             const bool ok = (P0) + pp < np && pp < PAIRS;                                                            \
-            const float4 v = make_float4(ok && q < cout ? gr[e].x : 0.f, ok && q + 1 < cout ? gr[e].y : 0.f,         \
-                                         ok && q + 2 < cout ? gr[e].z : 0.f, ok && q + 3 < cout ? gr[e].w : 0.f);    \
-            if (pp < PAIRS) SW_SPLIT_STORE(v, Gs + (BUF) * GSZ, GPL, pp, q >> 2, gscale)                             \
+            if (VEC) {                                                                                               \
+                const float sc_ = ok && q < cout ? gscale : 0.0f;                                                    \
+                if (pp < PAIRS) SW_SPLIT_STORE(gr[e], Gs + (BUF) * GSZ, GPL, pp, q >> 2, sc_)                        \
+            } else {                                                                                                 \
+                const float4 v = make_float4(ok && q < cout ? gr[e].x : 0.f, ok && q + 1 < cout ? gr[e].y : 0.f,     \
+                                             ok && q + 2 < cout ? gr[e].z : 0.f, ok && q + 3 < cout ? gr[e].w : 0.f); \
+                if (pp < PAIRS) SW_SPLIT_STORE(v, Gs + (BUF) * GSZ, GPL, pp, q >> 2, gscale)                         \
+            }                                                                                                        \
         }
 #define SW_MM(PA, PB) _Pragma("unroll") for (int t = 0; t < TPW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PA.v, PB[t].v, acc[t], 0, 0, 0);
 #define SW_MH(PA, PB) _Pragma("unroll") for (int t = 0; t < TPW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(mf_v8h, PA.v), __builtin_bit_cast(mf_v8h, PB[t].v), acc[t], 0, 0, 0);
@@ -1081,20 +1110,20 @@ __global__ __launch_bounds__(256, 2) void sp_conv_wgrad_x9_kernel(const float* _
         SW_STORE(0, 0, xa, ga);
         if (PAIRS < np) { SW_LOAD(PAIRS, xb, gb_); }
         __syncthreads();
-        int buf = 0, p0 = 0;
+        int p0 = 0;                                        // (the image a stage multiplies alternates 0, 1: literal in each half)
         while (true) {
             if (p0 + 2 * PAIRS < np) { SW_LOAD(p0 + 2 * PAIRS, xa, ga); }
-            SW_COMPUTE(buf)
+            SW_COMPUTE(0)
             if (p0 + PAIRS >= np) break;
-            SW_STORE(buf ^ 1, p0 + PAIRS, xb, gb_);        // buf ^ 1: last read before the previous barrier
+            SW_STORE(1, p0 + PAIRS, xb, gb_);              // image 1: last read before the previous barrier
             __syncthreads();
-            buf ^= 1; p0 += PAIRS;
+            p0 += PAIRS;
             if (p0 + 2 * PAIRS < np) { SW_LOAD(p0 + 2 * PAIRS, xb, gb_); }
-            SW_COMPUTE(buf)
+            SW_COMPUTE(1)
             if (p0 + PAIRS >= np) break;
-            SW_STORE(buf ^ 1, p0 + PAIRS, xa, ga);
+            SW_STORE(0, p0 + PAIRS, xa, ga);
             __syncthreads();
-            buf ^= 1; p0 += PAIRS;
+            p0 += PAIRS;
         }
     }
 #undef SW_COMPUTE

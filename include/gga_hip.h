@@ -473,7 +473,9 @@ int gga_dense_wgrad3x3_planes(const float* x, const float* grad_y, int B, int H,
 /* The same with the absmax of an operand given per 64-channel block (amax_x[ci / 64], amax_grad_y[co / 64]) when its
  * *_per_block flag is set: dW[ci][co] only sees channel ci of x and channel co of grad_y, so on two fp16 planes a block whose
  * values lie far below the tensor's largest magnitude keeps its own 22 significant bits (the 960-channel gradient of the 15 head
- * branches: regression branches with a few object cells beside the heat-map branches). */
+ * branches: regression branches with a few object cells beside the heat-map branches).
+ * One image of an operand (H * W * max(cin, cout) floats) must stay below 2 GiB: the kernel addresses a staged piece by a 32-bit
+ * offset inside its image row beside a scalar row base (GGA_ERR_* otherwise). */
 int gga_dense_wgrad3x3_block_amax(const float* x, const float* grad_y, int B, int H, int W, int cin, int cout,
                                   float* grad_weight, int64_t stride_co, int64_t stride_ci, int64_t stride_ky,
                                   int64_t stride_kx, int transposed, int planes, const uint32_t* amax_x, int amax_x_per_block,
@@ -512,7 +514,9 @@ size_t gga_sparse_conv_wgrad_workspace_bytes(int64_t n_rows, int kvol, int cin, 
 int gga_sparse_conv_wgrad_split(const float* x, const float* grad_out, const int32_t* nbr, int64_t n_rows,
                                 int kvol, int cin, int cout, float* grad_weight, void* workspace,
                                 size_t workspace_bytes, void* stream);
-/* The same with x / grad_out column blocks (<= 128 wide) of wider matrices: row strides in floats. */
+/* The same with x / grad_out column blocks (<= 128 wide) of wider matrices: row strides in floats.
+ * Every x row a rule-book entry names must start below byte 4 GiB of x (32-bit pair offsets; the kernel TRAPS - the stream
+ * reports a fault - on a row beyond it: 8 M rows of 128 floats). */
 int gga_sparse_conv_wgrad_split_strided(const float* x, int64_t x_row_stride, const float* grad_out,
                                         int64_t grad_out_row_stride, const int32_t* nbr, int64_t n_rows, int kvol, int cin,
                                         int cout, float* grad_weight, void* workspace, size_t workspace_bytes, void* stream);

@@ -29,6 +29,19 @@ def _i3(v):
     return (C.c_int32 * 3)(*v)
 
 
+def mask_order(mask, kvol):
+    """Rows in ascending order of their offset mask, ties in row order: what ``torch.sort(mask, stable=True)[1].int()`` returns,
+    from an LSD radix sort over the ``kvol`` mask bits (gga_sparse_mask_order, include/gga_hip.h) - the framework's stable
+    sort of int32 keys is a 22-launch merge sort per rule book on this stack."""
+    L = _lib.lib()
+    n = int(mask.shape[0])
+    order = torch.empty(n, dtype=torch.int32, device=mask.device)
+    nbytes = int(L.gga_sparse_mask_order_workspace_bytes(n))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=mask.device)
+    check(L.gga_sparse_mask_order(F._p(mask), n, int(kvol), F._p(order), F._p(ws), nbytes, F._stream()), 'gga_sparse_mask_order')
+    return order
+
+
 class _Rulebook:
     """Gather map [kvol, n_rows] + per-row offset bit mask + mask-sorted processing order."""
 
@@ -43,7 +56,7 @@ class _Rulebook:
             check(_lib.lib().gga_sparse_rowmask(F._p(nbr), n, kvol, F._p(self.mask), F._stream()), 'gga_sparse_rowmask')
             # index preprocessing (once per level, shared by every conv on it): rows with the same
             # neighbour pattern become adjacent, so a 128-row tile skips the offsets none of them uses
-            self.perm = torch.sort(self.mask, stable=True)[1].int()
+            self.perm = mask_order(self.mask, kvol)
 
     def halo(self):
         if self._halo is None:

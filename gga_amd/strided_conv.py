@@ -55,7 +55,8 @@ class _Book:
         check(_lib.lib().gga_sparse_rowmask(F._p(m), n, kvol, F._p(mask), F._stream()), 'gga_sparse_rowmask')
         if bool((mask == mask[0]).all()):          # every row has the same taps: the natural order is the best one
             return mask, None
-        return mask, torch.sort(mask, stable=True)[1].int()
+        from .sparse import mask_order
+        return mask, mask_order(mask, kvol)
 
 
 def book(B, H, W, k, s, p, device):

@@ -275,6 +275,13 @@ int gga_sparse_rulebook(const int32_t* out_coors, int64_t n_out, const int32_t* 
 /* Bit k of mask[r] is set when map[k][r] >= 0 (kvol <= 32). Sorting rows by this mask gives
  * tiles whose rows use the same kernel offsets; the conv kernel skips the others. */
 int gga_sparse_rowmask(const int32_t* map, int64_t n_rows, int kvol, uint32_t* mask, void* stream);
+/* order[i] = the row with the i-th smallest mask, rows with equal masks in row order (a stable sort of the int32 masks: the
+ * processing order gga_sparse_conv_apply_split takes as `perm`; replaces the framework's stable sort, sparse.py). kvol <= 32
+ * mask bits take part; masks are compared as signed 32-bit values when kvol == 32. workspace: device memory of
+ * gga_sparse_mask_order_workspace_bytes(n_rows) bytes. */
+size_t gga_sparse_mask_order_workspace_bytes(int64_t n_rows);
+int gga_sparse_mask_order(const uint32_t* mask, int64_t n_rows, int kvol, int32_t* order, void* workspace,
+                          size_t workspace_bytes, void* stream);
 
 /* Weights in the MFMA fragment order the conv kernel stages through LDS (one 16-byte copy per
  * thread instead of a transposing scatter): packed[k][chunk][lane][g][t][j] =

@@ -501,3 +501,22 @@ def test_index_plan_dies_with_its_coordinates_without_the_cyclic_collector():
         assert plan() is None and level() is None
     finally:
         gc.enable()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('kvol,n', [(27, 1), (27, 1000), (27, 513_777), (32, 70_001), (8, 4097), (9, 250_000)])
+def test_mask_order_is_the_stable_sort_of_the_masks(kvol, n):
+    """gga_sparse_mask_order (an LSD radix sort over the kvol mask bits) against torch.sort(mask, stable=True): a stable sort has
+    one answer - the same int32 order, ties in row order, the sign bit of a 32-offset mask included."""
+    from gga_amd.sparse import mask_order
+    g = torch.Generator().manual_seed(7 * kvol + n)
+    few = torch.randint(0, 2 ** 31 - 1, (37,), generator=g, dtype=torch.int64)               # few distinct patterns: many ties
+    m = few[torch.randint(0, 37, (n,), generator=g)]
+    m[::3] = torch.randint(0, 2 ** 31 - 1, (len(m[::3]),), generator=g, dtype=torch.int64)
+    m = m & ((1 << kvol) - 1)
+    if kvol == 32:
+        m = m | (torch.randint(0, 2, (n,), generator=g, dtype=torch.int64) << 31)
+    mask = torch.from_numpy(m.numpy().astype(np.uint32).view(np.int32)).cuda()
+    got = mask_order(mask, kvol)
+    want = torch.sort(mask, stable=True)[1].int()
+    assert got.dtype == torch.int32 and torch.equal(got, want)

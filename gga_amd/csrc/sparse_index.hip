@@ -369,9 +369,12 @@ extern "C" int gga_sparse_rowmask(const int32_t* map, int64_t n_rows, int kvol, 
 // radix_sort_pairs, a counting iterator as the values: 8-10 launches) instead of the framework's stable sort of int32 keys,
 // which is a merge sort on this stack - 22 launches of merge-path kernels per rule book, 1.3-1.8 ms of the sparse config's step.
 // A stable sort has one answer, so the order is the same.
+// (rocPRIM's default hands anything up to 2^20 items to its merge sort - the 42 launches per rule book this entry point exists
+// to avoid; with the limit at 4096 a level goes through Onesweep: one histogram and one pass per 8 mask bits)
+typedef rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 4096> sp_order_config;
 static size_t sp_order_temp_bytes(int64_t n_rows, int bits) {
     size_t tb = 0;
-    (void)rocprim::radix_sort_pairs(nullptr, tb, (const int32_t*)nullptr, (int32_t*)nullptr, rocprim::counting_iterator<int32_t>(0),
+    (void)rocprim::radix_sort_pairs<sp_order_config>(nullptr, tb, (const int32_t*)nullptr, (int32_t*)nullptr, rocprim::counting_iterator<int32_t>(0),
                                     (int32_t*)nullptr, (size_t)n_rows, 0, (unsigned)bits, (hipStream_t)0);
     return (tb + 255) / 256 * 256;
 }
@@ -392,7 +395,7 @@ extern "C" int gga_sparse_mask_order(const uint32_t* mask, int64_t n_rows, int k
     // (kvol == 32: bit 31 is the sign of the int32 the mask is kept in; the keys are compared as signed, like the sort this replaces)
     size_t tb = sp_order_temp_bytes(n_rows, kvol);
     int32_t* keys_out = reinterpret_cast<int32_t*>(static_cast<unsigned char*>(workspace) + sp_order_temp_bytes(n_rows, 32));
-    const hipError_t e = rocprim::radix_sort_pairs(workspace, tb, reinterpret_cast<const int32_t*>(mask), keys_out,
+    const hipError_t e = rocprim::radix_sort_pairs<sp_order_config>(workspace, tb, reinterpret_cast<const int32_t*>(mask), keys_out,
                                                    rocprim::counting_iterator<int32_t>(0), order, (size_t)n_rows, 0, (unsigned)kvol,
                                                    (hipStream_t)stream);
     if (e != hipSuccess) {

@@ -205,6 +205,18 @@ __global__ __launch_bounds__(1024) void bn_fwd_final_kernel(const double* __rest
     scale_shift[C + c] = sh;
 }
 
+// last-use streaming reads (-DBN_NT_LOADS: an experiment build, tools_dev/exp_libs): the conv output x and the incoming gradient
+// are not read again in this pass; a non-temporal load leaves the L2 / Infinity Cache lines to the tensor being written
+typedef float bn_v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 bn_ld_stream(const float4* p) {
+#ifdef BN_NT_LOADS
+    const bn_v4f v = __builtin_nontemporal_load(reinterpret_cast<const bn_v4f*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+#else
+    return *p;
+#endif
+}
+
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float4* __restrict__ x, const float4* __restrict__ res,
                                                       const float* __restrict__ scale_shift, BnGeom g, int relu,
                                                       float4* __restrict__ y, unsigned long long* __restrict__ bits,
@@ -224,7 +236,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float4* __restrict_
             const int64_t e = eb + u * stride;
             xv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
             rv[u] = xv[u];
-            if (e < g.n4) { xv[u] = x[e]; if (res) rv[u] = res[e]; }
+            if (e < g.n4) { xv[u] = bn_ld_stream(x + e); if (res) rv[u] = res[e]; }
         }
 #pragma unroll
         for (int u = 0; u < BN_U; ++u) {
@@ -299,7 +311,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float4* __restr
         for (int u = 0; u < BN_U; ++u) {
             const int64_t e = eb + u * stride;
             if (e < g.n4) {
-                gv[u] = dy[bn_strided(g, e, cg)]; xv[u] = x[e];
+                gv[u] = bn_ld_stream(dy + bn_strided(g, e, cg)); xv[u] = bn_ld_stream(x + e);
                 if (relu == 1) {
                     const unsigned long long* w = bits + (e >> 6) * 4;
 #pragma unroll

@@ -2,7 +2,7 @@
 #   r05_bench_default_output.json / _traced_output.json / _kernel_stats.csv   the driver's command, untraced and under rocprofv3 --kernel-trace --stats
 #   r05_pp_bs16_channels_last_steady_state.csv, r05_second_bs8_steady_state.csv  per-step kernel tables (last 3 of 8 steps)
 #   r05_pp_pmc.json, r05_second_pmc.json, r05_scatter_pmc.json                 PMC passes (separate --pmc runs, kernel-trace only)
-#   r05_sp_halo2.txt                                                          GGA_SP_HALO=2 (64-column halo form) against the default, SECOND leg
+#   (r05_sp_halo2.txt was taken before GGA_SP_HALO=2 left the tree)
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 cd /tmp
@@ -16,9 +16,6 @@ timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/tr_second -- py
 python3 $R/tools_dev/trace_summary.py /tmp/tr_second --steps 3 --top 90 --out $R/gpurun_out/r05_second_bs8_steady_state.csv | head -2
 timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/tr_pp -- python3 $R/bench.py --no-second-trunk --no-pgd --no-planes3 --no-fcaf3d --no-cpu-baseline --no-roofline --no-loader-fed --steps 8 --warmup 4 > /tmp/tr_pp.log 2>&1
 python3 $R/tools_dev/trace_summary.py /tmp/tr_pp --steps 3 --top 90 --out $R/gpurun_out/r05_pp_bs16_channels_last_steady_state.csv | head -2
-for h in 1 2 1 2; do GGA_SP_HALO=$h python3 $R/bench.py --config $R/configs/gga/gga_kitti_config.py --batch 8 --steps 20 --warmup 5 --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 | python3 -c "
-import json,sys; d=json.loads(sys.stdin.read()); print('GGA_SP_HALO=$h second step ms', d['ms_per_step'])"; done > $R/gpurun_out/r05_sp_halo2.txt 2>&1
-cat $R/gpurun_out/r05_sp_halo2.txt
 bash $R/tools_dev/pmc_scatter.sh r05 | tail -4
 bash $R/tools_dev/pmc_pp.sh r05 | tail -8
 sed -e 's/r04_second_pmc.json/r05_second_pmc.json/' $R/tools_dev/pmc_second.sh > /tmp/pmc_second_r05.sh; bash /tmp/pmc_second_r05.sh | tail -10

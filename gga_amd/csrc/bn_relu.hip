@@ -205,11 +205,12 @@ __global__ __launch_bounds__(1024) void bn_fwd_final_kernel(const double* __rest
     scale_shift[C + c] = sh;
 }
 
-// last-use streaming reads (-DBN_NT_LOADS: an experiment build, tools_dev/exp_libs): the conv output x and the incoming gradient
-// are not read again in this pass; a non-temporal load leaves the L2 / Infinity Cache lines to the tensor being written
+// Last-use streaming reads: the conv output x and the incoming gradient are not read again in this pass, so a non-temporal load
+// leaves the L2 / Infinity Cache lines to the tensor being written, which the next kernel reads. Round 5, same-box A/B
+// (tools_dev/ab_lib.sh, profiles/r05_ab_bn_nt.txt): PointPillars step -0.1 ms, sparse config -0.3..0.4 ms. -DBN_NO_NT_LOADS: plain loads.
 typedef float bn_v4f __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 bn_ld_stream(const float4* p) {
-#ifdef BN_NT_LOADS
+#ifndef BN_NO_NT_LOADS
     const bn_v4f v = __builtin_nontemporal_load(reinterpret_cast<const bn_v4f*>(p));
     return make_float4(v.x, v.y, v.z, v.w);
 #else

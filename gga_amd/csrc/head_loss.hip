@@ -92,10 +92,15 @@ extern "C" int gga_gather_pred_bwd(const float* grad_pred, const int64_t* ind, c
                 "gga_gather_pred_bwd: null pointer argument");
     GGA_REQUIRE(B >= 1 && K >= 1 && H >= 1 && W >= 1, "gga_gather_pred_bwd: bad sizes");
     const size_t hw = (size_t)H * W * sizeof(float);
-    GGA_CHECK_HIP(hipMemsetAsync(g_reg, 0, hw * B * 2, stream), "gather bwd memset");
-    GGA_CHECK_HIP(hipMemsetAsync(g_height, 0, hw * B, stream), "gather bwd memset");
-    GGA_CHECK_HIP(hipMemsetAsync(g_dim, 0, hw * B * 3, stream), "gather bwd memset");
-    GGA_CHECK_HIP(hipMemsetAsync(g_rot, 0, hw * B * 2, stream), "gather bwd memset");
+    const size_t fl = (size_t)H * W * B;
+    if (g_height == g_reg + 2 * fl && g_dim == g_height + fl && g_rot == g_dim + 3 * fl) {      // four views of one allocation: one memset
+        GGA_CHECK_HIP(hipMemsetAsync(g_reg, 0, hw * B * 8, stream), "gather bwd memset");
+    } else {
+        GGA_CHECK_HIP(hipMemsetAsync(g_reg, 0, hw * B * 2, stream), "gather bwd memset");
+        GGA_CHECK_HIP(hipMemsetAsync(g_height, 0, hw * B, stream), "gather bwd memset");
+        GGA_CHECK_HIP(hipMemsetAsync(g_dim, 0, hw * B * 3, stream), "gather bwd memset");
+        GGA_CHECK_HIP(hipMemsetAsync(g_rot, 0, hw * B * 2, stream), "gather bwd memset");
+    }
     const int n = B * K;
     hipLaunchKernelGGL(gather_pred_bwd_kernel, dim3((n * 8 + 255) / 256), dim3(256), 0, stream, grad_pred, ind, mask,
                        n, K, (int64_t)H * W, g_reg, g_height, g_dim, g_rot);

@@ -113,8 +113,7 @@ extern "C" int gga_sparse_build_index(const int32_t* coors, int64_t n, int B, in
     }
     const uint64_t cap = sp_cap(n);
     SpIndex ix = sp_index_view(index, n);
-    GGA_CHECK_HIP(hipMemsetAsync(ix.keys, 0xFF, cap * 8, stream), "sparse index memset");
-    GGA_CHECK_HIP(hipMemsetAsync(ix.vals, 0xFF, cap * 4, stream), "sparse index memset");   // -1
+    GGA_CHECK_HIP(hipMemsetAsync(ix.keys, 0xFF, cap * 12, stream), "sparse index memset");   // keys empty, the values behind them -1: one fill
     if (n > 0) {
         const SpDims d = { B, D, H, W };
         hipLaunchKernelGGL(sp_index_insert_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
@@ -266,8 +265,7 @@ extern "C" int gga_sparse_conv_out_sites(const int32_t* in_coors, int64_t n_in, 
     int32_t* cnt = (int32_t*)w; w += gga_align_up((size_t)n_in * 4, 256);
     int32_t* excl = (int32_t*)w; w += gga_align_up((size_t)n_in * 4, 256);
     int32_t* bsum = (int32_t*)w;
-    GGA_CHECK_HIP(hipMemsetAsync(ox_.keys, 0xFF, cap * 8, stream), "out sites memset");
-    GGA_CHECK_HIP(hipMemsetAsync(ox_.vals, 0xFF, cap * 4, stream), "out sites memset");
+    GGA_CHECK_HIP(hipMemsetAsync(ox_.keys, 0xFF, cap * 12, stream), "out sites memset");      // keys and the values behind them
     GGA_CHECK_HIP(hipMemsetAsync(first, 0xFF, cap * 8, stream), "out sites memset");
     const SpConvGeom g = { kernel[0], kernel[1], kernel[2], stride[0], stride[1], stride[2], pad[0], pad[1], pad[2] };
     const SpDims od = { B, out_dhw[0], out_dhw[1], out_dhw[2] };

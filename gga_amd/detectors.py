@@ -188,10 +188,12 @@ class MVXTwoStageDetector_GGA(nn.Module):
     def _parse_losses(self, losses):
         log_vars = OrderedDict()
         for name, value in losses.items():
+            # (the mean of a 0-d tensor is the tensor: no reduce launch - and no division in backward - for the 18 scalar terms of a
+            # CenterPoint-style head)
             if isinstance(value, torch.Tensor):
-                log_vars[name] = value.mean()
+                log_vars[name] = value.mean() if value.dim() else value
             elif isinstance(value, list):
-                log_vars[name] = sum(v.mean() for v in value)
+                log_vars[name] = sum(v.mean() if v.dim() else v for v in value)
             else:
                 raise TypeError(f'{name} is not a tensor or list of tensors')
         pal = getattr(getattr(self, 'pts_bbox_head', None), 'pal_backprop', False)

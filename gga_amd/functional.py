@@ -457,10 +457,13 @@ class _GaussianFocal(torch.autograd.Function):
                                    ws.numel(), _stream()), 'gga_focal_loss_fwd')
         ctx.save_for_backward(logits, target, out)
         ctx.cfg = (alpha, gamma, scale)
+        ctx.set_materialize_grads(False)     # no zero tensors (one fill launch each) for the gradients of the non-differentiable outputs
         return out[0], out[1]
 
     @staticmethod
     def backward(ctx, g_loss, _g_npos):
+        if g_loss is None:
+            return None, None, None, None, None
         logits, target, out = ctx.saved_tensors
         alpha, gamma, scale = ctx.cfg
         grad = torch.empty_like(logits)
@@ -499,10 +502,11 @@ class _GatherPred(torch.autograd.Function):
         ind, mask = ctx.saved_tensors
         B, K, H, W = ctx.geom
         dev = g.device
-        g_reg = torch.empty((B, 2, H, W), dtype=torch.float32, device=dev)
-        g_h = torch.empty((B, 1, H, W), dtype=torch.float32, device=dev)
-        g_dim = torch.empty((B, 3, H, W), dtype=torch.float32, device=dev)
-        g_rot = torch.empty((B, 2, H, W), dtype=torch.float32, device=dev)
+        # one allocation, four views one behind the other: the entry point then clears them with ONE memset
+        flat = torch.empty(B * 8 * H * W, dtype=torch.float32, device=dev)
+        hw = B * H * W
+        g_reg, g_h = flat[:2 * hw].view(B, 2, H, W), flat[2 * hw:3 * hw].view(B, 1, H, W)
+        g_dim, g_rot = flat[3 * hw:6 * hw].view(B, 3, H, W), flat[6 * hw:].view(B, 2, H, W)
         g = g.contiguous()
         check(_lib.lib().gga_gather_pred_bwd(_p(g), _p(ind), _p(mask), B, K, H, W, _p(g_reg),
                                              _p(g_h), _p(g_dim), _p(g_rot), _stream()), 'gga_gather_pred_bwd')
@@ -563,6 +567,7 @@ class _BoxLosses(torch.autograd.Function):
         ctx.save_for_backward(grad_pred)
         ctx.geom = (B, K)
         ctx.mark_non_differentiable(box_out)
+        ctx.set_materialize_grads(False)     # no zero tensors (one fill launch each) for the gradients of the non-differentiable outputs
         return losses, box_out
 
     @staticmethod
@@ -606,6 +611,7 @@ class _BNAct(torch.autograd.Function):
         if amax is None:
             amax = torch.empty(0, dtype=torch.int32, device=dev)
         ctx.mark_non_differentiable(amax, saved)
+        ctx.set_materialize_grads(False)     # no zero tensors (one fill launch each) for the gradients of the non-differentiable outputs
         return y, amax, saved
 
     @staticmethod
@@ -722,6 +728,7 @@ class _GNAct(torch.autograd.Function):
         if amax is None:
             amax = torch.empty(0, dtype=torch.int32, device=dev)
         ctx.mark_non_differentiable(amax)
+        ctx.set_materialize_grads(False)     # no zero tensors (one fill launch each) for the gradients of the non-differentiable outputs
         return y, amax
 
     @staticmethod
@@ -801,6 +808,7 @@ class _BNActCat(torch.autograd.Function):
         if amax is None:
             amax = torch.empty(0, dtype=torch.int32, device=dev)
         ctx.mark_non_differentiable(amax, *saved_all)
+        ctx.set_materialize_grads(False)     # no zero tensors (one fill launch each) for the gradients of the non-differentiable outputs
         return (out, amax, *saved_all)
 
     @staticmethod

@@ -65,6 +65,7 @@ class _PillarConv2d(torch.autograd.Function):
         ctx.save_for_backward(feats, weight, coors, num_valid)
         ctx.geom = (tuple(canvas.shape), stride, padding)
         ctx.mark_non_differentiable(stats)
+        ctx.set_materialize_grads(False)     # no zero tensors (one fill launch each) for the gradients of the non-differentiable outputs
         return y, stats
 
     @staticmethod

@@ -437,6 +437,7 @@ class _SparseConvFn(torch.autograd.Function):
         if stats is None:
             stats = torch.empty(0, dtype=torch.float64, device=feats.device)
         ctx.mark_non_differentiable(stats)
+        ctx.set_materialize_grads(False)     # no zero tensors (one fill launch each) for the gradients of the non-differentiable outputs
         return y, stats
 
     @staticmethod

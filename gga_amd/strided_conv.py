@@ -166,6 +166,7 @@ class _StridedConv(torch.autograd.Function):
         ctx.save_for_backward(x, weight)
         ctx.geom, ctx.amax = (k, s, p), (x_amax, None)
         ctx.mark_non_differentiable(stats)
+        ctx.set_materialize_grads(False)     # no zero tensors (one fill launch each) for the gradients of the non-differentiable outputs
         return y.view(B, bk.Ho, bk.Wo, -1).permute(0, 3, 1, 2), stats
 
     @staticmethod
@@ -203,6 +204,7 @@ class _Deconv(torch.autograd.Function):
         ctx.save_for_backward(x, weight)
         ctx.s, ctx.amax = s, (x_amax, None)
         ctx.mark_non_differentiable(stats)
+        ctx.set_materialize_grads(False)     # no zero tensors (one fill launch each) for the gradients of the non-differentiable outputs
         return y.view(B, H * s, W * s, -1).permute(0, 3, 1, 2), stats
 
     @staticmethod

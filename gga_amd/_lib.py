@@ -69,6 +69,8 @@ SIGNATURES = {
     'gga_sparse_rulebook': (i32, [vp, i64, vp, i64, i32, I3, I3, I3, I3, I3, vp, i64, vp, i64, vp, vp, vp]),
     'gga_sparse_rowmask': (i32, [vp, i64, i32, vp, vp]),
     'gga_sparse_mask_order_workspace_bytes': (sz, [i64]),
+    'gga_sparse_morton_order_workspace_bytes': (sz, [i64]),
+    'gga_sparse_morton_order': (i32, [vp, i64, i32, i32, vp, vp, sz, vp]),
     'gga_sparse_mask_order': (i32, [vp, i64, i32, vp, vp, sz, vp]),
     'gga_sparse_packed_weight_bytes': (sz, [i32, i32, i32]),
     'gga_sparse_pack_weight': (i32, [vp, i32, i32, i32, i32, vp, vp]),

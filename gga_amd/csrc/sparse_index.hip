@@ -402,3 +402,69 @@ extern "C" int gga_sparse_mask_order(const uint32_t* mask, int64_t n_rows, int k
     }
     return GGA_OK;
 }
+
+// Rows of a level along a Z-order curve per sample (the halo form's tiles, sparse.py: morton_order): key = sample, then the
+// bit-interleaved (z, y, x) - 17 elementwise launches and a merge sort of int64 keys in the framework; here one key kernel and an
+// Onesweep radix sort over the bits the level's extent can set. Coordinates are distinct, so the order is THE ascending order of
+// the keys whatever sorts them.
+__device__ __forceinline__ uint64_t sp_spread3(uint32_t v) {          // bits of v (< 2^16) moved to every third position
+    uint64_t x = v & 0xFFFFu;
+    x = (x | (x << 32)) & 0x1F00000000FFFFull;
+    x = (x | (x << 16)) & 0x1F0000FF0000FFull;
+    x = (x | (x << 8)) & 0x100F00F00F00F00Full;
+    x = (x | (x << 4)) & 0x10C30C30C30C30C3ull;
+    x = (x | (x << 2)) & 0x1249249249249249ull;
+    return x;
+}
+__global__ __launch_bounds__(256) void sp_morton_key_kernel(const int4* __restrict__ coors, int64_t n, int cbits,
+                                                           uint64_t* __restrict__ keys) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int4 c = coors[i];                                            // (sample, z, y, x)
+    keys[i] = ((uint64_t)(uint32_t)c.x << (3 * cbits)) | (sp_spread3((uint32_t)c.y) << 2) | (sp_spread3((uint32_t)c.z) << 1) |
+              sp_spread3((uint32_t)c.w);
+}
+typedef rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 4096> sp_morton_config;
+static size_t sp_morton_temp_bytes(int64_t n, int bits) {
+    size_t tb = 0;
+    (void)rocprim::radix_sort_pairs<sp_morton_config>(nullptr, tb, (const uint64_t*)nullptr, (uint64_t*)nullptr,
+                                                      rocprim::counting_iterator<int32_t>(0), (int32_t*)nullptr, (size_t)n, 0,
+                                                      (unsigned)bits, (hipStream_t)0);
+    return (tb + 255) / 256 * 256;
+}
+static inline size_t sp_morton_keys_bytes(int64_t n) { return ((size_t)n * 8 + 255) / 256 * 256; }
+
+extern "C" size_t gga_sparse_morton_order_workspace_bytes(int64_t n_rows) {
+    if (n_rows < 1) return 0;
+    return sp_morton_temp_bytes(n_rows, 64) + 2 * sp_morton_keys_bytes(n_rows);
+}
+
+extern "C" int gga_sparse_morton_order(const int32_t* coors, int64_t n_rows, int batch_size, int max_extent, int32_t* order,
+                                       void* workspace, size_t workspace_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    GGA_REQUIRE(coors && order && workspace && n_rows >= 1 && n_rows < ((int64_t)1 << 31) && batch_size >= 1 &&
+                max_extent >= 1 && max_extent <= 65536, "gga_sparse_morton_order: bad arguments");
+    if (workspace_bytes < gga_sparse_morton_order_workspace_bytes(n_rows)) {
+        gga_set_error("gga_sparse_morton_order: workspace too small");
+        return GGA_ERR_WORKSPACE;
+    }
+    int cbits = 1, bbits = 1;
+    while ((1 << cbits) < max_extent) ++cbits;                          // bits of a coordinate: 3 * cbits interleaved bits
+    while ((1 << bbits) < batch_size) ++bbits;
+    const int bits = 3 * cbits + bbits;
+    unsigned char* w = static_cast<unsigned char*>(workspace) + sp_morton_temp_bytes(n_rows, 64);
+    uint64_t* keys = reinterpret_cast<uint64_t*>(w);
+    uint64_t* keys_out = reinterpret_cast<uint64_t*>(w + sp_morton_keys_bytes(n_rows));
+    hipLaunchKernelGGL(sp_morton_key_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, stream, (const int4*)coors,
+                       n_rows, cbits, keys);
+    GGA_CHECK_LAUNCH("sp_morton_key_kernel");
+    size_t tb = sp_morton_temp_bytes(n_rows, bits);
+    const hipError_t e = rocprim::radix_sort_pairs<sp_morton_config>(workspace, tb, (const uint64_t*)keys, keys_out,
+                                                                     rocprim::counting_iterator<int32_t>(0), order,
+                                                                     (size_t)n_rows, 0, (unsigned)bits, stream);
+    if (e != hipSuccess) {
+        gga_set_error("gga_sparse_morton_order: rocprim::radix_sort_pairs: %s", hipGetErrorString(e));
+        return GGA_ERR_LAUNCH;
+    }
+    return GGA_OK;
+}

@@ -279,6 +279,12 @@ int gga_sparse_rowmask(const int32_t* map, int64_t n_rows, int kvol, uint32_t* m
  * processing order gga_sparse_conv_apply_split takes as `perm`; replaces the framework's stable sort, sparse.py). kvol <= 32
  * mask bits take part; masks are compared as signed 32-bit values when kvol == 32. workspace: device memory of
  * gga_sparse_mask_order_workspace_bytes(n_rows) bytes. */
+/* order[i] = the row with the i-th smallest Z-order key (sample, then the bit-interleaved (z, y, x)) of coors [n_rows][4] =
+ * (sample, z, y, x): consecutive rows are close in space - the tiles of the halo form (gga_sparse_halo_build). Coordinates must be
+ * distinct, 0 <= coordinate < max_extent <= 65536, 0 <= sample < batch_size. */
+size_t gga_sparse_morton_order_workspace_bytes(int64_t n_rows);
+int gga_sparse_morton_order(const int32_t* coors, int64_t n_rows, int batch_size, int max_extent, int32_t* order,
+                            void* workspace, size_t workspace_bytes, void* stream);
 size_t gga_sparse_mask_order_workspace_bytes(int64_t n_rows);
 int gga_sparse_mask_order(const uint32_t* mask, int64_t n_rows, int kvol, int32_t* order, void* workspace,
                           size_t workspace_bytes, void* stream);

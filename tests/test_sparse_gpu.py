@@ -520,3 +520,21 @@ def test_mask_order_is_the_stable_sort_of_the_masks(kvol, n):
     got = mask_order(mask, kvol)
     want = torch.sort(mask, stable=True)[1].int()
     assert got.dtype == torch.int32 and torch.equal(got, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,shape,n', [(1, (5, 7, 3), 60), (8, (11, 200, 176), 400_000), (3, (41, 1600, 1408), 250_000), (2, (1, 1, 9), 9)])
+def test_morton_order_entry_point_equals_the_tensor_expression(B, shape, n):
+    """gga_sparse_morton_order (key kernel + radix sort over the bits the level's extent can set) against the framework expression
+    it replaces (64-bit keys, torch.argsort): distinct coordinates have one ascending order."""
+    from gga_amd.sparse import morton_order
+    D, H, W = shape
+    g = torch.Generator().manual_seed(n + D)
+    cells = B * D * H * W
+    n = min(n, cells)
+    flat = torch.randperm(cells, generator=g)[:n] if cells < 5_000_000 else torch.unique(torch.randint(0, cells, (2 * n,), generator=g))[:n]
+    flat = flat[torch.randperm(flat.shape[0], generator=g)]
+    coors = torch.stack([flat // (D * H * W), (flat // (H * W)) % D, (flat // W) % H, flat % W], 1).int().cuda()
+    got = morton_order(coors, B, max(shape))
+    want = morton_order(coors)                                   # no extent: the tensor expression
+    assert got.dtype == torch.int32 and torch.equal(got.long(), want)

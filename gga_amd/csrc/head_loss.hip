@@ -427,8 +427,12 @@ extern "C" int gga_box_losses_fwd(const float* pred, const int64_t* ind, const u
     }
     float* part = (float*)workspace;
     GGA_CHECK_HIP(hipMemsetAsync(part, 0, (size_t)GGA_L_NUM * n * sizeof(float), stream), "box losses memset");
-    GGA_CHECK_HIP(hipMemsetAsync(grad_pred, 0, (size_t)GGA_L_NUM * n * 8 * sizeof(float), stream), "box losses memset");
-    GGA_CHECK_HIP(hipMemsetAsync(box_out, 0, (size_t)n * BOX_OUT_W * sizeof(float), stream), "box losses memset");
+    if (box_out == grad_pred + (size_t)GGA_L_NUM * n * 8) {         // two views of one allocation: one memset
+        GGA_CHECK_HIP(hipMemsetAsync(grad_pred, 0, ((size_t)GGA_L_NUM * n * 8 + (size_t)n * BOX_OUT_W) * sizeof(float), stream), "box losses memset");
+    } else {
+        GGA_CHECK_HIP(hipMemsetAsync(grad_pred, 0, (size_t)GGA_L_NUM * n * 8 * sizeof(float), stream), "box losses memset");
+        GGA_CHECK_HIP(hipMemsetAsync(box_out, 0, (size_t)n * BOX_OUT_W * sizeof(float), stream), "box losses memset");
+    }
     hipLaunchKernelGGL(box_slot_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, pred, ind, mask, anno_box,
                        lidar2img, bound_mask, *prm, box_out, grad_pred, part);
     GGA_CHECK_LAUNCH("box_slot_kernel");

@@ -367,10 +367,9 @@ class CenterHead_GGA(nn.Module):
             pred = F.gather_pred(pd['reg'], pd['height'], pd['dim'], pd['rot'], inds[task_id], masks[task_id])
             prm = F.loss_params(B, K, tc, l1_loss_weight=self.loss_bbox.loss_weight)
             xy, offs, slot = ibp_points[task_id]
-            losses, _ = F.box_losses(pred, inds[task_id], masks[task_id], anno_boxes[task_id],
-                                     anno_lidar2imgs[task_id], anno_bound_masks[task_id],
-                                     xy, offs, slot if slot.numel() else None, prm)
-            l_bpl, l_srl, l_pmin, l_px, l_py = losses.unbind(0)
+            (l_bpl, l_srl, l_pmin, l_px, l_py), _ = F.box_loss_terms(pred, inds[task_id], masks[task_id], anno_boxes[task_id],
+                                                                     anno_lidar2imgs[task_id], anno_bound_masks[task_id],
+                                                                     xy, offs, slot if slot.numel() else None, prm)
             loss_dict[f'task{task_id}.distancex'] = l_px
             loss_dict[f'task{task_id}.distancey'] = l_py
             loss_dict[f'task{task_id}.distancemin'] = l_pmin

@@ -555,8 +555,8 @@ class _BoxLosses(torch.autograd.Function):
         dev = pred.device
         L = _lib.lib()
         losses = torch.empty(5, dtype=torch.float32, device=dev)
-        box_out = torch.empty((B, K, 12), dtype=torch.float32, device=dev)
-        grad_pred = torch.empty((5, B, K, 8), dtype=torch.float32, device=dev)
+        flat = torch.empty(B * K * (5 * 8 + 12), dtype=torch.float32, device=dev)      # one allocation: the entry point clears both with one memset
+        grad_pred, box_out = flat[:5 * B * K * 8].view(5, B, K, 8), flat[5 * B * K * 8:].view(B, K, 12)
         ws = _workspace('box', L.gga_box_losses_workspace_bytes(B, K), dev)
         n_obj = 0 if ibp_slot is None else int(ibp_slot.shape[0])
         pred = pred.contiguous()
@@ -579,6 +579,43 @@ class _BoxLosses(torch.autograd.Function):
         check(_lib.lib().gga_box_losses_bwd(_p(grad_pred), _p(g_losses), B, K, _p(out),
                                             _stream()), 'gga_box_losses_bwd')
         return (out,) + (None,) * 9
+
+
+_ZERO_SCALAR = {}
+
+
+def _zero_scalar(dev):
+    z = _ZERO_SCALAR.get(str(dev))
+    if z is None:
+        z = _ZERO_SCALAR[str(dev)] = torch.zeros((), dtype=torch.float32, device=dev)
+    return z
+
+
+class _BoxLossTerms(torch.autograd.Function):
+    """_BoxLosses with the five terms as five scalar outputs: a head that puts two of them into the total loss and logs the
+    other three gets no UnbindBackward (a zero fill per unused term and a stack, every step and task) - the terms nobody
+    differentiates arrive here as None and the gradient vector is ONE stack over a cached zero."""
+
+    @staticmethod
+    def forward(ctx, *args):
+        losses, box_out = _BoxLosses.forward(ctx, *args)
+        return (*losses.unbind(0), box_out)
+
+    @staticmethod
+    def backward(ctx, g0, g1, g2, g3, g4, _g_box):
+        gs = (g0, g1, g2, g3, g4)
+        if all(g is None for g in gs):
+            return (None,) * 10
+        z = _zero_scalar(ctx.saved_tensors[0].device)
+        g_losses = torch.stack([z if g is None else g.float().reshape(()) for g in gs])
+        return _BoxLosses.backward(ctx, g_losses, None)
+
+
+def box_loss_terms(pred, ind, mask, anno_box, lidar2img, bound_mask, ibp_xy, ibp_offsets, ibp_slot, prm):
+    """``box_losses`` with the losses as a tuple of five scalars (bpl, srl, pal_min, pal_x, pal_y) instead of one [5] tensor."""
+    out = _BoxLossTerms.apply(pred, ind.contiguous(), mask.contiguous(), anno_box.contiguous(), lidar2img.contiguous(),
+                              bound_mask.contiguous(), ibp_xy, ibp_offsets, ibp_slot, prm)
+    return out[:5], out[5]
 
 
 def box_losses(pred, ind, mask, anno_box, lidar2img, bound_mask, ibp_xy, ibp_offsets, ibp_slot, prm):

@@ -117,6 +117,7 @@ SIGNATURES = {
     'gga_dense_conv3x3_stats': (i32, [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]),
     'gga_bn_relu_fwd_partials': (i32, [vp, vp, vp, vp, vp, vp, i64, i32, f32, f32, i32, vp, i64, vp, vp, vp, i32, vp, sz, vp]),
     'gga_bn_stats_partials': (i32, [vp, vp, vp, vp, i64, i32, f32, f32, vp, vp, vp, i32, vp]),
+    'gga_bn_stats_partials_cols': (i32, [vp, vp, vp, vp, i64, i32, f32, f32, vp, vp, vp, i32, i32, i32, vp]),
     'gga_dense_conv3x3': (i32, [vp, vp, i32, i32, i32, i32, i32, vp, vp]),
     'gga_bn_relu_workspace_bytes': (sz, [i64, i32]),
     'gga_bn_relu_mask_bytes': (sz, [i64, i32]),

@@ -146,16 +146,19 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float4* __restrict
 // fetched it 8 times over in 32 dependent trips: 16 us per layer, 70 layers a step). Row groups
 // fold with three shuffles inside a wavefront and in fixed order across the 16 wavefronts; lanes
 // 0..7 return the totals.
+// (Cw, off: the rows are [2][Cw] wide and this BatchNorm's channels are columns off .. off + C of them - the statistics of a
+// convolution launch that computed several BatchNorms' inputs side by side; Cw = C, off = 0 otherwise)
 __device__ __forceinline__ void bn_fold_partials(const double* __restrict__ partials, int nblocks, int C, int c,
-                                                 bool ok, double& s0, double& s1) {
+                                                 bool ok, double& s0, double& s1, int Cw = 0, int off = 0) {
+    if (Cw == 0) Cw = C;
     __shared__ double red[2][16][8];
     const int t = threadIdx.x, rg = t >> 3;
     double a0 = 0.0, a1 = 0.0;
     if (ok) {
 #pragma unroll 16
         for (int b = rg; b < nblocks; b += 128) {
-            a0 += partials[(int64_t)b * 2 * C + c];
-            a1 += partials[(int64_t)b * 2 * C + C + c];
+            a0 += partials[(int64_t)b * 2 * Cw + off + c];
+            a1 += partials[(int64_t)b * 2 * Cw + Cw + off + c];
         }
     }
 #pragma unroll
@@ -176,13 +179,13 @@ __global__ __launch_bounds__(1024) void bn_fwd_final_kernel(const double* __rest
                                                            const float* __restrict__ beta, float eps, float momentum,
                                                            int training, float* __restrict__ running_mean,
                                                            float* __restrict__ running_var, float* __restrict__ saved,
-                                                           float* __restrict__ scale_shift) {
+                                                           float* __restrict__ scale_shift, int Cw = 0, int off = 0) {
     const int c = blockIdx.x * 8 + (threadIdx.x & 7);
     const bool ok = c < C;
     float mean, invstd;
     if (training) {
         double s, ss;
-        bn_fold_partials(partials, nblocks, C, c, ok, s, ss);
+        bn_fold_partials(partials, nblocks, C, c, ok, s, ss, Cw, off);
         if (threadIdx.x >= 8 || !ok) return;
         const double mu = s / rows;
         double var = ss / rows - mu * mu;
@@ -411,17 +414,28 @@ extern "C" int gga_bn_relu_fwd_ex(const float* x, const float* residual, const f
                        workspace_bytes, stream_, amax_y);
 }
 
-extern "C" int gga_bn_stats_partials(const float* gamma, const float* beta, float* running_mean, float* running_var,
-                                     int64_t rows, int channels, float eps, float momentum, float* saved,
-                                     float* scale_shift, const double* partials, int n_partials, void* stream_) {
+extern "C" int gga_bn_stats_partials_cols(const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                          int64_t rows, int channels, float eps, float momentum, float* saved,
+                                          float* scale_shift, const double* partials, int n_partials, int partials_width,
+                                          int column_offset, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (int rc = bn_check("gga_bn_stats_partials", rows, channels)) return rc;
     GGA_REQUIRE(saved && scale_shift && running_mean && running_var && partials && n_partials >= 1,
                 "gga_bn_stats_partials: null pointer argument");
+    GGA_REQUIRE(column_offset >= 0 && partials_width >= column_offset + channels,
+                "gga_bn_stats_partials_cols: columns %d .. %d of rows %d wide", column_offset, column_offset + channels, partials_width);
     hipLaunchKernelGGL(bn_fwd_final_kernel, dim3((channels + 7) / 8), dim3(1024), 0, stream, partials, n_partials, channels,
-                       (double)rows, gamma, beta, eps, momentum, 1, running_mean, running_var, saved, scale_shift);
+                       (double)rows, gamma, beta, eps, momentum, 1, running_mean, running_var, saved, scale_shift, partials_width,
+                       column_offset);
     GGA_CHECK_LAUNCH("bn_fwd_final_kernel");
     return GGA_OK;
+}
+
+extern "C" int gga_bn_stats_partials(const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                     int64_t rows, int channels, float eps, float momentum, float* saved,
+                                     float* scale_shift, const double* partials, int n_partials, void* stream_) {
+    return gga_bn_stats_partials_cols(gamma, beta, running_mean, running_var, rows, channels, eps, momentum, saved, scale_shift,
+                                      partials, n_partials, channels, 0, stream_);
 }
 
 extern "C" int gga_bn_stats(const float* x, const float* gamma, const float* beta, float* running_mean,

@@ -1071,13 +1071,13 @@ class _HeadBranches(torch.autograd.Function):
         pair_stats = {}
         for i in range(0, n - 1, 2):          # (the pair's operand is assembled from the two parameters by the weight bank: no cat)
             _, st = dense_conv._run(x, [w1[i].detach(), w1[i + 1].detach()], False, True, x_amax, None, Y, C * i)
-            pair_stats[i], pair_stats[i + 1] = st[:, :, :C].contiguous(), st[:, :, C:].contiguous()
+            pair_stats[i], pair_stats[i + 1] = (st, 0), (st, C)          # columns of the pair's [tiles, 2, 2C] rows: no copies
         all_stats = []
         for i in range(n):
             if i in pair_stats:
                 all_stats.append(pair_stats[i])
             else:
-                all_stats.append(dense_conv._run(x, w1[i].detach(), False, True, x_amax, None, Y, C * i)[1])
+                all_stats.append((dense_conv._run(x, w1[i].detach(), False, True, x_amax, None, Y, C * i)[1], 0))
         # everything the branch launches write is allocated here, on this stream; odd branches are LAUNCHED on a second one
         w2c = [w.contiguous() for w in w2]
         for i in range(n):
@@ -1089,11 +1089,12 @@ class _HeadBranches(torch.autograd.Function):
             st_.wait_stream(streams[0])
         for i in range(n):
             eps, momentum = cfg[i]
-            stats = all_stats[i]
+            stats, col = all_stats[i]
             tiles = int(stats.shape[0])
             with torch.cuda.stream(streams[i % len(streams)]):
-                check(L.gga_bn_stats_partials(_p(gam[i]), _p(bet[i]), _p(rm[i]), _p(rv[i]), rows, C, eps, momentum, _p(saved_all[i]),
-                                              _p(ss_all[i]), _p(stats), tiles, _stream()), 'gga_bn_stats_partials')
+                check(L.gga_bn_stats_partials_cols(_p(gam[i]), _p(bet[i]), _p(rm[i]), _p(rv[i]), rows, C, eps, momentum,
+                                                   _p(saved_all[i]), _p(ss_all[i]), _p(stats), tiles, int(stats.shape[2]), col,
+                                                   _stream()), 'gga_bn_stats_partials_cols')
                 check(L.gga_head_conv3x3_fwd(Y.data_ptr() + 4 * C * i, tot, _p(ss_all[i]), _p(w2c[i]), _p(b2[i]), B, H, W, C,
                                              w2[i].shape[0], _p(outs[i]), _stream()), 'gga_head_conv3x3_fwd')
         for st_ in streams[1:]:

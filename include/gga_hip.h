@@ -632,6 +632,11 @@ int gga_bn_relu_fwd_partials(const float* x, const float* residual, const float*
 int gga_bn_stats_partials(const float* gamma, const float* beta, float* running_mean, float* running_var,
                           int64_t rows, int channels, float eps, float momentum, float* saved, float* scale_shift,
                           const double* partials, int n_partials, void* stream);
+/* The same for a BatchNorm whose channels are columns column_offset .. + channels of partial rows [2][partials_width] (a
+ * convolution launch that computed the inputs of several BatchNorms side by side: the head's paired first convolutions). */
+int gga_bn_stats_partials_cols(const float* gamma, const float* beta, float* running_mean, float* running_var, int64_t rows,
+                               int channels, float eps, float momentum, float* saved, float* scale_shift, const double* partials,
+                               int n_partials, int partials_width, int column_offset, void* stream);
 
 /* a5 (output convs of the head branches): 3x3 conv, 64 input channels -> 1..4 output channels,
  * stride 1, pad 1, + bias. Replaces the last layer of each SeparateHead branch,

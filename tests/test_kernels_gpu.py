@@ -260,6 +260,59 @@ def test_nan_target_propagates_like_reference():
     assert torch.isnan(losses[0]) and not torch.isnan(losses[1])
 
 
+def test_box_loss_terms_are_the_box_losses_with_scalar_outputs():
+    """F.box_loss_terms (what the head calls: five scalar outputs, unused terms arrive in backward as None) against F.box_losses
+    (one [5] tensor): same values, and the same gradient when two of the five terms enter the total - bit for bit."""
+    c = 'second'
+    B, K = 2, 500
+    prm = F.loss_params(B, K, TRAIN_CFG[c])
+    g = torch.Generator().manual_seed(11)
+    base = torch.randn(B, K, 8, generator=g)
+    base[..., 3:6] = base[..., 3:6].abs() * 0.2          # log-dims stay small
+    ind = torch.randint(0, 200 * 176, (B, K), generator=g).to(DEV)
+    mask = (torch.rand(B, K, generator=g) < 0.1).to(torch.uint8).to(DEV)
+    anno = torch.rand(B, K, 5, generator=g).to(DEV)
+    l2i = (torch.eye(4) + 0.01 * torch.randn(B, K, 4, 4, generator=g)).to(DEV)
+    bm = torch.ones(B, K, 4, dtype=torch.uint8, device=DEV)
+    pa = base.clone().to(DEV).requires_grad_()
+    pb = base.clone().to(DEV).requires_grad_()
+    la, box_a = F.box_losses(pa, ind, mask, anno, l2i, bm, None, None, None, prm)
+    (t0, t1, t2, t3, t4), box_b = F.box_loss_terms(pb, ind, mask, anno, l2i, bm, None, None, None, prm)
+    assert torch.equal(la, torch.stack([t0, t1, t2, t3, t4]).detach()) and torch.equal(box_a, box_b)
+    (la[0] * 1.5 + la[1]).backward()
+    (t0 * 1.5 + t1).backward()                            # t2..t4 only logged: their gradients never exist
+    assert torch.equal(pa.grad, pb.grad)
+
+
+def test_bn_statistics_from_a_column_block_of_wider_partial_rows():
+    """gga_bn_stats_partials_cols (the head's paired first convolutions: one [tiles, 2, 128] statistics array, two BatchNorms of
+    64 channels) against gga_bn_stats_partials on contiguous copies of the halves: the same saved statistics, scale / shift and
+    running buffers, bit for bit."""
+    from gga_amd import _lib
+    L = _lib.lib()
+    tiles, C, rows = 200, 64, 16 * 248 * 216
+    g = torch.Generator().manual_seed(5)
+    st = (torch.rand(tiles, 2, 2 * C, generator=g, dtype=torch.float64) * rows / tiles).to(DEV)
+    st[:, 1] = st[:, 0].abs() * 1.7 + 3.0                    # sums of squares above the squared sums
+    for col in (0, C):
+        gam, bet = torch.rand(C, generator=g).to(DEV), torch.randn(C, generator=g).to(DEV)
+        out = []
+        for form in ('cols', 'copy'):
+            rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+            saved, ss = torch.empty(2 * C, device=DEV), torch.empty(2 * C, device=DEV)
+            if form == 'cols':
+                rc = L.gga_bn_stats_partials_cols(F._p(gam), F._p(bet), F._p(rm), F._p(rv), rows, C, 1e-3, 0.01, F._p(saved), F._p(ss),
+                                                  F._p(st), tiles, 2 * C, col, F._stream())
+            else:
+                half = st[:, :, col:col + C].contiguous()
+                rc = L.gga_bn_stats_partials(F._p(gam), F._p(bet), F._p(rm), F._p(rv), rows, C, 1e-3, 0.01, F._p(saved), F._p(ss),
+                                             F._p(half), tiles, F._stream())
+            assert rc == 0
+            out.append((rm, rv, saved, ss))
+        for a, b in zip(*out):
+            assert torch.equal(a, b)
+
+
 def test_fused_pfn_vs_reference_golden(golden):
     """Fused PillarFeatureNet against the imported reference: forward, running stats and the
     parameter gradients (encoders.npz was produced by the reference's PillarFeatureNet)."""

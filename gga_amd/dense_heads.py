@@ -328,10 +328,11 @@ class CenterHead_GGA(nn.Module):
         dev = torch.device(device)
         B, T, fh, fw, ncls, map_base = pk['B'], pk['T'], pk['fh'], pk['fw'], self.num_classes, pk['map_base']
         objs = pk['objs']
-        hm = F.heatmap_splat(objs, int(map_base[-1]), fh, fw, dev,
+        # all nine arrays in one staging buffer and one copy (F.upload_many), queued BEFORE the splat kernel
+        up = F.upload_many(dict({k: pk[k] for k in ('anno_box', 'ind', 'mask', 'lidar2img', 'bound_mask', 'ibp_xy', 'ibp_offsets',
+                                                    'ibp_slot')}, objs=objs), dev)
+        hm = F.heatmap_splat(up['objs'] if dev.type == 'cuda' else objs, int(map_base[-1]), fh, fw, dev,
                              max_radius=max(16, int(objs[:, 3].max()) if len(objs) else 0))
-        up = {k: F.upload(pk[k], dev)
-              for k in ('anno_box', 'ind', 'mask', 'lidar2img', 'bound_mask', 'ibp_xy', 'ibp_offsets', 'ibp_slot')}
         heatmaps, ibp_points = [], []
         obj_base = np.concatenate([[0], np.cumsum(pk['task_nobj'])])
         for t in range(T):

@@ -380,3 +380,21 @@ def test_batchnorm_counters_deferred_into_one_add():
     with F.deferred_batch_counters():                  # an empty pass adds nothing
         pass
     assert int(a.num_batches_tracked) == 3
+
+
+def test_upload_many_hands_back_every_array_as_a_view_of_one_buffer():
+    """functional.upload_many (the head's target arrays: one staging buffer, one copy): every array comes back with its dtype,
+    shape and values - empty ones and odd sizes included - as views of ONE buffer at 256-byte offsets."""
+    from gga_amd import functional as F
+    g = np.random.default_rng(3)
+    arrays = dict(a=g.standard_normal((3, 2, 5)).astype(np.float32), b=g.integers(0, 1 << 40, (7,)).astype(np.int64),
+                  c=(g.random((2, 3, 4)) < 0.5).astype(np.uint8), d=np.zeros((0, 2), np.float32), e=np.arange(5, dtype=np.int32),
+                  f=g.standard_normal((4, 4)).astype(np.float64)[:, ::2])            # not contiguous
+    out = F.upload_many(arrays, 'cpu')
+    base = {t.untyped_storage().data_ptr() for t in out.values()}
+    assert len(base) == 1
+    for k, a in arrays.items():
+        t = out[k]
+        assert tuple(t.shape) == a.shape and t.dtype == torch.from_numpy(np.empty(0, a.dtype)).dtype
+        assert np.array_equal(t.numpy(), a)
+        assert t.numel() == 0 or (t.data_ptr() - next(iter(base))) % 256 == 0

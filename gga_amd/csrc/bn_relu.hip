@@ -16,7 +16,7 @@
 #include "gga_common.h"
 
 #define BN_MAX_BLOCKS 2048
-#define BN_U 4            // independent 16 B loads in flight per thread
+#define BN_U 2            // independent 16 B loads in flight per thread and tensor (round 5: 2 instead of 4 - twice the workgroups; sparse config -0.2 ms per step, PointPillars +-0, profiles/r05_ab_bn_geometry.txt)
 
 struct BnGeom {
     int64_t n4;      // rows * C / 4

@@ -93,6 +93,8 @@ def parse_args(argv=None):
     ap.add_argument('--no-loader-fed', action='store_true', help='skip the dataset-fed leg (on-disk synthetic KITTI tree -> train_detector)')
     ap.add_argument('--loader-frames', type=int, default=2048, help='frames of the synthetic on-disk tree of the loader_fed leg')
     ap.add_argument('--loader-workers', default='4,8', help='workers_per_gpu values the loader_fed leg is run with')
+    ap.add_argument('--no-inference', action='store_true', help='skip the inference / pseudo-label legs')
+    ap.add_argument('--inference-frames', type=int, default=256)
     ap.add_argument('--no-planes3', action='store_true',
                     help='skip the `planes3` legs (main config and second_trunk re-timed on three bf16 planes / six products)')
     return ap.parse_args(argv)
@@ -412,6 +414,130 @@ def run_loader_fed(args, device, resident_value):
     return out
 
 
+def run_inference(args, device, model_config, pc_range, frames=256, batch_sizes=(1, 16)):
+    """The pseudo-label run of the recipe (reference: tools/generate_pseudo_labels_gga.py:242 /
+    tools/test.py -> mmdet3d/apis/test.py single_gpu_test -> MVXTwoStageDetector_GGA.simple_test, centerpoint_head_gga.py:725-934
+    get_bboxes / get_task_detections, core/post_processing/box3d_nms.py:231-268; fps probe tools/analysis_tools/benchmark.py:66-91):
+    configs/gga/gga_kitti_matching_config.py's test section on the synthetic on-disk tree - LoadPointsFromFile + the test
+    pipeline in loader workers, max_voxels = 40000 (eval), trunk, head, decode (top-100 per task), score threshold, BEV
+    rotated NMS, bbox3d2result - `frames` frames after a warm-up pass, for `samples_per_gpu` 1 (the reference tool's default)
+    and 16; then KittiDataset_GGA_match.evaluate (detections -> camera frame -> image-plane IoU matching against the 2D boxes
+    -> the pseudo-label file). Random-init weights with the heat-map bias raised so that the detector reports boxes.
+    -> dict per samples_per_gpu: frames/s, ms per frame by stage (a second, synchronised pass)."""
+    import copy
+    import tempfile
+    import torch
+    from gga_amd import Config, build_model, synthetic, ops
+    from gga_amd.apis import single_gpu_test
+    from gga_amd.cnn import to_channels_last
+    from gga_amd.loader import build_dataloader, build_dataset
+    is_pp = 'pointpillars' in os.path.basename(model_config)
+    root = (os.environ.get('GGA_BENCH_TREE') or os.path.join(tempfile.gettempdir(), f'gga_bench_kitti_{os.getuid()}')) + ('' if is_pp else '_second')
+    info_path, _ = synthetic.write_kitti_tree(root, max(frames + 32, args.loader_frames if is_pp else frames + 32), pc_range=pc_range)
+    cfg = Config.fromfile(os.path.join(REPO, 'configs', 'gga', 'gga_kitti_matching_config.py'))
+    mcfg = Config.fromfile(model_config)
+    test = dict(cfg.data['test'])
+    pipe = copy.deepcopy(list(test['pipeline']))
+    for t in pipe[1]['transforms']:
+        if t['type'] == 'PointsRangeFilter':
+            t['point_cloud_range'] = list(pc_range)
+    test.update(data_root=root + '/', ann_file=info_path, pipeline=pipe, pcd_limit_range=list(pc_range), test_mode=True)
+    model_cfg = mcfg.model
+    model_cfg['train_cfg'] = None
+    if not args.nchw:
+        model_cfg['pts_middle_encoder']['channels_last'] = True
+    torch.manual_seed(0)
+    model = build_model(model_cfg)
+    damp_head_init(model, args.head_init_scale)
+    with torch.no_grad():
+        for th in model.pts_bbox_head.task_heads:
+            th.heatmap[-1].bias.fill_(-1.5)             # sigmoid(-1.5 +- noise) around the 0.1 score threshold: a detector that reports boxes
+    model = model.to(device)
+    if not args.nchw:
+        model = to_channels_last(model)
+    model.CLASSES = ('Pedestrian', 'Cyclist', 'Car')
+    model.eval()
+    import pickle
+    infos = pickle.load(open(info_path, 'rb'))
+
+    def subset(lo, hi, name):           # a dataset of exactly these frames (evaluate wants one result per frame of ITS dataset)
+        path = os.path.join(root, f'kitti_infos_{name}.pkl')
+        pickle.dump(infos[lo:hi], open(path, 'wb'))
+        return build_dataset(dict(test, ann_file=path))
+    timed_set, warm_set, stage_set = subset(0, frames, 'bench_timed'), subset(frames, frames + 32, 'bench_warm'), subset(0, min(64, frames), 'bench_stages')
+    out = {'workload': (f'single_gpu_test on {os.path.relpath(model_config, REPO)} + the test section of configs/gga/gga_kitti_matching_config.py: '
+                        f'{frames} synthetic KITTI frames of 20 000 points from disk through the test pipeline (4 loader workers), voxelize at max_voxels 40000, '
+                        f'trunk, head, decode top-100 per task, score threshold 0.1, BEV rotated NMS, then KittiDataset_GGA_match.evaluate'),
+           'frames': frames, 'weights': 'random init, heat-map bias -1.5'}
+
+    stages = {}
+
+    def timed(name, fn):
+        def wrapper(*a, **kw):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            r = fn(*a, **kw)
+            torch.cuda.synchronize()
+            stages[name] = stages.get(name, 0.0) + time.perf_counter() - t
+            return r
+        return wrapper
+    head = model.pts_bbox_head
+    for spg in batch_sizes:
+        mk = lambda ds: build_dataloader(ds, samples_per_gpu=spg, workers_per_gpu=4, dist=False, shuffle=False)
+        single_gpu_test(model, mk(warm_set), device)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        results = single_gpu_test(model, mk(timed_set), device)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        assert len(results) == frames
+        dets = sum(len(r['pts_bbox']['scores_3d']) for r in results) / frames
+        # second pass over 64 frames with a device synchronisation around every stage (slower than the pass above: the stages add up
+        # to more than its time per frame)
+        stages.clear()
+        real = dict(voxelize=model.voxelize, enc=model.pts_voxel_encoder.forward, mid=model.pts_middle_encoder.forward,
+                    bb=model.pts_backbone.forward, neck=model.pts_neck.forward, head=head.forward, decode=head.bbox_coder.decode,
+                    nms=ops.nms_bev, get=head.get_bboxes)
+        model.voxelize = timed('voxelize', real['voxelize'])
+        model.pts_voxel_encoder.forward = timed('trunk', real['enc'])
+        model.pts_middle_encoder.forward = timed('trunk', real['mid'])
+        model.pts_backbone.forward = timed('trunk', real['bb'])
+        model.pts_neck.forward = timed('trunk', real['neck'])
+        head.forward = timed('head', real['head'])
+        head.get_bboxes = timed('get_bboxes (decode + threshold + nms + merge)', real['get'])
+        head.bbox_coder.decode = timed('  of which decode', real['decode'])
+        ops.nms_bev = timed('  of which nms_bev', real['nms'])
+        try:
+            n_st = len(stage_set)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            single_gpu_test(model, mk(stage_set), device)
+            torch.cuda.synchronize()
+            st_total = time.perf_counter() - t1
+        finally:
+            model.voxelize = real['voxelize']
+            model.pts_voxel_encoder.forward, model.pts_middle_encoder.forward = real['enc'], real['mid']
+            model.pts_backbone.forward, model.pts_neck.forward = real['bb'], real['neck']
+            head.forward, head.get_bboxes, head.bbox_coder.decode, ops.nms_bev = real['head'], real['get'], real['decode'], real['nms']
+        per = {k: round(v / n_st * 1e3, 3) for k, v in stages.items()}
+        per['loader wait + upload + result hand-over (remainder of the synchronised pass)'] = round(
+            (st_total - sum(v for k, v in stages.items() if not k.startswith('  '))) / n_st * 1e3, 3)
+        out[f'samples_per_gpu_{spg}'] = {'value': round(frames / dt, 2), 'unit': 'frames/s', 'ms_per_frame': round(dt / frames * 1e3, 3),
+                                         'detections_per_frame': round(dets, 1), 'stage_ms_per_frame_synchronised': per}
+        last = results
+    # the matching step (host + gga_image_box_match): detections -> pseudo labels of the same frames
+    t0 = time.perf_counter()
+    res = timed_set.evaluate(last, metric=['mAP'], device=str(device),
+                             pseudo_label_file=os.path.join(tempfile.gettempdir(), f'gga_bench_pseudo_{os.getuid()}.pkl'))
+    torch.cuda.synchronize()
+    out['match_ms_per_frame'] = round((time.perf_counter() - t0) / frames * 1e3, 3)
+    out['pseudo_labels'] = {k: v for k, v in (res or {}).items() if k.startswith('pseudo_labels/')}
+    del model
+    gc.collect()
+    torch.cuda.empty_cache()
+    return out
+
+
 def scatter_roofline(model, batches, step_ms):
     """`roofline` of the pillar-scatter canvas kernel: algorithmic bytes over
     its mean duration INSIDE the timed steps (`step_ms`: one HIP-event pair per step around the
@@ -500,15 +626,17 @@ def sparse_roofline(run, args, steps=4):
     algo = rows * (128 + 128) * 4 + 27 * rows * 4 + 27 * 128 * 128 * 4
     avg = sum(ms) / len(ms)
     traffic, src = None, None
-    try:
-        pmc = json.load(open(os.path.join(REPO, 'profiles', 'r04_second_pmc.json')))
-        ks = [k for k in pmc['kernels'] if k['kernel'].startswith('sp_conv_halo_kernel<4' if halo else 'sp_conv_x9_kernel<4') and 'hbm_bytes_per_launch' in k
-              and k['avg_us'] > 500]
-        if ks and args.second_batch == 8:
-            traffic = int(sum(k['hbm_bytes_per_launch'] * k['launches_per_pass'] for k in ks) / sum(k['launches_per_pass'] for k in ks))
-            src = 'profiles/r04_second_pmc.json (separate --pmc FETCH_SIZE / WRITE_SIZE passes over tools_dev/pmc_target_second.py, not this run)'
-    except (OSError, KeyError, ValueError):
-        pass
+    for name in ('r06_second_pmc.json', 'r05_second_pmc.json', 'r04_second_pmc.json'):      # the newest PMC pass that holds this kernel
+        try:
+            pmc = json.load(open(os.path.join(REPO, 'profiles', name)))
+            ks = [k for k in pmc['kernels'] if k['kernel'].startswith('sp_conv_halo_kernel<4' if halo else 'sp_conv_x9_kernel<4') and 'hbm_bytes_per_launch' in k
+                  and k['avg_us'] > 500]
+            if ks and args.second_batch == 8:
+                traffic = int(sum(k['hbm_bytes_per_launch'] * k['launches_per_pass'] for k in ks) / sum(k['launches_per_pass'] for k in ks))
+                src = f'profiles/{name} (separate --pmc FETCH_SIZE / WRITE_SIZE passes over tools_dev/pmc_target_second.py, not this run)'
+                break
+        except (OSError, KeyError, ValueError):
+            continue
     gbs = algo / (avg * 1e-3) / 1e9
     mfma = None
     if halo and tilings:
@@ -608,9 +736,42 @@ def cpu_pieces(cfg, frames=16):
     return {k: round(v, 2) for k, v in out.items()}
 
 
-def cpu_baseline(cfg, frames=16):
+def bench_size_gpu_losses(run):
+    """Whole-step parity AT THE BENCH SIZE, GPU side: the 18 losses of one forward pass of the timed
+    model - its weights as the timed steps left them - on `batches[0]` of the timed loop (16 frames x 20 000 points), for
+    both arithmetic forms, with SRL draws that are handed to the CPU step (`cpu_baseline`) together with the weights and the
+    batch. -> dict(state, batch, srl, gpu={planes: {key: loss}})."""
+    import torch
+    from gga_amd import dense_conv
+    model, batch = run['model'], run['batches'][0]
+    B = len(batch['points'])
+    srl = model.pts_bbox_head.draw_srl(B)
+    gpu = {}
+    was = dense_conv.PLANES
+    try:
+        for planes in (2, 3):
+            dense_conv.PLANES = planes
+            dense_conv.AMAX_POOL.next_generation()
+            feats = model.extract_feat(batch['points'], None, batch['img_metas'])[1]
+            outs = model.pts_bbox_head(feats)
+            losses = model.pts_bbox_head.loss(batch['gt_bboxes_3d'], batch['gt_labels_3d'], outs, batch['GGA_boxes_img'],
+                                              batch['GGA_lidar2img'], batch['GGA_init_pseudo_labels'], batch['GGA_bdry_masks'],
+                                              batch['GGA_in_box_points'], batch['img_metas'], srl=srl)
+            gpu[planes] = {k: float(v.detach()) for k, v in losses.items()}
+            del feats, outs, losses
+    finally:
+        dense_conv.PLANES = was
+    torch.cuda.synchronize()
+    state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    cpu_batch = dict(batch, points=[p.detach().cpu() for p in batch['points']])
+    return dict(state=state, batch=cpu_batch, srl=srl, gpu=gpu, steps_taken=int(run['runner'].iter))
+
+
+def cpu_baseline(cfg, frames=16, parity=None):
     """The oracle's CPU restatement of the same train step (C voxelizer + torch fp32 on the
-    host cores), one timed step on `frames` frames after a 1-frame warm-up, and its pieces."""
+    host cores), one timed step on `frames` frames after a 1-frame warm-up, and its pieces.
+    `parity` (bench_size_gpu_losses): the timed step then runs on the GPU legs' own weights and batch with the same SRL
+    draws, and its losses are the fp32 side of `parity_at_bench_size` (the float64 side: one more forward pass)."""
     import torch
     from gga_amd import build_model, synthetic
     from oracle import torch_ref as R
@@ -621,23 +782,54 @@ def cpu_baseline(cfg, frames=16):
     torch.manual_seed(0)
     model = build_model(cfg.model)
     damp_head_init(model, 0.05)
+    if parity is not None:
+        model.load_state_dict(parity['state'])
     model.train()
     warm = synthetic.make_batch(1, start=900, n_points=2000, pc_range=synthetic.RANGE_PP, n_obj_range=(2, 3))
     R.reference_train_step(model, warm)      # first-touch / thread-pool warm-up
     model.zero_grad()
-    batch = synthetic.make_batch(frames, start=901, pc_range=synthetic.RANGE_PP)
+    if parity is not None:
+        model.load_state_dict(parity['state'])       # (the warm-up step moved the BatchNorm running statistics: put them back)
+        batch, frames = parity['batch'], len(parity['batch']['points'])
+    else:
+        batch = synthetic.make_batch(frames, start=901, pc_range=synthetic.RANGE_PP)
     t0 = time.perf_counter()
-    R.reference_train_step(model, batch)
+    cpu_losses, _ = R.reference_train_step(model, batch, srl=parity['srl'] if parity is not None else None)
     dt = time.perf_counter() - t0
+    parity_out = None
+    if parity is not None:
+        # the same step in float64 (forward only): the value every fp32 path approximates, and the fp32 CPU step's own distance
+        # from it (`fp32_floor`); deviations as in tests/test_model_gpu.py: |a - b| / max(|b|, 1)
+        import copy
+        t1 = time.perf_counter()
+        with torch.no_grad():
+            l64, _ = R.reference_train_step(copy.deepcopy(model).double(), batch, srl=parity['srl'], backward=False)
+        f64_s = time.perf_counter() - t1
+        l32 = {k: float(v) for k, v in cpu_losses.items()}
+        l64 = {k: float(v) for k, v in l64.items()}
+        rel = lambda a, b: abs(a - b) / max(abs(b), 1.0)
+        floor_key = max(l64, key=lambda k: rel(l32[k], l64[k]))
+        parity_out = {'what': (f'the 18 losses of ONE forward pass on the batch and weights of the timed GPU steps ({frames} frames x 20 000 points; weights '
+                               f'after {parity["steps_taken"]} optimizer steps; same SRL draws): GPU legs against the fp32 CPU step timed here '
+                               f'and against the same step in float64; deviation = |a - b| / max(|b|, 1); bound 1e-4 (north_star)'),
+                      'fp32_floor': rel(l32[floor_key], l64[floor_key]), 'fp32_floor_key': floor_key, 'float64_forward_s': round(f64_s, 1)}
+        for planes, got in parity['gpu'].items():
+            k64 = max(l64, key=lambda k: rel(got[k], l64[k]))
+            k32 = max(l32, key=lambda k: rel(got[k], l32[k]))
+            rms = (sum(rel(got[k], l64[k]) ** 2 for k in l64) / len(l64)) ** 0.5
+            parity_out[f'planes{planes}'] = {'planes': planes, 'worst_rel': rel(got[k64], l64[k64]), 'key': k64,
+                                             'worst_rel_vs_fp32_cpu': rel(got[k32], l32[k32]), 'key_vs_fp32_cpu': k32,
+                                             'rms_rel_over_keys': rms, 'within_1e-4': bool(rel(got[k64], l64[k64]) <= 1e-4 and rel(got[k32], l32[k32]) <= 1e-4)}
+        parity_out['fp32_floor_rms_over_keys'] = (sum(rel(l32[k], l64[k]) ** 2 for k in l64) / len(l64)) ** 0.5
     cpu_model = ''
     try:
         cpu_model = [l.split(':', 1)[1].strip() for l in open('/proc/cpuinfo') if l.startswith('model name')][0]
     except (OSError, IndexError):
         pass
-    # BASELINE.md 3's own protocol (3 warm-up + 10 timed iterations, median) on a 4-frame sample of the same frames, as far as a
-    # budget of ~45 s of CPU time allows: the iteration counts actually run are reported
-    small = synthetic.make_batch(4, start=901, pc_range=synthetic.RANGE_PP)
-    budget, t_begin, times, warm_done = 45.0, time.perf_counter(), [], 0
+    # BASELINE.md 3's own protocol - 3 warm-up + 10 timed iterations, median - run to its full counts on a 2-frame sample of
+    # the same frames (13 steps of the 16-frame sample would take ~7 minutes)
+    small = synthetic.make_batch(2, start=901, pc_range=synthetic.RANGE_PP)
+    times, warm_done = [], 0
     for i in range(13):
         model.zero_grad()
         t1 = time.perf_counter()
@@ -647,22 +839,21 @@ def cpu_baseline(cfg, frames=16):
             warm_done += 1
         else:
             times.append(d1)
-        if time.perf_counter() - t_begin + d1 > budget and len(times) >= 3:
-            break
     times.sort()
     med = times[len(times) // 2]
-    return {'value': round(frames / dt, 4), 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
-            'sample': f'1 train step (fwd+bwd, no optimizer) on {frames} synthetic frames, {dt:.1f} s',
-            'protocol_sample': {'value': round(4 / med, 4), 'unit': 'frames/s', 'frames': 4, 'warmup_iterations': warm_done,
-                                'timed_iterations': len(times), 'median_s': round(med, 3), 'threads': cores,
-                                'note': 'BASELINE.md 3: 3 warm-up + 10 timed iterations, median, on a 4-frame sample (timed iterations cut '
-                                        'short when ~45 s of CPU time are used up); threads = `cores`, not os.cpu_count(): torch\'s CPU '
-                                        'convolutions are slower with all hardware threads of this host than with 32'},
-            'protocol': ('`value`: one small warm-up step, ONE timed step of the full 16-frame sample on 32 threads (a step takes ~30 s: 13 of '
-                         'them would break the bound on the bench run). `protocol_sample`: BASELINE.md 3\'s 3 + 10 protocol on 4 frames. '
-                         'The pieces below follow the protocol too (median of 10 after 3)'),
-            'host_cpu': cpu_model, 'host_threads': os.cpu_count(),
-            'pieces_ms_per_16_frames': cpu_pieces(cfg, frames)}
+    out = {'value': round(frames / dt, 4), 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
+           'sample': (f'1 train step (fwd+bwd, no optimizer) on {frames} synthetic frames, {dt:.1f} s'
+                      + (' - the batch and the weights of the timed GPU steps (see parity_at_bench_size)' if parity is not None else '')),
+           'protocol_sample': {'value': round(2 / med, 4), 'unit': 'frames/s', 'frames': 2, 'warmup_iterations': warm_done,
+                               'timed_iterations': len(times), 'median_s': round(med, 3), 'threads': cores,
+                               'note': 'BASELINE.md 3: 3 warm-up + 10 timed iterations, median, on a 2-frame sample; threads = `cores`, not '
+                                       'os.cpu_count(): torch\'s CPU convolutions are slower with all hardware threads of this host than with 32'},
+           'protocol': ('`value`: one small warm-up step, ONE timed step of the full 16-frame sample on 32 threads (a step takes ~30 s: 13 of '
+                        'them would break the bound on the bench run). `protocol_sample`: BASELINE.md 3\'s 3 + 10 protocol on 2 frames. '
+                        'The pieces below follow the protocol too (median of 10 after 3)'),
+           'host_cpu': cpu_model, 'host_threads': os.cpu_count(),
+           'pieces_ms_per_16_frames': cpu_pieces(cfg, 16)}
+    return out, parity_out
 
 
 def main():
@@ -747,6 +938,9 @@ def main():
             res['dtype'] = DTYPE_PLANES3
         res['range_guard'] = main_run['runner'].range_reports
     cfg_main = main_run['cfg']
+    parity_pack = None
+    if rank == 0 and world == 1 and is_pp and not args.no_cpu_baseline:
+        parity_pack = bench_size_gpu_losses(main_run)
     del main_run
     gc.collect()
     torch.cuda.empty_cache()
@@ -826,6 +1020,15 @@ def main():
     if is_pp and world == 1 and not args.no_loader_fed:
         res['loader_fed'] = run_loader_fed(args, device, res['value'])
 
+    if is_pp and world == 1 and not args.no_inference:
+        from gga_amd import synthetic as _syn
+        res['inference'] = run_inference(args, device, args.config, _syn.RANGE_PP, frames=args.inference_frames)
+        res['inference']['vs_train_step_frames_per_s'] = round(res['inference']['samples_per_gpu_16']['value'] / res['value'], 2)
+        if not args.no_second_trunk:
+            res['inference']['second_trunk'] = run_inference(args, device, SECOND_CONFIG, _syn.RANGE_SECOND, frames=args.inference_frames)
+            res['inference']['second_trunk']['vs_train_step_frames_per_s'] = round(
+                res['inference']['second_trunk']['samples_per_gpu_16']['value'] / res['second_trunk']['value'], 2)
+
     if is_pp and not args.no_planes3:
         # the same steps on the library's default arithmetic (three bf16 planes / six products: fp32 semantics per element)
         s3, w3 = args.steps, args.warmup          # the same protocol as the headline
@@ -850,7 +1053,7 @@ def main():
 
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            res['cpu_baseline'] = cpu_baseline(cfg_main)
+            res['cpu_baseline'], res['parity_at_bench_size'] = cpu_baseline(cfg_main, parity=parity_pack)
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

@@ -273,8 +273,14 @@ __global__ __launch_bounds__(64 * X9_NW, 2) void sp_conv_x9_kernel(const float* 
                                                         float* __restrict__ Y, int64_t ys,
                                                         const uint32_t* __restrict__ amax_x,
                                                         const uint32_t* __restrict__ amax_w, double* __restrict__ stats,
-                                                        SpBnBwd bn, int tile_order, int64_t n_tiles) {
+                                                        SpBnBwd bn, int tile_order, int64_t n_tiles, int offset_sums) {
     // NP = 3: bf16 planes, six partial products; NP = 2: fp16 planes of the scaled operands, three (h2_split2)
+    // offset_sums (round 6, the default): the matrix instructions of ONE offset (cin / 16 k-steps x 3 or 6 products) run as
+    // their own chain from zero and the offset's partial result is added to the row's sum once - the summation order of the
+    // reference's gather -> GEMM -> scatter-add per offset (spconv / mmcv: one sgemm of K = cin per offset, 27 additions),
+    // with chains of 3 cin / 16 roundings instead of ONE chain of 27 x 3 cin / 16: the accumulator's rounding noise
+    // ~ 0.4 u sqrt(n / 2) for a chain of n additions falls from 7 u (cin 128) to 0.4 u sqrt((3 cin / 16 + 27) / 2) = 2 u
+    // (DESIGN.md 6f). Costs cout / 4 v_pk_add_f32 per offset beside cin / 16 x 3 x cout / 32 matrix instructions.
     constexpr int CO = NT * 32;
     constexpr int BPL = CO * X9_ROWB;                     // bytes per B plane
     constexpr int BSZ = NP * BPL;                         // bytes per B buffer
@@ -314,11 +320,11 @@ __global__ __launch_bounds__(64 * X9_NW, 2) void sp_conv_x9_kernel(const float* 
 #pragma unroll
     for (int w = 0; w < NW; ++w) tm |= wmask_s[w];
     const uint32_t tmask = __builtin_amdgcn_readfirstlane(tm);
-    mf_v16 acc[NT];
+    mf_v16 acc[NT], total[NT];                            // the running offset's chain; the sum of the finished offsets
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
+        for (int i = 0; i < 16; ++i) { acc[t][i] = 0.0f; total[t][i] = 0.0f; }
 
     const int nchunks = (cin + MF_TK - 1) / MF_TK;
     auto enabled = [&](int k) { const int kk = flip ? (kvol - 1 - k) : k; return kvol > 32 || ((tmask >> kk) & 1u); };
@@ -427,6 +433,14 @@ __global__ __launch_bounds__(64 * X9_NW, 2) void sp_conv_x9_kernel(const float* 
 #undef X9_MH
 #undef X9_MM
                 }
+                if (offset_sums && ch == nchunks - 1) {   // the offset's chain is complete: one addition per element, a fresh chain
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        total[t] += acc[t];
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
+                    }
+                }
             }
             if (!valid1) break;
             store_b(buf ^ 1);                            // last read before the previous barrier
@@ -439,6 +453,8 @@ __global__ __launch_bounds__(64 * X9_NW, 2) void sp_conv_x9_kernel(const float* 
             if (ch1 == nchunks) { ch1 = 0; k1 = knext; }
         }
     }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] += total[t];      // (offset_sums: acc is zero here; otherwise total is)
     x9_epilogue<NT, NP, NW>(acc, pr, wave, r, h, tid, cout, Y, ys, stats, tile, bn, Bs, sbx, sbw);
 }
 
@@ -861,11 +877,12 @@ extern "C" int gga_sparse_conv_apply_bn_bwd(const float* x, const int32_t* map, 
                 (long long)n_rows, kvol, cin, cout, (long long)y_row_stride);
     const int64_t n_tiles = (n_rows + X9_TM - 1) / X9_TM;
     static const int tile_order = getenv("GGA_SP_TILE_ORDER") ? atoi(getenv("GGA_SP_TILE_ORDER")) : 0;
+    static const int offset_sums = getenv("GGA_SP_OFFSET_SUMS") ? atoi(getenv("GGA_SP_OFFSET_SUMS")) : 1;      // 0: one chain over all offsets (rounds 1-5)
     const dim3 grid((unsigned)(tile_order == 1 ? 8 * ((n_tiles + 7) / 8) : n_tiles)), block(64 * X9_NW);
     hipEvent_t* tev = gga_timing_acquire(GGA_TIME_SPARSE_CONV, GGA_TIMING_CONV_KEY(cin, cout, 0));
     GGA_TIME_START(tev, stream);
-#define X9_LAUNCH(NT, VEC) { if (planes == 3) hipLaunchKernelGGL((sp_conv_x9_kernel<NT, VEC, 3>), grid, block, 0, stream, x, map, (const uint16_t*)split_weight, perm, rowmask, n_rows, kvol, cin, cout, flip, y, y_row_stride, amax_x, amax_weight, stats, bn, tile_order, n_tiles); \
-                             else hipLaunchKernelGGL((sp_conv_x9_kernel<NT, VEC, 2>), grid, block, 0, stream, x, map, (const uint16_t*)split_weight, perm, rowmask, n_rows, kvol, cin, cout, flip, y, y_row_stride, amax_x, amax_weight, stats, bn, tile_order, n_tiles); }
+#define X9_LAUNCH(NT, VEC) { if (planes == 3) hipLaunchKernelGGL((sp_conv_x9_kernel<NT, VEC, 3>), grid, block, 0, stream, x, map, (const uint16_t*)split_weight, perm, rowmask, n_rows, kvol, cin, cout, flip, y, y_row_stride, amax_x, amax_weight, stats, bn, tile_order, n_tiles, offset_sums); \
+                             else hipLaunchKernelGGL((sp_conv_x9_kernel<NT, VEC, 2>), grid, block, 0, stream, x, map, (const uint16_t*)split_weight, perm, rowmask, n_rows, kvol, cin, cout, flip, y, y_row_stride, amax_x, amax_weight, stats, bn, tile_order, n_tiles, offset_sums); }
     if ((cin & 3) == 0) {
         switch (mf_nt(cout)) {
             case 1: X9_LAUNCH(1, true); break;

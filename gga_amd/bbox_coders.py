@@ -29,7 +29,10 @@ class CenterPointBBoxCoder:
         B, C = fmap.shape[:2]
         return fmap.reshape(B, C, -1).gather(2, cells.unsqueeze(1).expand(B, C, cells.shape[1])).transpose(1, 2)
 
-    def decode(self, heat, rot_sine, rot_cosine, hei, dim, vel, reg=None, task_id=-1):
+    def decode_dense(self, heat, rot_sine, rot_cosine, hei, dim, vel, reg=None, task_id=-1):
+        """The top-``max_num`` cells of every frame, decoded, BEFORE the masks: boxes [B, K, code], scores [B, K] (descending),
+        labels [B, K] (class within the task, float). ``decode`` masks them per frame; the head's batched post-processing
+        (``functional.centerpoint_detect``) applies the same masks on the device for all frames and tasks at once."""
         if self.post_center_range is None:
             raise NotImplementedError('Need to reorganize output as a batch, only support '
                                       'post_center_range is not None for now!')
@@ -51,13 +54,16 @@ class CenterPointBBoxCoder:
         parts = [xs, ys, self._at(hei, cell), self._at(dim, cell), rot]
         if vel is not None:
             parts.append(self._at(vel, cell))
-        boxes = torch.cat(parts, dim=2)
+        return torch.cat(parts, dim=2), score, label.float()
+
+    def decode(self, heat, rot_sine, rot_cosine, hei, dim, vel, reg=None, task_id=-1):
+        boxes, score, label = self.decode_dense(heat, rot_sine, rot_cosine, hei, dim, vel, reg=reg, task_id=task_id)
         lim = F.const_tensor(list(self.post_center_range), heat.device)
         keep = (boxes[..., :3] >= lim[:3]).all(2) & (boxes[..., :3] <= lim[3:]).all(2)
         if self.score_threshold is not None:
             keep &= score > self.score_threshold
-        return [dict(bboxes=boxes[i, keep[i]], scores=score[i, keep[i]], labels=label[i, keep[i]].float())
-                for i in range(B)]
+        return [dict(bboxes=boxes[i, keep[i]], scores=score[i, keep[i]], labels=label[i, keep[i]])
+                for i in range(heat.shape[0])]
 
 
 # ----------------------------------------------------------------------------- mono3d coders (PGD / FCOS3D)

@@ -34,6 +34,14 @@ class LiDARInstance3DBoxes:
             shift = F.const_tensor([0.5 - origin[0], 0.5 - origin[1], 0.0 - origin[2]], self.tensor.device, self.tensor.dtype)
             self.tensor[:, :3] += self.tensor[:, 3:6] * shift
 
+    @classmethod
+    def wrap(cls, tensor, box_dim=7, with_yaw=True):
+        """A box object OVER ``tensor`` [N, box_dim] (no copy: the constructor clones, one launch per frame in a loop over a
+        batch's detections); origin (0.5, 0.5, 0)."""
+        obj = cls.__new__(cls)
+        obj.tensor, obj.box_dim, obj.with_yaw = tensor, box_dim, with_yaw
+        return obj
+
     volume = property(lambda self: self.tensor[:, 3] * self.tensor[:, 4] * self.tensor[:, 5])
     dims = property(lambda self: self.tensor[:, 3:6])
     yaw = property(lambda self: self.tensor[:, 6])

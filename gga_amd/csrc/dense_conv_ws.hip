@@ -18,7 +18,7 @@
 // LDS images, packed weight layout (dense_pack_weight_kernel / weight_bank.hip), arithmetic and epilogues (scale back, BatchNorm
 // statistics, the BatchNorm-backward mask + sums of DcBnBwd) are those of dense_conv3x3_x9_kernel; results differ from it only
 // in the order of the per-tile statistics' partial sums.
-// What it bought: 7-22 % stand-alone on dense random inputs, 3 % per launch inside the step - the matrix pipe went from
+// What it bought (EXPERIMENTS.md 6d): 7-22 % stand-alone on dense random inputs, 3 % per launch inside the step - the matrix pipe went from
 // 0.45-0.50 to 0.50-0.61 busy and the clock fell from 2.0-2.2 to 1.84-1.97 GHz with it: under this arithmetic the part is
 // power-managed (the same stream on zero operands runs a third faster), so a better-fed pipe is paid back in frequency.
 #include <stdlib.h>
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(512, 2) void dense_conv3x3_ws_kernel(const float* _
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // The same producer / consumer kernel with v_mfma_f32_16x16x32_f16 in the consumer waves (round 5). Why: the 32x32x16 form is
-// power-managed (busy x clock pinned near 1.0-1.1 GHz-equivalents), and under that regime the chip holds a
+// power-managed (busy x clock pinned near 1.0-1.1 GHz-equivalents, EXPERIMENTS.md 6d), and under that regime the chip holds a
 // higher clock on the 16x16x32 shape (MI355X_MICROARCH.md 'DVFS give-back' item 7). tools_dev/micro/ws_shape_probe.hip - this
 // kernel's consumer loop alone, random fp16 operands in LDS, same output tile per wave (128 accumulator registers), same LDS
 // bytes per FLOP - measured 1523 against 1374 TFLOP/s issued (2.32 against 1.98 GHz in-kernel) on this part.

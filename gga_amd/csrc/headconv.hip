@@ -13,7 +13,7 @@
 // in LDS: headconv_fwd_kernel / headconv_wgrad_kernel - kept for maps beyond the 32-bit tile offsets of the newer ones and
 // for the A/B, GGA_HEADCONV_PARKED) and round 3, the shipped ones (headconv_fwd16_kernel / headconv_wgrad16_kernel: operand
 // straight from the load into v_mfma_f32_16x16x4_f32, every load a tile ahead with counted waits; 0.091 -> 0.056-0.063 ms
-// forward, 0.100 -> 0.047-0.055 ms weight gradient at 16 x 248 x 216: DESIGN.md 6c).
+// forward, 0.100 -> 0.047-0.055 ms weight gradient at 16 x 248 x 216: EXPERIMENTS.md 6c).
 // Backward-data is never materialised on the train path: the gradient w.r.t. the (never stored)
 // normalised activation is recomputed from the 1-4 channel grad_y inside the BatchNorm backward of
 // the branch (headtail_bwd_kernel below).

@@ -7,7 +7,7 @@
 // Reference: mmdet3d/models/middle_encoders/sparse_encoder.py:107-214, mmdet3d/ops/sparse_block.py:82-199 (layers of the
 // un-vendored mmcv / spconv wheels).
 // Experiments that were measured and not shipped (an LDS-DMA ring form of the gather-GEMM, ablation builds of every kernel,
-// in-kernel cycle accounting) are in the history up to commit a966a5a; DESIGN.md 6c has their numbers.
+// in-kernel cycle accounting) are in the history up to commit a966a5a; EXPERIMENTS.md 6c has their numbers.
 #include <stdlib.h>
 
 #include "gga_common.h"
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(64 * X9_NW, 2) void sp_conv_x9_kernel(const float* 
     // reference's gather -> GEMM -> scatter-add per offset (spconv / mmcv: one sgemm of K = cin per offset, 27 additions),
     // with chains of 3 cin / 16 roundings instead of ONE chain of 27 x 3 cin / 16: the accumulator's rounding noise
     // ~ 0.4 u sqrt(n / 2) for a chain of n additions falls from 7 u (cin 128) to 0.4 u sqrt((3 cin / 16 + 27) / 2) = 2 u
-    // (DESIGN.md 6f). Costs cout / 4 v_pk_add_f32 per offset beside cin / 16 x 3 x cout / 32 matrix instructions.
+    // (EXPERIMENTS.md 6f). Costs cout / 4 v_pk_add_f32 per offset beside cin / 16 x 3 x cout / 32 matrix instructions.
     constexpr int CO = NT * 32;
     constexpr int BPL = CO * X9_ROWB;                     // bytes per B plane
     constexpr int BSZ = NP * BPL;                         // bytes per B buffer
@@ -459,7 +459,7 @@ __global__ __launch_bounds__(64 * X9_NW, 2) void sp_conv_x9_kernel(const float* 
 }
 
 // ------------------------------------------------------------------------------ the same product, halo form (SubM)
-// What bounds the two forms above at the 128-channel level of the shipped config is not the matrix pipe:
+// What bounds the two forms above at the 128-channel level of the shipped config (EXPERIMENTS.md 6c) is not the matrix pipe:
 //   bytes   sp_conv_x9_kernel moves 9.2 GB L2 -> CU per launch (every row 18 x its 512 bytes, a 16 KB weight stage per 128
 //           rows and stage): 28 GB/s per CU, what 64 KB in flight per CU get from beyond the L2;
 //   issue   every gathered fp32 element is split into its two fp16 planes by the lane that feeds it to the MFMA - ~12 vector

@@ -14,6 +14,8 @@ What differs is *where* the work runs:
 import copy
 
 import numpy as np
+import os
+
 import torch
 from torch import nn
 
@@ -385,6 +387,9 @@ class CenterHead_GGA(nn.Module):
         builds the box structure (default ``LiDARInstance3DBoxes``). Returns
         ``[[bboxes, scores, labels], ...]`` per sample."""
         from .box3d import LiDARInstance3DBoxes
+        fast = self._get_bboxes_batched(preds_dicts, img_metas)
+        if fast is not None:
+            return fast
         rets = []
         for task_id, preds_dict in enumerate(preds_dicts):
             pd = preds_dict[0]
@@ -417,6 +422,42 @@ class CenterHead_GGA(nn.Module):
                 labels.append(rets[j][i]['labels'].int() + flag)
                 flag += num_class
             ret_list.append([bboxes, scores, torch.cat(labels)])
+        return ret_list
+
+    # Round 6: all frames and tasks in ONE launch behind the coder's batched top-k decode (csrc/postproc.hip::
+    # centerpoint_detect_kernel - the same masks, NMS boxes, greedy order, range filter and merge as the loop below, which stays
+    # as the path for circle NMS, coders without ``decode_dense``, > 128 candidates per task, and CPU tensors; the two are
+    # compared detection by detection in tests/test_postproc_gpu.py). GGA_DETECT_BATCHED=0: off.
+    BATCHED = os.environ.get('GGA_DETECT_BATCHED', '1') != '0'
+
+    def _get_bboxes_batched(self, preds_dicts, img_metas):
+        from .box3d import LiDARInstance3DBoxes
+        tc, coder = self.test_cfg, self.bbox_coder
+        heat0 = preds_dicts[0][0]['heatmap']
+        if not (self.BATCHED and tc['nms_type'] == 'rotate' and heat0.is_cuda and hasattr(coder, 'decode_dense')
+                and coder.max_num <= 128 and coder.post_center_range is not None):
+            return None
+        boxes, scores, labels = [], [], []
+        for task_id, preds_dict in enumerate(preds_dicts):
+            pd = preds_dict[0]
+            batch_dim = torch.exp(pd['dim']) if self.norm_bbox else pd['dim']
+            b, s, l = coder.decode_dense(pd['heatmap'].sigmoid(), pd['rot'][:, 0].unsqueeze(1), pd['rot'][:, 1].unsqueeze(1),
+                                         pd['height'], batch_dim, pd.get('vel'), reg=pd['reg'], task_id=task_id)
+            boxes.append(b), scores.append(s), labels.append(l)
+        if len({tuple(b.shape) for b in boxes}) != 1:
+            return None
+        out_boxes, out_scores, out_labels, count = F.centerpoint_detect(
+            torch.stack(boxes), torch.stack(scores), torch.stack(labels), coder.post_center_range, coder.score_threshold,
+            tc['score_threshold'], tc['post_center_limit_range'], tc['nms_thr'], tc['pre_max_size'], tc['post_max_size'],
+            self.num_classes)
+        counts = count.tolist()                            # the one host read of the batch
+        ret_list = _BatchedDetections()
+        for i, n in enumerate(counts):
+            box_type = (img_metas[i].get('box_type_3d') if isinstance(img_metas[i], dict) else None) or LiDARInstance3DBoxes
+            view = out_boxes[i, :n]
+            ret_list.append([LiDARInstance3DBoxes.wrap(view, coder.code_size) if box_type is LiDARInstance3DBoxes
+                             else box_type(view, coder.code_size), out_scores[i, :n], out_labels[i, :n]])
+        ret_list.packed = (out_boxes, out_scores, out_labels, counts)
         return ret_list
 
     def get_task_detections(self, num_class_with_bg, batch_cls_preds, batch_reg_preds, batch_cls_labels, img_metas):
@@ -455,6 +496,12 @@ class CenterHead_GGA(nn.Module):
                                 scores=torch.zeros([0], dtype=dt, device=dev),
                                 labels=torch.zeros([0], dtype=top_labels.dtype, device=dev)))
         return out
+
+
+class _BatchedDetections(list):
+    """``get_bboxes``' list of [boxes, scores, labels] per frame, whose entries are views of one set of batch tensors
+    (``packed`` = (boxes [B, N, D], scores [B, N], labels [B, N], counts)): ``simple_test_pts`` moves those to the host once."""
+    packed = None
 
 
 def circle_nms(dets, thresh, post_max_size=83):

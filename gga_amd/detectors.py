@@ -173,6 +173,14 @@ class MVXTwoStageDetector_GGA(nn.Module):
         from .box3d import bbox3d2result
         outs = self.pts_bbox_head(x)
         bbox_list = self.pts_bbox_head.get_bboxes(outs, img_metas, rescale=rescale)
+        packed = getattr(bbox_list, 'packed', None)
+        if packed is not None:
+            # the batched post-processing left one set of batch tensors: three copies to the host for the whole batch
+            # instead of three per frame (each a synchronisation); the per-frame results are host-side views
+            boxes, scores, labels, counts = packed
+            boxes, scores, labels = boxes.cpu(), scores.cpu(), labels.cpu()
+            return [dict(boxes_3d=type(b)(boxes[i, :n], b.box_dim, with_yaw=b.with_yaw), scores_3d=scores[i, :n], labels_3d=labels[i, :n])
+                    for i, (n, (b, _, _)) in enumerate(zip(counts, bbox_list))]
         return [bbox3d2result(bboxes, scores, labels) for bboxes, scores, labels in bbox_list]
 
     @torch.no_grad()

@@ -1213,3 +1213,32 @@ def head_conv3x3(x, conv):
     if not ok:
         return conv(x)
     return _HeadConv3x3.apply(x, conv.weight, conv.bias)
+
+
+def centerpoint_detect(boxes, scores, labels, coder_range, coder_score_threshold, score_threshold, limit_range, nms_threshold,
+                       pre_max_size, post_max_size, num_classes):
+    """``gga_centerpoint_detect``: boxes [T, B, K, D] / scores / labels [T, B, K] of all tasks' decoded top-k cells -> the
+    detections of every frame (masks, rotated BEV NMS, range filter, task merge, bottom-centre z, global labels) in one launch.
+    -> (out_boxes [B, T*K, D], out_scores [B, T*K], out_labels int32 [B, T*K], count int32 [B])."""
+    _need_cuda(boxes, scores, labels)
+    T, B, K, D = boxes.shape
+    dev = boxes.device
+    boxes, scores, labels = boxes.float().contiguous(), scores.float().contiguous(), labels.float().contiguous()
+    out_boxes = torch.empty((B, T * K, D), dtype=torch.float32, device=dev)
+    out_scores = torch.empty((B, T * K), dtype=torch.float32, device=dev)
+    out_labels = torch.empty((B, T * K), dtype=torch.int32, device=dev)
+    count = torch.zeros((B,), dtype=torch.int32, device=dev)
+    offs, flag = [], 0
+    for n in num_classes:
+        offs.append(flag)
+        flag += int(n)
+    cr = const_tensor([float(v) for v in coder_range], dev)
+    lr = const_tensor([float(v) for v in limit_range], dev) if limit_range is not None and len(limit_range) > 0 else None
+    co = const_tensor(offs, dev, torch.int32)
+    sc = const_tensor([int(int(n) == 1) for n in num_classes], dev, torch.int32)
+    check(_lib.lib().gga_centerpoint_detect(_p(boxes), _p(scores), _p(labels), T, B, K, D, _p(cr),
+                                            float(coder_score_threshold) if coder_score_threshold is not None else 0.0,
+                                            int(coder_score_threshold is not None), float(score_threshold), _p(lr), float(nms_threshold),
+                                            int(pre_max_size or 0), int(post_max_size or 0), _p(co), _p(sc), _p(out_boxes), _p(out_scores),
+                                            _p(out_labels), _p(count), _stream()), 'gga_centerpoint_detect')
+    return out_boxes, out_scores, out_labels, count

@@ -24,6 +24,8 @@ from collections.abc import Mapping, Sequence
 from functools import partial
 
 import numpy as np
+import collections
+
 import torch
 from torch.utils.data import DataLoader, Sampler
 from torch.utils.data.dataloader import default_collate
@@ -272,6 +274,18 @@ class PackedFrames:
     def __len__(self):
         return len(self.sizes if self.inner is None else self.inner)
 
+    # The collate contract: mmcv's collate hands every non-stacked DataContainer payload over as a list with one entry per
+    # frame. Code that walks a batch without ``to_step_inputs`` (user hooks, ``batch['points'].data[0][i]``) finds that list
+    # here: the per-frame views, made on demand.
+    def frames(self):
+        return _unpack_frames(self)
+
+    def __iter__(self):
+        return iter(self.frames())
+
+    def __getitem__(self, i):
+        return self.frames()[i]
+
 
 class FrameList(list):
     """The per-frame views of a ``PackedFrames`` payload; ``flat`` / ``sizes`` (/ ``inner``) describe the memory behind them."""
@@ -355,6 +369,19 @@ class PointUploader:
         self.pinned, self.dev, self.copied = [None] * self.DEPTH, [None] * self.DEPTH, [None] * self.DEPTH
         self.queued = []            # events on the caller's stream, one per call: the work queued before that call
         self.calls = 0
+        # Loops that report their steps (``step_done`` after queueing the step that consumed the OLDEST uploaded batch;
+        # ``Runner.train_epochs`` does) give every slot the event of its last reader, and the next upload into the slot waits
+        # for exactly that - whatever the loop's look-ahead. Loops that never report keep the call-order rule below, which is
+        # only safe when at most one batch is uploaded ahead of the step being queued.
+        self.readers = [None] * self.DEPTH
+        self.unread = collections.deque()
+
+    def step_done(self):
+        """The step that reads the oldest not-yet-consumed upload has just been queued on the current stream."""
+        if self.unread:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            self.readers[self.unread.popleft()] = ev
 
     def _buffers(self, slot, like):
         rows = like.shape[0]
@@ -378,8 +405,15 @@ class PointUploader:
         pinned, dev = self._buffers(slot, flat)
         n = flat.shape[0]
         pinned[:n].copy_(flat)
-        if len(self.queued) >= 2:
+        if slot in self.unread:                      # the slot's previous content was never reported as consumed: everything queued so far may read it
+            self.stream.wait_event(now)
+            self.unread.remove(slot)
+        elif self.readers[slot] is not None:
+            self.stream.wait_event(self.readers[slot])
+        elif len(self.queued) >= 2:
             self.stream.wait_event(self.queued[-2])  # the slot's previous reader was queued before the previous call
+        self.readers[slot] = None
+        self.unread.append(slot)
         del self.queued[:-2]
         with torch.cuda.stream(self.stream):
             dev[:n].copy_(pinned[:n], non_blocking=True)

@@ -560,6 +560,8 @@ class Runner:
             on_gpu = self.device.type == 'cuda'
             uploader = PointUploader(self.device) if on_gpu and os.environ.get('GGA_POINT_UPLOADER', '1') == '1' else None
             to_inputs = lambda b: to_step_inputs(b, self.device if on_gpu else None, uploader=uploader)
+        else:
+            uploader = None
         clock = time.perf_counter
         acc = self.loop_seconds = dict(fetch=0.0, inputs=0.0, step=0.0, iters=0)
 
@@ -595,6 +597,8 @@ class Runner:
                     self.freeze_gc()
                 t = clock()
                 out = self.step(cur, next_data=nxt)
+                if uploader is not None:
+                    uploader.step_done()                  # the slot of `cur` has its last reader: the next upload into it waits for this step
                 acc['step'] += clock() - t
                 acc['iters'] += 1
                 n += 1

@@ -794,6 +794,24 @@ int gga_circle_nms_sorted(const float* xy_sorted, int n, double thresh, int max_
 int gga_points_in_boxes(const float* points, const float* boxes, int B, int M, int T, int all,
                         int32_t* out, void* stream);
 
+/* Detections of a whole batch in one launch: the per-(frame, task) post-processing of CenterHead_GGA.get_bboxes /
+ * get_task_detections (mmdet3d/models/dense_heads/centerpoint_head_gga.py:725-934) behind CenterPointBBoxCoder.decode's
+ * top-k (mmdet3d/core/bbox/coders/centerpoint_bbox_coders.py:117-229), with nms_bev -> mmcv.ops.nms_rotated
+ * (mmdet3d/core/post_processing/box3d_nms.py:231-268) inside. boxes [n_tasks, n_frames, k, box_dim] = the decoded boxes
+ * (x, y, z gravity centre, dx, dy, dz, yaw [, vx, vy]) of every task's k top-scored cells in descending score order, scores /
+ * labels [n_tasks, n_frames, k] (labels as the coder's float class index within the task). Per frame and task: coder mask
+ * (centre inside coder_range [6] inclusive, score > coder_score_threshold when has_coder_score_threshold), head threshold
+ * (score >= score_threshold when > 0), rotated BEV NMS over the first pre_max_size survivors on the boxes as nms_bev sees them
+ * (centre -/+ extent / 2 and back), IoU > nms_threshold suppresses, at most post_max_size kept (<= 0: no cap), range filter
+ * (limit_range [6] inclusive; NULL: none); tasks concatenated in order, z moved to the bottom centre, label + class_offset[task]
+ * (0 + offset when single_class[task]). out_boxes [n_frames, n_tasks * k, box_dim], out_scores / out_labels [n_frames,
+ * n_tasks * k], out_count [n_frames]: frame b's detections are rows 0 .. out_count[b]. k <= 128. */
+int gga_centerpoint_detect(const float* boxes, const float* scores, const float* labels, int n_tasks, int n_frames, int k,
+                           int box_dim, const float* coder_range, float coder_score_threshold, int has_coder_score_threshold,
+                           float score_threshold, const float* limit_range, float nms_threshold, int pre_max_size,
+                           int post_max_size, const int32_t* class_offset, const int32_t* single_class, float* out_boxes,
+                           float* out_scores, int32_t* out_labels, int32_t* out_count, void* stream);
+
 /* Pseudo-label matching: image-plane IoU of every detection with the ground truths of its own
  * frame and the argmax, i.e. `calculate_iou_partly(dt_annos, gt_annos, metric=0)` followed by
  * `np.argmax(c_overlap, axis=-1)` in tools/utils_pseudo_labels_gga.py:44-59 (IoU arithmetic:

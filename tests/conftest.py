@@ -41,7 +41,7 @@ def _restore_matrix_arithmetic():
 @pytest.fixture(scope='session', autouse=True)
 def _noise_stream():
     """GGA_TEST_NOISE=1: every GPU test runs beside a background thread that keeps small kernels (sort, scan, elementwise) on a
-    second, high-priority stream - the perturbation that exposed a missing barrier in round 3. A parity test
+    second, high-priority stream - the perturbation that exposed a missing barrier in round 3 (EXPERIMENTS.md 6c). A parity test
     that only passes on a quiet device has a race to hide. Off by default (the driver's runs are the quiet ones)."""
     if os.environ.get('GGA_TEST_NOISE') != '1':
         yield

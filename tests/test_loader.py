@@ -162,6 +162,10 @@ def test_packed_hand_over_gives_the_same_lists_and_the_same_targets(tmp_path):
     buf = io.BytesIO()
     ForkingPickler(buf).dump(packed)
     assert buf.getvalue().count(b'rebuild_storage') == 1
+    # the collate contract without to_step_inputs: a packed payload iterates / indexes as the per-frame list it stands for
+    raw_pts, plain_pts = wire['points'].data[1], LD.collate(samples, samples_per_gpu=3)['points'].data[1]
+    assert isinstance(raw_pts, LD.PackedFrames) and len(raw_pts) == 3
+    assert all(torch.equal(a, b) for a, b in zip(raw_pts, plain_pts)) and torch.equal(raw_pts[2], plain_pts[2])
     got = LD.to_step_inputs(wire, chunk=1)
     assert set(got) == set(plain)
     for k, a in plain.items():

@@ -123,3 +123,68 @@ def test_circle_nms_known_answer_and_vs_oracle():
         got = ops.circle_nms(dets.to(DEV), thr, pm).tolist()
         assert got == want, (thr, pm)
     assert ops.circle_nms(torch.zeros(0, 3, device=DEV), 1.0).numel() == 0
+
+
+@pytest.mark.parametrize('cfg_name,B,dim_shift,bias', [('gga_kitti_pointpillars_config.py', 5, 1.2, -2.19), ('gga_kitti_config.py', 3, 0.3, -1.0),
+                                                       ('gga_kitti_config.py', 2, 2.5, -6.0)])
+def test_batched_detections_equal_the_per_frame_loop(cfg_name, B, dim_shift, bias, monkeypatch):
+    """``CenterHead_GGA.get_bboxes`` (centerpoint_head_gga.py:725-934): the one-launch form for all frames and tasks
+    (csrc/postproc.hip::centerpoint_detect_kernel) against the reference's per-(frame, task) loop - coder masks, score
+    threshold, nms_bev on the xyxyr round trip, range filter, merge - which the known-answer tests above pin: the same
+    detections in the same order, bit for bit (boxes, scores, labels), on random head outputs with enough overlap for the NMS
+    to suppress (dim_shift), around the score threshold (bias), and with no survivor at all (bias -6)."""
+    from gga_amd.dense_heads import CenterHead_GGA
+    cfg = Config.fromfile(os.path.join(REPO, 'configs', 'gga', cfg_name))
+    torch.manual_seed(5)
+    model = build_model(cfg.model).to(DEV).eval()
+    head = model.pts_bbox_head
+    W, H = head._feature_map_size() if head.train_cfg else (216, 248)
+    g = torch.Generator(device='cpu').manual_seed(B)
+    preds = []
+    for t in range(len(head.task_heads)):
+        r = lambda c, s=1.0: (torch.randn(B, c, H, W, generator=g) * s).to(DEV)
+        preds.append([dict(heatmap=r(1, 0.6) + bias, reg=r(2, 0.3).sigmoid(), height=r(1), dim=r(3, 0.4) + dim_shift, rot=r(2))])
+    metas = [dict(box_type_3d=LiDARInstance3DBoxes) for _ in range(B)]
+    monkeypatch.setattr(CenterHead_GGA, 'BATCHED', False)
+    loop = head.get_bboxes(preds, metas)
+    monkeypatch.setattr(CenterHead_GGA, 'BATCHED', True)
+    fast = head.get_bboxes(preds, metas)
+    assert getattr(fast, 'packed', None) is not None and getattr(loop, 'packed', None) is None
+    total = suppressed = 0
+    for (b0, s0, l0), (b1, s1, l1) in zip(loop, fast):
+        assert b0.tensor.shape == b1.tensor.shape, (b0.tensor.shape, b1.tensor.shape)
+        assert torch.equal(b0.tensor, b1.tensor) and torch.equal(s0, s1) and torch.equal(l0.int(), l1.int())
+        total += len(s0)
+    if bias > -5:
+        # the case is not vacuous: candidates over the threshold, and the NMS removed some of them
+        cand = sum(int(((p[0]['heatmap'].sigmoid().reshape(B, -1).topk(head.bbox_coder.max_num)[0]) >= 0.1).sum()) for p in preds)
+        assert 0 < total < cand, (total, cand)
+    else:
+        assert total == 0
+    # and through the detector: simple_test's packed hand-over gives the per-frame result dicts of the loop
+    model.pts_bbox_head.BATCHED = True
+
+
+def test_simple_test_batched_results_equal_the_loop(monkeypatch):
+    from gga_amd.dense_heads import CenterHead_GGA
+    cfg = Config.fromfile(os.path.join(REPO, 'configs', 'gga', 'gga_kitti_pointpillars_config.py'))
+    torch.manual_seed(0)
+    model = build_model(cfg.model).to(DEV).eval()
+    with torch.no_grad():
+        for th in model.pts_bbox_head.task_heads:
+            for name in ('reg', 'height', 'dim', 'rot'):
+                getattr(th, name)[-1].weight.mul_(0.05)
+            th.dim[-1].bias.fill_(1.0)
+    b = synthetic.make_batch(3, n_points=6000, pc_range=synthetic.RANGE_PP)
+    pts = [p.to(DEV) for p in b['points']]
+    metas = [dict(m, box_type_3d=LiDARInstance3DBoxes) for m in b['img_metas']]
+    monkeypatch.setattr(CenterHead_GGA, 'BATCHED', False)
+    loop = model.simple_test(pts, metas)
+    monkeypatch.setattr(CenterHead_GGA, 'BATCHED', True)
+    fast = model.simple_test(pts, metas)
+    assert sum(len(r['pts_bbox']['scores_3d']) for r in loop) > 0
+    for r0, r1 in zip(loop, fast):
+        a, c = r0['pts_bbox'], r1['pts_bbox']
+        assert not c['boxes_3d'].tensor.is_cuda and type(c['boxes_3d']) is type(a['boxes_3d'])
+        assert torch.equal(a['boxes_3d'].tensor, c['boxes_3d'].tensor) and torch.equal(a['scores_3d'], c['scores_3d'])
+        assert torch.equal(a['labels_3d'].int(), c['labels_3d'].int())

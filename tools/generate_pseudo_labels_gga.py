@@ -56,6 +56,12 @@ def main():
         print()
         if result is not None:
             print(result)
+    if distributed:
+        # rank 0 has evaluated (the long part) by now: the other ranks wait here instead of leaving the process group while it is
+        # still in use, and the group is torn down in order
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == '__main__':

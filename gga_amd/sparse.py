@@ -58,15 +58,6 @@ class _Rulebook:
             # index preprocessing (once per level, shared by every conv on it): rows with the same
             # neighbour pattern become adjacent, so a 128-row tile skips the offsets none of them uses
             self.perm = mask_order(self.mask, kvol)
-            if BLOCK_ROWS > 0 and coors is not None and extent is not None and n > 2 * BLOCK_ROWS:
-                # experiment (round 6): mask order WITHIN spatial blocks of BLOCK_ROWS rows of the level's Z-order curve - the rows a
-                # tile gathers are then re-referenced by the tiles around it in the walk (an XCD's L2 holds a block's
-                # neighbourhood) and a tile's rows still share most of their offsets
-                mo = morton_order(coors, *extent).long()
-                rank = torch.empty_like(mo)
-                rank[mo] = torch.arange(n, device=mo.device)
-                key = (torch.div(rank, BLOCK_ROWS, rounding_mode='floor') << 32) | (self.mask.long() & 0xFFFFFFFF)
-                self.perm = torch.argsort(key, stable=True).int()
 
     def halo(self):
         if self._halo is None:
@@ -268,14 +259,6 @@ def build_index_plan(module, coors, spatial_shape, batch_size):
     """Walk the ``SparseConvolution`` layers of ``module`` in execution order (= registration order
     for the sequential encoders of the reference) and build every level / rule book they will ask for."""
     coors = coors if coors.dtype == torch.int32 else coors.int()
-    order = None
-    if SPATIAL_ROWS and coors.is_cuda and coors.shape[0] > 1:
-        # experiment (round 6): the encoder's rows along a Z-order curve instead of the voxelizer's first-appearance order (the
-        # points arrive shuffled: a row's 27 neighbours are anywhere in memory and a tile's gathers share nothing with the next
-        # tile's). The levels below inherit the order (output sites are numbered in the order of the input rows that propose them).
-        # The dense map the encoder returns does not depend on the row order.
-        order = morton_order(coors, int(batch_size), int(max(spatial_shape))).long()
-        coors = coors.index_select(0, order)
     lvl = level0 = _Level(coors, spatial_shape, batch_size)
     indice_dict = {}
     for m in module.modules():
@@ -295,9 +278,7 @@ def build_index_plan(module, coors, spatial_shape, batch_size):
                 if m.indice_key:
                     indice_dict[m.indice_key] = cached
             lvl = cached[1]
-    plan = IndexPlan(level0, indice_dict)
-    plan.order = order            # rows of the caller's features -> rows of level 0 (None: the same)
-    return plan
+    return IndexPlan(level0, indice_dict)
 
 
 class SparseModule(nn.Module):
@@ -365,8 +346,6 @@ SPLIT_BF16 = True
 # 0.8 ms of the 52 ms step bought the last rows of the precision table (profiles/r06_sparse_chain_ab.txt).
 HALO = int(os.environ.get('GGA_SP_HALO', '0'))
 HALO_COLUMNS = (128,)
-SPATIAL_ROWS = int(os.environ.get('GGA_SP_SPATIAL_ROWS', '0'))  # 1: level-0 rows in Z-order (build_index_plan)
-BLOCK_ROWS = int(os.environ.get('GGA_SP_BLOCK_ROWS', '0'))       # 0: one mask order over the whole level
 HALO_MIN_ROWS = int(os.environ.get('GGA_SP_HALO_MIN_ROWS', '65536'))
 HALO_MIN_OCCUPANCY = float(os.environ.get('GGA_SP_HALO_MIN_OCCUPANCY', '0.25'))
 

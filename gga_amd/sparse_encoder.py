@@ -116,8 +116,6 @@ class SparseEncoder(nn.Module):
     def forward(self, voxel_features, coors, batch_size):
         plan = getattr(coors, 'index_plan', None)
         if plan is not None and plan.level0.n == voxel_features.shape[0]:
-            if getattr(plan, 'order', None) is not None:
-                voxel_features = voxel_features.index_select(0, plan.order)
             x = SparseConvTensor(voxel_features, plan.level0.coors, self.sparse_shape, int(batch_size), _level=plan.level0)
             x.indice_dict = plan.indice_dict
         else:

@@ -62,7 +62,12 @@ def collect_results(part, size, tmpdir=None, gpu_collect=False):
             dist.broadcast_object_list(name, src=0)
             tmpdir = name[0]
         else:
-            os.makedirs(tmpdir, exist_ok=True)
+            # a directory the caller named: mmdet removes it whole afterwards - fine for one this run creates, not for one that was
+            # there before with other contents: rank 0 looks first, then everybody may write
+            if rank == 0:
+                own_tmpdir = not os.path.isdir(tmpdir)
+                os.makedirs(tmpdir, exist_ok=True)
+            dist.barrier()
         with open(os.path.join(tmpdir, f'part_{rank}.pkl'), 'wb') as f:
             pickle.dump(part, f)
         dist.barrier()
@@ -71,7 +76,7 @@ def collect_results(part, size, tmpdir=None, gpu_collect=False):
             parts = [pickle.load(open(os.path.join(tmpdir, f'part_{r}.pkl'), 'rb')) for r in range(world)]
             if own_tmpdir:
                 shutil.rmtree(tmpdir)
-            else:                              # a directory the caller named: only this run's files leave it
+            else:                              # a directory that existed before this run: only this run's files leave it
                 for r in range(world):
                     os.remove(os.path.join(tmpdir, f'part_{r}.pkl'))
     if rank != 0:

@@ -39,6 +39,9 @@ PP_SEEDS, SECOND_SEEDS = (1, 2, 3), (3, 4, 5, 6, 7, 8, 9, 10)      # weights (to
 _SWEEP = {}                      # (case, seed, planes) -> (worst deviation from float64, the fp32 CPU step's, rms over the 18 keys of both)
 
 
+LOSSES_ONLY_SEEDS = (6, 7, 8, 9, 10)      # sparse config: seeds whose case compares the 18 losses only (CPU restatements forward-only: a third of the time)
+
+
 def _reference_case(name, seed):
     """(model with CPU parameters, batch, srl, fp32 restatement after its step, float64 restatement after its step, losses
     of the fp32 restatement) of one whole-step parity case; the CPU side (oracle/torch_ref.reference_train_step in float32
@@ -68,8 +71,13 @@ def _reference_case(name, seed):
     threads = torch.get_num_threads()
     torch.set_num_threads(min(os.cpu_count() or 1, 32))
     try:
-        ref_losses, _ = R.reference_train_step(ref, batch, srl=srl)
-        ref64_losses, _ = R.reference_train_step(ref64, batch, srl=srl)
+        if name == 'second' and seed in LOSSES_ONLY_SEEDS:
+            with torch.no_grad():
+                ref_losses, _ = R.reference_train_step(ref, batch, srl=srl, backward=False)
+                ref64_losses, _ = R.reference_train_step(ref64, batch, srl=srl, backward=False)
+        else:
+            ref_losses, _ = R.reference_train_step(ref, batch, srl=srl)
+            ref64_losses, _ = R.reference_train_step(ref64, batch, srl=srl)
     finally:
         torch.set_num_threads(threads)
     _REF_CASES[(name, seed)] = (cfg, model, batch, srl, ref, ref64, {k: float(v) for k, v in ref_losses.items()},
@@ -117,6 +125,8 @@ def _gpu_step_against(case, channels_last, planes, monkeypatch, seed=None):
     for k, v in ref_losses.items():
         own = abs(v - ref64_losses[k])
         assert abs(float(losses[k]) - v) <= 1e-4 * max(abs(v), 1.0) + own, (k, float(losses[k]), v, ref64_losses[k])
+    if case == 'second' and seed in LOSSES_ONLY_SEEDS:
+        return                                   # (gradients: seeds 3, 4, 5)
     total, log_vars = model._parse_losses(losses)
     total.backward()
     grads = {}
@@ -130,6 +140,10 @@ def _gpu_step_against(case, channels_last, planes, monkeypatch, seed=None):
     # cannot get that close (early trunk layers, see oracle/torch_ref.gradient_offenders) - no
     # further from it than twice the fp32 CPU restatement is
     assert len(grads) > 100
+    every = R.gradient_offenders(grads, ref, ref64, tol=-1.0, slack=0.0)
+    ratios = sorted(e / max(f, 1e-12) for _, e, f in every)
+    print(f'GRAD_RATIOS {case} seed {seed} planes {planes}: {len(every)} parameters, error vs float64 / the fp32 CPU step\'s: median {ratios[len(ratios) // 2]:.2f}, '
+          f'90th percentile {ratios[int(0.9 * len(ratios))]:.2f}, max {ratios[-1]:.2f}; median error {sorted(e for _, e, _ in every)[len(every) // 2]:.2e}')
     if case == 'pp':
         assert R.gradient_offenders(grads, ref, ref64, tol=GRAD_TOL, slack=2.0) == []
     else:
@@ -165,7 +179,8 @@ def test_pp_train_step_matches_cpu_reference(channels_last, seed, planes, monkey
 
 @pytest.mark.parametrize('seed,planes', [(s, p) for s in SECOND_SEEDS for p in ((2, 3) if s == SECOND_SEEDS[0] else (2,))])
 def test_second_train_step_matches_restatement(seed, planes, monkeypatch):
-    """BASELINE config 1 - the reference's shipped config (configs/gga/gga_kitti_config.py: HardSimpleVFE + SparseEncoder +
+    """(Seeds 6-10: the 18 losses only - the CPU restatements run forward-only; seeds 3-5: losses and every gradient.)
+    BASELINE config 1 - the reference's shipped config (configs/gga/gga_kitti_config.py: HardSimpleVFE + SparseEncoder +
     SECOND + SECONDFPN + CenterHead_GGA; detectors/centerpoint_gga.py:43-86, middle_encoders/sparse_encoder.py:107-138) end to
     end, sparse trunk in the loop, at its real grid with 4 x 20 000 points: all 18 losses within 1e-4 of the float64 step AND
     of the fp32 step of oracle/torch_ref.reference_train_step (pair-list restatement of the 21 sparse convolutions, plain

@@ -48,7 +48,7 @@ ARITH = ('fp32 in / fp32 out, fp32 accumulate. Every convolution (dense 3x3, str
          'reference\'s gather -> GEMM -> scatter-add order; round 6). RMS error vs float64 on the operands of real steps, every '
          'convolution shape and direction of both LiDAR configs (tests/test_precision_gpu.py, profiles/r06_precision_shapes.json): '
          'dense shapes 0.72 x torch-CPU\'s and 0.73 x MIOpen\'s fp32 in the median, never above 1.34 x the less accurate of the two; '
-         'sparse shapes 0.7-1.2 x a per-offset fp32 sgemm + scatter-add (fp32-MFMA kernel of the 4 / 16-channel levels: 1.1-1.8 x; '
+         'sparse shapes 0.7-1.2 x a per-offset fp32 sgemm + scatter-add (the 4 / 16-channel levels, where the sgemm\'s chain is 4-16 terms: 1.1-1.8 x; '
          'asserted: <= 2 x; round 5: 1.5-5.1 x); per element an absolute accuracy of 2^-40 of its tensor\'s largest magnitude. '
          'Selected by the train Runner under its range guard (every operand of iteration 0 and of every 500th iteration is '
          'measured; an operand with > 0.1% of its non-zero elements below 2^-30 of its maximum sends the run to the library '

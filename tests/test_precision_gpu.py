@@ -21,7 +21,7 @@ shape and direction, for the shipped two-plane form:
   gradient where MIOpen is at 4e-7 and torch's CPU kernel at 2e-6);
 * sparse shapes: <= ``SPARSE_LIMIT`` = 2 x a per-offset sgemm + index_add on the CPU (whose chains are 16 .. 128 terms long: 5e-8 ..
   1e-7; the summation order of the reference's gather -> GEMM -> scatter-add) - measured round 6: 0.7 .. 1.2 x on the split-plane
-  kernel, 1.1 .. 1.8 x on the fp32-MFMA kernel of the 4- and 16-channel levels (round 5, one accumulator chain over all offsets:
+  kernel at 32-128 channels, 1.1 .. 1.8 x at the 4- and 16-channel levels (the sgemm's own chain is 4-16 terms there: 5e-8; round 5, one accumulator chain over all offsets:
   1.5 .. 5.1 x; ``sp_conv_x9_kernel``'s ``offset_sums``) - and every two-plane result <= ``ABS_LIMIT_2`` of the tensor's RMS
   (measured <= 1.2e-6: ten units of fp32's last place);
 * three bf16 planes / six products (the fall-back form): <= ``ABS_LIMIT_3`` (measured <= 5.0e-6, on every shape LESS accurate

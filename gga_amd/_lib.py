@@ -156,7 +156,8 @@ SIGNATURES = {
     'gga_points_in_convex_polyhedra': (i32, [vp, i64, i32, vp, vp, i32, i32, vp, vp]),
     'gga_plane_inliers': (i32, [vp, i64, i32, vp, i32, C.c_double, vp, vp, vp]),
     'gga_image_box_match': (i32, [vp, vp, vp, vp, i32, i64, i32, vp, vp, vp, vp, vp]),
-    'gga_centerpoint_detect': (i32, [vp, vp, vp, i32, i32, i32, i32, vp, C.c_float, i32, C.c_float, vp, C.c_float, i32, i32, vp, vp, vp, vp, vp, vp, vp]),
+    'gga_centerpoint_detect_workspace_bytes': (sz, [i32, i32]),
+    'gga_centerpoint_detect': (i32, [vp, vp, vp, i32, i32, i32, i32, vp, C.c_float, i32, C.c_float, vp, C.c_float, i32, i32, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
     'gga_points_in_boxes': (i32, [vp, vp, i32, i32, i32, i32, vp, vp]),
     'gga_fcos3d_targets': (i32, [vp, i32, i32, C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_float), f32, vp, i32,
                                   vp, vp, vp, vp, i32, vp, vp, vp, i64, i64, f32, vp, vp, vp, vp, vp, vp, vp]),

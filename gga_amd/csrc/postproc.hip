@@ -396,8 +396,8 @@ extern "C" int gga_circle_nms_sorted(const float* xy_sorted, int n, double thres
 // (centerpoint_bbox_coders.py:117-229), for ALL frames and tasks in ONE launch (round 6: the per-(frame, task) python loop
 // of the reference - boolean masks, sorts, two NMS launches and a count read-back each, ~25 launches and 4 host
 // synchronisations per pair - was 4-5 ms per frame, 78 % of the pseudo-label run's device-side time per frame).
-// One 128-thread workgroup per frame walks the tasks; per task, thread i owns candidate i of the K <= 128 decoded boxes
-// (already in descending score order: torch.topk) and the steps are the reference's, in its order:
+// One workgroup per (frame, task); thread i owns candidate i of the K <= 128 decoded boxes (already in descending score
+// order: torch.topk) and the steps are the reference's, in its order (a second small launch does step 6 per frame):
 //   1 coder mask      centre inside post_center_range (inclusive) and score > the coder's threshold      (bbox_coders:221-229)
 //   2 head threshold  score >= test_cfg.score_threshold when that is > 0                                     (head:836-846)
 //   3 NMS boxes       bev (x, y, dx, dy, yaw) -> xywhr2xyxyr -> nms_bev's conversion back to xywhr: centre -/+ extent / 2,
@@ -408,7 +408,55 @@ extern "C" int gga_circle_nms_sorted(const float* xy_sorted, int n, double thres
 //   6 merge           tasks concatenated in task order, z moved from the gravity centre to the bottom (z - dz * 0.5, two
 //                     rounded operations), label = class within the task + the classes of the tasks before     (head:797-817)
 // Output: frame b's detections compacted at out_*[b, 0 .. count[b]).
-#define CPD_THREADS 128
+#define CPD_THREADS 256
+#define CPD_K 128
+// rotated_inter_area / rotated_iou with the boxes' cos / sin handed in (computed once per candidate instead of once per pair:
+// the same float operations on the same values, so the overlap is bit-identical to rotated_iou's)
+__device__ __forceinline__ void rect_corners_cs(const float* b, float c, float s, float sx, float sy, P2 out[4]) {
+    const float hw = b[2] * 0.5f, hh = b[3] * 0.5f;
+    const float cx = b[0] - sx, cy = b[1] - sy;
+    const float dx[4] = { -hw, hw, hw, -hw }, dy[4] = { -hh, -hh, hh, hh };
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { out[i].x = cx + dx[i] * c - dy[i] * s; out[i].y = cy + dx[i] * s + dy[i] * c; }
+}
+
+__device__ float rotated_iou_cs(const float* b1, float c1, float s1, const float* b2, float c2, float s2) {
+    const float a1 = b1[2] * b1[3], a2 = b2[2] * b2[3];
+    if (a1 < 1e-14f || a2 < 1e-14f) return 0.0f;
+    const float sx = (b1[0] + b2[0]) * 0.5f, sy = (b1[1] + b2[1]) * 0.5f;
+    P2 poly[10], tmp[10], q[4];
+    rect_corners_cs(b1, c1, s1, sx, sy, poly);
+    rect_corners_cs(b2, c2, s2, sx, sy, q);
+    int n = 4;
+    for (int e = 0; e < 4 && n > 0; ++e) {
+        const P2 a = q[e], bq = q[(e + 1) & 3];
+        const P2 ed = { bq.x - a.x, bq.y - a.y };
+        int m = 0;
+        for (int i = 0; i < n; ++i) {
+            const P2 p = poly[i], r = poly[(i + 1) % n];
+            const float dp = cross2(ed, P2{ p.x - a.x, p.y - a.y });
+            const float dr = cross2(ed, P2{ r.x - a.x, r.y - a.y });
+            if (dp >= 0.0f) tmp[m++] = p;
+            if ((dp >= 0.0f) != (dr >= 0.0f)) {
+                const float t = dp / (dp - dr);
+                tmp[m++] = P2{ p.x + t * (r.x - p.x), p.y + t * (r.y - p.y) };
+            }
+        }
+        n = m;
+        for (int i = 0; i < n; ++i) poly[i] = tmp[i];
+    }
+    float inter = 0.0f;
+    if (n >= 3) {
+        float area = 0.0f;
+        for (int i = 0; i < n; ++i) area += cross2(poly[i], poly[(i + 1) % n]);
+        inter = fabsf(area) * 0.5f;
+    }
+    return inter / (a1 + a2 - inter);
+}
+
+// One 256-thread workgroup per (frame, task): steps 1-5 of the list above; the survivors go to the task's own segment
+// out_*[b, t * K ...] with their number in seg_count[b, t]. Thread pair (i, i + 128) shares candidate i's row of the overlap
+// mask: each takes half of the later candidates (the row's work falls with i, the split keeps the long rows short).
 __global__ __launch_bounds__(CPD_THREADS) void centerpoint_detect_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
                                                                         const float* __restrict__ labels, int T, int B, int K, int D,
                                                                         const float* __restrict__ coder_range, float coder_thr,
@@ -417,110 +465,149 @@ __global__ __launch_bounds__(CPD_THREADS) void centerpoint_detect_kernel(const f
                                                                         int pre_max, int post_max, const int32_t* __restrict__ class_offset,
                                                                         const int32_t* __restrict__ single_class,
                                                                         float* __restrict__ out_boxes, float* __restrict__ out_scores,
-                                                                        int32_t* __restrict__ out_labels, int32_t* __restrict__ out_count) {
+                                                                        int32_t* __restrict__ out_labels, int32_t* __restrict__ seg_count) {
 #pragma clang fp contract(off)
-    __shared__ float nb[CPD_THREADS * 5];
-    __shared__ unsigned long long mask[CPD_THREADS][2];
-    __shared__ int cand[CPD_THREADS], kept[CPD_THREADS];
+    __shared__ float nb[CPD_K * 5], ncs[CPD_K * 2];
+    __shared__ unsigned long long mask[CPD_K][2][2];       // [row][half of the pair][word]
+    __shared__ int cand[CPD_K], kept[CPD_K];
     __shared__ int wave_n[2], n_kept_s;
-    const int b = blockIdx.x, i = threadIdx.x, lane = i & 63, wave = i >> 6;
-    int base = 0;                                          // detections of the tasks before (uniform)
-    for (int t = 0; t < T; ++t) {
-        const float* bx = boxes + ((int64_t)(t * B + b) * K + (i < K ? i : 0)) * D;
+    const int b = blockIdx.x % B, t = blockIdx.x / B, tid = threadIdx.x, i = tid & (CPD_K - 1), half = tid >> 7;
+    const int lane = tid & 63, wave = (tid >> 6) & 1;      // (of the first 128 threads: the candidates' owners)
+    const float* bx = boxes + ((int64_t)(t * B + b) * K + (i < K ? i : 0)) * D;
+    float v[9];
+#pragma unroll
+    for (int d = 0; d < 9; ++d) v[d] = d < D ? bx[d] : 0.0f;
+    const float s = scores[(int64_t)(t * B + b) * K + (i < K ? i : 0)];
+    bool ok = i < K && half == 0;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) ok = ok && v[d] >= coder_range[d] && v[d] <= coder_range[3 + d];
+    if (has_coder_thr) ok = ok && s > coder_thr;
+    if (score_thr > 0.0f) ok = ok && s >= score_thr;
+    // rank among the survivors, in candidate (= score) order
+    const unsigned long long bal = __ballot(ok);
+    if (half == 0 && lane == 0) wave_n[wave] = __popcll(bal);
+    __syncthreads();
+    const int rank = __popcll(bal & ((1ull << lane) - 1ull)) + (wave ? wave_n[0] : 0);
+    int n = wave_n[0] + wave_n[1];
+    if (n > pre_max) n = pre_max;
+    if (ok && rank < n) {
+        cand[rank] = i;
+        const float hw = v[3] / 2.0f, hh = v[4] / 2.0f;
+        const float x1 = v[0] - hw, y1 = v[1] - hh, x2 = v[0] + hw, y2 = v[1] + hh;
+        nb[rank * 5 + 0] = (x1 + x2) / 2.0f; nb[rank * 5 + 1] = (y1 + y2) / 2.0f;
+        nb[rank * 5 + 2] = x2 - x1; nb[rank * 5 + 3] = y2 - y1; nb[rank * 5 + 4] = v[6];
+        ncs[rank * 2] = cosf(v[6]); ncs[rank * 2 + 1] = sinf(v[6]);
+    }
+    __syncthreads();
+    if (i < n) {
+        unsigned long long m0 = 0, m1 = 0;
+        float me[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) me[k] = nb[i * 5 + k];
+        const float mc = ncs[i * 2], ms = ncs[i * 2 + 1];
+        const int mid = i + 1 + (n - i - 1) / 2;
+        const int j0 = half ? mid : i + 1, j1 = half ? n : mid;
+        for (int j = j0; j < j1; ++j)
+            if (rotated_iou_cs(me, mc, ms, nb + j * 5, ncs[j * 2], ncs[j * 2 + 1]) > nms_thr) { if (j < 64) m0 |= 1ull << j; else m1 |= 1ull << (j - 64); }
+        mask[i][half][0] = m0; mask[i][half][1] = m1;
+    }
+    __syncthreads();
+    if (tid == 0) {                                        // greedy scan in score order (n <= 128: two words of "removed")
+        unsigned long long r0 = 0, r1 = 0;
+        int nk = 0;
+        for (int c = 0; c < n && nk < post_max; ++c) {
+            if (((c < 64 ? r0 >> c : r1 >> (c - 64)) & 1ull)) continue;
+            kept[nk++] = c;
+            r0 |= mask[c][0][0] | mask[c][1][0]; r1 |= mask[c][0][1] | mask[c][1][1];
+        }
+        n_kept_s = nk;
+    }
+    __syncthreads();
+    const int nk = n_kept_s;
+    // range filter of the survivors; thread q < 128 owns survivor q (its box is candidate cand[kept[q]])
+    bool in = false;
+    int src = 0;
+    if (half == 0 && i < nk) {
+        src = cand[kept[i]];
+        const float* sb = boxes + ((int64_t)(t * B + b) * K + src) * D;
+        in = true;
+        if (limit_range)
+#pragma unroll
+            for (int d = 0; d < 3; ++d) in = in && sb[d] >= limit_range[d] && sb[d] <= limit_range[3 + d];
+    }
+    const unsigned long long bal2 = __ballot(in);
+    __syncthreads();                                       // (wave_n is reused)
+    if (half == 0 && lane == 0) wave_n[wave] = __popcll(bal2);
+    __syncthreads();
+    const int pos = t * K + __popcll(bal2 & ((1ull << lane) - 1ull)) + (wave ? wave_n[0] : 0);
+    if (in) {
+        const float* sb = boxes + ((int64_t)(t * B + b) * K + src) * D;
+        float* ob = out_boxes + ((int64_t)b * T * K + pos) * D;
+        for (int d = 0; d < D; ++d) ob[d] = sb[d];
+        const float halfh = sb[5] * 0.5f;
+        ob[2] = sb[2] - halfh;
+        out_scores[(int64_t)b * T * K + pos] = scores[(int64_t)(t * B + b) * K + src];
+        const int cls = single_class[t] ? 0 : (int)labels[(int64_t)(t * B + b) * K + src];
+        out_labels[(int64_t)b * T * K + pos] = cls + class_offset[t];
+    }
+    if (tid == 0) seg_count[b * T + t] = wave_n[0] + wave_n[1];
+}
+
+// step 6: frame b's task segments [t * K, t * K + seg_count[b, t]) moved together in task order (in place: a segment only ever
+// moves towards the front, and the workgroup finishes one before it starts the next)
+__global__ __launch_bounds__(CPD_K) void centerpoint_merge_kernel(int T, int K, int D, const int32_t* __restrict__ seg_count,
+                                                                  float* __restrict__ out_boxes, float* __restrict__ out_scores,
+                                                                  int32_t* __restrict__ out_labels, int32_t* __restrict__ out_count) {
+    const int b = blockIdx.x, i = threadIdx.x;
+    int base = seg_count[b * T];
+    for (int t = 1; t < T; ++t) {
+        const int n = seg_count[b * T + t];
         float v[9];
-#pragma unroll
-        for (int d = 0; d < 9; ++d) v[d] = d < D ? bx[d] : 0.0f;
-        const float s = scores[(int64_t)(t * B + b) * K + (i < K ? i : 0)];
-        bool ok = i < K;
-#pragma unroll
-        for (int d = 0; d < 3; ++d) ok = ok && v[d] >= coder_range[d] && v[d] <= coder_range[3 + d];
-        if (has_coder_thr) ok = ok && s > coder_thr;
-        if (score_thr > 0.0f) ok = ok && s >= score_thr;
-        // rank among the survivors, in candidate (= score) order
-        const unsigned long long bal = __ballot(ok);
-        if (lane == 0) wave_n[wave] = __popcll(bal);
-        __syncthreads();
-        const int rank = __popcll(bal & ((1ull << lane) - 1ull)) + (wave ? wave_n[0] : 0);
-        int n = wave_n[0] + wave_n[1];
-        if (n > pre_max) n = pre_max;
-        if (ok && rank < n) {
-            cand[rank] = i;
-            const float hw = v[3] / 2.0f, hh = v[4] / 2.0f;
-            const float x1 = v[0] - hw, y1 = v[1] - hh, x2 = v[0] + hw, y2 = v[1] + hh;
-            nb[rank * 5 + 0] = (x1 + x2) / 2.0f; nb[rank * 5 + 1] = (y1 + y2) / 2.0f;
-            nb[rank * 5 + 2] = x2 - x1; nb[rank * 5 + 3] = y2 - y1; nb[rank * 5 + 4] = v[6];
-        }
-        __syncthreads();
+        float sc = 0.0f;
+        int lb = 0;
+        const int64_t src = (int64_t)b * T * K + t * K + i, dst = (int64_t)b * T * K + base + i;
         if (i < n) {
-            unsigned long long m0 = 0, m1 = 0;
-            float me[5];
-#pragma unroll
-            for (int k = 0; k < 5; ++k) me[k] = nb[i * 5 + k];
-            for (int j = i + 1; j < n; ++j)
-                if (rotated_iou(me, nb + j * 5, 0) > nms_thr) { if (j < 64) m0 |= 1ull << j; else m1 |= 1ull << (j - 64); }
-            mask[i][0] = m0; mask[i][1] = m1;
+            for (int d = 0; d < D; ++d) v[d] = out_boxes[src * D + d];
+            sc = out_scores[src]; lb = out_labels[src];
         }
         __syncthreads();
-        if (i == 0) {                                      // greedy scan in score order (n <= 128: two words of "removed")
-            unsigned long long r0 = 0, r1 = 0;
-            int nk = 0;
-            for (int c = 0; c < n && nk < post_max; ++c) {
-                if (((c < 64 ? r0 >> c : r1 >> (c - 64)) & 1ull)) continue;
-                kept[nk++] = c;
-                r0 |= mask[c][0]; r1 |= mask[c][1];
-            }
-            n_kept_s = nk;
+        if (i < n && base != t * K) {
+            for (int d = 0; d < D; ++d) out_boxes[dst * D + d] = v[d];
+            out_scores[dst] = sc; out_labels[dst] = lb;
         }
         __syncthreads();
-        const int nk = n_kept_s;
-        // range filter of the survivors; thread q owns survivor q (its box is candidate cand[kept[q]])
-        bool in = false;
-        int src = 0;
-        if (i < nk) {
-            src = cand[kept[i]];
-            const float* sb = boxes + ((int64_t)(t * B + b) * K + src) * D;
-            in = true;
-            if (limit_range)
-#pragma unroll
-                for (int d = 0; d < 3; ++d) in = in && sb[d] >= limit_range[d] && sb[d] <= limit_range[3 + d];
-        }
-        const unsigned long long bal2 = __ballot(in);
-        __syncthreads();                                   // (wave_n is reused)
-        if (lane == 0) wave_n[wave] = __popcll(bal2);
-        __syncthreads();
-        const int pos = base + __popcll(bal2 & ((1ull << lane) - 1ull)) + (wave ? wave_n[0] : 0);
-        if (in) {
-            const float* sb = boxes + ((int64_t)(t * B + b) * K + src) * D;
-            float* ob = out_boxes + ((int64_t)b * T * K + pos) * D;
-            for (int d = 0; d < D; ++d) ob[d] = sb[d];
-            const float half = sb[5] * 0.5f;
-            ob[2] = sb[2] - half;
-            out_scores[(int64_t)b * T * K + pos] = scores[(int64_t)(t * B + b) * K + src];
-            const int cls = single_class[t] ? 0 : (int)labels[(int64_t)(t * B + b) * K + src];
-            out_labels[(int64_t)b * T * K + pos] = cls + class_offset[t];
-        }
-        base += wave_n[0] + wave_n[1];
-        __syncthreads();
+        base += n;
     }
     if (i == 0) out_count[b] = base;
 }
+
+extern "C" size_t gga_centerpoint_detect_workspace_bytes(int n_tasks, int n_frames) { return (size_t)n_tasks * n_frames * 4 + 16; }
 
 extern "C" int gga_centerpoint_detect(const float* boxes, const float* scores, const float* labels, int n_tasks, int n_frames,
                                       int k, int box_dim, const float* coder_range, float coder_score_threshold,
                                       int has_coder_score_threshold, float score_threshold, const float* limit_range,
                                       float nms_threshold, int pre_max_size, int post_max_size, const int32_t* class_offset,
                                       const int32_t* single_class, float* out_boxes, float* out_scores, int32_t* out_labels,
-                                      int32_t* out_count, void* stream) {
-    GGA_REQUIRE(n_tasks >= 1 && n_frames >= 0 && k >= 1 && k <= CPD_THREADS && box_dim >= 7 && box_dim <= 9,
+                                      int32_t* out_count, void* workspace, size_t workspace_bytes, void* stream) {
+    GGA_REQUIRE(n_tasks >= 1 && n_frames >= 0 && k >= 1 && k <= CPD_K && box_dim >= 7 && box_dim <= 9,
                 "gga_centerpoint_detect: bad sizes (tasks=%d frames=%d k=%d box_dim=%d; k <= 128, 7 <= box_dim <= 9)", n_tasks,
                 n_frames, k, box_dim);
     if (n_frames == 0) return GGA_OK;
     GGA_REQUIRE(boxes && scores && labels && coder_range && class_offset && single_class && out_boxes && out_scores && out_labels &&
-                    out_count, "gga_centerpoint_detect: null pointer argument");
-    hipLaunchKernelGGL(centerpoint_detect_kernel, dim3((unsigned)n_frames), dim3(CPD_THREADS), 0, (hipStream_t)stream, boxes, scores,
-                       labels, n_tasks, n_frames, k, box_dim, coder_range, coder_score_threshold, has_coder_score_threshold,
+                    out_count && workspace, "gga_centerpoint_detect: null pointer argument");
+    if (workspace_bytes < gga_centerpoint_detect_workspace_bytes(n_tasks, n_frames)) {
+        gga_set_error("gga_centerpoint_detect: workspace %zu B < required %zu B", workspace_bytes,
+                      gga_centerpoint_detect_workspace_bytes(n_tasks, n_frames));
+        return GGA_ERR_WORKSPACE;
+    }
+    int32_t* seg_count = (int32_t*)workspace;
+    hipLaunchKernelGGL(centerpoint_detect_kernel, dim3((unsigned)(n_frames * n_tasks)), dim3(CPD_THREADS), 0, (hipStream_t)stream, boxes,
+                       scores, labels, n_tasks, n_frames, k, box_dim, coder_range, coder_score_threshold, has_coder_score_threshold,
                        score_threshold, limit_range, nms_threshold, pre_max_size > 0 ? pre_max_size : k,
-                       post_max_size > 0 ? post_max_size : k, class_offset, single_class, out_boxes, out_scores, out_labels, out_count);
+                       post_max_size > 0 ? post_max_size : k, class_offset, single_class, out_boxes, out_scores, out_labels, seg_count);
     GGA_CHECK_LAUNCH("centerpoint_detect_kernel");
+    hipLaunchKernelGGL(centerpoint_merge_kernel, dim3((unsigned)n_frames), dim3(CPD_K), 0, (hipStream_t)stream, n_tasks, k, box_dim,
+                       seg_count, out_boxes, out_scores, out_labels, out_count);
+    GGA_CHECK_LAUNCH("centerpoint_merge_kernel");
     return GGA_OK;
 }

@@ -1236,9 +1236,10 @@ def centerpoint_detect(boxes, scores, labels, coder_range, coder_score_threshold
     lr = const_tensor([float(v) for v in limit_range], dev) if limit_range is not None and len(limit_range) > 0 else None
     co = const_tensor(offs, dev, torch.int32)
     sc = const_tensor([int(int(n) == 1) for n in num_classes], dev, torch.int32)
+    ws = _workspace('cp_detect', _lib.lib().gga_centerpoint_detect_workspace_bytes(T, B), dev)
     check(_lib.lib().gga_centerpoint_detect(_p(boxes), _p(scores), _p(labels), T, B, K, D, _p(cr),
                                             float(coder_score_threshold) if coder_score_threshold is not None else 0.0,
                                             int(coder_score_threshold is not None), float(score_threshold), _p(lr), float(nms_threshold),
                                             int(pre_max_size or 0), int(post_max_size or 0), _p(co), _p(sc), _p(out_boxes), _p(out_scores),
-                                            _p(out_labels), _p(count), _stream()), 'gga_centerpoint_detect')
+                                            _p(out_labels), _p(count), _p(ws), ws.numel(), _stream()), 'gga_centerpoint_detect')
     return out_boxes, out_scores, out_labels, count

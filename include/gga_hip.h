@@ -805,12 +805,15 @@ int gga_points_in_boxes(const float* points, const float* boxes, int B, int M, i
  * (centre -/+ extent / 2 and back), IoU > nms_threshold suppresses, at most post_max_size kept (<= 0: no cap), range filter
  * (limit_range [6] inclusive; NULL: none); tasks concatenated in order, z moved to the bottom centre, label + class_offset[task]
  * (0 + offset when single_class[task]). out_boxes [n_frames, n_tasks * k, box_dim], out_scores / out_labels [n_frames,
- * n_tasks * k], out_count [n_frames]: frame b's detections are rows 0 .. out_count[b]. k <= 128. */
+ * n_tasks * k], out_count [n_frames]: frame b's detections are rows 0 .. out_count[b]. k <= 128. workspace:
+ * gga_centerpoint_detect_workspace_bytes (the per-task counts between the two launches). */
+size_t gga_centerpoint_detect_workspace_bytes(int n_tasks, int n_frames);
 int gga_centerpoint_detect(const float* boxes, const float* scores, const float* labels, int n_tasks, int n_frames, int k,
                            int box_dim, const float* coder_range, float coder_score_threshold, int has_coder_score_threshold,
                            float score_threshold, const float* limit_range, float nms_threshold, int pre_max_size,
                            int post_max_size, const int32_t* class_offset, const int32_t* single_class, float* out_boxes,
-                           float* out_scores, int32_t* out_labels, int32_t* out_count, void* stream);
+                           float* out_scores, int32_t* out_labels, int32_t* out_count, void* workspace, size_t workspace_bytes,
+                           void* stream);
 
 /* Pseudo-label matching: image-plane IoU of every detection with the ground truths of its own
  * frame and the argmax, i.e. `calculate_iou_partly(dt_annos, gt_annos, metric=0)` followed by

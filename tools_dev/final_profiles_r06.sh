@@ -28,3 +28,8 @@ json.dump(d.get('inference'), open('$R/gpurun_out/r06_inference.json', 'w'), ind
 json.dump(d.get('parity_at_bench_size'), open('$R/gpurun_out/r06_parity_at_bench_size.json', 'w'), indent=1)
 print('inference', {k: v['value'] for k, v in d['inference'].items() if k.startswith('samples')}, 'second', {k: v['value'] for k, v in d['inference']['second_trunk'].items() if k.startswith('samples')})
 print('parity_at_bench_size', d['parity_at_bench_size']['planes2'])"
+# the shipped config at the reference's own samples_per_gpu = 32 (configs/gga/gga_kitti_config.py:185)
+timeout 600 python3 $R/bench.py --no-pgd --no-fcaf3d --no-loader-fed --no-planes3 --no-cpu-baseline --no-inference --second-batch 32 --steps 10 --warmup 8 2>/dev/null | tail -1 > /tmp/bs32.json
+python3 -c "
+import json; d=json.load(open('/tmp/bs32.json')); s=d['second_trunk']; s.pop('roofline', None)
+json.dump(s, open('$R/gpurun_out/r06_second_bs32.json','w'), indent=1); print('bs32', s['ms_per_step'], s['value'])"

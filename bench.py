@@ -102,7 +102,7 @@ def parse_args(argv=None):
     ap.add_argument('--loader-frames', type=int, default=2048, help='frames of the synthetic on-disk tree of the loader_fed leg')
     ap.add_argument('--loader-workers', default='4,8', help='workers_per_gpu values the loader_fed leg is run with')
     ap.add_argument('--no-inference', action='store_true', help='skip the inference / pseudo-label legs')
-    ap.add_argument('--inference-frames', type=int, default=256)
+    ap.add_argument('--inference-frames', type=int, default=1024, help='timed frames of each inference pass (after 64 warm-up frames of the same loader)')
     ap.add_argument('--no-planes3', action='store_true',
                     help='skip the `planes3` legs (main config and second_trunk re-timed on three bf16 planes / six products)')
     return ap.parse_args(argv)
@@ -441,13 +441,13 @@ def run_loader_fed(args, device, resident_value):
     return out
 
 
-def run_inference(args, device, model_config, pc_range, frames=256, batch_sizes=(1, 16)):
+def run_inference(args, device, model_config, pc_range, frames=1024, batch_sizes=(1, 16)):
     """The pseudo-label run of the recipe (reference: tools/generate_pseudo_labels_gga.py:242 /
     tools/test.py -> mmdet3d/apis/test.py single_gpu_test -> MVXTwoStageDetector_GGA.simple_test, centerpoint_head_gga.py:725-934
     get_bboxes / get_task_detections, core/post_processing/box3d_nms.py:231-268; fps probe tools/analysis_tools/benchmark.py:66-91):
     configs/gga/gga_kitti_matching_config.py's test section on the synthetic on-disk tree - LoadPointsFromFile + the test
     pipeline in loader workers, max_voxels = 40000 (eval), trunk, head, decode (top-100 per task), score threshold, BEV
-    rotated NMS, bbox3d2result - `frames` frames after a warm-up pass, for `samples_per_gpu` 1 (the reference tool's default)
+    rotated NMS, bbox3d2result - `frames` frames after the first 64 of the same loader, for `samples_per_gpu` 1 (the reference tool's default)
     and 16; then KittiDataset_GGA_match.evaluate (detections -> camera frame -> image-plane IoU matching against the 2D boxes
     -> the pseudo-label file). Random-init weights with the heat-map bias raised so that the detector reports boxes.
     -> dict per samples_per_gpu: frames/s, ms per frame by stage (a second, synchronised pass)."""
@@ -460,7 +460,7 @@ def run_inference(args, device, model_config, pc_range, frames=256, batch_sizes=
     from gga_amd.loader import build_dataloader, build_dataset
     is_pp = 'pointpillars' in os.path.basename(model_config)
     root = bench_tree_root('' if is_pp else '_second')
-    info_path, _ = synthetic.write_kitti_tree(root, max(frames + 32, args.loader_frames if is_pp else frames + 32), pc_range=pc_range)
+    info_path, _ = synthetic.write_kitti_tree(root, max(frames + 64, args.loader_frames if is_pp else frames + 64), pc_range=pc_range)
     cfg = Config.fromfile(os.path.join(REPO, 'configs', 'gga', 'gga_kitti_matching_config.py'))
     mcfg = Config.fromfile(model_config)
     test = dict(cfg.data['test'])
@@ -488,8 +488,9 @@ def run_inference(args, device, model_config, pc_range, frames=256, batch_sizes=
         path = os.path.join(root, f'kitti_infos_{name}.pkl')
         pickle.dump(infos[lo:hi], open(path, 'wb'))
         return build_dataset(dict(test, ann_file=path))
-    timed_set, stage_set = subset(0, frames + 32, 'bench_timed'), subset(0, min(64, frames) + 32, 'bench_stages')
-    eval_set = subset(32, frames + 32, 'bench_eval')
+    WARM = 64 if frames >= 256 else 32
+    timed_set, stage_set = subset(0, frames + WARM, 'bench_timed'), subset(0, min(64, frames) + WARM, 'bench_stages')
+    eval_set = subset(WARM, frames + WARM, 'bench_eval')
     out = {'workload': (f'single_gpu_test on {os.path.relpath(model_config, REPO)} + the test section of configs/gga/gga_kitti_matching_config.py: '
                         f'{frames} synthetic KITTI frames of 20 000 points from disk through the test pipeline (8 loader workers), voxelize at max_voxels 40000, '
                         f'trunk, head, decode top-100 per task, score threshold 0.1, BEV rotated NMS, then KittiDataset_GGA_match.evaluate'),
@@ -509,19 +510,19 @@ def run_inference(args, device, model_config, pc_range, frames=256, batch_sizes=
     head = model.pts_bbox_head
     for spg in batch_sizes:
         mk = lambda ds: build_dataloader(ds, samples_per_gpu=spg, workers_per_gpu=8, dist=False, shuffle=False)
-        # one loader over 32 + `frames` frames; the clock starts when the first 32 results are in (loader workers started,
+        # one loader over WARM + `frames` frames; the clock starts when the first WARM results are in (loader workers started,
         # allocator warm - the reference's fps probe skips its first iterations the same way, benchmark.py:66-91)
         mark = {}
 
         def progress(n):
-            if 't0' not in mark and n >= 32:
+            if 't0' not in mark and n >= WARM:
                 torch.cuda.synchronize()
                 mark['t0'], mark['n0'] = time.perf_counter(), n
         results = single_gpu_test(model, mk(timed_set), device, progress=progress, planes=2)
         torch.cuda.synchronize()
         dt = time.perf_counter() - mark['t0']
         results = results[mark['n0']:]
-        assert mark['n0'] == 32, mark
+        assert mark['n0'] == WARM, mark
         assert len(results) == frames
         dets = sum(len(r['pts_bbox']['scores_3d']) for r in results) / frames
         # second pass over 64 frames with a device synchronisation around every stage (slower than the pass above: the stages add up
@@ -540,11 +541,11 @@ def run_inference(args, device, model_config, pc_range, frames=256, batch_sizes=
         head.bbox_coder.decode = timed('  of which decode', real['decode'])
         ops.nms_bev = timed('  of which nms_bev', real['nms'])
         try:
-            n_st = len(stage_set) - 32
+            n_st = len(stage_set) - WARM
             mark2 = {}
 
             def progress2(n):
-                if 't0' not in mark2 and n >= 32:
+                if 't0' not in mark2 and n >= WARM:
                     torch.cuda.synchronize()
                     mark2['t0'] = time.perf_counter()
                     stages.clear()

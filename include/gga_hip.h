@@ -529,7 +529,12 @@ int gga_sparse_conv_wgrad_split(const float* x, const float* grad_out, const int
                                 size_t workspace_bytes, void* stream);
 /* The same with x / grad_out column blocks (<= 128 wide) of wider matrices: row strides in floats.
  * Every x row a rule-book entry names must start below byte 4 GiB of x (32-bit pair offsets; the kernel TRAPS - the stream
- * reports a fault - on a row beyond it: 8 M rows of 128 floats). */
+ * reports a fault - on a row beyond it: 8 M rows of 128 floats).
+ * Non-finite inputs: absent neighbours, tail pairs and (dense weight gradient) pixels outside the image are not selected to zero
+ * but read a real element - row 0 / the clamped pixel - and multiply it by a scale of 0 (one instruction less per fragment beside
+ * the matrix instructions). With finite tensors that is 0; an Inf / NaN in the substituted element turns that padded contribution
+ * into NaN, i.e. a non-finite value in x or grad_out can reach weight-gradient entries it would not reach through a select. The
+ * train Runner's range guard reports non-finite operands on its guarded iterations. */
 int gga_sparse_conv_wgrad_split_strided(const float* x, int64_t x_row_stride, const float* grad_out,
                                         int64_t grad_out_row_stride, const int32_t* nbr, int64_t n_rows, int kvol, int cin,
                                         int cout, float* grad_weight, void* workspace, size_t workspace_bytes, void* stream);

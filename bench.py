@@ -594,7 +594,7 @@ def scatter_roofline(model, batches, step_ms):
     # HBM bytes per launch: NOT measured in this run. Taken from the PMC passes kept under profiles/
     # (FETCH_SIZE doubled per the gfx950 note, WRITE_SIZE exact) and only quoted when the shape is the profiled one.
     traffic, src = None, None
-    for name in ('r05_scatter_pmc.json', 'r04_scatter_pmc.json', 'r02_scatter_pmc.json', 'r01_scatter_pmc.json'):
+    for name in ('r06_scatter_pmc.json', 'r05_scatter_pmc.json', 'r04_scatter_pmc.json', 'r02_scatter_pmc.json', 'r01_scatter_pmc.json'):
         try:
             pmc = json.load(open(os.path.join(REPO, 'profiles', name)))
             if (B, ch, me.ny, me.nx) == (16, 64, 496, 432) and abs(m - 256000) < 2000:

@@ -190,6 +190,39 @@ def init_dist():
     return rank, world, local_rank
 
 
+def init_random_seed(seed=None, device='cuda'):
+    """``mmdet3d/apis/train.py:27-55``: the seed all ranks share - ``seed`` if given, else a random one drawn on rank 0 and
+    broadcast (the one collective of the start-up; ``tools/dist_train.sh:19`` passes ``--seed 0``, so the reference never takes
+    this branch)."""
+    if seed is not None:
+        return int(seed)
+    import numpy as np
+    seed = int(np.random.randint(2 ** 31))
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return seed
+    on = torch.device(device) if (torch.cuda.is_available() and dist.get_backend() == 'nccl') else torch.device('cpu')
+    t = torch.tensor(seed if dist.get_rank() == 0 else 0, dtype=torch.int32, device=on)
+    dist.broadcast(t, src=0)
+    return int(t.item())
+
+
+def set_random_seed(seed, deterministic=False):
+    """``mmdet3d/apis/train.py:57-74``: python's, numpy's and torch's generators (what ``tools/train.py`` calls before it builds
+    the model and the datasets: weight initialisation, the database sampler's order, the SRL draws and the loader workers'
+    base seed all come from them). ``deterministic``: the framework's convolution library in its deterministic mode - this
+    repo's kernels are deterministic as they are."""
+    import random
+    import numpy as np
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
+    if deterministic:
+        torch.backends.cudnn.deterministic = True
+        torch.backends.cudnn.benchmark = False
+
+
 def build_ddp(model, device, find_unused_parameters=False):
     """MMDistributedDataParallel(device_ids=[LOCAL_RANK], broadcast_buffers=False,
     find_unused_parameters=...) (apis/train.py:222-231)."""

@@ -398,3 +398,21 @@ def test_upload_many_hands_back_every_array_as_a_view_of_one_buffer():
         assert tuple(t.shape) == a.shape and t.dtype == torch.from_numpy(np.empty(0, a.dtype)).dtype
         assert np.array_equal(t.numpy(), a)
         assert t.numel() == 0 or (t.data_ptr() - next(iter(base))) % 256 == 0
+
+
+def test_seed_helpers_of_the_train_api():
+    """``init_random_seed`` / ``set_random_seed`` (mmdet3d/apis/train.py:27-74): a given seed is returned as it is, none gives a
+    fresh one; after ``set_random_seed`` python's, numpy's and torch's generators repeat - the three the train entry's objects draw
+    from (weight initialisation, database sampler order, SRL coefficients)."""
+    import random
+    from gga_amd.train import init_random_seed, set_random_seed
+    assert init_random_seed(7) == 7 and isinstance(init_random_seed(), int)
+
+    def draws():
+        return random.random(), float(np.random.rand()), float(torch.rand(())), float(torch.normal(torch.tensor(1.35), torch.tensor(0.48)))
+    set_random_seed(3)
+    a = draws()
+    set_random_seed(3)
+    assert draws() == a
+    set_random_seed(4)
+    assert draws() != a

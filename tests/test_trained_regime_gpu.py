@@ -97,9 +97,8 @@ def test_trained_regime_parity(case, monkeypatch):
     monkeypatch.setattr(dense_conv, 'PLANES_PINNED', False)
     # the reference's set_random_seed (tools/train.py:214-219; tools/train.py here): python, numpy, torch - the database sampler draws its
     # order from numpy's global generator when the dataset is built, so without it every run trains on other frames
-    import random
-    import numpy as np
-    random.seed(SEED[case]), np.random.seed(SEED[case]), torch.manual_seed(SEED[case])
+    from gga_amd.train import set_random_seed
+    set_random_seed(SEED[case])
     model = build_model(cfg.model)
     with torch.no_grad():       # random init only: keep exp(log-dims) finite on noise (bench.damp_head_init)
         for th in model.pts_bbox_head.task_heads:

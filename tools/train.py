@@ -66,8 +66,8 @@ def main():
     # augmentations differ per rank). The SAMPLER's seed must be the same on every rank - each rank takes its block of ONE
     # shuffled order (mmdet syncs it from rank 0, `sync_random_seed`); with the launcher's common --seed that is args.seed.
     seed = args.seed + (rank if args.diff_seed else 0)          # set_random_seed of the reference: python, numpy, torch
-    import random
-    random.seed(seed), np.random.seed(seed), torch.manual_seed(seed)
+    from gga_amd.train import set_random_seed
+    set_random_seed(seed, deterministic=getattr(args, 'deterministic', False))
     cfg.seed = args.seed
     cfg.worker_seed = seed
     logger(f'Distributed training: {distributed} ({world} rank(s)); seed {seed}; work_dir {cfg.work_dir}')

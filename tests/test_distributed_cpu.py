@@ -146,3 +146,32 @@ def test_two_rank_test_run_returns_the_dataset_in_order(gpu_collect, tmp_path):
     assert [r['sample_idx'] for r in res[0]] == list(range(7))
     assert [r['n_points'] for r in res[0]] == [3 + i for i in range(7)] and [r['mean'] for r in res[0]] == [float(i) for i in range(7)]
     assert not (tmp_path / 'collect').exists()
+
+
+def _seed_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import numpy as np
+    from gga_amd.train import init_random_seed
+    np.random.seed(100 + rank)                      # the ranks' own generators differ: what comes back must not
+    q.put((rank, init_random_seed(None, device='cpu'), init_random_seed(5, device='cpu')))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_init_random_seed_is_common_to_the_ranks():
+    """``init_random_seed`` (mmdet3d/apis/train.py:27-55): without a seed rank 0 draws one and broadcasts it - the one collective
+    of the start-up -, with a seed every rank returns it."""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_seed_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[0][1] == got[1][1] and got[0][2] == got[1][2] == 5

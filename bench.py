@@ -879,29 +879,15 @@ def cpu_baseline(cfg, frames=16, parity=None):
             times.append(d1)
     times.sort()
     med = times[len(times) // 2]
-    # the same 2-frame step with every hardware thread of the host (BASELINE.md 3 says os.cpu_count()): one warm-up, two timed - the
-    # measurement behind `cores` = 32
-    all_threads, t_all = os.cpu_count() or cores, None
-    if all_threads > cores:
-        torch.set_num_threads(all_threads)
-        try:
-            ts = []
-            for i in range(3):
-                model.zero_grad()
-                t1 = time.perf_counter()
-                R.reference_train_step(model, small)
-                ts.append(time.perf_counter() - t1)
-            t_all = min(ts[1:])
-        finally:
-            torch.set_num_threads(cores)
     out = {'value': round(frames / dt, 4), 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
            'sample': (f'1 train step (fwd+bwd, no optimizer) on {frames} synthetic frames, {dt:.1f} s'
                       + (' - the batch and the weights of the timed GPU steps (see parity_at_bench_size)' if parity is not None else '')),
            'protocol_sample': {'value': round(2 / med, 4), 'unit': 'frames/s', 'frames': 2, 'warmup_iterations': warm_done,
                                'timed_iterations': len(times), 'median_s': round(med, 3), 'threads': cores,
-                               'same_step_with_all_hardware_threads': None if t_all is None else {'threads': all_threads, 'best_of_2_s': round(t_all, 3), 'frames_per_s': round(2 / t_all, 4)},
                                'note': 'BASELINE.md 3: 3 warm-up + 10 timed iterations, median, on a 2-frame sample; threads = `cores`, not '
-                                       'os.cpu_count(): torch\'s CPU convolutions are slower with all hardware threads of this host than with 32'},
+                                       'os.cpu_count(): torch\'s CPU convolutions are slower with all hardware threads of this host than with 32 - measured round 6 on '
+                                       'the 256-thread EPYC 9575F host: this 2-frame step takes 151 s with torch.set_num_threads(256) against 2.8 s with 32 '
+                                       '(0.013 against 0.72 frames/s; tools: bench.py history, EXPERIMENTS.md 6f)'},
            'protocol': ('`value`: one small warm-up step, ONE timed step of the full 16-frame sample on 32 threads (a step takes ~30 s: 13 of '
                         'them would break the bound on the bench run). `protocol_sample`: BASELINE.md 3\'s 3 + 10 protocol on 2 frames. '
                         'The pieces below follow the protocol too (median of 10 after 3)'),
